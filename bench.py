@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config, measured on MI355X.
+
+metric  : query k-mers/s through hash -> n row gathers -> AND -> per-colour count (cid_search_count_dev),
+          inputs resident in HBM, hits bit-exact vs the CPU oracle on a sample.
+workload: configs[1] at the metric's colour count — m = 50,000,000-bit Bloom rows, n = 4 hashes, k = 31,
+          C = 256 colours; the distinct canonical 31-mers (with multiplicities) of 1,000,000 synthetic 150-bp
+          reads per GPU (1 % substitutions), `search -g -f 0` semantics.
+index   : synthetic: Bernoulli(p) background bits, p = 1 - exp(-n*Lg/m) for Lg = 3 Mbp genomes,
+          plus an exact Bloom insert (simple_bloom.rs:19-26, on the GPU) of every error-free query k-mer into
+          the colour its read was drawn from.
+step    : one pass of the hot path over the rank's whole k-mer batch (+ the RCCL all-reduce of the 3*C
+          per-colour counters when N > 1).  N > 1: reads are sharded over ranks, the index is replicated.
+
+Launch: `python bench.py [--gpus 1]`, or for N > 1
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+_HIP = None
+
+
+def hip_memcpy(dst, src, nbytes, kind):
+    """hipMemcpy between library-owned and torch-owned memory (kind: 2 = D2H, 3 = D2D); synchronous."""
+    global _HIP
+    import ctypes
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _HIP.hipMemcpy.restype = ctypes.c_int
+    rc = _HIP.hipMemcpy(dst, src, nbytes, kind)
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed: {rc}")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="synthetic reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--bloom", type=int, default=50_000_000)
+    ap.add_argument("--hashes", type=int, default=4)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--colours", type=int, default=256)
+    ap.add_argument("--genome-len", type=int, default=3_000_000)
+    ap.add_argument("--error-rate", type=float, default=0.01)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
+    return ap.parse_args()
+
+
+def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate):
+    """Distinct canonical k-mers of synthetic reads: (ascii [K,k] u8, freq [K] i32, colour [K] i32; colour >= C = not planted)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    codes = torch.randint(0, 4, (n_reads, read_len), device=dev, dtype=torch.int64, generator=g)
+    genome = torch.randint(0, n_colours, (n_reads,), device=dev, dtype=torch.int64, generator=g)
+    err = torch.rand((n_reads, read_len), device=dev, generator=g) < err_rate
+    nw = read_len - k + 1
+    fwd = torch.zeros((n_reads, nw), device=dev, dtype=torch.int64)
+    rc = torch.zeros((n_reads, nw), device=dev, dtype=torch.int64)
+    bad = torch.zeros((n_reads, nw), device=dev, dtype=torch.bool)
+    for j in range(k):
+        c = codes[:, j:j + nw]
+        fwd = (fwd << 2) | c
+        rc = rc | ((3 - c) << (2 * j))
+        bad |= err[:, j:j + nw]
+    canon = torch.minimum(fwd, rc).reshape(-1)  # A<C<G<T: numeric min == lexicographic min of the ASCII strings
+    del fwd, rc, codes, err
+    colour = torch.where(bad, torch.full_like(bad, n_colours, dtype=torch.int64), genome[:, None].expand(-1, nw)).reshape(-1)
+    del bad
+    uniq, inverse, counts = torch.unique(canon, return_inverse=True, return_counts=True)
+    del canon
+    col_u = torch.full((uniq.numel(),), n_colours, device=dev, dtype=torch.int64)
+    col_u.scatter_reduce_(0, inverse, colour, reduce="amin")  # any planted occurrence plants the distinct k-mer
+    del inverse, colour
+    # random order, as a hash map would iterate (hash order is irrelevant to the row access pattern anyway)
+    perm = torch.randperm(uniq.numel(), device=dev, generator=g)
+    uniq, counts, col_u = uniq[perm], counts[perm], col_u[perm]
+    lut = torch.tensor(list(b"ACGT"), device=dev, dtype=torch.uint8)
+    shifts = torch.arange(2 * (k - 1), -1, -2, device=dev, dtype=torch.int64)
+    K = uniq.numel()
+    ascii_k = torch.empty((K, k), device=dev, dtype=torch.uint8)
+    step = 8_000_000
+    for s in range(0, K, step):
+        ascii_k[s:s + step] = lut[((uniq[s:s + step, None] >> shifts[None, :]) & 3)]
+    return ascii_k.contiguous(), counts.to(torch.int32).contiguous(), col_u.to(torch.int32).contiguous()
+
+
+def fill_background(dev, mat_ptr, m, rs, n_colours, p, seed):
+    """Bernoulli(p) bits for colours < n_colours, zero padding elsewhere, written into the index matrix
+    (m rows x rs u64 words at device address mat_ptr)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    w64 = (n_colours + 63) // 64
+    weights = (torch.ones(64, dtype=torch.int64, device=dev) << torch.arange(64, device=dev, dtype=torch.int64))
+    chunk = 1 << 20
+    for r0 in range(0, m, chunk):
+        r1 = min(m, r0 + chunk)
+        bits = torch.rand((r1 - r0, w64 * 64), device=dev, generator=g) < p
+        if n_colours < w64 * 64:
+            bits[:, n_colours:] = False
+        words = torch.zeros((r1 - r0, rs), dtype=torch.int64, device=dev)
+        words[:, :w64] = (bits.view(r1 - r0, w64, 64).to(torch.int64) * weights).sum(dim=2)
+        torch.cuda.synchronize()
+        hip_memcpy(mat_ptr + r0 * rs * 8, words.data_ptr(), words.numel() * 8, 3)
+
+
+def main():
+    a = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path (the oracle is only the cpu_baseline leg)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import colorid_amd
+    ctx = colorid_amd.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)  # kernels run on torch's current stream: torch.cuda.Event brackets them
+
+    C, n, k, m = a.colours, a.hashes, a.k, a.bloom
+    t_setup = time.time()
+    hx = colorid_amd.Index(ctx, m, n, k, C)
+    ptr, rs = hx.device_matrix()
+    p_bg = 1.0 - math.exp(-n * a.genome_len / m)
+    fill_background(dev, ptr, m, rs, C, p_bg, seed=7)
+    mine = None
+    for r in range(world):  # the replicated index holds every rank's planted k-mers
+        kk, ff, cc = make_reads_kmers(dev, 42 + r, a.reads, a.read_len, k, C, a.error_rate)
+        torch.cuda.synchronize()
+        hx.insert_kmers_dev(kk.data_ptr(), cc.data_ptr(), kk.shape[0])
+        ctx.synchronize()
+        if r == rank:
+            mine = (kk, ff)
+        del cc
+    hx.finalize()
+    kmers, freq = mine
+    K = kmers.shape[0]
+    out = torch.zeros(3 * C, dtype=torch.int64, device=dev)  # hits | n_unique | sum_unique_freq (u64 on the device)
+    uc = torch.empty(K, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def step():
+        hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
+                            out.data_ptr() + 16 * C, uc.data_ptr())
+        if world > 1:
+            dist.all_reduce(out)  # RCCL over xGMI: sum of the per-accession counters (24*C bytes)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record(stream)
+        hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
+                            out.data_ptr() + 16 * C, uc.data_ptr())
+        ev[i][1].record(stream)
+        if world > 1:
+            dist.all_reduce(out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    tot_k = torch.tensor([K], dtype=torch.int64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot_k)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    total_kmers, elapsed = int(tot_k.item()), float(el.item())
+
+    result = None
+    if rank == 0:
+        w64 = (C + 63) // 64
+        alg_bytes_per_kmer = n * w64 * 8 + k + 4 + 4  # rows + k-mer bytes + freq in + unique-colour out
+        achieved = alg_bytes_per_kmer * K / (kern_ms * 1e-3) / 1e9
+        result = {
+            "metric": "query k-mers/s on 50M-bit n=4 256-colour BIGSI; bit-exact hits vs CPU",
+            "value": total_kmers * a.steps / elapsed,
+            "unit": "k-mers/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"configs[1] @ C={C}: m={m} n={n} k={k}, distinct canonical k-mers of "
+                                   f"{a.reads} synthetic {a.read_len}bp reads per GPU (search -g -f 0)",
+                       "kmers_per_gpu": K, "bloom_size": m, "num_hash": n, "k_size": k, "n_colors": C,
+                       "row_bytes": rs * 8, "index_bytes": m * rs * 8, "background_density": p_bg,
+                       "parallelism": f"reads sharded over {world} GPU(s), index replicated, all-reduce(3C u64)",
+                       "setup_s": round(t_setup, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_search_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": a.traffic_bytes, "alg_bytes_per_kmer": alg_bytes_per_kmer,
+                         "kernel_ms": kern_ms, "kmers_per_launch": K},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+    hx.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs):
+    """The oracle (kind "port": plain-C restatement, 1 thread like the reference's `search`) on a bounded sample of
+    the same k-mers against a host copy of the same index; also the bit-exactness check of the GPU result."""
+    from oracle import orc
+    w32 = (C + 31) // 32
+    oix = orc.Index(m, n, k, C)
+    rows = oix.rows()
+    step = 4_000_000
+    torch.cuda.synchronize()
+    for r0 in range(0, m, step):  # device u64 rows -> BitVec<u32> rows (same little-endian bytes)
+        nr = min(step, m - r0)
+        blk = np.empty((nr, rs * 2), np.uint32)
+        hip_memcpy(blk.ctypes.data, mat_ptr + r0 * rs * 8, blk.nbytes, 2)
+        rows[r0:r0 + nr, :] = blk[:, :w32]
+    for c in range(C):
+        oix.set_color(c, f"genome_{c:04d}", a.genome_len - k + 1)
+    K = kmers.shape[0]
+    probe = min(K, 100_000)
+    hk = kmers[:probe].cpu().numpy()
+    hf = freq[:probe].cpu().numpy().astype(np.uint64)
+    t = time.perf_counter()
+    oix.search_count(hk, hf)
+    rate = probe / (time.perf_counter() - t)
+    S = int(min(K, max(probe, rate * a.cpu_seconds)))
+    hk = kmers[:S].cpu().numpy()
+    hf = freq[:S].cpu().numpy()
+    t = time.perf_counter()
+    want = oix.search_count(hk, hf.astype(np.uint64))
+    dt = time.perf_counter() - t
+    got = hx.search_count(hk, hf.astype(np.uint32))
+    exact = all(np.array_equal(w, g) for w, g in zip(want, got))
+    base = {"value": S / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": f"first {S} of the {K} query k-mers, same index copied to host; oracle/liborc.so "
+                      f"orc_search_count, 1 thread (reference `search` is single-threaded), {dt:.1f}s; host has {os.cpu_count()} cores"}
+    return base, bool(exact)
+
+
+if __name__ == "__main__":
+    main()

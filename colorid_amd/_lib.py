@@ -1,0 +1,63 @@
+"""ctypes loader for libcolorid_hip.so.  Fails loudly when the HIP extension is missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcolorid_hip.so")
+_LIB = None
+
+u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/colorid_hip.h declares
+SIGNATURES = {
+    "cid_last_error": (C.c_char_p, []),
+    "cid_abi_version": (C.c_int, []),
+    "cid_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "cid_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "cid_ctx_set_stream": (C.c_int, [vp, vp]),
+    "cid_ctx_synchronize": (C.c_int, [vp]),
+    "cid_ctx_destroy": (None, [vp]),
+    "cid_index_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
+    "cid_index_put_rows": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "cid_index_device_matrix": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "cid_index_finalize": (C.c_int, [vp]),
+    "cid_index_get_rows": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "cid_index_insert_kmers_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "cid_index_destroy": (None, [vp]),
+    "cid_search_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
+    "cid_search_count_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
+    "cid_search_perfect": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.POINTER(C.c_int)]),
+    "cid_readid_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp]),
+    "cid_timer_start": (C.c_int, [vp]),
+    "cid_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+}
+
+
+class CidError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcolorid_hip error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """Return the loaded C-ABI library; raise if it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  colorid_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CidError(rc, load_library().cid_last_error().decode(errors="replace"))

@@ -1,0 +1,408 @@
+// C ABI of libcolorid_hip.so (see include/colorid_hip.h).  Host-side plumbing only: contexts, the
+// device-resident index, scratch buffers, launches.  There is no CPU compute path in this library.
+#include "../../include/colorid_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "cid_host_math.hpp"
+#include "cid_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_COUNT };
+
+}  // namespace
+
+struct cid_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *slot[S_COUNT] = {};
+    size_t slot_bytes[S_COUNT] = {};
+};
+
+struct cid_index {
+    cid_ctx *ctx = nullptr;
+    uint64_t m = 0;
+    uint32_t n_hash = 0, k = 0, n_colors = 0, w32 = 0, w64 = 0, rs = 0;
+    uint64_t *mat = nullptr;
+    bool finalized = false;
+    cid::ModMagic mod{};
+};
+
+namespace {
+
+int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    if (c->slot_bytes[s] < bytes) {
+        if (c->slot[s]) HIP_TRY(hipFree(c->slot[s]));
+        c->slot[s] = nullptr;
+        c->slot_bytes[s] = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&c->slot[s], want);
+        if (e != hipSuccess) return fail(CID_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        c->slot_bytes[s] = want;
+    }
+    *out = c->slot[s];
+    return CID_OK;
+}
+
+// Work per block: enough blocks to balance 256 CUs dynamically, few enough that the per-block flush of the
+// LDS counters (<= 3*C global atomics) stays negligible.
+uint32_t pick_tiles_per_block(const cid_ctx *c, uint64_t n_kmers) {
+    const uint64_t n_tiles = (n_kmers + cid::kWave - 1) / cid::kWave;
+    uint64_t tpb = n_tiles / ((uint64_t)c->n_cu * 32);
+    if (tpb < 4) tpb = 4;
+    if (tpb > 256) tpb = 256;
+    return (uint32_t)tpb;
+}
+
+int fill_search_params(const cid_ctx *c, const cid_index *ix, cid::SearchParams &p) {
+    memset(&p, 0, sizeof(p));
+    p.mat = ix->mat;
+    p.rs = ix->rs;
+    p.w64 = ix->w64;
+    p.n_colors = ix->n_colors;
+    p.n_hash = ix->n_hash;
+    p.k = ix->k;
+    p.c_pad = (ix->n_colors + 1u) & ~1u;
+    if (p.c_pad < 2) p.c_pad = 2;
+    p.wave_bytes = cid::kmer_img_bytes(ix->k) + cid::kWave * ix->n_hash * 4u;
+    p.wave_bytes = (p.wave_bytes + 15u) & ~15u;
+    p.mod = ix->mod;
+    if (cid::search_smem_bytes(p) > 160u * 1024u)
+        return fail(CID_ERR_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB (n_colors=%u k=%u n_hash=%u)",
+                    cid::search_smem_bytes(p), ix->n_colors, ix->k, ix->n_hash);
+    (void)c;
+    return CID_OK;
+}
+
+int check_ready(const cid_ctx *c, const cid_index *ix) {
+    if (!c || !ix) return fail(CID_ERR_INVALID, "null ctx/index");
+    if (!ix->finalized) return fail(CID_ERR_STATE, "index not finalized");
+    if (ix->ctx->device != c->device) return fail(CID_ERR_INVALID, "index lives on device %d, ctx on %d", ix->ctx->device, c->device);
+    return CID_OK;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+const char *cid_last_error(void) { return g_err; }
+int cid_abi_version(void) { return 1; }
+
+int cid_device_count(int *n) {
+    if (!n) return fail(CID_ERR_INVALID, "null out");
+    *n = 0;
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) { *n = 0; return fail(CID_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return CID_OK;
+}
+
+int cid_ctx_create(int device_id, cid_ctx **out) {
+    if (!out) return fail(CID_ERR_INVALID, "null out");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(CID_ERR_HIP, "no HIP device (this library has no CPU path)");
+    if (device_id < 0 || device_id >= n) return fail(CID_ERR_INVALID, "device %d of %d", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    cid_ctx *c = new (std::nothrow) cid_ctx();
+    if (!c) return fail(CID_ERR_NOMEM, "ctx");
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(CID_ERR_HIP, "stream/event creation failed");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return CID_OK;
+}
+
+int cid_ctx_set_stream(cid_ctx *c, void *hip_stream) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return CID_OK;
+}
+
+int cid_ctx_synchronize(cid_ctx *c) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
+}
+
+void cid_ctx_destroy(cid_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < S_COUNT; ++s)
+        if (c->slot[s]) (void)hipFree(c->slot[s]);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------ index
+
+int cid_index_create(cid_ctx *c, uint64_t bloom_size, uint32_t num_hash, uint32_t k_size, uint32_t n_colors,
+                     int hash_variant, cid_index **out) {
+    if (!c || !out) return fail(CID_ERR_INVALID, "null ctx/out");
+    *out = nullptr;
+    if (hash_variant != CID_HASH_XXH3_V08) return fail(CID_ERR_UNSUPPORTED, "hash variant %d", hash_variant);
+    if (bloom_size == 0 || num_hash == 0 || n_colors == 0 || k_size == 0) return fail(CID_ERR_INVALID, "zero parameter");
+    if (k_size > cid::kMaxK) return fail(CID_ERR_UNSUPPORTED, "k_size %u > %u", k_size, cid::kMaxK);
+    if (num_hash > 32) return fail(CID_ERR_UNSUPPORTED, "num_hash %u > 32", num_hash);
+    if (bloom_size > (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "bloom_size %llu > 2^32", (unsigned long long)bloom_size);
+    if (n_colors > 8192) return fail(CID_ERR_UNSUPPORTED, "n_colors %u > 8192 per index stripe", n_colors);
+    cid_index *ix = new (std::nothrow) cid_index();
+    if (!ix) return fail(CID_ERR_NOMEM, "index");
+    ix->ctx = c;
+    ix->m = bloom_size; ix->n_hash = num_hash; ix->k = k_size; ix->n_colors = n_colors;
+    ix->w32 = (n_colors + 31) / 32;
+    ix->w64 = (n_colors + 63) / 64;
+    ix->rs = cid::row_stride_words(n_colors);
+    const cid::ModMagicHost mh = cid::make_mod_magic(bloom_size);
+    ix->mod = cid::ModMagic{mh.m, mh.magic, mh.shift, mh.flags};
+    hipError_t e = hipSetDevice(c->device);
+    const size_t bytes = (size_t)bloom_size * ix->rs * 8;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ix->mat), bytes);
+    if (e != hipSuccess) { delete ix; return fail(CID_ERR_NOMEM, "hipMalloc(%zu) for the index: %s", bytes, hipGetErrorString(e)); }
+    e = hipMemsetAsync(ix->mat, 0, bytes, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(ix->mat); delete ix; return fail(CID_ERR_HIP, "memset: %s", hipGetErrorString(e)); }
+    *out = ix;
+    return CID_OK;
+}
+
+int cid_index_put_rows(cid_index *ix, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows) {
+    if (!ix || (n_rows && (!row_ids || !words_le))) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
+    cid_ctx *c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t tail_bits = ix->n_colors % 32;
+    const uint32_t tail_mask = tail_bits ? ((1u << tail_bits) - 1u) : 0xFFFFFFFFu;
+    for (size_t i = 0; i < n_rows; ++i) {
+        if (row_ids[i] >= ix->m) return fail(CID_ERR_INVALID, "row id %llu >= bloom_size", (unsigned long long)row_ids[i]);
+        if (words_le[i * ix->w32 + ix->w32 - 1] & ~tail_mask) return fail(CID_ERR_INVALID, "row %llu has bits beyond n_colors", (unsigned long long)row_ids[i]);
+    }
+    const size_t batch = 1u << 22;
+    for (size_t r0 = 0; r0 < n_rows; r0 += batch) {
+        const size_t nr = n_rows - r0 < batch ? n_rows - r0 : batch;
+        void *d_ids, *d_words;
+        int rc = slot_reserve(c, S_ROWIDS, nr * 8, &d_ids);
+        if (rc) return rc;
+        rc = slot_reserve(c, S_WORDS, nr * ix->w32 * 4, &d_words);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_ids, row_ids + r0, nr * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_words, words_le + r0 * ix->w32, nr * ix->w32 * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(cid::launch_put_rows(ix->mat, ix->rs, (const uint64_t *)d_ids, (const uint32_t *)d_words, ix->w32, nr, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return CID_OK;
+}
+
+int cid_index_device_matrix(cid_index *ix, void **dev_ptr, uint64_t *row_stride_words) {
+    if (!ix || !dev_ptr || !row_stride_words) return fail(CID_ERR_INVALID, "null argument");
+    *dev_ptr = ix->mat;
+    *row_stride_words = ix->rs;
+    return CID_OK;
+}
+
+int cid_index_finalize(cid_index *ix) {
+    if (!ix) return fail(CID_ERR_INVALID, "null index");
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    ix->finalized = true;
+    return CID_OK;
+}
+
+int cid_index_get_rows(const cid_index *ix, const uint64_t *row_ids, uint32_t *words_le, size_t n_rows) {
+    if (!ix || (n_rows && (!row_ids || !words_le))) return fail(CID_ERR_INVALID, "null argument");
+    cid_ctx *c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    for (size_t i = 0; i < n_rows; ++i)
+        if (row_ids[i] >= ix->m) return fail(CID_ERR_INVALID, "row id %llu >= bloom_size", (unsigned long long)row_ids[i]);
+    void *d_ids, *d_words;
+    int rc = slot_reserve(c, S_ROWIDS, n_rows * 8, &d_ids);
+    if (rc) return rc;
+    rc = slot_reserve(c, S_WORDS, n_rows * ix->w32 * 4, &d_words);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_ids, row_ids, n_rows * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(cid::launch_get_rows(ix->mat, ix->rs, (const uint64_t *)d_ids, (uint32_t *)d_words, ix->w32, n_rows, c->stream));
+    HIP_TRY(hipMemcpyAsync(words_le, d_words, n_rows * ix->w32 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
+}
+
+int cid_index_insert_kmers_dev(cid_index *ix, const uint8_t *d_kmers, const uint32_t *d_colour_of_kmer, size_t n_kmers) {
+    if (!ix || (n_kmers && (!d_kmers || !d_colour_of_kmer))) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
+    if (!aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    cid_ctx *c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    cid::InsertParams p{};
+    p.mat = ix->mat; p.rs = ix->rs; p.n_hash = ix->n_hash; p.k = ix->k; p.n_colors = ix->n_colors;
+    p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    p.mod = ix->mod; p.kmers = d_kmers; p.colour_of_kmer = d_colour_of_kmer; p.n_kmers = n_kmers;
+    HIP_TRY(cid::launch_insert_kmers(p, c->stream));
+    return CID_OK;
+}
+
+void cid_index_destroy(cid_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+    if (ix->mat) (void)hipFree(ix->mat);
+    delete ix;
+}
+
+// ------------------------------------------------------------------------------------------------ a5
+
+int cid_search_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint32_t *d_freq, size_t n_kmers,
+                         uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!d_hits || (n_kmers && !d_kmers)) return fail(CID_ERR_INVALID, "null argument");
+    if (!aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    cid::SearchParams p;
+    rc = fill_search_params(c, ix, p);
+    if (rc) return rc;
+    p.kmers = d_kmers; p.freq = d_freq; p.n_kmers = n_kmers;
+    p.hits = d_hits; p.n_unique = d_n_unique; p.sum_unique_freq = d_sum_unique_freq; p.unique_colour = d_unique_colour;
+    p.want_unique = (d_n_unique || d_sum_unique_freq || d_unique_colour) ? 1u : 0u;
+    p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    const size_t cb = (size_t)ix->n_colors * 8;
+    HIP_TRY(hipMemsetAsync(d_hits, 0, cb, c->stream));
+    if (d_n_unique) HIP_TRY(hipMemsetAsync(d_n_unique, 0, cb, c->stream));
+    if (d_sum_unique_freq) HIP_TRY(hipMemsetAsync(d_sum_unique_freq, 0, cb, c->stream));
+    HIP_TRY(cid::launch_search_count(p, c->stream));
+    return CID_OK;
+}
+
+int cid_search_count(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
+                     uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!hits || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t C = ix->n_colors;
+    void *d_k, *d_f = nullptr, *d_out, *d_uc = nullptr;
+    rc = slot_reserve(c, S_KMERS, n_kmers * ix->k, &d_k);
+    if (rc) return rc;
+    if (freq) { rc = slot_reserve(c, S_FREQ, n_kmers * 4, &d_f); if (rc) return rc; }
+    rc = slot_reserve(c, S_OUT, 3 * C * 8, &d_out);
+    if (rc) return rc;
+    if (unique_colour) { rc = slot_reserve(c, S_UC, n_kmers * 4, &d_uc); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
+    if (freq) HIP_TRY(hipMemcpyAsync(d_f, freq, n_kmers * 4, hipMemcpyHostToDevice, c->stream));
+    uint64_t *o = (uint64_t *)d_out;
+    rc = cid_search_count_dev(c, ix, (const uint8_t *)d_k, (const uint32_t *)d_f, n_kmers, o,
+                              n_unique ? o + C : nullptr, sum_unique_freq ? o + 2 * C : nullptr, (uint32_t *)d_uc);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(hits, o, C * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_unique) HIP_TRY(hipMemcpyAsync(n_unique, o + C, C * 8, hipMemcpyDeviceToHost, c->stream));
+    if (sum_unique_freq) HIP_TRY(hipMemcpyAsync(sum_unique_freq, o + 2 * C, C * 8, hipMemcpyDeviceToHost, c->stream));
+    if (unique_colour) HIP_TRY(hipMemcpyAsync(unique_colour, d_uc, n_kmers * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ a4
+
+int cid_search_perfect(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, size_t n_kmers, uint32_t *and_words_le,
+                       int *any_row_missing) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!and_words_le || !any_row_missing || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
+    if (n_kmers == 0) return fail(CID_ERR_INVALID, "perfect search needs at least one k-mer (src/perfect_search.rs:22-23)");
+    HIP_TRY(hipSetDevice(c->device));
+    void *d_k, *d_out;
+    rc = slot_reserve(c, S_KMERS, n_kmers * ix->k, &d_k);
+    if (rc) return rc;
+    rc = slot_reserve(c, S_MISC, (size_t)ix->rs * 8 + 16, &d_out);
+    if (rc) return rc;
+    uint64_t *d_and = (uint64_t *)d_out;
+    int *d_missing = (int *)(d_and + ix->rs);
+    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_and, 0xFF, (size_t)ix->rs * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(d_missing, 0, 16, c->stream));
+    cid::SearchParams p;
+    rc = fill_search_params(c, ix, p);
+    if (rc) return rc;
+    p.kmers = (const uint8_t *)d_k; p.n_kmers = n_kmers; p.and_words = d_and; p.missing = d_missing;
+    p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    HIP_TRY(cid::launch_search_perfect(p, c->stream));
+    std::vector<uint64_t> h(ix->rs);
+    int missing = 0;
+    HIP_TRY(hipMemcpyAsync(h.data(), d_and, (size_t)ix->rs * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&missing, d_missing, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *any_row_missing = missing ? 1 : 0;
+    for (uint32_t w = 0; w < ix->w32; ++w) {
+        const uint32_t v = (uint32_t)(h[w / 2] >> (32 * (w & 1)));
+        and_words_le[w] = missing ? 0u : v;
+    }
+    return CID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ a6/a7/a9/a10
+
+int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                     const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                     uint32_t *report, uint32_t *n_kmers, uint8_t *status) {
+    (void)bases; (void)seq_off; (void)n_seqs; (void)read_seq0; (void)n_reads; (void)stride_d; (void)start_sample;
+    (void)report; (void)n_kmers; (void)status;
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    return fail(CID_ERR_UNSUPPORTED, "cid_readid_count: kernel not built yet");
+}
+
+// ------------------------------------------------------------------------------------------------ timing
+
+int cid_timer_start(cid_ctx *c) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return CID_OK;
+}
+
+int cid_timer_stop_ms(cid_ctx *c, float *elapsed_ms) {
+    if (!c || !elapsed_ms) return fail(CID_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return CID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// Integer arithmetic of the BIGSI hash step, shared verbatim by the gfx950 kernels and by the CPU unit
+// test of that arithmetic (tests/cpu_shim/, compiled with g++): XXH3-64-with-seed for 1..128-byte inputs
+// read out of a byte image (LDS on the device) and the exact `% bloom_size`.
+//
+// Under hipcc every function here is a __device__ function; nothing in the product's host code calls them.
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define CID_FN __device__ __forceinline__
+#define CID_DEVCONST __device__
+#else
+#define CID_FN inline
+#define CID_DEVCONST
+#endif
+
+namespace cid {
+
+CID_FN uint64_t umul64hi(uint64_t a, uint64_t b) {
+#ifdef __HIPCC__
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+// ({hi,lo} >> 8*sh) & 0xffffffff, sh in 0..3  (v_alignbyte_b32)
+CID_FN uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+#ifdef __HIPCC__
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * sh));
+#endif
+}
+
+// ---------------------------------------------------------------- exact modulo by an invariant
+
+struct ModMagic {
+    uint64_t m;      // divisor (bloom_size)
+    uint64_t magic;  // multiplier
+    uint32_t shift;
+    uint32_t flags;  // 1 = power of two (mask), 2 = "add" fix-up step
+};
+
+CID_FN uint64_t mod_m(uint64_t h, const ModMagic &mm) {
+    if (mm.flags & 1u) return h & (mm.m - 1);
+    uint64_t q = umul64hi(h, mm.magic);
+    if (mm.flags & 2u) {
+        uint64_t t = ((h - q) >> 1) + q;
+        q = t >> mm.shift;
+    } else {
+        q >>= mm.shift;
+    }
+    return h - q * mm.m;
+}
+
+// ---------------------------------------------------------------- XXH3-64 (published v0.8 spec), inputs <= 128 B
+
+// First 128 bytes of the default secret as little-endian u64 words (every read the <=128-byte
+// branches make is 8-byte aligned except the two u32 reads of the 1..3-byte branch = halves of word 0).
+CID_DEVCONST constexpr uint64_t kSecretW[16] = {
+    0xbe4ba423396cfeb8ULL, 0x1cad21f72c81017cULL, 0xdb979083e96dd4deULL, 0x1f67b3b7a4a44072ULL,
+    0x78e5c0cc4ee679cbULL, 0x2172ffcc7dd05a82ULL, 0x8e2443f7744608b8ULL, 0x4c263a81e69035e0ULL,
+    0xcb00c391bb52283cULL, 0xa32e531b8b65d088ULL, 0x4ef90da297486471ULL, 0xd8acdea946ef1938ULL,
+    0x3f349ce33f76faa8ULL, 0x1d4f0bc7c7bbdcf9ULL, 0x3159b4cd4be0518aULL, 0x647378d9c97e9fc8ULL,
+};
+
+constexpr uint64_t P64_1 = 0x9E3779B185EBCA87ULL;
+constexpr uint64_t P64_2 = 0xC2B2AE3D27D4EB4FULL;
+constexpr uint64_t P64_3 = 0x165667B19E3779F9ULL;
+constexpr uint64_t PMX1 = 0x165667919E3779F9ULL;
+constexpr uint64_t PMX2 = 0x9FB21C651E98DF25ULL;
+
+CID_FN uint64_t mul128_fold64(uint64_t a, uint64_t b) { return (a * b) ^ umul64hi(a, b); }
+CID_FN uint64_t xxh3_avalanche(uint64_t h) {
+    h ^= h >> 37; h *= PMX1; h ^= h >> 32;
+    return h;
+}
+CID_FN uint64_t xxh64_avalanche(uint64_t h) {
+    h ^= h >> 33; h *= P64_2; h ^= h >> 29; h *= P64_3; h ^= h >> 32;
+    return h;
+}
+CID_FN uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+CID_FN uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
+
+// Unaligned little-endian reads out of an LDS byte image through aligned dwords + v_alignbyte.
+// The image must be readable 8 bytes past the last byte asked for (callers pad).
+CID_FN uint32_t lds_rd32(const uint32_t *img, uint32_t off) {
+    uint32_t w = off >> 2, sh = off & 3u;
+    return alignbyte(img[w + 1], img[w], sh);
+}
+CID_FN uint64_t lds_rd64(const uint32_t *img, uint32_t off) {
+    uint32_t w = off >> 2, sh = off & 3u;
+    uint32_t a = img[w], b = img[w + 1], c = img[w + 2];
+    uint32_t lo = alignbyte(b, a, sh);
+    uint32_t hi = alignbyte(c, b, sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+CID_FN uint32_t lds_rd8(const uint32_t *img, uint32_t off) {
+    return (img[off >> 2] >> (8u * (off & 3u))) & 0xffu;
+}
+
+// All n seeds (0..n-1) of one k-mer; emit(seed, hash).  len is wave-uniform.
+template <typename Emit>
+CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t n, Emit &&emit) {
+    if (len > 16 && len <= 32) {  // the k = 21/27/31 case: 2 x mix16B, inputs read once for all seeds
+        const uint64_t a0 = lds_rd64(img, off), a1 = lds_rd64(img, off + 8);
+        const uint64_t b0 = lds_rd64(img, off + len - 16), b1 = lds_rd64(img, off + len - 8);
+        for (uint32_t s = 0; s < n; ++s) {
+            uint64_t acc = (uint64_t)len * P64_1;
+            acc += mul128_fold64(a0 ^ (kSecretW[0] + s), a1 ^ (kSecretW[1] - s));
+            acc += mul128_fold64(b0 ^ (kSecretW[2] + s), b1 ^ (kSecretW[3] - s));
+            emit(s, xxh3_avalanche(acc));
+        }
+    } else if (len > 32) {  // 33..128: (len-1)/32 + 1 front/back pairs
+        const uint32_t nb = ((len - 1) >> 5) + 1;
+        for (uint32_t s = 0; s < n; ++s) {
+            uint64_t acc = (uint64_t)len * P64_1;
+            for (uint32_t i = 0; i < nb; ++i) {
+                const uint32_t f = off + 16 * i, b = off + len - 16 * (i + 1);
+                acc += mul128_fold64(lds_rd64(img, f) ^ (kSecretW[4 * i] + s), lds_rd64(img, f + 8) ^ (kSecretW[4 * i + 1] - s));
+                acc += mul128_fold64(lds_rd64(img, b) ^ (kSecretW[4 * i + 2] + s), lds_rd64(img, b + 8) ^ (kSecretW[4 * i + 3] - s));
+            }
+            emit(s, xxh3_avalanche(acc));
+        }
+    } else if (len > 8) {  // 9..16
+        const uint64_t i_lo = lds_rd64(img, off), i_hi = lds_rd64(img, off + len - 8);
+        for (uint32_t s = 0; s < n; ++s) {
+            const uint64_t lo = i_lo ^ ((kSecretW[3] ^ kSecretW[4]) + s);
+            const uint64_t hi = i_hi ^ ((kSecretW[5] ^ kSecretW[6]) - s);
+            emit(s, xxh3_avalanche((uint64_t)len + bswap64(lo) + hi + mul128_fold64(lo, hi)));
+        }
+    } else if (len >= 4) {  // 4..8
+        const uint64_t i1 = lds_rd32(img, off), i2 = lds_rd32(img, off + len - 4);
+        const uint64_t in64 = i2 + (i1 << 32);
+        for (uint32_t s = 0; s < n; ++s) {
+            uint64_t seed = (uint64_t)s ^ ((uint64_t)__builtin_bswap32(s) << 32);
+            uint64_t h = in64 ^ ((kSecretW[1] ^ kSecretW[2]) - seed);
+            h ^= rotl64(h, 49) ^ rotl64(h, 24);
+            h *= PMX2;
+            h ^= (h >> 35) + len;
+            h *= PMX2;
+            emit(s, h ^ (h >> 28));
+        }
+    } else {  // 1..3
+        const uint32_t c1 = lds_rd8(img, off), c2 = lds_rd8(img, off + (len >> 1)), c3 = lds_rd8(img, off + len - 1);
+        const uint32_t combined = (c1 << 16) | (c2 << 24) | c3 | (len << 8);
+        const uint64_t flip = (uint64_t)((uint32_t)kSecretW[0] ^ (uint32_t)(kSecretW[0] >> 32));
+        for (uint32_t s = 0; s < n; ++s) emit(s, xxh64_avalanche((uint64_t)combined ^ (flip + s)));
+    }
+}
+
+}  // namespace cid

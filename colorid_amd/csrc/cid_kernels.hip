@@ -1,0 +1,387 @@
+// BIGSI query kernels for MI355X (gfx950).  Hand-written HIP; wave64; HBM-bound bitwise work.
+//
+// Data layout in HBM: the index is a dense row-major bit matrix, row r = the colour bit-vector of Bloom
+// position r, `rs` u64 words per row (rs = 1, or a power of two 2..128 — 16 B .. 1 KiB per row — so that a
+// row never straddles a 128-byte line it does not fill).  Absent rows of the reference's sparse map are
+// all-zero rows here.
+//
+// Work decomposition (all kernels): one wave owns a tile of 64 k-mers at a time (grid-stride over tiles).
+//   1. the tile's 64*k bytes are copied HBM -> LDS with aligned 16-byte loads (wave-private image);
+//   2. lane l hashes k-mer l with seeds 0..n-1 (XXH3-64 out of LDS), reduces mod bloom_size and parks the
+//      n row numbers in LDS ("hash rows");
+//   3. the wave re-maps itself so that LPR = rs/2 adjacent lanes cover one row with 16 bytes each
+//      (LPR = 1 and 8 bytes for rs = 1): every row costs exactly one coalesced request per 128-byte line,
+//      all n loads of a k-mer are issued back-to-back, then ANDed in registers;
+//   4. kernel-specific epilogue on the AND words.
+#include "cid_kernels.hpp"
+
+namespace cid {
+
+// ------------------------------------------------------------------------------------------------
+// gather + AND of one k-mer's n rows, this lane's 16-byte (or 8-byte) column slice
+
+struct V16 { uint64_t x, y; };
+
+template <bool NARROW>
+__device__ __forceinline__ V16 load_slice(const uint64_t *p) {
+    if constexpr (NARROW) {
+        return V16{*p, ~0ull};
+    } else {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+        return V16{v.x, v.y};
+    }
+}
+
+// ridx: this wave's row numbers, ridx[s*64 + kmer_in_tile].  ZERO_DETECT also reports whether any of the
+// n slices was all-zero in this lane (the caller ORs that across the row's lanes).
+template <int NH, bool NARROW, bool ZERO_DETECT>
+__device__ __forceinline__ V16 gather_and_fixed(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, int kk,
+                                                uint32_t col_word, uint32_t s0, uint32_t &zero_mask) {
+    V16 v[NH];
+#pragma unroll
+    for (int s = 0; s < NH; ++s) {
+        const uint64_t row = ridx[(s0 + s) * kWave + kk];
+        v[s] = load_slice<NARROW>(mat + row * rs + col_word);
+    }
+    V16 a{~0ull, ~0ull};
+#pragma unroll
+    for (int s = 0; s < NH; ++s) {
+        if constexpr (ZERO_DETECT) {
+            const uint64_t o = NARROW ? v[s].x : (v[s].x | v[s].y);
+            zero_mask |= (o == 0) ? (1u << (s0 + s)) : 0u;
+        }
+        a.x &= v[s].x;
+        a.y &= v[s].y;
+    }
+    return a;
+}
+
+template <bool NARROW, bool ZERO_DETECT>
+__device__ __forceinline__ V16 gather_and(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, int kk,
+                                          uint32_t col_word, uint32_t n, uint32_t &zero_mask) {
+    zero_mask = 0;
+    switch (n) {  // n is wave-uniform; the common sizes are fully unrolled so all loads are in flight together
+    case 1: return gather_and_fixed<1, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
+    case 2: return gather_and_fixed<2, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
+    case 3: return gather_and_fixed<3, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
+    case 4: return gather_and_fixed<4, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
+    default: break;
+    }
+    V16 a{~0ull, ~0ull};
+    uint32_t s = 0;
+    for (; s + 4 <= n; s += 4) {
+        const V16 b = gather_and_fixed<4, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, s, zero_mask);
+        a.x &= b.x; a.y &= b.y;
+    }
+    for (; s < n; ++s) {
+        const V16 b = gather_and_fixed<1, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, s, zero_mask);
+        a.x &= b.x; a.y &= b.y;
+    }
+    return a;
+}
+
+// Sum / OR over the LPR adjacent lanes that share a row (LPR is a power of two <= 64).
+template <int LOG_LPR>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < (1 << LOG_LPR); o <<= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+template <int LOG_LPR>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < (1 << LOG_LPR); o <<= 1) v |= __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// Steps 1+2 of the header comment for one tile.  Returns nothing; fills ridx[s*64 + lane].
+__device__ __forceinline__ void stage_and_hash(uint32_t *img, uint32_t *ridx, const uint8_t *kmers, uint64_t n_kmers,
+                                               uint64_t first, uint32_t k, uint32_t n, const ModMagic &mm, int lane) {
+    wave_lds_fence();  // previous tile's readers are done with img/ridx
+    stage_kmers(img, kmers, n_kmers, first, k, lane);
+    wave_lds_fence();
+    if (first + lane < n_kmers) {
+        xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t s, uint64_t h) {
+            ridx[s * kWave + lane] = (uint32_t)mod_m(h, mm);
+        });
+    } else {
+        for (uint32_t s = 0; s < n; ++s) ridx[s * kWave + lane] = 0;
+    }
+    wave_lds_fence();
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5: proportional search  (src/batch_search_pe.rs:45-84, :125-164)
+
+template <int LOG_LPR, bool NARROW>
+__global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr int KPW = kWave / LPR;  // k-mers per sub-pass
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const uint32_t C = p.n_colors;
+
+    uint64_t *s_sum = reinterpret_cast<uint64_t *>(smem);                    // [C] sum of freq of unique hits
+    uint32_t *s_hits = reinterpret_cast<uint32_t *>(smem + 8ull * p.c_pad);  // [C]
+    uint32_t *s_nu = s_hits + p.c_pad;                                       // [C]
+    uint8_t *wbase = smem + 16ull * p.c_pad + (size_t)wave * p.wave_bytes;
+    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
+
+    for (uint32_t c = threadIdx.x; c < p.c_pad; c += blockDim.x) { s_sum[c] = 0; s_hits[c] = 0; s_nu[c] = 0; }
+    __syncthreads();
+
+    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
+    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
+    const uint32_t col = lane & (LPR - 1);
+    const uint32_t col_word = NARROW ? 0u : 2u * col;
+    const bool col_live = col_word < p.w64;  // lanes past the row's real width neither load nor count
+
+    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
+        const uint64_t first = tile * kWave;
+        stage_and_hash(img, ridx, p.kmers, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
+#pragma unroll 1
+        for (int sub = 0; sub < LPR; ++sub) {
+            const int kk = sub * KPW + (lane >> LOG_LPR);
+            const uint64_t kmer = first + kk;
+            const bool live = kmer < p.n_kmers;
+            V16 a{0, 0};
+            uint32_t zm;
+            if (live && col_live) a = gather_and<NARROW, false>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
+            if constexpr (NARROW) a.y = 0;
+            const uint32_t pc = (uint32_t)(__popcll(a.x) + __popcll(a.y));
+            const uint32_t total = group_sum<LOG_LPR>(pc);
+            // hits: one LDS atomic per set colour (AND words are sparse: a handful of colours per k-mer)
+            uint64_t w = a.x;
+            uint32_t base = col_word * 64u;
+            while (w) { atomicAdd(&s_hits[base + (uint32_t)__builtin_ctzll(w)], 1u); w &= w - 1; }
+            w = a.y;
+            base += 64u;
+            while (w) { atomicAdd(&s_hits[base + (uint32_t)__builtin_ctzll(w)], 1u); w &= w - 1; }
+            if (p.want_unique && live) {
+                if (total == 1u) {
+                    if (pc == 1u) {
+                        const uint32_t c = a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
+                                               : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y);
+                        atomicAdd(&s_nu[c], 1u);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&s_sum[c]),
+                                  (unsigned long long)(p.freq ? p.freq[kmer] : 1u));
+                        if (p.unique_colour) p.unique_colour[kmer] = c;
+                    }
+                } else if (col == 0 && p.unique_colour) {
+                    p.unique_colour[kmer] = 0xFFFFFFFFu;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < C; c += blockDim.x) {
+        const uint32_t h = s_hits[c];
+        if (h) atomicAdd(reinterpret_cast<unsigned long long *>(&p.hits[c]), (unsigned long long)h);
+        if (p.want_unique) {
+            const uint32_t u = s_nu[c];
+            if (u) {
+                if (p.n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&p.n_unique[c]), (unsigned long long)u);
+                if (p.sum_unique_freq)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&p.sum_unique_freq[c]), (unsigned long long)s_sum[c]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4: perfect search  (src/perfect_search.rs:25-52): AND over every row of every k-mer
+
+template <int LOG_LPR, bool NARROW>
+__global__ __launch_bounds__(kBlock) void k_search_perfect(SearchParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr int KPW = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+
+    uint64_t *s_and = reinterpret_cast<uint64_t *>(smem);  // [rs] block-level AND
+    uint8_t *wbase = smem + 16ull * p.c_pad + (size_t)wave * p.wave_bytes;
+    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
+
+    for (uint32_t c = threadIdx.x; c < p.rs; c += blockDim.x) s_and[c] = ~0ull;
+    __syncthreads();
+
+    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
+    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
+    const uint32_t col = lane & (LPR - 1);
+    const uint32_t col_word = NARROW ? 0u : 2u * col;
+    const bool col_live = col_word < p.w64;
+
+    V16 acc{~0ull, ~0ull};
+    uint32_t missing = 0;
+    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
+        const uint64_t first = tile * kWave;
+        stage_and_hash(img, ridx, p.kmers, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
+#pragma unroll 1
+        for (int sub = 0; sub < LPR; ++sub) {
+            const int kk = sub * KPW + (lane >> LOG_LPR);
+            const bool live = first + kk < p.n_kmers;
+            uint32_t zm = 0;
+            if (live && col_live) {
+                const V16 a = gather_and<NARROW, true>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
+                acc.x &= a.x; acc.y &= a.y;
+            } else {
+                zm = ~0u;  // a dead lane holds no bits of any row
+            }
+            // a row is absent (== all-zero) iff every live lane of its group saw a zero slice for that seed
+            uint32_t all_zero = zm;
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
+            const uint32_t seeds = p.n_hash >= 32 ? ~0u : ((1u << p.n_hash) - 1u);
+            if (live && (all_zero & seeds)) missing = 1;
+        }
+    }
+    // lanes with the same column slice -> one value per slice per wave
+#pragma unroll
+    for (int o = LPR; o < kWave; o <<= 1) {
+        acc.x &= __shfl_xor(acc.x, o, kWave);
+        acc.y &= __shfl_xor(acc.y, o, kWave);
+    }
+    if (lane < LPR && col_live) {
+        atomicAnd(reinterpret_cast<unsigned long long *>(&s_and[col_word]), (unsigned long long)acc.x);
+        if (!NARROW) atomicAnd(reinterpret_cast<unsigned long long *>(&s_and[col_word + 1]), (unsigned long long)acc.y);
+    }
+    if (__any(missing) && lane == 0) atomicOr(p.missing, 1);
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < p.w64; c += blockDim.x)
+        atomicAnd(reinterpret_cast<unsigned long long *>(&p.and_words[c]), (unsigned long long)s_and[c]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// index maintenance
+
+// .bxi rows -> dense matrix (src/bigsi.rs:59-63 feeds this): one thread per (row, u32 word)
+__global__ void k_put_rows(uint32_t *mat32, uint32_t rs, const uint64_t *row_ids, const uint32_t *words, uint32_t w32,
+                           uint64_t n_rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * w32) return;
+    const uint64_t r = i / w32, w = i % w32;
+    mat32[row_ids[r] * (2ull * rs) + w] = words[i];
+}
+
+__global__ void k_get_rows(const uint32_t *mat32, uint32_t rs, const uint64_t *row_ids, uint32_t *words, uint32_t w32,
+                           uint64_t n_rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * w32) return;
+    const uint64_t r = i / w32, w = i % w32;
+    words[i] = mat32[row_ids[r] * (2ull * rs) + w];
+}
+
+// Bloom insert (src/simple_bloom.rs:19-26) straight into the transposed matrix (src/build.rs:116-128)
+__global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    uint32_t *img = reinterpret_cast<uint32_t *>(smem + (size_t)wave * kmer_img_bytes(p.k));
+    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
+    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
+    unsigned int *mat32 = reinterpret_cast<unsigned int *>(p.mat);
+    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
+        const uint64_t first = tile * kWave;
+        wave_lds_fence();
+        stage_kmers(img, p.kmers, p.n_kmers, first, p.k, lane);
+        wave_lds_fence();
+        if (first + lane < p.n_kmers) {
+            const uint32_t c = p.colour_of_kmer[first + lane];
+            if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, [&](uint32_t, uint64_t h) {
+                const uint64_t row = mod_m(h, p.mod);
+                atomicOr(&mat32[row * (2ull * p.rs) + (c >> 5)], 1u << (c & 31u));
+            });
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+
+template <typename KernelT, typename ParamsT>
+static hipError_t launch_one(KernelT kernel, int grid, size_t shmem, hipStream_t stream, const ParamsT &p) {
+    if (shmem > 64 * 1024) {  // up to the CU's 160 KiB of LDS on request
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), shmem, stream, p);
+    return hipGetLastError();
+}
+
+#define CID_LAUNCH_BY_LAYOUT(KERNEL, log_lpr, narrow, grid, shmem, stream, params)           \
+    do {                                                                                     \
+        if (narrow) return launch_one(KERNEL<0, true>, grid, shmem, stream, params);         \
+        switch (log_lpr) {                                                                   \
+        case 0: return launch_one(KERNEL<0, false>, grid, shmem, stream, params);            \
+        case 1: return launch_one(KERNEL<1, false>, grid, shmem, stream, params);            \
+        case 2: return launch_one(KERNEL<2, false>, grid, shmem, stream, params);            \
+        case 3: return launch_one(KERNEL<3, false>, grid, shmem, stream, params);            \
+        case 4: return launch_one(KERNEL<4, false>, grid, shmem, stream, params);            \
+        case 5: return launch_one(KERNEL<5, false>, grid, shmem, stream, params);            \
+        case 6: return launch_one(KERNEL<6, false>, grid, shmem, stream, params);            \
+        default: return hipErrorInvalidValue;                                                \
+        }                                                                                    \
+    } while (0)
+
+static int log2u(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
+
+size_t search_smem_bytes(const SearchParams &p) { return 16ull * p.c_pad + (size_t)(kBlock / kWave) * p.wave_bytes; }
+
+int grid_for(uint64_t n_kmers, uint32_t tiles_per_block) {
+    const uint64_t n_tiles = (n_kmers + kWave - 1) / kWave;
+    return (int)((n_tiles + tiles_per_block - 1) / tiles_per_block);
+}
+
+hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
+    const bool narrow = p.rs == 1;
+    const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
+    const size_t shmem = search_smem_bytes(p);
+    const int grid = grid_for(p.n_kmers, p.tiles_per_block);
+    if (grid == 0) return hipSuccess;
+    CID_LAUNCH_BY_LAYOUT(k_search_count, log_lpr, narrow, grid, shmem, stream, p);
+}
+
+hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {
+    const bool narrow = p.rs == 1;
+    const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
+    const size_t shmem = search_smem_bytes(p);
+    const int grid = grid_for(p.n_kmers, p.tiles_per_block);
+    if (grid == 0) return hipSuccess;
+    CID_LAUNCH_BY_LAYOUT(k_search_perfect, log_lpr, narrow, grid, shmem, stream, p);
+}
+
+hipError_t launch_put_rows(uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, const uint32_t *d_words, uint32_t w32,
+                           uint64_t n_rows, hipStream_t stream) {
+    const uint64_t n = n_rows * w32;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_put_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<uint32_t *>(mat), rs, d_row_ids, d_words, w32, n_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_get_rows(const uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, uint32_t *d_words, uint32_t w32,
+                           uint64_t n_rows, hipStream_t stream) {
+    const uint64_t n = n_rows * w32;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_get_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint32_t *>(mat), rs, d_row_ids, d_words, w32, n_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_insert_kmers(const InsertParams &p, hipStream_t stream) {
+    const size_t shmem = (size_t)(kBlock / kWave) * kmer_img_bytes(p.k);
+    const int grid = grid_for(p.n_kmers, p.tiles_per_block);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_insert_kmers, dim3(grid), dim3(kBlock), shmem, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace cid

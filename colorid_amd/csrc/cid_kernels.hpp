@@ -1,0 +1,57 @@
+// Kernel parameter blocks and launchers shared by cid_kernels.hip and cid_api.hip.
+#pragma once
+#include "cid_device.hpp"
+
+namespace cid {
+
+constexpr int kBlock = 256;  // 4 waves; every wave works on its own 64-k-mer tiles
+
+struct SearchParams {
+    const uint64_t *mat;   // dense index, row r at mat + r*rs
+    uint32_t rs;           // row stride in u64 words (1, or a power of two 2..128)
+    uint32_t w64;          // words that carry colours = ceil(n_colors/64)
+    uint32_t n_colors;
+    uint32_t n_hash;
+    uint32_t k;
+    uint32_t c_pad;        // n_colors rounded up to even (LDS counter arrays)
+    uint32_t wave_bytes;   // LDS bytes per wave: k-mer image + hash rows
+    uint32_t want_unique;
+    uint32_t tiles_per_block;  // block b owns tiles [b*tpb, (b+1)*tpb); grid = ceil(n_tiles/tpb)
+    ModMagic mod;
+    const uint8_t *kmers;  // n_kmers * k ASCII bytes, 16-byte aligned
+    const uint32_t *freq;  // or nullptr
+    uint64_t n_kmers;
+    // a5 outputs (accumulated with atomics; caller zeroes)
+    uint64_t *hits;
+    uint64_t *n_unique;
+    uint64_t *sum_unique_freq;
+    uint32_t *unique_colour;
+    // a4 outputs (caller presets and_words to all-ones, *missing to 0)
+    uint64_t *and_words;
+    int *missing;
+};
+
+struct InsertParams {
+    uint64_t *mat;
+    uint32_t rs;
+    uint32_t n_hash;
+    uint32_t k;
+    uint32_t n_colors;
+    uint32_t tiles_per_block;
+    ModMagic mod;
+    const uint8_t *kmers;
+    const uint32_t *colour_of_kmer;
+    uint64_t n_kmers;
+};
+
+size_t search_smem_bytes(const SearchParams &p);
+int grid_for(uint64_t n_kmers, uint32_t tiles_per_block);
+hipError_t launch_search_count(const SearchParams &p, hipStream_t stream);
+hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream);
+hipError_t launch_put_rows(uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, const uint32_t *d_words, uint32_t w32,
+                           uint64_t n_rows, hipStream_t stream);
+hipError_t launch_get_rows(const uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, uint32_t *d_words, uint32_t w32,
+                           uint64_t n_rows, hipStream_t stream);
+hipError_t launch_insert_kmers(const InsertParams &p, hipStream_t stream);
+
+}  // namespace cid

@@ -1,0 +1,130 @@
+"""Thin object wrappers over the C ABI (host-pointer calls take numpy arrays, *_dev calls take ints)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, load_library, vp
+
+NOT_UNIQUE = 0xFFFFFFFF
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+class Context:
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        h = vp()
+        check(self.lib.cid_ctx_create(device_id, C.byref(h)))
+        self.h = h
+        self.device_id = device_id
+
+    def set_stream(self, hip_stream):
+        check(self.lib.cid_ctx_set_stream(self.h, vp(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        check(self.lib.cid_ctx_synchronize(self.h))
+
+    def timer_start(self):
+        check(self.lib.cid_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float(0)
+        check(self.lib.cid_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cid_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Index:
+    """Device-resident BIGSI matrix (BigsyMapNew.map, src/bigsi.rs:19-27)."""
+
+    def __init__(self, ctx, bloom_size, num_hash, k_size, n_colors, hash_variant=0):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.m, self.n_hash, self.k, self.n_colors = bloom_size, num_hash, k_size, n_colors
+        self.w32 = (n_colors + 31) // 32
+        h = vp()
+        check(self.lib.cid_index_create(ctx.h, bloom_size, num_hash, k_size, n_colors, hash_variant, C.byref(h)))
+        self.h = h
+
+    def put_rows(self, row_ids, words):
+        row_ids = np.ascontiguousarray(row_ids, np.uint64)
+        words = np.ascontiguousarray(words, np.uint32).reshape(len(row_ids), self.w32)
+        check(self.lib.cid_index_put_rows(self.h, _p(row_ids), _p(words), len(row_ids)))
+
+    def put_dense(self, rows_u32):
+        """rows_u32: bloom_size x w32 dense BitVec storage; only non-zero rows are sent (as a .bxi holds them)."""
+        rows_u32 = np.ascontiguousarray(rows_u32, np.uint32).reshape(self.m, self.w32)
+        nz = np.flatnonzero(rows_u32.any(axis=1)).astype(np.uint64)
+        self.put_rows(nz, rows_u32[nz])
+
+    def device_matrix(self):
+        ptr, rs = vp(), C.c_uint64(0)
+        check(self.lib.cid_index_device_matrix(self.h, C.byref(ptr), C.byref(rs)))
+        return ptr.value, rs.value
+
+    def finalize(self):
+        check(self.lib.cid_index_finalize(self.h))
+        return self
+
+    def get_rows(self, row_ids):
+        row_ids = np.ascontiguousarray(row_ids, np.uint64)
+        out = np.zeros((len(row_ids), self.w32), np.uint32)
+        check(self.lib.cid_index_get_rows(self.h, _p(row_ids), _p(out), len(row_ids)))
+        return out
+
+    def insert_kmers_dev(self, d_kmers, d_colour_of_kmer, n_kmers):
+        check(self.lib.cid_index_insert_kmers_dev(self.h, vp(d_kmers), vp(d_colour_of_kmer), n_kmers))
+
+    # ---- a5
+    def search_count(self, kmers, freq=None, want_unique=True, want_unique_colour=True):
+        kmers = np.ascontiguousarray(kmers, np.uint8).reshape(-1, self.k)
+        K = kmers.shape[0]
+        f = None if freq is None else np.ascontiguousarray(freq, np.uint32)
+        hits = np.zeros(self.n_colors, np.uint64)
+        nu = np.zeros(self.n_colors, np.uint64) if want_unique else None
+        sf = np.zeros(self.n_colors, np.uint64) if want_unique else None
+        uc = np.zeros(K, np.uint32) if want_unique_colour else None
+        check(self.lib.cid_search_count(self.ctx.h, self.h, _p(kmers), _p(f), K, _p(hits), _p(nu), _p(sf), _p(uc)))
+        return hits, nu, sf, uc
+
+    def search_count_dev(self, d_kmers, d_freq, n_kmers, d_hits, d_n_unique=None, d_sum=None, d_uc=None):
+        check(self.lib.cid_search_count_dev(self.ctx.h, self.h, vp(d_kmers), vp(d_freq) if d_freq else None, n_kmers,
+                                            vp(d_hits), vp(d_n_unique) if d_n_unique else None,
+                                            vp(d_sum) if d_sum else None, vp(d_uc) if d_uc else None))
+
+    # ---- a4
+    def search_perfect(self, kmers):
+        kmers = np.ascontiguousarray(kmers, np.uint8).reshape(-1, self.k)
+        words = np.zeros(self.w32, np.uint32)
+        missing = C.c_int(0)
+        check(self.lib.cid_search_perfect(self.ctx.h, self.h, _p(kmers), kmers.shape[0], _p(words), C.byref(missing)))
+        return words, bool(missing.value)
+
+    # ---- a6/a7/a9/a10
+    def readid_count(self, bases, seq_off, read_seq0, d=1, start_sample=3):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        read_seq0 = np.ascontiguousarray(read_seq0, np.uint64)
+        n_reads = len(read_seq0) - 1
+        rep = np.zeros((n_reads, self.n_colors + 1), np.uint32)
+        nk = np.zeros(n_reads, np.uint32)
+        st = np.zeros(n_reads, np.uint8)
+        check(self.lib.cid_readid_count(self.ctx.h, self.h, _p(bases), _p(seq_off), len(seq_off) - 1, _p(read_seq0),
+                                        n_reads, d, start_sample, _p(rep), _p(nk), _p(st)))
+        return rep, nk, st
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cid_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

@@ -1,0 +1,117 @@
+/*
+ * colorid_hip.h — C ABI of libcolorid_hip.so: the MI355X (gfx950) implementation of colorid's
+ * BIGSI query hot path.  Plain pointers and sizes only; a Rust `extern "C"` block (see
+ * INTEGRATION.md) binds these symbols in place of the loops cited next to each entry point.
+ * Citations are file:line in the reference tree (hcdenbakker/colorid @ 2024_10_08).
+ *
+ * Conventions
+ *   - every function returns CID_OK (0) or a negative CID_ERR_*; cid_last_error() returns the
+ *     calling thread's last message.  Nothing throws or aborts across the ABI.  (The reference
+ *     panics on every error: src/bigsi.rs:60-61, src/kmer.rs:11.)
+ *   - the caller owns every host buffer; the library owns device memory.
+ *   - a cid_index is immutable and shareable after cid_index_finalize(); a cid_ctx is used by
+ *     one host thread at a time.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     CID_ERR_HIP.
+ *   - k-mers are ASCII byte strings of exactly k_size bytes, hashed byte-for-byte
+ *     (upper/lower case preserved); 1 <= k_size <= 128.
+ *   - `*_dev` entry points take DEVICE pointers (16-byte aligned), enqueue on the ctx stream and
+ *     return without synchronising; the plain forms take HOST pointers and are synchronous.
+ */
+#ifndef COLORID_HIP_H
+#define COLORID_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CID_OK 0
+#define CID_ERR_INVALID (-1)     /* bad argument */
+#define CID_ERR_HIP (-2)         /* HIP runtime error / no device */
+#define CID_ERR_NOMEM (-3)
+#define CID_ERR_UNSUPPORTED (-4) /* e.g. k_size > 128, n_colors > 8192, bloom_size > 2^32 */
+#define CID_ERR_STATE (-5)       /* e.g. search on an index that is not finalized */
+
+/* Hash variants.  The reference calls xxh3::hash64_with_seed(kmer, i) % bloom_size
+ * (src/simple_bloom.rs:22-23; crate xxh3 ^0.1.1, not vendored, version unpinned).
+ * CID_HASH_XXH3_V08 = the published XXH3_64bits_withSeed (xxHash >= 0.8.0).  The .bxi format
+ * carries no hash id, so the caller states it. */
+#define CID_HASH_XXH3_V08 0
+
+#define CID_NOT_UNIQUE 0xFFFFFFFFu
+
+typedef struct cid_ctx cid_ctx;     /* one HIP device + stream + scratch */
+typedef struct cid_index cid_index; /* device-resident dense bit matrix: bloom_size rows x n_colors bits */
+
+const char *cid_last_error(void);
+int cid_abi_version(void);
+int cid_device_count(int *n_devices);
+
+/* ---- context ---- */
+int cid_ctx_create(int device_id, cid_ctx **out);
+/* Borrow an existing hipStream_t (e.g. the caller's framework stream); NULL restores the ctx's own stream. */
+int cid_ctx_set_stream(cid_ctx *, void *hip_stream);
+int cid_ctx_synchronize(cid_ctx *);
+void cid_ctx_destroy(cid_ctx *);
+
+/* ---- index: replaces BigsyMapNew.map (src/bigsi.rs:19-27) as handed to the search functions
+ *      (src/main.rs:600-625, :810-865).  Rows follow BitVec<u32> (bit-vec_serde/src/lib.rs:218-224,
+ *      :465-474): bit c of a row = colour c = words[c/32] >> (c%32) & 1. ---- */
+int cid_index_create(cid_ctx *, uint64_t bloom_size, uint32_t num_hash, uint32_t k_size, uint32_t n_colors,
+                     int hash_variant, cid_index **out);
+/* Sparse rows as the .bxi `map` stores them (src/bigsi.rs:59-63): n_rows x W32 little-endian
+ * u32 words, W32 = ceil(n_colors/32).  Rows never put stay all-zero == key absent from the map. */
+int cid_index_put_rows(cid_index *, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows);
+/* Native device layout: row r at matrix + r*row_stride_words (u64 words, little-endian pairs of the u32 words,
+ * zero padded).  Exposed so a caller can generate/fill an index in HBM directly (bits >= n_colors MUST be 0). */
+int cid_index_device_matrix(cid_index *, void **dev_ptr, uint64_t *row_stride_words);
+int cid_index_finalize(cid_index *);
+/* Read rows back (host): words_le receives n_rows x W32 u32 words. */
+int cid_index_get_rows(const cid_index *, const uint64_t *row_ids, uint32_t *words_le, size_t n_rows);
+/* Bloom insert on device: simple_bloom.rs:19-26 for colour `colour` of every k-mer (used to build/plant
+ * indices without leaving HBM; src/build.rs:116-128 transposed on the fly).  Before finalize only. */
+int cid_index_insert_kmers_dev(cid_index *, const uint8_t *d_kmers, const uint32_t *d_colour_of_kmer,
+                               size_t n_kmers);
+void cid_index_destroy(cid_index *);
+
+/* ---- a5: proportional search, the hot loop of batch_search_pe::batch_search
+ *      (src/batch_search_pe.rs:45-84 and :125-164).  For each distinct k-mer: n hashes -> n rows -> AND;
+ *      hits[c] += 1 for every set colour c; if exactly one colour is set: n_unique[c] += 1,
+ *      sum_unique_freq[c] += freq[kmer] (1 if freq == NULL), unique_colour[kmer] = c (else CID_NOT_UNIQUE).
+ *      n_unique / sum_unique_freq / unique_colour may be NULL. ---- */
+int cid_search_count(cid_ctx *, const cid_index *, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
+                     uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int cid_search_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint32_t *d_freq,
+                         size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
+                         uint32_t *d_unique_colour);
+
+/* ---- a4: perfect search, perfect_search::batch_search / batch_search_mf
+ *      (src/perfect_search.rs:25-52, :83-110): AND of all n*K rows.  and_words_le: W32 u32 words;
+ *      *any_row_missing = 1 iff some row is absent (the reference's "No perfect hits!"), in which case
+ *      and_words_le is all zero. ---- */
+int cid_search_perfect(cid_ctx *, const cid_index *, const uint8_t *kmers, size_t n_kmers,
+                       uint32_t *and_words_le, int *any_row_missing);
+
+/* ---- a6/a7/a9/a10: per-read classification counts, the body of read_id_mt_pe::parallel_vec before
+ *      kmer_poll_plus (src/read_id_mt_pe.rs:300-331): too_short test on the first mate (:305), distinct
+ *      canonical k-mers of the read(-pair) with stride d (src/kmer.rs:221-243, src/seq.rs:59-70), then
+ *      search_index_classic (start_sample == 0, :66-102) or search_index (:104-165).
+ *      Reads: `bases` concatenated (already quality-masked, src/seq.rs:36-56); seq s = bases[seq_off[s]..seq_off[s+1]);
+ *      read r = seqs read_seq0[r]..read_seq0[r+1]-1 (1 = SE, 2 = PE).
+ *      report: n_reads x (n_colors+1) counts, column n_colors = the reference's no_hits_num entry;
+ *      n_kmers[r] = |k-mer set|; status[r] = 1 for too_short, else 0.
+ *      k-mer iteration order is first occurrence (mate 1 then mate 2) — SURVEY.md App. B Q7. ---- */
+int cid_readid_count(cid_ctx *, const cid_index *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                     const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                     uint32_t *report, uint32_t *n_kmers, uint8_t *status);
+
+/* ---- measurement helpers (bench only): HIP-event timing on the ctx stream ---- */
+int cid_timer_start(cid_ctx *);
+int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as _orc
+    _orc.lib()
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def hip_ctx():
+    import colorid_amd
+    ctx = colorid_amd.Context(0)
+    yield ctx
+    ctx.close()

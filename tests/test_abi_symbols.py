@@ -1,0 +1,43 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/colorid_hip.h declares."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "colorid_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cid_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from colorid_amd import _lib
+    lib = _lib.load_library()
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/colorid_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.cid_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import colorid_amd
+    with pytest.raises(colorid_amd.CidError) as ei:
+        colorid_amd.Context(0)
+    assert ei.value.code == -2  # CID_ERR_HIP: the product never computes on the CPU
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "colorid_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and "oracle" not in txt.lower(), (dp, f)

@@ -1,0 +1,63 @@
+"""CPU check of the integer arithmetic the gfx950 kernels execute (same headers, compiled with g++):
+XXH3-64 seeds 0..n-1 out of a byte image at arbitrary alignment, and the exact `% bloom_size`."""
+import ctypes as C
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("shim") / "hash_shim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(HERE, "cpu_shim", "hash_shim.cpp")])
+    L = C.CDLL(so)
+    L.shim_hash_seeds.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.shim_mod.restype = C.c_uint64
+    L.shim_mod.argtypes = [C.c_uint64, C.c_uint64]
+    L.shim_row_stride_words.restype = C.c_uint32
+    L.shim_row_stride_words.argtypes = [C.c_uint32]
+    return L
+
+
+def test_device_hash_matches_published_kats(shim):
+    with open(os.path.join(HERE, "golden", "xxh3_kat.json")) as f:
+        vecs = json.load(f)["vectors"]
+    by_input = {}
+    for v in vecs:
+        if v["seed"] < 8:
+            by_input.setdefault(v["hex"], {})[v["seed"]] = v["h"]
+    n_checked = 0
+    for hx, seeds in by_input.items():
+        b = bytes.fromhex(hx)
+        if not 1 <= len(b) <= 128:
+            continue
+        for off in (0, 1, 2, 3, 5, 31, 62):
+            out = (C.c_uint64 * 8)()
+            shim.shim_hash_seeds(b, len(b), off, 8, out)
+            for s, h in seeds.items():
+                assert out[s] == h, (len(b), off, s)
+                n_checked += 1
+    assert n_checked > 3000
+
+
+def test_device_mod_is_exact(shim):
+    rnd = random.Random(9)
+    ms = [1, 2, 3, 5, 6, 7, 12, 1000, 750000, 30_000_000, 50_000_000, 250_000_000, 2**30, 2**32 - 1, 2**32,
+          2**31 + 1, 10**9 + 7, 2**63, 2**63 + 1, 2**64 - 1] + [rnd.getrandbits(rnd.randint(2, 64)) | 1 for _ in range(50)]
+    for m in ms:
+        hs = [0, 1, m - 1, m, (m + 1) % 2**64, 2**64 - 1, 2**63, 2**32] + [rnd.getrandbits(64) for _ in range(500)]
+        for h in hs:
+            assert shim.shim_mod(h, m) == h % m, (h, m)
+
+
+def test_row_stride_rule(shim):
+    want = {1: 1, 4: 1, 46: 1, 64: 1, 65: 2, 128: 2, 129: 4, 255: 4, 256: 4, 257: 8, 512: 8, 1024: 16, 1025: 32,
+            4096: 64, 8192: 128}
+    for c, rs in want.items():
+        assert shim.shim_row_stride_words(c) == rs

@@ -1,0 +1,199 @@
+"""Parity of the HIP path (through the C ABI) with the oracle: bit-exact integers on the same seeded inputs.
+Covers a5 (cid_search_count) and a4 (cid_search_perfect) over row widths, hash counts, k-mer lengths,
+ragged tiles, absent rows and empty inputs; plus put_rows/get_rows round trips."""
+import numpy as np
+import pytest
+
+from util import plant, random_index, random_kmers, to_hip_index
+
+pytestmark = pytest.mark.gpu
+
+# (n_colors, n_hash, k, bloom_size)
+LAYOUTS = [
+    (4, 4, 27, 750_000),        # test.sh parameters, rs=1 (8-byte rows)
+    (1, 1, 31, 4099),
+    (46, 4, 31, 100_003),       # ref_file_example.txt colour count
+    (64, 3, 21, 1 << 16),       # power-of-two bloom size (mask path)
+    (65, 2, 21, 50_021),        # rs=2 with one live bit in word 1
+    (128, 4, 31, 40_009),
+    (129, 4, 31, 40_009),       # w64=3 -> rs=4, dead lanes past the row's width
+    (255, 2, 21, 30_011),
+    (256, 4, 31, 1 << 20),      # the headline row width: 32-byte rows, 2 lanes per row
+    (300, 5, 31, 20_011),       # generic n_hash > 4 path
+    (512, 4, 31, 20_011),
+    (1024, 4, 31, 10_007),      # 128-byte rows, 8 lanes per row
+    (1500, 3, 31, 5_003),
+    (4096, 3, 31, 3_001),       # 512-byte rows
+    (8192, 2, 31, 1_009),       # 1 KiB rows: the whole wave covers one row
+]
+
+
+@pytest.mark.parametrize("n_colors,n_hash,k,m", LAYOUTS)
+def test_search_count_parity(orc, hip_ctx, n_colors, n_hash, k, m):
+    rng = np.random.default_rng(n_colors * 31 + n_hash)
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.25, zero_row_frac=0.15)
+    K = 3000 + n_colors % 61
+    kmers = random_kmers(rng, K, k)
+    plant(oix, rng, kmers, frac=0.5, max_colours=min(3, n_colors))
+    freq = rng.integers(1, 1000, size=K).astype(np.uint32)
+    hx = to_hip_index(hip_ctx, oix)
+    want = oix.search_count(kmers, freq)
+    got = hx.search_count(kmers, freq)
+    for w, g, name in zip(want, got, ("hits", "n_unique", "sum_unique_freq", "unique_colour")):
+        assert np.array_equal(w, g), name
+    assert want[0].sum() > 0
+    # outputs are optional: hits only
+    hits_only = hx.search_count(kmers, None, want_unique=False, want_unique_colour=False)[0]
+    assert np.array_equal(hits_only, want[0])
+    # freq == NULL counts every unique hit once
+    w2 = oix.search_count(kmers, None)
+    g2 = hx.search_count(kmers, None)
+    assert np.array_equal(w2[2], g2[2]) and np.array_equal(w2[1], g2[2])
+    hx.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 8, 9, 12, 16, 17, 21, 27, 31, 32, 33, 48, 64, 65, 96, 97, 127, 128])
+def test_kmer_lengths(orc, hip_ctx, k):
+    rng = np.random.default_rng(1000 + k)
+    alphabet = np.frombuffer(b"ACGTacgtN", np.uint8)        # raw bytes are hashed as they are (App. B Q2)
+    oix = random_index(orc, rng, 20_011, 3, k, 100, density=0.4, zero_row_frac=0.0)
+    kmers = random_kmers(rng, 777, k, alphabet)
+    hx = to_hip_index(hip_ctx, oix)
+    want = oix.search_count(kmers, None)
+    got = hx.search_count(kmers, None)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    hx.close()
+
+
+@pytest.mark.parametrize("n_hash", [1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 32])
+def test_hash_counts(orc, hip_ctx, n_hash):
+    rng = np.random.default_rng(2000 + n_hash)
+    oix = random_index(orc, rng, 9_973, n_hash, 31, 256, density=0.8, zero_row_frac=0.01)
+    kmers = random_kmers(rng, 1500, 31)
+    plant(oix, rng, kmers, frac=0.7)
+    hx = to_hip_index(hip_ctx, oix)
+    for w, g in zip(oix.search_count(kmers, None), hx.search_count(kmers, None)):
+        assert np.array_equal(w, g)
+    pw, pm = oix.search_perfect(kmers[:5])
+    gw, gm = hx.search_perfect(kmers[:5])
+    assert pm == gm and np.array_equal(pw, gw)
+    hx.close()
+
+
+@pytest.mark.parametrize("K", [0, 1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 4097])
+def test_ragged_and_empty_batches(orc, hip_ctx, K):
+    rng = np.random.default_rng(3000 + K)
+    oix = random_index(orc, rng, 30_011, 4, 31, 256, density=0.5, zero_row_frac=0.05)
+    kmers = random_kmers(rng, K, 31)
+    plant(oix, rng, kmers, frac=0.9)
+    freq = rng.integers(1, 5, size=K).astype(np.uint32)
+    hx = to_hip_index(hip_ctx, oix)
+    for w, g in zip(oix.search_count(kmers, freq), hx.search_count(kmers, freq)):
+        assert np.array_equal(w, g)
+    hx.close()
+
+
+def test_duplicates_and_dense_hits(orc, hip_ctx):
+    # every k-mer in every colour: AND words are all-ones (dense counting path), duplicates are counted per entry
+    rng = np.random.default_rng(77)
+    oix = orc.Index(5_003, 3, 21, 200)
+    oix.rows()[:] = 0xFFFFFFFF
+    oix.rows()[:, -1] = (1 << (200 - 192)) - 1
+    kmers = np.repeat(random_kmers(rng, 50, 21), 7, axis=0)
+    hx = to_hip_index(hip_ctx, oix)
+    want, got = oix.search_count(kmers, None), hx.search_count(kmers, None)
+    assert want[0].tolist() == [350] * 200
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    hx.close()
+
+
+@pytest.mark.parametrize("n_colors,n_hash,k,m", LAYOUTS)
+def test_search_perfect_parity(orc, hip_ctx, n_colors, n_hash, k, m):
+    rng = np.random.default_rng(n_colors * 17 + n_hash + 5)
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.2, zero_row_frac=0.1)
+    kmers = random_kmers(rng, 700, k)
+    # colours 0 and C-1 hold every k-mer; colour C//2 holds all but one
+    for j, km in enumerate(kmers):
+        oix.insert(0, km.tobytes())
+        oix.insert(n_colors - 1, km.tobytes())
+        if j != 333:
+            oix.insert(n_colors // 2, km.tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    ww, wm = oix.search_perfect(kmers)
+    gw, gm = hx.search_perfect(kmers)
+    assert not wm and not gm
+    assert np.array_equal(ww, gw)
+    assert ww[0] & 1 and ww[(n_colors - 1) // 32] >> ((n_colors - 1) % 32) & 1
+    # a k-mer with an absent row => "No perfect hits!" (perfect_search.rs:38-39)
+    rows = oix.rows()
+    absent = int(orc.xxh3(kmers[10].tobytes(), n_hash - 1) % m)
+    saved = rows[absent].copy()
+    rows[absent] = 0
+    hx2 = to_hip_index(hip_ctx, oix)
+    ww, wm = oix.search_perfect(kmers)
+    gw, gm = hx2.search_perfect(kmers)
+    assert wm and gm and not gw.any() and not ww.any()
+    rows[absent] = saved
+    for K in (1, 63, 65):
+        a, b = oix.search_perfect(kmers[:K]), hx.search_perfect(kmers[:K])
+        assert a[1] == b[1] and np.array_equal(a[0], b[0])
+    hx.close(); hx2.close()
+
+
+def test_put_get_rows_roundtrip(orc, hip_ctx):
+    import colorid_amd
+    rng = np.random.default_rng(11)
+    for n_colors in (4, 33, 64, 65, 256, 257, 1000):
+        m = 10_007
+        hx = colorid_amd.Index(hip_ctx, m, 2, 21, n_colors)
+        w32 = (n_colors + 31) // 32
+        ids = rng.choice(m, size=500, replace=False).astype(np.uint64)
+        words = rng.integers(0, 2**32, size=(500, w32), dtype=np.uint64).astype(np.uint32)
+        if n_colors % 32:
+            words[:, -1] &= np.uint32((1 << (n_colors % 32)) - 1)
+        hx.put_rows(ids, words)
+        hx.finalize()
+        assert np.array_equal(hx.get_rows(ids), words)
+        others = np.setdiff1d(np.arange(m, dtype=np.uint64), ids)[:300]
+        assert not hx.get_rows(others).any()                 # rows never put stay absent (all-zero)
+        hx.close()
+
+
+def test_error_behaviour(hip_ctx):
+    import colorid_amd
+    with pytest.raises(colorid_amd.CidError):
+        colorid_amd.Index(hip_ctx, 1000, 2, 129, 8)          # k_size > 128
+    with pytest.raises(colorid_amd.CidError):
+        colorid_amd.Index(hip_ctx, 1000, 2, 21, 8, hash_variant=7)
+    hx = colorid_amd.Index(hip_ctx, 1000, 2, 21, 8)
+    with pytest.raises(colorid_amd.CidError):                # not finalized
+        hx.search_count(np.zeros((1, 21), np.uint8))
+    with pytest.raises(colorid_amd.CidError):                # row id out of range
+        hx.put_rows(np.array([1000], np.uint64), np.array([[1]], np.uint32))
+    with pytest.raises(colorid_amd.CidError):                # bits beyond n_colors
+        hx.put_rows(np.array([1], np.uint64), np.array([[256]], np.uint32))
+    hx.close()
+
+
+def test_insert_kmers_matches_oracle_bloom(orc, hip_ctx):
+    import torch
+
+    import colorid_amd
+    rng = np.random.default_rng(21)
+    for n_colors, k, m, n_hash in ((4, 27, 75_011, 4), (256, 31, 1 << 16, 4), (1000, 21, 9_001, 2)):
+        kmers = random_kmers(rng, 5000, k)
+        cols = rng.integers(0, n_colors, size=5000).astype(np.uint32)
+        oix = orc.Index(m, n_hash, k, n_colors)
+        for km, c in zip(kmers, cols):
+            oix.insert(int(c), km.tobytes())
+        hx = colorid_amd.Index(hip_ctx, m, n_hash, k, n_colors)
+        dk = torch.from_numpy(kmers.reshape(-1)).cuda()
+        dc = torch.from_numpy(cols.astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        hx.insert_kmers_dev(dk.data_ptr(), dc.data_ptr(), 5000)
+        hx.finalize()
+        got = hx.get_rows(np.arange(m, dtype=np.uint64))
+        assert np.array_equal(got, oix.rows())
+        hx.close()

@@ -1,0 +1,274 @@
+"""The oracle pinned against every golden vector / known-answer test available for the path
+(SURVEY.md §8c): published XXH3 KATs, src/seq.rs:72-76, src/simple_bloom.rs:60-66, the BitVec bit layout
+(bit-vec_serde/src/lib.rs:335-363, :465-474), the sizing KAT for test_data/refs/Listeria_phage_B056.fasta,
+the bincode .bxi layout, and an independent pure-Python restatement of the search loop."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFS = os.path.join(HERE, "golden", "refs")
+PHAGES = ["Listeria_phage_B021", "Listeria_phage_B051", "Listeria_phage_B056", "Listeria_phage_B545"]
+
+
+def test_xxh3_published_kats(orc):
+    with open(os.path.join(HERE, "golden", "xxh3_kat.json")) as f:
+        kat = json.load(f)
+    assert len(kat["vectors"]) > 1000
+    for v in kat["vectors"]:
+        assert orc.xxh3(bytes.fromhex(v["hex"]), v["seed"]) == v["h"]
+
+
+def test_xxh3_survey_appendix_c(orc):
+    # hex digests for seeds 0..3 and `% 50_000_000`
+    want = {
+        b"ATGC": ("caaf223612b989e9 1fe32407d1d902a7 0179b9fcb0a2e122 1f867a716405d144", [23535593, 43116071, 16278946, 32989892]),
+        b"A" * 21: ("1b772345efdb0578 805f68dc5fe80a71 0d2d650c1021f29b 359baf9f25b4d395", [36446328, 3424497, 29715867, 17600789]),
+        b"TAATTAAATCTAACAATTTCGTTACAGATTT": ("2c624549743ccc73 df0b2df1ea809a28 0a197e76821ed30b 76a89e4cd5fef317", [21544179, 46411816, 1344651, 7845143]),
+    }
+    for b, (hx, mods) in want.items():
+        hs = [orc.xxh3(b, s) for s in range(4)]
+        assert [f"{h:016x}" for h in hs] == hx.split()
+        assert [h % 50_000_000 for h in hs] == mods
+
+
+def test_seq_rs_can_detect_no_n(orc):  # src/seq.rs:72-76
+    L = orc.lib()
+    assert L.orc_has_no_n(b"AAGT", 4)
+    assert not L.orc_has_no_n(b"NAGT", 4)
+    assert L.orc_has_no_n(b"acgtACGT", 8)
+    for bad in b"NnUuRY-*\n\r xX":
+        assert not L.orc_is_good_base(bad)
+
+
+def test_revcomp_switch_base(orc):  # src/kmer.rs:839-863
+    assert orc.revcomp(b"ACGTacgt") == b"acgtACGT"
+    assert orc.revcomp(b"AUuNnXx-") == b"NNNnNaAT"
+    assert orc.revcomp(b"") == b""
+
+
+def test_qual_mask(orc):  # src/seq.rs:36-56
+    seq, qual = b"ACGTACGT", b"II#I0/5I"
+    assert orc.qual_mask(seq, qual, 0) == seq
+    # threshold 15 -> chars < chr(48) = '0' are masked
+    assert orc.qual_mask(seq, qual, 15) == b"ACNTANGT"
+
+
+def test_simple_bloom_use_filter(orc):  # src/simple_bloom.rs:60-66 (m = 250_000_000, 4 hashes)
+    ix = orc.Index(250_000_000, 4, 4, 1)
+    ix.insert(0, b"ATGC")
+    assert ix.contains(0, b"ATGC") is True
+    assert ix.contains(0, b"ATGT") is False
+    rows = np.flatnonzero(ix.rows()[:, 0])
+    assert sorted(rows.tolist()) == sorted(orc.xxh3(b"ATGC", s) % 250_000_000 for s in range(4))
+
+
+def test_bitvec_bit_layout(orc):
+    # lib.rs:465-474/492-500: bit i lives at storage[i/32] >> (i%32); from_bytes (lib.rs:335-363) is MSB-first per byte
+    ix = orc.Index(4, 1, 4, 40)
+    assert ix.w32 == 2
+    rows = ix.rows()
+    # BitVec::from_bytes(&[0b10100000, 0b00010010]) == bits {0, 2, 11, 14}
+    for c in (0, 2, 11, 14, 33):
+        rows[1, c // 32] |= np.uint32(1 << (c % 32))
+    assert rows[1, 0] == (1 << 0) | (1 << 2) | (1 << 11) | (1 << 14)
+    assert rows[1, 1] == 1 << 1
+
+
+def test_canonical_choice_and_case(orc):
+    km = orc.Kmers(4)
+    km.kmerize_vector(b"ACGTTNAAAC", 1)      # windows with N dropped; upper-cased after the raw compare
+    d = km.as_dict()
+    assert b"ACGT" in d and d[b"ACGT"] == 1   # palindrome: takes the rc branch, same string
+    assert b"AACG" in d                        # CGTT -> rc AACG is smaller
+    assert all(b"N" not in k for k in d)
+    km = orc.Kmers(4)
+    km.kmerize_vector(b"acgaACGA", 1)          # compare is case-sensitive, THEN upper-cased
+    d = km.as_dict()
+    assert set(d) == {b"ACGA", b"CGAA", b"GAAC", b"AACG", b"TCGT"} or all(k == k.upper() for k in d)
+    assert all(k == k.upper() for k in d)
+    km = orc.Kmers(4)
+    km.kmerize_skip_n_set(b"acgaACGA", 1)      # read_id path: no upper-casing (Q2)
+    assert any(k != k.upper() for k in km.as_dict())
+    km = orc.Kmers(4)
+    assert km.kmerize_string(b"ACNT") == 0     # kmerize_string has no N filter (Q3)
+    assert len(km) == 1
+    assert orc.Kmers(5).kmerize_string(b"ACGT") == -1   # None
+
+
+def test_sizing_kat_phage_b056(orc):  # 42 records, 33 726 bp, 32 634 distinct canonical 27-mers
+    seqs = orc.read_fasta(os.path.join(REFS, "Listeria_phage_B056.fasta"))
+    assert len(seqs) == 42 and sum(map(len, seqs)) == 33726
+    km = orc.Kmers(27)
+    for s in seqs:
+        km.kmerize_vector(s, 1)
+    assert len(km) == 32634
+
+
+def _write_ref_tsv(tmp_path):
+    p = tmp_path / "ref_file.txt"
+    # same shape as test_data/ref_file.txt (accession \t path), deliberately unsorted
+    p.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in reversed(PHAGES)))
+    return str(p)
+
+
+@pytest.fixture(scope="module")
+def phage_index(orc, tmp_path_factory):
+    # test.sh:3 parameters: build -s 750000 -n 4 -k 27
+    return orc.Index.build_single(_write_ref_tsv(tmp_path_factory.mktemp("phage")), 750000, 4, 27)
+
+
+def test_build_single_colours_sorted(phage_index):
+    assert phage_index.colors() == sorted(PHAGES)          # build.rs:102-113
+    assert phage_index.n_ref_kmers()[2] == 32634            # B056, build.rs:92
+    assert phage_index.w32 == 1
+
+
+def test_bxi_layout_and_roundtrip(orc, phage_index, tmp_path):
+    p = str(tmp_path / "phage.bxi")
+    phage_index.save(p)
+    raw = open(p, "rb").read()
+    m, n, k, nc = struct.unpack_from("<4Q", raw, 0)
+    assert (m, n, k, nc) == (750000, 4, 27, 4)
+    off = 32
+    for c in range(4):
+        cid, ln = struct.unpack_from("<2Q", raw, off)
+        name = raw[off + 16: off + 16 + ln].decode()
+        assert (cid, name) == (c, sorted(PHAGES)[c])
+        off += 16 + ln
+    (nrows,) = struct.unpack_from("<Q", raw, off)
+    off += 8
+    rows = phage_index.rows()
+    assert nrows == int((rows[:, 0] != 0).sum())
+    r0, w32 = struct.unpack_from("<2Q", raw, off)
+    (word,) = struct.unpack_from("<I", raw, off + 16)
+    (nbits,) = struct.unpack_from("<Q", raw, off + 20)
+    assert w32 == 1 and nbits == 4 and word == rows[r0, 0] and word != 0
+    assert len(raw) == off + nrows * 28 + 8 + sum(8 + len(n_) + 8 for n_ in PHAGES)
+    back = orc.Index.read(p)
+    assert np.array_equal(back.rows(), rows)
+    assert back.colors() == phage_index.colors() and back.n_ref_kmers() == phage_index.n_ref_kmers()
+    p2 = str(tmp_path / "again.bxi")
+    back.save(p2)
+    assert open(p2, "rb").read() == raw
+
+
+def _py_search_count(rows, m, n_hash, n_colors, kmers, freq):
+    """Independent restatement of batch_search_pe.rs:45-84 with python-xxhash (a second opinion on the oracle)."""
+    import xxhash
+    hits = [0] * n_colors
+    nu = [0] * n_colors
+    sf = [0] * n_colors
+    for km, f in zip(kmers, freq):
+        acc = None
+        for s in range(n_hash):
+            r = xxhash.xxh3_64_intdigest(km, seed=s) % m
+            word = int(rows[r, 0])
+            if word == 0:
+                acc = None
+                break
+            acc = word if acc is None else acc & word
+        if acc is None:
+            continue
+        cs = [c for c in range(n_colors) if acc >> c & 1]
+        for c in cs:
+            hits[c] += 1
+        if len(cs) == 1:
+            nu[cs[0]] += 1
+            sf[cs[0]] += f
+    return hits, nu, sf
+
+
+def test_search_count_vs_independent_python(orc, phage_index):
+    xxhash = pytest.importorskip("xxhash")  # noqa: F841
+    seqs = orc.read_fasta(os.path.join(REFS, "Listeria_phage_B056.fasta"))
+    km = orc.Kmers(27)
+    for s in seqs[:6]:
+        km.kmerize_vector(s, 1)
+    keys, counts = km.keys(), km.counts()
+    rng = np.random.default_rng(5)
+    extra = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(500, 27))]
+    keys = np.concatenate([keys, extra])
+    counts = np.concatenate([counts, rng.integers(1, 9, size=500).astype(np.uint64)])
+    hits, nu, sf, uc = phage_index.search_count(keys, counts)
+    ph, pn, ps = _py_search_count(phage_index.rows(), 750000, 4, 4, [k.tobytes() for k in keys], counts.tolist())
+    assert hits.tolist() == ph and nu.tolist() == pn and sf.tolist() == ps
+    assert hits[2] >= len(km)                       # every B056 k-mer hits colour B056
+    assert int((uc != 0xFFFFFFFF).sum()) == int(nu.sum())
+
+
+def test_perfect_search(orc, phage_index):
+    seqs = orc.read_fasta(os.path.join(REFS, "Listeria_phage_B056.fasta"))
+    km = orc.Kmers(27)
+    km.kmerize_vector(seqs[0], 1)
+    words, missing = phage_index.search_perfect(km.keys())
+    assert not missing and words[0] >> 2 & 1        # B056 = colour 2 contains all its own k-mers
+    keys = np.concatenate([km.keys(), np.frombuffer(b"ACGT" * 6 + b"ACG", np.uint8)[None, :]])
+    words2, _ = phage_index.search_perfect(keys)
+    assert words2[0] & ~words[0] == 0
+
+
+def test_report_formats(orc, phage_index):
+    seqs = orc.read_fasta(os.path.join(REFS, "Listeria_phage_B056.fasta"))
+    km = orc.Kmers(27)
+    for s in seqs:
+        km.kmerize_vector(s, 1)
+    hits, nu, sf, uc = phage_index.search_count(km.keys(), km.counts())
+    modes = orc.unique_modes(uc, km.counts(), 4)
+    rep = phage_index.generate_report("q.fasta", hits, nu, sf, modes, len(km), 0.35)
+    row = [r for r in rep.splitlines() if "B056" in r][0].split("\t")
+    assert row[:4] == ["q.fasta", "32634", "Listeria_phage_B056", "1.00"]   # reports.rs:39-42 {:.2}
+    gene = phage_index.generate_report_gene("q.fasta", hits, len(km), 0.35)
+    assert "q.fasta\tListeria_phage_B056\t32634\t1.000" in gene.splitlines()  # reports.rs:59 {:.3}
+
+
+def test_auto_cutoff(orc):  # src/kmer.rs:866-942
+    km = orc.Kmers(5)
+    km.kmerize_vector(b"AAAAACCCCC", 1)
+    assert len(km) == 6 and km.auto_cutoff() == 0    # mean multiplicity < 1.5
+    km = orc.Kmers(3)
+    km.kmerize_vector(b"ACGTAC", 1)                  # {ACG: 2, GTA: 2}: `d1.len() - 1` underflows in the reference
+    assert km.as_dict() == {b"ACG": 2, b"GTA": 2} and km.auto_cutoff() == -1
+    # multiplicities: histogram {1: 30, 2: 4, 3: 1, 4: 2, 5: 6, 6: 9, 7: 6, 8: 2, 9: 1}
+    h = orc.lib()
+    km = orc.Kmers(4)
+    import itertools
+    keys = ["".join(p).encode() for p in itertools.product("ACGT", repeat=4)]
+    mult = [1] * 30 + [2] * 4 + [3] + [4] * 2 + [5] * 6 + [6] * 9 + [7] * 6 + [8] * 2 + [9]
+    for key, mu in zip(keys, mult):
+        h.orc_kmers_insert(km.h, key, mu)
+    # coverages = [30,4,1,2,6,9,6,2]; d1 = [4, .5, .33, .67, 1.5, 3]; first_pos_d1 = 2; mean = (0*4+1*1+2*2+3*6+4*9+5*6+6*2)/30 = 3.37
+    assert km.auto_cutoff() == 2
+    assert len(km.clean_map(2)) == 1 + 2 + 6 + 9 + 6 + 2 + 1
+
+
+def test_search_index_order_semantics(orc):
+    # read_id_mt_pe.rs:104-165 with start_sample: colours outside the sampled set are never counted later
+    ix = orc.Index(1 << 12, 2, 5, 3)
+    for c in range(3):
+        ix.set_color(c, f"c{c}", 100)
+    a, b, c_ = b"AAAAC", b"AAACC", b"AACCC"
+    ix.insert(0, a); ix.insert(0, b); ix.insert(1, b); ix.insert(1, c_); ix.insert(0, c_)
+    ks = np.frombuffer(a + b + c_, np.uint8).reshape(3, 5)
+    assert ix.search_index_classic(ks).tolist() == [3, 2, 0, 0]
+    assert ix.search_index(ks, 1).tolist() == [3, 0, 0, 0]      # sampled set = {0} after the first k-mer
+    assert ix.search_index(ks, 2).tolist() == [3, 2, 0, 0]
+    miss = np.frombuffer(a + b"GGGGG" + c_, np.uint8).reshape(3, 5)
+    assert ix.search_index_classic(miss).tolist() == [1, 0, 0, 1]  # absent row: report[C] += 1; break
+
+
+def test_kmer_poll_plus(orc):  # read_id_mt_pe.rs:187-251, SURVEY.md App. E1
+    ix = orc.Index(750000, 4, 27, 4)
+    for c, n in enumerate([30000, 31000, 32634, 29000]):
+        ix.set_color(c, f"phage{c}", n)
+    assert ix.kmer_poll_plus(np.array([0, 0, 0, 0, 1], np.uint64), 50) == ("no_hits", 0, 50, "accept", 0)
+    assert ix.kmer_poll_plus(np.array([0, 0, 0, 0, 0], np.uint64), 0) == ("no_hits", 0, 0, "accept", 0)
+    assert ix.kmer_poll_plus(np.array([0, 0, 40, 0, 0], np.uint64), 50) == ("phage2", 40, 50, "accept", 1)
+    assert ix.kmer_poll_plus(np.array([40, 0, 40, 0, 0], np.uint64), 50) == ("phage0,phage2", 40, 50, "reject", 2)
+    # one hit out of 1000 k-mers with p_false ~ 6e-4: hits(1) > critical(0.6) and pmf >= 1e-3 -> not significant
+    assert ix.kmer_poll_plus(np.array([1, 0, 0, 0, 0], np.uint64), 1000) == ("no_significant_hits", 0, 1000, "reject", 0)
+    p = orc.false_prob(750000, 4, 30000)
+    assert abs(p - (1 - np.exp(-4 * 30000.5 / 749999)) ** 4) < 1e-15
