@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--colours", type=int, default=256)
     ap.add_argument("--genome-len", type=int, default=3_000_000)
     ap.add_argument("--error-rate", type=float, default=0.01)
+    ap.add_argument("--density", type=float, default=None, help="override the background bit density (experiments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -143,14 +144,18 @@ def main():
 
     import colorid_amd
     ctx = colorid_amd.Context(local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)  # kernels run on torch's current stream: torch.cuda.Event brackets them
+    # One explicit (non-null) stream for torch ops, RCCL and our kernels: torch.cuda.Event then brackets the
+    # kernel on the stream it is launched on.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx.set_stream(stream.cuda_stream)
 
     C, n, k, m = a.colours, a.hashes, a.k, a.bloom
     t_setup = time.time()
     hx = colorid_amd.Index(ctx, m, n, k, C)
     ptr, rs = hx.device_matrix()
-    p_bg = 1.0 - math.exp(-n * a.genome_len / m)
+    p_bg = a.density if a.density is not None else 1.0 - math.exp(-n * a.genome_len / m)
     fill_background(dev, ptr, m, rs, C, p_bg, seed=7)
     mine = None
     for r in range(world):  # the replicated index holds every rank's planted k-mers
@@ -236,7 +241,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs):
+def cpu_baseline(a, hx, mat_ptr, kmers, freq, C, n, k, m, rs):
     """The oracle (kind "port": plain-C restatement, 1 thread like the reference's `search`) on a bounded sample of
     the same k-mers against a host copy of the same index; also the bit-exactness check of the GPU result."""
     from oracle import orc

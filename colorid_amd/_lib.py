@@ -2,6 +2,14 @@
 import ctypes as C
 import os
 
+try:
+    # PyTorch wheels bundle their own libamdhip64; whichever HIP runtime is loaded first serves the whole
+    # process.  Loading torch's first keeps torch (streams, RCCL) and this library on ONE runtime; loading
+    # ours first leaves torch without a device.  Without torch the system ROCm runtime is used.
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcolorid_hip.so")
 _LIB = None

@@ -94,6 +94,50 @@ __device__ __forceinline__ uint32_t group_or(uint32_t v) {
     return v;
 }
 
+// Per-colour counting without one atomic per hit: every lane keeps, for its own 128 (or 64) colour bits,
+// PLANES bit-sliced binary counters (plane j = bit j of each colour's count).  Adding an AND word is a ripple
+// carry over the planes (pure VALU, independent of how many colours are set); after 2^PLANES-1 additions
+// the counters are drained into the block's LDS histogram with one atomic per colour seen since the last drain.
+template <int PLANES, bool NARROW>
+struct VCount {
+    V16 pl[PLANES];
+    uint32_t adds;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < PLANES; ++j) pl[j] = V16{0, 0};
+        adds = 0;
+    }
+    __device__ __forceinline__ void add(V16 a) {
+#pragma unroll
+        for (int j = 0; j < PLANES; ++j) {
+            const V16 t{pl[j].x & a.x, NARROW ? 0ull : (pl[j].y & a.y)};
+            pl[j].x ^= a.x;
+            if constexpr (!NARROW) pl[j].y ^= a.y;
+            a = t;
+        }
+        ++adds;  // wave-uniform
+    }
+    __device__ __forceinline__ bool full() const { return adds == (1u << PLANES) - 1u; }
+    __device__ __forceinline__ void drain_word(uint32_t *hist, uint32_t base, bool hi) {
+        uint64_t any = 0;
+#pragma unroll
+        for (int j = 0; j < PLANES; ++j) any |= hi ? pl[j].y : pl[j].x;
+        while (any) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(any);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PLANES; ++j) cnt |= (uint32_t)(((hi ? pl[j].y : pl[j].x) >> b) & 1ull) << j;
+            atomicAdd(&hist[base + b], cnt);
+            any &= any - 1;
+        }
+    }
+    __device__ __forceinline__ void drain(uint32_t *hist, uint32_t col_word) {
+        drain_word(hist, col_word * 64u, false);
+        if constexpr (!NARROW) drain_word(hist, col_word * 64u + 64u, true);
+        clear();
+    }
+};
+
 // Steps 1+2 of the header comment for one tile.  Returns nothing; fills ridx[s*64 + lane].
 __device__ __forceinline__ void stage_and_hash(uint32_t *img, uint32_t *ridx, const uint8_t *kmers, uint64_t n_kmers,
                                                uint64_t first, uint32_t k, uint32_t n, const ModMagic &mm, int lane) {
@@ -139,6 +183,8 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
     const uint32_t col_word = NARROW ? 0u : 2u * col;
     const bool col_live = col_word < p.w64;  // lanes past the row's real width neither load nor count
 
+    VCount<kPlanes, NARROW> vc;
+    vc.clear();
     for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
         const uint64_t first = tile * kWave;
         stage_and_hash(img, ridx, p.kmers, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
@@ -153,13 +199,8 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
             if constexpr (NARROW) a.y = 0;
             const uint32_t pc = (uint32_t)(__popcll(a.x) + __popcll(a.y));
             const uint32_t total = group_sum<LOG_LPR>(pc);
-            // hits: one LDS atomic per set colour (AND words are sparse: a handful of colours per k-mer)
-            uint64_t w = a.x;
-            uint32_t base = col_word * 64u;
-            while (w) { atomicAdd(&s_hits[base + (uint32_t)__builtin_ctzll(w)], 1u); w &= w - 1; }
-            w = a.y;
-            base += 64u;
-            while (w) { atomicAdd(&s_hits[base + (uint32_t)__builtin_ctzll(w)], 1u); w &= w - 1; }
+            vc.add(a);  // hits[c] += bit c, for this lane's colours
+            if (vc.full()) vc.drain(s_hits, col_word);
             if (p.want_unique && live) {
                 if (total == 1u) {
                     if (pc == 1u) {
@@ -176,6 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
             }
         }
     }
+    vc.drain(s_hits, col_word);
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < C; c += blockDim.x) {
         const uint32_t h = s_hits[c];

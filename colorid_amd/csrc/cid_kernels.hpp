@@ -5,6 +5,7 @@
 namespace cid {
 
 constexpr int kBlock = 256;  // 4 waves; every wave works on its own 64-k-mer tiles
+constexpr int kPlanes = 8;   // bit-sliced per-colour counters per lane: drained every 255 k-mers
 
 struct SearchParams {
     const uint64_t *mat;   // dense index, row r at mat + r*rs
