@@ -380,11 +380,69 @@ int cid_search_perfect(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, si
 int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
                      const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                      uint32_t *report, uint32_t *n_kmers, uint8_t *status) {
-    (void)bases; (void)seq_off; (void)n_seqs; (void)read_seq0; (void)n_reads; (void)stride_d; (void)start_sample;
-    (void)report; (void)n_kmers; (void)status;
     int rc = check_ready(c, ix);
     if (rc) return rc;
-    return fail(CID_ERR_UNSUPPORTED, "cid_readid_count: kernel not built yet");
+    if (!seq_off || !read_seq0 || (n_reads && (!report || !n_kmers || !status))) return fail(CID_ERR_INVALID, "null argument");
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    if (n_reads == 0) return CID_OK;
+    if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
+    const uint64_t total_bases = seq_off[n_seqs];
+    if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
+    // per-batch LDS sizing: the longest read(-pair) and its window count
+    uint64_t max_bytes = 0, max_win = 0;
+    for (size_t r = 0; r < n_reads; ++r) {
+        const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
+        if (s1 < s0) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
+        uint64_t win = 0;
+        for (uint64_t s = s0; s < s1; ++s) {
+            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
+            const uint64_t len = seq_off[s + 1] - seq_off[s];
+            if (len >= ix->k) win += (len - ix->k) / stride_d + 1;
+        }
+        const uint64_t bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
+        if (bytes > max_bytes) max_bytes = bytes;
+        if (win > max_win) max_win = win;
+    }
+    cid::ReadIdParams p{};
+    p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
+    p.mod = ix->mod;
+    p.stride_d = stride_d; p.start_sample = start_sample;
+    p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
+    p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
+    if (p.win_cap < 4) p.win_cap = 4;
+    p.hist_pad = (ix->n_colors + 1 + 3) & ~3u;
+    const size_t wave_bytes = (size_t)p.bases_cap + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) + 4ull * cid::kWave * ix->n_hash + 4ull * p.hist_pad;
+    p.wave_bytes = (uint32_t)((wave_bytes + 15) & ~15ull);
+    int waves = 4;
+    while (waves > 1 && (size_t)waves * p.wave_bytes > 160u * 1024u) waves >>= 1;
+    if ((size_t)waves * p.wave_bytes > 160u * 1024u)
+        return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %u B of LDS per wave (> 160 KiB): "
+                    "long-read batches are not supported by this kernel yet", (unsigned long long)max_bytes,
+                    (unsigned long long)max_win, p.wave_bytes);
+    HIP_TRY(hipSetDevice(c->device));
+    void *d_bases, *d_so, *d_r0, *d_rep, *d_nk;
+    const size_t C1 = (size_t)ix->n_colors + 1;
+    rc = slot_reserve(c, S_BASES, total_bases, &d_bases); if (rc) return rc;
+    rc = slot_reserve(c, S_SEQOFF, (n_seqs + 1) * 8, &d_so); if (rc) return rc;
+    rc = slot_reserve(c, S_READ0, (n_reads + 1) * 8, &d_r0); if (rc) return rc;
+    rc = slot_reserve(c, S_REPORT, n_reads * C1 * 4, &d_rep); if (rc) return rc;
+    rc = slot_reserve(c, S_NK, n_reads * 4 + n_reads + 16, &d_nk); if (rc) return rc;
+    if (total_bases) HIP_TRY(hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    p.bases = (const uint8_t *)d_bases; p.seq_off = (const uint64_t *)d_so; p.read_seq0 = (const uint64_t *)d_r0;
+    p.n_reads = n_reads;
+    p.report = (uint32_t *)d_rep; p.n_kmers = (uint32_t *)d_nk; p.status = (uint8_t *)d_nk + n_reads * 4;
+    uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
+    if (rpb < (uint64_t)waves) rpb = waves;
+    if (rpb > 256) rpb = 256;
+    p.reads_per_block = (uint32_t)rpb;
+    HIP_TRY(cid::launch_readid(p, waves, c->stream));
+    HIP_TRY(hipMemcpyAsync(report, d_rep, n_reads * C1 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(status, (uint8_t *)d_nk + n_reads * 4, n_reads, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ timing

@@ -299,6 +299,185 @@ __global__ __launch_bounds__(kBlock) void k_search_perfect(SearchParams p) {
         atomicAnd(reinterpret_cast<unsigned long long *>(&p.and_words[c]), (unsigned long long)s_and[c]);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// a6/a7/a9/a10: per-read classification counts (src/read_id_mt_pe.rs:300-331).  One wave per read(-pair):
+//   windows with stride d -> seq::has_no_n filter -> canonical choice on raw bytes (src/kmer.rs:221-243)
+//   -> per-read set in first-occurrence order (exact: 32-bit tag match is confirmed on the bytes)
+//   -> search_index_classic (:66-102) or search_index (:104-165) with the reference's "absent row => count
+//   it once under no_hits_num and stop" rule applied in k-mer order.
+
+__device__ __forceinline__ bool good_base(uint32_t b) {  // src/seq.rs:59-64
+    const uint32_t u = b & 0xDFu;
+    return u == 'A' || u == 'C' || u == 'G' || u == 'T';
+}
+__device__ __forceinline__ uint32_t comp_base(uint32_t b) {  // src/kmer.rs:847-863 restricted to ACGTacgt
+    const uint32_t low = b & 0x1Fu;
+    return b ^ ((low == 1u || low == 0x14u) ? 0x15u : 0x04u);
+}
+// byte t of the canonical string of the window described by info = pos | rc << 31
+__device__ __forceinline__ uint32_t canon_byte(const uint8_t *bases, uint32_t info, uint32_t k, uint32_t t) {
+    const uint32_t pos = info & 0x7FFFFFFFu;
+    return (info >> 31) ? comp_base(bases[pos + k - 1 - t]) : (uint32_t)bases[pos + t];
+}
+
+template <int LOG_LPR, bool NARROW>
+__global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr int KPW = kWave / LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t C = p.n_colors, k = p.k, n = p.n_hash, S = p.start_sample;
+
+    uint8_t *wb = smem + (size_t)wave * p.wave_bytes;
+    uint8_t *s_bases = wb;
+    uint32_t *s_tag = reinterpret_cast<uint32_t *>(wb + p.bases_cap);
+    uint32_t *s_info = s_tag + p.win_cap;
+    uint32_t *img = s_info + p.win_cap;
+    uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+    uint32_t *ridx = img + kmer_img_bytes(k) / 4;
+    uint32_t *hist = ridx + kWave * n;
+
+    for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
+
+    const uint32_t col = lane & (LPR - 1);
+    const uint32_t col_word = NARROW ? 0u : 2u * col;
+    const bool col_live = col_word < p.w64;
+    const uint32_t seeds_mask = n >= 32 ? ~0u : ((1u << n) - 1u);
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    const uint64_t r_begin = (uint64_t)blockIdx.x * p.reads_per_block;
+    const uint64_t r_end = r_begin + p.reads_per_block < p.n_reads ? r_begin + p.reads_per_block : p.n_reads;
+    for (uint64_t read = r_begin + wave; read < r_end; read += waves) {
+        wave_lds_fence();
+        const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
+        const uint64_t g0 = p.seq_off[s0];
+        const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
+        uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
+        if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
+            for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+            if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 1; }
+            continue;
+        }
+        const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
+        for (uint32_t i = lane; i < tb; i += kWave) s_bases[i] = p.bases[g0 + i];
+        wave_lds_fence();
+
+        uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
+        bool stopped = false;  // an absent row was met: nothing after it is searched
+        VCount<kPlanes, NARROW> vc;
+        vc.clear();
+        V16 R{0, 0};           // colours seen in the first S k-mers (this lane's slice)
+
+        for (uint64_t s = s0; s < s1; ++s) {
+            const uint32_t off = (uint32_t)(p.seq_off[s] - g0);
+            const uint32_t len = (uint32_t)(p.seq_off[s + 1] - p.seq_off[s]);
+            if (len < k) continue;  // a mate shorter than k contributes nothing
+            const uint32_t nw = (len - k) / p.stride_d + 1;
+            for (uint32_t c0 = 0; c0 < nw; c0 += kWave) {
+                const uint32_t wi = c0 + lane;
+                const uint32_t pos = off + wi * p.stride_d;
+                bool valid = wi < nw;
+                if (valid)
+                    for (uint32_t t = 0; t < k; ++t) valid = valid && good_base(s_bases[pos + t]);
+                uint32_t rc = 1;  // palindromes take the reverse-complement branch (same string)
+                if (valid)
+                    for (uint32_t t = 0; t < k; ++t) {
+                        const uint32_t f = s_bases[pos + t], r = comp_base(s_bases[pos + k - 1 - t]);
+                        if (f != r) { rc = f < r ? 0u : 1u; break; }
+                    }
+                const uint32_t info = pos | (rc << 31);
+                wave_lds_fence();  // the previous chunk's gathers are done with img / ridx
+                if (valid)
+                    for (uint32_t t = 0; t < k; ++t) img8[(uint32_t)lane * k + t] = (uint8_t)canon_byte(s_bases, info, k, t);
+                wave_lds_fence();
+                uint32_t tag = 0;
+                if (valid)
+                    xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t sd, uint64_t h) {
+                        if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
+                        ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
+                    });
+                // ---- set semantics, first occurrence wins
+                bool dup = false;
+                for (uint32_t q = 0; q < nd; ++q) {  // against the distinct k-mers of earlier chunks
+                    if (valid && !dup && s_tag[q] == tag) {
+                        const uint32_t oi = s_info[q];
+                        bool same = true;
+                        for (uint32_t t = 0; t < k && same; ++t) same = canon_byte(s_bases, oi, k, t) == img8[(uint32_t)lane * k + t];
+                        dup = same;
+                    }
+                }
+                const uint64_t vmask = __ballot(valid);
+                for (int j = 0; j < kWave - 1; ++j) {  // against lower lanes of this chunk
+                    if (!((vmask >> j) & 1ull)) continue;
+                    const uint32_t tj = __builtin_amdgcn_readlane(tag, j);
+                    const uint32_t ij = __builtin_amdgcn_readlane(info, j);
+                    if (valid && !dup && j < lane && tj == tag) {
+                        bool same = true;
+                        for (uint32_t t = 0; t < k && same; ++t) same = canon_byte(s_bases, ij, k, t) == img8[(uint32_t)lane * k + t];
+                        dup = same;
+                    }
+                }
+                const bool distinct = valid && !dup;
+                const uint64_t dmask = __ballot(distinct);
+                if (distinct) {
+                    const uint32_t q = nd + (uint32_t)__popcll(dmask & lt_mask);
+                    s_tag[q] = tag;
+                    s_info[q] = info;
+                }
+                wave_lds_fence();
+                // ---- search (read_id_mt_pe.rs:66-102 / :104-165) over this chunk's distinct k-mers, in order
+                if (!stopped && dmask) {
+#pragma unroll 1
+                    for (int sub = 0; sub < LPR; ++sub) {
+                        const uint64_t sub_bits = (KPW == 64) ? dmask : ((dmask >> (sub * KPW)) & ((1ull << (KPW & 63)) - 1ull));
+                        if (!sub_bits) continue;
+                        const int kk = sub * KPW + (lane >> LOG_LPR);
+                        bool live = (dmask >> kk) & 1ull;
+                        const uint32_t q = nd + (uint32_t)__popcll(dmask & ((1ull << kk) - 1ull));
+                        V16 a{0, 0};
+                        uint32_t zm = ~0u;
+                        if (live && col_live) a = gather_and<NARROW, true>(p.mat, p.rs, ridx, kk, col_word, n, zm);
+                        if constexpr (NARROW) a.y = 0;
+                        uint32_t all_zero = zm;
+#pragma unroll
+                        for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
+                        const bool miss = live && (all_zero & seeds_mask);
+                        const uint64_t bm = __ballot(miss);
+                        // keep only the k-mers before the first absent row (lane order == k-mer order in a sub-pass)
+                        if (bm) live = live && (lane >> LOG_LPR) < (__builtin_ctzll(bm) >> LOG_LPR);
+                        if (!live) { a.x = 0; a.y = 0; }
+                        if (S > 0) {
+                            V16 ra = q < S ? a : V16{0, 0};
+#pragma unroll
+                            for (int o = LPR; o < kWave; o <<= 1) {
+                                ra.x |= __shfl_xor(ra.x, o, kWave);
+                                ra.y |= __shfl_xor(ra.y, o, kWave);
+                            }
+                            R.x |= ra.x; R.y |= ra.y;
+                            if (q >= S) { a.x &= R.x; a.y &= R.y; }
+                        }
+                        vc.add(a);
+                        if (vc.full()) vc.drain(hist, col_word);
+                        if (bm) {
+                            stopped = true;
+                            if (lane == 0) hist[C] += 1;  // *report.entry(no_hits_num) += 1; break
+                            break;
+                        }
+                    }
+                }
+                nd += (uint32_t)__popcll(dmask);
+            }
+        }
+        vc.drain(hist, col_word);
+        wave_lds_fence();
+        for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // index maintenance
 
@@ -347,6 +526,8 @@ __global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 
+static int log2u(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
+
 template <typename KernelT, typename ParamsT>
 static hipError_t launch_one(KernelT kernel, int grid, size_t shmem, hipStream_t stream, const ParamsT &p) {
     if (shmem > 64 * 1024) {  // up to the CU's 160 KiB of LDS on request
@@ -373,8 +554,6 @@ static hipError_t launch_one(KernelT kernel, int grid, size_t shmem, hipStream_t
         }                                                                                    \
     } while (0)
 
-static int log2u(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
-
 size_t search_smem_bytes(const SearchParams &p) { return 16ull * p.c_pad + (size_t)(kBlock / kWave) * p.wave_bytes; }
 
 int grid_for(uint64_t n_kmers, uint32_t tiles_per_block) {
@@ -398,6 +577,34 @@ hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {
     const int grid = grid_for(p.n_kmers, p.tiles_per_block);
     if (grid == 0) return hipSuccess;
     CID_LAUNCH_BY_LAYOUT(k_search_perfect, log_lpr, narrow, grid, shmem, stream, p);
+}
+
+template <typename KernelT>
+static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
+    const size_t shmem = (size_t)waves_per_block * p.wave_bytes;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves_per_block * kWave), shmem, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
+    if (p.rs == 1) return launch_readid_one(k_readid<0, true>, p, waves_per_block, stream);
+    switch (log2u(p.rs / 2)) {
+    case 0: return launch_readid_one(k_readid<0, false>, p, waves_per_block, stream);
+    case 1: return launch_readid_one(k_readid<1, false>, p, waves_per_block, stream);
+    case 2: return launch_readid_one(k_readid<2, false>, p, waves_per_block, stream);
+    case 3: return launch_readid_one(k_readid<3, false>, p, waves_per_block, stream);
+    case 4: return launch_readid_one(k_readid<4, false>, p, waves_per_block, stream);
+    case 5: return launch_readid_one(k_readid<5, false>, p, waves_per_block, stream);
+    case 6: return launch_readid_one(k_readid<6, false>, p, waves_per_block, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_put_rows(uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, const uint32_t *d_words, uint32_t w32,

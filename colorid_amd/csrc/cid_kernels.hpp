@@ -45,7 +45,27 @@ struct InsertParams {
     uint64_t n_kmers;
 };
 
+struct ReadIdParams {
+    const uint64_t *mat;
+    uint32_t rs, w64, n_colors, n_hash, k;
+    ModMagic mod;
+    const uint8_t *bases;       // concatenated, quality-masked reads
+    const uint64_t *seq_off;    // [n_seqs+1]
+    const uint64_t *read_seq0;  // [n_reads+1]
+    uint64_t n_reads;
+    uint32_t stride_d, start_sample;
+    uint32_t bases_cap;         // LDS bytes per wave for one read(-pair)'s bases (multiple of 16)
+    uint32_t win_cap;           // max windows (= max distinct k-mers) of one read(-pair)
+    uint32_t hist_pad;          // n_colors+1 rounded up to a multiple of 4
+    uint32_t wave_bytes;        // LDS bytes per wave
+    uint32_t reads_per_block;
+    uint32_t *report;           // [n_reads][n_colors+1]
+    uint32_t *n_kmers;          // [n_reads]
+    uint8_t *status;            // [n_reads]
+};
+
 size_t search_smem_bytes(const SearchParams &p);
+hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream);
 int grid_for(uint64_t n_kmers, uint32_t tiles_per_block);
 hipError_t launch_search_count(const SearchParams &p, hipStream_t stream);
 hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream);

@@ -126,8 +126,8 @@ class Kmers:
         self.h = handle if handle is not None else lib().orc_kmers_new(k)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_kmers_free(self.h)
+        if getattr(self, "h", None) and _LIB is not None:
+            _LIB.orc_kmers_free(self.h)
             self.h = None
 
     def __len__(self):
@@ -211,8 +211,8 @@ class Index:
             raise RuntimeError("orc_index: NULL")
 
     def __del__(self):
-        if getattr(self, "p", None):
-            lib().orc_index_free(self.p)
+        if getattr(self, "p", None) and _LIB is not None:
+            _LIB.orc_index_free(self.p)
             self.p = None
 
     m = property(lambda s: s.p.contents.bloom_size)

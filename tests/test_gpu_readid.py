@@ -1,0 +1,124 @@
+"""Parity of cid_readid_count (a6/a7/a9/a10) with the oracle's restatement of read_id_mt_pe.rs:300-331:
+per-read report rows (n_colors+1 counts), k-mer set sizes and too_short flags, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from util import random_index, to_hip_index
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFS = os.path.join(HERE, "golden", "refs")
+PHAGES = ["Listeria_phage_B021", "Listeria_phage_B051", "Listeria_phage_B056", "Listeria_phage_B545"]
+
+
+def pack_reads(reads):
+    """reads: list of lists of bytes (1 = SE, 2 = PE) -> (bases, seq_off, read_seq0)"""
+    seqs = [s for r in reads for s in r]
+    seq_off = np.zeros(len(seqs) + 1, np.uint64)
+    seq_off[1:] = np.cumsum([len(s) for s in seqs])
+    read_seq0 = np.zeros(len(reads) + 1, np.uint64)
+    read_seq0[1:] = np.cumsum([len(r) for r in reads])
+    bases = np.frombuffer(b"".join(seqs), np.uint8) if seqs else np.zeros(0, np.uint8)
+    return bases, seq_off, read_seq0
+
+
+def sample_reads(orc, rng, genomes, n_reads, read_len, paired, err=0.01, n_rate=0.005, lower_rate=0.02):
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = []
+    for _ in range(n_reads):
+        g = genomes[rng.integers(len(genomes))]
+        L = int(read_len if rng.random() < 0.8 else rng.integers(5, read_len + 1))
+        frag = int(max(L, rng.integers(L, 2 * L + 50)))
+        if len(g) <= frag:
+            continue
+        st = int(rng.integers(0, len(g) - frag))
+        mates = [g[st:st + L]]
+        if paired:
+            L2 = int(read_len if rng.random() < 0.85 else rng.integers(1, read_len + 1))
+            mates.append(g[st + frag - L2:st + frag].translate(comp)[::-1])
+        out = []
+        for m in mates:
+            a = np.frombuffer(m, np.uint8).copy()
+            e = rng.random(len(a)) < err
+            a[e] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(e.sum()))]
+            a[rng.random(len(a)) < n_rate] = ord("N")
+            if rng.random() < lower_rate:
+                a = np.frombuffer(a.tobytes().lower(), np.uint8).copy()
+            out.append(a.tobytes())
+        reads.append(out)
+    # hand-made edge cases
+    reads.append([b"A" * read_len] + ([b"T" * read_len] if paired else []))            # one distinct k-mer, many windows
+    reads.append([b"ACGT" * (read_len // 4)] + ([b"ACGT" * (read_len // 4)] if paired else []))  # 4 distinct windows repeated
+    reads.append([b"N" * read_len] + ([b"N" * 7] if paired else []))                   # no valid window
+    reads.append([b"ACG"] + ([genomes[0][:read_len]] if paired else []))                # first mate too short
+    if paired:
+        reads.append([genomes[0][100:100 + read_len], b"ACGTA"])                        # second mate shorter than k (Q8)
+        reads.append([genomes[1][500:500 + read_len], genomes[1][500:500 + read_len]])  # identical mates: all duplicates
+    return reads
+
+
+@pytest.fixture(scope="module")
+def phage(orc, hip_ctx, tmp_path_factory):
+    d = tmp_path_factory.mktemp("phage_gpu")
+    tsv = d / "refs.tsv"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES))
+    oix = orc.Index.build_single(str(tsv), 750_000, 4, 27)           # test.sh:3 parameters
+    genomes = [b"".join(orc.read_fasta(os.path.join(REFS, n + ".fasta"))) for n in PHAGES]
+    hx = to_hip_index(hip_ctx, oix)
+    yield oix, hx, genomes
+    hx.close()
+
+
+def check(oix, hx, reads, d, S):
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    want = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+    got = hx.readid_count(bases, seq_off, read_seq0, d, S)
+    assert np.array_equal(want[2], got[2]), "status"
+    assert np.array_equal(want[1], got[1]), "n_kmers"
+    bad = np.flatnonzero((want[0] != got[0]).any(axis=1))
+    assert len(bad) == 0, (bad[:5], want[0][bad[:1]], got[0][bad[:1]])
+    return want
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("d,S", [(1, 3), (1, 0), (10, 3), (1, 1), (3, 1000), (7, 0)])
+def test_readid_phage(orc, phage, paired, d, S):
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(100 * d + S + paired)
+    reads = sample_reads(orc, rng, genomes, 600, 150, paired)
+    rep, nk, st = check(oix, hx, reads, d, S)
+    assert st.sum() >= 1 and nk.max() >= 100 // d
+    assert rep[:, :4].sum() > 0 and rep[:, 4].sum() > 0      # both real hits and "absent row" stops occur
+
+
+@pytest.mark.parametrize("n_colors,n_hash,k,m", [(46, 4, 31, 200_003), (256, 2, 21, 1 << 18), (300, 3, 21, 50_021),
+                                                 (1024, 4, 31, 20_011), (64, 1, 15, 9_973), (4096, 2, 25, 3_001)])
+def test_readid_layouts(orc, hip_ctx, n_colors, n_hash, k, m):
+    rng = np.random.default_rng(n_colors + k)
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.05, zero_row_frac=0.02)
+    genomes = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3000)].tobytes() for _ in range(6)]
+    for gi, g in enumerate(genomes):                       # genome gi -> colours gi and n_colors-1-gi
+        km = orc.Kmers(k)
+        km.kmerize_vector(g, 1)
+        for key in km.keys():
+            oix.insert(gi, key.tobytes())
+            oix.insert(n_colors - 1 - gi, key.tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    for paired, d, S in ((True, 1, 3), (False, 1, 0), (True, 5, 2)):
+        reads = sample_reads(orc, rng, genomes, 300, 100 if k < 31 else 150, paired)
+        rep, nk, st = check(oix, hx, reads, d, S)
+        assert rep[:, :n_colors].sum() > 0
+    hx.close()
+
+
+def test_readid_long_reads_and_empty(orc, phage):
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(5)
+    reads = [[g[s:s + L]] for g in genomes for s, L in ((0, 1000), (2000, 2500), (5000, 27), (7000, 28))]
+    check(oix, hx, reads, 1, 3)
+    check(oix, hx, reads, 4, 0)
+    rep, nk, st = hx.readid_count(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(1, np.uint64))
+    assert rep.shape == (0, 5)
