@@ -48,6 +48,19 @@ def hip_memcpy(dst, src, nbytes, kind):
         raise RuntimeError(f"hipMemcpy failed: {rc}")
 
 
+def profiled_traffic(K, C, m, n, k):
+    """HBM bytes per launch of k_search_count from the committed rocprofv3 --pmc passes (profiles/), if they
+    were taken on this exact workload; None otherwise (PMC counters cannot be read from inside the timed run)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_search_count.json")) as f:
+            pj = json.load(f)
+        if (pj["kmers_per_launch"], pj["n_colors"], pj["bloom_size"], pj["num_hash"], pj["k_size"]) == (K, C, m, n, k):
+            return float(pj["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,7 +241,8 @@ def main():
                        "setup_s": round(t_setup, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_search_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": a.traffic_bytes, "alg_bytes_per_kmer": alg_bytes_per_kmer,
+                         "traffic": a.traffic_bytes if a.traffic_bytes is not None else profiled_traffic(K, C, m, n, k),
+                         "alg_bytes_per_kmer": alg_bytes_per_kmer,
                          "kernel_ms": kern_ms, "kmers_per_launch": K},
         }
         if world == 1 and not a.no_cpu_baseline:
