@@ -32,6 +32,7 @@ SIGNATURES = {
     "cid_index_finalize": (C.c_int, [vp]),
     "cid_index_get_rows": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "cid_index_insert_kmers_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "cid_index_insert_kmers": (C.c_int, [vp, vp, C.c_uint32, C.c_size_t]),
     "cid_index_destroy": (None, [vp]),
     "cid_search_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
     "cid_search_count_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),

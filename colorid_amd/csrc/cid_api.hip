@@ -277,6 +277,26 @@ int cid_index_insert_kmers_dev(cid_index *ix, const uint8_t *d_kmers, const uint
     return CID_OK;
 }
 
+int cid_index_insert_kmers(cid_index *ix, const uint8_t *kmers, uint32_t colour, size_t n_kmers) {
+    if (!ix || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
+    if (colour >= ix->n_colors) return fail(CID_ERR_INVALID, "colour %u >= n_colors", colour);
+    cid_ctx *c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    void *d_k;
+    int rc = slot_reserve(c, S_KMERS, n_kmers * ix->k, &d_k);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
+    cid::InsertParams p{};
+    p.mat = ix->mat; p.rs = ix->rs; p.n_hash = ix->n_hash; p.k = ix->k; p.n_colors = ix->n_colors;
+    p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    p.colour = colour;
+    p.mod = ix->mod; p.kmers = (const uint8_t *)d_k; p.colour_of_kmer = nullptr; p.n_kmers = n_kmers;
+    HIP_TRY(cid::launch_insert_kmers(p, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
+}
+
 void cid_index_destroy(cid_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->ctx->device);

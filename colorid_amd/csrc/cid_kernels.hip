@@ -514,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
         stage_kmers(img, p.kmers, p.n_kmers, first, p.k, lane);
         wave_lds_fence();
         if (first + lane < p.n_kmers) {
-            const uint32_t c = p.colour_of_kmer[first + lane];
+            const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
             if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, [&](uint32_t, uint64_t h) {
                 const uint64_t row = mod_m(h, p.mod);
                 atomicOr(&mat32[row * (2ull * p.rs) + (c >> 5)], 1u << (c & 31u));

@@ -39,6 +39,7 @@ struct InsertParams {
     uint32_t k;
     uint32_t n_colors;
     uint32_t tiles_per_block;
+    uint32_t colour;  // used when colour_of_kmer == nullptr
     ModMagic mod;
     const uint8_t *kmers;
     const uint32_t *colour_of_kmer;

@@ -1,0 +1,199 @@
+// .bxi (bincode 1.x of BigsyMapNew, src/bigsi.rs:19-27 / SURVEY.md App. A) <-> device-resident index,
+// and the index builder (src/build.rs:15-130) with the Bloom inserts done on the GPU.
+#include <algorithm>
+#include <cstring>
+
+#include "colorid_host.hpp"
+
+namespace colorid {
+
+#define CID_TRY(expr)                                                  \
+    do {                                                               \
+        if ((expr) != CID_OK) die("%s: %s", #expr, cid_last_error()); \
+    } while (0)
+
+namespace {
+
+struct BufReader {  // big sequential reads; the file is parsed once, front to back
+    FILE *f;
+    std::vector<uint8_t> buf;
+    size_t pos = 0, end = 0;
+    explicit BufReader(const std::string &path) : f(fopen(path.c_str(), "rb")), buf(64u << 20) {
+        if (!f) die("Can't open index!: %s", path.c_str());
+    }
+    ~BufReader() { fclose(f); }
+    void need(size_t n) {
+        if (end - pos >= n) return;
+        memmove(buf.data(), buf.data() + pos, end - pos);
+        end -= pos;
+        pos = 0;
+        if (n > buf.size()) buf.resize(n);
+        while (end < n) {
+            size_t got = fread(buf.data() + end, 1, buf.size() - end, f);
+            if (got == 0) die("can't deserialize: unexpected end of file");
+            end += got;
+        }
+    }
+    uint64_t u64() {
+        need(8);
+        uint64_t v;
+        memcpy(&v, buf.data() + pos, 8);  // little-endian host
+        pos += 8;
+        return v;
+    }
+    std::string str() {
+        const uint64_t n = u64();
+        if (n > (1u << 30)) die("can't deserialize: string of %llu bytes", (unsigned long long)n);
+        need(n);
+        std::string s(reinterpret_cast<const char *>(buf.data() + pos), n);
+        pos += n;
+        return s;
+    }
+};
+
+void w64(FILE *f, uint64_t v) { fwrite(&v, 8, 1, f); }
+
+}  // namespace
+
+Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only) {
+    BufReader r(path);
+    Bigsi b;
+    b.bloom_size = r.u64();
+    b.num_hash = r.u64();
+    b.k_size = r.u64();
+    const uint64_t nc = r.u64();
+    if (nc == 0 || nc > (1u << 24)) die("can't deserialize: %llu colours", (unsigned long long)nc);
+    b.colors.assign(nc, std::string());
+    for (uint64_t i = 0; i < nc; ++i) {
+        const uint64_t id = r.u64();
+        std::string name = r.str();
+        if (id >= nc) die("can't deserialize: colour id %llu of %llu", (unsigned long long)id, (unsigned long long)nc);
+        b.colors[id] = std::move(name);
+    }
+    const uint32_t w32 = (uint32_t)((nc + 31) / 32);
+    const uint64_t n_rows = r.u64();
+    if (!meta_only)
+        CID_TRY(cid_index_create(ctx, b.bloom_size, (uint32_t)b.num_hash, (uint32_t)b.k_size, (uint32_t)nc, hash_variant, &b.index));
+    const size_t batch = 1u << 22;
+    std::vector<uint64_t> ids;
+    std::vector<uint32_t> words;
+    ids.reserve(batch);
+    words.reserve(batch * w32);
+    for (uint64_t i = 0; i < n_rows; ++i) {  // { u64 row ; u64 W32 ; W32 x u32 ; u64 nbits }
+        r.need(16 + 4ull * w32 + 8);
+        uint64_t row, nw, nbits;
+        memcpy(&row, r.buf.data() + r.pos, 8);
+        memcpy(&nw, r.buf.data() + r.pos + 8, 8);
+        if (nw != w32) die("can't deserialize: row with %llu words, expected %u", (unsigned long long)nw, w32);
+        memcpy(&nbits, r.buf.data() + r.pos + 16 + 4ull * w32, 8);
+        if (nbits != nc) die("can't deserialize: row of %llu bits, expected %llu", (unsigned long long)nbits, (unsigned long long)nc);
+        if (!meta_only) {
+            ids.push_back(row);
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(r.buf.data() + r.pos + 16);
+            words.insert(words.end(), wp, wp + w32);
+            if (ids.size() == batch) {
+                CID_TRY(cid_index_put_rows(b.index, ids.data(), words.data(), ids.size()));
+                ids.clear();
+                words.clear();
+            }
+        }
+        r.pos += 16 + 4ull * w32 + 8;
+    }
+    if (!meta_only && !ids.empty()) CID_TRY(cid_index_put_rows(b.index, ids.data(), words.data(), ids.size()));
+    b.n_ref_kmers.assign(nc, 0);
+    std::map<std::string, uint64_t> by_name;
+    for (uint64_t c = 0; c < nc; ++c) by_name[b.colors[c]] = c;
+    const uint64_t n_ref = r.u64();
+    for (uint64_t i = 0; i < n_ref; ++i) {
+        std::string name = r.str();
+        const uint64_t v = r.u64();
+        auto it = by_name.find(name);
+        if (it != by_name.end()) b.n_ref_kmers[it->second] = v;
+    }
+    if (!meta_only) CID_TRY(cid_index_finalize(b.index));
+    return b;
+}
+
+void save_bigsi(const std::string &path, const Bigsi &b) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) die("problems preparing serialized data for writing: %s", path.c_str());
+    const uint64_t nc = b.colors.size();
+    const uint32_t w32 = (uint32_t)((nc + 31) / 32);
+    w64(f, b.bloom_size); w64(f, b.num_hash); w64(f, b.k_size);
+    w64(f, nc);
+    for (uint64_t c = 0; c < nc; ++c) { w64(f, c); w64(f, b.colors[c].size()); fwrite(b.colors[c].data(), 1, b.colors[c].size(), f); }
+    // rows come back from the device in ascending order; all-zero rows are dropped (build.rs:123-127)
+    const long count_pos = ftell(f);
+    w64(f, 0);
+    uint64_t n_rows = 0;
+    const uint64_t chunk = 1u << 22;
+    std::vector<uint64_t> ids(chunk);
+    std::vector<uint32_t> words(chunk * w32);
+    for (uint64_t r0 = 0; r0 < b.bloom_size; r0 += chunk) {
+        const uint64_t nr = std::min<uint64_t>(chunk, b.bloom_size - r0);
+        for (uint64_t i = 0; i < nr; ++i) ids[i] = r0 + i;
+        CID_TRY(cid_index_get_rows(b.index, ids.data(), words.data(), nr));
+        for (uint64_t i = 0; i < nr; ++i) {
+            const uint32_t *wp = words.data() + i * w32;
+            bool any = false;
+            for (uint32_t w = 0; w < w32; ++w) any |= wp[w] != 0;
+            if (!any) continue;
+            w64(f, r0 + i); w64(f, w32); fwrite(wp, 4, w32, f); w64(f, nc);
+            ++n_rows;
+        }
+    }
+    w64(f, nc);
+    for (uint64_t c = 0; c < nc; ++c) { w64(f, b.colors[c].size()); fwrite(b.colors[c].data(), 1, b.colors[c].size(), f); w64(f, b.n_ref_kmers[c]); }
+    fseek(f, count_pos, SEEK_SET);
+    w64(f, n_rows);
+    fclose(f);
+}
+
+Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
+                   int64_t cutoff, int hash_variant) {
+    // tab_to_map (build.rs:15-31): accession \t file [\t file2]; later lines overwrite earlier ones
+    std::map<std::string, std::vector<std::string>> refs;  // std::map iterates sorted == accessions.sort() (build.rs:105)
+    {
+        LineReader r(ref_tsv);
+        std::string line;
+        while (r.next(line)) {
+            std::vector<std::string> v;
+            size_t p = 0;
+            while (true) {
+                size_t e = line.find('\t', p);
+                v.push_back(line.substr(p, e == std::string::npos ? std::string::npos : e - p));
+                if (e == std::string::npos) break;
+                p = e + 1;
+            }
+            if (v.size() < 2) die("reference file line without a tab: '%s'", line.c_str());
+            refs[v[0]] = v.size() == 2 ? std::vector<std::string>{v[1]} : std::vector<std::string>{v[1], v[2]};
+        }
+    }
+    Bigsi b;
+    b.bloom_size = bloom; b.num_hash = hashes; b.k_size = k;
+    for (auto &kv : refs) b.colors.push_back(kv.first);
+    b.n_ref_kmers.assign(b.colors.size(), 0);
+    CID_TRY(cid_index_create(ctx, bloom, (uint32_t)hashes, (uint32_t)k, (uint32_t)b.colors.size(), hash_variant, &b.index));
+    uint32_t colour = 0, counter = 1;
+    for (auto &kv : refs) {
+        fprintf(stderr, "Adding %s to index (%u/%zu)\n", kv.first.c_str(), counter++, refs.size());
+        KmerMap km((uint32_t)k);
+        const std::vector<std::string> &v = kv.second;
+        auto clean_reads = [&]() {
+            if (cutoff == -1) { const int64_t t = km.auto_cutoff(); if (t < 0) die("auto_cutoff: histogram too short"); km.clean((uint64_t)t); }
+            else km.clean((uint64_t)cutoff);
+        };
+        if (v.size() == 2) { kmers_fq_pe_qual(v[0], v[1], quality, km); clean_reads(); }
+        else if (v[0].size() >= 2 && v[0].compare(v[0].size() - 2, 2, "gz") == 0) { kmers_from_fq_qual(v[0], quality, km); clean_reads(); }
+        else {
+            kmerize_vector(read_fasta(v[0]), 1, km);
+            if (cutoff != -1) km.clean((uint64_t)cutoff);  // build.rs:86-91: FASTA is only cleaned with an explicit -f
+        }
+        b.n_ref_kmers[colour] = km.size();
+        CID_TRY(cid_index_insert_kmers(b.index, km.keys(), colour, km.size()));
+        ++colour;
+    }
+    return b;
+}
+
+}  // namespace colorid

@@ -1,0 +1,94 @@
+// Host side of colorid's query path, C++17, above the C ABI (include/colorid_hip.h).
+// The reference host is Rust (no toolchain in this image); names and argument meaning follow the reference
+// functions cited at each declaration so the call sites read like src/main.rs.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../../include/colorid_hip.h"
+
+namespace colorid {
+
+[[noreturn]] void die(const char *fmt, ...);  // the reference panics (expect/unwrap): message + exit code 101
+
+// ---------------------------------------------------------------- seq.rs / kmer.rs (query side)
+std::vector<std::string> read_fasta(const std::string &path);                                          // kmer.rs:10-45
+void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, std::vector<std::string> &seqs);  // kmer.rs:47-84
+void qual_mask(std::string &seq, const std::string &qual, uint8_t q);                                  // seq.rs:36-56 (in place)
+
+// FnvHashMap<String, usize> of canonical k-mers: packed keys (n * k bytes) + counts.  Iteration order is
+// insertion order (the reference's is arbitrary).
+class KmerMap {
+  public:
+    explicit KmerMap(uint32_t k);
+    uint32_t k() const { return k_; }
+    size_t size() const { return counts_.size(); }
+    const uint8_t *keys() const { return keys_.data(); }
+    const std::vector<uint32_t> &counts() const { return counts_; }
+    void add(const uint8_t *key, uint32_t n = 1);
+    void clean(uint64_t t);          // kmer.rs:826-837: keep count > t
+    int64_t auto_cutoff() const;     // kmer.rs:866-942; -1 where the reference would panic
+  private:
+    void rehash();
+    uint32_t k_;
+    std::vector<uint8_t> keys_;
+    std::vector<uint32_t> counts_;
+    std::vector<uint32_t> table_;  // entry + 1
+};
+void kmerize_vector(const std::vector<std::string> &v, size_t d, KmerMap &out);   // kmer.rs:87-125
+bool kmerize_string(const std::string &l, KmerMap &out);                          // kmer.rs:271-299 (false = None)
+void kmers_from_fq_qual(const std::string &path, uint8_t q, KmerMap &out);        // kmer.rs:461-510
+void kmers_fq_pe_qual(const std::string &p1, const std::string &p2, uint8_t q, KmerMap &out);  // kmer.rs:581-655
+
+// gz/plain line reader with BufRead::lines() semantics (strips \n and \r\n)
+class LineReader {
+  public:
+    explicit LineReader(const std::string &path);
+    ~LineReader();
+    bool next(std::string &line);
+  private:
+    void *gz_;
+    std::vector<char> buf_;
+};
+
+// ---------------------------------------------------------------- bigsi.rs
+struct Bigsi {  // BigsyMapNew minus the map, which lives on the device
+    uint64_t bloom_size = 0, num_hash = 0, k_size = 0;
+    std::vector<std::string> colors;        // colour id -> accession
+    std::vector<uint64_t> n_ref_kmers;      // by colour id
+    cid_index *index = nullptr;
+};
+Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only = false);  // bigsi.rs:59-69
+void save_bigsi(const std::string &path, const Bigsi &b);                                           // bigsi.rs:51-57
+Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
+                   int64_t cutoff, int hash_variant);                                              // build.rs:15-130
+
+// ---------------------------------------------------------------- reports.rs / read_id tail
+double false_prob(double m, double k, double n);                                                     // read_id_mt_pe.rs:695-698
+struct Classification { std::string label; uint64_t count; uint64_t kmer_length; const char *verdict; uint64_t n_top; };
+Classification kmer_poll_plus(const uint32_t *report, uint64_t kmer_length, const Bigsi &b,
+                              const std::vector<double> &fp, double fp_correct);                    // read_id_mt_pe.rs:187-251
+void read_counts_five_fields(const std::string &reads_file, const std::string &prefix);            // reports.rs:98-120
+
+// ---------------------------------------------------------------- drivers (same names as the reference modules)
+namespace perfect_search {
+void batch_search(cid_ctx *, const std::vector<std::string> &files, const Bigsi &b);      // perfect_search.rs:6-60
+void batch_search_mf(cid_ctx *, const std::vector<std::string> &files, const Bigsi &b);   // perfect_search.rs:62-120
+}
+namespace batch_search_pe {
+void batch_search(cid_ctx *, const std::vector<std::string> &files1, const std::vector<std::string> &files2, const Bigsi &b,
+                  int64_t filter, double cov, bool gene_search, uint8_t qual_offset);     // batch_search_pe.rs:9-179
+}
+namespace read_id_mt_pe {
+void per_read_stream_se(cid_ctx *, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct, size_t batch,
+                        const std::string &prefix, uint8_t qual_offset, size_t start_sample);   // read_id_mt_pe.rs:835-951
+void per_read_stream_pe(cid_ctx *, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct, size_t batch,
+                        const std::string &prefix, uint8_t qual_offset, size_t start_sample);   // read_id_mt_pe.rs:701-832
+void stream_fasta(cid_ctx *, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct, size_t batch,
+                  const std::string &prefix, size_t start_sample);                              // read_id_mt_pe.rs:450-569
+}
+
+}  // namespace colorid

@@ -1,0 +1,379 @@
+// The reference's workload drivers with the hot loops replaced by C-ABI calls:
+//   perfect_search::batch_search / batch_search_mf   (src/perfect_search.rs)  -> cid_search_perfect
+//   batch_search_pe::batch_search                    (src/batch_search_pe.rs) -> cid_search_count
+//   read_id_mt_pe::per_read_stream_se/_pe, stream_fasta (src/read_id_mt_pe.rs) -> cid_readid_count
+// plus the CPU-side tails (src/reports.rs, kmer_poll_plus).  stdout/stderr/file formats follow the reference;
+// where the reference iterates a RandomState HashMap, rows come out in ascending colour id.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "colorid_host.hpp"
+
+namespace colorid {
+
+#define CID_TRY(expr)                                                  \
+    do {                                                               \
+        if ((expr) != CID_OK) die("%s: %s", #expr, cid_last_error()); \
+    } while (0)
+
+using Clock = std::chrono::steady_clock;
+static long secs_since(Clock::time_point t0) { return (long)std::chrono::duration_cast<std::chrono::seconds>(Clock::now() - t0).count(); }
+
+// ---------------------------------------------------------------------------------------------- reports.rs
+
+double false_prob(double m, double k, double n) { return std::pow(1.0 - std::pow(M_E, -((k * (n + 0.5)) / (m - 1.0))), k); }
+
+static double binomial_mass(uint64_t n, double p, uint64_t x) {  // probability::Binomial::mass, log-space
+    if (x > n) return 0.0;
+    if (p <= 0.0) return x == 0 ? 1.0 : 0.0;
+    if (p >= 1.0) return x == n ? 1.0 : 0.0;
+    const double lc = std::lgamma((double)n + 1.0) - std::lgamma((double)x + 1.0) - std::lgamma((double)(n - x) + 1.0);
+    return std::exp(lc + (double)x * std::log(p) + (double)(n - x) * std::log1p(-p));
+}
+
+static bool not_fp_significant(uint64_t observations, double p_false, double fp_correct, uint64_t hits) {  // read_id_mt_pe.rs:168-181
+    const double critical = (double)observations * p_false;
+    const double mpf = binomial_mass(observations, p_false, hits);
+    return ((double)hits < critical) || (((double)hits > critical) && (mpf >= fp_correct));
+}
+
+Classification kmer_poll_plus(const uint32_t *report, uint64_t kmer_length, const Bigsi &b, const std::vector<double> &fp,
+                              double fp_correct) {
+    const size_t C = b.colors.size();
+    size_t entries = 0;
+    for (size_t c = 0; c <= C; ++c) entries += report[c] != 0;
+    if (entries == 0 || (entries == 1 && report[C] != 0)) return {"no_hits", 0, kmer_length, "accept", 0};  // :197-205, :332-340
+    uint64_t best = 0, n_sig = 0;
+    std::vector<uint8_t> sig(C, 0);
+    for (size_t c = 0; c < C; ++c) {
+        if (!report[c]) continue;
+        if (not_fp_significant(kmer_length, fp[c], fp_correct, report[c])) continue;
+        sig[c] = 1;
+        ++n_sig;
+        best = std::max<uint64_t>(best, report[c]);
+    }
+    if (n_sig == 0) return {"no_significant_hits", 0, kmer_length, "reject", 0};  // :216-223
+    std::string label;
+    uint64_t n_top = 0;
+    for (size_t c = 0; c < C; ++c)
+        if (sig[c] && report[c] == best) {
+            if (n_top) label += ",";
+            label += b.colors[c];
+            ++n_top;
+        }
+    return {label, best, kmer_length, n_top == 1 ? "accept" : "reject", n_top};
+}
+
+void read_counts_five_fields(const std::string &reads_file, const std::string &prefix) {  // reports.rs:98-120
+    LineReader r(reads_file);
+    std::map<std::string, uint64_t> counts;
+    std::string line;
+    while (r.next(line)) {
+        std::vector<std::string> v;
+        size_t p = 0;
+        while (true) {
+            size_t e = line.find('\t', p);
+            v.push_back(line.substr(p, e == std::string::npos ? std::string::npos : e - p));
+            if (e == std::string::npos) break;
+            p = e + 1;
+        }
+        if (v.size() < 5) die("malformed line in %s", reads_file.c_str());
+        counts[v[4] == "accept" ? v[1] : std::string("reject")] += 1;
+    }
+    FILE *f = fopen((prefix + "_counts.txt").c_str(), "w");
+    if (!f) die("could not create outfile!");
+    for (auto &kv : counts) fprintf(f, "%s\t%llu\n", kv.first.c_str(), (unsigned long long)kv.second);
+    fclose(f);
+}
+
+// reports.rs:8-48: hits / n_ref_kmers > cov -> query, K, accession, cov, mean, mode, n_unique
+static void generate_report(const std::string &query, const Bigsi &b, const std::vector<uint64_t> &hits,
+                            const std::vector<uint64_t> &n_unique, const std::vector<uint64_t> &sum_freq,
+                            const std::vector<uint32_t> &unique_colour, const KmerMap &km, double cov) {
+    const size_t C = b.colors.size();
+    // mode of the unique-hit k-mer frequencies per colour (reports.rs:65-77; ties -> smallest value)
+    std::vector<std::map<uint32_t, uint64_t>> occ(C);
+    for (size_t j = 0; j < km.size(); ++j)
+        if (unique_colour[j] != CID_NOT_UNIQUE) occ[unique_colour[j]][km.counts()[j]] += 1;
+    for (size_t c = 0; c < C; ++c) {
+        if (!hits[c]) continue;
+        double mean = 0.0;
+        uint64_t modus = 0, specific = 0;
+        if (n_unique[c]) {
+            mean = (double)sum_freq[c] / (double)n_unique[c];
+            uint64_t bestc = 0;
+            for (auto &kv : occ[c])
+                if (kv.second > bestc) { bestc = kv.second; modus = kv.first; }
+            specific = n_unique[c];
+        }
+        const double genome_cov = (double)hits[c] / (double)b.n_ref_kmers[c];
+        if (genome_cov > cov)
+            printf("%s\t%zu\t%s\t%.2f\t%.2f\t%llu\t%llu\n", query.c_str(), km.size(), b.colors[c].c_str(), genome_cov, mean,
+                   (unsigned long long)modus, (unsigned long long)specific);
+    }
+}
+
+static void generate_report_gene(const std::string &query, const Bigsi &b, const std::vector<uint64_t> &hits, size_t num_kmers,
+                                 double cov) {  // reports.rs:50-62
+    for (size_t c = 0; c < b.colors.size(); ++c) {
+        if (!hits[c]) continue;
+        const double gene_match = (double)hits[c] / (double)num_kmers;
+        if (gene_match >= cov) printf("%s\t%s\t%zu\t%.3f\n", query.c_str(), b.colors[c].c_str(), num_kmers, gene_match);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- perfect_search.rs
+
+static void perfect_one(cid_ctx *ctx, const Bigsi &b, const std::string &label, const KmerMap &km) {
+    const uint32_t w32 = (uint32_t)((b.colors.size() + 31) / 32);
+    std::vector<uint32_t> words(w32);
+    int missing = 0;
+    CID_TRY(cid_search_perfect(ctx, b.index, km.keys(), km.size(), words.data(), &missing));
+    if (missing) {
+        fprintf(stderr, "No perfect hits!\n");
+        return;
+    }
+    size_t n_hits = 0;
+    for (size_t c = 0; c < b.colors.size(); ++c) n_hits += (words[c / 32] >> (c % 32)) & 1u;
+    fprintf(stderr, "%zu hits\n", n_hits);
+    for (size_t c = 0; c < b.colors.size(); ++c)
+        if ((words[c / 32] >> (c % 32)) & 1u) printf("%s\t%s\t%zu\t1.00\n", label.c_str(), b.colors[c].c_str(), km.size());
+}
+
+void perfect_search::batch_search(cid_ctx *ctx, const std::vector<std::string> &files, const Bigsi &b) {
+    for (const std::string &file : files) {
+        fprintf(stderr, "Counting k-mers, this may take a while!\n");
+        KmerMap km((uint32_t)b.k_size);
+        kmerize_vector(read_fasta(file), 1, km);
+        fprintf(stderr, "%zu kmers in query\n", km.size());
+        if (km.size() == 0) {
+            fprintf(stderr, "Warning! no kmers in query; maybe your kmer length is larger than your query length?\n");
+            continue;
+        }
+        perfect_one(ctx, b, file, km);
+    }
+}
+
+void perfect_search::batch_search_mf(cid_ctx *ctx, const std::vector<std::string> &files, const Bigsi &b) {
+    for (const std::string &file : files) {
+        std::vector<std::string> labels, seqs;
+        read_fasta_mf(file, labels, seqs);
+        for (size_t i = 0; i < labels.size(); ++i) {
+            if (i >= seqs.size()) die("index out of bounds: the len is %zu but the index is %zu", seqs.size(), i);  // sequences[i]
+            KmerMap km((uint32_t)b.k_size);
+            if (!kmerize_string(seqs[i], km)) {
+                printf("Warning! no kmers in query '%s'; maybe your kmer length is larger than your query length?\n", labels[i].c_str());
+                continue;
+            }
+            fprintf(stderr, "%zu kmers in query\n", km.size());
+            perfect_one(ctx, b, labels[i], km);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- batch_search_pe.rs
+
+void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> &files1, const std::vector<std::string> &files2,
+                                   const Bigsi &b, int64_t filter, double cov, bool gene_search, uint8_t qual_offset) {
+    const size_t C = b.colors.size();
+    for (size_t i = 0; i < files1.size(); ++i) {
+        const std::string &file1 = files1[i];
+        KmerMap km((uint32_t)b.k_size);
+        const bool gz = file1.size() >= 2 && file1.compare(file1.size() - 2, 2, "gz") == 0;
+        if (gz) {
+            if (files2.empty()) {
+                fprintf(stderr, "%s\nCounting k-mers, this may take a while!\n", file1.c_str());
+                kmers_from_fq_qual(file1, qual_offset, km);
+            } else {
+                if (i >= files2.size()) die("index out of bounds: the len is %zu but the index is %zu", files2.size(), i);
+                fprintf(stderr, "Paired end: %s %s\nCounting k-mers, this may take a while!\n", file1.c_str(), files2[i].c_str());
+                kmers_fq_pe_qual(file1, files2[i], qual_offset, km);
+            }
+            if (filter < 0) { const int64_t t = km.auto_cutoff(); if (t < 0) die("auto_cutoff: histogram too short"); km.clean((uint64_t)t); }
+            else km.clean((uint64_t)filter);
+        } else {  // anything else is taken to be FASTA (batch_search_pe.rs:106-123)
+            fprintf(stderr, "%s\nCounting k-mers, this may take a while!\n", file1.c_str());
+            kmerize_vector(read_fasta(file1), 1, km);
+            if (gene_search) km.clean(0);
+            else if (filter < 0) {
+                fprintf(stderr, "no gene search\n");
+                const int64_t t = km.auto_cutoff();
+                if (t < 0) die("auto_cutoff: histogram too short");
+                km.clean((uint64_t)t);
+            } else km.clean((uint64_t)filter);
+        }
+        fprintf(stderr, "%zu k-mers in query\n", km.size());
+        const auto t0 = Clock::now();
+        std::vector<uint64_t> hits(C), n_unique(C), sum_freq(C);
+        std::vector<uint32_t> uc(gene_search ? 0 : km.size());
+        CID_TRY(cid_search_count(ctx, b.index, km.keys(), km.counts().data(), km.size(), hits.data(),
+                                 gene_search ? nullptr : n_unique.data(), gene_search ? nullptr : sum_freq.data(),
+                                 gene_search ? nullptr : uc.data()));
+        if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
+        if (!gene_search) generate_report(file1, b, hits, n_unique, sum_freq, uc, km, cov);
+        else generate_report_gene(file1, b, hits, km.size(), cov);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- read_id_mt_pe.rs
+
+namespace {
+
+struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
+    std::vector<std::string> ids;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> seq_off{0};
+    std::vector<uint64_t> read_seq0{0};
+    void push(const std::string &id, const std::string *seqs, size_t n) {
+        ids.push_back(id);
+        for (size_t s = 0; s < n; ++s) {
+            bases.insert(bases.end(), seqs[s].begin(), seqs[s].end());
+            seq_off.push_back(bases.size());
+        }
+        read_seq0.push_back(seq_off.size() - 1);
+    }
+    size_t size() const { return ids.size(); }
+    void clear() { ids.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
+};
+
+// parallel_vec (read_id_mt_pe.rs:282-363): counts on the GPU, poll on the host; returns the number of rows written
+size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, double fp_correct, size_t start_sample,
+                      const std::vector<double> &fp, FILE *out) {
+    const size_t n = rb.size(), C = b.colors.size();
+    if (n == 0) return 0;
+    std::vector<uint32_t> report(n * (C + 1)), nk(n);
+    std::vector<uint8_t> status(n);
+    CID_TRY(cid_readid_count(ctx, b.index, rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1, rb.read_seq0.data(), n,
+                             (uint32_t)d, (uint32_t)start_sample, report.data(), nk.data(), status.data()));
+    for (size_t r = 0; r < n; ++r) {
+        if (status[r] == 1) {
+            fprintf(out, "%s\ttoo_short\t0\t0\taccept\t0\n", rb.ids[r].c_str());
+            continue;
+        }
+        const Classification c = kmer_poll_plus(report.data() + r * (C + 1), nk[r], b, fp, fp_correct);
+        fprintf(out, "%s\t%s\t%llu\t%llu\t%s\t%llu\n", rb.ids[r].c_str(), c.label.c_str(), (unsigned long long)c.count,
+                (unsigned long long)c.kmer_length, c.verdict, (unsigned long long)c.n_top);
+    }
+    rb.clear();
+    return n;
+}
+
+std::vector<double> false_prob_map(const Bigsi &b) {  // read_id_mt_pe.rs:18-38
+    std::vector<double> fp(b.colors.size());
+    for (size_t c = 0; c < fp.size(); ++c) fp[c] = false_prob((double)b.bloom_size, (double)b.num_hash, (double)b.n_ref_kmers[c]);
+    return fp;
+}
+
+}  // namespace
+
+void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
+                                       size_t batch, const std::string &prefix, uint8_t qual_offset, size_t start_sample) {
+    const auto t0 = Clock::now();
+    const std::vector<double> fp = false_prob_map(b);
+    FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
+    if (!out) die("could not create outfile!");
+    LineReader r(fq[0]);
+    ReadBatch rb;
+    std::string line, id, seq;
+    uint64_t line_count = 1, read_count = 0;
+    const uint64_t lines_per_batch = (uint64_t)batch * 4;
+    while (r.next(line)) {
+        if (line_count % 4 == 1) id = line;
+        else if (line_count % 4 == 2) seq = line;
+        else if (line_count % 4 == 0) {
+            qual_mask(seq, line, qual_offset);
+            rb.push(id, &seq, 1);
+        }
+        ++line_count;
+        if (line_count % lines_per_batch == 0) {
+            read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
+            fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
+        }
+    }
+    read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
+    fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
+    fclose(out);
+    fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
+}
+
+void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
+                                       size_t batch, const std::string &prefix, uint8_t qual_offset, size_t start_sample) {
+    const auto t0 = Clock::now();
+    const std::vector<double> fp = false_prob_map(b);
+    FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
+    if (!out) die("could not create outfile!");
+    LineReader r1(fq[0]), r2(fq[1]);
+    ReadBatch rb;
+    std::string l1, l2, id, seqs[2];
+    uint64_t line_count = 1, read_count = 0;
+    const uint64_t lines_per_batch = (uint64_t)batch * 4;
+    while (r1.next(l1)) {
+        const bool has2 = r2.next(l2);
+        if (line_count % 4 == 1) id = l1;
+        else if (line_count % 4 == 2) {
+            if (!has2) break;
+            seqs[0] = l1; seqs[1] = l2;
+        } else if (line_count % 4 == 0) {
+            if (!has2) break;
+            qual_mask(seqs[0], l1, qual_offset);
+            qual_mask(seqs[1], l2, qual_offset);
+            rb.push(id, seqs, 2);
+        }
+        ++line_count;
+        if (line_count % lines_per_batch == 0) {
+            read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
+            fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
+        }
+    }
+    read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
+    fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
+    fclose(out);
+    fprintf(stderr, "Classified %llu read pairs in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
+}
+
+void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
+                                 size_t batch, const std::string &prefix, size_t start_sample) {
+    // read_line() keeps the '\n' inside the sequence (k-mers across a line break fail has_no_n); ids keep the '>'
+    const auto t0 = Clock::now();
+    const std::vector<double> fp = false_prob_map(b);
+    FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
+    if (!out) die("could not create outfile!");
+    FILE *f = fopen(fq[0].c_str(), "rb");
+    if (!f) die("file not found: %s", fq[0].c_str());
+    ReadBatch rb;
+    std::string sub, id, l;
+    uint64_t count = 0, read_count = 0;
+    char *lineptr = nullptr;
+    size_t cap = 0;
+    ssize_t got;
+    while ((got = getline(&lineptr, &cap, f)) > 0) {
+        l.assign(lineptr, (size_t)got);
+        if (count == 0) {
+            id = l.substr(0, l.size() - 1);
+        } else if (l.find('>') != std::string::npos) {
+            if (!sub.empty()) {
+                rb.push(id, &sub, 1);
+                id = l.substr(0, l.size() - 1);
+                sub.clear();
+            }
+        } else {
+            sub += l;
+        }
+        ++count;
+        if (rb.size() > 0 && rb.size() % batch == 0) {
+            read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
+            fprintf(stderr, " %llu reads classified\r", (unsigned long long)read_count);
+        }
+    }
+    free(lineptr);
+    fclose(f);
+    rb.push(id, &sub, 1);
+    read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
+    fprintf(stderr, " %llu reads classified\r", (unsigned long long)read_count);
+    fclose(out);
+    fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
+}
+
+}  // namespace colorid

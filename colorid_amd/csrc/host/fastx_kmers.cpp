@@ -1,0 +1,299 @@
+// Sequence input and canonical k-mer counting on the host (src/seq.rs, the query-side functions of src/kmer.rs).
+// This is host staging for the GPU path: the reference counts k-mers on the CPU too (String keys + FNV);
+// here keys live packed in one arena and are hashed 8 bytes at a time.
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+#include "colorid_host.hpp"
+
+namespace colorid {
+
+void die(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "colorid: ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    exit(101);  // a Rust panic exits with 101
+}
+
+// ---------------------------------------------------------------------------------------------- files
+
+static std::string slurp(const std::string &path, const char *what) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) die("%s: %s", what, path.c_str());
+    std::string s;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    fclose(f);
+    return s;
+}
+
+// str::lines(): split at \n, drop one trailing \r, no empty line after a final \n
+template <typename F>
+static void for_each_line(const std::string &c, F &&fn) {
+    size_t pos = 0, n = c.size();
+    while (pos < n) {
+        size_t e = c.find('\n', pos);
+        size_t next = e == std::string::npos ? n : e + 1;
+        if (e == std::string::npos) e = n;
+        size_t le = e;
+        if (le > pos && c[le - 1] == '\r') --le;
+        fn(c.data() + pos, le - pos);
+        pos = next;
+    }
+}
+
+static void read_fasta_impl(const std::string &path, std::vector<std::string> *labels, std::vector<std::string> &seqs) {
+    const std::string c = slurp(path, "file not found");
+    size_t n_lines = 0;
+    for_each_line(c, [&](const char *, size_t) { ++n_lines; });
+    std::string sub;
+    size_t count = 0;
+    for_each_line(c, [&](const char *p, size_t len) {
+        ++count;
+        if (memchr(p, '>', len)) {  // any line containing '>' is a header (kmer.rs:26)
+            if (labels) labels->emplace_back(len ? p + 1 : p, len ? len - 1 : 0);  // line[1..]
+            if (!sub.empty()) seqs.push_back(sub);
+            sub.clear();
+        } else if (count == n_lines) {
+            sub.append(p, len);
+            if (!sub.empty()) seqs.push_back(sub);
+        } else {
+            sub.append(p, len);
+        }
+    });
+}
+
+std::vector<std::string> read_fasta(const std::string &path) {
+    std::vector<std::string> v;
+    read_fasta_impl(path, nullptr, v);
+    return v;
+}
+void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, std::vector<std::string> &seqs) {
+    read_fasta_impl(path, &labels, seqs);
+}
+
+LineReader::LineReader(const std::string &path) : buf_(1 << 16) {
+    gzFile f = gzopen(path.c_str(), "rb");  // transparently reads plain files too; multi-member gzip like MultiGzDecoder
+    if (!f) die("file not found: %s", path.c_str());
+    gzbuffer(f, 1 << 20);
+    gz_ = f;
+}
+LineReader::~LineReader() {
+    if (gz_) gzclose(static_cast<gzFile>(gz_));
+}
+bool LineReader::next(std::string &line) {
+    line.clear();
+    bool got = false;
+    while (gzgets(static_cast<gzFile>(gz_), buf_.data(), (int)buf_.size())) {
+        got = true;
+        size_t l = strlen(buf_.data());
+        line.append(buf_.data(), l);
+        if (l && buf_[l - 1] == '\n') break;
+    }
+    if (!got) return false;
+    if (!line.empty() && line.back() == '\n') line.pop_back();
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    return true;
+}
+
+void qual_mask(std::string &seq, const std::string &qual, uint8_t q) {
+    if (q == 0) return;
+    // the reference walks qual.chars() and takes one base per quality char: output length = qual length
+    if (seq.size() < qual.size()) die("ERROR: could not get the next nt in the sequence");
+    seq.resize(qual.size());
+    const uint8_t max_quality = (uint8_t)(q + 33);
+    for (size_t i = 0; i < qual.size(); ++i)
+        if ((uint8_t)qual[i] < max_quality) seq[i] = 'N';
+}
+
+// ---------------------------------------------------------------------------------------------- KmerMap
+
+static inline uint64_t key_hash(const uint8_t *p, uint32_t k) {
+    uint64_t h = 0x9E3779B185EBCA87ULL ^ k;
+    uint32_t i = 0;
+    for (; i + 8 <= k; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0xC2B2AE3D27D4EB4FULL;
+        h ^= h >> 29;
+    }
+    uint64_t w = 0;
+    if (i < k) memcpy(&w, p + i, k - i);
+    h = (h ^ w) * 0x165667B19E3779F9ULL;
+    return h ^ (h >> 32);
+}
+
+KmerMap::KmerMap(uint32_t k) : k_(k), table_(1 << 16, 0) {}
+
+void KmerMap::rehash() {
+    std::vector<uint32_t> t(table_.size() * 2, 0);
+    const size_t mask = t.size() - 1;
+    for (size_t e = 0; e < counts_.size(); ++e) {
+        size_t h = key_hash(keys_.data() + e * k_, k_) & mask;
+        while (t[h]) h = (h + 1) & mask;
+        t[h] = (uint32_t)e + 1;
+    }
+    table_.swap(t);
+}
+
+void KmerMap::add(const uint8_t *key, uint32_t n) {
+    size_t mask = table_.size() - 1;
+    size_t h = key_hash(key, k_) & mask;
+    while (table_[h]) {
+        const size_t e = table_[h] - 1;
+        if (memcmp(keys_.data() + e * k_, key, k_) == 0) {
+            if (counts_[e] > UINT32_MAX - n) die("k-mer multiplicity overflows 32 bits");
+            counts_[e] += n;
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+    if (counts_.size() >= UINT32_MAX - 1) die("more than 2^32 distinct k-mers in one query");
+    keys_.insert(keys_.end(), key, key + k_);
+    counts_.push_back(n);
+    table_[h] = (uint32_t)counts_.size();
+    if (counts_.size() * 2 > table_.size()) rehash();
+}
+
+void KmerMap::clean(uint64_t t) {
+    size_t w = 0;
+    for (size_t e = 0; e < counts_.size(); ++e) {
+        if (counts_[e] > t) {
+            if (w != e) {
+                memmove(keys_.data() + w * k_, keys_.data() + e * k_, k_);
+                counts_[w] = counts_[e];
+            }
+            ++w;
+        }
+    }
+    counts_.resize(w);
+    keys_.resize(w * k_);
+    std::fill(table_.begin(), table_.end(), 0);
+    const size_t mask = table_.size() - 1;
+    for (size_t e = 0; e < w; ++e) {
+        size_t h = key_hash(keys_.data() + e * k_, k_) & mask;
+        while (table_[h]) h = (h + 1) & mask;
+        table_[h] = (uint32_t)e + 1;
+    }
+}
+
+int64_t KmerMap::auto_cutoff() const {  // kmer.rs:866-942, panics reported as -1
+    uint64_t max_cov = 0;
+    for (uint32_t c : counts_) max_cov = c > max_cov ? c : max_cov;
+    std::vector<uint64_t> histo(max_cov + 2, 0);
+    for (uint32_t c : counts_) histo[c]++;
+    uint64_t sum = 0;
+    for (uint64_t i = 0; i <= max_cov; ++i) sum += i * histo[i];
+    const double total_mean = (double)sum / (double)counts_.size();
+    if (total_mean < 1.5) return 0;
+    const size_t ncov = max_cov >= 1 ? (size_t)(max_cov - 1) : 0;  // coverages[j] = histo[j+1], j < max_cov-1
+    if (ncov == 0) return -1;
+    const uint64_t *cov = histo.data() + 1;
+    const size_t nd1 = ncov >= 2 ? ncov - 2 : 0;
+    if (nd1 == 0) return -1;
+    std::vector<double> d1(nd1);
+    for (size_t i = 1; i + 1 < ncov; ++i) d1[i - 1] = (double)cov[i] / (double)cov[i + 1];
+    size_t first_d1 = 0, first_d2 = 0;
+    for (size_t i = 0; i < nd1; ++i)
+        if (d1[i] < 1.0) { first_d1 = i + 1; break; }
+    for (size_t i = 0; i + 1 < nd1; ++i)
+        if (d1[i] / d1[i + 1] < 1.0) { first_d2 = i + 1; break; }
+    uint64_t bigsum = 0, num = 0;
+    for (size_t i = 0; i + 1 < ncov; ++i) { bigsum += (uint64_t)i * cov[1 + i]; num += cov[1 + i]; }
+    const double mean = (double)bigsum / (double)num;
+    if (first_d1 > 0 && (double)first_d1 < mean * 0.75) return (int64_t)first_d1;
+    if (first_d2 > 0) return (int64_t)first_d2;
+    const double c = std::ceil(mean / 2.0);
+    const uint64_t cu = (c != c || c <= 0.0) ? 0 : (uint64_t)c;
+    return (int64_t)(cu > 1 ? cu : 1);
+}
+
+// ---------------------------------------------------------------------------------------------- window walk
+
+static inline bool good_base(uint8_t c) {
+    const uint8_t u = c & 0xDF;
+    return u == 'A' || u == 'C' || u == 'G' || u == 'T';
+}
+static inline uint8_t switch_base(uint8_t c) {  // kmer.rs:847-863
+    switch (c) {
+    case 'a': return 't'; case 'c': return 'g'; case 't': return 'a'; case 'g': return 'c';
+    case 'u': return 'a'; case 'n': return 'n';
+    case 'A': return 'T'; case 'C': return 'G'; case 'T': return 'A'; case 'G': return 'C';
+    case 'U': return 'A'; case 'N': return 'N';
+    default: return 'N';
+    }
+}
+
+// One string: windows i = 0, d, 2d...; keep iff (no filter or all k bases in ACGTacgt); choose fwd < rc ? fwd : rc on
+// the raw bytes; optionally upper-case the chosen string (FASTA paths), then count it.
+static void walk(const uint8_t *l, size_t len, size_t d, bool filter_n, bool upper, KmerMap &out) {
+    const size_t k = out.k();
+    if (len < k) return;
+    std::vector<uint8_t> rcbuf(len), tmp(k);
+    for (size_t i = 0; i < len; ++i) rcbuf[i] = switch_base(l[len - 1 - i]);
+    // bad[i] = number of non-ACGT bases in l[0..i)
+    std::vector<uint32_t> bad(len + 1, 0);
+    for (size_t i = 0; i < len; ++i) bad[i + 1] = bad[i] + (good_base(l[i]) ? 0u : 1u);
+    for (size_t i = 0; i + k <= len; i += d) {
+        if (filter_n && bad[i + k] != bad[i]) continue;
+        const uint8_t *fwd = l + i, *rc = rcbuf.data() + (len - (i + k));
+        const uint8_t *pick = memcmp(fwd, rc, k) < 0 ? fwd : rc;
+        if (upper) {
+            for (size_t t = 0; t < k; ++t) tmp[t] = (pick[t] >= 'a' && pick[t] <= 'z') ? (uint8_t)(pick[t] - 32) : pick[t];
+            out.add(tmp.data());
+        } else {
+            out.add(pick);
+        }
+    }
+}
+
+void kmerize_vector(const std::vector<std::string> &v, size_t d, KmerMap &out) {
+    for (const std::string &l : v) walk(reinterpret_cast<const uint8_t *>(l.data()), l.size(), d, true, true, out);
+}
+
+bool kmerize_string(const std::string &l, KmerMap &out) {
+    if (l.size() < out.k()) return false;
+    walk(reinterpret_cast<const uint8_t *>(l.data()), l.size(), 1, false, true, out);
+    return true;
+}
+
+void kmers_from_fq_qual(const std::string &path, uint8_t q, KmerMap &out) {
+    LineReader r(path);
+    std::string line, seq;
+    uint64_t line_count = 1;
+    while (r.next(line)) {
+        if (line_count % 4 == 2) seq = line;
+        else if (line_count % 4 == 0) {
+            qual_mask(seq, line, q);
+            walk(reinterpret_cast<const uint8_t *>(seq.data()), seq.size(), 1, true, false, out);
+        }
+        ++line_count;
+    }
+}
+
+void kmers_fq_pe_qual(const std::string &p1, const std::string &p2, uint8_t q, KmerMap &out) {
+    LineReader r1(p1), r2(p2);
+    std::string l1, l2, s1, s2;
+    uint64_t line_count = 1;
+    while (r1.next(l1)) {
+        if (!r2.next(l2)) break;
+        if (line_count % 4 == 2) { s1 = l1; s2 = l2; }
+        else if (line_count % 4 == 0) {
+            qual_mask(s1, l1, q);
+            qual_mask(s2, l2, q);
+            walk(reinterpret_cast<const uint8_t *>(s1.data()), s1.size(), 1, true, false, out);
+            walk(reinterpret_cast<const uint8_t *>(s2.data()), s2.size(), 1, true, false, out);
+        }
+        ++line_count;
+    }
+}
+
+}  // namespace colorid

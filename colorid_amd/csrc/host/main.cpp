@@ -1,0 +1,234 @@
+// `colorid` command line: the reference's drop-in surface for the query path (src/main.rs) —
+//   search  (src/main.rs:127-217, :555-628)   read_id (:241-328, :704-868)
+//   build   (:31-126, :466-554; needed to produce .bxi files)   info (:218-240, :630-703)
+// Same flag letters, defaults, stdout/stderr/file formats.  Extra flags: --device N, --hash xxh3_v08.
+// Not provided (outside the accelerated path): batch_id, read_filter, .mxi minimizer indices.
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "colorid_host.hpp"
+
+using namespace colorid;
+
+namespace {
+
+struct Args {
+    std::map<std::string, std::vector<std::string>> values;  // canonical long name -> values
+    std::map<std::string, bool> flags;
+    bool has(const std::string &k) const { return values.count(k) && !values.at(k).empty(); }
+    const std::string &one(const std::string &k) const { return values.at(k)[0]; }
+};
+
+struct OptSpec { char shrt; const char *lng; bool takes_value; bool multi; };
+
+Args parse(int argc, char **argv, int first, const std::vector<OptSpec> &spec) {
+    Args a;
+    for (int i = first; i < argc; ++i) {
+        std::string tok = argv[i];
+        const OptSpec *o = nullptr;
+        if (tok.size() > 2 && tok[0] == '-' && tok[1] == '-') {
+            for (auto &s : spec) if (tok.substr(2) == s.lng) o = &s;
+        } else if (tok.size() == 2 && tok[0] == '-') {
+            for (auto &s : spec) if (s.shrt == tok[1]) o = &s;
+        }
+        if (!o) die("error: Found argument '%s' which wasn't expected, or isn't valid in this context", tok.c_str());
+        if (!o->takes_value) { a.flags[o->lng] = true; continue; }
+        if (i + 1 >= argc) die("error: The argument '--%s' requires a value but none was supplied", o->lng);
+        a.values[o->lng].push_back(argv[++i]);
+        while (o->multi && i + 1 < argc && argv[i + 1][0] != '-') a.values[o->lng].push_back(argv[++i]);
+    }
+    return a;
+}
+
+template <typename T>
+T num_or(const Args &a, const char *k, T dflt) {  // value_t!(..).unwrap_or(dflt): a value that does not parse gives the default
+    if (!a.has(k)) return dflt;
+    char *end = nullptr;
+    const std::string &s = a.one(k);
+    if constexpr (std::is_floating_point<T>::value) {
+        const double v = strtod(s.c_str(), &end);
+        return (end && *end == 0 && !s.empty()) ? (T)v : dflt;
+    } else {
+        const long long v = strtoll(s.c_str(), &end, 10);
+        return (end && *end == 0 && !s.empty()) ? (T)v : dflt;
+    }
+}
+
+bool ends_with(const std::string &s, const char *suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+cid_ctx *make_ctx(const Args &a) {
+    cid_ctx *ctx = nullptr;
+    const int dev = num_or<int>(a, "device", 0);
+    if (cid_ctx_create(dev, &ctx) != CID_OK) die("cannot open GPU %d: %s (colorid has no CPU search path)", dev, cid_last_error());
+    return ctx;
+}
+
+int hash_variant(const Args &a) {
+    if (!a.has("hash") || a.one("hash") == "xxh3_v08") return CID_HASH_XXH3_V08;
+    die("unknown --hash '%s' (available: xxh3_v08)", a.one("hash").c_str());
+}
+
+Bigsi load_index(cid_ctx *ctx, const Args &a, bool meta_only = false) {
+    const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "Loading index\n");
+    Bigsi b = read_bigsi(ctx, a.one("bigsi"), hash_variant(a), meta_only);
+    fprintf(stderr, "Index loaded in %ld seconds\n",
+            (long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count());
+    return b;
+}
+
+const std::vector<OptSpec> kCommon = {{0, "device", true, false}, {0, "hash", true, false}};
+
+std::vector<OptSpec> with_common(std::vector<OptSpec> v) {
+    v.insert(v.end(), kCommon.begin(), kCommon.end());
+    return v;
+}
+
+int cmd_build(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'r', "refs", true, false}, {'k', "kmer", true, false},
+                                                     {'n', "num_hashes", true, false}, {'s', "bloom", true, false}, {'m', "minimizer", false, false},
+                                                     {'v', "value", true, false}, {'t', "threads", true, false}, {'Q', "quality", true, false},
+                                                     {'f', "filter", true, false}}));
+    for (const char *req : {"bigsi", "refs", "kmer", "num_hashes", "bloom"})
+        if (!a.has(req)) die("error: The following required arguments were not provided: --%s", req);
+    printf(" Ref_file : %s\n Bigsi file : %s\nK-mer size: %s\nBloom filter parameters: num hashes %s, filter size %s\n",
+           a.one("refs").c_str(), a.one("bigsi").c_str(), a.one("kmer").c_str(), a.one("num_hashes").c_str(), a.one("bloom").c_str());
+    if (a.flags.count("minimizer")) die("minimizer (.mxi) indices are outside the accelerated path");
+    cid_ctx *ctx = make_ctx(a);
+    Bigsi b = build_single(ctx, a.one("refs"), num_or<uint64_t>(a, "bloom", 50000000), num_or<uint64_t>(a, "num_hashes", 4),
+                           num_or<uint64_t>(a, "kmer", 31), num_or<uint8_t>(a, "quality", 15), num_or<int64_t>(a, "filter", -1),
+                           hash_variant(a));
+    printf("Saving BIGSI to file.\n");
+    save_bigsi(a.one("bigsi") + ".bxi", b);
+    cid_index_destroy(b.index);
+    cid_ctx_destroy(ctx);
+    return 0;
+}
+
+int cmd_search(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'q', "query", true, true}, {'r', "reverse", true, true},
+                                                     {'f', "filter", true, false}, {'p', "p_shared", true, false}, {'g', "gene_search", false, false},
+                                                     {'s', "perfect_search", false, false}, {'m', "multi_fasta", false, false},
+                                                     {'Q', "quality", true, false}}));
+    for (const char *req : {"bigsi", "query"})
+        if (!a.has(req)) die("error: The following required arguments were not provided: --%s", req);
+    const std::vector<std::string> files1 = a.values.at("query");
+    const std::vector<std::string> files2 = a.has("reverse") && a.one("reverse") != "none" ? a.values.at("reverse") : std::vector<std::string>{};
+    const int64_t filter = num_or<int64_t>(a, "filter", -1);
+    const double cov = num_or<double>(a, "p_shared", 0.35);
+    const uint8_t quality = num_or<uint8_t>(a, "quality", 15);
+    if (ends_with(a.one("bigsi"), ".mxi")) {
+        fprintf(stderr, "Error: An index with minimizers (.mxi) is used, but not available for this function\n");
+        return 0;
+    }
+    cid_ctx *ctx = make_ctx(a);
+    Bigsi b = load_index(ctx, a);
+    if (a.flags.count("perfect_search")) {
+        if (a.flags.count("multi_fasta")) perfect_search::batch_search_mf(ctx, files1, b);
+        else perfect_search::batch_search(ctx, files1, b);
+    } else {
+        batch_search_pe::batch_search(ctx, files1, files2, b, filter, cov, a.flags.count("gene_search") > 0, quality);
+    }
+    cid_index_destroy(b.index);
+    cid_ctx_destroy(ctx);
+    return 0;
+}
+
+int cmd_info(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'c', "compressed", true, false}}));
+    if (!a.has("bigsi")) die("error: The following required arguments were not provided: --bigsi");
+    if (ends_with(a.one("bigsi"), ".mxi")) die("minimizer (.mxi) indices are outside the accelerated path");
+    Bigsi b = load_index(nullptr, a, /*meta_only=*/true);
+    printf("BIGSI parameters:\nBloomfilter-size: %llu\nNumber of hashes: %llu\nK-mer size: %llu\n", (unsigned long long)b.bloom_size,
+           (unsigned long long)b.num_hash, (unsigned long long)b.k_size);
+    printf("Number of accessions in index: %zu\n", b.colors.size());
+    for (size_t c = 0; c < b.colors.size(); ++c)  // colour ids are already in sorted-name order
+        printf("%s %llu %.3f\n", b.colors[c].c_str(), (unsigned long long)b.n_ref_kmers[c],
+               false_prob((double)b.bloom_size, (double)b.num_hash, (double)b.n_ref_kmers[c]));
+    return 0;
+}
+
+int cmd_read_id(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'q', "query", true, true}, {'c', "batch", true, false},
+                                                     {'t', "threads", true, false}, {'n', "prefix", true, false}, {'d', "down_sample", true, false},
+                                                     {'H', "high_mem_load", false, false}, {'p', "fp_correct", true, false},
+                                                     {'Q', "quality", true, false}, {'B', "bitvector_sample", true, false}}));
+    for (const char *req : {"bigsi", "query", "prefix"})
+        if (!a.has(req)) die("error: The following required arguments were not provided: --%s", req);
+    const std::vector<std::string> fq = a.values.at("query");
+    const size_t down_sample = num_or<size_t>(a, "down_sample", 1);
+    const double fp_correct = std::pow(10.0, -num_or<double>(a, "fp_correct", 3.0));
+    const uint8_t quality = num_or<uint8_t>(a, "quality", 15);
+    const size_t batch = num_or<size_t>(a, "batch", 50000);
+    const size_t bitvector_sample = num_or<size_t>(a, "bitvector_sample", 3);
+    const std::string prefix = a.one("prefix");
+    if (ends_with(a.one("bigsi"), ".mxi")) die("minimizer (.mxi) indices are outside the accelerated path");
+    if (down_sample == 0 || batch == 0) die("attempt to calculate the remainder with a divisor of zero");
+    cid_ctx *ctx = make_ctx(a);
+    Bigsi b = load_index(ctx, a);
+    if (ends_with(fq[0], ".gz")) {
+        if (fq.size() > 1) read_id_mt_pe::per_read_stream_pe(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
+        else read_id_mt_pe::per_read_stream_se(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
+    } else {
+        read_id_mt_pe::stream_fasta(ctx, fq, b, down_sample, fp_correct, batch, prefix, bitvector_sample);
+    }
+    read_counts_five_fields(prefix + "_reads.txt", prefix);
+    cid_index_destroy(b.index);
+    cid_ctx_destroy(ctx);
+    return 0;
+}
+
+// host-only helper used by the CPU tests: distinct canonical k-mers of a file as "kmer\tcount" lines (insertion order)
+int cmd_debug_kmers(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, {{'q', "query", true, true}, {'k', "kmer", true, false}, {0, "mode", true, false},
+                                         {'Q', "quality", true, false}, {'f', "filter", true, false}});
+    KmerMap km(num_or<uint32_t>(a, "kmer", 31));
+    const std::string mode = a.has("mode") ? a.one("mode") : "vector";
+    const std::vector<std::string> q = a.values.at("query");
+    if (mode == "vector") kmerize_vector(read_fasta(q[0]), 1, km);
+    else if (mode == "fq") kmers_from_fq_qual(q[0], num_or<uint8_t>(a, "quality", 15), km);
+    else if (mode == "fqpe") kmers_fq_pe_qual(q[0], q[1], num_or<uint8_t>(a, "quality", 15), km);
+    else if (mode == "mf") {
+        std::vector<std::string> labels, seqs;
+        read_fasta_mf(q[0], labels, seqs);
+        for (size_t i = 0; i < labels.size() && i < seqs.size(); ++i) {
+            KmerMap one(km.k());
+            printf(">%s\t%d\n", labels[i].c_str(), kmerize_string(seqs[i], one) ? (int)one.size() : -1);
+        }
+        return 0;
+    } else die("unknown mode");
+    if (a.has("filter")) {
+        const int64_t f = num_or<int64_t>(a, "filter", 0);
+        if (f < 0) { const int64_t t = km.auto_cutoff(); printf("#auto_cutoff\t%lld\n", (long long)t); if (t >= 0) km.clean((uint64_t)t); }
+        else km.clean((uint64_t)f);
+    }
+    for (size_t e = 0; e < km.size(); ++e) {
+        fwrite(km.keys() + e * km.k(), 1, km.k(), stdout);
+        printf("\t%u\n", km.counts()[e]);
+    }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    // src/main.rs:16-20: init_log() prints this banner on stdout before anything else
+    printf("\n ************** initializing logger *****************\n\n");
+    if (argc < 2) {
+        fprintf(stderr, "colorid 0.1.4.3 (MI355X)\nUSAGE:\n    colorid <build|search|info|read_id> [FLAGS]\n");
+        return 1;
+    }
+    const std::string cmd = argv[1];
+    if (cmd == "build") return cmd_build(argc, argv);
+    if (cmd == "search") return cmd_search(argc, argv);
+    if (cmd == "info") return cmd_info(argc, argv);
+    if (cmd == "read_id") return cmd_read_id(argc, argv);
+    if (cmd == "debug-kmers") return cmd_debug_kmers(argc, argv);
+    if (cmd == "batch_id" || cmd == "read_filter") die("'%s' is outside the accelerated query path; use the reference binary", cmd.c_str());
+    die("error: Found argument '%s' which wasn't expected", cmd.c_str());
+}

@@ -74,6 +74,9 @@ int cid_index_get_rows(const cid_index *, const uint64_t *row_ids, uint32_t *wor
  * indices without leaving HBM; src/build.rs:116-128 transposed on the fly).  Before finalize only. */
 int cid_index_insert_kmers_dev(cid_index *, const uint8_t *d_kmers, const uint32_t *d_colour_of_kmer,
                                size_t n_kmers);
+/* Host-buffer form: every k-mer goes into one colour — one accession's BloomFilter::insert loop
+ * (src/build.rs:62-66, :93-97). */
+int cid_index_insert_kmers(cid_index *, const uint8_t *kmers, uint32_t colour, size_t n_kmers);
 void cid_index_destroy(cid_index *);
 
 /* ---- a5: proportional search, the hot loop of batch_search_pe::batch_search

@@ -298,6 +298,9 @@ orc_kmers *orc_kmers_from_fq_qual(const char *path, uint32_t k, uint8_t q) { /* 
         else if (line_count % 4 == 0) {
             /* qual_mask walks qual.chars() and consumes seq chars: output length = qual length */
             size_t l = line.len <= seq.len ? line.len : seq.len;
+            if (q == 0) {  /* qual_mask returns seq unchanged, whatever the quality string's length */
+                if (seq.len >= m->k) walk_windows(m, (const uint8_t *)seq.p, seq.len, 1, 1, 0);
+            } else
             orc_kmerize_fq_read(m, (const uint8_t *)seq.p, (const uint8_t *)line.p, l, q);
         }
         ++line_count;
@@ -319,8 +322,13 @@ orc_kmers *orc_kmers_fq_pe_qual(const char *p1, const char *p2, uint32_t k, uint
             s2.len = 0; sbuf_add(&s2, l2.p ? l2.p : "", l2.len);
         } else if (line_count % 4 == 0) {
             size_t a = l1.len <= s1.len ? l1.len : s1.len, b = l2.len <= s2.len ? l2.len : s2.len;
+            if (q == 0) {
+                if (s1.len >= m->k) walk_windows(m, (const uint8_t *)s1.p, s1.len, 1, 1, 0);
+                if (s2.len >= m->k) walk_windows(m, (const uint8_t *)s2.p, s2.len, 1, 1, 0);
+            } else {
             orc_kmerize_fq_read(m, (const uint8_t *)s1.p, (const uint8_t *)l1.p, a, q);
             orc_kmerize_fq_read(m, (const uint8_t *)s2.p, (const uint8_t *)l2.p, b, q);
+            }
         }
         ++line_count;
     }

@@ -1,0 +1,206 @@
+"""The C++ `colorid` CLI (the reference's drop-in surface) end to end on the GPU, against output composed from the
+oracle's restatement of the same reference functions: build -> .bxi bytes, search -s / -s -m / default / -g on FASTA and
+fastq.gz (SE, PE), read_id on fastq.gz SE/PE and FASTA.  Row ORDER is unspecified in the reference (RandomState
+HashMap), so multi-row outputs are compared as sorted lists."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_gpu_readid import pack_reads
+from util import synth_fastq_records, write_fastq_gz
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+BIN = os.path.join(ROOT, "colorid_amd", "bin", "colorid")
+REFS = os.path.join(HERE, "golden", "refs")
+PHAGES = ["Listeria_phage_B021", "Listeria_phage_B051", "Listeria_phage_B056", "Listeria_phage_B545"]
+BANNER = "\n ************** initializing logger *****************\n\n"
+
+
+def run(*args, cwd=None):
+    p = subprocess.run([BIN, *args], capture_output=True, text=True, cwd=cwd)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.startswith(BANNER)
+    return p.stdout[len(BANNER):], p.stderr
+
+
+@pytest.fixture(scope="module")
+def env(orc, tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    tsv = d / "ref_file.txt"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in reversed(PHAGES)))
+    # test.sh:3: build -s 750000 -n 4 -k 27
+    out, err = run("build", "-s", "750000", "-n", "4", "-k", "27", "-b", str(d / "phage"), "-r", str(tsv))
+    assert "Saving BIGSI to file." in out and "Adding Listeria_phage_B021 to index (1/4)" in err
+    oix = orc.Index.build_single(str(tsv), 750000, 4, 27)
+    genomes = [b"".join(orc.read_fasta(os.path.join(REFS, n + ".fasta"))) for n in PHAGES]
+    return d, str(d / "phage.bxi"), oix, genomes
+
+
+def test_build_writes_identical_bxi(env, tmp_path):
+    d, bxi, oix, _ = env
+    ref = str(tmp_path / "oracle.bxi")
+    oix.save(ref)
+    assert open(bxi, "rb").read() == open(ref, "rb").read()
+
+
+def test_search_perfect(orc, env):
+    d, bxi, oix, _ = env
+    q = os.path.join(REFS, "Listeria_phage_B056.fasta")
+    out, err = run("search", "-b", bxi, "-q", q, "-s")
+    km = orc.Kmers(27)
+    for s in orc.read_fasta(q):
+        km.kmerize_vector(s, 1)
+    words, missing = oix.search_perfect(km.keys())
+    assert not missing
+    want = [f"{q}\t{oix.colors()[c]}\t{len(km)}\t1.00" for c in range(4) if words[0] >> c & 1]
+    assert out.splitlines() == want and want == [f"{q}\tListeria_phage_B056\t32634\t1.00"]
+    assert "32634 kmers in query" in err and "1 hits" in err
+    # a query that is not in the index: absent rows -> "No perfect hits!" and no rows (perfect_search.rs:38-39)
+    rnd = d / "random.fasta"
+    rng = np.random.default_rng(1)
+    rnd.write_bytes(b">r\n" + np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 500)].tobytes() + b"\n")
+    out, err = run("search", "-b", bxi, "-q", str(rnd), "-s")
+    assert out == "" and "No perfect hits!" in err
+
+
+def test_search_perfect_multifasta(orc, env):
+    d, bxi, oix, _ = env
+    q = os.path.join(REFS, "Listeria_phage_B021.fasta")
+    out, err = run("search", "-b", bxi, "-q", q, "-s", "-m")
+    labels, seqs = orc.read_fasta_mf(q)
+    want = []
+    for lab, s in zip(labels, seqs):
+        km = orc.Kmers(27)
+        if km.kmerize_string(s) != 0:
+            want.append(f"Warning! no kmers in query '{lab.decode()}'; maybe your kmer length is larger than your query length?")
+            continue
+        words, missing = oix.search_perfect(km.keys())
+        if missing:
+            continue
+        want += [f"{lab.decode()}\t{oix.colors()[c]}\t{len(km)}\t1.00" for c in range(4) if words[0] >> c & 1]
+    assert out.splitlines() == want and len(want) >= len(labels)
+
+
+def expected_report(orc, oix, query, km, cov, gene):
+    hits, nu, sf, uc = oix.search_count(km.keys(), km.counts())
+    if gene:
+        return oix.generate_report_gene(query, hits, len(km), cov).splitlines()
+    modes = orc.unique_modes(uc, km.counts(), oix.n_colors)
+    return oix.generate_report(query, hits, nu, sf, modes, len(km), cov).splitlines()
+
+
+@pytest.mark.parametrize("gene", [False, True])
+def test_search_fasta(orc, env, gene):
+    d, bxi, oix, genomes = env
+    # a chimeric query: B056 + part of B545 + random sequence, so several accessions pass -p 0.05
+    q = d / "chimera.fasta"
+    rng = np.random.default_rng(2)
+    q.write_bytes(b">a\n" + genomes[2][:9000] + b"\n>b\n" + genomes[3][2000:9000] + b"\n>c\n" +
+                  np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3000)].tobytes() + b"\n")
+    km = orc.Kmers(27)
+    for s in orc.read_fasta(str(q)):
+        km.kmerize_vector(s, 1)
+    km = km.clean_map(0)   # gene: cutoff 0 (:112-113); default: auto_cutoff == 0 for an assembled query
+    args = ["search", "-b", bxi, "-q", str(q), "-p", "0.05"] + (["-g"] if gene else [])
+    out, err = run(*args)
+    want = expected_report(orc, oix, str(q), km, 0.05, gene)
+    assert sorted(out.splitlines()) == sorted(want) and len(want) >= 2
+    assert f"{len(km)} k-mers in query" in err
+
+
+@pytest.mark.parametrize("mode", ["se_f1", "pe_f0", "se_gene", "pe_auto"])
+def test_search_fastq(orc, env, mode):
+    d, bxi, oix, genomes = env
+    rng = np.random.default_rng(7)
+    r1 = synth_fastq_records(rng, genomes[2:3] + genomes[0:1], 2500, 150, mate=0)
+    rng = np.random.default_rng(7)
+    r2 = synth_fastq_records(rng, genomes[2:3] + genomes[0:1], 2500, 150, mate=1)
+    f1, f2 = str(d / f"{mode}_1.fastq.gz"), str(d / f"{mode}_2.fastq.gz")
+    write_fastq_gz(f1, r1)
+    write_fastq_gz(f2, r2)
+    pe = mode.startswith("pe")
+    km = orc.kmers_fq_pe_qual(f1, f2, 27, 15) if pe else orc.kmers_from_fq_qual(f1, 27, 15)
+    if mode == "pe_auto":
+        cutoff = km.auto_cutoff()
+        flt = []
+    else:
+        cutoff = 1 if mode == "se_f1" else 0
+        flt = ["-f", str(cutoff)]
+    km = km.clean_map(cutoff)
+    gene = mode == "se_gene"
+    args = ["search", "-b", bxi, "-q", f1] + (["-r", f2] if pe else []) + flt + (["-g"] if gene else []) + ["-p", "0.02"]
+    out, err = run(*args)
+    want = expected_report(orc, oix, f1, km, 0.02, gene)
+    assert sorted(out.splitlines()) == sorted(want) and len(want) >= 1
+    assert f"{len(km)} k-mers in query" in err and "Search: " in err
+
+
+def expected_readid(orc, oix, ids, reads, d, S, fp_correct=1e-3):
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    rep, nk, st = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+    lines = []
+    for i in range(len(reads)):
+        if st[i] == 1:
+            lines.append(f"{ids[i]}\ttoo_short\t0\t0\taccept\t0")
+            continue
+        lab, cnt, kl, verdict, ntop = oix.kmer_poll_plus(rep[i].astype(np.uint64), int(nk[i]), fp_correct)
+        lines.append(f"{ids[i]}\t{lab}\t{cnt}\t{kl}\t{verdict}\t{ntop}")
+    return lines
+
+
+def counts_file(lines):
+    c = {}
+    for l in lines:
+        v = l.split("\t")
+        key = v[1] if v[4] == "accept" else "reject"
+        c[key] = c.get(key, 0) + 1
+    return sorted(f"{k}\t{n}" for k, n in c.items())
+
+
+@pytest.mark.parametrize("pe,dflag,bflag,batch", [(False, 1, 3, 50000), (True, 1, 3, 50000), (False, 10, 3, 64), (True, 3, 0, 100),
+                                                   (False, 1, 1, 7)])
+def test_read_id_fastq(orc, env, pe, dflag, bflag, batch):
+    d, bxi, oix, genomes = env
+    rng = np.random.default_rng(11 + dflag)
+    r1 = synth_fastq_records(rng, genomes, 700, 150, mate=0)
+    rng = np.random.default_rng(11 + dflag)
+    r2 = synth_fastq_records(rng, genomes, 700, 150, mate=1)
+    tag = f"rid_{int(pe)}_{dflag}_{bflag}_{batch}"
+    f1, f2 = str(d / f"{tag}_1.fastq.gz"), str(d / f"{tag}_2.fastq.gz")
+    write_fastq_gz(f1, r1, multi_member=True)
+    write_fastq_gz(f2, r2)
+    prefix = str(d / tag)
+    args = ["read_id", "-b", bxi, "-q", f1] + ([f2] if pe else []) + ["-n", prefix, "-d", str(dflag), "-B", str(bflag), "-c", str(batch)]
+    out, err = run(*args)
+    ids = ["@" + r[0].decode() for r in r1]
+    masked = [[orc.qual_mask(a[1], a[2], 15)] + ([orc.qual_mask(b[1], b[2], 15)] if pe else []) for a, b in zip(r1, r2)]
+    want = expected_readid(orc, oix, ids, masked, dflag, bflag)
+    got = open(prefix + "_reads.txt").read().splitlines()
+    assert got == want
+    assert sorted(open(prefix + "_counts.txt").read().splitlines()) == counts_file(want)
+    assert len({l.split("\t")[1] for l in want}) >= 4        # several labels incl. no_hits / phage names occur
+    assert f"Classified {len(want)} read" in err
+
+
+def test_read_id_fasta(orc, env):
+    d, bxi, oix, genomes = env
+    # stream_fasta keeps line breaks inside the sequence (read_id_mt_pe.rs:480-494): 70-column records
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(60):
+        g = genomes[i % 4]
+        st = int(rng.integers(0, len(g) - 400))
+        s = g[st:st + int(rng.integers(30, 400))]
+        recs.append((f">contig{i} len={len(s)}".encode(), b"".join(s[j:j + 70] + b"\n" for j in range(0, len(s), 70))))
+    q = d / "contigs.fasta"
+    q.write_bytes(b"".join(h + b"\n" + body for h, body in recs))
+    prefix = str(d / "rid_fasta")
+    run("read_id", "-b", bxi, "-q", str(q), "-n", prefix, "-B", "0")
+    ids = [h.decode() for h, _ in recs]
+    want = expected_readid(orc, oix, ids, [[body] for _, body in recs], 1, 0)
+    assert open(prefix + "_reads.txt").read().splitlines() == want

@@ -38,3 +38,44 @@ def to_hip_index(ctx, oix):
     hx = colorid_amd.Index(ctx, oix.m, oix.n_hash, oix.k, oix.n_colors)
     hx.put_dense(oix.rows())
     return hx.finalize()
+
+
+# ---------------------------------------------------------------------------------------------- fastq fixtures
+
+def write_fastq_gz(path, records, multi_member=False):
+    """records: list of (id, seq, qual) byte strings.  multi_member=True writes two concatenated gzip members
+    (the reference reads with MultiGzDecoder)."""
+    import gzip
+    lines = [b"@" + i + b"\n" + s + b"\n+\n" + q + b"\n" for i, s, q in records]
+    if multi_member and len(lines) > 1:
+        h = len(lines) // 2
+        with open(path, "wb") as f:
+            f.write(gzip.compress(b"".join(lines[:h])))
+            f.write(gzip.compress(b"".join(lines[h:])))
+    else:
+        with gzip.open(path, "wb") as f:
+            f.write(b"".join(lines))
+
+
+def synth_fastq_records(rng, genomes, n, read_len, mate=0, err=0.01, lowq=0.05, n_rate=0.003):
+    """Reads drawn from `genomes` (list of bytes) with substitutions, some low-quality bases (phred < 15),
+    some N and a few lower-case / short reads.  Deterministic in rng; mate=1 gives the reverse mates."""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    recs = []
+    for i in range(n):
+        g = genomes[int(rng.integers(len(genomes)))]
+        L = int(read_len if rng.random() < 0.9 else rng.integers(10, read_len))
+        frag = int(rng.integers(L, 2 * L + 20))
+        st = int(rng.integers(0, max(1, len(g) - frag)))
+        s = g[st:st + L] if mate == 0 else g[st + frag - L:st + frag].translate(comp)[::-1]
+        a = np.frombuffer(s, np.uint8).copy()
+        e = rng.random(len(a)) < err
+        a[e] = ACGT[rng.integers(0, 4, int(e.sum()))]
+        a[rng.random(len(a)) < n_rate] = ord("N")
+        if rng.random() < 0.03:
+            a = np.frombuffer(a.tobytes().lower(), np.uint8).copy()
+        q = np.full(len(a), ord("I"), np.uint8)
+        lq = rng.random(len(a)) < lowq
+        q[lq] = rng.integers(33, 48, int(lq.sum()))       # phred 0..14 -> masked at -Q 15
+        recs.append((f"read{i}/{mate + 1} extra words".encode(), a.tobytes(), q.tobytes()))
+    return recs
