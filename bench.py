@@ -187,11 +187,12 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
+    from colorid_amd.dist import allreduce_counts
+
     def step():
         hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
                             out.data_ptr() + 16 * C, uc.data_ptr())
-        if world > 1:
-            dist.all_reduce(out)  # RCCL over xGMI: sum of the per-accession counters (24*C bytes)
+        allreduce_counts(out)  # RCCL over xGMI when N > 1: sum of the per-accession counters (24*C bytes)
 
     for _ in range(a.warmup):
         step()
@@ -206,8 +207,7 @@ def main():
         hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
                             out.data_ptr() + 16 * C, uc.data_ptr())
         ev[i][1].record(stream)
-        if world > 1:
-            dist.all_reduce(out)
+        allreduce_counts(out)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
