@@ -82,7 +82,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate):
+def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate, return_reads=False):
     """Distinct canonical k-mers of synthetic reads: (ascii [K,k] u8, freq [K] i32, colour [K] i32; colour >= C = not planted)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -99,6 +99,7 @@ def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate):
         rc = rc | ((3 - c) << (2 * j))
         bad |= err[:, j:j + nw]
     canon = torch.minimum(fwd, rc).reshape(-1)  # A<C<G<T: numeric min == lexicographic min of the ASCII strings
+    reads_ascii = torch.tensor(list(b"ACGT"), device=dev, dtype=torch.uint8)[codes] if return_reads else None
     del fwd, rc, codes, err
     colour = torch.where(bad, torch.full_like(bad, n_colours, dtype=torch.int64), genome[:, None].expand(-1, nw)).reshape(-1)
     del bad
@@ -117,6 +118,8 @@ def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate):
     step = 8_000_000
     for s in range(0, K, step):
         ascii_k[s:s + step] = lut[((uniq[s:s + step, None] >> shifts[None, :]) & 3)]
+    if return_reads:
+        return ascii_k.contiguous(), counts.to(torch.int32).contiguous(), col_u.to(torch.int32).contiguous(), reads_ascii
     return ascii_k.contiguous(), counts.to(torch.int32).contiguous(), col_u.to(torch.int32).contiguous()
 
 

@@ -397,6 +397,58 @@ int cid_search_perfect(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, si
 
 // ------------------------------------------------------------------------------------------------ a6/a7/a9/a10
 
+static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
+                         cid::ReadIdParams &p, int &waves) {
+    p = cid::ReadIdParams{};
+    p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
+    p.mod = ix->mod;
+    p.stride_d = stride_d; p.start_sample = start_sample;
+    p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
+    p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
+    if (p.win_cap < 4) p.win_cap = 4;
+    p.hist_pad = (ix->n_colors + 1 + 3) & ~3u;
+    p.table_slots = 64;
+    while (p.table_slots < p.win_cap + p.win_cap / 2) p.table_slots <<= 1;
+    // key region: the larger of the byte-string layout (tags, window infos, k-mer image) and the packed layout
+    // (hash table keys + indices, 2-bit bases, bad-base bits)
+    const size_t key_bytes_path = 8ull * p.win_cap + cid::kmer_img_bytes(ix->k);
+    const size_t key_packed_path = 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
+    const size_t key_bytes = ((key_bytes_path > key_packed_path ? key_bytes_path : key_packed_path) + 15) & ~15ull;
+    const size_t wave_bytes = (size_t)p.bases_cap + 4ull * cid::kWave * ix->n_hash + 4ull * p.hist_pad + key_bytes;
+    p.wave_bytes = (uint32_t)((wave_bytes + 15) & ~15ull);
+    waves = 4;
+    while (waves > 1 && (size_t)waves * p.wave_bytes > 160u * 1024u) waves >>= 1;
+    if ((size_t)waves * p.wave_bytes > 160u * 1024u)
+        return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %u B of LDS per wave (> 160 KiB): "
+                    "long-read batches are not supported by this kernel yet", (unsigned long long)max_bytes,
+                    (unsigned long long)max_win, p.wave_bytes);
+    return CID_OK;
+}
+
+int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off,
+                         const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                         uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_report, uint32_t *d_n_kmers,
+                         uint8_t *d_status) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    if (n_reads == 0) return CID_OK;
+    if (!d_bases || !d_seq_off || !d_read_seq0 || !d_report || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
+    cid::ReadIdParams p;
+    int waves;
+    rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, p, waves);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
+    p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status;
+    uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
+    if (rpb < (uint64_t)waves) rpb = waves;
+    if (rpb > 256) rpb = 256;
+    p.reads_per_block = (uint32_t)rpb;
+    HIP_TRY(cid::launch_readid(p, waves, c->stream));
+    return CID_OK;
+}
+
 int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
                      const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                      uint32_t *report, uint32_t *n_kmers, uint8_t *status) {
@@ -423,22 +475,12 @@ int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, cons
         if (bytes > max_bytes) max_bytes = bytes;
         if (win > max_win) max_win = win;
     }
-    cid::ReadIdParams p{};
-    p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
-    p.mod = ix->mod;
-    p.stride_d = stride_d; p.start_sample = start_sample;
-    p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
-    p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
-    if (p.win_cap < 4) p.win_cap = 4;
-    p.hist_pad = (ix->n_colors + 1 + 3) & ~3u;
-    const size_t wave_bytes = (size_t)p.bases_cap + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) + 4ull * cid::kWave * ix->n_hash + 4ull * p.hist_pad;
-    p.wave_bytes = (uint32_t)((wave_bytes + 15) & ~15ull);
-    int waves = 4;
-    while (waves > 1 && (size_t)waves * p.wave_bytes > 160u * 1024u) waves >>= 1;
-    if ((size_t)waves * p.wave_bytes > 160u * 1024u)
-        return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %u B of LDS per wave (> 160 KiB): "
-                    "long-read batches are not supported by this kernel yet", (unsigned long long)max_bytes,
-                    (unsigned long long)max_win, p.wave_bytes);
+    {   // fail before any copy if the batch does not fit the kernel's LDS budget
+        cid::ReadIdParams probe;
+        int waves;
+        rc = readid_params(ix, stride_d, start_sample, max_bytes, max_win, probe, waves);
+        if (rc) return rc;
+    }
     HIP_TRY(hipSetDevice(c->device));
     void *d_bases, *d_so, *d_r0, *d_rep, *d_nk;
     const size_t C1 = (size_t)ix->n_colors + 1;
@@ -450,14 +492,9 @@ int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, cons
     if (total_bases) HIP_TRY(hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    p.bases = (const uint8_t *)d_bases; p.seq_off = (const uint64_t *)d_so; p.read_seq0 = (const uint64_t *)d_r0;
-    p.n_reads = n_reads;
-    p.report = (uint32_t *)d_rep; p.n_kmers = (uint32_t *)d_nk; p.status = (uint8_t *)d_nk + n_reads * 4;
-    uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
-    if (rpb < (uint64_t)waves) rpb = waves;
-    if (rpb > 256) rpb = 256;
-    p.reads_per_block = (uint32_t)rpb;
-    HIP_TRY(cid::launch_readid(p, waves, c->stream));
+    rc = cid_readid_count_dev(c, ix, (const uint8_t *)d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d,
+                              start_sample, max_bytes, max_win, (uint32_t *)d_rep, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(report, d_rep, n_reads * C1 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(status, (uint8_t *)d_nk + n_reads * 4, n_reads, hipMemcpyDeviceToHost, c->stream));

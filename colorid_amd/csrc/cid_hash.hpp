@@ -99,12 +99,39 @@ CID_FN uint32_t lds_rd8(const uint32_t *img, uint32_t off) {
     return (img[off >> 2] >> (8u * (off & 3u))) & 0xffu;
 }
 
+// Input readers: where the k-mer's bytes come from.
+struct LdsReader {  // bytes [off, off+len) of an LDS (or host) dword image
+    const uint32_t *img;
+    uint32_t off;
+    CID_FN uint64_t rd64(uint32_t o) const { return lds_rd64(img, off + o); }
+    CID_FN uint32_t rd32(uint32_t o) const { return lds_rd32(img, off + o); }
+    CID_FN uint32_t rd8(uint32_t o) const { return lds_rd8(img, off + o); }
+};
+
+// 4 bases (2 bits each, base j at bits 2j+1:2j; A,C,G,T = 0..3) -> their 4 upper-case ASCII bytes, little-endian
+CID_FN uint32_t ascii4(uint32_t x8) {
+    uint32_t y = (x8 | (x8 << 12)) & 0x000F000Fu;
+    y = (y | (y << 6)) & 0x03030303u;
+    const uint32_t b0 = y & 0x01010101u, b1 = (y >> 1) & 0x01010101u;
+    return 0x41414141u + 2u * y + 2u * b1 + 11u * (b0 & b1);  // 'A'+{0,2,6,19}: no byte ever carries
+}
+
+struct CodeReader {  // an upper-case ACGT k-mer (k <= 32) held as a 2-bit code, base j at bits 2j+1:2j
+    uint64_t code;
+    CID_FN uint32_t rd32(uint32_t o) const { return ascii4((uint32_t)(code >> (2u * o)) & 0xFFu); }
+    CID_FN uint64_t rd64(uint32_t o) const {
+        const uint32_t x = (uint32_t)(code >> (2u * o)) & 0xFFFFu;
+        return ((uint64_t)ascii4(x >> 8) << 32) | ascii4(x & 0xFFu);
+    }
+    CID_FN uint32_t rd8(uint32_t o) const { return ascii4((uint32_t)(code >> (2u * o)) & 3u) & 0xFFu; }
+};
+
 // All n seeds (0..n-1) of one k-mer; emit(seed, hash).  len is wave-uniform.
-template <typename Emit>
-CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t n, Emit &&emit) {
+template <typename Reader, typename Emit>
+CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, Emit &&emit) {
     if (len > 16 && len <= 32) {  // the k = 21/27/31 case: 2 x mix16B, inputs read once for all seeds
-        const uint64_t a0 = lds_rd64(img, off), a1 = lds_rd64(img, off + 8);
-        const uint64_t b0 = lds_rd64(img, off + len - 16), b1 = lds_rd64(img, off + len - 8);
+        const uint64_t a0 = in.rd64(0), a1 = in.rd64(8);
+        const uint64_t b0 = in.rd64(len - 16), b1 = in.rd64(len - 8);
         for (uint32_t s = 0; s < n; ++s) {
             uint64_t acc = (uint64_t)len * P64_1;
             acc += mul128_fold64(a0 ^ (kSecretW[0] + s), a1 ^ (kSecretW[1] - s));
@@ -116,21 +143,21 @@ CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t
         for (uint32_t s = 0; s < n; ++s) {
             uint64_t acc = (uint64_t)len * P64_1;
             for (uint32_t i = 0; i < nb; ++i) {
-                const uint32_t f = off + 16 * i, b = off + len - 16 * (i + 1);
-                acc += mul128_fold64(lds_rd64(img, f) ^ (kSecretW[4 * i] + s), lds_rd64(img, f + 8) ^ (kSecretW[4 * i + 1] - s));
-                acc += mul128_fold64(lds_rd64(img, b) ^ (kSecretW[4 * i + 2] + s), lds_rd64(img, b + 8) ^ (kSecretW[4 * i + 3] - s));
+                const uint32_t f = 16 * i, b = len - 16 * (i + 1);
+                acc += mul128_fold64(in.rd64(f) ^ (kSecretW[4 * i] + s), in.rd64(f + 8) ^ (kSecretW[4 * i + 1] - s));
+                acc += mul128_fold64(in.rd64(b) ^ (kSecretW[4 * i + 2] + s), in.rd64(b + 8) ^ (kSecretW[4 * i + 3] - s));
             }
             emit(s, xxh3_avalanche(acc));
         }
     } else if (len > 8) {  // 9..16
-        const uint64_t i_lo = lds_rd64(img, off), i_hi = lds_rd64(img, off + len - 8);
+        const uint64_t i_lo = in.rd64(0), i_hi = in.rd64(len - 8);
         for (uint32_t s = 0; s < n; ++s) {
             const uint64_t lo = i_lo ^ ((kSecretW[3] ^ kSecretW[4]) + s);
             const uint64_t hi = i_hi ^ ((kSecretW[5] ^ kSecretW[6]) - s);
             emit(s, xxh3_avalanche((uint64_t)len + bswap64(lo) + hi + mul128_fold64(lo, hi)));
         }
     } else if (len >= 4) {  // 4..8
-        const uint64_t i1 = lds_rd32(img, off), i2 = lds_rd32(img, off + len - 4);
+        const uint64_t i1 = in.rd32(0), i2 = in.rd32(len - 4);
         const uint64_t in64 = i2 + (i1 << 32);
         for (uint32_t s = 0; s < n; ++s) {
             uint64_t seed = (uint64_t)s ^ ((uint64_t)__builtin_bswap32(s) << 32);
@@ -142,11 +169,41 @@ CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t
             emit(s, h ^ (h >> 28));
         }
     } else {  // 1..3
-        const uint32_t c1 = lds_rd8(img, off), c2 = lds_rd8(img, off + (len >> 1)), c3 = lds_rd8(img, off + len - 1);
+        const uint32_t c1 = in.rd8(0), c2 = in.rd8(len >> 1), c3 = in.rd8(len - 1);
         const uint32_t combined = (c1 << 16) | (c2 << 24) | c3 | (len << 8);
         const uint64_t flip = (uint64_t)((uint32_t)kSecretW[0] ^ (uint32_t)(kSecretW[0] >> 32));
         for (uint32_t s = 0; s < n; ++s) emit(s, xxh64_avalanche((uint64_t)combined ^ (flip + s)));
     }
+}
+
+template <typename Emit>
+CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t n, Emit &&emit) {
+    xxh3_seeds_from(LdsReader{img, off}, len, n, emit);
+}
+
+// ---------------------------------------------------------------- 2-bit k-mer codes (upper-case ACGT, k <= 32)
+
+// Reverse the order of the 2k-bit code's 2-bit fields (base j <-> base k-1-j), result right-aligned.
+CID_FN uint64_t rev_fields(uint64_t code, uint32_t k) {
+    uint64_t x = code;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = bswap64(x);
+    return x >> (64u - 2u * k);
+}
+CID_FN uint64_t code_mask(uint32_t k) { return k >= 32 ? ~0ULL : ((1ULL << (2u * k)) - 1ULL); }
+
+// A window's code read LSB-first (base j at bits 2j+1:2j) is `lsb`.  Returns the canonical k-mer
+// (the byte-wise smaller of the window and its reverse complement; ties -> reverse complement, same string)
+// in LSB-first form for hashing and in MSB-first form (`*msb`, base 0 most significant = lexicographic order).
+CID_FN uint64_t canonical_code(uint64_t lsb, uint32_t k, uint64_t *msb) {
+    const uint64_t mask = code_mask(k);
+    const uint64_t f_msb = rev_fields(lsb, k);
+    const uint64_t rc_msb = ~lsb & mask;            // complement, then the LSB-first reading IS the reversed order
+    const uint64_t rc_lsb = ~f_msb & mask;
+    const bool fwd = f_msb < rc_msb;                 // `l[i..i+k] < l_r[..]` (src/kmer.rs:104,231)
+    *msb = fwd ? f_msb : rc_msb;
+    return fwd ? lsb : rc_lsb;
 }
 
 }  // namespace cid

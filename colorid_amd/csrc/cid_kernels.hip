@@ -303,9 +303,14 @@ __global__ __launch_bounds__(kBlock) void k_search_perfect(SearchParams p) {
 // ------------------------------------------------------------------------------------------------
 // a6/a7/a9/a10: per-read classification counts (src/read_id_mt_pe.rs:300-331).  One wave per read(-pair):
 //   windows with stride d -> seq::has_no_n filter -> canonical choice on raw bytes (src/kmer.rs:221-243)
-//   -> per-read set in first-occurrence order (exact: 32-bit tag match is confirmed on the bytes)
-//   -> search_index_classic (:66-102) or search_index (:104-165) with the reference's "absent row => count
-//   it once under no_hits_num and stop" rule applied in k-mer order.
+//   -> per-read set in first-occurrence order -> search_index_classic (:66-102) or search_index (:104-165)
+//   with the reference's "absent row => count it once under no_hits_num and stop" rule applied in k-mer order.
+// Two key paths, chosen per read (wave-uniform):
+//   packed : the read holds no lower-case base and k <= 32 — bases are packed 2 bits each in LDS, a window's code
+//            is three dword reads, the canonical choice is one integer compare, the set is an LDS hash table on the
+//            64-bit code (exact), and the hash inputs are re-expanded to ASCII in registers;
+//   bytes  : anything else (lower-case bases are hashed as they are; k > 32) — byte strings in
+//            LDS, 32-bit tag match confirmed on the bytes.
 
 __device__ __forceinline__ bool good_base(uint32_t b) {  // src/seq.rs:59-64
     const uint32_t u = b & 0xDFu;
@@ -320,6 +325,16 @@ __device__ __forceinline__ uint32_t canon_byte(const uint8_t *bases, uint32_t in
     const uint32_t pos = info & 0x7FFFFFFFu;
     return (info >> 31) ? comp_base(bases[pos + k - 1 - t]) : (uint32_t)bases[pos + t];
 }
+// `nbits` (<= 64) bits starting at bit `bit` of a little-endian dword array (readable 2 dwords past the end)
+__device__ __forceinline__ uint64_t bits_at(const uint32_t *w, uint32_t bit, uint32_t nbits) {
+    const uint32_t i = bit >> 5, sh = bit & 31u;
+    const uint64_t lo = ((uint64_t)w[i + 1] << 32) | w[i];
+    uint64_t v = lo >> sh;
+    if (sh) v |= (uint64_t)w[i + 2] << (64u - sh);
+    return nbits >= 64 ? v : (v & ((1ull << nbits) - 1ull));
+}
+
+constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained every 7 additions
 
 template <int LOG_LPR, bool NARROW>
 __global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
@@ -332,13 +347,20 @@ __global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
     const uint32_t C = p.n_colors, k = p.k, n = p.n_hash, S = p.start_sample;
 
     uint8_t *wb = smem + (size_t)wave * p.wave_bytes;
-    uint8_t *s_bases = wb;
-    uint32_t *s_tag = reinterpret_cast<uint32_t *>(wb + p.bases_cap);
-    uint32_t *s_info = s_tag + p.win_cap;
-    uint32_t *img = s_info + p.win_cap;
+    uint8_t *s_bases = wb;                                                     // bases_cap
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.bases_cap);           // 64*n
+    uint32_t *hist = ridx + kWave * n;                                         // hist_pad
+    uint8_t *keyreg = reinterpret_cast<uint8_t *>(hist + p.hist_pad);          // key_bytes: one of the two layouts below
+    // bytes path
+    uint32_t *s_tag = reinterpret_cast<uint32_t *>(keyreg);                    // win_cap
+    uint32_t *s_info = s_tag + p.win_cap;                                      // win_cap
+    uint32_t *img = s_info + p.win_cap;                                        // kmer_img_bytes(k)
     uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
-    uint32_t *ridx = img + kmer_img_bytes(k) / 4;
-    uint32_t *hist = ridx + kWave * n;
+    // packed path
+    unsigned long long *t_key = reinterpret_cast<unsigned long long *>(keyreg);   // table_slots
+    uint32_t *t_idx = reinterpret_cast<uint32_t *>(t_key + p.table_slots);     // table_slots
+    uint32_t *s_pack = t_idx + p.table_slots;                                  // bases_cap/16 + 4 dwords, 16 bases each
+    uint32_t *s_bad = s_pack + (p.bases_cap / 16 + 4);                         // bases_cap/32 + 4 dwords, 1 bit per base
 
     for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
 
@@ -347,6 +369,7 @@ __global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
     const bool col_live = col_word < p.w64;
     const uint32_t seeds_mask = n >= 32 ? ~0u : ((1u << n) - 1u);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t tmask = p.table_slots - 1;
 
     const uint64_t r_begin = (uint64_t)blockIdx.x * p.reads_per_block;
     const uint64_t r_end = r_begin + p.reads_per_block < p.n_reads ? r_begin + p.reads_per_block : p.n_reads;
@@ -362,12 +385,40 @@ __global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
             continue;
         }
         const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
-        for (uint32_t i = lane; i < tb; i += kWave) s_bases[i] = p.bases[g0 + i];
+        bool lower = false;
+        for (uint32_t i = lane; i < tb; i += kWave) {
+            const uint8_t b = p.bases[g0 + i];
+            s_bases[i] = b;
+            lower = lower || (good_base(b) && (b & 0x20u));
+        }
+        const bool packed = k <= 32 && !__any(lower);
+        wave_lds_fence();
+        if (packed) {
+            // 16 bases per lane-step: 2-bit codes (A,C,G,T = 0..3, anything else 0 + its bad bit)
+            for (uint32_t j0 = 0; j0 * 16 < tb + 64; j0 += kWave) {
+                const uint32_t j = j0 + lane;
+                uint32_t code = 0, bad = 0;
+                for (uint32_t t = 0; t < 16; ++t) {
+                    const uint32_t i = j * 16 + t;
+                    const uint32_t b = i < tb ? s_bases[i] : 'N';
+                    const uint32_t c2 = (b >> 1) & 3u;            // A 00, C 01, T 10, G 11  ->  swap G/T below
+                    code |= (c2 ^ (c2 >> 1)) << (2 * t);          // A 0, C 1, G 2, T 3
+                    bad |= (good_base(b) ? 0u : 1u) << t;
+                }
+                const uint32_t bad_hi = __shfl_down(bad, 1, kWave);
+                if (j * 16 < tb + 64) {
+                    s_pack[j] = code;
+                    if (!(lane & 1)) s_bad[j >> 1] = bad | (bad_hi << 16);
+                }
+            }
+            for (uint32_t t = lane; t < p.table_slots; t += kWave) { t_key[t] = ~0ull; t_idx[t] = ~0u; }
+        }
         wave_lds_fence();
 
         uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
+        uint32_t wbase = 0;    // windows enumerated so far (first-occurrence order index)
         bool stopped = false;  // an absent row was met: nothing after it is searched
-        VCount<kPlanes, NARROW> vc;
+        VCount<kReadPlanes, NARROW> vc;
         vc.clear();
         V16 R{0, 0};           // colours seen in the first S k-mers (this lane's slice)
 
@@ -379,54 +430,82 @@ __global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
             for (uint32_t c0 = 0; c0 < nw; c0 += kWave) {
                 const uint32_t wi = c0 + lane;
                 const uint32_t pos = off + wi * p.stride_d;
-                bool valid = wi < nw;
-                if (valid)
-                    for (uint32_t t = 0; t < k; ++t) valid = valid && good_base(s_bases[pos + t]);
-                uint32_t rc = 1;  // palindromes take the reverse-complement branch (same string)
-                if (valid)
-                    for (uint32_t t = 0; t < k; ++t) {
-                        const uint32_t f = s_bases[pos + t], r = comp_base(s_bases[pos + k - 1 - t]);
-                        if (f != r) { rc = f < r ? 0u : 1u; break; }
+                bool distinct;
+                wave_lds_fence();  // the previous chunk's gathers are done with ridx / img
+                if (packed) {
+                    bool valid = wi < nw;
+                    uint64_t lsb = 0;
+                    if (valid) {
+                        valid = bits_at(s_bad, pos, k) == 0;                   // seq::has_no_n over the window
+                        lsb = bits_at(s_pack, 2 * pos, 2 * k);
                     }
-                const uint32_t info = pos | (rc << 31);
-                wave_lds_fence();  // the previous chunk's gathers are done with img / ridx
-                if (valid)
-                    for (uint32_t t = 0; t < k; ++t) img8[(uint32_t)lane * k + t] = (uint8_t)canon_byte(s_bases, info, k, t);
-                wave_lds_fence();
-                uint32_t tag = 0;
-                if (valid)
-                    xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t sd, uint64_t h) {
-                        if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
-                        ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
-                    });
-                // ---- set semantics, first occurrence wins
-                bool dup = false;
-                for (uint32_t q = 0; q < nd; ++q) {  // against the distinct k-mers of earlier chunks
-                    if (valid && !dup && s_tag[q] == tag) {
-                        const uint32_t oi = s_info[q];
-                        bool same = true;
-                        for (uint32_t t = 0; t < k && same; ++t) same = canon_byte(s_bases, oi, k, t) == img8[(uint32_t)lane * k + t];
-                        dup = same;
+                    uint64_t msb = 0;
+                    const uint64_t canon = canonical_code(lsb, k, &msb);
+                    // exact set with first-occurrence order: slot key = canonical code, slot value = smallest window index
+                    uint32_t slot = (uint32_t)((msb * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
+                    if (valid) {
+                        while (true) {
+                            const unsigned long long old = atomicCAS(&t_key[slot], ~0ull, (unsigned long long)msb);
+                            if (old == ~0ull || old == msb) break;
+                            slot = (slot + 1) & tmask;
+                        }
+                        atomicMin(&t_idx[slot], wbase + wi);
+                    }
+                    wave_lds_fence();
+                    distinct = valid && t_idx[slot] == wbase + wi;
+                    if (distinct)
+                        xxh3_seeds_from(CodeReader{canon}, k, n, [&](uint32_t sd, uint64_t h) {
+                            ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
+                        });
+                } else {
+                    bool valid = wi < nw;
+                    if (valid)
+                        for (uint32_t t = 0; t < k; ++t) valid = valid && good_base(s_bases[pos + t]);
+                    uint32_t rc = 1;  // palindromes take the reverse-complement branch (same string)
+                    if (valid)
+                        for (uint32_t t = 0; t < k; ++t) {
+                            const uint32_t f = s_bases[pos + t], r = comp_base(s_bases[pos + k - 1 - t]);
+                            if (f != r) { rc = f < r ? 0u : 1u; break; }
+                        }
+                    const uint32_t info = pos | (rc << 31);
+                    if (valid)
+                        for (uint32_t t = 0; t < k; ++t) img8[(uint32_t)lane * k + t] = (uint8_t)canon_byte(s_bases, info, k, t);
+                    wave_lds_fence();
+                    uint32_t tag = 0;
+                    if (valid)
+                        xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t sd, uint64_t h) {
+                            if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
+                            ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
+                        });
+                    bool dup = false;
+                    for (uint32_t q = 0; q < nd; ++q) {  // against the distinct k-mers of earlier chunks
+                        if (valid && !dup && s_tag[q] == tag) {
+                            const uint32_t oi = s_info[q];
+                            bool same = true;
+                            for (uint32_t t = 0; t < k && same; ++t) same = canon_byte(s_bases, oi, k, t) == img8[(uint32_t)lane * k + t];
+                            dup = same;
+                        }
+                    }
+                    const uint64_t vmask = __ballot(valid);
+                    for (int j = 0; j < kWave - 1; ++j) {  // against lower lanes of this chunk
+                        if (!((vmask >> j) & 1ull)) continue;
+                        const uint32_t tj = __builtin_amdgcn_readlane(tag, j);
+                        const uint32_t ij = __builtin_amdgcn_readlane(info, j);
+                        if (valid && !dup && j < lane && tj == tag) {
+                            bool same = true;
+                            for (uint32_t t = 0; t < k && same; ++t) same = canon_byte(s_bases, ij, k, t) == img8[(uint32_t)lane * k + t];
+                            dup = same;
+                        }
+                    }
+                    distinct = valid && !dup;
+                    const uint64_t dm = __ballot(distinct);
+                    if (distinct) {
+                        const uint32_t q = nd + (uint32_t)__popcll(dm & lt_mask);
+                        s_tag[q] = tag;
+                        s_info[q] = info;
                     }
                 }
-                const uint64_t vmask = __ballot(valid);
-                for (int j = 0; j < kWave - 1; ++j) {  // against lower lanes of this chunk
-                    if (!((vmask >> j) & 1ull)) continue;
-                    const uint32_t tj = __builtin_amdgcn_readlane(tag, j);
-                    const uint32_t ij = __builtin_amdgcn_readlane(info, j);
-                    if (valid && !dup && j < lane && tj == tag) {
-                        bool same = true;
-                        for (uint32_t t = 0; t < k && same; ++t) same = canon_byte(s_bases, ij, k, t) == img8[(uint32_t)lane * k + t];
-                        dup = same;
-                    }
-                }
-                const bool distinct = valid && !dup;
                 const uint64_t dmask = __ballot(distinct);
-                if (distinct) {
-                    const uint32_t q = nd + (uint32_t)__popcll(dmask & lt_mask);
-                    s_tag[q] = tag;
-                    s_info[q] = info;
-                }
                 wave_lds_fence();
                 // ---- search (read_id_mt_pe.rs:66-102 / :104-165) over this chunk's distinct k-mers, in order
                 if (!stopped && dmask) {
@@ -470,6 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
                 }
                 nd += (uint32_t)__popcll(dmask);
             }
+            wbase += nw;
         }
         vc.drain(hist, col_word);
         wave_lds_fence();

@@ -121,6 +121,11 @@ class Index:
                                         n_reads, d, start_sample, _p(rep), _p(nk), _p(st)))
         return rep, nk, st
 
+    def readid_count_dev(self, d_bases, d_seq_off, d_read_seq0, n_reads, d, start_sample, max_read_bytes, max_read_windows,
+                         d_report, d_nk, d_status):
+        check(self.lib.cid_readid_count_dev(self.ctx.h, self.h, vp(d_bases), vp(d_seq_off), vp(d_read_seq0), n_reads, d,
+                                            start_sample, max_read_bytes, max_read_windows, vp(d_report), vp(d_nk), vp(d_status)))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.cid_index_destroy(self.h)

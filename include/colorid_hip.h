@@ -110,6 +110,13 @@ int cid_readid_count(cid_ctx *, const cid_index *, const uint8_t *bases, const u
                      const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                      uint32_t *report, uint32_t *n_kmers, uint8_t *status);
 
+/* Device-pointer form (asynchronous on the ctx stream).  The caller states the longest read(-pair) of the batch in
+ * bytes and in k-mer windows (sum over its mates of (len-k)/d+1 for len >= k): they size the kernel's LDS. */
+int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *d_seq_off,
+                         const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                         uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_report, uint32_t *d_n_kmers,
+                         uint8_t *d_status);
+
 /* ---- measurement helpers (bench only): HIP-event timing on the ctx stream ---- */
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */

@@ -16,6 +16,22 @@ void shim_hash_seeds(const uint8_t *kmer, uint32_t len, uint32_t off, uint32_t n
     cid::xxh3_seeds(img.data(), off, len, n, [&](uint32_t s, uint64_t h) { out[s] = h; });
 }
 
+// The packed path: an upper-case ACGT k-mer (k <= 32) -> LSB-first 2-bit code -> canonical code -> hashes of the
+// canonical string.  out_canon receives the canonical ASCII string as the device would hash it.
+void shim_hash_canonical_code(const uint8_t *kmer, uint32_t k, uint32_t n, uint64_t *out, uint8_t *out_canon, uint64_t *out_msb) {
+    uint64_t lsb = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint64_t c = kmer[j] == 'A' ? 0 : kmer[j] == 'C' ? 1 : kmer[j] == 'G' ? 2 : 3;
+        lsb |= c << (2 * j);
+    }
+    uint64_t msb;
+    const uint64_t canon = cid::canonical_code(lsb, k, &msb);
+    *out_msb = msb;
+    const cid::CodeReader r{canon};
+    for (uint32_t j = 0; j < k; ++j) out_canon[j] = (uint8_t)r.rd8(j);
+    cid::xxh3_seeds_from(r, k, n, [&](uint32_t s, uint64_t h) { out[s] = h; });
+}
+
 uint64_t shim_mod(uint64_t h, uint64_t m) {
     const cid::ModMagicHost mh = cid::make_mod_magic(m);
     const cid::ModMagic mm{mh.m, mh.magic, mh.shift, mh.flags};

@@ -18,6 +18,8 @@ def shim(tmp_path_factory):
                            os.path.join(HERE, "cpu_shim", "hash_shim.cpp")])
     L = C.CDLL(so)
     L.shim_hash_seeds.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.shim_hash_canonical_code.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_char_p,
+                                           C.POINTER(C.c_uint64)]
     L.shim_mod.restype = C.c_uint64
     L.shim_mod.argtypes = [C.c_uint64, C.c_uint64]
     L.shim_row_stride_words.restype = C.c_uint32
@@ -61,3 +63,31 @@ def test_row_stride_rule(shim):
             4096: 64, 8192: 128}
     for c, rs in want.items():
         assert shim.shim_row_stride_words(c) == rs
+
+
+def test_packed_code_path_matches_string_path(shim, orc):
+    """2-bit window code -> canonical choice -> ASCII re-expansion -> XXH3: equals hashing the canonical string
+    the reference would build (min(window, revcomp) on bytes, ties -> revcomp), for every k <= 32."""
+    import xxhash
+    rnd = random.Random(4)
+    for k in range(1, 33):
+        for trial in range(60):
+            if trial == 0:
+                s = (b"ACGT" * 9)[:k]
+            elif trial == 1:
+                s = b"A" * k
+            elif trial == 2:
+                half = bytes(rnd.choice(b"ACGT") for _ in range(k // 2))
+                s = (half + orc.revcomp(half))[:k] if k % 2 == 0 else bytes(rnd.choice(b"ACGT") for _ in range(k))
+            else:
+                s = bytes(rnd.choice(b"ACGT") for _ in range(k))
+            rc = orc.revcomp(s)
+            want = s if s < rc else rc
+            out = (C.c_uint64 * 4)()
+            canon = C.create_string_buffer(k)
+            msb = C.c_uint64(0)
+            shim.shim_hash_canonical_code(s, k, 4, out, canon, C.byref(msb))
+            assert canon.raw == want, (k, s)
+            assert msb.value == int("".join(str(b"ACGT".index(c)) for c in want), 4)
+            for sd in range(4):
+                assert out[sd] == xxhash.xxh3_64_intdigest(want, seed=sd), (k, s, sd)

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <chrono>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -113,6 +114,26 @@ int main(int argc, char **argv) {
     for (auto &x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (uint32_t)((s >> 11) % n_rows); }
     CK(hipMemcpy(idx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (variant == 10) {  // vector gather (3/4 of the groups) and scalar gather (1/4) concurrently on two streams
+        hipStream_t sa, sb; CK(hipStreamCreate(&sa)); CK(hipStreamCreate(&sb));
+        const int sfrac = argc > 5 ? atoi(argv[5]) : 4;
+        const uint64_t gs = n_groups / sfrac, gv = n_groups - gs;
+        for (int mode = 0; mode < 3; ++mode) {  // 0 both, 1 vector part alone, 2 scalar part alone
+            float best = 1e9f;
+            for (int it = 0; it < 5; ++it) {
+                CK(hipDeviceSynchronize());
+                auto t0 = std::chrono::steady_clock::now();
+                if (mode != 2) hipLaunchKernelGGL(probe2<0>, dim3((unsigned)((gv * 2 + 255) / 256)), dim3(256), 0, sa, tab, idx, gv, out);
+                if (mode != 1) hipLaunchKernelGGL(probe_s, dim3((unsigned)((gs + 255) / 256)), dim3(256), 0, sb, tab, idx + gv * 4, gs, out);
+                CK(hipDeviceSynchronize());
+                const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (ms < best) best = ms;
+            }
+            printf("hybrid 1/%d scalar, mode %d: %.3f ms (vector %llu M rows, scalar %llu M rows)\n", sfrac, mode, best,
+                   (unsigned long long)(gv * 4 / 1000000), (unsigned long long)(gs * 4 / 1000000));
+        }
+        return 0;
+    }
     float best = 1e9f;
     for (int it = 0; it < 5; ++it) {
         CK(hipEventRecord(e0));
