@@ -37,6 +37,19 @@ SIGNATURES = {
     "cid_search_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
     "cid_search_count_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
     "cid_search_perfect": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.POINTER(C.c_int)]),
+    "cid_search_count_codes_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
+    "cid_kmerset_create": (C.c_int, [vp, C.c_uint32, C.POINTER(vp)]),
+    "cid_kmerset_add_seqs": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int]),
+    "cid_kmerset_finalize": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "cid_kmerset_size": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "cid_kmerset_count_histogram": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "cid_kmerset_clean": (C.c_int, [vp, C.c_uint64]),
+    "cid_kmerset_order_for_index": (C.c_int, [vp, vp]),
+    "cid_kmerset_download": (C.c_int, [vp, vp, vp]),
+    "cid_kmerset_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "cid_kmerset_destroy": (None, [vp]),
+    "cid_search_count_set": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    "cid_search_perfect_set": (C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_int)]),
     "cid_readid_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "cid_readid_count_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "cid_timer_start": (C.c_int, [vp]),

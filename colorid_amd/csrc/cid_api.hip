@@ -9,12 +9,13 @@
 #include <vector>
 
 #include "cid_host_math.hpp"
-#include "cid_kernels.hpp"
+#include "cid_internal.hpp"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace cid {
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -22,6 +23,11 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+}  // namespace cid
+
+namespace {
+
+using cid::fail;
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -51,6 +57,14 @@ struct cid_index {
     bool finalized = false;
     cid::ModMagic mod{};
 };
+
+namespace cid {
+int ctx_device(const cid_ctx *c) { return c->device; }
+hipStream_t ctx_stream(const cid_ctx *c) { return c->stream; }
+uint32_t index_k(const cid_index *ix) { return ix->k; }
+uint32_t index_rs(const cid_index *ix) { return ix->rs; }
+ModMagic index_mod(const cid_index *ix) { return ix->mod; }
+}  // namespace cid
 
 namespace {
 
@@ -307,17 +321,18 @@ void cid_index_destroy(cid_index *ix) {
 
 // ------------------------------------------------------------------------------------------------ a5
 
-int cid_search_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint32_t *d_freq, size_t n_kmers,
-                         uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
+static int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, const uint32_t *d_freq,
+                               size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
+                               uint32_t *d_unique_colour) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
-    if (!d_hits || (n_kmers && !d_kmers)) return fail(CID_ERR_INVALID, "null argument");
-    if (!aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    if (!d_hits || (n_kmers && !d_kmers && !d_codes)) return fail(CID_ERR_INVALID, "null argument");
+    if (d_kmers && !aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
     cid::SearchParams p;
     rc = fill_search_params(c, ix, p);
     if (rc) return rc;
-    p.kmers = d_kmers; p.freq = d_freq; p.n_kmers = n_kmers;
+    p.kmers = d_kmers; p.codes = d_codes; p.freq = d_freq; p.n_kmers = n_kmers;
     p.hits = d_hits; p.n_unique = d_n_unique; p.sum_unique_freq = d_sum_unique_freq; p.unique_colour = d_unique_colour;
     p.want_unique = (d_n_unique || d_sum_unique_freq || d_unique_colour) ? 1u : 0u;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
@@ -329,25 +344,28 @@ int cid_search_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers
     return CID_OK;
 }
 
-int cid_search_count(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
-                     uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
-    int rc = check_ready(c, ix);
-    if (rc) return rc;
-    if (!hits || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(c->device));
+int cid_search_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint32_t *d_freq, size_t n_kmers,
+                         uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
+    return search_count_launch(c, ix, d_kmers, nullptr, d_freq, n_kmers, d_hits, d_n_unique, d_sum_unique_freq, d_unique_colour);
+}
+
+int cid_search_count_codes_dev(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_freq, size_t n_kmers,
+                               uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
+    if (ix && ix->k > 32) return fail(CID_ERR_UNSUPPORTED, "2-bit codes need k_size <= 32");
+    return search_count_launch(c, ix, nullptr, d_codes, d_freq, n_kmers, d_hits, d_n_unique, d_sum_unique_freq, d_unique_colour);
+}
+
+// host results for k-mers (ASCII `d_k` or codes `d_codes`) that are already on the device
+static int search_count_to_host(cid_ctx *c, const cid_index *ix, const uint8_t *d_k, const uint64_t *d_codes, const uint32_t *d_f,
+                                size_t n_kmers, uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
     const size_t C = ix->n_colors;
-    void *d_k, *d_f = nullptr, *d_out, *d_uc = nullptr;
-    rc = slot_reserve(c, S_KMERS, n_kmers * ix->k, &d_k);
-    if (rc) return rc;
-    if (freq) { rc = slot_reserve(c, S_FREQ, n_kmers * 4, &d_f); if (rc) return rc; }
-    rc = slot_reserve(c, S_OUT, 3 * C * 8, &d_out);
+    void *d_out, *d_uc = nullptr;
+    int rc = slot_reserve(c, S_OUT, 3 * C * 8, &d_out);
     if (rc) return rc;
     if (unique_colour) { rc = slot_reserve(c, S_UC, n_kmers * 4, &d_uc); if (rc) return rc; }
-    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
-    if (freq) HIP_TRY(hipMemcpyAsync(d_f, freq, n_kmers * 4, hipMemcpyHostToDevice, c->stream));
     uint64_t *o = (uint64_t *)d_out;
-    rc = cid_search_count_dev(c, ix, (const uint8_t *)d_k, (const uint32_t *)d_f, n_kmers, o,
-                              n_unique ? o + C : nullptr, sum_unique_freq ? o + 2 * C : nullptr, (uint32_t *)d_uc);
+    rc = search_count_launch(c, ix, d_k, d_codes, d_f, n_kmers, o, n_unique ? o + C : nullptr, sum_unique_freq ? o + 2 * C : nullptr,
+                             (uint32_t *)d_uc);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(hits, o, C * 8, hipMemcpyDeviceToHost, c->stream));
     if (n_unique) HIP_TRY(hipMemcpyAsync(n_unique, o + C, C * 8, hipMemcpyDeviceToHost, c->stream));
@@ -357,29 +375,37 @@ int cid_search_count(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, cons
     return CID_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ a4
-
-int cid_search_perfect(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, size_t n_kmers, uint32_t *and_words_le,
-                       int *any_row_missing) {
+int cid_search_count(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
+                     uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
-    if (!and_words_le || !any_row_missing || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
-    if (n_kmers == 0) return fail(CID_ERR_INVALID, "perfect search needs at least one k-mer (src/perfect_search.rs:22-23)");
+    if (!hits || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    void *d_k, *d_out;
+    void *d_k, *d_f = nullptr;
     rc = slot_reserve(c, S_KMERS, n_kmers * ix->k, &d_k);
     if (rc) return rc;
-    rc = slot_reserve(c, S_MISC, (size_t)ix->rs * 8 + 16, &d_out);
+    if (freq) { rc = slot_reserve(c, S_FREQ, n_kmers * 4, &d_f); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
+    if (freq) HIP_TRY(hipMemcpyAsync(d_f, freq, n_kmers * 4, hipMemcpyHostToDevice, c->stream));
+    return search_count_to_host(c, ix, (const uint8_t *)d_k, nullptr, (const uint32_t *)d_f, n_kmers, hits, n_unique, sum_unique_freq,
+                                unique_colour);
+}
+
+// ------------------------------------------------------------------------------------------------ a4
+
+static int search_perfect_to_host(cid_ctx *c, const cid_index *ix, const uint8_t *d_k, const uint64_t *d_codes, size_t n_kmers,
+                                  uint32_t *and_words_le, int *any_row_missing) {
+    void *d_out;
+    int rc = slot_reserve(c, S_MISC, (size_t)ix->rs * 8 + 16, &d_out);
     if (rc) return rc;
     uint64_t *d_and = (uint64_t *)d_out;
     int *d_missing = (int *)(d_and + ix->rs);
-    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_and, 0xFF, (size_t)ix->rs * 8, c->stream));
     HIP_TRY(hipMemsetAsync(d_missing, 0, 16, c->stream));
     cid::SearchParams p;
     rc = fill_search_params(c, ix, p);
     if (rc) return rc;
-    p.kmers = (const uint8_t *)d_k; p.n_kmers = n_kmers; p.and_words = d_and; p.missing = d_missing;
+    p.kmers = d_k; p.codes = d_codes; p.n_kmers = n_kmers; p.and_words = d_and; p.missing = d_missing;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
     HIP_TRY(cid::launch_search_perfect(p, c->stream));
     std::vector<uint64_t> h(ix->rs);
@@ -394,6 +420,44 @@ int cid_search_perfect(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, si
     }
     return CID_OK;
 }
+
+int cid_search_perfect(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, size_t n_kmers, uint32_t *and_words_le,
+                       int *any_row_missing) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!and_words_le || !any_row_missing || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
+    if (n_kmers == 0) return fail(CID_ERR_INVALID, "perfect search needs at least one k-mer (src/perfect_search.rs:22-23)");
+    HIP_TRY(hipSetDevice(c->device));
+    void *d_k;
+    rc = slot_reserve(c, S_KMERS, n_kmers * ix->k, &d_k);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
+    return search_perfect_to_host(c, ix, (const uint8_t *)d_k, nullptr, n_kmers, and_words_le, any_row_missing);
+}
+
+extern "C++" {
+namespace cid {
+int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,
+                       uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!hits) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->k != k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", k, ix->k);
+    HIP_TRY(hipSetDevice(c->device));
+    return search_count_to_host(c, ix, nullptr, d_codes, d_counts, n, hits, n_unique, sum_unique_freq, unique_colour);
+}
+int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t *and_words_le,
+                         int *any_row_missing) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!and_words_le || !any_row_missing) return fail(CID_ERR_INVALID, "null argument");
+    if (n == 0) return fail(CID_ERR_INVALID, "perfect search needs at least one k-mer (src/perfect_search.rs:22-23)");
+    if (ix->k != k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", k, ix->k);
+    HIP_TRY(hipSetDevice(c->device));
+    return search_perfect_to_host(c, ix, nullptr, d_codes, n, and_words_le, any_row_missing);
+}
+}  // namespace cid
+}  // extern "C++"
 
 // ------------------------------------------------------------------------------------------------ a6/a7/a9/a10
 

@@ -1,0 +1,23 @@
+// Internals shared by the translation units of libcolorid_hip.so (not part of the ABI).
+#pragma once
+#include "cid_kernels.hpp"
+
+struct cid_ctx;
+struct cid_index;
+
+namespace cid {
+
+int fail(int code, const char *fmt, ...);  // records the thread's last error message, returns `code`
+int ctx_device(const cid_ctx *c);
+hipStream_t ctx_stream(const cid_ctx *c);
+uint32_t index_k(const cid_index *ix);
+uint32_t index_rs(const cid_index *ix);
+ModMagic index_mod(const cid_index *ix);
+
+// a5 / a4 on k-mers that are already on the device as 2-bit codes (k <= 32); outputs go to HOST buffers
+int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,
+                       uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t *and_words_le,
+                         int *any_row_missing);
+
+}  // namespace cid

@@ -139,9 +139,20 @@ struct VCount {
 };
 
 // Steps 1+2 of the header comment for one tile.  Returns nothing; fills ridx[s*64 + lane].
-__device__ __forceinline__ void stage_and_hash(uint32_t *img, uint32_t *ridx, const uint8_t *kmers, uint64_t n_kmers,
-                                               uint64_t first, uint32_t k, uint32_t n, const ModMagic &mm, int lane) {
+__device__ __forceinline__ void stage_and_hash(uint32_t *img, uint32_t *ridx, const uint8_t *kmers, const uint64_t *codes,
+                                               uint64_t n_kmers, uint64_t first, uint32_t k, uint32_t n, const ModMagic &mm,
+                                               int lane) {
     wave_lds_fence();  // previous tile's readers are done with img/ridx
+    if (codes) {  // packed input: 8 bytes per k-mer, ASCII re-expanded in registers (no LDS image)
+        if (first + lane < n_kmers) {
+            const uint64_t lsb = rev_fields(codes[first + lane], k);
+            xxh3_seeds_from(CodeReader{lsb}, k, n, [&](uint32_t s, uint64_t h) { ridx[s * kWave + lane] = (uint32_t)mod_m(h, mm); });
+        } else {
+            for (uint32_t s = 0; s < n; ++s) ridx[s * kWave + lane] = 0;
+        }
+        wave_lds_fence();
+        return;
+    }
     stage_kmers(img, kmers, n_kmers, first, k, lane);
     wave_lds_fence();
     if (first + lane < n_kmers) {
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
     vc.clear();
     for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
         const uint64_t first = tile * kWave;
-        stage_and_hash(img, ridx, p.kmers, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
+        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
 #pragma unroll 1
         for (int sub = 0; sub < LPR; ++sub) {
             const int kk = sub * KPW + (lane >> LOG_LPR);
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_search_perfect(SearchParams p) {
     uint32_t missing = 0;
     for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
         const uint64_t first = tile * kWave;
-        stage_and_hash(img, ridx, p.kmers, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
+        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
 #pragma unroll 1
         for (int sub = 0; sub < LPR; ++sub) {
             const int kk = sub * KPW + (lane >> LOG_LPR);

@@ -19,7 +19,8 @@ struct SearchParams {
     uint32_t want_unique;
     uint32_t tiles_per_block;  // block b owns tiles [b*tpb, (b+1)*tpb); grid = ceil(n_tiles/tpb)
     ModMagic mod;
-    const uint8_t *kmers;  // n_kmers * k ASCII bytes, 16-byte aligned
+    const uint8_t *kmers;  // n_kmers * k ASCII bytes, 16-byte aligned (or nullptr when codes != nullptr)
+    const uint64_t *codes; // alternative input: canonical upper-case k-mers as 2-bit codes, base 0 most significant
     const uint32_t *freq;  // or nullptr
     uint64_t n_kmers;
     // a5 outputs (accumulated with atomics; caller zeroes)

@@ -1,0 +1,480 @@
+// GPU k-mer counting for `search`: replaces the reference's String-keyed FnvHashMap counting
+// (src/kmer.rs:87-125 kmerize_vector, :461-510 / :581-655 the fastq bodies, :826-837 clean_map) for k <= 32:
+//   windows -> 2-bit canonical codes (one u64 each) -> radix sort -> run-length = (distinct k-mer, multiplicity).
+// The set stays in HBM and feeds k_search_count / k_search_perfect directly (8 bytes per k-mer instead of k).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "../../include/colorid_hip.h"
+#include "cid_internal.hpp"
+
+namespace cid {
+
+struct Segment {  // <= kSegWindows consecutive windows of one sequence
+    uint64_t base_off;  // offset of the first window's first base in `bases`
+    uint64_t out_off;   // where the window codes go
+    uint32_t n_win;
+    uint32_t pad;
+};
+constexpr uint32_t kSegWindows = 2048;
+
+__device__ __forceinline__ uint8_t switch_base_dev(uint8_t c) {  // src/kmer.rs:847-863 for ACGTacgt
+    const uint32_t low = c & 0x1Fu;
+    return (uint8_t)(c ^ ((low == 1u || low == 0x14u) ? 0x15u : 0x04u));
+}
+__device__ __forceinline__ bool good_base_dev(uint32_t b) {
+    const uint32_t u = b & 0xDFu;
+    return u == 'A' || u == 'C' || u == 'G' || u == 'T';
+}
+__device__ __forceinline__ uint64_t bits_at_dev(const uint32_t *w, uint32_t bit, uint32_t nbits) {
+    const uint32_t i = bit >> 5, sh = bit & 31u;
+    uint64_t v = (((uint64_t)w[i + 1] << 32) | w[i]) >> sh;
+    if (sh) v |= (uint64_t)w[i + 2] << (64u - sh);
+    return nbits >= 64 ? v : (v & ((1ull << nbits) - 1ull));
+}
+
+// mode 0: kmerize_vector (has_no_n filter; compare raw bytes, then upper-case; src/kmer.rs:104-117)
+// mode 1: fastq body (has_no_n filter; raw case kept, so a lower-case base cannot be packed: flags[0] is raised)
+__global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, const Segment *segs, uint32_t n_segs, uint32_t k,
+                                                       int mode, uint64_t sentinel, uint64_t *out, int *flags) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr uint32_t kBytes = kSegWindows + 32 + 96;                  // bases of one segment (+ slack)
+    uint8_t *s_bases = smem + (size_t)wave * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
+    uint32_t *s_pack = reinterpret_cast<uint32_t *>(s_bases + kBytes);
+    uint32_t *s_bad = s_pack + (kBytes / 16 + 4);
+    uint32_t *s_low = s_bad + (kBytes / 32 + 4);
+    for (uint32_t sg = blockIdx.x * 4 + wave; sg < n_segs; sg += gridDim.x * 4) {
+        const Segment seg = segs[sg];
+        const uint32_t nb = seg.n_win + k - 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool lower = false;
+        for (uint32_t i = lane; i < nb; i += 64) {
+            const uint8_t b = bases[seg.base_off + i];
+            s_bases[i] = b;
+            lower = lower || (good_base_dev(b) && (b & 0x20u));
+        }
+        if (mode == 1 && __any(lower)) {
+            if (lane == 0) atomicOr(&flags[0], 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t j0 = 0; j0 * 16 < nb + 64; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            uint32_t code = 0, bad = 0, low = 0;
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t i = j * 16 + t;
+                const uint32_t b = i < nb ? s_bases[i] : 'N';
+                const uint32_t c2 = (b >> 1) & 3u;
+                code |= (c2 ^ (c2 >> 1)) << (2 * t);
+                bad |= (good_base_dev(b) ? 0u : 1u) << t;
+                low |= ((b >> 5) & 1u) << t;
+            }
+            const uint32_t bad_hi = __shfl_down(bad, 1, 64), low_hi = __shfl_down(low, 1, 64);
+            if (j * 16 < nb + 64) {
+                s_pack[j] = code;
+                if (!(lane & 1)) { s_bad[j >> 1] = bad | (bad_hi << 16); s_low[j >> 1] = low | (low_hi << 16); }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint64_t mask = code_mask(k);
+        for (uint32_t w = lane; w < seg.n_win; w += 64) {
+            uint64_t result = sentinel;
+            if (bits_at_dev(s_bad, w, k) == 0) {
+                const uint64_t lsb = bits_at_dev(s_pack, 2 * w, 2 * k);
+                const uint64_t lowbits = bits_at_dev(s_low, w, k);
+                uint64_t msb;
+                if (lowbits == 0 || lowbits == (k >= 64 ? ~0ull : ((1ull << k) - 1ull))) {
+                    canonical_code(lsb, k, &msb);            // uniform case: byte order == code order
+                } else {                                     // mixed case: the reference compares the raw bytes
+                    bool fwd = false;                        // equal strings take the reverse-complement branch
+                    for (uint32_t t = 0; t < k; ++t) {
+                        const uint8_t f = s_bases[w + t], r = switch_base_dev(s_bases[w + k - 1 - t]);
+                        if (f != r) { fwd = f < r; break; }
+                    }
+                    const uint64_t f_msb = rev_fields(lsb, k);
+                    msb = fwd ? f_msb : (~lsb & mask);
+                }
+                result = msb;
+            }
+            out[seg.out_off + w] = result;
+        }
+    }
+}
+
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_flag_gt(const uint32_t *counts, uint64_t t, uint8_t *flags, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = counts[i] > t ? 1 : 0;
+}
+__global__ void k_codes_to_ascii(const uint64_t *codes, uint32_t k, uint8_t *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = codes[i];
+    for (uint32_t t = 0; t < k; ++t) out[i * k + t] = (uint8_t)"ACGT"[(c >> (2 * (k - 1 - t))) & 3u];
+}
+// sort key for index locality: the 128-byte line of the k-mer's first row
+__global__ void k_row0_line(const uint64_t *codes, uint32_t k, ModMagic mm, uint32_t line_shift, uint32_t *keys, uint32_t *idx, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t lsb = rev_fields(codes[i], k);
+    uint32_t row0 = 0;
+    xxh3_seeds_from(CodeReader{lsb}, k, 1, [&](uint32_t, uint64_t h) { row0 = (uint32_t)mod_m(h, mm); });
+    keys[i] = row0 >> line_shift;
+    idx[i] = (uint32_t)i;
+}
+__global__ void k_gather_set(const uint32_t *idx, const uint64_t *codes_in, const uint32_t *counts_in, uint64_t *codes_out,
+                             uint32_t *counts_out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    codes_out[i] = codes_in[idx[i]];
+    counts_out[i] = counts_in[idx[i]];
+}
+
+}  // namespace cid
+
+struct cid_kmerset {
+    cid_ctx *ctx = nullptr;
+    uint32_t k = 0;
+    uint64_t sentinel = 0;
+    unsigned end_bit = 64;
+    uint64_t *raw = nullptr;  size_t n_raw = 0, cap_raw = 0;   // window codes not yet merged
+    uint64_t *codes = nullptr; uint32_t *counts = nullptr; size_t n = 0;  // distinct k-mers, ascending code unless reordered
+    int *d_flags = nullptr;
+    bool finalized = false;
+    size_t compact_at = 1ull << 30;   // merge the unsorted window buffer into the set beyond this many codes (8 GiB)
+};
+
+namespace {
+
+using cid::fail;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {  // scoped device allocation
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
+        return e == hipSuccess ? CID_OK : fail(CID_ERR_NOMEM, "hipMalloc(%zu): %s", n * sizeof(T), hipGetErrorString(e));
+    }
+    T *release() { T *q = p; p = nullptr; return q; }
+};
+
+unsigned grid_for_n(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+// merge the raw window codes into (codes, counts): sort + run-length (first merge) or sort pairs + reduce by key
+int compact(cid_kmerset *ks) {
+    if (ks->n_raw == 0) return CID_OK;
+    hipStream_t st = cid::ctx_stream(ks->ctx);
+    const size_t total = ks->n + ks->n_raw;
+    DevBuf<uint64_t> uniq;
+    DevBuf<uint32_t> agg;
+    DevBuf<uint64_t> d_count;
+    int rc;
+    if ((rc = uniq.alloc(total)) || (rc = agg.alloc(total)) || (rc = d_count.alloc(1))) return rc;
+    size_t tmp_bytes = 0;
+    if (ks->n == 0) {
+        DevBuf<uint64_t> sorted;
+        if ((rc = sorted.alloc(total))) return rc;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
+        DevBuf<uint8_t> tmp;
+        if ((rc = tmp.alloc(tmp_bytes))) return rc;
+        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
+        size_t tmp2 = 0;
+        HIP_TRY(rocprim::run_length_encode(nullptr, tmp2, sorted.p, total, uniq.p, agg.p, d_count.p, st));
+        DevBuf<uint8_t> t2;
+        if ((rc = t2.alloc(tmp2))) return rc;
+        HIP_TRY(rocprim::run_length_encode(t2.p, tmp2, sorted.p, total, uniq.p, agg.p, d_count.p, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        DevBuf<uint64_t> kin, kout;
+        DevBuf<uint32_t> vin, vout;
+        if ((rc = kin.alloc(total)) || (rc = kout.alloc(total)) || (rc = vin.alloc(total)) || (rc = vout.alloc(total))) return rc;
+        HIP_TRY(hipMemcpyAsync(kin.p, ks->codes, ks->n * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(kin.p + ks->n, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(vin.p, ks->counts, ks->n * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(cid::k_fill_u32, dim3(grid_for_n(ks->n_raw)), dim3(256), 0, st, vin.p + ks->n, 1u, (uint64_t)ks->n_raw);
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin.p, kout.p, vin.p, vout.p, total, 0u, ks->end_bit, st));
+        DevBuf<uint8_t> tmp;
+        if ((rc = tmp.alloc(tmp_bytes))) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin.p, kout.p, vin.p, vout.p, total, 0u, ks->end_bit, st));
+        size_t tmp2 = 0;
+        HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p));
+        DevBuf<uint8_t> t2;
+        if ((rc = t2.alloc(tmp2))) return rc;
+        HIP_TRY(rocprim::reduce_by_key(t2.p, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, rocprim::plus<uint32_t>(),
+                                       rocprim::equal_to<uint64_t>(), st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    uint64_t n_runs = 0;
+    HIP_TRY(hipMemcpy(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost));
+    if (n_runs > 0) {  // the sentinel (invalid windows) sorts last: drop it
+        uint64_t last = 0;
+        HIP_TRY(hipMemcpy(&last, uniq.p + (n_runs - 1), 8, hipMemcpyDeviceToHost));
+        if (last == ks->sentinel) --n_runs;
+    }
+    if (ks->codes) (void)hipFree(ks->codes);
+    if (ks->counts) (void)hipFree(ks->counts);
+    ks->codes = uniq.release();
+    ks->counts = agg.release();
+    ks->n = n_runs;
+    ks->n_raw = 0;
+    return CID_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cid_kmerset_create(cid_ctx *c, uint32_t k_size, cid_kmerset **out) {
+    if (!c || !out) return fail(CID_ERR_INVALID, "null ctx/out");
+    *out = nullptr;
+    if (k_size == 0 || k_size > 32) return fail(CID_ERR_UNSUPPORTED, "GPU k-mer counting packs k-mers in 64 bits: k_size %u > 32", k_size);
+    cid_kmerset *ks = new (std::nothrow) cid_kmerset();
+    if (!ks) return fail(CID_ERR_NOMEM, "kmerset");
+    ks->ctx = c; ks->k = k_size;
+    ks->sentinel = k_size < 32 ? (1ull << (2 * k_size)) : ~0ull;   // never a canonical code (T^32's canonical form is A^32)
+    ks->end_bit = k_size < 32 ? 2 * k_size + 1 : 64;
+    HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+    if (hipMalloc(reinterpret_cast<void **>(&ks->d_flags), 16) != hipSuccess) { delete ks; return fail(CID_ERR_NOMEM, "flags"); }
+    HIP_TRY(hipMemset(ks->d_flags, 0, 16));
+    if (const char *e = getenv("CID_KMERSET_COMPACT_WINDOWS")) ks->compact_at = strtoull(e, nullptr, 10);  // tests
+    *out = ks;
+    return CID_OK;
+}
+
+int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode) {
+    if (!ks || !seq_off || (mode != 0 && mode != 1)) return fail(CID_ERR_INVALID, "bad argument");
+    if (ks->finalized) return fail(CID_ERR_STATE, "k-mer set already finalized");
+    if (n_seqs == 0) return CID_OK;
+    const uint64_t total_bases = seq_off[n_seqs];
+    if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
+    std::vector<cid::Segment> segs;
+    uint64_t n_win_total = 0;
+    for (size_t s = 0; s < n_seqs; ++s) {
+        if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic");
+        const uint64_t len = seq_off[s + 1] - seq_off[s];
+        if (len < ks->k) continue;
+        const uint64_t nw = len - ks->k + 1;
+        for (uint64_t w0 = 0; w0 < nw; w0 += cid::kSegWindows) {
+            const uint32_t m = (uint32_t)(nw - w0 < cid::kSegWindows ? nw - w0 : cid::kSegWindows);
+            segs.push_back(cid::Segment{seq_off[s] + w0, ks->n_raw + n_win_total, m, 0});
+            n_win_total += m;
+        }
+    }
+    if (n_win_total == 0) return CID_OK;
+    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    hipStream_t st = cid::ctx_stream(ks->ctx);
+    if (ks->n_raw + n_win_total > ks->cap_raw) {
+        size_t want = (ks->n_raw + n_win_total) * 3 / 2;
+        DevBuf<uint64_t> nb;
+        int rc = nb.alloc(want);
+        if (rc) return rc;
+        if (ks->n_raw) HIP_TRY(hipMemcpy(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice));
+        if (ks->raw) (void)hipFree(ks->raw);
+        ks->raw = nb.release();
+        ks->cap_raw = want;
+    }
+    DevBuf<uint8_t> d_bases;
+    DevBuf<cid::Segment> d_segs;
+    int rc;
+    if ((rc = d_bases.alloc(total_bases)) || (rc = d_segs.alloc(segs.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_bases.p, bases, total_bases, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(cid::Segment), hipMemcpyHostToDevice, st));
+    constexpr uint32_t kBytes = cid::kSegWindows + 32 + 96;
+    const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
+    unsigned grid = (unsigned)((segs.size() + 3) / 4);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases.p, d_segs.p, (uint32_t)segs.size(), ks->k, mode,
+                       ks->sentinel, ks->raw, ks->d_flags);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    ks->n_raw += n_win_total;
+    if (mode == 1) {
+        int flag = 0;
+        HIP_TRY(hipMemcpy(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost));
+        if (flag) return fail(CID_ERR_UNSUPPORTED, "lower-case bases in a case-preserving (fastq) k-mer count: count on the host");
+    }
+    if (ks->n_raw > ks->compact_at) return compact(ks);
+    return CID_OK;
+}
+
+int cid_kmerset_finalize(cid_kmerset *ks, uint64_t *n_distinct) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    int rc = compact(ks);
+    if (rc) return rc;
+    if (ks->raw) { (void)hipFree(ks->raw); ks->raw = nullptr; ks->cap_raw = 0; }
+    ks->finalized = true;
+    if (n_distinct) *n_distinct = ks->n;
+    return CID_OK;
+}
+
+int cid_kmerset_size(const cid_kmerset *ks, uint64_t *n_distinct) {
+    if (!ks || !n_distinct) return fail(CID_ERR_INVALID, "null argument");
+    *n_distinct = ks->n;
+    return CID_OK;
+}
+
+int cid_kmerset_count_histogram(const cid_kmerset *ks, uint32_t *values, uint64_t *n_kmers, size_t cap, size_t *n_bins) {
+    if (!ks || !n_bins) return fail(CID_ERR_INVALID, "null argument");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    *n_bins = 0;
+    if (ks->n == 0) return CID_OK;
+    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    hipStream_t st = cid::ctx_stream(ks->ctx);
+    DevBuf<uint32_t> sorted, uniq, runs;
+    DevBuf<uint64_t> d_count;
+    int rc;
+    if ((rc = sorted.alloc(ks->n)) || (rc = uniq.alloc(ks->n)) || (rc = runs.alloc(ks->n)) || (rc = d_count.alloc(1))) return rc;
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, ks->counts, sorted.p, ks->n, 0u, 32u, st));
+    DevBuf<uint8_t> tmp;
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, ks->counts, sorted.p, ks->n, 0u, 32u, st));
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::run_length_encode(nullptr, tb2, sorted.p, ks->n, uniq.p, runs.p, d_count.p, st));
+    DevBuf<uint8_t> tmp2;
+    if ((rc = tmp2.alloc(tb2))) return rc;
+    HIP_TRY(rocprim::run_length_encode(tmp2.p, tb2, sorted.p, ks->n, uniq.p, runs.p, d_count.p, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t nb = 0;
+    HIP_TRY(hipMemcpy(&nb, d_count.p, 8, hipMemcpyDeviceToHost));
+    *n_bins = nb;
+    if (!values || !n_kmers) return CID_OK;   // size query
+    if (cap < nb) return fail(CID_ERR_INVALID, "histogram needs %llu bins", (unsigned long long)nb);
+    std::vector<uint32_t> r(nb);
+    HIP_TRY(hipMemcpy(values, uniq.p, nb * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(r.data(), runs.p, nb * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < nb; ++i) n_kmers[i] = r[i];
+    return CID_OK;
+}
+
+int cid_kmerset_clean(cid_kmerset *ks, uint64_t t) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (ks->n == 0 || t == 0) return CID_OK;   // every stored k-mer has count >= 1 > 0
+    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    hipStream_t st = cid::ctx_stream(ks->ctx);
+    DevBuf<uint8_t> flags;
+    DevBuf<uint64_t> oc, d_count;
+    DevBuf<uint32_t> on;
+    int rc;
+    if ((rc = flags.alloc(ks->n)) || (rc = oc.alloc(ks->n)) || (rc = on.alloc(ks->n)) || (rc = d_count.alloc(1))) return rc;
+    hipLaunchKernelGGL(cid::k_flag_gt, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->counts, t, flags.p, (uint64_t)ks->n);
+    size_t tb = 0;
+    HIP_TRY(rocprim::select(nullptr, tb, ks->codes, flags.p, oc.p, d_count.p, ks->n, st));
+    DevBuf<uint8_t> tmp;
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::select(tmp.p, tb, ks->codes, flags.p, oc.p, d_count.p, ks->n, st));
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::select(nullptr, tb2, ks->counts, flags.p, on.p, d_count.p, ks->n, st));
+    DevBuf<uint8_t> tmp2;
+    if ((rc = tmp2.alloc(tb2))) return rc;
+    HIP_TRY(rocprim::select(tmp2.p, tb2, ks->counts, flags.p, on.p, d_count.p, ks->n, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t kept = 0;
+    HIP_TRY(hipMemcpy(&kept, d_count.p, 8, hipMemcpyDeviceToHost));
+    (void)hipFree(ks->codes); (void)hipFree(ks->counts);
+    ks->codes = oc.release(); ks->counts = on.release(); ks->n = kept;
+    return CID_OK;
+}
+
+int cid_kmerset_order_for_index(cid_kmerset *ks, const cid_index *ix) {
+    if (!ks || !ix) return fail(CID_ERR_INVALID, "null argument");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (ks->n == 0) return CID_OK;
+    if (ks->n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 distinct k-mers");
+    if (cid::index_k(ix) != ks->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", ks->k, cid::index_k(ix));
+    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    hipStream_t st = cid::ctx_stream(ks->ctx);
+    const uint32_t rs = cid::index_rs(ix);
+    uint32_t line_shift = 0;
+    while ((rs << line_shift) < 16) ++line_shift;   // rows per 128-byte line = 16 / rs
+    DevBuf<uint32_t> keys, idx, keys2, idx2, on;
+    DevBuf<uint64_t> oc;
+    int rc;
+    if ((rc = keys.alloc(ks->n)) || (rc = idx.alloc(ks->n)) || (rc = keys2.alloc(ks->n)) || (rc = idx2.alloc(ks->n)) ||
+        (rc = oc.alloc(ks->n)) || (rc = on.alloc(ks->n))) return rc;
+    hipLaunchKernelGGL(cid::k_row0_line, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, cid::index_mod(ix), line_shift, keys.p,
+                       idx.p, (uint64_t)ks->n);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, 32u, st));
+    DevBuf<uint8_t> tmp;
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, 32u, st));
+    hipLaunchKernelGGL(cid::k_gather_set, dim3(grid_for_n(ks->n)), dim3(256), 0, st, idx2.p, ks->codes, ks->counts, oc.p, on.p, (uint64_t)ks->n);
+    HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(ks->codes); (void)hipFree(ks->counts);
+    ks->codes = oc.release(); ks->counts = on.release();
+    return CID_OK;
+}
+
+int cid_kmerset_download(const cid_kmerset *ks, uint8_t *kmers_ascii, uint32_t *counts) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (ks->n == 0) return CID_OK;
+    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    hipStream_t st = cid::ctx_stream(ks->ctx);
+    if (kmers_ascii) {
+        DevBuf<uint8_t> a;
+        int rc = a.alloc(ks->n * ks->k);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cid::k_codes_to_ascii, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, a.p, (uint64_t)ks->n);
+        HIP_TRY(hipMemcpyAsync(kmers_ascii, a.p, ks->n * ks->k, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (counts) HIP_TRY(hipMemcpy(counts, ks->counts, ks->n * 4, hipMemcpyDeviceToHost));
+    return CID_OK;
+}
+
+int cid_kmerset_device_arrays(const cid_kmerset *ks, void **d_codes, void **d_counts, uint64_t *n) {
+    if (!ks || !d_codes || !d_counts || !n) return fail(CID_ERR_INVALID, "null argument");
+    *d_codes = ks->codes; *d_counts = ks->counts; *n = ks->n;
+    return CID_OK;
+}
+
+void cid_kmerset_destroy(cid_kmerset *ks) {
+    if (!ks) return;
+    (void)hipSetDevice(cid::ctx_device(ks->ctx));
+    if (ks->raw) (void)hipFree(ks->raw);
+    if (ks->codes) (void)hipFree(ks->codes);
+    if (ks->counts) (void)hipFree(ks->counts);
+    if (ks->d_flags) (void)hipFree(ks->d_flags);
+    delete ks;
+}
+
+int cid_search_count_set(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks, uint64_t *hits, uint64_t *n_unique,
+                         uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    return cid::search_count_codes(c, ix, ks->codes, ks->counts, ks->n, ks->k, hits, n_unique, sum_unique_freq, unique_colour);
+}
+
+int cid_search_perfect_set(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks, uint32_t *and_words_le, int *any_row_missing) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    return cid::search_perfect_codes(c, ix, ks->codes, ks->n, ks->k, and_words_le, any_row_missing);
+}
+
+}  // extern "C"

@@ -133,3 +133,80 @@ class Index:
 
     def __del__(self):
         self.close()
+
+
+class KmerSet:
+    """Device-resident distinct canonical k-mers with multiplicities (cid_kmerset, k <= 32)."""
+
+    MODE_FASTA, MODE_FASTQ = 0, 1
+
+    def __init__(self, ctx, k):
+        self.ctx, self.lib, self.k = ctx, ctx.lib, k
+        h = vp()
+        check(self.lib.cid_kmerset_create(ctx.h, k, C.byref(h)))
+        self.h = h
+
+    def add_seqs(self, seqs, mode=0):
+        """seqs: list of bytes"""
+        off = np.zeros(len(seqs) + 1, np.uint64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        bases = np.frombuffer(b"".join(seqs), np.uint8) if seqs else np.zeros(0, np.uint8)
+        check(self.lib.cid_kmerset_add_seqs(self.h, _p(bases), _p(off), len(seqs), mode))
+
+    def finalize(self):
+        n = C.c_uint64(0)
+        check(self.lib.cid_kmerset_finalize(self.h, C.byref(n)))
+        return n.value
+
+    def __len__(self):
+        n = C.c_uint64(0)
+        check(self.lib.cid_kmerset_size(self.h, C.byref(n)))
+        return n.value
+
+    def histogram(self):
+        nb = C.c_size_t(0)
+        check(self.lib.cid_kmerset_count_histogram(self.h, None, None, 0, C.byref(nb)))
+        vals = np.zeros(nb.value, np.uint32)
+        cnts = np.zeros(nb.value, np.uint64)
+        check(self.lib.cid_kmerset_count_histogram(self.h, _p(vals), _p(cnts), nb.value, C.byref(nb)))
+        return vals, cnts
+
+    def clean(self, t):
+        check(self.lib.cid_kmerset_clean(self.h, t))
+
+    def order_for_index(self, index):
+        check(self.lib.cid_kmerset_order_for_index(self.h, index.h))
+
+    def download(self):
+        n = len(self)
+        km = np.zeros((n, self.k), np.uint8)
+        cnt = np.zeros(n, np.uint32)
+        check(self.lib.cid_kmerset_download(self.h, _p(km), _p(cnt)))
+        return km, cnt
+
+    def as_dict(self):
+        km, cnt = self.download()
+        return {km[i].tobytes(): int(cnt[i]) for i in range(len(cnt))}
+
+    def search_count(self, index):
+        n = len(self)
+        hits = np.zeros(index.n_colors, np.uint64)
+        nu = np.zeros(index.n_colors, np.uint64)
+        sf = np.zeros(index.n_colors, np.uint64)
+        uc = np.zeros(n, np.uint32)
+        check(self.lib.cid_search_count_set(self.ctx.h, index.h, self.h, _p(hits), _p(nu), _p(sf), _p(uc)))
+        return hits, nu, sf, uc
+
+    def search_perfect(self, index):
+        words = np.zeros(index.w32, np.uint32)
+        missing = C.c_int(0)
+        check(self.lib.cid_search_perfect_set(self.ctx.h, index.h, self.h, _p(words), C.byref(missing)))
+        return words, bool(missing.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cid_kmerset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

@@ -90,6 +90,39 @@ int cid_search_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, c
                          size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
                          uint32_t *d_unique_colour);
 
+/* Same, for k-mers given as 2-bit codes (k_size <= 32): one u64 per canonical UPPER-CASE k-mer, base 0 in the most
+ * significant of the 2*k_size low bits, A,C,G,T = 0..3 (8 bytes of input per k-mer instead of k_size). */
+int cid_search_count_codes_dev(cid_ctx *, const cid_index *, const uint64_t *d_codes, const uint32_t *d_freq,
+                               size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
+                               uint32_t *d_unique_colour);
+
+/* ---- a10 (next row): canonical k-mer counting on the GPU for k_size <= 32 — replaces the
+ *      FnvHashMap<String,usize> producers of `search`: kmerize_vector (src/kmer.rs:87-125, mode 0: has_no_n filter,
+ *      orientation chosen on the raw bytes, then upper-cased) and the fastq bodies (src/kmer.rs:481-503 / :619-647,
+ *      mode 1: has_no_n filter, case preserved — a lower-case base cannot be packed and makes add_seqs return
+ *      CID_ERR_UNSUPPORTED: count that file on the host).  Sequences: `bases` + seq_off[n_seqs+1] (for mode 1
+ *      already quality-masked, src/seq.rs:36-56).  The set lives in HBM: windows -> 2-bit codes -> radix sort ->
+ *      run-length.  clean == clean_map (src/kmer.rs:826-837: keep multiplicity > t); count_histogram gives the
+ *      (multiplicity, number of k-mers) pairs auto_cutoff needs (src/kmer.rs:866-942). ---- */
+typedef struct cid_kmerset cid_kmerset;
+int cid_kmerset_create(cid_ctx *, uint32_t k_size, cid_kmerset **out);
+int cid_kmerset_add_seqs(cid_kmerset *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode);
+int cid_kmerset_finalize(cid_kmerset *, uint64_t *n_distinct);
+int cid_kmerset_size(const cid_kmerset *, uint64_t *n_distinct);
+int cid_kmerset_count_histogram(const cid_kmerset *, uint32_t *multiplicity, uint64_t *n_kmers, size_t cap, size_t *n_bins);
+int cid_kmerset_clean(cid_kmerset *, uint64_t t);
+/* Optional: reorder the set by the 128-byte index line of each k-mer's first row (seed 0), so that consecutive
+ * k-mers share that line (order is unspecified in the reference: it iterates a hash map). */
+int cid_kmerset_order_for_index(cid_kmerset *, const cid_index *);
+/* Host copies in set order: n_distinct x k_size ASCII bytes and/or multiplicities (either may be NULL). */
+int cid_kmerset_download(const cid_kmerset *, uint8_t *kmers_ascii, uint32_t *counts);
+int cid_kmerset_device_arrays(const cid_kmerset *, void **d_codes, void **d_counts, uint64_t *n_distinct);
+void cid_kmerset_destroy(cid_kmerset *);
+/* a5 / a4 over a finalized set (results in set order; unique_colour has n_distinct entries). */
+int cid_search_count_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
+                         uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int cid_search_perfect_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint32_t *and_words_le, int *any_row_missing);
+
 /* ---- a4: perfect search, perfect_search::batch_search / batch_search_mf
  *      (src/perfect_search.rs:25-52, :83-110): AND of all n*K rows.  and_words_le: W32 u32 words;
  *      *any_row_missing = 1 iff some row is absent (the reference's "No perfect hits!"), in which case

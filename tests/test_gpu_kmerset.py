@@ -1,0 +1,151 @@
+"""GPU k-mer counting (cid_kmerset) against the oracle's k-mer maps: kmerize_vector semantics
+(mode 0: N filter, orientation chosen on raw bytes, upper-cased) and the fastq body (mode 1: raw case), clean_map,
+the multiplicity histogram auto_cutoff needs, and searches over the device-resident set."""
+import os
+
+import numpy as np
+import pytest
+
+from util import plant, random_index, to_hip_index
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFS = os.path.join(HERE, "golden", "refs")
+
+
+def oracle_map(orc, seqs, k, mode):
+    km = orc.Kmers(k)
+    for s in seqs:
+        if mode == 0:
+            km.kmerize_vector(s, 1)
+        elif len(s) >= k:
+            km.kmerize_skip_n_set(s, 1)     # same window walk as the fastq body, but a set: use counts below
+    return km
+
+
+def fastq_counts(orc, seqs, k):
+    """the fastq body (kmer.rs:481-503) without quality masking: q = 0"""
+    km = orc.Kmers(k)
+    for s in seqs:
+        km.kmerize_fq_read(s, b"I" * len(s), 0)
+    return km
+
+
+def rand_seq(rng, n, alphabet=b"ACGT"):
+    return np.frombuffer(alphabet, np.uint8)[rng.integers(0, len(alphabet), n)].tobytes()
+
+
+@pytest.mark.parametrize("k", [1, 4, 15, 16, 17, 21, 27, 31, 32])
+def test_fasta_mode_matches_kmerize_vector(orc, hip_ctx, k):
+    import colorid_amd
+    rng = np.random.default_rng(k)
+    seqs = [rand_seq(rng, 5000), rand_seq(rng, 3), rand_seq(rng, k), rand_seq(rng, 2047 + k), rand_seq(rng, 2048 + k),
+            rand_seq(rng, 7000, b"ACGTN"), rand_seq(rng, 3000, b"ACGTacgt"),          # mixed case: raw-byte orientation
+            rand_seq(rng, 2000, b"acgtn"), b"A" * 300, (b"ACGT" * 100), b"", rand_seq(rng, 900, b"ACGTRYKM-")]
+    seqs.append(seqs[0][100:900])                                                      # repeats -> multiplicities > 1
+    want = orc.Kmers(k)
+    for s in seqs:
+        want.kmerize_vector(s, 1)
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    ks.add_seqs(seqs[:5], 0)
+    ks.add_seqs(seqs[5:], 0)
+    assert ks.finalize() == len(want)
+    assert ks.as_dict() == want.as_dict()
+    vals, cnts = ks.histogram()
+    wc = want.counts()
+    assert dict(zip(vals.tolist(), cnts.tolist())) == {int(v): int((wc == v).sum()) for v in np.unique(wc)}
+    ks.clean(1)
+    assert ks.as_dict() == want.clean_map(1).as_dict()
+    ks.close()
+
+
+def test_fastq_mode_and_lowercase_refusal(orc, hip_ctx):
+    import colorid_amd
+    rng = np.random.default_rng(9)
+    seqs = [rand_seq(rng, 150, b"ACGTN" if i % 7 == 0 else b"ACGT") for i in range(3000)] + [b"ACG", b""]
+    seqs += seqs[:500]
+    want = fastq_counts(orc, seqs, 27)
+    ks = colorid_amd.KmerSet(hip_ctx, 27)
+    ks.add_seqs(seqs, 1)
+    ks.finalize()
+    assert ks.as_dict() == want.as_dict()
+    ks.close()
+    ks = colorid_amd.KmerSet(hip_ctx, 27)
+    with pytest.raises(colorid_amd.CidError) as ei:          # case-preserving count cannot pack a lower-case k-mer
+        ks.add_seqs([rand_seq(rng, 150, b"ACGTacgt")], 1)
+    assert ei.value.code == -4
+    ks.close()
+    with pytest.raises(colorid_amd.CidError):
+        colorid_amd.KmerSet(hip_ctx, 33)
+
+
+def test_incremental_merge_path(orc, hip_ctx, monkeypatch):
+    import colorid_amd
+    monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "20000")   # force sort-pairs + reduce-by-key merges
+    rng = np.random.default_rng(3)
+    genome = rand_seq(rng, 30000)
+    batches = [[genome[s:s + 400] for s in rng.integers(0, len(genome) - 400, 200)] for _ in range(6)]
+    want = orc.Kmers(21)
+    ks = colorid_amd.KmerSet(hip_ctx, 21)
+    for b in batches:
+        for s in b:
+            want.kmerize_vector(s, 1)
+        ks.add_seqs(b, 0)
+    assert ks.finalize() == len(want)
+    assert ks.as_dict() == want.as_dict()
+    assert want.counts().max() > 5
+    ks.close()
+
+
+def test_phage_fixture_counts(orc, hip_ctx):
+    import colorid_amd
+    for name, k in (("Listeria_phage_B056.fasta", 27), ("Listeria_phage_B021.fasta", 31)):
+        seqs = orc.read_fasta(os.path.join(REFS, name))
+        want = orc.Kmers(k)
+        for s in seqs:
+            want.kmerize_vector(s, 1)
+        ks = colorid_amd.KmerSet(hip_ctx, k)
+        ks.add_seqs(seqs, 0)
+        n = ks.finalize()
+        assert n == len(want) and (name != "Listeria_phage_B056.fasta" or n == 32634)   # SURVEY §6 sizing KAT
+        assert ks.as_dict() == want.as_dict()
+        ks.close()
+
+
+@pytest.mark.parametrize("n_colors,n_hash,k", [(4, 4, 27), (256, 4, 31), (1024, 3, 21), (65, 2, 32)])
+def test_search_over_device_set(orc, hip_ctx, n_colors, n_hash, k):
+    import colorid_amd
+    rng = np.random.default_rng(n_colors + k)
+    genome = rand_seq(rng, 20000)
+    reads = [genome[s:s + 150] for s in rng.integers(0, len(genome) - 150, 1500)]
+    want = orc.Kmers(k)
+    for s in reads:
+        want.kmerize_vector(s, 1)
+    oix = random_index(orc, rng, 60_013, n_hash, k, n_colors, density=0.2, zero_row_frac=0.1)
+    plant(oix, rng, want.keys(), frac=0.6, max_colours=min(3, n_colors))
+    hx = to_hip_index(hip_ctx, oix)
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    ks.add_seqs(reads, 0)
+    ks.finalize()
+    for reorder in (False, True):
+        if reorder:
+            ks.order_for_index(hx)
+        km, cnt = ks.download()
+        assert {km[i].tobytes(): int(cnt[i]) for i in range(len(cnt))} == want.as_dict()
+        w = oix.search_count(km, cnt.astype(np.uint64))         # the oracle on the same k-mers in the set's order
+        g = ks.search_count(hx)
+        for a, b in zip(w, g):
+            assert np.array_equal(a, b)
+        assert w[0].sum() > 0
+    sub = colorid_amd.KmerSet(hip_ctx, k)
+    sub.add_seqs([genome[:300]], 0)
+    sub.finalize()
+    skm, _ = sub.download()
+    for key in skm:
+        oix.insert(0, key.tobytes())
+    hx2 = to_hip_index(hip_ctx, oix)
+    pw, pm = oix.search_perfect(skm)
+    gw, gm = sub.search_perfect(hx2)
+    assert pm == gm and np.array_equal(pw, gw) and (pm or pw[0] & 1)
+    hx.close(); hx2.close(); ks.close(); sub.close()
