@@ -75,6 +75,7 @@ def parse_args():
     ap.add_argument("--genome-len", type=int, default=3_000_000)
     ap.add_argument("--error-rate", type=float, default=0.01)
     ap.add_argument("--density", type=float, default=None, help="override the background bit density (experiments)")
+    ap.add_argument("--codes", action="store_true", help="experiment: feed 2-bit codes (cid_search_count_codes_dev) instead of ASCII")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -82,7 +83,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate, return_reads=False):
+def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate, return_reads=False, return_codes=False):
     """Distinct canonical k-mers of synthetic reads: (ascii [K,k] u8, freq [K] i32, colour [K] i32; colour >= C = not planted)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -118,6 +119,8 @@ def make_reads_kmers(dev, seed, n_reads, read_len, k, n_colours, err_rate, retur
     step = 8_000_000
     for s in range(0, K, step):
         ascii_k[s:s + step] = lut[((uniq[s:s + step, None] >> shifts[None, :]) & 3)]
+    if return_codes:
+        return ascii_k.contiguous(), counts.to(torch.int32).contiguous(), col_u.to(torch.int32).contiguous(), uniq.contiguous()
     if return_reads:
         return ascii_k.contiguous(), counts.to(torch.int32).contiguous(), col_u.to(torch.int32).contiguous(), reads_ascii
     return ascii_k.contiguous(), counts.to(torch.int32).contiguous(), col_u.to(torch.int32).contiguous()
@@ -175,15 +178,15 @@ def main():
     fill_background(dev, ptr, m, rs, C, p_bg, seed=7)
     mine = None
     for r in range(world):  # the replicated index holds every rank's planted k-mers
-        kk, ff, cc = make_reads_kmers(dev, 42 + r, a.reads, a.read_len, k, C, a.error_rate)
+        kk, ff, cc, codes = make_reads_kmers(dev, 42 + r, a.reads, a.read_len, k, C, a.error_rate, return_codes=True)
         torch.cuda.synchronize()
         hx.insert_kmers_dev(kk.data_ptr(), cc.data_ptr(), kk.shape[0])
         ctx.synchronize()
         if r == rank:
-            mine = (kk, ff)
+            mine = (kk, ff, codes)
         del cc
     hx.finalize()
-    kmers, freq = mine
+    kmers, freq, codes = mine
     K = kmers.shape[0]
     out = torch.zeros(3 * C, dtype=torch.int64, device=dev)  # hits | n_unique | sum_unique_freq (u64 on the device)
     uc = torch.empty(K, dtype=torch.int32, device=dev)
@@ -192,9 +195,17 @@ def main():
 
     from colorid_amd.dist import allreduce_counts
 
+    def launch():
+        if a.codes:
+            from colorid_amd._lib import check, vp
+            check(hx.lib.cid_search_count_codes_dev(ctx.h, hx.h, vp(codes.data_ptr()), vp(freq.data_ptr()), K, vp(out.data_ptr()),
+                                                    vp(out.data_ptr() + 8 * C), vp(out.data_ptr() + 16 * C), vp(uc.data_ptr())))
+        else:
+            hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
+                                out.data_ptr() + 16 * C, uc.data_ptr())
+
     def step():
-        hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
-                            out.data_ptr() + 16 * C, uc.data_ptr())
+        launch()
         allreduce_counts(out)  # RCCL over xGMI when N > 1: sum of the per-accession counters (24*C bytes)
 
     for _ in range(a.warmup):
@@ -207,8 +218,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         ev[i][0].record(stream)
-        hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
-                            out.data_ptr() + 16 * C, uc.data_ptr())
+        launch()
         ev[i][1].record(stream)
         allreduce_counts(out)
     torch.cuda.synchronize()
@@ -226,7 +236,7 @@ def main():
     result = None
     if rank == 0:
         w64 = (C + 63) // 64
-        alg_bytes_per_kmer = n * w64 * 8 + k + 4 + 4  # rows + k-mer bytes + freq in + unique-colour out
+        alg_bytes_per_kmer = n * w64 * 8 + (8 if a.codes else k) + 4 + 4  # rows + k-mer bytes + freq in + unique-colour out
         achieved = alg_bytes_per_kmer * K / (kern_ms * 1e-3) / 1e9
         result = {
             "metric": "query k-mers/s on 50M-bit n=4 256-colour BIGSI; bit-exact hits vs CPU",

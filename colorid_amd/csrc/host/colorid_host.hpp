@@ -38,6 +38,8 @@ class KmerMap {
     std::vector<uint32_t> counts_;
     std::vector<uint32_t> table_;  // entry + 1
 };
+// kmer.rs:866-942 on the histogram {multiplicity -> number of distinct k-mers}; -1 where the reference would panic
+int64_t auto_cutoff_from_histogram(const std::map<uint64_t, uint64_t> &histo, uint64_t n_distinct);
 void kmerize_vector(const std::vector<std::string> &v, size_t d, KmerMap &out);   // kmer.rs:87-125
 bool kmerize_string(const std::string &l, KmerMap &out);                          // kmer.rs:271-299 (false = None)
 void kmers_from_fq_qual(const std::string &path, uint8_t q, KmerMap &out);        // kmer.rs:461-510

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "colorid_host.hpp"
@@ -91,12 +92,12 @@ void read_counts_five_fields(const std::string &reads_file, const std::string &p
 // reports.rs:8-48: hits / n_ref_kmers > cov -> query, K, accession, cov, mean, mode, n_unique
 static void generate_report(const std::string &query, const Bigsi &b, const std::vector<uint64_t> &hits,
                             const std::vector<uint64_t> &n_unique, const std::vector<uint64_t> &sum_freq,
-                            const std::vector<uint32_t> &unique_colour, const KmerMap &km, double cov) {
+                            const std::vector<uint32_t> &unique_colour, const uint32_t *counts, size_t n_kmers, double cov) {
     const size_t C = b.colors.size();
     // mode of the unique-hit k-mer frequencies per colour (reports.rs:65-77; ties -> smallest value)
     std::vector<std::map<uint32_t, uint64_t>> occ(C);
-    for (size_t j = 0; j < km.size(); ++j)
-        if (unique_colour[j] != CID_NOT_UNIQUE) occ[unique_colour[j]][km.counts()[j]] += 1;
+    for (size_t j = 0; j < n_kmers; ++j)
+        if (unique_colour[j] != CID_NOT_UNIQUE) occ[unique_colour[j]][counts[j]] += 1;
     for (size_t c = 0; c < C; ++c) {
         if (!hits[c]) continue;
         double mean = 0.0;
@@ -110,7 +111,7 @@ static void generate_report(const std::string &query, const Bigsi &b, const std:
         }
         const double genome_cov = (double)hits[c] / (double)b.n_ref_kmers[c];
         if (genome_cov > cov)
-            printf("%s\t%zu\t%s\t%.2f\t%.2f\t%llu\t%llu\n", query.c_str(), km.size(), b.colors[c].c_str(), genome_cov, mean,
+            printf("%s\t%zu\t%s\t%.2f\t%.2f\t%llu\t%llu\n", query.c_str(), n_kmers, b.colors[c].c_str(), genome_cov, mean,
                    (unsigned long long)modus, (unsigned long long)specific);
     }
 }
@@ -126,11 +127,88 @@ static void generate_report_gene(const std::string &query, const Bigsi &b, const
 
 // ---------------------------------------------------------------------------------------------- perfect_search.rs
 
+// ---------------------------------------------------------------------------------------------- GPU k-mer counting
+//  k <= 32: the k-mer map is built and kept on the device; COLORID_HOST_KMERS=1 forces the host map.
+
+static bool gpu_counting(const Bigsi &b) { return b.k_size <= 32 && !getenv("COLORID_HOST_KMERS"); }
+
+struct SeqBatch {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off{0};
+    void push(const std::string &s) { bases.insert(bases.end(), s.begin(), s.end()); off.push_back(bases.size()); }
+    size_t n() const { return off.size() - 1; }
+    void clear() { bases.clear(); off.assign(1, 0); }
+};
+
+static cid_kmerset *count_fasta_gpu(cid_ctx *ctx, const Bigsi &b, const std::vector<std::string> &seqs) {
+    cid_kmerset *ks = nullptr;
+    CID_TRY(cid_kmerset_create(ctx, (uint32_t)b.k_size, &ks));
+    SeqBatch sb;
+    for (const std::string &s : seqs) sb.push(s);
+    CID_TRY(cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 0));
+    CID_TRY(cid_kmerset_finalize(ks, nullptr));
+    return ks;
+}
+
+// fastq(.gz) SE or PE (kmer.rs:461-510 / :581-655); nullptr = the file holds lower-case bases: count it on the host
+static cid_kmerset *count_fastq_gpu(cid_ctx *ctx, const Bigsi &b, const std::string &f1, const std::string *f2, uint8_t q) {
+    cid_kmerset *ks = nullptr;
+    CID_TRY(cid_kmerset_create(ctx, (uint32_t)b.k_size, &ks));
+    LineReader r1(f1);
+    LineReader *r2 = f2 ? new LineReader(*f2) : nullptr;
+    SeqBatch sb;
+    std::string l1, l2, s1, s2;
+    uint64_t line_count = 1;
+    bool ok = true;
+    auto flush = [&]() {
+        if (sb.n() == 0) return;
+        const int rc = cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 1);
+        if (rc == CID_ERR_UNSUPPORTED) ok = false;
+        else if (rc != CID_OK) die("cid_kmerset_add_seqs: %s", cid_last_error());
+        sb.clear();
+    };
+    while (ok && r1.next(l1)) {
+        if (r2 && !r2->next(l2)) break;
+        if (line_count % 4 == 2) { s1 = l1; if (r2) s2 = l2; }
+        else if (line_count % 4 == 0) {
+            qual_mask(s1, l1, q);
+            sb.push(s1);
+            if (r2) { qual_mask(s2, l2, q); sb.push(s2); }
+            if (sb.bases.size() >= (256u << 20)) flush();
+        }
+        ++line_count;
+    }
+    if (ok) flush();
+    delete r2;
+    if (!ok) { cid_kmerset_destroy(ks); return nullptr; }
+    CID_TRY(cid_kmerset_finalize(ks, nullptr));
+    return ks;
+}
+
+static int64_t auto_cutoff_gpu(cid_kmerset *ks) {
+    size_t nb = 0;
+    CID_TRY(cid_kmerset_count_histogram(ks, nullptr, nullptr, 0, &nb));
+    std::vector<uint32_t> mult(nb);
+    std::vector<uint64_t> cnt(nb);
+    CID_TRY(cid_kmerset_count_histogram(ks, mult.data(), cnt.data(), nb, &nb));
+    std::map<uint64_t, uint64_t> hm;
+    for (size_t i = 0; i < nb; ++i) hm[mult[i]] = cnt[i];
+    uint64_t n = 0;
+    CID_TRY(cid_kmerset_size(ks, &n));
+    return auto_cutoff_from_histogram(hm, n);
+}
+
+static void print_perfect(const Bigsi &b, const std::string &label, size_t n_kmers, const std::vector<uint32_t> &words, int missing);
+
 static void perfect_one(cid_ctx *ctx, const Bigsi &b, const std::string &label, const KmerMap &km) {
     const uint32_t w32 = (uint32_t)((b.colors.size() + 31) / 32);
     std::vector<uint32_t> words(w32);
     int missing = 0;
     CID_TRY(cid_search_perfect(ctx, b.index, km.keys(), km.size(), words.data(), &missing));
+    print_perfect(b, label, km.size(), words, missing);
+}
+
+static void print_perfect(const Bigsi &b, const std::string &label, size_t n_kmers, const std::vector<uint32_t> &words, int missing) {
     if (missing) {
         fprintf(stderr, "No perfect hits!\n");
         return;
@@ -139,12 +217,28 @@ static void perfect_one(cid_ctx *ctx, const Bigsi &b, const std::string &label, 
     for (size_t c = 0; c < b.colors.size(); ++c) n_hits += (words[c / 32] >> (c % 32)) & 1u;
     fprintf(stderr, "%zu hits\n", n_hits);
     for (size_t c = 0; c < b.colors.size(); ++c)
-        if ((words[c / 32] >> (c % 32)) & 1u) printf("%s\t%s\t%zu\t1.00\n", label.c_str(), b.colors[c].c_str(), km.size());
+        if ((words[c / 32] >> (c % 32)) & 1u) printf("%s\t%s\t%zu\t1.00\n", label.c_str(), b.colors[c].c_str(), n_kmers);
 }
 
 void perfect_search::batch_search(cid_ctx *ctx, const std::vector<std::string> &files, const Bigsi &b) {
     for (const std::string &file : files) {
         fprintf(stderr, "Counting k-mers, this may take a while!\n");
+        if (gpu_counting(b)) {
+            cid_kmerset *ks = count_fasta_gpu(ctx, b, read_fasta(file));
+            uint64_t n = 0;
+            CID_TRY(cid_kmerset_size(ks, &n));
+            fprintf(stderr, "%llu kmers in query\n", (unsigned long long)n);
+            if (n == 0) {
+                fprintf(stderr, "Warning! no kmers in query; maybe your kmer length is larger than your query length?\n");
+            } else {
+                std::vector<uint32_t> words((b.colors.size() + 31) / 32);
+                int missing = 0;
+                CID_TRY(cid_search_perfect_set(ctx, b.index, ks, words.data(), &missing));
+                print_perfect(b, file, n, words, missing);
+            }
+            cid_kmerset_destroy(ks);
+            continue;
+        }
         KmerMap km((uint32_t)b.k_size);
         kmerize_vector(read_fasta(file), 1, km);
         fprintf(stderr, "%zu kmers in query\n", km.size());
@@ -180,40 +274,60 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
     const size_t C = b.colors.size();
     for (size_t i = 0; i < files1.size(); ++i) {
         const std::string &file1 = files1[i];
-        KmerMap km((uint32_t)b.k_size);
         const bool gz = file1.size() >= 2 && file1.compare(file1.size() - 2, 2, "gz") == 0;
-        if (gz) {
-            if (files2.empty()) {
-                fprintf(stderr, "%s\nCounting k-mers, this may take a while!\n", file1.c_str());
-                kmers_from_fq_qual(file1, qual_offset, km);
-            } else {
-                if (i >= files2.size()) die("index out of bounds: the len is %zu but the index is %zu", files2.size(), i);
-                fprintf(stderr, "Paired end: %s %s\nCounting k-mers, this may take a while!\n", file1.c_str(), files2[i].c_str());
-                kmers_fq_pe_qual(file1, files2[i], qual_offset, km);
-            }
-            if (filter < 0) { const int64_t t = km.auto_cutoff(); if (t < 0) die("auto_cutoff: histogram too short"); km.clean((uint64_t)t); }
-            else km.clean((uint64_t)filter);
-        } else {  // anything else is taken to be FASTA (batch_search_pe.rs:106-123)
-            fprintf(stderr, "%s\nCounting k-mers, this may take a while!\n", file1.c_str());
-            kmerize_vector(read_fasta(file1), 1, km);
-            if (gene_search) km.clean(0);
-            else if (filter < 0) {
-                fprintf(stderr, "no gene search\n");
-                const int64_t t = km.auto_cutoff();
-                if (t < 0) die("auto_cutoff: histogram too short");
-                km.clean((uint64_t)t);
-            } else km.clean((uint64_t)filter);
-        }
-        fprintf(stderr, "%zu k-mers in query\n", km.size());
-        const auto t0 = Clock::now();
+        if (gz && !files2.empty() && i >= files2.size()) die("index out of bounds: the len is %zu but the index is %zu", files2.size(), i);
+        if (gz && files2.empty()) fprintf(stderr, "%s\nCounting k-mers, this may take a while!\n", file1.c_str());
+        else if (gz) fprintf(stderr, "Paired end: %s %s\nCounting k-mers, this may take a while!\n", file1.c_str(), files2[i].c_str());
+        else fprintf(stderr, "%s\nCounting k-mers, this may take a while!\n", file1.c_str());  // anything else is FASTA (:106-123)
+        // which cutoff applies (batch_search_pe.rs:34-39 fastq, :111-121 FASTA): -1 = auto_cutoff
+        const bool fasta_gene = !gz && gene_search;
+        const bool use_auto = !fasta_gene && filter < 0;
+        if (!gz && !gene_search && filter < 0) fprintf(stderr, "no gene search\n");
+
         std::vector<uint64_t> hits(C), n_unique(C), sum_freq(C);
-        std::vector<uint32_t> uc(gene_search ? 0 : km.size());
-        CID_TRY(cid_search_count(ctx, b.index, km.keys(), km.counts().data(), km.size(), hits.data(),
-                                 gene_search ? nullptr : n_unique.data(), gene_search ? nullptr : sum_freq.data(),
-                                 gene_search ? nullptr : uc.data()));
-        if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
-        if (!gene_search) generate_report(file1, b, hits, n_unique, sum_freq, uc, km, cov);
-        else generate_report_gene(file1, b, hits, km.size(), cov);
+        std::vector<uint32_t> uc, counts;
+        size_t n_kmers = 0;
+        cid_kmerset *ks = nullptr;
+        if (gpu_counting(b)) {
+            ks = gz ? count_fastq_gpu(ctx, b, file1, files2.empty() ? nullptr : &files2[i], qual_offset)
+                    : count_fasta_gpu(ctx, b, read_fasta(file1));
+        }
+        if (ks) {  // the k-mer map lives on the device
+            uint64_t t = fasta_gene ? 0 : (uint64_t)(filter < 0 ? 0 : filter);
+            if (use_auto) { const int64_t a = auto_cutoff_gpu(ks); if (a < 0) die("auto_cutoff: histogram too short"); t = (uint64_t)a; }
+            CID_TRY(cid_kmerset_clean(ks, t));
+            uint64_t n = 0;
+            CID_TRY(cid_kmerset_size(ks, &n));
+            n_kmers = n;
+            fprintf(stderr, "%zu k-mers in query\n", n_kmers);
+            const auto t0 = Clock::now();
+            if (!gene_search) { uc.resize(n_kmers); counts.resize(n_kmers); }
+            CID_TRY(cid_search_count_set(ctx, b.index, ks, hits.data(), gene_search ? nullptr : n_unique.data(),
+                                         gene_search ? nullptr : sum_freq.data(), gene_search ? nullptr : uc.data()));
+            if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
+            if (!gene_search) CID_TRY(cid_kmerset_download(ks, nullptr, counts.data()));
+            cid_kmerset_destroy(ks);
+        } else {  // host k-mer map (k > 32, lower-case fastq, or COLORID_HOST_KMERS)
+            fprintf(stderr, "k-mer map on the host\n");
+            KmerMap km((uint32_t)b.k_size);
+            if (gz && files2.empty()) kmers_from_fq_qual(file1, qual_offset, km);
+            else if (gz) kmers_fq_pe_qual(file1, files2[i], qual_offset, km);
+            else kmerize_vector(read_fasta(file1), 1, km);
+            uint64_t t = fasta_gene ? 0 : (uint64_t)(filter < 0 ? 0 : filter);
+            if (use_auto) { const int64_t a = km.auto_cutoff(); if (a < 0) die("auto_cutoff: histogram too short"); t = (uint64_t)a; }
+            km.clean(t);
+            n_kmers = km.size();
+            fprintf(stderr, "%zu k-mers in query\n", n_kmers);
+            const auto t0 = Clock::now();
+            if (!gene_search) uc.resize(n_kmers);
+            CID_TRY(cid_search_count(ctx, b.index, km.keys(), km.counts().data(), km.size(), hits.data(),
+                                     gene_search ? nullptr : n_unique.data(), gene_search ? nullptr : sum_freq.data(),
+                                     gene_search ? nullptr : uc.data()));
+            if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
+            counts = km.counts();
+        }
+        if (!gene_search) generate_report(file1, b, hits, n_unique, sum_freq, uc, counts.data(), n_kmers, cov);
+        else generate_report_gene(file1, b, hits, n_kmers, cov);
     }
 }
 

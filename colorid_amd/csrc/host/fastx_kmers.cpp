@@ -185,35 +185,39 @@ void KmerMap::clean(uint64_t t) {
     }
 }
 
-int64_t KmerMap::auto_cutoff() const {  // kmer.rs:866-942, panics reported as -1
-    uint64_t max_cov = 0;
-    for (uint32_t c : counts_) max_cov = c > max_cov ? c : max_cov;
-    std::vector<uint64_t> histo(max_cov + 2, 0);
-    for (uint32_t c : counts_) histo[c]++;
-    uint64_t sum = 0;
-    for (uint64_t i = 0; i <= max_cov; ++i) sum += i * histo[i];
-    const double total_mean = (double)sum / (double)counts_.size();
+int64_t auto_cutoff_from_histogram(const std::map<uint64_t, uint64_t> &hm, uint64_t n_distinct) {  // kmer.rs:866-942
+    uint64_t max_cov = 0, sum = 0;
+    for (auto &kv : hm) { max_cov = kv.first > max_cov ? kv.first : max_cov; sum += kv.first * kv.second; }
+    const double total_mean = (double)sum / (double)n_distinct;
     if (total_mean < 1.5) return 0;
-    const size_t ncov = max_cov >= 1 ? (size_t)(max_cov - 1) : 0;  // coverages[j] = histo[j+1], j < max_cov-1
-    if (ncov == 0) return -1;
-    const uint64_t *cov = histo.data() + 1;
+    const size_t ncov = max_cov >= 1 ? (size_t)(max_cov - 1) : 0;  // coverages[j] = #k-mers with multiplicity j+1, j < max_cov-1
+    if (ncov == 0) return -1;                                       // `coverages.len() - 1` underflows: panic
+    auto cov = [&](size_t j) -> uint64_t { auto it = hm.find(j + 1); return it == hm.end() ? 0 : it->second; };
     const size_t nd1 = ncov >= 2 ? ncov - 2 : 0;
-    if (nd1 == 0) return -1;
-    std::vector<double> d1(nd1);
-    for (size_t i = 1; i + 1 < ncov; ++i) d1[i - 1] = (double)cov[i] / (double)cov[i + 1];
+    if (nd1 == 0) return -1;                                        // `d1.len() - 1` underflows: panic
+    // max_cov can be huge (poly-A): d1/d2 only matter up to their first element < 1, so walk them lazily
     size_t first_d1 = 0, first_d2 = 0;
+    auto d1 = [&](size_t i) { return (double)cov(i + 1) / (double)cov(i + 2); };
     for (size_t i = 0; i < nd1; ++i)
-        if (d1[i] < 1.0) { first_d1 = i + 1; break; }
+        if (d1(i) < 1.0) { first_d1 = i + 1; break; }
     for (size_t i = 0; i + 1 < nd1; ++i)
-        if (d1[i] / d1[i + 1] < 1.0) { first_d2 = i + 1; break; }
+        if (d1(i) / d1(i + 1) < 1.0) { first_d2 = i + 1; break; }
     uint64_t bigsum = 0, num = 0;
-    for (size_t i = 0; i + 1 < ncov; ++i) { bigsum += (uint64_t)i * cov[1 + i]; num += cov[1 + i]; }
+    for (auto &kv : hm) {  // i * coverages[1+i] over i = 0..ncov-2, coverages[1+i] = histo[i+2]
+        if (kv.first >= 2 && kv.first - 2 + 1 < ncov) { bigsum += (kv.first - 2) * kv.second; num += kv.second; }
+    }
     const double mean = (double)bigsum / (double)num;
     if (first_d1 > 0 && (double)first_d1 < mean * 0.75) return (int64_t)first_d1;
     if (first_d2 > 0) return (int64_t)first_d2;
     const double c = std::ceil(mean / 2.0);
     const uint64_t cu = (c != c || c <= 0.0) ? 0 : (uint64_t)c;
     return (int64_t)(cu > 1 ? cu : 1);
+}
+
+int64_t KmerMap::auto_cutoff() const {
+    std::map<uint64_t, uint64_t> hm;
+    for (uint32_t c : counts_) hm[c] += 1;
+    return auto_cutoff_from_histogram(hm, counts_.size());
 }
 
 // ---------------------------------------------------------------------------------------------- window walk

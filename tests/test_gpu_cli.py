@@ -21,8 +21,11 @@ PHAGES = ["Listeria_phage_B021", "Listeria_phage_B051", "Listeria_phage_B056", "
 BANNER = "\n ************** initializing logger *****************\n\n"
 
 
-def run(*args, cwd=None):
-    p = subprocess.run([BIN, *args], capture_output=True, text=True, cwd=cwd)
+def run(*args, cwd=None, host_kmers=False):
+    env = dict(os.environ)
+    if host_kmers:
+        env["COLORID_HOST_KMERS"] = "1"      # k-mer map on the host instead of cid_kmerset
+    p = subprocess.run([BIN, *args], capture_output=True, text=True, cwd=cwd, env=env)
     assert p.returncode == 0, p.stderr
     assert p.stdout.startswith(BANNER)
     return p.stdout[len(BANNER):], p.stderr
@@ -48,10 +51,11 @@ def test_build_writes_identical_bxi(env, tmp_path):
     assert open(bxi, "rb").read() == open(ref, "rb").read()
 
 
-def test_search_perfect(orc, env):
+@pytest.mark.parametrize("host_kmers", [False, True])
+def test_search_perfect(orc, env, host_kmers):
     d, bxi, oix, _ = env
     q = os.path.join(REFS, "Listeria_phage_B056.fasta")
-    out, err = run("search", "-b", bxi, "-q", q, "-s")
+    out, err = run("search", "-b", bxi, "-q", q, "-s", host_kmers=host_kmers)
     km = orc.Kmers(27)
     for s in orc.read_fasta(q):
         km.kmerize_vector(s, 1)
@@ -64,7 +68,7 @@ def test_search_perfect(orc, env):
     rnd = d / "random.fasta"
     rng = np.random.default_rng(1)
     rnd.write_bytes(b">r\n" + np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 500)].tobytes() + b"\n")
-    out, err = run("search", "-b", bxi, "-q", str(rnd), "-s")
+    out, err = run("search", "-b", bxi, "-q", str(rnd), "-s", host_kmers=host_kmers)
     assert out == "" and "No perfect hits!" in err
 
 
@@ -94,8 +98,9 @@ def expected_report(orc, oix, query, km, cov, gene):
     return oix.generate_report(query, hits, nu, sf, modes, len(km), cov).splitlines()
 
 
+@pytest.mark.parametrize("host_kmers", [False, True])
 @pytest.mark.parametrize("gene", [False, True])
-def test_search_fasta(orc, env, gene):
+def test_search_fasta(orc, env, gene, host_kmers):
     d, bxi, oix, genomes = env
     # a chimeric query: B056 + part of B545 + random sequence, so several accessions pass -p 0.05
     q = d / "chimera.fasta"
@@ -107,19 +112,21 @@ def test_search_fasta(orc, env, gene):
         km.kmerize_vector(s, 1)
     km = km.clean_map(0)   # gene: cutoff 0 (:112-113); default: auto_cutoff == 0 for an assembled query
     args = ["search", "-b", bxi, "-q", str(q), "-p", "0.05"] + (["-g"] if gene else [])
-    out, err = run(*args)
+    out, err = run(*args, host_kmers=host_kmers)
     want = expected_report(orc, oix, str(q), km, 0.05, gene)
     assert sorted(out.splitlines()) == sorted(want) and len(want) >= 2
     assert f"{len(km)} k-mers in query" in err
 
 
+@pytest.mark.parametrize("host_kmers", [False, True])
 @pytest.mark.parametrize("mode", ["se_f1", "pe_f0", "se_gene", "pe_auto"])
-def test_search_fastq(orc, env, mode):
+def test_search_fastq(orc, env, mode, host_kmers):
     d, bxi, oix, genomes = env
+    lower = 0.03 if mode == "se_f1" else 0.0     # lower-case reads force the host k-mer map (case is preserved, Q2)
     rng = np.random.default_rng(7)
-    r1 = synth_fastq_records(rng, genomes[2:3] + genomes[0:1], 2500, 150, mate=0)
+    r1 = synth_fastq_records(rng, genomes[2:3] + genomes[0:1], 2500, 150, mate=0, lower_rate=lower)
     rng = np.random.default_rng(7)
-    r2 = synth_fastq_records(rng, genomes[2:3] + genomes[0:1], 2500, 150, mate=1)
+    r2 = synth_fastq_records(rng, genomes[2:3] + genomes[0:1], 2500, 150, mate=1, lower_rate=lower)
     f1, f2 = str(d / f"{mode}_1.fastq.gz"), str(d / f"{mode}_2.fastq.gz")
     write_fastq_gz(f1, r1)
     write_fastq_gz(f2, r2)
@@ -134,10 +141,11 @@ def test_search_fastq(orc, env, mode):
     km = km.clean_map(cutoff)
     gene = mode == "se_gene"
     args = ["search", "-b", bxi, "-q", f1] + (["-r", f2] if pe else []) + flt + (["-g"] if gene else []) + ["-p", "0.02"]
-    out, err = run(*args)
+    out, err = run(*args, host_kmers=host_kmers)
     want = expected_report(orc, oix, f1, km, 0.02, gene)
     assert sorted(out.splitlines()) == sorted(want) and len(want) >= 1
     assert f"{len(km)} k-mers in query" in err and "Search: " in err
+    assert ("k-mer map on the host" in err) == (host_kmers or lower > 0)
 
 
 def expected_readid(orc, oix, ids, reads, d, S, fp_correct=1e-3):

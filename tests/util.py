@@ -57,7 +57,7 @@ def write_fastq_gz(path, records, multi_member=False):
             f.write(b"".join(lines))
 
 
-def synth_fastq_records(rng, genomes, n, read_len, mate=0, err=0.01, lowq=0.05, n_rate=0.003):
+def synth_fastq_records(rng, genomes, n, read_len, mate=0, err=0.01, lowq=0.05, n_rate=0.003, lower_rate=0.03):
     """Reads drawn from `genomes` (list of bytes) with substitutions, some low-quality bases (phred < 15),
     some N and a few lower-case / short reads.  Deterministic in rng; mate=1 gives the reverse mates."""
     comp = bytes.maketrans(b"ACGT", b"TGCA")
@@ -72,7 +72,7 @@ def synth_fastq_records(rng, genomes, n, read_len, mate=0, err=0.01, lowq=0.05, 
         e = rng.random(len(a)) < err
         a[e] = ACGT[rng.integers(0, 4, int(e.sum()))]
         a[rng.random(len(a)) < n_rate] = ord("N")
-        if rng.random() < 0.03:
+        if rng.random() < lower_rate:
             a = np.frombuffer(a.tobytes().lower(), np.uint8).copy()
         q = np.full(len(a), ord("I"), np.uint8)
         lq = rng.random(len(a)) < lowq
