@@ -158,7 +158,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path (the oracle is only the cpu_baseline leg)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path with one rank
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import colorid_amd
@@ -264,7 +264,7 @@ def main():
         print(json.dumps(result), flush=True)
     hx.close()
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

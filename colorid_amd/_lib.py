@@ -11,7 +11,7 @@ except ImportError:  # pragma: no cover
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcolorid_hip.so")
+LIB_PATH = os.environ.get("COLORID_HIP_LIB") or os.path.join(_HERE, "libcolorid_hip.so")  # override: A/B experiments
 _LIB = None
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
@@ -38,6 +38,10 @@ SIGNATURES = {
     "cid_search_count_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
     "cid_search_perfect": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.POINTER(C.c_int)]),
     "cid_search_count_codes_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
+    "cid_search_count_stripe_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp, vp]),
+    "cid_search_unique_finalize_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp]),
+    "cid_search_perfect_stripe_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
+    "cid_index_row_stride_words": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "cid_kmerset_create": (C.c_int, [vp, C.c_uint32, C.POINTER(vp)]),
     "cid_kmerset_add_seqs": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int]),
     "cid_kmerset_finalize": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
@@ -74,6 +78,8 @@ def load_library():
             "(hipcc --offload-arch=gfx950).  colorid_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("COLORID_HIP_LIB") and not hasattr(lib, name):
+            continue  # an older build loaded on purpose for an A/B measurement
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args

@@ -349,6 +349,64 @@ int cid_search_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers
     return search_count_launch(c, ix, d_kmers, nullptr, d_freq, n_kmers, d_hits, d_n_unique, d_sum_unique_freq, d_unique_colour);
 }
 
+// One colour stripe of a wider index: per-colour hits are final; per-k-mer popcounts and unique
+// candidates accumulate across the stripes' calls and are resolved by cid_search_unique_finalize_dev.
+int cid_search_count_stripe_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
+                                uint32_t colour_base, uint64_t *d_hits, uint32_t *d_pop_total, uint32_t *d_cand) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!d_hits || !d_pop_total || !d_cand || (n_kmers && !d_kmers && !d_codes)) return fail(CID_ERR_INVALID, "null argument");
+    if (d_kmers && !aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    if (d_codes && ix->k > 32) return fail(CID_ERR_UNSUPPORTED, "2-bit codes need k_size <= 32");
+    HIP_TRY(hipSetDevice(c->device));
+    cid::SearchParams p;
+    rc = fill_search_params(c, ix, p);
+    if (rc) return rc;
+    p.kmers = d_kmers; p.codes = d_codes; p.n_kmers = n_kmers; p.hits = d_hits;
+    p.colour_base = colour_base; p.pop_total = d_pop_total; p.cand = d_cand;
+    p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    HIP_TRY(hipMemsetAsync(d_hits, 0, (size_t)ix->n_colors * 8, c->stream));
+    HIP_TRY(cid::launch_search_count(p, c->stream));
+    return CID_OK;
+}
+
+int cid_search_unique_finalize_dev(cid_ctx *c, const uint32_t *d_pop_total, const uint32_t *d_cand, const uint32_t *d_freq,
+                                   size_t n_kmers, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
+    if (!c || (n_kmers && (!d_pop_total || !d_cand))) return fail(CID_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cid::launch_unique_finalize(d_pop_total, d_cand, d_freq, n_kmers, d_n_unique, d_sum_unique_freq, d_unique_colour, c->stream));
+    return CID_OK;
+}
+
+// Perfect search on one stripe: the stripe's AND words are final; d_zero_acc[n_kmers] (preset to all-ones) collects,
+// per k-mer, the seeds whose row is all-zero in every stripe so far — any bit left at the end means "row absent".
+int cid_search_perfect_stripe_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
+                                  uint64_t *d_and_words, uint32_t *d_zero_acc) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!d_and_words || !d_zero_acc || (n_kmers && !d_kmers && !d_codes)) return fail(CID_ERR_INVALID, "null argument");
+    if (d_kmers && !aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    void *d_scratch;
+    rc = slot_reserve(c, S_MISC, 16, &d_scratch);
+    if (rc) return rc;
+    cid::SearchParams p;
+    rc = fill_search_params(c, ix, p);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d_and_words, 0xFF, (size_t)ix->rs * 8, c->stream));
+    p.kmers = d_kmers; p.codes = d_codes; p.n_kmers = n_kmers; p.and_words = d_and_words; p.missing = (int *)d_scratch;
+    p.zero_acc = d_zero_acc;
+    p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    HIP_TRY(cid::launch_search_perfect(p, c->stream));
+    return CID_OK;
+}
+
+int cid_index_row_stride_words(const cid_index *ix, uint64_t *row_stride_words) {
+    if (!ix || !row_stride_words) return fail(CID_ERR_INVALID, "null argument");
+    *row_stride_words = ix->rs;
+    return CID_OK;
+}
+
 int cid_search_count_codes_dev(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_freq, size_t n_kmers,
                                uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
     if (ix && ix->k > 32) return fail(CID_ERR_UNSUPPORTED, "2-bit codes need k_size <= 32");

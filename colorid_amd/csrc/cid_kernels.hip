@@ -212,7 +212,14 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
             const uint32_t total = group_sum<LOG_LPR>(pc);
             vc.add(a);  // hits[c] += bit c, for this lane's colours
             if (vc.full()) vc.drain(s_hits, col_word);
-            if (p.want_unique && live) {
+            if (p.pop_total) {  // striped: uniqueness is decided after all stripes (k_unique_finalize)
+                if (live) {
+                    if (col == 0) p.pop_total[kmer] += total;
+                    if (total == 1u && pc == 1u)
+                        p.cand[kmer] = p.colour_base + (a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
+                                                            : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y));
+                }
+            } else if (p.want_unique && live) {
                 if (total == 1u) {
                     if (pc == 1u) {
                         const uint32_t c = a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
@@ -291,7 +298,9 @@ __global__ __launch_bounds__(kBlock) void k_search_perfect(SearchParams p) {
 #pragma unroll
             for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
             const uint32_t seeds = p.n_hash >= 32 ? ~0u : ((1u << p.n_hash) - 1u);
-            if (live && (all_zero & seeds)) missing = 1;
+            if (p.zero_acc) {  // striped: a row is absent only if it is zero in every stripe
+                if (live && col == 0) p.zero_acc[first + kk] &= (all_zero & seeds);
+            } else if (live && (all_zero & seeds)) missing = 1;
         }
     }
     // lanes with the same column slice -> one value per slice per wave
@@ -567,6 +576,29 @@ __global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
         for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
+}
+
+// Striped a5 epilogue: a k-mer hits exactly one colour of the WHOLE index iff the stripes' popcounts sum to 1.
+__global__ void k_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
+                                  uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_kmers) return;
+    if (pop_total[i] == 1u) {
+        const uint32_t c = cand[i];
+        if (unique_colour) unique_colour[i] = c;
+        if (n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&n_unique[c]), 1ull);
+        if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), (unsigned long long)(freq ? freq[i] : 1u));
+    } else if (unique_colour) {
+        unique_colour[i] = 0xFFFFFFFFu;
+    }
+}
+
+hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
+                                  uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour, hipStream_t stream) {
+    if (n_kmers == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unique_finalize, dim3((unsigned)((n_kmers + 255) / 256)), dim3(256), 0, stream, pop_total, cand, freq, n_kmers,
+                       n_unique, sum_unique_freq, unique_colour);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ def shard_bounds(n_units: int, rank: int, world: int):
 
 
 def _active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized()
 
 
 def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:

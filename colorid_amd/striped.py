@@ -1,0 +1,119 @@
+"""Colour-striped BIGSI search: the index is split by colour ranges into stripes, several per GPU
+(indices wider than 8192 colours) and/or one set of stripes per rank (indices larger than one GPU's HBM).
+
+Every stripe sees every k-mer.  Per-colour hits of a stripe are final.  The two per-k-mer facts that need all stripes —
+"the AND word has exactly one set bit" and "some row is absent" — are accumulated in u32[K] device arrays by the stripe
+kernels and combined across ranks with three small-footprint collectives (RCCL over xGMI; gloo in the CPU tests):
+    pop_total : all_reduce(SUM)     cand : all_reduce(MAX)     hits : all_reduce(SUM) of the zero-padded full vector
+RCCL has no bitwise reduction, so the perfect search's zero_acc and AND words are all-gathered and ANDed locally.
+"""
+import torch
+import torch.distributed as dist
+
+from ._lib import check, vp
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized()
+
+
+def reduce_stripe_facts(pop_total: torch.Tensor, cand: torch.Tensor, hits_full: torch.Tensor):
+    """Cross-rank combination for the proportional search (in place): int32[K], int32[K], int64[C_total]."""
+    if _active():
+        dist.all_reduce(pop_total, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cand, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hits_full, op=dist.ReduceOp.SUM)
+
+
+def reduce_perfect_facts(zero_acc: torch.Tensor, and_full: torch.Tensor):
+    """Cross-rank combination for the perfect search: zero_acc int32[K] (bitwise AND over ranks), and_full int64[W64_total]
+    (each rank filled only its own stripes' words, the others are all-ones: bitwise AND over ranks)."""
+    if not _active():
+        return zero_acc, and_full
+    world = dist.get_world_size()
+    zs = [torch.empty_like(zero_acc) for _ in range(world)]
+    ws = [torch.empty_like(and_full) for _ in range(world)]
+    dist.all_gather(zs, zero_acc)
+    dist.all_gather(ws, and_full)
+    z, w = zs[0].clone(), ws[0].clone()
+    for i in range(1, world):
+        z &= zs[i]
+        w &= ws[i]
+    return z, w
+
+
+class StripedIndex:
+    """stripes: list of (colorid_amd.Index, colour_base) held by THIS rank; n_colors_total over all ranks."""
+
+    def __init__(self, ctx, stripes, n_colors_total):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.stripes = list(stripes)
+        self.n_colors = n_colors_total
+        self.n_hash = self.stripes[0][0].n_hash
+        self.k = self.stripes[0][0].k
+
+    def search_count(self, d_kmers: torch.Tensor, d_freq: torch.Tensor = None, codes: bool = False):
+        """d_kmers: uint8[K, k] (or int64[K] 2-bit codes with codes=True) on this rank's GPU, identical on every rank."""
+        dev = d_kmers.device
+        K = d_kmers.shape[0]
+        pop = torch.zeros(K, dtype=torch.int32, device=dev)
+        cand = torch.zeros(K, dtype=torch.int32, device=dev)
+        hits_full = torch.zeros(self.n_colors, dtype=torch.int64, device=dev)
+        self._sync_torch()
+        for ix, base in self.stripes:
+            h = torch.zeros(ix.n_colors, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            check(self.lib.cid_search_count_stripe_dev(self.ctx.h, ix.h, None if codes else vp(d_kmers.data_ptr()),
+                                                       vp(d_kmers.data_ptr()) if codes else None, K, base, vp(h.data_ptr()),
+                                                       vp(pop.data_ptr()), vp(cand.data_ptr())))
+            self.ctx.synchronize()
+            hits_full[base:base + ix.n_colors] = h
+        reduce_stripe_facts(pop, cand, hits_full)
+        nu = torch.zeros(self.n_colors, dtype=torch.int64, device=dev)
+        sf = torch.zeros(self.n_colors, dtype=torch.int64, device=dev)
+        uc = torch.empty(K, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        check(self.lib.cid_search_unique_finalize_dev(self.ctx.h, vp(pop.data_ptr()), vp(cand.data_ptr()),
+                                                      vp(d_freq.data_ptr()) if d_freq is not None else None, K,
+                                                      vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
+        self.ctx.synchronize()
+        return hits_full, nu, sf, uc
+
+    def search_perfect(self, d_kmers: torch.Tensor, w64_total: int, word_base_of, codes: bool = False):
+        """word_base_of(colour_base) -> index of the stripe's first u64 word in the full AND vector (colour_base // 64 when
+        every stripe starts on a multiple of 64).  Returns (and_words int64[w64_total], any_row_missing)."""
+        dev = d_kmers.device
+        K = d_kmers.shape[0]
+        zero_acc = torch.full((K,), -1, dtype=torch.int32, device=dev)
+        and_full = torch.full((w64_total,), -1, dtype=torch.int64, device=dev)
+        for ix, base in self.stripes:
+            rs = C_u64()
+            check(self.lib.cid_index_row_stride_words(ix.h, rs_ref(rs)))
+            w = torch.empty(rs.value, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            check(self.lib.cid_search_perfect_stripe_dev(self.ctx.h, ix.h, None if codes else vp(d_kmers.data_ptr()),
+                                                         vp(d_kmers.data_ptr()) if codes else None, K, vp(w.data_ptr()),
+                                                         vp(zero_acc.data_ptr())))
+            self.ctx.synchronize()
+            nw = (ix.n_colors + 63) // 64
+            b = word_base_of(base)
+            and_full[b:b + nw] = w[:nw]
+        zero_acc, and_full = reduce_perfect_facts(zero_acc, and_full)
+        seeds = (1 << self.n_hash) - 1 if self.n_hash < 32 else -1
+        missing = bool(((zero_acc & seeds) != 0).any().item()) if K else False
+        if missing:
+            and_full.zero_()
+        return and_full, missing
+
+    def _sync_torch(self):
+        torch.cuda.synchronize()
+
+
+def C_u64():
+    import ctypes
+    return ctypes.c_uint64(0)
+
+
+def rs_ref(x):
+    import ctypes
+    return ctypes.byref(x)

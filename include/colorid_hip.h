@@ -96,6 +96,21 @@ int cid_search_count_codes_dev(cid_ctx *, const cid_index *, const uint64_t *d_c
                                size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
                                uint32_t *d_unique_colour);
 
+/* ---- colour-striped indices: one cid_index per stripe of colours [colour_base, colour_base+n_colors)
+ *      of a wider index, on one GPU (more than 8192 colours) or one stripe per GPU (an index larger than one HBM).
+ *      Per-colour hits of a stripe are final.  "Exactly one colour hit" (batch_search_pe.rs:75-82) and "row absent"
+ *      (perfect_search.rs:31-39) need every stripe: each stripe call accumulates per-k-mer facts into caller arrays
+ *      (d_pop_total / d_cand: u32[n_kmers], zeroed before the first stripe; d_zero_acc: u32[n_kmers], preset to
+ *      0xFFFFFFFF), which are summed / MAX-ed / AND-ed across GPUs by the caller (RCCL) and then resolved by
+ *      cid_search_unique_finalize_dev, resp. by testing d_zero_acc != 0.  Exactly one of d_kmers / d_codes is given. ---- */
+int cid_search_count_stripe_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
+                                uint32_t colour_base, uint64_t *d_hits, uint32_t *d_pop_total, uint32_t *d_cand);
+int cid_search_unique_finalize_dev(cid_ctx *, const uint32_t *d_pop_total, const uint32_t *d_cand, const uint32_t *d_freq,
+                                   size_t n_kmers, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour);
+int cid_search_perfect_stripe_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
+                                  uint64_t *d_and_words /* row_stride_words u64 */, uint32_t *d_zero_acc);
+int cid_index_row_stride_words(const cid_index *, uint64_t *row_stride_words);
+
 /* ---- a10 (next row): canonical k-mer counting on the GPU for k_size <= 32 — replaces the
  *      FnvHashMap<String,usize> producers of `search`: kmerize_vector (src/kmer.rs:87-125, mode 0: has_no_n filter,
  *      orientation chosen on the raw bytes, then upper-cased) and the fastq bodies (src/kmer.rs:481-503 / :619-647,

@@ -1,0 +1,64 @@
+"""Colour-striped search on one GPU: an index split into 2-3 stripes (separate cid_index objects) must give exactly the
+whole-index results — per-colour hits, the exactly-one-colour statistics and the perfect-search AND / absent-row flag."""
+import numpy as np
+import pytest
+import torch
+
+from util import plant, random_index, random_kmers
+
+pytestmark = pytest.mark.gpu
+
+
+def stripe_indices(ctx, orc, oix, bounds):
+    import colorid_amd
+    rows = oix.rows()
+    out = []
+    for lo, hi in bounds:
+        assert lo % 64 == 0
+        nc = hi - lo
+        w32 = (nc + 31) // 32
+        sub = np.zeros((oix.m, w32), np.uint32)
+        src = rows[:, lo // 32:(hi + 31) // 32].copy()
+        if nc % 32:
+            src[:, -1] &= np.uint32((1 << (nc % 32)) - 1)
+        sub[:, :src.shape[1]] = src
+        hx = colorid_amd.Index(ctx, oix.m, oix.n_hash, oix.k, nc)
+        hx.put_dense(sub)
+        out.append((hx.finalize(), lo))
+    return out
+
+
+@pytest.mark.parametrize("n_colors,bounds", [(300, [(0, 128), (128, 300)]), (1000, [(0, 320), (320, 640), (640, 1000)]),
+                                              (130, [(0, 64), (64, 128), (128, 130)])])
+def test_striped_equals_whole(orc, hip_ctx, n_colors, bounds):
+    from colorid_amd.striped import StripedIndex
+    rng = np.random.default_rng(n_colors)
+    oix = random_index(orc, rng, 30_011, 3, 31, n_colors, density=0.02, zero_row_frac=0.3)
+    kmers = random_kmers(rng, 4000, 31)
+    plant(oix, rng, kmers, frac=0.8, max_colours=2)
+    for km in kmers[:300]:                                  # a perfect-search subset present in colours 1 and C-1
+        oix.insert(1, km.tobytes())
+        oix.insert(n_colors - 1, km.tobytes())
+    freq = rng.integers(1, 50, size=len(kmers)).astype(np.uint32)
+    stripes = stripe_indices(hip_ctx, orc, oix, bounds)
+    si = StripedIndex(hip_ctx, stripes, n_colors)
+    dk = torch.from_numpy(kmers.reshape(-1)).cuda().reshape(len(kmers), 31)
+    df = torch.from_numpy(freq.astype(np.int32)).cuda()
+    hits, nu, sf, uc = si.search_count(dk, df)
+    w = oix.search_count(kmers, freq.astype(np.uint64))
+    assert np.array_equal(hits.cpu().numpy().astype(np.uint64), w[0])
+    assert np.array_equal(nu.cpu().numpy().astype(np.uint64), w[1])
+    assert np.array_equal(sf.cpu().numpy().astype(np.uint64), w[2])
+    assert np.array_equal(uc.cpu().numpy().view(np.uint32), w[3])
+    assert w[1].sum() > 100                                  # unique hits that straddle stripe boundaries are exercised
+    # perfect search: present subset, then one with an absent row
+    w64_total = (n_colors + 63) // 64
+    for sel in (slice(0, 300), slice(0, 1000)):
+        sub = kmers[sel]
+        ds = torch.from_numpy(sub.reshape(-1)).cuda().reshape(len(sub), 31)
+        aw, missing = si.search_perfect(ds, w64_total, lambda base: base // 64)
+        pw, pm = oix.search_perfect(sub)
+        got32 = aw.cpu().numpy().view(np.uint32)[:oix.w32]
+        assert missing == pm and np.array_equal(got32, pw)
+    for hx, _ in stripes:
+        hx.close()
