@@ -357,7 +357,7 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t *w, uint32_t bit, uin
 constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained every 7 additions
 
 template <int LOG_LPR, bool NARROW>
-__global__ __launch_bounds__(kBlock) void k_readid(ReadIdParams p) {
+__global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
     constexpr int KPW = kWave / LPR;

@@ -19,6 +19,8 @@ u64p = C.POINTER(C.c_uint64)
 
 def build():
     """Compile the C restatement (gcc); no-op when liborc.so is newer than its sources."""
+    if os.environ.get("ORC_LIB"):  # e.g. liborc_asan.so (make -C oracle asan) under LD_PRELOAD=libasan
+        return os.environ["ORC_LIB"]
     so = os.path.join(_HERE, "liborc.so")
     srcs = [os.path.join(_HERE, f) for f in ("orc_xxh3.c", "orc_colorid.c", "orc.h")]
     if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
