@@ -64,6 +64,9 @@ hipStream_t ctx_stream(const cid_ctx *c) { return c->stream; }
 uint32_t index_k(const cid_index *ix) { return ix->k; }
 uint32_t index_rs(const cid_index *ix) { return ix->rs; }
 ModMagic index_mod(const cid_index *ix) { return ix->mod; }
+uint32_t index_n_colors(const cid_index *ix) { return ix->n_colors; }
+uint32_t index_n_hash(const cid_index *ix) { return ix->n_hash; }
+const uint64_t *index_matrix(const cid_index *ix) { return ix->mat; }
 }  // namespace cid
 
 namespace {
@@ -597,11 +600,13 @@ int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, cons
         if (bytes > max_bytes) max_bytes = bytes;
         if (win > max_win) max_win = win;
     }
-    {   // fail before any copy if the batch does not fit the kernel's LDS budget
+    bool long_path = false;
+    {   // reads whose k-mer set does not fit one wave's LDS go through the sort-based path (k <= 32, upper-case)
         cid::ReadIdParams probe;
         int waves;
         rc = readid_params(ix, stride_d, start_sample, max_bytes, max_win, probe, waves);
-        if (rc) return rc;
+        if (rc == CID_ERR_UNSUPPORTED) long_path = true;
+        else if (rc) return rc;
     }
     HIP_TRY(hipSetDevice(c->device));
     void *d_bases, *d_so, *d_r0, *d_rep, *d_nk;
@@ -614,8 +619,14 @@ int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, cons
     if (total_bases) HIP_TRY(hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    rc = cid_readid_count_dev(c, ix, (const uint8_t *)d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d,
-                              start_sample, max_bytes, max_win, (uint32_t *)d_rep, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4);
+    if (long_path) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = cid::readid_long(c, ix, (const uint8_t *)d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, (uint32_t *)d_rep,
+                              (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4);
+    } else {
+        rc = cid_readid_count_dev(c, ix, (const uint8_t *)d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d,
+                                  start_sample, max_bytes, max_win, (uint32_t *)d_rep, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4);
+    }
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(report, d_rep, n_reads * C1 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));

@@ -13,6 +13,13 @@ hipStream_t ctx_stream(const cid_ctx *c);
 uint32_t index_k(const cid_index *ix);
 uint32_t index_rs(const cid_index *ix);
 ModMagic index_mod(const cid_index *ix);
+uint32_t index_n_colors(const cid_index *ix);
+uint32_t index_n_hash(const cid_index *ix);
+const uint64_t *index_matrix(const cid_index *ix);
+
+// read_id for batches whose reads do not fit the LDS kernel (cid_kmerset.hip): sort-based per-read k-mer sets
+int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
+                size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status);
 
 // a5 / a4 on k-mers that are already on the device as 2-bit codes (k <= 32); outputs go to HOST buffers
 int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,

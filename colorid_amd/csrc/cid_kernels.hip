@@ -356,11 +356,64 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t *w, uint32_t bit, uin
 
 constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained every 7 additions
 
+
+// The in-order search over one chunk's distinct k-mers (bit kk of dmask = lane kk holds a distinct k-mer whose n row
+// numbers sit in ridx[s*64 + kk]); nd = distinct k-mers before this chunk == the reference's `counter`
+// (read_id_mt_pe.rs:66-102 classic / :104-165 sampled).  Shared by k_readid and k_readid_list.
+template <int LOG_LPR, bool NARROW>
+__device__ __forceinline__ void readid_search_chunk(const uint64_t *mat, uint32_t rs, uint32_t w64, uint32_t n, uint32_t C, uint32_t S,
+                                                    const uint32_t *ridx, uint32_t *hist, uint64_t dmask, uint32_t nd, bool &stopped,
+                                                    VCount<kReadPlanes, NARROW> &vc, V16 &R, int lane) {
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr int KPW = kWave / LPR;
+    if (stopped || !dmask) return;
+    const uint32_t col = lane & (LPR - 1);
+    const uint32_t col_word = NARROW ? 0u : 2u * col;
+    const bool col_live = col_word < w64;
+    const uint32_t seeds_mask = n >= 32 ? ~0u : ((1u << n) - 1u);
+#pragma unroll 1
+    for (int sub = 0; sub < LPR; ++sub) {
+        const uint64_t sub_bits = (KPW == 64) ? dmask : ((dmask >> (sub * KPW)) & ((1ull << (KPW & 63)) - 1ull));
+        if (!sub_bits) continue;
+        const int kk = sub * KPW + (lane >> LOG_LPR);
+        bool live = (dmask >> kk) & 1ull;
+        const uint32_t q = nd + (uint32_t)__popcll(dmask & ((1ull << kk) - 1ull));
+        V16 a{0, 0};
+        uint32_t zm = ~0u;
+        if (live && col_live) a = gather_and<NARROW, true>(mat, rs, ridx, kk, col_word, n, zm);
+        if constexpr (NARROW) a.y = 0;
+        uint32_t all_zero = zm;
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
+        const bool miss = live && (all_zero & seeds_mask);
+        const uint64_t bm = __ballot(miss);
+        // keep only the k-mers before the first absent row (lane order == k-mer order in a sub-pass)
+        if (bm) live = live && (lane >> LOG_LPR) < (__builtin_ctzll(bm) >> LOG_LPR);
+        if (!live) { a.x = 0; a.y = 0; }
+        if (S > 0) {
+            V16 ra = q < S ? a : V16{0, 0};
+#pragma unroll
+            for (int o = LPR; o < kWave; o <<= 1) {
+                ra.x |= __shfl_xor(ra.x, o, kWave);
+                ra.y |= __shfl_xor(ra.y, o, kWave);
+            }
+            R.x |= ra.x; R.y |= ra.y;
+            if (q >= S) { a.x &= R.x; a.y &= R.y; }
+        }
+        vc.add(a);
+        if (vc.full()) vc.drain(hist, col_word);
+        if (bm) {
+            stopped = true;
+            if (lane == 0) hist[C] += 1;  // *report.entry(no_hits_num) += 1; break
+            return;
+        }
+    }
+}
+
 template <int LOG_LPR, bool NARROW>
 __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
-    constexpr int KPW = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
@@ -386,8 +439,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
 
     const uint32_t col = lane & (LPR - 1);
     const uint32_t col_word = NARROW ? 0u : 2u * col;
-    const bool col_live = col_word < p.w64;
-    const uint32_t seeds_mask = n >= 32 ? ~0u : ((1u << n) - 1u);
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t tmask = p.table_slots - 1;
 
@@ -527,46 +578,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                 }
                 const uint64_t dmask = __ballot(distinct);
                 wave_lds_fence();
-                // ---- search (read_id_mt_pe.rs:66-102 / :104-165) over this chunk's distinct k-mers, in order
-                if (!stopped && dmask) {
-#pragma unroll 1
-                    for (int sub = 0; sub < LPR; ++sub) {
-                        const uint64_t sub_bits = (KPW == 64) ? dmask : ((dmask >> (sub * KPW)) & ((1ull << (KPW & 63)) - 1ull));
-                        if (!sub_bits) continue;
-                        const int kk = sub * KPW + (lane >> LOG_LPR);
-                        bool live = (dmask >> kk) & 1ull;
-                        const uint32_t q = nd + (uint32_t)__popcll(dmask & ((1ull << kk) - 1ull));
-                        V16 a{0, 0};
-                        uint32_t zm = ~0u;
-                        if (live && col_live) a = gather_and<NARROW, true>(p.mat, p.rs, ridx, kk, col_word, n, zm);
-                        if constexpr (NARROW) a.y = 0;
-                        uint32_t all_zero = zm;
-#pragma unroll
-                        for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
-                        const bool miss = live && (all_zero & seeds_mask);
-                        const uint64_t bm = __ballot(miss);
-                        // keep only the k-mers before the first absent row (lane order == k-mer order in a sub-pass)
-                        if (bm) live = live && (lane >> LOG_LPR) < (__builtin_ctzll(bm) >> LOG_LPR);
-                        if (!live) { a.x = 0; a.y = 0; }
-                        if (S > 0) {
-                            V16 ra = q < S ? a : V16{0, 0};
-#pragma unroll
-                            for (int o = LPR; o < kWave; o <<= 1) {
-                                ra.x |= __shfl_xor(ra.x, o, kWave);
-                                ra.y |= __shfl_xor(ra.y, o, kWave);
-                            }
-                            R.x |= ra.x; R.y |= ra.y;
-                            if (q >= S) { a.x &= R.x; a.y &= R.y; }
-                        }
-                        vc.add(a);
-                        if (vc.full()) vc.drain(hist, col_word);
-                        if (bm) {
-                            stopped = true;
-                            if (lane == 0) hist[C] += 1;  // *report.entry(no_hits_num) += 1; break
-                            break;
-                        }
-                    }
-                }
+                readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
                 nd += (uint32_t)__popcll(dmask);
             }
             wbase += nw;
@@ -575,6 +587,54 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
         wave_lds_fence();
         for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
+    }
+}
+
+
+// Long reads / contigs: the per-read k-mer set does not fit one wave's LDS, so it is built in HBM by a sort
+// (cid_readid_long.hip) and arrives here as, per read, its distinct canonical k-mers (2-bit codes, base 0 most
+// significant) in first-occurrence order.  Same search, same outputs as k_readid.
+template <int LOG_LPR, bool NARROW>
+__global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t C = p.n_colors, k = p.k, n = p.n_hash, S = p.start_sample;
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(smem + (size_t)wave * p.wave_bytes);
+    uint32_t *hist = ridx + kWave * n;
+    for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
+    const uint32_t col_word = NARROW ? 0u : 2u * (lane & ((1 << LOG_LPR) - 1));
+    for (uint64_t read = (uint64_t)blockIdx.x * waves + wave; read < p.n_reads; read += (uint64_t)gridDim.x * waves) {
+        wave_lds_fence();
+        uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
+        if (p.status[read] == 1) {  // too_short, decided on the host side of the call
+            for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+            if (lane == 0) p.n_kmers[read] = 0;
+            continue;
+        }
+        const uint64_t d0 = p.list_start[read], d1 = p.list_start[read + 1];
+        uint32_t nd = 0;
+        bool stopped = false;
+        VCount<kReadPlanes, NARROW> vc;
+        vc.clear();
+        V16 R{0, 0};
+        for (uint64_t c0 = d0; c0 < d1 && !stopped; c0 += kWave) {
+            const bool have = c0 + lane < d1;
+            wave_lds_fence();
+            if (have) {
+                const uint64_t lsb = rev_fields(p.list_codes[c0 + lane], k);
+                xxh3_seeds_from(CodeReader{lsb}, k, n, [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+            }
+            const uint64_t dmask = __ballot(have);
+            wave_lds_fence();
+            readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
+            nd += (uint32_t)__popcll(dmask);
+        }
+        vc.drain(hist, col_word);
+        wave_lds_fence();
+        for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        if (lane == 0) p.n_kmers[read] = (uint32_t)(d1 - d0);
     }
 }
 
@@ -726,6 +786,32 @@ hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t
     case 4: return launch_readid_one(k_readid<4, false>, p, waves_per_block, stream);
     case 5: return launch_readid_one(k_readid<5, false>, p, waves_per_block, stream);
     case 6: return launch_readid_one(k_readid<6, false>, p, waves_per_block, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename KernelT>
+static hipError_t launch_readid_list_one(KernelT kernel, const ReadIdListParams &p, int grid, hipStream_t stream) {
+    const size_t shmem = (size_t)(kBlock / kWave) * p.wave_bytes;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), shmem, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream) {
+    if (p.n_reads == 0) return hipSuccess;
+    if (p.rs == 1) return launch_readid_list_one(k_readid_list<0, true>, p, grid, stream);
+    switch (log2u(p.rs / 2)) {
+    case 0: return launch_readid_list_one(k_readid_list<0, false>, p, grid, stream);
+    case 1: return launch_readid_list_one(k_readid_list<1, false>, p, grid, stream);
+    case 2: return launch_readid_list_one(k_readid_list<2, false>, p, grid, stream);
+    case 3: return launch_readid_list_one(k_readid_list<3, false>, p, grid, stream);
+    case 4: return launch_readid_list_one(k_readid_list<4, false>, p, grid, stream);
+    case 5: return launch_readid_list_one(k_readid_list<5, false>, p, grid, stream);
+    case 6: return launch_readid_list_one(k_readid_list<6, false>, p, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -73,7 +73,22 @@ struct ReadIdParams {
     uint8_t *status;            // [n_reads]
 };
 
+struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in first-occurrence order
+    const uint64_t *mat;
+    uint32_t rs, w64, n_colors, n_hash, k;
+    ModMagic mod;
+    const uint64_t *list_codes;   // canonical 2-bit codes, base 0 most significant
+    const uint64_t *list_start;   // [n_reads+1] offsets into list_codes
+    uint64_t n_reads;
+    uint32_t start_sample;
+    uint32_t hist_pad, wave_bytes;
+    uint32_t *report;
+    uint32_t *n_kmers;
+    const uint8_t *status;        // 1 = too_short (set by the caller)
+};
+
 size_t search_smem_bytes(const SearchParams &p);
+hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream);
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream);
 hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
                                   uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour, hipStream_t stream);

@@ -17,11 +17,11 @@
 
 namespace cid {
 
-struct Segment {  // <= kSegWindows consecutive windows of one sequence
+struct Segment {  // consecutive windows of one sequence: window w starts at base_off + w*stride
     uint64_t base_off;  // offset of the first window's first base in `bases`
     uint64_t out_off;   // where the window codes go
-    uint32_t n_win;
-    uint32_t pad;
+    uint32_t n_win;     // (n_win-1)*stride + k <= kSegWindows + 31
+    uint32_t stride;
 };
 constexpr uint32_t kSegWindows = 2048;
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, con
     uint32_t *s_low = s_bad + (kBytes / 32 + 4);
     for (uint32_t sg = blockIdx.x * 4 + wave; sg < n_segs; sg += gridDim.x * 4) {
         const Segment seg = segs[sg];
-        const uint32_t nb = seg.n_win + k - 1;
+        const uint32_t nb = (seg.n_win - 1) * seg.stride + k;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         bool lower = false;
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, con
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint64_t mask = code_mask(k);
-        for (uint32_t w = lane; w < seg.n_win; w += 64) {
+        for (uint32_t wi = lane; wi < seg.n_win; wi += 64) {
+            const uint32_t w = wi * seg.stride;              // position of the window in the staged bases
             uint64_t result = sentinel;
             if (bits_at_dev(s_bad, w, k) == 0) {
                 const uint64_t lsb = bits_at_dev(s_pack, 2 * w, 2 * k);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, con
                 }
                 result = msb;
             }
-            out[seg.out_off + w] = result;
+            out[seg.out_off + wi] = result;
         }
     }
 }
@@ -244,6 +245,139 @@ int compact(cid_kmerset *ks) {
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------ long reads (read_id)
+// Per-read distinct k-mers in first-occurrence order for reads whose k-mer set does not fit a wave's LDS:
+// window codes -> one stable radix sort by code (windows are laid out read by read, so inside a run of equal codes
+// the entries of one read are adjacent and ascending) -> first-occurrence flags -> exclusive scan -> ordered lists.
+namespace cid {
+
+__device__ __forceinline__ uint32_t read_of_window(const uint64_t *wstart, uint32_t n_reads, uint64_t w) {
+    uint32_t lo = 0, hi = n_reads;  // largest r with wstart[r] <= w
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (wstart[mid] <= w) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ void k_iota_u32(uint32_t *p, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)i;
+}
+__global__ void k_first_flags(const uint64_t *sorted_codes, const uint32_t *sorted_idx, const uint64_t *wstart, uint32_t n_reads,
+                              uint64_t sentinel, uint32_t *flags, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t code = sorted_codes[i];
+    const uint32_t w = sorted_idx[i];
+    bool first = code != sentinel;
+    if (first && i > 0 && sorted_codes[i - 1] == code)
+        first = read_of_window(wstart, n_reads, sorted_idx[i - 1]) != read_of_window(wstart, n_reads, w);
+    flags[w] = first ? 1u : 0u;
+}
+__global__ void k_scatter_list(const uint64_t *codes, const uint32_t *flags, const uint32_t *pos, uint64_t *list, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) list[pos[i]] = codes[i];
+}
+__global__ void k_list_starts(const uint64_t *wstart, const uint32_t *pos, uint64_t *list_start, uint32_t n_reads) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_reads) list_start[r] = pos[wstart[r]];
+}
+
+// d_bases resident; host seq_off / read_seq0.  Writes report / n_kmers / status to DEVICE arrays.
+int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
+                size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status) {
+    const uint32_t k = index_k(ix);
+    if (k > 32) return fail(CID_ERR_UNSUPPORTED, "long reads need the packed path: k_size %u > 32", k);
+    hipStream_t st = ctx_stream(c);
+    const uint64_t sentinel = k < 32 ? (1ull << (2 * k)) : ~0ull;
+    const unsigned end_bit = k < 32 ? 2 * k + 1 : 64;
+    // windows are numbered read by read, mate by mate
+    std::vector<uint64_t> wstart(n_reads + 1, 0);
+    std::vector<uint8_t> status(n_reads, 0);
+    std::vector<Segment> segs;
+    const uint32_t seg_win = kSegWindows / stride_d ? kSegWindows / stride_d : 1;
+    uint64_t W = 0;
+    for (size_t r = 0; r < n_reads; ++r) {
+        wstart[r] = W;
+        const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
+        if (s1 == s0 || seq_off[s0 + 1] - seq_off[s0] < k) { status[r] = 1; continue; }   // too_short (first mate only)
+        for (uint64_t s = s0; s < s1; ++s) {
+            const uint64_t len = seq_off[s + 1] - seq_off[s];
+            if (len < k) continue;
+            const uint64_t nw = (len - k) / stride_d + 1;
+            for (uint64_t w0 = 0; w0 < nw; w0 += seg_win) {
+                const uint32_t m = (uint32_t)(nw - w0 < seg_win ? nw - w0 : seg_win);
+                segs.push_back(Segment{seq_off[s] + w0 * stride_d, W, m, stride_d});
+                W += m;
+            }
+        }
+    }
+    wstart[n_reads] = W;
+    if (W >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
+    const size_t C1 = (size_t)index_n_colors(ix) + 1;
+    HIP_TRY(hipMemcpyAsync(d_status, status.data(), n_reads, hipMemcpyHostToDevice, st));
+    DevBuf<uint64_t> d_wstart, d_codes, d_sorted, d_list, d_lstart;
+    DevBuf<uint32_t> d_idx, d_sidx, d_flags, d_pos;
+    DevBuf<Segment> d_segs;
+    DevBuf<int> d_lower;
+    int rc;
+    if ((rc = d_wstart.alloc(n_reads + 1)) || (rc = d_codes.alloc(W + 1)) || (rc = d_sorted.alloc(W + 1)) || (rc = d_idx.alloc(W + 1)) ||
+        (rc = d_sidx.alloc(W + 1)) || (rc = d_flags.alloc(W + 1)) || (rc = d_pos.alloc(W + 1)) || (rc = d_segs.alloc(segs.size())) ||
+        (rc = d_lstart.alloc(n_reads + 1)) || (rc = d_lower.alloc(4))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_wstart.p, wstart.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_lower.p, 0, 16, st));
+    HIP_TRY(hipMemsetAsync(d_flags.p, 0, (W + 1) * 4, st));
+    if (W) {
+        HIP_TRY(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice, st));
+        constexpr uint32_t kBytes = kSegWindows + 32 + 96;
+        const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
+        unsigned grid = (unsigned)((segs.size() + 3) / 4);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel,
+                           d_codes.p, d_lower.p);
+        hipLaunchKernelGGL(k_iota_u32, dim3(grid_for_n(W)), dim3(256), 0, st, d_idx.p, (uint64_t)W);
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, end_bit, st));
+        DevBuf<uint8_t> tmp;
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, end_bit, st));
+        hipLaunchKernelGGL(k_first_flags, dim3(grid_for_n(W)), dim3(256), 0, st, d_sorted.p, d_sidx.p, d_wstart.p, (uint32_t)n_reads,
+                           sentinel, d_flags.p, (uint64_t)W);
+        HIP_TRY(hipStreamSynchronize(st));
+        int lower = 0;
+        HIP_TRY(hipMemcpy(&lower, d_lower.p, 4, hipMemcpyDeviceToHost));
+        if (lower) return fail(CID_ERR_UNSUPPORTED, "long reads with lower-case bases are not supported (case-preserving k-mers cannot be packed)");
+    }
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, d_flags.p, d_pos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
+    DevBuf<uint8_t> tmp2;
+    if ((rc = tmp2.alloc(tb2))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp2.p, tb2, d_flags.p, d_pos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
+    uint32_t D = 0;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(&D, d_pos.p + W, 4, hipMemcpyDeviceToHost));
+    if ((rc = d_list.alloc(D))) return rc;
+    if (W) hipLaunchKernelGGL(k_scatter_list, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, d_flags.p, d_pos.p, d_list.p, (uint64_t)W);
+    hipLaunchKernelGGL(k_list_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, d_wstart.p, d_pos.p, d_lstart.p,
+                       (uint32_t)n_reads);
+    ReadIdListParams p{};
+    p.mat = index_matrix(ix); p.rs = index_rs(ix); p.w64 = (index_n_colors(ix) + 63) / 64; p.n_colors = index_n_colors(ix);
+    p.n_hash = index_n_hash(ix); p.k = k; p.mod = index_mod(ix);
+    p.list_codes = d_list.p; p.list_start = d_lstart.p; p.n_reads = n_reads; p.start_sample = start_sample;
+    p.hist_pad = (uint32_t)((C1 + 3) & ~(size_t)3);
+    p.wave_bytes = (uint32_t)((4ull * kWave * p.n_hash + 4ull * p.hist_pad + 15) & ~15ull);
+    if ((size_t)(kBlock / kWave) * p.wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
+    p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status;
+    uint64_t grid = (n_reads + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    HIP_TRY(launch_readid_list(p, (int)grid, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CID_OK;
+}
+
+}  // namespace cid
+
 extern "C" {
 
 int cid_kmerset_create(cid_ctx *c, uint32_t k_size, cid_kmerset **out) {
@@ -278,7 +412,7 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         const uint64_t nw = len - ks->k + 1;
         for (uint64_t w0 = 0; w0 < nw; w0 += cid::kSegWindows) {
             const uint32_t m = (uint32_t)(nw - w0 < cid::kSegWindows ? nw - w0 : cid::kSegWindows);
-            segs.push_back(cid::Segment{seq_off[s] + w0, ks->n_raw + n_win_total, m, 0});
+            segs.push_back(cid::Segment{seq_off[s] + w0, ks->n_raw + n_win_total, m, 1});
             n_win_total += m;
         }
     }

@@ -122,3 +122,22 @@ def test_readid_long_reads_and_empty(orc, phage):
     check(oix, hx, reads, 4, 0)
     rep, nk, st = hx.readid_count(np.zeros(0, np.uint8), np.zeros(1, np.uint64), np.zeros(1, np.uint64))
     assert rep.shape == (0, 5)
+
+
+@pytest.mark.parametrize("d,S", [(1, 3), (1, 0), (7, 2)])
+def test_readid_very_long_reads_sort_path(orc, phage, d, S):
+    """Reads whose k-mer set cannot live in one wave's LDS (whole phage genomes, a 150 kb chimera, repeats) take the
+    sort-based path; mixed with short reads in the same batch."""
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(d * 10 + S)
+    rnd = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 50_000)].tobytes()
+    chimera = genomes[0] + rnd[:20_000] + genomes[1][:30_000] + genomes[0][:5_000] + b"N" * 40 + genomes[3]
+    reads = [[genomes[2]], [chimera], [genomes[1][:40_000], genomes[1][10_000:45_000]],     # a long "pair" with shared k-mers
+             [genomes[0][100:250]], [b"ACG"], [b"A" * 30_000], [genomes[3][:20_000] * 3]]
+    check(oix, hx, reads, d, S)
+    bases, so, r0 = pack_reads([[(genomes[2] + genomes[1]).lower()]])
+    if d == 1:
+        with pytest.raises(Exception):  # lower-case bases in a read this long cannot be packed: refused, not mis-hashed
+            hx.readid_count(bases, so, r0, d, S)
+    else:                               # with -d 7 the same read fits the LDS kernel, whose byte path keeps the case
+        check(oix, hx, [[genomes[2][:20_000].lower()]], d, S)
