@@ -374,10 +374,12 @@ int cid_search_count_stripe_dev(cid_ctx *c, const cid_index *ix, const uint8_t *
 }
 
 int cid_search_unique_finalize_dev(cid_ctx *c, const uint32_t *d_pop_total, const uint32_t *d_cand, const uint32_t *d_freq,
-                                   size_t n_kmers, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
-    if (!c || (n_kmers && (!d_pop_total || !d_cand))) return fail(CID_ERR_INVALID, "null argument");
+                                   size_t n_kmers, uint32_t n_colors_total, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
+                                   uint32_t *d_unique_colour) {
+    if (!c || (n_kmers && (!d_pop_total || !d_cand)) || n_colors_total == 0) return fail(CID_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(cid::launch_unique_finalize(d_pop_total, d_cand, d_freq, n_kmers, d_n_unique, d_sum_unique_freq, d_unique_colour, c->stream));
+    HIP_TRY(cid::launch_unique_finalize(d_pop_total, d_cand, d_freq, n_kmers, n_colors_total, d_n_unique, d_sum_unique_freq,
+                                        d_unique_colour, c->stream));
     return CID_OK;
 }
 

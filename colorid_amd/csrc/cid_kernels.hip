@@ -639,24 +639,61 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
 }
 
 // Striped a5 epilogue: a k-mer hits exactly one colour of the WHOLE index iff the stripes' popcounts sum to 1.
-__global__ void k_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
-                                  uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_kmers) return;
-    if (pop_total[i] == 1u) {
-        const uint32_t c = cand[i];
-        if (unique_colour) unique_colour[i] = c;
-        if (n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&n_unique[c]), 1ull);
-        if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), (unsigned long long)(freq ? freq[i] : 1u));
-    } else if (unique_colour) {
-        unique_colour[i] = 0xFFFFFFFFu;
+// Per-block LDS histograms (when the whole colour range fits) keep the global atomics to one per colour per block.
+__global__ __launch_bounds__(256) void k_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq,
+                                                        uint64_t n_kmers, uint32_t n_colors_total, uint32_t use_lds, uint64_t per_block,
+                                                        uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    unsigned long long *s_sum = reinterpret_cast<unsigned long long *>(smem);
+    uint32_t *s_nu = reinterpret_cast<uint32_t *>(smem + 8ull * n_colors_total);
+    if (use_lds) {
+        for (uint32_t c = threadIdx.x; c < n_colors_total; c += blockDim.x) { s_sum[c] = 0; s_nu[c] = 0; }
+        __syncthreads();
+    }
+    const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
+    const uint64_t i1 = i0 + per_block < n_kmers ? i0 + per_block : n_kmers;
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        if (pop_total[i] == 1u) {
+            const uint32_t c = cand[i];
+            const unsigned long long f = freq ? freq[i] : 1u;
+            if (unique_colour) unique_colour[i] = c;
+            if (use_lds) {
+                atomicAdd(&s_nu[c], 1u);
+                atomicAdd(&s_sum[c], f);
+            } else {
+                if (n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&n_unique[c]), 1ull);
+                if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), f);
+            }
+        } else if (unique_colour) {
+            unique_colour[i] = 0xFFFFFFFFu;
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < n_colors_total; c += blockDim.x) {
+            const uint32_t u = s_nu[c];
+            if (!u) continue;
+            if (n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&n_unique[c]), (unsigned long long)u);
+            if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), s_sum[c]);
+        }
     }
 }
 
 hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
-                                  uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour, hipStream_t stream) {
+                                  uint32_t n_colors_total, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour,
+                                  hipStream_t stream) {
     if (n_kmers == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_unique_finalize, dim3((unsigned)((n_kmers + 255) / 256)), dim3(256), 0, stream, pop_total, cand, freq, n_kmers,
+    const size_t lds = 12ull * n_colors_total;
+    const uint32_t use_lds = lds <= 96u * 1024u ? 1u : 0u;
+    const size_t shmem = use_lds ? lds : 0;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_unique_finalize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    uint64_t per_block = (n_kmers + 4095) / 4096;
+    if (per_block < 4096) per_block = 4096;
+    const unsigned grid = (unsigned)((n_kmers + per_block - 1) / per_block);
+    hipLaunchKernelGGL(k_unique_finalize, dim3(grid), dim3(256), shmem, stream, pop_total, cand, freq, n_kmers, n_colors_total, use_lds, per_block,
                        n_unique, sum_unique_freq, unique_colour);
     return hipGetLastError();
 }

@@ -91,7 +91,8 @@ size_t search_smem_bytes(const SearchParams &p);
 hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream);
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream);
 hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
-                                  uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour, hipStream_t stream);
+                                  uint32_t n_colors_total, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour,
+                                  hipStream_t stream);
 int grid_for(uint64_t n_kmers, uint32_t tiles_per_block);
 hipError_t launch_search_count(const SearchParams &p, hipStream_t stream);
 hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream);

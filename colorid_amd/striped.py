@@ -74,7 +74,7 @@ class StripedIndex:
         uc = torch.empty(K, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
         check(self.lib.cid_search_unique_finalize_dev(self.ctx.h, vp(pop.data_ptr()), vp(cand.data_ptr()),
-                                                      vp(d_freq.data_ptr()) if d_freq is not None else None, K,
+                                                      vp(d_freq.data_ptr()) if d_freq is not None else None, K, self.n_colors,
                                                       vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
         self.ctx.synchronize()
         return hits_full, nu, sf, uc

@@ -106,7 +106,8 @@ int cid_search_count_codes_dev(cid_ctx *, const cid_index *, const uint64_t *d_c
 int cid_search_count_stripe_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
                                 uint32_t colour_base, uint64_t *d_hits, uint32_t *d_pop_total, uint32_t *d_cand);
 int cid_search_unique_finalize_dev(cid_ctx *, const uint32_t *d_pop_total, const uint32_t *d_cand, const uint32_t *d_freq,
-                                   size_t n_kmers, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour);
+                                   size_t n_kmers, uint32_t n_colors_total, uint64_t *d_n_unique /* n_colors_total, zeroed */,
+                                   uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour);
 int cid_search_perfect_stripe_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
                                   uint64_t *d_and_words /* row_stride_words u64 */, uint32_t *d_zero_acc);
 int cid_index_row_stride_words(const cid_index *, uint64_t *row_stride_words);

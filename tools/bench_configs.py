@@ -140,7 +140,7 @@ if "E" in only:
     def stripe():
         pop.zero_(); cand.zero_(); nu.zero_(); sf.zero_()
         check(hx.lib.cid_search_count_stripe_dev(ctx.h, hx.h, vp(kk.data_ptr()), None, K, 1024, vp(hits.data_ptr()), vp(pop.data_ptr()), vp(cand.data_ptr())))
-        check(hx.lib.cid_search_unique_finalize_dev(ctx.h, vp(pop.data_ptr()), vp(cand.data_ptr()), vp(ff.data_ptr()), K, vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
+        check(hx.lib.cid_search_unique_finalize_dev(ctx.h, vp(pop.data_ptr()), vp(cand.data_ptr()), vp(ff.data_ptr()), K, 4096, vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
     ms = timed(stripe, steps=5)
     want = None
     S = 200_000
