@@ -299,9 +299,20 @@ def cpu_baseline(a, hx, mat_ptr, kmers, freq, C, n, k, m, rs):
     dt = time.perf_counter() - t
     got = hx.search_count(hk, hf.astype(np.uint32))
     exact = all(np.array_equal(w, g) for w, g in zip(want, got))
+    # second figure, for honesty about the hardware rather than the reference: the same loop on every host core
+    ncpu = os.cpu_count() or 1
+    S2 = int(min(K, S * min(ncpu, 64)))
+    hk2 = kmers[:S2].cpu().numpy()
+    hf2 = freq[:S2].cpu().numpy().astype(np.uint64)
+    t = time.perf_counter()
+    want2 = oix.search_count_mt(hk2, hf2, ncpu)
+    dt2 = time.perf_counter() - t
+    got2 = hx.search_count(hk2, hf2.astype(np.uint32))
+    exact = exact and all(np.array_equal(w, g) for w, g in zip(want2, got2))
     base = {"value": S / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
             "sample": f"first {S} of the {K} query k-mers, same index copied to host; oracle/liborc.so "
-                      f"orc_search_count, 1 thread (reference `search` is single-threaded), {dt:.1f}s; host has {os.cpu_count()} cores"}
+                      f"orc_search_count, 1 thread (reference `search` is single-threaded), {dt:.1f}s; host has {ncpu} cores",
+            "all_cores": {"value": S2 / dt2, "cores": ncpu, "sample": f"first {S2} k-mers, orc_search_count_mt, {dt2:.1f}s"}}
     return base, bool(exact)
 
 

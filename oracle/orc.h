@@ -71,6 +71,9 @@ orc_index *orc_read_bigsi(const char *path);                                    
 /* batch_search_pe.rs:45-84 / 125-164.  unique_colour[i] = colour if hits.len()==1 else 0xFFFFFFFF (may be NULL) */
 void orc_search_count(const orc_index *, const uint8_t *kmers, const uint64_t *freq, uint64_t n_kmers,
                       uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
+/* the same loop over n_threads POSIX threads (the bench's "best-effort CPU" figure; the reference is single-threaded here) */
+void orc_search_count_mt(const orc_index *, const uint8_t *kmers, const uint64_t *freq, uint64_t n_kmers, int n_threads,
+                         uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
 /* perfect_search.rs:25-52: AND of all n*K rows; *missing = 1 iff some row is absent ("No perfect hits!") */
 void orc_search_perfect(const orc_index *, const uint8_t *kmers, uint64_t n_kmers, uint32_t *and_words, int *missing);
 /* read_id_mt_pe.rs:66-102 ; report has C+1 entries, [C] = no_hits_num */

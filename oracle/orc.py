@@ -78,6 +78,7 @@ def lib():
         "orc_save_bigsi": (C.c_int, [C.c_char_p, ip]),
         "orc_read_bigsi": (ip, [C.c_char_p]),
         "orc_search_count": (None, [ip, vp, vp, C.c_uint64, vp, vp, vp, vp]),
+        "orc_search_count_mt": (None, [ip, vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp]),
         "orc_search_perfect": (None, [ip, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
         "orc_search_index_classic": (None, [ip, vp, C.c_uint64, vp]),
         "orc_search_index": (None, [ip, vp, C.c_uint64, C.c_uint64, vp]),
@@ -274,6 +275,15 @@ class Index:
         sf = np.zeros(Cn, np.uint64)
         uc = np.zeros(K, np.uint32) if want_unique else None
         lib().orc_search_count(self.p, _ptr(kmers), _ptr(freq64), K, _ptr(hits), _ptr(nu), _ptr(sf), _ptr(uc))
+        return hits, nu, sf, uc
+
+    def search_count_mt(self, kmers: np.ndarray, freq, n_threads):
+        kmers = np.ascontiguousarray(kmers, np.uint8)
+        K = kmers.shape[0]
+        freq64 = None if freq is None else np.ascontiguousarray(freq, np.uint64)
+        hits, nu, sf = (np.zeros(self.n_colors, np.uint64) for _ in range(3))
+        uc = np.zeros(K, np.uint32)
+        lib().orc_search_count_mt(self.p, _ptr(kmers), _ptr(freq64), K, n_threads, _ptr(hits), _ptr(nu), _ptr(sf), _ptr(uc))
         return hits, nu, sf, uc
 
     def search_perfect(self, kmers: np.ndarray):

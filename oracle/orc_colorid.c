@@ -562,6 +562,45 @@ void orc_search_count(const orc_index *ix, const uint8_t *kmers, const uint64_t 
     free(first);
 }
 
+/* Best-effort CPU variant for the bench's second baseline figure (BASELINE.md §2 mode ii): the same loop, k-mers split
+ * over n_threads POSIX threads, per-thread counters summed at the end.  (The reference's `search` is single-threaded.) */
+#include <pthread.h>
+typedef struct {
+    const orc_index *ix; const uint8_t *kmers; const uint64_t *freq; uint64_t n;
+    uint64_t *hits, *nu, *sf; uint32_t *uc;
+} mt_job;
+static void *mt_run(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    orc_search_count(j->ix, j->kmers, j->freq, j->n, j->hits, j->nu, j->sf, j->uc);
+    return NULL;
+}
+void orc_search_count_mt(const orc_index *ix, const uint8_t *kmers, const uint64_t *freq, uint64_t n_kmers, int n_threads,
+                         uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    const uint64_t C = ix->n_colors;
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    mt_job *jobs = (mt_job *)calloc((size_t)n_threads, sizeof(mt_job));
+    uint64_t *buf = (uint64_t *)calloc((size_t)n_threads * 3 * C, sizeof(uint64_t));
+    for (int t = 0; t < n_threads; ++t) {
+        const uint64_t lo = n_kmers * (uint64_t)t / (uint64_t)n_threads, hi = n_kmers * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        jobs[t] = (mt_job){ix, kmers + lo * ix->k_size, freq ? freq + lo : NULL, hi - lo, buf + (size_t)t * 3 * C,
+                           buf + (size_t)t * 3 * C + C, buf + (size_t)t * 3 * C + 2 * C, unique_colour ? unique_colour + lo : NULL};
+        pthread_create(&th[t], NULL, mt_run, &jobs[t]);
+    }
+    memset(hits, 0, C * sizeof(uint64_t));
+    if (n_unique) memset(n_unique, 0, C * sizeof(uint64_t));
+    if (sum_unique_freq) memset(sum_unique_freq, 0, C * sizeof(uint64_t));
+    for (int t = 0; t < n_threads; ++t) {
+        pthread_join(th[t], NULL);
+        for (uint64_t c = 0; c < C; ++c) {
+            hits[c] += jobs[t].hits[c];
+            if (n_unique) n_unique[c] += jobs[t].nu[c];
+            if (sum_unique_freq) sum_unique_freq[c] += jobs[t].sf[c];
+        }
+    }
+    free(buf); free(jobs); free(th);
+}
+
 void orc_search_perfect(const orc_index *ix, const uint8_t *kmers, uint64_t n_kmers, uint32_t *and_words, int *missing) {
     /* perfect_search.rs:25-52 (and :83-110) */
     const uint64_t n = ix->num_hash, k = ix->k_size;
