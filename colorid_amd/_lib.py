@@ -52,6 +52,7 @@ SIGNATURES = {
     "cid_kmerset_download": (C.c_int, [vp, vp, vp]),
     "cid_kmerset_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "cid_kmerset_destroy": (None, [vp]),
+    "cid_index_insert_kmerset": (C.c_int, [vp, vp, C.c_uint32]),
     "cid_search_count_set": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "cid_search_perfect_set": (C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_int)]),
     "cid_readid_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp]),

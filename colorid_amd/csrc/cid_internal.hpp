@@ -17,6 +17,9 @@ uint32_t index_n_colors(const cid_index *ix);
 uint32_t index_n_hash(const cid_index *ix);
 const uint64_t *index_matrix(const cid_index *ix);
 
+// Bloom insert of 2-bit codes already on the device into one colour (build.rs:62-66 with the k-mer map on the GPU)
+int index_insert_codes(cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t colour);
+
 // read_id for batches whose reads do not fit the LDS kernel (cid_kmerset.hip): sort-based per-read k-mer sets
 int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                 size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status);

@@ -730,15 +730,24 @@ __global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
     unsigned int *mat32 = reinterpret_cast<unsigned int *>(p.mat);
     for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
         const uint64_t first = tile * kWave;
+        auto set_bit = [&](uint32_t c, uint64_t h) {
+            const uint64_t row = mod_m(h, p.mod);
+            atomicOr(&mat32[row * (2ull * p.rs) + (c >> 5)], 1u << (c & 31u));
+        };
+        if (p.codes) {
+            if (first + lane < p.n_kmers) {
+                const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
+                const uint64_t lsb = rev_fields(p.codes[first + lane], p.k);
+                if (c < p.n_colors) xxh3_seeds_from(CodeReader{lsb}, p.k, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
+            }
+            continue;
+        }
         wave_lds_fence();
         stage_kmers(img, p.kmers, p.n_kmers, first, p.k, lane);
         wave_lds_fence();
         if (first + lane < p.n_kmers) {
             const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-            if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, [&](uint32_t, uint64_t h) {
-                const uint64_t row = mod_m(h, p.mod);
-                atomicOr(&mat32[row * (2ull * p.rs) + (c >> 5)], 1u << (c & 31u));
-            });
+            if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
         }
     }
 }

@@ -48,7 +48,8 @@ struct InsertParams {
     uint32_t tiles_per_block;
     uint32_t colour;  // used when colour_of_kmer == nullptr
     ModMagic mod;
-    const uint8_t *kmers;
+    const uint8_t *kmers;       // ASCII, or nullptr when codes != nullptr
+    const uint64_t *codes;      // 2-bit canonical codes (k <= 32)
     const uint32_t *colour_of_kmer;
     uint64_t n_kmers;
 };

@@ -598,6 +598,12 @@ void cid_kmerset_destroy(cid_kmerset *ks) {
     delete ks;
 }
 
+int cid_index_insert_kmerset(cid_index *ix, const cid_kmerset *ks, uint32_t colour) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    return cid::index_insert_codes(ix, ks->codes, ks->n, ks->k, colour);
+}
+
 int cid_search_count_set(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks, uint64_t *hits, uint64_t *n_unique,
                          uint64_t *sum_unique_freq, uint32_t *unique_colour) {
     if (!ks) return fail(CID_ERR_INVALID, "null set");

@@ -177,20 +177,39 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
     uint32_t colour = 0, counter = 1;
     for (auto &kv : refs) {
         fprintf(stderr, "Adding %s to index (%u/%zu)\n", kv.first.c_str(), counter++, refs.size());
-        KmerMap km((uint32_t)k);
         const std::vector<std::string> &v = kv.second;
-        auto clean_reads = [&]() {
-            if (cutoff == -1) { const int64_t t = km.auto_cutoff(); if (t < 0) die("auto_cutoff: histogram too short"); km.clean((uint64_t)t); }
-            else km.clean((uint64_t)cutoff);
-        };
-        if (v.size() == 2) { kmers_fq_pe_qual(v[0], v[1], quality, km); clean_reads(); }
-        else if (v[0].size() >= 2 && v[0].compare(v[0].size() - 2, 2, "gz") == 0) { kmers_from_fq_qual(v[0], quality, km); clean_reads(); }
-        else {
-            kmerize_vector(read_fasta(v[0]), 1, km);
-            if (cutoff != -1) km.clean((uint64_t)cutoff);  // build.rs:86-91: FASTA is only cleaned with an explicit -f
+        const bool is_gz = v.size() == 2 || (v[0].size() >= 2 && v[0].compare(v[0].size() - 2, 2, "gz") == 0);
+        cid_kmerset *ks = nullptr;
+        if (gpu_counting_enabled(k))
+            ks = is_gz ? count_fastq_gpu(ctx, k, v[0], v.size() == 2 ? &v[1] : nullptr, quality) : count_fasta_gpu(ctx, k, read_fasta(v[0]));
+        if (ks) {  // the accession's k-mer map never leaves HBM: count, clean, Bloom-insert
+            if (is_gz) {
+                uint64_t t = (uint64_t)(cutoff < 0 ? 0 : cutoff);
+                if (cutoff == -1) { const int64_t a = auto_cutoff_gpu(ks); if (a < 0) die("auto_cutoff: histogram too short"); t = (uint64_t)a; }
+                CID_TRY(cid_kmerset_clean(ks, t));
+            } else if (cutoff != -1) {
+                CID_TRY(cid_kmerset_clean(ks, (uint64_t)cutoff));   // build.rs:86-91: FASTA is only cleaned with an explicit -f
+            }
+            uint64_t nk = 0;
+            CID_TRY(cid_kmerset_size(ks, &nk));
+            b.n_ref_kmers[colour] = nk;
+            CID_TRY(cid_index_insert_kmerset(b.index, ks, colour));
+            cid_kmerset_destroy(ks);
+        } else {
+            KmerMap km((uint32_t)k);
+            auto clean_reads = [&]() {
+                if (cutoff == -1) { const int64_t t = km.auto_cutoff(); if (t < 0) die("auto_cutoff: histogram too short"); km.clean((uint64_t)t); }
+                else km.clean((uint64_t)cutoff);
+            };
+            if (v.size() == 2) { kmers_fq_pe_qual(v[0], v[1], quality, km); clean_reads(); }
+            else if (is_gz) { kmers_from_fq_qual(v[0], quality, km); clean_reads(); }
+            else {
+                kmerize_vector(read_fasta(v[0]), 1, km);
+                if (cutoff != -1) km.clean((uint64_t)cutoff);
+            }
+            b.n_ref_kmers[colour] = km.size();
+            CID_TRY(cid_index_insert_kmers(b.index, km.keys(), colour, km.size()));
         }
-        b.n_ref_kmers[colour] = km.size();
-        CID_TRY(cid_index_insert_kmers(b.index, km.keys(), colour, km.size()));
         ++colour;
     }
     return b;

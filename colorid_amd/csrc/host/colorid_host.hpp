@@ -56,6 +56,13 @@ class LineReader {
     std::vector<char> buf_;
 };
 
+// GPU k-mer maps (cid_kmerset, k <= 32; COLORID_HOST_KMERS=1 forces the host map).  count_fastq_gpu returns nullptr when
+// the file holds lower-case bases (their case is kept, so they cannot be packed): the caller counts on the host.
+bool gpu_counting_enabled(uint64_t k);
+cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs);
+cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q);
+int64_t auto_cutoff_gpu(cid_kmerset *ks);   // kmer.rs:866-942 from the device histogram
+
 // ---------------------------------------------------------------- bigsi.rs
 struct Bigsi {  // BigsyMapNew minus the map, which lives on the device
     uint64_t bloom_size = 0, num_hash = 0, k_size = 0;

@@ -130,7 +130,8 @@ static void generate_report_gene(const std::string &query, const Bigsi &b, const
 // ---------------------------------------------------------------------------------------------- GPU k-mer counting
 //  k <= 32: the k-mer map is built and kept on the device; COLORID_HOST_KMERS=1 forces the host map.
 
-static bool gpu_counting(const Bigsi &b) { return b.k_size <= 32 && !getenv("COLORID_HOST_KMERS"); }
+bool gpu_counting_enabled(uint64_t k) { return k <= 32 && !getenv("COLORID_HOST_KMERS"); }
+static bool gpu_counting(const Bigsi &b) { return gpu_counting_enabled(b.k_size); }
 
 struct SeqBatch {
     std::vector<uint8_t> bases;
@@ -140,9 +141,9 @@ struct SeqBatch {
     void clear() { bases.clear(); off.assign(1, 0); }
 };
 
-static cid_kmerset *count_fasta_gpu(cid_ctx *ctx, const Bigsi &b, const std::vector<std::string> &seqs) {
+cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs) {
     cid_kmerset *ks = nullptr;
-    CID_TRY(cid_kmerset_create(ctx, (uint32_t)b.k_size, &ks));
+    CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
     SeqBatch sb;
     for (const std::string &s : seqs) sb.push(s);
     CID_TRY(cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 0));
@@ -151,9 +152,9 @@ static cid_kmerset *count_fasta_gpu(cid_ctx *ctx, const Bigsi &b, const std::vec
 }
 
 // fastq(.gz) SE or PE (kmer.rs:461-510 / :581-655); nullptr = the file holds lower-case bases: count it on the host
-static cid_kmerset *count_fastq_gpu(cid_ctx *ctx, const Bigsi &b, const std::string &f1, const std::string *f2, uint8_t q) {
+cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q) {
     cid_kmerset *ks = nullptr;
-    CID_TRY(cid_kmerset_create(ctx, (uint32_t)b.k_size, &ks));
+    CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
     LineReader r1(f1);
     LineReader *r2 = f2 ? new LineReader(*f2) : nullptr;
     SeqBatch sb;
@@ -185,7 +186,7 @@ static cid_kmerset *count_fastq_gpu(cid_ctx *ctx, const Bigsi &b, const std::str
     return ks;
 }
 
-static int64_t auto_cutoff_gpu(cid_kmerset *ks) {
+int64_t auto_cutoff_gpu(cid_kmerset *ks) {
     size_t nb = 0;
     CID_TRY(cid_kmerset_count_histogram(ks, nullptr, nullptr, 0, &nb));
     std::vector<uint32_t> mult(nb);
@@ -224,7 +225,7 @@ void perfect_search::batch_search(cid_ctx *ctx, const std::vector<std::string> &
     for (const std::string &file : files) {
         fprintf(stderr, "Counting k-mers, this may take a while!\n");
         if (gpu_counting(b)) {
-            cid_kmerset *ks = count_fasta_gpu(ctx, b, read_fasta(file));
+            cid_kmerset *ks = count_fasta_gpu(ctx, b.k_size, read_fasta(file));
             uint64_t n = 0;
             CID_TRY(cid_kmerset_size(ks, &n));
             fprintf(stderr, "%llu kmers in query\n", (unsigned long long)n);
@@ -289,8 +290,8 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
         size_t n_kmers = 0;
         cid_kmerset *ks = nullptr;
         if (gpu_counting(b)) {
-            ks = gz ? count_fastq_gpu(ctx, b, file1, files2.empty() ? nullptr : &files2[i], qual_offset)
-                    : count_fasta_gpu(ctx, b, read_fasta(file1));
+            ks = gz ? count_fastq_gpu(ctx, b.k_size, file1, files2.empty() ? nullptr : &files2[i], qual_offset)
+                    : count_fasta_gpu(ctx, b.k_size, read_fasta(file1));
         }
         if (ks) {  // the k-mer map lives on the device
             uint64_t t = fasta_gene ? 0 : (uint64_t)(filter < 0 ? 0 : filter);

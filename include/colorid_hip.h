@@ -134,6 +134,9 @@ int cid_kmerset_order_for_index(cid_kmerset *, const cid_index *);
 int cid_kmerset_download(const cid_kmerset *, uint8_t *kmers_ascii, uint32_t *counts);
 int cid_kmerset_device_arrays(const cid_kmerset *, void **d_codes, void **d_counts, uint64_t *n_distinct);
 void cid_kmerset_destroy(cid_kmerset *);
+/* Bloom insert of a whole finalized set into one colour: one accession of `build` without the k-mers leaving HBM
+ * (src/build.rs:54-99 with the map on the GPU). */
+int cid_index_insert_kmerset(cid_index *, const cid_kmerset *, uint32_t colour);
 /* a5 / a4 over a finalized set (results in set order; unique_colour has n_distinct entries). */
 int cid_search_count_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
                          uint64_t *sum_unique_freq, uint32_t *unique_colour);

@@ -48,7 +48,32 @@ def test_build_writes_identical_bxi(env, tmp_path):
     d, bxi, oix, _ = env
     ref = str(tmp_path / "oracle.bxi")
     oix.save(ref)
-    assert open(bxi, "rb").read() == open(ref, "rb").read()
+    assert open(bxi, "rb").read() == open(ref, "rb").read()          # k-mer maps counted on the GPU (default)
+    run("build", "-s", "750000", "-n", "4", "-k", "27", "-b", str(tmp_path / "hostmap"), "-r", str(d / "ref_file.txt"), host_kmers=True)
+    assert open(tmp_path / "hostmap.bxi", "rb").read() == open(ref, "rb").read()
+
+
+def test_build_from_fastq_accessions(orc, env, tmp_path):
+    """build.rs:54-84: paired and single fastq.gz accessions with -f (explicit) and the auto cutoff, next to a FASTA one."""
+    d, _, _, genomes = env
+    rng = np.random.default_rng(3)
+    r1 = synth_fastq_records(rng, [genomes[0][:4000]], 2500, 120, mate=0, lower_rate=0.0)
+    rng = np.random.default_rng(3)
+    r2 = synth_fastq_records(rng, [genomes[0][:4000]], 2500, 120, mate=1, lower_rate=0.0)
+    f1, f2, f3 = str(tmp_path / "a_1.fastq.gz"), str(tmp_path / "a_2.fastq.gz"), str(tmp_path / "b.fastq.gz")
+    write_fastq_gz(f1, r1); write_fastq_gz(f2, r2); write_fastq_gz(f3, r1[:1500])
+    tsv = tmp_path / "refs.tsv"
+    tsv.write_text(f"pe_sample\t{f1}\t{f2}\nse_sample\t{f3}\nphage\t{os.path.join(REFS, PHAGES[1] + '.fasta')}\n")
+    for flt in ([], ["-f", "2"]):
+        pre = str(tmp_path / ("idx" + "".join(flt)))
+        run("build", "-s", "200003", "-n", "3", "-k", "21", "-b", pre, "-r", str(tsv), *flt)
+        oix = orc.Index.build_single(str(tsv), 200003, 3, 21, 15, int(flt[1]) if flt else -1)
+        ref = pre + "_oracle.bxi"
+        oix.save(ref)
+        assert open(pre + ".bxi", "rb").read() == open(ref, "rb").read()
+        nref = dict(zip(oix.colors(), oix.n_ref_kmers()))
+        assert nref["pe_sample"] > 1000 and nref["se_sample"] > 1000
+        assert (nref["phage"] == 0) == bool(flt)      # an explicit -f 2 empties a single-copy FASTA accession (build.rs:89-91)
 
 
 @pytest.mark.parametrize("host_kmers", [False, True])
