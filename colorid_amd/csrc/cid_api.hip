@@ -108,6 +108,10 @@ int fill_search_params(const cid_ctx *c, const cid_index *ix, cid::SearchParams 
     if (p.c_pad < 2) p.c_pad = 2;
     p.wave_bytes = cid::kmer_img_bytes(ix->k) + cid::kWave * ix->n_hash * 4u;
     p.wave_bytes = (p.wave_bytes + 15u) & ~15u;
+    if (ix->rs > 128) {  // wide rows: no block histogram; the perfect search keeps a per-wave AND accumulator of rs words
+        p.c_pad = 0;
+        p.wave_bytes += 8u * ix->rs;
+    }
     p.mod = ix->mod;
     if (cid::search_smem_bytes(p) > 160u * 1024u)
         return fail(CID_ERR_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB (n_colors=%u k=%u n_hash=%u)",
@@ -199,7 +203,7 @@ int cid_index_create(cid_ctx *c, uint64_t bloom_size, uint32_t num_hash, uint32_
     if (k_size > cid::kMaxK) return fail(CID_ERR_UNSUPPORTED, "k_size %u > %u", k_size, cid::kMaxK);
     if (num_hash > 32) return fail(CID_ERR_UNSUPPORTED, "num_hash %u > 32", num_hash);
     if (bloom_size > (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "bloom_size %llu > 2^32", (unsigned long long)bloom_size);
-    if (n_colors > 8192) return fail(CID_ERR_UNSUPPORTED, "n_colors %u > 8192 per index stripe", n_colors);
+    if (n_colors > (1u << 20)) return fail(CID_ERR_UNSUPPORTED, "n_colors %u > 2^20", n_colors);
     cid_index *ix = new (std::nothrow) cid_index();
     if (!ix) return fail(CID_ERR_NOMEM, "index");
     ix->ctx = c;
@@ -548,7 +552,7 @@ static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_
     p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
     p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
     if (p.win_cap < 4) p.win_cap = 4;
-    p.hist_pad = (ix->n_colors + 1 + 3) & ~3u;
+    p.hist_pad = ix->rs > 128 ? 4u * ix->rs : ((ix->n_colors + 1 + 3) & ~3u);   // wide rows: AND word + sampled-colour set
     p.table_slots = 64;
     while (p.table_slots < p.win_cap + p.win_cap / 2) p.table_slots <<= 1;
     // key region: the larger of the byte-string layout (tags, window infos, k-mer image) and the packed layout
@@ -587,6 +591,7 @@ int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases
     if (rpb < (uint64_t)waves) rpb = waves;
     if (rpb > 256) rpb = 256;
     p.reads_per_block = (uint32_t)rpb;
+    if (ix->rs > 128) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * ((size_t)ix->n_colors + 1) * 4, c->stream));  // wide rows count in place
     HIP_TRY(cid::launch_readid(p, waves, c->stream));
     return CID_OK;
 }

@@ -30,10 +30,12 @@ inline ModMagicHost make_mod_magic(uint64_t m) {
     return mm;
 }
 
-// u64 words per matrix row: 1 for <= 64 colours, else the next power of two >= ceil(C/64) (>= 2).
+// u64 words per matrix row: 1 for <= 64 colours, else the next power of two >= ceil(C/64) (2..128 words); beyond
+// 8192 colours ("wide" rows) a multiple of 128 words = whole KiB, covered by one wave in rs/128 steps.
 inline uint32_t row_stride_words(uint32_t n_colors) {
     const uint32_t w64 = (n_colors + 63u) / 64u;
     if (w64 <= 1) return 1;
+    if (w64 > 128) return (w64 + 127u) / 128u * 128u;
     uint32_t rs = 2;
     while (rs < w64) rs <<= 1;
     return rs;

@@ -320,6 +320,149 @@ __global__ __launch_bounds__(kBlock) void k_search_perfect(SearchParams p) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Wide rows (more than 8192 colours; rs = a multiple of 128 words): a whole wave covers one row, 1 KiB per step, one
+// k-mer at a time.  These kernels stream KiBs per k-mer, so per-colour results go straight to global atomics.
+
+__device__ __forceinline__ uint32_t wave_and_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) v &= __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_search_count_wide(SearchParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    uint8_t *wbase = smem + (size_t)wave * p.wave_bytes;
+    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
+    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
+    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
+    const uint32_t steps = p.rs / 128u;
+    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
+        const uint64_t first = tile * kWave;
+        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
+        const uint32_t cnt = p.n_kmers - first < (uint64_t)kWave ? (uint32_t)(p.n_kmers - first) : (uint32_t)kWave;
+        for (uint32_t kk = 0; kk < cnt; ++kk) {
+            const uint64_t kmer = first + kk;
+            uint32_t mine = 0, ucol = 0;
+            for (uint32_t j = 0; j < steps; ++j) {
+                const uint32_t col_word = 128u * j + 2u * lane;
+                if (col_word >= p.w64) continue;
+                uint32_t zm;
+                const V16 a = gather_and<false, false>(p.mat, p.rs, ridx, (int)kk, col_word, p.n_hash, zm);
+                const uint32_t pc = (uint32_t)(__popcll(a.x) + __popcll(a.y));
+                if (!pc) continue;
+                mine += pc;
+                ucol = a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x) : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y);
+                uint64_t w = a.x;
+                while (w) { atomicAdd(reinterpret_cast<unsigned long long *>(&p.hits[col_word * 64u + (uint32_t)__builtin_ctzll(w)]), 1ull); w &= w - 1; }
+                w = a.y;
+                while (w) { atomicAdd(reinterpret_cast<unsigned long long *>(&p.hits[col_word * 64u + 64u + (uint32_t)__builtin_ctzll(w)]), 1ull); w &= w - 1; }
+            }
+            if (p.want_unique) {
+                const uint32_t total = wave_sum_u32(mine);
+                if (total == 1u) {
+                    if (mine == 1u) {
+                        if (p.n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&p.n_unique[ucol]), 1ull);
+                        if (p.sum_unique_freq)
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&p.sum_unique_freq[ucol]), (unsigned long long)(p.freq ? p.freq[kmer] : 1u));
+                        if (p.unique_colour) p.unique_colour[kmer] = ucol;
+                    }
+                } else if (lane == 0 && p.unique_colour) {
+                    p.unique_colour[kmer] = 0xFFFFFFFFu;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_search_perfect_wide(SearchParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    uint8_t *wbase = smem + (size_t)wave * p.wave_bytes;
+    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
+    uint64_t *s_and = reinterpret_cast<uint64_t *>(wbase + ((kmer_img_bytes(p.k) + 4u * kWave * p.n_hash + 15u) & ~15u));  // [rs] per wave
+    for (uint32_t w = lane; w < p.rs; w += kWave) s_and[w] = ~0ull;
+    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
+    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
+    const uint32_t steps = p.rs / 128u;
+    const uint32_t seeds = p.n_hash >= 32 ? ~0u : ((1u << p.n_hash) - 1u);
+    uint32_t missing = 0;
+    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
+        const uint64_t first = tile * kWave;
+        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
+        const uint32_t cnt = p.n_kmers - first < (uint64_t)kWave ? (uint32_t)(p.n_kmers - first) : (uint32_t)kWave;
+        for (uint32_t kk = 0; kk < cnt; ++kk) {
+            uint32_t zml = ~0u;
+            for (uint32_t j = 0; j < steps; ++j) {
+                const uint32_t col_word = 128u * j + 2u * lane;
+                if (col_word >= p.w64) continue;
+                uint32_t zm;
+                const V16 a = gather_and<false, true>(p.mat, p.rs, ridx, (int)kk, col_word, p.n_hash, zm);
+                s_and[col_word] &= a.x;       // lane-owned words: plain read-modify-write
+                s_and[col_word + 1] &= a.y;
+                zml &= zm;
+            }
+            if (wave_and_u32(zml) & seeds) missing = 1;   // a row is absent iff it is zero in every step of every lane
+        }
+    }
+    wave_lds_fence();
+    for (uint32_t w = lane; w < p.w64; w += kWave) atomicAnd(reinterpret_cast<unsigned long long *>(&p.and_words[w]), (unsigned long long)s_and[w]);
+    if (missing && lane == 0) atomicOr(p.missing, 1);
+}
+
+// read_id over wide rows: the chunk's distinct k-mers one at a time, in order; counts go straight to the (pre-zeroed)
+// report row.  s_words / s_R: rs u64 words each per wave (the AND word of the current k-mer, the colours of the first S).
+__device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, uint32_t rs, uint32_t w64, uint32_t n, uint32_t C, uint32_t S,
+                                                         const uint32_t *ridx, uint64_t *s_words, uint64_t *s_R, uint32_t *row_out,
+                                                         uint64_t dmask, uint32_t nd, bool &stopped, int lane) {
+    if (stopped || !dmask) return;
+    const uint32_t steps = rs / 128u;
+    const uint32_t seeds = n >= 32 ? ~0u : ((1u << n) - 1u);
+    uint32_t q = nd;
+    for (uint64_t dm = dmask; dm; dm &= dm - 1, ++q) {
+        const int kk = __builtin_ctzll(dm);
+        uint32_t zml = ~0u;
+        for (uint32_t j = 0; j < steps; ++j) {
+            const uint32_t col_word = 128u * j + 2u * lane;
+            if (col_word >= w64) continue;
+            uint32_t zm;
+            const V16 a = gather_and<false, true>(mat, rs, ridx, kk, col_word, n, zm);
+            s_words[col_word] = a.x;
+            s_words[col_word + 1] = a.y;
+            zml &= zm;
+        }
+        if (wave_and_u32(zml) & seeds) {  // absent row: *report.entry(no_hits_num) += 1; break
+            if (lane == 0) atomicAdd(&row_out[C], 1u);
+            stopped = true;
+            return;
+        }
+        for (uint32_t j = 0; j < steps; ++j) {
+            const uint32_t col_word = 128u * j + 2u * lane;
+            if (col_word >= w64) continue;
+            uint64_t x = s_words[col_word], y = s_words[col_word + 1];
+            if (S > 0) {
+                if (q < S) { s_R[col_word] |= x; s_R[col_word + 1] |= y; }
+                else { x &= s_R[col_word]; y &= s_R[col_word + 1]; }
+            }
+            while (x) { atomicAdd(&row_out[col_word * 64u + (uint32_t)__builtin_ctzll(x)], 1u); x &= x - 1; }
+            while (y) { atomicAdd(&row_out[col_word * 64u + 64u + (uint32_t)__builtin_ctzll(y)], 1u); y &= y - 1; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a6/a7/a9/a10: per-read classification counts (src/read_id_mt_pe.rs:300-331).  One wave per read(-pair):
 //   windows with stride d -> seq::has_no_n filter -> canonical choice on raw bytes (src/kmer.rs:221-243)
@@ -410,7 +553,7 @@ __device__ __forceinline__ void readid_search_chunk(const uint64_t *mat, uint32_
     }
 }
 
-template <int LOG_LPR, bool NARROW>
+template <int LOG_LPR, bool NARROW, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
@@ -451,7 +594,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
         const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
         uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
         if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
-            for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+            if constexpr (!WIDE)  // (wide rows: the host zeroes the whole report before the launch)
+                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 1; }
             continue;
         }
@@ -492,6 +636,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
         VCount<kReadPlanes, NARROW> vc;
         vc.clear();
         V16 R{0, 0};           // colours seen in the first S k-mers (this lane's slice)
+        if constexpr (WIDE) {
+            uint64_t *s_R = reinterpret_cast<uint64_t *>(hist) + p.rs;
+            for (uint32_t w = lane; w < p.rs; w += kWave) s_R[w] = 0;
+            wave_lds_fence();
+        }
 
         for (uint64_t s = s0; s < s1; ++s) {
             const uint32_t off = (uint32_t)(p.seq_off[s] - g0);
@@ -578,14 +727,21 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                 }
                 const uint64_t dmask = __ballot(distinct);
                 wave_lds_fence();
-                readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
+                if constexpr (WIDE) {
+                    uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
+                    readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
+                } else {
+                    readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
+                }
                 nd += (uint32_t)__popcll(dmask);
             }
             wbase += nw;
         }
-        vc.drain(hist, col_word);
-        wave_lds_fence();
-        for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        if constexpr (!WIDE) {
+            vc.drain(hist, col_word);
+            wave_lds_fence();
+            for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        }
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
 }
@@ -594,7 +750,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
 // Long reads / contigs: the per-read k-mer set does not fit one wave's LDS, so it is built in HBM by a sort
 // (cid_readid_long.hip) and arrives here as, per read, its distinct canonical k-mers (2-bit codes, base 0 most
 // significant) in first-occurrence order.  Same search, same outputs as k_readid.
-template <int LOG_LPR, bool NARROW>
+template <int LOG_LPR, bool NARROW, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -609,7 +765,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
         wave_lds_fence();
         uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
         if (p.status[read] == 1) {  // too_short, decided on the host side of the call
-            for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+            if constexpr (!WIDE)
+                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) p.n_kmers[read] = 0;
             continue;
         }
@@ -619,6 +776,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
         VCount<kReadPlanes, NARROW> vc;
         vc.clear();
         V16 R{0, 0};
+        if constexpr (WIDE) {
+            uint64_t *s_R = reinterpret_cast<uint64_t *>(hist) + p.rs;
+            for (uint32_t w = lane; w < p.rs; w += kWave) s_R[w] = 0;
+            wave_lds_fence();
+        }
         for (uint64_t c0 = d0; c0 < d1 && !stopped; c0 += kWave) {
             const bool have = c0 + lane < d1;
             wave_lds_fence();
@@ -628,12 +790,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
             }
             const uint64_t dmask = __ballot(have);
             wave_lds_fence();
-            readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
+            if constexpr (WIDE) {
+                uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
+                readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
+            } else {
+                readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
+            }
             nd += (uint32_t)__popcll(dmask);
         }
-        vc.drain(hist, col_word);
-        wave_lds_fence();
-        for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        if constexpr (!WIDE) {
+            vc.drain(hist, col_word);
+            wave_lds_fence();
+            for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        }
         if (lane == 0) p.n_kmers[read] = (uint32_t)(d1 - d0);
     }
 }
@@ -791,6 +960,10 @@ int grid_for(uint64_t n_kmers, uint32_t tiles_per_block) {
 }
 
 hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
+    if (p.rs > 128) {
+        const int g = grid_for(p.n_kmers, p.tiles_per_block);
+        return g ? launch_one(k_search_count_wide, g, (size_t)(kBlock / kWave) * p.wave_bytes, stream, p) : hipSuccess;
+    }
     const bool narrow = p.rs == 1;
     const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
     const size_t shmem = search_smem_bytes(p);
@@ -800,6 +973,10 @@ hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
 }
 
 hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {
+    if (p.rs > 128) {
+        const int g = grid_for(p.n_kmers, p.tiles_per_block);
+        return g ? launch_one(k_search_perfect_wide, g, (size_t)(kBlock / kWave) * p.wave_bytes, stream, p) : hipSuccess;
+    }
     const bool narrow = p.rs == 1;
     const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
     const size_t shmem = search_smem_bytes(p);
@@ -823,6 +1000,7 @@ static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int w
 }
 
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
+    if (p.rs > 128) return launch_readid_one(k_readid<0, false, true>, p, waves_per_block, stream);
     if (p.rs == 1) return launch_readid_one(k_readid<0, true>, p, waves_per_block, stream);
     switch (log2u(p.rs / 2)) {
     case 0: return launch_readid_one(k_readid<0, false>, p, waves_per_block, stream);
@@ -849,6 +1027,7 @@ static hipError_t launch_readid_list_one(KernelT kernel, const ReadIdListParams 
 
 hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream) {
     if (p.n_reads == 0) return hipSuccess;
+    if (p.rs > 128) return launch_readid_list_one(k_readid_list<0, false, true>, p, grid, stream);
     if (p.rs == 1) return launch_readid_list_one(k_readid_list<0, true>, p, grid, stream);
     switch (log2u(p.rs / 2)) {
     case 0: return launch_readid_list_one(k_readid_list<0, false>, p, grid, stream);

@@ -365,7 +365,8 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     p.mat = index_matrix(ix); p.rs = index_rs(ix); p.w64 = (index_n_colors(ix) + 63) / 64; p.n_colors = index_n_colors(ix);
     p.n_hash = index_n_hash(ix); p.k = k; p.mod = index_mod(ix);
     p.list_codes = d_list.p; p.list_start = d_lstart.p; p.n_reads = n_reads; p.start_sample = start_sample;
-    p.hist_pad = (uint32_t)((C1 + 3) & ~(size_t)3);
+    p.hist_pad = p.rs > 128 ? 4u * p.rs : (uint32_t)((C1 + 3) & ~(size_t)3);
+    if (p.rs > 128) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, st));   // wide rows count in place
     p.wave_bytes = (uint32_t)((4ull * kWave * p.n_hash + 4ull * p.hist_pad + 15) & ~15ull);
     if ((size_t)(kBlock / kWave) * p.wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
     p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status;

@@ -31,7 +31,7 @@ extern "C" {
 #define CID_ERR_INVALID (-1)     /* bad argument */
 #define CID_ERR_HIP (-2)         /* HIP runtime error / no device */
 #define CID_ERR_NOMEM (-3)
-#define CID_ERR_UNSUPPORTED (-4) /* e.g. k_size > 128, n_colors > 8192, bloom_size > 2^32 */
+#define CID_ERR_UNSUPPORTED (-4) /* e.g. k_size > 128, bloom_size > 2^32 */
 #define CID_ERR_STATE (-5)       /* e.g. search on an index that is not finalized */
 
 /* Hash variants.  The reference calls xxh3::hash64_with_seed(kmer, i) % bloom_size

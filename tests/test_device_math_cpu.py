@@ -60,7 +60,7 @@ def test_device_mod_is_exact(shim):
 
 def test_row_stride_rule(shim):
     want = {1: 1, 4: 1, 46: 1, 64: 1, 65: 2, 128: 2, 129: 4, 255: 4, 256: 4, 257: 8, 512: 8, 1024: 16, 1025: 32,
-            4096: 64, 8192: 128}
+            4096: 64, 8192: 128, 8193: 256, 16384: 256, 16385: 384, 20000: 384, 65536: 1024}
     for c, rs in want.items():
         assert shim.shim_row_stride_words(c) == rs
 

@@ -95,7 +95,8 @@ def test_readid_phage(orc, phage, paired, d, S):
 
 
 @pytest.mark.parametrize("n_colors,n_hash,k,m", [(46, 4, 31, 200_003), (256, 2, 21, 1 << 18), (300, 3, 21, 50_021),
-                                                 (1024, 4, 31, 20_011), (64, 1, 15, 9_973), (4096, 2, 25, 3_001)])
+                                                 (1024, 4, 31, 20_011), (64, 1, 15, 9_973), (4096, 2, 25, 3_001),
+                                                 (10_000, 2, 21, 2_003)])
 def test_readid_layouts(orc, hip_ctx, n_colors, n_hash, k, m):
     rng = np.random.default_rng(n_colors + k)
     oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.05, zero_row_frac=0.02)
@@ -141,3 +142,22 @@ def test_readid_very_long_reads_sort_path(orc, phage, d, S):
             hx.readid_count(bases, so, r0, d, S)
     else:                               # with -d 7 the same read fits the LDS kernel, whose byte path keeps the case
         check(oix, hx, [[genomes[2][:20_000].lower()]], d, S)
+
+
+def test_readid_wide_rows_long_reads(orc, hip_ctx):
+    """more than 8192 colours AND reads too long for the LDS kernel: k_readid_list over 1-KiB row steps"""
+    rng = np.random.default_rng(99)
+    n_colors, n_hash, k, m = 9000, 2, 21, 4_001
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.01, zero_row_frac=0.02)
+    g = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 60_000)].tobytes()
+    km = orc.Kmers(k)
+    km.kmerize_vector(g[:50_000], 1)
+    for key in km.keys():
+        oix.insert(7, key.tobytes())
+        oix.insert(8999, key.tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    reads = [[g[:45_000]], [g[30_000:60_000], g[:20_000]], [g[100:250]], [b"AC"]]
+    for d, S in ((1, 3), (1, 0), (3, 1)):
+        rep, nk, st = check(oix, hx, reads, d, S)
+        assert rep[0, 7] > 1000 and rep[0, 8999] == rep[0, 7]
+    hx.close()

@@ -25,6 +25,8 @@ LAYOUTS = [
     (1500, 3, 31, 5_003),
     (4096, 3, 31, 3_001),       # 512-byte rows
     (8192, 2, 31, 1_009),       # 1 KiB rows: the whole wave covers one row
+    (8193, 2, 31, 1_009),       # "wide" rows (> 8192 colours): 2 KiB stride, one wave walks a row in 1-KiB steps
+    (20_000, 3, 21, 503),       # 3 KiB rows, GTDB-scale colour count
 ]
 
 
@@ -167,6 +169,8 @@ def test_error_behaviour(hip_ctx):
         colorid_amd.Index(hip_ctx, 1000, 2, 129, 8)          # k_size > 128
     with pytest.raises(colorid_amd.CidError):
         colorid_amd.Index(hip_ctx, 1000, 2, 21, 8, hash_variant=7)
+    with pytest.raises(colorid_amd.CidError):
+        colorid_amd.Index(hip_ctx, 1000, 2, 21, (1 << 20) + 1)  # colour limit
     hx = colorid_amd.Index(hip_ctx, 1000, 2, 21, 8)
     with pytest.raises(colorid_amd.CidError):                # not finalized
         hx.search_count(np.zeros((1, 21), np.uint8))
