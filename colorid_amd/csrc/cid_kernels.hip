@@ -1,18 +1,21 @@
 // BIGSI query kernels for MI355X (gfx950).  Hand-written HIP; wave64; HBM-bound bitwise work.
 //
 // Data layout in HBM: the index is a dense row-major bit matrix, row r = the colour bit-vector of Bloom
-// position r, `rs` u64 words per row (rs = 1, or a power of two 2..128 — 16 B .. 1 KiB per row — so that a
-// row never straddles a 128-byte line it does not fill).  Absent rows of the reference's sparse map are
-// all-zero rows here.
+// position r, `rs` u64 words per row: rs = 1, or a power of two 2..128 (16 B .. 1 KiB per row, so that a row never
+// straddles a 128-byte line it does not fill), or — beyond 8192 colours, "wide" rows — a multiple of 128 words.
+// Absent rows of the reference's sparse map are all-zero rows here.
 //
-// Work decomposition (all kernels): one wave owns a tile of 64 k-mers at a time (grid-stride over tiles).
-//   1. the tile's 64*k bytes are copied HBM -> LDS with aligned 16-byte loads (wave-private image);
-//   2. lane l hashes k-mer l with seeds 0..n-1 (XXH3-64 out of LDS), reduces mod bloom_size and parks the
-//      n row numbers in LDS ("hash rows");
+// Work decomposition (search kernels): one wave owns a tile of 64 k-mers at a time; a block owns a contiguous
+// range of tiles (dynamic balance over the CUs, no cross-workgroup communication except the final atomics).
+//   1. the tile's 64*k bytes are copied HBM -> LDS with aligned 16-byte loads (wave-private image) — or, when the
+//      k-mers arrive as 2-bit codes, one u64 per lane is read and re-expanded to ASCII in registers;
+//   2. lane l hashes k-mer l with seeds 0..n-1 (XXH3-64), reduces mod bloom_size and parks the n row numbers in
+//      LDS ("hash rows");
 //   3. the wave re-maps itself so that LPR = rs/2 adjacent lanes cover one row with 16 bytes each
-//      (LPR = 1 and 8 bytes for rs = 1): every row costs exactly one coalesced request per 128-byte line,
-//      all n loads of a k-mer are issued back-to-back, then ANDed in registers;
+//      (LPR = 1 and 8 bytes for rs = 1; wide rows: the whole wave, in rs/128 steps): every row costs exactly one
+//      coalesced request per 128-byte line, all n loads of a k-mer are issued back-to-back, then ANDed in registers;
 //   4. kernel-specific epilogue on the AND words.
+// read_id kernels: one wave per read(-pair); see k_readid / k_readid_list.
 #include "cid_kernels.hpp"
 
 namespace cid {
@@ -33,7 +36,7 @@ __device__ __forceinline__ V16 load_slice(const uint64_t *p) {
 }
 
 // ridx: this wave's row numbers, ridx[s*64 + kmer_in_tile].  ZERO_DETECT also reports whether any of the
-// n slices was all-zero in this lane (the caller ORs that across the row's lanes).
+// n slices was all-zero in this lane (the caller ANDs those masks across the row's lanes).
 template <int NH, bool NARROW, bool ZERO_DETECT>
 __device__ __forceinline__ V16 gather_and_fixed(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, int kk,
                                                 uint32_t col_word, uint32_t s0, uint32_t &zero_mask) {
@@ -80,17 +83,11 @@ __device__ __forceinline__ V16 gather_and(const uint64_t *mat, uint32_t rs, cons
     return a;
 }
 
-// Sum / OR over the LPR adjacent lanes that share a row (LPR is a power of two <= 64).
+// Sum over the LPR adjacent lanes that share a row (LPR is a power of two <= 64).
 template <int LOG_LPR>
 __device__ __forceinline__ uint32_t group_sum(uint32_t v) {
 #pragma unroll
     for (int o = 1; o < (1 << LOG_LPR); o <<= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
-template <int LOG_LPR>
-__device__ __forceinline__ uint32_t group_or(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < (1 << LOG_LPR); o <<= 1) v |= __shfl_xor(v, o, kWave);
     return v;
 }
 

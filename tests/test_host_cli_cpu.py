@@ -125,3 +125,35 @@ def test_cli_errors():
     assert p.returncode != 0 and ("GPU" in p.stderr or "index" in p.stderr)
     p = subprocess.run([BIN, "search", "-q", "x.fasta"], capture_output=True, text=True)
     assert p.returncode != 0 and "required" in p.stderr
+
+
+def test_bxi_loader_rejects_malformed_files(orc, tmp_path):
+    """The reference panics ("can't deserialize") on a malformed index; the C++ loader must fail loudly too, never read past
+    the file or accept rows of the wrong width (parsed through `info`, which walks the whole file without a GPU)."""
+    import struct
+    oix = orc.Index(1000, 2, 21, 40)
+    for c in range(40):
+        oix.set_color(c, f"acc{c:02d}", 100 + c)
+    rows = oix.rows()
+    rows[5, 0] = 3
+    rows[900, 1] = 0x80
+    good = str(tmp_path / "good.bxi")
+    oix.save(good)
+    out, _ = run("info", "-b", good)
+    assert "Number of accessions in index: 40" in out
+    raw = open(good, "rb").read()
+
+    def expect_fail(blob, name):
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        r = subprocess.run([BIN, "info", "-b", p], capture_output=True, text=True)
+        assert r.returncode != 0 and "deserialize" in r.stderr, (name, r.stderr)
+
+    expect_fail(raw[:len(raw) // 2], "truncated.bxi")
+    expect_fail(raw[:40], "header_only.bxi")
+    # first row record starts after the colours block: find it and corrupt its word count (2 -> 3)
+    off = 32 + sum(16 + len(f"acc{c:02d}") for c in range(40)) + 8
+    assert struct.unpack_from("<2Q", raw, off) == (5, 2)
+    expect_fail(raw[:off + 8] + struct.pack("<Q", 3) + raw[off + 16:], "bad_words.bxi")
+    expect_fail(raw[:off + 16 + 8] + struct.pack("<Q", 41) + raw[off + 32:], "bad_nbits.bxi")
+    expect_fail(struct.pack("<4Q", 1000, 2, 21, 0) + raw[32:], "no_colours.bxi")
