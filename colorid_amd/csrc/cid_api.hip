@@ -47,6 +47,9 @@ struct cid_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *slot[S_COUNT] = {};
     size_t slot_bytes[S_COUNT] = {};
+    // result of the last cid_readid_count_sparse, fetched by cid_readid_sparse_fetch
+    uint64_t *sp_start = nullptr; uint32_t *sp_col = nullptr, *sp_cnt = nullptr;
+    uint64_t sp_rows = 0, sp_entries = 0;
 };
 
 struct cid_index {
@@ -186,6 +189,9 @@ void cid_ctx_destroy(cid_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (int s = 0; s < S_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
+    if (c->sp_start) (void)hipFree(c->sp_start);
+    if (c->sp_col) (void)hipFree(c->sp_col);
+    if (c->sp_cnt) (void)hipFree(c->sp_cnt);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -596,14 +602,14 @@ int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases
     return CID_OK;
 }
 
-int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
-                     const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
-                     uint32_t *report, uint32_t *n_kmers, uint8_t *status) {
+// uploads the batch, runs the LDS or the sort-based kernel; leaves report / n_kmers / status in the ctx's device scratch
+static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                            const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t **d_report_out,
+                            uint32_t **d_nk_out, uint8_t **d_status_out) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
-    if (!seq_off || !read_seq0 || (n_reads && (!report || !n_kmers || !status))) return fail(CID_ERR_INVALID, "null argument");
+    if (!seq_off || !read_seq0) return fail(CID_ERR_INVALID, "null argument");
     if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
-    if (n_reads == 0) return CID_OK;
     if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
     const uint64_t total_bases = seq_off[n_seqs];
     if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
@@ -650,10 +656,61 @@ int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, cons
                                   start_sample, max_bytes, max_win, (uint32_t *)d_rep, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4);
     }
     if (rc) return rc;
+    *d_report_out = (uint32_t *)d_rep; *d_nk_out = (uint32_t *)d_nk; *d_status_out = (uint8_t *)d_nk + n_reads * 4;
+    return CID_OK;
+}
+
+int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                     const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                     uint32_t *report, uint32_t *n_kmers, uint8_t *status) {
+    if (n_reads == 0) return check_ready(c, ix);
+    if (!report || !n_kmers || !status) return fail(CID_ERR_INVALID, "null argument");
+    uint32_t *d_rep, *d_nk;
+    uint8_t *d_st;
+    int rc = readid_to_device(c, ix, bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, &d_rep, &d_nk, &d_st);
+    if (rc) return rc;
+    const size_t C1 = (size_t)ix->n_colors + 1;
     HIP_TRY(hipMemcpyAsync(report, d_rep, n_reads * C1 * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(status, (uint8_t *)d_nk + n_reads * 4, n_reads, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(status, d_st, n_reads, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
+}
+
+int cid_readid_count_sparse(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                            const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                            uint32_t *n_kmers, uint8_t *status, uint64_t *n_entries) {
+    if (!n_entries) return fail(CID_ERR_INVALID, "null argument");
+    *n_entries = 0;
+    if (n_reads == 0) { int rc0 = check_ready(c, ix); if (rc0 == CID_OK) { c->sp_rows = 0; c->sp_entries = 0; } return rc0; }
+    if (!n_kmers || !status) return fail(CID_ERR_INVALID, "null argument");
+    uint32_t *d_rep, *d_nk;
+    uint8_t *d_st;
+    int rc = readid_to_device(c, ix, bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, &d_rep, &d_nk, &d_st);
+    if (rc) return rc;
+    if (c->sp_start) { (void)hipFree(c->sp_start); c->sp_start = nullptr; }
+    if (c->sp_col) { (void)hipFree(c->sp_col); c->sp_col = nullptr; }
+    if (c->sp_cnt) { (void)hipFree(c->sp_cnt); c->sp_cnt = nullptr; }
+    rc = cid::compact_report(c, d_rep, ix->n_colors + 1, n_reads, &c->sp_start, &c->sp_col, &c->sp_cnt, &c->sp_entries);
+    if (rc) return rc;
+    c->sp_rows = n_reads;
+    HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(status, d_st, n_reads, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n_entries = c->sp_entries;
+    return CID_OK;
+}
+
+int cid_readid_sparse_fetch(cid_ctx *c, uint64_t *row_start, uint32_t *colours, uint32_t *counts) {
+    if (!c || !row_start) return fail(CID_ERR_INVALID, "null argument");
+    if (c->sp_rows == 0) { row_start[0] = 0; return CID_OK; }
+    if (c->sp_entries && (!colours || !counts)) return fail(CID_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy(row_start, c->sp_start, (c->sp_rows + 1) * 8, hipMemcpyDeviceToHost));
+    if (c->sp_entries) {
+        HIP_TRY(hipMemcpy(colours, c->sp_col, c->sp_entries * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(counts, c->sp_cnt, c->sp_entries * 4, hipMemcpyDeviceToHost));
+    }
     return CID_OK;
 }
 

@@ -30,4 +30,8 @@ int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes,
 int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t *and_words_le,
                          int *any_row_missing);
 
+// dense report rows (device) -> per-row (colour, count) lists, ascending colour; outputs are hipMalloc'ed for the caller
+int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_t n_rows, uint64_t **d_row_start, uint32_t **d_colours,
+                   uint32_t **d_counts, uint64_t *n_entries);
+
 }  // namespace cid

@@ -379,6 +379,71 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
 
 }  // namespace cid
 
+// ------------------------------------------------------------------------------------------------ sparse read_id reports
+// A report row has n_colors+1 counters but only a handful are non-zero: compact the dense rows (left in HBM by
+// k_readid) into per-read (colour, count) lists in ascending colour order, so that only those cross PCIe.
+namespace cid {
+
+__global__ __launch_bounds__(256) void k_row_nnz(const uint32_t *report, uint32_t width, uint64_t n_rows, uint32_t *nnz) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t *r = report + row * width;
+    uint32_t n = 0;
+    for (uint32_t c0 = 0; c0 < width; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        n += (uint32_t)__popcll(__ballot(c < width && r[c] != 0));
+    }
+    if (lane == 0) nnz[row] = n;
+}
+__global__ __launch_bounds__(256) void k_row_compact(const uint32_t *report, uint32_t width, uint64_t n_rows, const uint64_t *row_start,
+                                                     uint32_t *colours, uint32_t *counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t *r = report + row * width;
+    uint64_t out = row_start[row];
+    for (uint32_t c0 = 0; c0 < width; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < width ? r[c] : 0u;
+        const uint64_t m = __ballot(v != 0);
+        if (v) {
+            const uint64_t o = out + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+            colours[o] = c;
+            counts[o] = v;
+        }
+        out += (uint64_t)__popcll(m);
+    }
+}
+
+// d_report: n_rows x width dense counters (device).  Leaves row_start (u64[n_rows+1]) and the entry arrays in the buffers
+// it allocates; the caller owns (and frees) them.
+int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_t n_rows, uint64_t **d_row_start, uint32_t **d_colours,
+                   uint32_t **d_counts, uint64_t *n_entries) {
+    hipStream_t st = ctx_stream(c);
+    DevBuf<uint32_t> nnz, col, cnt;
+    DevBuf<uint64_t> start;
+    int rc;
+    if ((rc = nnz.alloc(n_rows + 1)) || (rc = start.alloc(n_rows + 1))) return rc;
+    HIP_TRY(hipMemsetAsync(nnz.p, 0, (n_rows + 1) * 4, st));
+    if (n_rows) hipLaunchKernelGGL(k_row_nnz, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, d_report, width, n_rows, nnz.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
+    DevBuf<uint8_t> tmp;
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpy(&total, start.p + n_rows, 8, hipMemcpyDeviceToHost));
+    if ((rc = col.alloc(total)) || (rc = cnt.alloc(total))) return rc;
+    if (n_rows) hipLaunchKernelGGL(k_row_compact, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, d_report, width, n_rows, start.p, col.p, cnt.p);
+    HIP_TRY(hipStreamSynchronize(st));
+    *d_row_start = start.release(); *d_colours = col.release(); *d_counts = cnt.release(); *n_entries = total;
+    return CID_OK;
+}
+
+}  // namespace cid
+
 extern "C" {
 
 int cid_kmerset_create(cid_ctx *c, uint32_t k_size, cid_kmerset **out) {

@@ -78,8 +78,9 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
 // ---------------------------------------------------------------- reports.rs / read_id tail
 double false_prob(double m, double k, double n);                                                     // read_id_mt_pe.rs:695-698
 struct Classification { std::string label; uint64_t count; uint64_t kmer_length; const char *verdict; uint64_t n_top; };
-Classification kmer_poll_plus(const uint32_t *report, uint64_t kmer_length, const Bigsi &b,
-                              const std::vector<double> &fp, double fp_correct);                    // read_id_mt_pe.rs:187-251
+// read_id_mt_pe.rs:187-251 on the report's non-zero entries (ascending colour id; colour C = no_hits_num)
+Classification kmer_poll_plus(const uint32_t *colours, const uint32_t *counts, size_t n_entries, uint64_t kmer_length, const Bigsi &b,
+                              const std::vector<double> &fp, double fp_correct);
 void read_counts_five_fields(const std::string &reads_file, const std::string &prefix);            // reports.rs:98-120
 
 // ---------------------------------------------------------------- drivers (same names as the reference modules)

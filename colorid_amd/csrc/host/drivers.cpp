@@ -40,28 +40,27 @@ static bool not_fp_significant(uint64_t observations, double p_false, double fp_
     return ((double)hits < critical) || (((double)hits > critical) && (mpf >= fp_correct));
 }
 
-Classification kmer_poll_plus(const uint32_t *report, uint64_t kmer_length, const Bigsi &b, const std::vector<double> &fp,
-                              double fp_correct) {
+Classification kmer_poll_plus(const uint32_t *colours, const uint32_t *counts, size_t n_entries, uint64_t kmer_length, const Bigsi &b,
+                              const std::vector<double> &fp, double fp_correct) {
+    // `report` as the sparse list of its non-zero entries in ascending colour id (colour C = no_hits_num)
     const size_t C = b.colors.size();
-    size_t entries = 0;
-    for (size_t c = 0; c <= C; ++c) entries += report[c] != 0;
-    if (entries == 0 || (entries == 1 && report[C] != 0)) return {"no_hits", 0, kmer_length, "accept", 0};  // :197-205, :332-340
+    if (n_entries == 0 || (n_entries == 1 && colours[0] == C)) return {"no_hits", 0, kmer_length, "accept", 0};  // :197-205, :332-340
     uint64_t best = 0, n_sig = 0;
-    std::vector<uint8_t> sig(C, 0);
-    for (size_t c = 0; c < C; ++c) {
-        if (!report[c]) continue;
-        if (not_fp_significant(kmer_length, fp[c], fp_correct, report[c])) continue;
-        sig[c] = 1;
+    std::vector<uint8_t> sig(n_entries, 0);
+    for (size_t e = 0; e < n_entries; ++e) {
+        if (colours[e] == C) continue;
+        if (not_fp_significant(kmer_length, fp[colours[e]], fp_correct, counts[e])) continue;
+        sig[e] = 1;
         ++n_sig;
-        best = std::max<uint64_t>(best, report[c]);
+        best = std::max<uint64_t>(best, counts[e]);
     }
     if (n_sig == 0) return {"no_significant_hits", 0, kmer_length, "reject", 0};  // :216-223
     std::string label;
     uint64_t n_top = 0;
-    for (size_t c = 0; c < C; ++c)
-        if (sig[c] && report[c] == best) {
+    for (size_t e = 0; e < n_entries; ++e)
+        if (sig[e] && counts[e] == best) {
             if (n_top) label += ",";
-            label += b.colors[c];
+            label += b.colors[colours[e]];
             ++n_top;
         }
     return {label, best, kmer_length, n_top == 1 ? "accept" : "reject", n_top};
@@ -356,18 +355,24 @@ struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
 // parallel_vec (read_id_mt_pe.rs:282-363): counts on the GPU, poll on the host; returns the number of rows written
 size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, double fp_correct, size_t start_sample,
                       const std::vector<double> &fp, FILE *out) {
-    const size_t n = rb.size(), C = b.colors.size();
+    const size_t n = rb.size();
     if (n == 0) return 0;
-    std::vector<uint32_t> report(n * (C + 1)), nk(n);
+    // counts stay on the GPU as dense rows; only each read's non-zero (colour, count) entries come back
+    std::vector<uint32_t> nk(n);
     std::vector<uint8_t> status(n);
-    CID_TRY(cid_readid_count(ctx, b.index, rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1, rb.read_seq0.data(), n,
-                             (uint32_t)d, (uint32_t)start_sample, report.data(), nk.data(), status.data()));
+    uint64_t n_entries = 0;
+    CID_TRY(cid_readid_count_sparse(ctx, b.index, rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1, rb.read_seq0.data(), n,
+                                    (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
+    std::vector<uint64_t> row_start(n + 1);
+    std::vector<uint32_t> colours(n_entries), counts(n_entries);
+    CID_TRY(cid_readid_sparse_fetch(ctx, row_start.data(), colours.data(), counts.data()));
     for (size_t r = 0; r < n; ++r) {
         if (status[r] == 1) {
             fprintf(out, "%s\ttoo_short\t0\t0\taccept\t0\n", rb.ids[r].c_str());
             continue;
         }
-        const Classification c = kmer_poll_plus(report.data() + r * (C + 1), nk[r], b, fp, fp_correct);
+        const Classification c = kmer_poll_plus(colours.data() + row_start[r], counts.data() + row_start[r],
+                                                (size_t)(row_start[r + 1] - row_start[r]), nk[r], b, fp, fp_correct);
         fprintf(out, "%s\t%s\t%llu\t%llu\t%s\t%llu\n", rb.ids[r].c_str(), c.label.c_str(), (unsigned long long)c.count,
                 (unsigned long long)c.kmer_length, c.verdict, (unsigned long long)c.n_top);
     }

@@ -121,6 +121,23 @@ class Index:
                                         n_reads, d, start_sample, _p(rep), _p(nk), _p(st)))
         return rep, nk, st
 
+    def readid_count_sparse(self, bases, seq_off, read_seq0, d=1, start_sample=3):
+        """-> (row_start u64[n_reads+1], colours u32[E], counts u32[E], n_kmers, status)"""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        read_seq0 = np.ascontiguousarray(read_seq0, np.uint64)
+        n_reads = len(read_seq0) - 1
+        nk = np.zeros(n_reads, np.uint32)
+        st = np.zeros(n_reads, np.uint8)
+        ne = C.c_uint64(0)
+        check(self.lib.cid_readid_count_sparse(self.ctx.h, self.h, _p(bases), _p(seq_off), len(seq_off) - 1, _p(read_seq0), n_reads, d,
+                                               start_sample, _p(nk), _p(st), C.byref(ne)))
+        rs = np.zeros(n_reads + 1, np.uint64)
+        col = np.zeros(ne.value, np.uint32)
+        cnt = np.zeros(ne.value, np.uint32)
+        check(self.lib.cid_readid_sparse_fetch(self.ctx.h, _p(rs), _p(col), _p(cnt)))
+        return rs, col, cnt, nk, st
+
     def readid_count_dev(self, d_bases, d_seq_off, d_read_seq0, n_reads, d, start_sample, max_read_bytes, max_read_windows,
                          d_report, d_nk, d_status):
         check(self.lib.cid_readid_count_dev(self.ctx.h, self.h, vp(d_bases), vp(d_seq_off), vp(d_read_seq0), n_reads, d,

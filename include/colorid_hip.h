@@ -162,6 +162,15 @@ int cid_readid_count(cid_ctx *, const cid_index *, const uint8_t *bases, const u
                      const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                      uint32_t *report, uint32_t *n_kmers, uint8_t *status);
 
+/* Sparse form of the same call: report rows are compacted on the device to their non-zero (colour, count) entries in
+ * ascending colour order, so only those cross PCIe (a row has n_colors+1 counters, a read hits a handful).  The result
+ * stays in the ctx until the next call; fetch it with cid_readid_sparse_fetch into row_start[n_reads+1] and
+ * colours/counts[*n_entries] (column n_colors, the no_hits_num entry, appears like any colour). */
+int cid_readid_count_sparse(cid_ctx *, const cid_index *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                            const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                            uint32_t *n_kmers, uint8_t *status, uint64_t *n_entries);
+int cid_readid_sparse_fetch(cid_ctx *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
+
 /* Device-pointer form (asynchronous on the ctx stream).  The caller states the longest read(-pair) of the batch in
  * bytes and in k-mer windows (sum over its mates of (len-k)/d+1 for len >= k): they size the kernel's LDS. */
 int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *d_seq_off,

@@ -80,6 +80,12 @@ def check(oix, hx, reads, d, S):
     assert np.array_equal(want[1], got[1]), "n_kmers"
     bad = np.flatnonzero((want[0] != got[0]).any(axis=1))
     assert len(bad) == 0, (bad[:5], want[0][bad[:1]], got[0][bad[:1]])
+    # the sparse form of the same call: non-zero entries per read, ascending colour
+    rs, col, cnt, nk, st = hx.readid_count_sparse(bases, seq_off, read_seq0, d, S)
+    assert np.array_equal(nk, want[1]) and np.array_equal(st, want[2])
+    rows, cols = np.nonzero(want[0])
+    assert np.array_equal(rs, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=len(want[0])))]).astype(np.uint64))
+    assert np.array_equal(col, cols.astype(np.uint32)) and np.array_equal(cnt, want[0][rows, cols])
     return want
 
 
