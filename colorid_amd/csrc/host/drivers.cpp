@@ -21,6 +21,10 @@ namespace colorid {
 
 using Clock = std::chrono::steady_clock;
 static long secs_since(Clock::time_point t0) { return (long)std::chrono::duration_cast<std::chrono::seconds>(Clock::now() - t0).count(); }
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+// COLORID_TIMING=1: sub-second phase times on stderr (the reference's own timers print whole seconds)
+static bool g_timing = getenv("COLORID_TIMING") != nullptr;
+static double g_ms_gpu = 0, g_ms_poll = 0;
 
 // ---------------------------------------------------------------------------------------------- reports.rs
 
@@ -358,6 +362,7 @@ size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, dou
     const size_t n = rb.size();
     if (n == 0) return 0;
     // counts stay on the GPU as dense rows; only each read's non-zero (colour, count) entries come back
+    const auto t_gpu = Clock::now();
     std::vector<uint32_t> nk(n);
     std::vector<uint8_t> status(n);
     uint64_t n_entries = 0;
@@ -366,6 +371,8 @@ size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, dou
     std::vector<uint64_t> row_start(n + 1);
     std::vector<uint32_t> colours(n_entries), counts(n_entries);
     CID_TRY(cid_readid_sparse_fetch(ctx, row_start.data(), colours.data(), counts.data()));
+    g_ms_gpu += ms_since(t_gpu);
+    const auto t_poll = Clock::now();
     for (size_t r = 0; r < n; ++r) {
         if (status[r] == 1) {
             fprintf(out, "%s\ttoo_short\t0\t0\taccept\t0\n", rb.ids[r].c_str());
@@ -376,6 +383,7 @@ size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, dou
         fprintf(out, "%s\t%s\t%llu\t%llu\t%s\t%llu\n", rb.ids[r].c_str(), c.label.c_str(), (unsigned long long)c.count,
                 (unsigned long long)c.kmer_length, c.verdict, (unsigned long long)c.n_top);
     }
+    g_ms_poll += ms_since(t_poll);
     rb.clear();
     return n;
 }
@@ -416,6 +424,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
+    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll);
 }
 
 void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,

@@ -36,7 +36,7 @@ res = {"genomes": G, "genome_len": LG, "reads": R, "fastq_gz_MB": os.path.getsiz
 
 def run(*args):
     t = time.time()
-    p = subprocess.run([BIN, *args], capture_output=True, text=True)
+    p = subprocess.run([BIN, *args], capture_output=True, text=True, env=dict(os.environ, COLORID_TIMING="1"))
     dt = time.time() - t
     if p.returncode != 0:
         print(p.stderr[-2000:]); sys.exit(1)
@@ -52,7 +52,7 @@ res["search_g_total_s"] = dt; res["search_g_rows"] = len(out.strip().splitlines(
 res["search_stderr"] = [l for l in err.splitlines() if "Index loaded" in l or "k-mers in query" in l or "Search:" in l]
 dt, out, err = run("read_id", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-n", f"{W}/rid")
 res["read_id_total_s"] = dt
-res["read_id_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "Index loaded" in l]
+res["read_id_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "Index loaded" in l or "timing:" in l]
 counts = dict(l.split("\t") for l in open(f"{W}/rid_counts.txt").read().splitlines())
 res["read_id_accept_frac"] = 1.0 - int(counts.get("reject", 0)) / R
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/g007.fasta", "-s")
