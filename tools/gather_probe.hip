@@ -98,6 +98,37 @@ __global__ __launch_bounds__(256) void probe_s(const uint8_t *tab, const uint32_
     if (acc == 0x12345678u) out[t & 1023] = acc;
 }
 
+// scalar PREFETCH: one s_load_dword per row pulls (only) the row's 64-byte half line into L2; mode 0 = prefetch only,
+// mode 1 = prefetch this wave's 256 rows, then gather them with the vector path (do they now hit in L2?)
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_pf(const uint8_t *tab, const uint32_t *idx, uint64_t n_groups, uint32_t *out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one lane per group of 4 rows
+    const uint64_t g = t < n_groups ? t : n_groups - 1;
+    const uint4 my = *reinterpret_cast<const uint4 *>(idx + g * 4);
+    typedef const __attribute__((address_space(4))) uint32_t *cptr;
+    uint32_t acc = 0;
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t r0 = __builtin_amdgcn_readlane(my.x, i), r1 = __builtin_amdgcn_readlane(my.y, i);
+        const uint32_t r2 = __builtin_amdgcn_readlane(my.z, i), r3 = __builtin_amdgcn_readlane(my.w, i);
+        acc ^= *(cptr)(tab + (uint64_t)r0 * 32) ^ *(cptr)(tab + (uint64_t)r1 * 32) ^ *(cptr)(tab + (uint64_t)r2 * 32) ^ *(cptr)(tab + (uint64_t)r3 * 32);
+    }
+    uint32_t r = acc;
+    if (MODE == 1) {
+        // vector gather of the same rows: lane pair (2j, 2j+1) takes group j's... here simply 1 lane per row, 32 B
+        uint4 v[8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t row = s == 0 ? my.x : s == 1 ? my.y : s == 2 ? my.z : my.w;
+            const uint4 *p = reinterpret_cast<const uint4 *>(tab + (uint64_t)row * 32);
+            v[2 * s] = p[0]; v[2 * s + 1] = p[1];
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) r ^= v[s].x & v[s].y & v[s].z & v[s].w;
+    }
+    if (r == 0x12345678u) out[t & 1023] = r;
+}
+
 int main(int argc, char **argv) {
     const int variant = argc > 1 ? atoi(argv[1]) : 0;
     const uint64_t tab_mib = argc > 2 ? strtoull(argv[2], 0, 10) : 1526;
@@ -137,7 +168,9 @@ int main(int argc, char **argv) {
     float best = 1e9f;
     for (int it = 0; it < 5; ++it) {
         CK(hipEventRecord(e0));
-        if (variant == 8) hipLaunchKernelGGL(probe_s, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        if (variant == 11) hipLaunchKernelGGL(probe_pf<0>, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 12) hipLaunchKernelGGL(probe_pf<1>, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 8) hipLaunchKernelGGL(probe_s, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
         else if (variant == 9) hipLaunchKernelGGL(probe1, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
         else {
             const unsigned grid = (unsigned)((n_groups * 2 + 255) / 256);
