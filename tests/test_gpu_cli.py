@@ -237,3 +237,30 @@ def test_read_id_fasta(orc, env):
     ids = [h.decode() for h, _ in recs]
     want = expected_readid(orc, oix, ids, [[body] for _, body in recs], 1, 0)
     assert open(prefix + "_reads.txt").read().splitlines() == want
+
+
+def test_k_above_32_uses_host_map(orc, env, tmp_path):
+    """k > 32 cannot be packed in 64 bits: build / search / read_id fall back to byte-string k-mers (host map, LDS byte path)."""
+    d, _, _, genomes = env
+    tsv = tmp_path / "refs.tsv"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES[:3]))
+    pre = str(tmp_path / "k35")
+    run("build", "-s", "300007", "-n", "3", "-k", "35", "-b", pre, "-r", str(tsv))
+    oix = orc.Index.build_single(str(tsv), 300007, 3, 35)
+    ref = pre + "_oracle.bxi"
+    oix.save(ref)
+    assert open(pre + ".bxi", "rb").read() == open(ref, "rb").read()
+    q = os.path.join(REFS, PHAGES[1] + ".fasta")
+    out, err = run("search", "-b", pre + ".bxi", "-q", q, "-g", "-p", "0.01")
+    km = orc.Kmers(35)
+    for s in orc.read_fasta(q):
+        km.kmerize_vector(s, 1)
+    assert sorted(out.splitlines()) == sorted(expected_report(orc, oix, q, km.clean_map(0), 0.01, True))
+    assert "k-mer map on the host" in err
+    rng = np.random.default_rng(4)
+    r1 = synth_fastq_records(rng, genomes[:3], 300, 150, mate=0)
+    f1 = str(tmp_path / "r.fastq.gz")
+    write_fastq_gz(f1, r1)
+    run("read_id", "-b", pre + ".bxi", "-q", f1, "-n", str(tmp_path / "rid"))
+    want = expected_readid(orc, oix, ["@" + r[0].decode() for r in r1], [[orc.qual_mask(a[1], a[2], 15)] for a in r1], 1, 3)
+    assert open(tmp_path / "rid_reads.txt").read().splitlines() == want

@@ -102,7 +102,7 @@ def test_readid_phage(orc, phage, paired, d, S):
 
 @pytest.mark.parametrize("n_colors,n_hash,k,m", [(46, 4, 31, 200_003), (256, 2, 21, 1 << 18), (300, 3, 21, 50_021),
                                                  (1024, 4, 31, 20_011), (64, 1, 15, 9_973), (4096, 2, 25, 3_001),
-                                                 (10_000, 2, 21, 2_003)])
+                                                 (10_000, 2, 21, 2_003), (200, 6, 40, 30_011), (33, 5, 33, 9_001)])
 def test_readid_layouts(orc, hip_ctx, n_colors, n_hash, k, m):
     rng = np.random.default_rng(n_colors + k)
     oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.05, zero_row_frac=0.02)
