@@ -64,8 +64,8 @@ def profiled_traffic(K, C, m, n, k):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=1_000_000, help="synthetic reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--bloom", type=int, default=50_000_000)
