@@ -56,6 +56,7 @@ struct cid_index {
     cid_ctx *ctx = nullptr;
     uint64_t m = 0;
     uint32_t n_hash = 0, k = 0, n_colors = 0, w32 = 0, w64 = 0, rs = 0;
+    uint32_t m_size = 0;  // > 0: minimizer (.mxi) index
     uint64_t *mat = nullptr;
     bool finalized = false;
     cid::ModMagic mod{};
@@ -69,6 +70,7 @@ uint32_t index_rs(const cid_index *ix) { return ix->rs; }
 ModMagic index_mod(const cid_index *ix) { return ix->mod; }
 uint32_t index_n_colors(const cid_index *ix) { return ix->n_colors; }
 uint32_t index_n_hash(const cid_index *ix) { return ix->n_hash; }
+uint32_t index_m_size(const cid_index *ix) { return ix->m_size; }
 const uint64_t *index_matrix(const cid_index *ix) { return ix->mat; }
 }  // namespace cid
 
@@ -131,6 +133,12 @@ int check_ready(const cid_ctx *c, const cid_index *ix) {
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// `search` is not defined on minimizer indices ("An index with minimizers (.mxi) is used, but not available for this
+// function", src/main.rs:569-573)
+int check_not_mini(const cid_index *ix) {
+    return ix->m_size ? fail(CID_ERR_UNSUPPORTED, "search on a minimizer (.mxi) index is not defined by the reference") : CID_OK;
+}
 
 }  // namespace
 
@@ -230,6 +238,14 @@ int cid_index_create(cid_ctx *c, uint64_t bloom_size, uint32_t num_hash, uint32_
     return CID_OK;
 }
 
+int cid_index_set_minimizer(cid_index *ix, uint32_t m_size) {
+    if (!ix) return fail(CID_ERR_INVALID, "null index");
+    if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
+    if (m_size == 0 || m_size > ix->k) return fail(CID_ERR_INVALID, "minimizer size %u must be in 1..k_size (%u)", m_size, ix->k);
+    ix->m_size = m_size;
+    return CID_OK;
+}
+
 int cid_index_put_rows(cid_index *ix, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows) {
     if (!ix || (n_rows && (!row_ids || !words_le))) return fail(CID_ERR_INVALID, "null argument");
     if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
@@ -299,6 +315,7 @@ int cid_index_insert_kmers_dev(cid_index *ix, const uint8_t *d_kmers, const uint
     cid::InsertParams p{};
     p.mat = ix->mat; p.rs = ix->rs; p.n_hash = ix->n_hash; p.k = ix->k; p.n_colors = ix->n_colors;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    p.m_size = ix->m_size;
     p.mod = ix->mod; p.kmers = d_kmers; p.colour_of_kmer = d_colour_of_kmer; p.n_kmers = n_kmers;
     HIP_TRY(cid::launch_insert_kmers(p, c->stream));
     return CID_OK;
@@ -317,7 +334,7 @@ int cid_index_insert_kmers(cid_index *ix, const uint8_t *kmers, uint32_t colour,
     cid::InsertParams p{};
     p.mat = ix->mat; p.rs = ix->rs; p.n_hash = ix->n_hash; p.k = ix->k; p.n_colors = ix->n_colors;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
-    p.colour = colour;
+    p.colour = colour; p.m_size = ix->m_size;
     p.mod = ix->mod; p.kmers = (const uint8_t *)d_k; p.colour_of_kmer = nullptr; p.n_kmers = n_kmers;
     HIP_TRY(cid::launch_insert_kmers(p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -339,6 +356,7 @@ static int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d
                                uint32_t *d_unique_colour) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
+    if ((rc = check_not_mini(ix))) return rc;
     if (!d_hits || (n_kmers && !d_kmers && !d_codes)) return fail(CID_ERR_INVALID, "null argument");
     if (d_kmers && !aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
@@ -469,7 +487,9 @@ int cid_search_count(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, cons
 static int search_perfect_to_host(cid_ctx *c, const cid_index *ix, const uint8_t *d_k, const uint64_t *d_codes, size_t n_kmers,
                                   uint32_t *and_words_le, int *any_row_missing) {
     void *d_out;
-    int rc = slot_reserve(c, S_MISC, (size_t)ix->rs * 8 + 16, &d_out);
+    int rc = check_not_mini(ix);
+    if (rc) return rc;
+    rc = slot_reserve(c, S_MISC, (size_t)ix->rs * 8 + 16, &d_out);
     if (rc) return rc;
     uint64_t *d_and = (uint64_t *)d_out;
     int *d_missing = (int *)(d_and + ix->rs);
@@ -520,7 +540,7 @@ int index_insert_codes(cid_index *ix, const uint64_t *d_codes, size_t n, uint32_
     cid::InsertParams p{};
     p.mat = ix->mat; p.rs = ix->rs; p.n_hash = ix->n_hash; p.k = ix->k; p.n_colors = ix->n_colors;
     p.tiles_per_block = pick_tiles_per_block(c, n);
-    p.colour = colour; p.mod = ix->mod; p.codes = d_codes; p.n_kmers = n;
+    p.colour = colour; p.m_size = ix->m_size; p.mod = ix->mod; p.codes = d_codes; p.n_kmers = n;
     HIP_TRY(cid::launch_insert_kmers(p, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CID_OK;
@@ -555,6 +575,7 @@ static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_
     p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
     p.mod = ix->mod;
     p.stride_d = stride_d; p.start_sample = start_sample;
+    p.m_size = ix->m_size;
     p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
     p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
     if (p.win_cap < 4) p.win_cap = 4;
@@ -563,7 +584,8 @@ static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_
     while (p.table_slots < p.win_cap + p.win_cap / 2) p.table_slots <<= 1;
     // key region: the larger of the byte-string layout (tags, window infos, k-mer image) and the packed layout
     // (hash table keys + indices, 2-bit bases, bad-base bits)
-    const size_t key_bytes_path = 8ull * p.win_cap + cid::kmer_img_bytes(ix->k);
+    const size_t key_bytes_path = 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
+                                  (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);
     const size_t key_packed_path = 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
     const size_t key_bytes = ((key_bytes_path > key_packed_path ? key_bytes_path : key_packed_path) + 15) & ~15ull;
     const size_t wave_bytes = (size_t)p.bases_cap + 4ull * cid::kWave * ix->n_hash + 4ull * p.hist_pad + key_bytes;

@@ -206,4 +206,19 @@ CID_FN uint64_t canonical_code(uint64_t lsb, uint32_t k, uint64_t *msb) {
     return fwd ? lsb : rc_lsb;
 }
 
+// Minimizer of a canonical k-mer held as an MSB-first code (src/kmer.rs:971-986, find_minimizer): the smallest m-mer
+// among the k-mer's m-mers at positions 0..k-m and the reverse complements of those at positions 1..k-m (position 0's
+// reverse complement is never tried — the reference starts from `&seq[..m]`).  Returns an MSB-first m-field code.
+CID_FN uint64_t minimizer_code(uint64_t msb, uint32_t k, uint32_t m) {
+    const uint64_t mask = code_mask(m);
+    uint64_t best = (msb >> (2u * (k - m))) & mask;
+    for (uint32_t i = 1; i + m <= k; ++i) {
+        const uint64_t f = (msb >> (2u * (k - m - i))) & mask;
+        const uint64_t r = rev_fields(~f & mask, m);
+        best = f < best ? f : best;
+        best = r < best ? r : best;
+    }
+    return best;
+}
+
 }  // namespace cid

@@ -15,6 +15,7 @@ uint32_t index_rs(const cid_index *ix);
 ModMagic index_mod(const cid_index *ix);
 uint32_t index_n_colors(const cid_index *ix);
 uint32_t index_n_hash(const cid_index *ix);
+uint32_t index_m_size(const cid_index *ix);
 const uint64_t *index_matrix(const cid_index *ix);
 
 // Bloom insert of 2-bit codes already on the device into one colour (build.rs:62-66 with the k-mer map on the GPU)

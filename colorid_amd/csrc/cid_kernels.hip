@@ -485,6 +485,29 @@ __device__ __forceinline__ uint32_t canon_byte(const uint8_t *bases, uint32_t in
     const uint32_t pos = info & 0x7FFFFFFFu;
     return (info >> 31) ? comp_base(bases[pos + k - 1 - t]) : (uint32_t)bases[pos + t];
 }
+// find_minimizer (src/kmer.rs:971-986) on a k-byte canonical string `seq` in LDS, byte-wise and case-sensitive as the
+// reference compares; candidate = (start i, reverse-complement flag): byte t is seq[i+t] or comp(seq[i+m-1-t]).
+__device__ __forceinline__ uint32_t mini_byte(const uint8_t *seq, uint32_t cand, uint32_t m, uint32_t t) {
+    const uint32_t i = cand & 0xFFFFu;
+    return (cand >> 16) ? comp_base(seq[i + m - 1 - t]) : (uint32_t)seq[i + t];
+}
+__device__ __forceinline__ bool mini_less(const uint8_t *seq, uint32_t a, uint32_t b, uint32_t m) {
+    for (uint32_t t = 0; t < m; ++t) {
+        const uint32_t x = mini_byte(seq, a, m, t), y = mini_byte(seq, b, m, t);
+        if (x != y) return x < y;
+    }
+    return false;
+}
+__device__ __forceinline__ uint32_t find_minimizer_bytes(const uint8_t *seq, uint32_t k, uint32_t m) {
+    uint32_t best = 0;  // &seq[..m]: position 0, forward only
+    for (uint32_t i = 1; i + m <= k; ++i) {
+        if (mini_less(seq, i, best, m)) best = i;
+        if (mini_less(seq, i | (1u << 16), best, m)) best = i | (1u << 16);
+    }
+    return best;
+}
+__device__ __forceinline__ uint8_t upper_base(uint32_t b) { return (uint8_t)((b >= 'a' && b <= 'z') ? b - 32u : b); }
+
 // `nbits` (<= 64) bits starting at bit `bit` of a little-endian dword array (readable 2 dwords past the end)
 __device__ __forceinline__ uint64_t bits_at(const uint32_t *w, uint32_t bit, uint32_t nbits) {
     const uint32_t i = bit >> 5, sh = bit & 31u;
@@ -569,6 +592,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
     uint32_t *s_info = s_tag + p.win_cap;                                      // win_cap
     uint32_t *img = s_info + p.win_cap;                                        // kmer_img_bytes(k)
     uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+    uint32_t *mimg = img + kmer_img_bytes(k) / 4;                              // .mxi only: kmer_img_bytes(m_size) minimizer image
+    uint8_t *mimg8 = reinterpret_cast<uint8_t *>(mimg);
+    uint8_t *s_mstr = mimg8 + kmer_img_bytes(p.m_size ? p.m_size : 1);         // .mxi only: win_cap x m_size distinct minimizers
+    const uint32_t klen = p.m_size ? p.m_size : k;                             // length of the hashed key
     // packed path
     unsigned long long *t_key = reinterpret_cast<unsigned long long *>(keyreg);   // table_slots
     uint32_t *t_idx = reinterpret_cast<uint32_t *>(t_key + p.table_slots);     // table_slots
@@ -657,7 +684,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                         lsb = bits_at(s_pack, 2 * pos, 2 * k);
                     }
                     uint64_t msb = 0;
-                    const uint64_t canon = canonical_code(lsb, k, &msb);
+                    uint64_t canon = canonical_code(lsb, k, &msb);
+                    if (p.m_size) {  // .mxi: the set holds the k-mers' minimizers (kmer.rs:363-394)
+                        msb = minimizer_code(msb, k, p.m_size);
+                        canon = rev_fields(msb, p.m_size);
+                    }
                     // exact set with first-occurrence order: slot key = canonical code, slot value = smallest window index
                     uint32_t slot = (uint32_t)((msb * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
                     if (valid) {
@@ -671,7 +702,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                     wave_lds_fence();
                     distinct = valid && t_idx[slot] == wbase + wi;
                     if (distinct)
-                        xxh3_seeds_from(CodeReader{canon}, k, n, [&](uint32_t sd, uint64_t h) {
+                        xxh3_seeds_from(CodeReader{canon}, klen, n, [&](uint32_t sd, uint64_t h) {
                             ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
                         });
                 } else {
@@ -689,12 +720,50 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                         for (uint32_t t = 0; t < k; ++t) img8[(uint32_t)lane * k + t] = (uint8_t)canon_byte(s_bases, info, k, t);
                     wave_lds_fence();
                     uint32_t tag = 0;
+                    bool dup = false;
+                    const uint64_t vmask = __ballot(valid);
+                    if (p.m_size) {  // .mxi: the key is the (upper-cased) minimizer of the canonical k-mer; strings kept in s_mstr
+                        const uint32_t m = p.m_size;
+                        if (valid) {
+                            const uint8_t *seq = img8 + (uint32_t)lane * k;
+                            const uint32_t cand = find_minimizer_bytes(seq, k, m);
+                            for (uint32_t t = 0; t < m; ++t) mimg8[(uint32_t)lane * m + t] = upper_base(mini_byte(seq, cand, m, t));
+                        }
+                        wave_lds_fence();
+                        if (valid)
+                            xxh3_seeds(mimg, (uint32_t)lane * m, m, n, [&](uint32_t sd, uint64_t h) {
+                                if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
+                                ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
+                            });
+                        for (uint32_t q = 0; q < nd; ++q) {
+                            if (valid && !dup && s_tag[q] == tag) {
+                                bool same = true;
+                                for (uint32_t t = 0; t < m && same; ++t) same = s_mstr[q * m + t] == mimg8[(uint32_t)lane * m + t];
+                                dup = same;
+                            }
+                        }
+                        for (int j = 0; j < kWave - 1; ++j) {
+                            if (!((vmask >> j) & 1ull)) continue;
+                            const uint32_t tj = __builtin_amdgcn_readlane(tag, j);
+                            if (valid && !dup && j < lane && tj == tag) {
+                                bool same = true;
+                                for (uint32_t t = 0; t < m && same; ++t) same = mimg8[(uint32_t)j * m + t] == mimg8[(uint32_t)lane * m + t];
+                                dup = same;
+                            }
+                        }
+                        distinct = valid && !dup;
+                        const uint64_t dm = __ballot(distinct);
+                        if (distinct) {
+                            const uint32_t q = nd + (uint32_t)__popcll(dm & lt_mask);
+                            s_tag[q] = tag;
+                            for (uint32_t t = 0; t < m; ++t) s_mstr[q * m + t] = mimg8[(uint32_t)lane * m + t];
+                        }
+                    } else {
                     if (valid)
                         xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t sd, uint64_t h) {
                             if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
                             ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
                         });
-                    bool dup = false;
                     for (uint32_t q = 0; q < nd; ++q) {  // against the distinct k-mers of earlier chunks
                         if (valid && !dup && s_tag[q] == tag) {
                             const uint32_t oi = s_info[q];
@@ -703,7 +772,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                             dup = same;
                         }
                     }
-                    const uint64_t vmask = __ballot(valid);
                     for (int j = 0; j < kWave - 1; ++j) {  // against lower lanes of this chunk
                         if (!((vmask >> j) & 1ull)) continue;
                         const uint32_t tj = __builtin_amdgcn_readlane(tag, j);
@@ -720,6 +788,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                         const uint32_t q = nd + (uint32_t)__popcll(dm & lt_mask);
                         s_tag[q] = tag;
                         s_info[q] = info;
+                    }
                     }
                 }
                 const uint64_t dmask = __ballot(distinct);
@@ -903,14 +972,33 @@ __global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
         if (p.codes) {
             if (first + lane < p.n_kmers) {
                 const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-                const uint64_t lsb = rev_fields(p.codes[first + lane], p.k);
-                if (c < p.n_colors) xxh3_seeds_from(CodeReader{lsb}, p.k, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
+                uint64_t code = p.codes[first + lane];
+                uint32_t klen = p.k;
+                if (p.m_size) { code = minimizer_code(code, p.k, p.m_size); klen = p.m_size; }
+                const uint64_t lsb = rev_fields(code, klen);
+                if (c < p.n_colors) xxh3_seeds_from(CodeReader{lsb}, klen, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
             }
             continue;
         }
         wave_lds_fence();
         stage_kmers(img, p.kmers, p.n_kmers, first, p.k, lane);
         wave_lds_fence();
+        if (p.m_size) {  // ASCII k-mers into a minimizer index: byte-wise find_minimizer, then hash its m_size bytes
+            uint32_t *mimg = reinterpret_cast<uint32_t *>(smem + (size_t)(kBlock / kWave) * kmer_img_bytes(p.k) + (size_t)wave * kmer_img_bytes(p.m_size));
+            uint8_t *mimg8 = reinterpret_cast<uint8_t *>(mimg);
+            const bool have = first + lane < p.n_kmers;
+            if (have) {
+                const uint8_t *seq = reinterpret_cast<const uint8_t *>(img) + (uint32_t)lane * p.k;
+                const uint32_t cand = find_minimizer_bytes(seq, p.k, p.m_size);
+                for (uint32_t t = 0; t < p.m_size; ++t) mimg8[(uint32_t)lane * p.m_size + t] = mini_byte(seq, cand, p.m_size, t);
+            }
+            wave_lds_fence();
+            if (have) {
+                const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
+                if (c < p.n_colors) xxh3_seeds(mimg, (uint32_t)lane * p.m_size, p.m_size, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
+            }
+            continue;
+        }
         if (first + lane < p.n_kmers) {
             const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
             if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
@@ -1057,7 +1145,7 @@ hipError_t launch_get_rows(const uint64_t *mat, uint32_t rs, const uint64_t *d_r
 }
 
 hipError_t launch_insert_kmers(const InsertParams &p, hipStream_t stream) {
-    const size_t shmem = (size_t)(kBlock / kWave) * kmer_img_bytes(p.k);
+    const size_t shmem = (size_t)(kBlock / kWave) * (kmer_img_bytes(p.k) + (p.m_size ? kmer_img_bytes(p.m_size) : 0));
     const int grid = grid_for(p.n_kmers, p.tiles_per_block);
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(k_insert_kmers, dim3(grid), dim3(kBlock), shmem, stream, p);

@@ -47,6 +47,7 @@ struct InsertParams {
     uint32_t n_colors;
     uint32_t tiles_per_block;
     uint32_t colour;  // used when colour_of_kmer == nullptr
+    uint32_t m_size;  // > 0: a minimizer (.mxi) index — the Bloom key is find_minimizer(kmer, m_size) (build.rs:455-459)
     ModMagic mod;
     const uint8_t *kmers;       // ASCII, or nullptr when codes != nullptr
     const uint64_t *codes;      // 2-bit canonical codes (k <= 32)
@@ -63,6 +64,7 @@ struct ReadIdParams {
     const uint64_t *read_seq0;  // [n_reads+1]
     uint64_t n_reads;
     uint32_t stride_d, start_sample;
+    uint32_t m_size;            // > 0: minimizer index — the per-read set holds minimizers (kmer.rs:363-394), hashed with length m_size
     uint32_t bases_cap;         // LDS bytes per wave for one read(-pair)'s bases (multiple of 16)
     uint32_t win_cap;           // max windows (= max distinct k-mers) of one read(-pair)
     uint32_t hist_pad;          // n_colors+1 rounded up to a multiple of 4
@@ -76,7 +78,7 @@ struct ReadIdParams {
 
 struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in first-occurrence order
     const uint64_t *mat;
-    uint32_t rs, w64, n_colors, n_hash, k;
+    uint32_t rs, w64, n_colors, n_hash, k;   // k = length of the listed keys (k-mers, or minimizers for a .mxi index)
     ModMagic mod;
     const uint64_t *list_codes;   // canonical 2-bit codes, base 0 most significant
     const uint64_t *list_start;   // [n_reads+1] offsets into list_codes

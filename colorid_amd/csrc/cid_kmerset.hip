@@ -260,6 +260,12 @@ __device__ __forceinline__ uint32_t read_of_window(const uint64_t *wstart, uint3
     }
     return lo;
 }
+__global__ void k_codes_to_minimizers(uint64_t *codes, uint64_t n, uint32_t k, uint32_t m, uint64_t sentinel_k, uint64_t sentinel_m) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = codes[i];
+    codes[i] = c == sentinel_k ? sentinel_m : minimizer_code(c, k, m);
+}
 __global__ void k_iota_u32(uint32_t *p, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = (uint32_t)i;
@@ -290,8 +296,11 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     const uint32_t k = index_k(ix);
     if (k > 32) return fail(CID_ERR_UNSUPPORTED, "long reads need the packed path: k_size %u > 32", k);
     hipStream_t st = ctx_stream(c);
-    const uint64_t sentinel = k < 32 ? (1ull << (2 * k)) : ~0ull;
-    const unsigned end_bit = k < 32 ? 2 * k + 1 : 64;
+    const uint32_t msz = index_m_size(ix);           // > 0: the sets hold minimizers of length msz
+    const uint32_t key_len = msz ? msz : k;
+    const uint64_t sentinel_k = k < 32 ? (1ull << (2 * k)) : ~0ull;
+    const uint64_t sentinel = key_len < 32 ? (1ull << (2 * key_len)) : ~0ull;
+    const unsigned end_bit = key_len < 32 ? 2 * key_len + 1 : 64;
     // windows are numbered read by read, mate by mate
     std::vector<uint64_t> wstart(n_reads + 1, 0);
     std::vector<uint8_t> status(n_reads, 0);
@@ -334,8 +343,9 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
         unsigned grid = (unsigned)((segs.size() + 3) / 4);
         if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel,
+        hipLaunchKernelGGL(k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel_k,
                            d_codes.p, d_lower.p);
+        if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
         hipLaunchKernelGGL(k_iota_u32, dim3(grid_for_n(W)), dim3(256), 0, st, d_idx.p, (uint64_t)W);
         size_t tb = 0;
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, end_bit, st));
@@ -363,7 +373,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
                        (uint32_t)n_reads);
     ReadIdListParams p{};
     p.mat = index_matrix(ix); p.rs = index_rs(ix); p.w64 = (index_n_colors(ix) + 63) / 64; p.n_colors = index_n_colors(ix);
-    p.n_hash = index_n_hash(ix); p.k = k; p.mod = index_mod(ix);
+    p.n_hash = index_n_hash(ix); p.k = key_len; p.mod = index_mod(ix);
     p.list_codes = d_list.p; p.list_start = d_lstart.p; p.n_reads = n_reads; p.start_sample = start_sample;
     p.hist_pad = p.rs > 128 ? 4u * p.rs : (uint32_t)((C1 + 3) & ~(size_t)3);
     if (p.rs > 128) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, st));   // wide rows count in place

@@ -61,6 +61,8 @@ Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool m
     b.bloom_size = r.u64();
     b.num_hash = r.u64();
     b.k_size = r.u64();
+    const bool mini = path.size() >= 4 && path.compare(path.size() - 4, 4, ".mxi") == 0;   // the suffix selects the struct (main.rs:723)
+    if (mini) b.m_size = r.u64();                                                            // BigsyMapMiniNew.m_size
     const uint64_t nc = r.u64();
     if (nc == 0 || nc > (1u << 24)) die("can't deserialize: %llu colours", (unsigned long long)nc);
     b.colors.assign(nc, std::string());
@@ -72,8 +74,10 @@ Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool m
     }
     const uint32_t w32 = (uint32_t)((nc + 31) / 32);
     const uint64_t n_rows = r.u64();
-    if (!meta_only)
+    if (!meta_only) {
         CID_TRY(cid_index_create(ctx, b.bloom_size, (uint32_t)b.num_hash, (uint32_t)b.k_size, (uint32_t)nc, hash_variant, &b.index));
+        if (mini) CID_TRY(cid_index_set_minimizer(b.index, (uint32_t)b.m_size));
+    }
     const size_t batch = 1u << 22;
     std::vector<uint64_t> ids;
     std::vector<uint32_t> words;
@@ -120,6 +124,7 @@ void save_bigsi(const std::string &path, const Bigsi &b) {
     const uint64_t nc = b.colors.size();
     const uint32_t w32 = (uint32_t)((nc + 31) / 32);
     w64(f, b.bloom_size); w64(f, b.num_hash); w64(f, b.k_size);
+    if (b.m_size) w64(f, b.m_size);
     w64(f, nc);
     for (uint64_t c = 0; c < nc; ++c) { w64(f, c); w64(f, b.colors[c].size()); fwrite(b.colors[c].data(), 1, b.colors[c].size(), f); }
     // rows come back from the device in ascending order; all-zero rows are dropped (build.rs:123-127)
@@ -150,7 +155,7 @@ void save_bigsi(const std::string &path, const Bigsi &b) {
 }
 
 Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
-                   int64_t cutoff, int hash_variant) {
+                   int64_t cutoff, int hash_variant, uint64_t m_size) {
     // tab_to_map (build.rs:15-31): accession \t file [\t file2]; later lines overwrite earlier ones
     std::map<std::string, std::vector<std::string>> refs;  // std::map iterates sorted == accessions.sort() (build.rs:105)
     {
@@ -170,10 +175,11 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
         }
     }
     Bigsi b;
-    b.bloom_size = bloom; b.num_hash = hashes; b.k_size = k;
+    b.bloom_size = bloom; b.num_hash = hashes; b.k_size = k; b.m_size = m_size;
     for (auto &kv : refs) b.colors.push_back(kv.first);
     b.n_ref_kmers.assign(b.colors.size(), 0);
     CID_TRY(cid_index_create(ctx, bloom, (uint32_t)hashes, (uint32_t)k, (uint32_t)b.colors.size(), hash_variant, &b.index));
+    if (m_size) CID_TRY(cid_index_set_minimizer(b.index, (uint32_t)m_size));   // the inserts below then key on find_minimizer(kmer, m)
     uint32_t colour = 0, counter = 1;
     for (auto &kv : refs) {
         fprintf(stderr, "Adding %s to index (%u/%zu)\n", kv.first.c_str(), counter++, refs.size());
@@ -192,7 +198,7 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
             }
             uint64_t nk = 0;
             CID_TRY(cid_kmerset_size(ks, &nk));
-            b.n_ref_kmers[colour] = nk;
+            b.n_ref_kmers[colour] = (m_size && is_gz) ? 0 : nk;   // build_single_mini records it for FASTA accessions only (Q13)
             CID_TRY(cid_index_insert_kmerset(b.index, ks, colour));
             cid_kmerset_destroy(ks);
         } else {
@@ -207,7 +213,7 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
                 kmerize_vector(read_fasta(v[0]), 1, km);
                 if (cutoff != -1) km.clean((uint64_t)cutoff);
             }
-            b.n_ref_kmers[colour] = km.size();
+            b.n_ref_kmers[colour] = (m_size && is_gz) ? 0 : km.size();
             CID_TRY(cid_index_insert_kmers(b.index, km.keys(), colour, km.size()));
         }
         ++colour;

@@ -66,6 +66,7 @@ int64_t auto_cutoff_gpu(cid_kmerset *ks);   // kmer.rs:866-942 from the device h
 // ---------------------------------------------------------------- bigsi.rs
 struct Bigsi {  // BigsyMapNew minus the map, which lives on the device
     uint64_t bloom_size = 0, num_hash = 0, k_size = 0;
+    uint64_t m_size = 0;                    // > 0: BigsyMapMiniNew (.mxi), Bloom keys are minimizers of this length
     std::vector<std::string> colors;        // colour id -> accession
     std::vector<uint64_t> n_ref_kmers;      // by colour id
     cid_index *index = nullptr;
@@ -73,7 +74,7 @@ struct Bigsi {  // BigsyMapNew minus the map, which lives on the device
 Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only = false);  // bigsi.rs:59-69
 void save_bigsi(const std::string &path, const Bigsi &b);                                           // bigsi.rs:51-57
 Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
-                   int64_t cutoff, int hash_variant);                                              // build.rs:15-130
+                   int64_t cutoff, int hash_variant, uint64_t m_size = 0);   // build.rs:15-130; m_size > 0: build_single_mini :396-492
 
 // ---------------------------------------------------------------- reports.rs / read_id tail
 double false_prob(double m, double k, double n);                                                     // read_id_mt_pe.rs:695-698

@@ -2,7 +2,7 @@
 //   search  (src/main.rs:127-217, :555-628)   read_id (:241-328, :704-868)
 //   build   (:31-126, :466-554; needed to produce .bxi files)   info (:218-240, :630-703)
 // Same flag letters, defaults, stdout/stderr/file formats.  Extra flags: --device N, --hash xxh3_v08.
-// Not provided (outside the accelerated path): batch_id, read_filter, .mxi minimizer indices.
+// Minimizer indices (.mxi): build -m [-v M], info, read_id.  Not provided (outside the query path): batch_id, read_filter.
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -98,13 +98,21 @@ int cmd_build(int argc, char **argv) {
         if (!a.has(req)) die("error: The following required arguments were not provided: --%s", req);
     printf(" Ref_file : %s\n Bigsi file : %s\nK-mer size: %s\nBloom filter parameters: num hashes %s, filter size %s\n",
            a.one("refs").c_str(), a.one("bigsi").c_str(), a.one("kmer").c_str(), a.one("num_hashes").c_str(), a.one("bloom").c_str());
-    if (a.flags.count("minimizer")) die("minimizer (.mxi) indices are outside the accelerated path");
+    const bool minimizer = a.flags.count("minimizer") > 0;
+    uint64_t m_value = 0;
+    if (minimizer) {   // main.rs:480-486; -v defaults to 15 and must parse (the reference unwraps)
+        const std::string v = a.has("value") ? a.one("value") : std::string("15");
+        char *end = nullptr;
+        m_value = strtoull(v.c_str(), &end, 10);
+        if (v.empty() || *end) die("called `Result::unwrap()` on an `Err` value: ParseIntError (-v %s)", v.c_str());
+        printf("Build with minimizers, minimizer size: %llu\n", (unsigned long long)m_value);
+    }
     cid_ctx *ctx = make_ctx(a);
     Bigsi b = build_single(ctx, a.one("refs"), num_or<uint64_t>(a, "bloom", 50000000), num_or<uint64_t>(a, "num_hashes", 4),
                            num_or<uint64_t>(a, "kmer", 31), num_or<uint8_t>(a, "quality", 15), num_or<int64_t>(a, "filter", -1),
-                           hash_variant(a));
+                           hash_variant(a), m_value);
     printf("Saving BIGSI to file.\n");
-    save_bigsi(a.one("bigsi") + ".bxi", b);
+    save_bigsi(a.one("bigsi") + (minimizer ? ".mxi" : ".bxi"), b);
     cid_index_destroy(b.index);
     cid_ctx_destroy(ctx);
     return 0;
@@ -142,10 +150,13 @@ int cmd_search(int argc, char **argv) {
 int cmd_info(int argc, char **argv) {
     const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'c', "compressed", true, false}}));
     if (!a.has("bigsi")) die("error: The following required arguments were not provided: --bigsi");
-    if (ends_with(a.one("bigsi"), ".mxi")) die("minimizer (.mxi) indices are outside the accelerated path");
     Bigsi b = load_index(nullptr, a, /*meta_only=*/true);
-    printf("BIGSI parameters:\nBloomfilter-size: %llu\nNumber of hashes: %llu\nK-mer size: %llu\n", (unsigned long long)b.bloom_size,
-           (unsigned long long)b.num_hash, (unsigned long long)b.k_size);
+    if (b.m_size)   // main.rs:645-648
+        printf("BIGSI parameters:\nBloomfilter-size: %llu\nNumber of hashes: %llu\nK-mer size: %llu\n minimizer size: %llu\n\n",
+               (unsigned long long)b.bloom_size, (unsigned long long)b.num_hash, (unsigned long long)b.k_size, (unsigned long long)b.m_size);
+    else
+        printf("BIGSI parameters:\nBloomfilter-size: %llu\nNumber of hashes: %llu\nK-mer size: %llu\n", (unsigned long long)b.bloom_size,
+               (unsigned long long)b.num_hash, (unsigned long long)b.k_size);
     printf("Number of accessions in index: %zu\n", b.colors.size());
     for (size_t c = 0; c < b.colors.size(); ++c)  // colour ids are already in sorted-name order
         printf("%s %llu %.3f\n", b.colors[c].c_str(), (unsigned long long)b.n_ref_kmers[c],
@@ -167,7 +178,6 @@ int cmd_read_id(int argc, char **argv) {
     const size_t batch = num_or<size_t>(a, "batch", 50000);
     const size_t bitvector_sample = num_or<size_t>(a, "bitvector_sample", 3);
     const std::string prefix = a.one("prefix");
-    if (ends_with(a.one("bigsi"), ".mxi")) die("minimizer (.mxi) indices are outside the accelerated path");
     if (down_sample == 0 || batch == 0) die("attempt to calculate the remainder with a divisor of zero");
     cid_ctx *ctx = make_ctx(a);
     Bigsi b = load_index(ctx, a);

@@ -50,9 +50,15 @@ class Index:
         self.ctx, self.lib = ctx, ctx.lib
         self.m, self.n_hash, self.k, self.n_colors = bloom_size, num_hash, k_size, n_colors
         self.w32 = (n_colors + 31) // 32
+        self.m_size = 0
         h = vp()
         check(self.lib.cid_index_create(ctx.h, bloom_size, num_hash, k_size, n_colors, hash_variant, C.byref(h)))
         self.h = h
+
+    def set_minimizer(self, m_size):
+        check(self.lib.cid_index_set_minimizer(self.h, m_size))
+        self.m_size = m_size
+        return self
 
     def put_rows(self, row_ids, words):
         row_ids = np.ascontiguousarray(row_ids, np.uint64)

@@ -61,6 +61,11 @@ void cid_ctx_destroy(cid_ctx *);
  *      :465-474): bit c of a row = colour c = words[c/32] >> (c%32) & 1. ---- */
 int cid_index_create(cid_ctx *, uint64_t bloom_size, uint32_t num_hash, uint32_t k_size, uint32_t n_colors,
                      int hash_variant, cid_index **out);
+/* Minimizer index (BigsyMapMiniNew, src/bigsi.rs:40-49, the `.mxi` file): the Bloom key of a k-mer is
+ * find_minimizer(kmer, m_size) (src/kmer.rs:971-986) instead of the k-mer.  Call once after create.  Affects
+ * cid_index_insert_kmers* (src/build.rs:455-459) and cid_readid_count* (src/kmer.rs:363-394); the search entry points
+ * refuse such an index, as the reference does (src/main.rs:569-573). */
+int cid_index_set_minimizer(cid_index *, uint32_t m_size);
 /* Sparse rows as the .bxi `map` stores them (src/bigsi.rs:59-63): n_rows x W32 little-endian
  * u32 words, W32 = ceil(n_colors/32).  Rows never put stay all-zero == key absent from the map. */
 int cid_index_put_rows(cid_index *, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows);

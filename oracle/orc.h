@@ -49,6 +49,7 @@ orc_kmers *orc_kmers_fq_pe_qual(const char *p1, const char *p2, uint32_t k, uint
 /* ---- index model: BigsyMapNew (bigsi.rs:19-27) with BitVec<u32> rows (bit-vec lib.rs:218-224) ---- */
 typedef struct orc_index {
     uint64_t bloom_size, num_hash, k_size, n_colors;
+    uint64_t m_size;         /* 0 = BigsyMapNew (.bxi); > 0 = BigsyMapMiniNew (.mxi, bigsi.rs:40-49): keys are minimizers */
     uint32_t w32;            /* blocks_for_bits(C) */
     uint32_t *rows;          /* dense bloom_size x w32; an all-zero row == key absent from `map` (build.rs:123-127) */
     char **colors;           /* colour id -> accession */
@@ -64,7 +65,11 @@ void orc_index_insert(orc_index *, uint64_t c, const uint8_t *kmer);
 int orc_index_contains(const orc_index *, uint64_t c, const uint8_t *kmer);           /* simple_bloom.rs:28-38 */
 /* build.rs:33-130 (FASTA and fastq.gz accessions, colours = rank in sorted names) */
 orc_index *orc_build_single(const char *ref_tsv, uint64_t m, uint64_t n_hash, uint64_t k, uint8_t quality, int64_t cutoff);
-int orc_save_bigsi(const char *path, const orc_index *);                               /* bigsi.rs:51-57 + bincode 1.x layout */
+/* build.rs:396-492 (build_single_mini): the same k-mer maps, each distinct k-mer contributes find_minimizer(kmer, m) */
+orc_index *orc_build_single_mini(const char *ref_tsv, uint64_t m, uint64_t n_hash, uint64_t k, uint64_t m_size, uint8_t quality, int64_t cutoff);
+void orc_find_minimizer(const uint8_t *kmer, size_t k, size_t m, uint8_t *out);        /* kmer.rs:971-986 */
+int orc_minimerize_skip_n_set(orc_kmers *set_of_minimizers, const uint8_t *l, size_t len, size_t k, size_t d);  /* kmer.rs:363-394 (one string) */
+int orc_save_bigsi(const char *path, const orc_index *);                               /* bigsi.rs:51-57 / 71-77 + bincode 1.x layout */
 orc_index *orc_read_bigsi(const char *path);                                           /* bigsi.rs:59-63 */
 
 /* ---- search loops ---- */

@@ -31,7 +31,7 @@ def build():
 
 class _Index(C.Structure):
     _fields_ = [("bloom_size", C.c_uint64), ("num_hash", C.c_uint64), ("k_size", C.c_uint64),
-                ("n_colors", C.c_uint64), ("w32", C.c_uint32), ("rows", u32p),
+                ("n_colors", C.c_uint64), ("m_size", C.c_uint64), ("w32", C.c_uint32), ("rows", u32p),
                 ("colors", C.POINTER(C.c_char_p)), ("n_ref_kmers", u64p)]
 
 
@@ -75,6 +75,9 @@ def lib():
         "orc_index_insert": (None, [ip, C.c_uint64, C.c_char_p]),
         "orc_index_contains": (C.c_int, [ip, C.c_uint64, C.c_char_p]),
         "orc_build_single": (ip, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint8, C.c_int64]),
+        "orc_build_single_mini": (ip, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint8, C.c_int64]),
+        "orc_find_minimizer": (None, [C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p]),
+        "orc_minimerize_skip_n_set": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t]),
         "orc_save_bigsi": (C.c_int, [C.c_char_p, ip]),
         "orc_read_bigsi": (ip, [C.c_char_p]),
         "orc_search_count": (None, [ip, vp, vp, C.c_uint64, vp, vp, vp, vp]),
@@ -222,6 +225,11 @@ class Index:
     n_hash = property(lambda s: s.p.contents.num_hash)
     k = property(lambda s: s.p.contents.k_size)
     n_colors = property(lambda s: s.p.contents.n_colors)
+    m_size = property(lambda s: s.p.contents.m_size)
+
+    def set_minimizer(self, m_size):
+        """turn the index into a BigsyMapMiniNew: keys are minimizers of length m_size (call before inserting)"""
+        self.p.contents.m_size = m_size
     w32 = property(lambda s: s.p.contents.w32)
 
     def rows(self) -> np.ndarray:
@@ -255,6 +263,13 @@ class Index:
         p = lib().orc_read_bigsi(path.encode())
         if not p:
             raise IOError(path)
+        return Index(handle=p)
+
+    @staticmethod
+    def build_single_mini(ref_tsv, m, n_hash, k, m_size, quality=15, cutoff=-1):
+        p = lib().orc_build_single_mini(ref_tsv.encode(), m, n_hash, k, m_size, quality, cutoff)
+        if not p:
+            raise IOError(ref_tsv)
         return Index(handle=p)
 
     @staticmethod
@@ -343,6 +358,20 @@ def unique_modes(unique_colour, freq, n_colors):
     modes = np.zeros(n_colors, np.uint64)
     lib().orc_unique_modes(_ptr(uc), _ptr(f), len(uc), n_colors, _ptr(modes))
     return modes
+
+
+def find_minimizer(kmer: bytes, m: int) -> bytes:
+    out = C.create_string_buffer(m)
+    lib().orc_find_minimizer(kmer, len(kmer), m, out)
+    return out.raw
+
+
+def minimizer_set(seqs, k, m, d=1):
+    """kmer.rs:363-394 over a read's mates -> Kmers of width m (first-occurrence order)"""
+    km = Kmers(m)
+    for s in seqs:
+        lib().orc_minimerize_skip_n_set(km.h, s, len(s), k, d)
+    return km
 
 
 def false_prob(m, k, n):

@@ -163,6 +163,35 @@ int orc_kmerize_fq_read(orc_kmers *m, const uint8_t *seq, const uint8_t *qual, s
     return 0;
 }
 
+void orc_find_minimizer(const uint8_t *seq, size_t k, size_t m, uint8_t *out) { /* kmer.rs:971-986 */
+    uint8_t *r_seq = (uint8_t *)malloc(k ? k : 1);
+    orc_revcomp(seq, k, r_seq);
+    const uint8_t *minmer = seq;                                    /* &seq[..m]: the rc of position 0 is never tried */
+    for (size_t i = 1; i + m <= k; ++i) {
+        const uint8_t *min_f = seq + i, *min_rc = r_seq + (k - (i + m));
+        if (memcmp(min_f, minmer, m) < 0) minmer = min_f;
+        if (memcmp(min_rc, minmer, m) < 0) minmer = min_rc;
+    }
+    memcpy(out, minmer, m);
+    free(r_seq);
+}
+
+int orc_minimerize_skip_n_set(orc_kmers *set, const uint8_t *l, size_t len, size_t k, size_t d) { /* kmer.rs:363-394; set->k == m */
+    if (len < k) return 0;                                          /* `continue` */
+    const size_t m = set->k;
+    uint8_t *l_r = (uint8_t *)malloc(len), *mn = (uint8_t *)malloc(m), *up = (uint8_t *)malloc(m);
+    orc_revcomp(l, len, l_r);
+    for (size_t i = 0; i + k <= len; i += d) {
+        const uint8_t *fwd = l + i, *rc = l_r + (len - (i + k));
+        if (!orc_has_no_n(fwd, k)) continue;
+        orc_find_minimizer(memcmp(fwd, rc, k) < 0 ? fwd : rc, k, m, mn);
+        upper_copy(up, mn, m);                                       /* min.to_uppercase() */
+        orc_kmers_insert(set, up, 1);
+    }
+    free(l_r); free(mn); free(up);
+    return 0;
+}
+
 orc_kmers *orc_clean_map(const orc_kmers *m, uint64_t t) { /* kmer.rs:826-837: keep value > t */
     orc_kmers *o = orc_kmers_new(m->k);
     for (uint64_t e = 0; e < m->n; ++e)
@@ -360,9 +389,9 @@ void orc_index_set_color(orc_index *ix, uint64_t c, const char *name, uint64_t n
 const uint32_t *orc_index_rows(const orc_index *ix) { return ix->rows; }
 uint32_t *orc_index_rows_mut(orc_index *ix) { return ix->rows; }
 
-static inline uint64_t bit_index(const orc_index *ix, const uint8_t *kmer, uint64_t i) {
-    /* xxh3::hash64_with_seed(&k.as_bytes(), i as u64) % bloom_size as u64 */
-    return orc_xxh3_64_with_seed(kmer, (size_t)ix->k_size, i) % ix->bloom_size;
+static inline uint64_t bit_index(const orc_index *ix, const uint8_t *key, uint64_t i) {
+    /* xxh3::hash64_with_seed(&k.as_bytes(), i as u64) % bloom_size as u64 — the key is a k-mer, or a minimizer in a .mxi */
+    return orc_xxh3_64_with_seed(key, (size_t)(ix->m_size ? ix->m_size : ix->k_size), i) % ix->bloom_size;
 }
 static inline const uint32_t *row_ptr(const orc_index *ix, uint64_t r) { return ix->rows + r * ix->w32; }
 static inline int row_absent(const orc_index *ix, uint64_t r) {  /* !bigsi_map.contains_key(&bi) */
@@ -373,6 +402,11 @@ static inline int row_absent(const orc_index *ix, uint64_t r) {  /* !bigsi_map.c
 static inline int bit_get(const uint32_t *row, uint64_t c) { return (row[c / 32] >> (c % 32)) & 1; } /* lib.rs:465-474 */
 
 void orc_index_insert(orc_index *ix, uint64_t c, const uint8_t *kmer) { /* simple_bloom.rs:19-26 + build.rs:116-128 */
+    uint8_t mini[256];
+    if (ix->m_size) {                                               /* build.rs:455-459: filter.insert(&find_minimizer(&kmer, m)) */
+        orc_find_minimizer(kmer, (size_t)ix->k_size, (size_t)ix->m_size, mini);
+        kmer = mini;
+    }
     for (uint64_t i = 0; i < ix->num_hash; ++i) {
         uint64_t r = bit_index(ix, kmer, i);
         ix->rows[r * ix->w32 + c / 32] |= 1u << (c % 32);     /* lib.rs:492-500 */
@@ -387,8 +421,16 @@ int orc_index_contains(const orc_index *ix, uint64_t c, const uint8_t *kmer) { /
 typedef struct { char *name; char *f1; char *f2; } acc_t;
 static int acc_cmp(const void *a, const void *b) { return strcmp(((const acc_t *)a)->name, ((const acc_t *)b)->name); }
 
+static orc_index *build_single_impl(const char *ref_tsv, uint64_t m, uint64_t n_hash, uint64_t k, uint64_t m_size, uint8_t quality, int64_t cutoff);
 orc_index *orc_build_single(const char *ref_tsv, uint64_t m, uint64_t n_hash, uint64_t k, uint8_t quality, int64_t cutoff) {
-    /* build.rs:15-31 (tab_to_map) + build.rs:33-130 */
+    return build_single_impl(ref_tsv, m, n_hash, k, 0, quality, cutoff);
+}
+orc_index *orc_build_single_mini(const char *ref_tsv, uint64_t m, uint64_t n_hash, uint64_t k, uint64_t m_size, uint8_t quality, int64_t cutoff) {
+    return build_single_impl(ref_tsv, m, n_hash, k, m_size, quality, cutoff);
+}
+static orc_index *build_single_impl(const char *ref_tsv, uint64_t m, uint64_t n_hash, uint64_t k, uint64_t m_size, uint8_t quality, int64_t cutoff) {
+    /* build.rs:15-31 (tab_to_map) + build.rs:33-130; with m_size > 0: build.rs:396-492 (same maps, minimizers inserted;
+     * n_ref_kmers is only recorded for FASTA accessions there — SURVEY App. B Q13) */
     size_t n; char *c = slurp(ref_tsv, &n);
     if (!c) return NULL;
     acc_t *acc = NULL; size_t na = 0;
@@ -411,8 +453,10 @@ orc_index *orc_build_single(const char *ref_tsv, uint64_t m, uint64_t n_hash, ui
     free(c);
     qsort(acc, na, sizeof(acc_t), acc_cmp);                /* accessions.sort(): colour = rank, build.rs:102-113 */
     orc_index *ix = orc_index_new(m, n_hash, k, na);
+    ix->m_size = m_size;
     for (size_t a = 0; a < na; ++a) {
         orc_kmers *km;
+        int is_fasta = 0;
         if (acc[a].f2) {                                    /* build.rs:54-67 */
             orc_kmers *u = orc_kmers_fq_pe_qual(acc[a].f1, acc[a].f2, (uint32_t)k, quality);
             if (!u) { orc_index_free(ix); return NULL; }
@@ -433,9 +477,11 @@ orc_index *orc_build_single(const char *ref_tsv, uint64_t m, uint64_t n_hash, ui
                 orc_strvec_free(&v);
                 if (cutoff == -1) km = u;
                 else { km = orc_clean_map(u, (uint64_t)cutoff); orc_kmers_free(u); }
+                is_fasta = 1;
             }
         }
-        orc_index_set_color(ix, a, acc[a].name, orc_kmers_len(km));   /* ref_kmer.insert(accession, kmers.len()) */
+        /* ref_kmer.insert(accession, kmers.len()); build_single_mini forgets it for fastq accessions */
+        orc_index_set_color(ix, a, acc[a].name, (m_size && !is_fasta) ? 0 : orc_kmers_len(km));
         for (uint64_t e2 = 0; e2 < orc_kmers_len(km); ++e2) orc_index_insert(ix, a, orc_kmers_keys(km) + e2 * k);
         orc_kmers_free(km);
     }
@@ -452,6 +498,7 @@ int orc_save_bigsi(const char *path, const orc_index *ix) { /* bigsi.rs:51-57; s
     FILE *f = fopen(path, "wb");
     if (!f) return -1;
     w64(f, ix->bloom_size); w64(f, ix->num_hash); w64(f, ix->k_size);
+    if (ix->m_size) w64(f, ix->m_size);                     /* BigsyMapMiniNew.m_size (bigsi.rs:40-49) */
     w64(f, ix->n_colors);                                   /* colors: FnvHashMap<usize,String> */
     for (uint64_t c = 0; c < ix->n_colors; ++c) {
         size_t l = strlen(ix->colors[c]);
@@ -483,12 +530,15 @@ static int r64(FILE *f, uint64_t *v) {
     return 0;
 }
 
-orc_index *orc_read_bigsi(const char *path) { /* bigsi.rs:59-63 */
+orc_index *orc_read_bigsi(const char *path) { /* bigsi.rs:59-63; a path ending in ".mxi" is a BigsyMapMiniNew (bigsi.rs:79-83) */
     FILE *f = fopen(path, "rb");
     if (!f) return NULL;
-    uint64_t m, nh, k, nc;
-    if (r64(f, &m) || r64(f, &nh) || r64(f, &k) || r64(f, &nc)) { fclose(f); return NULL; }
+    uint64_t m, nh, k, nc, msz = 0;
+    const size_t pl = strlen(path);
+    const int mini = pl >= 4 && strcmp(path + pl - 4, ".mxi") == 0;
+    if (r64(f, &m) || r64(f, &nh) || r64(f, &k) || (mini && r64(f, &msz)) || r64(f, &nc)) { fclose(f); return NULL; }
     orc_index *ix = orc_index_new(m, nh, k, nc);
+    ix->m_size = msz;
     for (uint64_t i = 0; i < nc; ++i) {
         uint64_t id, l;
         if (r64(f, &id) || r64(f, &l) || id >= nc) goto fail;
@@ -636,7 +686,7 @@ void orc_search_index_classic(const orc_index *ix, const uint8_t *kmers, uint64_
     memset(report, 0, (C + 1) * sizeof(uint64_t));
     for (uint64_t j = 0; j < n_kmers; ++j) {
         int absent;
-        and_rows(ix, kmers + j * ix->k_size, first, &absent);
+        and_rows(ix, kmers + j * (ix->m_size ? ix->m_size : ix->k_size), first, &absent);
         if (absent) { report[C] += 1; break; }             /* :86-89 */
         for (uint64_t c = 0; c < C; ++c) if (bit_get(first, c)) report[c] += 1;   /* :91-98 */
     }
@@ -652,7 +702,7 @@ void orc_search_index(const orc_index *ix, const uint8_t *kmers, uint64_t n_kmer
     uint64_t counter = 0;
     for (uint64_t j = 0; j < n_kmers; ++j) {
         int absent;
-        and_rows(ix, kmers + j * ix->k_size, first, &absent);
+        and_rows(ix, kmers + j * (ix->m_size ? ix->m_size : ix->k_size), first, &absent);
         if (absent) { report[C] += 1; break; }             /* :126-128 / :150-152 */
         if (counter < start_sample) {
             for (uint64_t c = 0; c < C; ++c) if (bit_get(first, c)) { in_set[c] = 1; report[c] += 1; }  /* :130-138 */
@@ -676,9 +726,13 @@ void orc_readid_counts(const orc_index *ix, const uint8_t *bases, const uint64_t
         n_kmers[r] = 0; status[r] = 0;
         uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
         if (s0 == s1 || seq_off[s0 + 1] - seq_off[s0] < k) { status[r] = 1; continue; }  /* :305 too_short (first mate only) */
-        orc_kmers *set = orc_kmers_new((uint32_t)k);
-        for (uint64_t s = s0; s < s1; ++s)
-            orc_kmerize_skip_n_set(set, bases + seq_off[s], (size_t)(seq_off[s + 1] - seq_off[s]), (size_t)d);
+        orc_kmers *set = orc_kmers_new((uint32_t)(ix->m_size ? ix->m_size : k));
+        for (uint64_t s = s0; s < s1; ++s) {
+            const uint8_t *l = bases + seq_off[s];
+            const size_t len = (size_t)(seq_off[s + 1] - seq_off[s]);
+            if (ix->m_size) orc_minimerize_skip_n_set(set, l, len, (size_t)k, (size_t)d);   /* :317-318 (m > 0) */
+            else orc_kmerize_skip_n_set(set, l, len, (size_t)d);                            /* :315-316 */
+        }
         n_kmers[r] = (uint32_t)orc_kmers_len(set);
         if (start_sample == 0) orc_search_index_classic(ix, orc_kmers_keys(set), orc_kmers_len(set), rep);
         else orc_search_index(ix, orc_kmers_keys(set), orc_kmers_len(set), start_sample, rep);

@@ -32,6 +32,16 @@ void shim_hash_canonical_code(const uint8_t *kmer, uint32_t k, uint32_t n, uint6
     cid::xxh3_seeds_from(r, k, n, [&](uint32_t s, uint64_t h) { out[s] = h; });
 }
 
+// canonical ACGT k-mer (ASCII) -> minimizer as the device computes it from the 2-bit code -> ASCII, and its hashes (len m)
+void shim_minimizer(const uint8_t *kmer, uint32_t k, uint32_t m, uint32_t n, uint8_t *out_mini, uint64_t *out_hash) {
+    uint64_t msb = 0;
+    for (uint32_t j = 0; j < k; ++j) msb = (msb << 2) | (uint64_t)(kmer[j] == 'A' ? 0 : kmer[j] == 'C' ? 1 : kmer[j] == 'G' ? 2 : 3);
+    const uint64_t mini = cid::minimizer_code(msb, k, m);
+    const cid::CodeReader r{cid::rev_fields(mini, m)};
+    for (uint32_t j = 0; j < m; ++j) out_mini[j] = (uint8_t)r.rd8(j);
+    cid::xxh3_seeds_from(r, m, n, [&](uint32_t s, uint64_t h) { out_hash[s] = h; });
+}
+
 uint64_t shim_mod(uint64_t h, uint64_t m) {
     const cid::ModMagicHost mh = cid::make_mod_magic(m);
     const cid::ModMagic mm{mh.m, mh.magic, mh.shift, mh.flags};

@@ -20,6 +20,7 @@ def shim(tmp_path_factory):
     L.shim_hash_seeds.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.shim_hash_canonical_code.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_char_p,
                                            C.POINTER(C.c_uint64)]
+    L.shim_minimizer.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint64)]
     L.shim_mod.restype = C.c_uint64
     L.shim_mod.argtypes = [C.c_uint64, C.c_uint64]
     L.shim_row_stride_words.restype = C.c_uint32
@@ -91,3 +92,19 @@ def test_packed_code_path_matches_string_path(shim, orc):
             assert msb.value == int("".join(str(b"ACGT".index(c)) for c in want), 4)
             for sd in range(4):
                 assert out[sd] == xxhash.xxh3_64_intdigest(want, seed=sd), (k, s, sd)
+
+
+def test_minimizer_code_matches_find_minimizer(shim, orc):
+    """device minimizer of a 2-bit code == find_minimizer (kmer.rs:971-986) of the string, and its hash == XXH3 of that string"""
+    import xxhash
+    rnd = random.Random(8)
+    for k, m in ((31, 15), (27, 15), (21, 11), (32, 16), (15, 15), (16, 1), (31, 31), (20, 9), (12, 4)):
+        for trial in range(200):
+            s = bytes(rnd.choice(b"ACGT") for _ in range(k)) if trial else b"A" * k
+            want = orc.find_minimizer(s, m)
+            out = C.create_string_buffer(m)
+            hs = (C.c_uint64 * 3)()
+            shim.shim_minimizer(s, k, m, 3, out, hs)
+            assert out.raw == want, (k, m, s)
+            for sd in range(3):
+                assert hs[sd] == xxhash.xxh3_64_intdigest(want, seed=sd)

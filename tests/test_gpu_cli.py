@@ -264,3 +264,38 @@ def test_k_above_32_uses_host_map(orc, env, tmp_path):
     run("read_id", "-b", pre + ".bxi", "-q", f1, "-n", str(tmp_path / "rid"))
     want = expected_readid(orc, oix, ["@" + r[0].decode() for r in r1], [[orc.qual_mask(a[1], a[2], 15)] for a in r1], 1, 3)
     assert open(tmp_path / "rid_reads.txt").read().splitlines() == want
+
+
+def test_minimizer_index_cli(orc, env, tmp_path):
+    """`build -m -v 15` -> .mxi (BigsyMapMiniNew), `info`, `read_id`, and `search` refusing it (src/main.rs:485-522, 569-573, 645-648)."""
+    d, _, _, genomes = env
+    tsv = str(d / "ref_file.txt")
+    pre = str(tmp_path / "mini")
+    out, err = run("build", "-s", "750000", "-n", "4", "-k", "27", "-b", pre, "-r", tsv, "-m", "-v", "15")
+    assert "Build with minimizers, minimizer size: 15" in out
+    oix = orc.Index.build_single_mini(tsv, 750000, 4, 27, 15)
+    ref = str(tmp_path / "oracle.mxi")
+    oix.save(ref)
+    assert open(pre + ".mxi", "rb").read() == open(ref, "rb").read()
+    run("build", "-s", "750000", "-n", "4", "-k", "27", "-b", pre + "_h", "-r", tsv, "-m", host_kmers=True)   # -v defaults to 15
+    assert open(pre + "_h.mxi", "rb").read() == open(ref, "rb").read()
+    out, _ = run("info", "-b", pre + ".mxi")
+    assert out.splitlines()[:7] == ["BIGSI parameters:", "Bloomfilter-size: 750000", "Number of hashes: 4", "K-mer size: 27",
+                                    " minimizer size: 15", "", "Number of accessions in index: 4"]
+    out, err = run("search", "-b", pre + ".mxi", "-q", os.path.join(REFS, PHAGES[0] + ".fasta"), "-s")
+    assert out == "" and "An index with minimizers (.mxi) is used, but not available for this function" in err
+    for pe in (False, True):
+        rng = np.random.default_rng(21)
+        r1 = synth_fastq_records(rng, genomes, 500, 150, mate=0)
+        rng = np.random.default_rng(21)
+        r2 = synth_fastq_records(rng, genomes, 500, 150, mate=1)
+        f1, f2 = str(tmp_path / f"m{int(pe)}_1.fastq.gz"), str(tmp_path / f"m{int(pe)}_2.fastq.gz")
+        write_fastq_gz(f1, r1)
+        write_fastq_gz(f2, r2)
+        prefix = str(tmp_path / f"rid{int(pe)}")
+        run("read_id", "-b", pre + ".mxi", "-q", f1, *([f2] if pe else []), "-n", prefix)
+        ids = ["@" + r[0].decode() for r in r1]
+        masked = [[orc.qual_mask(a[1], a[2], 15)] + ([orc.qual_mask(b[1], b[2], 15)] if pe else []) for a, b in zip(r1, r2)]
+        want = expected_readid(orc, oix, ids, masked, 1, 3)
+        assert open(prefix + "_reads.txt").read().splitlines() == want
+        assert sum("Listeria_phage" in l for l in want) > 300

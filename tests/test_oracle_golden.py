@@ -272,3 +272,72 @@ def test_kmer_poll_plus(orc):  # read_id_mt_pe.rs:187-251, SURVEY.md App. E1
     assert ix.kmer_poll_plus(np.array([1, 0, 0, 0, 0], np.uint64), 1000) == ("no_significant_hits", 0, 1000, "reject", 0)
     p = orc.false_prob(750000, 4, 30000)
     assert abs(p - (1 - np.exp(-4 * 30000.5 / 749999)) ** 4) < 1e-15
+
+
+def _py_find_minimizer(kmer: bytes, m: int) -> bytes:
+    """Independent restatement of kmer.rs:971-986: window 0 contributes its forward m-mer only, later windows also their
+    reverse-complement m-mer; strict `<` keeps the first minimum."""
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    rc = bytes(comp.get(c, c) for c in reversed(kmer))
+    n = len(kmer)
+    best = kmer[:m]
+    for i in range(1, n - m + 1):
+        best = min(best, kmer[i:i + m], rc[n - (i + m):n - i])
+    return best
+
+
+def test_find_minimizer(orc):  # src/kmer.rs:971-986
+    assert orc.find_minimizer(b"TTTTA", 3) == b"AAA"            # revcomp of window 1 (TTT) wins
+    assert orc.find_minimizer(b"TTTAC", 3) == b"GTA"            # revcomp GTAAA: its AAA sits over window 0 and is never compared
+    assert orc.find_minimizer(b"TTTGG", 5) == b"TTTGG"          # m == k: the forward k-mer, its revcomp is never compared
+    assert orc.find_minimizer(b"ACGTACGTAC", 4) == b"ACGT"
+    rng = np.random.default_rng(5)
+    for k, m in ((27, 15), (31, 15), (21, 7), (35, 19), (16, 16), (64, 33)):
+        for _ in range(300):
+            km = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), k))
+            assert orc.find_minimizer(km, m) == _py_find_minimizer(km, m)
+
+
+def test_minimizer_set_of_read(orc):  # src/kmer.rs:363-394: canonical k-mers without N, one minimizer each, -d stride
+    rng = np.random.default_rng(6)
+    read = bytearray(rng.choice(np.frombuffer(b"ACGT", np.uint8), 120))
+    read[40] = ord("N")
+    read = bytes(read)
+    for d in (1, 3):
+        km = orc.Kmers(27)
+        km.kmerize_skip_n_set(read, d)
+        want = []
+        for key in km.keys():
+            mm = _py_find_minimizer(key.tobytes(), 15)
+            if mm not in want:
+                want.append(mm)
+        got = [r.tobytes() for r in orc.minimizer_set([read], 27, 15, d).keys()]
+        assert got == want and 0 < len(want) < len(km)
+
+
+def test_mxi_layout_and_roundtrip(orc, tmp_path):  # bigsi.rs:40-49, 71-83: BigsyMapMiniNew = BigsyMapNew + m_size after k_size
+    tsv = _write_ref_tsv(tmp_path)
+    mix = orc.Index.build_single_mini(tsv, 750000, 4, 27, 15)
+    full = orc.Index.build_single(tsv, 750000, 4, 27)
+    assert mix.m_size == 15 and mix.colors() == sorted(PHAGES)
+    assert mix.n_ref_kmers() == full.n_ref_kmers()              # FASTA accessions: distinct k-mers, not minimizers (build.rs:444)
+    assert 0 < int((mix.rows()[:, 0] != 0).sum()) < int((full.rows()[:, 0] != 0).sum())
+    # every k-mer of an accession is found again through its minimizer, under that accession's colour
+    seqs = orc.read_fasta(os.path.join(REFS, PHAGES[1] + ".fasta"))
+    km = orc.Kmers(27)
+    km.kmerize_vector(seqs[0], 1)
+    import xxhash
+    for key in km.keys()[:200]:
+        mm = _py_find_minimizer(key.tobytes(), 15)
+        for s in range(4):
+            assert int(mix.rows()[xxhash.xxh3_64_intdigest(mm, seed=s) % 750000, 0]) >> 1 & 1
+    p = str(tmp_path / "phage.mxi")
+    mix.save(p)
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<5Q", raw, 0) == (750000, 4, 27, 15, 4)
+    back = orc.Index.read(p)
+    assert back.m_size == 15 and np.array_equal(back.rows(), mix.rows())
+    assert back.colors() == mix.colors() and back.n_ref_kmers() == mix.n_ref_kmers()
+    p2 = str(tmp_path / "again.mxi")
+    back.save(p2)
+    assert open(p2, "rb").read() == raw
