@@ -46,14 +46,16 @@ void kmers_from_fq_qual(const std::string &path, uint8_t q, KmerMap &out);      
 void kmers_fq_pe_qual(const std::string &p1, const std::string &p2, uint8_t q, KmerMap &out);  // kmer.rs:581-655
 
 // gz/plain line reader with BufRead::lines() semantics (strips \n and \r\n)
-class LineReader {
+class LineReader {   // inflates on its own thread, a few MiB ahead of the caller (two mates of a pair decode in parallel)
   public:
     explicit LineReader(const std::string &path);
     ~LineReader();
+    LineReader(const LineReader &) = delete;
+    LineReader &operator=(const LineReader &) = delete;
     bool next(std::string &line);
   private:
-    void *gz_;
-    std::vector<char> buf_;
+    struct Impl;
+    Impl *p_;
 };
 
 // GPU k-mer maps (cid_kmerset, k <= 32; COLORID_HOST_KMERS=1 forces the host map).  count_fastq_gpu returns nullptr when

@@ -9,6 +9,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 #include "colorid_host.hpp"
 
@@ -394,6 +398,71 @@ std::vector<double> false_prob_map(const Bigsi &b) {  // read_id_mt_pe.rs:18-38
     return fp;
 }
 
+// The GPU call, the poll and the output of batch i run on their own thread while the caller parses batch i+1
+// (and the LineReaders inflate further ahead): the phases the reference runs back to back (read_id_mt_pe.rs:864-907).
+// Rows leave in submission order.  The classifier thread is the only one that touches `ctx` while it runs.
+class BatchClassifier {
+  public:
+    BatchClassifier(cid_ctx *ctx, const Bigsi &b, size_t d, double fp_correct, size_t start_sample, const std::vector<double> &fp, FILE *out,
+                    const char *progress_fmt)
+        : ctx_(ctx), b_(b), d_(d), fp_correct_(fp_correct), start_sample_(start_sample), fp_(fp), out_(out), progress_fmt_(progress_fmt),
+          worker_([this] { run(); }) {}
+    // hands `rb` over and leaves an empty batch in its place; waits while kDepth batches are queued
+    void submit(ReadBatch &rb) {
+        if (rb.size() == 0) return;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_room_.wait(lk, [&] { return queue_.size() < kDepth; });
+        queue_.push_back(std::move(rb));
+        if (!spare_.empty()) { rb = std::move(spare_.back()); spare_.pop_back(); }
+        else rb = ReadBatch();
+        rb.clear();
+        cv_work_.notify_one();
+    }
+    uint64_t finish() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            done_ = true;
+        }
+        cv_work_.notify_one();
+        worker_.join();
+        return n_reads_;
+    }
+  private:
+    static constexpr size_t kDepth = 2;
+    void run() {
+        for (;;) {
+            ReadBatch rb;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return done_ || !queue_.empty(); });
+                if (queue_.empty()) return;
+                rb = std::move(queue_.front());
+                queue_.pop_front();
+                cv_room_.notify_one();
+            }
+            n_reads_ += classify_batch(ctx_, b_, rb, d_, fp_correct_, start_sample_, fp_, out_);
+            fprintf(stderr, progress_fmt_, (unsigned long long)n_reads_);
+            std::lock_guard<std::mutex> lk(mu_);
+            spare_.push_back(std::move(rb));
+        }
+    }
+    cid_ctx *ctx_;
+    const Bigsi &b_;
+    size_t d_;
+    double fp_correct_;
+    size_t start_sample_;
+    const std::vector<double> &fp_;
+    FILE *out_;
+    const char *progress_fmt_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_room_;
+    std::deque<ReadBatch> queue_;
+    std::vector<ReadBatch> spare_;
+    bool done_ = false;
+    uint64_t n_reads_ = 0;
+    std::thread worker_;   // last member: starts after everything above is initialised
+};
+
 }  // namespace
 
 void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
@@ -404,8 +473,9 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     LineReader r(fq[0]);
     ReadBatch rb;
+    BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
     std::string line, id, seq;
-    uint64_t line_count = 1, read_count = 0;
+    uint64_t line_count = 1;
     const uint64_t lines_per_batch = (uint64_t)batch * 4;
     while (r.next(line)) {
         if (line_count % 4 == 1) id = line;
@@ -415,13 +485,10 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
             rb.push(id, &seq, 1);
         }
         ++line_count;
-        if (line_count % lines_per_batch == 0) {
-            read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
-            fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
-        }
+        if (line_count % lines_per_batch == 0) classifier.submit(rb);
     }
-    read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
-    fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
+    classifier.submit(rb);
+    const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
     if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll);
@@ -435,8 +502,9 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     LineReader r1(fq[0]), r2(fq[1]);
     ReadBatch rb;
+    BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
     std::string l1, l2, id, seqs[2];
-    uint64_t line_count = 1, read_count = 0;
+    uint64_t line_count = 1;
     const uint64_t lines_per_batch = (uint64_t)batch * 4;
     while (r1.next(l1)) {
         const bool has2 = r2.next(l2);
@@ -451,15 +519,13 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
             rb.push(id, seqs, 2);
         }
         ++line_count;
-        if (line_count % lines_per_batch == 0) {
-            read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
-            fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
-        }
+        if (line_count % lines_per_batch == 0) classifier.submit(rb);
     }
-    read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
-    fprintf(stderr, "%llu read pairs classified\r", (unsigned long long)read_count);
+    classifier.submit(rb);
+    const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu read pairs in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
+    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll);
 }
 
 void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
@@ -472,8 +538,9 @@ void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &f
     FILE *f = fopen(fq[0].c_str(), "rb");
     if (!f) die("file not found: %s", fq[0].c_str());
     ReadBatch rb;
+    BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, " %llu reads classified\r");
     std::string sub, id, l;
-    uint64_t count = 0, read_count = 0;
+    uint64_t count = 0;
     char *lineptr = nullptr;
     size_t cap = 0;
     ssize_t got;
@@ -491,16 +558,13 @@ void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &f
             sub += l;
         }
         ++count;
-        if (rb.size() > 0 && rb.size() % batch == 0) {
-            read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
-            fprintf(stderr, " %llu reads classified\r", (unsigned long long)read_count);
-        }
+        if (rb.size() > 0 && rb.size() % batch == 0) classifier.submit(rb);
     }
     free(lineptr);
     fclose(f);
     rb.push(id, &sub, 1);
-    read_count += classify_batch(ctx, b, rb, d, fp_correct, start_sample, fp, out);
-    fprintf(stderr, " %llu reads classified\r", (unsigned long long)read_count);
+    classifier.submit(rb);
+    const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
 }

@@ -7,6 +7,10 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 #include "colorid_host.hpp"
 
@@ -80,27 +84,93 @@ void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, st
     read_fasta_impl(path, &labels, seqs);
 }
 
-LineReader::LineReader(const std::string &path) : buf_(1 << 16) {
-    gzFile f = gzopen(path.c_str(), "rb");  // transparently reads plain files too; multi-member gzip like MultiGzDecoder
-    if (!f) die("file not found: %s", path.c_str());
-    gzbuffer(f, 1 << 20);
-    gz_ = f;
+// Decoded text travels in blocks through a small bounded queue: zlib runs on the reader's own thread while the caller
+// splits lines, masks qualities and feeds the GPU.  gzread() continues across gzip members like MultiGzDecoder and reads
+// plain files as they are.
+struct LineReader::Impl {
+    static constexpr size_t kBlock = 4u << 20, kDepth = 4;
+    gzFile gz = nullptr;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_full, cv_free;
+    std::deque<std::vector<char>> full, free_blocks;
+    bool eof = false, stop = false;
+    std::vector<char> cur;   // block being split by next()
+    size_t pos = 0;
+
+    void run() {
+        for (;;) {
+            std::vector<char> blk;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_free.wait(lk, [&] { return stop || full.size() < kDepth; });
+                if (stop) return;
+                if (!free_blocks.empty()) { blk = std::move(free_blocks.front()); free_blocks.pop_front(); }
+            }
+            blk.resize(kBlock);
+            size_t got = 0;
+            while (got < kBlock) {   // gzread may return short counts at member boundaries
+                const int n = gzread(gz, blk.data() + got, (unsigned)(kBlock - got));
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+            blk.resize(got);
+            std::lock_guard<std::mutex> lk(mu);
+            if (got) full.push_back(std::move(blk));
+            if (got < kBlock) eof = true;
+            cv_full.notify_one();
+            if (eof) return;
+        }
+    }
+    bool refill() {   // false at end of input
+        std::unique_lock<std::mutex> lk(mu);
+        if (cur.capacity()) free_blocks.push_back(std::move(cur));
+        cv_full.wait(lk, [&] { return eof || !full.empty(); });
+        if (full.empty()) { cur = std::vector<char>(); pos = 0; return false; }
+        cur = std::move(full.front());
+        full.pop_front();
+        pos = 0;
+        cv_free.notify_one();
+        return true;
+    }
+};
+
+LineReader::LineReader(const std::string &path) : p_(new Impl) {
+    p_->gz = gzopen(path.c_str(), "rb");
+    if (!p_->gz) die("file not found: %s", path.c_str());
+    gzbuffer(p_->gz, 1 << 20);
+    p_->worker = std::thread([this] { p_->run(); });
 }
 LineReader::~LineReader() {
-    if (gz_) gzclose(static_cast<gzFile>(gz_));
+    {
+        std::lock_guard<std::mutex> lk(p_->mu);
+        p_->stop = true;
+    }
+    p_->cv_free.notify_all();
+    if (p_->worker.joinable()) p_->worker.join();
+    if (p_->gz) gzclose(p_->gz);
+    delete p_;
 }
 bool LineReader::next(std::string &line) {
     line.clear();
     bool got = false;
-    while (gzgets(static_cast<gzFile>(gz_), buf_.data(), (int)buf_.size())) {
+    for (;;) {
+        if (p_->pos == p_->cur.size() && !p_->refill()) break;
         got = true;
-        size_t l = strlen(buf_.data());
-        line.append(buf_.data(), l);
-        if (l && buf_[l - 1] == '\n') break;
+        const char *b = p_->cur.data() + p_->pos;
+        const size_t left = p_->cur.size() - p_->pos;
+        const char *nl = static_cast<const char *>(memchr(b, '\n', left));
+        if (nl) {
+            line.append(b, (size_t)(nl - b));
+            p_->pos += (size_t)(nl - b) + 1;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            return true;
+        }
+        line.append(b, left);   // the line continues in the next block
+        p_->pos = p_->cur.size();
     }
     if (!got) return false;
-    if (!line.empty() && line.back() == '\n') line.pop_back();
-    if (!line.empty() && line.back() == '\r') line.pop_back();
+    if (!line.empty() && line.back() == '\r') line.pop_back();   // last line without a newline
     return true;
 }
 

@@ -55,6 +55,9 @@ res["read_id_total_s"] = dt
 res["read_id_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "Index loaded" in l or "timing:" in l]
 counts = dict(l.split("\t") for l in open(f"{W}/rid_counts.txt").read().splitlines())
 res["read_id_accept_frac"] = 1.0 - int(counts.get("reject", 0)) / R
+dt, out, err = run("read_id", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", f"{W}/reads.fastq.gz", "-n", f"{W}/rid_pe")
+res["read_id_pe_total_s"] = dt
+res["read_id_pe_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "timing:" in l]
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/g007.fasta", "-s")
 res["search_s_total_s"] = dt; res["search_s_out"] = out.strip().splitlines()[-1] if out.strip() else ""
 print(json.dumps(res))
