@@ -651,7 +651,7 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
         if (win > max_win) max_win = win;
     }
     bool long_path = false;
-    {   // reads whose k-mer set does not fit one wave's LDS go through the sort-based path (k <= 32, upper-case)
+    {   // reads whose k-mer set does not fit one wave's LDS go through the sort-based path (readid_long)
         cid::ReadIdParams probe;
         int waves;
         rc = readid_params(ix, stride_d, start_sample, max_bytes, max_win, probe, waves);

@@ -816,6 +816,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
 // Long reads / contigs: the per-read k-mer set does not fit one wave's LDS, so it is built in HBM by a sort
 // (cid_readid_long.hip) and arrives here as, per read, its distinct canonical k-mers (2-bit codes, base 0 most
 // significant) in first-occurrence order.  Same search, same outputs as k_readid.
+struct BaseReader {  // a key that lives in HBM as a stretch of the read (forward or reverse complement), see k_general_keys
+    const uint8_t *b;
+    uint32_t len, rc, upper;
+    __device__ __forceinline__ uint32_t rd8(uint32_t o) const {
+        uint32_t c = rc ? comp_base(b[len - 1 - o]) : (uint32_t)b[o];
+        if (upper) c = upper_base(c);
+        return c;
+    }
+    __device__ __forceinline__ uint32_t rd32(uint32_t o) const { return rd8(o) | (rd8(o + 1) << 8) | (rd8(o + 2) << 16) | (rd8(o + 3) << 24); }
+    __device__ __forceinline__ uint64_t rd64(uint32_t o) const { return (uint64_t)rd32(o) | ((uint64_t)rd32(o + 4) << 32); }
+};
+
 template <int LOG_LPR, bool NARROW, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -851,8 +863,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
             const bool have = c0 + lane < d1;
             wave_lds_fence();
             if (have) {
-                const uint64_t lsb = rev_fields(p.list_codes[c0 + lane], k);
-                xxh3_seeds_from(CodeReader{lsb}, k, n, [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+                const uint64_t e = p.list_codes[c0 + lane];
+                if (p.bases) {
+                    xxh3_seeds_from(BaseReader{p.bases + (e >> 1), k, (uint32_t)(e & 1ull), p.upper}, k, n,
+                                    [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+                } else {
+                    xxh3_seeds_from(CodeReader{rev_fields(e, k)}, k, n, [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+                }
             }
             const uint64_t dmask = __ballot(have);
             wave_lds_fence();

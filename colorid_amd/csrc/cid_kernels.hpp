@@ -80,7 +80,9 @@ struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in
     const uint64_t *mat;
     uint32_t rs, w64, n_colors, n_hash, k;   // k = length of the listed keys (k-mers, or minimizers for a .mxi index)
     ModMagic mod;
-    const uint64_t *list_codes;   // canonical 2-bit codes, base 0 most significant
+    const uint64_t *list_codes;   // canonical 2-bit codes, base 0 most significant; with `bases`: key location << 1 | reverse-complement
+    const uint8_t *bases;         // non-NULL: keys are byte strings inside `bases` (k > 32 or lower-case bases), k bytes each
+    uint32_t upper;               // byte keys are upper-cased before hashing (.mxi minimizers)
     const uint64_t *list_start;   // [n_reads+1] offsets into list_codes
     uint64_t n_reads;
     uint32_t start_sample;

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/colorid_hip.h"
@@ -290,14 +291,104 @@ __global__ void k_list_starts(const uint64_t *wstart, const uint32_t *pos, uint6
     if (r <= n_reads) list_start[r] = pos[wstart[r]];
 }
 
+// ---- general keys: k > 32 or lower-case bases (their case is kept), so a key is a byte string.
+// One thread per window: validity, canonical orientation and (for .mxi) the minimizer, all on raw bytes as the reference
+// compares them.  A key is described by where its bytes sit in `bases`: entry = offset << 1 | reverse-complement flag
+// (minimizers are upper-cased afterwards, kmer.rs:381); its sort image is 4 bits per base (2-bit base | lower-case << 2),
+// 16 bases per word, word-major arrays; a window without a key gets all-ones words (no base encodes to 0xF).
+__device__ __forceinline__ uint32_t key_byte(const uint8_t *bases, uint64_t entry, uint32_t klen, bool upper, uint32_t t) {
+    const uint64_t off = entry >> 1;
+    uint32_t b = (entry & 1ull) ? switch_base_dev(bases[off + klen - 1 - t]) : bases[off + t];
+    if (upper && b >= 'a' && b <= 'z') b -= 32u;
+    return b;
+}
+__global__ __launch_bounds__(256) void k_general_keys(const uint8_t *bases, const Segment *segs, uint32_t n_segs, uint64_t W, uint32_t k,
+                                                      uint32_t msz, uint32_t n_words, uint64_t *keyw, uint64_t *entry) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    uint32_t lo = 0, hi = n_segs;   // the segment holding window w: largest s with segs[s].out_off <= w
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (segs[mid].out_off <= w) lo = mid; else hi = mid;
+    }
+    const uint64_t pos = segs[lo].base_off + (w - segs[lo].out_off) * segs[lo].stride;
+    const uint8_t *b = bases + pos;
+    bool ok = true;
+    for (uint32_t t = 0; t < k; ++t) ok = ok && good_base_dev(b[t]);
+    if (!ok) {
+        entry[w] = ~0ull;
+        for (uint32_t j = 0; j < n_words; ++j) keyw[(uint64_t)j * W + w] = ~0ull;
+        return;
+    }
+    uint32_t rc = 1;   // palindromes take the reverse-complement branch (the same string)
+    for (uint32_t t = 0; t < k; ++t) {
+        const uint32_t f = b[t], r = switch_base_dev(b[k - 1 - t]);
+        if (f != r) { rc = f < r ? 0u : 1u; break; }
+    }
+    uint64_t e = (pos << 1) | rc;
+    uint32_t klen = k;
+    if (msz) {   // find_minimizer (kmer.rs:971-986) over the canonical string: candidates (i, reverse-complement)
+        const uint64_t canon = e;
+        auto cand_byte = [&](uint32_t cand, uint32_t t) -> uint32_t {
+            const uint32_t i = cand & 0xFFFFu;
+            return (cand >> 16) ? (uint32_t)switch_base_dev((uint8_t)key_byte(bases, canon, k, false, i + msz - 1 - t))
+                                : key_byte(bases, canon, k, false, i + t);
+        };
+        auto less = [&](uint32_t x, uint32_t y) -> bool {
+            for (uint32_t t = 0; t < msz; ++t) {
+                const uint32_t bx = cand_byte(x, t), by = cand_byte(y, t);
+                if (bx != by) return bx < by;
+            }
+            return false;
+        };
+        uint32_t best = 0;
+        for (uint32_t i = 1; i + msz <= k; ++i) {
+            if (less(i, best)) best = i;
+            if (less(i | (1u << 16), best)) best = i | (1u << 16);
+        }
+        // the minimizer as a stretch of `bases`: canonical byte j is b[j] (rc = 0) or comp(b[k-1-j]) (rc = 1)
+        const uint32_t i = best & 0xFFFFu, mrc = best >> 16;
+        const uint64_t off = rc ? pos + k - i - msz : pos + i;
+        e = (off << 1) | (rc ^ mrc);
+        klen = msz;
+    }
+    entry[w] = e;
+    for (uint32_t j = 0; j < n_words; ++j) {
+        uint64_t word = 0;
+        for (uint32_t t = 16 * j; t < 16 * j + 16 && t < klen; ++t) {
+            const uint32_t c = key_byte(bases, e, klen, msz != 0, t);
+            word |= (uint64_t)(((c >> 1) & 3u) | ((c >> 3) & 4u)) << (4u * (t & 15u));
+        }
+        keyw[(uint64_t)j * W + w] = word;
+    }
+}
+__global__ void k_gather_u64(const uint64_t *src, const uint32_t *idx, uint64_t *dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_first_flags_general(const uint64_t *keyw, uint32_t n_words, const uint64_t *entry, const uint32_t *sorted_idx,
+                                      const uint64_t *wstart, uint32_t n_reads, uint32_t *flags, uint64_t W) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W) return;
+    const uint32_t w = sorted_idx[i];
+    bool first = entry[w] != ~0ull;
+    if (first && i > 0) {
+        const uint32_t pw = sorted_idx[i - 1];
+        bool same = true;
+        for (uint32_t j = 0; j < n_words && same; ++j) same = keyw[(uint64_t)j * W + w] == keyw[(uint64_t)j * W + pw];
+        if (same) first = read_of_window(wstart, n_reads, pw) != read_of_window(wstart, n_reads, w);
+    }
+    flags[w] = first ? 1u : 0u;
+}
+
 // d_bases resident; host seq_off / read_seq0.  Writes report / n_kmers / status to DEVICE arrays.
 int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                 size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status) {
     const uint32_t k = index_k(ix);
-    if (k > 32) return fail(CID_ERR_UNSUPPORTED, "long reads need the packed path: k_size %u > 32", k);
     hipStream_t st = ctx_stream(c);
     const uint32_t msz = index_m_size(ix);           // > 0: the sets hold minimizers of length msz
     const uint32_t key_len = msz ? msz : k;
+    bool general = k > 32;                           // byte-string keys; also taken when a lower-case base shows up
     const uint64_t sentinel_k = k < 32 ? (1ull << (2 * k)) : ~0ull;
     const uint64_t sentinel = key_len < 32 ? (1ull << (2 * key_len)) : ~0ull;
     const unsigned end_bit = key_len < 32 ? 2 * key_len + 1 : 64;
@@ -339,25 +430,45 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     HIP_TRY(hipMemsetAsync(d_flags.p, 0, (W + 1) * 4, st));
     if (W) {
         HIP_TRY(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice, st));
-        constexpr uint32_t kBytes = kSegWindows + 32 + 96;
-        const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
-        unsigned grid = (unsigned)((segs.size() + 3) / 4);
-        if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel_k,
-                           d_codes.p, d_lower.p);
-        if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
+        if (!general) {
+            constexpr uint32_t kBytes = kSegWindows + 32 + 96;
+            const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
+            unsigned grid = (unsigned)((segs.size() + 3) / 4);
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL(k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel_k,
+                               d_codes.p, d_lower.p);
+            int lower = 0;
+            HIP_TRY(hipMemcpyAsync(&lower, d_lower.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            general = lower != 0;   // case-preserving k-mers cannot be packed in 2 bits per base
+        }
         hipLaunchKernelGGL(k_iota_u32, dim3(grid_for_n(W)), dim3(256), 0, st, d_idx.p, (uint64_t)W);
         size_t tb = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, end_bit, st));
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, 64u, st));
         DevBuf<uint8_t> tmp;
         if ((rc = tmp.alloc(tb))) return rc;
-        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, end_bit, st));
-        hipLaunchKernelGGL(k_first_flags, dim3(grid_for_n(W)), dim3(256), 0, st, d_sorted.p, d_sidx.p, d_wstart.p, (uint32_t)n_reads,
-                           sentinel, d_flags.p, (uint64_t)W);
-        HIP_TRY(hipStreamSynchronize(st));
-        int lower = 0;
-        HIP_TRY(hipMemcpy(&lower, d_lower.p, 4, hipMemcpyDeviceToHost));
-        if (lower) return fail(CID_ERR_UNSUPPORTED, "long reads with lower-case bases are not supported (case-preserving k-mers cannot be packed)");
+        if (!general) {
+            if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
+            HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, end_bit, st));
+            hipLaunchKernelGGL(k_first_flags, dim3(grid_for_n(W)), dim3(256), 0, st, d_sorted.p, d_sidx.p, d_wstart.p, (uint32_t)n_reads,
+                               sentinel, d_flags.p, (uint64_t)W);
+        } else {
+            // stable LSD radix sort over the key words; d_codes ends up holding the entries the search kernel reads
+            const uint32_t n_words = (key_len + 15) / 16;
+            DevBuf<uint64_t> d_keyw, d_gath;
+            if ((rc = d_keyw.alloc((size_t)n_words * W)) || (rc = d_gath.alloc(W))) return rc;
+            hipLaunchKernelGGL(k_general_keys, dim3(grid_for_n(W)), dim3(256), 0, st, d_bases, d_segs.p, (uint32_t)segs.size(), (uint64_t)W, k, msz,
+                               n_words, d_keyw.p, d_codes.p);
+            uint32_t *cur = d_idx.p, *nxt = d_sidx.p;
+            for (uint32_t j = 0; j < n_words; ++j) {
+                hipLaunchKernelGGL(k_gather_u64, dim3(grid_for_n(W)), dim3(256), 0, st, d_keyw.p + (size_t)j * W, cur, d_gath.p, (uint64_t)W);
+                HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, d_gath.p, d_sorted.p, cur, nxt, W, 0u, 64u, st));
+                std::swap(cur, nxt);
+            }
+            hipLaunchKernelGGL(k_first_flags_general, dim3(grid_for_n(W)), dim3(256), 0, st, d_keyw.p, n_words, d_codes.p, cur, d_wstart.p,
+                               (uint32_t)n_reads, d_flags.p, (uint64_t)W);
+            HIP_TRY(hipStreamSynchronize(st));   // d_keyw / d_gath go out of scope
+        }
     }
     size_t tb2 = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, d_flags.p, d_pos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
@@ -375,6 +486,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     p.mat = index_matrix(ix); p.rs = index_rs(ix); p.w64 = (index_n_colors(ix) + 63) / 64; p.n_colors = index_n_colors(ix);
     p.n_hash = index_n_hash(ix); p.k = key_len; p.mod = index_mod(ix);
     p.list_codes = d_list.p; p.list_start = d_lstart.p; p.n_reads = n_reads; p.start_sample = start_sample;
+    p.bases = general ? d_bases : nullptr; p.upper = msz != 0;
     p.hist_pad = p.rs > 128 ? 4u * p.rs : (uint32_t)((C1 + 3) & ~(size_t)3);
     if (p.rs > 128) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, st));   // wide rows count in place
     p.wave_bytes = (uint32_t)((4ull * kWave * p.n_hash + 4ull * p.hist_pad + 15) & ~15ull);

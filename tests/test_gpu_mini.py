@@ -42,8 +42,12 @@ def test_readid_on_minimizer_index(orc, hip_ctx, n_colors, n_hash, k, msz, m):
         reads = sample_reads(orc, rng, genomes, 250, 150, paired)          # includes lower-case, N, short and repeat reads
         rep, nk, st = check(oix, hx, reads, d, S)
         assert rep[:, :n_colors].sum() > 0 and (nk.max() < 150 or msz == k)  # far fewer minimizers than windows
-    if k <= 32:   # reads longer than the LDS kernel holds: sort-based path with the minimizer transform
-        check(oix, hx, [[genomes[0] + genomes[1] + genomes[2] * 12], [genomes[1][:500]]], 1, 3)
+    # reads longer than the LDS kernel holds: sort-based path with the minimizer transform (2-bit codes; byte keys for
+    # k > 32 or lower-case bases)
+    long_read = genomes[0] + genomes[1] + genomes[2] * 12
+    mixed = long_read[:9000] + long_read[9000:9700].lower() + long_read[9700:]
+    check(oix, hx, [[long_read], [genomes[1][:500]], [mixed, genomes[0].lower()]], 1, 3)
+    check(oix, hx, [[mixed], [long_read]], 3, 0)
     with pytest.raises(Exception):                                          # src/main.rs:569-573
         hx.search_count(random_kmers(rng, 10, k))
     hx.close()

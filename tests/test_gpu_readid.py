@@ -142,12 +142,35 @@ def test_readid_very_long_reads_sort_path(orc, phage, d, S):
     reads = [[genomes[2]], [chimera], [genomes[1][:40_000], genomes[1][10_000:45_000]],     # a long "pair" with shared k-mers
              [genomes[0][100:250]], [b"ACG"], [b"A" * 30_000], [genomes[3][:20_000] * 3]]
     check(oix, hx, reads, d, S)
-    bases, so, r0 = pack_reads([[(genomes[2] + genomes[1]).lower()]])
-    if d == 1:
-        with pytest.raises(Exception):  # lower-case bases in a read this long cannot be packed: refused, not mis-hashed
-            hx.readid_count(bases, so, r0, d, S)
-    else:                               # with -d 7 the same read fits the LDS kernel, whose byte path keeps the case
-        check(oix, hx, [[genomes[2][:20_000].lower()]], d, S)
+    # lower-case and mixed-case long reads: their case is kept, so the sort-based path keys on byte strings
+    mixed = bytearray(genomes[2] + genomes[1])
+    for a in range(0, len(mixed), 997):
+        mixed[a:a + 300] = bytes(mixed[a:a + 300]).lower()
+    check(oix, hx, [[(genomes[2] + genomes[1]).lower()], [bytes(mixed)], [genomes[0][:300]], [bytes(mixed[:50_000]), genomes[2][:9_000].lower()]], d, S)
+
+
+@pytest.mark.parametrize("k,n_hash", [(35, 2), (64, 3), (128, 1), (33, 4)])
+def test_readid_long_reads_k_above_32(orc, hip_ctx, k, n_hash):
+    """k > 32 and a read too long for the LDS kernel: byte-string keys through the multi-word sort"""
+    rng = np.random.default_rng(k)
+    n_colors, m = 40, 60_013
+    g = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 70_000)].tobytes() for _ in range(2)]
+    oix = orc.Index(m, n_hash, k, n_colors)
+    for c in range(n_colors):
+        oix.set_color(c, f"acc{c:03d}", 5000)
+    for gi, gg in enumerate(g):
+        km = orc.Kmers(k)
+        km.kmerize_vector(gg[:30_000], 1)
+        for key in km.keys():
+            oix.insert(3 + 7 * gi, key.tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    low = bytearray(g[1][:60_000])
+    low[1000:1500] = bytes(low[1000:1500]).lower()
+    reads = [[g[0]], [g[0][10_000:65_000], g[1][:50_000]], [bytes(low)], [g[0][:200]], [g[1][:k - 1]], [g[0][:20_000] * 3 + b"N" + g[1][:30_000]]]
+    for d, S in ((1, 3), (1, 0), (5, 2)):
+        rep, nk, st = check(oix, hx, reads, d, S)
+        assert rep[0, 3] > 1000 and st[4] == 1
+    hx.close()
 
 
 def test_readid_wide_rows_long_reads(orc, hip_ctx):
