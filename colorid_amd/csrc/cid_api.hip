@@ -35,7 +35,7 @@ using cid::fail;
         if (e_ != hipSuccess) return fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_COUNT };
+enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_COUNT };
 
 }  // namespace
 
@@ -50,6 +50,10 @@ struct cid_ctx {
     // result of the last cid_readid_count_sparse, fetched by cid_readid_sparse_fetch
     uint64_t *sp_start = nullptr; uint32_t *sp_col = nullptr, *sp_cnt = nullptr;
     uint64_t sp_rows = 0, sp_entries = 0;
+    // scratch block cache (cid::ctx_alloc / ctx_free)
+    struct Block { void *p; size_t bytes; bool used; };
+    std::vector<Block> blocks;
+    size_t idle_bytes = 0;
 };
 
 struct cid_index {
@@ -63,6 +67,56 @@ struct cid_index {
 };
 
 namespace cid {
+int ctx_alloc(cid_ctx *c, size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    int best = -1;   // the smallest idle block that fits without wasting more than half of itself
+    for (size_t i = 0; i < c->blocks.size(); ++i) {
+        const cid_ctx::Block &b = c->blocks[i];
+        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20) && (best < 0 || b.bytes < c->blocks[best].bytes)) best = (int)i;
+    }
+    if (best >= 0) {
+        c->blocks[best].used = true;
+        c->idle_bytes -= c->blocks[best].bytes;
+        *out = c->blocks[best].p;
+        return CID_OK;
+    }
+    const size_t want = bytes + bytes / 8;   // batches vary a little in size: leave room for the next one
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    size_t got = want;
+    if (e != hipSuccess) {   // give the idle blocks back and ask for exactly what is needed
+        (void)hipGetLastError();
+        for (size_t i = 0; i < c->blocks.size();) {
+            if (!c->blocks[i].used) { (void)hipFree(c->blocks[i].p); c->blocks.erase(c->blocks.begin() + (long)i); }
+            else ++i;
+        }
+        c->idle_bytes = 0;
+        got = bytes;
+        e = hipMalloc(&p, got);
+        if (e != hipSuccess) return fail(CID_ERR_NOMEM, "hipMalloc(%zu): %s", got, hipGetErrorString(e));
+    }
+    c->blocks.push_back(cid_ctx::Block{p, got, true});
+    *out = p;
+    return CID_OK;
+}
+void ctx_free(cid_ctx *c, void *p) {
+    if (!p) return;
+    constexpr size_t kMaxIdle = 64ull << 30;   // of 288 GB; beyond that blocks really go back
+    for (size_t i = 0; i < c->blocks.size(); ++i) {
+        if (c->blocks[i].p != p) continue;
+        if (c->idle_bytes + c->blocks[i].bytes > kMaxIdle) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(p);
+            c->blocks.erase(c->blocks.begin() + (long)i);
+        } else {
+            c->blocks[i].used = false;
+            c->idle_bytes += c->blocks[i].bytes;
+        }
+        return;
+    }
+    (void)hipFree(p);   // not one of ours
+}
 int ctx_device(const cid_ctx *c) { return c->device; }
 hipStream_t ctx_stream(const cid_ctx *c) { return c->stream; }
 uint32_t index_k(const cid_index *ix) { return ix->k; }
@@ -197,9 +251,7 @@ void cid_ctx_destroy(cid_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (int s = 0; s < S_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
-    if (c->sp_start) (void)hipFree(c->sp_start);
-    if (c->sp_col) (void)hipFree(c->sp_col);
-    if (c->sp_cnt) (void)hipFree(c->sp_cnt);
+    for (const cid_ctx::Block &b : c->blocks) (void)hipFree(b.p);   // includes the sparse read_id result
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -569,13 +621,15 @@ int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_code
 
 // ------------------------------------------------------------------------------------------------ a6/a7/a9/a10
 
-static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                         cid::ReadIdParams &p, int &waves) {
+// LDS layout of k_readid for reads of at most max_bytes bases / max_win windows; returns the bytes one wave needs
+static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
+                            cid::ReadIdParams &p) {
     p = cid::ReadIdParams{};
     p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
     p.mod = ix->mod;
     p.stride_d = stride_d; p.start_sample = start_sample;
     p.m_size = ix->m_size;
+    if (max_bytes > (1ull << 30) || max_win > (1ull << 30)) return ~(size_t)0;
     p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
     p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
     if (p.win_cap < 4) p.win_cap = 4;
@@ -588,14 +642,47 @@ static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_
                                   (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);
     const size_t key_packed_path = 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
     const size_t key_bytes = ((key_bytes_path > key_packed_path ? key_bytes_path : key_packed_path) + 15) & ~15ull;
-    const size_t wave_bytes = (size_t)p.bases_cap + 4ull * cid::kWave * ix->n_hash + 4ull * p.hist_pad + key_bytes;
-    p.wave_bytes = (uint32_t)((wave_bytes + 15) & ~15ull);
+    const size_t wave_bytes = ((size_t)p.bases_cap + 4ull * cid::kWave * ix->n_hash + 4ull * p.hist_pad + key_bytes + 15) & ~15ull;
+    p.wave_bytes = (uint32_t)(wave_bytes < 0xFFFFFFF0ull ? wave_bytes : 0xFFFFFFF0ull);
+    return wave_bytes;
+}
+
+constexpr size_t kLdsBytes = 160u * 1024u;
+// k_readid keeps a read's set in one wave's LDS.  With fewer than two waves per workgroup (one per CU) the gathers are no
+// longer hidden and the sort-based path is faster (tools/bench_readlen.py: 150 Mbases of 4 kb reads 50.7 vs 24.5 ms; 2 kb
+// reads, two waves, 30.3 vs 36.7 ms), so such reads are routed there.
+constexpr size_t kLdsReadBytesMax = kLdsBytes / 2;
+
+static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
+                         cid::ReadIdParams &p, int &waves) {
+    const size_t wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, p);
     waves = 4;
-    while (waves > 1 && (size_t)waves * p.wave_bytes > 160u * 1024u) waves >>= 1;
-    if ((size_t)waves * p.wave_bytes > 160u * 1024u)
-        return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %u B of LDS per wave (> 160 KiB): "
-                    "long-read batches are not supported by this kernel yet", (unsigned long long)max_bytes,
-                    (unsigned long long)max_win, p.wave_bytes);
+    while (waves > 1 && (size_t)waves * wave_bytes > kLdsBytes) waves >>= 1;
+    if (wave_bytes > kLdsBytes)
+        return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %zu B of LDS per wave (> 160 KiB): "
+                    "use the host-pointer calls, which route such reads through the sort-based path", (unsigned long long)max_bytes,
+                    (unsigned long long)max_win, wave_bytes);
+    return CID_OK;
+}
+
+static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off,
+                           const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                           uint64_t max_read_bytes, uint64_t max_read_windows, const uint8_t *d_skip, bool clear_wide, uint32_t *d_report,
+                           uint32_t *d_n_kmers, uint8_t *d_status) {
+    cid::ReadIdParams p;
+    int waves;
+    int rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, p, waves);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
+    p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status; p.skip = d_skip;
+    uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
+    if (rpb < (uint64_t)waves) rpb = waves;
+    if (rpb > 256) rpb = 256;
+    p.reads_per_block = (uint32_t)rpb;
+    if (ix->rs > 128 && clear_wide)   // wide rows count in place
+        HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * ((size_t)ix->n_colors + 1) * 4, c->stream));
+    HIP_TRY(cid::launch_readid(p, waves, c->stream));
     return CID_OK;
 }
 
@@ -608,20 +695,8 @@ int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases
     if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
     if (n_reads == 0) return CID_OK;
     if (!d_bases || !d_seq_off || !d_read_seq0 || !d_report || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
-    cid::ReadIdParams p;
-    int waves;
-    rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, p, waves);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
-    p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status;
-    uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
-    if (rpb < (uint64_t)waves) rpb = waves;
-    if (rpb > 256) rpb = 256;
-    p.reads_per_block = (uint32_t)rpb;
-    if (ix->rs > 128) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * ((size_t)ix->n_colors + 1) * 4, c->stream));  // wide rows count in place
-    HIP_TRY(cid::launch_readid(p, waves, c->stream));
-    return CID_OK;
+    return readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, max_read_bytes, max_read_windows, nullptr,
+                           true, d_report, d_n_kmers, d_status);
 }
 
 // uploads the batch, runs the LDS or the sort-based kernel; leaves report / n_kmers / status in the ctx's device scratch
@@ -635,29 +710,44 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
     if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
     const uint64_t total_bases = seq_off[n_seqs];
     if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
-    // per-batch LDS sizing: the longest read(-pair) and its window count
-    uint64_t max_bytes = 0, max_win = 0;
-    for (size_t r = 0; r < n_reads; ++r) {
+    // LDS sizing by the longest read(-pair) the LDS kernel will see
+    auto read_size = [&](size_t r, uint64_t &bytes, uint64_t &win) {
         const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
-        if (s1 < s0) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
-        uint64_t win = 0;
+        win = 0;
         for (uint64_t s = s0; s < s1; ++s) {
-            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
             const uint64_t len = seq_off[s + 1] - seq_off[s];
             if (len >= ix->k) win += (len - ix->k) / stride_d + 1;
         }
-        const uint64_t bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
+        bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
+    };
+    uint64_t max_bytes = 0, max_win = 0;
+    for (size_t r = 0; r < n_reads; ++r) {
+        if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
+        for (uint64_t s = read_seq0[r]; s < read_seq0[r + 1]; ++s)
+            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
+        uint64_t bytes, win;
+        read_size(r, bytes, win);
         if (bytes > max_bytes) max_bytes = bytes;
         if (win > max_win) max_win = win;
     }
-    bool long_path = false;
-    {   // reads whose k-mer set does not fit one wave's LDS go through the sort-based path (readid_long)
-        cid::ReadIdParams probe;
-        int waves;
-        rc = readid_params(ix, stride_d, start_sample, max_bytes, max_win, probe, waves);
-        if (rc == CID_ERR_UNSUPPORTED) long_path = true;
-        else if (rc) return rc;
+    // routing: reads whose set would leave k_readid fewer than two waves per workgroup go through the sort-based path
+    std::vector<uint8_t> route;   // empty = one path for the whole batch
+    size_t n_long = 0;
+    cid::ReadIdParams probe;
+    if (readid_layout(ix, stride_d, start_sample, max_bytes, max_win, probe) > kLdsReadBytesMax) {
+        route.assign(n_reads, 0);
+        max_bytes = max_win = 0;
+        for (size_t r = 0; r < n_reads; ++r) {
+            uint64_t bytes, win;
+            read_size(r, bytes, win);
+            if (readid_layout(ix, stride_d, start_sample, bytes, win, probe) > kLdsReadBytesMax) { route[r] = 1; ++n_long; }
+            else {
+                if (bytes > max_bytes) max_bytes = bytes;
+                if (win > max_win) max_win = win;
+            }
+        }
     }
+    const bool all_long = n_long == n_reads, mixed = n_long > 0 && !all_long;
     HIP_TRY(hipSetDevice(c->device));
     void *d_bases, *d_so, *d_r0, *d_rep, *d_nk;
     const size_t C1 = (size_t)ix->n_colors + 1;
@@ -669,13 +759,23 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
     if (total_bases) HIP_TRY(hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    if (long_path) {
+    uint8_t *d_status = (uint8_t *)d_nk + n_reads * 4;
+    if (ix->rs > 128 && mixed) HIP_TRY(hipMemsetAsync(d_rep, 0, n_reads * C1 * 4, c->stream));   // both kernels count in place
+    if (n_long) {   // first: it writes a status for every read (2 = the other kernel's)
         HIP_TRY(hipStreamSynchronize(c->stream));
-        rc = cid::readid_long(c, ix, (const uint8_t *)d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, (uint32_t *)d_rep,
-                              (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4);
-    } else {
-        rc = cid_readid_count_dev(c, ix, (const uint8_t *)d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d,
-                                  start_sample, max_bytes, max_win, (uint32_t *)d_rep, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4);
+        rc = cid::readid_long(c, ix, (const uint8_t *)d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample,
+                              mixed ? route.data() : nullptr, !mixed, (uint32_t *)d_rep, (uint32_t *)d_nk, d_status);
+        if (rc) return rc;
+    }
+    if (!all_long) {
+        void *d_skip = nullptr;
+        if (mixed) {
+            rc = slot_reserve(c, S_ROUTE, n_reads, &d_skip); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(d_skip, route.data(), n_reads, hipMemcpyHostToDevice, c->stream));
+        }
+        rc = readid_dev_impl(c, ix, (const uint8_t *)d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample,
+                             max_bytes, max_win, (const uint8_t *)d_skip, !mixed, (uint32_t *)d_rep, (uint32_t *)d_nk, d_status);
+        if (mixed) HIP_TRY(hipStreamSynchronize(c->stream));   // `route` leaves scope
     }
     if (rc) return rc;
     *d_report_out = (uint32_t *)d_rep; *d_nk_out = (uint32_t *)d_nk; *d_status_out = (uint8_t *)d_nk + n_reads * 4;
@@ -710,9 +810,9 @@ int cid_readid_count_sparse(cid_ctx *c, const cid_index *ix, const uint8_t *base
     uint8_t *d_st;
     int rc = readid_to_device(c, ix, bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, &d_rep, &d_nk, &d_st);
     if (rc) return rc;
-    if (c->sp_start) { (void)hipFree(c->sp_start); c->sp_start = nullptr; }
-    if (c->sp_col) { (void)hipFree(c->sp_col); c->sp_col = nullptr; }
-    if (c->sp_cnt) { (void)hipFree(c->sp_cnt); c->sp_cnt = nullptr; }
+    cid::ctx_free(c, c->sp_start); c->sp_start = nullptr;
+    cid::ctx_free(c, c->sp_col); c->sp_col = nullptr;
+    cid::ctx_free(c, c->sp_cnt); c->sp_cnt = nullptr;
     rc = cid::compact_report(c, d_rep, ix->n_colors + 1, n_reads, &c->sp_start, &c->sp_col, &c->sp_cnt, &c->sp_entries);
     if (rc) return rc;
     c->sp_rows = n_reads;

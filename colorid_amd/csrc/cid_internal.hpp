@@ -10,6 +10,12 @@ namespace cid {
 int fail(int code, const char *fmt, ...);  // records the thread's last error message, returns `code`
 int ctx_device(const cid_ctx *c);
 hipStream_t ctx_stream(const cid_ctx *c);
+// Device scratch that survives the call: hipMalloc of a GiB-sized block costs tens of milliseconds here (the driver clears
+// it), so blocks go back to a per-ctx cache instead of hipFree and the next batch takes them again.  All users run on the
+// ctx stream, which orders a block's last kernel before its next owner's first.  Objects holding such blocks
+// (cid_kmerset, sparse read_id results) must be destroyed before their ctx.
+int ctx_alloc(cid_ctx *c, size_t bytes, void **out);
+void ctx_free(cid_ctx *c, void *p);
 uint32_t index_k(const cid_index *ix);
 uint32_t index_rs(const cid_index *ix);
 ModMagic index_mod(const cid_index *ix);
@@ -21,9 +27,12 @@ const uint64_t *index_matrix(const cid_index *ix);
 // Bloom insert of 2-bit codes already on the device into one colour (build.rs:62-66 with the k-mer map on the GPU)
 int index_insert_codes(cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t colour);
 
-// read_id for batches whose reads do not fit the LDS kernel (cid_kmerset.hip): sort-based per-read k-mer sets
+// read_id for reads that do not fit (or badly fit) the LDS kernel (cid_kmerset.hip): sort-based per-read k-mer sets.
+// route == NULL: every read; else only reads with route[r] != 0 — the others get status 2 and nothing else is written for
+// them.  clear_wide: zero the whole report first when rows are wider than 128 words (those kernels count in place).
 int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
-                size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status);
+                size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
+                uint32_t *d_n_kmers, uint8_t *d_status);
 
 // a5 / a4 on k-mers that are already on the device as 2-bit codes (k <= 32); outputs go to HOST buffers
 int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,
@@ -31,7 +40,7 @@ int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes,
 int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t *and_words_le,
                          int *any_row_missing);
 
-// dense report rows (device) -> per-row (colour, count) lists, ascending colour; outputs are hipMalloc'ed for the caller
+// dense report rows (device) -> per-row (colour, count) lists, ascending colour; outputs are ctx_alloc'ed for the caller (return them with ctx_free)
 int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_t n_rows, uint64_t **d_row_start, uint32_t **d_colours,
                    uint32_t **d_counts, uint64_t *n_entries);
 

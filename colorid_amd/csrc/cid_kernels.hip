@@ -612,6 +612,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
     const uint64_t r_begin = (uint64_t)blockIdx.x * p.reads_per_block;
     const uint64_t r_end = r_begin + p.reads_per_block < p.n_reads ? r_begin + p.reads_per_block : p.n_reads;
     for (uint64_t read = r_begin + wave; read < r_end; read += waves) {
+        if (p.skip && p.skip[read]) continue;
         wave_lds_fence();
         const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
         const uint64_t g0 = p.seq_off[s0];
@@ -842,6 +843,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
     for (uint64_t read = (uint64_t)blockIdx.x * waves + wave; read < p.n_reads; read += (uint64_t)gridDim.x * waves) {
         wave_lds_fence();
         uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
+        if (p.status[read] == 2) continue;
         if (p.status[read] == 1) {  // too_short, decided on the host side of the call
             if constexpr (!WIDE)
                 for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;

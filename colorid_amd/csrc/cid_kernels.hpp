@@ -74,6 +74,7 @@ struct ReadIdParams {
     uint32_t *report;           // [n_reads][n_colors+1]
     uint32_t *n_kmers;          // [n_reads]
     uint8_t *status;            // [n_reads]
+    const uint8_t *skip;        // NULL, or [n_reads]: non-zero = this read belongs to the sort-based path (k_readid_list), leave it alone
 };
 
 struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in first-occurrence order
@@ -89,7 +90,7 @@ struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in
     uint32_t hist_pad, wave_bytes;
     uint32_t *report;
     uint32_t *n_kmers;
-    const uint8_t *status;        // 1 = too_short (set by the caller)
+    const uint8_t *status;        // set by the caller: 1 = too_short, 2 = not this kernel's read (k_readid handles it)
 };
 
 size_t search_smem_bytes(const SearchParams &p);

@@ -172,14 +172,20 @@ using cid::fail;
     } while (0)
 
 template <typename T>
-struct DevBuf {  // scoped device allocation
+struct DevBuf {  // scoped device scratch from the ctx's block cache (hipMalloc of GiB-sized blocks costs tens of ms on this platform)
+    cid_ctx *c;
     T *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    explicit DevBuf(cid_ctx *ctx) : c(ctx) {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) cid::ctx_free(c, p); }
     int alloc(size_t n) {
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), (n ? n : 1) * sizeof(T));
-        return e == hipSuccess ? CID_OK : fail(CID_ERR_NOMEM, "hipMalloc(%zu): %s", n * sizeof(T), hipGetErrorString(e));
+        void *q = nullptr;
+        const int rc = cid::ctx_alloc(c, (n ? n : 1) * sizeof(T), &q);
+        p = static_cast<T *>(q);
+        return rc;
     }
-    T *release() { T *q = p; p = nullptr; return q; }
+    T *release() { T *q = p; p = nullptr; return q; }   // the new owner returns it with ctx_free
 };
 
 unsigned grid_for_n(uint64_t n) { return (unsigned)((n + 255) / 256); }
@@ -189,40 +195,40 @@ int compact(cid_kmerset *ks) {
     if (ks->n_raw == 0) return CID_OK;
     hipStream_t st = cid::ctx_stream(ks->ctx);
     const size_t total = ks->n + ks->n_raw;
-    DevBuf<uint64_t> uniq;
-    DevBuf<uint32_t> agg;
-    DevBuf<uint64_t> d_count;
+    DevBuf<uint64_t> uniq(ks->ctx);
+    DevBuf<uint32_t> agg(ks->ctx);
+    DevBuf<uint64_t> d_count(ks->ctx);
     int rc;
     if ((rc = uniq.alloc(total)) || (rc = agg.alloc(total)) || (rc = d_count.alloc(1))) return rc;
     size_t tmp_bytes = 0;
     if (ks->n == 0) {
-        DevBuf<uint64_t> sorted;
+        DevBuf<uint64_t> sorted(ks->ctx);
         if ((rc = sorted.alloc(total))) return rc;
         HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
-        DevBuf<uint8_t> tmp;
+        DevBuf<uint8_t> tmp(ks->ctx);
         if ((rc = tmp.alloc(tmp_bytes))) return rc;
         HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
         size_t tmp2 = 0;
         HIP_TRY(rocprim::run_length_encode(nullptr, tmp2, sorted.p, total, uniq.p, agg.p, d_count.p, st));
-        DevBuf<uint8_t> t2;
+        DevBuf<uint8_t> t2(ks->ctx);
         if ((rc = t2.alloc(tmp2))) return rc;
         HIP_TRY(rocprim::run_length_encode(t2.p, tmp2, sorted.p, total, uniq.p, agg.p, d_count.p, st));
         HIP_TRY(hipStreamSynchronize(st));
     } else {
-        DevBuf<uint64_t> kin, kout;
-        DevBuf<uint32_t> vin, vout;
+        DevBuf<uint64_t> kin(ks->ctx), kout(ks->ctx);
+        DevBuf<uint32_t> vin(ks->ctx), vout(ks->ctx);
         if ((rc = kin.alloc(total)) || (rc = kout.alloc(total)) || (rc = vin.alloc(total)) || (rc = vout.alloc(total))) return rc;
         HIP_TRY(hipMemcpyAsync(kin.p, ks->codes, ks->n * 8, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(kin.p + ks->n, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemcpyAsync(vin.p, ks->counts, ks->n * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(cid::k_fill_u32, dim3(grid_for_n(ks->n_raw)), dim3(256), 0, st, vin.p + ks->n, 1u, (uint64_t)ks->n_raw);
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin.p, kout.p, vin.p, vout.p, total, 0u, ks->end_bit, st));
-        DevBuf<uint8_t> tmp;
+        DevBuf<uint8_t> tmp(ks->ctx);
         if ((rc = tmp.alloc(tmp_bytes))) return rc;
         HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin.p, kout.p, vin.p, vout.p, total, 0u, ks->end_bit, st));
         size_t tmp2 = 0;
         HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p));
-        DevBuf<uint8_t> t2;
+        DevBuf<uint8_t> t2(ks->ctx);
         if ((rc = t2.alloc(tmp2))) return rc;
         HIP_TRY(rocprim::reduce_by_key(t2.p, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, rocprim::plus<uint32_t>(),
                                        rocprim::equal_to<uint64_t>(), st));
@@ -235,8 +241,8 @@ int compact(cid_kmerset *ks) {
         HIP_TRY(hipMemcpy(&last, uniq.p + (n_runs - 1), 8, hipMemcpyDeviceToHost));
         if (last == ks->sentinel) --n_runs;
     }
-    if (ks->codes) (void)hipFree(ks->codes);
-    if (ks->counts) (void)hipFree(ks->counts);
+    if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
+    if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
     ks->codes = uniq.release();
     ks->counts = agg.release();
     ks->n = n_runs;
@@ -383,7 +389,8 @@ __global__ void k_first_flags_general(const uint64_t *keyw, uint32_t n_words, co
 
 // d_bases resident; host seq_off / read_seq0.  Writes report / n_kmers / status to DEVICE arrays.
 int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
-                size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status) {
+                size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
+                uint32_t *d_n_kmers, uint8_t *d_status) {
     const uint32_t k = index_k(ix);
     hipStream_t st = ctx_stream(c);
     const uint32_t msz = index_m_size(ix);           // > 0: the sets hold minimizers of length msz
@@ -400,6 +407,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     uint64_t W = 0;
     for (size_t r = 0; r < n_reads; ++r) {
         wstart[r] = W;
+        if (route && !route[r]) { status[r] = 2; continue; }
         const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
         if (s1 == s0 || seq_off[s0 + 1] - seq_off[s0] < k) { status[r] = 1; continue; }   // too_short (first mate only)
         for (uint64_t s = s0; s < s1; ++s) {
@@ -417,10 +425,10 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     if (W >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
     const size_t C1 = (size_t)index_n_colors(ix) + 1;
     HIP_TRY(hipMemcpyAsync(d_status, status.data(), n_reads, hipMemcpyHostToDevice, st));
-    DevBuf<uint64_t> d_wstart, d_codes, d_sorted, d_list, d_lstart;
-    DevBuf<uint32_t> d_idx, d_sidx, d_flags, d_pos;
-    DevBuf<Segment> d_segs;
-    DevBuf<int> d_lower;
+    DevBuf<uint64_t> d_wstart(c), d_codes(c), d_sorted(c), d_list(c), d_lstart(c);
+    DevBuf<uint32_t> d_idx(c), d_sidx(c), d_flags(c), d_pos(c);
+    DevBuf<Segment> d_segs(c);
+    DevBuf<int> d_lower(c);
     int rc;
     if ((rc = d_wstart.alloc(n_reads + 1)) || (rc = d_codes.alloc(W + 1)) || (rc = d_sorted.alloc(W + 1)) || (rc = d_idx.alloc(W + 1)) ||
         (rc = d_sidx.alloc(W + 1)) || (rc = d_flags.alloc(W + 1)) || (rc = d_pos.alloc(W + 1)) || (rc = d_segs.alloc(segs.size())) ||
@@ -445,7 +453,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         hipLaunchKernelGGL(k_iota_u32, dim3(grid_for_n(W)), dim3(256), 0, st, d_idx.p, (uint64_t)W);
         size_t tb = 0;
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_codes.p, d_sorted.p, d_idx.p, d_sidx.p, W, 0u, 64u, st));
-        DevBuf<uint8_t> tmp;
+        DevBuf<uint8_t> tmp(c);
         if ((rc = tmp.alloc(tb))) return rc;
         if (!general) {
             if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
@@ -455,7 +463,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         } else {
             // stable LSD radix sort over the key words; d_codes ends up holding the entries the search kernel reads
             const uint32_t n_words = (key_len + 15) / 16;
-            DevBuf<uint64_t> d_keyw, d_gath;
+            DevBuf<uint64_t> d_keyw(c), d_gath(c);
             if ((rc = d_keyw.alloc((size_t)n_words * W)) || (rc = d_gath.alloc(W))) return rc;
             hipLaunchKernelGGL(k_general_keys, dim3(grid_for_n(W)), dim3(256), 0, st, d_bases, d_segs.p, (uint32_t)segs.size(), (uint64_t)W, k, msz,
                                n_words, d_keyw.p, d_codes.p);
@@ -472,7 +480,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     }
     size_t tb2 = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, d_flags.p, d_pos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
-    DevBuf<uint8_t> tmp2;
+    DevBuf<uint8_t> tmp2(c);
     if ((rc = tmp2.alloc(tb2))) return rc;
     HIP_TRY(rocprim::exclusive_scan(tmp2.p, tb2, d_flags.p, d_pos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
     uint32_t D = 0;
@@ -488,7 +496,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     p.list_codes = d_list.p; p.list_start = d_lstart.p; p.n_reads = n_reads; p.start_sample = start_sample;
     p.bases = general ? d_bases : nullptr; p.upper = msz != 0;
     p.hist_pad = p.rs > 128 ? 4u * p.rs : (uint32_t)((C1 + 3) & ~(size_t)3);
-    if (p.rs > 128) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, st));   // wide rows count in place
+    if (p.rs > 128 && clear_wide) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, st));   // wide rows count in place
     p.wave_bytes = (uint32_t)((4ull * kWave * p.n_hash + 4ull * p.hist_pad + 15) & ~15ull);
     if ((size_t)(kBlock / kWave) * p.wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
     p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status;
@@ -543,15 +551,15 @@ __global__ __launch_bounds__(256) void k_row_compact(const uint32_t *report, uin
 int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_t n_rows, uint64_t **d_row_start, uint32_t **d_colours,
                    uint32_t **d_counts, uint64_t *n_entries) {
     hipStream_t st = ctx_stream(c);
-    DevBuf<uint32_t> nnz, col, cnt;
-    DevBuf<uint64_t> start;
+    DevBuf<uint32_t> nnz(c), col(c), cnt(c);
+    DevBuf<uint64_t> start(c);
     int rc;
     if ((rc = nnz.alloc(n_rows + 1)) || (rc = start.alloc(n_rows + 1))) return rc;
     HIP_TRY(hipMemsetAsync(nnz.p, 0, (n_rows + 1) * 4, st));
     if (n_rows) hipLaunchKernelGGL(k_row_nnz, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, d_report, width, n_rows, nnz.p);
     size_t tb = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
-    DevBuf<uint8_t> tmp;
+    DevBuf<uint8_t> tmp(c);
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -609,16 +617,16 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
     hipStream_t st = cid::ctx_stream(ks->ctx);
     if (ks->n_raw + n_win_total > ks->cap_raw) {
         size_t want = (ks->n_raw + n_win_total) * 3 / 2;
-        DevBuf<uint64_t> nb;
+        DevBuf<uint64_t> nb(ks->ctx);
         int rc = nb.alloc(want);
         if (rc) return rc;
         if (ks->n_raw) HIP_TRY(hipMemcpy(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice));
-        if (ks->raw) (void)hipFree(ks->raw);
+        if (ks->raw) cid::ctx_free(ks->ctx, ks->raw);
         ks->raw = nb.release();
         ks->cap_raw = want;
     }
-    DevBuf<uint8_t> d_bases;
-    DevBuf<cid::Segment> d_segs;
+    DevBuf<uint8_t> d_bases(ks->ctx);
+    DevBuf<cid::Segment> d_segs(ks->ctx);
     int rc;
     if ((rc = d_bases.alloc(total_bases)) || (rc = d_segs.alloc(segs.size()))) return rc;
     HIP_TRY(hipMemcpyAsync(d_bases.p, bases, total_bases, hipMemcpyHostToDevice, st));
@@ -646,7 +654,7 @@ int cid_kmerset_finalize(cid_kmerset *ks, uint64_t *n_distinct) {
     HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
     int rc = compact(ks);
     if (rc) return rc;
-    if (ks->raw) { (void)hipFree(ks->raw); ks->raw = nullptr; ks->cap_raw = 0; }
+    if (ks->raw) { cid::ctx_free(ks->ctx, ks->raw); ks->raw = nullptr; ks->cap_raw = 0; }
     ks->finalized = true;
     if (n_distinct) *n_distinct = ks->n;
     return CID_OK;
@@ -665,18 +673,18 @@ int cid_kmerset_count_histogram(const cid_kmerset *ks, uint32_t *values, uint64_
     if (ks->n == 0) return CID_OK;
     HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
     hipStream_t st = cid::ctx_stream(ks->ctx);
-    DevBuf<uint32_t> sorted, uniq, runs;
-    DevBuf<uint64_t> d_count;
+    DevBuf<uint32_t> sorted(ks->ctx), uniq(ks->ctx), runs(ks->ctx);
+    DevBuf<uint64_t> d_count(ks->ctx);
     int rc;
     if ((rc = sorted.alloc(ks->n)) || (rc = uniq.alloc(ks->n)) || (rc = runs.alloc(ks->n)) || (rc = d_count.alloc(1))) return rc;
     size_t tb = 0;
     HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, ks->counts, sorted.p, ks->n, 0u, 32u, st));
-    DevBuf<uint8_t> tmp;
+    DevBuf<uint8_t> tmp(ks->ctx);
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, ks->counts, sorted.p, ks->n, 0u, 32u, st));
     size_t tb2 = 0;
     HIP_TRY(rocprim::run_length_encode(nullptr, tb2, sorted.p, ks->n, uniq.p, runs.p, d_count.p, st));
-    DevBuf<uint8_t> tmp2;
+    DevBuf<uint8_t> tmp2(ks->ctx);
     if ((rc = tmp2.alloc(tb2))) return rc;
     HIP_TRY(rocprim::run_length_encode(tmp2.p, tb2, sorted.p, ks->n, uniq.p, runs.p, d_count.p, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -698,26 +706,26 @@ int cid_kmerset_clean(cid_kmerset *ks, uint64_t t) {
     if (ks->n == 0 || t == 0) return CID_OK;   // every stored k-mer has count >= 1 > 0
     HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
     hipStream_t st = cid::ctx_stream(ks->ctx);
-    DevBuf<uint8_t> flags;
-    DevBuf<uint64_t> oc, d_count;
-    DevBuf<uint32_t> on;
+    DevBuf<uint8_t> flags(ks->ctx);
+    DevBuf<uint64_t> oc(ks->ctx), d_count(ks->ctx);
+    DevBuf<uint32_t> on(ks->ctx);
     int rc;
     if ((rc = flags.alloc(ks->n)) || (rc = oc.alloc(ks->n)) || (rc = on.alloc(ks->n)) || (rc = d_count.alloc(1))) return rc;
     hipLaunchKernelGGL(cid::k_flag_gt, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->counts, t, flags.p, (uint64_t)ks->n);
     size_t tb = 0;
     HIP_TRY(rocprim::select(nullptr, tb, ks->codes, flags.p, oc.p, d_count.p, ks->n, st));
-    DevBuf<uint8_t> tmp;
+    DevBuf<uint8_t> tmp(ks->ctx);
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(rocprim::select(tmp.p, tb, ks->codes, flags.p, oc.p, d_count.p, ks->n, st));
     size_t tb2 = 0;
     HIP_TRY(rocprim::select(nullptr, tb2, ks->counts, flags.p, on.p, d_count.p, ks->n, st));
-    DevBuf<uint8_t> tmp2;
+    DevBuf<uint8_t> tmp2(ks->ctx);
     if ((rc = tmp2.alloc(tb2))) return rc;
     HIP_TRY(rocprim::select(tmp2.p, tb2, ks->counts, flags.p, on.p, d_count.p, ks->n, st));
     HIP_TRY(hipStreamSynchronize(st));
     uint64_t kept = 0;
     HIP_TRY(hipMemcpy(&kept, d_count.p, 8, hipMemcpyDeviceToHost));
-    (void)hipFree(ks->codes); (void)hipFree(ks->counts);
+    cid::ctx_free(ks->ctx, ks->codes); cid::ctx_free(ks->ctx, ks->counts);
     ks->codes = oc.release(); ks->counts = on.release(); ks->n = kept;
     return CID_OK;
 }
@@ -733,8 +741,8 @@ int cid_kmerset_order_for_index(cid_kmerset *ks, const cid_index *ix) {
     const uint32_t rs = cid::index_rs(ix);
     uint32_t line_shift = 0;
     while ((rs << line_shift) < 16) ++line_shift;   // rows per 128-byte line = 16 / rs
-    DevBuf<uint32_t> keys, idx, keys2, idx2, on;
-    DevBuf<uint64_t> oc;
+    DevBuf<uint32_t> keys(ks->ctx), idx(ks->ctx), keys2(ks->ctx), idx2(ks->ctx), on(ks->ctx);
+    DevBuf<uint64_t> oc(ks->ctx);
     int rc;
     if ((rc = keys.alloc(ks->n)) || (rc = idx.alloc(ks->n)) || (rc = keys2.alloc(ks->n)) || (rc = idx2.alloc(ks->n)) ||
         (rc = oc.alloc(ks->n)) || (rc = on.alloc(ks->n))) return rc;
@@ -742,12 +750,12 @@ int cid_kmerset_order_for_index(cid_kmerset *ks, const cid_index *ix) {
                        idx.p, (uint64_t)ks->n);
     size_t tb = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, 32u, st));
-    DevBuf<uint8_t> tmp;
+    DevBuf<uint8_t> tmp(ks->ctx);
     if ((rc = tmp.alloc(tb))) return rc;
     HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, 32u, st));
     hipLaunchKernelGGL(cid::k_gather_set, dim3(grid_for_n(ks->n)), dim3(256), 0, st, idx2.p, ks->codes, ks->counts, oc.p, on.p, (uint64_t)ks->n);
     HIP_TRY(hipStreamSynchronize(st));
-    (void)hipFree(ks->codes); (void)hipFree(ks->counts);
+    cid::ctx_free(ks->ctx, ks->codes); cid::ctx_free(ks->ctx, ks->counts);
     ks->codes = oc.release(); ks->counts = on.release();
     return CID_OK;
 }
@@ -759,7 +767,7 @@ int cid_kmerset_download(const cid_kmerset *ks, uint8_t *kmers_ascii, uint32_t *
     HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
     hipStream_t st = cid::ctx_stream(ks->ctx);
     if (kmers_ascii) {
-        DevBuf<uint8_t> a;
+        DevBuf<uint8_t> a(ks->ctx);
         int rc = a.alloc(ks->n * ks->k);
         if (rc) return rc;
         hipLaunchKernelGGL(cid::k_codes_to_ascii, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, a.p, (uint64_t)ks->n);
@@ -779,9 +787,9 @@ int cid_kmerset_device_arrays(const cid_kmerset *ks, void **d_codes, void **d_co
 void cid_kmerset_destroy(cid_kmerset *ks) {
     if (!ks) return;
     (void)hipSetDevice(cid::ctx_device(ks->ctx));
-    if (ks->raw) (void)hipFree(ks->raw);
-    if (ks->codes) (void)hipFree(ks->codes);
-    if (ks->counts) (void)hipFree(ks->counts);
+    if (ks->raw) cid::ctx_free(ks->ctx, ks->raw);
+    if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
+    if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
     if (ks->d_flags) (void)hipFree(ks->d_flags);
     delete ks;
 }

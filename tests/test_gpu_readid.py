@@ -173,6 +173,26 @@ def test_readid_long_reads_k_above_32(orc, hip_ctx, k, n_hash):
     hx.close()
 
 
+def test_readid_mixed_batch_routes_per_read(orc, phage):
+    """One batch with short reads (LDS kernel), 2-6 kb reads (two waves per workgroup still fit / no longer fit) and whole
+    genomes (sort-based lists): every read goes to its own path and the rows come back in input order."""
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(77)
+    reads = []
+    for i in range(400):
+        g = genomes[i % 4]
+        L = int(rng.choice([30, 150, 151, 700, 2000, 2600, 3500, 6000, 12_000]))
+        st = int(rng.integers(0, len(g) - L))
+        r = g[st:st + L]
+        if i % 37 == 0:
+            r = r.lower()
+        reads.append([r] if i % 3 else [r, g[st:st + min(L, 500)]])
+    reads += [[genomes[1]], [b"ACG"], [genomes[0][:5000], genomes[2][:9000]], [b"N" * 5000]]
+    for d, S in ((1, 3), (1, 0), (4, 2)):
+        rep, nk, st = check(oix, hx, reads, d, S)
+        assert st[-3] == 1 and rep[-4, 1] > 50 and nk[-4] > 5_000
+
+
 def test_readid_wide_rows_long_reads(orc, hip_ctx):
     """more than 8192 colours AND reads too long for the LDS kernel: k_readid_list over 1-KiB row steps"""
     rng = np.random.default_rng(99)
@@ -185,7 +205,7 @@ def test_readid_wide_rows_long_reads(orc, hip_ctx):
         oix.insert(7, key.tobytes())
         oix.insert(8999, key.tobytes())
     hx = to_hip_index(hip_ctx, oix)
-    reads = [[g[:45_000]], [g[30_000:60_000], g[:20_000]], [g[100:250]], [b"AC"]]
+    reads = [[g[:45_000]], [g[30_000:60_000], g[:20_000]], [g[100:250]], [b"AC"], [g[5_000:5_400]], [g[:3000]]]   # mixed routing
     for d, S in ((1, 3), (1, 0), (3, 1)):
         rep, nk, st = check(oix, hx, reads, d, S)
         assert rep[0, 7] > 1000 and rep[0, 8999] == rep[0, 7]
