@@ -35,7 +35,7 @@ using cid::fail;
         if (e_ != hipSuccess) return fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_COUNT };
+enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_REDO, S_COUNT };
 
 }  // namespace
 
@@ -621,30 +621,42 @@ int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_code
 
 // ------------------------------------------------------------------------------------------------ a6/a7/a9/a10
 
-// LDS layout of k_readid for reads of at most max_bytes bases / max_win windows; returns the bytes one wave needs
+// LDS layout of k_readid (bytes_kernel = false) or k_readid_bytes for reads of at most max_bytes bases / max_win windows;
+// returns the bytes one wave needs (the kernels carve the same regions in the same order)
 static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                            cid::ReadIdParams &p) {
+                            bool bytes_kernel, cid::ReadIdParams &p) {
     p = cid::ReadIdParams{};
     p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
     p.mod = ix->mod;
     p.stride_d = stride_d; p.start_sample = start_sample;
     p.m_size = ix->m_size;
     if (max_bytes > (1ull << 30) || max_win > (1ull << 30)) return ~(size_t)0;
+    const bool wide = ix->rs > 128;
     p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
     p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
     if (p.win_cap < 4) p.win_cap = 4;
-    p.hist_pad = ix->rs > 128 ? 4u * ix->rs : ((ix->n_colors + 1 + 3) & ~3u);   // wide rows: AND word + sampled-colour set
+    p.hist_pad = wide ? 4u * ix->rs : ((ix->n_colors + 1 + 3) & ~3u);   // wide rows: AND word + sampled-colour set
     p.table_slots = 64;
     while (p.table_slots < p.win_cap + p.win_cap / 2) p.table_slots <<= 1;
-    // key region: the larger of the byte-string layout (tags, window infos, k-mer image) and the packed layout
-    // (hash table keys + indices, 2-bit bases, bad-base bits)
-    const size_t key_bytes_path = 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
-                                  (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);
-    const size_t key_packed_path = 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
-    const size_t key_bytes = ((key_bytes_path > key_packed_path ? key_bytes_path : key_packed_path) + 15) & ~15ull;
-    const size_t wave_bytes = ((size_t)p.bases_cap + 4ull * cid::kWave * ix->n_hash + 4ull * p.hist_pad + key_bytes + 15) & ~15ull;
+    const size_t chunk_rows = 4ull * cid::kWave * ix->n_hash;                     // one chunk's row numbers
+    const size_t rall_bytes = wide ? 0 : 4ull * p.win_cap * ix->n_hash;           // rows of the read's distinct k-mers (wide rows search chunk by chunk)
+    size_t wave_bytes = (size_t)p.bases_cap + 4ull * p.hist_pad + rall_bytes;
+    if (bytes_kernel)   // tags, window infos, k-mer image (+ minimizer image and the distinct minimizer strings)
+        wave_bytes += chunk_rows + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
+                      (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);
+    else                // hash table keys + indices, 2-bit bases, bad-base bits
+        wave_bytes += (wide ? chunk_rows : 0) + 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
+    wave_bytes = (wave_bytes + 15) & ~15ull;
     p.wave_bytes = (uint32_t)(wave_bytes < 0xFFFFFFF0ull ? wave_bytes : 0xFFFFFFF0ull);
     return wave_bytes;
+}
+// what a read needs of the LDS kernels: k <= 32 reads may end up in either of them
+static size_t readid_need(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win) {
+    cid::ReadIdParams p;
+    const size_t b = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, true, p);
+    if (ix->k > 32) return b;
+    const size_t a = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, false, p);
+    return a > b ? a : b;
 }
 
 constexpr size_t kLdsBytes = 160u * 1024u;
@@ -654,8 +666,8 @@ constexpr size_t kLdsBytes = 160u * 1024u;
 constexpr size_t kLdsReadBytesMax = kLdsBytes / 2;
 
 static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                         cid::ReadIdParams &p, int &waves) {
-    const size_t wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, p);
+                         bool bytes_kernel, cid::ReadIdParams &p, int &waves) {
+    const size_t wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, p);
     waves = 4;
     while (waves > 1 && (size_t)waves * wave_bytes > kLdsBytes) waves >>= 1;
     if (wave_bytes > kLdsBytes)
@@ -669,20 +681,43 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
                            const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                            uint64_t max_read_bytes, uint64_t max_read_windows, const uint8_t *d_skip, bool clear_wide, uint32_t *d_report,
                            uint32_t *d_n_kmers, uint8_t *d_status) {
-    cid::ReadIdParams p;
-    int waves;
-    int rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, p, waves);
+    if (n_reads >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 reads in one batch");
+    cid::ReadIdParams pb, pp;
+    int waves_b, waves_p = 0;
+    int rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, true, pb, waves_b);
     if (rc) return rc;
+    const bool packable = ix->k <= 32;
+    if (packable && (rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, false, pp, waves_p))) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
-    p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status; p.skip = d_skip;
-    uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
-    if (rpb < (uint64_t)waves) rpb = waves;
-    if (rpb > 256) rpb = 256;
-    p.reads_per_block = (uint32_t)rpb;
+    auto fill = [&](cid::ReadIdParams &p, int waves) {
+        p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
+        p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status; p.skip = d_skip;
+        uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
+        if (rpb < (uint64_t)waves) rpb = waves;
+        if (rpb > 256) rpb = 256;
+        p.reads_per_block = (uint32_t)rpb;
+    };
     if (ix->rs > 128 && clear_wide)   // wide rows count in place
         HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * ((size_t)ix->n_colors + 1) * 4, c->stream));
-    HIP_TRY(cid::launch_readid(p, waves, c->stream));
+    if (packable) {
+        // k_readid takes every read it can pack; the ones with lower-case bases come back in the redo list for k_readid_bytes
+        void *d_redo;
+        rc = slot_reserve(c, S_REDO, 16 + 4 * n_reads, &d_redo); if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_redo, 0, 16, c->stream));
+        fill(pp, waves_p);
+        pp.redo_count = (uint32_t *)d_redo; pp.redo_list = (uint32_t *)d_redo + 4;
+        HIP_TRY(cid::launch_readid(pp, waves_p, c->stream));
+        fill(pb, waves_b);
+        pb.redo_count = pp.redo_count; pb.redo_list = pp.redo_list;
+        uint64_t grid = (n_reads + waves_b - 1) / waves_b;
+        if (grid > (uint64_t)c->n_cu * 4) grid = (uint64_t)c->n_cu * 4;
+        HIP_TRY(cid::launch_readid_bytes(pb, waves_b, (int)grid, c->stream));
+    } else {
+        fill(pb, waves_b);
+        uint64_t grid = (n_reads + waves_b - 1) / waves_b;
+        if (grid > (uint64_t)c->n_cu * 64) grid = (uint64_t)c->n_cu * 64;
+        HIP_TRY(cid::launch_readid_bytes(pb, waves_b, (int)grid, c->stream));
+    }
     return CID_OK;
 }
 
@@ -733,14 +768,13 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
     // routing: reads whose set would leave k_readid fewer than two waves per workgroup go through the sort-based path
     std::vector<uint8_t> route;   // empty = one path for the whole batch
     size_t n_long = 0;
-    cid::ReadIdParams probe;
-    if (readid_layout(ix, stride_d, start_sample, max_bytes, max_win, probe) > kLdsReadBytesMax) {
+    if (readid_need(ix, stride_d, start_sample, max_bytes, max_win) > kLdsReadBytesMax) {
         route.assign(n_reads, 0);
         max_bytes = max_win = 0;
         for (size_t r = 0; r < n_reads; ++r) {
             uint64_t bytes, win;
             read_size(r, bytes, win);
-            if (readid_layout(ix, stride_d, start_sample, bytes, win, probe) > kLdsReadBytesMax) { route[r] = 1; ++n_long; }
+            if (readid_need(ix, stride_d, start_sample, bytes, win) > kLdsReadBytesMax) { route[r] = 1; ++n_long; }
             else {
                 if (bytes > max_bytes) max_bytes = bytes;
                 if (win > max_win) max_win = win;

@@ -517,95 +517,146 @@ __device__ __forceinline__ uint64_t bits_at(const uint32_t *w, uint32_t bit, uin
     return nbits >= 64 ? v : (v & ((1ull << nbits) - 1ull));
 }
 
+constexpr int kReadRunUnroll = 2;   // sub-passes of a read's search whose row loads are in flight together
 constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained every 7 additions
 
 
-// The in-order search over one chunk's distinct k-mers (bit kk of dmask = lane kk holds a distinct k-mer whose n row
-// numbers sit in ridx[s*64 + kk]); nd = distinct k-mers before this chunk == the reference's `counter`
-// (read_id_mt_pe.rs:66-102 classic / :104-165 sampled).  Shared by k_readid and k_readid_list.
-template <int LOG_LPR, bool NARROW>
-__device__ __forceinline__ void readid_search_chunk(const uint64_t *mat, uint32_t rs, uint32_t w64, uint32_t n, uint32_t C, uint32_t S,
-                                                    const uint32_t *ridx, uint32_t *hist, uint64_t dmask, uint32_t nd, bool &stopped,
-                                                    VCount<kReadPlanes, NARROW> &vc, V16 &R, int lane) {
+// The in-order search (read_id_mt_pe.rs:66-102 classic / :104-165 sampled) over a dense run of distinct k-mers: k-mer j (0 <= j < count, order index q_base + j) has its row
+// numbers at ridx[s*stride + j].  U sub-passes (U * 64/LPR k-mers) have all their row loads issued before the first is
+// consumed: a read's search is a chain of dependent gather rounds, and what bounds the kernel is how many of them there are.
+template <int NH, int U, bool NARROW>
+__device__ __forceinline__ void gather_run_fixed(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, uint32_t stride, const uint32_t (&j)[U],
+                                                 const bool (&live)[U], uint32_t col_word, uint32_t s0, V16 (&a)[U], uint32_t (&zm)[U]) {
+    V16 v[U][NH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < NH; ++s) {
+            const uint64_t row = live[u] ? ridx[(s0 + s) * stride + j[u]] : 0u;   // idle lanes read row 0: no branch, an L2 hit
+            v[u][s] = load_slice<NARROW>(mat + row * rs + col_word);
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < NH; ++s) {
+            const uint64_t o = NARROW ? v[u][s].x : (v[u][s].x | v[u][s].y);
+            zm[u] |= (o == 0) ? (1u << (s0 + s)) : 0u;
+            a[u].x &= v[u][s].x;
+            a[u].y &= v[u][s].y;
+        }
+}
+
+template <int LOG_LPR, bool NARROW, int U>
+__device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t rs, uint32_t n, uint32_t C, uint32_t S, const uint32_t *ridx,
+                                                  uint32_t stride, uint32_t count, uint32_t q_base, uint32_t *hist, bool &stopped,
+                                                  VCount<kReadPlanes, NARROW> &vc, V16 &R, int lane) {
     constexpr int LPR = 1 << LOG_LPR;
     constexpr int KPW = kWave / LPR;
-    if (stopped || !dmask) return;
+    if (stopped || !count) return;
     const uint32_t col = lane & (LPR - 1);
-    const uint32_t col_word = NARROW ? 0u : 2u * col;
-    const bool col_live = col_word < w64;
+    const uint32_t col_word = NARROW ? 0u : 2u * col;   // slices past the last colour word are zero padding of the row
     const uint32_t seeds_mask = n >= 32 ? ~0u : ((1u << n) - 1u);
 #pragma unroll 1
-    for (int sub = 0; sub < LPR; ++sub) {
-        const uint64_t sub_bits = (KPW == 64) ? dmask : ((dmask >> (sub * KPW)) & ((1ull << (KPW & 63)) - 1ull));
-        if (!sub_bits) continue;
-        const int kk = sub * KPW + (lane >> LOG_LPR);
-        bool live = (dmask >> kk) & 1ull;
-        const uint32_t q = nd + (uint32_t)__popcll(dmask & ((1ull << kk) - 1ull));
-        V16 a{0, 0};
-        uint32_t zm = ~0u;
-        if (live && col_live) a = gather_and<NARROW, true>(mat, rs, ridx, kk, col_word, n, zm);
-        if constexpr (NARROW) a.y = 0;
-        uint32_t all_zero = zm;
+    for (uint32_t j0 = 0; j0 < count; j0 += U * KPW) {
+        uint32_t j[U];
+        bool live[U];
+        V16 a[U];
+        uint32_t zm[U];
 #pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
-        const bool miss = live && (all_zero & seeds_mask);
-        const uint64_t bm = __ballot(miss);
-        // keep only the k-mers before the first absent row (lane order == k-mer order in a sub-pass)
-        if (bm) live = live && (lane >> LOG_LPR) < (__builtin_ctzll(bm) >> LOG_LPR);
-        if (!live) { a.x = 0; a.y = 0; }
-        if (S > 0) {
-            V16 ra = q < S ? a : V16{0, 0};
-#pragma unroll
-            for (int o = LPR; o < kWave; o <<= 1) {
-                ra.x |= __shfl_xor(ra.x, o, kWave);
-                ra.y |= __shfl_xor(ra.y, o, kWave);
-            }
-            R.x |= ra.x; R.y |= ra.y;
-            if (q >= S) { a.x &= R.x; a.y &= R.y; }
+        for (int u = 0; u < U; ++u) {
+            j[u] = j0 + u * KPW + (lane >> LOG_LPR);
+            live[u] = j[u] < count;
+            a[u] = V16{~0ull, ~0ull};
+            zm[u] = 0;
         }
-        vc.add(a);
-        if (vc.full()) vc.drain(hist, col_word);
-        if (bm) {
-            stopped = true;
-            if (lane == 0) hist[C] += 1;  // *report.entry(no_hits_num) += 1; break
-            return;
+        switch (n) {   // n is wave-uniform; the common sizes are fully unrolled
+        case 1: gather_run_fixed<1, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+        case 2: gather_run_fixed<2, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+        case 3: gather_run_fixed<3, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+        case 4: gather_run_fixed<4, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+        default: {
+            uint32_t sd = 0;
+            for (; sd + 4 <= n; sd += 4) gather_run_fixed<4, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, sd, a, zm);
+            for (; sd < n; ++sd) gather_run_fixed<1, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, sd, a, zm);
+        }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (j0 + u * KPW >= count) break;   // wave-uniform
+            V16 w = a[u];
+            if constexpr (NARROW) w.y = 0;
+            uint32_t all_zero = zm[u];
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
+            bool lv = live[u];
+            const bool miss = lv && (all_zero & seeds_mask);
+            const uint64_t bm = __ballot(miss);
+            // keep only the k-mers before the first absent row (lane order == k-mer order in a sub-pass)
+            if (bm) lv = lv && (lane >> LOG_LPR) < (__builtin_ctzll(bm) >> LOG_LPR);
+            if (!lv) { w.x = 0; w.y = 0; }
+            if (S > 0) {
+                const uint32_t q = q_base + j[u];
+                if (q_base + j0 + u * KPW < S) {   // wave-uniform: this sub-pass holds some of the first S k-mers
+                    V16 ra = q < S ? w : V16{0, 0};
+#pragma unroll
+                    for (int o = LPR; o < kWave; o <<= 1) {
+                        ra.x |= __shfl_xor(ra.x, o, kWave);
+                        ra.y |= __shfl_xor(ra.y, o, kWave);
+                    }
+                    R.x |= ra.x; R.y |= ra.y;
+                }
+                if (q >= S) { w.x &= R.x; w.y &= R.y; }
+            }
+            vc.add(w);
+            if (vc.full()) vc.drain(hist, col_word);
+            if (bm) {
+                stopped = true;
+                if (lane == 0) hist[C] += 1;  // *report.entry(no_hits_num) += 1; break
+                return;
+            }
         }
     }
 }
 
-template <int LOG_LPR, bool NARROW, bool WIDE = false>
+// Output of one read: drain the counters, copy the histogram to the report row, clear it for the next read.
+template <bool NARROW, bool WIDE>
+__device__ __forceinline__ void readid_finish_read(VCount<kReadPlanes, NARROW> &vc, uint32_t *hist, uint32_t col_word, uint32_t *row_out,
+                                                   uint32_t C, int lane) {
+    if constexpr (!WIDE) {
+        vc.drain(hist, col_word);
+        wave_lds_fence();
+        for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+    }
+}
+
+// ---- k_readid: reads without lower-case bases, k <= 32.  Per-wave LDS: bases | ridx (WIDE only: 64*n) | hist | rall (not
+// WIDE: win_cap*n) | table keys + indices | 2-bit bases | bad-base bits.  A read with a lower-case base (its case must be
+// kept) is appended to p.redo_list for k_readid_bytes.
+template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI>
 __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
+    constexpr uint32_t RS = NARROW ? 1u : 2u * LPR;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const uint32_t C = p.n_colors, k = p.k, n = p.n_hash, S = p.start_sample;
+    const uint32_t klen = MINI ? p.m_size : k;   // length of the hashed key
 
     uint8_t *wb = smem + (size_t)wave * p.wave_bytes;
     uint8_t *s_bases = wb;                                                     // bases_cap
-    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.bases_cap);           // 64*n
-    uint32_t *hist = ridx + kWave * n;                                         // hist_pad
-    uint8_t *keyreg = reinterpret_cast<uint8_t *>(hist + p.hist_pad);          // key_bytes: one of the two layouts below
-    // bytes path
-    uint32_t *s_tag = reinterpret_cast<uint32_t *>(keyreg);                    // win_cap
-    uint32_t *s_info = s_tag + p.win_cap;                                      // win_cap
-    uint32_t *img = s_info + p.win_cap;                                        // kmer_img_bytes(k)
-    uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
-    uint32_t *mimg = img + kmer_img_bytes(k) / 4;                              // .mxi only: kmer_img_bytes(m_size) minimizer image
-    uint8_t *mimg8 = reinterpret_cast<uint8_t *>(mimg);
-    uint8_t *s_mstr = mimg8 + kmer_img_bytes(p.m_size ? p.m_size : 1);         // .mxi only: win_cap x m_size distinct minimizers
-    const uint32_t klen = p.m_size ? p.m_size : k;                             // length of the hashed key
-    // packed path
-    unsigned long long *t_key = reinterpret_cast<unsigned long long *>(keyreg);   // table_slots
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.bases_cap);           // WIDE: 64*n, this chunk's rows
+    uint32_t *hist = ridx + (WIDE ? kWave * n : 0u);                           // hist_pad
+    uint32_t *rall = hist + p.hist_pad;                                        // not WIDE: win_cap*n, rows of the read's distinct k-mers in order
+    const uint32_t rcap = p.win_cap;
+    unsigned long long *t_key = reinterpret_cast<unsigned long long *>(rall + (WIDE ? 0u : rcap * n));   // table_slots
     uint32_t *t_idx = reinterpret_cast<uint32_t *>(t_key + p.table_slots);     // table_slots
     uint32_t *s_pack = t_idx + p.table_slots;                                  // bases_cap/16 + 4 dwords, 16 bases each
     uint32_t *s_bad = s_pack + (p.bases_cap / 16 + 4);                         // bases_cap/32 + 4 dwords, 1 bit per base
 
     for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
 
-    const uint32_t col = lane & (LPR - 1);
-    const uint32_t col_word = NARROW ? 0u : 2u * col;
+    const uint32_t col_word = NARROW ? 0u : 2u * (lane & (LPR - 1));
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t tmask = p.table_slots - 1;
 
@@ -631,28 +682,29 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
             s_bases[i] = b;
             lower = lower || (good_base(b) && (b & 0x20u));
         }
-        const bool packed = k <= 32 && !__any(lower);
-        wave_lds_fence();
-        if (packed) {
-            // 16 bases per lane-step: 2-bit codes (A,C,G,T = 0..3, anything else 0 + its bad bit)
-            for (uint32_t j0 = 0; j0 * 16 < tb + 64; j0 += kWave) {
-                const uint32_t j = j0 + lane;
-                uint32_t code = 0, bad = 0;
-                for (uint32_t t = 0; t < 16; ++t) {
-                    const uint32_t i = j * 16 + t;
-                    const uint32_t b = i < tb ? s_bases[i] : 'N';
-                    const uint32_t c2 = (b >> 1) & 3u;            // A 00, C 01, T 10, G 11  ->  swap G/T below
-                    code |= (c2 ^ (c2 >> 1)) << (2 * t);          // A 0, C 1, G 2, T 3
-                    bad |= (good_base(b) ? 0u : 1u) << t;
-                }
-                const uint32_t bad_hi = __shfl_down(bad, 1, kWave);
-                if (j * 16 < tb + 64) {
-                    s_pack[j] = code;
-                    if (!(lane & 1)) s_bad[j >> 1] = bad | (bad_hi << 16);
-                }
-            }
-            for (uint32_t t = lane; t < p.table_slots; t += kWave) { t_key[t] = ~0ull; t_idx[t] = ~0u; }
+        if (__any(lower)) {   // the byte-string kernel takes this read
+            if (lane == 0) p.redo_list[atomicAdd(p.redo_count, 1u)] = (uint32_t)read;
+            continue;
         }
+        wave_lds_fence();
+        // 16 bases per lane-step: 2-bit codes (A,C,G,T = 0..3, anything else 0 + its bad bit)
+        for (uint32_t j0 = 0; j0 * 16 < tb + 64; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            uint32_t code = 0, bad = 0;
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t i = j * 16 + t;
+                const uint32_t b = i < tb ? s_bases[i] : 'N';
+                const uint32_t c2 = (b >> 1) & 3u;            // A 00, C 01, T 10, G 11  ->  swap G/T below
+                code |= (c2 ^ (c2 >> 1)) << (2 * t);          // A 0, C 1, G 2, T 3
+                bad |= (good_base(b) ? 0u : 1u) << t;
+            }
+            const uint32_t bad_hi = __shfl_down(bad, 1, kWave);
+            if (j * 16 < tb + 64) {
+                s_pack[j] = code;
+                if (!(lane & 1)) s_bad[j >> 1] = bad | (bad_hi << 16);
+            }
+        }
+        for (uint32_t t = lane; t < p.table_slots; t += kWave) { t_key[t] = ~0ull; t_idx[t] = ~0u; }
         wave_lds_fence();
 
         uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
@@ -666,7 +718,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
             for (uint32_t w = lane; w < p.rs; w += kWave) s_R[w] = 0;
             wave_lds_fence();
         }
-
         for (uint64_t s = s0; s < s1; ++s) {
             const uint32_t off = (uint32_t)(p.seq_off[s] - g0);
             const uint32_t len = (uint32_t)(p.seq_off[s + 1] - p.seq_off[s]);
@@ -675,91 +726,178 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
             for (uint32_t c0 = 0; c0 < nw; c0 += kWave) {
                 const uint32_t wi = c0 + lane;
                 const uint32_t pos = off + wi * p.stride_d;
-                bool distinct;
-                wave_lds_fence();  // the previous chunk's gathers are done with ridx / img
-                if (packed) {
-                    bool valid = wi < nw;
-                    uint64_t lsb = 0;
-                    if (valid) {
-                        valid = bits_at(s_bad, pos, k) == 0;                   // seq::has_no_n over the window
-                        lsb = bits_at(s_pack, 2 * pos, 2 * k);
+                if constexpr (WIDE) wave_lds_fence();  // the previous chunk's gathers are done with ridx
+                bool valid = wi < nw;
+                uint64_t lsb = 0;
+                if (valid) {
+                    valid = bits_at(s_bad, pos, k) == 0;                   // seq::has_no_n over the window
+                    lsb = bits_at(s_pack, 2 * pos, 2 * k);
+                }
+                uint64_t msb = 0;
+                uint64_t canon = canonical_code(lsb, k, &msb);
+                if constexpr (MINI) {  // .mxi: the set holds the k-mers' minimizers (kmer.rs:363-394)
+                    msb = minimizer_code(msb, k, klen);
+                    canon = rev_fields(msb, klen);
+                }
+                // exact set with first-occurrence order: slot key = canonical code, slot value = smallest window index
+                uint32_t slot = (uint32_t)((msb * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
+                if (valid) {
+                    while (true) {
+                        const unsigned long long old = atomicCAS(&t_key[slot], ~0ull, (unsigned long long)msb);
+                        if (old == ~0ull || old == msb) break;
+                        slot = (slot + 1) & tmask;
                     }
-                    uint64_t msb = 0;
-                    uint64_t canon = canonical_code(lsb, k, &msb);
-                    if (p.m_size) {  // .mxi: the set holds the k-mers' minimizers (kmer.rs:363-394)
-                        msb = minimizer_code(msb, k, p.m_size);
-                        canon = rev_fields(msb, p.m_size);
+                    atomicMin(&t_idx[slot], wbase + wi);
+                }
+                wave_lds_fence();
+                const bool distinct = valid && t_idx[slot] == wbase + wi;
+                const uint64_t dmask = __ballot(distinct);
+                if (distinct) {   // WIDE: this chunk's slot; else the read's list at the k-mer's order index
+                    uint32_t *dst = WIDE ? ridx + lane : rall + nd + (uint32_t)__popcll(dmask & lt_mask);
+                    const uint32_t st = WIDE ? (uint32_t)kWave : rcap;
+                    xxh3_seeds_from(CodeReader{canon}, klen, n, [&](uint32_t sd, uint64_t h) { dst[sd * st] = (uint32_t)mod_m(h, p.mod); });
+                }
+                if constexpr (WIDE) {
+                    wave_lds_fence();
+                    uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
+                    readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
+                }
+                nd += (uint32_t)__popcll(dmask);
+            }
+            wbase += nw;
+        }
+        if constexpr (!WIDE) {
+            // the set is complete: search its nd k-mers in order, several sub-passes of row loads in flight at a time
+            wave_lds_fence();
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane);
+        }
+        readid_finish_read<NARROW, WIDE>(vc, hist, col_word, row_out, C, lane);
+        if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
+    }
+}
+
+// ---- k_readid_bytes: the same per-read work on byte strings — reads with lower-case bases (p.redo_list, filled by
+// k_readid) or every read when k > 32 (p.redo_list == NULL).  Per-wave LDS: bases | ridx (64*n) | hist | rall | tags |
+// window infos | k-mer image | minimizer image + distinct minimizer strings (.mxi).  A 32-bit tag match is confirmed on the bytes.
+template <int LOG_LPR, bool NARROW, bool WIDE>
+__global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int LPR = 1 << LOG_LPR;
+    constexpr uint32_t RS = NARROW ? 1u : 2u * LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t C = p.n_colors, k = p.k, n = p.n_hash, S = p.start_sample;
+
+    uint8_t *wb = smem + (size_t)wave * p.wave_bytes;
+    uint8_t *s_bases = wb;                                                     // bases_cap
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.bases_cap);           // 64*n: this chunk's rows
+    uint32_t *hist = ridx + kWave * n;                                         // hist_pad
+    uint32_t *rall = hist + p.hist_pad;                                        // not WIDE: win_cap*n
+    const uint32_t rcap = p.win_cap;
+    uint32_t *s_tag = rall + (WIDE ? 0u : rcap * n);                           // win_cap
+    uint32_t *s_info = s_tag + p.win_cap;                                      // win_cap
+    uint32_t *img = s_info + p.win_cap;                                        // kmer_img_bytes(k)
+    uint8_t *img8 = reinterpret_cast<uint8_t *>(img);
+    uint32_t *mimg = img + kmer_img_bytes(k) / 4;                              // .mxi only: kmer_img_bytes(m_size) minimizer image
+    uint8_t *mimg8 = reinterpret_cast<uint8_t *>(mimg);
+    uint8_t *s_mstr = mimg8 + kmer_img_bytes(p.m_size ? p.m_size : 1);         // .mxi only: win_cap x m_size distinct minimizers
+
+    for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
+    const uint32_t col_word = NARROW ? 0u : 2u * (lane & (LPR - 1));
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+    const uint64_t n_items = p.redo_list ? (uint64_t)*p.redo_count : p.n_reads;
+    for (uint64_t item = (uint64_t)blockIdx.x * waves + wave; item < n_items; item += (uint64_t)gridDim.x * waves) {
+        const uint64_t read = p.redo_list ? (uint64_t)p.redo_list[item] : item;
+        if (p.skip && p.skip[read]) continue;
+        wave_lds_fence();
+        const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
+        const uint64_t g0 = p.seq_off[s0];
+        const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
+        uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
+        if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
+            if constexpr (!WIDE)
+                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+            if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 1; }
+            continue;
+        }
+        const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
+        for (uint32_t i = lane; i < tb; i += kWave) s_bases[i] = p.bases[g0 + i];
+        wave_lds_fence();
+
+        uint32_t nd = 0;
+        bool stopped = false;
+        VCount<kReadPlanes, NARROW> vc;
+        vc.clear();
+        V16 R{0, 0};
+        if constexpr (WIDE) {
+            uint64_t *s_R = reinterpret_cast<uint64_t *>(hist) + p.rs;
+            for (uint32_t w = lane; w < p.rs; w += kWave) s_R[w] = 0;
+            wave_lds_fence();
+        }
+        for (uint64_t s = s0; s < s1; ++s) {
+            const uint32_t off = (uint32_t)(p.seq_off[s] - g0);
+            const uint32_t len = (uint32_t)(p.seq_off[s + 1] - p.seq_off[s]);
+            if (len < k) continue;
+            const uint32_t nw = (len - k) / p.stride_d + 1;
+            for (uint32_t c0 = 0; c0 < nw; c0 += kWave) {
+                const uint32_t wi = c0 + lane;
+                const uint32_t pos = off + wi * p.stride_d;
+                wave_lds_fence();  // the previous chunk is done with ridx / img
+                bool valid = wi < nw;
+                if (valid)
+                    for (uint32_t t = 0; t < k; ++t) valid = valid && good_base(s_bases[pos + t]);
+                uint32_t rc = 1;  // palindromes take the reverse-complement branch (same string)
+                if (valid)
+                    for (uint32_t t = 0; t < k; ++t) {
+                        const uint32_t f = s_bases[pos + t], r = comp_base(s_bases[pos + k - 1 - t]);
+                        if (f != r) { rc = f < r ? 0u : 1u; break; }
                     }
-                    // exact set with first-occurrence order: slot key = canonical code, slot value = smallest window index
-                    uint32_t slot = (uint32_t)((msb * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
+                const uint32_t info = pos | (rc << 31);
+                if (valid)
+                    for (uint32_t t = 0; t < k; ++t) img8[(uint32_t)lane * k + t] = (uint8_t)canon_byte(s_bases, info, k, t);
+                wave_lds_fence();
+                uint32_t tag = 0;
+                bool dup = false;
+                const uint64_t vmask = __ballot(valid);
+                uint64_t dmask;
+                if (p.m_size) {  // .mxi: the key is the (upper-cased) minimizer of the canonical k-mer; strings kept in s_mstr
+                    const uint32_t m = p.m_size;
                     if (valid) {
-                        while (true) {
-                            const unsigned long long old = atomicCAS(&t_key[slot], ~0ull, (unsigned long long)msb);
-                            if (old == ~0ull || old == msb) break;
-                            slot = (slot + 1) & tmask;
-                        }
-                        atomicMin(&t_idx[slot], wbase + wi);
+                        const uint8_t *seq = img8 + (uint32_t)lane * k;
+                        const uint32_t cand = find_minimizer_bytes(seq, k, m);
+                        for (uint32_t t = 0; t < m; ++t) mimg8[(uint32_t)lane * m + t] = upper_base(mini_byte(seq, cand, m, t));
                     }
                     wave_lds_fence();
-                    distinct = valid && t_idx[slot] == wbase + wi;
-                    if (distinct)
-                        xxh3_seeds_from(CodeReader{canon}, klen, n, [&](uint32_t sd, uint64_t h) {
+                    if (valid)
+                        xxh3_seeds(mimg, (uint32_t)lane * m, m, n, [&](uint32_t sd, uint64_t h) {
+                            if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
                             ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
                         });
+                    for (uint32_t q = 0; q < nd; ++q) {
+                        if (valid && !dup && s_tag[q] == tag) {
+                            bool same = true;
+                            for (uint32_t t = 0; t < m && same; ++t) same = s_mstr[q * m + t] == mimg8[(uint32_t)lane * m + t];
+                            dup = same;
+                        }
+                    }
+                    for (int j = 0; j < kWave - 1; ++j) {
+                        if (!((vmask >> j) & 1ull)) continue;
+                        const uint32_t tj = __builtin_amdgcn_readlane(tag, j);
+                        if (valid && !dup && j < lane && tj == tag) {
+                            bool same = true;
+                            for (uint32_t t = 0; t < m && same; ++t) same = mimg8[(uint32_t)j * m + t] == mimg8[(uint32_t)lane * m + t];
+                            dup = same;
+                        }
+                    }
+                    dmask = __ballot(valid && !dup);
+                    if (valid && !dup) {
+                        const uint32_t q = nd + (uint32_t)__popcll(dmask & lt_mask);
+                        s_tag[q] = tag;
+                        for (uint32_t t = 0; t < m; ++t) s_mstr[q * m + t] = mimg8[(uint32_t)lane * m + t];
+                    }
                 } else {
-                    bool valid = wi < nw;
-                    if (valid)
-                        for (uint32_t t = 0; t < k; ++t) valid = valid && good_base(s_bases[pos + t]);
-                    uint32_t rc = 1;  // palindromes take the reverse-complement branch (same string)
-                    if (valid)
-                        for (uint32_t t = 0; t < k; ++t) {
-                            const uint32_t f = s_bases[pos + t], r = comp_base(s_bases[pos + k - 1 - t]);
-                            if (f != r) { rc = f < r ? 0u : 1u; break; }
-                        }
-                    const uint32_t info = pos | (rc << 31);
-                    if (valid)
-                        for (uint32_t t = 0; t < k; ++t) img8[(uint32_t)lane * k + t] = (uint8_t)canon_byte(s_bases, info, k, t);
-                    wave_lds_fence();
-                    uint32_t tag = 0;
-                    bool dup = false;
-                    const uint64_t vmask = __ballot(valid);
-                    if (p.m_size) {  // .mxi: the key is the (upper-cased) minimizer of the canonical k-mer; strings kept in s_mstr
-                        const uint32_t m = p.m_size;
-                        if (valid) {
-                            const uint8_t *seq = img8 + (uint32_t)lane * k;
-                            const uint32_t cand = find_minimizer_bytes(seq, k, m);
-                            for (uint32_t t = 0; t < m; ++t) mimg8[(uint32_t)lane * m + t] = upper_base(mini_byte(seq, cand, m, t));
-                        }
-                        wave_lds_fence();
-                        if (valid)
-                            xxh3_seeds(mimg, (uint32_t)lane * m, m, n, [&](uint32_t sd, uint64_t h) {
-                                if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
-                                ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
-                            });
-                        for (uint32_t q = 0; q < nd; ++q) {
-                            if (valid && !dup && s_tag[q] == tag) {
-                                bool same = true;
-                                for (uint32_t t = 0; t < m && same; ++t) same = s_mstr[q * m + t] == mimg8[(uint32_t)lane * m + t];
-                                dup = same;
-                            }
-                        }
-                        for (int j = 0; j < kWave - 1; ++j) {
-                            if (!((vmask >> j) & 1ull)) continue;
-                            const uint32_t tj = __builtin_amdgcn_readlane(tag, j);
-                            if (valid && !dup && j < lane && tj == tag) {
-                                bool same = true;
-                                for (uint32_t t = 0; t < m && same; ++t) same = mimg8[(uint32_t)j * m + t] == mimg8[(uint32_t)lane * m + t];
-                                dup = same;
-                            }
-                        }
-                        distinct = valid && !dup;
-                        const uint64_t dm = __ballot(distinct);
-                        if (distinct) {
-                            const uint32_t q = nd + (uint32_t)__popcll(dm & lt_mask);
-                            s_tag[q] = tag;
-                            for (uint32_t t = 0; t < m; ++t) s_mstr[q * m + t] = mimg8[(uint32_t)lane * m + t];
-                        }
-                    } else {
                     if (valid)
                         xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t sd, uint64_t h) {
                             if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
@@ -783,40 +921,33 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
                             dup = same;
                         }
                     }
-                    distinct = valid && !dup;
-                    const uint64_t dm = __ballot(distinct);
-                    if (distinct) {
-                        const uint32_t q = nd + (uint32_t)__popcll(dm & lt_mask);
+                    dmask = __ballot(valid && !dup);
+                    if (valid && !dup) {
+                        const uint32_t q = nd + (uint32_t)__popcll(dmask & lt_mask);
                         s_tag[q] = tag;
                         s_info[q] = info;
                     }
-                    }
                 }
-                const uint64_t dmask = __ballot(distinct);
-                wave_lds_fence();
                 if constexpr (WIDE) {
+                    wave_lds_fence();
                     uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
                     readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
-                } else {
-                    readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
+                } else if (valid && !dup) {
+                    const uint32_t q = nd + (uint32_t)__popcll(dmask & lt_mask);
+                    for (uint32_t sd = 0; sd < n; ++sd) rall[sd * rcap + q] = ridx[sd * kWave + lane];
                 }
                 nd += (uint32_t)__popcll(dmask);
             }
-            wbase += nw;
         }
         if constexpr (!WIDE) {
-            vc.drain(hist, col_word);
             wave_lds_fence();
-            for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane);
         }
+        readid_finish_read<NARROW, WIDE>(vc, hist, col_word, row_out, C, lane);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
 }
 
-
-// Long reads / contigs: the per-read k-mer set does not fit one wave's LDS, so it is built in HBM by a sort
-// (cid_readid_long.hip) and arrives here as, per read, its distinct canonical k-mers (2-bit codes, base 0 most
-// significant) in first-occurrence order.  Same search, same outputs as k_readid.
 struct BaseReader {  // a key that lives in HBM as a stretch of the read (forward or reverse complement), see k_general_keys
     const uint8_t *b;
     uint32_t len, rc, upper;
@@ -878,8 +1009,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
             if constexpr (WIDE) {
                 uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
                 readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
-            } else {
-                readid_search_chunk<LOG_LPR, NARROW>(p.mat, p.rs, p.w64, n, C, S, ridx, hist, dmask, nd, stopped, vc, R, lane);
+            } else {   // the chunk's entries are dense from lane 0
+                readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, NARROW ? 1u : 2u << LOG_LPR, n, C, S, ridx, (uint32_t)kWave,
+                                                                   (uint32_t)__popcll(dmask), nd, hist, stopped, vc, R, lane);
             }
             nd += (uint32_t)__popcll(dmask);
         }
@@ -1090,30 +1222,52 @@ hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {
 }
 
 template <typename KernelT>
-static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
+static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int waves_per_block, int grid, hipStream_t stream) {
     const size_t shmem = (size_t)waves_per_block * p.wave_bytes;
     if (shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
     }
-    const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves_per_block * kWave), shmem, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
-    if (p.rs > 128) return launch_readid_one(k_readid<0, false, true>, p, waves_per_block, stream);
-    if (p.rs == 1) return launch_readid_one(k_readid<0, true>, p, waves_per_block, stream);
+template <bool MINI>
+static hipError_t launch_readid_packed(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
+    if (p.rs > 128) return launch_readid_one(k_readid<0, false, true, MINI>, p, wpb, grid, stream);
+    if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, MINI>, p, wpb, grid, stream);
     switch (log2u(p.rs / 2)) {
-    case 0: return launch_readid_one(k_readid<0, false>, p, waves_per_block, stream);
-    case 1: return launch_readid_one(k_readid<1, false>, p, waves_per_block, stream);
-    case 2: return launch_readid_one(k_readid<2, false>, p, waves_per_block, stream);
-    case 3: return launch_readid_one(k_readid<3, false>, p, waves_per_block, stream);
-    case 4: return launch_readid_one(k_readid<4, false>, p, waves_per_block, stream);
-    case 5: return launch_readid_one(k_readid<5, false>, p, waves_per_block, stream);
-    case 6: return launch_readid_one(k_readid<6, false>, p, waves_per_block, stream);
+    case 0: return launch_readid_one(k_readid<0, false, false, MINI>, p, wpb, grid, stream);
+    case 1: return launch_readid_one(k_readid<1, false, false, MINI>, p, wpb, grid, stream);
+    case 2: return launch_readid_one(k_readid<2, false, false, MINI>, p, wpb, grid, stream);
+    case 3: return launch_readid_one(k_readid<3, false, false, MINI>, p, wpb, grid, stream);
+    case 4: return launch_readid_one(k_readid<4, false, false, MINI>, p, wpb, grid, stream);
+    case 5: return launch_readid_one(k_readid<5, false, false, MINI>, p, wpb, grid, stream);
+    case 6: return launch_readid_one(k_readid<6, false, false, MINI>, p, wpb, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// k <= 32, no lower-case base: one block per p.reads_per_block reads
+hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
+    const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
+    return p.m_size ? launch_readid_packed<true>(p, waves_per_block, grid, stream) : launch_readid_packed<false>(p, waves_per_block, grid, stream);
+}
+
+// byte-string keys: the reads listed in p.redo_list (count on the device), or all of them
+hipError_t launch_readid_bytes(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
+    if (p.rs > 128) return launch_readid_one(k_readid_bytes<0, false, true>, p, wpb, grid, stream);
+    if (p.rs == 1) return launch_readid_one(k_readid_bytes<0, true, false>, p, wpb, grid, stream);
+    switch (log2u(p.rs / 2)) {
+    case 0: return launch_readid_one(k_readid_bytes<0, false, false>, p, wpb, grid, stream);
+    case 1: return launch_readid_one(k_readid_bytes<1, false, false>, p, wpb, grid, stream);
+    case 2: return launch_readid_one(k_readid_bytes<2, false, false>, p, wpb, grid, stream);
+    case 3: return launch_readid_one(k_readid_bytes<3, false, false>, p, wpb, grid, stream);
+    case 4: return launch_readid_one(k_readid_bytes<4, false, false>, p, wpb, grid, stream);
+    case 5: return launch_readid_one(k_readid_bytes<5, false, false>, p, wpb, grid, stream);
+    case 6: return launch_readid_one(k_readid_bytes<6, false, false>, p, wpb, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -75,6 +75,8 @@ struct ReadIdParams {
     uint32_t *n_kmers;          // [n_reads]
     uint8_t *status;            // [n_reads]
     const uint8_t *skip;        // NULL, or [n_reads]: non-zero = this read belongs to the sort-based path (k_readid_list), leave it alone
+    uint32_t *redo_count;       // k_readid appends the reads it cannot pack (lower-case bases) to redo_list; k_readid_bytes
+    uint32_t *redo_list;        //   works through that list (redo_list == NULL: through all reads, k > 32)
 };
 
 struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in first-occurrence order
@@ -96,6 +98,7 @@ struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in
 size_t search_smem_bytes(const SearchParams &p);
 hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream);
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream);
+hipError_t launch_readid_bytes(const ReadIdParams &p, int waves_per_block, int grid, hipStream_t stream);
 hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
                                   uint32_t n_colors_total, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour,
                                   hipStream_t stream);
