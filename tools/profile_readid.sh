@@ -10,7 +10,7 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $O/pmc_sq2 -- $B --steps 2 > $O/pmc_sq2.log 2>&1
 for d in pmc_rdreq pmc_write pmc_sq pmc_sq2; do
   f=$(find $O/$d -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && (head -1 $f; grep "k_readid" $f) > $O/$d.csv && rm -rf $O/$d
+  [ -n "$f" ] && (head -1 $f; grep "k_readid<" $f) > $O/$d.csv && rm -rf $O/$d
 done
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv
 rm -rf $O/stats

@@ -9,7 +9,7 @@ with open(os.path.join(dst, f"{tag}_readid_kernel_stats.csv"), "w", newline="") 
     w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader()
     for r in rows[:10]:
         r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
-ks = next(r for r in rows if "k_readid" in r["Name"]); avg_ns = float(ks["AverageNs"])
+ks = next(r for r in rows if "k_readid<" in r["Name"]); avg_ns = float(ks["AverageNs"])
 mean, allrows, hdr = {}, [], None
 acc = collections.defaultdict(list)
 for name in ("pmc_rdreq", "pmc_write", "pmc_sq", "pmc_sq2"):
