@@ -1,424 +1,8 @@
-// BIGSI query kernels for MI355X (gfx950).  Hand-written HIP; wave64; HBM-bound bitwise work.
-//
-// Data layout in HBM: the index is a dense row-major bit matrix, row r = the colour bit-vector of Bloom
-// position r, `rs` u64 words per row: rs = 1, or a power of two 2..128 (16 B .. 1 KiB per row, so that a row never
-// straddles a 128-byte line it does not fill), or — beyond 8192 colours, "wide" rows — a multiple of 128 words.
-// Absent rows of the reference's sparse map are all-zero rows here.
-//
-// Work decomposition (search kernels): one wave owns a tile of 64 k-mers at a time; a block owns a contiguous
-// range of tiles (dynamic balance over the CUs, no cross-workgroup communication except the final atomics).
-//   1. the tile's 64*k bytes are copied HBM -> LDS with aligned 16-byte loads (wave-private image) — or, when the
-//      k-mers arrive as 2-bit codes, one u64 per lane is read and re-expanded to ASCII in registers;
-//   2. lane l hashes k-mer l with seeds 0..n-1 (XXH3-64), reduces mod bloom_size and parks the n row numbers in
-//      LDS ("hash rows");
-//   3. the wave re-maps itself so that LPR = rs/2 adjacent lanes cover one row with 16 bytes each
-//      (LPR = 1 and 8 bytes for rs = 1; wide rows: the whole wave, in rs/128 steps): every row costs exactly one
-//      coalesced request per 128-byte line, all n loads of a k-mer are issued back-to-back, then ANDed in registers;
-//   4. kernel-specific epilogue on the AND words.
-// read_id kernels: one wave per read(-pair); see k_readid / k_readid_list.
-#include "cid_kernels.hpp"
+// read_id kernels for MI355X (gfx950): one wave per read(-pair) — a6/a7/a9/a10 of SURVEY.md §8
+// (read_id_mt_pe.rs:66-165, 282-363; kmer.rs:221-243, 363-394).  Index layout and gather scheme: see cid_search.hip.
+#include "cid_gather.hpp"
 
 namespace cid {
-
-// ------------------------------------------------------------------------------------------------
-// gather + AND of one k-mer's n rows, this lane's 16-byte (or 8-byte) column slice
-
-struct V16 { uint64_t x, y; };
-
-template <bool NARROW>
-__device__ __forceinline__ V16 load_slice(const uint64_t *p) {
-    if constexpr (NARROW) {
-        return V16{*p, ~0ull};
-    } else {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
-        return V16{v.x, v.y};
-    }
-}
-
-// ridx: this wave's row numbers, ridx[s*64 + kmer_in_tile].  ZERO_DETECT also reports whether any of the
-// n slices was all-zero in this lane (the caller ANDs those masks across the row's lanes).
-template <int NH, bool NARROW, bool ZERO_DETECT>
-__device__ __forceinline__ V16 gather_and_fixed(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, int kk,
-                                                uint32_t col_word, uint32_t s0, uint32_t &zero_mask) {
-    V16 v[NH];
-#pragma unroll
-    for (int s = 0; s < NH; ++s) {
-        const uint64_t row = ridx[(s0 + s) * kWave + kk];
-        v[s] = load_slice<NARROW>(mat + row * rs + col_word);
-    }
-    V16 a{~0ull, ~0ull};
-#pragma unroll
-    for (int s = 0; s < NH; ++s) {
-        if constexpr (ZERO_DETECT) {
-            const uint64_t o = NARROW ? v[s].x : (v[s].x | v[s].y);
-            zero_mask |= (o == 0) ? (1u << (s0 + s)) : 0u;
-        }
-        a.x &= v[s].x;
-        a.y &= v[s].y;
-    }
-    return a;
-}
-
-template <bool NARROW, bool ZERO_DETECT>
-__device__ __forceinline__ V16 gather_and(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, int kk,
-                                          uint32_t col_word, uint32_t n, uint32_t &zero_mask) {
-    zero_mask = 0;
-    switch (n) {  // n is wave-uniform; the common sizes are fully unrolled so all loads are in flight together
-    case 1: return gather_and_fixed<1, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
-    case 2: return gather_and_fixed<2, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
-    case 3: return gather_and_fixed<3, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
-    case 4: return gather_and_fixed<4, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, 0, zero_mask);
-    default: break;
-    }
-    V16 a{~0ull, ~0ull};
-    uint32_t s = 0;
-    for (; s + 4 <= n; s += 4) {
-        const V16 b = gather_and_fixed<4, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, s, zero_mask);
-        a.x &= b.x; a.y &= b.y;
-    }
-    for (; s < n; ++s) {
-        const V16 b = gather_and_fixed<1, NARROW, ZERO_DETECT>(mat, rs, ridx, kk, col_word, s, zero_mask);
-        a.x &= b.x; a.y &= b.y;
-    }
-    return a;
-}
-
-// Sum over the LPR adjacent lanes that share a row (LPR is a power of two <= 64).
-template <int LOG_LPR>
-__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < (1 << LOG_LPR); o <<= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
-
-// Per-colour counting without one atomic per hit: every lane keeps, for its own 128 (or 64) colour bits,
-// PLANES bit-sliced binary counters (plane j = bit j of each colour's count).  Adding an AND word is a ripple
-// carry over the planes (pure VALU, independent of how many colours are set); after 2^PLANES-1 additions
-// the counters are drained into the block's LDS histogram with one atomic per colour seen since the last drain.
-template <int PLANES, bool NARROW>
-struct VCount {
-    V16 pl[PLANES];
-    uint32_t adds;
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int j = 0; j < PLANES; ++j) pl[j] = V16{0, 0};
-        adds = 0;
-    }
-    __device__ __forceinline__ void add(V16 a) {
-#pragma unroll
-        for (int j = 0; j < PLANES; ++j) {
-            const V16 t{pl[j].x & a.x, NARROW ? 0ull : (pl[j].y & a.y)};
-            pl[j].x ^= a.x;
-            if constexpr (!NARROW) pl[j].y ^= a.y;
-            a = t;
-        }
-        ++adds;  // wave-uniform
-    }
-    __device__ __forceinline__ bool full() const { return adds == (1u << PLANES) - 1u; }
-    __device__ __forceinline__ void drain_word(uint32_t *hist, uint32_t base, bool hi) {
-        uint64_t any = 0;
-#pragma unroll
-        for (int j = 0; j < PLANES; ++j) any |= hi ? pl[j].y : pl[j].x;
-        while (any) {
-            const uint32_t b = (uint32_t)__builtin_ctzll(any);
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int j = 0; j < PLANES; ++j) cnt |= (uint32_t)(((hi ? pl[j].y : pl[j].x) >> b) & 1ull) << j;
-            atomicAdd(&hist[base + b], cnt);
-            any &= any - 1;
-        }
-    }
-    __device__ __forceinline__ void drain(uint32_t *hist, uint32_t col_word) {
-        drain_word(hist, col_word * 64u, false);
-        if constexpr (!NARROW) drain_word(hist, col_word * 64u + 64u, true);
-        clear();
-    }
-};
-
-// Steps 1+2 of the header comment for one tile.  Returns nothing; fills ridx[s*64 + lane].
-__device__ __forceinline__ void stage_and_hash(uint32_t *img, uint32_t *ridx, const uint8_t *kmers, const uint64_t *codes,
-                                               uint64_t n_kmers, uint64_t first, uint32_t k, uint32_t n, const ModMagic &mm,
-                                               int lane) {
-    wave_lds_fence();  // previous tile's readers are done with img/ridx
-    if (codes) {  // packed input: 8 bytes per k-mer, ASCII re-expanded in registers (no LDS image)
-        if (first + lane < n_kmers) {
-            const uint64_t lsb = rev_fields(codes[first + lane], k);
-            xxh3_seeds_from(CodeReader{lsb}, k, n, [&](uint32_t s, uint64_t h) { ridx[s * kWave + lane] = (uint32_t)mod_m(h, mm); });
-        } else {
-            for (uint32_t s = 0; s < n; ++s) ridx[s * kWave + lane] = 0;
-        }
-        wave_lds_fence();
-        return;
-    }
-    stage_kmers(img, kmers, n_kmers, first, k, lane);
-    wave_lds_fence();
-    if (first + lane < n_kmers) {
-        xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t s, uint64_t h) {
-            ridx[s * kWave + lane] = (uint32_t)mod_m(h, mm);
-        });
-    } else {
-        for (uint32_t s = 0; s < n; ++s) ridx[s * kWave + lane] = 0;
-    }
-    wave_lds_fence();
-}
-
-// ------------------------------------------------------------------------------------------------
-// a5: proportional search  (src/batch_search_pe.rs:45-84, :125-164)
-
-template <int LOG_LPR, bool NARROW>
-__global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    constexpr int LPR = 1 << LOG_LPR;
-    constexpr int KPW = kWave / LPR;  // k-mers per sub-pass
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const uint32_t C = p.n_colors;
-
-    uint64_t *s_sum = reinterpret_cast<uint64_t *>(smem);                    // [C] sum of freq of unique hits
-    uint32_t *s_hits = reinterpret_cast<uint32_t *>(smem + 8ull * p.c_pad);  // [C]
-    uint32_t *s_nu = s_hits + p.c_pad;                                       // [C]
-    uint8_t *wbase = smem + 16ull * p.c_pad + (size_t)wave * p.wave_bytes;
-    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
-    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
-
-    for (uint32_t c = threadIdx.x; c < p.c_pad; c += blockDim.x) { s_sum[c] = 0; s_hits[c] = 0; s_nu[c] = 0; }
-    __syncthreads();
-
-    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
-    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
-    const uint32_t col = lane & (LPR - 1);
-    const uint32_t col_word = NARROW ? 0u : 2u * col;
-    const bool col_live = col_word < p.w64;  // lanes past the row's real width neither load nor count
-
-    VCount<kPlanes, NARROW> vc;
-    vc.clear();
-    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
-        const uint64_t first = tile * kWave;
-        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
-#pragma unroll 1
-        for (int sub = 0; sub < LPR; ++sub) {
-            const int kk = sub * KPW + (lane >> LOG_LPR);
-            const uint64_t kmer = first + kk;
-            const bool live = kmer < p.n_kmers;
-            V16 a{0, 0};
-            uint32_t zm;
-            if (live && col_live) a = gather_and<NARROW, false>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
-            if constexpr (NARROW) a.y = 0;
-            const uint32_t pc = (uint32_t)(__popcll(a.x) + __popcll(a.y));
-            const uint32_t total = group_sum<LOG_LPR>(pc);
-            vc.add(a);  // hits[c] += bit c, for this lane's colours
-            if (vc.full()) vc.drain(s_hits, col_word);
-            if (p.pop_total) {  // striped: uniqueness is decided after all stripes (k_unique_finalize)
-                if (live) {
-                    if (col == 0) p.pop_total[kmer] += total;
-                    if (total == 1u && pc == 1u)
-                        p.cand[kmer] = p.colour_base + (a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
-                                                            : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y));
-                }
-            } else if (p.want_unique && live) {
-                if (total == 1u) {
-                    if (pc == 1u) {
-                        const uint32_t c = a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
-                                               : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y);
-                        atomicAdd(&s_nu[c], 1u);
-                        atomicAdd(reinterpret_cast<unsigned long long *>(&s_sum[c]),
-                                  (unsigned long long)(p.freq ? p.freq[kmer] : 1u));
-                        if (p.unique_colour) p.unique_colour[kmer] = c;
-                    }
-                } else if (col == 0 && p.unique_colour) {
-                    p.unique_colour[kmer] = 0xFFFFFFFFu;
-                }
-            }
-        }
-    }
-    vc.drain(s_hits, col_word);
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < C; c += blockDim.x) {
-        const uint32_t h = s_hits[c];
-        if (h) atomicAdd(reinterpret_cast<unsigned long long *>(&p.hits[c]), (unsigned long long)h);
-        if (p.want_unique) {
-            const uint32_t u = s_nu[c];
-            if (u) {
-                if (p.n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&p.n_unique[c]), (unsigned long long)u);
-                if (p.sum_unique_freq)
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&p.sum_unique_freq[c]), (unsigned long long)s_sum[c]);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// a4: perfect search  (src/perfect_search.rs:25-52): AND over every row of every k-mer
-
-template <int LOG_LPR, bool NARROW>
-__global__ __launch_bounds__(kBlock) void k_search_perfect(SearchParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    constexpr int LPR = 1 << LOG_LPR;
-    constexpr int KPW = kWave / LPR;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-
-    uint64_t *s_and = reinterpret_cast<uint64_t *>(smem);  // [rs] block-level AND
-    uint8_t *wbase = smem + 16ull * p.c_pad + (size_t)wave * p.wave_bytes;
-    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
-    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
-
-    for (uint32_t c = threadIdx.x; c < p.rs; c += blockDim.x) s_and[c] = ~0ull;
-    __syncthreads();
-
-    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
-    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
-    const uint32_t col = lane & (LPR - 1);
-    const uint32_t col_word = NARROW ? 0u : 2u * col;
-    const bool col_live = col_word < p.w64;
-
-    V16 acc{~0ull, ~0ull};
-    uint32_t missing = 0;
-    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
-        const uint64_t first = tile * kWave;
-        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
-#pragma unroll 1
-        for (int sub = 0; sub < LPR; ++sub) {
-            const int kk = sub * KPW + (lane >> LOG_LPR);
-            const bool live = first + kk < p.n_kmers;
-            uint32_t zm = 0;
-            if (live && col_live) {
-                const V16 a = gather_and<NARROW, true>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
-                acc.x &= a.x; acc.y &= a.y;
-            } else {
-                zm = ~0u;  // a dead lane holds no bits of any row
-            }
-            // a row is absent (== all-zero) iff every live lane of its group saw a zero slice for that seed
-            uint32_t all_zero = zm;
-#pragma unroll
-            for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
-            const uint32_t seeds = p.n_hash >= 32 ? ~0u : ((1u << p.n_hash) - 1u);
-            if (p.zero_acc) {  // striped: a row is absent only if it is zero in every stripe
-                if (live && col == 0) p.zero_acc[first + kk] &= (all_zero & seeds);
-            } else if (live && (all_zero & seeds)) missing = 1;
-        }
-    }
-    // lanes with the same column slice -> one value per slice per wave
-#pragma unroll
-    for (int o = LPR; o < kWave; o <<= 1) {
-        acc.x &= __shfl_xor(acc.x, o, kWave);
-        acc.y &= __shfl_xor(acc.y, o, kWave);
-    }
-    if (lane < LPR && col_live) {
-        atomicAnd(reinterpret_cast<unsigned long long *>(&s_and[col_word]), (unsigned long long)acc.x);
-        if (!NARROW) atomicAnd(reinterpret_cast<unsigned long long *>(&s_and[col_word + 1]), (unsigned long long)acc.y);
-    }
-    if (__any(missing) && lane == 0) atomicOr(p.missing, 1);
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < p.w64; c += blockDim.x)
-        atomicAnd(reinterpret_cast<unsigned long long *>(&p.and_words[c]), (unsigned long long)s_and[c]);
-}
-
-
-
-// ------------------------------------------------------------------------------------------------
-// Wide rows (more than 8192 colours; rs = a multiple of 128 words): a whole wave covers one row, 1 KiB per step, one
-// k-mer at a time.  These kernels stream KiBs per k-mer, so per-colour results go straight to global atomics.
-
-__device__ __forceinline__ uint32_t wave_and_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) v &= __shfl_xor(v, o, kWave);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
-
-__global__ __launch_bounds__(kBlock) void k_search_count_wide(SearchParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    uint8_t *wbase = smem + (size_t)wave * p.wave_bytes;
-    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
-    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
-    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
-    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
-    const uint32_t steps = p.rs / 128u;
-    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
-        const uint64_t first = tile * kWave;
-        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
-        const uint32_t cnt = p.n_kmers - first < (uint64_t)kWave ? (uint32_t)(p.n_kmers - first) : (uint32_t)kWave;
-        for (uint32_t kk = 0; kk < cnt; ++kk) {
-            const uint64_t kmer = first + kk;
-            uint32_t mine = 0, ucol = 0;
-            for (uint32_t j = 0; j < steps; ++j) {
-                const uint32_t col_word = 128u * j + 2u * lane;
-                if (col_word >= p.w64) continue;
-                uint32_t zm;
-                const V16 a = gather_and<false, false>(p.mat, p.rs, ridx, (int)kk, col_word, p.n_hash, zm);
-                const uint32_t pc = (uint32_t)(__popcll(a.x) + __popcll(a.y));
-                if (!pc) continue;
-                mine += pc;
-                ucol = a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x) : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y);
-                uint64_t w = a.x;
-                while (w) { atomicAdd(reinterpret_cast<unsigned long long *>(&p.hits[col_word * 64u + (uint32_t)__builtin_ctzll(w)]), 1ull); w &= w - 1; }
-                w = a.y;
-                while (w) { atomicAdd(reinterpret_cast<unsigned long long *>(&p.hits[col_word * 64u + 64u + (uint32_t)__builtin_ctzll(w)]), 1ull); w &= w - 1; }
-            }
-            if (p.want_unique) {
-                const uint32_t total = wave_sum_u32(mine);
-                if (total == 1u) {
-                    if (mine == 1u) {
-                        if (p.n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&p.n_unique[ucol]), 1ull);
-                        if (p.sum_unique_freq)
-                            atomicAdd(reinterpret_cast<unsigned long long *>(&p.sum_unique_freq[ucol]), (unsigned long long)(p.freq ? p.freq[kmer] : 1u));
-                        if (p.unique_colour) p.unique_colour[kmer] = ucol;
-                    }
-                } else if (lane == 0 && p.unique_colour) {
-                    p.unique_colour[kmer] = 0xFFFFFFFFu;
-                }
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_search_perfect_wide(SearchParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    uint8_t *wbase = smem + (size_t)wave * p.wave_bytes;
-    uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
-    uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
-    uint64_t *s_and = reinterpret_cast<uint64_t *>(wbase + ((kmer_img_bytes(p.k) + 4u * kWave * p.n_hash + 15u) & ~15u));  // [rs] per wave
-    for (uint32_t w = lane; w < p.rs; w += kWave) s_and[w] = ~0ull;
-    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
-    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
-    const uint32_t steps = p.rs / 128u;
-    const uint32_t seeds = p.n_hash >= 32 ? ~0u : ((1u << p.n_hash) - 1u);
-    uint32_t missing = 0;
-    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
-        const uint64_t first = tile * kWave;
-        stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
-        const uint32_t cnt = p.n_kmers - first < (uint64_t)kWave ? (uint32_t)(p.n_kmers - first) : (uint32_t)kWave;
-        for (uint32_t kk = 0; kk < cnt; ++kk) {
-            uint32_t zml = ~0u;
-            for (uint32_t j = 0; j < steps; ++j) {
-                const uint32_t col_word = 128u * j + 2u * lane;
-                if (col_word >= p.w64) continue;
-                uint32_t zm;
-                const V16 a = gather_and<false, true>(p.mat, p.rs, ridx, (int)kk, col_word, p.n_hash, zm);
-                s_and[col_word] &= a.x;       // lane-owned words: plain read-modify-write
-                s_and[col_word + 1] &= a.y;
-                zml &= zm;
-            }
-            if (wave_and_u32(zml) & seeds) missing = 1;   // a row is absent iff it is zero in every step of every lane
-        }
-    }
-    wave_lds_fence();
-    for (uint32_t w = lane; w < p.w64; w += kWave) atomicAnd(reinterpret_cast<unsigned long long *>(&p.and_words[w]), (unsigned long long)s_and[w]);
-    if (missing && lane == 0) atomicOr(p.missing, 1);
-}
 
 // read_id over wide rows: the chunk's distinct k-mers one at a time, in order; counts go straight to the (pre-zeroed)
 // report row.  s_words / s_R: rs u64 words each per wave (the AND word of the current k-mer, the colours of the first S).
@@ -471,51 +55,6 @@ __device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, ui
 //            64-bit code (exact), and the hash inputs are re-expanded to ASCII in registers;
 //   bytes  : anything else (lower-case bases are hashed as they are; k > 32) — byte strings in
 //            LDS, 32-bit tag match confirmed on the bytes.
-
-__device__ __forceinline__ bool good_base(uint32_t b) {  // src/seq.rs:59-64
-    const uint32_t u = b & 0xDFu;
-    return u == 'A' || u == 'C' || u == 'G' || u == 'T';
-}
-__device__ __forceinline__ uint32_t comp_base(uint32_t b) {  // src/kmer.rs:847-863 restricted to ACGTacgt
-    const uint32_t low = b & 0x1Fu;
-    return b ^ ((low == 1u || low == 0x14u) ? 0x15u : 0x04u);
-}
-// byte t of the canonical string of the window described by info = pos | rc << 31
-__device__ __forceinline__ uint32_t canon_byte(const uint8_t *bases, uint32_t info, uint32_t k, uint32_t t) {
-    const uint32_t pos = info & 0x7FFFFFFFu;
-    return (info >> 31) ? comp_base(bases[pos + k - 1 - t]) : (uint32_t)bases[pos + t];
-}
-// find_minimizer (src/kmer.rs:971-986) on a k-byte canonical string `seq` in LDS, byte-wise and case-sensitive as the
-// reference compares; candidate = (start i, reverse-complement flag): byte t is seq[i+t] or comp(seq[i+m-1-t]).
-__device__ __forceinline__ uint32_t mini_byte(const uint8_t *seq, uint32_t cand, uint32_t m, uint32_t t) {
-    const uint32_t i = cand & 0xFFFFu;
-    return (cand >> 16) ? comp_base(seq[i + m - 1 - t]) : (uint32_t)seq[i + t];
-}
-__device__ __forceinline__ bool mini_less(const uint8_t *seq, uint32_t a, uint32_t b, uint32_t m) {
-    for (uint32_t t = 0; t < m; ++t) {
-        const uint32_t x = mini_byte(seq, a, m, t), y = mini_byte(seq, b, m, t);
-        if (x != y) return x < y;
-    }
-    return false;
-}
-__device__ __forceinline__ uint32_t find_minimizer_bytes(const uint8_t *seq, uint32_t k, uint32_t m) {
-    uint32_t best = 0;  // &seq[..m]: position 0, forward only
-    for (uint32_t i = 1; i + m <= k; ++i) {
-        if (mini_less(seq, i, best, m)) best = i;
-        if (mini_less(seq, i | (1u << 16), best, m)) best = i | (1u << 16);
-    }
-    return best;
-}
-__device__ __forceinline__ uint8_t upper_base(uint32_t b) { return (uint8_t)((b >= 'a' && b <= 'z') ? b - 32u : b); }
-
-// `nbits` (<= 64) bits starting at bit `bit` of a little-endian dword array (readable 2 dwords past the end)
-__device__ __forceinline__ uint64_t bits_at(const uint32_t *w, uint32_t bit, uint32_t nbits) {
-    const uint32_t i = bit >> 5, sh = bit & 31u;
-    const uint64_t lo = ((uint64_t)w[i + 1] << 32) | w[i];
-    uint64_t v = lo >> sh;
-    if (sh) v |= (uint64_t)w[i + 2] << (64u - sh);
-    return nbits >= 64 ? v : (v & ((1ull << nbits) - 1ull));
-}
 
 constexpr int kReadRunUnroll = 2;   // sub-passes of a read's search whose row loads are in flight together
 constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained every 7 additions
@@ -1024,202 +563,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
     }
 }
 
-// Striped a5 epilogue: a k-mer hits exactly one colour of the WHOLE index iff the stripes' popcounts sum to 1.
-// Per-block LDS histograms (when the whole colour range fits) keep the global atomics to one per colour per block.
-__global__ __launch_bounds__(256) void k_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq,
-                                                        uint64_t n_kmers, uint32_t n_colors_total, uint32_t use_lds, uint64_t per_block,
-                                                        uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    unsigned long long *s_sum = reinterpret_cast<unsigned long long *>(smem);
-    uint32_t *s_nu = reinterpret_cast<uint32_t *>(smem + 8ull * n_colors_total);
-    if (use_lds) {
-        for (uint32_t c = threadIdx.x; c < n_colors_total; c += blockDim.x) { s_sum[c] = 0; s_nu[c] = 0; }
-        __syncthreads();
-    }
-    const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
-    const uint64_t i1 = i0 + per_block < n_kmers ? i0 + per_block : n_kmers;
-    for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        if (pop_total[i] == 1u) {
-            const uint32_t c = cand[i];
-            const unsigned long long f = freq ? freq[i] : 1u;
-            if (unique_colour) unique_colour[i] = c;
-            if (use_lds) {
-                atomicAdd(&s_nu[c], 1u);
-                atomicAdd(&s_sum[c], f);
-            } else {
-                if (n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&n_unique[c]), 1ull);
-                if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), f);
-            }
-        } else if (unique_colour) {
-            unique_colour[i] = 0xFFFFFFFFu;
-        }
-    }
-    if (use_lds) {
-        __syncthreads();
-        for (uint32_t c = threadIdx.x; c < n_colors_total; c += blockDim.x) {
-            const uint32_t u = s_nu[c];
-            if (!u) continue;
-            if (n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&n_unique[c]), (unsigned long long)u);
-            if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), s_sum[c]);
-        }
-    }
-}
-
-hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
-                                  uint32_t n_colors_total, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour,
-                                  hipStream_t stream) {
-    if (n_kmers == 0) return hipSuccess;
-    const size_t lds = 12ull * n_colors_total;
-    const uint32_t use_lds = lds <= 96u * 1024u ? 1u : 0u;
-    const size_t shmem = use_lds ? lds : 0;
-    if (shmem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_unique_finalize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-    }
-    uint64_t per_block = (n_kmers + 4095) / 4096;
-    if (per_block < 4096) per_block = 4096;
-    const unsigned grid = (unsigned)((n_kmers + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_unique_finalize, dim3(grid), dim3(256), shmem, stream, pop_total, cand, freq, n_kmers, n_colors_total, use_lds, per_block,
-                       n_unique, sum_unique_freq, unique_colour);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// index maintenance
-
-// .bxi rows -> dense matrix (src/bigsi.rs:59-63 feeds this): one thread per (row, u32 word)
-__global__ void k_put_rows(uint32_t *mat32, uint32_t rs, const uint64_t *row_ids, const uint32_t *words, uint32_t w32,
-                           uint64_t n_rows) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * w32) return;
-    const uint64_t r = i / w32, w = i % w32;
-    mat32[row_ids[r] * (2ull * rs) + w] = words[i];
-}
-
-__global__ void k_get_rows(const uint32_t *mat32, uint32_t rs, const uint64_t *row_ids, uint32_t *words, uint32_t w32,
-                           uint64_t n_rows) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * w32) return;
-    const uint64_t r = i / w32, w = i % w32;
-    words[i] = mat32[row_ids[r] * (2ull * rs) + w];
-}
-
-// Bloom insert (src/simple_bloom.rs:19-26) straight into the transposed matrix (src/build.rs:116-128)
-__global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    uint32_t *img = reinterpret_cast<uint32_t *>(smem + (size_t)wave * kmer_img_bytes(p.k));
-    const uint64_t n_tiles = (p.n_kmers + kWave - 1) / kWave;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * p.tiles_per_block;
-    const uint64_t tile1 = tile0 + p.tiles_per_block < n_tiles ? tile0 + p.tiles_per_block : n_tiles;
-    unsigned int *mat32 = reinterpret_cast<unsigned int *>(p.mat);
-    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
-        const uint64_t first = tile * kWave;
-        auto set_bit = [&](uint32_t c, uint64_t h) {
-            const uint64_t row = mod_m(h, p.mod);
-            atomicOr(&mat32[row * (2ull * p.rs) + (c >> 5)], 1u << (c & 31u));
-        };
-        if (p.codes) {
-            if (first + lane < p.n_kmers) {
-                const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-                uint64_t code = p.codes[first + lane];
-                uint32_t klen = p.k;
-                if (p.m_size) { code = minimizer_code(code, p.k, p.m_size); klen = p.m_size; }
-                const uint64_t lsb = rev_fields(code, klen);
-                if (c < p.n_colors) xxh3_seeds_from(CodeReader{lsb}, klen, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
-            }
-            continue;
-        }
-        wave_lds_fence();
-        stage_kmers(img, p.kmers, p.n_kmers, first, p.k, lane);
-        wave_lds_fence();
-        if (p.m_size) {  // ASCII k-mers into a minimizer index: byte-wise find_minimizer, then hash its m_size bytes
-            uint32_t *mimg = reinterpret_cast<uint32_t *>(smem + (size_t)(kBlock / kWave) * kmer_img_bytes(p.k) + (size_t)wave * kmer_img_bytes(p.m_size));
-            uint8_t *mimg8 = reinterpret_cast<uint8_t *>(mimg);
-            const bool have = first + lane < p.n_kmers;
-            if (have) {
-                const uint8_t *seq = reinterpret_cast<const uint8_t *>(img) + (uint32_t)lane * p.k;
-                const uint32_t cand = find_minimizer_bytes(seq, p.k, p.m_size);
-                for (uint32_t t = 0; t < p.m_size; ++t) mimg8[(uint32_t)lane * p.m_size + t] = mini_byte(seq, cand, p.m_size, t);
-            }
-            wave_lds_fence();
-            if (have) {
-                const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-                if (c < p.n_colors) xxh3_seeds(mimg, (uint32_t)lane * p.m_size, p.m_size, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
-            }
-            continue;
-        }
-        if (first + lane < p.n_kmers) {
-            const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-            if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, [&](uint32_t, uint64_t h) { set_bit(c, h); });
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // launchers
-
-static int log2u(uint32_t v) { int l = 0; while ((1u << l) < v) ++l; return l; }
-
-template <typename KernelT, typename ParamsT>
-static hipError_t launch_one(KernelT kernel, int grid, size_t shmem, hipStream_t stream, const ParamsT &p) {
-    if (shmem > 64 * 1024) {  // up to the CU's 160 KiB of LDS on request
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), shmem, stream, p);
-    return hipGetLastError();
-}
-
-#define CID_LAUNCH_BY_LAYOUT(KERNEL, log_lpr, narrow, grid, shmem, stream, params)           \
-    do {                                                                                     \
-        if (narrow) return launch_one(KERNEL<0, true>, grid, shmem, stream, params);         \
-        switch (log_lpr) {                                                                   \
-        case 0: return launch_one(KERNEL<0, false>, grid, shmem, stream, params);            \
-        case 1: return launch_one(KERNEL<1, false>, grid, shmem, stream, params);            \
-        case 2: return launch_one(KERNEL<2, false>, grid, shmem, stream, params);            \
-        case 3: return launch_one(KERNEL<3, false>, grid, shmem, stream, params);            \
-        case 4: return launch_one(KERNEL<4, false>, grid, shmem, stream, params);            \
-        case 5: return launch_one(KERNEL<5, false>, grid, shmem, stream, params);            \
-        case 6: return launch_one(KERNEL<6, false>, grid, shmem, stream, params);            \
-        default: return hipErrorInvalidValue;                                                \
-        }                                                                                    \
-    } while (0)
-
-size_t search_smem_bytes(const SearchParams &p) { return 16ull * p.c_pad + (size_t)(kBlock / kWave) * p.wave_bytes; }
-
-int grid_for(uint64_t n_kmers, uint32_t tiles_per_block) {
-    const uint64_t n_tiles = (n_kmers + kWave - 1) / kWave;
-    return (int)((n_tiles + tiles_per_block - 1) / tiles_per_block);
-}
-
-hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
-    if (p.rs > 128) {
-        const int g = grid_for(p.n_kmers, p.tiles_per_block);
-        return g ? launch_one(k_search_count_wide, g, (size_t)(kBlock / kWave) * p.wave_bytes, stream, p) : hipSuccess;
-    }
-    const bool narrow = p.rs == 1;
-    const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
-    const size_t shmem = search_smem_bytes(p);
-    const int grid = grid_for(p.n_kmers, p.tiles_per_block);
-    if (grid == 0) return hipSuccess;
-    CID_LAUNCH_BY_LAYOUT(k_search_count, log_lpr, narrow, grid, shmem, stream, p);
-}
-
-hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {
-    if (p.rs > 128) {
-        const int g = grid_for(p.n_kmers, p.tiles_per_block);
-        return g ? launch_one(k_search_perfect_wide, g, (size_t)(kBlock / kWave) * p.wave_bytes, stream, p) : hipSuccess;
-    }
-    const bool narrow = p.rs == 1;
-    const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
-    const size_t shmem = search_smem_bytes(p);
-    const int grid = grid_for(p.n_kmers, p.tiles_per_block);
-    if (grid == 0) return hipSuccess;
-    CID_LAUNCH_BY_LAYOUT(k_search_perfect, log_lpr, narrow, grid, shmem, stream, p);
-}
 
 template <typename KernelT>
 static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int waves_per_block, int grid, hipStream_t stream) {
@@ -1297,32 +642,6 @@ hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t s
     case 6: return launch_readid_list_one(k_readid_list<6, false>, p, grid, stream);
     default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t launch_put_rows(uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, const uint32_t *d_words, uint32_t w32,
-                           uint64_t n_rows, hipStream_t stream) {
-    const uint64_t n = n_rows * w32;
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_put_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<uint32_t *>(mat), rs, d_row_ids, d_words, w32, n_rows);
-    return hipGetLastError();
-}
-
-hipError_t launch_get_rows(const uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, uint32_t *d_words, uint32_t w32,
-                           uint64_t n_rows, hipStream_t stream) {
-    const uint64_t n = n_rows * w32;
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_get_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const uint32_t *>(mat), rs, d_row_ids, d_words, w32, n_rows);
-    return hipGetLastError();
-}
-
-hipError_t launch_insert_kmers(const InsertParams &p, hipStream_t stream) {
-    const size_t shmem = (size_t)(kBlock / kWave) * (kmer_img_bytes(p.k) + (p.m_size ? kmer_img_bytes(p.m_size) : 0));
-    const int grid = grid_for(p.n_kmers, p.tiles_per_block);
-    if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_insert_kmers, dim3(grid), dim3(kBlock), shmem, stream, p);
-    return hipGetLastError();
 }
 
 }  // namespace cid
