@@ -165,7 +165,7 @@ int fill_search_params(const cid_ctx *c, const cid_index *ix, cid::SearchParams 
     p.k = ix->k;
     p.c_pad = (ix->n_colors + 1u) & ~1u;
     if (p.c_pad < 2) p.c_pad = 2;
-    p.wave_bytes = cid::kmer_img_bytes(ix->k) + cid::kWave * ix->n_hash * 4u;
+    p.wave_bytes = cid::kmer_img_bytes(ix->k) + cid::kWave * ix->n_hash * 4u + 2u * cid::kWave * 4u;   // image, hash rows, per-k-mer results of the tile
     p.wave_bytes = (p.wave_bytes + 15u) & ~15u;
     if (ix->rs > 128) {  // wide rows: no block histogram; the perfect search keeps a per-wave AND accumulator of rs words
         p.c_pad = 0;

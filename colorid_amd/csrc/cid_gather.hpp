@@ -68,6 +68,46 @@ __device__ __forceinline__ V16 gather_and(const uint64_t *mat, uint32_t rs, cons
     return a;
 }
 
+// Branch-free variant for several sub-passes at once: k-mer j[u] has its row numbers at ridx[s*stride + j[u]].
+template <int NH, int U, bool NARROW>
+__device__ __forceinline__ void gather_run_fixed(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, uint32_t stride, const uint32_t (&j)[U],
+                                                 const bool (&live)[U], uint32_t col_word, uint32_t s0, V16 (&a)[U], uint32_t (&zm)[U]) {
+    V16 v[U][NH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < NH; ++s) {
+            const uint64_t row = live[u] ? ridx[(s0 + s) * stride + j[u]] : 0u;   // idle lanes read row 0: no branch, an L2 hit
+            v[u][s] = load_slice<NARROW>(mat + row * rs + col_word);
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < NH; ++s) {
+            const uint64_t o = NARROW ? v[u][s].x : (v[u][s].x | v[u][s].y);
+            zm[u] |= (o == 0) ? (1u << (s0 + s)) : 0u;
+            a[u].x &= v[u][s].x;
+            a[u].y &= v[u][s].y;
+        }
+}
+
+// U sub-passes' worth of row loads (U x n per lane) issued before any is consumed; a[u] must start as all-ones, zm[u] as 0.
+template <int U, bool NARROW>
+__device__ __forceinline__ void gather_run(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, uint32_t stride, const uint32_t (&j)[U],
+                                           const bool (&live)[U], uint32_t col_word, uint32_t n, V16 (&a)[U], uint32_t (&zm)[U]) {
+    switch (n) {   // n is wave-uniform; the common sizes are fully unrolled
+    case 1: gather_run_fixed<1, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+    case 2: gather_run_fixed<2, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+    case 3: gather_run_fixed<3, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+    case 4: gather_run_fixed<4, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
+    default: {
+        uint32_t sd = 0;
+        for (; sd + 4 <= n; sd += 4) gather_run_fixed<4, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, sd, a, zm);
+        for (; sd < n; ++sd) gather_run_fixed<1, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, sd, a, zm);
+    }
+    }
+}
+
 // Sum over the LPR adjacent lanes that share a row (LPR is a power of two <= 64).
 template <int LOG_LPR>
 __device__ __forceinline__ uint32_t group_sum(uint32_t v) {

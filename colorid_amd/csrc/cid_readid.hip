@@ -63,28 +63,6 @@ constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained ev
 // The in-order search (read_id_mt_pe.rs:66-102 classic / :104-165 sampled) over a dense run of distinct k-mers: k-mer j (0 <= j < count, order index q_base + j) has its row
 // numbers at ridx[s*stride + j].  U sub-passes (U * 64/LPR k-mers) have all their row loads issued before the first is
 // consumed: a read's search is a chain of dependent gather rounds, and what bounds the kernel is how many of them there are.
-template <int NH, int U, bool NARROW>
-__device__ __forceinline__ void gather_run_fixed(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, uint32_t stride, const uint32_t (&j)[U],
-                                                 const bool (&live)[U], uint32_t col_word, uint32_t s0, V16 (&a)[U], uint32_t (&zm)[U]) {
-    V16 v[U][NH];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int s = 0; s < NH; ++s) {
-            const uint64_t row = live[u] ? ridx[(s0 + s) * stride + j[u]] : 0u;   // idle lanes read row 0: no branch, an L2 hit
-            v[u][s] = load_slice<NARROW>(mat + row * rs + col_word);
-        }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int s = 0; s < NH; ++s) {
-            const uint64_t o = NARROW ? v[u][s].x : (v[u][s].x | v[u][s].y);
-            zm[u] |= (o == 0) ? (1u << (s0 + s)) : 0u;
-            a[u].x &= v[u][s].x;
-            a[u].y &= v[u][s].y;
-        }
-}
-
 template <int LOG_LPR, bool NARROW, int U>
 __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t rs, uint32_t n, uint32_t C, uint32_t S, const uint32_t *ridx,
                                                   uint32_t stride, uint32_t count, uint32_t q_base, uint32_t *hist, bool &stopped,
@@ -108,17 +86,7 @@ __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t 
             a[u] = V16{~0ull, ~0ull};
             zm[u] = 0;
         }
-        switch (n) {   // n is wave-uniform; the common sizes are fully unrolled
-        case 1: gather_run_fixed<1, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
-        case 2: gather_run_fixed<2, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
-        case 3: gather_run_fixed<3, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
-        case 4: gather_run_fixed<4, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, 0, a, zm); break;
-        default: {
-            uint32_t sd = 0;
-            for (; sd + 4 <= n; sd += 4) gather_run_fixed<4, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, sd, a, zm);
-            for (; sd < n; ++sd) gather_run_fixed<1, U, NARROW>(mat, rs, ridx, stride, j, live, col_word, sd, a, zm);
-        }
-        }
+        gather_run<U, NARROW>(mat, rs, ridx, stride, j, live, col_word, n, a, zm);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (j0 + u * KPW >= count) break;   // wave-uniform

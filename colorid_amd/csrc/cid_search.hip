@@ -39,6 +39,10 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
     uint8_t *wbase = smem + 16ull * p.c_pad + (size_t)wave * p.wave_bytes;
     uint32_t *img = reinterpret_cast<uint32_t *>(wbase);
     uint32_t *ridx = reinterpret_cast<uint32_t *>(wbase + kmer_img_bytes(p.k));
+    // Per-k-mer results are parked here and leave once per tile as one coalesced 256-byte store: written straight from the
+    // sub-passes they were 32..128-byte partial-line stores and cost 0.6 ms (C = 256) to 1.9 ms (C = 1024) per 120 M k-mers.
+    uint32_t *s_res = ridx + kWave * p.n_hash;   // [64] unique colour / stripe candidate colour
+    uint32_t *s_pop = s_res + kWave;              // [64] striped: popcount of the stripe's AND word; else the k-mers' multiplicities
 
     for (uint32_t c = threadIdx.x; c < p.c_pad; c += blockDim.x) { s_sum[c] = 0; s_hits[c] = 0; s_nu[c] = 0; }
     __syncthreads();
@@ -54,7 +58,10 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
     vc.clear();
     for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
         const uint64_t first = tile * kWave;
+        // the tile's multiplicities: one coalesced load that is back long before the first sub-pass needs it
+        const uint32_t my_freq = (p.freq && p.want_unique && !p.pop_total && first + lane < p.n_kmers) ? p.freq[first + lane] : 1u;
         stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
+        if (!p.pop_total) { s_pop[lane] = my_freq; wave_lds_fence(); }
 #pragma unroll 1
         for (int sub = 0; sub < LPR; ++sub) {
             const int kk = sub * KPW + (lane >> LOG_LPR);
@@ -70,10 +77,10 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
             if (vc.full()) vc.drain(s_hits, col_word);
             if (p.pop_total) {  // striped: uniqueness is decided after all stripes (k_unique_finalize)
                 if (live) {
-                    if (col == 0) p.pop_total[kmer] += total;
-                    if (total == 1u && pc == 1u)
-                        p.cand[kmer] = p.colour_base + (a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
-                                                            : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y));
+                    if (col == 0) { s_pop[kk] = total; s_res[kk] = 0xFFFFFFFFu; }
+                    if (total == 1u && pc == 1u)   // (after col 0's store in program order: LDS ops of a wave execute in order)
+                        s_res[kk] = p.colour_base + (a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
+                                                         : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y));
                 }
             } else if (p.want_unique && live) {
                 if (total == 1u) {
@@ -81,12 +88,23 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
                         const uint32_t c = a.x ? col_word * 64u + (uint32_t)__builtin_ctzll(a.x)
                                                : col_word * 64u + 64u + (uint32_t)__builtin_ctzll(a.y);
                         atomicAdd(&s_nu[c], 1u);
-                        atomicAdd(reinterpret_cast<unsigned long long *>(&s_sum[c]),
-                                  (unsigned long long)(p.freq ? p.freq[kmer] : 1u));
-                        if (p.unique_colour) p.unique_colour[kmer] = c;
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&s_sum[c]), (unsigned long long)s_pop[kk]);
+                        s_res[kk] = c;
                     }
-                } else if (col == 0 && p.unique_colour) {
-                    p.unique_colour[kmer] = 0xFFFFFFFFu;
+                } else if (col == 0) {
+                    s_res[kk] = 0xFFFFFFFFu;
+                }
+            }
+        }
+        if (p.pop_total || (p.want_unique && p.unique_colour)) {   // the tile's per-k-mer results, one coalesced store
+            wave_lds_fence();
+            const uint64_t kmer = first + lane;
+            if (kmer < p.n_kmers) {
+                if (p.pop_total) {
+                    p.pop_total[kmer] += s_pop[lane];
+                    if (s_res[lane] != 0xFFFFFFFFu) p.cand[kmer] = s_res[lane];
+                } else {
+                    __builtin_nontemporal_store(s_res[lane], &p.unique_colour[kmer]);   // written once, never read here
                 }
             }
         }
