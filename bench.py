@@ -147,6 +147,11 @@ def fill_background(dev, mat_ptr, m, rs, n_colours, p, seed):
 
 def main():
     a = parse_args()
+    # stdout carries exactly one line, the JSON: RCCL prints a version banner to C stdout (late, when that is a pipe), so
+    # everything else this process or its libraries write to fd 1 goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -261,7 +266,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
     if result is not None:
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     hx.close()
     ctx.close()
     if dist.is_initialized():
