@@ -357,6 +357,9 @@ struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
         read_seq0.push_back(seq_off.size() - 1);
     }
     size_t size() const { return ids.size(); }
+    // long reads: a batch also closes once it holds this many bases (the library numbers a batch's k-mer windows in 32 bits;
+    // batch boundaries never change a read's result)
+    bool heavy() const { return bases.size() >= (256u << 20); }
     void clear() { ids.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
 };
 
@@ -485,7 +488,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
             rb.push(id, &seq, 1);
         }
         ++line_count;
-        if (line_count % lines_per_batch == 0) classifier.submit(rb);
+        if (line_count % lines_per_batch == 0 || rb.heavy()) classifier.submit(rb);
     }
     classifier.submit(rb);
     const uint64_t read_count = classifier.finish();
@@ -519,7 +522,7 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
             rb.push(id, seqs, 2);
         }
         ++line_count;
-        if (line_count % lines_per_batch == 0) classifier.submit(rb);
+        if (line_count % lines_per_batch == 0 || rb.heavy()) classifier.submit(rb);
     }
     classifier.submit(rb);
     const uint64_t read_count = classifier.finish();
@@ -558,7 +561,7 @@ void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &f
             sub += l;
         }
         ++count;
-        if (rb.size() > 0 && rb.size() % batch == 0) classifier.submit(rb);
+        if (rb.size() > 0 && (rb.size() % batch == 0 || rb.heavy())) classifier.submit(rb);
     }
     free(lineptr);
     fclose(f);
