@@ -79,6 +79,13 @@ void orc_search_count(const orc_index *, const uint8_t *kmers, const uint64_t *f
 /* the same loop over n_threads POSIX threads (the bench's "best-effort CPU" figure; the reference is single-threaded here) */
 void orc_search_count_mt(const orc_index *, const uint8_t *kmers, const uint64_t *freq, uint64_t n_kmers, int n_threads,
                          uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
+/* the same loop over the reference's data structure: FNV-hashed map row -> bit vector, one heap clone per k-mer (the
+ * bench's "faithful structure" CPU figure) */
+typedef struct orc_sparse orc_sparse;
+orc_sparse *orc_sparse_build(const orc_index *);
+void orc_sparse_free(orc_sparse *);
+void orc_search_count_sparse(const orc_sparse *, const orc_index *, const uint8_t *kmers, const uint64_t *freq, uint64_t n_kmers,
+                             uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq);
 /* perfect_search.rs:25-52: AND of all n*K rows; *missing = 1 iff some row is absent ("No perfect hits!") */
 void orc_search_perfect(const orc_index *, const uint8_t *kmers, uint64_t n_kmers, uint32_t *and_words, int *missing);
 /* read_id_mt_pe.rs:66-102 ; report has C+1 entries, [C] = no_hits_num */

@@ -82,6 +82,9 @@ def lib():
         "orc_read_bigsi": (ip, [C.c_char_p]),
         "orc_search_count": (None, [ip, vp, vp, C.c_uint64, vp, vp, vp, vp]),
         "orc_search_count_mt": (None, [ip, vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp]),
+        "orc_sparse_build": (vp, [ip]),
+        "orc_sparse_free": (None, [vp]),
+        "orc_search_count_sparse": (None, [vp, ip, vp, vp, C.c_uint64, vp, vp, vp]),
         "orc_search_perfect": (None, [ip, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
         "orc_search_index_classic": (None, [ip, vp, C.c_uint64, vp]),
         "orc_search_index": (None, [ip, vp, C.c_uint64, C.c_uint64, vp]),
@@ -301,6 +304,17 @@ class Index:
         lib().orc_search_count_mt(self.p, _ptr(kmers), _ptr(freq64), K, n_threads, _ptr(hits), _ptr(nu), _ptr(sf), _ptr(uc))
         return hits, nu, sf, uc
 
+    def sparse_map(self):
+        """the reference's data structure (FNV-hashed map row -> bit vector) over this index; free with orc.sparse_free"""
+        return lib().orc_sparse_build(self.p)
+
+    def search_count_sparse(self, sparse, kmers: np.ndarray, freq):
+        kmers = np.ascontiguousarray(kmers, np.uint8)
+        freq64 = None if freq is None else np.ascontiguousarray(freq, np.uint64)
+        hits, nu, sf = (np.zeros(self.n_colors, np.uint64) for _ in range(3))
+        lib().orc_search_count_sparse(sparse, self.p, _ptr(kmers), _ptr(freq64), kmers.shape[0], _ptr(hits), _ptr(nu), _ptr(sf))
+        return hits, nu, sf
+
     def search_perfect(self, kmers: np.ndarray):
         kmers = np.ascontiguousarray(kmers, np.uint8)
         words = np.zeros(max(self.w32, 1), np.uint32)
@@ -372,6 +386,10 @@ def minimizer_set(seqs, k, m, d=1):
     for s in seqs:
         lib().orc_minimerize_skip_n_set(km.h, s, len(s), k, d)
     return km
+
+
+def sparse_free(sparse):
+    lib().orc_sparse_free(sparse)
 
 
 def false_prob(m, k, n):

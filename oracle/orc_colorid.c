@@ -612,6 +612,72 @@ void orc_search_count(const orc_index *ix, const uint8_t *kmers, const uint64_t 
     free(first);
 }
 
+/* Faithful-structure variant for the bench's third baseline figure (BASELINE.md §2 mode i): the index as the reference holds
+ * it — a hash map row -> bit vector with the FNV-1a hasher (bigsi.rs:19-27, FnvHashMap<usize, BitVec>) — and one heap
+ * allocation per k-mer for `kmer_slices[0].to_owned()` (batch_search_pe.rs:60).  Same results as orc_search_count. */
+struct orc_sparse { uint64_t cap; uint64_t *keys; uint32_t *vals; };   /* open addressing, linear probing; vals = row number + 1 */
+static inline uint64_t fnv1a_u64(uint64_t x) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int i = 0; i < 8; ++i) { h ^= (x >> (8 * i)) & 0xff; h *= 0x100000001b3ull; }
+    return h;
+}
+orc_sparse *orc_sparse_build(const orc_index *ix) {
+    uint64_t n = 0;
+    for (uint64_t r = 0; r < ix->bloom_size; ++r) n += !row_absent(ix, r);
+    orc_sparse *m = (orc_sparse *)calloc(1, sizeof *m);
+    m->cap = 16;
+    while (m->cap < n * 2) m->cap <<= 1;
+    m->keys = (uint64_t *)malloc(m->cap * sizeof(uint64_t));
+    m->vals = (uint32_t *)calloc(m->cap, sizeof(uint32_t));
+    if (!m->keys || !m->vals) { orc_sparse_free(m); return NULL; }
+    for (uint64_t r = 0; r < ix->bloom_size; ++r) {
+        if (row_absent(ix, r)) continue;
+        uint64_t i = fnv1a_u64(r) & (m->cap - 1);
+        while (m->vals[i]) i = (i + 1) & (m->cap - 1);
+        m->keys[i] = r; m->vals[i] = (uint32_t)(r + 1);
+    }
+    return m;
+}
+void orc_sparse_free(orc_sparse *m) { if (m) { free(m->keys); free(m->vals); free(m); } }
+static inline const uint32_t *sparse_get(const orc_sparse *m, const orc_index *ix, uint64_t r) {   /* bigsi_map.get(&bit_index) */
+    uint64_t i = fnv1a_u64(r) & (m->cap - 1);
+    while (m->vals[i]) {
+        if (m->keys[i] == r) return row_ptr(ix, r);
+        i = (i + 1) & (m->cap - 1);
+    }
+    return NULL;
+}
+void orc_search_count_sparse(const orc_sparse *map, const orc_index *ix, const uint8_t *kmers, const uint64_t *freq, uint64_t n_kmers,
+                             uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq) {
+    const uint64_t C = ix->n_colors, n = ix->num_hash, k = ix->k_size;
+    const size_t wbytes = (ix->w32 ? ix->w32 : 1) * sizeof(uint32_t);
+    memset(hits, 0, C * sizeof(uint64_t));
+    if (n_unique) memset(n_unique, 0, C * sizeof(uint64_t));
+    if (sum_unique_freq) memset(sum_unique_freq, 0, C * sizeof(uint64_t));
+    for (uint64_t j = 0; j < n_kmers; ++j) {
+        const uint8_t *km = kmers + j * k;
+        uint32_t *first = NULL;
+        uint64_t got = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t *row = sparse_get(map, ix, bit_index(ix, km, i));
+            if (!row) break;
+            if (got == 0) { first = (uint32_t *)malloc(wbytes); memcpy(first, row, wbytes); }
+            else for (uint32_t w = 0; w < ix->w32; ++w) first[w] &= row[w];
+            ++got;
+        }
+        if (got == n) {
+            uint64_t nh = 0, last = 0;
+            for (uint64_t c = 0; c < C; ++c)
+                if (bit_get(first, c)) { hits[c] += 1; ++nh; last = c; }
+            if (nh == 1) {
+                if (n_unique) n_unique[last] += 1;
+                if (sum_unique_freq) sum_unique_freq[last] += freq ? freq[j] : 1;
+            }
+        }
+        free(first);
+    }
+}
+
 /* Best-effort CPU variant for the bench's second baseline figure (BASELINE.md §2 mode ii): the same loop, k-mers split
  * over n_threads POSIX threads, per-thread counters summed at the end.  (The reference's `search` is single-threaded.) */
 #include <pthread.h>

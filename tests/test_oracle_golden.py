@@ -341,3 +341,22 @@ def test_mxi_layout_and_roundtrip(orc, tmp_path):  # bigsi.rs:40-49, 71-83: Bigs
     p2 = str(tmp_path / "again.mxi")
     back.save(p2)
     assert open(p2, "rb").read() == raw
+
+
+def test_sparse_structure_variant_equals_dense(orc, phage_index):
+    """the bench's "faithful structure" CPU figure runs the same loop over an FNV-hashed row map: same counts"""
+    seqs = orc.read_fasta(os.path.join(REFS, PHAGES[3] + ".fasta"))
+    km = orc.Kmers(27)
+    for s in seqs:
+        km.kmerize_vector(s, 1)
+    keys = km.keys()[:4000]
+    freq = km.counts()[:4000].astype(np.uint64)
+    rng = np.random.default_rng(2)
+    noise = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (500, 27))]
+    keys = np.concatenate([keys, noise])
+    freq = np.concatenate([freq, np.ones(500, np.uint64)])
+    want = phage_index.search_count(keys, freq)
+    sp = phage_index.sparse_map()
+    got = phage_index.search_count_sparse(sp, keys, freq)
+    orc.sparse_free(sp)
+    assert all(np.array_equal(w, g) for w, g in zip(want[:3], got)) and want[0].sum() >= 4000
