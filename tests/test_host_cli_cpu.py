@@ -157,3 +157,40 @@ def test_bxi_loader_rejects_malformed_files(orc, tmp_path):
     expect_fail(raw[:off + 8] + struct.pack("<Q", 3) + raw[off + 16:], "bad_words.bxi")
     expect_fail(raw[:off + 16 + 8] + struct.pack("<Q", 41) + raw[off + 32:], "bad_nbits.bxi")
     expect_fail(struct.pack("<4Q", 1000, 2, 21, 0) + raw[32:], "no_colours.bxi")
+
+
+def test_line_reader_edge_cases(orc, genomes, tmp_path):
+    """The threaded gz/plain reader keeps BufRead::lines() semantics: CRLF, a last line without a newline, records whose
+    sequence line is longer than the reader's 4 MiB blocks, plain (uncompressed) input, an empty file."""
+    import gzip
+    g = genomes[0]
+    big = (g * 300)[:9_000_000]                                  # one 9 Mbp sequence line: spans three decode blocks
+    recs = [(b"r0", g[:200], b"I" * 200), (b"big", big, b"I" * len(big)), (b"r2", g[300:420], b"I" * 120)]
+
+    def blob(eol, last_newline=True):
+        s = b"".join(b"@" + i + eol + q + eol + b"+" + eol + w + eol for i, q, w in recs)
+        return s if last_newline else s[:-len(eol)]
+
+    want = None
+    for tag, eol, last, gz in (("lf", b"\n", True, True), ("crlf", b"\r\n", True, True), ("nolast", b"\n", False, True), ("plain", b"\n", True, False),
+                               ("crlf_plain_nolast", b"\r\n", False, False)):
+        path = str(tmp_path / (tag + (".fastq.gz" if gz else ".fastq")))
+        data = blob(eol, last)
+        if gz:
+            with gzip.open(path, "wb", compresslevel=1) as f:
+                f.write(data)
+        else:
+            open(path, "wb").write(data)
+        got, _ = parse_kmers(run("debug-kmers", "-q", path, "-k", "27", "--mode", "fq", "-Q", "15")[0])
+        if want is None:
+            km = orc.Kmers(27)
+            for _, seq, qual in recs:
+                km.kmerize_fq_read(seq, qual, 15)
+            want = km.as_dict()
+            assert len(want) > 10_000
+        assert got == want, tag
+    empty = str(tmp_path / "empty.fastq.gz")
+    with gzip.open(empty, "wb") as f:
+        pass
+    got, _ = parse_kmers(run("debug-kmers", "-q", empty, "-k", "27", "--mode", "fq", "-Q", "15")[0])
+    assert got == {}
