@@ -1,0 +1,109 @@
+"""Randomised differential tests: random index shapes (k, hashes, colours, Bloom size, minimizers) and random, awkward reads
+(lengths around k, empty mates, N runs, lower case, repeats, a few reads long enough for the sort-based path) through
+cid_readid_count and cid_search_count / cid_search_perfect, each compared bit for bit with the oracle."""
+import numpy as np
+import pytest
+
+from test_gpu_readid import check
+from util import to_hip_index
+
+pytestmark = pytest.mark.gpu
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def random_read(rng, genome, k):
+    kind = rng.integers(0, 12)
+    if kind == 0:
+        L = int(rng.choice([0, 1, k - 1, k, k + 1, 2 * k - 1]))
+    elif kind == 1:
+        L = int(rng.integers(2_000, 9_000))           # beyond two waves' worth of LDS for many shapes: sort-based path
+    else:
+        L = int(rng.integers(k, 400))
+    L = min(L, len(genome) - 1)
+    st = int(rng.integers(0, len(genome) - L))
+    a = np.frombuffer(genome[st:st + L], np.uint8).copy()
+    if kind == 2 and L:
+        a[rng.integers(0, L, max(1, L // 20))] = ord("N")
+    if kind == 3 and L > 10:
+        s0 = int(rng.integers(0, L - 5))
+        a[s0:s0 + int(rng.integers(1, 40))] = ord("N")
+    if kind == 4:
+        a = np.frombuffer(a.tobytes().lower(), np.uint8).copy()
+    if kind == 5 and L:
+        low = rng.random(L) < 0.3
+        a[low] |= 0x20
+    if kind == 6 and L:
+        a = np.tile(a[:max(1, min(L, int(rng.integers(1, 12))))], 40)[:max(L, k + 5)]
+    if kind == 7 and L:
+        a[rng.integers(0, L, 3)] = np.frombuffer(b"RY-", np.uint8)
+    return a.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_readid_random_shapes(orc, hip_ctx, seed):
+    import colorid_amd
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([5, 11, 16, 21, 27, 31, 32, 33, 40, 64]))
+    n_hash = int(rng.integers(1, 7))
+    C = int(rng.choice([1, 2, 31, 33, 64, 65, 128, 200, 513, 1000]))
+    m = int(rng.choice([1 << 12, 4099, 30011, 1 << 15]))
+    msz = int(rng.integers(max(3, k // 3), k + 1)) if seed % 3 == 2 else 0
+    genomes = [ACGT[rng.integers(0, 4, 12_000)].tobytes() for _ in range(3)]
+    oix = orc.Index(m, n_hash, k, C)
+    if msz:
+        oix.set_minimizer(msz)
+    for c in range(C):
+        oix.set_color(c, f"a{c}", 100)
+    for gi, g in enumerate(genomes):
+        km = orc.Kmers(k)
+        km.kmerize_vector(g[:int(rng.integers(3000, 12_000))], 1)
+        for key in km.keys()[::int(rng.integers(1, 4))]:
+            oix.insert(int(rng.integers(0, C)) if gi else gi % C, key.tobytes())
+    hx = colorid_amd.Index(hip_ctx, m, n_hash, k, C)
+    if msz:
+        hx.set_minimizer(msz)
+    hx.put_dense(oix.rows())
+    hx.finalize()
+    for _ in range(2):
+        d, S = int(rng.integers(1, 13)), int(rng.integers(0, 7))
+        reads = []
+        for _ in range(int(rng.integers(1, 160))):
+            g = genomes[rng.integers(0, 3)]
+            n_mates = int(rng.choice([1, 1, 2, 2, 3]))
+            reads.append([random_read(rng, g, k) for _ in range(n_mates)])
+        check(oix, hx, reads, d, S)
+    hx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_search_random_shapes(orc, hip_ctx, seed):
+    rng = np.random.default_rng(2000 + seed)
+    k = int(rng.choice([1, 7, 16, 17, 31, 32, 33, 48, 97, 128]))
+    n_hash = int(rng.integers(1, 9))
+    C = int(rng.choice([1, 5, 32, 63, 64, 100, 256, 300, 1025, 4097]))
+    m = int(rng.choice([257, 1 << 10, 10007, 1 << 16]))
+    oix = orc.Index(m, n_hash, k, C)
+    for c in range(C):
+        oix.set_color(c, f"a{c}", 100)
+    alphabet = np.frombuffer(b"ACGTacgtN", np.uint8) if seed % 2 else ACGT
+    K = int(rng.integers(1, 3000))
+    kmers = alphabet[rng.integers(0, len(alphabet), (K, k))]
+    for j in np.flatnonzero(rng.random(K) < 0.7):
+        for c in rng.choice(C, size=min(C, int(rng.integers(1, 4))), replace=False):
+            oix.insert(int(c), kmers[j].tobytes())
+    freq = rng.integers(1, 1000, K).astype(np.uint32)
+    hx = to_hip_index(hip_ctx, oix)
+    want = oix.search_count(kmers, freq.astype(np.uint64))
+    got = hx.search_count(kmers, freq)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    assert want[0].sum() > 0
+    pw, pm = oix.search_perfect(kmers)
+    gw, gm = hx.search_perfect(kmers)
+    assert pm == gm and np.array_equal(pw, gw)
+    sub = np.flatnonzero(want[3] != 0xFFFFFFFF)[:50]      # k-mers with exactly one colour: their AND is that colour, never missing
+    if len(sub):
+        pw, pm = oix.search_perfect(kmers[sub[:1]])
+        gw, gm = hx.search_perfect(kmers[sub[:1]])
+        assert pm == gm and not gm and np.array_equal(pw, gw)
+    hx.close()
