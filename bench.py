@@ -210,6 +210,7 @@ def main():
                                 out.data_ptr() + 16 * C, uc.data_ptr())
 
     def step():
+        out.zero_()            # every step is one whole query: fresh counters, search, reduction
         launch()
         allreduce_counts(out)  # RCCL over xGMI when N > 1: sum of the per-accession counters (24*C bytes)
 
@@ -222,6 +223,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
+        out.zero_()
         ev[i][0].record(stream)
         launch()
         ev[i][1].record(stream)
