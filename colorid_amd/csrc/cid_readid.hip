@@ -56,7 +56,9 @@ __device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, ui
 //   bytes  : anything else (lower-case bases are hashed as they are; k > 32) — byte strings in
 //            LDS, 32-bit tag match confirmed on the bytes.
 
-constexpr int kReadRunUnroll = 2;   // sub-passes of a read's search whose row loads are in flight together
+// Sub-passes of a read's search whose row loads are in flight together.  Measured on configs[2] (1 M x 150 bp): 2 costs 24 more
+// VGPRs than 1 and is no faster; 1 lets k_readid fit 96 VGPRs = 5 waves per SIMD, which is (6.13 vs 6.43-6.74 ms).
+constexpr int kReadRunUnroll = 1;
 constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained every 7 additions
 
 
@@ -140,7 +142,7 @@ __device__ __forceinline__ void readid_finish_read(VCount<kReadPlanes, NARROW> &
 // WIDE: win_cap*n) | table keys + indices | 2-bit bases | bad-base bits.  A read with a lower-case base (its case must be
 // kept) is appended to p.redo_list for k_readid_bytes.
 template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI>
-__global__ __launch_bounds__(kBlock, 4) void k_readid(ReadIdParams p) {
+__global__ __launch_bounds__(kBlock, 5) void k_readid(ReadIdParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
     constexpr uint32_t RS = NARROW ? 1u : 2u * LPR;
