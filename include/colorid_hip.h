@@ -10,7 +10,8 @@
  *     panics on every error: src/bigsi.rs:60-61, src/kmer.rs:11.)
  *   - the caller owns every host buffer; the library owns device memory.
  *   - a cid_index is immutable and shareable after cid_index_finalize(); a cid_ctx is used by
- *     one host thread at a time.
+ *     one host thread at a time.  Objects made from a ctx (cid_index, cid_kmerset) borrow its device
+ *     scratch: destroy them before the ctx.
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
  *     CID_ERR_HIP.
  *   - k-mers are ASCII byte strings of exactly k_size bytes, hashed byte-for-byte
