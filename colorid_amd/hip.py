@@ -1,5 +1,6 @@
 """Thin object wrappers over the C ABI (host-pointer calls take numpy arrays, *_dev calls take ints)."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -19,6 +20,7 @@ class Context:
         check(self.lib.cid_ctx_create(device_id, C.byref(h)))
         self.h = h
         self.device_id = device_id
+        self._children = weakref.WeakSet()   # indices / k-mer sets made from this ctx: they borrow its scratch, so they go first
 
     def set_stream(self, hip_stream):
         check(self.lib.cid_ctx_set_stream(self.h, vp(hip_stream) if hip_stream else None))
@@ -36,6 +38,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for child in list(self._children):
+                child.close()
             self.lib.cid_ctx_destroy(self.h)
             self.h = None
 
@@ -54,6 +58,7 @@ class Index:
         h = vp()
         check(self.lib.cid_index_create(ctx.h, bloom_size, num_hash, k_size, n_colors, hash_variant, C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def set_minimizer(self, m_size):
         check(self.lib.cid_index_set_minimizer(self.h, m_size))
@@ -168,6 +173,7 @@ class KmerSet:
         h = vp()
         check(self.lib.cid_kmerset_create(ctx.h, k, C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     def add_seqs(self, seqs, mode=0):
         """seqs: list of bytes"""
