@@ -325,6 +325,33 @@ int cid_index_put_rows(cid_index *ix, const uint64_t *row_ids, const uint32_t *w
     return CID_OK;
 }
 
+int cid_index_put_records(cid_index *ix, const uint8_t *records, size_t n_records) {
+    if (!ix || (n_records && !records)) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
+    cid_ctx *c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t rec_bytes = 24 + 4ull * ix->w32;
+    const size_t batch = (256u << 20) / rec_bytes;   // records per upload
+    for (size_t r0 = 0; r0 < n_records; r0 += batch) {
+        const size_t nr = n_records - r0 < batch ? n_records - r0 : batch;
+        void *d_rec, *d_err;
+        int rc = slot_reserve(c, S_WORDS, nr * rec_bytes, &d_rec);
+        if (rc) return rc;
+        rc = slot_reserve(c, S_MISC, 16, &d_err);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_err, 0, 4, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_rec, records + r0 * rec_bytes, nr * rec_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(cid::launch_put_records(ix->mat, ix->rs, (const uint32_t *)d_rec, ix->w32, nr, ix->m, ix->n_colors, (uint32_t *)d_err, c->stream));
+        uint32_t err = 0;
+        HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (err)
+            return fail(CID_ERR_INVALID, "malformed row record(s):%s%s%s%s", (err & 1) ? " word count != ceil(n_colors/32)" : "",
+                        (err & 2) ? " bit count != n_colors" : "", (err & 4) ? " row >= bloom_size" : "", (err & 8) ? " bits beyond n_colors" : "");
+    }
+    return CID_OK;
+}
+
 int cid_index_device_matrix(cid_index *ix, void **dev_ptr, uint64_t *row_stride_words) {
     if (!ix || !dev_ptr || !row_stride_words) return fail(CID_ERR_INVALID, "null argument");
     *dev_ptr = ix->mat;

@@ -2,6 +2,7 @@
 // and the index builder (src/build.rs:15-130) with the Bloom inserts done on the GPU.
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 #include "colorid_host.hpp"
 
@@ -18,7 +19,7 @@ struct BufReader {  // big sequential reads; the file is parsed once, front to b
     FILE *f;
     std::vector<uint8_t> buf;
     size_t pos = 0, end = 0;
-    explicit BufReader(const std::string &path) : f(fopen(path.c_str(), "rb")), buf(64u << 20) {
+    explicit BufReader(const std::string &path) : f(fopen(path.c_str(), "rb")), buf(1u << 20) {
         if (!f) die("Can't open index!: %s", path.c_str());
     }
     ~BufReader() { fclose(f); }
@@ -32,6 +33,17 @@ struct BufReader {  // big sequential reads; the file is parsed once, front to b
             size_t got = fread(buf.data() + end, 1, buf.size() - end, f);
             if (got == 0) die("can't deserialize: unexpected end of file");
             end += got;
+        }
+    }
+    void read_exact(uint8_t *dst, size_t n) {   // bulk: what is buffered first, then straight from the file
+        const size_t take = std::min(n, end - pos);
+        memcpy(dst, buf.data() + pos, take);
+        pos += take;
+        size_t got = take;
+        while (got < n) {
+            const size_t g = fread(dst + got, 1, n - got, f);
+            if (g == 0) die("can't deserialize: unexpected end of file");
+            got += g;
         }
     }
     uint64_t u64() {
@@ -78,32 +90,47 @@ Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool m
         CID_TRY(cid_index_create(ctx, b.bloom_size, (uint32_t)b.num_hash, (uint32_t)b.k_size, (uint32_t)nc, hash_variant, &b.index));
         if (mini) CID_TRY(cid_index_set_minimizer(b.index, (uint32_t)b.m_size));
     }
-    const size_t batch = 1u << 22;
-    std::vector<uint64_t> ids;
-    std::vector<uint32_t> words;
-    ids.reserve(batch);
-    words.reserve(batch * w32);
-    for (uint64_t i = 0; i < n_rows; ++i) {  // { u64 row ; u64 W32 ; W32 x u32 ; u64 nbits }
-        r.need(16 + 4ull * w32 + 8);
-        uint64_t row, nw, nbits;
-        memcpy(&row, r.buf.data() + r.pos, 8);
-        memcpy(&nw, r.buf.data() + r.pos + 8, 8);
-        if (nw != w32) die("can't deserialize: row with %llu words, expected %u", (unsigned long long)nw, w32);
-        memcpy(&nbits, r.buf.data() + r.pos + 16 + 4ull * w32, 8);
-        if (nbits != nc) die("can't deserialize: row of %llu bits, expected %llu", (unsigned long long)nbits, (unsigned long long)nc);
-        if (!meta_only) {
-            ids.push_back(row);
-            const uint32_t *wp = reinterpret_cast<const uint32_t *>(r.buf.data() + r.pos + 16);
-            words.insert(words.end(), wp, wp + w32);
-            if (ids.size() == batch) {
-                CID_TRY(cid_index_put_rows(b.index, ids.data(), words.data(), ids.size()));
-                ids.clear();
-                words.clear();
+    // The row records go to the device as they sit in the file — { u64 row ; u64 W32 ; W32 x u32 ; u64 nbits } each — and are
+    // parsed and checked there (cid_index_put_records); a second thread reads the next chunk while this one is uploaded.
+    const size_t rec = 24 + 4ull * w32;
+    if (n_rows > (~0ull) / rec) die("can't deserialize: %llu rows", (unsigned long long)n_rows);
+    if (meta_only) {   // `info`: no device; the records are still checked, as deserialising them would
+        std::vector<uint8_t> chunk;
+        for (uint64_t left = n_rows; left;) {
+            const size_t nr = (size_t)std::min<uint64_t>(left, (16u << 20) / rec + 1);
+            chunk.resize(nr * rec);
+            r.read_exact(chunk.data(), nr * rec);
+            for (size_t i = 0; i < nr; ++i) {
+                uint64_t nw, nbits;
+                memcpy(&nw, chunk.data() + i * rec + 8, 8);
+                memcpy(&nbits, chunk.data() + i * rec + 16 + 4ull * w32, 8);
+                if (nw != w32) die("can't deserialize: row with %llu words, expected %u", (unsigned long long)nw, w32);
+                if (nbits != nc) die("can't deserialize: row of %llu bits, expected %llu", (unsigned long long)nbits, (unsigned long long)nc);
             }
+            left -= nr;
         }
-        r.pos += 16 + 4ull * w32 + 8;
+    } else {
+        const size_t chunk_recs = std::max<size_t>(1, (128u << 20) / rec);
+        std::vector<uint8_t> bufs[2];
+        size_t have[2] = {0, 0};
+        uint64_t left = n_rows;
+        auto fill = [&](int which) {
+            const size_t nr = (size_t)std::min<uint64_t>(left, chunk_recs);
+            bufs[which].resize(nr * rec);
+            r.read_exact(bufs[which].data(), nr * rec);
+            have[which] = nr;
+            left -= nr;
+        };
+        fill(0);
+        int cur = 0;
+        while (have[cur]) {
+            std::thread prefetch([&, cur] { fill(cur ^ 1); });
+            const int rc = cid_index_put_records(b.index, bufs[cur].data(), have[cur]);
+            prefetch.join();
+            if (rc != CID_OK) die("can't deserialize: %s", cid_last_error());
+            cur ^= 1;
+        }
     }
-    if (!meta_only && !ids.empty()) CID_TRY(cid_index_put_rows(b.index, ids.data(), words.data(), ids.size()));
     b.n_ref_kmers.assign(nc, 0);
     std::map<std::string, uint64_t> by_name;
     for (uint64_t c = 0; c < nc; ++c) by_name[b.colors[c]] = c;

@@ -70,6 +70,13 @@ class Index:
         words = np.ascontiguousarray(words, np.uint32).reshape(len(row_ids), self.w32)
         check(self.lib.cid_index_put_rows(self.h, _p(row_ids), _p(words), len(row_ids)))
 
+    def put_records(self, records: bytes):
+        """rows as raw .bxi records ({u64 row; u64 W32; W32 x u32; u64 n_bits} each), parsed on the device"""
+        rec = 24 + 4 * self.w32
+        assert len(records) % rec == 0
+        buf = np.frombuffer(records, np.uint8)
+        check(self.lib.cid_index_put_records(self.h, _p(buf), len(records) // rec))
+
     def put_dense(self, rows_u32):
         """rows_u32: bloom_size x w32 dense BitVec storage; only non-zero rows are sent (as a .bxi holds them)."""
         rows_u32 = np.ascontiguousarray(rows_u32, np.uint32).reshape(self.m, self.w32)

@@ -70,6 +70,11 @@ int cid_index_set_minimizer(cid_index *, uint32_t m_size);
 /* Sparse rows as the .bxi `map` stores them (src/bigsi.rs:59-63): n_rows x W32 little-endian
  * u32 words, W32 = ceil(n_colors/32).  Rows never put stay all-zero == key absent from the map. */
 int cid_index_put_rows(cid_index *, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows);
+/* The same rows as they sit in a .bxi/.mxi file: n_records consecutive bincode records
+ * { u64 row ; u64 n_words ; n_words x u32 ; u64 n_bits }, 24 + 4*W32 bytes each.  The records are parsed
+ * and checked on the device (n_words == W32, n_bits == n_colors, row < bloom_size, no bit beyond n_colors), so a loader
+ * only has to read the file: CID_ERR_INVALID for a malformed record (the reference: "can't deserialize" panic, bigsi.rs:61). */
+int cid_index_put_records(cid_index *, const uint8_t *records, size_t n_records);
 /* Native device layout: row r at matrix + r*row_stride_words (u64 words, little-endian pairs of the u32 words,
  * zero padded).  Exposed so a caller can generate/fill an index in HBM directly (bits >= n_colors MUST be 0). */
 int cid_index_device_matrix(cid_index *, void **dev_ptr, uint64_t *row_stride_words);

@@ -201,3 +201,44 @@ def test_insert_kmers_matches_oracle_bloom(orc, hip_ctx):
         got = hx.get_rows(np.arange(m, dtype=np.uint64))
         assert np.array_equal(got, oix.rows())
         hx.close()
+
+
+def test_put_records_parses_bxi_rows_on_the_device(orc, hip_ctx, tmp_path):
+    """cid_index_put_records takes the .bxi file's own row records; the matrix equals the one built row by row, and malformed
+    records are refused (bigsi.rs:59-63: the reference's deserialiser would panic)."""
+    import struct
+
+    import colorid_amd
+    rng = np.random.default_rng(8)
+    for n_colors in (5, 32, 33, 100, 300):
+        oix = random_index(orc, rng, 20_011, 3, 21, n_colors, density=0.3, zero_row_frac=0.4)
+        path = str(tmp_path / f"c{n_colors}.bxi")
+        oix.save(path)
+        raw = open(path, "rb").read()
+        off = 32
+        for _ in range(n_colors):
+            (ln,) = struct.unpack_from("<Q", raw, off + 8)
+            off += 16 + ln
+        (n_rows,) = struct.unpack_from("<Q", raw, off)
+        off += 8
+        rec = 24 + 4 * oix.w32
+        records = raw[off:off + n_rows * rec]
+        hx = colorid_amd.Index(hip_ctx, oix.m, oix.n_hash, oix.k, n_colors)
+        cut = (n_rows // 3) * rec
+        hx.put_records(records[:cut])            # in two calls, any order
+        hx.put_records(records[cut:])
+        hx.finalize()
+        assert np.array_equal(hx.get_rows(np.arange(oix.m, dtype=np.uint64)), oix.rows())
+        hx.close()
+        # malformed: wrong word count / wrong bit count / row beyond bloom_size / a bit beyond n_colors
+        bad = []
+        b = bytearray(records[:rec]); struct.pack_into("<Q", b, 8, oix.w32 + 1); bad.append(bytes(b))
+        b = bytearray(records[:rec]); struct.pack_into("<Q", b, 16 + 4 * oix.w32, n_colors + 1); bad.append(bytes(b))
+        b = bytearray(records[:rec]); struct.pack_into("<Q", b, 0, oix.m); bad.append(bytes(b))
+        if n_colors % 32:
+            b = bytearray(records[:rec]); b[16 + 4 * oix.w32 - 1] |= 0x80; bad.append(bytes(b))
+        for rb in bad:
+            hx = colorid_amd.Index(hip_ctx, oix.m, oix.n_hash, oix.k, n_colors)
+            with pytest.raises(Exception):
+                hx.put_records(records[:5 * rec] + rb)
+            hx.close()
