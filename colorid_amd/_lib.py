@@ -33,6 +33,7 @@ SIGNATURES = {
     "cid_index_device_matrix": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "cid_index_finalize": (C.c_int, [vp]),
     "cid_index_get_rows": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "cid_index_get_records": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp]),
     "cid_index_insert_kmers_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "cid_index_insert_kmers": (C.c_int, [vp, vp, C.c_uint32, C.c_size_t]),
     "cid_index_destroy": (None, [vp]),

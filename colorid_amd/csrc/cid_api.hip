@@ -385,6 +385,14 @@ int cid_index_get_rows(const cid_index *ix, const uint64_t *row_ids, uint32_t *w
     return CID_OK;
 }
 
+int cid_index_get_records(const cid_index *ix, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records) {
+    if (!ix || !n_records || (n_rows && !records)) return fail(CID_ERR_INVALID, "null argument");
+    if (row_begin > ix->m || n_rows > ix->m - row_begin) return fail(CID_ERR_INVALID, "rows [%llu, +%llu) outside bloom_size",
+                                                                     (unsigned long long)row_begin, (unsigned long long)n_rows);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    return cid::index_get_records(ix->ctx, ix, row_begin, n_rows, records, n_records);
+}
+
 int cid_index_insert_kmers_dev(cid_index *ix, const uint8_t *d_kmers, const uint32_t *d_colour_of_kmer, size_t n_kmers) {
     if (!ix || (n_kmers && (!d_kmers || !d_colour_of_kmer))) return fail(CID_ERR_INVALID, "null argument");
     if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");

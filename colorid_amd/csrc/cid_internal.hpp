@@ -40,6 +40,9 @@ int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes,
 int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t *and_words_le,
                          int *any_row_missing);
 
+// the non-zero rows of [row_begin, row_begin + n_rows) as .bxi row records in a host buffer (cid_kmerset.hip)
+int index_get_records(cid_ctx *c, const cid_index *ix, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records);
+
 // dense report rows (device) -> per-row (colour, count) lists, ascending colour; outputs are ctx_alloc'ed for the caller (return them with ctx_free)
 int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_t n_rows, uint64_t **d_row_start, uint32_t **d_colours,
                    uint32_t **d_counts, uint64_t *n_entries);

@@ -509,6 +509,63 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
 
 }  // namespace cid
 
+// ------------------------------------------------------------------------------------------------ rows -> .bxi records
+// save_bigsi (bigsi.rs:51-57 / build.rs:123-127): the non-zero rows of a row range, in ascending order, as the bincode
+// records the file holds — { u64 row ; u64 W32 ; W32 x u32 ; u64 n_colors } — formatted on the device so that the host only
+// writes the bytes.
+namespace cid {
+
+__global__ void k_row_nonzero(const uint64_t *mat, uint32_t rs, uint64_t row_begin, uint64_t n, uint32_t *flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { flags[i] = 0; return; }   // slot n receives the total
+    const uint64_t *row = mat + (row_begin + i) * rs;
+    uint64_t any = 0;
+    for (uint32_t w = 0; w < rs; ++w) any |= row[w];
+    flags[i] = any ? 1u : 0u;
+}
+__global__ void k_emit_records(const uint32_t *mat32, uint32_t rs, uint32_t w32, uint32_t n_colors, uint64_t row_begin, uint64_t n,
+                               const uint32_t *flags, const uint32_t *pos, uint32_t *out32) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const uint64_t row = row_begin + i;
+    uint32_t *rec = out32 + (uint64_t)pos[i] * (6ull + w32);
+    rec[0] = (uint32_t)row; rec[1] = (uint32_t)(row >> 32);
+    rec[2] = w32; rec[3] = 0;
+    const uint32_t *src = mat32 + row * (2ull * rs);
+    for (uint32_t w = 0; w < w32; ++w) rec[4 + w] = src[w];
+    rec[4 + w32] = n_colors; rec[5 + w32] = 0;
+}
+
+// host buffer `records` holds up to n_rows records; *n_records = the number written
+int index_get_records(cid_ctx *c, const cid_index *ix, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records) {
+    *n_records = 0;
+    if (n_rows == 0) return CID_OK;
+    if (n_rows >= (1ull << 32)) return fail(CID_ERR_INVALID, "at most 2^32-1 rows per call");
+    hipStream_t st = ctx_stream(c);
+    const uint32_t w32 = (index_n_colors(ix) + 31) / 32, rs = index_rs(ix);
+    const size_t rec = 24 + 4ull * w32;
+    DevBuf<uint32_t> flags(c), pos(c);
+    DevBuf<uint8_t> out(c), tmp(c);
+    int rc;
+    if ((rc = flags.alloc(n_rows + 1)) || (rc = pos.alloc(n_rows + 1)) || (rc = out.alloc(n_rows * rec))) return rc;
+    hipLaunchKernelGGL(k_row_nonzero, dim3(grid_for_n(n_rows + 1)), dim3(256), 0, st, index_matrix(ix), rs, row_begin, n_rows, flags.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, flags.p, pos.p, 0u, n_rows + 1, rocprim::plus<uint32_t>(), st));
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, flags.p, pos.p, 0u, n_rows + 1, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(k_emit_records, dim3(grid_for_n(n_rows)), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(index_matrix(ix)), rs, w32,
+                       index_n_colors(ix), row_begin, n_rows, flags.p, pos.p, reinterpret_cast<uint32_t *>(out.p));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, pos.p + n_rows, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (total) HIP_TRY(hipMemcpy(records, out.p, (size_t)total * rec, hipMemcpyDeviceToHost));
+    *n_records = total;
+    return CID_OK;
+}
+
+}  // namespace cid
+
 // ------------------------------------------------------------------------------------------------ sparse read_id reports
 // A report row has n_colors+1 counters but only a handful are non-zero: compact the dense rows (left in HBM by
 // k_readid) into per-read (colour, count) lists in ascending colour order, so that only those cross PCIe.

@@ -158,21 +158,15 @@ void save_bigsi(const std::string &path, const Bigsi &b) {
     const long count_pos = ftell(f);
     w64(f, 0);
     uint64_t n_rows = 0;
-    const uint64_t chunk = 1u << 22;
-    std::vector<uint64_t> ids(chunk);
-    std::vector<uint32_t> words(chunk * w32);
+    const size_t rec = 24 + 4ull * w32;
+    const uint64_t chunk = std::max<uint64_t>(1, (128u << 20) / rec);   // records are formatted on the device; the host writes bytes
+    std::vector<uint8_t> records(chunk * rec);
     for (uint64_t r0 = 0; r0 < b.bloom_size; r0 += chunk) {
         const uint64_t nr = std::min<uint64_t>(chunk, b.bloom_size - r0);
-        for (uint64_t i = 0; i < nr; ++i) ids[i] = r0 + i;
-        CID_TRY(cid_index_get_rows(b.index, ids.data(), words.data(), nr));
-        for (uint64_t i = 0; i < nr; ++i) {
-            const uint32_t *wp = words.data() + i * w32;
-            bool any = false;
-            for (uint32_t w = 0; w < w32; ++w) any |= wp[w] != 0;
-            if (!any) continue;
-            w64(f, r0 + i); w64(f, w32); fwrite(wp, 4, w32, f); w64(f, nc);
-            ++n_rows;
-        }
+        uint64_t got = 0;
+        CID_TRY(cid_index_get_records(b.index, r0, nr, records.data(), &got));
+        if (got && fwrite(records.data(), rec, got, f) != got) die("problems writing %s", path.c_str());
+        n_rows += got;
     }
     w64(f, nc);
     for (uint64_t c = 0; c < nc; ++c) { w64(f, b.colors[c].size()); fwrite(b.colors[c].data(), 1, b.colors[c].size(), f); w64(f, b.n_ref_kmers[c]); }

@@ -98,6 +98,14 @@ class Index:
         check(self.lib.cid_index_get_rows(self.h, _p(row_ids), _p(out), len(row_ids)))
         return out
 
+    def get_records(self, row_begin, n_rows) -> bytes:
+        """the non-zero rows of [row_begin, row_begin + n_rows) as raw .bxi records"""
+        rec = 24 + 4 * self.w32
+        buf = np.empty(max(1, n_rows * rec), np.uint8)
+        n = C.c_uint64(0)
+        check(self.lib.cid_index_get_records(self.h, row_begin, n_rows, _p(buf), C.byref(n)))
+        return buf[:n.value * rec].tobytes()
+
     def insert_kmers_dev(self, d_kmers, d_colour_of_kmer, n_kmers):
         check(self.lib.cid_index_insert_kmers_dev(self.h, vp(d_kmers), vp(d_colour_of_kmer), n_kmers))
 

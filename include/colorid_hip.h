@@ -81,6 +81,10 @@ int cid_index_device_matrix(cid_index *, void **dev_ptr, uint64_t *row_stride_wo
 int cid_index_finalize(cid_index *);
 /* Read rows back (host): words_le receives n_rows x W32 u32 words. */
 int cid_index_get_rows(const cid_index *, const uint64_t *row_ids, uint32_t *words_le, size_t n_rows);
+/* save_bigsi (src/bigsi.rs:51-57): the non-zero rows of [row_begin, row_begin + n_rows) in ascending order as the file's row
+ * records (see cid_index_put_records), formatted on the device.  `records` must hold n_rows * (24 + 4*W32) bytes;
+ * *n_records = how many were written (all-zero rows are not keys of the map, src/build.rs:123-127).  n_rows < 2^32. */
+int cid_index_get_records(const cid_index *, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records);
 /* Bloom insert on device: simple_bloom.rs:19-26 for colour `colour` of every k-mer (used to build/plant
  * indices without leaving HBM; src/build.rs:116-128 transposed on the fly).  Before finalize only. */
 int cid_index_insert_kmers_dev(cid_index *, const uint8_t *d_kmers, const uint32_t *d_colour_of_kmer,

@@ -229,6 +229,10 @@ def test_put_records_parses_bxi_rows_on_the_device(orc, hip_ctx, tmp_path):
         hx.put_records(records[cut:])
         hx.finalize()
         assert np.array_equal(hx.get_rows(np.arange(oix.m, dtype=np.uint64)), oix.rows())
+        # and back: the non-zero rows formatted on the device are the file's bytes (cid_index_get_records), also piecewise
+        assert hx.get_records(0, oix.m) == records
+        mid = oix.m // 2 + 3
+        assert hx.get_records(0, mid) + hx.get_records(mid, oix.m - mid) == records and hx.get_records(7, 0) == b""
         hx.close()
         # malformed: wrong word count / wrong bit count / row beyond bloom_size / a bit beyond n_colors
         bad = []
