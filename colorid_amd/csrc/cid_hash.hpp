@@ -50,7 +50,9 @@ CID_FN uint64_t mod_m(uint64_t h, const ModMagic &mm) {
     } else {
         q >>= mm.shift;
     }
-    return h - q * mm.m;
+    // bloom_size <= 2^32 and 2^32 itself takes the mask path, so m and the remainder fit 32 bits: the subtraction is exact
+    // modulo 2^32 and one 32-bit multiply replaces the 64-bit one
+    return (uint64_t)((uint32_t)h - (uint32_t)q * (uint32_t)mm.m);
 }
 
 // ---------------------------------------------------------------- XXH3-64 (published v0.8 spec), inputs <= 128 B

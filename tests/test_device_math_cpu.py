@@ -51,8 +51,9 @@ def test_device_hash_matches_published_kats(shim):
 
 def test_device_mod_is_exact(shim):
     rnd = random.Random(9)
-    ms = [1, 2, 3, 5, 6, 7, 12, 1000, 750000, 30_000_000, 50_000_000, 250_000_000, 2**30, 2**32 - 1, 2**32,
-          2**31 + 1, 10**9 + 7, 2**63, 2**63 + 1, 2**64 - 1] + [rnd.getrandbits(rnd.randint(2, 64)) | 1 for _ in range(50)]
+    # every bloom_size the library accepts: 1 .. 2^32 (cid_index_create refuses more; mod_m relies on it)
+    ms = [1, 2, 3, 5, 6, 7, 12, 1000, 750000, 30_000_000, 50_000_000, 250_000_000, 2**30, 2**32 - 1, 2**32, 2**32 - 5,
+          2**31 + 1, 2**31 - 1, 2**31, 10**9 + 7, 3 * 2**30] + [rnd.getrandbits(rnd.randint(2, 32)) | 1 for _ in range(80)]
     for m in ms:
         hs = [0, 1, m - 1, m, (m + 1) % 2**64, 2**64 - 1, 2**63, 2**32] + [rnd.getrandbits(64) for _ in range(500)]
         for h in hs:
