@@ -1,6 +1,7 @@
 // Sequence input and canonical k-mer counting on the host (src/seq.rs, the query-side functions of src/kmer.rs).
 // This is host staging for the GPU path: the reference counts k-mers on the CPU too (String keys + FNV);
 // here keys live packed in one arena and are hashed 8 bytes at a time.
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cmath>
@@ -23,7 +24,10 @@ void die(const char *fmt, ...) {
     vfprintf(stderr, fmt, ap);
     fprintf(stderr, "\n");
     va_end(ap);
-    exit(101);  // a Rust panic exits with 101
+    // a Rust panic exits with 101.  Reader / classifier threads may be running (and may be the caller): flush what was written
+    // and leave without running static destructors under them.
+    fflush(nullptr);
+    _exit(101);
 }
 
 // ---------------------------------------------------------------------------------------------- files
