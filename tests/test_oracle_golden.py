@@ -277,7 +277,7 @@ def test_kmer_poll_plus(orc):  # read_id_mt_pe.rs:187-251, SURVEY.md App. E1
 def _py_find_minimizer(kmer: bytes, m: int) -> bytes:
     """Independent restatement of kmer.rs:971-986: window 0 contributes its forward m-mer only, later windows also their
     reverse-complement m-mer; strict `<` keeps the first minimum."""
-    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    comp = {65: 84, 67: 71, 71: 67, 84: 65, 97: 116, 99: 103, 103: 99, 116: 97}   # switch_base keeps the case (kmer.rs:847-863)
     rc = bytes(comp.get(c, c) for c in reversed(kmer))
     n = len(kmer)
     best = kmer[:m]
@@ -360,3 +360,105 @@ def test_sparse_structure_variant_equals_dense(orc, phage_index):
     got = phage_index.search_count_sparse(sp, keys, freq)
     orc.sparse_free(sp)
     assert all(np.array_equal(w, g) for w, g in zip(want[:3], got)) and want[0].sum() >= 4000
+
+
+def _py_readid(rows, m, n_hash, n_colors, k, msz, mates, d, S):
+    """Independent restatement (python-xxhash, python sets) of parallel_vec's per-read work — kmer.rs:221-243 / :363-394
+    for the set (first-occurrence order, the documented normalisation), read_id_mt_pe.rs:66-102 (S == 0) / :104-165 for the
+    search — returning (report[C+1], n_kmers, too_short)."""
+    import xxhash
+    comp = {65: 84, 67: 71, 71: 67, 84: 65, 97: 116, 99: 103, 103: 99, 116: 97}
+    if len(mates[0]) < k:
+        return None, 0, True
+    keys = []
+    seen = set()
+    for l in mates:
+        if len(l) < k:
+            continue
+        rc = bytes(comp.get(c, c) for c in reversed(l))
+        L = len(l)
+        for i in range(0, L - k + 1, d):
+            w = l[i:i + k]
+            if any(c not in b"ACGTacgt" for c in w):
+                continue
+            r = rc[L - (i + k):L - i]
+            canon = w if w < r else r
+            if msz:
+                canon = _py_find_minimizer(canon, msz).upper()
+            if canon not in seen:
+                seen.add(canon)
+                keys.append(canon)
+    report = [0] * (n_colors + 1)
+    sampled = set()
+    for counter, key in enumerate(keys):
+        acc = None
+        for s in range(n_hash):
+            word = 0
+            r = xxhash.xxh3_64_intdigest(key, seed=s) % m
+            for w in range(rows.shape[1]):
+                word |= int(rows[r, w]) << (32 * w)
+            if word == 0:
+                acc = None
+                break
+            acc = word if acc is None else acc & word
+        if acc is None:
+            report[n_colors] += 1
+            break
+        cols = [c for c in range(n_colors) if acc >> c & 1]
+        if S == 0:
+            for c in cols:
+                report[c] += 1
+        elif counter < S:
+            for c in cols:
+                sampled.add(c)
+                report[c] += 1
+        else:
+            for c in cols:
+                if c in sampled:
+                    report[c] += 1
+    return report, len(keys), False
+
+
+@pytest.mark.parametrize("msz", [0, 11])
+def test_readid_counts_vs_independent_python(orc, msz):
+    rng = np.random.default_rng(31 + msz)
+    m, n_hash, k, C = 20_011, 3, 21, 40
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 6000)].tobytes()
+    oix = orc.Index(m, n_hash, k, C)
+    if msz:
+        oix.set_minimizer(msz)
+    for c in range(C):
+        oix.set_color(c, f"a{c}", 100)
+    km = orc.Kmers(k)
+    km.kmerize_vector(genome[:4000], 1)
+    for i, key in enumerate(km.keys()):
+        oix.insert(i % 7, key.tobytes())
+        if i % 3 == 0:
+            oix.insert(20 + i % 11, key.tobytes())
+    reads = []
+    for i in range(120):
+        L = int(rng.integers(15, 200))
+        st = int(rng.integers(0, len(genome) - L))
+        a = bytearray(genome[st:st + L])
+        if i % 5 == 0:
+            a[int(rng.integers(0, L))] = ord("N")
+        if i % 7 == 0:
+            a = bytearray(bytes(a).lower())
+        if i % 11 == 0:
+            for p in rng.integers(0, L, 4):
+                a[p] = ord("acgt"[int(rng.integers(0, 4))])
+        mates = [bytes(a)]
+        if i % 2:
+            mates.append(genome[st + 50:st + 50 + int(rng.integers(5, 150))])
+        reads.append(mates)
+    from test_gpu_readid import pack_reads
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    for d, S in ((1, 3), (1, 0), (4, 2), (2, 1000)):
+        rep, nk, st = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+        for i, mates in enumerate(reads):
+            want, n_keys, short = _py_readid(oix.rows(), m, n_hash, C, k, msz, mates, d, S)
+            assert bool(st[i]) == short, i
+            if short:
+                continue
+            assert nk[i] == n_keys and list(rep[i]) == want, (i, d, S)
+        assert rep[:, :C].sum() > 0 and rep[:, C].sum() > 0
