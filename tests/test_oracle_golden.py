@@ -462,3 +462,58 @@ def test_readid_counts_vs_independent_python(orc, msz):
                 continue
             assert nk[i] == n_keys and list(rep[i]) == want, (i, d, S)
         assert rep[:, :C].sum() > 0 and rep[:, C].sum() > 0
+
+
+def _py_canon_windows(l: bytes, k: int, d: int = 1):
+    comp = {65: 84, 67: 71, 71: 67, 84: 65, 97: 116, 99: 103, 103: 99, 116: 97, 117: 97, 85: 65, 110: 110}
+    rc = bytes(comp.get(c, 78) for c in reversed(l))
+    L = len(l)
+    for i in range(0, L - k + 1, d):
+        w = l[i:i + k]
+        if all(c in b"ACGTacgt" for c in w):
+            r = rc[L - (i + k):L - i]
+            yield w if w < r else r
+
+
+def _py_qual_mask(seq: bytes, qual: bytes, q: int) -> bytes:   # seq.rs:36-56
+    if q == 0:
+        return seq
+    return bytes(78 if qc < q + 33 else seq[i] for i, qc in enumerate(qual))
+
+
+def test_kmer_maps_vs_independent_python(orc, tmp_path):
+    """kmerize_vector (kmer.rs:87-125, upper-cases), kmers_from_fq_qual (:461-510) and kmers_fq_pe_qual (:581-655, stops
+    with the shorter file, keeps the case) restated with python dicts and gzip, against the oracle's C."""
+    import gzip
+    from collections import Counter
+    from util import synth_fastq_records, write_fastq_gz
+    rng = np.random.default_rng(12)
+    genomes = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 5000)].tobytes() for _ in range(2)]
+    mixed = bytearray(genomes[0][:900])
+    mixed[100:180] = bytes(mixed[100:180]).lower()
+    mixed[300] = ord("N"); mixed[301] = ord("n"); mixed[500] = ord("R")
+    for k, d in ((21, 1), (5, 3), (31, 7)):
+        km = orc.Kmers(k)
+        km.kmerize_vector(bytes(mixed), d)
+        want = Counter(w.upper() for w in _py_canon_windows(bytes(mixed), k, d))
+        assert km.as_dict() == dict(want)
+    r1 = synth_fastq_records(rng, genomes, 120, 100, mate=0)
+    r2 = synth_fastq_records(rng, genomes, 110, 100, mate=1)
+    f1, f2 = str(tmp_path / "x_1.fastq.gz"), str(tmp_path / "x_2.fastq.gz")
+    write_fastq_gz(f1, r1, multi_member=True)
+    write_fastq_gz(f2, r2)
+
+    def records(path):
+        lines = gzip.open(path, "rb").read().split(b"\n")
+        return [(lines[i + 1], lines[i + 3]) for i in range(0, len(lines) - 3, 4)]
+    for q in (0, 15, 30):
+        want = Counter()
+        for seq, qual in records(f1):
+            want.update(_py_canon_windows(_py_qual_mask(seq, qual, q), 27))
+        assert orc.kmers_from_fq_qual(f1, 27, q).as_dict() == dict(want)
+        want = Counter()
+        for (s1, q1), (s2, q2) in zip(records(f1), records(f2)):          # zip stops with the shorter file, like the reference
+            for seq, qual in ((s1, q1), (s2, q2)):
+                want.update(_py_canon_windows(_py_qual_mask(seq, qual, q), 27))
+        assert orc.kmers_fq_pe_qual(f1, f2, 27, q).as_dict() == dict(want)
+        assert len(want) > 2000
