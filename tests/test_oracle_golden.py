@@ -517,3 +517,84 @@ def test_kmer_maps_vs_independent_python(orc, tmp_path):
                 want.update(_py_canon_windows(_py_qual_mask(seq, qual, q), 27))
         assert orc.kmers_fq_pe_qual(f1, f2, 27, q).as_dict() == dict(want)
         assert len(want) > 2000
+
+
+def _py_auto_cutoff(mults):
+    """kmer.rs:866-942 restated; None where the reference would panic (usize underflow, index out of range) and float
+    semantics as in Rust (x/0 = inf, 0/0 = NaN, comparisons with NaN false)."""
+    import math
+    from collections import Counter
+
+    def div(a, b):
+        if b == 0:
+            return math.nan if a == 0 else math.inf
+        return a / b
+    histo = Counter(mults)
+    max_cov = max(mults)
+    total_mean = sum(i * p for i, p in histo.items()) / len(mults)
+    if total_mean < 1.5:
+        return 0
+    cov = [histo.get(c, 0) for c in range(1, max_cov)]
+    if len(cov) < 1:                      # `1..coverages.len() - 1` underflows
+        return None
+    d1 = [div(float(cov[i]), float(cov[i + 1])) for i in range(1, len(cov) - 1)]
+    if len(d1) < 1:                       # `0..d1.len() - 1` underflows
+        return None
+    d2 = []
+    for i in range(len(d1) - 1):
+        a, b = d1[i], d1[i + 1]
+        if math.isnan(a) or math.isnan(b):
+            d2.append(math.nan)
+        elif math.isinf(a) and math.isinf(b):
+            d2.append(math.nan)
+        elif math.isinf(b):
+            d2.append(0.0)
+        elif b == 0:
+            d2.append(math.nan if a == 0 else math.inf)
+        else:
+            d2.append(a / b)
+    p1 = next((i + 1 for i, p in enumerate(d1) if p < 1.0), 0)
+    p2 = next((i + 1 for i, p in enumerate(d2) if p < 1.0), 0)
+    bigsum = sum(i * p for i, p in enumerate(cov[1:]))
+    num = sum(cov[1:])
+    mean = div(float(bigsum), float(num))
+    if p1 > 0 and p1 < mean * 0.75:
+        return p1
+    if p2 > 0:
+        return p2
+    if math.isnan(mean):
+        return 1                          # `NaN.ceil() as usize` saturates to 0; max(1, 0)
+    return max(1, math.ceil(mean / 2.0))
+
+
+def test_auto_cutoff_vs_independent_python(orc):
+    import itertools
+    rng = np.random.default_rng(77)
+    keys = ["".join(p).encode() for p in itertools.product("ACGT", repeat=6)]
+    n_cases = n_panic = 0
+    for case in range(300):
+        shape = case % 5
+        n = int(rng.integers(3, 600))
+        if shape == 0:        # sequencing-like: error k-mers at 1-2, a coverage peak
+            mults = np.concatenate([rng.integers(1, 3, n), rng.poisson(int(rng.integers(5, 40)), n) + 1])
+        elif shape == 1:
+            mults = rng.integers(1, int(rng.integers(2, 12)), n)
+        elif shape == 2:
+            mults = rng.geometric(0.3, n)
+        elif shape == 3:
+            mults = np.full(n, int(rng.integers(1, 6)))
+        else:
+            mults = rng.choice([1, 2, 3, 9, 10, 30], n)
+        mults = [int(x) for x in mults[:len(keys)]]
+        km = orc.Kmers(6)
+        for key, mu in zip(keys, mults):
+            orc.lib().orc_kmers_insert(km.h, key, mu)
+        want = _py_auto_cutoff(mults)
+        got = km.auto_cutoff()
+        if want is None:
+            assert got == -1, (case, mults[:20])
+            n_panic += 1
+        else:
+            assert got == want, (case, sorted(mults)[:30], want, got)
+        n_cases += 1
+    assert n_cases == 300 and n_panic >= 1
