@@ -598,3 +598,60 @@ def test_auto_cutoff_vs_independent_python(orc):
             assert got == want, (case, sorted(mults)[:30], want, got)
         n_cases += 1
     assert n_cases == 300 and n_panic >= 1
+
+
+def test_kmer_poll_plus_vs_independent_python(orc):
+    """read_id_mt_pe.rs:168-251 restated with scipy's binomial pmf standing in for `probability::Binomial::mass`: random sparse
+    reports, cases within 5 % of the pmf == fp_correct boundary skipped (two correct pmf implementations may differ in the
+    last bits there); ties keep ascending colour id (the documented normalisation of the reference's arbitrary order)."""
+    from scipy.stats import binom
+    rng = np.random.default_rng(55)
+    C, m, n_hash = 12, 750_000, 4
+    ix = orc.Index(m, n_hash, 27, C)
+    n_ref = [int(x) for x in rng.integers(5_000, 120_000, C)]
+    for c in range(C):
+        ix.set_color(c, f"acc{c:02d}", n_ref[c])
+    p_false = [orc.false_prob(m, n_hash, n) for n in n_ref]
+    for c in range(C):      # read_id_mt_pe.rs:695-698
+        assert abs(p_false[c] - (1.0 - np.exp(-(n_hash * (n_ref[c] + 0.5)) / (m - 1.0))) ** n_hash) < 1e-15
+    n_done = 0
+    outcomes = set()
+    for case in range(600):
+        klen = int(rng.integers(1, 300))
+        report = np.zeros(C + 1, np.uint64)
+        for c in rng.choice(C, size=int(rng.integers(0, 5)), replace=False):
+            report[c] = int(rng.integers(1, klen + 1)) if case % 3 else int(rng.integers(1, 4))
+        if case % 4 == 0:
+            report[C] = 1
+        if case % 7 == 0 and report[:C].any():       # force a tie at the top
+            top = int(report[:C].max())
+            report[int(rng.integers(0, C))] = top
+        if not report.any():
+            continue
+        fp_correct = float(rng.choice([1e-3, 1e-2, 1e-6, 0.05]))
+        near_boundary = False
+        sig = []
+        for c in sorted(range(C), key=lambda c: (-int(report[c]), c)):
+            h = int(report[c])
+            if h == 0:
+                continue
+            crit = klen * p_false[c]
+            mpf = float(binom.pmf(h, klen, p_false[c]))
+            if abs(mpf - fp_correct) <= 0.05 * fp_correct or h == crit:
+                near_boundary = True
+            if h < crit or (h > crit and mpf >= fp_correct):
+                continue
+            sig.append((c, h))
+        if near_boundary:
+            continue
+        if not report[:C].any():
+            want = ("no_hits", 0, klen, "accept", 0)
+        elif not sig:
+            want = ("no_significant_hits", 0, klen, "reject", 0)
+        else:
+            tops = [f"acc{c:02d}" for c, h in sig if h == sig[0][1]]
+            want = (",".join(tops), sig[0][1], klen, "accept" if len(tops) == 1 else "reject", len(tops))
+        assert ix.kmer_poll_plus(report, klen, fp_correct) == want, (case, report, klen, fp_correct)
+        outcomes.add(want[0] if want[0].startswith("no_") else want[3])
+        n_done += 1
+    assert n_done > 400 and outcomes == {"no_hits", "no_significant_hits", "accept", "reject"}
