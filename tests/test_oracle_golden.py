@@ -655,3 +655,40 @@ def test_kmer_poll_plus_vs_independent_python(orc):
         outcomes.add(want[0] if want[0].startswith("no_") else want[3])
         n_done += 1
     assert n_done > 400 and outcomes == {"no_hits", "no_significant_hits", "accept", "reject"}
+
+
+def test_reports_vs_independent_python(orc):
+    """reports.rs:8-62 restated with python formatting: a row per colour with hits (ascending colour id, the documented
+    normalisation), `{:.2}` / `{:.3}` proportions, mean = Σfreq / n_unique, thresholds `>` (default) and `>=` (-g)."""
+    rng = np.random.default_rng(91)
+    C = 9
+    for case in range(200):
+        ix = orc.Index(1000, 2, 21, C)
+        n_ref = [int(x) for x in rng.integers(0 if case % 10 == 0 else 1, 5000, C)]
+        for c in range(C):
+            ix.set_color(c, f"genome_{c}", n_ref[c])
+        num_kmers = int(rng.integers(1, 6000))
+        hits = rng.integers(0, 5000, C).astype(np.uint64)
+        hits[rng.random(C) < 0.3] = 0
+        nu = np.minimum(hits, rng.integers(0, 3000, C).astype(np.uint64))
+        nu[rng.random(C) < 0.3] = 0
+        sf = (nu * rng.integers(1, 400, C).astype(np.uint64) + rng.integers(0, 7, C).astype(np.uint64)) * (nu > 0)
+        modes = rng.integers(1, 300, C).astype(np.uint64) * (nu > 0)
+        cov = float(rng.choice([0.35, 0.0, 0.9, 0.5, 1.0]))
+        want = []
+        for c in range(C):
+            if hits[c] == 0:
+                continue
+            g = float("inf") if n_ref[c] == 0 else int(hits[c]) / n_ref[c]
+            if g > cov:
+                mean = int(sf[c]) / int(nu[c]) if nu[c] else 0.0
+                want.append(f"q.fq\t{num_kmers}\tgenome_{c}\t{g:.2f}\t{mean:.2f}\t{int(modes[c])}\t{int(nu[c])}")
+        got = ix.generate_report("q.fq", hits, nu, sf, modes, num_kmers, cov)
+        assert got.splitlines() == want, case
+        want = [f"q.fq\tgenome_{c}\t{num_kmers}\t{int(hits[c]) / num_kmers:.3f}" for c in range(C)
+                if hits[c] and int(hits[c]) / num_kmers >= cov]
+        assert ix.generate_report_gene("q.fq", hits, num_kmers, cov).splitlines() == want, case
+    # mode (reports.rs:65-77): the most frequent multiplicity among a colour's unique k-mers; ties -> the smallest value
+    uc = np.array([0, 0, 0, 1, 1, 0xFFFFFFFF, 2, 2], np.uint32)
+    fr = np.array([5, 7, 5, 9, 8, 5, 4, 4], np.uint64)
+    assert list(orc.unique_modes(uc, fr, 4)) == [5, 8, 4, 0]
