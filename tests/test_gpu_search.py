@@ -246,3 +246,49 @@ def test_put_records_parses_bxi_rows_on_the_device(orc, hip_ctx, tmp_path):
             with pytest.raises(Exception):
                 hx.put_records(records[:5 * rec] + rb)
             hx.close()
+
+
+def test_index_shared_by_two_contexts_on_two_threads(orc, hip_ctx):
+    """A finalized index is read-only: a second context (own stream and scratch) on another host thread searches and classifies
+    against it at the same time as the first, and both get the oracle's answers."""
+    import threading
+
+    import colorid_amd
+    from test_gpu_readid import pack_reads
+    rng = np.random.default_rng(17)
+    oix = random_index(orc, rng, 60_013, 3, 27, 200, density=0.25, zero_row_frac=0.1)
+    kmers = random_kmers(rng, 40_000, 27)
+    plant(oix, rng, kmers[:8000], frac=1.0)
+    freq = rng.integers(1, 9, len(kmers)).astype(np.uint32)
+    hx = to_hip_index(hip_ctx, oix)
+    want = oix.search_count(kmers, freq.astype(np.uint64))
+    reads = [[kmers[i:i + 5].tobytes()] for i in range(0, 3000, 5)]
+    bases, so, r0 = pack_reads(reads)
+    want_r = oix.readid_counts(bases, so, r0, 1, 3)
+    ctx2 = colorid_amd.Context(0)
+    errors = []
+
+    def worker(ctx, n_iter):
+        try:
+            lib = ctx.lib
+            for _ in range(n_iter):
+                hits = np.zeros(200, np.uint64); nu = np.zeros(200, np.uint64); sf = np.zeros(200, np.uint64)
+                uc = np.zeros(len(kmers), np.uint32)
+                colorid_amd.hip.check(lib.cid_search_count(ctx.h, hx.h, kmers.ctypes.data, freq.ctypes.data, len(kmers), hits.ctypes.data,
+                                                           nu.ctypes.data, sf.ctypes.data, uc.ctypes.data))
+                assert all(np.array_equal(a, b) for a, b in zip(want, (hits, nu, sf, uc)))
+                rep = np.zeros((len(reads), 201), np.uint32); nk = np.zeros(len(reads), np.uint32); st = np.zeros(len(reads), np.uint8)
+                colorid_amd.hip.check(lib.cid_readid_count(ctx.h, hx.h, bases.ctypes.data, so.ctypes.data, len(so) - 1, r0.ctypes.data,
+                                                           len(reads), 1, 3, rep.ctypes.data, nk.ctypes.data, st.ctypes.data))
+                assert np.array_equal(rep, want_r[0]) and np.array_equal(nk, want_r[1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(c, 15)) for c in (hip_ctx, ctx2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    ctx2.close()
+    hx.close()
