@@ -59,16 +59,20 @@ __device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, ui
 // Sub-passes of a read's search whose row loads are in flight together.  Measured on configs[2] (1 M x 150 bp): 2 costs 24 more
 // VGPRs than 1 and is no faster; 1 lets k_readid fit 96 VGPRs = 5 waves per SIMD, which is (6.13 vs 6.43-6.74 ms).
 constexpr int kReadRunUnroll = 1;
-constexpr int kReadPlanes = 3;  // a lane adds one word per sub-pass: drained every 7 additions
+// Counter planes per lane (drained every 2^planes - 1 additions; a lane adds one word per sub-pass).  k_readid comes in two
+// register budgets: 3 planes in 96 VGPRs (5 waves per SIMD), or 2 planes in 80 VGPRs (6 waves per SIMD) when six workgroups'
+// LDS fit a CU — configs[2], 1 M x 150 bp single-end: 5.8 ms vs 6.1 ms; paired reads need more LDS and stay on the first.
+constexpr int kReadPlanes = 3;
+constexpr int kReadPlanesDense = 2;
 
 
 // The in-order search (read_id_mt_pe.rs:66-102 classic / :104-165 sampled) over a dense run of distinct k-mers: k-mer j (0 <= j < count, order index q_base + j) has its row
 // numbers at ridx[s*stride + j].  U sub-passes (U * 64/LPR k-mers) have all their row loads issued before the first is
 // consumed: a read's search is a chain of dependent gather rounds, and what bounds the kernel is how many of them there are.
-template <int LOG_LPR, bool NARROW, int U>
+template <int LOG_LPR, bool NARROW, int U, int PLANES = kReadPlanes>
 __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t rs, uint32_t n, uint32_t C, uint32_t S, const uint32_t *ridx,
                                                   uint32_t stride, uint32_t count, uint32_t q_base, uint32_t *hist, bool &stopped,
-                                                  VCount<kReadPlanes, NARROW> &vc, V16 &R, int lane) {
+                                                  VCount<PLANES, NARROW> &vc, V16 &R, int lane) {
     constexpr int LPR = 1 << LOG_LPR;
     constexpr int KPW = kWave / LPR;
     if (stopped || !count) return;
@@ -128,8 +132,8 @@ __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t 
 }
 
 // Output of one read: drain the counters, copy the histogram to the report row, clear it for the next read.
-template <bool NARROW, bool WIDE>
-__device__ __forceinline__ void readid_finish_read(VCount<kReadPlanes, NARROW> &vc, uint32_t *hist, uint32_t col_word, uint32_t *row_out,
+template <bool NARROW, bool WIDE, int PLANES = kReadPlanes>
+__device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, uint32_t *hist, uint32_t col_word, uint32_t *row_out,
                                                    uint32_t C, int lane) {
     if constexpr (!WIDE) {
         vc.drain(hist, col_word);
@@ -141,8 +145,9 @@ __device__ __forceinline__ void readid_finish_read(VCount<kReadPlanes, NARROW> &
 // ---- k_readid: reads without lower-case bases, k <= 32.  Per-wave LDS: bases | ridx (WIDE only: 64*n) | hist | rall (not
 // WIDE: win_cap*n) | table keys + indices | 2-bit bases | bad-base bits.  A read with a lower-case base (its case must be
 // kept) is appended to p.redo_list for k_readid_bytes.
-template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI>
-__global__ __launch_bounds__(kBlock, 5) void k_readid(ReadIdParams p) {
+template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE>
+__global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p) {
+    constexpr int PLANES = DENSE ? kReadPlanesDense : kReadPlanes;
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
     constexpr uint32_t RS = NARROW ? 1u : 2u * LPR;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid(ReadIdParams p) {
         uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
         uint32_t wbase = 0;    // windows enumerated so far (first-occurrence order index)
         bool stopped = false;  // an absent row was met: nothing after it is searched
-        VCount<kReadPlanes, NARROW> vc;
+        VCount<PLANES, NARROW> vc;
         vc.clear();
         V16 R{0, 0};           // colours seen in the first S k-mers (this lane's slice)
         if constexpr (WIDE) {
@@ -278,9 +283,9 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid(ReadIdParams p) {
         if constexpr (!WIDE) {
             // the set is complete: search its nd k-mers in order, several sub-passes of row loads in flight at a time
             wave_lds_fence();
-            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane);
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane);
         }
-        readid_finish_read<NARROW, WIDE>(vc, hist, col_word, row_out, C, lane);
+        readid_finish_read<NARROW, WIDE, PLANES>(vc, hist, col_word, row_out, C, lane);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
 }
@@ -470,7 +475,7 @@ struct BaseReader {  // a key that lives in HBM as a stretch of the read (forwar
 };
 
 template <int LOG_LPR, bool NARROW, bool WIDE = false>
-__global__ __launch_bounds__(kBlock, 4) void k_readid_list(ReadIdListParams p) {
+__global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -549,26 +554,32 @@ static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int w
     return hipGetLastError();
 }
 
-template <bool MINI>
+template <bool MINI, bool DENSE>
 static hipError_t launch_readid_packed(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
-    if (p.rs > 128) return launch_readid_one(k_readid<0, false, true, MINI>, p, wpb, grid, stream);
-    if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, MINI>, p, wpb, grid, stream);
+    if (p.rs > 128) return launch_readid_one(k_readid<0, false, true, MINI, DENSE>, p, wpb, grid, stream);
+    if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, MINI, DENSE>, p, wpb, grid, stream);
     switch (log2u(p.rs / 2)) {
-    case 0: return launch_readid_one(k_readid<0, false, false, MINI>, p, wpb, grid, stream);
-    case 1: return launch_readid_one(k_readid<1, false, false, MINI>, p, wpb, grid, stream);
-    case 2: return launch_readid_one(k_readid<2, false, false, MINI>, p, wpb, grid, stream);
-    case 3: return launch_readid_one(k_readid<3, false, false, MINI>, p, wpb, grid, stream);
-    case 4: return launch_readid_one(k_readid<4, false, false, MINI>, p, wpb, grid, stream);
-    case 5: return launch_readid_one(k_readid<5, false, false, MINI>, p, wpb, grid, stream);
-    case 6: return launch_readid_one(k_readid<6, false, false, MINI>, p, wpb, grid, stream);
+    case 0: return launch_readid_one(k_readid<0, false, false, MINI, DENSE>, p, wpb, grid, stream);
+    case 1: return launch_readid_one(k_readid<1, false, false, MINI, DENSE>, p, wpb, grid, stream);
+    case 2: return launch_readid_one(k_readid<2, false, false, MINI, DENSE>, p, wpb, grid, stream);
+    case 3: return launch_readid_one(k_readid<3, false, false, MINI, DENSE>, p, wpb, grid, stream);
+    case 4: return launch_readid_one(k_readid<4, false, false, MINI, DENSE>, p, wpb, grid, stream);
+    case 5: return launch_readid_one(k_readid<5, false, false, MINI, DENSE>, p, wpb, grid, stream);
+    case 6: return launch_readid_one(k_readid<6, false, false, MINI, DENSE>, p, wpb, grid, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
-// k <= 32, no lower-case base: one block per p.reads_per_block reads
+// k <= 32, no lower-case base: one block per p.reads_per_block reads.  The 6-waves-per-SIMD build is used when six
+// workgroups' LDS fit the CU's 160 KiB.
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
     const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
-    return p.m_size ? launch_readid_packed<true>(p, waves_per_block, grid, stream) : launch_readid_packed<false>(p, waves_per_block, grid, stream);
+    const bool dense = 6ull * (size_t)waves_per_block * p.wave_bytes <= 160u * 1024u;
+    if (p.m_size)
+        return dense ? launch_readid_packed<true, true>(p, waves_per_block, grid, stream)
+                     : launch_readid_packed<true, false>(p, waves_per_block, grid, stream);
+    return dense ? launch_readid_packed<false, true>(p, waves_per_block, grid, stream)
+                 : launch_readid_packed<false, false>(p, waves_per_block, grid, stream);
 }
 
 // byte-string keys: the reads listed in p.redo_list (count on the device), or all of them
