@@ -1,6 +1,8 @@
-"""Randomised differential tests: random index shapes (k, hashes, colours, Bloom size, minimizers) and random, awkward reads
+"""Randomised differential tests (FUZZ_SEED0 / FUZZ_N in the environment run a longer campaign): random index shapes (k, hashes, colours, Bloom size, minimizers) and random, awkward reads
 (lengths around k, empty mates, N runs, lower case, repeats, a few reads long enough for the sort-based path) through
 cid_readid_count and cid_search_count / cid_search_perfect, each compared bit for bit with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -39,7 +41,7 @@ def random_read(rng, genome, k):
     return a.tobytes()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24))))
 def test_readid_random_shapes(orc, hip_ctx, seed):
     import colorid_amd
     rng = np.random.default_rng(1000 + seed)
@@ -75,7 +77,7 @@ def test_readid_random_shapes(orc, hip_ctx, seed):
     hx.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24)) // 2))
 def test_search_random_shapes(orc, hip_ctx, seed):
     rng = np.random.default_rng(2000 + seed)
     k = int(rng.choice([1, 7, 16, 17, 31, 32, 33, 48, 97, 128]))
