@@ -90,7 +90,8 @@ def test_search_random_shapes(orc, hip_ctx, seed):
     alphabet = np.frombuffer(b"ACGTacgtN", np.uint8) if seed % 2 else ACGT
     K = int(rng.integers(1, 3000))
     kmers = alphabet[rng.integers(0, len(alphabet), (K, k))]
-    for j in np.flatnonzero(rng.random(K) < 0.7):
+    planted = np.flatnonzero(rng.random(K) < 0.7)
+    for j in planted:
         for c in rng.choice(C, size=min(C, int(rng.integers(1, 4))), replace=False):
             oix.insert(int(c), kmers[j].tobytes())
     freq = rng.integers(1, 1000, K).astype(np.uint32)
@@ -99,7 +100,7 @@ def test_search_random_shapes(orc, hip_ctx, seed):
     got = hx.search_count(kmers, freq)
     for w, g in zip(want, got):
         assert np.array_equal(w, g)
-    assert want[0].sum() > 0
+    assert want[0].sum() > 0 or len(planted) == 0
     pw, pm = oix.search_perfect(kmers)
     gw, gm = hx.search_perfect(kmers)
     assert pm == gm and np.array_equal(pw, gw)
