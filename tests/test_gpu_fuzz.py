@@ -110,3 +110,38 @@ def test_search_random_shapes(orc, hip_ctx, seed):
         gw, gm = hx.search_perfect(kmers[sub[:1]])
         assert pm == gm and not gm and np.array_equal(pw, gw)
     hx.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24)) // 2))
+def test_kmerset_random_inputs(orc, hip_ctx, seed):
+    """GPU k-mer counting (cid_kmerset) on random sequence sets: FASTA mode (mixed case allowed, upper-cased keys) in several
+    add_seqs calls against kmerize_vector, with clean_map and the multiplicity histogram."""
+    import colorid_amd
+    rng = np.random.default_rng(3000 + seed)
+    k = int(rng.integers(1, 33))
+    alphabets = [b"ACGT", b"ACGTN", b"ACGTacgt", b"ACGTacgtNn", b"AC", b"ACGTRY"]
+    seqs = []
+    for _ in range(int(rng.integers(1, 12))):
+        L = int(rng.choice([0, 1, k - 1, k, k + 1, 50, 300, 2047 + k, 2048 + k, 2049 + k, 5000]))
+        a = alphabets[rng.integers(0, len(alphabets))]
+        s = np.frombuffer(a, np.uint8)[rng.integers(0, len(a), max(L, 0))].tobytes()
+        if rng.random() < 0.3 and len(s) > 10:
+            s = s[:len(s) // 2] * 3
+        seqs.append(s)
+    want = orc.Kmers(k)
+    for s in seqs:
+        want.kmerize_vector(s, 1)
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    cut = int(rng.integers(0, len(seqs) + 1))
+    ks.add_seqs(seqs[:cut], 0)
+    ks.add_seqs(seqs[cut:], 0)
+    assert ks.finalize() == len(want)
+    assert ks.as_dict() == want.as_dict()
+    if len(want):
+        vals, cnts = ks.histogram()
+        wc = want.counts()
+        assert dict(zip(vals.tolist(), cnts.tolist())) == {int(v): int((wc == v).sum()) for v in np.unique(wc)}
+        t = int(rng.integers(0, 4))
+        ks.clean(t)
+        assert ks.as_dict() == want.clean_map(t).as_dict()
+    ks.close()
