@@ -265,6 +265,22 @@ def main():
                          "alg_bytes_per_kmer": alg_bytes_per_kmer,
                          "kernel_ms": kern_ms, "kmers_per_launch": K},
         }
+        if world == 1 and not a.codes:
+            # for the record, not the headline: the same query with the k-mers as the 2-bit codes that GPU k-mer counting
+            # produces (what `colorid search` feeds the kernel for k <= 32): 8 instead of k input bytes per k-mer
+            from colorid_amd._lib import check, vp
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(12):
+                if i == 2:
+                    e0.record(stream)
+                out.zero_()
+                check(hx.lib.cid_search_count_codes_dev(ctx.h, hx.h, vp(codes.data_ptr()), vp(freq.data_ptr()), K, vp(out.data_ptr()),
+                                                        vp(out.data_ptr() + 8 * C), vp(out.data_ptr() + 16 * C), vp(uc.data_ptr())))
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms_codes = e0.elapsed_time(e1) / 10
+            result["config"]["codes_input"] = {"ms_per_step": ms_codes, "kmers_per_s": K / ms_codes * 1e3,
+                                               "note": "2-bit-code input (cid_search_count_codes_dev), 10 steps, not the headline value"}
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
     if result is not None:
