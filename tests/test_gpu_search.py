@@ -292,3 +292,49 @@ def test_index_shared_by_two_contexts_on_two_threads(orc, hip_ctx):
     assert not errors, errors
     ctx2.close()
     hx.close()
+
+
+def test_more_error_behaviour(orc, hip_ctx):
+    """Every misuse comes back as an error code + message (nothing aborts across the ABI): state errors, argument errors,
+    the perfect search without k-mers (src/perfect_search.rs:22-23), inconsistent read batches."""
+    import ctypes as C
+
+    import colorid_amd
+    lib = hip_ctx.lib
+    rng = np.random.default_rng(2)
+    oix = random_index(orc, rng, 5003, 2, 21, 40, density=0.3, zero_row_frac=0.1)
+    hx = to_hip_index(hip_ctx, oix)
+    with pytest.raises(colorid_amd.CidError):                 # finalized indices are immutable
+        hx.put_rows(np.array([1], np.uint64), np.array([[1, 0]], np.uint32))
+    with pytest.raises(colorid_amd.CidError):
+        hx.put_records(b"\x00" * 32)
+    with pytest.raises(colorid_amd.CidError):                 # "needs at least one k-mer"
+        hx.search_perfect(np.zeros((0, 21), np.uint8))
+    hits = np.zeros(40, np.uint64)
+    assert lib.cid_search_count(hip_ctx.h, hx.h, None, None, 5, hits.ctypes.data, None, None, None) < 0      # null k-mers
+    assert lib.cid_search_count(hip_ctx.h, hx.h, None, None, 0, hits.ctypes.data, None, None, None) == 0     # empty batch is fine
+    assert lib.cid_search_count(None, hx.h, None, None, 0, hits.ctypes.data, None, None, None) < 0
+    assert b"null" in lib.cid_last_error()
+    # read batches: offsets must be monotonic and inside the arrays, the stride positive
+    bases = np.frombuffer(b"ACGT" * 50, np.uint8)
+    rep = np.zeros((1, 41), np.uint32); nk = np.zeros(1, np.uint32); st = np.zeros(1, np.uint8)
+
+    def readid(seq_off, read0, n_seqs, n_reads, d=1):
+        so = np.array(seq_off, np.uint64); r0 = np.array(read0, np.uint64)
+        return lib.cid_readid_count(hip_ctx.h, hx.h, bases.ctypes.data, so.ctypes.data, n_seqs, r0.ctypes.data, n_reads, d, 3,
+                                    rep.ctypes.data, nk.ctypes.data, st.ctypes.data)
+    assert readid([0, 200], [0, 1], 1, 1) == 0
+    assert readid([0, 200], [0, 1], 1, 1, d=0) < 0            # stride 0
+    assert readid([200, 0], [0, 1], 1, 1) < 0                 # seq_off not monotonic
+    assert readid([0, 200], [0, 2], 1, 1) < 0                 # read_seq0 points past n_seqs
+    assert readid([0, 200], [1, 0], 1, 1) < 0                 # read_seq0 not monotonic
+    with pytest.raises(colorid_amd.CidError):                 # rows outside the index
+        hx.get_records(5000, 10)
+    mx = colorid_amd.Index(hip_ctx, 5003, 2, 21, 40)
+    with pytest.raises(colorid_amd.CidError):                 # minimizer longer than k
+        mx.set_minimizer(22)
+    mx.close()
+    # the failed calls left the index usable
+    kmers = random_kmers(rng, 100, 21)
+    assert np.array_equal(hx.search_count(kmers)[0], oix.search_count(kmers, None)[0])
+    hx.close()
