@@ -36,6 +36,7 @@ struct BufReader {  // big sequential reads; the file is parsed once, front to b
         }
     }
     void read_exact(uint8_t *dst, size_t n) {   // bulk: what is buffered first, then straight from the file
+        if (n == 0) return;
         const size_t take = std::min(n, end - pos);
         memcpy(dst, buf.data() + pos, take);
         pos += take;

@@ -1,0 +1,32 @@
+# Host-side sanitizer runs of the CLI on a GPU box (GPU ASan is not available on this pool): build tools/bin/colorid_asan and
+# tools/bin/colorid_tsan with g++ -fsanitize=address,undefined / -fsanitize=thread from colorid_amd/csrc/host/*.cpp first.
+set -x
+cd $GRAFT_REPO_ROOT
+W=/tmp/san; mkdir -p $W
+python3 - <<'PY'
+import gzip, numpy as np, os
+rng=np.random.default_rng(1); W="/tmp/san"
+ac=np.frombuffer(b"ACGT",np.uint8)
+with open(f"{W}/refs.tsv","w") as t:
+    gs=[]
+    for g in range(6):
+        s=ac[rng.integers(0,4,200000)].tobytes(); gs.append(s)
+        open(f"{W}/g{g}.fasta","wb").write(b">g%d\n"%g + b"\n".join(s[i:i+70] for i in range(0,len(s),70))+b"\n")
+        t.write(f"genome{g}\t{W}/g{g}.fasta\n")
+def fq(path, n, mate):
+    r=np.random.default_rng(5)
+    with gzip.open(path,"wb",compresslevel=1) as f:
+        for i in range(n):
+            g=gs[r.integers(0,6)]; p=int(r.integers(0,len(g)-300)); L=int(r.integers(30,151))
+            s=g[p:p+L] if mate==0 else g[p+100:p+100+L]
+            f.write(b"@r%d/%d\n"%(i,mate+1)+s+b"\n+\n"+b"I"*len(s)+b"\n")
+fq(f"{W}/r_1.fastq.gz",60000,0); fq(f"{W}/r_2.fastq.gz",60000,1)
+PY
+for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
+  echo "=== $B"
+  export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 TSAN_OPTIONS="report_signal_unsafe=0 second_deadlock_stack=1"
+  $B build -s 2000000 -n 3 -k 27 -b $W/ix -r $W/refs.tsv > $W/build.out 2> $W/build.err; echo "build rc=$?"; tail -3 $W/build.err
+  $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -g -f 0 > $W/s.out 2> $W/s.err; echo "search rc=$?"; grep -c . $W/s.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s.err | head -5
+  $B read_id -b $W/ix.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid -c 5000 > $W/r.out 2> $W/r.err; echo "read_id rc=$?"; wc -l $W/rid_reads.txt; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r.err | head -5
+  $B read_id -b $W/ix.bxi -q $W/r_1.fastq.gz -n $W/rid1 -c 777 > $W/r1.out 2> $W/r1.err; echo "read_id SE rc=$?"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r1.err | head -5
+done
