@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-BIN = os.path.join(ROOT, "colorid_amd", "bin", "colorid")
+BIN = os.environ.get("COLORID_BIN", os.path.join(ROOT, "colorid_amd", "bin", "colorid"))   # COLORID_BIN: e.g. a sanitizer build
 REFS = os.path.join(HERE, "golden", "refs")
 PHAGES = ["Listeria_phage_B021", "Listeria_phage_B051", "Listeria_phage_B056", "Listeria_phage_B545"]
 BANNER = "\n ************** initializing logger *****************\n\n"

@@ -11,7 +11,7 @@ from util import synth_fastq_records, write_fastq_gz
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-BIN = os.path.join(ROOT, "colorid_amd", "bin", "colorid")
+BIN = os.environ.get("COLORID_BIN", os.path.join(ROOT, "colorid_amd", "bin", "colorid"))   # COLORID_BIN: e.g. a sanitizer build
 REFS = os.path.join(HERE, "golden", "refs")
 BANNER = "\n ************** initializing logger *****************\n\n"   # src/main.rs:18
 
