@@ -145,6 +145,39 @@ def fill_background(dev, mat_ptr, m, rs, n_colours, p, seed):
         hip_memcpy(mat_ptr + r0 * rs * 8, words.data_ptr(), words.numel() * 8, 3)
 
 
+def fill_background_fast(dev, mat_ptr, m, rs, n_colours, p, seed, digits=8):
+    """Like fill_background for matrices of tens of GiB: every u64 word is folded from `digits` uniform random words by the
+    AND/OR recurrence over the binary expansion of p (bit probability q / 2^digits, q = round(p * 2^digits)) instead of one
+    float per bit.  Returns the density actually used."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    w64 = (n_colours + 63) // 64
+    q = max(1, round(p * (1 << digits)))
+    tail = n_colours % 64
+    tail_mask = ((1 << tail) - 1) if tail else -1
+    if tail_mask >= 1 << 63:
+        tail_mask -= 1 << 64
+    chunk = max(1, (1 << 27) // max(rs, w64))  # <= 1 GiB per temporary
+    for r0 in range(0, m, chunk):
+        nr = min(chunk, m - r0)
+        acc = torch.zeros((nr, w64), dtype=torch.int64, device=dev)
+        for i in range(digits):  # least significant digit first: P <- (digit + P) / 2
+            w = torch.randint(-2**31, 2**31, (nr, 2 * w64), device=dev, dtype=torch.int32, generator=g).view(torch.int64)
+            acc = (w | acc) if (q >> i) & 1 else (w & acc)
+            del w
+        if tail:
+            acc[:, w64 - 1] &= tail_mask
+        if rs != w64:
+            words = torch.zeros((nr, rs), dtype=torch.int64, device=dev)
+            words[:, :w64] = acc
+        else:
+            words = acc
+        torch.cuda.synchronize()
+        hip_memcpy(mat_ptr + r0 * rs * 8, words.data_ptr(), words.numel() * 8, 3)
+        del words, acc
+    return q / (1 << digits)
+
+
 def main():
     a = parse_args()
     # stdout carries exactly one line, the JSON: RCCL prints a version banner to C stdout (late, when that is a pipe), so

@@ -41,8 +41,8 @@ SIGNATURES = {
     "cid_search_count_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
     "cid_search_perfect": (C.c_int, [vp, vp, vp, C.c_size_t, vp, C.POINTER(C.c_int)]),
     "cid_search_count_codes_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp, vp, vp]),
-    "cid_search_count_stripe_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp, vp]),
-    "cid_search_unique_finalize_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp, vp]),
+    "cid_search_count_stripe_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp]),
+    "cid_search_unique_finalize_dev": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint32, vp, vp, vp]),
     "cid_search_perfect_stripe_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
     "cid_index_row_stride_words": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "cid_kmerset_create": (C.c_int, [vp, C.c_uint32, C.POINTER(vp)]),

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -199,7 +200,7 @@ int check_not_mini(const cid_index *ix) {
 extern "C" {
 
 const char *cid_last_error(void) { return g_err; }
-int cid_abi_version(void) { return 1; }
+int cid_abi_version(void) { return 2; }
 
 int cid_device_count(int *n) {
     if (!n) return fail(CID_ERR_INVALID, "null out");
@@ -470,10 +471,11 @@ int cid_search_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers
 // One colour stripe of a wider index: per-colour hits are final; per-k-mer popcounts and unique
 // candidates accumulate across the stripes' calls and are resolved by cid_search_unique_finalize_dev.
 int cid_search_count_stripe_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
-                                uint32_t colour_base, uint64_t *d_hits, uint32_t *d_pop_total, uint32_t *d_cand) {
+                                uint32_t colour_base, uint64_t *d_hits, uint32_t *d_fact) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
-    if (!d_hits || !d_pop_total || !d_cand || (n_kmers && !d_kmers && !d_codes)) return fail(CID_ERR_INVALID, "null argument");
+    if ((rc = check_not_mini(ix))) return rc;
+    if (!d_hits || !d_fact || (n_kmers && !d_kmers && !d_codes)) return fail(CID_ERR_INVALID, "null argument");
     if (d_kmers && !aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
     if (d_codes && ix->k > 32) return fail(CID_ERR_UNSUPPORTED, "2-bit codes need k_size <= 32");
     HIP_TRY(hipSetDevice(c->device));
@@ -481,19 +483,19 @@ int cid_search_count_stripe_dev(cid_ctx *c, const cid_index *ix, const uint8_t *
     rc = fill_search_params(c, ix, p);
     if (rc) return rc;
     p.kmers = d_kmers; p.codes = d_codes; p.n_kmers = n_kmers; p.hits = d_hits;
-    p.colour_base = colour_base; p.pop_total = d_pop_total; p.cand = d_cand;
+    p.colour_base = colour_base; p.fact = d_fact;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
     HIP_TRY(hipMemsetAsync(d_hits, 0, (size_t)ix->n_colors * 8, c->stream));
     HIP_TRY(cid::launch_search_count(p, c->stream));
     return CID_OK;
 }
 
-int cid_search_unique_finalize_dev(cid_ctx *c, const uint32_t *d_pop_total, const uint32_t *d_cand, const uint32_t *d_freq,
+int cid_search_unique_finalize_dev(cid_ctx *c, const uint32_t *d_fact, const uint32_t *d_freq,
                                    size_t n_kmers, uint32_t n_colors_total, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
                                    uint32_t *d_unique_colour) {
-    if (!c || (n_kmers && (!d_pop_total || !d_cand)) || n_colors_total == 0) return fail(CID_ERR_INVALID, "bad argument");
+    if (!c || (n_kmers && !d_fact) || n_colors_total == 0 || n_colors_total > (1u << 20)) return fail(CID_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(cid::launch_unique_finalize(d_pop_total, d_cand, d_freq, n_kmers, n_colors_total, d_n_unique, d_sum_unique_freq,
+    HIP_TRY(cid::launch_unique_finalize(d_fact, d_freq, n_kmers, n_colors_total, d_n_unique, d_sum_unique_freq,
                                         d_unique_colour, c->stream));
     return CID_OK;
 }
@@ -504,7 +506,9 @@ int cid_search_perfect_stripe_dev(cid_ctx *c, const cid_index *ix, const uint8_t
                                   uint64_t *d_and_words, uint32_t *d_zero_acc) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
+    if ((rc = check_not_mini(ix))) return rc;
     if (!d_and_words || !d_zero_acc || (n_kmers && !d_kmers && !d_codes)) return fail(CID_ERR_INVALID, "null argument");
+    if (d_codes && ix->k > 32) return fail(CID_ERR_UNSUPPORTED, "2-bit codes need k_size <= 32");
     if (d_kmers && !aligned16(d_kmers)) return fail(CID_ERR_INVALID, "d_kmers must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
     void *d_scratch;
@@ -695,6 +699,8 @@ static size_t readid_need(const cid_index *ix, uint32_t stride_d, uint32_t start
 }
 
 constexpr size_t kLdsBytes = 160u * 1024u;
+// device scratch for dense read_id report rows per launch: cid_readid_count slices larger batches, the sparse form refuses them
+static size_t kDenseReportBytes = getenv("CID_DENSE_REPORT_BYTES") ? strtoull(getenv("CID_DENSE_REPORT_BYTES"), nullptr, 10) : (2ull << 30);
 // k_readid keeps a read's set in one wave's LDS.  With fewer than two waves per workgroup (one per CU) the gathers are no
 // longer hidden and the sort-based path is faster (tools/bench_readlen.py: 150 Mbases of 4 kb reads 50.7 vs 24.5 ms; 2 kb
 // reads, two waves, 30.3 vs 36.7 ms), so such reads are routed there.
@@ -856,15 +862,41 @@ int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, cons
                      uint32_t *report, uint32_t *n_kmers, uint8_t *status) {
     if (n_reads == 0) return check_ready(c, ix);
     if (!report || !n_kmers || !status) return fail(CID_ERR_INVALID, "null argument");
-    uint32_t *d_rep, *d_nk;
-    uint8_t *d_st;
-    int rc = readid_to_device(c, ix, bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, &d_rep, &d_nk, &d_st);
-    if (rc) return rc;
+    if (!c || !ix || !seq_off || !read_seq0) return fail(CID_ERR_INVALID, "null argument");
+    // A dense report row has n_colors+1 counters (4 GB per million reads at 1024 colours): the batch is worked through in
+    // slices whose rows fit kDenseReportBytes of device scratch; a read's row does not depend on its neighbours.
     const size_t C1 = (size_t)ix->n_colors + 1;
-    HIP_TRY(hipMemcpyAsync(report, d_rep, n_reads * C1 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(status, d_st, n_reads, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    size_t per = kDenseReportBytes / (C1 * 4);
+    if (per == 0) per = 1;
+    std::vector<uint64_t> so, r0v;
+    for (size_t r0 = 0; r0 < n_reads; r0 += per) {
+        const size_t nr = n_reads - r0 < per ? n_reads - r0 : per;
+        const uint64_t *so_p = seq_off, *r0_p = read_seq0;
+        const uint8_t *bases_p = bases;
+        size_t ns = n_seqs;
+        if (nr != n_reads) {   // rebase the slice: its own seq_off / read_seq0 starting at 0
+            if (read_seq0[r0 + nr] > n_seqs || read_seq0[r0] > read_seq0[r0 + nr]) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
+            const uint64_t s0 = read_seq0[r0], s1 = read_seq0[r0 + nr];
+            ns = (size_t)(s1 - s0);
+            so.resize(ns + 1);
+            for (size_t i = 0; i <= ns; ++i) {
+                if (seq_off[s0 + i] < seq_off[s0]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)(s0 + i));
+                so[i] = seq_off[s0 + i] - seq_off[s0];
+            }
+            r0v.resize(nr + 1);
+            for (size_t i = 0; i <= nr; ++i) r0v[i] = read_seq0[r0 + i] - s0;
+            so_p = so.data(); r0_p = r0v.data();
+            bases_p = bases ? bases + seq_off[s0] : nullptr;
+        }
+        uint32_t *d_rep, *d_nk;
+        uint8_t *d_st;
+        int rc = readid_to_device(c, ix, bases_p, so_p, ns, r0_p, nr, stride_d, start_sample, &d_rep, &d_nk, &d_st);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(report + r0 * C1, d_rep, nr * C1 * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n_kmers + r0, d_nk, nr * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(status + r0, d_st, nr, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return CID_OK;
 }
 
@@ -875,6 +907,9 @@ int cid_readid_count_sparse(cid_ctx *c, const cid_index *ix, const uint8_t *base
     *n_entries = 0;
     if (n_reads == 0) { int rc0 = check_ready(c, ix); if (rc0 == CID_OK) { c->sp_rows = 0; c->sp_entries = 0; } return rc0; }
     if (!n_kmers || !status) return fail(CID_ERR_INVALID, "null argument");
+    if (ix && (double)n_reads * ((double)ix->n_colors + 1.0) * 4.0 > 64.0 * (double)(1ull << 30))
+        return fail(CID_ERR_UNSUPPORTED, "%zu reads x %u colours need more than 64 GiB of dense report rows on the device: use smaller batches",
+                    n_reads, ix->n_colors);
     uint32_t *d_rep, *d_nk;
     uint8_t *d_st;
     int rc = readid_to_device(c, ix, bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, &d_rep, &d_nk, &d_st);

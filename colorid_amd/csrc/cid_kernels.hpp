@@ -34,8 +34,7 @@ struct SearchParams {
     // colour-striped indices (this index holds colours [colour_base, colour_base + n_colors) of a wider one): the
     // per-k-mer facts that need every stripe are accumulated in caller-provided arrays instead of being decided here
     uint32_t colour_base;
-    uint32_t *pop_total;   // [n_kmers] += popcount of this stripe's AND word            (a5; nullptr = not striped)
-    uint32_t *cand;        // [n_kmers]  = global colour id when this stripe's popcount is exactly 1
+    uint32_t *fact;        // [n_kmers] packed stripe fact, see stripe_fact_merge            (a5; nullptr = not striped)
     uint32_t *zero_acc;    // [n_kmers] &= bit s set iff row s is all-zero in this stripe  (a4; nullptr = not striped)
 };
 
@@ -99,7 +98,7 @@ size_t search_smem_bytes(const SearchParams &p);
 hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream);
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream);
 hipError_t launch_readid_bytes(const ReadIdParams &p, int waves_per_block, int grid, hipStream_t stream);
-hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
+hipError_t launch_unique_finalize(const uint32_t *fact, const uint32_t *freq, uint64_t n_kmers,
                                   uint32_t n_colors_total, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour,
                                   hipStream_t stream);
 int grid_for(uint64_t n_kmers, uint32_t tiles_per_block);

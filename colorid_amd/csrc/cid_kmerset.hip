@@ -119,6 +119,10 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+__global__ void k_flag_saturated(const uint32_t *counts, const uint64_t *n, int *flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *n && counts[i] == 0xFFFFFFFFu) atomicOr(flag, 1);
+}
 __global__ void k_flag_gt(const uint32_t *counts, uint64_t t, uint8_t *flags, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = counts[i] > t ? 1 : 0;
@@ -190,11 +194,16 @@ struct DevBuf {  // scoped device scratch from the ctx's block cache (hipMalloc 
 
 unsigned grid_for_n(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
+struct SatAdd {   // u32 multiplicities saturate instead of wrapping
+    __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { const uint32_t s = a + b; return s < a ? 0xFFFFFFFFu : s; }
+};
+
 // merge the raw window codes into (codes, counts): sort + run-length (first merge) or sort pairs + reduce by key
 int compact(cid_kmerset *ks) {
     if (ks->n_raw == 0) return CID_OK;
     hipStream_t st = cid::ctx_stream(ks->ctx);
     const size_t total = ks->n + ks->n_raw;
+    if (total >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "%zu k-mer windows and distinct k-mers in one merge (limit 2^32 - 1): add fewer sequences per set", total);
     DevBuf<uint64_t> uniq(ks->ctx);
     DevBuf<uint32_t> agg(ks->ctx);
     DevBuf<uint64_t> d_count(ks->ctx);
@@ -227,12 +236,16 @@ int compact(cid_kmerset *ks) {
         if ((rc = tmp.alloc(tmp_bytes))) return rc;
         HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin.p, kout.p, vin.p, vout.p, total, 0u, ks->end_bit, st));
         size_t tmp2 = 0;
-        HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p));
+        HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
         DevBuf<uint8_t> t2(ks->ctx);
         if ((rc = t2.alloc(tmp2))) return rc;
-        HIP_TRY(rocprim::reduce_by_key(t2.p, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, rocprim::plus<uint32_t>(),
-                                       rocprim::equal_to<uint64_t>(), st));
+        HIP_TRY(rocprim::reduce_by_key(t2.p, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
+        // multiplicities are u32 (the reference: usize): a sum that saturated cannot be reported faithfully
+        hipLaunchKernelGGL(cid::k_flag_saturated, dim3(grid_for_n(total)), dim3(256), 0, st, agg.p, d_count.p, ks->d_flags + 1);
+        int sat = 0;
+        HIP_TRY(hipMemcpyAsync(&sat, ks->d_flags + 1, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (sat) return fail(CID_ERR_UNSUPPORTED, "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
     }
     uint64_t n_runs = 0;
     HIP_TRY(hipMemcpy(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost));

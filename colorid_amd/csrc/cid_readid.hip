@@ -131,6 +131,18 @@ __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t 
     }
 }
 
+// The per-wave LDS regions were sized by the caller's longest read (bases_cap = that + 16 rounded up, win_cap windows): a read
+// beyond them must not be staged (wave-uniform test).
+__device__ __forceinline__ bool read_exceeds_caps(const ReadIdParams &p, uint64_t s0, uint64_t s1, uint32_t tb) {
+    if ((uint64_t)tb + 16u > p.bases_cap) return true;
+    uint64_t win = 0;
+    for (uint64_t s = s0; s < s1; ++s) {
+        const uint64_t len = p.seq_off[s + 1] - p.seq_off[s];
+        if (len >= p.k) win += (len - p.k) / p.stride_d + 1;
+    }
+    return win > p.win_cap;
+}
+
 // Output of one read: drain the counters, copy the histogram to the report row, clear it for the next read.
 template <bool NARROW, bool WIDE, int PLANES = kReadPlanes>
 __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, uint32_t *hist, uint32_t col_word, uint32_t *row_out,
@@ -190,6 +202,12 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             continue;
         }
         const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
+        if (read_exceeds_caps(p, s0, s1, tb)) {   // the caller understated max_read_bytes / max_read_windows: leave the read alone
+            if constexpr (!WIDE)
+                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+            if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 3; }
+            continue;
+        }
         bool lower = false;
         for (uint32_t i = lane; i < tb; i += kWave) {
             const uint8_t b = p.bases[g0 + i];
@@ -337,6 +355,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
             continue;
         }
         const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
+        if (read_exceeds_caps(p, s0, s1, tb)) {
+            if constexpr (!WIDE)
+                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+            if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 3; }
+            continue;
+        }
         for (uint32_t i = lane; i < tb; i += kWave) s_bases[i] = p.bases[g0 + i];
         wave_lds_fence();
 

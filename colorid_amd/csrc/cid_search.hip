@@ -22,6 +22,21 @@
 namespace cid {
 
 // ------------------------------------------------------------------------------------------------
+// Colour stripes: the one per-k-mer fact that needs every stripe is "the AND word over ALL colours has exactly one set bit"
+// (src/batch_search_pe.rs:75-82).  It travels as one u32 per k-mer,  n << 26 | (colour + 1),  where n = min(set bits, 2) over
+// the stripes seen so far (saturating inside a GPU) and the colour field is only kept while n == 1.  Across GPUs the words are
+// simply SUMMED (one RCCL all-reduce): the n fields add up to <= 2 * ranks (6 bits: up to 31 ranks) and, whenever the total is
+// 1, exactly one rank contributed a colour field, so the low 26 bits are that colour + 1 (colours < 2^20, so up to 64 ranks'
+// fields cannot carry into n).
+constexpr uint32_t kFactShift = 26;
+constexpr uint32_t kFactColourMask = (1u << kFactShift) - 1u;
+__device__ __forceinline__ uint32_t stripe_fact_merge(uint32_t old, uint32_t pop, uint32_t global_colour) {
+    const uint32_t n = min((old >> kFactShift) + min(pop, 2u), 2u);
+    const uint32_t col = n == 1u ? (pop == 1u ? global_colour + 1u : (old & kFactColourMask)) : 0u;
+    return (n << kFactShift) | col;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a5: proportional search  (src/batch_search_pe.rs:45-84, :125-164)
 
 template <int LOG_LPR, bool NARROW>
@@ -59,9 +74,9 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
     for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
         const uint64_t first = tile * kWave;
         // the tile's multiplicities: one coalesced load that is back long before the first sub-pass needs it
-        const uint32_t my_freq = (p.freq && p.want_unique && !p.pop_total && first + lane < p.n_kmers) ? p.freq[first + lane] : 1u;
+        const uint32_t my_freq = (p.freq && p.want_unique && !p.fact && first + lane < p.n_kmers) ? p.freq[first + lane] : 1u;
         stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
-        if (!p.pop_total) { s_pop[lane] = my_freq; wave_lds_fence(); }
+        if (!p.fact) { s_pop[lane] = my_freq; wave_lds_fence(); }
 #pragma unroll 1
         for (int sub = 0; sub < LPR; ++sub) {
             const int kk = sub * KPW + (lane >> LOG_LPR);
@@ -75,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
             const uint32_t total = group_sum<LOG_LPR>(pc);
             vc.add(a);  // hits[c] += bit c, for this lane's colours
             if (vc.full()) vc.drain(s_hits, col_word);
-            if (p.pop_total) {  // striped: uniqueness is decided after all stripes (k_unique_finalize)
+            if (p.fact) {  // striped: uniqueness is decided after all stripes (k_unique_finalize)
                 if (live) {
                     if (col == 0) { s_pop[kk] = total; s_res[kk] = 0xFFFFFFFFu; }
                     if (total == 1u && pc == 1u)   // (after col 0's store in program order: LDS ops of a wave execute in order)
@@ -96,13 +111,12 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
                 }
             }
         }
-        if (p.pop_total || (p.want_unique && p.unique_colour)) {   // the tile's per-k-mer results, one coalesced store
+        if (p.fact || (p.want_unique && p.unique_colour)) {   // the tile's per-k-mer results, one coalesced store
             wave_lds_fence();
             const uint64_t kmer = first + lane;
             if (kmer < p.n_kmers) {
-                if (p.pop_total) {
-                    p.pop_total[kmer] += s_pop[lane];
-                    if (s_res[lane] != 0xFFFFFFFFu) p.cand[kmer] = s_res[lane];
+                if (p.fact) {
+                    p.fact[kmer] = stripe_fact_merge(p.fact[kmer], s_pop[lane], s_res[lane]);
                 } else {
                     __builtin_nontemporal_store(s_res[lane], &p.unique_colour[kmer]);   // written once, never read here
                 }
@@ -231,7 +245,11 @@ __global__ __launch_bounds__(kBlock) void k_search_count_wide(SearchParams p) {
                 w = a.y;
                 while (w) { atomicAdd(reinterpret_cast<unsigned long long *>(&p.hits[col_word * 64u + 64u + (uint32_t)__builtin_ctzll(w)]), 1ull); w &= w - 1; }
             }
-            if (p.want_unique) {
+            if (p.fact) {  // striped: uniqueness is decided after all stripes (k_unique_finalize)
+                const uint32_t total = wave_sum_u32(mine);
+                const uint32_t gcol = (uint32_t)__shfl((int)(p.colour_base + ucol), __builtin_ctzll(__ballot(mine != 0) | (1ull << 63)), kWave);
+                if (lane == 0) p.fact[kmer] = stripe_fact_merge(p.fact[kmer], total, gcol);
+            } else if (p.want_unique) {
                 const uint32_t total = wave_sum_u32(mine);
                 if (total == 1u) {
                     if (mine == 1u) {
@@ -278,7 +296,10 @@ __global__ __launch_bounds__(kBlock) void k_search_perfect_wide(SearchParams p) 
                 s_and[col_word + 1] &= a.y;
                 zml &= zm;
             }
-            if (wave_and_u32(zml) & seeds) missing = 1;   // a row is absent iff it is zero in every step of every lane
+            const uint32_t all_zero = wave_and_u32(zml) & seeds;   // a row is absent iff it is zero in every step of every lane
+            if (p.zero_acc) {  // striped: a row is absent only if it is zero in every stripe
+                if (lane == 0) p.zero_acc[first + kk] &= all_zero;
+            } else if (all_zero) missing = 1;
         }
     }
     wave_lds_fence();
@@ -288,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_search_perfect_wide(SearchParams p) 
 
 // Striped a5 epilogue: a k-mer hits exactly one colour of the WHOLE index iff the stripes' popcounts sum to 1.
 // Per-block LDS histograms (when the whole colour range fits) keep the global atomics to one per colour per block.
-__global__ __launch_bounds__(256) void k_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq,
+__global__ __launch_bounds__(256) void k_unique_finalize(const uint32_t *fact, const uint32_t *freq,
                                                         uint64_t n_kmers, uint32_t n_colors_total, uint32_t use_lds, uint64_t per_block,
                                                         uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -301,16 +322,17 @@ __global__ __launch_bounds__(256) void k_unique_finalize(const uint32_t *pop_tot
     const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
     const uint64_t i1 = i0 + per_block < n_kmers ? i0 + per_block : n_kmers;
     for (uint64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        if (pop_total[i] == 1u) {
-            const uint32_t c = cand[i];
-            const unsigned long long f = freq ? freq[i] : 1u;
+        const uint32_t f = fact[i];
+        if ((f >> kFactShift) == 1u) {
+            const uint32_t c = (f & kFactColourMask) - 1u;
+            const unsigned long long fq = freq ? freq[i] : 1u;
             if (unique_colour) unique_colour[i] = c;
             if (use_lds) {
                 atomicAdd(&s_nu[c], 1u);
-                atomicAdd(&s_sum[c], f);
+                atomicAdd(&s_sum[c], fq);
             } else {
                 if (n_unique) atomicAdd(reinterpret_cast<unsigned long long *>(&n_unique[c]), 1ull);
-                if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), f);
+                if (sum_unique_freq) atomicAdd(reinterpret_cast<unsigned long long *>(&sum_unique_freq[c]), fq);
             }
         } else if (unique_colour) {
             unique_colour[i] = 0xFFFFFFFFu;
@@ -327,7 +349,7 @@ __global__ __launch_bounds__(256) void k_unique_finalize(const uint32_t *pop_tot
     }
 }
 
-hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *cand, const uint32_t *freq, uint64_t n_kmers,
+hipError_t launch_unique_finalize(const uint32_t *fact, const uint32_t *freq, uint64_t n_kmers,
                                   uint32_t n_colors_total, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour,
                                   hipStream_t stream) {
     if (n_kmers == 0) return hipSuccess;
@@ -341,7 +363,7 @@ hipError_t launch_unique_finalize(const uint32_t *pop_total, const uint32_t *can
     uint64_t per_block = (n_kmers + 4095) / 4096;
     if (per_block < 4096) per_block = 4096;
     const unsigned grid = (unsigned)((n_kmers + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_unique_finalize, dim3(grid), dim3(256), shmem, stream, pop_total, cand, freq, n_kmers, n_colors_total, use_lds, per_block,
+    hipLaunchKernelGGL(k_unique_finalize, dim3(grid), dim3(256), shmem, stream, fact, freq, n_kmers, n_colors_total, use_lds, per_block,
                        n_unique, sum_unique_freq, unique_colour);
     return hipGetLastError();
 }

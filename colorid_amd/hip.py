@@ -20,10 +20,12 @@ class Context:
         check(self.lib.cid_ctx_create(device_id, C.byref(h)))
         self.h = h
         self.device_id = device_id
+        self.stream = None                   # a borrowed hipStream_t (set_stream), or None = the ctx's own stream
         self._children = weakref.WeakSet()   # indices / k-mer sets made from this ctx: they borrow its scratch, so they go first
 
     def set_stream(self, hip_stream):
         check(self.lib.cid_ctx_set_stream(self.h, vp(hip_stream) if hip_stream else None))
+        self.stream = hip_stream or None
 
     def synchronize(self):
         check(self.lib.cid_ctx_synchronize(self.h))

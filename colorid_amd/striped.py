@@ -1,27 +1,37 @@
 """Colour-striped BIGSI search: the index is split by colour ranges into stripes, several per GPU
-(indices wider than 8192 colours) and/or one set of stripes per rank (indices larger than one GPU's HBM).
+(any width, also beyond 8192 colours) and/or one set of stripes per rank (indices larger than one GPU's HBM).
 
 Every stripe sees every k-mer.  Per-colour hits of a stripe are final.  The two per-k-mer facts that need all stripes —
-"the AND word has exactly one set bit" and "some row is absent" — are accumulated in u32[K] device arrays by the stripe
-kernels and combined across ranks with three small-footprint collectives (RCCL over xGMI; gloo in the CPU tests):
-    pop_total : all_reduce(SUM)     cand : all_reduce(MAX)     hits : all_reduce(SUM) of the zero-padded full vector
+"the AND word has exactly one set bit" and "some row is absent" — are merged into u32[K] device arrays by the stripe
+kernels and combined across ranks (RCCL over xGMI; gloo in the CPU tests):
+    fact      : ONE all_reduce(SUM) of 4 bytes per k-mer (n << 26 | colour + 1, include/colorid_hip.h) — the only
+                bandwidth-relevant collective of this placement
+    hits      : all_reduce(SUM) of the zero-padded full per-colour vector (8 * C bytes)
 RCCL has no bitwise reduction, so the perfect search's zero_acc and AND words are all-gathered and ANDed locally.
+
+All launches of one call go to the ctx stream back to back; when that stream is torch's current stream (bench.py) there is
+no host synchronisation at all inside a call, otherwise one hand-over each way.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
 from ._lib import check, vp
+
+MAX_RANKS = 31           # the summed n fields (2 per rank) must fit the fact word's 6 high bits
+MAX_COLOURS = 1 << 20
 
 
 def _active():
     return dist.is_available() and dist.is_initialized()
 
 
-def reduce_stripe_facts(pop_total: torch.Tensor, cand: torch.Tensor, hits_full: torch.Tensor):
-    """Cross-rank combination for the proportional search (in place): int32[K], int32[K], int64[C_total]."""
+def reduce_stripe_facts(fact: torch.Tensor, hits_full: torch.Tensor):
+    """Cross-rank combination for the proportional search (in place): int32[K] packed facts, int64[C_total]."""
     if _active():
-        dist.all_reduce(pop_total, op=dist.ReduceOp.SUM)
-        dist.all_reduce(cand, op=dist.ReduceOp.MAX)
+        assert dist.get_world_size() <= MAX_RANKS
+        dist.all_reduce(fact, op=dist.ReduceOp.SUM)
         dist.all_reduce(hits_full, op=dist.ReduceOp.SUM)
 
 
@@ -46,37 +56,57 @@ class StripedIndex:
     """stripes: list of (colorid_amd.Index, colour_base) held by THIS rank; n_colors_total over all ranks."""
 
     def __init__(self, ctx, stripes, n_colors_total):
+        assert n_colors_total <= MAX_COLOURS
         self.ctx, self.lib = ctx, ctx.lib
         self.stripes = list(stripes)
         self.n_colors = n_colors_total
         self.n_hash = self.stripes[0][0].n_hash
         self.k = self.stripes[0][0].k
 
+    # torch's current stream and the ctx stream: the same one (no hand-over needed) or ordered by a host wait each way
+    def _shared_stream(self, dev):
+        return self.ctx.stream is not None and self.ctx.stream == torch.cuda.current_stream(dev).cuda_stream
+
+    def _to_ctx(self, dev):
+        if not self._shared_stream(dev):
+            torch.cuda.current_stream(dev).synchronize()
+
+    def _to_torch(self, dev):
+        if not self._shared_stream(dev):
+            self.ctx.synchronize()
+
+    def search_count_local(self, d_kmers: torch.Tensor, fact: torch.Tensor, hits_full: torch.Tensor, codes: bool = False):
+        """This rank's stripes only: merges into fact (int32[K], zeroed by the caller) and writes the stripes' slices of
+        hits_full.  Asynchronous on the ctx stream."""
+        K = d_kmers.shape[0]
+        for ix, base in self.stripes:
+            check(self.lib.cid_search_count_stripe_dev(self.ctx.h, ix.h, None if codes else vp(d_kmers.data_ptr()),
+                                                       vp(d_kmers.data_ptr()) if codes else None, K, base,
+                                                       vp(hits_full.data_ptr() + 8 * base), vp(fact.data_ptr())))
+
+    def unique_finalize(self, fact, d_freq, nu, sf, uc):
+        K = fact.shape[0]
+        check(self.lib.cid_search_unique_finalize_dev(self.ctx.h, vp(fact.data_ptr()), vp(d_freq.data_ptr()) if d_freq is not None else None,
+                                                      K, self.n_colors, vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
+
     def search_count(self, d_kmers: torch.Tensor, d_freq: torch.Tensor = None, codes: bool = False):
-        """d_kmers: uint8[K, k] (or int64[K] 2-bit codes with codes=True) on this rank's GPU, identical on every rank."""
+        """d_kmers: uint8[K, k] (or int64[K] 2-bit codes with codes=True) on this rank's GPU, identical on every rank.
+        Returns (hits, n_unique, sum_unique_freq: int64[C_total]; unique_colour: int32[K])."""
         dev = d_kmers.device
         K = d_kmers.shape[0]
-        pop = torch.zeros(K, dtype=torch.int32, device=dev)
-        cand = torch.zeros(K, dtype=torch.int32, device=dev)
+        fact = torch.zeros(K, dtype=torch.int32, device=dev)
         hits_full = torch.zeros(self.n_colors, dtype=torch.int64, device=dev)
-        self._sync_torch()
-        for ix, base in self.stripes:
-            h = torch.zeros(ix.n_colors, dtype=torch.int64, device=dev)
-            torch.cuda.synchronize()
-            check(self.lib.cid_search_count_stripe_dev(self.ctx.h, ix.h, None if codes else vp(d_kmers.data_ptr()),
-                                                       vp(d_kmers.data_ptr()) if codes else None, K, base, vp(h.data_ptr()),
-                                                       vp(pop.data_ptr()), vp(cand.data_ptr())))
-            self.ctx.synchronize()
-            hits_full[base:base + ix.n_colors] = h
-        reduce_stripe_facts(pop, cand, hits_full)
         nu = torch.zeros(self.n_colors, dtype=torch.int64, device=dev)
         sf = torch.zeros(self.n_colors, dtype=torch.int64, device=dev)
         uc = torch.empty(K, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        check(self.lib.cid_search_unique_finalize_dev(self.ctx.h, vp(pop.data_ptr()), vp(cand.data_ptr()),
-                                                      vp(d_freq.data_ptr()) if d_freq is not None else None, K, self.n_colors,
-                                                      vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
-        self.ctx.synchronize()
+        self._to_ctx(dev)
+        self.search_count_local(d_kmers, fact, hits_full, codes)
+        if _active():
+            self._to_torch(dev)
+            reduce_stripe_facts(fact, hits_full)
+            self._to_ctx(dev)
+        self.unique_finalize(fact, d_freq, nu, sf, uc)
+        self._to_torch(dev)
         return hits_full, nu, sf, uc
 
     def search_perfect(self, d_kmers: torch.Tensor, w64_total: int, word_base_of, codes: bool = False):
@@ -86,15 +116,18 @@ class StripedIndex:
         K = d_kmers.shape[0]
         zero_acc = torch.full((K,), -1, dtype=torch.int32, device=dev)
         and_full = torch.full((w64_total,), -1, dtype=torch.int64, device=dev)
-        for ix, base in self.stripes:
-            rs = C_u64()
-            check(self.lib.cid_index_row_stride_words(ix.h, rs_ref(rs)))
-            w = torch.empty(rs.value, dtype=torch.int64, device=dev)
-            torch.cuda.synchronize()
+        words = []
+        for ix, _ in self.stripes:
+            rs = ctypes.c_uint64(0)
+            check(self.lib.cid_index_row_stride_words(ix.h, ctypes.byref(rs)))
+            words.append(torch.empty(rs.value, dtype=torch.int64, device=dev))
+        self._to_ctx(dev)
+        for (ix, _), w in zip(self.stripes, words):
             check(self.lib.cid_search_perfect_stripe_dev(self.ctx.h, ix.h, None if codes else vp(d_kmers.data_ptr()),
                                                          vp(d_kmers.data_ptr()) if codes else None, K, vp(w.data_ptr()),
                                                          vp(zero_acc.data_ptr())))
-            self.ctx.synchronize()
+        self._to_torch(dev)
+        for (ix, base), w in zip(self.stripes, words):
             nw = (ix.n_colors + 63) // 64
             b = word_base_of(base)
             and_full[b:b + nw] = w[:nw]
@@ -104,16 +137,3 @@ class StripedIndex:
         if missing:
             and_full.zero_()
         return and_full, missing
-
-    def _sync_torch(self):
-        torch.cuda.synchronize()
-
-
-def C_u64():
-    import ctypes
-    return ctypes.c_uint64(0)
-
-
-def rs_ref(x):
-    import ctypes
-    return ctypes.byref(x)

@@ -112,15 +112,21 @@ int cid_search_count_codes_dev(cid_ctx *, const cid_index *, const uint64_t *d_c
                                uint32_t *d_unique_colour);
 
 /* ---- colour-striped indices: one cid_index per stripe of colours [colour_base, colour_base+n_colors)
- *      of a wider index, on one GPU (more than 8192 colours) or one stripe per GPU (an index larger than one HBM).
- *      Per-colour hits of a stripe are final.  "Exactly one colour hit" (batch_search_pe.rs:75-82) and "row absent"
- *      (perfect_search.rs:31-39) need every stripe: each stripe call accumulates per-k-mer facts into caller arrays
- *      (d_pop_total / d_cand: u32[n_kmers], zeroed before the first stripe; d_zero_acc: u32[n_kmers], preset to
- *      0xFFFFFFFF), which are summed / MAX-ed / AND-ed across GPUs by the caller (RCCL) and then resolved by
- *      cid_search_unique_finalize_dev, resp. by testing d_zero_acc != 0.  Exactly one of d_kmers / d_codes is given. ---- */
+ *      of a wider index, several on one GPU and/or one (set of) stripe(s) per GPU (an index larger than one HBM).  Stripes of
+ *      any width work, including more than 8192 colours.  Per-colour hits of a stripe are final.  "Exactly one colour hit"
+ *      (batch_search_pe.rs:75-82) and "row absent" (perfect_search.rs:31-39) need every stripe: each stripe call merges
+ *      per-k-mer facts into caller arrays —
+ *        d_fact[n_kmers] (u32, zeroed before the first stripe):  n << 26 | (colour + 1),  n = min(set bits of the AND word, 2)
+ *            over the stripes merged so far (saturating), the colour field kept only while n == 1.  Across GPUs the caller
+ *            SUMS the arrays (one RCCL all-reduce of 4 bytes per k-mer; at most 31 ranks, at most 2^20 colours in total) and
+ *            hands the result to cid_search_unique_finalize_dev: a k-mer is unique iff the summed n is 1, and then the low
+ *            26 bits are its colour + 1.
+ *        d_zero_acc[n_kmers] (u32, preset to 0xFFFFFFFF): bit s stays set while row s was all-zero in every stripe; AND
+ *            across GPUs, "row absent" iff != 0 afterwards.
+ *      Exactly one of d_kmers / d_codes is given. ---- */
 int cid_search_count_stripe_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
-                                uint32_t colour_base, uint64_t *d_hits, uint32_t *d_pop_total, uint32_t *d_cand);
-int cid_search_unique_finalize_dev(cid_ctx *, const uint32_t *d_pop_total, const uint32_t *d_cand, const uint32_t *d_freq,
+                                uint32_t colour_base, uint64_t *d_hits, uint32_t *d_fact);
+int cid_search_unique_finalize_dev(cid_ctx *, const uint32_t *d_fact, const uint32_t *d_freq,
                                    size_t n_kmers, uint32_t n_colors_total, uint64_t *d_n_unique /* n_colors_total, zeroed */,
                                    uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour);
 int cid_search_perfect_stripe_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
@@ -187,7 +193,8 @@ int cid_readid_count_sparse(cid_ctx *, const cid_index *, const uint8_t *bases, 
 int cid_readid_sparse_fetch(cid_ctx *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
 
 /* Device-pointer form (asynchronous on the ctx stream).  The caller states the longest read(-pair) of the batch in
- * bytes and in k-mer windows (sum over its mates of (len-k)/d+1 for len >= k): they size the kernel's LDS. */
+ * bytes and in k-mer windows (sum over its mates of (len-k)/d+1 for len >= k): they size the kernel's LDS.  A read that
+ * exceeds either is not processed: its status is 3, its row and n_kmers are zero. */
 int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *d_seq_off,
                          const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                          uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_report, uint32_t *d_n_kmers,

@@ -76,7 +76,7 @@ def _stripe_worker(rank, world, port, out_dir):
     lo, hi = rank * 128, (rank + 1) * 128
     mine = rows64[:, lo // 32:hi // 32]                                   # this rank's stripe: 4 u32 words per row
     K = len(kmers)
-    pop = np.zeros(K, np.int32); cand = np.zeros(K, np.int32); zero_acc = np.full(K, -1, np.int32)
+    fact = np.zeros(K, np.uint32); zero_acc = np.full(K, -1, np.int32)       # fact: n << 26 | colour + 1 (include/colorid_hip.h)
     hits_full = np.zeros(C, np.int64)
     and_words = np.full(4, 0xFFFFFFFF, np.uint64)
     for j, km in enumerate(kmers):
@@ -90,23 +90,23 @@ def _stripe_worker(rank, world, port, out_dir):
         zero_acc[j] &= zmask
         and_words &= a
         bits = [c for c in range(128) if (int(a[c // 32]) >> (c % 32)) & 1]
-        pop[j] = len(bits)
-        if len(bits) == 1:
-            cand[j] = lo + bits[0]
+        fact[j] = (min(len(bits), 2) << 26) | (lo + bits[0] + 1 if len(bits) == 1 else 0)
         for c in bits:
             hits_full[lo + c] += 1
-    tp, tc, th = torch.from_numpy(pop), torch.from_numpy(cand), torch.from_numpy(hits_full)
-    reduce_stripe_facts(tp, tc, th)
+    tf, th = torch.from_numpy(fact.view(np.int32)), torch.from_numpy(hits_full)
+    reduce_stripe_facts(tf, th)                                           # ONE 4-byte-per-k-mer collective + the tiny hits vector
     and_full = np.full(4, -1, np.int64)                                   # 4 u64 words for 256 colours
     w64 = (and_words[0::2] | (and_words[1::2] << np.uint64(32))).view(np.int64)
     and_full[rank * 2:rank * 2 + 2] = w64
     tz, tw = reduce_perfect_facts(torch.from_numpy(zero_acc), torch.from_numpy(and_full))
     if rank == 0:
         full = oix.search_count(kmers, None)
-        uniq = tp.numpy() == 1
-        nu = np.bincount(tc.numpy()[uniq], minlength=C)
+        summed = tf.numpy().view(np.uint32)
+        uniq = (summed >> 26) == 1
+        col = (summed & ((1 << 26) - 1)).astype(np.int64) - 1
+        nu = np.bincount(col[uniq], minlength=C)
         ok = np.array_equal(th.numpy().astype(np.uint64), full[0]) and np.array_equal(nu.astype(np.uint64), full[1])
-        uc = np.where(uniq, tc.numpy().astype(np.uint32), np.uint32(0xFFFFFFFF))
+        uc = np.where(uniq, col.astype(np.uint32), np.uint32(0xFFFFFFFF))
         ok = ok and np.array_equal(uc, full[3]) and int(full[1].sum()) > 50
         pw, pm = oix.search_perfect(kmers)
         missing = bool(((tz.numpy() & ((1 << n) - 1)) != 0).any())

@@ -210,3 +210,62 @@ def test_readid_wide_rows_long_reads(orc, hip_ctx):
         rep, nk, st = check(oix, hx, reads, d, S)
         assert rep[0, 7] > 1000 and rep[0, 8999] == rep[0, 7]
     hx.close()
+
+
+def test_readid_dev_understated_maxima_are_flagged(orc, phage):
+    """cid_readid_count_dev sizes the kernel's LDS by the caller's maxima: a read beyond them is left alone with status 3
+    (its neighbours' rows stay right) instead of overrunning another wave's LDS."""
+    import torch
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(5)
+    reads = [[genomes[i % 4][s:s + 150]] for i, s in enumerate(rng.integers(0, 30000, 64))]
+    reads[10] = [genomes[0][1000:1400]]             # 400 bases: beyond the stated 150
+    reads[40] = [genomes[1][2000:2151]]             # one base / one window too many
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    want = oix.readid_counts(bases, seq_off, read_seq0, 1, 3)
+    db = torch.from_numpy(bases.copy()).cuda()
+    dso = torch.from_numpy(seq_off.astype(np.int64)).cuda()
+    dr0 = torch.from_numpy(read_seq0.astype(np.int64)).cuda()
+    C = oix.n_colors
+    rep = torch.full((len(reads), C + 1), 7, dtype=torch.int32, device="cuda")
+    nk = torch.full((len(reads),), 7, dtype=torch.int32, device="cuda")
+    st = torch.full((len(reads),), 7, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    hx.readid_count_dev(db.data_ptr(), dso.data_ptr(), dr0.data_ptr(), len(reads), 1, 3, 150, 150 - 27 + 1, rep.data_ptr(), nk.data_ptr(),
+                        st.data_ptr())
+    hx.ctx.synchronize()
+    st, nk, rep = st.cpu().numpy(), nk.cpu().numpy().view(np.uint32), rep.cpu().numpy().view(np.uint32)
+    over = np.zeros(len(reads), bool)
+    over[[10, 40]] = True
+    assert np.array_equal(st[over], [3, 3]) and not nk[over].any() and not rep[over].any()
+    assert np.array_equal(st[~over], want[2][~over]) and np.array_equal(nk[~over], want[1][~over])
+    assert np.array_equal(rep[~over], want[0][~over])
+
+
+def test_readid_dense_report_is_sliced(orc, phage):
+    """The dense host call works through a batch in slices whose report rows fit a device scratch budget
+    (CID_DENSE_REPORT_BYTES; 2 GiB by default): same rows as one launch."""
+    import subprocess
+    import sys
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(6)
+    reads = sample_reads(orc, rng, genomes, 300, 120, True)
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    want = oix.readid_counts(bases, seq_off, read_seq0, 1, 3)
+    np.savez("/tmp/_slice_case.npz", bases=bases, seq_off=seq_off, read_seq0=read_seq0, rep=want[0], nk=want[1], st=want[2], rows=oix.rows())
+    # the budget is read once per process: run the sliced call in a child with 37 rows per slice
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(HERE)!r})
+import colorid_amd
+z = np.load('/tmp/_slice_case.npz')
+ctx = colorid_amd.Context(0)
+hx = colorid_amd.Index(ctx, {oix.m}, {oix.n_hash}, {oix.k}, {oix.n_colors})
+hx.put_dense(z['rows']); hx.finalize()
+rep, nk, st = hx.readid_count(z['bases'], z['seq_off'], z['read_seq0'], 1, 3)
+assert np.array_equal(rep, z['rep']) and np.array_equal(nk, z['nk']) and np.array_equal(st, z['st'])
+print('sliced ok')
+"""
+    env = dict(os.environ, CID_DENSE_REPORT_BYTES=str(37 * (oix.n_colors + 1) * 4))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "sliced ok" in p.stdout, p.stderr[-2000:]

@@ -28,12 +28,14 @@ def stripe_indices(ctx, orc, oix, bounds):
     return out
 
 
-@pytest.mark.parametrize("n_colors,bounds", [(300, [(0, 128), (128, 300)]), (1000, [(0, 320), (320, 640), (640, 1000)]),
-                                              (130, [(0, 64), (64, 128), (128, 130)])])
-def test_striped_equals_whole(orc, hip_ctx, n_colors, bounds):
+@pytest.mark.parametrize("n_colors,bounds,m", [(300, [(0, 128), (128, 300)], 30_011), (1000, [(0, 320), (320, 640), (640, 1000)], 30_011),
+                                                (130, [(0, 64), (64, 128), (128, 130)], 30_011),
+                                                # a stripe wider than 8192 colours runs the wide-row kernels (rows of whole KiB)
+                                                (9100, [(0, 8832), (8832, 9100)], 3001), (17000, [(0, 8448), (8448, 17000)], 2003)])
+def test_striped_equals_whole(orc, hip_ctx, n_colors, bounds, m):
     from colorid_amd.striped import StripedIndex
     rng = np.random.default_rng(n_colors)
-    oix = random_index(orc, rng, 30_011, 3, 31, n_colors, density=0.02, zero_row_frac=0.3)
+    oix = random_index(orc, rng, m, 3, 31, n_colors, density=0.02 if n_colors < 8192 else 0.002, zero_row_frac=0.3)
     kmers = random_kmers(rng, 4000, 31)
     plant(oix, rng, kmers, frac=0.8, max_colours=2)
     for km in kmers[:300]:                                  # a perfect-search subset present in colours 1 and C-1
@@ -62,3 +64,21 @@ def test_striped_equals_whole(orc, hip_ctx, n_colors, bounds):
         assert missing == pm and np.array_equal(got32, pw)
     for hx, _ in stripes:
         hx.close()
+
+
+def test_stripe_calls_refuse_minimizer_index(orc, hip_ctx):
+    """`search` is not defined on .mxi indices (src/main.rs:569-573): the stripe entry points refuse them like the plain ones."""
+    import colorid_amd
+    from colorid_amd._lib import vp
+    hx = colorid_amd.Index(hip_ctx, 1009, 2, 21, 64)
+    assert hip_ctx.lib.cid_index_set_minimizer(hx.h, 11) == 0
+    hx.finalize()
+    k = torch.zeros((4, 21), dtype=torch.uint8, device="cuda") + 65
+    h = torch.zeros(64, dtype=torch.int64, device="cuda")
+    a = torch.zeros(4, dtype=torch.int32, device="cuda")
+    b = torch.zeros(4, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert hip_ctx.lib.cid_search_count_stripe_dev(hip_ctx.h, hx.h, vp(k.data_ptr()), None, 4, 0, vp(h.data_ptr()), vp(a.data_ptr()),
+                                                   vp(b.data_ptr())) == -4
+    assert hip_ctx.lib.cid_search_perfect_stripe_dev(hip_ctx.h, hx.h, vp(k.data_ptr()), None, 4, vp(h.data_ptr()), vp(a.data_ptr())) == -4
+    hx.close()

@@ -134,13 +134,13 @@ if "E" in only:
     C, n, k, m = 512, 3, 31, 1 << 30        # one GPU's stripe of the 4096-colour, 512 GiB index
     hx, ptr, rs, (kk, ff, cc) = make_index(C, n, k, m, 5_000_000)
     hx.finalize(); K = kk.shape[0]
-    hits = torch.zeros(C, dtype=torch.int64, device=dev); pop = torch.zeros(K, dtype=torch.int32, device=dev); cand = torch.zeros(K, dtype=torch.int32, device=dev)
+    hits = torch.zeros(C, dtype=torch.int64, device=dev); fact = torch.zeros(K, dtype=torch.int32, device=dev)
     nu = torch.zeros(4096, dtype=torch.int64, device=dev); sf = torch.zeros(4096, dtype=torch.int64, device=dev); uc = torch.empty(K, dtype=torch.int32, device=dev)
 
     def stripe():
-        pop.zero_(); cand.zero_(); nu.zero_(); sf.zero_()
-        check(hx.lib.cid_search_count_stripe_dev(ctx.h, hx.h, vp(kk.data_ptr()), None, K, 1024, vp(hits.data_ptr()), vp(pop.data_ptr()), vp(cand.data_ptr())))
-        check(hx.lib.cid_search_unique_finalize_dev(ctx.h, vp(pop.data_ptr()), vp(cand.data_ptr()), vp(ff.data_ptr()), K, 4096, vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
+        fact.zero_(); nu.zero_(); sf.zero_()
+        check(hx.lib.cid_search_count_stripe_dev(ctx.h, hx.h, vp(kk.data_ptr()), None, K, 1024, vp(hits.data_ptr()), vp(fact.data_ptr())))
+        check(hx.lib.cid_search_unique_finalize_dev(ctx.h, vp(fact.data_ptr()), vp(ff.data_ptr()), K, 4096, vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr())))
     ms = timed(stripe, steps=5)
     want = None
     S = 200_000

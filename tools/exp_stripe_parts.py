@@ -20,13 +20,13 @@ kk, ff, cc = bench.make_reads_kmers(dev, 42, 1_000_000, 150, k, C, 0.01)
 torch.cuda.synchronize()
 hx.insert_kmers_dev(kk.data_ptr(), cc.data_ptr(), kk.shape[0]); ctx.synchronize(); hx.finalize()
 K = kk.shape[0]
-hits = torch.zeros(C, dtype=torch.int64, device=dev); pop = torch.zeros(K, dtype=torch.int32, device=dev); cand = torch.zeros(K, dtype=torch.int32, device=dev)
+hits = torch.zeros(C, dtype=torch.int64, device=dev); fact = torch.zeros(K, dtype=torch.int32, device=dev)
 nu = torch.zeros(4096, dtype=torch.int64, device=dev); sf = torch.zeros(4096, dtype=torch.int64, device=dev); uc = torch.empty(K, dtype=torch.int32, device=dev)
 out = torch.zeros(3 * C, dtype=torch.int64, device=dev)
 parts = {
-    "clear": lambda: (pop.zero_(), cand.zero_(), nu.zero_(), sf.zero_()),
-    "stripe_kernel": lambda: check(hx.lib.cid_search_count_stripe_dev(ctx.h, hx.h, vp(kk.data_ptr()), None, K, 1024, vp(hits.data_ptr()), vp(pop.data_ptr()), vp(cand.data_ptr()))),
-    "finalize": lambda: check(hx.lib.cid_search_unique_finalize_dev(ctx.h, vp(pop.data_ptr()), vp(cand.data_ptr()), vp(ff.data_ptr()), K, 4096, vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr()))),
+    "clear": lambda: (fact.zero_(), nu.zero_(), sf.zero_()),
+    "stripe_kernel": lambda: check(hx.lib.cid_search_count_stripe_dev(ctx.h, hx.h, vp(kk.data_ptr()), None, K, 1024, vp(hits.data_ptr()), vp(fact.data_ptr()))),
+    "finalize": lambda: check(hx.lib.cid_search_unique_finalize_dev(ctx.h, vp(fact.data_ptr()), vp(ff.data_ptr()), K, 4096, vp(nu.data_ptr()), vp(sf.data_ptr()), vp(uc.data_ptr()))),
     "plain_search_same_index": lambda: hx.search_count_dev(kk.data_ptr(), ff.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C, out.data_ptr() + 16 * C, uc.data_ptr()),
 }
 for name, fn in parts.items():
