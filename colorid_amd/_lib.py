@@ -28,6 +28,7 @@ SIGNATURES = {
     "cid_ctx_destroy": (None, [vp]),
     "cid_index_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "cid_index_set_minimizer": (C.c_int, [vp, C.c_uint32]),
+    "cid_index_set_hash_variant": (C.c_int, [vp, C.c_int]),
     "cid_index_put_rows": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "cid_index_put_records": (C.c_int, [vp, vp, C.c_size_t]),
     "cid_index_device_matrix": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),

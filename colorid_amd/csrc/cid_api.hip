@@ -265,7 +265,7 @@ int cid_index_create(cid_ctx *c, uint64_t bloom_size, uint32_t num_hash, uint32_
                      int hash_variant, cid_index **out) {
     if (!c || !out) return fail(CID_ERR_INVALID, "null ctx/out");
     *out = nullptr;
-    if (hash_variant != CID_HASH_XXH3_V08) return fail(CID_ERR_UNSUPPORTED, "hash variant %d", hash_variant);
+    if (hash_variant < 0 || hash_variant >= CID_HASH_VARIANTS) return fail(CID_ERR_UNSUPPORTED, "hash variant %d", hash_variant);
     if (bloom_size == 0 || num_hash == 0 || n_colors == 0 || k_size == 0) return fail(CID_ERR_INVALID, "zero parameter");
     if (k_size > cid::kMaxK) return fail(CID_ERR_UNSUPPORTED, "k_size %u > %u", k_size, cid::kMaxK);
     if (num_hash > 32) return fail(CID_ERR_UNSUPPORTED, "num_hash %u > 32", num_hash);
@@ -279,7 +279,7 @@ int cid_index_create(cid_ctx *c, uint64_t bloom_size, uint32_t num_hash, uint32_
     ix->w64 = (n_colors + 63) / 64;
     ix->rs = cid::row_stride_words(n_colors);
     const cid::ModMagicHost mh = cid::make_mod_magic(bloom_size);
-    ix->mod = cid::ModMagic{mh.m, mh.magic, mh.shift, mh.flags};
+    ix->mod = cid::ModMagic{mh.m, mh.magic, mh.shift, mh.flags | ((uint32_t)hash_variant << 8)};
     hipError_t e = hipSetDevice(c->device);
     const size_t bytes = (size_t)bloom_size * ix->rs * 8;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ix->mat), bytes);
@@ -296,6 +296,15 @@ int cid_index_set_minimizer(cid_index *ix, uint32_t m_size) {
     if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
     if (m_size == 0 || m_size > ix->k) return fail(CID_ERR_INVALID, "minimizer size %u must be in 1..k_size (%u)", m_size, ix->k);
     ix->m_size = m_size;
+    return CID_OK;
+}
+
+int cid_index_set_hash_variant(cid_index *ix, int hash_variant) {
+    if (!ix) return fail(CID_ERR_INVALID, "null index");
+    if (hash_variant < 0 || hash_variant >= CID_HASH_VARIANTS) return fail(CID_ERR_UNSUPPORTED, "hash variant %d", hash_variant);
+    HIP_TRY(hipSetDevice(ix->ctx->device));
+    HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
+    ix->mod.flags = (ix->mod.flags & 0xFFu) | ((uint32_t)hash_variant << 8);
     return CID_OK;
 }
 

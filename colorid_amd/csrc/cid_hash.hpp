@@ -38,8 +38,12 @@ struct ModMagic {
     uint64_t m;      // divisor (bloom_size)
     uint64_t magic;  // multiplier
     uint32_t shift;
-    uint32_t flags;  // 1 = power of two (mask), 2 = "add" fix-up step
+    uint32_t flags;  // 1 = power of two (mask), 2 = "add" fix-up step; bits 8..15 = the index's hash variant (kHash*)
 };
+// Hash variants (include/colorid_hip.h CID_HASH_*): which XXH3 the index was built with.
+constexpr uint32_t kHashV08 = 0;   // published XXH3_64bits_withSeed (xxHash >= 0.8.0), pinned to known answers
+constexpr uint32_t kHashV07 = 1;   // the XXH3 draft of xxHash v0.7.1 / v0.7.2 (candidate for crate xxh3 0.1.x; unverified, see below)
+CID_FN uint32_t hash_variant_of(const ModMagic &mm) { return (mm.flags >> 8) & 0xFFu; }
 
 CID_FN uint64_t mod_m(uint64_t h, const ModMagic &mm) {
     if (mm.flags & 1u) return h & (mm.m - 1);
@@ -66,6 +70,7 @@ CID_DEVCONST constexpr uint64_t kSecretW[16] = {
     0x3f349ce33f76faa8ULL, 0x1d4f0bc7c7bbdcf9ULL, 0x3159b4cd4be0518aULL, 0x647378d9c97e9fc8ULL,
 };
 
+constexpr uint64_t P32_1 = 0x9E3779B1ULL;
 constexpr uint64_t P64_1 = 0x9E3779B185EBCA87ULL;
 constexpr uint64_t P64_2 = 0xC2B2AE3D27D4EB4FULL;
 constexpr uint64_t P64_3 = 0x165667B19E3779F9ULL;
@@ -73,8 +78,9 @@ constexpr uint64_t PMX1 = 0x165667919E3779F9ULL;
 constexpr uint64_t PMX2 = 0x9FB21C651E98DF25ULL;
 
 CID_FN uint64_t mul128_fold64(uint64_t a, uint64_t b) { return (a * b) ^ umul64hi(a, b); }
-CID_FN uint64_t xxh3_avalanche(uint64_t h) {
-    h ^= h >> 37; h *= PMX1; h ^= h >> 32;
+// v0.8: h ^= h >> 37; h *= 0x165667919E3779F9; h ^= h >> 32.  The v0.7.1/v0.7.2 draft multiplies by PRIME64_3 instead.
+CID_FN uint64_t xxh3_avalanche(uint64_t h, uint32_t hv = kHashV08) {
+    h ^= h >> 37; h *= (hv == kHashV07 ? P64_3 : PMX1); h ^= h >> 32;
     return h;
 }
 CID_FN uint64_t xxh64_avalanche(uint64_t h) {
@@ -128,9 +134,41 @@ struct CodeReader {  // an upper-case ACGT k-mer (k <= 32) held as a 2-bit code,
     CID_FN uint32_t rd8(uint32_t o) const { return ascii4((uint32_t)(code >> (2u * o)) & 3u) & 0xFFu; }
 };
 
-// All n seeds (0..n-1) of one k-mer; emit(seed, hash).  len is wave-uniform.
+// kHashV07 — XXH3 as drafted in xxHash v0.7.1 / v0.7.2 (Aug-Oct 2019), the code base a 2019 Rust port with the entry point
+// `xxh3::hash64_with_seed` (crate xxh3 0.1.x, later twox-hash's xxh3 module) was written against.  Restated from memory of that
+// source: NO known answer exists in this image, so this variant is a CANDIDATE for `colorid hashcheck`, not a parity claim.
+//   17..128 bytes: exactly the v0.8 construction (seed folded into the secret words, len * PRIME64_1, mix16B pairs) with the
+//                  avalanche multiplier PRIME64_3;
+//   9..16: lo = in[0..8] ^ (secret[0..8] + seed), hi = in[len-8..] ^ (secret[8..16] - seed); avalanche(len + lo + hi + fold(lo*hi));
+//   4..8 : keyed = (in32[0] | in32[len-4] << 32) ^ (secret[0..8] + seed); mix = len + (keyed ^ keyed >> 51) * PRIME32_1;
+//          avalanche((mix ^ mix >> 47) * PRIME64_2);
+//   1..3 : combined = c1 | c2 << 8 | c3 << 16 | len << 24; avalanche((combined ^ (secret32[0] + seed)) * PRIME64_1).
 template <typename Reader, typename Emit>
-CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, Emit &&emit) {
+CID_FN void xxh3_v07_short(const Reader &in, uint32_t len, uint32_t n, Emit &&emit) {
+    if (len > 8) {
+        const uint64_t i_lo = in.rd64(0), i_hi = in.rd64(len - 8);
+        for (uint32_t s = 0; s < n; ++s) {
+            const uint64_t lo = i_lo ^ (kSecretW[0] + s), hi = i_hi ^ (kSecretW[1] - s);
+            emit(s, xxh3_avalanche((uint64_t)len + lo + hi + mul128_fold64(lo, hi), kHashV07));
+        }
+    } else if (len >= 4) {
+        const uint64_t in64 = (uint64_t)in.rd32(0) + ((uint64_t)in.rd32(len - 4) << 32);
+        for (uint32_t s = 0; s < n; ++s) {
+            const uint64_t keyed = in64 ^ (kSecretW[0] + s);
+            const uint64_t mix = (uint64_t)len + (keyed ^ (keyed >> 51)) * P32_1;
+            emit(s, xxh3_avalanche((mix ^ (mix >> 47)) * P64_2, kHashV07));
+        }
+    } else {
+        const uint32_t c1 = in.rd8(0), c2 = in.rd8(len >> 1), c3 = in.rd8(len - 1);
+        const uint64_t combined = (uint64_t)(c1 | (c2 << 8) | (c3 << 16) | (len << 24));
+        for (uint32_t s = 0; s < n; ++s) emit(s, xxh3_avalanche((combined ^ ((uint64_t)(uint32_t)kSecretW[0] + s)) * P64_1, kHashV07));
+    }
+}
+
+// All n seeds (0..n-1) of one k-mer; emit(seed, hash).  len and hv (the hash variant) are wave-uniform.
+template <typename Reader, typename Emit>
+CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, uint32_t hv, Emit &&emit) {
+    if (hv == kHashV07 && len <= 16) { xxh3_v07_short(in, len, n, emit); return; }
     if (len > 16 && len <= 32) {  // the k = 21/27/31 case: 2 x mix16B, inputs read once for all seeds
         const uint64_t a0 = in.rd64(0), a1 = in.rd64(8);
         const uint64_t b0 = in.rd64(len - 16), b1 = in.rd64(len - 8);
@@ -138,7 +176,7 @@ CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, Emit &&e
             uint64_t acc = (uint64_t)len * P64_1;
             acc += mul128_fold64(a0 ^ (kSecretW[0] + s), a1 ^ (kSecretW[1] - s));
             acc += mul128_fold64(b0 ^ (kSecretW[2] + s), b1 ^ (kSecretW[3] - s));
-            emit(s, xxh3_avalanche(acc));
+            emit(s, xxh3_avalanche(acc, hv));
         }
     } else if (len > 32) {  // 33..128: (len-1)/32 + 1 front/back pairs
         const uint32_t nb = ((len - 1) >> 5) + 1;
@@ -149,7 +187,7 @@ CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, Emit &&e
                 acc += mul128_fold64(in.rd64(f) ^ (kSecretW[4 * i] + s), in.rd64(f + 8) ^ (kSecretW[4 * i + 1] - s));
                 acc += mul128_fold64(in.rd64(b) ^ (kSecretW[4 * i + 2] + s), in.rd64(b + 8) ^ (kSecretW[4 * i + 3] - s));
             }
-            emit(s, xxh3_avalanche(acc));
+            emit(s, xxh3_avalanche(acc, hv));
         }
     } else if (len > 8) {  // 9..16
         const uint64_t i_lo = in.rd64(0), i_hi = in.rd64(len - 8);
@@ -179,8 +217,8 @@ CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, Emit &&e
 }
 
 template <typename Emit>
-CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t n, Emit &&emit) {
-    xxh3_seeds_from(LdsReader{img, off}, len, n, emit);
+CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t n, uint32_t hv, Emit &&emit) {
+    xxh3_seeds_from(LdsReader{img, off}, len, n, hv, emit);
 }
 
 // ---------------------------------------------------------------- 2-bit k-mer codes (upper-case ACGT, k <= 32)

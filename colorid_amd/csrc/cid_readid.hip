@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 if (distinct) {   // WIDE: this chunk's slot; else the read's list at the k-mer's order index
                     uint32_t *dst = WIDE ? ridx + lane : rall + nd + (uint32_t)__popcll(dmask & lt_mask);
                     const uint32_t st = WIDE ? (uint32_t)kWave : rcap;
-                    xxh3_seeds_from(CodeReader{canon}, klen, n, [&](uint32_t sd, uint64_t h) { dst[sd * st] = (uint32_t)mod_m(h, p.mod); });
+                    xxh3_seeds_from(CodeReader{canon}, klen, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) { dst[sd * st] = (uint32_t)mod_m(h, p.mod); });
                 }
                 if constexpr (WIDE) {
                     wave_lds_fence();
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
                     }
                     wave_lds_fence();
                     if (valid)
-                        xxh3_seeds(mimg, (uint32_t)lane * m, m, n, [&](uint32_t sd, uint64_t h) {
+                        xxh3_seeds(mimg, (uint32_t)lane * m, m, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) {
                             if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
                             ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
                         });
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
                     }
                 } else {
                     if (valid)
-                        xxh3_seeds(img, (uint32_t)lane * k, k, n, [&](uint32_t sd, uint64_t h) {
+                        xxh3_seeds(img, (uint32_t)lane * k, k, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) {
                             if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
                             ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
                         });
@@ -536,10 +536,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
             if (have) {
                 const uint64_t e = p.list_codes[c0 + lane];
                 if (p.bases) {
-                    xxh3_seeds_from(BaseReader{p.bases + (e >> 1), k, (uint32_t)(e & 1ull), p.upper}, k, n,
+                    xxh3_seeds_from(BaseReader{p.bases + (e >> 1), k, (uint32_t)(e & 1ull), p.upper}, k, n, hash_variant_of(p.mod),
                                     [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
                 } else {
-                    xxh3_seeds_from(CodeReader{rev_fields(e, k)}, k, n, [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+                    xxh3_seeds_from(CodeReader{rev_fields(e, k)}, k, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
                 }
             }
             const uint64_t dmask = __ballot(have);

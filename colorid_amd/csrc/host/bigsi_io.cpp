@@ -176,26 +176,74 @@ void save_bigsi(const std::string &path, const Bigsi &b) {
     fclose(f);
 }
 
+// tab_to_map (build.rs:15-31): accession \t file [\t file2]; later lines overwrite earlier ones
+static std::map<std::string, std::vector<std::string>> tab_to_map(const std::string &ref_tsv) {
+    std::map<std::string, std::vector<std::string>> refs;  // std::map iterates sorted == accessions.sort() (build.rs:105)
+    LineReader r(ref_tsv);
+    std::string line;
+    while (r.next(line)) {
+        std::vector<std::string> v;
+        size_t p = 0;
+        while (true) {
+            size_t e = line.find('\t', p);
+            v.push_back(line.substr(p, e == std::string::npos ? std::string::npos : e - p));
+            if (e == std::string::npos) break;
+            p = e + 1;
+        }
+        if (v.size() < 2) die("reference file line without a tab: '%s'", line.c_str());
+        refs[v[0]] = v.size() == 2 ? std::vector<std::string>{v[1]} : std::vector<std::string>{v[1], v[2]};
+    }
+    return refs;
+}
+
+size_t hashcheck(cid_ctx *ctx, Bigsi &b, const std::string &ref_tsv, uint8_t quality, const char *const *variant_names, std::vector<double> &worst) {
+    if (b.m_size) die("hashcheck works on k-mer indices (.bxi); a minimizer index shares its hash with the .bxi built by the same binary");
+    const auto refs = tab_to_map(ref_tsv);
+    const size_t C = b.colors.size();
+    std::vector<uint64_t> hits(C);
+    size_t n_checked = 0;
+    printf("variant\taccession\tkmers\tpresent\tfraction\n");
+    for (auto &kv : refs) {
+        const auto it = std::find(b.colors.begin(), b.colors.end(), kv.first);
+        if (it == b.colors.end()) { fprintf(stderr, "%s is not an accession of the index: skipped\n", kv.first.c_str()); continue; }
+        const uint32_t colour = (uint32_t)(it - b.colors.begin());
+        const std::vector<std::string> &v = kv.second;
+        const bool is_gz = v.size() == 2 || (v[0].size() >= 2 && v[0].compare(v[0].size() - 2, 2, "gz") == 0);
+        // the accession's k-mers as build counts them (reads: with the automatic cutoff, the build default)
+        cid_kmerset *ks = nullptr;
+        KmerMap km((uint32_t)b.k_size);
+        uint64_t nk = 0;
+        if (gpu_counting_enabled(b.k_size))
+            ks = is_gz ? count_fastq_gpu(ctx, b.k_size, v[0], v.size() == 2 ? &v[1] : nullptr, quality) : count_fasta_gpu(ctx, b.k_size, read_fasta(v[0]));
+        if (ks) {
+            if (is_gz) { const int64_t t = auto_cutoff_gpu(ks); CID_TRY(cid_kmerset_clean(ks, (uint64_t)(t < 0 ? 0 : t))); }
+            CID_TRY(cid_kmerset_size(ks, &nk));
+        } else {
+            if (v.size() == 2) kmers_fq_pe_qual(v[0], v[1], quality, km);
+            else if (is_gz) kmers_from_fq_qual(v[0], quality, km);
+            else kmerize_vector(read_fasta(v[0]), 1, km);
+            if (is_gz) { const int64_t t = km.auto_cutoff(); km.clean((uint64_t)(t < 0 ? 0 : t)); }
+            nk = km.size();
+        }
+        if (nk == 0) { fprintf(stderr, "%s has no k-mers: skipped\n", kv.first.c_str()); if (ks) cid_kmerset_destroy(ks); continue; }
+        for (int hv = 0; hv < CID_HASH_VARIANTS; ++hv) {
+            CID_TRY(cid_index_set_hash_variant(b.index, hv));
+            if (ks) CID_TRY(cid_search_count_set(ctx, b.index, ks, hits.data(), nullptr, nullptr, nullptr));
+            else CID_TRY(cid_search_count(ctx, b.index, km.keys(), nullptr, km.size(), hits.data(), nullptr, nullptr, nullptr));
+            const double frac = (double)hits[colour] / (double)nk;
+            printf("%s\t%s\t%llu\t%llu\t%.4f\n", variant_names[hv], kv.first.c_str(), (unsigned long long)nk, (unsigned long long)hits[colour], frac);
+            if (frac < worst[hv]) worst[hv] = frac;
+        }
+        if (ks) cid_kmerset_destroy(ks);
+        ++n_checked;
+    }
+    CID_TRY(cid_index_set_hash_variant(b.index, CID_HASH_XXH3_V08));
+    return n_checked;
+}
+
 Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
                    int64_t cutoff, int hash_variant, uint64_t m_size) {
-    // tab_to_map (build.rs:15-31): accession \t file [\t file2]; later lines overwrite earlier ones
-    std::map<std::string, std::vector<std::string>> refs;  // std::map iterates sorted == accessions.sort() (build.rs:105)
-    {
-        LineReader r(ref_tsv);
-        std::string line;
-        while (r.next(line)) {
-            std::vector<std::string> v;
-            size_t p = 0;
-            while (true) {
-                size_t e = line.find('\t', p);
-                v.push_back(line.substr(p, e == std::string::npos ? std::string::npos : e - p));
-                if (e == std::string::npos) break;
-                p = e + 1;
-            }
-            if (v.size() < 2) die("reference file line without a tab: '%s'", line.c_str());
-            refs[v[0]] = v.size() == 2 ? std::vector<std::string>{v[1]} : std::vector<std::string>{v[1], v[2]};
-        }
-    }
+    const auto refs = tab_to_map(ref_tsv);
     Bigsi b;
     b.bloom_size = bloom; b.num_hash = hashes; b.k_size = k; b.m_size = m_size;
     for (auto &kv : refs) b.colors.push_back(kv.first);

@@ -78,6 +78,11 @@ void save_bigsi(const std::string &path, const Bigsi &b);                       
 Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
                    int64_t cutoff, int hash_variant, uint64_t m_size = 0);   // build.rs:15-130; m_size > 0: build_single_mini :396-492
 
+// For every hash variant v and every accession of ref_tsv that is a colour of b: the fraction of the accession's k-mers (counted
+// as build does, build.rs:54-99) whose n rows are all set in its colour.  Prints one line per (variant, accession); worst[v] = the
+// smallest fraction under variant v.  Returns the number of accessions checked.
+size_t hashcheck(cid_ctx *ctx, Bigsi &b, const std::string &ref_tsv, uint8_t quality, const char *const *variant_names, std::vector<double> &worst);
+
 // ---------------------------------------------------------------- reports.rs / read_id tail
 double false_prob(double m, double k, double n);                                                     // read_id_mt_pe.rs:695-698
 struct Classification { std::string label; uint64_t count; uint64_t kmer_length; const char *verdict; uint64_t n_top; };

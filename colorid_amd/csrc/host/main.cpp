@@ -1,7 +1,8 @@
 // `colorid` command line: the reference's drop-in surface for the query path (src/main.rs) —
 //   search  (src/main.rs:127-217, :555-628)   read_id (:241-328, :704-868)
 //   build   (:31-126, :466-554; needed to produce .bxi files)   info (:218-240, :630-703)
-// Same flag letters, defaults, stdout/stderr/file formats.  Extra flags: --device N, --hash xxh3_v08.
+// Same flag letters, defaults, stdout/stderr/file formats.  Extra flags: --device N, --hash xxh3_v08|xxh3_v07.  Extra command:
+// hashcheck (which hash variant was an index built with).
 // Minimizer indices (.mxi): build -m [-v M], info, read_id.  Not provided (outside the query path): batch_id, read_filter.
 #include <chrono>
 #include <cmath>
@@ -68,14 +69,23 @@ cid_ctx *make_ctx(const Args &a) {
     return ctx;
 }
 
+const char *const kHashNames[CID_HASH_VARIANTS] = {"xxh3_v08", "xxh3_v07"};
+
 int hash_variant(const Args &a) {
-    if (!a.has("hash") || a.one("hash") == "xxh3_v08") return CID_HASH_XXH3_V08;
-    die("unknown --hash '%s' (available: xxh3_v08)", a.one("hash").c_str());
+    if (!a.has("hash")) return CID_HASH_XXH3_V08;
+    for (int v = 0; v < CID_HASH_VARIANTS; ++v)
+        if (a.one("hash") == kHashNames[v]) return v;
+    die("unknown --hash '%s' (available: xxh3_v08, xxh3_v07)", a.one("hash").c_str());
 }
 
 Bigsi load_index(cid_ctx *ctx, const Args &a, bool meta_only = false) {
     const auto t0 = std::chrono::steady_clock::now();
     fprintf(stderr, "Loading index\n");
+    // The file format carries no hash id and the reference's hash crate (xxh3 ^0.1.1) cannot be run here: an index written by
+    // this program matches its own --hash; for one written by the Rust binary, `colorid hashcheck` decides which --hash applies.
+    if (!meta_only && !a.has("hash") && !getenv("COLORID_QUIET"))
+        fprintf(stderr, "note: --hash defaults to xxh3_v08 (published XXH3); parity with an index built by the Rust colorid is unverified — "
+                        "run `colorid hashcheck -b <index> -r <ref_file>` once to find the variant it was built with\n");
     Bigsi b = read_bigsi(ctx, a.one("bigsi"), hash_variant(a), meta_only);
     fprintf(stderr, "Index loaded in %ld seconds\n",
             (long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count());
@@ -193,6 +203,37 @@ int cmd_read_id(int argc, char **argv) {
     return 0;
 }
 
+// Which hash variant was this index built with?  The .bxi/.mxi format has no hash id and the reference hashes with a 2019 crate
+// (xxh3 ^0.1.1, Cargo.toml:9; call sites src/simple_bloom.rs:19-38) that cannot run here.  A Bloom filter has no false negatives:
+// under the RIGHT variant every k-mer of an accession's own sequence file has all its n rows set in the accession's colour
+// (src/build.rs:54-99 inserted exactly those k-mers), under a wrong one only the fraction ~ (row density)^n does.  For every
+// variant and every accession of the reference list (`-r`, the file `build` was given) this prints that fraction.
+int cmd_hashcheck(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'r', "refs", true, false}, {'Q', "quality", true, false}}));
+    for (const char *req : {"bigsi", "refs"})
+        if (!a.has(req)) die("error: The following required arguments were not provided: --%s", req);
+    if (a.has("hash")) die("hashcheck tries every variant: --hash is not accepted");
+    cid_ctx *ctx = make_ctx(a);
+    fprintf(stderr, "Loading index\n");
+    Bigsi b = read_bigsi(ctx, a.one("bigsi"), CID_HASH_XXH3_V08, false);
+    std::vector<double> worst(CID_HASH_VARIANTS, 2.0);
+    const size_t n_checked = hashcheck(ctx, b, a.one("refs"), num_or<uint8_t>(a, "quality", 15), kHashNames, worst);
+    if (n_checked == 0) die("no accession of %s is a colour of %s", a.one("refs").c_str(), a.one("bigsi").c_str());
+    int match = -1, n_match = 0;
+    for (int v = 0; v < CID_HASH_VARIANTS; ++v)
+        if (worst[v] >= 0.999) { match = v; ++n_match; }
+    if (n_match == 1) printf("verdict\t%s\tevery accession's own k-mers are present: use --hash %s\n", kHashNames[match], kHashNames[match]);
+    else if (n_match == 0) printf("verdict\tnone\tno available hash variant reproduces this index (lowest fractions:");
+    else printf("verdict\tambiguous\tmore than one variant fits (index too dense to tell)\n");
+    if (n_match == 0) {
+        for (int v = 0; v < CID_HASH_VARIANTS; ++v) printf(" %s %.4f", kHashNames[v], worst[v]);
+        printf(")\n");
+    }
+    cid_index_destroy(b.index);
+    cid_ctx_destroy(ctx);
+    return n_match == 1 ? 0 : 3;
+}
+
 // host-only helper used by the CPU tests: distinct canonical k-mers of a file as "kmer\tcount" lines (insertion order)
 int cmd_debug_kmers(int argc, char **argv) {
     const Args a = parse(argc, argv, 2, {{'q', "query", true, true}, {'k', "kmer", true, false}, {0, "mode", true, false},
@@ -230,7 +271,7 @@ int main(int argc, char **argv) {
     // src/main.rs:16-20: init_log() prints this banner on stdout before anything else
     printf("\n ************** initializing logger *****************\n\n");
     if (argc < 2) {
-        fprintf(stderr, "colorid 0.1.4.3 (MI355X)\nUSAGE:\n    colorid <build|search|info|read_id> [FLAGS]\n");
+        fprintf(stderr, "colorid 0.1.4.3 (MI355X)\nUSAGE:\n    colorid <build|search|info|read_id|hashcheck> [FLAGS]\n");
         return 1;
     }
     const std::string cmd = argv[1];
@@ -238,6 +279,7 @@ int main(int argc, char **argv) {
     if (cmd == "search") return cmd_search(argc, argv);
     if (cmd == "info") return cmd_info(argc, argv);
     if (cmd == "read_id") return cmd_read_id(argc, argv);
+    if (cmd == "hashcheck") return cmd_hashcheck(argc, argv);
     if (cmd == "debug-kmers") return cmd_debug_kmers(argc, argv);
     if (cmd == "batch_id" || cmd == "read_filter") die("'%s' is outside the accelerated query path; use the reference binary", cmd.c_str());
     die("error: Found argument '%s' which wasn't expected", cmd.c_str());

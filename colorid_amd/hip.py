@@ -67,6 +67,10 @@ class Index:
         self.m_size = m_size
         return self
 
+    def set_hash_variant(self, hash_variant):
+        check(self.lib.cid_index_set_hash_variant(self.h, hash_variant))
+        return self
+
     def put_rows(self, row_ids, words):
         row_ids = np.ascontiguousarray(row_ids, np.uint64)
         words = np.ascontiguousarray(words, np.uint32).reshape(len(row_ids), self.w32)

@@ -40,6 +40,12 @@ extern "C" {
  * CID_HASH_XXH3_V08 = the published XXH3_64bits_withSeed (xxHash >= 0.8.0).  The .bxi format
  * carries no hash id, so the caller states it. */
 #define CID_HASH_XXH3_V08 0
+/* CID_HASH_XXH3_V07 = the XXH3 draft of xxHash v0.7.1 / v0.7.2 (2019), the most likely code base of crate xxh3 0.1.x: for the
+ * k-mer lengths 17..128 it is the v0.8 construction with the avalanche multiplier PRIME64_3; restated from memory, no known
+ * answer available: a CANDIDATE that `colorid hashcheck` (cid_index_set_hash_variant + cid_search_count_set per accession)
+ * confirms or rejects against a reference-built index — not a parity claim. */
+#define CID_HASH_XXH3_V07 1
+#define CID_HASH_VARIANTS 2
 
 #define CID_NOT_UNIQUE 0xFFFFFFFFu
 
@@ -67,6 +73,9 @@ int cid_index_create(cid_ctx *, uint64_t bloom_size, uint32_t num_hash, uint32_t
  * cid_index_insert_kmers* (src/build.rs:455-459) and cid_readid_count* (src/kmer.rs:363-394); the search entry points
  * refuse such an index, as the reference does (src/main.rs:569-573). */
 int cid_index_set_minimizer(cid_index *, uint32_t m_size);
+/* Re-interpret the same rows under another hash variant (the file carries no hash id; rows are rows).  Changes which rows
+ * every later insert / search on this index computes; call it only while no call on the index is in flight. */
+int cid_index_set_hash_variant(cid_index *, int hash_variant);
 /* Sparse rows as the .bxi `map` stores them (src/bigsi.rs:59-63): n_rows x W32 little-endian
  * u32 words, W32 = ceil(n_colors/32).  Rows never put stay all-zero == key absent from the map. */
 int cid_index_put_rows(cid_index *, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows);

@@ -15,7 +15,11 @@ extern "C" {
 #endif
 
 /* ---- hash (3rd-party crate xxh3 ^0.1.1; restated from the published XXH3 spec) ---- */
-uint64_t orc_xxh3_64_with_seed(const uint8_t *in, size_t len, uint64_t seed);
+uint64_t orc_xxh3_64_with_seed(const uint8_t *in, size_t len, uint64_t seed);            /* the variant selected below */
+uint64_t orc_xxh3_published_64_with_seed(const uint8_t *in, size_t len, uint64_t seed);  /* variant 0: xxHash >= 0.8 */
+uint64_t orc_xxh3_v07_64_with_seed(const uint8_t *in, size_t len, uint64_t seed);        /* variant 1: v0.7.1/0.7.2 draft, <= 128 bytes, unverified */
+void orc_set_hash_variant(int v);                                                        /* process-wide; every later hash uses it */
+int orc_get_hash_variant(void);
 
 /* ---- src/seq.rs ---- */
 int orc_is_good_base(uint8_t c);                                  /* seq.rs:59-64 */

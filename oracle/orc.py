@@ -48,6 +48,10 @@ def lib():
     ip = C.POINTER(_Index)
     sig = {
         "orc_xxh3_64_with_seed": (C.c_uint64, [C.c_char_p, C.c_size_t, C.c_uint64]),
+        "orc_xxh3_published_64_with_seed": (C.c_uint64, [C.c_char_p, C.c_size_t, C.c_uint64]),
+        "orc_xxh3_v07_64_with_seed": (C.c_uint64, [C.c_char_p, C.c_size_t, C.c_uint64]),
+        "orc_set_hash_variant": (None, [C.c_int]),
+        "orc_get_hash_variant": (C.c_int, []),
         "orc_is_good_base": (C.c_int, [C.c_uint8]),
         "orc_has_no_n": (C.c_int, [C.c_char_p, C.c_size_t]),
         "orc_qual_mask": (None, [C.c_char_p, C.c_char_p, C.c_size_t, C.c_uint8, C.c_char_p]),
@@ -113,6 +117,24 @@ def _ptr(a):
 
 def xxh3(b: bytes, seed: int = 0) -> int:
     return lib().orc_xxh3_64_with_seed(b, len(b), seed)
+
+
+def xxh3_v07(b: bytes, seed: int = 0) -> int:
+    return lib().orc_xxh3_v07_64_with_seed(b, len(b), seed)
+
+
+class hash_variant:
+    """`with orc.hash_variant(1): ...` — every oracle hash inside uses the v0.7 draft (candidate for crate xxh3 0.1.x)."""
+
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        self.old = lib().orc_get_hash_variant()
+        lib().orc_set_hash_variant(self.v)
+
+    def __exit__(self, *a):
+        lib().orc_set_hash_variant(self.old)
 
 
 def revcomp(b: bytes) -> bytes:

@@ -135,8 +135,76 @@ static uint64_t hash_long(const uint8_t *in, size_t len, uint64_t seed) {
     return xxh3_avalanche(r);
 }
 
-/* XXH3_64bits_withSeed, all input lengths. */
+/* ---- candidate variant 1: the XXH3 draft of xxHash v0.7.1 / v0.7.2 (Aug-Oct 2019) — what a 2019 Rust port exposing
+ * `xxh3::hash64_with_seed` (crate xxh3 0.1.x; the same code later became twox-hash's xxh3 module) would have been written
+ * against.  Restated from memory of xxh3.h at those tags; NO known-answer vector for it exists in this image, so it is a
+ * CANDIDATE that `colorid hashcheck` can confirm or reject against a reference-built .bxi — parity unpinned.
+ * Differences from the frozen v0.8 for inputs up to 128 bytes: XXH3_avalanche multiplies by PRIME64_3; the 1..16-byte paths
+ * key the input with secret[0..16] +/- seed and have no bswap / rrmxmx steps.  (129..240 and long inputs: not restated —
+ * k-mers are at most 128 bytes here.) */
+static uint64_t v07_avalanche(uint64_t h) {
+    h ^= h >> 37; h *= P64_3; h ^= h >> 32;
+    return h;
+}
+static uint64_t v07_mix16(const uint8_t *in, const uint8_t *key, uint64_t seed) {
+    uint64_t ll1 = rd64(in), ll2 = rd64(in + 8);
+    return mul128_fold64(ll1 ^ (rd64(key) + seed), ll2 ^ (rd64(key + 8) - seed));
+}
+uint64_t orc_xxh3_v07_64_with_seed(const uint8_t *in, size_t len, uint64_t seed) {
+    const uint8_t *key = kSecret;
+    if (len <= 16) {
+        if (len > 8) {                                             /* XXH3_len_9to16_64b */
+            uint64_t ll1 = rd64(in) ^ (rd64(key) + seed);
+            uint64_t ll2 = rd64(in + len - 8) ^ (rd64(key + 8) - seed);
+            return v07_avalanche((uint64_t)len + (ll1 + ll2) + mul128_fold64(ll1, ll2));
+        }
+        if (len >= 4) {                                            /* XXH3_len_4to8_64b */
+            uint32_t in1 = rd32(in), in2 = rd32(in + len - 4);
+            uint64_t in64 = (uint64_t)in1 + ((uint64_t)in2 << 32);
+            uint64_t keyed = in64 ^ (rd64(key) + seed);
+            uint64_t mix64 = (uint64_t)len + ((keyed ^ (keyed >> 51)) * (uint64_t)P32_1);
+            return v07_avalanche((mix64 ^ (mix64 >> 47)) * P64_2);
+        }
+        if (len > 0) {                                             /* XXH3_len_1to3_64b */
+            uint8_t c1 = in[0], c2 = in[len >> 1], c3 = in[len - 1];
+            uint32_t combined = (uint32_t)c1 + ((uint32_t)c2 << 8) + ((uint32_t)c3 << 16) + ((uint32_t)len << 24);
+            uint64_t keyed = (uint64_t)combined ^ ((uint64_t)rd32(key) + seed);
+            return v07_avalanche(keyed * P64_1);
+        }
+        return 0;
+    }
+    if (len <= 128) {                                              /* XXH3_len_17to128_64b, nested form */
+        uint64_t acc = (uint64_t)len * P64_1;
+        if (len > 32) {
+            if (len > 64) {
+                if (len > 96) {
+                    acc += v07_mix16(in + 48, key + 96, seed);
+                    acc += v07_mix16(in + len - 64, key + 112, seed);
+                }
+                acc += v07_mix16(in + 32, key + 64, seed);
+                acc += v07_mix16(in + len - 48, key + 80, seed);
+            }
+            acc += v07_mix16(in + 16, key + 32, seed);
+            acc += v07_mix16(in + len - 32, key + 48, seed);
+        }
+        acc += v07_mix16(in, key, seed);
+        acc += v07_mix16(in + len - 16, key + 16, seed);
+        return v07_avalanche(acc);
+    }
+    return 0;   /* not restated beyond 128 bytes */
+}
+
+/* which variant orc_colorid.c's bit_index() uses: 0 = published v0.8 (default), 1 = the v0.7 draft above.  Process-wide test switch. */
+static int g_variant = 0;
+void orc_set_hash_variant(int v) { g_variant = v; }
+int orc_get_hash_variant(void) { return g_variant; }
+uint64_t orc_xxh3_published_64_with_seed(const uint8_t *in, size_t len, uint64_t seed);
 uint64_t orc_xxh3_64_with_seed(const uint8_t *in, size_t len, uint64_t seed) {
+    return g_variant == 1 ? orc_xxh3_v07_64_with_seed(in, len, seed) : orc_xxh3_published_64_with_seed(in, len, seed);
+}
+
+/* XXH3_64bits_withSeed, all input lengths. */
+uint64_t orc_xxh3_published_64_with_seed(const uint8_t *in, size_t len, uint64_t seed) {
     const uint8_t *sec = kSecret;
     if (len == 0) return xxh64_avalanche(seed ^ (rd64(sec + 56) ^ rd64(sec + 64)));
     if (len <= 3) {

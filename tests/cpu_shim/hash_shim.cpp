@@ -10,10 +10,12 @@
 extern "C" {
 
 // Hash `kmer` (len bytes) with seeds 0..n-1 exactly as a lane does: out of a dword image at byte offset `off`.
+static uint32_t g_hv = 0;   // hash variant (cid::kHashV08 / kHashV07) used by every shim call
+void shim_set_hash_variant(uint32_t hv) { g_hv = hv; }
 void shim_hash_seeds(const uint8_t *kmer, uint32_t len, uint32_t off, uint32_t n, uint64_t *out) {
     std::vector<uint32_t> img((off + len + 16 + 3) / 4 + 4, 0xA5A5A5A5u);
     memcpy(reinterpret_cast<uint8_t *>(img.data()) + off, kmer, len);
-    cid::xxh3_seeds(img.data(), off, len, n, [&](uint32_t s, uint64_t h) { out[s] = h; });
+    cid::xxh3_seeds(img.data(), off, len, n, g_hv, [&](uint32_t s, uint64_t h) { out[s] = h; });
 }
 
 // The packed path: an upper-case ACGT k-mer (k <= 32) -> LSB-first 2-bit code -> canonical code -> hashes of the
@@ -29,7 +31,7 @@ void shim_hash_canonical_code(const uint8_t *kmer, uint32_t k, uint32_t n, uint6
     *out_msb = msb;
     const cid::CodeReader r{canon};
     for (uint32_t j = 0; j < k; ++j) out_canon[j] = (uint8_t)r.rd8(j);
-    cid::xxh3_seeds_from(r, k, n, [&](uint32_t s, uint64_t h) { out[s] = h; });
+    cid::xxh3_seeds_from(r, k, n, g_hv, [&](uint32_t s, uint64_t h) { out[s] = h; });
 }
 
 // canonical ACGT k-mer (ASCII) -> minimizer as the device computes it from the 2-bit code -> ASCII, and its hashes (len m)
@@ -39,7 +41,7 @@ void shim_minimizer(const uint8_t *kmer, uint32_t k, uint32_t m, uint32_t n, uin
     const uint64_t mini = cid::minimizer_code(msb, k, m);
     const cid::CodeReader r{cid::rev_fields(mini, m)};
     for (uint32_t j = 0; j < m; ++j) out_mini[j] = (uint8_t)r.rd8(j);
-    cid::xxh3_seeds_from(r, m, n, [&](uint32_t s, uint64_t h) { out_hash[s] = h; });
+    cid::xxh3_seeds_from(r, m, n, g_hv, [&](uint32_t s, uint64_t h) { out_hash[s] = h; });
 }
 
 uint64_t shim_mod(uint64_t h, uint64_t m) {

@@ -109,3 +109,55 @@ def test_minimizer_code_matches_find_minimizer(shim, orc):
             assert out.raw == want, (k, m, s)
             for sd in range(3):
                 assert hs[sd] == xxhash.xxh3_64_intdigest(want, seed=sd)
+
+
+# ---------------------------------------------------------------------------------------------- the v0.7 draft (candidate variant)
+
+_M64 = (1 << 64) - 1
+_SECRET16 = bytes.fromhex("b8fe6c3923a44bbe7c01812cf721ad1cded46de9839097db7240a4a4b7b3671f")   # first 32 bytes of the default secret
+
+
+def _py_xxh3_17to32(b, seed, avalanche_mult):
+    """Third, independent restatement (Python ints) of XXH3's 17..32-byte path; the avalanche multiplier is the parameter."""
+    def rd(x, o):
+        return int.from_bytes(x[o:o + 8], "little")
+
+    def mix(p, o, key_o):
+        lo = rd(p, o) ^ ((rd(_SECRET16, key_o) + seed) & _M64)
+        hi = rd(p, o + 8) ^ ((rd(_SECRET16, key_o + 8) - seed) & _M64)
+        prod = lo * hi
+        return (prod & _M64) ^ (prod >> 64)
+    acc = (len(b) * 0x9E3779B185EBCA87 + mix(b, 0, 0) + mix(b, len(b) - 16, 16)) & _M64
+    acc ^= acc >> 37
+    acc = (acc * avalanche_mult) & _M64
+    return acc ^ (acc >> 32)
+
+
+def test_v07_draft_variant_device_matches_oracle_and_structure(shim, orc):
+    """CID_HASH_XXH3_V07 (candidate for crate xxh3 0.1.x, unverified against it): the device header and the oracle's separately
+    written restatement agree for every length 1..128 at every image alignment; and for the k-mer lengths that matter (17..32) a
+    third restatement in Python, validated with the v0.8 multiplier against python-xxhash, gives the same values with PRIME64_3."""
+    import xxhash
+    rnd = random.Random(12)
+    shim.shim_set_hash_variant.argtypes = [C.c_uint32]
+    shim.shim_set_hash_variant(1)
+    try:
+        for ln in list(range(1, 129)):
+            for trial in range(6):
+                b = bytes(rnd.getrandbits(8) for _ in range(ln)) if trial else (b"ACGT" * 32)[:ln]
+                for off in (0, 1, 3, 6):
+                    out = (C.c_uint64 * 6)()
+                    shim.shim_hash_seeds(b, ln, off, 6, out)
+                    for s in range(6):
+                        assert out[s] == orc.xxh3_v07(b, s), (ln, off, s)
+                if 17 <= ln <= 32:
+                    for s in (0, 1, 3):
+                        assert _py_xxh3_17to32(b, s, 0x165667919E3779F9) == xxhash.xxh3_64_intdigest(b, seed=s)   # the structure is right
+                        assert _py_xxh3_17to32(b, s, 0x165667B19E3779F9) == orc.xxh3_v07(b, s)                   # the draft = same, other multiplier
+                        assert orc.xxh3_v07(b, s) != orc.xxh3(b, s)
+    finally:
+        shim.shim_set_hash_variant(0)
+    # the oracle's switch routes every index hash through the chosen variant
+    with orc.hash_variant(1):
+        assert orc.xxh3(b"ACGTACGTACGTACGTACGTA", 2) == orc.xxh3_v07(b"ACGTACGTACGTACGTACGTA", 2)
+    assert orc.xxh3(b"ACGTACGTACGTACGTACGTA", 2) == xxhash.xxh3_64_intdigest(b"ACGTACGTACGTACGTACGTA", seed=2)

@@ -211,7 +211,7 @@ def test_config_d_shape_full_size(hip_ctx, orc):
     p, ucp = run(hx, torch, kmers[perm].contiguous(), freq[perm].contiguous())
     assert np.array_equal(p, whole) and np.array_equal(ucp, uc[perm.cpu().numpy()])
     hits, nu, sf = whole[:C], whole[C:2 * C], whole[2 * C:]
-    assert hits.sum() >= K * 0.9 and nu.sum() == (uc != -1).sum() and nu.sum() > K // 2
+    assert hits.sum() >= K * 0.9 and nu.sum() == (uc != -1).sum() and nu.sum() > K // 20   # ~2 false-positive colours per k-mer at this density
     assert sf.sum() == freq.cpu().numpy().astype(np.int64)[uc != -1].sum()
     # the oracle on a sample: its index holds just the rows the sample touches (the rest of its 6.4 GB stays untouched zero pages)
     S = 120_000
