@@ -11,6 +11,7 @@
 
 #include "cid_host_math.hpp"
 #include "cid_internal.hpp"
+#include "cid_objects.hpp"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -36,36 +37,9 @@ using cid::fail;
         if (e_ != hipSuccess) return fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_REDO, S_COUNT };
+using namespace cid::slots;
 
 }  // namespace
-
-struct cid_ctx {
-    int device = 0;
-    int n_cu = 256;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    void *slot[S_COUNT] = {};
-    size_t slot_bytes[S_COUNT] = {};
-    // result of the last cid_readid_count_sparse, fetched by cid_readid_sparse_fetch
-    uint64_t *sp_start = nullptr; uint32_t *sp_col = nullptr, *sp_cnt = nullptr;
-    uint64_t sp_rows = 0, sp_entries = 0;
-    // scratch block cache (cid::ctx_alloc / ctx_free)
-    struct Block { void *p; size_t bytes; bool used; };
-    std::vector<Block> blocks;
-    size_t idle_bytes = 0;
-};
-
-struct cid_index {
-    cid_ctx *ctx = nullptr;
-    uint64_t m = 0;
-    uint32_t n_hash = 0, k = 0, n_colors = 0, w32 = 0, w64 = 0, rs = 0;
-    uint32_t m_size = 0;  // > 0: minimizer (.mxi) index
-    uint64_t *mat = nullptr;
-    bool finalized = false;
-    cid::ModMagic mod{};
-};
 
 namespace cid {
 int ctx_alloc(cid_ctx *c, size_t bytes, void **out) {
@@ -129,8 +103,7 @@ uint32_t index_m_size(const cid_index *ix) { return ix->m_size; }
 const uint64_t *index_matrix(const cid_index *ix) { return ix->mat; }
 }  // namespace cid
 
-namespace {
-
+namespace cid {
 int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
     if (bytes == 0) bytes = 16;
     if (c->slot_bytes[s] < bytes) {
@@ -145,6 +118,23 @@ int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
     *out = c->slot[s];
     return CID_OK;
 }
+int check_ready(const cid_ctx *c, const cid_index *ix) {
+    if (!c || !ix) return fail(CID_ERR_INVALID, "null ctx/index");
+    if (!ix->finalized) return fail(CID_ERR_STATE, "index not finalized");
+    if (ix->ctx->device != c->device) return fail(CID_ERR_INVALID, "index lives on device %d, ctx on %d", ix->ctx->device, c->device);
+    return CID_OK;
+}
+// `search` is not defined on minimizer indices ("An index with minimizers (.mxi) is used, but not available for this
+// function", src/main.rs:569-573)
+int check_not_mini(const cid_index *ix) {
+    return ix->m_size ? fail(CID_ERR_UNSUPPORTED, "search on a minimizer (.mxi) index is not defined by the reference") : CID_OK;
+}
+}  // namespace cid
+
+namespace {
+using cid::check_not_mini;
+using cid::check_ready;
+using cid::slot_reserve;
 
 // Work per block: enough blocks to balance 256 CUs dynamically, few enough that the per-block flush of the
 // LDS counters (<= 3*C global atomics) stays negligible.
@@ -180,20 +170,7 @@ int fill_search_params(const cid_ctx *c, const cid_index *ix, cid::SearchParams 
     return CID_OK;
 }
 
-int check_ready(const cid_ctx *c, const cid_index *ix) {
-    if (!c || !ix) return fail(CID_ERR_INVALID, "null ctx/index");
-    if (!ix->finalized) return fail(CID_ERR_STATE, "index not finalized");
-    if (ix->ctx->device != c->device) return fail(CID_ERR_INVALID, "index lives on device %d, ctx on %d", ix->ctx->device, c->device);
-    return CID_OK;
-}
-
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-// `search` is not defined on minimizer indices ("An index with minimizers (.mxi) is used, but not available for this
-// function", src/main.rs:569-573)
-int check_not_mini(const cid_index *ix) {
-    return ix->m_size ? fail(CID_ERR_UNSUPPORTED, "search on a minimizer (.mxi) index is not defined by the reference") : CID_OK;
-}
 
 }  // namespace
 

@@ -1,0 +1,55 @@
+// The objects behind the ABI's opaque handles, shared by the translation units that implement them (cid_api.hip, cid_group.hip).
+#pragma once
+#include <vector>
+
+#include "cid_internal.hpp"
+
+namespace cid {
+namespace slots {
+enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_REDO, S_COUNT };
+}
+}  // namespace cid
+
+struct cid_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *slot[cid::slots::S_COUNT] = {};
+    size_t slot_bytes[cid::slots::S_COUNT] = {};
+    // result of the last cid_readid_count_sparse, fetched by cid_readid_sparse_fetch
+    uint64_t *sp_start = nullptr; uint32_t *sp_col = nullptr, *sp_cnt = nullptr;
+    uint64_t sp_rows = 0, sp_entries = 0;
+    // scratch block cache (cid::ctx_alloc / ctx_free)
+    struct Block { void *p; size_t bytes; bool used; };
+    std::vector<Block> blocks;
+    size_t idle_bytes = 0;
+    // second stream + events for the host-pointer entry points: the H2D copy of chunk i+1 runs beside the kernel of chunk i
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+};
+
+struct cid_index {
+    cid_ctx *ctx = nullptr;
+    uint64_t m = 0;
+    uint32_t n_hash = 0, k = 0, n_colors = 0, w32 = 0, w64 = 0, rs = 0;
+    uint32_t m_size = 0;  // > 0: minimizer (.mxi) index
+    uint64_t *mat = nullptr;
+    bool finalized = false;
+    cid::ModMagic mod{};
+};
+
+namespace cid {
+// grow-only per-role device buffers of a ctx
+int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out);
+// a5 launch on device-resident inputs/outputs (zeroes the counters first); asynchronous on the ctx stream
+int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, const uint32_t *d_freq,
+                        size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour,
+                        bool zero_counters = true);
+// a4 launch: d_and (rs words) and d_missing (int) are preset here; asynchronous
+int search_perfect_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers, uint64_t *d_and,
+                          int *d_missing);
+int check_ready(const cid_ctx *c, const cid_index *ix);
+int check_not_mini(const cid_index *ix);
+}  // namespace cid

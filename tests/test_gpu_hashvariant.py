@@ -109,7 +109,7 @@ def test_hashcheck_identifies_the_variant(orc, tmp_path):
         assert len(frac) == 2 * len(PHAGES)
         for acc in PHAGES:
             nk, present, f = frac[(name, acc)]
-            assert present == nk and f == 1.0 and nk > 30_000
+            assert present == nk and f == 1.0 and nk > 20_000
             assert frac[(other, acc)][2] < 0.05                              # ~ density^4 for a wrong variant
         verdict = [r for r in rows if r[0] == "verdict"][0]
         assert verdict[1] == name and rc == 0

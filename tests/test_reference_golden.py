@@ -68,7 +68,7 @@ def workdir(tmp_path):
 def test_flow_on_a_synthetic_run_matches_the_oracle(orc, workdir):
     genome = b"".join(orc.read_fasta(os.path.join(REFS, "Listeria_phage_B056.fasta")))
     rng = np.random.default_rng(548019)
-    recs = synth_fastq_records(rng, [genome], 6000, 100, lower_rate=0.0)
+    recs = synth_fastq_records(rng, [genome], 20000, 100, lower_rate=0.0)
     fq = os.path.join(workdir, "synthetic_B056.fastq.gz")
     write_fastq_gz(fq, recs)
     oix = orc.Index.build_single(os.path.join(workdir, "ref_file.txt"), 750000, 4, 27)
@@ -81,8 +81,8 @@ def test_flow_on_a_synthetic_run_matches_the_oracle(orc, workdir):
     want = oix.generate_report(fq, hits, nu, sf, modes, len(km), 0.35)
     assert sorted("\t".join(r) for r in rows) == sorted(l for l in want.splitlines() if l)
     b056 = [r for r in rows if r[2] == "Listeria_phage_B056"]
-    assert len(b056) == 1 and float(b056[0][3]) > 0.9                       # the phage the reads came from is covered
-    assert len(reads) == 6000 and sum(1 for r in reads if r[1] == "Listeria_phage_B056") > 3000
+    assert len(b056) == 1 and float(b056[0][3]) > 0.8                       # the phage the reads came from is covered
+    assert len(reads) == 20000 and sum(1 for r in reads if r[1] == "Listeria_phage_B056") > 10000
 
 
 def test_golden_row_of_test_sh(workdir):
