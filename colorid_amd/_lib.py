@@ -63,6 +63,19 @@ SIGNATURES = {
     "cid_readid_count_sparse": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64)]),
     "cid_readid_sparse_fetch": (C.c_int, [vp, vp, vp, vp]),
     "cid_readid_count_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp]),
+    "cid_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
+    "cid_group_size": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "cid_group_ctx": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "cid_group_uses_rccl": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "cid_group_destroy": (None, [vp]),
+    "cid_group_replicate_index": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "cid_group_search_count": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, vp, vp, vp]),
+    "cid_group_search_count_set": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
+    "cid_group_search_perfect": (C.c_int, [vp, C.POINTER(vp), vp, C.c_size_t, vp, C.POINTER(C.c_int)]),
+    "cid_group_search_perfect_set": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.POINTER(C.c_int)]),
+    "cid_group_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,
+                                                C.POINTER(C.c_uint64)]),
+    "cid_group_readid_sparse_fetch": (C.c_int, [vp, vp, vp, vp]),
     "cid_timer_start": (C.c_int, [vp]),
     "cid_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
 }

@@ -39,6 +39,9 @@ using cid::fail;
 
 using namespace cid::slots;
 
+// bytes per chunk of the pipelined host-pointer calls (H2D of chunk i+1 beside the kernel of chunk i)
+const size_t kUploadChunkBytes = getenv("CID_UPLOAD_CHUNK_BYTES") ? strtoull(getenv("CID_UPLOAD_CHUNK_BYTES"), nullptr, 10) : (256ull << 20);
+
 }  // namespace
 
 namespace cid {
@@ -200,7 +203,11 @@ int cid_ctx_create(int device_id, cid_ctx **out) {
     c->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+    bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return fail(CID_ERR_HIP, "stream/event creation failed");
@@ -230,6 +237,11 @@ void cid_ctx_destroy(cid_ctx *c) {
     for (int s = 0; s < S_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     for (const cid_ctx::Block &b : c->blocks) (void)hipFree(b.p);   // includes the sparse read_id result
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+    }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -425,9 +437,10 @@ void cid_index_destroy(cid_index *ix) {
 
 // ------------------------------------------------------------------------------------------------ a5
 
-static int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, const uint32_t *d_freq,
-                               size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
-                               uint32_t *d_unique_colour) {
+}  // extern "C"
+int cid::search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, const uint32_t *d_freq,
+                             size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
+                             uint32_t *d_unique_colour, bool zero_counters) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
     if ((rc = check_not_mini(ix))) return rc;
@@ -442,12 +455,16 @@ static int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d
     p.want_unique = (d_n_unique || d_sum_unique_freq || d_unique_colour) ? 1u : 0u;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
     const size_t cb = (size_t)ix->n_colors * 8;
-    HIP_TRY(hipMemsetAsync(d_hits, 0, cb, c->stream));
-    if (d_n_unique) HIP_TRY(hipMemsetAsync(d_n_unique, 0, cb, c->stream));
-    if (d_sum_unique_freq) HIP_TRY(hipMemsetAsync(d_sum_unique_freq, 0, cb, c->stream));
+    if (zero_counters) {
+        HIP_TRY(hipMemsetAsync(d_hits, 0, cb, c->stream));
+        if (d_n_unique) HIP_TRY(hipMemsetAsync(d_n_unique, 0, cb, c->stream));
+        if (d_sum_unique_freq) HIP_TRY(hipMemsetAsync(d_sum_unique_freq, 0, cb, c->stream));
+    }
     HIP_TRY(cid::launch_search_count(p, c->stream));
     return CID_OK;
 }
+using cid::search_count_launch;
+extern "C" {
 
 int cid_search_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint32_t *d_freq, size_t n_kmers,
                          uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour) {
@@ -543,33 +560,92 @@ static int search_count_to_host(cid_ctx *c, const cid_index *ix, const uint8_t *
     return CID_OK;
 }
 
-int cid_search_count(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
-                     uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+// Host-pointer form.  The batch goes through in chunks: the H2D copy of chunk i+1 (copy stream) runs beside the kernel of chunk i
+// (ctx stream), and the per-k-mer results of chunk i-1 come back while both run; counters accumulate on the device over the
+// chunks.  What is left is the PCIe time of 31+4 bytes in and 4 bytes out per k-mer.
+}  // extern "C"
+// host k-mers in, per-k-mer results out to the host, the 3*C counters (hits | n_unique | sum_unique_freq) left on the device in
+// *d_counters (the ctx's S_OUT slot); returns with both streams drained
+int cid::search_count_host_input(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers, bool want_unique,
+                                 uint32_t *unique_colour, uint64_t **d_counters) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
-    if (!hits || (n_kmers && !kmers)) return fail(CID_ERR_INVALID, "null argument");
+    if (n_kmers && !kmers) return fail(CID_ERR_INVALID, "null argument");
+    uint64_t hits_dummy = 0;
+    uint64_t *hits = &hits_dummy, *n_unique = want_unique ? &hits_dummy : nullptr, *sum_unique_freq = n_unique;
     HIP_TRY(hipSetDevice(c->device));
-    void *d_k, *d_f = nullptr;
-    rc = slot_reserve(c, S_KMERS, n_kmers * ix->k, &d_k);
+    const size_t C = ix->n_colors, k = ix->k;
+    size_t chunk = kUploadChunkBytes / (k + 8);
+    chunk = (chunk + 63) & ~(size_t)63;          // chunks start on a tile boundary: 64*k bytes keep the 16-byte alignment of the k-mer array
+    if (chunk >= n_kmers || c->stream != c->own_stream) chunk = n_kmers ? n_kmers : 1;   // a borrowed stream: keep everything on it
+    void *d_k, *d_f = nullptr, *d_out, *d_uc = nullptr;
+    const size_t two = chunk < n_kmers ? 2 : 1;
+    rc = slot_reserve(c, S_KMERS, two * chunk * k, &d_k); if (rc) return rc;
+    if (freq) { rc = slot_reserve(c, S_FREQ, two * chunk * 4, &d_f); if (rc) return rc; }
+    rc = slot_reserve(c, S_OUT, 3 * C * 8, &d_out); if (rc) return rc;
+    if (unique_colour) { rc = slot_reserve(c, S_UC, two * chunk * 4, &d_uc); if (rc) return rc; }
+    uint64_t *o = (uint64_t *)d_out;
+    HIP_TRY(hipMemsetAsync(o, 0, 3 * C * 8, c->stream));
+    const bool piped = two == 2;
+    hipStream_t cs = piped ? c->copy_stream : c->stream;
+    size_t prev_first = 0, prev_n = 0;
+    int prev_b = 0;
+    size_t i = 0;
+    for (size_t first = 0; first < n_kmers || first == 0; first += chunk, ++i) {
+        const size_t nk = n_kmers - first < chunk ? n_kmers - first : chunk;
+        const int b = (int)(i & 1);
+        uint8_t *dk = (uint8_t *)d_k + (size_t)b * chunk * k;
+        uint32_t *df = d_f ? (uint32_t *)d_f + (size_t)b * chunk : nullptr;
+        uint32_t *du = d_uc ? (uint32_t *)d_uc + (size_t)b * chunk : nullptr;
+        if (piped && i >= 2) HIP_TRY(hipStreamWaitEvent(cs, c->ev_done[b], 0));     // buffer b's previous kernel has consumed it
+        if (nk) HIP_TRY(hipMemcpyAsync(dk, kmers + first * k, nk * k, hipMemcpyHostToDevice, cs));
+        if (nk && freq) HIP_TRY(hipMemcpyAsync(df, freq + first, nk * 4, hipMemcpyHostToDevice, cs));
+        if (piped) {
+            HIP_TRY(hipEventRecord(c->ev_copied[b], cs));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_copied[b], 0));
+        }
+        rc = search_count_launch(c, ix, dk, nullptr, df, nk, o, n_unique ? o + C : nullptr, sum_unique_freq ? o + 2 * C : nullptr, du, false);
+        if (rc) return rc;
+        if (piped) HIP_TRY(hipEventRecord(c->ev_done[b], c->stream));
+        // the previous chunk's per-k-mer results: its kernel finished while this chunk was copied in
+        if (unique_colour && prev_n) {
+            if (piped) HIP_TRY(hipStreamWaitEvent(cs, c->ev_done[prev_b], 0));
+            HIP_TRY(hipMemcpyAsync(unique_colour + prev_first, (uint32_t *)d_uc + (size_t)prev_b * chunk, prev_n * 4, hipMemcpyDeviceToHost, cs));
+        }
+        prev_first = first; prev_n = nk; prev_b = b;
+        if (n_kmers == 0) break;
+    }
+    if (unique_colour && prev_n)
+        HIP_TRY(hipMemcpyAsync(unique_colour + prev_first, (uint32_t *)d_uc + (size_t)prev_b * chunk, prev_n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (piped) HIP_TRY(hipStreamSynchronize(cs));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hits;
+    *d_counters = o;
+    return CID_OK;
+}
+extern "C" {
+
+int cid_search_count(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
+                     uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    if (!hits) return fail(CID_ERR_INVALID, "null argument");
+    uint64_t *o = nullptr;
+    int rc = cid::search_count_host_input(c, ix, kmers, freq, n_kmers, n_unique || sum_unique_freq || unique_colour, unique_colour, &o);
     if (rc) return rc;
-    if (freq) { rc = slot_reserve(c, S_FREQ, n_kmers * 4, &d_f); if (rc) return rc; }
-    HIP_TRY(hipMemcpyAsync(d_k, kmers, n_kmers * ix->k, hipMemcpyHostToDevice, c->stream));
-    if (freq) HIP_TRY(hipMemcpyAsync(d_f, freq, n_kmers * 4, hipMemcpyHostToDevice, c->stream));
-    return search_count_to_host(c, ix, (const uint8_t *)d_k, nullptr, (const uint32_t *)d_f, n_kmers, hits, n_unique, sum_unique_freq,
-                                unique_colour);
+    const size_t C = ix->n_colors;
+    HIP_TRY(hipMemcpyAsync(hits, o, C * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_unique) HIP_TRY(hipMemcpyAsync(n_unique, o + C, C * 8, hipMemcpyDeviceToHost, c->stream));
+    if (sum_unique_freq) HIP_TRY(hipMemcpyAsync(sum_unique_freq, o + 2 * C, C * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ a4
 
-static int search_perfect_to_host(cid_ctx *c, const cid_index *ix, const uint8_t *d_k, const uint64_t *d_codes, size_t n_kmers,
-                                  uint32_t *and_words_le, int *any_row_missing) {
-    void *d_out;
+}  // extern "C"
+int cid::search_perfect_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_k, const uint64_t *d_codes, size_t n_kmers, uint64_t *d_and,
+                               int *d_missing) {
     int rc = check_not_mini(ix);
     if (rc) return rc;
-    rc = slot_reserve(c, S_MISC, (size_t)ix->rs * 8 + 16, &d_out);
-    if (rc) return rc;
-    uint64_t *d_and = (uint64_t *)d_out;
-    int *d_missing = (int *)(d_and + ix->rs);
     HIP_TRY(hipMemsetAsync(d_and, 0xFF, (size_t)ix->rs * 8, c->stream));
     HIP_TRY(hipMemsetAsync(d_missing, 0, 16, c->stream));
     cid::SearchParams p;
@@ -578,6 +654,19 @@ static int search_perfect_to_host(cid_ctx *c, const cid_index *ix, const uint8_t
     p.kmers = d_k; p.codes = d_codes; p.n_kmers = n_kmers; p.and_words = d_and; p.missing = d_missing;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
     HIP_TRY(cid::launch_search_perfect(p, c->stream));
+    return CID_OK;
+}
+extern "C" {
+
+static int search_perfect_to_host(cid_ctx *c, const cid_index *ix, const uint8_t *d_k, const uint64_t *d_codes, size_t n_kmers,
+                                  uint32_t *and_words_le, int *any_row_missing) {
+    void *d_out;
+    int rc = slot_reserve(c, S_MISC, (size_t)ix->rs * 8 + 16, &d_out);
+    if (rc) return rc;
+    uint64_t *d_and = (uint64_t *)d_out;
+    int *d_missing = (int *)(d_and + ix->rs);
+    rc = cid::search_perfect_launch(c, ix, d_k, d_codes, n_kmers, d_and, d_missing);
+    if (rc) return rc;
     std::vector<uint64_t> h(ix->rs);
     int missing = 0;
     HIP_TRY(hipMemcpyAsync(h.data(), d_and, (size_t)ix->rs * 8, hipMemcpyDeviceToHost, c->stream));

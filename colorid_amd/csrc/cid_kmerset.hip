@@ -165,6 +165,15 @@ struct cid_kmerset {
     size_t compact_at = 1ull << 30;   // merge the unsorted window buffer into the set beyond this many codes (8 GiB)
 };
 
+namespace cid {
+int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, const uint32_t **counts, uint64_t *n, uint32_t *k) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    *ctx = ks->ctx; *codes = ks->codes; *counts = ks->counts; *n = ks->n; *k = ks->k;
+    return CID_OK;
+}
+}  // namespace cid
+
 namespace {
 
 using cid::fail;

@@ -50,6 +50,8 @@ int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers,
 // a4 launch: d_and (rs words) and d_missing (int) are preset here; asynchronous
 int search_perfect_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers, uint64_t *d_and,
                           int *d_missing);
+int search_count_host_input(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers, bool want_unique,
+                            uint32_t *unique_colour, uint64_t **d_counters);
 int check_ready(const cid_ctx *c, const cid_index *ix);
 int check_not_mini(const cid_index *ix);
 }  // namespace cid

@@ -91,6 +91,10 @@ Classification kmer_poll_plus(const uint32_t *colours, const uint32_t *counts, s
                               const std::vector<double> &fp, double fp_correct);
 void read_counts_five_fields(const std::string &reads_file, const std::string &prefix);            // reports.rs:98-120
 
+// ---------------------------------------------------------------- several GPUs (--gpus N / --devices a,b,..)
+// When set, the drivers below shard every query over the group's ranks (cid_group_*); results are identical.
+void set_group(cid_group *group, const std::vector<cid_index *> &replicas);
+
 // ---------------------------------------------------------------- drivers (same names as the reference modules)
 namespace perfect_search {
 void batch_search(cid_ctx *, const std::vector<std::string> &files, const Bigsi &b);      // perfect_search.rs:6-60

@@ -30,6 +30,27 @@ static double ms_since(Clock::time_point t0) { return std::chrono::duration<doub
 static bool g_timing = getenv("COLORID_TIMING") != nullptr;
 static double g_ms_gpu = 0, g_ms_poll = 0;
 
+// ---------------------------------------------------------------------------------------------- several GPUs
+static cid_group *g_group = nullptr;
+static std::vector<cid_index *> g_replicas;
+void set_group(cid_group *group, const std::vector<cid_index *> &replicas) { g_group = group; g_replicas = replicas; }
+
+// the five hot calls, on one GPU or sharded over the group
+static int hot_search_count(cid_ctx *ctx, const Bigsi &b, const uint8_t *kmers, const uint32_t *freq, size_t n, uint64_t *hits, uint64_t *nu,
+                            uint64_t *sf, uint32_t *uc) {
+    return g_group ? cid_group_search_count(g_group, g_replicas.data(), kmers, freq, n, hits, nu, sf, uc)
+                   : cid_search_count(ctx, b.index, kmers, freq, n, hits, nu, sf, uc);
+}
+static int hot_search_count_set(cid_ctx *ctx, const Bigsi &b, const cid_kmerset *ks, uint64_t *hits, uint64_t *nu, uint64_t *sf, uint32_t *uc) {
+    return g_group ? cid_group_search_count_set(g_group, g_replicas.data(), ks, hits, nu, sf, uc) : cid_search_count_set(ctx, b.index, ks, hits, nu, sf, uc);
+}
+static int hot_search_perfect(cid_ctx *ctx, const Bigsi &b, const uint8_t *kmers, size_t n, uint32_t *words, int *missing) {
+    return g_group ? cid_group_search_perfect(g_group, g_replicas.data(), kmers, n, words, missing) : cid_search_perfect(ctx, b.index, kmers, n, words, missing);
+}
+static int hot_search_perfect_set(cid_ctx *ctx, const Bigsi &b, const cid_kmerset *ks, uint32_t *words, int *missing) {
+    return g_group ? cid_group_search_perfect_set(g_group, g_replicas.data(), ks, words, missing) : cid_search_perfect_set(ctx, b.index, ks, words, missing);
+}
+
 // ---------------------------------------------------------------------------------------------- reports.rs
 
 double false_prob(double m, double k, double n) { return std::pow(1.0 - std::pow(M_E, -((k * (n + 0.5)) / (m - 1.0))), k); }
@@ -212,7 +233,7 @@ static void perfect_one(cid_ctx *ctx, const Bigsi &b, const std::string &label, 
     const uint32_t w32 = (uint32_t)((b.colors.size() + 31) / 32);
     std::vector<uint32_t> words(w32);
     int missing = 0;
-    CID_TRY(cid_search_perfect(ctx, b.index, km.keys(), km.size(), words.data(), &missing));
+    CID_TRY(hot_search_perfect(ctx, b, km.keys(), km.size(), words.data(), &missing));
     print_perfect(b, label, km.size(), words, missing);
 }
 
@@ -241,7 +262,7 @@ void perfect_search::batch_search(cid_ctx *ctx, const std::vector<std::string> &
             } else {
                 std::vector<uint32_t> words((b.colors.size() + 31) / 32);
                 int missing = 0;
-                CID_TRY(cid_search_perfect_set(ctx, b.index, ks, words.data(), &missing));
+                CID_TRY(hot_search_perfect_set(ctx, b, ks, words.data(), &missing));
                 print_perfect(b, file, n, words, missing);
             }
             cid_kmerset_destroy(ks);
@@ -310,7 +331,7 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
             fprintf(stderr, "%zu k-mers in query\n", n_kmers);
             const auto t0 = Clock::now();
             if (!gene_search) { uc.resize(n_kmers); counts.resize(n_kmers); }
-            CID_TRY(cid_search_count_set(ctx, b.index, ks, hits.data(), gene_search ? nullptr : n_unique.data(),
+            CID_TRY(hot_search_count_set(ctx, b, ks, hits.data(), gene_search ? nullptr : n_unique.data(),
                                          gene_search ? nullptr : sum_freq.data(), gene_search ? nullptr : uc.data()));
             if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
             if (!gene_search) CID_TRY(cid_kmerset_download(ks, nullptr, counts.data()));
@@ -328,7 +349,7 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
             fprintf(stderr, "%zu k-mers in query\n", n_kmers);
             const auto t0 = Clock::now();
             if (!gene_search) uc.resize(n_kmers);
-            CID_TRY(cid_search_count(ctx, b.index, km.keys(), km.counts().data(), km.size(), hits.data(),
+            CID_TRY(hot_search_count(ctx, b, km.keys(), km.counts().data(), km.size(), hits.data(),
                                      gene_search ? nullptr : n_unique.data(), gene_search ? nullptr : sum_freq.data(),
                                      gene_search ? nullptr : uc.data()));
             if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
@@ -373,11 +394,16 @@ size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, dou
     std::vector<uint32_t> nk(n);
     std::vector<uint8_t> status(n);
     uint64_t n_entries = 0;
-    CID_TRY(cid_readid_count_sparse(ctx, b.index, rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1, rb.read_seq0.data(), n,
-                                    (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
+    if (g_group)
+        CID_TRY(cid_group_readid_count_sparse(g_group, g_replicas.data(), rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1,
+                                              rb.read_seq0.data(), n, (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
+    else
+        CID_TRY(cid_readid_count_sparse(ctx, b.index, rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1, rb.read_seq0.data(), n,
+                                        (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
     std::vector<uint64_t> row_start(n + 1);
     std::vector<uint32_t> colours(n_entries), counts(n_entries);
-    CID_TRY(cid_readid_sparse_fetch(ctx, row_start.data(), colours.data(), counts.data()));
+    if (g_group) CID_TRY(cid_group_readid_sparse_fetch(g_group, row_start.data(), colours.data(), counts.data()));
+    else CID_TRY(cid_readid_sparse_fetch(ctx, row_start.data(), colours.data(), counts.data()));
     g_ms_gpu += ms_since(t_gpu);
     const auto t_poll = Clock::now();
     for (size_t r = 0; r < n; ++r) {

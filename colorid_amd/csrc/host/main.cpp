@@ -1,7 +1,8 @@
 // `colorid` command line: the reference's drop-in surface for the query path (src/main.rs) —
 //   search  (src/main.rs:127-217, :555-628)   read_id (:241-328, :704-868)
 //   build   (:31-126, :466-554; needed to produce .bxi files)   info (:218-240, :630-703)
-// Same flag letters, defaults, stdout/stderr/file formats.  Extra flags: --device N, --hash xxh3_v08|xxh3_v07.  Extra command:
+// Same flag letters, defaults, stdout/stderr/file formats.  Extra flags: --device N, --gpus N | --devices a,b,.. (search, read_id:
+// the query is sharded over the GPUs), --hash xxh3_v08|xxh3_v07.  Extra command:
 // hashcheck (which hash variant was an index built with).
 // Minimizer indices (.mxi): build -m [-v M], info, read_id.  Not provided (outside the query path): batch_id, read_filter.
 #include <chrono>
@@ -62,8 +63,78 @@ bool ends_with(const std::string &s, const char *suf) {
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+// --gpus N (devices 0..N-1) or --devices a,b,... (an id may repeat: several ranks on one GPU): reads / k-mers are sharded over
+// the ranks, the index is replicated, per-accession counters are all-reduced (RCCL over xGMI).  The reference's -t (rayon threads,
+// src/main.rs:718-721) has no meaning here and is ignored with a note.
+struct Gpus {
+    cid_group *group = nullptr;            // nullptr: one GPU (--device)
+    cid_ctx *ctx = nullptr;                // rank 0's context (or the only one)
+    std::vector<cid_index *> replicas;
+};
+
+std::vector<int> device_list(const Args &a) {
+    std::vector<int> ids;
+    if (a.has("devices")) {
+        const std::string &s = a.one("devices");
+        size_t p = 0;
+        while (p <= s.size()) {
+            const size_t e = s.find(',', p);
+            const std::string tok = s.substr(p, e == std::string::npos ? std::string::npos : e - p);
+            char *end = nullptr;
+            const long v = strtol(tok.c_str(), &end, 10);
+            if (tok.empty() || *end) die("--devices expects a comma-separated list of device ids, got '%s'", s.c_str());
+            ids.push_back((int)v);
+            if (e == std::string::npos) break;
+            p = e + 1;
+        }
+    } else if (a.has("gpus")) {
+        const int n = num_or<int>(a, "gpus", 1);
+        if (n < 1) die("--gpus expects a positive number");
+        for (int i = 0; i < n; ++i) ids.push_back(i);
+    }
+    return ids;
+}
+
+Gpus make_gpus(const Args &a) {
+    Gpus g;
+    if (a.has("threads"))
+        fprintf(stderr, "note: -t %s is ignored: the search runs on the GPU (--gpus N shards the query over N GPUs)\n", a.one("threads").c_str());
+    const std::vector<int> ids = device_list(a);
+    const bool one_rank_group = ids.size() == 1 && getenv("COLORID_REDUCE");   // exercises the group / RCCL path with a single rank
+    if (ids.size() <= 1 && !one_rank_group) {
+        const int dev = ids.empty() ? num_or<int>(a, "device", 0) : ids[0];
+        if (cid_ctx_create(dev, &g.ctx) != CID_OK) die("cannot open GPU %d: %s (colorid has no CPU search path)", dev, cid_last_error());
+        return g;
+    }
+    if (cid_group_create(ids.data(), (int)ids.size(), &g.group) != CID_OK) die("cannot open %zu GPUs: %s", ids.size(), cid_last_error());
+    if (cid_group_ctx(g.group, 0, &g.ctx) != CID_OK) die("%s", cid_last_error());
+    int rccl = 0;
+    cid_group_uses_rccl(g.group, &rccl);
+    fprintf(stderr, "%zu ranks; per-accession counters are reduced %s\n", ids.size(), rccl ? "with RCCL all-reduce" : "through the host");
+    return g;
+}
+
+void replicate(Gpus &g, Bigsi &b) {   // after the index is loaded on rank 0
+    if (!g.group) return;
+    int n = 0;
+    cid_group_size(g.group, &n);
+    g.replicas.assign((size_t)n, nullptr);
+    if (cid_group_replicate_index(g.group, b.index, g.replicas.data()) != CID_OK) die("replicating the index: %s", cid_last_error());
+    set_group(g.group, g.replicas);
+}
+
+void release(Gpus &g, Bigsi &b) {
+    for (cid_index *ix : g.replicas)
+        if (ix && ix != b.index) cid_index_destroy(ix);
+    cid_index_destroy(b.index);
+    if (g.group) cid_group_destroy(g.group);   // owns the contexts
+    else cid_ctx_destroy(g.ctx);
+}
+
 cid_ctx *make_ctx(const Args &a) {
     cid_ctx *ctx = nullptr;
+    if (a.has("threads"))
+        fprintf(stderr, "note: -t %s is ignored: k-mer counting and Bloom inserts run on the GPU\n", a.one("threads").c_str());
     const int dev = num_or<int>(a, "device", 0);
     if (cid_ctx_create(dev, &ctx) != CID_OK) die("cannot open GPU %d: %s (colorid has no CPU search path)", dev, cid_last_error());
     return ctx;
@@ -92,7 +163,7 @@ Bigsi load_index(cid_ctx *ctx, const Args &a, bool meta_only = false) {
     return b;
 }
 
-const std::vector<OptSpec> kCommon = {{0, "device", true, false}, {0, "hash", true, false}};
+const std::vector<OptSpec> kCommon = {{0, "device", true, false}, {0, "hash", true, false}, {0, "gpus", true, false}, {0, "devices", true, false}};
 
 std::vector<OptSpec> with_common(std::vector<OptSpec> v) {
     v.insert(v.end(), kCommon.begin(), kCommon.end());
@@ -144,16 +215,17 @@ int cmd_search(int argc, char **argv) {
         fprintf(stderr, "Error: An index with minimizers (.mxi) is used, but not available for this function\n");
         return 0;
     }
-    cid_ctx *ctx = make_ctx(a);
+    Gpus gpus = make_gpus(a);
+    cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a);
+    replicate(gpus, b);
     if (a.flags.count("perfect_search")) {
         if (a.flags.count("multi_fasta")) perfect_search::batch_search_mf(ctx, files1, b);
         else perfect_search::batch_search(ctx, files1, b);
     } else {
         batch_search_pe::batch_search(ctx, files1, files2, b, filter, cov, a.flags.count("gene_search") > 0, quality);
     }
-    cid_index_destroy(b.index);
-    cid_ctx_destroy(ctx);
+    release(gpus, b);
     return 0;
 }
 
@@ -189,8 +261,10 @@ int cmd_read_id(int argc, char **argv) {
     const size_t bitvector_sample = num_or<size_t>(a, "bitvector_sample", 3);
     const std::string prefix = a.one("prefix");
     if (down_sample == 0 || batch == 0) die("attempt to calculate the remainder with a divisor of zero");
-    cid_ctx *ctx = make_ctx(a);
+    Gpus gpus = make_gpus(a);
+    cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a);
+    replicate(gpus, b);
     if (ends_with(fq[0], ".gz")) {
         if (fq.size() > 1) read_id_mt_pe::per_read_stream_pe(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
         else read_id_mt_pe::per_read_stream_se(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
@@ -198,8 +272,7 @@ int cmd_read_id(int argc, char **argv) {
         read_id_mt_pe::stream_fasta(ctx, fq, b, down_sample, fp_correct, batch, prefix, bitvector_sample);
     }
     read_counts_five_fields(prefix + "_reads.txt", prefix);
-    cid_index_destroy(b.index);
-    cid_ctx_destroy(ctx);
+    release(gpus, b);
     return 0;
 }
 

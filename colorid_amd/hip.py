@@ -260,3 +260,122 @@ class KmerSet:
 
     def __del__(self):
         self.close()
+
+
+class _BorrowedContext(Context):
+    """A rank's context owned by a Group (not destroyed on close)."""
+
+    def __init__(self, lib, h, device_id):
+        self.lib, self.h, self.device_id, self.stream = lib, h, device_id, None
+        self._children = weakref.WeakSet()
+
+    def close(self):
+        if getattr(self, "h", None):
+            for child in list(self._children):
+                child.close()
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Group:
+    """Several GPUs of one node (cid_group): reads / k-mers sharded over the ranks, the index replicated, per-accession
+    counters all-reduced (RCCL over xGMI; through the host when a device id repeats)."""
+
+    def __init__(self, device_ids):
+        self.lib = load_library()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = vp()
+        check(self.lib.cid_group_create(ids, len(device_ids), C.byref(h)))
+        self.h = h
+        self.n = len(device_ids)
+        self.ctxs = []
+        for r in range(self.n):
+            ch = vp()
+            check(self.lib.cid_group_ctx(self.h, r, C.byref(ch)))
+            self.ctxs.append(_BorrowedContext(self.lib, ch, device_ids[r]))
+        self._replica_handles = None
+        self._src = None
+
+    @property
+    def uses_rccl(self):
+        y = C.c_int(0)
+        check(self.lib.cid_group_uses_rccl(self.h, C.byref(y)))
+        return bool(y.value)
+
+    def replicate(self, index):
+        """index: a finalized Index made from self.ctxs[r] for some r (normally 0)"""
+        arr = (vp * self.n)()
+        check(self.lib.cid_group_replicate_index(self.h, index.h, arr))
+        self._replica_handles, self._src = arr, index
+        return self
+
+    def _idx(self):
+        assert self._replica_handles is not None, "call replicate() first"
+        return self._replica_handles, self._src
+
+    def search_count(self, kmers, freq=None):
+        arr, ix = self._idx()
+        kmers = np.ascontiguousarray(kmers, np.uint8).reshape(-1, ix.k)
+        K = kmers.shape[0]
+        f = None if freq is None else np.ascontiguousarray(freq, np.uint32)
+        hits, nu, sf = (np.zeros(ix.n_colors, np.uint64) for _ in range(3))
+        uc = np.zeros(K, np.uint32)
+        check(self.lib.cid_group_search_count(self.h, arr, _p(kmers), _p(f), K, _p(hits), _p(nu), _p(sf), _p(uc)))
+        return hits, nu, sf, uc
+
+    def search_count_set(self, kmerset):
+        arr, ix = self._idx()
+        hits, nu, sf = (np.zeros(ix.n_colors, np.uint64) for _ in range(3))
+        uc = np.zeros(len(kmerset), np.uint32)
+        check(self.lib.cid_group_search_count_set(self.h, arr, kmerset.h, _p(hits), _p(nu), _p(sf), _p(uc)))
+        return hits, nu, sf, uc
+
+    def search_perfect(self, kmers):
+        arr, ix = self._idx()
+        kmers = np.ascontiguousarray(kmers, np.uint8).reshape(-1, ix.k)
+        words = np.zeros(ix.w32, np.uint32)
+        missing = C.c_int(0)
+        check(self.lib.cid_group_search_perfect(self.h, arr, _p(kmers), kmers.shape[0], _p(words), C.byref(missing)))
+        return words, bool(missing.value)
+
+    def search_perfect_set(self, kmerset):
+        arr, ix = self._idx()
+        words = np.zeros(ix.w32, np.uint32)
+        missing = C.c_int(0)
+        check(self.lib.cid_group_search_perfect_set(self.h, arr, kmerset.h, _p(words), C.byref(missing)))
+        return words, bool(missing.value)
+
+    def readid_count_sparse(self, bases, seq_off, read_seq0, d=1, start_sample=3):
+        arr, _ = self._idx()
+        bases = np.ascontiguousarray(bases, np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        read_seq0 = np.ascontiguousarray(read_seq0, np.uint64)
+        n_reads = len(read_seq0) - 1
+        nk = np.zeros(n_reads, np.uint32)
+        st = np.zeros(n_reads, np.uint8)
+        ne = C.c_uint64(0)
+        check(self.lib.cid_group_readid_count_sparse(self.h, arr, _p(bases), _p(seq_off), len(seq_off) - 1, _p(read_seq0), n_reads, d,
+                                                     start_sample, _p(nk), _p(st), C.byref(ne)))
+        rs = np.zeros(n_reads + 1, np.uint64)
+        col = np.zeros(ne.value, np.uint32)
+        cnt = np.zeros(ne.value, np.uint32)
+        check(self.lib.cid_group_readid_sparse_fetch(self.h, _p(rs), _p(col), _p(cnt)))
+        return rs, col, cnt, nk, st
+
+    def close(self):
+        if getattr(self, "h", None):
+            if self._replica_handles is not None:
+                for r in range(self.n):
+                    h = self._replica_handles[r]
+                    if h and h != self._src.h.value:
+                        self.lib.cid_index_destroy(vp(h))
+                self._replica_handles = None
+            for c in self.ctxs:
+                c.close()          # closes the indices / k-mer sets made from the ranks' contexts
+            self.lib.cid_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

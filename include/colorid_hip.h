@@ -209,6 +209,37 @@ int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, c
                          uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_report, uint32_t *d_n_kmers,
                          uint8_t *d_status);
 
+/* ---- several GPUs of one node: the reference's parallel boundary is the rayon map over reads
+ *      (src/read_id_mt_pe.rs:300-302, `-t`, src/main.rs:718-721); here the reads / distinct k-mers of a query are sharded in
+ *      contiguous balanced ranges over N contexts, one per GPU, each with its own replica of the index (1.6-6.4 GB of 288 GB).
+ *      The single exchange step is the sum of the 3*n_colors per-accession counters (hits | n_unique | sum_unique_freq):
+ *      RCCL ncclAllReduce over xGMI on the ranks' streams (librccl is dlopen'ed on first use); if a device id is listed twice
+ *      (several ranks on one GPU — RCCL refuses that) or COLORID_REDUCE=host is set, the 24*n_colors bytes per rank are summed
+ *      through the host instead.  Perfect search ANDs the ranks' words on the host (RCCL has no bitwise reduction); read_id
+ *      needs no exchange, its rows are concatenated in input order.  Results are identical to the single-GPU calls.
+ *      A group and its ranks' contexts are used from one host thread at a time (the calls run one thread per rank inside). ---- */
+typedef struct cid_group cid_group;
+int cid_group_create(const int *device_ids, int n_devices, cid_group **out);
+int cid_group_size(const cid_group *, int *n_ranks);
+int cid_group_ctx(cid_group *, int rank, cid_ctx **out);   /* borrowed: load / build the index of rank 0 with it */
+int cid_group_uses_rccl(const cid_group *, int *yes);
+void cid_group_destroy(cid_group *);                         /* after the replicas and k-mer sets made from its contexts */
+/* replicas[r] = an index on rank r's device holding src's rows: src itself where src lives on that rank's ctx, otherwise a
+ * device-to-device copy (xGMI peer copy) that the caller destroys with cid_index_destroy. */
+int cid_group_replicate_index(cid_group *, cid_index *src, cid_index **replicas /* n_ranks */);
+/* a5 / a4 / a6-a10 with the work sharded over the ranks; arguments as in the single-GPU calls of the same name */
+int cid_group_search_count(cid_group *, cid_index *const *replicas, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
+                           uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int cid_group_search_count_set(cid_group *, cid_index *const *replicas, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
+                               uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int cid_group_search_perfect(cid_group *, cid_index *const *replicas, const uint8_t *kmers, size_t n_kmers, uint32_t *and_words_le,
+                             int *any_row_missing);
+int cid_group_search_perfect_set(cid_group *, cid_index *const *replicas, const cid_kmerset *, uint32_t *and_words_le, int *any_row_missing);
+int cid_group_readid_count_sparse(cid_group *, cid_index *const *replicas, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                                  const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *n_kmers,
+                                  uint8_t *status, uint64_t *n_entries);
+int cid_group_readid_sparse_fetch(cid_group *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
+
 /* ---- measurement helpers (bench only): HIP-event timing on the ctx stream ---- */
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */
