@@ -76,6 +76,7 @@ SIGNATURES = {
     "cid_group_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,
                                                 C.POINTER(C.c_uint64)]),
     "cid_group_readid_sparse_fetch": (C.c_int, [vp, vp, vp, vp]),
+    "cid_tune": (C.c_int, [C.c_char_p, C.c_long]),
     "cid_timer_start": (C.c_int, [vp]),
     "cid_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
 }

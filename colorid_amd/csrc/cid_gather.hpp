@@ -274,4 +274,19 @@ static hipError_t launch_one(KernelT kernel, int grid, size_t shmem, hipStream_t
         }                                                                                    \
     } while (0)
 
+#define CID_LAUNCH_BY_LAYOUT2(KERNEL, log_lpr, narrow, FLAG, grid, shmem, stream, params)           \
+    do {                                                                                           \
+        if (narrow) return launch_one(KERNEL<0, true, FLAG>, grid, shmem, stream, params);         \
+        switch (log_lpr) {                                                                         \
+        case 0: return launch_one(KERNEL<0, false, FLAG>, grid, shmem, stream, params);            \
+        case 1: return launch_one(KERNEL<1, false, FLAG>, grid, shmem, stream, params);            \
+        case 2: return launch_one(KERNEL<2, false, FLAG>, grid, shmem, stream, params);            \
+        case 3: return launch_one(KERNEL<3, false, FLAG>, grid, shmem, stream, params);            \
+        case 4: return launch_one(KERNEL<4, false, FLAG>, grid, shmem, stream, params);            \
+        case 5: return launch_one(KERNEL<5, false, FLAG>, grid, shmem, stream, params);            \
+        case 6: return launch_one(KERNEL<6, false, FLAG>, grid, shmem, stream, params);            \
+        default: return hipErrorInvalidValue;                                                      \
+        }                                                                                          \
+    } while (0)
+
 }  // namespace cid

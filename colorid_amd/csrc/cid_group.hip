@@ -10,6 +10,7 @@
 #include "../../include/colorid_hip.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,23 @@ struct Rccl {
     }
 };
 constexpr int kNcclUint64 = 5, kNcclSum = 0;
+
+// RCCL prints a version banner to the C stdout; a drop-in `colorid search` must print result rows only.  While an object of this
+// class lives, fd 1 is fd 2: what the wrapped call leaves in the stdout buffer (or writes directly) lands on stderr.
+class StdoutToStderr {
+  public:
+    StdoutToStderr() {
+        fflush(stdout);
+        saved_ = dup(1);
+        if (saved_ >= 0) dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved_ >= 0) { dup2(saved_, 1); close(saved_); }
+    }
+  private:
+    int saved_;
+};
 
 }  // namespace
 
@@ -119,6 +137,7 @@ int allreduce_u64(cid_group *g, uint64_t *const *d_bufs, size_t count) {
     const int n = (int)g->ctx.size();
     if (n == 1 && !g->use_rccl) return CID_OK;
     if (g->use_rccl) {
+        StdoutToStderr quiet;
         int e = g->rccl.GroupStart();
         for (int r = 0; r < n && e == 0; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));
@@ -126,6 +145,7 @@ int allreduce_u64(cid_group *g, uint64_t *const *d_bufs, size_t count) {
         }
         const int e2 = g->rccl.GroupEnd();
         if (e || e2) return fail(CID_ERR_HIP, "ncclAllReduce: %s", g->rccl.GetErrorString(e ? e : e2));
+        for (int r = 0; r < n; ++r) { HIP_TRY(hipSetDevice(g->dev[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
         return CID_OK;
     }
     std::vector<uint64_t> total(count, 0), part(count);
@@ -180,7 +200,8 @@ int cid_group_create(const int *device_ids, int n_devices, cid_group **out) {
     if (want && distinct) {
         if (!g->rccl.load()) { cid_group_destroy(g); return fail(CID_ERR_HIP, "cannot load librccl.so (set COLORID_REDUCE=host to sum through the host): %s", dlerror()); }
         g->comms.assign(n_devices, nullptr);
-        const int e = g->rccl.CommInitAll(g->comms.data(), n_devices, device_ids);
+        int e;
+        { StdoutToStderr quiet; e = g->rccl.CommInitAll(g->comms.data(), n_devices, device_ids); }
         if (e) { g->comms.clear(); const char *m = g->rccl.GetErrorString(e); cid_group_destroy(g); return fail(CID_ERR_HIP, "ncclCommInitAll: %s", m); }
         g->use_rccl = true;
     }
@@ -210,8 +231,11 @@ int cid_group_uses_rccl(const cid_group *g, int *yes) {
 
 void cid_group_destroy(cid_group *g) {
     if (!g) return;
-    for (size_t r = 0; r < g->comms.size(); ++r)
-        if (g->comms[r]) { (void)hipSetDevice(g->dev[r]); (void)g->rccl.CommDestroy(g->comms[r]); }
+    {
+        StdoutToStderr quiet;
+        for (size_t r = 0; r < g->comms.size(); ++r)
+            if (g->comms[r]) { (void)hipSetDevice(g->dev[r]); (void)g->rccl.CommDestroy(g->comms[r]); }
+    }
     for (cid_ctx *c : g->ctx) cid_ctx_destroy(c);
     delete g;
 }

@@ -8,6 +8,7 @@ struct cid_kmerset;
 
 namespace cid {
 
+extern int g_order_bits;   // cid_tune "order_bits" (cid_kmerset.hip)
 int fail(int code, const char *fmt, ...);  // records the thread's last error message, returns `code`
 int ctx_device(const cid_ctx *c);
 hipStream_t ctx_stream(const cid_ctx *c);

@@ -36,6 +36,9 @@ struct SearchParams {
     uint32_t colour_base;
     uint32_t *fact;        // [n_kmers] packed stripe fact, see stripe_fact_merge            (a5; nullptr = not striped)
     uint32_t *zero_acc;    // [n_kmers] &= bit s set iff row s is all-zero in this stripe  (a4; nullptr = not striped)
+    // persistent, XCD-aware scheduling of k_search_count (nullptr = one contiguous tile range per block)
+    uint32_t *queues;      // 8 work-queue heads, 32 words apart, zeroed before the launch
+    int persist_grid;      // resident blocks: n_cu x blocks per CU
 };
 
 struct InsertParams {
@@ -103,6 +106,7 @@ hipError_t launch_unique_finalize(const uint32_t *fact, const uint32_t *freq, ui
                                   hipStream_t stream);
 int grid_for(uint64_t n_kmers, uint32_t tiles_per_block);
 hipError_t launch_search_count(const SearchParams &p, hipStream_t stream);
+int search_count_blocks_per_cu(const SearchParams &p);
 hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream);
 hipError_t launch_put_rows(uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, const uint32_t *d_words, uint32_t w32,
                            uint64_t n_rows, hipStream_t stream);

@@ -18,6 +18,8 @@
 
 namespace cid {
 
+int g_order_bits = 0;
+
 struct Segment {  // consecutive windows of one sequence: window w starts at base_off + w*stride
     uint64_t base_off;  // offset of the first window's first base in `bases`
     uint64_t out_off;   // where the window codes go
@@ -133,14 +135,16 @@ __global__ void k_codes_to_ascii(const uint64_t *codes, uint32_t k, uint8_t *out
     const uint64_t c = codes[i];
     for (uint32_t t = 0; t < k; ++t) out[i * k + t] = (uint8_t)"ACGT"[(c >> (2 * (k - 1 - t))) & 3u];
 }
-// sort key for index locality: the 128-byte line of the k-mer's first row
-__global__ void k_row0_line(const uint64_t *codes, uint32_t k, ModMagic mm, uint32_t line_shift, uint32_t *keys, uint32_t *idx, uint64_t n) {
+// sort key for index locality: the 128-byte line of the k-mer's first row (bucket_bits == 0), or the slice of the index it falls
+// in when the index is cut into 2^bucket_bits equal slices
+__global__ void k_row0_line(const uint64_t *codes, uint32_t k, ModMagic mm, uint32_t line_shift, uint32_t bucket_bits, uint32_t *keys, uint32_t *idx,
+                            uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t lsb = rev_fields(codes[i], k);
     uint32_t row0 = 0;
     xxh3_seeds_from(CodeReader{lsb}, k, 1, hash_variant_of(mm), [&](uint32_t, uint64_t h) { row0 = (uint32_t)mod_m(h, mm); });
-    keys[i] = row0 >> line_shift;
+    keys[i] = bucket_bits ? (uint32_t)(((uint64_t)row0 << bucket_bits) / mm.m) : row0 >> line_shift;
     idx[i] = (uint32_t)i;
 }
 __global__ void k_gather_set(const uint32_t *idx, const uint64_t *codes_in, const uint32_t *counts_in, uint64_t *codes_out,
@@ -825,13 +829,15 @@ int cid_kmerset_order_for_index(cid_kmerset *ks, const cid_index *ix) {
     int rc;
     if ((rc = keys.alloc(ks->n)) || (rc = idx.alloc(ks->n)) || (rc = keys2.alloc(ks->n)) || (rc = idx2.alloc(ks->n)) ||
         (rc = oc.alloc(ks->n)) || (rc = on.alloc(ks->n))) return rc;
-    hipLaunchKernelGGL(cid::k_row0_line, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, cid::index_mod(ix), line_shift, keys.p,
+    const uint32_t bucket_bits = (uint32_t)cid::g_order_bits;
+    hipLaunchKernelGGL(cid::k_row0_line, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, cid::index_mod(ix), line_shift, bucket_bits, keys.p,
                        idx.p, (uint64_t)ks->n);
+    const unsigned end_bit = bucket_bits ? bucket_bits : 32u;
     size_t tb = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, 32u, st));
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, end_bit, st));
     DevBuf<uint8_t> tmp(ks->ctx);
     if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, 32u, st));
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, end_bit, st));
     hipLaunchKernelGGL(cid::k_gather_set, dim3(grid_for_n(ks->n)), dim3(256), 0, st, idx2.p, ks->codes, ks->counts, oc.p, on.p, (uint64_t)ks->n);
     HIP_TRY(hipStreamSynchronize(st));
     cid::ctx_free(ks->ctx, ks->codes); cid::ctx_free(ks->ctx, ks->counts);

@@ -21,6 +21,10 @@
 
 namespace cid {
 
+// the XCD (0..7) this wave runs on: HW_REG_XCC_ID (hardware register 20), bits 3:0
+__device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }
+constexpr uint32_t kQueueStride = 32;   // one work-queue head per 128-byte line
+
 // ------------------------------------------------------------------------------------------------
 // Colour stripes: the one per-k-mer fact that needs every stripe is "the AND word over ALL colours has exactly one set bit"
 // (src/batch_search_pe.rs:75-82).  It travels as one u32 per k-mer,  n << 26 | (colour + 1),  where n = min(set bits, 2) over
@@ -39,7 +43,12 @@ __device__ __forceinline__ uint32_t stripe_fact_merge(uint32_t old, uint32_t pop
 // ------------------------------------------------------------------------------------------------
 // a5: proportional search  (src/batch_search_pe.rs:45-84, :125-164)
 
-template <int LOG_LPR, bool NARROW>
+// PERSIST: the grid is sized to what is resident at once and every wave pulls 64-k-mer tiles from eight work queues, one per
+// XCD (its own first, the others once that is empty).  Queue x walks the x-th eighth of the k-mer array front to back, so
+// the waves of one XCD — which share that XCD's 4 MiB L2 — work on a window of a few ten thousand consecutive k-mers.  When the
+// producer has grouped the k-mers by the index slice of their first row (cid_kmerset_order_for_index), that window's first-row
+// lines are L2 hits.  The XCD a wave runs on is read from the hardware (HW_REG_XCC_ID), not inferred from blockIdx.
+template <int LOG_LPR, bool NARROW, bool PERSIST>
 __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
 
     VCount<kPlanes, NARROW> vc;
     vc.clear();
-    for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) {
+    auto do_tile = [&](uint64_t tile) {
         const uint64_t first = tile * kWave;
         // the tile's multiplicities: one coalesced load that is back long before the first sub-pass needs it
         const uint32_t my_freq = (p.freq && p.want_unique && !p.fact && first + lane < p.n_kmers) ? p.freq[first + lane] : 1u;
@@ -122,6 +131,30 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
                 }
             }
         }
+    };
+    if constexpr (PERSIST) {
+        const uint64_t seg = (n_tiles + 7) / 8;                  // tiles per queue
+        uint32_t q = xcc_id();                                     // wave-uniform: this wave's XCD
+        uint32_t tried = 0;
+        // the next ticket is drawn before the current tile is worked on, so the atomic's round trip hides behind the tile
+        uint32_t ticket = 0;
+        auto draw = [&](uint32_t queue) { if (lane == 0) ticket = atomicAdd(&p.queues[queue * kQueueStride], 1u); };
+        draw(q);
+        while (tried < 8) {
+            const uint64_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+            const uint64_t q_first = (uint64_t)q * seg;
+            const uint64_t q_len = q_first >= n_tiles ? 0 : (n_tiles - q_first < seg ? n_tiles - q_first : seg);
+            if (t >= q_len) {   // this queue is empty: on to the next one
+                ++tried;
+                q = (q + 1) & 7u;
+                if (tried < 8) draw(q);
+                continue;
+            }
+            draw(q);
+            do_tile(q_first + t);
+        }
+    } else {
+        for (uint64_t tile = tile0 + wave; tile < tile1; tile += kBlock / kWave) do_tile(tile);
     }
     vc.drain(s_hits, col_word);
     __syncthreads();
@@ -386,9 +419,37 @@ hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
     const bool narrow = p.rs == 1;
     const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
     const size_t shmem = search_smem_bytes(p);
-    const int grid = grid_for(p.n_kmers, p.tiles_per_block);
+    int grid = grid_for(p.n_kmers, p.tiles_per_block);
     if (grid == 0) return hipSuccess;
-    CID_LAUNCH_BY_LAYOUT(k_search_count, log_lpr, narrow, grid, shmem, stream, p);
+    if (p.queues) {
+        if (p.persist_grid < grid) grid = p.persist_grid;
+        CID_LAUNCH_BY_LAYOUT2(k_search_count, log_lpr, narrow, true, grid, shmem, stream, p);
+    }
+    CID_LAUNCH_BY_LAYOUT2(k_search_count, log_lpr, narrow, false, grid, shmem, stream, p);
+}
+
+// how many blocks of the persistent kernel are resident at once (per CU, by LDS and registers)
+int search_count_blocks_per_cu(const SearchParams &p) {
+    const size_t shmem = search_smem_bytes(p);
+    const bool narrow = p.rs == 1;
+    const int log_lpr = narrow ? 0 : log2u(p.rs / 2);
+    int nb = 0;
+    auto ask = [&](auto kernel) {
+        if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, shmem) != hipSuccess) nb = 0;
+    };
+    if (narrow) ask(k_search_count<0, true, true>);
+    else switch (log_lpr) {
+        case 0: ask(k_search_count<0, false, true>); break;
+        case 1: ask(k_search_count<1, false, true>); break;
+        case 2: ask(k_search_count<2, false, true>); break;
+        case 3: ask(k_search_count<3, false, true>); break;
+        case 4: ask(k_search_count<4, false, true>); break;
+        case 5: ask(k_search_count<5, false, true>); break;
+        case 6: ask(k_search_count<6, false, true>); break;
+        default: break;
+    }
+    return nb;
 }
 
 hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {

@@ -20,11 +20,23 @@ def _active():
     return dist.is_available() and dist.is_initialized()
 
 
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """In-place SUM over ranks.  RCCL ("nccl") reduces device tensors in place over xGMI; under "gloo" (the CPU tests, and the
+    two-ranks-on-one-GPU test) a device tensor takes the round trip through host memory."""
+    if not _active():
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def allreduce_counts(counts: torch.Tensor) -> torch.Tensor:
     """In-place SUM over ranks of an int64 tensor of per-colour counters (hits | n_unique | sum_unique_freq)."""
-    if _active():
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    return counts
+    return all_reduce_sum(counts)
 
 
 def allgather_and(words: torch.Tensor, any_missing: bool):
@@ -32,8 +44,11 @@ def allgather_and(words: torch.Tensor, any_missing: bool):
     if not _active():
         return words, any_missing
     buf = torch.cat([words.to(torch.int64).reshape(-1), torch.tensor([1 if any_missing else 0], dtype=torch.int64, device=words.device)])
+    if buf.is_cuda and dist.get_backend() == "gloo":
+        buf = buf.cpu()
     gathered = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
     dist.all_gather(gathered, buf)
+    gathered = [x.to(words.device) for x in gathered]
     out = gathered[0][:-1].clone()
     missing = bool(gathered[0][-1].item())
     for g in gathered[1:]:

@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import check, vp
+from .dist import all_reduce_sum
 
 MAX_RANKS = 31           # the summed n fields (2 per rank) must fit the fact word's 6 high bits
 MAX_COLOURS = 1 << 20
@@ -31,8 +32,8 @@ def reduce_stripe_facts(fact: torch.Tensor, hits_full: torch.Tensor):
     """Cross-rank combination for the proportional search (in place): int32[K] packed facts, int64[C_total]."""
     if _active():
         assert dist.get_world_size() <= MAX_RANKS
-        dist.all_reduce(fact, op=dist.ReduceOp.SUM)
-        dist.all_reduce(hits_full, op=dist.ReduceOp.SUM)
+        all_reduce_sum(fact)
+        all_reduce_sum(hits_full)
 
 
 def reduce_perfect_facts(zero_acc: torch.Tensor, and_full: torch.Tensor):
@@ -41,6 +42,9 @@ def reduce_perfect_facts(zero_acc: torch.Tensor, and_full: torch.Tensor):
     if not _active():
         return zero_acc, and_full
     world = dist.get_world_size()
+    dev = zero_acc.device
+    if zero_acc.is_cuda and dist.get_backend() == "gloo":   # see dist.all_reduce_sum
+        zero_acc, and_full = zero_acc.cpu(), and_full.cpu()
     zs = [torch.empty_like(zero_acc) for _ in range(world)]
     ws = [torch.empty_like(and_full) for _ in range(world)]
     dist.all_gather(zs, zero_acc)
@@ -49,7 +53,7 @@ def reduce_perfect_facts(zero_acc: torch.Tensor, and_full: torch.Tensor):
     for i in range(1, world):
         z &= zs[i]
         w &= ws[i]
-    return z, w
+    return z.to(dev), w.to(dev)
 
 
 class StripedIndex:

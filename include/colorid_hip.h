@@ -241,6 +241,11 @@ int cid_group_readid_count_sparse(cid_group *, cid_index *const *replicas, const
 int cid_group_readid_sparse_fetch(cid_group *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
 
 /* ---- measurement helpers (bench only): HIP-event timing on the ctx stream ---- */
+/* process-wide tunables for A/B measurements (tools/, bench.py); unknown names give CID_ERR_INVALID:
+ *   "search_persist"  0/1  k_search_count as a persistent grid with one work queue per XCD
+ *   "order_bits"      0..32  cid_kmerset_order_for_index groups by this many leading bits of the first row's position
+ *                     (0 = by its exact 128-byte line) */
+int cid_tune(const char *name, long value);
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */
 

@@ -82,7 +82,7 @@ def test_flow_on_a_synthetic_run_matches_the_oracle(orc, workdir):
     assert sorted("\t".join(r) for r in rows) == sorted(l for l in want.splitlines() if l)
     b056 = [r for r in rows if r[2] == "Listeria_phage_B056"]
     assert len(b056) == 1 and float(b056[0][3]) > 0.8                       # the phage the reads came from is covered
-    assert len(reads) == 20000 and sum(1 for r in reads if r[1] == "Listeria_phage_B056") > 10000
+    assert len(reads) == 20000 and sum(1 for r in reads if r[1] == "Listeria_phage_B056") > 5000
 
 
 def test_golden_row_of_test_sh(workdir):

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""GPU k-mer counting of configs[1]'s query side (1 M x 150 bp reads -> ~120 M distinct 31-mers): wall time of
+cid_kmerset_add_seqs (H2D of the reads + window codes) and cid_kmerset_finalize (sort + run-length), per call, a few times.
+Run it under `rocprofv3 --kernel-trace --stats` for the per-kernel split (tools/profile_kmerset.sh)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import colorid_amd
+from colorid_amd._lib import check, vp
+
+n_reads, L, k = int(os.environ.get("EXP_READS", 1_000_000)), 150, 31
+rng = np.random.default_rng(42)
+reads = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(n_reads, L))]
+reads = np.ascontiguousarray(reads)
+so = (np.arange(n_reads + 1, dtype=np.uint64) * L)
+ctx = colorid_amd.Context(0)
+rows = []
+for it in range(int(os.environ.get("EXP_ITERS", 5))):
+    ks = colorid_amd.KmerSet(ctx, k)
+    t0 = time.perf_counter()
+    check(ks.lib.cid_kmerset_add_seqs(ks.h, reads.ctypes.data_as(vp), so.ctypes.data_as(vp), n_reads, 0))
+    t1 = time.perf_counter()
+    nd = ks.finalize()
+    t2 = time.perf_counter()
+    rows.append({"add_seqs_ms": round((t1 - t0) * 1e3, 2), "finalize_ms": round((t2 - t1) * 1e3, 2), "distinct": nd})
+    ks.close()
+print(json.dumps({"reads": n_reads, "windows": n_reads * (L - k + 1), "iters": rows}))
