@@ -28,7 +28,7 @@ def _case(orc):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import plant, random_index, random_kmers
     rng = np.random.default_rng(2024)
-    C, n, k, m = 320, 3, 31, 50_021
+    C, n, k, m = 384, 3, 31, 50_021   # two stripes of 192 colours: stripes start on a multiple of 64
     oix = random_index(orc, rng, m, n, k, C, density=0.05, zero_row_frac=0.2)
     kmers = random_kmers(rng, 20_003, k)
     plant(oix, rng, kmers, frac=0.8, max_colours=2)
@@ -53,6 +53,12 @@ def _worker(rank, world, port, out_dir):
     dev = torch.device("cuda", 0)                 # both ranks on the one GPU
     ctx = colorid_amd.Context(0)
     ok = True
+    fails = []
+
+    def chk(i, cond):
+        if not cond:
+            fails.append(i)
+        return bool(cond)
     # ---- read-sharded, index replicated
     hx = colorid_amd.Index(ctx, m, n, k, C)
     hx.put_dense(oix.rows())
@@ -68,19 +74,19 @@ def _worker(rank, world, port, out_dir):
     allreduce_counts(out)
     want = oix.search_count(kmers, freq.astype(np.uint64))
     got = out.cpu().numpy().astype(np.uint64)
-    ok &= all(np.array_equal(got[i * C:(i + 1) * C], want[i]) for i in range(3))
-    ok &= np.array_equal(uc.cpu().numpy().view(np.uint32), want[3][lo:hi])
+    ok = chk(1, all(np.array_equal(got[i * C:(i + 1) * C], want[i]) for i in range(3))) and ok
+    ok = chk(2, np.array_equal(uc.cpu().numpy().view(np.uint32), want[3][lo:hi])) and ok
     single = hx.search_count(kmers, freq)          # the single-rank call on the same GPU
-    ok &= all(np.array_equal(a, b) for a, b in zip(single, want))
+    ok = chk(3, all(np.array_equal(a, b) for a, b in zip(single, want))) and ok
     # perfect search over a sharded subset: AND of the ranks' words, OR of the flags
     sub = kmers[:500]
     slo, shi = shard_bounds(len(sub), rank, world)
     w_r, m_r = hx.search_perfect(sub[slo:shi])
     words, missing = allgather_and(torch.from_numpy(w_r.astype(np.int64)).to(dev), m_r)
     pw, pm = oix.search_perfect(sub)
-    ok &= missing == pm and np.array_equal(words.cpu().numpy().astype(np.uint32), pw)
+    ok = chk(4, missing == pm and np.array_equal(words.cpu().numpy().astype(np.uint32), pw)) and ok
     hx.close()
-    # ---- colour stripes: rank r holds colours [r*160, (r+1)*160)
+    # ---- colour stripes: rank r holds colours [r*192, (r+1)*192)
     per = C // world
     base = rank * per
     w32s = (per + 31) // 32
@@ -92,17 +98,19 @@ def _worker(rank, world, port, out_dir):
     dka = torch.from_numpy(kmers.reshape(-1).copy()).to(dev).reshape(len(kmers), k)
     dfa = torch.from_numpy(freq.astype(np.int32)).to(dev)
     h, nu, sf, ucs = si.search_count(dka, dfa)
-    ok &= np.array_equal(h.cpu().numpy().astype(np.uint64), want[0]) and np.array_equal(nu.cpu().numpy().astype(np.uint64), want[1])
-    ok &= np.array_equal(sf.cpu().numpy().astype(np.uint64), want[2]) and np.array_equal(ucs.cpu().numpy().view(np.uint32), want[3])
-    ok &= int(want[1].sum()) > 1000
+    ok = chk(5, np.array_equal(h.cpu().numpy().astype(np.uint64), want[0]) and np.array_equal(nu.cpu().numpy().astype(np.uint64), want[1])) and ok
+    ok = chk(6, np.array_equal(sf.cpu().numpy().astype(np.uint64), want[2]) and np.array_equal(ucs.cpu().numpy().view(np.uint32), want[3])) and ok
+    ok = chk(7, int(want[1].sum()) > 1000) and ok
     ds = torch.from_numpy(sub.reshape(-1).copy()).to(dev).reshape(len(sub), k)
     aw, miss = si.search_perfect(ds, (C + 63) // 64, lambda b: b // 64)
-    ok &= miss == pm and np.array_equal(aw.cpu().numpy().view(np.uint32)[:oix.w32], pw)
+    ok = chk(8, miss == pm and np.array_equal(aw.cpu().numpy().view(np.uint32)[:oix.w32], pw)) and ok
     aw2, miss2 = si.search_perfect(dka[:3000].contiguous(), (C + 63) // 64, lambda b: b // 64)
     pw2, pm2 = oix.search_perfect(kmers[:3000])
-    ok &= miss2 == pm2 and np.array_equal(aw2.cpu().numpy().view(np.uint32)[:oix.w32], pw2)
+    ok = chk(9, miss2 == pm2 and np.array_equal(aw2.cpu().numpy().view(np.uint32)[:oix.w32], pw2)) and ok
     hs.close()
     ctx.close()
+    if not ok:
+        print(f"rank {rank}: checks failed: {fails}", file=sys.stderr)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

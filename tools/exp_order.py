@@ -50,6 +50,23 @@ def timed(ks, steps=10):
     return e0.elapsed_time(e1) / steps, out.cpu().numpy().copy(), K
 
 
+# ASCII input (the bench headline's input form), both schedulings
+kk, ff, cc = bench.make_reads_kmers(dev, 42, 1_000_000, 150, k, C, 0.01)
+K0 = kk.shape[0]
+uc0 = torch.empty(K0, dtype=torch.int32, device=dev)
+for persist in (0, 1):
+    check(lib.cid_tune(b"search_persist", persist))
+    def run_ascii():
+        hx.search_count_dev(kk.data_ptr(), ff.data_ptr(), K0, out.data_ptr(), out.data_ptr() + 8 * C, out.data_ptr() + 16 * C, uc0.data_ptr())
+    run_ascii(); run_ascii(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(10):
+        run_ascii()
+    e1.record(stream); torch.cuda.synchronize()
+    print(json.dumps({"input": "ascii, random order", "persist": persist, "ms": round(e0.elapsed_time(e1) / 10, 3), "C": C}), flush=True)
+del kk, ff, cc, uc0
+
 res = []
 ref = None
 orders = [("code order", None)] + [(f"2^{b} slices", int(b)) for b in (sys.argv[1:] or ["8", "10", "12", "14", "16"])] + [("exact line", 0)]
