@@ -78,6 +78,12 @@ def parse_args():
     ap.add_argument("--codes", action="store_true", help="experiment: feed 2-bit codes (cid_search_count_codes_dev) instead of ASCII")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--placement", choices=["replicated", "striped"], default="replicated",
+                    help="replicated (default, the metric's config): reads sharded over the GPUs, index replicated; striped = BASELINE "
+                         "configs[4]: every GPU holds one colour stripe of an index too large for one HBM and sees every k-mer")
+    ap.add_argument("--stripe-colours", type=int, default=512)
+    ap.add_argument("--stripe-log2-bloom", type=int, default=30)
+    ap.add_argument("--stripe-hashes", type=int, default=3)
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -178,6 +184,107 @@ def fill_background_fast(dev, mat_ptr, m, rs, n_colours, p, seed, digits=8):
     return q / (1 << digits)
 
 
+def box_clocks():
+    """sclk / mclk of GPU 0 as rocm-smi reports them right now (the pool's boxes differ by a few per cent on the same binary)."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        return {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower()}
+    except Exception as e:  # noqa: BLE001 - best effort, never fails the bench
+        return {"error": str(e)[:80]}
+
+
+def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
+    """BASELINE configs[4]: m = 2^30, n = 3, 512 colours per GPU (64 GiB resident per rank; 4096 colours = 512 GiB over 8 GPUs).
+    Every rank sees every k-mer (the distinct canonical 31-mers of the same 1 M reads), searches its own stripe
+    (cid_search_count_stripe_dev), then ONE all-reduce(SUM) of the packed per-k-mer facts (4 B per k-mer, RCCL over xGMI) + the tiny
+    per-colour vector, then the exactly-one-colour rule on every rank (cid_search_unique_finalize_dev).  value = distinct query
+    k-mers answered per second against the whole 512*N-colour index (weak scaling: the index grows with N, the query does not)."""
+    import colorid_amd
+    from colorid_amd.striped import StripedIndex, reduce_stripe_facts
+    Cs, n, k, m = a.stripe_colours, a.stripe_hashes, a.k, 1 << a.stripe_log2_bloom
+    C_total = Cs * world
+    t_setup = time.time()
+    hx = colorid_amd.Index(ctx, m, n, k, Cs)
+    ptr, rs = hx.device_matrix()
+    p_bg = fill_background_fast(dev, ptr, m, rs, Cs, 1.0 - math.exp(-n * 5_000_000 / m), seed=7 + rank)
+    kmers, freq, colour = make_reads_kmers(dev, 42, a.reads, a.read_len, k, C_total, a.error_rate)   # the same k-mers on every rank
+    K = kmers.shape[0]
+    base = rank * Cs
+    mine = torch.where((colour >= base) & (colour < base + Cs), colour - base, torch.full_like(colour, Cs)).contiguous()
+    torch.cuda.synchronize()
+    hx.insert_kmers_dev(kmers.data_ptr(), mine.data_ptr(), K)
+    ctx.synchronize()
+    hx.finalize()
+    del mine, colour
+    si = StripedIndex(ctx, [(hx, base)], C_total)
+    fact = torch.zeros(K, dtype=torch.int32, device=dev)
+    hits = torch.zeros(C_total, dtype=torch.int64, device=dev)
+    nu = torch.zeros(C_total, dtype=torch.int64, device=dev)
+    sf = torch.zeros(C_total, dtype=torch.int64, device=dev)
+    uc = torch.empty(K, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i=None):
+        fact.zero_(); hits.zero_(); nu.zero_(); sf.zero_()
+        if i is not None:
+            ev[i][0].record(stream)
+        si.search_count_local(kmers, fact, hits)
+        if i is not None:
+            ev[i][1].record(stream)
+        reduce_stripe_facts(fact, hits)
+        si.unique_finalize(fact, freq, nu, sf, uc)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank == 0:
+        w64 = (Cs + 63) // 64
+        alg = n * w64 * 8 + k + 4 + 4   # rows + k-mer bytes + the k-mer's packed fact read and written
+        achieved = alg * K / (kern_ms * 1e-3) / 1e9
+        # consistency: every unique k-mer is counted once, and the planted k-mers are found
+        ok = int(nu.sum().item()) == int((uc != -1).sum().item()) and int(hits.sum().item()) >= int(0.9 * K)
+        result = {
+            "metric": "query k-mers/s on 50M-bit n=4 256-colour BIGSI; bit-exact hits vs CPU",
+            "value": K * a.steps / elapsed, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"configs[4] (NOT the metric's config): m=2^{a.stripe_log2_bloom} n={n} k={k}, {Cs} colours per GPU x {world} GPU(s) = "
+                                   f"{C_total} colours colour-striped, the {K} distinct canonical k-mers of {a.reads} synthetic {a.read_len}bp reads seen by every GPU",
+                       "placement": "striped", "kmers": K, "bloom_size": m, "num_hash": n, "k_size": k, "n_colors_total": C_total,
+                       "stripe_bytes": m * rs * 8, "background_density": p_bg,
+                       "parallelism": f"colour stripes over {world} GPU(s); one all-reduce(SUM) of 4 B per k-mer + 8*C_total bytes per step",
+                       "collective_bytes_per_step": 4 * K + 8 * C_total, "setup_s": round(t_setup, 1), "consistent": bool(ok), "box": box_clocks()},
+            "roofline": {"bound": "hbm", "kernel": "k_search_count (stripe mode)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_kmer": alg, "kernel_ms": kern_ms, "kmers_per_launch": K},
+            "cpu_baseline": None,
+        }
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
+    hx.close()
+    ctx.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     a = parse_args()
     # stdout carries exactly one line, the JSON: RCCL prints a version banner to C stdout (late, when that is a pipe), so
@@ -208,6 +315,8 @@ def main():
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
 
+    if a.placement == "striped":
+        return bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream)
     C, n, k, m = a.colours, a.hashes, a.k, a.bloom
     t_setup = time.time()
     hx = colorid_amd.Index(ctx, m, n, k, C)
@@ -314,6 +423,34 @@ def main():
             ms_codes = e0.elapsed_time(e1) / 10
             result["config"]["codes_input"] = {"ms_per_step": ms_codes, "kmers_per_s": K / ms_codes * 1e3,
                                                "note": "2-bit-code input (cid_search_count_codes_dev), 10 steps, not the headline value"}
+            # and with the k-mers grouped by the index line of their first row (cid_order_codes_for_index_dev): the grouping timed on
+            # its own, then the search over the grouped k-mers — a quarter of the row fetches become hits in lines just fetched
+            oc, of = torch.empty_like(codes), torch.empty_like(freq)
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            for i in range(4):
+                if i == 1:
+                    e[0].record(stream)
+                check(hx.lib.cid_order_codes_for_index_dev(ctx.h, hx.h, vp(codes.data_ptr()), vp(freq.data_ptr()), K, vp(oc.data_ptr()), vp(of.data_ptr())))
+            e[1].record(stream)
+            for i in range(10):
+                out.zero_()
+                check(hx.lib.cid_search_count_codes_dev(ctx.h, hx.h, vp(oc.data_ptr()), vp(of.data_ptr()), K, vp(out.data_ptr()),
+                                                        vp(out.data_ptr() + 8 * C), vp(out.data_ptr() + 16 * C), vp(uc.data_ptr())))
+            e[2].record(stream)
+            torch.cuda.synchronize()
+            ordered_counts = out.clone()
+            ms_order, ms_search = e[0].elapsed_time(e[1]) / 3, e[1].elapsed_time(e[2]) / 10
+            out.zero_()
+            check(hx.lib.cid_search_count_codes_dev(ctx.h, hx.h, vp(codes.data_ptr()), vp(freq.data_ptr()), K, vp(out.data_ptr()),
+                                                    vp(out.data_ptr() + 8 * C), vp(out.data_ptr() + 16 * C), vp(uc.data_ptr())))
+            torch.cuda.synchronize()
+            result["config"]["producer_ordered"] = {
+                "search_ms": ms_search, "kmers_per_s": K / ms_search * 1e3, "grouping_ms": ms_order,
+                "in_step_ms": ms_order + ms_search, "same_counts": bool(torch.equal(ordered_counts, out)),
+                "note": "2-bit codes grouped by the 128-byte index line of their first row; search_ms = the search alone (ordering done by the "
+                        "producer), in_step_ms = grouping + search inside one step; neither is the headline value"}
+            del oc, of
+            result["config"]["box"] = box_clocks()
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
     if result is not None:

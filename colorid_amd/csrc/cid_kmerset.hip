@@ -145,14 +145,7 @@ __global__ void k_row0_line(const uint64_t *codes, uint32_t k, ModMagic mm, uint
     uint32_t row0 = 0;
     xxh3_seeds_from(CodeReader{lsb}, k, 1, hash_variant_of(mm), [&](uint32_t, uint64_t h) { row0 = (uint32_t)mod_m(h, mm); });
     keys[i] = bucket_bits ? (uint32_t)(((uint64_t)row0 << bucket_bits) / mm.m) : row0 >> line_shift;
-    idx[i] = (uint32_t)i;
-}
-__global__ void k_gather_set(const uint32_t *idx, const uint64_t *codes_in, const uint32_t *counts_in, uint64_t *codes_out,
-                             uint32_t *counts_out, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    codes_out[i] = codes_in[idx[i]];
-    counts_out[i] = counts_in[idx[i]];
+    if (idx) idx[i] = (uint32_t)i;
 }
 
 }  // namespace cid
@@ -813,33 +806,51 @@ int cid_kmerset_clean(cid_kmerset *ks, uint64_t t) {
     return CID_OK;
 }
 
+// Device arrays in, device arrays out (asynchronous on the ctx stream): the n k-mers (2-bit codes + multiplicities) grouped by the
+// 128-byte index line of their first row (cid_tune "order_bits" > 0: by that many leading bits of its position instead).  The
+// codes and the multiplicities each ride through their own stable radix sort on that key (same permutation), restricted to the
+// key's significant bits: no index array, no random gather.
+int cid_order_codes_for_index_dev(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n,
+                                  uint64_t *d_codes_out, uint32_t *d_counts_out) {
+    if (!c || !ix || (n && (!d_codes || !d_codes_out)) || (d_counts && !d_counts_out)) return fail(CID_ERR_INVALID, "null argument");
+    if (n == 0) return CID_OK;
+    if (n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mers");
+    if (cid::index_k(ix) > 32) return fail(CID_ERR_UNSUPPORTED, "2-bit codes need k_size <= 32");
+    HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+    hipStream_t st = cid::ctx_stream(c);
+    const uint32_t rs = cid::index_rs(ix);
+    uint32_t line_shift = 0;
+    while ((rs << line_shift) < 16) ++line_shift;   // rows per 128-byte line = 16 / rs
+    const uint32_t bucket_bits = (uint32_t)cid::g_order_bits;
+    const uint64_t max_key = bucket_bits ? ((1ull << bucket_bits) - 1) : ((cid::index_mod(ix).m - 1) >> line_shift);
+    unsigned end_bit = 1;
+    while (end_bit < 32 && (max_key >> end_bit)) ++end_bit;
+    DevBuf<uint32_t> keys(c), keys2(c);
+    int rc;
+    if ((rc = keys.alloc(n)) || (rc = keys2.alloc(n))) return rc;
+    hipLaunchKernelGGL(cid::k_row0_line, dim3(grid_for_n(n)), dim3(256), 0, st, d_codes, cid::index_k(ix), cid::index_mod(ix), line_shift, bucket_bits,
+                       keys.p, (uint32_t *)nullptr, (uint64_t)n);
+    size_t tb = 0, tb2 = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, d_codes, d_codes_out, n, 0u, end_bit, st));
+    if (d_counts) HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb2, keys.p, keys2.p, d_counts, d_counts_out, n, 0u, end_bit, st));
+    DevBuf<uint8_t> tmp(c);
+    if ((rc = tmp.alloc(tb > tb2 ? tb : tb2))) return rc;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys2.p, d_codes, d_codes_out, n, 0u, end_bit, st));
+    if (d_counts) HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb2, keys.p, keys2.p, d_counts, d_counts_out, n, 0u, end_bit, st));
+    return CID_OK;   // the scratch goes back to the ctx's block cache; later work on the same stream is ordered behind these kernels
+}
+
 int cid_kmerset_order_for_index(cid_kmerset *ks, const cid_index *ix) {
     if (!ks || !ix) return fail(CID_ERR_INVALID, "null argument");
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
     if (ks->n == 0) return CID_OK;
-    if (ks->n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 distinct k-mers");
     if (cid::index_k(ix) != ks->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", ks->k, cid::index_k(ix));
-    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
-    hipStream_t st = cid::ctx_stream(ks->ctx);
-    const uint32_t rs = cid::index_rs(ix);
-    uint32_t line_shift = 0;
-    while ((rs << line_shift) < 16) ++line_shift;   // rows per 128-byte line = 16 / rs
-    DevBuf<uint32_t> keys(ks->ctx), idx(ks->ctx), keys2(ks->ctx), idx2(ks->ctx), on(ks->ctx);
+    DevBuf<uint32_t> on(ks->ctx);
     DevBuf<uint64_t> oc(ks->ctx);
     int rc;
-    if ((rc = keys.alloc(ks->n)) || (rc = idx.alloc(ks->n)) || (rc = keys2.alloc(ks->n)) || (rc = idx2.alloc(ks->n)) ||
-        (rc = oc.alloc(ks->n)) || (rc = on.alloc(ks->n))) return rc;
-    const uint32_t bucket_bits = (uint32_t)cid::g_order_bits;
-    hipLaunchKernelGGL(cid::k_row0_line, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, cid::index_mod(ix), line_shift, bucket_bits, keys.p,
-                       idx.p, (uint64_t)ks->n);
-    const unsigned end_bit = bucket_bits ? bucket_bits : 32u;
-    size_t tb = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, end_bit, st));
-    DevBuf<uint8_t> tmp(ks->ctx);
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, end_bit, st));
-    hipLaunchKernelGGL(cid::k_gather_set, dim3(grid_for_n(ks->n)), dim3(256), 0, st, idx2.p, ks->codes, ks->counts, oc.p, on.p, (uint64_t)ks->n);
-    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = oc.alloc(ks->n)) || (rc = on.alloc(ks->n))) return rc;
+    if ((rc = cid_order_codes_for_index_dev(ks->ctx, ix, ks->codes, ks->counts, ks->n, oc.p, on.p))) return rc;
+    HIP_TRY(hipStreamSynchronize(cid::ctx_stream(ks->ctx)));
     cid::ctx_free(ks->ctx, ks->codes); cid::ctx_free(ks->ctx, ks->counts);
     ks->codes = oc.release(); ks->counts = on.release();
     return CID_OK;

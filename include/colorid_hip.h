@@ -160,6 +160,12 @@ int cid_kmerset_clean(cid_kmerset *, uint64_t t);
 /* Optional: reorder the set by the 128-byte index line of each k-mer's first row (seed 0), so that consecutive
  * k-mers share that line (order is unspecified in the reference: it iterates a hash map). */
 int cid_kmerset_order_for_index(cid_kmerset *, const cid_index *);
+/* The same on plain device arrays (asynchronous on the ctx stream; d_counts / d_counts_out may be NULL): out = in grouped by the
+ * index line of each k-mer's first row.  The search then finds a k-mer's first row in a line its neighbours have just fetched
+ * (one quarter fewer HBM line fetches at n = 4); the grouping itself costs about half a search of the same k-mers, so it
+ * pays when a set is searched more than once. */
+int cid_order_codes_for_index_dev(cid_ctx *, const cid_index *, const uint64_t *d_codes, const uint32_t *d_counts, size_t n_kmers,
+                                  uint64_t *d_codes_out, uint32_t *d_counts_out);
 /* Host copies in set order: n_distinct x k_size ASCII bytes and/or multiplicities (either may be NULL). */
 int cid_kmerset_download(const cid_kmerset *, uint8_t *kmers_ascii, uint32_t *counts);
 int cid_kmerset_device_arrays(const cid_kmerset *, void **d_codes, void **d_counts, uint64_t *n_distinct);
