@@ -78,6 +78,7 @@ def parse_args():
     ap.add_argument("--codes", action="store_true", help="experiment: feed 2-bit codes (cid_search_count_codes_dev) instead of ASCII")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="only the headline launches (profiling runs: every k_search_count dispatch is a headline step)")
     ap.add_argument("--placement", choices=["replicated", "striped"], default="replicated",
                     help="replicated (default, the metric's config): reads sharded over the GPUs, index replicated; striped = BASELINE "
                          "configs[4]: every GPU holds one colour stripe of an index too large for one HBM and sees every k-mer")
@@ -407,7 +408,7 @@ def main():
                          "alg_bytes_per_kmer": alg_bytes_per_kmer,
                          "kernel_ms": kern_ms, "kmers_per_launch": K},
         }
-        if world == 1 and not a.codes:
+        if world == 1 and not a.codes and not a.no_variants:
             # for the record, not the headline: the same query with the k-mers as the 2-bit codes that GPU k-mer counting
             # produces (what `colorid search` feeds the kernel for k <= 32): 8 instead of k input bytes per k-mer
             from colorid_amd._lib import check, vp
