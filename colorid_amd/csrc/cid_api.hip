@@ -803,10 +803,16 @@ static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_
     return CID_OK;
 }
 
+struct StripeArgs {   // read_id over colour stripes (ReadIdParams::zero_acc ...); all zero = a whole index
+    uint32_t *zero_acc = nullptr;
+    const uint32_t *zero_in = nullptr;
+    uint32_t zero_stride = 0, colour_base = 0, report_width = 0, write_nohits = 0;
+};
+
 static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off,
                            const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                            uint64_t max_read_bytes, uint64_t max_read_windows, const uint8_t *d_skip, bool clear_wide, uint32_t *d_report,
-                           uint32_t *d_n_kmers, uint8_t *d_status) {
+                           uint32_t *d_n_kmers, uint8_t *d_status, const StripeArgs &sa = StripeArgs()) {
     if (n_reads >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 reads in one batch");
     cid::ReadIdParams pb, pp;
     int waves_b, waves_p = 0;
@@ -818,6 +824,8 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
     auto fill = [&](cid::ReadIdParams &p, int waves) {
         p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
         p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status; p.skip = d_skip;
+        p.zero_acc = sa.zero_acc; p.zero_in = sa.zero_in; p.zero_stride = sa.zero_stride;
+        p.colour_base = sa.colour_base; p.report_width = sa.report_width; p.write_nohits = sa.write_nohits;
         uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
         if (rpb < (uint64_t)waves) rpb = waves;
         if (rpb > 256) rpb = 256;
@@ -858,6 +866,54 @@ int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases
     if (!d_bases || !d_seq_off || !d_read_seq0 || !d_report || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
     return readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, max_read_bytes, max_read_windows, nullptr,
                            true, d_report, d_n_kmers, d_status);
+}
+
+// read_id over colour stripes (src/read_id_mt_pe.rs:66-165 with the absent-row stop decided over ALL colours).
+// Pass 1, once per stripe: d_zero_acc[read * max_read_windows + q] &= the seeds whose row is all-zero in this stripe, for the
+// read's q-th distinct k-mer (first-occurrence order).  Between the passes the caller ANDs the arrays of different GPUs.
+// Pass 2, once per stripe: the ordered count; a k-mer is "absent" iff its accumulated mask is non-zero.
+static int readid_stripe_common(cid_ctx *c, const cid_index *ix, const void *d_bases, const void *d_seq_off, const void *d_read_seq0,
+                                uint64_t max_read_bytes, uint64_t max_read_windows) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!d_bases || !d_seq_off || !d_read_seq0) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->rs > 128) return fail(CID_ERR_UNSUPPORTED, "read_id over stripes wider than 8192 colours is not built: use narrower stripes");
+    if (max_read_windows == 0 || max_read_windows > (1u << 20)) return fail(CID_ERR_INVALID, "max_read_windows out of range");
+    if (readid_need(ix, 1, 0, max_read_bytes, max_read_windows) > kLdsBytes)
+        return fail(CID_ERR_UNSUPPORTED, "reads of %llu bases do not fit a wave's LDS: read_id over stripes handles short reads only",
+                    (unsigned long long)max_read_bytes);
+    return CID_OK;
+}
+
+int cid_readid_stripe_zero_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0,
+                               size_t n_reads, uint32_t stride_d, uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_zero_acc,
+                               uint32_t *d_n_kmers, uint8_t *d_status) {
+    int rc = readid_stripe_common(c, ix, d_bases, d_seq_off, d_read_seq0, max_read_bytes, max_read_windows);
+    if (rc) return rc;
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    if (n_reads == 0) return CID_OK;
+    if (!d_zero_acc || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
+    StripeArgs sa;
+    sa.zero_acc = d_zero_acc; sa.zero_stride = (uint32_t)max_read_windows; sa.report_width = ix->n_colors + 1;
+    return readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, 0, max_read_bytes, max_read_windows, nullptr, false,
+                           reinterpret_cast<uint32_t *>(d_zero_acc) /* never written in this pass */, d_n_kmers, d_status, sa);
+}
+
+int cid_readid_stripe_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0,
+                                size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint64_t max_read_bytes, uint64_t max_read_windows,
+                                uint32_t colour_base, uint32_t n_colors_total, int write_nohits, const uint32_t *d_zero_acc, uint32_t *d_report,
+                                uint32_t *d_n_kmers, uint8_t *d_status) {
+    int rc = readid_stripe_common(c, ix, d_bases, d_seq_off, d_read_seq0, max_read_bytes, max_read_windows);
+    if (rc) return rc;
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    if ((uint64_t)colour_base + ix->n_colors > n_colors_total) return fail(CID_ERR_INVALID, "stripe [%u, +%u) outside %u colours", colour_base, ix->n_colors, n_colors_total);
+    if (n_reads == 0) return CID_OK;
+    if (!d_zero_acc || !d_report || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
+    StripeArgs sa;
+    sa.zero_in = d_zero_acc; sa.zero_stride = (uint32_t)max_read_windows; sa.colour_base = colour_base; sa.report_width = n_colors_total + 1;
+    sa.write_nohits = write_nohits ? 1u : 0u;
+    return readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, max_read_bytes, max_read_windows, nullptr, false,
+                           d_report, d_n_kmers, d_status, sa);
 }
 
 // uploads the batch, runs the LDS or the sort-based kernel; leaves report / n_kmers / status in the ctx's device scratch

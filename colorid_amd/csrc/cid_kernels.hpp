@@ -79,6 +79,17 @@ struct ReadIdParams {
     const uint8_t *skip;        // NULL, or [n_reads]: non-zero = this read belongs to the sort-based path (k_readid_list), leave it alone
     uint32_t *redo_count;       // k_readid appends the reads it cannot pack (lower-case bases) to redo_list; k_readid_bytes
     uint32_t *redo_list;        //   works through that list (redo_list == NULL: through all reads, k > 32)
+    // colour stripes (this index = colours [colour_base, colour_base + n_colors) of a wider one; all three NULL/0 otherwise).
+    // "A row is absent" (read_id_mt_pe.rs:81-89, :126-128) means: all-zero in EVERY stripe, so the rule runs in two passes:
+    //   zero pass  (zero_acc != NULL): every distinct k-mer of every read is looked up, nothing is counted;
+    //              zero_acc[read * zero_stride + q] &= bit s set iff row s of the read's q-th k-mer is all-zero in this stripe;
+    //   count pass (zero_in  != NULL): the ordered search, with "absent" read from the accumulated masks instead of this stripe's rows;
+    //              report rows are report_width wide, this stripe's colours land at [colour_base ..), the no-hits entry at
+    //              [report_width - 1] is written by the stripe with write_nohits set.
+    uint32_t *zero_acc;
+    const uint32_t *zero_in;
+    uint32_t zero_stride;
+    uint32_t colour_base, report_width, write_nohits;
 };
 
 struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in first-occurrence order

@@ -69,10 +69,13 @@ constexpr int kReadPlanesDense = 2;
 // The in-order search (read_id_mt_pe.rs:66-102 classic / :104-165 sampled) over a dense run of distinct k-mers: k-mer j (0 <= j < count, order index q_base + j) has its row
 // numbers at ridx[s*stride + j].  U sub-passes (U * 64/LPR k-mers) have all their row loads issued before the first is
 // consumed: a read's search is a chain of dependent gather rounds, and what bounds the kernel is how many of them there are.
+// Colour stripes: zacc / zin point at this read's slice of ReadIdParams::zero_acc / zero_in (NULL = not that pass)
+struct StripeRead { uint32_t *zacc; const uint32_t *zin; };
+
 template <int LOG_LPR, bool NARROW, int U, int PLANES = kReadPlanes>
 __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t rs, uint32_t n, uint32_t C, uint32_t S, const uint32_t *ridx,
                                                   uint32_t stride, uint32_t count, uint32_t q_base, uint32_t *hist, bool &stopped,
-                                                  VCount<PLANES, NARROW> &vc, V16 &R, int lane) {
+                                                  VCount<PLANES, NARROW> &vc, V16 &R, int lane, StripeRead sr = StripeRead{nullptr, nullptr}) {
     constexpr int LPR = 1 << LOG_LPR;
     constexpr int KPW = kWave / LPR;
     if (stopped || !count) return;
@@ -102,6 +105,11 @@ __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t 
 #pragma unroll
             for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
             bool lv = live[u];
+            if (sr.zacc) {   // zero pass of a colour stripe: record, count nothing, never stop
+                if (lv && (lane & (LPR - 1)) == 0) sr.zacc[q_base + j[u]] &= (all_zero & seeds_mask);
+                continue;
+            }
+            if (sr.zin) all_zero = lv ? sr.zin[q_base + j[u]] : 0u;   // absent = all-zero in every stripe
             const bool miss = lv && (all_zero & seeds_mask);
             const uint64_t bm = __ballot(miss);
             // keep only the k-mers before the first absent row (lane order == k-mer order in a sub-pass)
@@ -146,11 +154,18 @@ __device__ __forceinline__ bool read_exceeds_caps(const ReadIdParams &p, uint64_
 // Output of one read: drain the counters, copy the histogram to the report row, clear it for the next read.
 template <bool NARROW, bool WIDE, int PLANES = kReadPlanes>
 __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, uint32_t *hist, uint32_t col_word, uint32_t *row_out,
-                                                   uint32_t C, int lane) {
+                                                   uint32_t C, int lane, const ReadIdParams &p) {
     if constexpr (!WIDE) {
         vc.drain(hist, col_word);
         wave_lds_fence();
-        for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        if (p.zero_acc) {          // zero pass: nothing to report
+            for (uint32_t c = lane; c <= C; c += kWave) hist[c] = 0;
+        } else if (p.zero_in) {    // count pass of a stripe: its colours inside the wide row; the no-hits entry from one stripe only
+            for (uint32_t c = lane; c < C; c += kWave) { row_out[p.colour_base + c] = hist[c]; hist[c] = 0; }
+            if (lane == 0) { if (p.write_nohits) row_out[p.report_width - 1] = hist[C]; hist[C] = 0; }
+        } else {
+            for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        }
     }
 }
 
@@ -194,17 +209,19 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
         const uint64_t g0 = p.seq_off[s0];
         const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
-        uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
+        const bool striped = p.zero_acc || p.zero_in;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
+        uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
+        const StripeRead sr{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
         if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
             if constexpr (!WIDE)  // (wide rows: the host zeroes the whole report before the launch)
-                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+                if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 1; }
             continue;
         }
         const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
         if (read_exceeds_caps(p, s0, s1, tb)) {   // the caller understated max_read_bytes / max_read_windows: leave the read alone
             if constexpr (!WIDE)
-                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+                if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 3; }
             continue;
         }
@@ -301,9 +318,9 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         if constexpr (!WIDE) {
             // the set is complete: search its nd k-mers in order, several sub-passes of row loads in flight at a time
             wave_lds_fence();
-            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane);
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
         }
-        readid_finish_read<NARROW, WIDE, PLANES>(vc, hist, col_word, row_out, C, lane);
+        readid_finish_read<NARROW, WIDE, PLANES>(vc, hist, col_word, row_out, C, lane, p);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
 }
@@ -347,17 +364,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
         const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
         const uint64_t g0 = p.seq_off[s0];
         const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
-        uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
+        const bool striped = p.zero_acc || p.zero_in;
+        uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
+        const StripeRead sr{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
         if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
             if constexpr (!WIDE)
-                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+                if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 1; }
             continue;
         }
         const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
         if (read_exceeds_caps(p, s0, s1, tb)) {
             if constexpr (!WIDE)
-                for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
+                if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 3; }
             continue;
         }
@@ -479,9 +498,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
         }
         if constexpr (!WIDE) {
             wave_lds_fence();
-            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane);
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
         }
-        readid_finish_read<NARROW, WIDE>(vc, hist, col_word, row_out, C, lane);
+        readid_finish_read<NARROW, WIDE>(vc, hist, col_word, row_out, C, lane, p);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
 }

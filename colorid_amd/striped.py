@@ -141,3 +141,33 @@ class StripedIndex:
         if missing:
             and_full.zero_()
         return and_full, missing
+
+    def readid_count(self, d_bases: torch.Tensor, d_seq_off: torch.Tensor, d_read_seq0: torch.Tensor, n_reads: int, stride_d: int,
+                     start_sample: int, max_read_bytes: int, max_read_windows: int):
+        """read_id over the stripes (src/read_id_mt_pe.rs:66-165): device tensors as for cid_readid_count_dev, identical on every
+        rank.  Returns (report int32[n_reads, C_total + 1], n_kmers int32[n_reads], status uint8[n_reads]).  Two passes: which rows
+        are all-zero in every stripe (AND over the stripes, and over the ranks), then the ordered count per stripe."""
+        dev = d_bases.device
+        zero = torch.full((n_reads, max_read_windows), -1, dtype=torch.int32, device=dev)
+        rep = torch.zeros((n_reads, self.n_colors + 1), dtype=torch.int32, device=dev)
+        nk = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+        st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+        args = (vp(d_bases.data_ptr()), vp(d_seq_off.data_ptr()), vp(d_read_seq0.data_ptr()), n_reads, stride_d)
+        self._to_ctx(dev)
+        for ix, _ in self.stripes:
+            check(self.lib.cid_readid_stripe_zero_dev(self.ctx.h, ix.h, *args, max_read_bytes, max_read_windows, vp(zero.data_ptr()),
+                                                      vp(nk.data_ptr()), vp(st.data_ptr())))
+        rank = dist.get_rank() if _active() else 0
+        if _active():
+            self._to_torch(dev)
+            zero, _ = reduce_perfect_facts(zero.reshape(-1), torch.zeros(1, dtype=torch.int64, device=dev))
+            zero = zero.reshape(n_reads, max_read_windows).contiguous()
+            self._to_ctx(dev)
+        for i, (ix, base) in enumerate(self.stripes):
+            check(self.lib.cid_readid_stripe_count_dev(self.ctx.h, ix.h, *args, start_sample, max_read_bytes, max_read_windows, base, self.n_colors,
+                                                       1 if (rank == 0 and i == 0) else 0, vp(zero.data_ptr()), vp(rep.data_ptr()),
+                                                       vp(nk.data_ptr()), vp(st.data_ptr())))
+        self._to_torch(dev)
+        if _active():
+            all_reduce_sum(rep)       # the ranks' columns are disjoint; the no-hits column comes from rank 0 only
+        return rep, nk, st

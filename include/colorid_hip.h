@@ -141,6 +141,23 @@ int cid_search_unique_finalize_dev(cid_ctx *, const uint32_t *d_fact, const uint
 int cid_search_perfect_stripe_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint64_t *d_codes, size_t n_kmers,
                                   uint64_t *d_and_words /* row_stride_words u64 */, uint32_t *d_zero_acc);
 int cid_index_row_stride_words(const cid_index *, uint64_t *row_stride_words);
+/* read_id over colour stripes (src/read_id_mt_pe.rs:66-165): per-colour counts of a stripe are independent of the other stripes
+ * except for the rule "the first k-mer with an absent row ends the read" (:81-89, :126-128), where absent means all-zero in EVERY
+ * stripe.  Two passes over the same resident read batch (arguments as cid_readid_count_dev; short reads, stripes of at most 8192
+ * colours):
+ *   zero pass, once per stripe: d_zero_acc[read * max_read_windows + q] (u32, preset to 0xFFFFFFFF) &= the seeds whose row is
+ *     all-zero in this stripe, q = the k-mer's rank in the read's first-occurrence order.  Stripes on other GPUs: AND the arrays
+ *     (all-gather + AND, or sum per-seed "non-zero" indicators) before the second pass.
+ *   count pass, once per stripe: the ordered search with "absent" read from the masks; d_report has n_colors_total + 1 columns
+ *     (zeroed by the caller before the first stripe), a stripe fills [colour_base, colour_base + n_colors) and — exactly one
+ *     stripe, write_nohits != 0 — the last column (the reference's no_hits_num entry). */
+int cid_readid_stripe_zero_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0,
+                               size_t n_reads, uint32_t stride_d, uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_zero_acc,
+                               uint32_t *d_n_kmers, uint8_t *d_status);
+int cid_readid_stripe_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0,
+                                size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint64_t max_read_bytes, uint64_t max_read_windows,
+                                uint32_t colour_base, uint32_t n_colors_total, int write_nohits, const uint32_t *d_zero_acc, uint32_t *d_report,
+                                uint32_t *d_n_kmers, uint8_t *d_status);
 
 /* ---- a10 (next row): canonical k-mer counting on the GPU for k_size <= 32 — replaces the
  *      FnvHashMap<String,usize> producers of `search`: kmerize_vector (src/kmer.rs:87-125, mode 0: has_no_n filter,

@@ -82,3 +82,53 @@ def test_stripe_calls_refuse_minimizer_index(orc, hip_ctx):
                                                    vp(b.data_ptr())) == -4
     assert hip_ctx.lib.cid_search_perfect_stripe_dev(hip_ctx.h, hx.h, vp(k.data_ptr()), None, 4, vp(h.data_ptr()), vp(a.data_ptr())) == -4
     hx.close()
+
+
+@pytest.mark.parametrize("n_colors,bounds", [(300, [(0, 128), (128, 300)]), (700, [(0, 256), (256, 512), (512, 700)])])
+@pytest.mark.parametrize("paired", [False, True])
+def test_readid_over_stripes_equals_whole_index(orc, hip_ctx, n_colors, bounds, paired):
+    """read_id with the index cut into colour stripes == the oracle on the whole index: the absent-row stop (a row that is zero in
+    one stripe but set in another is NOT absent), -B S sampling, -d strides, too-short and all-N reads."""
+    from colorid_amd.striped import StripedIndex
+    from test_gpu_readid import pack_reads
+    rng = np.random.default_rng(n_colors + paired)
+    k, n, m = 21, 3, 40_009
+    oix = random_index(orc, rng, m, n, k, n_colors, density=0.004, zero_row_frac=0.05)     # sparse: rows zero in one stripe, set in another
+    genome = bytes(rng.choice(list(b"ACGT"), size=30_000).astype(np.uint8))
+    for pos in range(0, len(genome) - k, 3):                                                # plant part of the genome in a few colours
+        km = orc.Kmers(k)
+        km.kmerize_vector(genome[pos:pos + k], 1)
+        for key in km.keys():
+            for c in rng.choice(n_colors, size=2, replace=False):
+                oix.insert(int(c), key.tobytes())
+    reads = []
+    for i in range(400):
+        st = int(rng.integers(0, len(genome) - 400))
+        L = int(rng.integers(60, 151))
+        mates = [genome[st:st + L]]
+        if paired:
+            mates.append(orc.revcomp(genome[st + 150:st + 150 + int(rng.integers(30, 151))]))
+        reads.append(mates)
+    reads += [[b"ACG"] + ([genome[:100]] if paired else []), [b"N" * 80] + ([b"N" * 5] if paired else []),
+              [bytes(rng.choice(list(b"ACGT"), size=120).astype(np.uint8))] + ([bytes(rng.choice(list(b"ACGT"), size=90).astype(np.uint8))] if paired else [])]
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    stripes = stripe_indices(hip_ctx, orc, oix, bounds)
+    si = StripedIndex(hip_ctx, stripes, n_colors)
+    db = torch.from_numpy(bases.copy()).cuda()
+    dso = torch.from_numpy(seq_off.astype(np.int64)).cuda()
+    dr0 = torch.from_numpy(read_seq0.astype(np.int64)).cuda()
+    max_bytes = max(sum(len(s) for s in r) for r in reads)
+    stopped_somewhere = False
+    for d, S in ((1, 3), (1, 0), (4, 2), (10, 3)):
+        max_win = max(sum(((len(s) - k) // d + 1) if len(s) >= k else 0 for s in r) for r in reads)
+        want = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+        rep, nk, st = si.readid_count(db, dso, dr0, len(reads), d, S, max_bytes, max_win)
+        assert np.array_equal(st.cpu().numpy(), want[2]) and np.array_equal(nk.cpu().numpy().view(np.uint32), want[1])
+        got = rep.cpu().numpy().view(np.uint32)
+        bad = np.flatnonzero((got != want[0]).any(axis=1))
+        assert len(bad) == 0, (d, S, bad[:5], want[0][bad[:1]], got[bad[:1]])
+        stopped_somewhere |= bool(want[0][:, n_colors].any())
+        assert want[0][:, :n_colors].sum() > 1000
+    assert stopped_somewhere                      # the absent-row stop was exercised
+    for hx, _ in stripes:
+        hx.close()
