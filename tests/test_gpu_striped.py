@@ -93,7 +93,7 @@ def test_readid_over_stripes_equals_whole_index(orc, hip_ctx, n_colors, bounds, 
     from test_gpu_readid import pack_reads
     rng = np.random.default_rng(n_colors + paired)
     k, n, m = 21, 3, 40_009
-    oix = random_index(orc, rng, m, n, k, n_colors, density=0.004, zero_row_frac=0.05)     # sparse: rows zero in one stripe, set in another
+    oix = random_index(orc, rng, m, n, k, n_colors, density=0.02, zero_row_frac=0.004)    # rows often zero in one stripe and set in another; ~1 % of the k-mers meet a truly absent row
     genome = bytes(rng.choice(list(b"ACGT"), size=30_000).astype(np.uint8))
     for pos in range(0, len(genome) - k, 3):                                                # plant part of the genome in a few colours
         km = orc.Kmers(k)
