@@ -118,7 +118,7 @@ def test_readid_over_stripes_equals_whole_index(orc, hip_ctx, n_colors, bounds, 
     dso = torch.from_numpy(seq_off.astype(np.int64)).cuda()
     dr0 = torch.from_numpy(read_seq0.astype(np.int64)).cuda()
     max_bytes = max(sum(len(s) for s in r) for r in reads)
-    stopped_somewhere = False
+    stopped_somewhere, total_counts = False, 0
     for d, S in ((1, 3), (1, 0), (4, 2), (10, 3)):
         max_win = max(sum(((len(s) - k) // d + 1) if len(s) >= k else 0 for s in r) for r in reads)
         want = oix.readid_counts(bases, seq_off, read_seq0, d, S)
@@ -128,7 +128,7 @@ def test_readid_over_stripes_equals_whole_index(orc, hip_ctx, n_colors, bounds, 
         bad = np.flatnonzero((got != want[0]).any(axis=1))
         assert len(bad) == 0, (d, S, bad[:5], want[0][bad[:1]], got[bad[:1]])
         stopped_somewhere |= bool(want[0][:, n_colors].any())
-        assert want[0][:, :n_colors].sum() > 1000
-    assert stopped_somewhere                      # the absent-row stop was exercised
+        total_counts += int(want[0][:, :n_colors].sum())
+    assert stopped_somewhere and total_counts > 5000     # the absent-row stop was exercised, and colours were counted
     for hx, _ in stripes:
         hx.close()
