@@ -721,6 +721,39 @@ int index_insert_codes(cid_index *ix, const uint64_t *d_codes, size_t n, uint32_
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CID_OK;
 }
+int index_insert_ascii(cid_index *ix, const uint8_t *d_ascii, size_t n, uint32_t k, uint32_t colour) {
+    if (!ix || (n && !d_ascii)) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
+    if (ix->k != k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", k, ix->k);
+    if (colour >= ix->n_colors) return fail(CID_ERR_INVALID, "colour %u >= n_colors", colour);
+    cid_ctx *c = ix->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    cid::InsertParams p{};
+    p.mat = ix->mat; p.rs = ix->rs; p.n_hash = ix->n_hash; p.k = ix->k; p.n_colors = ix->n_colors;
+    p.tiles_per_block = pick_tiles_per_block(c, n);
+    p.colour = colour; p.m_size = ix->m_size; p.mod = ix->mod; p.kmers = d_ascii; p.n_kmers = n;
+    HIP_TRY(cid::launch_insert_kmers(p, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
+}
+int search_count_ascii(cid_ctx *c, const cid_index *ix, const uint8_t *d_ascii, const uint32_t *d_counts, size_t n, uint32_t k,
+                       uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!hits) return fail(CID_ERR_INVALID, "null argument");
+    if (ix->k != k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", k, ix->k);
+    HIP_TRY(hipSetDevice(c->device));
+    return search_count_to_host(c, ix, d_ascii, nullptr, d_counts, n, hits, n_unique, sum_unique_freq, unique_colour);
+}
+int search_perfect_ascii(cid_ctx *c, const cid_index *ix, const uint8_t *d_ascii, size_t n, uint32_t k, uint32_t *and_words_le, int *any_row_missing) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!and_words_le || !any_row_missing) return fail(CID_ERR_INVALID, "null argument");
+    if (n == 0) return fail(CID_ERR_INVALID, "perfect search needs at least one k-mer (src/perfect_search.rs:22-23)");
+    if (ix->k != k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", k, ix->k);
+    HIP_TRY(hipSetDevice(c->device));
+    return search_perfect_to_host(c, ix, d_ascii, nullptr, n, and_words_le, any_row_missing);
+}
 int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,
                        uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour) {
     int rc = check_ready(c, ix);

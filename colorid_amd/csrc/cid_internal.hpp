@@ -45,6 +45,12 @@ int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_code
 // a finalized set's device arrays (codes ascending unless reordered; counts u32) and the ctx they live in
 int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, const uint32_t **counts, uint64_t *n, uint32_t *k);
 
+// the same three for sets of byte-string k-mers (k > 32): d_ascii = n x k bytes on the device
+int index_insert_ascii(cid_index *ix, const uint8_t *d_ascii, size_t n, uint32_t k, uint32_t colour);
+int search_count_ascii(cid_ctx *c, const cid_index *ix, const uint8_t *d_ascii, const uint32_t *d_counts, size_t n, uint32_t k,
+                       uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int search_perfect_ascii(cid_ctx *c, const cid_index *ix, const uint8_t *d_ascii, size_t n, uint32_t k, uint32_t *and_words_le, int *any_row_missing);
+
 // the non-zero rows of [row_begin, row_begin + n_rows) as .bxi row records in a host buffer (cid_kmerset.hip)
 int index_get_records(cid_ctx *c, const cid_index *ix, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records);
 

@@ -160,12 +160,22 @@ struct cid_kmerset {
     int *d_flags = nullptr;
     bool finalized = false;
     size_t compact_at = 1ull << 30;   // merge the unsorted window buffer into the set beyond this many codes (8 GiB)
+    // k > 32: keys are byte strings.  The sequences stay resident until finalize (g_bases, g_segs), where every window's key is
+    // described as a stretch of them, sorted on a 4-bit-per-base image (LSD radix, 16 bases per pass) and run-length counted; the
+    // finished set is n x k ASCII bytes (`ascii`) + counts, and feeds the byte-string kernels.
+    bool general = false;
+    int g_mode = -1;
+    uint8_t *g_bases = nullptr; size_t g_n = 0, g_cap = 0;
+    std::vector<cid::Segment> g_segs;
+    uint64_t g_windows = 0;
+    uint8_t *ascii = nullptr;
 };
 
 namespace cid {
 int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, const uint32_t **counts, uint64_t *n, uint32_t *k) {
     if (!ks) return fail(CID_ERR_INVALID, "null set");
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (ks->general) return fail(CID_ERR_UNSUPPORTED, "a k_size > 32 set holds byte strings: shard it with the host-pointer group calls");
     *ctx = ks->ctx; *codes = ks->codes; *counts = ks->counts; *n = ks->n; *k = ks->k;
     return CID_OK;
 }
@@ -271,6 +281,8 @@ int compact(cid_kmerset *ks) {
 
 }  // namespace
 
+// k > 32: all windows of the resident sequences -> distinct canonical byte strings + multiplicities
+static int finalize_general(cid_kmerset *ks);
 
 // ------------------------------------------------------------------------------------------------ long reads (read_id)
 // Per-read distinct k-mers in first-occurrence order for reads whose k-mer set does not fit a wave's LDS:
@@ -328,7 +340,7 @@ __device__ __forceinline__ uint32_t key_byte(const uint8_t *bases, uint64_t entr
     return b;
 }
 __global__ __launch_bounds__(256) void k_general_keys(const uint8_t *bases, const Segment *segs, uint32_t n_segs, uint64_t W, uint32_t k,
-                                                      uint32_t msz, uint32_t n_words, uint64_t *keyw, uint64_t *entry) {
+                                                      uint32_t msz, uint32_t n_words, uint64_t *keyw, uint64_t *entry, uint32_t upper_keys = 0) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
     uint32_t lo = 0, hi = n_segs;   // the segment holding window w: largest s with segs[s].out_off <= w
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(256) void k_general_keys(const uint8_t *bases, cons
     for (uint32_t j = 0; j < n_words; ++j) {
         uint64_t word = 0;
         for (uint32_t t = 16 * j; t < 16 * j + 16 && t < klen; ++t) {
-            const uint32_t c = key_byte(bases, e, klen, msz != 0, t);
+            const uint32_t c = key_byte(bases, e, klen, msz != 0 || upper_keys != 0, t);
             word |= (uint64_t)(((c >> 1) & 3u) | ((c >> 3) & 4u)) << (4u * (t & 15u));
         }
         keyw[(uint64_t)j * W + w] = word;
@@ -404,6 +416,54 @@ __global__ void k_first_flags_general(const uint64_t *keyw, uint32_t n_words, co
         if (same) first = read_of_window(wstart, n_reads, pw) != read_of_window(wstart, n_reads, w);
     }
     flags[w] = first ? 1u : 0u;
+}
+
+// ---- byte-string k-mer sets (k > 32): run boundaries over the whole sorted window list
+__global__ void k_first_flags_set(const uint64_t *keyw, uint32_t n_words, const uint64_t *entry, const uint32_t *sorted_idx, uint32_t *flags,
+                                  uint32_t *valid, uint64_t W) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > W) return;
+    if (i == W) { flags[i] = 0; valid[i] = 0; return; }   // slot W receives the totals
+    const uint32_t w = sorted_idx[i];
+    const bool ok = entry[w] != ~0ull;
+    bool first = ok;
+    if (first && i > 0) {
+        const uint32_t pw = sorted_idx[i - 1];
+        bool same = true;
+        for (uint32_t j = 0; j < n_words && same; ++j) same = keyw[(uint64_t)j * W + w] == keyw[(uint64_t)j * W + pw];
+        first = !same;
+    }
+    flags[i] = first ? 1u : 0u;
+    valid[i] = ok ? 1u : 0u;
+}
+// run j starts at sorted position starts[j]; starts[n_runs] = number of valid windows (they sort before the invalid ones)
+__global__ void k_set_starts(const uint32_t *flags, const uint32_t *pos, const uint32_t *sorted_idx, const uint64_t *entry, uint32_t *starts,
+                             uint64_t *run_entry, uint64_t W) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < W && flags[i]) { starts[pos[i]] = (uint32_t)i; run_entry[pos[i]] = entry[sorted_idx[i]]; }
+}
+__global__ void k_run_counts(const uint32_t *starts, uint32_t n_runs, uint32_t n_valid, uint32_t *counts) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_runs) counts[j] = (j + 1 < n_runs ? starts[j + 1] : n_valid) - starts[j];
+}
+__global__ void k_entries_to_ascii(const uint8_t *bases, const uint64_t *run_entry, uint32_t k, uint32_t upper, uint8_t *out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t e = run_entry[i];
+    for (uint32_t t = 0; t < k; ++t) out[i * k + t] = (uint8_t)key_byte(bases, e, k, upper != 0, t);
+}
+__global__ void k_compact_rows(const uint8_t *rows_in, const uint32_t *counts_in, const uint32_t *keep, const uint32_t *pos, uint32_t k,
+                               uint8_t *rows_out, uint32_t *counts_out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const uint64_t o = pos[i];
+    for (uint32_t t = 0; t < k; ++t) rows_out[o * k + t] = rows_in[i * k + t];
+    counts_out[o] = counts_in[i];
+}
+__global__ void k_keep_gt(const uint32_t *counts, uint64_t t, uint32_t *keep, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    keep[i] = (i < n && counts[i] > t) ? 1u : 0u;
 }
 
 // d_bases resident; host seq_off / read_seq0.  Writes report / n_kmers / status to DEVICE arrays.
@@ -650,15 +710,86 @@ int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_
 
 }  // namespace cid
 
+static int finalize_general(cid_kmerset *ks) {
+    using namespace cid;
+    cid_ctx *c = ks->ctx;
+    hipStream_t st = ctx_stream(c);
+    const uint64_t W = ks->g_windows;
+    const uint32_t k = ks->k;
+    ks->n = 0;
+    if (W == 0) return CID_OK;
+    if (W >= (1ull << 32) - 1) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 - 2 k-mer windows in one byte-string k-mer set");
+    const uint32_t n_words = (k + 15) / 16;
+    const uint32_t upper = ks->g_mode == 0 ? 1u : 0u;   // kmerize_vector upper-cases after the canonical choice (kmer.rs:104-117); fastq keeps case
+    DevBuf<Segment> d_segs(c);
+    DevBuf<uint64_t> keyw(c), entry(c), gath(c), sorted(c), run_entry(c);
+    DevBuf<uint32_t> idx(c), idx2(c), flags(c), valid(c), pos(c), vpos(c), starts(c);
+    int rc;
+    if ((rc = d_segs.alloc(ks->g_segs.size())) || (rc = keyw.alloc((size_t)n_words * W)) || (rc = entry.alloc(W)) || (rc = gath.alloc(W)) ||
+        (rc = sorted.alloc(W)) || (rc = idx.alloc(W)) || (rc = idx2.alloc(W)) || (rc = flags.alloc(W + 1)) || (rc = valid.alloc(W + 1)) ||
+        (rc = pos.alloc(W + 1)) || (rc = vpos.alloc(W + 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_segs.p, ks->g_segs.data(), ks->g_segs.size() * sizeof(Segment), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_general_keys, dim3(grid_for_n(W)), dim3(256), 0, st, ks->g_bases, d_segs.p, (uint32_t)ks->g_segs.size(), W, k, 0u, n_words,
+                       keyw.p, entry.p, upper);
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid_for_n(W)), dim3(256), 0, st, idx.p, W);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, gath.p, sorted.p, idx.p, idx2.p, W, 0u, 64u, st));
+    DevBuf<uint8_t> tmp(c);
+    if ((rc = tmp.alloc(tb))) return rc;
+    uint32_t *cur = idx.p, *nxt = idx2.p;
+    for (uint32_t j = 0; j < n_words; ++j) {   // stable LSD passes, least significant word (the key's LAST bases) first
+        const uint32_t word = n_words - 1 - j;
+        hipLaunchKernelGGL(k_gather_u64, dim3(grid_for_n(W)), dim3(256), 0, st, keyw.p + (size_t)word * W, cur, gath.p, W);
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, gath.p, sorted.p, cur, nxt, W, 0u, 64u, st));
+        std::swap(cur, nxt);
+    }
+    hipLaunchKernelGGL(k_first_flags_set, dim3(grid_for_n(W + 1)), dim3(256), 0, st, keyw.p, n_words, entry.p, cur, flags.p, valid.p, W);
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, flags.p, pos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
+    DevBuf<uint8_t> tmp2(c);
+    if ((rc = tmp2.alloc(tb2))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp2.p, tb2, flags.p, pos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
+    HIP_TRY(rocprim::exclusive_scan(tmp2.p, tb2, valid.p, vpos.p, 0u, W + 1, rocprim::plus<uint32_t>(), st));
+    uint32_t n_runs = 0, n_valid = 0;
+    HIP_TRY(hipMemcpyAsync(&n_runs, pos.p + W, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&n_valid, vpos.p + W, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_runs) {
+        DevBuf<uint32_t> counts(c);
+        DevBuf<uint8_t> ascii(c);
+        if ((rc = starts.alloc(n_runs)) || (rc = run_entry.alloc(n_runs)) || (rc = counts.alloc(n_runs)) || (rc = ascii.alloc((size_t)n_runs * k))) return rc;
+        hipLaunchKernelGGL(k_set_starts, dim3(grid_for_n(W)), dim3(256), 0, st, flags.p, pos.p, cur, entry.p, starts.p, run_entry.p, W);
+        hipLaunchKernelGGL(k_run_counts, dim3(grid_for_n(n_runs)), dim3(256), 0, st, starts.p, n_runs, n_valid, counts.p);
+        hipLaunchKernelGGL(k_entries_to_ascii, dim3(grid_for_n(n_runs)), dim3(256), 0, st, ks->g_bases, run_entry.p, k, upper, ascii.p, (uint64_t)n_runs);
+        HIP_TRY(hipStreamSynchronize(st));
+        ks->ascii = ascii.release();
+        ks->counts = counts.release();
+    }
+    ks->n = n_runs;
+    HIP_TRY(hipStreamSynchronize(st));
+    return CID_OK;
+}
+
+namespace cid {
+int kmerset_view_ascii(const cid_kmerset *ks, cid_ctx **ctx, const uint8_t **ascii, const uint32_t **counts, uint64_t *n, uint32_t *k) {
+    if (!ks) return fail(CID_ERR_INVALID, "null set");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (!ks->general) return fail(CID_ERR_INVALID, "not a byte-string k-mer set");
+    *ctx = ks->ctx; *ascii = ks->ascii; *counts = ks->counts; *n = ks->n; *k = ks->k;
+    return CID_OK;
+}
+}  // namespace cid
+
 extern "C" {
 
 int cid_kmerset_create(cid_ctx *c, uint32_t k_size, cid_kmerset **out) {
     if (!c || !out) return fail(CID_ERR_INVALID, "null ctx/out");
     *out = nullptr;
-    if (k_size == 0 || k_size > 32) return fail(CID_ERR_UNSUPPORTED, "GPU k-mer counting packs k-mers in 64 bits: k_size %u > 32", k_size);
+    if (k_size == 0 || k_size > cid::kMaxK) return fail(CID_ERR_UNSUPPORTED, "k_size %u outside 1..%u", k_size, cid::kMaxK);
     cid_kmerset *ks = new (std::nothrow) cid_kmerset();
     if (!ks) return fail(CID_ERR_NOMEM, "kmerset");
     ks->ctx = c; ks->k = k_size;
+    ks->general = k_size > 32;   // beyond 32 bases a k-mer no longer packs into one u64: byte-string keys
     ks->sentinel = k_size < 32 ? (1ull << (2 * k_size)) : ~0ull;   // never a canonical code (T^32's canonical form is A^32)
     ks->end_bit = k_size < 32 ? 2 * k_size + 1 : 64;
     HIP_TRY(hipSetDevice(cid::ctx_device(c)));
@@ -675,6 +806,38 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
     if (n_seqs == 0) return CID_OK;
     const uint64_t total_bases = seq_off[n_seqs];
     if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
+    if (ks->general) {   // keep the sequences resident; the windows are keyed, sorted and counted at finalize
+        if (ks->g_mode >= 0 && ks->g_mode != mode) return fail(CID_ERR_INVALID, "one byte-string k-mer set takes one mode");
+        ks->g_mode = mode;
+        HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+        hipStream_t st = cid::ctx_stream(ks->ctx);
+        for (size_t q = 0; q < n_seqs; ++q) {
+            if (seq_off[q + 1] < seq_off[q]) return fail(CID_ERR_INVALID, "seq_off not monotonic");
+            const uint64_t len = seq_off[q + 1] - seq_off[q];
+            if (len < ks->k) continue;
+            const uint64_t nw = len - ks->k + 1;
+            for (uint64_t w0 = 0; w0 < nw; w0 += cid::kSegWindows) {
+                const uint32_t mw = (uint32_t)(nw - w0 < cid::kSegWindows ? nw - w0 : cid::kSegWindows);
+                ks->g_segs.push_back(cid::Segment{ks->g_n + seq_off[q] + w0, ks->g_windows, mw, 1});
+                ks->g_windows += mw;
+            }
+        }
+        if (ks->g_n + total_bases > ks->g_cap) {
+            const size_t want = (ks->g_n + total_bases) * 3 / 2 + 256;
+            DevBuf<uint8_t> nb(ks->ctx);
+            int rc = nb.alloc(want);
+            if (rc) return rc;
+            if (ks->g_n) HIP_TRY(hipMemcpyAsync(nb.p, ks->g_bases, ks->g_n, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (ks->g_bases) cid::ctx_free(ks->ctx, ks->g_bases);
+            ks->g_bases = nb.release();
+            ks->g_cap = want;
+        }
+        if (total_bases) HIP_TRY(hipMemcpyAsync(ks->g_bases + ks->g_n, bases, total_bases, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        ks->g_n += total_bases;
+        return CID_OK;
+    }
     std::vector<cid::Segment> segs;
     uint64_t n_win_total = 0;
     for (size_t s = 0; s < n_seqs; ++s) {
@@ -728,6 +891,16 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
 int cid_kmerset_finalize(cid_kmerset *ks, uint64_t *n_distinct) {
     if (!ks) return fail(CID_ERR_INVALID, "null set");
     HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    if (ks->general) {
+        if (ks->finalized) { if (n_distinct) *n_distinct = ks->n; return CID_OK; }
+        const int rcg = finalize_general(ks);
+        if (rcg) return rcg;
+        if (ks->g_bases) { cid::ctx_free(ks->ctx, ks->g_bases); ks->g_bases = nullptr; ks->g_cap = ks->g_n = 0; }
+        ks->g_segs.clear(); ks->g_segs.shrink_to_fit();
+        ks->finalized = true;
+        if (n_distinct) *n_distinct = ks->n;
+        return CID_OK;
+    }
     int rc = compact(ks);
     if (rc) return rc;
     if (ks->raw) { cid::ctx_free(ks->ctx, ks->raw); ks->raw = nullptr; ks->cap_raw = 0; }
@@ -782,6 +955,27 @@ int cid_kmerset_clean(cid_kmerset *ks, uint64_t t) {
     if (ks->n == 0 || t == 0) return CID_OK;   // every stored k-mer has count >= 1 > 0
     HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
     hipStream_t st = cid::ctx_stream(ks->ctx);
+    if (ks->general) {
+        DevBuf<uint32_t> keep(ks->ctx), pos(ks->ctx), oc(ks->ctx);
+        DevBuf<uint8_t> orows(ks->ctx), tmp(ks->ctx);
+        int rc;
+        if ((rc = keep.alloc(ks->n + 1)) || (rc = pos.alloc(ks->n + 1))) return rc;
+        hipLaunchKernelGGL(cid::k_keep_gt, dim3(grid_for_n(ks->n + 1)), dim3(256), 0, st, ks->counts, t, keep.p, (uint64_t)ks->n);
+        size_t tb = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, keep.p, pos.p, 0u, ks->n + 1, rocprim::plus<uint32_t>(), st));
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, keep.p, pos.p, 0u, ks->n + 1, rocprim::plus<uint32_t>(), st));
+        uint32_t kept = 0;
+        HIP_TRY(hipMemcpyAsync(&kept, pos.p + ks->n, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if ((rc = orows.alloc((size_t)kept * ks->k)) || (rc = oc.alloc(kept))) return rc;
+        hipLaunchKernelGGL(cid::k_compact_rows, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->ascii, ks->counts, keep.p, pos.p, ks->k, orows.p, oc.p,
+                           (uint64_t)ks->n);
+        HIP_TRY(hipStreamSynchronize(st));
+        cid::ctx_free(ks->ctx, ks->ascii); cid::ctx_free(ks->ctx, ks->counts);
+        ks->ascii = orows.release(); ks->counts = oc.release(); ks->n = kept;
+        return CID_OK;
+    }
     DevBuf<uint8_t> flags(ks->ctx);
     DevBuf<uint64_t> oc(ks->ctx), d_count(ks->ctx);
     DevBuf<uint32_t> on(ks->ctx);
@@ -845,6 +1039,7 @@ int cid_kmerset_order_for_index(cid_kmerset *ks, const cid_index *ix) {
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
     if (ks->n == 0) return CID_OK;
     if (cid::index_k(ix) != ks->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", ks->k, cid::index_k(ix));
+    if (ks->general) return fail(CID_ERR_UNSUPPORTED, "ordering is defined for 2-bit-code sets (k_size <= 32)");
     DevBuf<uint32_t> on(ks->ctx);
     DevBuf<uint64_t> oc(ks->ctx);
     int rc;
@@ -862,7 +1057,10 @@ int cid_kmerset_download(const cid_kmerset *ks, uint8_t *kmers_ascii, uint32_t *
     if (ks->n == 0) return CID_OK;
     HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
     hipStream_t st = cid::ctx_stream(ks->ctx);
-    if (kmers_ascii) {
+    if (kmers_ascii && ks->general) {
+        HIP_TRY(hipMemcpyAsync(kmers_ascii, ks->ascii, ks->n * ks->k, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else if (kmers_ascii) {
         DevBuf<uint8_t> a(ks->ctx);
         int rc = a.alloc(ks->n * ks->k);
         if (rc) return rc;
@@ -876,6 +1074,7 @@ int cid_kmerset_download(const cid_kmerset *ks, uint8_t *kmers_ascii, uint32_t *
 
 int cid_kmerset_device_arrays(const cid_kmerset *ks, void **d_codes, void **d_counts, uint64_t *n) {
     if (!ks || !d_codes || !d_counts || !n) return fail(CID_ERR_INVALID, "null argument");
+    if (ks->general) return fail(CID_ERR_UNSUPPORTED, "a k_size > 32 set holds byte strings, not 2-bit codes");
     *d_codes = ks->codes; *d_counts = ks->counts; *n = ks->n;
     return CID_OK;
 }
@@ -886,6 +1085,8 @@ void cid_kmerset_destroy(cid_kmerset *ks) {
     if (ks->raw) cid::ctx_free(ks->ctx, ks->raw);
     if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
     if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
+    if (ks->g_bases) cid::ctx_free(ks->ctx, ks->g_bases);
+    if (ks->ascii) cid::ctx_free(ks->ctx, ks->ascii);
     if (ks->d_flags) (void)hipFree(ks->d_flags);
     delete ks;
 }
@@ -893,6 +1094,7 @@ void cid_kmerset_destroy(cid_kmerset *ks) {
 int cid_index_insert_kmerset(cid_index *ix, const cid_kmerset *ks, uint32_t colour) {
     if (!ks) return fail(CID_ERR_INVALID, "null set");
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (ks->general) return cid::index_insert_ascii(ix, ks->ascii, ks->n, ks->k, colour);
     return cid::index_insert_codes(ix, ks->codes, ks->n, ks->k, colour);
 }
 
@@ -900,12 +1102,14 @@ int cid_search_count_set(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks,
                          uint64_t *sum_unique_freq, uint32_t *unique_colour) {
     if (!ks) return fail(CID_ERR_INVALID, "null set");
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (ks->general) return cid::search_count_ascii(c, ix, ks->ascii, ks->counts, ks->n, ks->k, hits, n_unique, sum_unique_freq, unique_colour);
     return cid::search_count_codes(c, ix, ks->codes, ks->counts, ks->n, ks->k, hits, n_unique, sum_unique_freq, unique_colour);
 }
 
 int cid_search_perfect_set(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks, uint32_t *and_words_le, int *any_row_missing) {
     if (!ks) return fail(CID_ERR_INVALID, "null set");
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (ks->general) return cid::search_perfect_ascii(c, ix, ks->ascii, ks->n, ks->k, and_words_le, any_row_missing);
     return cid::search_perfect_codes(c, ix, ks->codes, ks->n, ks->k, and_words_le, any_row_missing);
 }
 

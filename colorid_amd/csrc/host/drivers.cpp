@@ -156,10 +156,12 @@ static void generate_report_gene(const std::string &query, const Bigsi &b, const
 // ---------------------------------------------------------------------------------------------- perfect_search.rs
 
 // ---------------------------------------------------------------------------------------------- GPU k-mer counting
-//  k <= 32: the k-mer map is built and kept on the device; COLORID_HOST_KMERS=1 forces the host map.
+//  the k-mer map is built and kept on the device (2-bit codes for k <= 32, byte strings beyond);
+// COLORID_HOST_KMERS=1 forces the host map.
 
-bool gpu_counting_enabled(uint64_t k) { return k <= 32 && !getenv("COLORID_HOST_KMERS"); }
-static bool gpu_counting(const Bigsi &b) { return gpu_counting_enabled(b.k_size); }
+bool gpu_counting_enabled(uint64_t k) { return k <= 128 && !getenv("COLORID_HOST_KMERS"); }
+// (a byte-string set, k > 32, cannot be sliced device-to-device over a group's ranks: with several GPUs those k-mers take the host map)
+static bool gpu_counting(const Bigsi &b) { return gpu_counting_enabled(b.k_size) && !(g_group && b.k_size > 32); }
 
 struct SeqBatch {
     std::vector<uint8_t> bases;

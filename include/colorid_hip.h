@@ -159,14 +159,18 @@ int cid_readid_stripe_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_b
                                 uint32_t colour_base, uint32_t n_colors_total, int write_nohits, const uint32_t *d_zero_acc, uint32_t *d_report,
                                 uint32_t *d_n_kmers, uint8_t *d_status);
 
-/* ---- a10 (next row): canonical k-mer counting on the GPU for k_size <= 32 — replaces the
+/* ---- a10 (next row): canonical k-mer counting on the GPU — replaces the
  *      FnvHashMap<String,usize> producers of `search`: kmerize_vector (src/kmer.rs:87-125, mode 0: has_no_n filter,
  *      orientation chosen on the raw bytes, then upper-cased) and the fastq bodies (src/kmer.rs:481-503 / :619-647,
  *      mode 1: has_no_n filter, case preserved — a lower-case base cannot be packed and makes add_seqs return
  *      CID_ERR_UNSUPPORTED: count that file on the host).  Sequences: `bases` + seq_off[n_seqs+1] (for mode 1
  *      already quality-masked, src/seq.rs:36-56).  The set lives in HBM: windows -> 2-bit codes -> radix sort ->
  *      run-length.  clean == clean_map (src/kmer.rs:826-837: keep multiplicity > t); count_histogram gives the
- *      (multiplicity, number of k-mers) pairs auto_cutoff needs (src/kmer.rs:866-942). ---- */
+ *      (multiplicity, number of k-mers) pairs auto_cutoff needs (src/kmer.rs:866-942).
+ *      k_size 33..128: a k-mer no longer packs into 64 bits, the keys are byte strings (case kept in mode 1, so lower-case bases
+ *      are fine there): the sequences stay resident until finalize, every window's key is sorted on a 4-bit-per-base image
+ *      (one stable radix pass per 16 bases) and run-length counted; the finished set is n x k_size ASCII bytes.  Such a set
+ *      serves every call below except cid_kmerset_device_arrays / _order_for_index and the cid_group_*_set calls. ---- */
 typedef struct cid_kmerset cid_kmerset;
 int cid_kmerset_create(cid_ctx *, uint32_t k_size, cid_kmerset **out);
 int cid_kmerset_add_seqs(cid_kmerset *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode);

@@ -240,7 +240,8 @@ def test_read_id_fasta(orc, env):
 
 
 def test_k_above_32_uses_host_map(orc, env, tmp_path):
-    """k > 32 cannot be packed in 64 bits: build / search / read_id fall back to byte-string k-mers (host map, LDS byte path)."""
+    """k > 32 cannot be packed in 64 bits: build / search / read_id use byte-string k-mers — counted on the GPU (sorted on a
+    4-bit-per-base image), or in the host map with COLORID_HOST_KMERS=1; read_id takes the LDS byte path."""
     d, _, _, genomes = env
     tsv = tmp_path / "refs.tsv"
     tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES[:3]))
@@ -256,7 +257,14 @@ def test_k_above_32_uses_host_map(orc, env, tmp_path):
     for s in orc.read_fasta(q):
         km.kmerize_vector(s, 1)
     assert sorted(out.splitlines()) == sorted(expected_report(orc, oix, q, km.clean_map(0), 0.01, True))
-    assert "k-mer map on the host" in err
+    assert "k-mer map on the host" not in err
+    out2, err2 = run("search", "-b", pre + ".bxi", "-q", q, "-g", "-p", "0.01", host_kmers=True)
+    assert sorted(out2.splitlines()) == sorted(out.splitlines()) and "k-mer map on the host" in err2
+    out3, _ = run("search", "-b", pre + ".bxi", "-q", q, "-p", "0.01")                     # default report: per-k-mer unique colours
+    out4, _ = run("search", "-b", pre + ".bxi", "-q", q, "-p", "0.01", host_kmers=True)
+    assert sorted(out3.splitlines()) == sorted(out4.splitlines()) == sorted(expected_report(orc, oix, q, km.clean_map(0), 0.01, False))
+    run("build", "-s", "300007", "-n", "3", "-k", "35", "-b", pre + "_host", "-r", str(tsv), host_kmers=True)
+    assert open(pre + "_host.bxi", "rb").read() == open(ref, "rb").read()
     rng = np.random.default_rng(4)
     r1 = synth_fastq_records(rng, genomes[:3], 300, 150, mate=0)
     f1 = str(tmp_path / "r.fastq.gz")

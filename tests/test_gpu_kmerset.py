@@ -77,7 +77,66 @@ def test_fastq_mode_and_lowercase_refusal(orc, hip_ctx):
     assert ei.value.code == -4
     ks.close()
     with pytest.raises(colorid_amd.CidError):
-        colorid_amd.KmerSet(hip_ctx, 33)
+        colorid_amd.KmerSet(hip_ctx, 129)
+
+
+@pytest.mark.parametrize("k", [33, 40, 48, 49, 64, 100, 128])
+def test_byte_string_sets_k_above_32(orc, hip_ctx, k):
+    """k > 32 (src/kmer.rs:87-125 and :461-510 at k >= 33): keys are byte strings — sorted on a 4-bit-per-base image, run-length
+    counted, kept as n x k ASCII.  FASTA mode upper-cases after the raw-byte orientation choice, fastq mode keeps the case."""
+    import colorid_amd
+    rng = np.random.default_rng(k)
+    seqs = [rand_seq(rng, 4000), rand_seq(rng, k - 1), rand_seq(rng, k), rand_seq(rng, 2047 + k), rand_seq(rng, 2048 + k), rand_seq(rng, 5000, b"ACGTN"),
+            rand_seq(rng, 3000, b"ACGTacgt"), rand_seq(rng, 1500, b"acgtn"), b"A" * 400, (b"ACGT" * 150), b"", rand_seq(rng, 900, b"ACGTRYKM-")]
+    seqs.append(seqs[0][100:1500])
+    seqs.append(seqs[6][50:900])
+    want = orc.Kmers(k)
+    for s in seqs:
+        want.kmerize_vector(s, 1)
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    ks.add_seqs(seqs[:5], 0)
+    ks.add_seqs(seqs[5:], 0)
+    assert ks.finalize() == len(want)
+    assert ks.as_dict() == want.as_dict()
+    vals, cnts = ks.histogram()
+    wc = want.counts()
+    assert dict(zip(vals.tolist(), cnts.tolist())) == {int(v): int((wc == v).sum()) for v in np.unique(wc)}
+    # searches over the device-resident byte-string set == the oracle over the same k-mers
+    oix = random_index(orc, rng, 20_011, 3, k, 100, density=0.2, zero_row_frac=0.0)
+    keys = want.keys()
+    plant(oix, rng, keys[:2000], frac=0.8)
+    hx = to_hip_index(hip_ctx, oix)
+    km, cnt = ks.download()
+    w = oix.search_count(km, cnt.astype(np.uint64))
+    g = ks.search_count(hx)
+    assert all(np.array_equal(a, b) for a, b in zip(w, g))
+    pw, pm = oix.search_perfect(km)
+    gw, gm = ks.search_perfect(hx)
+    assert pm == gm and np.array_equal(pw, gw)
+    hx.close()
+    ks.clean(1)
+    assert ks.as_dict() == want.clean_map(1).as_dict()
+    ks.close()
+    # fastq mode keeps the case: lower-case k-mers are their own keys
+    fq = [rand_seq(rng, 150, b"ACGTN" if i % 5 == 0 else (b"ACGTacgt" if i % 11 == 0 else b"ACGT")) for i in range(1500)] + [b"ACG", b""]
+    fq += fq[:300]
+    wantq = fastq_counts(orc, fq, k)
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    ks.add_seqs(fq[:700], 1)
+    ks.add_seqs(fq[700:], 1)
+    ks.finalize()
+    assert ks.as_dict() == wantq.as_dict()
+    # Bloom insert of the set == the oracle's inserts
+    o2 = orc.Index(30_011, 3, k, 4)
+    for key in wantq.keys():
+        o2.insert(2, key.tobytes())
+    h2 = colorid_amd.Index(hip_ctx, 30_011, 3, k, 4)
+    from colorid_amd._lib import check
+    check(hip_ctx.lib.cid_index_insert_kmerset(h2.h, ks.h, 2))
+    h2.finalize()
+    assert np.array_equal(h2.get_rows(np.arange(30_011, dtype=np.uint64)), o2.rows())
+    h2.close()
+    ks.close()
 
 
 def test_incremental_merge_path(orc, hip_ctx, monkeypatch):
