@@ -41,6 +41,8 @@ using namespace cid::slots;
 
 // A/B switch while the persistent XCD-aware scheduling of k_search_count is being measured (cid_tune "search_persist")
 bool kSearchPersist = getenv("CID_SEARCH_PERSIST") && atoi(getenv("CID_SEARCH_PERSIST")) != 0;
+// 32-byte rows: the last row of every k-mer through the scalar cache (cid_tune "search_mixed")
+bool kSearchMixed = getenv("CID_SEARCH_MIXED") ? atoi(getenv("CID_SEARCH_MIXED")) != 0 : false;
 // bytes per chunk of the pipelined host-pointer calls (H2D of chunk i+1 beside the kernel of chunk i)
 const size_t kUploadChunkBytes = getenv("CID_UPLOAD_CHUNK_BYTES") ? strtoull(getenv("CID_UPLOAD_CHUNK_BYTES"), nullptr, 10) : (256ull << 20);
 
@@ -456,6 +458,7 @@ int cid::search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_k
     p.hits = d_hits; p.n_unique = d_n_unique; p.sum_unique_freq = d_sum_unique_freq; p.unique_colour = d_unique_colour;
     p.want_unique = (d_n_unique || d_sum_unique_freq || d_unique_colour) ? 1u : 0u;
     p.tiles_per_block = pick_tiles_per_block(c, n_kmers);
+    p.mixed = kSearchMixed ? 1u : 0u;
     if (kSearchPersist && ix->rs <= 128 && n_kmers >= (1u << 16)) {   // persistent grid, one work queue per XCD (cid_search.hip)
         void *d_q;
         rc = slot_reserve(c, S_QUEUE, 8 * 128, &d_q); if (rc) return rc;
@@ -1119,6 +1122,7 @@ int cid_readid_sparse_fetch(cid_ctx *c, uint64_t *row_start, uint32_t *colours, 
 int cid_tune(const char *name, long value) {
     if (!name) return fail(CID_ERR_INVALID, "null name");
     if (!strcmp(name, "search_persist")) { kSearchPersist = value != 0; return CID_OK; }
+    if (!strcmp(name, "search_mixed")) { kSearchMixed = value != 0; return CID_OK; }
     if (!strcmp(name, "order_bits")) { if (value < 0 || value > 32) return fail(CID_ERR_INVALID, "order_bits 0..32"); cid::g_order_bits = (int)value; return CID_OK; }
     return fail(CID_ERR_INVALID, "unknown tunable '%s'", name);
 }

@@ -39,6 +39,7 @@ struct SearchParams {
     // persistent, XCD-aware scheduling of k_search_count (nullptr = one contiguous tile range per block)
     uint32_t *queues;      // 8 work-queue heads, 32 words apart, zeroed before the launch
     int persist_grid;      // resident blocks: n_cu x blocks per CU
+    uint32_t mixed;        // 32-byte rows: fetch each k-mer's last row through the scalar cache (gather_and_mixed32)
 };
 
 struct InsertParams {

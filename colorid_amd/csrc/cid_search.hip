@@ -93,7 +93,21 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
             const bool live = kmer < p.n_kmers;
             V16 a{0, 0};
             uint32_t zm;
-            if (live && col_live) a = gather_and<NARROW, false>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
+            bool mixed = false;
+            if constexpr (LOG_LPR == 1 && !NARROW) {   // 32-byte rows: the last row of every k-mer through the scalar cache
+                if (p.mixed && p.n_hash >= 2 && p.n_hash <= 4) {
+                    mixed = true;
+                    const uint32_t rlast = ridx[(p.n_hash - 1) * kWave + lane];
+                    V16 m;
+                    switch (p.n_hash) {
+                    case 2: m = gather_and_mixed32<2>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
+                    case 3: m = gather_and_mixed32<3>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
+                    default: m = gather_and_mixed32<4>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
+                    }
+                    if (live) a = m;
+                }
+            }
+            if (!mixed && live && col_live) a = gather_and<NARROW, false>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
             if constexpr (NARROW) a.y = 0;
             const uint32_t pc = (uint32_t)(__popcll(a.x) + __popcll(a.y));
             const uint32_t total = group_sum<LOG_LPR>(pc);

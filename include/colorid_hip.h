@@ -270,6 +270,7 @@ int cid_group_readid_sparse_fetch(cid_group *, uint64_t *row_start, uint32_t *co
 /* ---- measurement helpers (bench only): HIP-event timing on the ctx stream ---- */
 /* process-wide tunables for A/B measurements (tools/, bench.py); unknown names give CID_ERR_INVALID:
  *   "search_persist"  0/1  k_search_count as a persistent grid with one work queue per XCD
+ *   "search_mixed"    0/1  k_search_count on 32-byte rows: each k-mer's last row through the scalar cache (64-byte lines)
  *   "order_bits"      0..32  cid_kmerset_order_for_index groups by this many leading bits of the first row's position
  *                     (0 = by its exact 128-byte line) */
 int cid_tune(const char *name, long value);

@@ -338,3 +338,26 @@ def test_more_error_behaviour(orc, hip_ctx):
     kmers = random_kmers(rng, 100, 21)
     assert np.array_equal(hx.search_count(kmers)[0], oix.search_count(kmers, None)[0])
     hx.close()
+
+
+@pytest.mark.parametrize("tunable", [b"search_persist", b"search_mixed"])
+@pytest.mark.parametrize("n_colors,n_hash", [(256, 4), (200, 3), (129, 2), (64, 4), (1024, 4)])
+def test_alternative_schedulings_are_bit_exact(orc, hip_ctx, tunable, n_colors, n_hash):
+    """The two measured-and-not-adopted variants of k_search_count stay bit-exact behind cid_tune: the persistent grid with one
+    work queue per XCD, and (32-byte rows) the last row of each k-mer fetched through the scalar cache."""
+    from colorid_amd._lib import check
+    rng = np.random.default_rng(n_colors * 7 + n_hash)
+    oix = random_index(orc, rng, 60_013, n_hash, 31, n_colors, density=0.2, zero_row_frac=0.05)
+    kmers = random_kmers(rng, 70_001, 31)            # > 2^16: the persistent path engages
+    plant(oix, rng, kmers[:5000], frac=0.9)
+    freq = rng.integers(1, 20, size=len(kmers)).astype(np.uint32)
+    want = oix.search_count(kmers, freq.astype(np.uint64))
+    hx = to_hip_index(hip_ctx, oix)
+    check(hip_ctx.lib.cid_tune(tunable, 1))
+    try:
+        got = hx.search_count(kmers, freq)
+    finally:
+        check(hip_ctx.lib.cid_tune(tunable, 0))
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    hx.close()

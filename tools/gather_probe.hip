@@ -98,6 +98,67 @@ __global__ __launch_bounds__(256) void probe_s(const uint8_t *tab, const uint32_
     if (acc == 0x12345678u) out[t & 1023] = acc;
 }
 
+// MIXED gather inside one wave (the shape a mixed k_search_count would have): a wave owns 64 groups; NS of each group's 4 rows come
+// through the scalar cache (s_load_dwordx8 = 64-byte lines, 8 in flight per batch, handed to the owning lane pair with
+// v_writelane), the other 4 - NS through the vector path (lane pair per row, 16 B per lane, 2 sub-passes of 32 groups).
+// v_writelane with an SGPR value needs its lane select in M0 (or an inline constant) on gfx9: one SGPR on the constant bus
+#define WL(acc, val, ln) asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(acc) : "s"(val), "s"(ln) : "m0")
+template <int NS, int BATCH = 8, int SUBS = 2>
+__global__ __launch_bounds__(256) void probe_mix(const uint8_t *tab, const uint32_t *idx, uint64_t n_groups, uint32_t *out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t g0 = wave * 64;
+    if (g0 >= n_groups) return;
+    const uint64_t gl = g0 + lane < n_groups ? g0 + lane : n_groups - 1;
+    const uint4 my = *reinterpret_cast<const uint4 *>(idx + gl * 4);      // lane l holds the 4 row numbers of group g0 + l
+    typedef const __attribute__((address_space(4))) u32x8 *cptr;
+    uint32_t r = 0;
+#pragma unroll 1
+    for (int sub = 0; sub < 2; ++sub) {
+        const int kk = sub * 32 + (lane >> 1);                             // the group this lane pair works on
+        const uint32_t half = lane & 1;
+        const bool use_scalar = sub < SUBS;       // wave-uniform
+        uint4 v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s >= 4 - NS && use_scalar) { v[s] = uint4{~0u, ~0u, ~0u, ~0u}; continue; }
+            const uint32_t src = s == 0 ? my.x : s == 1 ? my.y : s == 2 ? my.z : my.w;
+            const uint32_t row = (uint32_t)__shfl((int)src, kk, 64);
+            v[s] = *reinterpret_cast<const uint4 *>(tab + (uint64_t)row * 32 + half * 16);
+        }
+        uint32_t sc0 = ~0u, sc1 = ~0u, sc2 = ~0u, sc3 = ~0u;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!use_scalar) break;
+            const uint32_t srcv = s == 0 ? my.w : my.z;
+            uint32_t t0 = ~0u, t1 = ~0u, t2 = ~0u, t3 = ~0u;      // this lane's 16 bytes of its group's row
+#pragma unroll 1
+            for (int b = 0; b < 32; b += BATCH) {
+                u32x8 q[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const uint32_t row = __builtin_amdgcn_readlane(srcv, sub * 32 + b + u);
+                    q[u] = *(cptr)(tab + (uint64_t)row * 32);
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int l0 = 2 * (b + u);
+                    WL(t0, q[u][0], l0); WL(t0, q[u][4], l0 + 1);
+                    WL(t1, q[u][1], l0); WL(t1, q[u][5], l0 + 1);
+                    WL(t2, q[u][2], l0); WL(t2, q[u][6], l0 + 1);
+                    WL(t3, q[u][3], l0); WL(t3, q[u][7], l0 + 1);
+                }
+            }
+            sc0 &= t0; sc1 &= t1; sc2 &= t2; sc3 &= t3;
+        }
+        uint4 a{sc0, sc1, sc2, sc3};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { a.x &= v[s].x; a.y &= v[s].y; a.z &= v[s].z; a.w &= v[s].w; }
+        r ^= a.x ^ a.y ^ a.z ^ a.w;
+    }
+    if (r == 0x12345678u) out[threadIdx.x & 1023] = r;
+}
+
 // scalar PREFETCH: one s_load_dword per row pulls (only) the row's 64-byte half line into L2; mode 0 = prefetch only,
 // mode 1 = prefetch this wave's 256 rows, then gather them with the vector path (do they now hit in L2?)
 template <int MODE>
@@ -170,6 +231,12 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(e0));
         if (variant == 11) hipLaunchKernelGGL(probe_pf<0>, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
         else if (variant == 12) hipLaunchKernelGGL(probe_pf<1>, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 13) hipLaunchKernelGGL((probe_mix<1, 8, 2>), dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 14) hipLaunchKernelGGL((probe_mix<2, 8, 2>), dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 15) hipLaunchKernelGGL((probe_mix<1, 4, 2>), dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 16) hipLaunchKernelGGL((probe_mix<1, 8, 1>), dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 17) hipLaunchKernelGGL((probe_mix<1, 16, 2>), dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
+        else if (variant == 18) hipLaunchKernelGGL((probe_mix<2, 8, 1>), dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
         else if (variant == 8) hipLaunchKernelGGL(probe_s, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
         else if (variant == 9) hipLaunchKernelGGL(probe1, dim3((n_groups + 255) / 256), dim3(256), 0, 0, tab, idx, n_groups, out);
         else {
