@@ -2,6 +2,7 @@
 // device-resident index, scratch buffers, launches.  There is no CPU compute path in this library.
 #include "../../include/colorid_hip.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -800,12 +801,14 @@ static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t sta
     while (p.table_slots < p.win_cap + p.win_cap / 2) p.table_slots <<= 1;
     const size_t chunk_rows = 4ull * cid::kWave * ix->n_hash;                     // one chunk's row numbers
     const size_t rall_bytes = wide ? 0 : 4ull * p.win_cap * ix->n_hash;           // rows of the read's distinct k-mers (wide rows search chunk by chunk)
-    size_t wave_bytes = (size_t)p.bases_cap + 4ull * p.hist_pad + rall_bytes;
-    if (bytes_kernel)   // tags, window infos, k-mer image (+ minimizer image and the distinct minimizer strings)
-        wave_bytes += chunk_rows + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
+    size_t wave_bytes = (size_t)p.bases_cap + rall_bytes;
+    if (bytes_kernel)   // histogram, tags, window infos, k-mer image (+ minimizer image and the distinct minimizer strings)
+        wave_bytes += 4ull * p.hist_pad + chunk_rows + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
                       (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);
-    else                // hash table keys + indices, 2-bit bases, bad-base bits
-        wave_bytes += (wide ? chunk_rows : 0) + 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
+    else if (wide)      // chunk rows, histogram, hash table keys + indices, 2-bit bases, bad-base bits
+        wave_bytes += chunk_rows + 4ull * p.hist_pad + 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
+    else                // the histogram shares the hash table's region (k_readid)
+        wave_bytes += std::max<size_t>(12ull * p.table_slots, 4ull * p.hist_pad) + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
     wave_bytes = (wave_bytes + 15) & ~15ull;
     p.wave_bytes = (uint32_t)(wave_bytes < 0xFFFFFFF0ull ? wave_bytes : 0xFFFFFFF0ull);
     return wave_bytes;
@@ -830,8 +833,15 @@ constexpr size_t kLdsReadBytesMax = kLdsBytes / 2;
 static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
                          bool bytes_kernel, cid::ReadIdParams &p, int &waves) {
     const size_t wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, p);
-    waves = 4;
-    while (waves > 1 && (size_t)waves * wave_bytes > kLdsBytes) waves >>= 1;
+    // waves per workgroup: whatever puts the most waves on a CU (160 KiB of LDS, at most 8 workgroups of this size... 32 waves)
+    waves = 1;
+    size_t best = 0;
+    for (int w = 4; w >= 1; --w) {
+        if ((size_t)w * wave_bytes > kLdsBytes) continue;
+        size_t blocks = kLdsBytes / ((size_t)w * wave_bytes);
+        if (blocks > 32u / (size_t)w) blocks = 32u / (size_t)w;
+        if (blocks * (size_t)w > best) { best = blocks * (size_t)w; waves = w; }
+    }
     if (wave_bytes > kLdsBytes)
         return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %zu B of LDS per wave (> 160 KiB): "
                     "use the host-pointer calls, which route such reads through the sort-based path", (unsigned long long)max_bytes,

@@ -169,9 +169,11 @@ __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, u
     }
 }
 
-// ---- k_readid: reads without lower-case bases, k <= 32.  Per-wave LDS: bases | ridx (WIDE only: 64*n) | hist | rall (not
-// WIDE: win_cap*n) | table keys + indices | 2-bit bases | bad-base bits.  A read with a lower-case base (its case must be
-// kept) is appended to p.redo_list for k_readid_bytes.
+// ---- k_readid: reads without lower-case bases, k <= 32.  Per-wave LDS, not WIDE: bases | rall (win_cap*n) | table keys +
+// indices | 2-bit bases | bad-base bits — the per-colour histogram of the search phase lives IN the table's region (the table is
+// dead once the read's set is complete; the region is max(table, histogram) bytes), which is what lets paired 150-bp reads run
+// 5 waves per SIMD instead of 4.  WIDE: bases | ridx (64*n) | hist | table | ... (the search interleaves with the set building).
+// A read with a lower-case base (its case must be kept) is appended to p.redo_list for k_readid_bytes.
 template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE>
 __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p) {
     constexpr int PLANES = DENSE ? kReadPlanesDense : kReadPlanes;
@@ -187,15 +189,17 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
     uint8_t *wb = smem + (size_t)wave * p.wave_bytes;
     uint8_t *s_bases = wb;                                                     // bases_cap
     uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.bases_cap);           // WIDE: 64*n, this chunk's rows
-    uint32_t *hist = ridx + (WIDE ? kWave * n : 0u);                           // hist_pad
-    uint32_t *rall = hist + p.hist_pad;                                        // not WIDE: win_cap*n, rows of the read's distinct k-mers in order
     const uint32_t rcap = p.win_cap;
+    uint32_t *rall = ridx + (WIDE ? kWave * n + p.hist_pad : 0u);              // not WIDE: win_cap*n, rows of the read's distinct k-mers in order
     unsigned long long *t_key = reinterpret_cast<unsigned long long *>(rall + (WIDE ? 0u : rcap * n));   // table_slots
     uint32_t *t_idx = reinterpret_cast<uint32_t *>(t_key + p.table_slots);     // table_slots
-    uint32_t *s_pack = t_idx + p.table_slots;                                  // bases_cap/16 + 4 dwords, 16 bases each
+    uint32_t *hist = WIDE ? ridx + kWave * n : reinterpret_cast<uint32_t *>(t_key);   // hist_pad; not WIDE: shares the table's region
+    const uint32_t region = WIDE ? 12u * p.table_slots : (12u * p.table_slots > 4u * p.hist_pad ? 12u * p.table_slots : 4u * p.hist_pad);
+    uint32_t *s_pack = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(t_key) + region);   // bases_cap/16 + 4 dwords, 16 bases each
     uint32_t *s_bad = s_pack + (p.bases_cap / 16 + 4);                         // bases_cap/32 + 4 dwords, 1 bit per base
 
-    for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
+    if constexpr (WIDE)
+        for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
 
     const uint32_t col_word = NARROW ? 0u : 2u * (lane & (LPR - 1));
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -316,7 +320,9 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             wbase += nw;
         }
         if constexpr (!WIDE) {
-            // the set is complete: search its nd k-mers in order, several sub-passes of row loads in flight at a time
+            // the set is complete: the table's region becomes the histogram; search the nd k-mers in order
+            wave_lds_fence();
+            for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
             wave_lds_fence();
             readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
         }
@@ -617,7 +623,7 @@ static hipError_t launch_readid_packed(const ReadIdParams &p, int wpb, int grid,
 // workgroups' LDS fit the CU's 160 KiB.
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
     const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
-    const bool dense = 6ull * (size_t)waves_per_block * p.wave_bytes <= 160u * 1024u;
+    const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block >= 24;   // 6 waves per SIMD fit
     if (p.m_size)
         return dense ? launch_readid_packed<true, true>(p, waves_per_block, grid, stream)
                      : launch_readid_packed<true, false>(p, waves_per_block, grid, stream);
