@@ -273,7 +273,8 @@ int cid_index_create(cid_ctx *c, uint64_t bloom_size, uint32_t num_hash, uint32_
     ix->w64 = (n_colors + 63) / 64;
     ix->rs = cid::row_stride_words(n_colors);
     const cid::ModMagicHost mh = cid::make_mod_magic(bloom_size);
-    ix->mod = cid::ModMagic{mh.m, mh.magic, mh.shift, mh.flags | ((uint32_t)hash_variant << 8)};
+    ix->mod = cid::ModMagic{mh.m, mh.magic, mh.shift, mh.flags | ((uint32_t)hash_variant << 8),
+                            hash_variant == CID_HASH_XXH3_V07 ? 0x165667B19E3779F9ULL : 0x165667919E3779F9ULL};
     hipError_t e = hipSetDevice(c->device);
     const size_t bytes = (size_t)bloom_size * ix->rs * 8;
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ix->mat), bytes);
@@ -299,6 +300,7 @@ int cid_index_set_hash_variant(cid_index *ix, int hash_variant) {
     HIP_TRY(hipSetDevice(ix->ctx->device));
     HIP_TRY(hipStreamSynchronize(ix->ctx->stream));
     ix->mod.flags = (ix->mod.flags & 0xFFu) | ((uint32_t)hash_variant << 8);
+    ix->mod.xmul = hash_variant == CID_HASH_XXH3_V07 ? 0x165667B19E3779F9ULL : 0x165667919E3779F9ULL;
     return CID_OK;
 }
 
@@ -808,7 +810,8 @@ static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t sta
     else if (wide)      // chunk rows, histogram, hash table keys + indices, 2-bit bases, bad-base bits
         wave_bytes += chunk_rows + 4ull * p.hist_pad + 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
     else                // the histogram shares the hash table's region (k_readid)
-        wave_bytes += std::max<size_t>(12ull * p.table_slots, 4ull * p.hist_pad) + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
+        wave_bytes += (CID_READID_ALIAS ? std::max<size_t>(12ull * p.table_slots, 4ull * p.hist_pad) : 12ull * p.table_slots + 4ull * p.hist_pad) +
+                      4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
     wave_bytes = (wave_bytes + 15) & ~15ull;
     p.wave_bytes = (uint32_t)(wave_bytes < 0xFFFFFFF0ull ? wave_bytes : 0xFFFFFFF0ull);
     return wave_bytes;
@@ -879,6 +882,15 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
     };
     if (ix->rs > 128 && clear_wide)   // wide rows count in place
         HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * ((size_t)ix->n_colors + 1) * 4, c->stream));
+    if (!d_skip) {   // device-pointer callers state the maxima: reads beyond them are marked and left alone (k_readid_check_caps)
+        void *d_sk;
+        rc = slot_reserve(c, S_ROUTE, n_reads, &d_sk); if (rc) return rc;
+        cid::ReadIdParams pc = pb;   // bases_cap / win_cap are the same for both kernels' layouts
+        fill(pc, waves_b);
+        pc.report_width = (sa.zero_acc || sa.zero_in) ? 0u : ix->n_colors + 1;   // striped passes only add to rows the caller zeroed
+        HIP_TRY(cid::launch_readid_check_caps(pc, (uint8_t *)d_sk, c->stream));
+        d_skip = (const uint8_t *)d_sk;
+    }
     if (packable) {
         // k_readid takes every read it can pack; the ones with lower-case bases come back in the redo list for k_readid_bytes
         void *d_redo;

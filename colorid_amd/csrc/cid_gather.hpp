@@ -213,7 +213,7 @@ __device__ __forceinline__ void stage_and_hash(uint32_t *img, uint32_t *ridx, co
     if (codes) {  // packed input: 8 bytes per k-mer, ASCII re-expanded in registers (no LDS image)
         if (first + lane < n_kmers) {
             const uint64_t lsb = rev_fields(codes[first + lane], k);
-            xxh3_seeds_from(CodeReader{lsb}, k, n, hash_variant_of(mm), [&](uint32_t s, uint64_t h) { ridx[s * kWave + lane] = (uint32_t)mod_m(h, mm); });
+            xxh3_seeds_from(CodeReader{lsb}, k, n, HashSel::of(mm), [&](uint32_t s, uint64_t h) { ridx[s * kWave + lane] = (uint32_t)mod_m(h, mm); });
         } else {
             for (uint32_t s = 0; s < n; ++s) ridx[s * kWave + lane] = 0;
         }
@@ -223,7 +223,7 @@ __device__ __forceinline__ void stage_and_hash(uint32_t *img, uint32_t *ridx, co
     stage_kmers(img, kmers, n_kmers, first, k, lane);
     wave_lds_fence();
     if (first + lane < n_kmers) {
-        xxh3_seeds(img, (uint32_t)lane * k, k, n, hash_variant_of(mm), [&](uint32_t s, uint64_t h) {
+        xxh3_seeds(img, (uint32_t)lane * k, k, n, HashSel::of(mm), [&](uint32_t s, uint64_t h) {
             ridx[s * kWave + lane] = (uint32_t)mod_m(h, mm);
         });
     } else {

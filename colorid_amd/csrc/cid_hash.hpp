@@ -39,6 +39,7 @@ struct ModMagic {
     uint64_t magic;  // multiplier
     uint32_t shift;
     uint32_t flags;  // 1 = power of two (mask), 2 = "add" fix-up step; bits 8..15 = the index's hash variant (kHash*)
+    uint64_t xmul;   // the variant's XXH3 avalanche multiplier (a kernel argument like the rest: no select in the hash loops)
 };
 // Hash variants (include/colorid_hip.h CID_HASH_*): which XXH3 the index was built with.
 constexpr uint32_t kHashV08 = 0;   // published XXH3_64bits_withSeed (xxHash >= 0.8.0), pinned to known answers
@@ -79,10 +80,11 @@ constexpr uint64_t PMX2 = 0x9FB21C651E98DF25ULL;
 
 CID_FN uint64_t mul128_fold64(uint64_t a, uint64_t b) { return (a * b) ^ umul64hi(a, b); }
 // v0.8: h ^= h >> 37; h *= 0x165667919E3779F9; h ^= h >> 32.  The v0.7.1/v0.7.2 draft multiplies by PRIME64_3 instead.
-CID_FN uint64_t xxh3_avalanche(uint64_t h, uint32_t hv = kHashV08) {
-    h ^= h >> 37; h *= (hv == kHashV07 ? P64_3 : PMX1); h ^= h >> 32;
+CID_FN uint64_t xxh3_avalanche(uint64_t h, uint64_t mult = PMX1) {
+    h ^= h >> 37; h *= mult; h ^= h >> 32;
     return h;
 }
+CID_FN uint64_t avalanche_mult_of(uint32_t hv) { return hv == kHashV07 ? P64_3 : PMX1; }
 CID_FN uint64_t xxh64_avalanche(uint64_t h) {
     h ^= h >> 33; h *= P64_2; h ^= h >> 29; h *= P64_3; h ^= h >> 32;
     return h;
@@ -149,26 +151,36 @@ CID_FN void xxh3_v07_short(const Reader &in, uint32_t len, uint32_t n, Emit &&em
         const uint64_t i_lo = in.rd64(0), i_hi = in.rd64(len - 8);
         for (uint32_t s = 0; s < n; ++s) {
             const uint64_t lo = i_lo ^ (kSecretW[0] + s), hi = i_hi ^ (kSecretW[1] - s);
-            emit(s, xxh3_avalanche((uint64_t)len + lo + hi + mul128_fold64(lo, hi), kHashV07));
+            emit(s, xxh3_avalanche((uint64_t)len + lo + hi + mul128_fold64(lo, hi), P64_3));
         }
     } else if (len >= 4) {
         const uint64_t in64 = (uint64_t)in.rd32(0) + ((uint64_t)in.rd32(len - 4) << 32);
         for (uint32_t s = 0; s < n; ++s) {
             const uint64_t keyed = in64 ^ (kSecretW[0] + s);
             const uint64_t mix = (uint64_t)len + (keyed ^ (keyed >> 51)) * P32_1;
-            emit(s, xxh3_avalanche((mix ^ (mix >> 47)) * P64_2, kHashV07));
+            emit(s, xxh3_avalanche((mix ^ (mix >> 47)) * P64_2, P64_3));
         }
     } else {
         const uint32_t c1 = in.rd8(0), c2 = in.rd8(len >> 1), c3 = in.rd8(len - 1);
         const uint64_t combined = (uint64_t)(c1 | (c2 << 8) | (c3 << 16) | (len << 24));
-        for (uint32_t s = 0; s < n; ++s) emit(s, xxh3_avalanche((combined ^ ((uint64_t)(uint32_t)kSecretW[0] + s)) * P64_1, kHashV07));
+        for (uint32_t s = 0; s < n; ++s) emit(s, xxh3_avalanche((combined ^ ((uint64_t)(uint32_t)kSecretW[0] + s)) * P64_1, P64_3));
     }
 }
 
-// All n seeds (0..n-1) of one k-mer; emit(seed, hash).  len and hv (the hash variant) are wave-uniform.
+// which XXH3: the variant id (only consulted for inputs of <= 16 bytes) and its avalanche multiplier.  A kernel that is compiled
+// for the published variant only passes the constants (HashSel::published()) and keeps two SGPRs.
+struct HashSel {
+    uint32_t hv;
+    uint64_t xmul;
+    CID_FN static HashSel of(const ModMagic &mm) { return HashSel{hash_variant_of(mm), mm.xmul}; }
+    CID_FN static HashSel published() { return HashSel{kHashV08, PMX1}; }
+};
+
+// All n seeds (0..n-1) of one k-mer; emit(seed, hash).  len and the hash variant are wave-uniform.
 template <typename Reader, typename Emit>
-CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, uint32_t hv, Emit &&emit) {
-    if (hv == kHashV07 && len <= 16) { xxh3_v07_short(in, len, n, emit); return; }
+CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, const HashSel hs, Emit &&emit) {
+    if (len <= 16 && hs.hv == kHashV07) { xxh3_v07_short(in, len, n, emit); return; }
+    const uint64_t xmul = hs.xmul;
     if (len > 16 && len <= 32) {  // the k = 21/27/31 case: 2 x mix16B, inputs read once for all seeds
         const uint64_t a0 = in.rd64(0), a1 = in.rd64(8);
         const uint64_t b0 = in.rd64(len - 16), b1 = in.rd64(len - 8);
@@ -176,7 +188,7 @@ CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, uint32_t
             uint64_t acc = (uint64_t)len * P64_1;
             acc += mul128_fold64(a0 ^ (kSecretW[0] + s), a1 ^ (kSecretW[1] - s));
             acc += mul128_fold64(b0 ^ (kSecretW[2] + s), b1 ^ (kSecretW[3] - s));
-            emit(s, xxh3_avalanche(acc, hv));
+            emit(s, xxh3_avalanche(acc, xmul));
         }
     } else if (len > 32) {  // 33..128: (len-1)/32 + 1 front/back pairs
         const uint32_t nb = ((len - 1) >> 5) + 1;
@@ -187,7 +199,7 @@ CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, uint32_t
                 acc += mul128_fold64(in.rd64(f) ^ (kSecretW[4 * i] + s), in.rd64(f + 8) ^ (kSecretW[4 * i + 1] - s));
                 acc += mul128_fold64(in.rd64(b) ^ (kSecretW[4 * i + 2] + s), in.rd64(b + 8) ^ (kSecretW[4 * i + 3] - s));
             }
-            emit(s, xxh3_avalanche(acc, hv));
+            emit(s, xxh3_avalanche(acc, xmul));
         }
     } else if (len > 8) {  // 9..16
         const uint64_t i_lo = in.rd64(0), i_hi = in.rd64(len - 8);
@@ -217,8 +229,8 @@ CID_FN void xxh3_seeds_from(const Reader &in, uint32_t len, uint32_t n, uint32_t
 }
 
 template <typename Emit>
-CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t n, uint32_t hv, Emit &&emit) {
-    xxh3_seeds_from(LdsReader{img, off}, len, n, hv, emit);
+CID_FN void xxh3_seeds(const uint32_t *img, uint32_t off, uint32_t len, uint32_t n, const HashSel hs, Emit &&emit) {
+    xxh3_seeds_from(LdsReader{img, off}, len, n, hs, emit);
 }
 
 // ---------------------------------------------------------------- 2-bit k-mer codes (upper-case ACGT, k <= 32)

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
                 uint32_t klen = p.k;
                 if (p.m_size) { code = minimizer_code(code, p.k, p.m_size); klen = p.m_size; }
                 const uint64_t lsb = rev_fields(code, klen);
-                if (c < p.n_colors) xxh3_seeds_from(CodeReader{lsb}, klen, p.n_hash, hash_variant_of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
+                if (c < p.n_colors) xxh3_seeds_from(CodeReader{lsb}, klen, p.n_hash, HashSel::of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
             }
             continue;
         }
@@ -86,13 +86,13 @@ __global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
             wave_lds_fence();
             if (have) {
                 const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-                if (c < p.n_colors) xxh3_seeds(mimg, (uint32_t)lane * p.m_size, p.m_size, p.n_hash, hash_variant_of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
+                if (c < p.n_colors) xxh3_seeds(mimg, (uint32_t)lane * p.m_size, p.m_size, p.n_hash, HashSel::of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
             }
             continue;
         }
         if (first + lane < p.n_kmers) {
             const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-            if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, hash_variant_of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
+            if (c < p.n_colors) xxh3_seeds(img, (uint32_t)lane * p.k, p.k, p.n_hash, HashSel::of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
         }
     }
 }

@@ -5,6 +5,9 @@
 namespace cid {
 
 constexpr int kBlock = 256;  // 4 waves; every wave works on its own 64-k-mer tiles
+#ifndef CID_READID_ALIAS
+#define CID_READID_ALIAS 1   // k_readid: the search-phase histogram shares the hash table's LDS region (0: separate regions, A/B builds)
+#endif
 constexpr int kPlanes = 8;   // bit-sliced per-colour counters per lane: drained every 255 k-mers
 
 struct SearchParams {
@@ -113,6 +116,7 @@ size_t search_smem_bytes(const SearchParams &p);
 hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream);
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream);
 hipError_t launch_readid_bytes(const ReadIdParams &p, int waves_per_block, int grid, hipStream_t stream);
+hipError_t launch_readid_check_caps(const ReadIdParams &p, uint8_t *skip, hipStream_t stream);
 hipError_t launch_unique_finalize(const uint32_t *fact, const uint32_t *freq, uint64_t n_kmers,
                                   uint32_t n_colors_total, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour,
                                   hipStream_t stream);

@@ -143,7 +143,7 @@ __global__ void k_row0_line(const uint64_t *codes, uint32_t k, ModMagic mm, uint
     if (i >= n) return;
     const uint64_t lsb = rev_fields(codes[i], k);
     uint32_t row0 = 0;
-    xxh3_seeds_from(CodeReader{lsb}, k, 1, hash_variant_of(mm), [&](uint32_t, uint64_t h) { row0 = (uint32_t)mod_m(h, mm); });
+    xxh3_seeds_from(CodeReader{lsb}, k, 1, HashSel::of(mm), [&](uint32_t, uint64_t h) { row0 = (uint32_t)mod_m(h, mm); });
     keys[i] = bucket_bits ? (uint32_t)(((uint64_t)row0 << bucket_bits) / mm.m) : row0 >> line_shift;
     if (idx) idx[i] = (uint32_t)i;
 }

@@ -72,7 +72,7 @@ constexpr int kReadPlanesDense = 2;
 // Colour stripes: zacc / zin point at this read's slice of ReadIdParams::zero_acc / zero_in (NULL = not that pass)
 struct StripeRead { uint32_t *zacc; const uint32_t *zin; };
 
-template <int LOG_LPR, bool NARROW, int U, int PLANES = kReadPlanes>
+template <int LOG_LPR, bool NARROW, int U, int PLANES = kReadPlanes, bool STRIPED = false>
 __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t rs, uint32_t n, uint32_t C, uint32_t S, const uint32_t *ridx,
                                                   uint32_t stride, uint32_t count, uint32_t q_base, uint32_t *hist, bool &stopped,
                                                   VCount<PLANES, NARROW> &vc, V16 &R, int lane, StripeRead sr = StripeRead{nullptr, nullptr}) {
@@ -105,11 +105,13 @@ __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t 
 #pragma unroll
             for (int o = 1; o < LPR; o <<= 1) all_zero &= __shfl_xor(all_zero, o, kWave);
             bool lv = live[u];
-            if (sr.zacc) {   // zero pass of a colour stripe: record, count nothing, never stop
-                if (lv && (lane & (LPR - 1)) == 0) sr.zacc[q_base + j[u]] &= (all_zero & seeds_mask);
-                continue;
+            if constexpr (STRIPED) {
+                if (sr.zacc) {   // zero pass of a colour stripe: record, count nothing, never stop
+                    if (lv && (lane & (LPR - 1)) == 0) sr.zacc[q_base + j[u]] &= (all_zero & seeds_mask);
+                    continue;
+                }
+                if (sr.zin) all_zero = lv ? sr.zin[q_base + j[u]] : 0u;   // absent = all-zero in every stripe
             }
-            if (sr.zin) all_zero = lv ? sr.zin[q_base + j[u]] : 0u;   // absent = all-zero in every stripe
             const bool miss = lv && (all_zero & seeds_mask);
             const uint64_t bm = __ballot(miss);
             // keep only the k-mers before the first absent row (lane order == k-mer order in a sub-pass)
@@ -139,30 +141,48 @@ __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t 
     }
 }
 
-// The per-wave LDS regions were sized by the caller's longest read (bases_cap = that + 16 rounded up, win_cap windows): a read
-// beyond them must not be staged (wave-uniform test).
-__device__ __forceinline__ bool read_exceeds_caps(const ReadIdParams &p, uint64_t s0, uint64_t s1, uint32_t tb) {
-    if ((uint64_t)tb + 16u > p.bases_cap) return true;
+// The per-wave LDS regions of k_readid / k_readid_bytes are sized by the caller's longest read (bases_cap = that + 16 rounded up,
+// win_cap windows).  The device-pointer entry points cannot trust those maxima, so this kernel runs first: one thread per read;
+// a read beyond either maximum is marked skip = 1 (the LDS kernels then leave it alone), status 3, n_kmers 0, and its report row
+// is zeroed (report_width == 0: no row to zero).  Keeping the test out of the LDS kernels keeps their register budget.
+__global__ __launch_bounds__(256) void k_readid_check_caps(ReadIdParams p, uint8_t *skip) {
+    const uint64_t read = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (read >= p.n_reads) return;
+    const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
+    const uint64_t tb = s1 > s0 ? p.seq_off[s1] - p.seq_off[s0] : 0;
     uint64_t win = 0;
     for (uint64_t s = s0; s < s1; ++s) {
         const uint64_t len = p.seq_off[s + 1] - p.seq_off[s];
         if (len >= p.k) win += (len - p.k) / p.stride_d + 1;
     }
-    return win > p.win_cap;
+    const bool over = tb + 16u > p.bases_cap || win > p.win_cap;
+    skip[read] = over ? 1 : 0;
+    if (over) {
+        p.status[read] = 3;
+        p.n_kmers[read] = 0;
+        if (p.report_width) for (uint32_t c = 0; c < p.report_width; ++c) p.report[read * (uint64_t)p.report_width + c] = 0;
+    }
+}
+hipError_t launch_readid_check_caps(const ReadIdParams &p, uint8_t *skip, hipStream_t stream) {
+    if (p.n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_readid_check_caps, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, stream, p, skip);
+    return hipGetLastError();
 }
 
 // Output of one read: drain the counters, copy the histogram to the report row, clear it for the next read.
-template <bool NARROW, bool WIDE, int PLANES = kReadPlanes>
+template <bool NARROW, bool WIDE, int PLANES = kReadPlanes, bool STRIPED = false>
 __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, uint32_t *hist, uint32_t col_word, uint32_t *row_out,
                                                    uint32_t C, int lane, const ReadIdParams &p) {
     if constexpr (!WIDE) {
         vc.drain(hist, col_word);
         wave_lds_fence();
-        if (p.zero_acc) {          // zero pass: nothing to report
-            for (uint32_t c = lane; c <= C; c += kWave) hist[c] = 0;
-        } else if (p.zero_in) {    // count pass of a stripe: its colours inside the wide row; the no-hits entry from one stripe only
-            for (uint32_t c = lane; c < C; c += kWave) { row_out[p.colour_base + c] = hist[c]; hist[c] = 0; }
-            if (lane == 0) { if (p.write_nohits) row_out[p.report_width - 1] = hist[C]; hist[C] = 0; }
+        if constexpr (STRIPED) {
+            if (p.zero_acc) {          // zero pass: nothing to report
+                for (uint32_t c = lane; c <= C; c += kWave) hist[c] = 0;
+            } else {                   // count pass of a stripe: its colours inside the wide row; the no-hits entry from one stripe only
+                for (uint32_t c = lane; c < C; c += kWave) { row_out[p.colour_base + c] = hist[c]; hist[c] = 0; }
+                if (lane == 0) { if (p.write_nohits) row_out[p.report_width - 1] = hist[C]; hist[C] = 0; }
+            }
         } else {
             for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
         }
@@ -174,7 +194,7 @@ __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, u
 // dead once the read's set is complete; the region is max(table, histogram) bytes), which is what lets paired 150-bp reads run
 // 5 waves per SIMD instead of 4.  WIDE: bases | ridx (64*n) | hist | table | ... (the search interleaves with the set building).
 // A read with a lower-case base (its case must be kept) is appended to p.redo_list for k_readid_bytes.
-template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE>
+template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE, bool STRIPED = false>
 __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p) {
     constexpr int PLANES = DENSE ? kReadPlanesDense : kReadPlanes;
     extern __shared__ __align__(16) uint8_t smem[];
@@ -190,15 +210,16 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
     uint8_t *s_bases = wb;                                                     // bases_cap
     uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.bases_cap);           // WIDE: 64*n, this chunk's rows
     const uint32_t rcap = p.win_cap;
-    uint32_t *rall = ridx + (WIDE ? kWave * n + p.hist_pad : 0u);              // not WIDE: win_cap*n, rows of the read's distinct k-mers in order
+    constexpr bool SEPARATE = WIDE || !CID_READID_ALIAS;                       // histogram in a region of its own
+    uint32_t *rall = ridx + (WIDE ? kWave * n : 0u) + (SEPARATE ? p.hist_pad : 0u);   // not WIDE: win_cap*n, rows of the read's distinct k-mers in order
     unsigned long long *t_key = reinterpret_cast<unsigned long long *>(rall + (WIDE ? 0u : rcap * n));   // table_slots
     uint32_t *t_idx = reinterpret_cast<uint32_t *>(t_key + p.table_slots);     // table_slots
-    uint32_t *hist = WIDE ? ridx + kWave * n : reinterpret_cast<uint32_t *>(t_key);   // hist_pad; not WIDE: shares the table's region
-    const uint32_t region = WIDE ? 12u * p.table_slots : (12u * p.table_slots > 4u * p.hist_pad ? 12u * p.table_slots : 4u * p.hist_pad);
+    uint32_t *hist = SEPARATE ? ridx + (WIDE ? kWave * n : 0u) : reinterpret_cast<uint32_t *>(t_key);   // hist_pad; else: shares the table's region
+    const uint32_t region = SEPARATE ? 12u * p.table_slots : (12u * p.table_slots > 4u * p.hist_pad ? 12u * p.table_slots : 4u * p.hist_pad);
     uint32_t *s_pack = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(t_key) + region);   // bases_cap/16 + 4 dwords, 16 bases each
     uint32_t *s_bad = s_pack + (p.bases_cap / 16 + 4);                         // bases_cap/32 + 4 dwords, 1 bit per base
 
-    if constexpr (WIDE)
+    if constexpr (SEPARATE)
         for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
 
     const uint32_t col_word = NARROW ? 0u : 2u * (lane & (LPR - 1));
@@ -213,9 +234,10 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
         const uint64_t g0 = p.seq_off[s0];
         const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
-        const bool striped = p.zero_acc || p.zero_in;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
+        constexpr bool striped = STRIPED;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
         uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
-        const StripeRead sr{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
+        StripeRead sr{nullptr, nullptr};
+        if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
         if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
             if constexpr (!WIDE)  // (wide rows: the host zeroes the whole report before the launch)
                 if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
@@ -223,12 +245,6 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             continue;
         }
         const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
-        if (read_exceeds_caps(p, s0, s1, tb)) {   // the caller understated max_read_bytes / max_read_windows: leave the read alone
-            if constexpr (!WIDE)
-                if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
-            if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 3; }
-            continue;
-        }
         bool lower = false;
         for (uint32_t i = lane; i < tb; i += kWave) {
             const uint8_t b = p.bases[g0 + i];
@@ -308,7 +324,9 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 if (distinct) {   // WIDE: this chunk's slot; else the read's list at the k-mer's order index
                     uint32_t *dst = WIDE ? ridx + lane : rall + nd + (uint32_t)__popcll(dmask & lt_mask);
                     const uint32_t st = WIDE ? (uint32_t)kWave : rcap;
-                    xxh3_seeds_from(CodeReader{canon}, klen, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) { dst[sd * st] = (uint32_t)mod_m(h, p.mod); });
+                    // (the 6-waves-per-SIMD build is compiled for the published hash only: launch_readid sends other variants to the 5-wave build)
+                    xxh3_seeds_from(CodeReader{canon}, klen, n, DENSE ? HashSel::published() : HashSel::of(p.mod),
+                                    [&](uint32_t sd, uint64_t h) { dst[sd * st] = (uint32_t)mod_m(h, p.mod); });
                 }
                 if constexpr (WIDE) {
                     wave_lds_fence();
@@ -322,11 +340,13 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         if constexpr (!WIDE) {
             // the set is complete: the table's region becomes the histogram; search the nd k-mers in order
             wave_lds_fence();
-            for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
-            wave_lds_fence();
-            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
+            if constexpr (!SEPARATE) {
+                for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
+                wave_lds_fence();
+            }
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES, STRIPED>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
         }
-        readid_finish_read<NARROW, WIDE, PLANES>(vc, hist, col_word, row_out, C, lane, p);
+        readid_finish_read<NARROW, WIDE, PLANES, STRIPED>(vc, hist, col_word, row_out, C, lane, p);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
 }
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
 // ---- k_readid_bytes: the same per-read work on byte strings — reads with lower-case bases (p.redo_list, filled by
 // k_readid) or every read when k > 32 (p.redo_list == NULL).  Per-wave LDS: bases | ridx (64*n) | hist | rall | tags |
 // window infos | k-mer image | minimizer image + distinct minimizer strings (.mxi).  A 32-bit tag match is confirmed on the bytes.
-template <int LOG_LPR, bool NARROW, bool WIDE>
+template <int LOG_LPR, bool NARROW, bool WIDE, bool STRIPED = false>
 __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
@@ -370,9 +390,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
         const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
         const uint64_t g0 = p.seq_off[s0];
         const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
-        const bool striped = p.zero_acc || p.zero_in;
+        constexpr bool striped = STRIPED;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
         uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
-        const StripeRead sr{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
+        StripeRead sr{nullptr, nullptr};
+        if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
         if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
             if constexpr (!WIDE)
                 if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
@@ -380,12 +401,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
             continue;
         }
         const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
-        if (read_exceeds_caps(p, s0, s1, tb)) {
-            if constexpr (!WIDE)
-                if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
-            if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 3; }
-            continue;
-        }
         for (uint32_t i = lane; i < tb; i += kWave) s_bases[i] = p.bases[g0 + i];
         wave_lds_fence();
 
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
                     }
                     wave_lds_fence();
                     if (valid)
-                        xxh3_seeds(mimg, (uint32_t)lane * m, m, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) {
+                        xxh3_seeds(mimg, (uint32_t)lane * m, m, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) {
                             if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
                             ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
                         });
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
                     }
                 } else {
                     if (valid)
-                        xxh3_seeds(img, (uint32_t)lane * k, k, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) {
+                        xxh3_seeds(img, (uint32_t)lane * k, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) {
                             if (sd == 0) tag = (uint32_t)h ^ (uint32_t)(h >> 32);
                             ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod);
                         });
@@ -504,9 +519,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
         }
         if constexpr (!WIDE) {
             wave_lds_fence();
-            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, kReadPlanes, STRIPED>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
         }
-        readid_finish_read<NARROW, WIDE>(vc, hist, col_word, row_out, C, lane, p);
+        readid_finish_read<NARROW, WIDE, kReadPlanes, STRIPED>(vc, hist, col_word, row_out, C, lane, p);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
     }
 }
@@ -561,10 +576,10 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
             if (have) {
                 const uint64_t e = p.list_codes[c0 + lane];
                 if (p.bases) {
-                    xxh3_seeds_from(BaseReader{p.bases + (e >> 1), k, (uint32_t)(e & 1ull), p.upper}, k, n, hash_variant_of(p.mod),
+                    xxh3_seeds_from(BaseReader{p.bases + (e >> 1), k, (uint32_t)(e & 1ull), p.upper}, k, n, HashSel::of(p.mod),
                                     [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
                 } else {
-                    xxh3_seeds_from(CodeReader{rev_fields(e, k)}, k, n, hash_variant_of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+                    xxh3_seeds_from(CodeReader{rev_fields(e, k)}, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
                 }
             }
             const uint64_t dmask = __ballot(have);
@@ -603,6 +618,23 @@ static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int w
     return hipGetLastError();
 }
 
+// colour-stripe passes (zero_acc / zero_in set): separate instantiations, so that the plain kernels carry none of that logic
+template <bool MINI>
+static hipError_t launch_readid_packed_striped(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
+    if (p.rs > 128) return hipErrorInvalidValue;
+    if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, MINI, false, true>, p, wpb, grid, stream);
+    switch (log2u(p.rs / 2)) {
+    case 0: return launch_readid_one(k_readid<0, false, false, MINI, false, true>, p, wpb, grid, stream);
+    case 1: return launch_readid_one(k_readid<1, false, false, MINI, false, true>, p, wpb, grid, stream);
+    case 2: return launch_readid_one(k_readid<2, false, false, MINI, false, true>, p, wpb, grid, stream);
+    case 3: return launch_readid_one(k_readid<3, false, false, MINI, false, true>, p, wpb, grid, stream);
+    case 4: return launch_readid_one(k_readid<4, false, false, MINI, false, true>, p, wpb, grid, stream);
+    case 5: return launch_readid_one(k_readid<5, false, false, MINI, false, true>, p, wpb, grid, stream);
+    case 6: return launch_readid_one(k_readid<6, false, false, MINI, false, true>, p, wpb, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 template <bool MINI, bool DENSE>
 static hipError_t launch_readid_packed(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
     if (p.rs > 128) return launch_readid_one(k_readid<0, false, true, MINI, DENSE>, p, wpb, grid, stream);
@@ -623,7 +655,10 @@ static hipError_t launch_readid_packed(const ReadIdParams &p, int wpb, int grid,
 // workgroups' LDS fit the CU's 160 KiB.
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
     const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
-    const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block >= 24;   // 6 waves per SIMD fit
+    if (p.zero_acc || p.zero_in)
+        return p.m_size ? launch_readid_packed_striped<true>(p, waves_per_block, grid, stream) : launch_readid_packed_striped<false>(p, waves_per_block, grid, stream);
+    const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block >= 24 &&   // 6 waves per SIMD fit
+                       ((p.mod.flags >> 8) & 0xFFu) == kHashV08;
     if (p.m_size)
         return dense ? launch_readid_packed<true, true>(p, waves_per_block, grid, stream)
                      : launch_readid_packed<true, false>(p, waves_per_block, grid, stream);
@@ -633,6 +668,20 @@ hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t
 
 // byte-string keys: the reads listed in p.redo_list (count on the device), or all of them
 hipError_t launch_readid_bytes(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
+    if (p.zero_acc || p.zero_in) {
+        if (p.rs > 128) return hipErrorInvalidValue;
+        if (p.rs == 1) return launch_readid_one(k_readid_bytes<0, true, false, true>, p, wpb, grid, stream);
+        switch (log2u(p.rs / 2)) {
+        case 0: return launch_readid_one(k_readid_bytes<0, false, false, true>, p, wpb, grid, stream);
+        case 1: return launch_readid_one(k_readid_bytes<1, false, false, true>, p, wpb, grid, stream);
+        case 2: return launch_readid_one(k_readid_bytes<2, false, false, true>, p, wpb, grid, stream);
+        case 3: return launch_readid_one(k_readid_bytes<3, false, false, true>, p, wpb, grid, stream);
+        case 4: return launch_readid_one(k_readid_bytes<4, false, false, true>, p, wpb, grid, stream);
+        case 5: return launch_readid_one(k_readid_bytes<5, false, false, true>, p, wpb, grid, stream);
+        case 6: return launch_readid_one(k_readid_bytes<6, false, false, true>, p, wpb, grid, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (p.rs > 128) return launch_readid_one(k_readid_bytes<0, false, true>, p, wpb, grid, stream);
     if (p.rs == 1) return launch_readid_one(k_readid_bytes<0, true, false>, p, wpb, grid, stream);
     switch (log2u(p.rs / 2)) {

@@ -10,12 +10,12 @@
 extern "C" {
 
 // Hash `kmer` (len bytes) with seeds 0..n-1 exactly as a lane does: out of a dword image at byte offset `off`.
-static uint32_t g_hv = 0;   // hash variant (cid::kHashV08 / kHashV07) used by every shim call
-void shim_set_hash_variant(uint32_t hv) { g_hv = hv; }
+static cid::ModMagic g_hv{1, 0, 0, 1, cid::PMX1};   // carries the hash variant (cid::kHashV08 / kHashV07) used by every shim call
+void shim_set_hash_variant(uint32_t hv) { g_hv.flags = 1u | (hv << 8); g_hv.xmul = cid::avalanche_mult_of(hv); }
 void shim_hash_seeds(const uint8_t *kmer, uint32_t len, uint32_t off, uint32_t n, uint64_t *out) {
     std::vector<uint32_t> img((off + len + 16 + 3) / 4 + 4, 0xA5A5A5A5u);
     memcpy(reinterpret_cast<uint8_t *>(img.data()) + off, kmer, len);
-    cid::xxh3_seeds(img.data(), off, len, n, g_hv, [&](uint32_t s, uint64_t h) { out[s] = h; });
+    cid::xxh3_seeds(img.data(), off, len, n, cid::HashSel::of(g_hv), [&](uint32_t s, uint64_t h) { out[s] = h; });
 }
 
 // The packed path: an upper-case ACGT k-mer (k <= 32) -> LSB-first 2-bit code -> canonical code -> hashes of the
@@ -31,7 +31,7 @@ void shim_hash_canonical_code(const uint8_t *kmer, uint32_t k, uint32_t n, uint6
     *out_msb = msb;
     const cid::CodeReader r{canon};
     for (uint32_t j = 0; j < k; ++j) out_canon[j] = (uint8_t)r.rd8(j);
-    cid::xxh3_seeds_from(r, k, n, g_hv, [&](uint32_t s, uint64_t h) { out[s] = h; });
+    cid::xxh3_seeds_from(r, k, n, cid::HashSel::of(g_hv), [&](uint32_t s, uint64_t h) { out[s] = h; });
 }
 
 // canonical ACGT k-mer (ASCII) -> minimizer as the device computes it from the 2-bit code -> ASCII, and its hashes (len m)
@@ -41,12 +41,12 @@ void shim_minimizer(const uint8_t *kmer, uint32_t k, uint32_t m, uint32_t n, uin
     const uint64_t mini = cid::minimizer_code(msb, k, m);
     const cid::CodeReader r{cid::rev_fields(mini, m)};
     for (uint32_t j = 0; j < m; ++j) out_mini[j] = (uint8_t)r.rd8(j);
-    cid::xxh3_seeds_from(r, m, n, g_hv, [&](uint32_t s, uint64_t h) { out_hash[s] = h; });
+    cid::xxh3_seeds_from(r, m, n, cid::HashSel::of(g_hv), [&](uint32_t s, uint64_t h) { out_hash[s] = h; });
 }
 
 uint64_t shim_mod(uint64_t h, uint64_t m) {
     const cid::ModMagicHost mh = cid::make_mod_magic(m);
-    const cid::ModMagic mm{mh.m, mh.magic, mh.shift, mh.flags};
+    const cid::ModMagic mm{mh.m, mh.magic, mh.shift, mh.flags, cid::PMX1};
     return cid::mod_m(h, mm);
 }
 
