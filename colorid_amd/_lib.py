@@ -63,6 +63,8 @@ SIGNATURES = {
     "cid_index_insert_kmerset": (C.c_int, [vp, vp, C.c_uint32]),
     "cid_search_count_set": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
     "cid_search_perfect_set": (C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_int)]),
+    "cid_search_count_set_report": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    "cid_unique_freq_modes_dev": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint32, vp]),
     "cid_readid_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "cid_readid_count_sparse": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64)]),
     "cid_readid_sparse_fetch": (C.c_int, [vp, vp, vp, vp]),

@@ -588,6 +588,110 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
 
 }  // namespace cid
 
+// ------------------------------------------------------------------------------------------------ modes of the unique-hit frequencies
+// reports.rs:65-77 on the vectors batch_search_pe.rs:75-82 fills: per colour, the most frequent multiplicity among the k-mers that
+// hit exactly that colour (ties -> the smallest value; the reference's tie is HashMap order).  Done on the device so that neither
+// the per-k-mer unique colours nor the multiplicities (4 + 4 bytes per k-mer) have to cross PCIe for the report.
+//   small multiplicities (f < FL): a colour x FL table of counts, privatised per workgroup in LDS, flushed with global atomics;
+//   the rest: appended as (colour << 32 | f) keys, then sorted and run-length counted;
+//   every (colour, f, count) cell proposes count << 32 | ~f to an atomicMax per colour: highest count wins, ties go to the smaller f.
+namespace cid {
+
+__global__ __launch_bounds__(256) void k_mode_hist(const uint32_t *uc, const uint32_t *freq, uint64_t n, uint32_t C, uint32_t FL, uint64_t per_block,
+                                                   uint32_t *table, uint64_t *ovf, unsigned long long *ovf_count) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t *cells = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t n_cells = C * FL;
+    for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x) cells[i] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
+    const uint64_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = i0; base < i1; base += blockDim.x) {   // block-uniform trip count: the ballot below sees whole waves
+        const uint64_t i = base + threadIdx.x;
+        bool big = false;
+        uint64_t key = 0;
+        if (i < i1) {
+            const uint32_t c = uc[i];
+            if (c != 0xFFFFFFFFu) {
+                const uint32_t f = freq ? freq[i] : 1u;
+                if (f < FL) atomicAdd(&cells[c * FL + f], 1u);
+                else { big = true; key = ((uint64_t)c << 32) | f; }
+            }
+        }
+        const uint64_t m = __ballot(big);
+        if (m) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(ovf_count, (unsigned long long)__popcll(m));
+            at = (unsigned long long)__shfl((long long)at, 0, 64);
+            if (big) ovf[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x)
+        if (cells[i]) atomicAdd(&table[i], cells[i]);
+}
+__global__ void k_mode_pick_table(const uint32_t *table, uint32_t C, uint32_t FL, unsigned long long *best) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * FL) return;
+    const uint32_t v = table[i];
+    if (v) atomicMax(&best[i / FL], ((unsigned long long)v << 32) | (0xFFFFFFFFu - (i % FL)));
+}
+__global__ void k_mode_pick_runs(const uint64_t *keys, const uint32_t *runs, const uint64_t *n_runs, unsigned long long *best) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_runs) return;
+    const uint64_t k = keys[i];
+    atomicMax(&best[k >> 32], ((unsigned long long)runs[i] << 32) | (0xFFFFFFFFu - (uint32_t)k));
+}
+__global__ void k_mode_final(const unsigned long long *best, uint32_t C, uint64_t *modes) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) modes[c] = best[c] ? (uint64_t)(0xFFFFFFFFu - (uint32_t)best[c]) : 0ull;
+}
+
+int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes) {
+    hipStream_t st = ctx_stream(c);
+    if (n == 0) { HIP_TRY(hipMemsetAsync(d_modes, 0, (size_t)C * 8, st)); return CID_OK; }
+    if (n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mers");
+    uint32_t FL = 64;
+    while (FL > 1 && (uint64_t)C * FL > 16384) FL >>= 1;     // the per-workgroup table: at most 64 KiB of LDS
+    if ((uint64_t)C * FL > 16384) FL = 0;                     // very many colours: every (colour, f) goes through the sort
+    DevBuf<uint32_t> table(c), runs(c);
+    DevBuf<uint64_t> ovf(c), keys_sorted(c), keys_u(c), n_runs(c);
+    DevBuf<unsigned long long> best(c), ovf_count(c);
+    int rc;
+    if ((rc = table.alloc((size_t)C * (FL ? FL : 1))) || (rc = ovf.alloc(n)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2)) || (rc = n_runs.alloc(1))) return rc;
+    HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)C * (FL ? FL : 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(best.p, 0, (size_t)C * 8, st));
+    HIP_TRY(hipMemsetAsync(ovf_count.p, 0, 16, st));
+    const unsigned blocks = 1024;
+    uint64_t per_block = (n + blocks - 1) / blocks;
+    per_block = (per_block + 255) / 256 * 256;
+    const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
+    const size_t shmem = (size_t)C * FL * 4;
+    if (shmem > 64 * 1024) return fail(CID_ERR_UNSUPPORTED, "mode table");
+    hipLaunchKernelGGL(k_mode_hist, dim3(grid), dim3(256), shmem, st, d_uc, d_freq, n, C, FL, per_block, table.p, ovf.p, ovf_count.p);
+    if (FL) hipLaunchKernelGGL(k_mode_pick_table, dim3((C * FL + 255) / 256), dim3(256), 0, st, table.p, C, FL, best.p);
+    unsigned long long n_ovf = 0;
+    HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_ovf) {
+        if ((rc = keys_sorted.alloc(n_ovf)) || (rc = keys_u.alloc(n_ovf)) || (rc = runs.alloc(n_ovf))) return rc;
+        size_t tb = 0, tb2 = 0;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, ovf.p, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st));
+        HIP_TRY(rocprim::run_length_encode(nullptr, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st));
+        DevBuf<uint8_t> tmp(c);
+        if ((rc = tmp.alloc(tb > tb2 ? tb : tb2))) return rc;
+        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, ovf.p, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st));
+        HIP_TRY(rocprim::run_length_encode(tmp.p, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st));
+        hipLaunchKernelGGL(k_mode_pick_runs, dim3(grid_for_n(n_ovf)), dim3(256), 0, st, keys_u.p, runs.p, n_runs.p, best.p);
+    }
+    hipLaunchKernelGGL(k_mode_final, dim3((C + 255) / 256), dim3(256), 0, st, best.p, C, d_modes);
+    HIP_TRY(hipStreamSynchronize(st));   // the scratch goes out of scope
+    return CID_OK;
+}
+
+}  // namespace cid
+
 // ------------------------------------------------------------------------------------------------ rows -> .bxi records
 // save_bigsi (bigsi.rs:51-57 / build.rs:123-127): the non-zero rows of a row range, in ascending order, as the bincode
 // records the file holds — { u64 row ; u64 W32 ; W32 x u32 ; u64 n_colors } — formatted on the device so that the host only
@@ -1104,6 +1208,37 @@ int cid_search_count_set(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks,
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
     if (ks->general) return cid::search_count_ascii(c, ix, ks->ascii, ks->counts, ks->n, ks->k, hits, n_unique, sum_unique_freq, unique_colour);
     return cid::search_count_codes(c, ix, ks->codes, ks->counts, ks->n, ks->k, hits, n_unique, sum_unique_freq, unique_colour);
+}
+
+int cid_unique_freq_modes_dev(cid_ctx *c, const uint32_t *d_unique_colour, const uint32_t *d_freq, size_t n_kmers, uint32_t n_colors, uint64_t *d_modes) {
+    if (!c || !d_modes || n_colors == 0 || (n_kmers && !d_unique_colour)) return fail(CID_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+    return cid::unique_freq_modes(c, d_unique_colour, d_freq, n_kmers, n_colors, d_modes);
+}
+
+// a5 over a finalized set with everything reports::generate_report needs (reports.rs:8-48) and nothing per k-mer: hits, the number
+// of unique-hit k-mers, the sum of their multiplicities (-> mean) and their mode, n_colors values each
+int cid_search_count_set_report(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks, uint64_t *hits, uint64_t *n_unique,
+                                uint64_t *sum_unique_freq, uint64_t *mode_unique_freq) {
+    if (!ks || !hits || !n_unique || !sum_unique_freq || !mode_unique_freq) return fail(CID_ERR_INVALID, "null argument");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+    const uint32_t C = cid::index_n_colors(ix);
+    DevBuf<uint32_t> uc(ks->ctx);
+    DevBuf<uint64_t> out(ks->ctx);
+    int rc;
+    if ((rc = uc.alloc(ks->n)) || (rc = out.alloc((size_t)4 * C))) return rc;
+    if (ks->general) rc = cid_search_count_dev(c, ix, ks->ascii, ks->counts, ks->n, out.p, out.p + C, out.p + 2 * C, uc.p);
+    else rc = cid_search_count_codes_dev(c, ix, ks->codes, ks->counts, ks->n, out.p, out.p + C, out.p + 2 * C, uc.p);
+    if (rc) return rc;
+    if ((rc = cid::unique_freq_modes(c, uc.p, ks->counts, ks->n, C, out.p + 3 * C))) return rc;
+    hipStream_t st = cid::ctx_stream(c);
+    HIP_TRY(hipMemcpyAsync(hits, out.p, (size_t)C * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(n_unique, out.p + C, (size_t)C * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(sum_unique_freq, out.p + 2 * C, (size_t)C * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(mode_unique_freq, out.p + 3 * C, (size_t)C * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CID_OK;
 }
 
 int cid_search_perfect_set(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks, uint32_t *and_words_le, int *any_row_missing) {

@@ -118,23 +118,29 @@ void read_counts_five_fields(const std::string &reads_file, const std::string &p
 }
 
 // reports.rs:8-48: hits / n_ref_kmers > cov -> query, K, accession, cov, mean, mode, n_unique
+// `modes`: the per-colour mode of the unique-hit k-mer frequencies when the device computed it (cid_search_count_set_report);
+// NULL: derived here from the per-k-mer unique colours and multiplicities (reports.rs:65-77; ties -> smallest value)
 static void generate_report(const std::string &query, const Bigsi &b, const std::vector<uint64_t> &hits,
                             const std::vector<uint64_t> &n_unique, const std::vector<uint64_t> &sum_freq,
-                            const std::vector<uint32_t> &unique_colour, const uint32_t *counts, size_t n_kmers, double cov) {
+                            const std::vector<uint32_t> &unique_colour, const uint32_t *counts, size_t n_kmers, double cov,
+                            const std::vector<uint64_t> *modes = nullptr) {
     const size_t C = b.colors.size();
-    // mode of the unique-hit k-mer frequencies per colour (reports.rs:65-77; ties -> smallest value)
-    std::vector<std::map<uint32_t, uint64_t>> occ(C);
-    for (size_t j = 0; j < n_kmers; ++j)
-        if (unique_colour[j] != CID_NOT_UNIQUE) occ[unique_colour[j]][counts[j]] += 1;
+    std::vector<std::map<uint32_t, uint64_t>> occ(modes ? 0 : C);
+    if (!modes)
+        for (size_t j = 0; j < n_kmers; ++j)
+            if (unique_colour[j] != CID_NOT_UNIQUE) occ[unique_colour[j]][counts[j]] += 1;
     for (size_t c = 0; c < C; ++c) {
         if (!hits[c]) continue;
         double mean = 0.0;
         uint64_t modus = 0, specific = 0;
         if (n_unique[c]) {
             mean = (double)sum_freq[c] / (double)n_unique[c];
-            uint64_t bestc = 0;
-            for (auto &kv : occ[c])
-                if (kv.second > bestc) { bestc = kv.second; modus = kv.first; }
+            if (modes) modus = (*modes)[c];
+            else {
+                uint64_t bestc = 0;
+                for (auto &kv : occ[c])
+                    if (kv.second > bestc) { bestc = kv.second; modus = kv.first; }
+            }
             specific = n_unique[c];
         }
         const double genome_cov = (double)hits[c] / (double)b.n_ref_kmers[c];
@@ -315,7 +321,8 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
         const bool use_auto = !fasta_gene && filter < 0;
         if (!gz && !gene_search && filter < 0) fprintf(stderr, "no gene search\n");
 
-        std::vector<uint64_t> hits(C), n_unique(C), sum_freq(C);
+        std::vector<uint64_t> hits(C), n_unique(C), sum_freq(C), modes;
+        bool have_modes = false;
         std::vector<uint32_t> uc, counts;
         size_t n_kmers = 0;
         cid_kmerset *ks = nullptr;
@@ -332,11 +339,17 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
             n_kmers = n;
             fprintf(stderr, "%zu k-mers in query\n", n_kmers);
             const auto t0 = Clock::now();
-            if (!gene_search) { uc.resize(n_kmers); counts.resize(n_kmers); }
-            CID_TRY(hot_search_count_set(ctx, b, ks, hits.data(), gene_search ? nullptr : n_unique.data(),
-                                         gene_search ? nullptr : sum_freq.data(), gene_search ? nullptr : uc.data()));
+            if (!gene_search && !g_group) {   // the whole report on the device: nothing per k-mer comes back
+                modes.assign(C, 0);
+                have_modes = true;
+                CID_TRY(cid_search_count_set_report(ctx, b.index, ks, hits.data(), n_unique.data(), sum_freq.data(), modes.data()));
+            } else {
+                if (!gene_search) { uc.resize(n_kmers); counts.resize(n_kmers); }
+                CID_TRY(hot_search_count_set(ctx, b, ks, hits.data(), gene_search ? nullptr : n_unique.data(),
+                                             gene_search ? nullptr : sum_freq.data(), gene_search ? nullptr : uc.data()));
+                if (!gene_search) CID_TRY(cid_kmerset_download(ks, nullptr, counts.data()));
+            }
             if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
-            if (!gene_search) CID_TRY(cid_kmerset_download(ks, nullptr, counts.data()));
             cid_kmerset_destroy(ks);
         } else {  // host k-mer map (k > 32, lower-case fastq, or COLORID_HOST_KMERS)
             fprintf(stderr, "k-mer map on the host\n");
@@ -357,7 +370,7 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
             if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
             counts = km.counts();
         }
-        if (!gene_search) generate_report(file1, b, hits, n_unique, sum_freq, uc, counts.data(), n_kmers, cov);
+        if (!gene_search) generate_report(file1, b, hits, n_unique, sum_freq, uc, counts.data(), n_kmers, cov, have_modes ? &modes : nullptr);
         else generate_report_gene(file1, b, hits, n_kmers, cov);
     }
 }

@@ -247,6 +247,12 @@ class KmerSet:
         check(self.lib.cid_search_count_set(self.ctx.h, index.h, self.h, _p(hits), _p(nu), _p(sf), _p(uc)))
         return hits, nu, sf, uc
 
+    def search_count_report(self, index):
+        """-> (hits, n_unique, sum_unique_freq, mode_unique_freq): what generate_report needs, nothing per k-mer"""
+        out = [np.zeros(index.n_colors, np.uint64) for _ in range(4)]
+        check(self.lib.cid_search_count_set_report(self.ctx.h, index.h, self.h, *[_p(o) for o in out]))
+        return tuple(out)
+
     def search_perfect(self, index):
         words = np.zeros(index.w32, np.uint32)
         missing = C.c_int(0)

@@ -198,6 +198,14 @@ int cid_index_insert_kmerset(cid_index *, const cid_kmerset *, uint32_t colour);
 int cid_search_count_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
                          uint64_t *sum_unique_freq, uint32_t *unique_colour);
 int cid_search_perfect_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint32_t *and_words_le, int *any_row_missing);
+/* The same search with everything reports::generate_report prints (src/reports.rs:8-48) and nothing per k-mer: per colour the
+ * hits, the number of k-mers that hit only that colour, the sum of their multiplicities (-> mean) and their MODE
+ * (src/reports.rs:65-77; ties -> the smallest value, the reference's tie follows HashMap order) — 4 x n_colors u64 instead of
+ * 8 bytes per k-mer crossing PCIe.  cid_unique_freq_modes_dev is the mode step alone on device arrays (d_freq NULL = all 1). */
+int cid_search_count_set_report(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
+                                uint64_t *sum_unique_freq, uint64_t *mode_unique_freq);
+int cid_unique_freq_modes_dev(cid_ctx *, const uint32_t *d_unique_colour, const uint32_t *d_freq, size_t n_kmers, uint32_t n_colors,
+                              uint64_t *d_modes);
 
 /* ---- a4: perfect search, perfect_search::batch_search / batch_search_mf
  *      (src/perfect_search.rs:25-52, :83-110): AND of all n*K rows.  and_words_le: W32 u32 words;

@@ -208,3 +208,33 @@ def test_search_over_device_set(orc, hip_ctx, n_colors, n_hash, k):
     gw, gm = sub.search_perfect(hx2)
     assert pm == gm and np.array_equal(pw, gw) and (pm or pw[0] & 1)
     hx.close(); hx2.close(); ks.close(); sub.close()
+
+
+@pytest.mark.parametrize("n_colors,k", [(256, 31), (46, 27), (3000, 21), (20000, 25), (100, 40)])
+def test_report_outputs_on_the_device(orc, hip_ctx, n_colors, k):
+    """cid_search_count_set_report: hits / n_unique / sum / MODE per colour (reports.rs:65-77, ties -> smallest value) computed on the
+    device == the oracle's unique_modes over the per-k-mer results; multiplicities both below and above the LDS table's range."""
+    import colorid_amd
+    rng = np.random.default_rng(n_colors + k)
+    m = 30_011 if n_colors < 5000 else 3001
+    oix = random_index(orc, rng, m, 3, k, n_colors, density=0.01 if n_colors < 5000 else 0.001, zero_row_frac=0.0)
+    base = [rand_seq(rng, 400) for _ in range(30)]
+    seqs = []
+    for i, s_ in enumerate(base):                     # multiplicities 1 .. 130: both tiers of the mode histogram
+        seqs += [s_] * int(rng.choice([1, 2, 3, 7, 30, 63, 64, 65, 130]))
+    seqs += [rand_seq(rng, 3000) for _ in range(5)]
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    ks.add_seqs(seqs, 0)
+    ks.finalize()
+    km, cnt = ks.download()
+    for j in rng.choice(len(km), size=min(len(km), 6000), replace=False):      # most k-mers hit exactly one colour
+        oix.insert(int(rng.integers(0, n_colors)) if rng.random() < 0.8 else int(rng.integers(0, min(n_colors, 3))), km[j].tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    w = oix.search_count(km, cnt.astype(np.uint64))
+    modes = orc.unique_modes(w[3], cnt.astype(np.uint64), n_colors)
+    hits, nu, sf, md = ks.search_count_report(hx)
+    assert np.array_equal(hits, w[0]) and np.array_equal(nu, w[1]) and np.array_equal(sf, w[2])
+    assert np.array_equal(md, modes), (np.flatnonzero(md != modes)[:5], md[md != modes][:5], modes[md != modes][:5])
+    assert (nu > 0).sum() > 10 and len(np.unique(modes)) > 3
+    hx.close()
+    ks.close()
