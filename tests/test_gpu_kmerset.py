@@ -218,23 +218,33 @@ def test_report_outputs_on_the_device(orc, hip_ctx, n_colors, k):
     rng = np.random.default_rng(n_colors + k)
     m = 30_011 if n_colors < 5000 else 3001
     oix = random_index(orc, rng, m, 3, k, n_colors, density=0.01 if n_colors < 5000 else 0.001, zero_row_frac=0.0)
-    base = [rand_seq(rng, 400) for _ in range(30)]
+    mults = [1, 2, 3, 7, 30, 63, 64, 65, 130, 2, 64, 5]             # both tiers of the mode histogram (table: f < 64 at 256 colours)
+    base = [rand_seq(rng, 300) for _ in mults]
     seqs = []
-    for i, s_ in enumerate(base):                     # multiplicities 1 .. 130: both tiers of the mode histogram
-        seqs += [s_] * int(rng.choice([1, 2, 3, 7, 30, 63, 64, 65, 130]))
-    seqs += [rand_seq(rng, 3000) for _ in range(5)]
+    for s_, mu in zip(base, mults):
+        seqs += [s_] * mu
     ks = colorid_amd.KmerSet(hip_ctx, k)
     ks.add_seqs(seqs, 0)
     ks.finalize()
     km, cnt = ks.download()
-    for j in rng.choice(len(km), size=min(len(km), 6000), replace=False):      # most k-mers hit exactly one colour
-        oix.insert(int(rng.integers(0, n_colors)) if rng.random() < 0.8 else int(rng.integers(0, min(n_colors, 3))), km[j].tobytes())
+    # colour i (< 12) holds k-mers of base sequence i alone (mode = that sequence's multiplicity), further colours share them
+    # (not unique); colour 20 holds exactly five k-mers each of sequences 1 and 2: a tie, resolved to the smaller multiplicity
+    for i, s_ in enumerate(base):
+        one = orc.Kmers(k)
+        one.kmerize_vector(s_, 1)
+        cols = [c for c in range(min(n_colors, 40)) if c % len(mults) == i and c != 20]
+        for j, key in enumerate(one.keys()):
+            if i in (1, 2) and j < 5:
+                oix.insert(20, key.tobytes())
+                continue
+            for c in cols[:1] if rng.random() < 0.5 else cols:
+                oix.insert(int(c), key.tobytes())
     hx = to_hip_index(hip_ctx, oix)
     w = oix.search_count(km, cnt.astype(np.uint64))
     modes = orc.unique_modes(w[3], cnt.astype(np.uint64), n_colors)
     hits, nu, sf, md = ks.search_count_report(hx)
     assert np.array_equal(hits, w[0]) and np.array_equal(nu, w[1]) and np.array_equal(sf, w[2])
     assert np.array_equal(md, modes), (np.flatnonzero(md != modes)[:5], md[md != modes][:5], modes[md != modes][:5])
-    assert (nu > 0).sum() > 10 and len(np.unique(modes)) > 3
+    assert (nu > 0).sum() >= 10 and len(np.unique(modes)) > 4 and modes.max() >= 64 and (n_colors <= 20 or modes[20] == 2)
     hx.close()
     ks.close()
