@@ -1,5 +1,6 @@
 # Host-side sanitizer runs of the CLI on a GPU box (GPU ASan is not available on this pool): build tools/bin/colorid_asan and
-# tools/bin/colorid_tsan with g++ -fsanitize=address,undefined / -fsanitize=thread from colorid_amd/csrc/host/*.cpp first.
+# tools/bin/colorid_tsan with g++ -fsanitize=address,undefined / -fsanitize=thread from colorid_amd/csrc/host/*.cpp first
+# (`make -C tools sanitizers`, in the build container).
 set -x
 cd $GRAFT_REPO_ROOT
 W=/tmp/san; mkdir -p $W
@@ -29,4 +30,9 @@ for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
   $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -g -f 0 > $W/s.out 2> $W/s.err; echo "search rc=$?"; grep -c . $W/s.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s.err | head -5
   $B read_id -b $W/ix.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid -c 5000 > $W/r.out 2> $W/r.err; echo "read_id rc=$?"; wc -l $W/rid_reads.txt; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r.err | head -5
   $B read_id -b $W/ix.bxi -q $W/r_1.fastq.gz -n $W/rid1 -c 777 > $W/r1.out 2> $W/r1.err; echo "read_id SE rc=$?"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r1.err | head -5
+  # round 2: the default report (device-side mode), several ranks on the one GPU (cid_group: one host thread per rank), hashcheck
+  $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -f 0 -p 0.01 > $W/s2.out 2> $W/s2.err; echo "search default rc=$?"; grep -c . $W/s2.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s2.err | head -5
+  $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 --devices 0,0,0 > $W/s3.out 2> $W/s3.err; echo "search 3 ranks rc=$?"; grep -c . $W/s3.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s3.err | head -5
+  $B read_id -b $W/ix.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid3 -c 5000 --devices 0,0 > $W/r3.out 2> $W/r3.err; echo "read_id 2 ranks rc=$?"; cmp $W/rid_reads.txt $W/rid3_reads.txt && echo "same rows as one rank"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r3.err | head -5
+  $B hashcheck -b $W/ix.bxi -r $W/refs.tsv > $W/h.out 2> $W/h.err; echo "hashcheck rc=$?"; grep verdict $W/h.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/h.err | head -5
 done
