@@ -153,3 +153,64 @@ def test_cli_gpus_equals_single_gpu(orc, tmp_path):
     _, err = _cli(*cases["search_fasta"], "--devices", "0", env={"COLORID_REDUCE": "rccl"})
     _, err2 = _cli(*cases["search_fasta"], "--devices", "0,0")
     assert "RCCL all-reduce" in err and "through the host" in err2
+
+
+def test_round2_entry_points_refuse_misuse(orc, hip_ctx):
+    """Every misuse of the round-2 entry points comes back as an error code + message (nothing aborts across the ABI)."""
+    import ctypes as C
+
+    import torch
+
+    import colorid_amd
+    from colorid_amd._lib import vp
+    lib = hip_ctx.lib
+    gh = vp()
+    assert lib.cid_group_create(None, 2, C.byref(gh)) == -1
+    assert lib.cid_group_create((C.c_int * 1)(0), 0, C.byref(gh)) == -1
+    assert lib.cid_group_create((C.c_int * 1)(99), 1, C.byref(gh)) < 0 and not gh.value          # no such device
+    assert lib.cid_tune(b"no_such_knob", 1) == -1 and b"unknown tunable" in lib.cid_last_error()
+    assert lib.cid_tune(b"order_bits", 40) == -1
+    rng = np.random.default_rng(3)
+    oix = random_index(orc, rng, 5003, 2, 21, 70, density=0.2, zero_row_frac=0.1)
+    g = colorid_amd.Group([0, 0])
+    hx = colorid_amd.Index(g.ctxs[0], oix.m, oix.n_hash, oix.k, oix.n_colors)
+    hx.put_dense(oix.rows())
+    arr = (vp * 2)()
+    assert lib.cid_group_replicate_index(g.h, hx.h, arr) == -5                                      # not finalized
+    hx.finalize()
+    g.replicate(hx)
+    other = colorid_amd.Index(g.ctxs[1], 4001, 2, 21, 70).finalize()                                # a replica of another shape
+    bad = (vp * 2)(hx.h.value, other.h.value)
+    hits = np.zeros(70, np.uint64)
+    km = random_kmers(rng, 10, 21)
+    assert lib.cid_group_search_count(g.h, bad, km.ctypes.data, None, 10, hits.ctypes.data, None, None, None) == -1
+    assert b"differs" in lib.cid_last_error()
+    wrong_dev = (vp * 2)(hx.h.value, hx.h.value)                                                     # rank 1's replica must live in rank 1's ctx?  same device: accepted
+    assert lib.cid_group_search_count(g.h, wrong_dev, km.ctypes.data, None, 10, hits.ctypes.data, None, None, None) == 0
+    words = np.zeros(3, np.uint32)
+    miss = C.c_int(0)
+    assert lib.cid_group_search_perfect(g.h, g._replica_handles, km.ctypes.data, 0, words.ctypes.data, C.byref(miss)) == -1    # no k-mers
+    ks = colorid_amd.KmerSet(g.ctxs[0], 40)                                                          # byte-string set: not sliceable over a group
+    ks.add_seqs([bytes(rng.choice(list(b"ACGT"), size=200).astype(np.uint8))], 0)
+    ks.finalize()
+    assert lib.cid_group_search_count_set(g.h, g._replica_handles, ks.h, hits.ctypes.data, None, None, None) < 0
+    with pytest.raises(colorid_amd.CidError):
+        ks.order_for_index(hx)
+    ks.close()
+    # stripes: read_id passes refuse wide stripes and nonsense maxima; the packed fact refuses more than 2^20 colours
+    d = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(8, dtype=torch.int64, device="cuda")
+    z = torch.zeros(64, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    c0 = g.ctxs[0]
+    assert lib.cid_readid_stripe_zero_dev(c0.h, hx.h, vp(d.data_ptr()), vp(o.data_ptr()), vp(o.data_ptr()), 1, 1, 64, 0, vp(z.data_ptr()),
+                                          vp(z.data_ptr()), vp(d.data_ptr())) == -1                 # max_read_windows = 0
+    assert lib.cid_readid_stripe_count_dev(c0.h, hx.h, vp(d.data_ptr()), vp(o.data_ptr()), vp(o.data_ptr()), 1, 1, 3, 64, 44, 60, 100, 1,
+                                           vp(z.data_ptr()), vp(z.data_ptr()), vp(z.data_ptr()), vp(d.data_ptr())) == -1   # stripe outside the colour range
+    assert lib.cid_search_unique_finalize_dev(c0.h, vp(z.data_ptr()), None, 64, (1 << 20) + 1, vp(o.data_ptr()), vp(o.data_ptr()), vp(z.data_ptr())) == -1
+    assert lib.cid_index_set_hash_variant(hx.h, 7) == -4
+    # everything still works afterwards
+    got = g.search_count(km)
+    assert np.array_equal(got[0], oix.search_count(km, None)[0])
+    other.close()
+    g.close()
