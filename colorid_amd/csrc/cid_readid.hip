@@ -277,7 +277,6 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         wave_lds_fence();
 
         uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
-        uint32_t wbase = 0;    // windows enumerated so far (first-occurrence order index)
         bool stopped = false;  // an absent row was met: nothing after it is searched
         VCount<PLANES, NARROW> vc;
         vc.clear();
@@ -287,14 +286,38 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             for (uint32_t w = lane; w < p.rs; w += kWave) s_R[w] = 0;
             wave_lds_fence();
         }
-        for (uint64_t s = s0; s < s1; ++s) {
-            const uint32_t off = (uint32_t)(p.seq_off[s] - g0);
+        // The read's windows as ONE sequence over its mates (mate 1's first: the first-occurrence order), cut into chunks of 64:
+        // a chunk may straddle the mate boundary, so 2 x 130 windows are 5 chunks, not 6 (each chunk is a wave-wide pass).
+        // A mate shorter than k contributes nothing.
+        const uint32_t n_mates = (uint32_t)(s1 - s0);
+        const uint32_t nw0 = (first_len - k) / p.stride_d + 1;
+        uint32_t off1 = 0, nw1 = 0;
+        if (n_mates >= 2) {
+            off1 = (uint32_t)(p.seq_off[s0 + 1] - g0);
+            const uint32_t len1 = (uint32_t)(p.seq_off[s0 + 2] - p.seq_off[s0 + 1]);
+            nw1 = len1 >= k ? (len1 - k) / p.stride_d + 1 : 0u;
+        }
+        uint32_t wtot = nw0 + nw1;
+        for (uint64_t s = s0 + 2; s < s1; ++s) {   // reads of more than two mates (never from the CLI): counted here, located below
             const uint32_t len = (uint32_t)(p.seq_off[s + 1] - p.seq_off[s]);
-            if (len < k) continue;  // a mate shorter than k contributes nothing
-            const uint32_t nw = (len - k) / p.stride_d + 1;
-            for (uint32_t c0 = 0; c0 < nw; c0 += kWave) {
-                const uint32_t wi = c0 + lane;
-                const uint32_t pos = off + wi * p.stride_d;
+            if (len >= k) wtot += (len - k) / p.stride_d + 1;
+        }
+        {
+            for (uint32_t c0 = 0; c0 < wtot; c0 += kWave) {
+                const uint32_t wi = c0 + lane;                 // index in the read's window sequence == first-occurrence order index
+                uint32_t pos = wi < nw0 ? wi * p.stride_d : off1 + (wi - nw0) * p.stride_d;
+                if (n_mates > 2 && c0 + kWave > nw0 + nw1) {   // (wave-uniform) this chunk reaches into a third or later mate
+                    uint32_t base = nw0 + nw1;
+                    for (uint64_t s = s0 + 2; s < s1; ++s) {
+                        const uint32_t len = (uint32_t)(p.seq_off[s + 1] - p.seq_off[s]);
+                        if (len < k) continue;
+                        const uint32_t nws = (len - k) / p.stride_d + 1;
+                        if (wi >= base && wi < base + nws) pos = (uint32_t)(p.seq_off[s] - g0) + (wi - base) * p.stride_d;
+                        base += nws;
+                    }
+                }
+                constexpr uint32_t wbase = 0;
+                const uint32_t nw = wtot;
                 if constexpr (WIDE) wave_lds_fence();  // the previous chunk's gathers are done with ridx
                 bool valid = wi < nw;
                 uint64_t lsb = 0;
@@ -335,7 +358,6 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 }
                 nd += (uint32_t)__popcll(dmask);
             }
-            wbase += nw;
         }
         if constexpr (!WIDE) {
             // the set is complete: the table's region becomes the histogram; search the nd k-mers in order

@@ -269,3 +269,26 @@ print('sliced ok')
     env = dict(os.environ, CID_DENSE_REPORT_BYTES=str(37 * (oix.n_colors + 1) * 4))
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "sliced ok" in p.stdout, p.stderr[-2000:]
+
+
+def test_readid_more_than_two_mates(orc, phage):
+    """A read is any number of sequences (read_seq0): the window sequence runs over all of them in order — three and four mates,
+    short ones in between, chunks of 64 windows straddling every mate boundary."""
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(11)
+    reads = []
+    for i in range(120):
+        g = genomes[i % 4]
+        n_m = int(rng.integers(3, 5))
+        mates = []
+        for j in range(n_m):
+            L = int(rng.choice([5, 26, 27, 28, 60, 91, 150]))
+            st = int(rng.integers(0, len(g) - 200))
+            mates.append(g[st:st + L])
+        if len(mates[0]) < 27:
+            mates[0] = g[100:190]                      # keep most reads classifiable (too_short looks at the first mate only)
+        reads.append(mates)
+    reads.append([genomes[0][:150], b"", genomes[0][150:300], b"ACGT"])
+    reads.append([b"ACG", genomes[1][:150], genomes[1][200:350]])       # first mate too short -> too_short whatever follows
+    for d, S in ((1, 3), (1, 0), (7, 2)):
+        check(oix, hx, reads, d, S)
