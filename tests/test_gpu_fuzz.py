@@ -115,10 +115,11 @@ def test_search_random_shapes(orc, hip_ctx, seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24)) // 2))
 def test_kmerset_random_inputs(orc, hip_ctx, seed):
     """GPU k-mer counting (cid_kmerset) on random sequence sets: FASTA mode (mixed case allowed, upper-cased keys) in several
-    add_seqs calls against kmerize_vector, with clean_map and the multiplicity histogram."""
+    add_seqs calls against kmerize_vector, with clean_map, the multiplicity histogram and the device-side report (hits / unique /
+    sum / mode) of a search over the set; k = 1..32 as 2-bit codes, 33..128 as byte strings."""
     import colorid_amd
     rng = np.random.default_rng(3000 + seed)
-    k = int(rng.integers(1, 33))
+    k = int(rng.integers(1, 33)) if seed % 3 else int(rng.integers(33, 129))     # every third case: byte-string keys (k > 32)
     alphabets = [b"ACGT", b"ACGTN", b"ACGTacgt", b"ACGTacgtNn", b"AC", b"ACGTRY"]
     seqs = []
     for _ in range(int(rng.integers(1, 12))):
@@ -141,6 +142,20 @@ def test_kmerset_random_inputs(orc, hip_ctx, seed):
         vals, cnts = ks.histogram()
         wc = want.counts()
         assert dict(zip(vals.tolist(), cnts.tolist())) == {int(v): int((wc == v).sum()) for v in np.unique(wc)}
+        if seed % 2 == 0 and len(want) > 3:     # search the set + the whole report on the device
+            from util import random_index, to_hip_index
+            C = int(rng.choice([3, 64, 70, 300]))
+            oix = random_index(orc, rng, 4001, int(rng.integers(1, 5)), k, C, density=0.05, zero_row_frac=0.1)
+            keys = want.keys()
+            for j in rng.choice(len(keys), size=min(len(keys), 200), replace=False):
+                oix.insert(int(rng.integers(0, C)), keys[j].tobytes())
+            hx = to_hip_index(hip_ctx, oix)
+            km, cnt = ks.download()
+            w = oix.search_count(km, cnt.astype(np.uint64))
+            modes = orc.unique_modes(w[3], cnt.astype(np.uint64), C)
+            hits, nu, sf, md = ks.search_count_report(hx)
+            assert np.array_equal(hits, w[0]) and np.array_equal(nu, w[1]) and np.array_equal(sf, w[2]) and np.array_equal(md, modes)
+            hx.close()
         t = int(rng.integers(0, 4))
         ks.clean(t)
         assert ks.as_dict() == want.clean_map(t).as_dict()
