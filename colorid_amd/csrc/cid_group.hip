@@ -97,6 +97,15 @@ void shard_bounds(size_t n_units, int rank, int world, size_t *lo, size_t *hi) {
     *hi = *lo + base + ((size_t)rank < rem ? 1 : 0);
 }
 
+// the same with every boundary on a multiple of 64 units (byte-string k-mers: a shard's first k-mer must sit on a 16-byte boundary)
+void shard_bounds64(size_t n_units, int rank, int world, size_t *lo, size_t *hi) {
+    const size_t blocks = (n_units + 63) / 64;
+    shard_bounds(blocks, rank, world, lo, hi);
+    *lo *= 64; *hi *= 64;
+    if (*lo > n_units) *lo = n_units;
+    if (*hi > n_units) *hi = n_units;
+}
+
 // run fn(rank) on one host thread per rank (a cid_ctx is used by one thread at a time); returns the first failure, whose
 // message is re-recorded on the calling thread (cid_last_error is thread-local)
 template <typename F>
@@ -297,40 +306,45 @@ int cid_group_search_count_set(cid_group *g, cid_index *const *replicas, const c
     if (rc) return rc;
     if (!hits) return fail(CID_ERR_INVALID, "null argument");
     cid_ctx *kc;
-    const uint64_t *codes;
+    const uint64_t *codes = nullptr;
+    const uint8_t *ascii = nullptr;     // byte-string sets (k > 32): n x k bytes instead of 2-bit codes
     const uint32_t *counts;
     uint64_t nk;
     uint32_t kk;
-    if ((rc = cid::kmerset_view(ks, &kc, &codes, &counts, &nk, &kk))) return rc;
+    if (cid::kmerset_view_ascii(ks, &kc, &ascii, &counts, &nk, &kk) != CID_OK) {
+        ascii = nullptr;
+        if ((rc = cid::kmerset_view(ks, &kc, &codes, &counts, &nk, &kk))) return rc;
+    }
     if (kk != replicas[0]->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", kk, replicas[0]->k);
     const int n = (int)g->ctx.size();
     const size_t C = replicas[0]->n_colors;
+    const size_t unit = ascii ? kk : 8;   // bytes per k-mer in the set
     HIP_TRY(hipSetDevice(kc->device));
     HIP_TRY(hipStreamSynchronize(kc->stream));
     std::vector<uint64_t *> d_out(n, nullptr);
     rc = for_each_rank(g, [&](int r) -> int {
         cid_ctx *c = g->ctx[r];
         size_t lo, hi;
-        shard_bounds(nk, r, n, &lo, &hi);
+        if (ascii) shard_bounds64(nk, r, n, &lo, &hi); else shard_bounds(nk, r, n, &lo, &hi);
         const size_t ns = hi - lo;
         HIP_TRY(hipSetDevice(c->device));
         void *d_o, *d_uc = nullptr, *d_k = nullptr, *d_f = nullptr;
         int e = cid::slot_reserve(c, S_OUT, 3 * C * 8, &d_o); if (e) return e;
         if (unique_colour) { e = cid::slot_reserve(c, S_UC, ns * 4, &d_uc); if (e) return e; }
-        const uint64_t *my_codes = codes + lo;
+        const uint8_t *my_keys = ascii ? ascii + lo * unit : reinterpret_cast<const uint8_t *>(codes + lo);
         const uint32_t *my_counts = counts + lo;
         if (c->device != kc->device) {   // another GPU: the slice travels over xGMI
-            e = cid::slot_reserve(c, S_KMERS, ns * 8, &d_k); if (e) return e;
+            e = cid::slot_reserve(c, S_KMERS, ns * unit, &d_k); if (e) return e;
             e = cid::slot_reserve(c, S_FREQ, ns * 4, &d_f); if (e) return e;
             if (ns) {
-                HIP_TRY(hipMemcpyPeerAsync(d_k, c->device, codes + lo, kc->device, ns * 8, c->stream));
+                HIP_TRY(hipMemcpyPeerAsync(d_k, c->device, my_keys, kc->device, ns * unit, c->stream));
                 HIP_TRY(hipMemcpyPeerAsync(d_f, c->device, counts + lo, kc->device, ns * 4, c->stream));
             }
-            my_codes = (const uint64_t *)d_k; my_counts = (const uint32_t *)d_f;
+            my_keys = (const uint8_t *)d_k; my_counts = (const uint32_t *)d_f;
         }
         uint64_t *o = (uint64_t *)d_o;
-        e = cid::search_count_launch(c, replicas[r], nullptr, my_codes, my_counts, ns, o, n_unique ? o + C : nullptr,
-                                     sum_unique_freq ? o + 2 * C : nullptr, (uint32_t *)d_uc);
+        e = cid::search_count_launch(c, replicas[r], ascii ? my_keys : nullptr, ascii ? nullptr : reinterpret_cast<const uint64_t *>(my_keys), my_counts, ns, o,
+                                     n_unique ? o + C : nullptr, sum_unique_freq ? o + 2 * C : nullptr, (uint32_t *)d_uc);
         if (e) return e;
         if (!n_unique) HIP_TRY(hipMemsetAsync(o + C, 0, C * 8, c->stream));           // the all-reduce covers all 3*C words
         if (!sum_unique_freq) HIP_TRY(hipMemsetAsync(o + 2 * C, 0, C * 8, c->stream));
@@ -387,11 +401,15 @@ int cid_group_search_perfect_set(cid_group *g, cid_index *const *replicas, const
     if (rc) return rc;
     if (!and_words_le || !any_row_missing) return fail(CID_ERR_INVALID, "null argument");
     cid_ctx *kc;
-    const uint64_t *codes;
+    const uint64_t *codes = nullptr;
+    const uint8_t *ascii = nullptr;
     const uint32_t *counts;
     uint64_t nk;
     uint32_t kk;
-    if ((rc = cid::kmerset_view(ks, &kc, &codes, &counts, &nk, &kk))) return rc;
+    if (cid::kmerset_view_ascii(ks, &kc, &ascii, &counts, &nk, &kk) != CID_OK) {
+        ascii = nullptr;
+        if ((rc = cid::kmerset_view(ks, &kc, &codes, &counts, &nk, &kk))) return rc;
+    }
     if (nk == 0) return fail(CID_ERR_INVALID, "perfect search needs at least one k-mer (src/perfect_search.rs:22-23)");
     if (kk != replicas[0]->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", kk, replicas[0]->k);
     const int n = (int)g->ctx.size();
@@ -403,18 +421,20 @@ int cid_group_search_perfect_set(cid_group *g, cid_index *const *replicas, const
     rc = for_each_rank(g, [&](int r) -> int {
         cid_ctx *c = g->ctx[r];
         size_t lo, hi;
-        shard_bounds(nk, r, n, &lo, &hi);
+        if (ascii) shard_bounds64(nk, r, n, &lo, &hi); else shard_bounds(nk, r, n, &lo, &hi);
         shard_n[r] = hi - lo;
         if (hi == lo) return CID_OK;
         HIP_TRY(hipSetDevice(c->device));
-        const uint64_t *my_codes = codes + lo;
+        const size_t unit = ascii ? kk : 8;
+        const uint8_t *my_keys = ascii ? ascii + lo * unit : reinterpret_cast<const uint8_t *>(codes + lo);
         if (c->device != kc->device) {
             void *d_k;
-            const int e = cid::slot_reserve(c, S_KMERS, (hi - lo) * 8, &d_k); if (e) return e;
-            HIP_TRY(hipMemcpyPeerAsync(d_k, c->device, codes + lo, kc->device, (hi - lo) * 8, c->stream));
-            my_codes = (const uint64_t *)d_k;
+            const int e = cid::slot_reserve(c, S_KMERS, (hi - lo) * unit, &d_k); if (e) return e;
+            HIP_TRY(hipMemcpyPeerAsync(d_k, c->device, my_keys, kc->device, (hi - lo) * unit, c->stream));
+            my_keys = (const uint8_t *)d_k;
         }
-        return cid::search_perfect_codes(c, replicas[r], my_codes, hi - lo, kk, words[r].data(), &missing[r]);
+        if (ascii) return cid::search_perfect_ascii(c, replicas[r], my_keys, hi - lo, kk, words[r].data(), &missing[r]);
+        return cid::search_perfect_codes(c, replicas[r], reinterpret_cast<const uint64_t *>(my_keys), hi - lo, kk, words[r].data(), &missing[r]);
     });
     if (rc) return rc;
     return perfect_combine(g, replicas, words, missing, shard_n, and_words_le, any_row_missing);

@@ -166,8 +166,7 @@ static void generate_report_gene(const std::string &query, const Bigsi &b, const
 // COLORID_HOST_KMERS=1 forces the host map.
 
 bool gpu_counting_enabled(uint64_t k) { return k <= 128 && !getenv("COLORID_HOST_KMERS"); }
-// (a byte-string set, k > 32, cannot be sliced device-to-device over a group's ranks: with several GPUs those k-mers take the host map)
-static bool gpu_counting(const Bigsi &b) { return gpu_counting_enabled(b.k_size) && !(g_group && b.k_size > 32); }
+static bool gpu_counting(const Bigsi &b) { return gpu_counting_enabled(b.k_size); }
 
 struct SeqBatch {
     std::vector<uint8_t> bases;

@@ -170,7 +170,7 @@ int cid_readid_stripe_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_b
  *      k_size 33..128: a k-mer no longer packs into 64 bits, the keys are byte strings (case kept in mode 1, so lower-case bases
  *      are fine there): the sequences stay resident until finalize, every window's key is sorted on a 4-bit-per-base image
  *      (one stable radix pass per 16 bases) and run-length counted; the finished set is n x k_size ASCII bytes.  Such a set
- *      serves every call below except cid_kmerset_device_arrays / _order_for_index and the cid_group_*_set calls. ---- */
+ *      serves every call below (the cid_group_*_set calls included) except cid_kmerset_device_arrays / _order_for_index. ---- */
 typedef struct cid_kmerset cid_kmerset;
 int cid_kmerset_create(cid_ctx *, uint32_t k_size, cid_kmerset **out);
 int cid_kmerset_add_seqs(cid_kmerset *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode);

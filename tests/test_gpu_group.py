@@ -62,8 +62,8 @@ def test_group_search_equals_single_rank_and_oracle(orc, hip_ctx, devices, n_col
         pw, pm = oix.search_perfect(sel)
         gw, gm = g.search_perfect(sel)
         assert gm == pm and np.array_equal(gw, pw)
-    # device-resident k-mer sets (k <= 32): counted on rank 0, sliced to the ranks device-to-device
-    if k <= 32:
+    # device-resident k-mer sets (2-bit codes, or byte strings for k > 32): counted on rank 0, sliced to the ranks device-to-device
+    if True:
         seqs = [bytes(rng.choice(list(b"ACGT"), size=3000).astype(np.uint8)) for _ in range(5)] + [sub[:200].tobytes()]
         ks = colorid_amd.KmerSet(g.ctxs[0], k)
         ks.add_seqs(seqs, 0)
@@ -190,10 +190,10 @@ def test_round2_entry_points_refuse_misuse(orc, hip_ctx):
     words = np.zeros(3, np.uint32)
     miss = C.c_int(0)
     assert lib.cid_group_search_perfect(g.h, g._replica_handles, km.ctypes.data, 0, words.ctypes.data, C.byref(miss)) == -1    # no k-mers
-    ks = colorid_amd.KmerSet(g.ctxs[0], 40)                                                          # byte-string set: not sliceable over a group
+    ks = colorid_amd.KmerSet(g.ctxs[0], 40)                                                          # a byte-string set against a k = 21 index
     ks.add_seqs([bytes(rng.choice(list(b"ACGT"), size=200).astype(np.uint8))], 0)
     ks.finalize()
-    assert lib.cid_group_search_count_set(g.h, g._replica_handles, ks.h, hits.ctypes.data, None, None, None) < 0
+    assert lib.cid_group_search_count_set(g.h, g._replica_handles, ks.h, hits.ctypes.data, None, None, None) == -1 and b"k=" in lib.cid_last_error()
     with pytest.raises(colorid_amd.CidError):
         ks.order_for_index(hx)
     ks.close()
