@@ -408,6 +408,10 @@ def main():
                          "alg_bytes_per_kmer": alg_bytes_per_kmer,
                          "kernel_ms": kern_ms, "kmers_per_launch": K},
         }
+        tr = result["roofline"]["traffic"]
+        if tr:   # the PMC traffic of profiles/ at this run's kernel time: what the kernel really moves (every 32-byte row costs a 128-byte line)
+            result["roofline"]["traffic_GBs"] = tr / (kern_ms * 1e-3) / 1e9
+            result["roofline"]["traffic_frac"] = tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not a.codes and not a.no_variants:
             # for the record, not the headline: the same query with the k-mers as the 2-bit codes that GPU k-mer counting
             # produces (what `colorid search` feeds the kernel for k <= 32): 8 instead of k input bytes per k-mer
