@@ -44,6 +44,8 @@ using namespace cid::slots;
 bool kSearchPersist = getenv("CID_SEARCH_PERSIST") && atoi(getenv("CID_SEARCH_PERSIST")) != 0;
 // 32-byte rows: the last row of every k-mer through the scalar cache (cid_tune "search_mixed")
 bool kSearchMixed = getenv("CID_SEARCH_MIXED") ? atoi(getenv("CID_SEARCH_MIXED")) != 0 : false;
+// rows of 64 bytes and more: sub-passes of k_search_count whose row loads are issued together (cid_tune "search_unroll"; 2: -1.5 %)
+int kSearchUnroll = getenv("CID_SEARCH_UNROLL") ? atoi(getenv("CID_SEARCH_UNROLL")) : 2;
 // bytes per chunk of the pipelined host-pointer calls (H2D of chunk i+1 beside the kernel of chunk i)
 const size_t kUploadChunkBytes = getenv("CID_UPLOAD_CHUNK_BYTES") ? strtoull(getenv("CID_UPLOAD_CHUNK_BYTES"), nullptr, 10) : (256ull << 20);
 
@@ -171,6 +173,7 @@ int fill_search_params(const cid_ctx *c, const cid_index *ix, cid::SearchParams 
         p.wave_bytes += 8u * ix->rs;
     }
     p.mod = ix->mod;
+    p.unroll = (uint32_t)kSearchUnroll;
     if (cid::search_smem_bytes(p) > 160u * 1024u)
         return fail(CID_ERR_UNSUPPORTED, "LDS need %zu B exceeds 160 KiB (n_colors=%u k=%u n_hash=%u)",
                     cid::search_smem_bytes(p), ix->n_colors, ix->k, ix->n_hash);
@@ -1145,6 +1148,7 @@ int cid_tune(const char *name, long value) {
     if (!name) return fail(CID_ERR_INVALID, "null name");
     if (!strcmp(name, "search_persist")) { kSearchPersist = value != 0; return CID_OK; }
     if (!strcmp(name, "search_mixed")) { kSearchMixed = value != 0; return CID_OK; }
+    if (!strcmp(name, "search_unroll")) { kSearchUnroll = (int)value; return CID_OK; }
     if (!strcmp(name, "order_bits")) { if (value < 0 || value > 32) return fail(CID_ERR_INVALID, "order_bits 0..32"); cid::g_order_bits = (int)value; return CID_OK; }
     return fail(CID_ERR_INVALID, "unknown tunable '%s'", name);
 }

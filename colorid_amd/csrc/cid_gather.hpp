@@ -153,6 +153,44 @@ __device__ __forceinline__ void gather_run(const uint64_t *mat, uint32_t rs, con
     }
 }
 
+// U k-mers' rows (U x n loads per lane) issued before any is consumed, branch-free: a lane that is not `ok` reads row 0's first
+// slice (an L2 hit) and gets zeros.
+template <int NH, int U, bool NARROW>
+__device__ __forceinline__ void gather_and_multi_fixed(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, const uint32_t (&kk)[U],
+                                                       const bool (&ok)[U], uint32_t col_word, uint32_t s0, V16 (&a)[U]) {
+    V16 v[U][NH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < NH; ++s) {
+            const uint64_t row = ok[u] ? ridx[(s0 + s) * kWave + kk[u]] : 0u;
+            v[u][s] = load_slice<NARROW>(mat + row * rs + (ok[u] ? col_word : 0u));
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int s = 0; s < NH; ++s) { a[u].x &= v[u][s].x; a[u].y &= v[u][s].y; }
+}
+template <int U, bool NARROW>
+__device__ __forceinline__ void gather_and_multi(const uint64_t *mat, uint32_t rs, const uint32_t *ridx, const uint32_t (&kk)[U],
+                                                 const bool (&ok)[U], uint32_t col_word, uint32_t n, V16 (&a)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = V16{~0ull, ~0ull};
+    switch (n) {   // n is wave-uniform
+    case 1: gather_and_multi_fixed<1, U, NARROW>(mat, rs, ridx, kk, ok, col_word, 0, a); break;
+    case 2: gather_and_multi_fixed<2, U, NARROW>(mat, rs, ridx, kk, ok, col_word, 0, a); break;
+    case 3: gather_and_multi_fixed<3, U, NARROW>(mat, rs, ridx, kk, ok, col_word, 0, a); break;
+    case 4: gather_and_multi_fixed<4, U, NARROW>(mat, rs, ridx, kk, ok, col_word, 0, a); break;
+    default: {
+        uint32_t sd = 0;
+        for (; sd + 4 <= n; sd += 4) gather_and_multi_fixed<4, U, NARROW>(mat, rs, ridx, kk, ok, col_word, sd, a);
+        for (; sd < n; ++sd) gather_and_multi_fixed<1, U, NARROW>(mat, rs, ridx, kk, ok, col_word, sd, a);
+    }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (!ok[u]) a[u] = V16{0, 0};
+}
+
 // Sum over the LPR adjacent lanes that share a row (LPR is a power of two <= 64).
 template <int LOG_LPR>
 __device__ __forceinline__ uint32_t group_sum(uint32_t v) {

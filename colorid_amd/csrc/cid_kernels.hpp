@@ -43,6 +43,7 @@ struct SearchParams {
     uint32_t *queues;      // 8 work-queue heads, 32 words apart, zeroed before the launch
     int persist_grid;      // resident blocks: n_cu x blocks per CU
     uint32_t mixed;        // 32-byte rows: fetch each k-mer's last row through the scalar cache (gather_and_mixed32)
+    uint32_t unroll;       // rows of >= 64 bytes: sub-passes whose loads are issued together (1 or 2)
 };
 
 struct InsertParams {

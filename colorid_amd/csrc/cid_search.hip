@@ -48,8 +48,8 @@ __device__ __forceinline__ uint32_t stripe_fact_merge(uint32_t old, uint32_t pop
 // the waves of one XCD — which share that XCD's 4 MiB L2 — work on a window of a few ten thousand consecutive k-mers.  When the
 // producer has grouped the k-mers by the index slice of their first row (cid_kmerset_order_for_index), that window's first-row
 // lines are L2 hits.  The XCD a wave runs on is read from the hardware (HW_REG_XCC_ID), not inferred from blockIdx.
-template <int LOG_LPR, bool NARROW, bool PERSIST>
-__global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
+template <int LOG_LPR, bool NARROW, bool PERSIST, int UNROLL = 1>
+__global__ __launch_bounds__(kBlock, UNROLL == 1 ? 4 : 3) void k_search_count(SearchParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
     constexpr int KPW = kWave / LPR;  // k-mers per sub-pass
@@ -86,28 +86,8 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
         const uint32_t my_freq = (p.freq && p.want_unique && !p.fact && first + lane < p.n_kmers) ? p.freq[first + lane] : 1u;
         stage_and_hash(img, ridx, p.kmers, p.codes, p.n_kmers, first, p.k, p.n_hash, p.mod, lane);
         if (!p.fact) { s_pop[lane] = my_freq; wave_lds_fence(); }
-#pragma unroll 1
-        for (int sub = 0; sub < LPR; ++sub) {
-            const int kk = sub * KPW + (lane >> LOG_LPR);
-            const uint64_t kmer = first + kk;
-            const bool live = kmer < p.n_kmers;
-            V16 a{0, 0};
-            uint32_t zm;
-            bool mixed = false;
-            if constexpr (LOG_LPR == 1 && !NARROW) {   // 32-byte rows: the last row of every k-mer through the scalar cache
-                if (p.mixed && p.n_hash >= 2 && p.n_hash <= 4) {
-                    mixed = true;
-                    const uint32_t rlast = ridx[(p.n_hash - 1) * kWave + lane];
-                    V16 m;
-                    switch (p.n_hash) {
-                    case 2: m = gather_and_mixed32<2>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
-                    case 3: m = gather_and_mixed32<3>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
-                    default: m = gather_and_mixed32<4>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
-                    }
-                    if (live) a = m;
-                }
-            }
-            if (!mixed && live && col_live) a = gather_and<NARROW, false>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
+        // what follows a k-mer's gather: count its AND word's bits, decide uniqueness
+        auto after_gather = [&](const int kk, const bool live, V16 a) {
             if constexpr (NARROW) a.y = 0;
             const uint32_t pc = (uint32_t)(__popcll(a.x) + __popcll(a.y));
             const uint32_t total = group_sum<LOG_LPR>(pc);
@@ -133,6 +113,46 @@ __global__ __launch_bounds__(kBlock) void k_search_count(SearchParams p) {
                     s_res[kk] = 0xFFFFFFFFu;
                 }
             }
+        };
+        constexpr int U = UNROLL < LPR ? UNROLL : LPR;   // sub-passes whose row loads are issued together
+#pragma unroll 1
+        for (int sub = 0; sub < LPR; sub += U) {
+            if constexpr (U > 1) {   // rows of 64 bytes and more: a sub-pass covers only 64/LPR k-mers, so several are in flight at once
+                uint32_t kk[U];
+                bool live[U], ok[U];
+                V16 a[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    kk[u] = (uint32_t)((sub + u) * KPW + (lane >> LOG_LPR));
+                    live[u] = first + kk[u] < p.n_kmers;
+                    ok[u] = live[u] && col_live;
+                }
+                gather_and_multi<U, NARROW>(p.mat, p.rs, ridx, kk, ok, col_word, p.n_hash, a);
+#pragma unroll
+                for (int u = 0; u < U; ++u) after_gather((int)kk[u], live[u], a[u]);
+                continue;
+            }
+            const int kk = sub * KPW + (lane >> LOG_LPR);
+            const uint64_t kmer = first + kk;
+            const bool live = kmer < p.n_kmers;
+            V16 a{0, 0};
+            uint32_t zm;
+            bool mixed = false;
+            if constexpr (LOG_LPR == 1 && !NARROW) {   // 32-byte rows: the last row of every k-mer through the scalar cache
+                if (p.mixed && p.n_hash >= 2 && p.n_hash <= 4) {
+                    mixed = true;
+                    const uint32_t rlast = ridx[(p.n_hash - 1) * kWave + lane];
+                    V16 m;
+                    switch (p.n_hash) {
+                    case 2: m = gather_and_mixed32<2>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
+                    case 3: m = gather_and_mixed32<3>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
+                    default: m = gather_and_mixed32<4>(p.mat, ridx, kk, col_word, rlast, sub * KPW); break;
+                    }
+                    if (live) a = m;
+                }
+            }
+            if (!mixed && live && col_live) a = gather_and<NARROW, false>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
+            after_gather(kk, live, a);
         }
         if (p.fact || (p.want_unique && p.unique_colour)) {   // the tile's per-k-mer results, one coalesced store
             wave_lds_fence();
@@ -439,6 +459,10 @@ hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
         if (p.persist_grid < grid) grid = p.persist_grid;
         CID_LAUNCH_BY_LAYOUT2(k_search_count, log_lpr, narrow, true, grid, shmem, stream, p);
     }
+    // rows of 64 and 128 bytes (a sub-pass covers only 16 or 8 k-mers): two sub-passes' row loads in flight per lane, -1.5 %
+    // (tools/exp_unroll.py); wider rows gain nothing from it
+    if (p.unroll == 2 && !narrow && log_lpr == 2) return launch_one(k_search_count<2, false, false, 2>, grid, shmem, stream, p);
+    if (p.unroll == 2 && !narrow && log_lpr == 3) return launch_one(k_search_count<3, false, false, 2>, grid, shmem, stream, p);
     CID_LAUNCH_BY_LAYOUT2(k_search_count, log_lpr, narrow, false, grid, shmem, stream, p);
 }
 

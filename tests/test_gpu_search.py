@@ -361,3 +361,26 @@ def test_alternative_schedulings_are_bit_exact(orc, hip_ctx, tunable, n_colors, 
     for w, g in zip(want, got):
         assert np.array_equal(w, g)
     hx.close()
+
+
+@pytest.mark.parametrize("unroll", [1, 2])
+@pytest.mark.parametrize("n_colors,n_hash", [(512, 3), (320, 4), (1024, 4), (700, 2), (1000, 5)])
+def test_search_count_unroll_is_bit_exact(orc, hip_ctx, unroll, n_colors, n_hash):
+    """Rows of 64 and 128 bytes: k_search_count with one and with two sub-passes' row loads in flight (cid_tune "search_unroll";
+    2 is the default) against the oracle, ragged last tile, colours that do not fill the row (320, 700, 1000), 5 seeds."""
+    from colorid_amd._lib import check
+    rng = np.random.default_rng(n_colors * 11 + n_hash)
+    oix = random_index(orc, rng, 40_009, n_hash, 31, n_colors, density=0.25, zero_row_frac=0.05)
+    kmers = random_kmers(rng, 20_003, 31)
+    plant(oix, rng, kmers[:4000], frac=0.9)
+    freq = rng.integers(1, 20, size=len(kmers)).astype(np.uint32)
+    want = oix.search_count(kmers, freq.astype(np.uint64))
+    hx = to_hip_index(hip_ctx, oix)
+    check(hip_ctx.lib.cid_tune(b"search_unroll", unroll))
+    try:
+        got = hx.search_count(kmers, freq)
+    finally:
+        check(hip_ctx.lib.cid_tune(b"search_unroll", 2))
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    hx.close()
