@@ -24,27 +24,60 @@ __global__ __launch_bounds__(256) void gather4(const uint8_t *tab, const uint32_
     for (int s = 0; s < 4; ++s) r &= v[s].x & v[s].y & v[s].z & v[s].w;
     if (r == 0x12345678u) out[t & 1023] = r;
 }
-// the same gather + one 4-byte result per group, written as the search kernel writes its per-k-mer output
+// the same gather + one 4-byte result per group.  W = 0: nontemporal 4-byte store per lane pair (a wave writes one 128-byte line
+// per pass, as the search kernel writes its per-k-mer output); 1: the same with a plain store; 2 / 3: a wave works through 8
+// passes (256 groups), parks the results in LDS and writes 1 KiB at once, 16 bytes per lane (nontemporal / plain).
+template <int W>
 __global__ __launch_bounds__(256) void gather4w(const uint8_t *tab, const uint32_t *idx, uint64_t n_groups, uint32_t *res) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t g = t >> 1;
-    if (g >= n_groups) return;
-    const uint32_t half = t & 1;
-    uint4 v[4];
+    __shared__ uint32_t park[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t half = lane & 1;
+    if constexpr (W <= 1) {
+        const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t g = t >> 1;
+        if (g >= n_groups) return;
+        uint4 v[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) v[s] = *reinterpret_cast<const uint4 *>(tab + (uint64_t)idx[g * 4 + s] * 32 + half * 16);
-    uint32_t r = ~0u;
+        for (int s = 0; s < 4; ++s) v[s] = *reinterpret_cast<const uint4 *>(tab + (uint64_t)idx[g * 4 + s] * 32 + half * 16);
+        uint32_t r = ~0u;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) r &= v[s].x & v[s].y & v[s].z & v[s].w;
-    r &= __shfl_xor(r, 1);
-    if (!half) __builtin_nontemporal_store(r, &res[g]);
+        for (int s = 0; s < 4; ++s) r &= v[s].x & v[s].y & v[s].z & v[s].w;
+        r &= __shfl_xor(r, 1);
+        if (!half) { if constexpr (W == 0) __builtin_nontemporal_store(r, &res[g]); else res[g] = r; }
+    } else {
+        const uint64_t g0 = ((uint64_t)blockIdx.x * 4 + wave) * 256;   // this wave's 256 groups
+        if (g0 >= n_groups) return;
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t g = g0 + i * 32 + (lane >> 1);
+            uint32_t r = ~0u;
+            if (g < n_groups) {
+                uint4 v[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[s] = *reinterpret_cast<const uint4 *>(tab + (uint64_t)idx[g * 4 + s] * 32 + half * 16);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) r &= v[s].x & v[s].y & v[s].z & v[s].w;
+            }
+            r &= __shfl_xor(r, 1);
+            if (!half) park[wave][i * 32 + (lane >> 1)] = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint4 o = *reinterpret_cast<const uint4 *>(&park[wave][4 * lane]);
+        if (g0 + 4 * lane + 3 < n_groups) {
+            typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+            v4 ov = {o.x, o.y, o.z, o.w};
+            if constexpr (W == 2) __builtin_nontemporal_store(ov, reinterpret_cast<v4 *>(&res[g0 + 4 * lane]));
+            else *reinterpret_cast<v4 *>(&res[g0 + 4 * lane]) = ov;
+        }
+    }
 }
+template <int W>
 static float run_w(const uint8_t *tab, const uint32_t *idx, uint64_t n_groups, uint32_t *res) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9f;
     for (int it = 0; it < 4; ++it) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(gather4w, dim3((unsigned)((n_groups * 2 + 255) / 256)), dim3(256), 0, 0, tab, idx, n_groups, res);
+        hipLaunchKernelGGL(gather4w<W>, dim3((unsigned)(W <= 1 ? (n_groups * 2 + 255) / 256 : (n_groups + 1023) / 1024)), dim3(256), 0, 0, tab, idx, n_groups, res);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
@@ -90,10 +123,10 @@ int main(int argc, char **argv) {
         tabs.push_back(tab);
         uint32_t *res; CK(hipMalloc(&res, n_groups * 4)); ress.push_back(res);
     }
-    for (int i = 0; i < 8; i += 3)
-        for (int j = 0; j < 8; ++j) {
-            const float ms = run_w(tabs[i], idx, n_groups, ress[j]);
-            printf("gather + result write: table #%d, results in allocation #%d %p: %.3f ms\n", i, j, (void *)ress[j], ms);
+    for (int i = 0; i < 8; i += 4)
+        for (int j = 0; j < 8; j += 2) {
+            printf("gather + result write: table #%d, results in allocation #%d %p: nt 4 B %.3f ms | plain 4 B %.3f | 1 KiB nt %.3f | 1 KiB plain %.3f\n", i, j, (void *)ress[j],
+                   run_w<0>(tabs[i], idx, n_groups, ress[j]), run_w<1>(tabs[i], idx, n_groups, ress[j]), run_w<2>(tabs[i], idx, n_groups, ress[j]), run_w<3>(tabs[i], idx, n_groups, ress[j]));
         }
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
