@@ -101,6 +101,10 @@ void orc_search_index(const orc_index *, const uint8_t *kmers, uint64_t n_kmers,
 void orc_readid_counts(const orc_index *, const uint8_t *bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                        uint64_t n_reads, uint64_t d, uint64_t start_sample,
                        uint32_t *report, uint32_t *n_kmers, uint8_t *status);
+/* the same on n_threads threads (the reference's rayon pool over the batch, read_id_mt_pe.rs:300) */
+void orc_readid_counts_mt(const orc_index *, const uint8_t *bases, const uint64_t *seq_off, const uint64_t *read_seq0,
+                          uint64_t n_reads, uint64_t d, uint64_t start_sample, int n_threads,
+                          uint32_t *report, uint32_t *n_kmers, uint8_t *status);
 double orc_false_prob(double m, double k, double n);                                   /* read_id_mt_pe.rs:695-698 */
 /* read_id_mt_pe.rs:168-181 (binomial pmf via lgamma; crate `probability` is unpinned) */
 int orc_not_fp_significant(uint64_t observations, double p_false, double fp_correct, uint64_t taxon_hits);

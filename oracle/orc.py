@@ -93,6 +93,7 @@ def lib():
         "orc_search_index_classic": (None, [ip, vp, C.c_uint64, vp]),
         "orc_search_index": (None, [ip, vp, C.c_uint64, C.c_uint64, vp]),
         "orc_readid_counts": (None, [ip, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp]),
+        "orc_readid_counts_mt": (None, [ip, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, vp, vp, vp]),
         "orc_false_prob": (C.c_double, [C.c_double] * 3),
         "orc_not_fp_significant": (C.c_int, [C.c_uint64, C.c_double, C.c_double, C.c_uint64]),
         "orc_kmer_poll_plus": (C.c_int, [ip, vp, C.c_uint64, C.c_double, C.c_char_p, C.c_size_t,
@@ -356,7 +357,7 @@ class Index:
         lib().orc_search_index(self.p, _ptr(kmers), kmers.shape[0], start_sample, _ptr(rep))
         return rep
 
-    def readid_counts(self, bases, seq_off, read_seq0, d=1, start_sample=3):
+    def readid_counts(self, bases, seq_off, read_seq0, d=1, start_sample=3, n_threads=1):
         bases = np.ascontiguousarray(bases, np.uint8)
         seq_off = np.ascontiguousarray(seq_off, np.uint64)
         read_seq0 = np.ascontiguousarray(read_seq0, np.uint64)
@@ -364,8 +365,12 @@ class Index:
         rep = np.zeros((n_reads, self.n_colors + 1), np.uint32)
         nk = np.zeros(n_reads, np.uint32)
         st = np.zeros(n_reads, np.uint8)
-        lib().orc_readid_counts(self.p, _ptr(bases), _ptr(seq_off), _ptr(read_seq0), n_reads, d, start_sample,
-                                _ptr(rep), _ptr(nk), _ptr(st))
+        if n_threads > 1:   # the reference's rayon pool over the batch
+            lib().orc_readid_counts_mt(self.p, _ptr(bases), _ptr(seq_off), _ptr(read_seq0), n_reads, d, start_sample, n_threads,
+                                       _ptr(rep), _ptr(nk), _ptr(st))
+        else:
+            lib().orc_readid_counts(self.p, _ptr(bases), _ptr(seq_off), _ptr(read_seq0), n_reads, d, start_sample,
+                                    _ptr(rep), _ptr(nk), _ptr(st))
         return rep, nk, st
 
     def kmer_poll_plus(self, report, kmer_length, fp_correct=1e-3):

@@ -808,6 +808,31 @@ void orc_readid_counts(const orc_index *ix, const uint8_t *bases, const uint64_t
     free(rep);
 }
 
+/* The reference runs parallel_vec's per-read closure on a rayon pool (read_id_mt_pe.rs:300, main.rs -t): contiguous slices of the
+ * batch on n_threads pthreads; rows of the outputs are per read, so the slices write disjoint memory. */
+typedef struct { const orc_index *ix; const uint8_t *bases; const uint64_t *seq_off, *read_seq0; uint64_t n_reads, d, start_sample;
+                 uint32_t *report, *n_kmers; uint8_t *status; } readid_job;
+static void *readid_run(void *arg) {
+    readid_job *j = (readid_job *)arg;
+    orc_readid_counts(j->ix, j->bases, j->seq_off, j->read_seq0, j->n_reads, j->d, j->start_sample, j->report, j->n_kmers, j->status);
+    return NULL;
+}
+void orc_readid_counts_mt(const orc_index *ix, const uint8_t *bases, const uint64_t *seq_off, const uint64_t *read_seq0,
+                          uint64_t n_reads, uint64_t d, uint64_t start_sample, int n_threads,
+                          uint32_t *report, uint32_t *n_kmers, uint8_t *status) {
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    readid_job *jobs = (readid_job *)calloc((size_t)n_threads, sizeof(readid_job));
+    for (int t = 0; t < n_threads; ++t) {
+        const uint64_t lo = n_reads * (uint64_t)t / (uint64_t)n_threads, hi = n_reads * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        jobs[t] = (readid_job){ix, bases, seq_off, read_seq0 + lo, hi - lo, d, start_sample,
+                               report + lo * (ix->n_colors + 1), n_kmers + lo, status + lo};
+        pthread_create(&th[t], NULL, readid_run, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(jobs); free(th);
+}
+
 double orc_false_prob(double m, double k, double n) { /* read_id_mt_pe.rs:695-698 */
     return pow(1.0 - pow(M_E, -((k * (n + 0.5)) / (m - 1.0))), k);
 }

@@ -462,6 +462,10 @@ def test_readid_counts_vs_independent_python(orc, msz):
                 continue
             assert nk[i] == n_keys and list(rep[i]) == want, (i, d, S)
         assert rep[:, :C].sum() > 0 and rep[:, C].sum() > 0
+        # the rayon analogue (contiguous slices of the batch on pthreads) returns the same rows
+        for nt in (2, 7, 200):
+            rep_mt, nk_mt, st_mt = oix.readid_counts(bases, seq_off, read_seq0, d, S, n_threads=nt)
+            assert np.array_equal(rep, rep_mt) and np.array_equal(nk, nk_mt) and np.array_equal(st, st_mt)
 
 
 def _py_canon_windows(l: bytes, k: int, d: int = 1):

@@ -123,10 +123,18 @@ if "C" in only:
         t = time.perf_counter()
         want = oix.readid_counts(bases[:S * 150 * mates].cpu().numpy(), so[:S * mates + 1].cpu().numpy().astype(np.uint64), r0[:S + 1].cpu().numpy().astype(np.uint64), 1, 3)
         cpu_s = time.perf_counter() - t
+        ncore = os.cpu_count() or 1
+        S2 = min(R, 2000 * ncore)      # all host cores, the reference's rayon pool (-t): a larger sample so every thread has work
+        hb2, so2, r02 = bases[:S2 * 150 * mates].cpu().numpy(), so[:S2 * mates + 1].cpu().numpy().astype(np.uint64), r0[:S2 + 1].cpu().numpy().astype(np.uint64)
+        t = time.perf_counter()
+        want_mt = oix.readid_counts(hb2, so2, r02, 1, 3, n_threads=ncore)
+        cpu_mt_s = time.perf_counter() - t
+        mt_ok = bool(np.array_equal(want_mt[0], rep[:S2].cpu().numpy().view(np.uint32)))
         nks = int(nk.to(torch.int64).sum().item())
         out.append({"config": f"C read_id {'PE' if paired else 'SE'}, m=30M n=2 k=21 C=256, 1 M x 150 bp", "reads": R, "gpu_ms": ms, "gpu_reads_per_s": R / ms * 1e3,
                     "gpu_kmers_per_s": nks / ms * 1e3, "alg_GBs": (nks * n * rs * 8 + bases.numel() + R * (C + 1) * 4) / ms / 1e6,
                     "cpu_oracle_1thread_reads_per_s": S / cpu_s,
+                    "cpu_oracle_all_cores_reads_per_s": S2 / cpu_mt_s, "cpu_cores": ncore, "cpu_all_cores_sample_reads": S2, "bit_exact_all_cores_sample": mt_ok,
                     "bit_exact": bool(np.array_equal(want[0], rep[:S].cpu().numpy().view(np.uint32)) and np.array_equal(want[1], nk[:S].cpu().numpy().view(np.uint32)))})
         hx.close(); del oix, kk, ff, cc, reads, rep
 
