@@ -82,6 +82,16 @@ SIGNATURES = {
     "cid_group_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,
                                                 C.POINTER(C.c_uint64)]),
     "cid_group_readid_sparse_fetch": (C.c_int, [vp, vp, vp, vp]),
+    "cid_group_stripes_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
+    "cid_group_stripes_base": (C.c_int, [vp, C.POINTER(vp), vp]),
+    "cid_group_stripes_put_records": (C.c_int, [vp, C.POINTER(vp), vp, C.c_size_t]),
+    "cid_group_stripes_put_rows": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t]),
+    "cid_group_stripes_search_count": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, vp, vp, vp]),
+    "cid_group_stripes_search_count_set": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
+    "cid_group_stripes_search_perfect": (C.c_int, [vp, C.POINTER(vp), vp, C.c_size_t, vp, C.POINTER(C.c_int)]),
+    "cid_group_stripes_search_perfect_set": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.POINTER(C.c_int)]),
+    "cid_group_stripes_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,
+                                                        C.POINTER(C.c_uint64)]),
     "cid_tune": (C.c_int, [C.c_char_p, C.c_long]),
     "cid_timer_start": (C.c_int, [vp]),
     "cid_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),

@@ -334,12 +334,18 @@ int cid_index_put_rows(cid_index *ix, const uint64_t *row_ids, const uint32_t *w
     return CID_OK;
 }
 
-int cid_index_put_records(cid_index *ix, const uint8_t *records, size_t n_records) {
+}  // extern "C"
+
+// records of a file with n_colors_total colours; the index takes the colours [colour_base, colour_base + ix->n_colors) (colour_base a
+// multiple of 32: whole u32 words)
+int cid::index_put_records_slice(cid_index *ix, const uint8_t *records, size_t n_records, uint32_t n_colors_total, uint32_t colour_base) {
     if (!ix || (n_records && !records)) return fail(CID_ERR_INVALID, "null argument");
     if (ix->finalized) return fail(CID_ERR_STATE, "index already finalized");
+    if (colour_base % 32u || (uint64_t)colour_base + ix->n_colors > n_colors_total) return fail(CID_ERR_INVALID, "stripe [%u, +%u) of %u colours", colour_base, ix->n_colors, n_colors_total);
     cid_ctx *c = ix->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t rec_bytes = 24 + 4ull * ix->w32;
+    const uint32_t w32_rec = (n_colors_total + 31u) / 32u;
+    const size_t rec_bytes = 24 + 4ull * w32_rec;
     const size_t batch = (256u << 20) / rec_bytes;   // records per upload
     for (size_t r0 = 0; r0 < n_records; r0 += batch) {
         const size_t nr = n_records - r0 < batch ? n_records - r0 : batch;
@@ -350,7 +356,8 @@ int cid_index_put_records(cid_index *ix, const uint8_t *records, size_t n_record
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(d_err, 0, 4, c->stream));
         HIP_TRY(hipMemcpyAsync(d_rec, records + r0 * rec_bytes, nr * rec_bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(cid::launch_put_records(ix->mat, ix->rs, (const uint32_t *)d_rec, ix->w32, nr, ix->m, ix->n_colors, (uint32_t *)d_err, c->stream));
+        HIP_TRY(cid::launch_put_records(ix->mat, ix->rs, (const uint32_t *)d_rec, w32_rec, colour_base / 32u, ix->w32, nr, ix->m, n_colors_total,
+                                        (uint32_t *)d_err, c->stream));
         uint32_t err = 0;
         HIP_TRY(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -359,6 +366,13 @@ int cid_index_put_records(cid_index *ix, const uint8_t *records, size_t n_record
                         (err & 2) ? " bit count != n_colors" : "", (err & 4) ? " row >= bloom_size" : "", (err & 8) ? " bits beyond n_colors" : "");
     }
     return CID_OK;
+}
+
+extern "C" {
+
+int cid_index_put_records(cid_index *ix, const uint8_t *records, size_t n_records) {
+    if (!ix) return fail(CID_ERR_INVALID, "null argument");
+    return cid::index_put_records_slice(ix, records, n_records, ix->n_colors, 0);
 }
 
 int cid_index_device_matrix(cid_index *ix, void **dev_ptr, uint64_t *row_stride_words) {

@@ -7,142 +7,19 @@
 // COLORID_REDUCE=host, the 24*C bytes per rank are summed through the host.  Perfect search: AND of the ranks' W words on the
 // host (RCCL has no bitwise reduction).  read_id: no exchange; rows are concatenated in input order.
 // Host code only: every kernel launch goes through the single-GPU entry points.
-#include "../../include/colorid_hip.h"
+#include "cid_group.hpp"
 
-#include <dlfcn.h>
-#include <unistd.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <new>
-#include <thread>
-#include <vector>
-
-#include "cid_objects.hpp"
-
-namespace {
 
 using cid::fail;
 using namespace cid::slots;
+using namespace cidg;
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+#define HIP_TRY(expr) CIDG_HIP_TRY(expr)
 
-// the handful of RCCL entry points used (rccl.h: ncclResult_t = int, ncclSuccess = 0, ncclUint64 = 5, ncclSum = 0)
-struct Rccl {
-    void *lib = nullptr;
-    int (*CommInitAll)(void **, int, const int *) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    bool load() {
-        if (lib) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
-        if (!lib) return false;
-        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
-        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
-        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
-        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
-        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
-        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString;
-    }
-};
-constexpr int kNcclUint64 = 5, kNcclSum = 0;
+namespace cidg {
 
-// RCCL prints a version banner to the C stdout; a drop-in `colorid search` must print result rows only.  While an object of this
-// class lives, fd 1 is fd 2: what the wrapped call leaves in the stdout buffer (or writes directly) lands on stderr.
-class StdoutToStderr {
-  public:
-    StdoutToStderr() {
-        fflush(stdout);
-        saved_ = dup(1);
-        if (saved_ >= 0) dup2(2, 1);
-    }
-    ~StdoutToStderr() {
-        fflush(stdout);
-        if (saved_ >= 0) { dup2(saved_, 1); close(saved_); }
-    }
-  private:
-    int saved_;
-};
-
-}  // namespace
-
-struct cid_group {
-    std::vector<cid_ctx *> ctx;
-    std::vector<int> dev;
-    bool use_rccl = false;
-    Rccl rccl;
-    std::vector<void *> comms;
-    // sparse read_id results of the last cid_group_readid_count_sparse (per rank: rows and entries)
-    std::vector<uint64_t> sp_rows, sp_entries;
-};
-
-namespace {
-
-// contiguous, balanced partition (the same rule as colorid_amd/dist.py shard_bounds): sizes differ by at most one
-void shard_bounds(size_t n_units, int rank, int world, size_t *lo, size_t *hi) {
-    const size_t base = n_units / (size_t)world, rem = n_units % (size_t)world;
-    *lo = (size_t)rank * base + ((size_t)rank < rem ? (size_t)rank : rem);
-    *hi = *lo + base + ((size_t)rank < rem ? 1 : 0);
-}
-
-// the same with every boundary on a multiple of 64 units (byte-string k-mers: a shard's first k-mer must sit on a 16-byte boundary)
-void shard_bounds64(size_t n_units, int rank, int world, size_t *lo, size_t *hi) {
-    const size_t blocks = (n_units + 63) / 64;
-    shard_bounds(blocks, rank, world, lo, hi);
-    *lo *= 64; *hi *= 64;
-    if (*lo > n_units) *lo = n_units;
-    if (*hi > n_units) *hi = n_units;
-}
-
-// run fn(rank) on one host thread per rank (a cid_ctx is used by one thread at a time); returns the first failure, whose
-// message is re-recorded on the calling thread (cid_last_error is thread-local)
-template <typename F>
-int for_each_rank(cid_group *g, F &&fn) {
-    const int n = (int)g->ctx.size();
-    std::vector<int> rc(n, CID_OK);
-    std::vector<std::string> msg(n);
-    auto body = [&](int r) {
-        rc[r] = fn(r);
-        if (rc[r] != CID_OK) msg[r] = cid_last_error();
-    };
-    if (n == 1) body(0);
-    else {
-        std::vector<std::thread> th;
-        for (int r = 0; r < n; ++r) th.emplace_back(body, r);
-        for (auto &t : th) t.join();
-    }
-    for (int r = 0; r < n; ++r)
-        if (rc[r] != CID_OK) return fail(rc[r], "rank %d (device %d): %s", r, g->dev[r], msg[r].c_str());
-    return CID_OK;
-}
-
-int check_replicas(const cid_group *g, cid_index *const *replicas) {
-    if (!g || !replicas) return fail(CID_ERR_INVALID, "null group/replicas");
-    for (size_t r = 0; r < g->ctx.size(); ++r) {
-        const int rc = cid::check_ready(g->ctx[r], replicas[r]);
-        if (rc) return rc;
-        if (replicas[r]->n_colors != replicas[0]->n_colors || replicas[r]->k != replicas[0]->k || replicas[r]->m != replicas[0]->m ||
-            replicas[r]->n_hash != replicas[0]->n_hash)
-            return fail(CID_ERR_INVALID, "replica %zu differs from replica 0 in shape", r);
-    }
-    return CID_OK;
-}
-
-// sum of one u64[count] device array per rank, every rank ends with the total; enqueued on the ranks' ctx streams (RCCL) or
-// done through the host (synchronous)
-int allreduce_u64(cid_group *g, uint64_t *const *d_bufs, size_t count) {
+int allreduce_sum(cid_group *g, void *const *d_bufs, size_t count, int elem_bytes) {
     const int n = (int)g->ctx.size();
     if (n == 1 && !g->use_rccl) return CID_OK;
     if (g->use_rccl) {
@@ -150,26 +27,41 @@ int allreduce_u64(cid_group *g, uint64_t *const *d_bufs, size_t count) {
         int e = g->rccl.GroupStart();
         for (int r = 0; r < n && e == 0; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));
-            e = g->rccl.AllReduce(d_bufs[r], d_bufs[r], count, kNcclUint64, kNcclSum, g->comms[r], g->ctx[r]->stream);
+            e = g->rccl.AllReduce(d_bufs[r], d_bufs[r], count, elem_bytes == 8 ? kNcclUint64 : kNcclUint32, kNcclSum, g->comms[r], g->ctx[r]->stream);
         }
         const int e2 = g->rccl.GroupEnd();
         if (e || e2) return fail(CID_ERR_HIP, "ncclAllReduce: %s", g->rccl.GetErrorString(e ? e : e2));
         for (int r = 0; r < n; ++r) { HIP_TRY(hipSetDevice(g->dev[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
         return CID_OK;
     }
-    std::vector<uint64_t> total(count, 0), part(count);
+    const size_t bytes = count * (size_t)elem_bytes;
+    std::vector<uint8_t> total(bytes, 0), part(bytes);
     for (int r = 0; r < n; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
-        HIP_TRY(hipMemcpyAsync(part.data(), d_bufs[r], count * 8, hipMemcpyDeviceToHost, g->ctx[r]->stream));
+        HIP_TRY(hipMemcpyAsync(part.data(), d_bufs[r], bytes, hipMemcpyDeviceToHost, g->ctx[r]->stream));
         HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream));
-        for (size_t i = 0; i < count; ++i) total[i] += part[i];
+        if (elem_bytes == 8) {
+            uint64_t *t = reinterpret_cast<uint64_t *>(total.data()); const uint64_t *p = reinterpret_cast<const uint64_t *>(part.data());
+            for (size_t i = 0; i < count; ++i) t[i] += p[i];
+        } else {
+            uint32_t *t = reinterpret_cast<uint32_t *>(total.data()); const uint32_t *p = reinterpret_cast<const uint32_t *>(part.data());
+            for (size_t i = 0; i < count; ++i) t[i] += p[i];
+        }
     }
     for (int r = 0; r < n; ++r) {
         HIP_TRY(hipSetDevice(g->dev[r]));
-        HIP_TRY(hipMemcpyAsync(d_bufs[r], total.data(), count * 8, hipMemcpyHostToDevice, g->ctx[r]->stream));
+        HIP_TRY(hipMemcpyAsync(d_bufs[r], total.data(), bytes, hipMemcpyHostToDevice, g->ctx[r]->stream));
         HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream));
     }
     return CID_OK;
+}
+
+}  // namespace cidg
+
+namespace {
+
+int allreduce_u64(cid_group *g, uint64_t *const *d_bufs, size_t count) {
+    return cidg::allreduce_sum(g, reinterpret_cast<void *const *>(d_bufs), count, 8);
 }
 
 // rank 0's counters -> the caller's host arrays
@@ -450,6 +342,7 @@ int cid_group_readid_count_sparse(cid_group *g, cid_index *const *replicas, cons
     *n_entries = 0;
     if (n_reads && read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
     const int n = (int)g->ctx.size();
+    g->sp_striped = false;
     rc = for_each_rank(g, [&](int r) -> int {
         size_t lo, hi;
         shard_bounds(n_reads, r, n, &lo, &hi);
@@ -477,6 +370,7 @@ int cid_group_readid_count_sparse(cid_group *g, cid_index *const *replicas, cons
 
 int cid_group_readid_sparse_fetch(cid_group *g, uint64_t *row_start, uint32_t *colours, uint32_t *counts) {
     if (!g || !row_start) return fail(CID_ERR_INVALID, "null argument");
+    if (g->sp_striped) return cidg::stripes_sparse_fetch(g, row_start, colours, counts);
     uint64_t row = 0, ent = 0;
     row_start[0] = 0;
     for (size_t r = 0; r < g->ctx.size(); ++r) {

@@ -16,24 +16,26 @@ __global__ void k_put_rows(uint32_t *mat32, uint32_t rs, const uint64_t *row_ids
 }
 
 // The same from the file's own bytes: record i = { u64 row ; u64 n_words ; n_words x u32 ; u64 n_bits } (bincode of
-// (usize, BitVec)), rec_bytes = 24 + 4*w32, every field 4-byte aligned.  One thread per (record, word);
-// word 0's thread also checks the record.  err[0] |= 1 bad word count, 2 bad bit count, 4 row >= bloom_size, 8 bits past n_colors.
-__global__ void k_put_records(uint32_t *mat32, uint32_t rs, const uint32_t *rec32, uint32_t w32, uint64_t n_records, uint64_t bloom_size,
-                              uint32_t n_colors, uint32_t tail_mask, uint32_t *err) {
+// (usize, BitVec)), rec_bytes = 24 + 4*w32_rec, every field 4-byte aligned.  The index takes the record's
+// words [w_off, w_off + w32_take) — all of them, or its colour stripe of a wider file (cid_group_stripes_put_records).  One
+// thread per (record, taken word); word 0's thread also checks the record against the FILE's shape (w32_rec words, n_colors
+// bits).  err[0] |= 1 bad word count, 2 bad bit count, 4 row >= bloom_size, 8 bits past n_colors.
+__global__ void k_put_records(uint32_t *mat32, uint32_t rs, const uint32_t *rec32, uint32_t w32_rec, uint32_t w_off, uint32_t w32_take,
+                              uint64_t n_records, uint64_t bloom_size, uint32_t n_colors, uint32_t tail_mask, uint32_t *err) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_records * w32) return;
-    const uint64_t r = i / w32;
-    const uint32_t w = (uint32_t)(i % w32);
-    const uint32_t *rec = rec32 + r * (6ull + w32);
+    if (i >= n_records * w32_take) return;
+    const uint64_t r = i / w32_take;
+    const uint32_t w = (uint32_t)(i % w32_take);
+    const uint32_t *rec = rec32 + r * (6ull + w32_rec);
     const uint64_t row = (uint64_t)rec[0] | ((uint64_t)rec[1] << 32);
     if (w == 0) {
         const uint64_t nw = (uint64_t)rec[2] | ((uint64_t)rec[3] << 32);
-        const uint64_t nbits = (uint64_t)rec[4 + w32] | ((uint64_t)rec[5 + w32] << 32);
-        uint32_t e = (nw != w32 ? 1u : 0u) | (nbits != n_colors ? 2u : 0u) | (row >= bloom_size ? 4u : 0u) |
-                     ((rec[4 + w32 - 1] & ~tail_mask) ? 8u : 0u);
+        const uint64_t nbits = (uint64_t)rec[4 + w32_rec] | ((uint64_t)rec[5 + w32_rec] << 32);
+        uint32_t e = (nw != w32_rec ? 1u : 0u) | (nbits != n_colors ? 2u : 0u) | (row >= bloom_size ? 4u : 0u) |
+                     ((rec[4 + w32_rec - 1] & ~tail_mask) ? 8u : 0u);
         if (e) atomicOr(err, e);
     }
-    if (row < bloom_size) mat32[row * (2ull * rs) + w] = rec[4 + w];
+    if (row < bloom_size) mat32[row * (2ull * rs) + w] = rec[4 + w_off + w];
 }
 
 __global__ void k_get_rows(const uint32_t *mat32, uint32_t rs, const uint64_t *row_ids, uint32_t *words, uint32_t w32,
@@ -109,13 +111,13 @@ hipError_t launch_put_rows(uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids
     return hipGetLastError();
 }
 
-hipError_t launch_put_records(uint64_t *mat, uint32_t rs, const uint32_t *d_records, uint32_t w32, uint64_t n_records, uint64_t bloom_size,
-                              uint32_t n_colors, uint32_t *d_err, hipStream_t stream) {
-    const uint64_t n = n_records * w32;
+hipError_t launch_put_records(uint64_t *mat, uint32_t rs, const uint32_t *d_records, uint32_t w32_rec, uint32_t w_off, uint32_t w32_take,
+                              uint64_t n_records, uint64_t bloom_size, uint32_t n_colors, uint32_t *d_err, hipStream_t stream) {
+    const uint64_t n = n_records * w32_take;
     if (n == 0) return hipSuccess;
     const uint32_t tail_bits = n_colors % 32;
     hipLaunchKernelGGL(k_put_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(mat), rs, d_records,
-                       w32, n_records, bloom_size, n_colors, tail_bits ? ((1u << tail_bits) - 1u) : 0xFFFFFFFFu, d_err);
+                       w32_rec, w_off, w32_take, n_records, bloom_size, n_colors, tail_bits ? ((1u << tail_bits) - 1u) : 0xFFFFFFFFu, d_err);
     return hipGetLastError();
 }
 

@@ -127,8 +127,8 @@ int search_count_blocks_per_cu(const SearchParams &p);
 hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream);
 hipError_t launch_put_rows(uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, const uint32_t *d_words, uint32_t w32,
                            uint64_t n_rows, hipStream_t stream);
-hipError_t launch_put_records(uint64_t *mat, uint32_t rs, const uint32_t *d_records, uint32_t w32, uint64_t n_records, uint64_t bloom_size,
-                              uint32_t n_colors, uint32_t *d_err, hipStream_t stream);
+hipError_t launch_put_records(uint64_t *mat, uint32_t rs, const uint32_t *d_records, uint32_t w32_rec, uint32_t w_off, uint32_t w32_take,
+                              uint64_t n_records, uint64_t bloom_size, uint32_t n_colors, uint32_t *d_err, hipStream_t stream);
 hipError_t launch_get_rows(const uint64_t *mat, uint32_t rs, const uint64_t *d_row_ids, uint32_t *d_words, uint32_t w32,
                            uint64_t n_rows, hipStream_t stream);
 hipError_t launch_insert_kmers(const InsertParams &p, hipStream_t stream);

@@ -53,5 +53,6 @@ int search_perfect_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmer
 int search_count_host_input(cid_ctx *c, const cid_index *ix, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers, bool want_unique,
                             uint32_t *unique_colour, uint64_t **d_counters);
 int check_ready(const cid_ctx *c, const cid_index *ix);
+int index_put_records_slice(cid_index *ix, const uint8_t *records, size_t n_records, uint32_t n_colors_total, uint32_t colour_base);
 int check_not_mini(const cid_index *ix);
 }  // namespace cid

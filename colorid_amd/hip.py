@@ -370,6 +370,10 @@ class Group:
         check(self.lib.cid_group_readid_sparse_fetch(self.h, _p(rs), _p(col), _p(cnt)))
         return rs, col, cnt, nk, st
 
+    def stripes(self, m, n_hash, k, n_colors_total, hash_variant=0):
+        """A colour-striped index over the ranks (cid_group_stripes_*): rank r holds colours [base[r], base[r+1])."""
+        return GroupStripes(self, m, n_hash, k, n_colors_total, hash_variant)
+
     def close(self):
         if getattr(self, "h", None):
             if self._replica_handles is not None:
@@ -378,6 +382,8 @@ class Group:
                     if h and h != self._src.h.value:
                         self.lib.cid_index_destroy(vp(h))
                 self._replica_handles = None
+            for st in list(getattr(self, "_stripes", [])):
+                st.close()
             for c in self.ctxs:
                 c.close()          # closes the indices / k-mer sets made from the ranks' contexts
             self.lib.cid_group_destroy(self.h)
@@ -385,3 +391,87 @@ class Group:
 
     def __del__(self):
         self.close()
+
+
+class GroupStripes:
+    """One index cut into colour stripes, one per rank of a Group.  Outputs cover all colours."""
+
+    def __init__(self, group, m, n_hash, k, n_colors_total, hash_variant=0):
+        self.g, self.lib = group, group.lib
+        self.m, self.n_hash, self.k, self.n_colors = m, n_hash, k, n_colors_total
+        self.w32 = (n_colors_total + 31) // 32
+        self.arr = (vp * group.n)()
+        check(self.lib.cid_group_stripes_create(group.h, m, n_hash, k, n_colors_total, hash_variant, self.arr))
+        base = np.zeros(group.n + 1, np.uint32)
+        check(self.lib.cid_group_stripes_base(group.h, self.arr, _p(base)))
+        self.base = base
+        if not hasattr(group, "_stripes"):
+            group._stripes = []
+        group._stripes.append(self)
+
+    def put_rows(self, row_ids, words):
+        row_ids = np.ascontiguousarray(row_ids, np.uint64)
+        words = np.ascontiguousarray(words, np.uint32).reshape(len(row_ids), self.w32)
+        check(self.lib.cid_group_stripes_put_rows(self.g.h, self.arr, _p(row_ids), _p(words), len(row_ids)))
+
+    def put_records(self, records, n_records):
+        buf = np.frombuffer(records, np.uint8)
+        check(self.lib.cid_group_stripes_put_records(self.g.h, self.arr, _p(buf), n_records))
+
+    def finalize(self):
+        for r in range(self.g.n):
+            check(self.lib.cid_index_finalize(vp(self.arr[r])))
+        return self
+
+    def search_count(self, kmers, freq=None):
+        kmers = np.ascontiguousarray(kmers, np.uint8).reshape(-1, self.k)
+        K = kmers.shape[0]
+        f = None if freq is None else np.ascontiguousarray(freq, np.uint32)
+        hits, nu, sf = (np.zeros(self.n_colors, np.uint64) for _ in range(3))
+        uc = np.zeros(K, np.uint32)
+        check(self.lib.cid_group_stripes_search_count(self.g.h, self.arr, _p(kmers), _p(f), K, _p(hits), _p(nu), _p(sf), _p(uc)))
+        return hits, nu, sf, uc
+
+    def search_count_set(self, kmerset):
+        hits, nu, sf = (np.zeros(self.n_colors, np.uint64) for _ in range(3))
+        uc = np.zeros(len(kmerset), np.uint32)
+        check(self.lib.cid_group_stripes_search_count_set(self.g.h, self.arr, kmerset.h, _p(hits), _p(nu), _p(sf), _p(uc)))
+        return hits, nu, sf, uc
+
+    def search_perfect(self, kmers):
+        kmers = np.ascontiguousarray(kmers, np.uint8).reshape(-1, self.k)
+        words = np.zeros(self.w32, np.uint32)
+        missing = C.c_int(0)
+        check(self.lib.cid_group_stripes_search_perfect(self.g.h, self.arr, _p(kmers), kmers.shape[0], _p(words), C.byref(missing)))
+        return words, bool(missing.value)
+
+    def search_perfect_set(self, kmerset):
+        words = np.zeros(self.w32, np.uint32)
+        missing = C.c_int(0)
+        check(self.lib.cid_group_stripes_search_perfect_set(self.g.h, self.arr, kmerset.h, _p(words), C.byref(missing)))
+        return words, bool(missing.value)
+
+    def readid_count_sparse(self, bases, seq_off, read_seq0, d=1, start_sample=3):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        read_seq0 = np.ascontiguousarray(read_seq0, np.uint64)
+        n_reads = len(read_seq0) - 1
+        nk = np.zeros(n_reads, np.uint32)
+        st = np.zeros(n_reads, np.uint8)
+        ne = C.c_uint64(0)
+        check(self.lib.cid_group_stripes_readid_count_sparse(self.g.h, self.arr, _p(bases), _p(seq_off), len(seq_off) - 1, _p(read_seq0), n_reads,
+                                                             d, start_sample, _p(nk), _p(st), C.byref(ne)))
+        rs = np.zeros(n_reads + 1, np.uint64)
+        col = np.zeros(ne.value, np.uint32)
+        cnt = np.zeros(ne.value, np.uint32)
+        check(self.lib.cid_group_readid_sparse_fetch(self.g.h, _p(rs), _p(col), _p(cnt)))
+        return rs, col, cnt, nk, st
+
+    def close(self):
+        if getattr(self, "arr", None) is not None:
+            for r in range(self.g.n):
+                if self.arr[r]:
+                    self.lib.cid_index_destroy(vp(self.arr[r]))
+            self.arr = None
+            if self in getattr(self.g, "_stripes", []):
+                self.g._stripes.remove(self)

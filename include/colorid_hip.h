@@ -275,10 +275,38 @@ int cid_group_readid_count_sparse(cid_group *, cid_index *const *replicas, const
                                   uint8_t *status, uint64_t *n_entries);
 int cid_group_readid_sparse_fetch(cid_group *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
 
+/* ---- colour stripes over a group (BASELINE configs[4]): rank r holds the colours [base_r, base_{r+1}) of EVERY row —
+ *      an index larger than one GPU's HBM.  Every rank sees every query k-mer / read; per call ONE exchange: the packed per-k-mer
+ *      facts summed (RCCL all-reduce, 4 bytes per k-mer), the perfect search's / read_id's zero-row masks ANDed (peer copies).
+ *      `stripes` = n_ranks handles, stripes[r] made from rank r's ctx; all but the last hold whole 64-colour words.
+ *   create: balanced runs of 64-colour words (CID_ERR_INVALID when there are fewer words than ranks); fill with _put_records (the
+ *      records of the whole .bxi: every rank keeps its own words) or _put_rows, then cid_index_finalize each stripe; destroy each
+ *      with cid_index_destroy.  The call families mirror cid_group_search_* / cid_group_readid_*; outputs have n_colors_total
+ *      entries (W32_total words), the sparse report's colours are global (no-hits entry = n_colors_total, last in its read).
+ *      read_id handles reads that fit a wave's LDS and stripes of <= 8192 colours (CID_ERR_UNSUPPORTED otherwise). ---- */
+int cid_group_stripes_create(cid_group *, uint64_t bloom_size, uint32_t num_hash, uint32_t k_size, uint32_t n_colors_total, int hash_variant,
+                             cid_index **stripes /* n_ranks */);
+int cid_group_stripes_base(const cid_group *, cid_index *const *stripes, uint32_t *colour_base /* n_ranks + 1 */);
+int cid_group_stripes_put_records(cid_group *, cid_index *const *stripes, const uint8_t *records, size_t n_records);
+int cid_group_stripes_put_rows(cid_group *, cid_index *const *stripes, const uint64_t *row_ids, const uint32_t *words_le /* n_rows x W32_total */,
+                               size_t n_rows);
+int cid_group_stripes_search_count(cid_group *, cid_index *const *stripes, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
+                                   uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int cid_group_stripes_search_count_set(cid_group *, cid_index *const *stripes, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
+                                       uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int cid_group_stripes_search_perfect(cid_group *, cid_index *const *stripes, const uint8_t *kmers, size_t n_kmers, uint32_t *and_words_le,
+                                     int *any_row_missing);
+int cid_group_stripes_search_perfect_set(cid_group *, cid_index *const *stripes, const cid_kmerset *, uint32_t *and_words_le, int *any_row_missing);
+/* fetch the lists with cid_group_readid_sparse_fetch */
+int cid_group_stripes_readid_count_sparse(cid_group *, cid_index *const *stripes, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                                          const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                                          uint32_t *n_kmers, uint8_t *status, uint64_t *n_entries);
+
 /* ---- measurement helpers (bench only): HIP-event timing on the ctx stream ---- */
 /* process-wide tunables for A/B measurements (tools/, bench.py); unknown names give CID_ERR_INVALID:
  *   "search_persist"  0/1  k_search_count as a persistent grid with one work queue per XCD
  *   "search_mixed"    0/1  k_search_count on 32-byte rows: each k-mer's last row through the scalar cache (64-byte lines)
+ *   "search_unroll"   1/2  k_search_count on 64- and 128-byte rows: sub-passes whose row loads are issued together (default 2)
  *   "order_bits"      0..32  cid_kmerset_order_for_index groups by this many leading bits of the first row's position
  *                     (0 = by its exact 128-byte line) */
 int cid_tune(const char *name, long value);

@@ -1,0 +1,141 @@
+"""Colour stripes over the ranks of a cid_group (cid_group_stripes_*): rank r holds the colours [base_r, base_{r+1})
+of every row, every rank sees the whole query, one exchange per call (packed per-k-mer facts summed; zero-row masks ANDed).  The
+results must equal the oracle's on the unsplit index — proportional search (host k-mers and device-resident sets), perfect search,
+read_id — for 1..4 ranks sharing the one GPU (peer copies + add / AND kernels; RCCL would refuse repeated device ids), stripes
+narrower and wider than 8192 colours, colour counts that do not fill the last word, and a .bxi's own records as the input."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from test_gpu_readid import pack_reads, sample_reads
+from util import plant, random_index, random_kmers
+
+pytestmark = pytest.mark.gpu
+
+
+def _striped(g, oix, via_records=False):
+    st = g.stripes(oix.m, oix.n_hash, oix.k, oix.n_colors)
+    rows = oix.rows()                                  # dense m x W32; the file / put_rows carry the non-zero rows only
+    w32 = (oix.n_colors + 31) // 32
+    ids = np.nonzero(rows.any(axis=1))[0].astype(np.uint64)
+    words = np.ascontiguousarray(rows[ids.astype(np.int64)], np.uint32)
+    if via_records:   # bincode (usize, BitVec<u32>) records as a .bxi holds them
+        rec = b"".join(struct.pack("<QQ", int(i), w32) + w.astype("<u4").tobytes() + struct.pack("<Q", oix.n_colors) for i, w in zip(ids, words))
+        st.put_records(rec, len(ids))
+    else:
+        st.put_rows(ids, words)
+    return st.finalize()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0], [0, 0, 0, 0]])
+@pytest.mark.parametrize("n_colors,k,via_records", [(512, 31, False), (300, 27, True), (1100, 21, False), (20000, 31, True), (256, 40, False)])
+def test_striped_group_search_equals_oracle(orc, devices, n_colors, k, via_records):
+    import colorid_amd
+    if (n_colors + 63) // 64 < len(devices):
+        pytest.skip("fewer 64-colour words than ranks")
+    rng = np.random.default_rng(n_colors * 3 + len(devices))
+    m = 30_011 if n_colors < 2000 else 3001
+    oix = random_index(orc, rng, m, 3, k, n_colors, density=0.12 if n_colors < 2000 else 0.004, zero_row_frac=0.05)
+    kmers = random_kmers(rng, 9001, k)
+    plant(oix, rng, kmers, frac=0.7)
+    freq = rng.integers(1, 30, size=len(kmers)).astype(np.uint32)
+    want = oix.search_count(kmers, freq.astype(np.uint64))
+    g = colorid_amd.Group(devices)
+    st = _striped(g, oix, via_records)
+    assert st.base[0] == 0 and st.base[-1] == n_colors and all(b % 64 == 0 for b in st.base[:-1])
+    got = st.search_count(kmers, freq)
+    for w, x in zip(want, got):
+        assert np.array_equal(w, x)
+    for nk in (1, 0):
+        w = oix.search_count(kmers[:nk], freq[:nk].astype(np.uint64))
+        x = st.search_count(kmers[:nk], freq[:nk])
+        assert all(np.array_equal(a, b) for a, b in zip(w, x))
+    g.close()
+    # perfect search: a subset planted in the first and the last colour (two different stripes), then sets with an absent row
+    sub = kmers[:500].copy()
+    for km in sub:
+        oix.insert(0, km.tobytes())
+        oix.insert(n_colors - 1, km.tobytes())
+    g = colorid_amd.Group(devices)
+    st = _striped(g, oix, via_records)
+    hit = False
+    for sel in (sub, kmers[:3000], kmers[:1]):
+        pw, pm = oix.search_perfect(sel)
+        gw, gm = st.search_perfect(sel)
+        assert gm == pm and np.array_equal(gw, pw)
+        hit = hit or (not pm and pw.any())
+    assert hit
+    # device-resident k-mer set on rank 0 (2-bit codes; byte strings for k > 32)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=2500).astype(np.uint8)) for _ in range(4)] + [sub[:200].tobytes()]
+    ks = colorid_amd.KmerSet(g.ctxs[0], k)
+    ks.add_seqs(seqs, 0)
+    ks.finalize()
+    km, cnt = ks.download()
+    w = oix.search_count(km, cnt.astype(np.uint64))
+    x = st.search_count_set(ks)
+    assert all(np.array_equal(a, b) for a, b in zip(w, x))
+    pw, pm = oix.search_perfect(km)
+    gw, gm = st.search_perfect_set(ks)
+    assert gm == pm and np.array_equal(gw, pw)
+    g.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("n_colors", [384, 200])
+def test_striped_group_readid_equals_oracle(orc, devices, n_colors):
+    import colorid_amd
+    rng = np.random.default_rng(n_colors + len(devices))
+    k, m = 21, 60_013
+    genomes = [bytes(rng.choice(list(b"ACGT"), size=6000).astype(np.uint8)) for _ in range(12)]
+    oix = orc.Index(m, 2, k, n_colors)
+    for c in range(n_colors):
+        oix.set_color(c, f"acc{c}", 1000)
+    kms = orc.Kmers(k)
+    for gi, gen in enumerate(genomes):
+        kms = orc.Kmers(k)
+        kms.kmerize_vector(gen, 1)
+        for key in kms.keys():
+            for c in (gi, gi + 100, n_colors - 1 - gi):     # colours in different stripes share k-mers
+                oix.insert(c, key.tobytes())
+    g = colorid_amd.Group(devices)
+    st = _striped(g, oix)
+    for paired, n_reads in ((True, 301), (False, 200), (False, 0)):
+        reads = sample_reads(orc, rng, genomes, n_reads, 150, paired) if n_reads else []
+        bases, seq_off, read_seq0 = pack_reads(reads)
+        for d, S in ((1, 3), (1, 0), (7, 2)):
+            want = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+            rs, col, cnt, nk, stt = st.readid_count_sparse(bases, seq_off, read_seq0, d, S)
+            assert np.array_equal(nk, want[1]) and np.array_equal(stt, want[2])
+            rows, cols = np.nonzero(want[0])
+            assert np.array_equal(rs, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=len(want[0])))]).astype(np.uint64))
+            assert np.array_equal(col, cols.astype(np.uint32)) and np.array_equal(cnt, want[0][rows, cols])
+            if n_reads:
+                assert (cols == n_colors).any() and (cols < n_colors).any()      # no-hits entries and real colours both occur
+    g.close()
+
+
+def test_striped_group_refuses_misuse(orc):
+    import ctypes as C
+
+    import colorid_amd
+    from colorid_amd._lib import vp
+    g = colorid_amd.Group([0, 0, 0])
+    arr = (vp * 3)()
+    assert g.lib.cid_group_stripes_create(g.h, 1000, 2, 21, 128, 0, arr) == -1 and b"fewer than the 3 ranks" in g.lib.cid_last_error()
+    st = g.stripes(1000, 2, 21, 640)
+    hits = np.zeros(640, np.uint64)
+    km = np.frombuffer(b"A" * 21, np.uint8)
+    rc = g.lib.cid_group_stripes_search_count(g.h, st.arr, km.ctypes.data_as(vp), None, 1, hits.ctypes.data_as(vp), None, None, None)
+    assert rc < 0 and b"not finalized" in g.lib.cid_last_error()
+    st.finalize()
+    words = np.zeros(20, np.uint32)
+    miss = C.c_int(0)
+    assert g.lib.cid_group_stripes_search_perfect(g.h, st.arr, km.ctypes.data_as(vp), 0, words.ctypes.data_as(vp), C.byref(miss)) == -1
+    # a malformed record (word count of another file) is reported, not written
+    rec = struct.pack("<QQ", 5, 3) + b"\0" * 12 + struct.pack("<Q", 96)
+    st2 = g.stripes(1000, 2, 21, 640)
+    buf = np.frombuffer(rec, np.uint8)
+    assert g.lib.cid_group_stripes_put_records(g.h, st2.arr, buf.ctypes.data_as(vp), 1) < 0 and b"malformed" in g.lib.cid_last_error()
+    g.close()
