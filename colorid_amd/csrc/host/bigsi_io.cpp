@@ -68,7 +68,7 @@ void w64(FILE *f, uint64_t v) { fwrite(&v, 8, 1, f); }
 
 }  // namespace
 
-Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only) {
+Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only, cid_group *group, std::vector<cid_index *> *stripes) {
     BufReader r(path);
     Bigsi b;
     b.bloom_size = r.u64();
@@ -87,7 +87,13 @@ Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool m
     }
     const uint32_t w32 = (uint32_t)((nc + 31) / 32);
     const uint64_t n_rows = r.u64();
-    if (!meta_only) {
+    if (!meta_only && stripes) {   // one colour stripe per rank of the group (an index larger than one GPU's HBM)
+        if (mini) die("Error: an index with minimizers (.mxi) cannot be striped over GPUs");
+        int n_ranks = 0;
+        CID_TRY(cid_group_size(group, &n_ranks));
+        stripes->assign((size_t)n_ranks, nullptr);
+        CID_TRY(cid_group_stripes_create(group, b.bloom_size, (uint32_t)b.num_hash, (uint32_t)b.k_size, (uint32_t)nc, hash_variant, stripes->data()));
+    } else if (!meta_only) {
         CID_TRY(cid_index_create(ctx, b.bloom_size, (uint32_t)b.num_hash, (uint32_t)b.k_size, (uint32_t)nc, hash_variant, &b.index));
         if (mini) CID_TRY(cid_index_set_minimizer(b.index, (uint32_t)b.m_size));
     }
@@ -126,7 +132,8 @@ Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool m
         int cur = 0;
         while (have[cur]) {
             std::thread prefetch([&, cur] { fill(cur ^ 1); });
-            const int rc = cid_index_put_records(b.index, bufs[cur].data(), have[cur]);
+            const int rc = stripes ? cid_group_stripes_put_records(group, stripes->data(), bufs[cur].data(), have[cur])
+                                   : cid_index_put_records(b.index, bufs[cur].data(), have[cur]);
             prefetch.join();
             if (rc != CID_OK) die("can't deserialize: %s", cid_last_error());
             cur ^= 1;
@@ -142,7 +149,9 @@ Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool m
         auto it = by_name.find(name);
         if (it != by_name.end()) b.n_ref_kmers[it->second] = v;
     }
-    if (!meta_only) CID_TRY(cid_index_finalize(b.index));
+    if (!meta_only && stripes) {
+        for (cid_index *ix : *stripes) CID_TRY(cid_index_finalize(ix));
+    } else if (!meta_only) CID_TRY(cid_index_finalize(b.index));
     return b;
 }
 

@@ -73,7 +73,9 @@ struct Bigsi {  // BigsyMapNew minus the map, which lives on the device
     std::vector<uint64_t> n_ref_kmers;      // by colour id
     cid_index *index = nullptr;
 };
-Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only = false);  // bigsi.rs:59-69
+// stripes != nullptr: the index goes to the ranks of `group` as colour stripes (cid_group_stripes_*) instead of to one GPU; b.index stays null
+Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only = false, cid_group *group = nullptr,
+                 std::vector<cid_index *> *stripes = nullptr);  // bigsi.rs:59-69
 void save_bigsi(const std::string &path, const Bigsi &b);                                           // bigsi.rs:51-57
 Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
                    int64_t cutoff, int hash_variant, uint64_t m_size = 0);   // build.rs:15-130; m_size > 0: build_single_mini :396-492
@@ -94,6 +96,7 @@ void read_counts_five_fields(const std::string &reads_file, const std::string &p
 // ---------------------------------------------------------------- several GPUs (--gpus N / --devices a,b,..)
 // When set, the drivers below shard every query over the group's ranks (cid_group_*); results are identical.
 void set_group(cid_group *group, const std::vector<cid_index *> &replicas);
+void set_stripes(cid_group *group, const std::vector<cid_index *> &stripes);   // the same calls over a colour-striped index
 
 // ---------------------------------------------------------------- drivers (same names as the reference modules)
 namespace perfect_search {

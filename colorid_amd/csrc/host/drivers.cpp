@@ -32,22 +32,28 @@ static double g_ms_gpu = 0, g_ms_poll = 0;
 
 // ---------------------------------------------------------------------------------------------- several GPUs
 static cid_group *g_group = nullptr;
-static std::vector<cid_index *> g_replicas;
-void set_group(cid_group *group, const std::vector<cid_index *> &replicas) { g_group = group; g_replicas = replicas; }
+static std::vector<cid_index *> g_replicas;   // one handle per rank: replicas of the index, or (g_striped) its colour stripes
+static bool g_striped = false;
+void set_group(cid_group *group, const std::vector<cid_index *> &replicas) { g_group = group; g_replicas = replicas; g_striped = false; }
+void set_stripes(cid_group *group, const std::vector<cid_index *> &stripes) { g_group = group; g_replicas = stripes; g_striped = true; }
 
-// the five hot calls, on one GPU or sharded over the group
+// the hot-path calls: one GPU, a group with replicas (query sharded), or a group with colour stripes (index sharded)
 static int hot_search_count(cid_ctx *ctx, const Bigsi &b, const uint8_t *kmers, const uint32_t *freq, size_t n, uint64_t *hits, uint64_t *nu,
                             uint64_t *sf, uint32_t *uc) {
+    if (g_striped) return cid_group_stripes_search_count(g_group, g_replicas.data(), kmers, freq, n, hits, nu, sf, uc);
     return g_group ? cid_group_search_count(g_group, g_replicas.data(), kmers, freq, n, hits, nu, sf, uc)
                    : cid_search_count(ctx, b.index, kmers, freq, n, hits, nu, sf, uc);
 }
 static int hot_search_count_set(cid_ctx *ctx, const Bigsi &b, const cid_kmerset *ks, uint64_t *hits, uint64_t *nu, uint64_t *sf, uint32_t *uc) {
+    if (g_striped) return cid_group_stripes_search_count_set(g_group, g_replicas.data(), ks, hits, nu, sf, uc);
     return g_group ? cid_group_search_count_set(g_group, g_replicas.data(), ks, hits, nu, sf, uc) : cid_search_count_set(ctx, b.index, ks, hits, nu, sf, uc);
 }
 static int hot_search_perfect(cid_ctx *ctx, const Bigsi &b, const uint8_t *kmers, size_t n, uint32_t *words, int *missing) {
+    if (g_striped) return cid_group_stripes_search_perfect(g_group, g_replicas.data(), kmers, n, words, missing);
     return g_group ? cid_group_search_perfect(g_group, g_replicas.data(), kmers, n, words, missing) : cid_search_perfect(ctx, b.index, kmers, n, words, missing);
 }
 static int hot_search_perfect_set(cid_ctx *ctx, const Bigsi &b, const cid_kmerset *ks, uint32_t *words, int *missing) {
+    if (g_striped) return cid_group_stripes_search_perfect_set(g_group, g_replicas.data(), ks, words, missing);
     return g_group ? cid_group_search_perfect_set(g_group, g_replicas.data(), ks, words, missing) : cid_search_perfect_set(ctx, b.index, ks, words, missing);
 }
 
@@ -408,7 +414,10 @@ size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, dou
     std::vector<uint32_t> nk(n);
     std::vector<uint8_t> status(n);
     uint64_t n_entries = 0;
-    if (g_group)
+    if (g_striped)
+        CID_TRY(cid_group_stripes_readid_count_sparse(g_group, g_replicas.data(), rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1,
+                                                      rb.read_seq0.data(), n, (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
+    else if (g_group)
         CID_TRY(cid_group_readid_count_sparse(g_group, g_replicas.data(), rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1,
                                               rb.read_seq0.data(), n, (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
     else

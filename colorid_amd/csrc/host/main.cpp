@@ -66,10 +66,13 @@ bool ends_with(const std::string &s, const char *suf) {
 // --gpus N (devices 0..N-1) or --devices a,b,... (an id may repeat: several ranks on one GPU): reads / k-mers are sharded over
 // the ranks, the index is replicated, per-accession counters are all-reduced (RCCL over xGMI).  The reference's -t (rayon threads,
 // src/main.rs:718-721) has no meaning here and is ignored with a note.
+// --placement striped (with --gpus / --devices): the INDEX is sharded instead — rank r holds a stripe of colours of every row, every
+// rank sees the whole query (an index larger than one GPU's HBM).
 struct Gpus {
     cid_group *group = nullptr;            // nullptr: one GPU (--device)
     cid_ctx *ctx = nullptr;                // rank 0's context (or the only one)
-    std::vector<cid_index *> replicas;
+    std::vector<cid_index *> replicas;     // replicas, or the stripes
+    bool striped = false;
 };
 
 std::vector<int> device_list(const Args &a) {
@@ -100,8 +103,14 @@ Gpus make_gpus(const Args &a) {
     if (a.has("threads"))
         fprintf(stderr, "note: -t %s is ignored: the search runs on the GPU (--gpus N shards the query over N GPUs)\n", a.one("threads").c_str());
     const std::vector<int> ids = device_list(a);
-    const bool one_rank_group = ids.size() == 1 && getenv("COLORID_REDUCE");   // exercises the group / RCCL path with a single rank
+    if (a.has("placement")) {
+        const std::string &pl = a.one("placement");
+        if (pl == "striped") g.striped = true;
+        else if (pl != "replicated") die("--placement expects replicated or striped, got '%s'", pl.c_str());
+    }
+    const bool one_rank_group = ids.size() == 1 && (getenv("COLORID_REDUCE") || g.striped);   // the group path with a single rank
     if (ids.size() <= 1 && !one_rank_group) {
+        if (g.striped) die("--placement striped needs --gpus N or --devices a,b,...");
         const int dev = ids.empty() ? num_or<int>(a, "device", 0) : ids[0];
         if (cid_ctx_create(dev, &g.ctx) != CID_OK) die("cannot open GPU %d: %s (colorid has no CPU search path)", dev, cid_last_error());
         return g;
@@ -110,12 +119,17 @@ Gpus make_gpus(const Args &a) {
     if (cid_group_ctx(g.group, 0, &g.ctx) != CID_OK) die("%s", cid_last_error());
     int rccl = 0;
     cid_group_uses_rccl(g.group, &rccl);
-    fprintf(stderr, "%zu ranks; per-accession counters are reduced %s\n", ids.size(), rccl ? "with RCCL all-reduce" : "through the host");
+    if (g.striped)
+        fprintf(stderr, "%zu ranks, one colour stripe of the index each; per-k-mer facts are summed %s\n", ids.size(),
+                rccl ? "with RCCL all-reduce" : "with peer copies");
+    else
+        fprintf(stderr, "%zu ranks; per-accession counters are reduced %s\n", ids.size(), rccl ? "with RCCL all-reduce" : "through the host");
     return g;
 }
 
 void replicate(Gpus &g, Bigsi &b) {   // after the index is loaded on rank 0
     if (!g.group) return;
+    if (g.striped) { set_stripes(g.group, g.replicas); return; }   // load_index put the stripes in place
     int n = 0;
     cid_group_size(g.group, &n);
     g.replicas.assign((size_t)n, nullptr);
@@ -126,7 +140,7 @@ void replicate(Gpus &g, Bigsi &b) {   // after the index is loaded on rank 0
 void release(Gpus &g, Bigsi &b) {
     for (cid_index *ix : g.replicas)
         if (ix && ix != b.index) cid_index_destroy(ix);
-    cid_index_destroy(b.index);
+    if (b.index) cid_index_destroy(b.index);
     if (g.group) cid_group_destroy(g.group);   // owns the contexts
     else cid_ctx_destroy(g.ctx);
 }
@@ -149,7 +163,7 @@ int hash_variant(const Args &a) {
     die("unknown --hash '%s' (available: xxh3_v08, xxh3_v07)", a.one("hash").c_str());
 }
 
-Bigsi load_index(cid_ctx *ctx, const Args &a, bool meta_only = false) {
+Bigsi load_index(cid_ctx *ctx, const Args &a, bool meta_only = false, Gpus *gpus = nullptr) {
     const auto t0 = std::chrono::steady_clock::now();
     fprintf(stderr, "Loading index\n");
     // The file format carries no hash id and the reference's hash crate (xxh3 ^0.1.1) cannot be run here: an index written by
@@ -157,13 +171,15 @@ Bigsi load_index(cid_ctx *ctx, const Args &a, bool meta_only = false) {
     if (!meta_only && !a.has("hash") && !getenv("COLORID_QUIET"))
         fprintf(stderr, "note: --hash defaults to xxh3_v08 (published XXH3); parity with an index built by the Rust colorid is unverified — "
                         "run `colorid hashcheck -b <index> -r <ref_file>` once to find the variant it was built with\n");
-    Bigsi b = read_bigsi(ctx, a.one("bigsi"), hash_variant(a), meta_only);
+    const bool striped = gpus && gpus->striped;
+    Bigsi b = read_bigsi(ctx, a.one("bigsi"), hash_variant(a), meta_only, striped ? gpus->group : nullptr, striped ? &gpus->replicas : nullptr);
     fprintf(stderr, "Index loaded in %ld seconds\n",
             (long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count());
     return b;
 }
 
-const std::vector<OptSpec> kCommon = {{0, "device", true, false}, {0, "hash", true, false}, {0, "gpus", true, false}, {0, "devices", true, false}};
+const std::vector<OptSpec> kCommon = {{0, "device", true, false}, {0, "hash", true, false}, {0, "gpus", true, false}, {0, "devices", true, false},
+                                      {0, "placement", true, false}};
 
 std::vector<OptSpec> with_common(std::vector<OptSpec> v) {
     v.insert(v.end(), kCommon.begin(), kCommon.end());
@@ -217,7 +233,7 @@ int cmd_search(int argc, char **argv) {
     }
     Gpus gpus = make_gpus(a);
     cid_ctx *ctx = gpus.ctx;
-    Bigsi b = load_index(ctx, a);
+    Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
     if (a.flags.count("perfect_search")) {
         if (a.flags.count("multi_fasta")) perfect_search::batch_search_mf(ctx, files1, b);
@@ -263,7 +279,7 @@ int cmd_read_id(int argc, char **argv) {
     if (down_sample == 0 || batch == 0) die("attempt to calculate the remainder with a divisor of zero");
     Gpus gpus = make_gpus(a);
     cid_ctx *ctx = gpus.ctx;
-    Bigsi b = load_index(ctx, a);
+    Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
     if (ends_with(fq[0], ".gz")) {
         if (fq.size() > 1) read_id_mt_pe::per_read_stream_pe(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);

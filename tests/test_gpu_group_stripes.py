@@ -139,3 +139,62 @@ def test_striped_group_refuses_misuse(orc):
     buf = np.frombuffer(rec, np.uint8)
     assert g.lib.cid_group_stripes_put_records(g.h, st2.arr, buf.ctypes.data_as(vp), 1) < 0 and b"malformed" in g.lib.cid_last_error()
     g.close()
+
+
+def test_cli_placement_striped_equals_single_gpu(orc, tmp_path):
+    """`colorid search|read_id --devices 0,0[,0] --placement striped` (the .bxi loaded as colour stripes, one per rank) prints what
+    `--device 0` prints: 200 synthetic accessions (4 words of 64 colours), proportional / gene / perfect searches and read_id."""
+    import subprocess
+
+    from test_gpu_cli import BANNER, BIN
+    from util import synth_fastq_records, write_fastq_gz
+
+    def cli(*args):
+        p = subprocess.run([BIN, *args], capture_output=True, text=True, env=dict(os.environ, COLORID_QUIET="1"))
+        assert p.returncode == 0, p.stderr[-3000:]
+        assert p.stdout.startswith(BANNER)
+        return p.stdout[len(BANNER):], p.stderr
+
+    rng = np.random.default_rng(77)
+    genomes = []
+    lines = []
+    for i in range(200):
+        g = bytes(rng.choice(list(b"ACGT"), size=4000).astype(np.uint8))
+        if i % 10 == 3:                              # related accessions: shared k-mers, fewer unique hits
+            g = genomes[i - 1][:2500] + g[2500:]
+        genomes.append(g)
+        fa = tmp_path / f"acc{i:03d}.fasta"
+        fa.write_text(f">acc{i:03d}\n{g.decode()}\n")
+        lines.append(f"acc{i:03d}\t{fa}\n")
+    tsv = tmp_path / "refs.tsv"
+    tsv.write_text("".join(lines))
+    pre = str(tmp_path / "syn")
+    cli("build", "-s", "400000", "-n", "3", "-k", "25", "-b", pre, "-r", str(tsv))
+    r1 = synth_fastq_records(np.random.default_rng(5), genomes[:40], 3000, 120, mate=0)
+    r2 = synth_fastq_records(np.random.default_rng(5), genomes[:40], 3000, 120, mate=1)
+    f1, f2 = str(tmp_path / "r_1.fastq.gz"), str(tmp_path / "r_2.fastq.gz")
+    write_fastq_gz(f1, r1)
+    write_fastq_gz(f2, r2)
+    fasta = str(tmp_path / "acc007.fasta")
+    cases = {
+        "search_pe": ("search", "-b", pre + ".bxi", "-q", f1, "-r", f2, "-f", "1", "-p", "0.01"),
+        "search_gene": ("search", "-b", pre + ".bxi", "-q", f1, "-g", "-f", "0", "-p", "0.01"),
+        "search_fasta": ("search", "-b", pre + ".bxi", "-q", fasta, "-p", "0.01"),
+        "perfect": ("search", "-b", pre + ".bxi", "-q", fasta, "-s"),
+        "perfect_mf": ("search", "-b", pre + ".bxi", "-q", fasta, "-s", "-m"),
+    }
+    for name, args in cases.items():
+        base, _ = cli(*args, "--device", "0")
+        assert base.strip(), name
+        for devs in ("0,0", "0,0,0", "0"):
+            out, err = cli(*args, "--devices", devs, "--placement", "striped")
+            assert sorted(out.splitlines()) == sorted(base.splitlines()), (name, devs)
+            assert "one colour stripe of the index each" in err
+    for tag, q in (("se", (f1,)), ("pe", (f1, f2))):
+        cli("read_id", "-b", pre + ".bxi", "-q", *q, "-n", str(tmp_path / f"one_{tag}"), "-c", "700")
+        cli("read_id", "-b", pre + ".bxi", "-q", *q, "-n", str(tmp_path / f"str_{tag}"), "-c", "700", "--devices", "0,0,0", "--placement", "striped")
+        assert open(tmp_path / f"one_{tag}_reads.txt").read() == open(tmp_path / f"str_{tag}_reads.txt").read()
+        assert open(tmp_path / f"one_{tag}_counts.txt").read() == open(tmp_path / f"str_{tag}_counts.txt").read()
+    # more ranks than 64-colour words: refused with the reason
+    p = subprocess.run([BIN, *cases["perfect"], "--devices", "0,0,0,0,0", "--placement", "striped"], capture_output=True, text=True)
+    assert p.returncode != 0 and "fewer than the 5 ranks" in p.stderr
