@@ -14,6 +14,11 @@ with open(f"{W}/refs.tsv","w") as t:
         s=ac[rng.integers(0,4,200000)].tobytes(); gs.append(s)
         open(f"{W}/g{g}.fasta","wb").write(b">g%d\n"%g + b"\n".join(s[i:i+70] for i in range(0,len(s),70))+b"\n")
         t.write(f"genome{g}\t{W}/g{g}.fasta\n")
+with open(f"{W}/refs130.tsv","w") as t:      # 130 accessions = 3 words of 64 colours: an index that can be striped over 2-3 ranks
+    for g in range(130):
+        s=gs[g%6][(g//6)*8000:(g//6)*8000+20000]
+        open(f"{W}/h{g}.fasta","wb").write(b">h%d\n"%g + s + b"\n")
+        t.write(f"acc{g:03d}\t{W}/h{g}.fasta\n")
 def fq(path, n, mate):
     r=np.random.default_rng(5)
     with gzip.open(path,"wb",compresslevel=1) as f:
@@ -34,6 +39,12 @@ for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
   $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -f 0 -p 0.01 > $W/s2.out 2> $W/s2.err; echo "search default rc=$?"; grep -c . $W/s2.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s2.err | head -5
   $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 --devices 0,0,0 > $W/s3.out 2> $W/s3.err; echo "search 3 ranks rc=$?"; grep -c . $W/s3.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s3.err | head -5
   $B read_id -b $W/ix.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid3 -c 5000 --devices 0,0 > $W/r3.out 2> $W/r3.err; echo "read_id 2 ranks rc=$?"; cmp $W/rid_reads.txt $W/rid3_reads.txt && echo "same rows as one rank"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r3.err | head -5
+  # colour stripes over the ranks (cid_group_stripes_*): loader, searches, read_id and the per-read splice of the ranks' lists
+  $B build -s 3000000 -n 3 -k 27 -b $W/ix130 -r $W/refs130.tsv > $W/b130.out 2> $W/b130.err; echo "build 130 rc=$?"
+  $B search -b $W/ix130.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 > $W/s4a.out 2> $W/s4a.err; echo "search 130 one GPU rc=$?"
+  $B search -b $W/ix130.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 --devices 0,0,0 --placement striped > $W/s4.out 2> $W/s4.err; echo "search striped 3 ranks rc=$?"; grep -c . $W/s4.out; sort $W/s4a.out > $W/s4a.sorted; sort $W/s4.out | cmp - $W/s4a.sorted && echo "same rows as one GPU"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s4.err | head -5
+  $B read_id -b $W/ix130.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid4a -c 5000 > $W/r4a.out 2> $W/r4a.err; echo "read_id 130 one GPU rc=$?"
+  $B read_id -b $W/ix130.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid4 -c 5000 --devices 0,0 --placement striped > $W/r4.out 2> $W/r4.err; echo "read_id striped 2 ranks rc=$?"; cmp $W/rid4a_reads.txt $W/rid4_reads.txt && echo "same rows as one GPU"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r4.err | head -5
   $B hashcheck -b $W/ix.bxi -r $W/refs.tsv > $W/h.out 2> $W/h.err; echo "hashcheck rc=$?"; grep verdict $W/h.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/h.err | head -5
 done
 # TSan: the HIP/HSA runtime is not instrumented and reports races between its own threads (objects it allocates inside an API call
