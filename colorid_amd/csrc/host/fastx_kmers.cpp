@@ -91,9 +91,15 @@ void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, st
 // Decoded text travels in blocks through a small bounded queue: zlib runs on the reader's own thread while the caller
 // splits lines, masks qualities and feeds the GPU.  gzread() continues across gzip members like MultiGzDecoder and reads
 // plain files as they are.
+// BGZF input (block gzip: every member <= 64 KiB and its compressed size in a "BC" extra field — bgzip, htslib, Illumina's
+// converters): the members of a batch are independent, so the reader thread only walks the headers and hands the batch's members to
+// COLORID_GZ_THREADS (default 8) inflating threads, each writing at its member's offset of the output block (the members'
+// uncompressed sizes are in their trailers).  Single-stream gzip has no such boundaries and stays on one zlib thread.
 struct LineReader::Impl {
     static constexpr size_t kBlock = 4u << 20, kDepth = 4;
     gzFile gz = nullptr;
+    FILE *raw = nullptr;           // BGZF mode: the compressed file itself
+    int gz_threads = 8;
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv_full, cv_free;
@@ -102,15 +108,45 @@ struct LineReader::Impl {
     std::vector<char> cur;   // block being split by next()
     size_t pos = 0;
 
+    // a block-gzip member header: 1f 8b 08 04 | mtime xfl os | XLEN | ... 'B' 'C' 02 00 BSIZE ... ; returns the member's total size or 0
+    static size_t bgzf_member_size(const unsigned char *h, size_t have) {
+        if (have < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return 0;
+        const size_t xlen = h[10] | ((size_t)h[11] << 8);
+        if (have < 12 + xlen) return 0;
+        for (size_t o = 12; o + 4 <= 12 + xlen;) {
+            const size_t slen = h[o + 2] | ((size_t)h[o + 3] << 8);
+            if (h[o] == 'B' && h[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) return (size_t)(h[o + 4] | ((size_t)h[o + 5] << 8)) + 1;
+            o += 4 + slen;
+        }
+        return 0;
+    }
+    static bool is_bgzf(const std::string &path) {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        unsigned char h[64];
+        const size_t n = fread(h, 1, sizeof h, f);
+        fclose(f);
+        return bgzf_member_size(h, n) >= 26;
+    }
+
+    void push(std::vector<char> &&blk, bool last) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!blk.empty()) full.push_back(std::move(blk));
+        if (last) eof = true;
+        cv_full.notify_one();
+    }
+    bool take_free(std::vector<char> &blk) {   // false: asked to stop
+        std::unique_lock<std::mutex> lk(mu);
+        cv_free.wait(lk, [&] { return stop || full.size() < kDepth; });
+        if (stop) return false;
+        if (!free_blocks.empty()) { blk = std::move(free_blocks.front()); free_blocks.pop_front(); }
+        return true;
+    }
+
     void run() {
         for (;;) {
             std::vector<char> blk;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_free.wait(lk, [&] { return stop || full.size() < kDepth; });
-                if (stop) return;
-                if (!free_blocks.empty()) { blk = std::move(free_blocks.front()); free_blocks.pop_front(); }
-            }
+            if (!take_free(blk)) return;
             blk.resize(kBlock);
             size_t got = 0;
             while (got < kBlock) {   // gzread may return short counts at member boundaries
@@ -119,11 +155,77 @@ struct LineReader::Impl {
                 got += (size_t)n;
             }
             blk.resize(got);
-            std::lock_guard<std::mutex> lk(mu);
-            if (got) full.push_back(std::move(blk));
-            if (got < kBlock) eof = true;
-            cv_full.notify_one();
-            if (eof) return;
+            const bool last = got < kBlock;
+            push(std::move(blk), last);
+            if (last) return;
+        }
+    }
+
+    // BGZF: batches of members worth ~16 MiB of text, inflated by gz_threads threads
+    struct Member { size_t in_off, in_len, out_off, out_len; };
+    void run_bgzf() {
+        constexpr size_t kBatchOut = 16u << 20;
+        std::vector<unsigned char> in;        // compressed bytes of the batch (plus the unread tail of the last fread)
+        size_t in_have = 0, in_pos = 0;
+        bool file_end = false;
+        auto need = [&](size_t bytes) {       // make in[in_pos, in_pos + bytes) available if the file has them (grows, never moves)
+            while (in_have - in_pos < bytes && !file_end) {
+                if (in.size() < in_have + (4u << 20)) in.resize(in_have + (4u << 20));
+                const size_t n = fread(in.data() + in_have, 1, in.size() - in_have, raw);
+                if (n == 0) file_end = true;
+                in_have += n;
+            }
+            return in_have - in_pos >= bytes;
+        };
+        for (;;) {
+            std::vector<char> blk;
+            if (!take_free(blk)) return;
+            std::vector<Member> mem;
+            size_t out_total = 0;
+            // the unread tail moves to the front once per batch (never inside one: members are addressed by offset)
+            if (in_pos) { memmove(in.data(), in.data() + in_pos, in_have - in_pos); in_have -= in_pos; in_pos = 0; }
+            size_t scan = in_pos;
+            bool last = false;
+            while (out_total < kBatchOut) {
+                in_pos = scan;
+                if (!need(18)) { if (in_have - in_pos != 0) die("truncated gzip member header"); last = true; break; }
+                const size_t msz = bgzf_member_size(in.data() + in_pos, in_have - in_pos);
+                if (msz < 26) die("not a block-gzip (BGZF) member inside a BGZF file: mixed gzip streams are not supported in one file");
+                if (!need(msz)) die("truncated gzip member");
+                const unsigned char *t = in.data() + in_pos + msz - 4;
+                const size_t isize = t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                if (isize > (1u << 16)) die("BGZF member larger than 64 KiB");
+                if (isize) mem.push_back(Member{in_pos, msz, out_total, isize});   // (an empty member — the BGZF end marker — holds nothing)
+                out_total += isize;
+                scan = in_pos + msz;
+            }
+            in_pos = scan;
+            blk.resize(out_total);
+            if (!mem.empty()) {
+                const int nt = (int)std::min<size_t>((size_t)gz_threads, mem.size());
+                std::vector<std::thread> th;
+                std::vector<int> bad(nt, 0);
+                auto work = [&](int t) {
+                    z_stream zs;
+                    memset(&zs, 0, sizeof zs);
+                    if (inflateInit2(&zs, 15 + 16) != Z_OK) { bad[t] = 1; return; }
+                    for (size_t i = (size_t)t; i < mem.size(); i += (size_t)nt) {
+                        const Member &m = mem[i];
+                        inflateReset(&zs);
+                        zs.next_in = in.data() + m.in_off; zs.avail_in = (uInt)m.in_len;
+                        zs.next_out = reinterpret_cast<Bytef *>(blk.data() + m.out_off); zs.avail_out = (uInt)m.out_len;
+                        const int rc = inflate(&zs, Z_FINISH);
+                        if (rc != Z_STREAM_END || zs.total_out != m.out_len) { bad[t] = 1; break; }   // zlib checked the member's CRC-32
+                    }
+                    inflateEnd(&zs);
+                };
+                for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+                work(0);
+                for (auto &x : th) x.join();
+                for (int t = 0; t < nt; ++t) if (bad[t]) die("corrupt gzip member (inflate / CRC-32 failed)");
+            }
+            push(std::move(blk), last);
+            if (last) return;
         }
     }
     bool refill() {   // false at end of input
@@ -140,6 +242,14 @@ struct LineReader::Impl {
 };
 
 LineReader::LineReader(const std::string &path) : p_(new Impl) {
+    const char *gt = getenv("COLORID_GZ_THREADS");
+    if (gt) p_->gz_threads = atoi(gt);
+    if (p_->gz_threads > 1 && Impl::is_bgzf(path)) {
+        p_->raw = fopen(path.c_str(), "rb");
+        if (!p_->raw) die("file not found: %s", path.c_str());
+        p_->worker = std::thread([this] { p_->run_bgzf(); });
+        return;
+    }
     p_->gz = gzopen(path.c_str(), "rb");
     if (!p_->gz) die("file not found: %s", path.c_str());
     gzbuffer(p_->gz, 1 << 20);
@@ -153,6 +263,7 @@ LineReader::~LineReader() {
     p_->cv_free.notify_all();
     if (p_->worker.joinable()) p_->worker.join();
     if (p_->gz) gzclose(p_->gz);
+    if (p_->raw) fclose(p_->raw);
     delete p_;
 }
 bool LineReader::next(std::string &line) {

@@ -1,0 +1,92 @@
+"""The CLI's input reader (colorid_amd/csrc/host/fastx_kmers.cpp, LineReader) on plain text, single-stream gzip, multi-member gzip
+and block gzip (BGZF: members inflated by several threads): the same lines in the same order.  Host code only — runs without a GPU."""
+import gzip
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def write_bgzf(path, data: bytes, block=65280, level=6, eof_marker=True):
+    """Block gzip as bgzip / htslib write it (SAM spec §4.1): members of <= 64 KiB with their size in a 'BC' extra field."""
+    with open(path, "wb") as f:
+        chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_marker else [])
+        for c in chunks:
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = co.compress(c) + co.flush()
+            bsize = 12 + 6 + len(body) + 8 - 1
+            f.write(b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize))
+            f.write(body + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c)))
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    lib = os.path.join(ROOT, "colorid_amd", "libcolorid_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("libcolorid_hip.so not built")
+    exe = str(tmp_path_factory.mktemp("lr") / "lr_shim")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(HERE, "cpu_shim", "linereader_shim.cpp"),
+                    os.path.join(ROOT, "colorid_amd", "csrc", "host", "fastx_kmers.cpp"), "-L" + os.path.join(ROOT, "colorid_amd"),
+                    "-lcolorid_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "colorid_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def _fastq(rng, n_reads):
+    out = []
+    for i in range(n_reads):
+        L = int(rng.integers(30, 251))
+        s = bytes(rng.choice(list(b"ACGTN"), size=L).astype(np.uint8))
+        out.append(b"@read%d some words\n" % i + s + b"\n+\n" + b"I" * L + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("n_reads", [0, 1, 3000, 120_000])
+def test_linereader_same_lines_for_every_container(shim, tmp_path, n_reads):
+    rng = np.random.default_rng(n_reads)
+    text = _fastq(rng, n_reads)
+    if n_reads == 3000:
+        text = text[:-1]                      # no newline at the very end
+    paths = {}
+    paths["plain"] = tmp_path / "a.fastq"
+    paths["plain"].write_bytes(text)
+    paths["gz"] = tmp_path / "a.fastq.gz"
+    with gzip.open(paths["gz"], "wb", compresslevel=4) as f:
+        f.write(text)
+    paths["multi"] = tmp_path / "m.fastq.gz"   # three concatenated members (MultiGzDecoder in the reference)
+    third = len(text) // 3
+    with open(paths["multi"], "wb") as f:
+        for part in (text[:third], text[third:2 * third], text[2 * third:]):
+            f.write(gzip.compress(part, 3))
+    paths["bgzf"] = tmp_path / "b.fastq.gz"
+    write_bgzf(paths["bgzf"], text)
+    paths["bgzf_small"] = tmp_path / "c.fastq.gz"     # odd block size: lines and reads straddle members and batches
+    write_bgzf(paths["bgzf_small"], text, block=777, eof_marker=False)
+    outs = {}
+    for name, p in paths.items():
+        for threads in (("8",) if "bgzf" not in name else ("8", "3", "1")):
+            r = subprocess.run([shim, str(p)], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads))
+            assert r.returncode == 0, (name, r.stderr)
+            outs[(name, threads)] = r.stdout.split()
+    want = outs[("plain", "8")]
+    assert int(want[0]) == text.count(b"\n") + (1 if text and not text.endswith(b"\n") else 0)
+    assert int(want[1]) == len(text) - text.count(b"\n")
+    for key, got in outs.items():
+        assert got == want, key
+
+
+def test_linereader_reports_a_corrupt_bgzf_member(shim, tmp_path):
+    rng = np.random.default_rng(9)
+    text = _fastq(rng, 5000)
+    p = tmp_path / "bad.fastq.gz"
+    write_bgzf(p, text)
+    raw = bytearray(p.read_bytes())
+    raw[len(raw) // 2] ^= 0x55                  # somewhere inside a member's deflate stream (or its CRC)
+    p.write_bytes(bytes(raw))
+    r = subprocess.run([shim, str(p)], capture_output=True, text=True)
+    assert r.returncode == 101 and ("corrupt gzip member" in r.stderr or "BGZF" in r.stderr or "truncated" in r.stderr)

@@ -60,6 +60,24 @@ res["read_id_accept_frac"] = 1.0 - int(counts.get("reject", 0)) / R
 dt, out, err = run("read_id", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", f"{W}/reads.fastq.gz", "-n", f"{W}/rid_pe")
 res["read_id_pe_total_s"] = dt
 res["read_id_pe_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "timing:" in l]
+# the same reads as block gzip (BGZF, what bgzip / htslib / Illumina's converters write): members are inflated by 8 threads
+import struct, zlib
+with open(f"{W}/reads.bgzf.fastq.gz", "wb") as f:
+    for i in range(0, len(blob), 65280):
+        c = blob[i:i + 65280]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = co.compress(c) + co.flush()
+        f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
+        f.write(body + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c)))
+dt, out, err = run("read_id", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.bgzf.fastq.gz", "-n", f"{W}/rid_b")
+res["read_id_bgzf_total_s"] = dt
+res["read_id_bgzf_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "timing:" in l]
+res["read_id_bgzf_same_rows"] = open(f"{W}/rid_b_reads.txt").read() == open(f"{W}/rid_reads.txt").read()
+dt, out, err = run("read_id", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.bgzf.fastq.gz", f"{W}/reads.bgzf.fastq.gz", "-n", f"{W}/rid_pe_b")
+res["read_id_pe_bgzf_total_s"] = dt
+res["read_id_pe_bgzf_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "timing:" in l]
+dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.bgzf.fastq.gz", "-g", "-f", "0", "-p", "0.005")
+res["search_g_bgzf_total_s"] = dt
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/g007.fasta", "-s")
 res["search_s_total_s"] = dt; res["search_s_out"] = out.strip().splitlines()[-1] if out.strip() else ""
 print(json.dumps(res))
