@@ -67,8 +67,9 @@ int check_stripes(const cid_group *g, cid_index *const *stripes, Stripes &st) {
 // Peer copies into a scratch block of rank 0 (64 MiB at a time) and one elementwise kernel per chunk; synchronous.
 int reduce_u32(cid_group *g, uint32_t *const *d_bufs, size_t count, bool sum, bool everywhere) {
     const int n = (int)g->ctx.size();
-    if (n == 1 || count == 0) return CID_OK;
-    if (sum && g->use_rccl) return allreduce_sum(g, reinterpret_cast<void *const *>(d_bufs), count, 4);
+    if (count == 0) return CID_OK;
+    if (sum && g->use_rccl) return allreduce_sum(g, reinterpret_cast<void *const *>(d_bufs), count, 4);   // (also with one rank: COLORID_REDUCE=rccl)
+    if (n == 1) return CID_OK;
     for (int r = 0; r < n; ++r) { HIP_TRY(hipSetDevice(g->dev[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
     cid_ctx *c0 = g->ctx[0];
     HIP_TRY(hipSetDevice(c0->device));

@@ -149,8 +149,8 @@ def test_cli_placement_striped_equals_single_gpu(orc, tmp_path):
     from test_gpu_cli import BANNER, BIN
     from util import synth_fastq_records, write_fastq_gz
 
-    def cli(*args):
-        p = subprocess.run([BIN, *args], capture_output=True, text=True, env=dict(os.environ, COLORID_QUIET="1"))
+    def cli(*args, env=None):
+        p = subprocess.run([BIN, *args], capture_output=True, text=True, env=dict(os.environ, COLORID_QUIET="1", **(env or {})))
         assert p.returncode == 0, p.stderr[-3000:]
         assert p.stdout.startswith(BANNER)
         return p.stdout[len(BANNER):], p.stderr
@@ -190,6 +190,10 @@ def test_cli_placement_striped_equals_single_gpu(orc, tmp_path):
             out, err = cli(*args, "--devices", devs, "--placement", "striped")
             assert sorted(out.splitlines()) == sorted(base.splitlines()), (name, devs)
             assert "one colour stripe of the index each" in err
+        # the RCCL reduction of the per-k-mer facts (ncclAllReduce, u32, K) with one rank: what N distinct GPUs take
+        out, err = cli(*args, "--devices", "0", "--placement", "striped", env={"COLORID_REDUCE": "rccl"})
+        assert sorted(out.splitlines()) == sorted(base.splitlines()), (name, "rccl")
+        assert "with RCCL all-reduce" in err
     for tag, q in (("se", (f1,)), ("pe", (f1, f2))):
         cli("read_id", "-b", pre + ".bxi", "-q", *q, "-n", str(tmp_path / f"one_{tag}"), "-c", "700")
         cli("read_id", "-b", pre + ".bxi", "-q", *q, "-n", str(tmp_path / f"str_{tag}"), "-c", "700", "--devices", "0,0,0", "--placement", "striped")
