@@ -121,9 +121,13 @@ struct LdsReader {  // bytes [off, off+len) of an LDS (or host) dword image
 // 4 bases (2 bits each, base j at bits 2j+1:2j; A,C,G,T = 0..3) -> their 4 upper-case ASCII bytes, little-endian
 CID_FN uint32_t ascii4(uint32_t x8) {
     uint32_t y = (x8 | (x8 << 12)) & 0x000F000Fu;
-    y = (y | (y << 6)) & 0x03030303u;
+    y = (y | (y << 6)) & 0x03030303u;           // one code (0..3) per byte
+#if defined(__HIPCC__) && !defined(CID_ASCII4_ARITH)
+    return __builtin_amdgcn_perm(0u, 0x54474341u, y);   // v_perm_b32 as a 4-entry byte table: selector 0..3 picks 'A','C','G','T'
+#else
     const uint32_t b0 = y & 0x01010101u, b1 = (y >> 1) & 0x01010101u;
     return 0x41414141u + 2u * y + 2u * b1 + 11u * (b0 & b1);  // 'A'+{0,2,6,19}: no byte ever carries
+#endif
 }
 
 struct CodeReader {  // an upper-case ACGT k-mer (k <= 32) held as a 2-bit code, base j at bits 2j+1:2j
