@@ -2,11 +2,12 @@
 # bench run, with the box's clocks recorded before and after.  Kernel timing and PMC counters are separate runs (guide:
 # MI355X_MICROARCH.md §HBM / rocprofv3 PMC slots); one derived metric per pass; counters only for k_search_count; every pass under
 # its own timeout (a two-metric pass once aborted and hung the profiler for 24 minutes).
-TAG=${1:-r02}
+TAG=${1:-r02}; shift   # remaining arguments go to bench.py (e.g. --colours 1024 for configs[3]'s row width)
+EXTRA="$@"
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG; export TMPDIR=/tmp
-BENCH="python3 bench.py --no-cpu-baseline --no-variants"
+BENCH="python3 bench.py --no-cpu-baseline --no-variants $EXTRA"
 rocm-smi --showclocks > gpurun_out/$TAG/clocks_before.txt 2>&1
-timeout 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
+timeout 300 python3 bench.py $EXTRA --steps 20 --warmup 5 > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 rocm-smi --showclocks > gpurun_out/$TAG/clocks_after_bench.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG/stats -- $BENCH --steps 20 --warmup 3 > gpurun_out/$TAG/bench_stats.log 2>&1
 pmc() {  # pmc <dir> <counters...>
