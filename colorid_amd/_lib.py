@@ -82,6 +82,17 @@ SIGNATURES = {
     "cid_group_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,
                                                 C.POINTER(C.c_uint64)]),
     "cid_group_readid_sparse_fetch": (C.c_int, [vp, vp, vp, vp]),
+    "cid_group_kmerset_create": (C.c_int, [vp, C.c_uint32, C.POINTER(vp)]),
+    "cid_group_kmerset_add_seqs": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int]),
+    "cid_group_kmerset_finalize": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "cid_group_kmerset_size": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+    "cid_group_kmerset_part_sizes": (C.c_int, [vp, vp]),
+    "cid_group_kmerset_count_histogram": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "cid_group_kmerset_clean": (C.c_int, [vp, C.c_uint64]),
+    "cid_group_kmerset_download": (C.c_int, [vp, vp, vp]),
+    "cid_group_kmerset_destroy": (None, [vp]),
+    "cid_group_search_count_parts": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
+    "cid_group_search_perfect_parts": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.POINTER(C.c_int)]),
     "cid_group_stripes_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "cid_group_stripes_base": (C.c_int, [vp, C.POINTER(vp), vp]),
     "cid_group_stripes_put_records": (C.c_int, [vp, C.POINTER(vp), vp, C.c_size_t]),

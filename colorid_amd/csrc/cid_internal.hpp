@@ -44,6 +44,8 @@ int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_code
 
 // a finalized set's device arrays (codes ascending unless reordered; counts u32) and the ctx they live in
 int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, const uint32_t **counts, uint64_t *n, uint32_t *k);
+// replace a finalized 2-bit-code set's contents by the merge (sort by code, add counts of equal codes) of `total` pairs on its device
+int kmerset_assign_merged(cid_kmerset *ks, const uint64_t *d_codes_in, const uint32_t *d_counts_in, size_t total);
 int kmerset_view_ascii(const cid_kmerset *ks, cid_ctx **ctx, const uint8_t **ascii, const uint32_t **counts, uint64_t *n, uint32_t *k);   // k > 32 sets
 
 // the same three for sets of byte-string k-mers (k > 32): d_ascii = n x k bytes on the device

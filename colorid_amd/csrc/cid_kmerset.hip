@@ -281,6 +281,45 @@ int compact(cid_kmerset *ks) {
 
 }  // namespace
 
+// A finalized code set's contents replaced by the merge of `total` (code, count) pairs in any order (device arrays in ks's ctx; the
+// caller keeps owning them): sort by code, equal codes' counts added (cid_group_kmerset: the ranges a rank receives from the others).
+int cid::kmerset_assign_merged(cid_kmerset *ks, const uint64_t *d_codes_in, const uint32_t *d_counts_in, size_t total) {
+    if (!ks || ks->general || !ks->finalized) return fail(CID_ERR_STATE, "kmerset_assign_merged: a finalized 2-bit-code set is needed");
+    if (total >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "%zu k-mers in one rank's share of the set (limit 2^32 - 1): use more GPUs", total);
+    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
+    hipStream_t st = cid::ctx_stream(ks->ctx);
+    DevBuf<uint64_t> uniq(ks->ctx), kout(ks->ctx), d_count(ks->ctx);
+    DevBuf<uint32_t> agg(ks->ctx), vout(ks->ctx);
+    int rc;
+    if ((rc = uniq.alloc(total)) || (rc = agg.alloc(total)) || (rc = kout.alloc(total)) || (rc = vout.alloc(total)) || (rc = d_count.alloc(1))) return rc;
+    uint64_t n_runs = 0;
+    if (total) {
+        size_t tmp_bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_codes_in, kout.p, d_counts_in, vout.p, total, 0u, ks->end_bit, st));
+        DevBuf<uint8_t> tmp(ks->ctx);
+        if ((rc = tmp.alloc(tmp_bytes))) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, d_codes_in, kout.p, d_counts_in, vout.p, total, 0u, ks->end_bit, st));
+        size_t tmp2 = 0;
+        HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
+        DevBuf<uint8_t> t2(ks->ctx);
+        if ((rc = t2.alloc(tmp2))) return rc;
+        HIP_TRY(rocprim::reduce_by_key(t2.p, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
+        HIP_TRY(hipMemsetAsync(ks->d_flags + 1, 0, 4, st));
+        hipLaunchKernelGGL(cid::k_flag_saturated, dim3(grid_for_n(total)), dim3(256), 0, st, agg.p, d_count.p, ks->d_flags + 1);
+        int sat = 0;
+        HIP_TRY(hipMemcpyAsync(&sat, ks->d_flags + 1, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (sat) return fail(CID_ERR_UNSUPPORTED, "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
+    }
+    if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
+    if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
+    ks->codes = uniq.release();
+    ks->counts = agg.release();
+    ks->n = n_runs;
+    return CID_OK;
+}
+
 // k > 32: all windows of the resident sequences -> distinct canonical byte strings + multiplicities
 static int finalize_general(cid_kmerset *ks);
 
@@ -963,7 +1002,10 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         DevBuf<uint64_t> nb(ks->ctx);
         int rc = nb.alloc(want);
         if (rc) return rc;
-        if (ks->n_raw) HIP_TRY(hipMemcpy(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice));
+        // on the ctx stream and waited for: a device-to-device hipMemcpy on the null stream returns before it has run, and the block
+        // freed below is handed out again at once (as this call's d_bases) — the copy then read ASCII bases as codes
+        if (ks->n_raw) HIP_TRY(hipMemcpyAsync(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
         if (ks->raw) cid::ctx_free(ks->ctx, ks->raw);
         ks->raw = nb.release();
         ks->cap_raw = want;

@@ -370,6 +370,10 @@ class Group:
         check(self.lib.cid_group_readid_sparse_fetch(self.h, _p(rs), _p(col), _p(cnt)))
         return rs, col, cnt, nk, st
 
+    def kmerset(self, k):
+        """A k-mer set counted over all ranks (cid_group_kmerset)."""
+        return GroupKmerSet(self, k)
+
     def stripes(self, m, n_hash, k, n_colors_total, hash_variant=0):
         """A colour-striped index over the ranks (cid_group_stripes_*): rank r holds colours [base[r], base[r+1])."""
         return GroupStripes(self, m, n_hash, k, n_colors_total, hash_variant)
@@ -384,6 +388,8 @@ class Group:
                 self._replica_handles = None
             for st in list(getattr(self, "_stripes", [])):
                 st.close()
+            for ks in list(getattr(self, "_ksets", [])):
+                ks.close()
             for c in self.ctxs:
                 c.close()          # closes the indices / k-mer sets made from the ranks' contexts
             self.lib.cid_group_destroy(self.h)
@@ -475,3 +481,77 @@ class GroupStripes:
             self.arr = None
             if self in getattr(self.g, "_stripes", []):
                 self.g._stripes.remove(self)
+
+
+class GroupKmerSet:
+    """Distinct canonical k-mers of a query counted over all ranks of a Group (cid_group_kmerset): rank r ends up with the r-th code
+    range; the parts laid end to end are the set in a KmerSet's order."""
+
+    def __init__(self, group, k):
+        self.g, self.lib, self.k = group, group.lib, k
+        h = vp()
+        check(self.lib.cid_group_kmerset_create(group.h, k, C.byref(h)))
+        self.h = h
+        if not hasattr(group, "_ksets"):
+            group._ksets = []
+        group._ksets.append(self)
+
+    def add_seqs(self, seqs, mode=0):
+        off = np.zeros(len(seqs) + 1, np.uint64)
+        off[1:] = np.cumsum([len(s) for s in seqs])
+        bases = np.frombuffer(b"".join(seqs), np.uint8) if seqs else np.zeros(0, np.uint8)
+        check(self.lib.cid_group_kmerset_add_seqs(self.h, _p(bases), _p(off), len(seqs), mode))
+
+    def finalize(self):
+        n = C.c_uint64(0)
+        check(self.lib.cid_group_kmerset_finalize(self.h, C.byref(n)))
+        return n.value
+
+    def __len__(self):
+        n = C.c_uint64(0)
+        check(self.lib.cid_group_kmerset_size(self.h, C.byref(n)))
+        return n.value
+
+    def part_sizes(self):
+        s = np.zeros(self.g.n, np.uint64)
+        check(self.lib.cid_group_kmerset_part_sizes(self.h, _p(s)))
+        return s
+
+    def histogram(self):
+        nb = C.c_size_t(0)
+        check(self.lib.cid_group_kmerset_count_histogram(self.h, None, None, 0, C.byref(nb)))
+        vals = np.zeros(nb.value, np.uint32)
+        cnts = np.zeros(nb.value, np.uint64)
+        check(self.lib.cid_group_kmerset_count_histogram(self.h, _p(vals), _p(cnts), nb.value, C.byref(nb)))
+        return vals, cnts
+
+    def clean(self, t):
+        check(self.lib.cid_group_kmerset_clean(self.h, t))
+
+    def download(self):
+        n = len(self)
+        km = np.zeros((n, self.k), np.uint8)
+        cnt = np.zeros(n, np.uint32)
+        check(self.lib.cid_group_kmerset_download(self.h, _p(km), _p(cnt)))
+        return km, cnt
+
+    def search_count(self):
+        arr, ix = self.g._idx()
+        hits, nu, sf = (np.zeros(ix.n_colors, np.uint64) for _ in range(3))
+        uc = np.zeros(len(self), np.uint32)
+        check(self.lib.cid_group_search_count_parts(self.g.h, arr, self.h, _p(hits), _p(nu), _p(sf), _p(uc)))
+        return hits, nu, sf, uc
+
+    def search_perfect(self):
+        arr, ix = self.g._idx()
+        words = np.zeros(ix.w32, np.uint32)
+        missing = C.c_int(0)
+        check(self.lib.cid_group_search_perfect_parts(self.g.h, arr, self.h, _p(words), C.byref(missing)))
+        return words, bool(missing.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cid_group_kmerset_destroy(self.h)
+            self.h = None
+            if self in getattr(self.g, "_ksets", []):
+                self.g._ksets.remove(self)

@@ -275,6 +275,27 @@ int cid_group_readid_count_sparse(cid_group *, cid_index *const *replicas, const
                                   uint8_t *status, uint64_t *n_entries);
 int cid_group_readid_sparse_fetch(cid_group *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
 
+/* ---- canonical k-mer counting over the group (SURVEY.md §8e.1 caveat + §8f.1): the reference counts DISTINCT k-mers over the whole
+ *      query, so a read set is not simply cut into shards — every rank counts the windows of its share of the sequences, the code
+ *      space is cut into n_ranks ranges (splitters from the ranks' own quantiles), every range travels to its owner (peer copies over
+ *      xGMI, 12 bytes per locally-distinct k-mer: the one exchange of this path) and is merged there.  Rank r then holds the r-th
+ *      range, ascending: the parts laid end to end are the set in the order a cid_kmerset has.  k_size <= 32; the calls mirror
+ *      cid_kmerset_* (add_seqs: CID_ERR_UNSUPPORTED on a lower-case base under mode 1, as there).  _search_*_parts: every rank
+ *      searches its own part against its replica, only the 3*C counters are reduced; unique_colour in set order. ---- */
+typedef struct cid_group_kmerset cid_group_kmerset;
+int cid_group_kmerset_create(cid_group *, uint32_t k_size, cid_group_kmerset **out);
+int cid_group_kmerset_add_seqs(cid_group_kmerset *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode);
+int cid_group_kmerset_finalize(cid_group_kmerset *, uint64_t *n_distinct);
+int cid_group_kmerset_size(const cid_group_kmerset *, uint64_t *n_distinct);
+int cid_group_kmerset_part_sizes(const cid_group_kmerset *, uint64_t *sizes /* n_ranks */);
+int cid_group_kmerset_count_histogram(const cid_group_kmerset *, uint32_t *multiplicity, uint64_t *n_kmers, size_t cap, size_t *n_bins);
+int cid_group_kmerset_clean(cid_group_kmerset *, uint64_t t);
+int cid_group_kmerset_download(const cid_group_kmerset *, uint8_t *kmers_ascii, uint32_t *counts);
+void cid_group_kmerset_destroy(cid_group_kmerset *);
+int cid_group_search_count_parts(cid_group *, cid_index *const *replicas, const cid_group_kmerset *, uint64_t *hits, uint64_t *n_unique,
+                                 uint64_t *sum_unique_freq, uint32_t *unique_colour);
+int cid_group_search_perfect_parts(cid_group *, cid_index *const *replicas, const cid_group_kmerset *, uint32_t *and_words_le, int *any_row_missing);
+
 /* ---- colour stripes over a group (BASELINE configs[4]): rank r holds the colours [base_r, base_{r+1}) of EVERY row —
  *      an index larger than one GPU's HBM.  Every rank sees every query k-mer / read; per call ONE exchange: the packed per-k-mer
  *      facts summed (RCCL all-reduce, 4 bytes per k-mer), the perfect search's / read_id's zero-row masks ANDed (peer copies).

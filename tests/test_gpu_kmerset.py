@@ -248,3 +248,25 @@ def test_report_outputs_on_the_device(orc, hip_ctx, n_colors, k):
     assert (nu > 0).sum() >= 10 and len(np.unique(modes)) > 4 and modes.max() >= 64 and (n_colors <= 20 or modes[20] == 2)
     hx.close()
     ks.close()
+
+
+def test_many_add_calls_on_a_used_context(orc, hip_ctx):
+    """The window buffer of a set grows across cid_kmerset_add_seqs calls; the old contents must be carried over before the old
+    block is recycled (a null-stream device-to-device hipMemcpy once let this call's own base upload overtake that copy: ASCII
+    bases turned up as k-mer codes).  Six calls of growing size, three rounds on a context whose scratch blocks have been used."""
+    import colorid_amd
+    rng = np.random.default_rng(99)
+    for k in (32, 21):
+        for rnd in range(3):
+            seqs = [bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(200, 900))).astype(np.uint8)) for _ in range(700)]
+            ks = colorid_amd.KmerSet(hip_ctx, k)
+            at = 0
+            for n in (5, 20, 60, 115, 200, 300):
+                ks.add_seqs(seqs[at:at + n], 0)
+                at += n
+            ks.finalize()
+            om = orc.Kmers(k)
+            for s in seqs[:at]:
+                om.kmerize_vector(s, 1)
+            assert ks.as_dict() == om.as_dict(), (k, rnd)
+            ks.close() if hasattr(ks, "close") else None
