@@ -192,10 +192,10 @@ cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::st
     return ks;
 }
 
-// fastq(.gz) SE or PE (kmer.rs:461-510 / :581-655); nullptr = the file holds lower-case bases: count it on the host
-cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q) {
-    cid_kmerset *ks = nullptr;
-    CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
+// fastq(.gz) SE or PE (kmer.rs:461-510 / :581-655) in batches of 256 MB of bases: add(batch) returns the add_seqs code;
+// false = a batch held lower-case bases (CID_ERR_UNSUPPORTED): count the file on the host
+template <typename Add>
+static bool stream_fastq_batches(const std::string &f1, const std::string *f2, uint8_t q, Add &&add) {
     LineReader r1(f1);
     LineReader *r2 = f2 ? new LineReader(*f2) : nullptr;
     SeqBatch sb;
@@ -204,7 +204,7 @@ cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, co
     bool ok = true;
     auto flush = [&]() {
         if (sb.n() == 0) return;
-        const int rc = cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 1);
+        const int rc = add(sb);
         if (rc == CID_ERR_UNSUPPORTED) ok = false;
         else if (rc != CID_OK) die("cid_kmerset_add_seqs: %s", cid_last_error());
         sb.clear();
@@ -222,6 +222,14 @@ cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, co
     }
     if (ok) flush();
     delete r2;
+    return ok;
+}
+
+// nullptr = the file holds lower-case bases: count it on the host
+cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q) {
+    cid_kmerset *ks = nullptr;
+    CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
+    const bool ok = stream_fastq_batches(f1, f2, q, [&](const SeqBatch &sb) { return cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 1); });
     if (!ok) { cid_kmerset_destroy(ks); return nullptr; }
     CID_TRY(cid_kmerset_finalize(ks, nullptr));
     return ks;
@@ -238,6 +246,63 @@ int64_t auto_cutoff_gpu(cid_kmerset *ks) {
     uint64_t n = 0;
     CID_TRY(cid_kmerset_size(ks, &n));
     return auto_cutoff_from_histogram(hm, n);
+}
+
+// The query's k-mer map on the GPU side of the search drivers: one cid_kmerset (one GPU, or a striped index whose ranks all need
+// the whole set), or — a replicated group, k <= 32 — a cid_group_kmerset counted over all ranks, each of which then searches its
+// own range of the set (COLORID_ONE_GPU_KMERS=1 keeps the counting on rank 0).
+struct GpuSet {
+    cid_kmerset *one = nullptr;
+    cid_group_kmerset *many = nullptr;
+    explicit operator bool() const { return one || many; }
+    uint64_t size() const {
+        uint64_t n = 0;
+        if (many) CID_TRY(cid_group_kmerset_size(many, &n)); else CID_TRY(cid_kmerset_size(one, &n));
+        return n;
+    }
+    void clean(uint64_t t) { if (many) CID_TRY(cid_group_kmerset_clean(many, t)); else CID_TRY(cid_kmerset_clean(one, t)); }
+    void counts(uint32_t *out) const { if (many) CID_TRY(cid_group_kmerset_download(many, nullptr, out)); else CID_TRY(cid_kmerset_download(one, nullptr, out)); }
+    int64_t auto_cutoff() const {
+        if (!many) return auto_cutoff_gpu(one);
+        size_t nb = 0;
+        CID_TRY(cid_group_kmerset_count_histogram(many, nullptr, nullptr, 0, &nb));
+        std::vector<uint32_t> mult(nb);
+        std::vector<uint64_t> cnt(nb);
+        CID_TRY(cid_group_kmerset_count_histogram(many, mult.data(), cnt.data(), nb, &nb));
+        std::map<uint64_t, uint64_t> hm;
+        for (size_t i = 0; i < nb; ++i) hm[mult[i]] = cnt[i];
+        return auto_cutoff_from_histogram(hm, size());
+    }
+    void destroy() { if (many) cid_group_kmerset_destroy(many); if (one) cid_kmerset_destroy(one); many = nullptr; one = nullptr; }
+};
+static bool count_over_group(uint64_t k) { return g_group && !g_striped && k <= 32 && !getenv("COLORID_ONE_GPU_KMERS"); }
+
+static GpuSet count_fasta_set(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs) {
+    GpuSet gs;
+    if (!count_over_group(k)) { gs.one = count_fasta_gpu(ctx, k, seqs); return gs; }
+    CID_TRY(cid_group_kmerset_create(g_group, (uint32_t)k, &gs.many));
+    SeqBatch sb;
+    for (const std::string &s : seqs) sb.push(s);
+    CID_TRY(cid_group_kmerset_add_seqs(gs.many, sb.bases.data(), sb.off.data(), sb.n(), 0));
+    CID_TRY(cid_group_kmerset_finalize(gs.many, nullptr));
+    return gs;
+}
+static GpuSet count_fastq_set(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q) {
+    GpuSet gs;
+    if (!count_over_group(k)) { gs.one = count_fastq_gpu(ctx, k, f1, f2, q); return gs; }
+    CID_TRY(cid_group_kmerset_create(g_group, (uint32_t)k, &gs.many));
+    const bool ok = stream_fastq_batches(f1, f2, q, [&](const SeqBatch &sb) { return cid_group_kmerset_add_seqs(gs.many, sb.bases.data(), sb.off.data(), sb.n(), 1); });
+    if (!ok) { gs.destroy(); return gs; }
+    CID_TRY(cid_group_kmerset_finalize(gs.many, nullptr));
+    return gs;
+}
+static int hot_search_count_gpuset(cid_ctx *ctx, const Bigsi &b, const GpuSet &gs, uint64_t *hits, uint64_t *nu, uint64_t *sf, uint32_t *uc) {
+    if (gs.many) return cid_group_search_count_parts(g_group, g_replicas.data(), gs.many, hits, nu, sf, uc);
+    return hot_search_count_set(ctx, b, gs.one, hits, nu, sf, uc);
+}
+static int hot_search_perfect_gpuset(cid_ctx *ctx, const Bigsi &b, const GpuSet &gs, uint32_t *words, int *missing) {
+    if (gs.many) return cid_group_search_perfect_parts(g_group, g_replicas.data(), gs.many, words, missing);
+    return hot_search_perfect_set(ctx, b, gs.one, words, missing);
 }
 
 static void print_perfect(const Bigsi &b, const std::string &label, size_t n_kmers, const std::vector<uint32_t> &words, int missing);
@@ -266,19 +331,18 @@ void perfect_search::batch_search(cid_ctx *ctx, const std::vector<std::string> &
     for (const std::string &file : files) {
         fprintf(stderr, "Counting k-mers, this may take a while!\n");
         if (gpu_counting(b)) {
-            cid_kmerset *ks = count_fasta_gpu(ctx, b.k_size, read_fasta(file));
-            uint64_t n = 0;
-            CID_TRY(cid_kmerset_size(ks, &n));
+            GpuSet ks = count_fasta_set(ctx, b.k_size, read_fasta(file));
+            const uint64_t n = ks.size();
             fprintf(stderr, "%llu kmers in query\n", (unsigned long long)n);
             if (n == 0) {
                 fprintf(stderr, "Warning! no kmers in query; maybe your kmer length is larger than your query length?\n");
             } else {
                 std::vector<uint32_t> words((b.colors.size() + 31) / 32);
                 int missing = 0;
-                CID_TRY(hot_search_perfect_set(ctx, b, ks, words.data(), &missing));
+                CID_TRY(hot_search_perfect_gpuset(ctx, b, ks, words.data(), &missing));
                 print_perfect(b, file, n, words, missing);
             }
-            cid_kmerset_destroy(ks);
+            ks.destroy();
             continue;
         }
         KmerMap km((uint32_t)b.k_size);
@@ -330,32 +394,30 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
         bool have_modes = false;
         std::vector<uint32_t> uc, counts;
         size_t n_kmers = 0;
-        cid_kmerset *ks = nullptr;
+        GpuSet ks;
         if (gpu_counting(b)) {
-            ks = gz ? count_fastq_gpu(ctx, b.k_size, file1, files2.empty() ? nullptr : &files2[i], qual_offset)
-                    : count_fasta_gpu(ctx, b.k_size, read_fasta(file1));
+            ks = gz ? count_fastq_set(ctx, b.k_size, file1, files2.empty() ? nullptr : &files2[i], qual_offset)
+                    : count_fasta_set(ctx, b.k_size, read_fasta(file1));
         }
-        if (ks) {  // the k-mer map lives on the device
+        if (ks) {  // the k-mer map lives on the device(s)
             uint64_t t = fasta_gene ? 0 : (uint64_t)(filter < 0 ? 0 : filter);
-            if (use_auto) { const int64_t a = auto_cutoff_gpu(ks); if (a < 0) die("auto_cutoff: histogram too short"); t = (uint64_t)a; }
-            CID_TRY(cid_kmerset_clean(ks, t));
-            uint64_t n = 0;
-            CID_TRY(cid_kmerset_size(ks, &n));
-            n_kmers = n;
+            if (use_auto) { const int64_t a = ks.auto_cutoff(); if (a < 0) die("auto_cutoff: histogram too short"); t = (uint64_t)a; }
+            ks.clean(t);
+            n_kmers = ks.size();
             fprintf(stderr, "%zu k-mers in query\n", n_kmers);
             const auto t0 = Clock::now();
             if (!gene_search && !g_group) {   // the whole report on the device: nothing per k-mer comes back
                 modes.assign(C, 0);
                 have_modes = true;
-                CID_TRY(cid_search_count_set_report(ctx, b.index, ks, hits.data(), n_unique.data(), sum_freq.data(), modes.data()));
+                CID_TRY(cid_search_count_set_report(ctx, b.index, ks.one, hits.data(), n_unique.data(), sum_freq.data(), modes.data()));
             } else {
                 if (!gene_search) { uc.resize(n_kmers); counts.resize(n_kmers); }
-                CID_TRY(hot_search_count_set(ctx, b, ks, hits.data(), gene_search ? nullptr : n_unique.data(),
-                                             gene_search ? nullptr : sum_freq.data(), gene_search ? nullptr : uc.data()));
-                if (!gene_search) CID_TRY(cid_kmerset_download(ks, nullptr, counts.data()));
+                CID_TRY(hot_search_count_gpuset(ctx, b, ks, hits.data(), gene_search ? nullptr : n_unique.data(),
+                                                gene_search ? nullptr : sum_freq.data(), gene_search ? nullptr : uc.data()));
+                if (!gene_search) ks.counts(counts.data());
             }
             if (gz) fprintf(stderr, "Search: %ld sec\n", secs_since(t0));
-            cid_kmerset_destroy(ks);
+            ks.destroy();
         } else {  // host k-mer map (k > 32, lower-case fastq, or COLORID_HOST_KMERS)
             fprintf(stderr, "k-mer map on the host\n");
             KmerMap km((uint32_t)b.k_size);

@@ -143,6 +143,9 @@ def test_cli_gpus_equals_single_gpu(orc, tmp_path):
         # lower-case / k > 32 inputs take the host k-mer map: the host-pointer group calls
         out, _ = _cli(*args, "--devices", "0,0", env={"COLORID_HOST_KMERS": "1"})
         assert sorted(out.splitlines()) == sorted(base.splitlines()), (name, "host map")
+        # the query counted on rank 0 only and sliced to the ranks (the default counts it over all ranks: cid_group_kmerset)
+        out, _ = _cli(*args, "--devices", "0,0,0", env={"COLORID_ONE_GPU_KMERS": "1"})
+        assert sorted(out.splitlines()) == sorted(base.splitlines()), (name, "rank-0 counting")
     # read_id: per-read rows in input order, identical files
     for tag, q in (("se", (f1,)), ("pe", (f1, f2))):
         _cli("read_id", "-b", pre + ".bxi", "-q", *q, "-n", str(tmp_path / f"one_{tag}"), "-c", "700", "-t", "8")
