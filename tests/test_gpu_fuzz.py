@@ -160,3 +160,80 @@ def test_kmerset_random_inputs(orc, hip_ctx, seed):
         ks.clean(t)
         assert ks.as_dict() == want.clean_map(t).as_dict()
     ks.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24)) // 2))
+def test_group_random_shapes(orc, seed):
+    """The same random shapes through the multi-rank calls (1-4 ranks sharing the one GPU): a replicated index with the query
+    sharded (cid_group_search_*), the k-mer set counted over the ranks (cid_group_kmerset + _search_*_parts), and the index cut into
+    colour stripes (cid_group_stripes_*: search, perfect search, read_id) — every result against the oracle on the whole index."""
+    import colorid_amd
+    from test_gpu_group_stripes import _striped
+    from test_gpu_readid import pack_reads
+    rng = np.random.default_rng(4000 + seed)
+    n_ranks = int(rng.integers(1, 5))
+    k = int(rng.choice([7, 16, 21, 31, 32]))
+    n_hash = int(rng.integers(1, 6))
+    C = int(rng.choice([64 * n_ranks, 64 * n_ranks + 1, 300, 513, 1000, 8300])) if n_ranks > 1 else int(rng.choice([1, 63, 300]))
+    C = max(C, 64 * (n_ranks - 1) + 1)                       # at least one 64-colour word per rank
+    m = int(rng.choice([1031, 4099, 30011]))
+    oix = orc.Index(m, n_hash, k, C)
+    for c in range(C):
+        oix.set_color(c, f"a{c}", 100)
+    genomes = [ACGT[rng.integers(0, 4, 3000)].tobytes() for _ in range(4)]
+    for gi, gen in enumerate(genomes):
+        km = orc.Kmers(k)
+        km.kmerize_vector(gen, 1)
+        for key in km.keys():
+            for c in {gi % C, (gi * 97 + 64) % C, C - 1 - gi % C}:
+                oix.insert(int(c), key.tobytes())
+    seqs = [genomes[int(rng.integers(0, 4))][int(s):int(s) + int(rng.integers(k, 400))] for s in rng.integers(0, 2500, 40)]
+    seqs += [ACGT[rng.integers(0, 4, 200)].tobytes() for _ in range(5)]          # k-mers the index has never seen
+    want_set = orc.Kmers(k)
+    for s in seqs:
+        want_set.kmerize_vector(s, 1)
+    keys, cnts = want_set.keys(), want_set.counts()
+    order = np.lexsort(keys.T[::-1])                                              # ascending, the device set's order
+    keys, cnts = keys[order], cnts[order]
+    want = oix.search_count(keys, cnts)
+    wp = oix.search_perfect(keys)
+    devices = [0] * n_ranks
+    # replicated index: host k-mers sharded; the set counted over the ranks and searched in parts
+    g = colorid_amd.Group(devices)
+    hx = colorid_amd.Index(g.ctxs[0], m, n_hash, k, C)
+    hx.put_dense(oix.rows()); hx.finalize(); g.replicate(hx)
+    got = g.search_count(keys, cnts.astype(np.uint32))
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    gs = g.kmerset(k)
+    gs.add_seqs(seqs[:17], 0); gs.add_seqs(seqs[17:], 0)
+    assert gs.finalize() == len(keys)
+    km, c2 = gs.download()
+    assert np.array_equal(km, keys) and np.array_equal(c2, cnts.astype(np.uint32))
+    got = gs.search_count()
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    gw, gm = gs.search_perfect()
+    assert gm == wp[1] and np.array_equal(gw, wp[0])
+    g.close()
+    # colour stripes
+    g = colorid_amd.Group(devices)
+    st = _striped(g, oix, via_records=bool(seed % 2))
+    got = st.search_count(keys, cnts.astype(np.uint32))
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    gw, gm = st.search_perfect(keys)
+    assert gm == wp[1] and np.array_equal(gw, wp[0])
+    one = keys[np.flatnonzero(want[0].sum() >= 0)[:1]] if len(keys) else keys
+    if len(one):
+        pw, pm = oix.search_perfect(one)
+        gw, gm = st.search_perfect(one)
+        assert gm == pm and np.array_equal(gw, pw)
+    if C <= 8192 * n_ranks and max(int(b) - int(a) for a, b in zip(st.base[:-1], st.base[1:])) <= 8192:
+        reads = [[s] if i % 3 else [s, seqs[(i + 1) % len(seqs)][:150]] for i, s in enumerate(seqs[:30])]
+        reads = [[x[:300] for x in r] for r in reads]
+        bases, seq_off, read_seq0 = pack_reads(reads)
+        d, S = int(rng.choice([1, 3])), int(rng.choice([0, 3]))
+        w = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+        rs, col, cnt, nk, stt = st.readid_count_sparse(bases, seq_off, read_seq0, d, S)
+        rows, cols = np.nonzero(w[0])
+        assert np.array_equal(nk, w[1]) and np.array_equal(stt, w[2])
+        assert np.array_equal(col, cols.astype(np.uint32)) and np.array_equal(cnt, w[0][rows, cols])
+    g.close()
