@@ -804,7 +804,7 @@ int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_code
 // LDS layout of k_readid (bytes_kernel = false) or k_readid_bytes for reads of at most max_bytes bases / max_win windows;
 // returns the bytes one wave needs (the kernels carve the same regions in the same order)
 static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                            bool bytes_kernel, cid::ReadIdParams &p) {
+                            bool bytes_kernel, cid::ReadIdParams &p, bool packed_table = false) {
     p = cid::ReadIdParams{};
     p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
     p.mod = ix->mod;
@@ -818,6 +818,14 @@ static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t sta
     p.hist_pad = wide ? 4u * ix->rs : ((ix->n_colors + 1 + 3) & ~3u);   // wide rows: AND word + sampled-colour set
     p.table_slots = 64;
     while (p.table_slots < p.win_cap + p.win_cap / 2) p.table_slots <<= 1;
+    size_t slot_bytes = 12;
+    if (packed_table) {   // one u64 per slot: code << idx_bits | window index
+        uint32_t ib = 1;
+        while ((1ull << ib) <= p.win_cap) ++ib;
+        if (2u * ix->k + ib > 63u) return ~(size_t)0;
+        p.idx_bits = ib;
+        slot_bytes = 8;
+    }
     const size_t chunk_rows = 4ull * cid::kWave * ix->n_hash;                     // one chunk's row numbers
     const size_t rall_bytes = wide ? 0 : 4ull * p.win_cap * ix->n_hash;           // rows of the read's distinct k-mers (wide rows search chunk by chunk)
     size_t wave_bytes = (size_t)p.bases_cap + rall_bytes;
@@ -827,7 +835,7 @@ static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t sta
     else if (wide)      // chunk rows, histogram, hash table keys + indices, 2-bit bases, bad-base bits
         wave_bytes += chunk_rows + 4ull * p.hist_pad + 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
     else                // the histogram shares the hash table's region (k_readid)
-        wave_bytes += (CID_READID_ALIAS ? std::max<size_t>(12ull * p.table_slots, 4ull * p.hist_pad) : 12ull * p.table_slots + 4ull * p.hist_pad) +
+        wave_bytes += (CID_READID_ALIAS ? std::max<size_t>(slot_bytes * p.table_slots, 4ull * p.hist_pad) : slot_bytes * p.table_slots + 4ull * p.hist_pad) +
                       4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
     wave_bytes = (wave_bytes + 15) & ~15ull;
     p.wave_bytes = (uint32_t)(wave_bytes < 0xFFFFFFF0ull ? wave_bytes : 0xFFFFFFF0ull);
@@ -850,17 +858,31 @@ static size_t kDenseReportBytes = getenv("CID_DENSE_REPORT_BYTES") ? strtoull(ge
 // reads, two waves, 30.3 vs 36.7 ms), so such reads are routed there.
 constexpr size_t kLdsReadBytesMax = kLdsBytes / 2;
 
+static bool kReadidPackedTable = getenv("CID_READID_PACKED_TABLE") ? atoi(getenv("CID_READID_PACKED_TABLE")) != 0 : true;   // cid_tune "readid_packed_table"
 static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                         bool bytes_kernel, cid::ReadIdParams &p, int &waves) {
-    const size_t wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, p);
-    // waves per workgroup: whatever puts the most waves on a CU (160 KiB of LDS, at most 8 workgroups of this size... 32 waves)
-    waves = 1;
-    size_t best = 0;
-    for (int w = 4; w >= 1; --w) {
-        if ((size_t)w * wave_bytes > kLdsBytes) continue;
-        size_t blocks = kLdsBytes / ((size_t)w * wave_bytes);
-        if (blocks > 32u / (size_t)w) blocks = 32u / (size_t)w;
-        if (blocks * (size_t)w > best) { best = blocks * (size_t)w; waves = w; }
+                         bool bytes_kernel, cid::ReadIdParams &p, int &waves, bool striped = false) {
+    size_t wave_bytes = 0, best = 0;
+    auto choose = [&](bool packed_table) {
+        wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, p, packed_table);
+        // waves per workgroup: whatever puts the most waves on a CU (160 KiB of LDS, at most 8 workgroups of this size... 32 waves)
+        waves = 1;
+        best = 0;
+        if (wave_bytes == ~(size_t)0) return;
+        for (int w = 4; w >= 1; --w) {
+            if ((size_t)w * wave_bytes > kLdsBytes) continue;
+            size_t blocks = kLdsBytes / ((size_t)w * wave_bytes);
+            if (blocks > 32u / (size_t)w) blocks = 32u / (size_t)w;
+            if (blocks * (size_t)w > best) { best = blocks * (size_t)w; waves = w; }
+        }
+    };
+    // the 8-byte-per-slot set is built for the six-waves-per-SIMD kernel only (whole k-mers, published hash, rows <= 1 KiB, no stripe
+    // passes): taken when the 12-byte slots leave fewer than six waves per SIMD and the 8-byte ones reach them (paired 150-bp reads,
+    // k <= 27: 10.6 -> 10.1 ms per million pairs, tools/exp_readid_table.py)
+    const bool can_pack = !bytes_kernel && kReadidPackedTable && ix->rs <= 128 && !ix->m_size && ix->k <= 31 && ((ix->mod.flags >> 8) & 0xFFu) == CID_HASH_XXH3_V08 && !striped;
+    choose(false);
+    if (best < 24 && can_pack) {   // (where six waves per SIMD fit anyway the 12-byte slots are marginally faster: 6.02 vs 6.07 ms single-end)
+        choose(true);
+        if (best < 24) choose(false);
     }
     if (wave_bytes > kLdsBytes)
         return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %zu B of LDS per wave (> 160 KiB): "
@@ -885,7 +907,7 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
     int rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, true, pb, waves_b);
     if (rc) return rc;
     const bool packable = ix->k <= 32;
-    if (packable && (rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, false, pp, waves_p))) return rc;
+    if (packable && (rc = readid_params(ix, stride_d, start_sample, max_read_bytes, max_read_windows, false, pp, waves_p, sa.zero_acc || sa.zero_in))) return rc;
     HIP_TRY(hipSetDevice(c->device));
     auto fill = [&](cid::ReadIdParams &p, int waves) {
         p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
@@ -1163,6 +1185,7 @@ int cid_tune(const char *name, long value) {
     if (!strcmp(name, "search_persist")) { kSearchPersist = value != 0; return CID_OK; }
     if (!strcmp(name, "search_mixed")) { kSearchMixed = value != 0; return CID_OK; }
     if (!strcmp(name, "search_unroll")) { kSearchUnroll = (int)value; return CID_OK; }
+    if (!strcmp(name, "readid_packed_table")) { kReadidPackedTable = value != 0; return CID_OK; }
     if (!strcmp(name, "order_bits")) { if (value < 0 || value > 32) return fail(CID_ERR_INVALID, "order_bits 0..32"); cid::g_order_bits = (int)value; return CID_OK; }
     return fail(CID_ERR_INVALID, "unknown tunable '%s'", name);
 }

@@ -292,3 +292,36 @@ def test_readid_more_than_two_mates(orc, phage):
     reads.append([b"ACG", genomes[1][:150], genomes[1][200:350]])       # first mate too short -> too_short whatever follows
     for d, S in ((1, 3), (1, 0), (7, 2)):
         check(oix, hx, reads, d, S)
+
+
+@pytest.mark.parametrize("packed", [0, 1])
+@pytest.mark.parametrize("k,n_colors", [(21, 256), (27, 100), (9, 300)])
+def test_readid_set_slot_layouts_are_bit_exact(orc, hip_ctx, packed, k, n_colors):
+    """k_readid's per-read k-mer set with 12-byte slots and with one u64 per slot (code << idx_bits | first window index; taken for
+    read pairs whose 12-byte table would cost the sixth wave per SIMD; cid_tune "readid_packed_table"): paired 150-bp reads with
+    repeats (the same k-mer in both mates: the earlier window must win), N runs, short mates — against the oracle."""
+    from colorid_amd._lib import check as cid_check
+    rng = np.random.default_rng(k * 100 + n_colors + packed)
+    genomes = [bytes(rng.choice(list(b"ACGT"), size=5000).astype(np.uint8)) for _ in range(6)]
+    oix = orc.Index(50_021, 2, k, n_colors)
+    for c in range(n_colors):
+        oix.set_color(c, f"a{c}", 500)
+    for gi, gen in enumerate(genomes):
+        km = orc.Kmers(k)
+        km.kmerize_vector(gen, 1)
+        for key in km.keys():
+            oix.insert(gi, key.tobytes())
+            oix.insert(n_colors - 1 - gi, key.tobytes())
+    reads = sample_reads(orc, rng, genomes, 400, 150, True)
+    g0 = genomes[0]
+    reads.append([g0[100:250], g0[100:250]])                       # both mates identical: every k-mer twice
+    reads.append([g0[100:250], g0[180:330]])                       # overlapping mates
+    reads.append([(g0[300:320] * 8)[:150], (g0[300:320] * 8)[:150]])   # a 20-base period: few distinct k-mers, many windows
+    hx = to_hip_index(hip_ctx, oix)
+    cid_check(hip_ctx.lib.cid_tune(b"readid_packed_table", packed))
+    try:
+        for d, S in ((1, 3), (1, 0), (2, 5)):
+            check(oix, hx, reads, d, S)
+    finally:
+        cid_check(hip_ctx.lib.cid_tune(b"readid_packed_table", 1))
+    hx.close()
