@@ -881,8 +881,9 @@ static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_
     const bool can_pack = !bytes_kernel && kReadidPackedTable && ix->rs <= 128 && !ix->m_size && ix->k <= 31 && ((ix->mod.flags >> 8) & 0xFFu) == CID_HASH_XXH3_V08 && !striped;
     choose(false);
     if (best < 24 && can_pack) {   // (where six waves per SIMD fit anyway the 12-byte slots are marginally faster: 6.02 vs 6.07 ms single-end)
+        const size_t classic = best;
         choose(true);
-        if (best < 24) choose(false);
+        if (best <= classic || best <= 20) choose(false);   // worth it only with more waves than the 96-VGPR (5 per SIMD) build runs
     }
     if (wave_bytes > kLdsBytes)
         return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %zu B of LDS per wave (> 160 KiB): "

@@ -708,7 +708,7 @@ hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t
     const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
     if (p.zero_acc || p.zero_in)
         return p.m_size ? launch_readid_packed_striped<true>(p, waves_per_block, grid, stream) : launch_readid_packed_striped<false>(p, waves_per_block, grid, stream);
-    const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block >= 24 &&   // 6 waves per SIMD fit
+    const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block > 20 &&   // more waves fit a CU than the 96-VGPR build can run (5 per SIMD)
                        ((p.mod.flags >> 8) & 0xFFu) == kHashV08;
     if (p.idx_bits) return dense && !p.m_size ? launch_readid_packed_table(p, waves_per_block, grid, stream) : hipErrorInvalidValue;   // (the host lays the 8-byte slots out only then)
     if (p.m_size)

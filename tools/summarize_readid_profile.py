@@ -28,7 +28,7 @@ md = f"""# {tag}: k_readid on MI355X — rocprofv3 evidence
 
 `tools/profile_readid.sh`: `rocprofv3 --kernel-trace --stats -- python3 tools/bench_readid.py --check 0`, PMC in separate passes.
 Workload: BASELINE.json configs[2] shape — m = {b['config']['m']:,}, n = {b['config']['n']}, k = {b['config']['k']}, C = {b['config']['C']},
-{b['reads']:,} synthetic 150-bp single-end reads resident in HBM, `read_id -d {b['d']} -B {b['B']}`.
+{b['reads']:,} synthetic 150-bp {'read PAIRS' if b.get('paired') else 'single-end reads'} resident in HBM, `read_id -d {b['d']} -B {b['B']}`.
 
 | quantity | value |
 |---|---|
