@@ -92,6 +92,7 @@ SIGNATURES = {
     "cid_group_kmerset_download": (C.c_int, [vp, vp, vp]),
     "cid_group_kmerset_destroy": (None, [vp]),
     "cid_group_search_count_parts": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
+    "cid_group_search_count_parts_report": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
     "cid_group_search_perfect_parts": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.POINTER(C.c_int)]),
     "cid_group_stripes_create": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "cid_group_stripes_base": (C.c_int, [vp, C.POINTER(vp), vp]),

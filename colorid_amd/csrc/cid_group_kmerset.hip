@@ -309,6 +309,63 @@ int cid_group_search_count_parts(cid_group *g, cid_index *const *replicas, const
     return CID_OK;
 }
 
+// The same with everything reports::generate_report prints and nothing per k-mer (the group form of cid_search_count_set_report):
+// every rank also reduces its part's unique hits to a (colour, multiplicity) histogram on the device; the histograms add up on the
+// host and give the mode per colour (ties -> the smallest multiplicity, as on one GPU).
+int cid_group_search_count_parts_report(cid_group *g, cid_index *const *replicas, const cid_group_kmerset *s, uint64_t *hits, uint64_t *n_unique,
+                                        uint64_t *sum_unique_freq, uint64_t *mode_unique_freq) {
+    int rc = check_replicas(g, replicas);
+    if (rc) return rc;
+    if ((rc = check_set(s, true))) return rc;
+    if (s->g != g) return fail(CID_ERR_INVALID, "the k-mer set belongs to another group");
+    if (!hits || !n_unique || !sum_unique_freq || !mode_unique_freq) return fail(CID_ERR_INVALID, "null argument");
+    if (s->k != replicas[0]->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", s->k, replicas[0]->k);
+    const int n = (int)g->ctx.size();
+    const size_t C = replicas[0]->n_colors;
+    std::vector<uint64_t *> d_out(n, nullptr);
+    std::vector<std::vector<uint64_t>> keys(n);
+    std::vector<std::vector<uint32_t>> cnts(n);
+    rc = for_each_rank(g, [&](int r) -> int {
+        cid_ctx *c = g->ctx[r];
+        View v;
+        int e = view_of(s->part[r], v); if (e) return e;
+        HIP_TRY(hipSetDevice(c->device));
+        void *d_o, *d_uc;
+        e = cid::slot_reserve(c, S_OUT, 3 * C * 8, &d_o); if (e) return e;
+        e = cid::slot_reserve(c, S_UC, (v.n ? v.n : 1) * 4, &d_uc); if (e) return e;
+        uint64_t *o = (uint64_t *)d_o;
+        e = cid::search_count_launch(c, replicas[r], nullptr, v.codes, v.counts, v.n, o, o + C, o + 2 * C, (uint32_t *)d_uc);
+        if (e) return e;
+        e = cid::unique_freq_hist(c, (const uint32_t *)d_uc, v.counts, v.n, keys[r], cnts[r]);
+        d_out[r] = o;
+        return e;
+    });
+    if (rc) return rc;
+    if ((rc = allreduce_sum(g, reinterpret_cast<void *const *>(d_out.data()), 3 * C, 8))) return rc;
+    cid_ctx *c0 = g->ctx[0];
+    HIP_TRY(hipSetDevice(c0->device));
+    HIP_TRY(hipMemcpyAsync(hits, d_out[0], C * 8, hipMemcpyDeviceToHost, c0->stream));
+    HIP_TRY(hipMemcpyAsync(n_unique, d_out[0] + C, C * 8, hipMemcpyDeviceToHost, c0->stream));
+    HIP_TRY(hipMemcpyAsync(sum_unique_freq, d_out[0] + 2 * C, C * 8, hipMemcpyDeviceToHost, c0->stream));
+    HIP_TRY(hipStreamSynchronize(c0->stream));
+    // merge the ranks' sorted histograms; per colour the multiplicity with the most k-mers (keys ascend, so the first maximum is the smallest)
+    std::vector<std::pair<uint64_t, uint64_t>> all;
+    for (int r = 0; r < n; ++r)
+        for (size_t i = 0; i < keys[r].size(); ++i) all.emplace_back(keys[r][i], (uint64_t)cnts[r][i]);
+    std::sort(all.begin(), all.end());
+    for (size_t c = 0; c < C; ++c) mode_unique_freq[c] = 0;
+    std::vector<uint64_t> best(C, 0);
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i;
+        uint64_t tot = 0;
+        while (j < all.size() && all[j].first == all[i].first) tot += all[j++].second;
+        const uint64_t col = all[i].first >> 32, f = all[i].first & 0xFFFFFFFFull;
+        if (col < C && tot > best[col]) { best[col] = tot; mode_unique_freq[col] = f; }
+        i = j;
+    }
+    return CID_OK;
+}
+
 // a4 over the parts: AND of the ranks' words on the host (empty parts are neutral)
 int cid_group_search_perfect_parts(cid_group *g, cid_index *const *replicas, const cid_group_kmerset *s, uint32_t *and_words_le, int *any_row_missing) {
     int rc = check_replicas(g, replicas);

@@ -1258,6 +1258,53 @@ int cid_unique_freq_modes_dev(cid_ctx *c, const uint32_t *d_unique_colour, const
     return cid::unique_freq_modes(c, d_unique_colour, d_freq, n_kmers, n_colors, d_modes);
 }
 
+}  // extern "C"
+
+namespace cid {
+__global__ void k_colour_freq_keys(const uint32_t *uc, const uint32_t *freq, uint64_t n, uint64_t *keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = uc[i];
+    keys[i] = c == 0xFFFFFFFFu ? ~0ull : (((uint64_t)c << 32) | (freq ? freq[i] : 1u));
+}
+// The (colour, multiplicity) histogram of the k-mers that hit exactly one colour, as sorted keys colour << 32 | multiplicity with
+// the number of k-mers each: what the mode of reports.rs:65-77 is taken from, in a form that ADDS over disjoint parts of a k-mer set
+// (a mode does not) — cid_group_search_count_parts_report merges the ranks' histograms.  Host vectors; synchronous.
+int unique_freq_hist(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, std::vector<uint64_t> &keys, std::vector<uint32_t> &counts) {
+    keys.clear(); counts.clear();
+    if (n == 0) return CID_OK;
+    if (n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 - 1 k-mers in one part");
+    HIP_TRY(hipSetDevice(ctx_device(c)));
+    hipStream_t st = ctx_stream(c);
+    DevBuf<uint64_t> kin(c), kout(c), uniq(c), d_count(c);
+    DevBuf<uint32_t> runs(c);
+    int rc;
+    if ((rc = kin.alloc(n)) || (rc = kout.alloc(n)) || (rc = uniq.alloc(n)) || (rc = runs.alloc(n)) || (rc = d_count.alloc(1))) return rc;
+    hipLaunchKernelGGL(k_colour_freq_keys, dim3(grid_for_n(n)), dim3(256), 0, st, d_uc, d_freq, n, kin.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, kin.p, kout.p, n, 0u, 64u, st));
+    DevBuf<uint8_t> tmp(c);
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, kin.p, kout.p, n, 0u, 64u, st));
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::run_length_encode(nullptr, tb2, kout.p, n, uniq.p, runs.p, d_count.p, st));
+    DevBuf<uint8_t> tmp2(c);
+    if ((rc = tmp2.alloc(tb2))) return rc;
+    HIP_TRY(rocprim::run_length_encode(tmp2.p, tb2, kout.p, n, uniq.p, runs.p, d_count.p, st));
+    uint64_t nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, d_count.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    keys.resize(nb); counts.resize(nb);
+    HIP_TRY(hipMemcpyAsync(keys.data(), uniq.p, nb * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(counts.data(), runs.p, nb * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (nb && keys.back() == ~0ull) { keys.pop_back(); counts.pop_back(); }   // the k-mers without a unique colour
+    return CID_OK;
+}
+}  // namespace cid
+
+extern "C" {
+
 // a5 over a finalized set with everything reports::generate_report needs (reports.rs:8-48) and nothing per k-mer: hits, the number
 // of unique-hit k-mers, the sum of their multiplicities (-> mean) and their mode, n_colors values each
 int cid_search_count_set_report(cid_ctx *c, const cid_index *ix, const cid_kmerset *ks, uint64_t *hits, uint64_t *n_unique,

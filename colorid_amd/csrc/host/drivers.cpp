@@ -410,6 +410,10 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
                 modes.assign(C, 0);
                 have_modes = true;
                 CID_TRY(cid_search_count_set_report(ctx, b.index, ks.one, hits.data(), n_unique.data(), sum_freq.data(), modes.data()));
+            } else if (!gene_search && ks.many) {   // the same over the ranks' parts: the (colour, multiplicity) histograms add up
+                modes.assign(C, 0);
+                have_modes = true;
+                CID_TRY(cid_group_search_count_parts_report(g_group, g_replicas.data(), ks.many, hits.data(), n_unique.data(), sum_freq.data(), modes.data()));
             } else {
                 if (!gene_search) { uc.resize(n_kmers); counts.resize(n_kmers); }
                 CID_TRY(hot_search_count_gpuset(ctx, b, ks, hits.data(), gene_search ? nullptr : n_unique.data(),

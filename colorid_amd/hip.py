@@ -542,6 +542,13 @@ class GroupKmerSet:
         check(self.lib.cid_group_search_count_parts(self.g.h, arr, self.h, _p(hits), _p(nu), _p(sf), _p(uc)))
         return hits, nu, sf, uc
 
+    def search_count_report(self):
+        """hits, n_unique, sum_unique_freq, mode_unique_freq per colour; nothing per k-mer leaves the GPUs"""
+        arr, ix = self.g._idx()
+        hits, nu, sf, md = (np.zeros(ix.n_colors, np.uint64) for _ in range(4))
+        check(self.lib.cid_group_search_count_parts_report(self.g.h, arr, self.h, _p(hits), _p(nu), _p(sf), _p(md)))
+        return hits, nu, sf, md
+
     def search_perfect(self):
         arr, ix = self.g._idx()
         words = np.zeros(ix.w32, np.uint32)

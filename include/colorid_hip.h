@@ -294,6 +294,10 @@ int cid_group_kmerset_download(const cid_group_kmerset *, uint8_t *kmers_ascii, 
 void cid_group_kmerset_destroy(cid_group_kmerset *);
 int cid_group_search_count_parts(cid_group *, cid_index *const *replicas, const cid_group_kmerset *, uint64_t *hits, uint64_t *n_unique,
                                  uint64_t *sum_unique_freq, uint32_t *unique_colour);
+/* the group form of cid_search_count_set_report: per colour hits, unique k-mers, their multiplicities' sum and MODE; nothing per k-mer
+ * leaves the GPUs (every rank reduces its part to a (colour, multiplicity) histogram, the histograms add up on the host) */
+int cid_group_search_count_parts_report(cid_group *, cid_index *const *replicas, const cid_group_kmerset *, uint64_t *hits, uint64_t *n_unique,
+                                        uint64_t *sum_unique_freq, uint64_t *mode_unique_freq);
 int cid_group_search_perfect_parts(cid_group *, cid_index *const *replicas, const cid_group_kmerset *, uint32_t *and_words_le, int *any_row_missing);
 
 /* ---- colour stripes over a group (BASELINE configs[4]): rank r holds the colours [base_r, base_{r+1}) of EVERY row —

@@ -211,6 +211,9 @@ def test_group_random_shapes(orc, seed):
     assert np.array_equal(km, keys) and np.array_equal(c2, cnts.astype(np.uint32))
     got = gs.search_count()
     assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    hits, nu, sf, md = gs.search_count_report()
+    assert np.array_equal(hits, want[0]) and np.array_equal(nu, want[1]) and np.array_equal(sf, want[2])
+    assert np.array_equal(md, orc.unique_modes(want[3], cnts, C))
     gw, gm = gs.search_perfect()
     assert gm == wp[1] and np.array_equal(gw, wp[0])
     g.close()

@@ -91,6 +91,11 @@ def test_group_search_over_parts_equals_single_set_and_oracle(orc, hip_ctx, devi
     pw, pm = oix.search_perfect(km)
     gw, gm = gs.search_perfect()
     assert gm == pm and np.array_equal(gw, pw)
+    # the whole report without anything per k-mer: the ranks' (colour, multiplicity) histograms added up -> the modes
+    modes = orc.unique_modes(want[3], cnt.astype(np.uint64), C)
+    hits, nu, sf, md = gs.search_count_report()
+    assert np.array_equal(hits, want[0]) and np.array_equal(nu, want[1]) and np.array_equal(sf, want[2]) and np.array_equal(md, modes)
+    assert (want[1] > 0).sum() > 10 and len(set(md.tolist())) > 1
     # a set whose k-mers all sit in two colours: a perfect hit over parts held by different ranks
     sub = seqs[:5]
     gs2 = g.kmerset(k)

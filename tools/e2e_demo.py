@@ -78,6 +78,17 @@ res["read_id_pe_bgzf_total_s"] = dt
 res["read_id_pe_bgzf_stderr"] = [l.split("\r")[-1] for l in err.splitlines() if "Classified" in l or "timing:" in l]
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.bgzf.fastq.gz", "-g", "-f", "0", "-p", "0.005")
 res["search_g_bgzf_total_s"] = dt
+if G >= 128 and os.environ.get("E2E_GROUPS", "1") != "0":
+    # the multi-rank call sequences at this size (two ranks share the one GPU here, so this shows overhead and agreement, not speed-up):
+    # index replicated + the query's k-mers counted over the ranks; index cut into colour stripes
+    base = sorted(run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-f", "0", "-p", "0.005")[1].splitlines())
+    for tag, extra in (("replicated_2ranks", ("--devices", "0,0")), ("striped_2ranks", ("--devices", "0,0", "--placement", "striped"))):
+        dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-f", "0", "-p", "0.005", *extra)
+        res[f"search_default_{tag}_s"] = dt
+        res[f"search_default_{tag}_same_rows"] = sorted(out.splitlines()) == base
+        dt, out, err = run("read_id", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-n", f"{W}/rid_{tag}", *extra)
+        res[f"read_id_{tag}_s"] = dt
+        res[f"read_id_{tag}_same_rows"] = open(f"{W}/rid_{tag}_reads.txt").read() == open(f"{W}/rid_reads.txt").read()
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/g007.fasta", "-s")
 res["search_s_total_s"] = dt; res["search_s_out"] = out.strip().splitlines()[-1] if out.strip() else ""
 print(json.dumps(res))
