@@ -100,6 +100,7 @@ SIGNATURES = {
     "cid_group_stripes_put_rows": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t]),
     "cid_group_stripes_search_count": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, vp, vp, vp]),
     "cid_group_stripes_search_count_set": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
+    "cid_group_stripes_search_count_set_report": (C.c_int, [vp, C.POINTER(vp), vp, vp, vp, vp, vp]),
     "cid_group_stripes_search_perfect": (C.c_int, [vp, C.POINTER(vp), vp, C.c_size_t, vp, C.POINTER(C.c_int)]),
     "cid_group_stripes_search_perfect_set": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.POINTER(C.c_int)]),
     "cid_group_stripes_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,

@@ -153,12 +153,12 @@ int query_from_set(const cid_kmerset *ks, uint32_t index_k, Query &q) {
 }
 
 int stripes_search_count(cid_group *g, cid_index *const *stripes, const Query &q, uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq,
-                         uint32_t *unique_colour) {
+                         uint32_t *unique_colour, uint64_t *mode_unique_freq = nullptr) {
     Stripes st;
     int rc = check_stripes(g, stripes, st);
     if (rc) return rc;
     if (!hits) return fail(CID_ERR_INVALID, "null argument");
-    const bool want_unique = n_unique || sum_unique_freq || unique_colour;
+    const bool want_unique = n_unique || sum_unique_freq || unique_colour || mode_unique_freq;
     const size_t K = q.n;
     std::vector<uint32_t *> d_fact(st.n, nullptr);
     rc = for_each_rank(g, [&](int r) -> int {
@@ -197,6 +197,19 @@ int stripes_search_count(cid_group *g, cid_index *const *stripes, const Query &q
     void *d_uc;
     rc = cid::ctx_alloc(c0, (K ? K : 1) * 4, &d_uc); if (rc) return rc;
     rc = cid_search_unique_finalize_dev(c0, d_fact[0], d_freq, K, st.total, d_nu, d_sf, (uint32_t *)d_uc);
+    if (rc == CID_OK && mode_unique_freq) {   // the report's mode per colour, on rank 0's device: nothing per k-mer goes to the host
+        void *d_modes;
+        rc = cid::ctx_alloc(c0, (size_t)st.total * 8, &d_modes);
+        if (rc == CID_OK) {
+            rc = cid::unique_freq_modes(c0, (const uint32_t *)d_uc, d_freq, K, st.total, (uint64_t *)d_modes);
+            if (rc == CID_OK) {
+                hipError_t e = hipMemcpyAsync(mode_unique_freq, d_modes, (size_t)st.total * 8, hipMemcpyDeviceToHost, c0->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
+                if (e != hipSuccess) rc = fail(CID_ERR_HIP, "striped report: %s", hipGetErrorString(e));
+            }
+            cid::ctx_free(c0, d_modes);
+        }
+    }
     if (rc == CID_OK) {
         hipError_t e = hipSuccess;
         if (n_unique) e = hipMemcpyAsync(n_unique, d_nu, (size_t)st.total * 8, hipMemcpyDeviceToHost, c0->stream);
@@ -335,6 +348,15 @@ int cid_group_stripes_search_count_set(cid_group *g, cid_index *const *stripes, 
     const int rc = query_from_set(ks, stripes[0]->k, q);
     if (rc) return rc;
     return stripes_search_count(g, stripes, q, hits, n_unique, sum_unique_freq, unique_colour);
+}
+
+int cid_group_stripes_search_count_set_report(cid_group *g, cid_index *const *stripes, const cid_kmerset *ks, uint64_t *hits, uint64_t *n_unique,
+                                              uint64_t *sum_unique_freq, uint64_t *mode_unique_freq) {
+    if (!g || !stripes || !stripes[0] || !mode_unique_freq) return fail(CID_ERR_INVALID, "null argument");
+    Query q;
+    const int rc = query_from_set(ks, stripes[0]->k, q);
+    if (rc) return rc;
+    return stripes_search_count(g, stripes, q, hits, n_unique, sum_unique_freq, nullptr, mode_unique_freq);
 }
 
 int cid_group_stripes_search_perfect(cid_group *g, cid_index *const *stripes, const uint8_t *kmers, size_t n_kmers, uint32_t *and_words_le,

@@ -47,6 +47,8 @@ int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_code
 int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, const uint32_t **counts, uint64_t *n, uint32_t *k);
 // replace a finalized 2-bit-code set's contents by the merge (sort by code, add counts of equal codes) of `total` pairs on its device
 int kmerset_assign_merged(cid_kmerset *ks, const uint64_t *d_codes_in, const uint32_t *d_counts_in, size_t total);
+// d_modes[c] = the most frequent multiplicity among the k-mers whose unique colour is c (ties -> the smallest; 0 = none); asynchronous
+int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes);
 // sorted (colour << 32 | multiplicity) keys and their k-mer counts over the k-mers with a unique colour (host vectors; synchronous)
 int unique_freq_hist(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, std::vector<uint64_t> &keys, std::vector<uint32_t> &counts);
 int kmerset_view_ascii(const cid_kmerset *ks, cid_ctx **ctx, const uint8_t **ascii, const uint32_t **counts, uint64_t *n, uint32_t *k);   // k > 32 sets

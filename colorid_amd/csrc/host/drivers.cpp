@@ -410,6 +410,10 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
                 modes.assign(C, 0);
                 have_modes = true;
                 CID_TRY(cid_search_count_set_report(ctx, b.index, ks.one, hits.data(), n_unique.data(), sum_freq.data(), modes.data()));
+            } else if (!gene_search && g_striped && ks.one) {   // the same over colour stripes: the report is finished on rank 0's device
+                modes.assign(C, 0);
+                have_modes = true;
+                CID_TRY(cid_group_stripes_search_count_set_report(g_group, g_replicas.data(), ks.one, hits.data(), n_unique.data(), sum_freq.data(), modes.data()));
             } else if (!gene_search && ks.many) {   // the same over the ranks' parts: the (colour, multiplicity) histograms add up
                 modes.assign(C, 0);
                 have_modes = true;

@@ -444,6 +444,11 @@ class GroupStripes:
         check(self.lib.cid_group_stripes_search_count_set(self.g.h, self.arr, kmerset.h, _p(hits), _p(nu), _p(sf), _p(uc)))
         return hits, nu, sf, uc
 
+    def search_count_set_report(self, kmerset):
+        hits, nu, sf, md = (np.zeros(self.n_colors, np.uint64) for _ in range(4))
+        check(self.lib.cid_group_stripes_search_count_set_report(self.g.h, self.arr, kmerset.h, _p(hits), _p(nu), _p(sf), _p(md)))
+        return hits, nu, sf, md
+
     def search_perfect(self, kmers):
         kmers = np.ascontiguousarray(kmers, np.uint8).reshape(-1, self.k)
         words = np.zeros(self.w32, np.uint32)

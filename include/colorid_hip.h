@@ -319,6 +319,9 @@ int cid_group_stripes_search_count(cid_group *, cid_index *const *stripes, const
                                    uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
 int cid_group_stripes_search_count_set(cid_group *, cid_index *const *stripes, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
                                        uint64_t *sum_unique_freq, uint32_t *unique_colour);
+/* the striped form of cid_search_count_set_report (per colour hits, unique k-mers, sum and MODE of their multiplicities) */
+int cid_group_stripes_search_count_set_report(cid_group *, cid_index *const *stripes, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
+                                              uint64_t *sum_unique_freq, uint64_t *mode_unique_freq);
 int cid_group_stripes_search_perfect(cid_group *, cid_index *const *stripes, const uint8_t *kmers, size_t n_kmers, uint32_t *and_words_le,
                                      int *any_row_missing);
 int cid_group_stripes_search_perfect_set(cid_group *, cid_index *const *stripes, const cid_kmerset *, uint32_t *and_words_le, int *any_row_missing);

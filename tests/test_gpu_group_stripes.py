@@ -76,6 +76,9 @@ def test_striped_group_search_equals_oracle(orc, devices, n_colors, k, via_recor
     w = oix.search_count(km, cnt.astype(np.uint64))
     x = st.search_count_set(ks)
     assert all(np.array_equal(a, b) for a, b in zip(w, x))
+    hits, nu, sf, md = st.search_count_set_report(ks)          # the report finished on rank 0's device (mode per colour)
+    assert np.array_equal(hits, w[0]) and np.array_equal(nu, w[1]) and np.array_equal(sf, w[2])
+    assert np.array_equal(md, orc.unique_modes(w[3], cnt.astype(np.uint64), n_colors))
     pw, pm = oix.search_perfect(km)
     gw, gm = st.search_perfect_set(ks)
     assert gm == pm and np.array_equal(gw, pw)
