@@ -49,6 +49,10 @@ SIGNATURES = {
     "cid_readid_stripe_zero_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "cid_readid_stripe_count_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32,
                                               C.c_int, vp, vp, vp, vp]),
+    "cid_readid_stripe_mask_words": (C.c_int, [C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "cid_readid_stripe_zero": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, vp, vp, vp]),
+    "cid_readid_stripe_count": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                          vp, vp, vp, vp]),
     "cid_kmerset_create": (C.c_int, [vp, C.c_uint32, C.POINTER(vp)]),
     "cid_kmerset_add_seqs": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int]),
     "cid_kmerset_finalize": (C.c_int, [vp, C.POINTER(C.c_uint64)]),

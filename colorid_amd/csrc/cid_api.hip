@@ -892,11 +892,7 @@ static int readid_params(const cid_index *ix, uint32_t stride_d, uint32_t start_
     return CID_OK;
 }
 
-struct StripeArgs {   // read_id over colour stripes (ReadIdParams::zero_acc ...); all zero = a whole index
-    uint32_t *zero_acc = nullptr;
-    const uint32_t *zero_in = nullptr;
-    uint32_t zero_stride = 0, colour_base = 0, report_width = 0, write_nohits = 0;
-};
+using StripeArgs = cid::StripePass;
 
 static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off,
                            const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
@@ -913,7 +909,7 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
     auto fill = [&](cid::ReadIdParams &p, int waves) {
         p.bases = d_bases; p.seq_off = d_seq_off; p.read_seq0 = d_read_seq0; p.n_reads = n_reads;
         p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status; p.skip = d_skip;
-        p.zero_acc = sa.zero_acc; p.zero_in = sa.zero_in; p.zero_stride = sa.zero_stride;
+        p.zero_acc = sa.zero_acc; p.zero_in = sa.zero_in; p.zero_start = sa.zero_start;
         p.colour_base = sa.colour_base; p.report_width = sa.report_width; p.write_nohits = sa.write_nohits;
         uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
         if (rpb < (uint64_t)waves) rpb = waves;
@@ -970,29 +966,42 @@ int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases
 // Pass 1, once per stripe: d_zero_acc[read * max_read_windows + q] &= the seeds whose row is all-zero in this stripe, for the
 // read's q-th distinct k-mer (first-occurrence order).  Between the passes the caller ANDs the arrays of different GPUs.
 // Pass 2, once per stripe: the ordered count; a k-mer is "absent" iff its accumulated mask is non-zero.
+__global__ void k_mask_starts(uint64_t *zero_start, uint64_t n_reads, uint64_t stride) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) zero_start[r] = r * stride;
+}
+// the device-pointer pair: masks laid out [read][max_read_windows]
 static int readid_stripe_common(cid_ctx *c, const cid_index *ix, const void *d_bases, const void *d_seq_off, const void *d_read_seq0,
-                                uint64_t max_read_bytes, uint64_t max_read_windows) {
+                                size_t n_reads, uint64_t max_read_bytes, uint64_t max_read_windows, const uint64_t **d_zero_start) {
     int rc = check_ready(c, ix);
     if (rc) return rc;
     if (!d_bases || !d_seq_off || !d_read_seq0) return fail(CID_ERR_INVALID, "null argument");
-    if (ix->rs > 128) return fail(CID_ERR_UNSUPPORTED, "read_id over stripes wider than 8192 colours is not built: use narrower stripes");
     if (max_read_windows == 0 || max_read_windows > (1u << 20)) return fail(CID_ERR_INVALID, "max_read_windows out of range");
     if (readid_need(ix, 1, 0, max_read_bytes, max_read_windows) > kLdsBytes)
-        return fail(CID_ERR_UNSUPPORTED, "reads of %llu bases do not fit a wave's LDS: read_id over stripes handles short reads only",
+        return fail(CID_ERR_UNSUPPORTED, "reads of %llu bases do not fit a wave's LDS: cid_readid_stripe_zero / _count route such reads through the sort-based path",
                     (unsigned long long)max_read_bytes);
+    *d_zero_start = nullptr;
+    if (n_reads == 0) return CID_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    void *d_zs;
+    rc = slot_reserve(c, S_ZSTART, n_reads * 8, &d_zs); if (rc) return rc;
+    hipLaunchKernelGGL(k_mask_starts, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream, (uint64_t *)d_zs, (uint64_t)n_reads, max_read_windows);
+    HIP_TRY(hipGetLastError());
+    *d_zero_start = (const uint64_t *)d_zs;
     return CID_OK;
 }
 
 int cid_readid_stripe_zero_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0,
                                size_t n_reads, uint32_t stride_d, uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_zero_acc,
                                uint32_t *d_n_kmers, uint8_t *d_status) {
-    int rc = readid_stripe_common(c, ix, d_bases, d_seq_off, d_read_seq0, max_read_bytes, max_read_windows);
+    const uint64_t *d_zs;
+    int rc = readid_stripe_common(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, max_read_bytes, max_read_windows, &d_zs);
     if (rc) return rc;
     if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
     if (n_reads == 0) return CID_OK;
     if (!d_zero_acc || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
     StripeArgs sa;
-    sa.zero_acc = d_zero_acc; sa.zero_stride = (uint32_t)max_read_windows; sa.report_width = ix->n_colors + 1;
+    sa.zero_acc = d_zero_acc; sa.zero_start = d_zs; sa.report_width = ix->n_colors + 1;
     return readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, 0, max_read_bytes, max_read_windows, nullptr, false,
                            reinterpret_cast<uint32_t *>(d_zero_acc) /* never written in this pass */, d_n_kmers, d_status, sa);
 }
@@ -1001,31 +1010,29 @@ int cid_readid_stripe_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *
                                 size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint64_t max_read_bytes, uint64_t max_read_windows,
                                 uint32_t colour_base, uint32_t n_colors_total, int write_nohits, const uint32_t *d_zero_acc, uint32_t *d_report,
                                 uint32_t *d_n_kmers, uint8_t *d_status) {
-    int rc = readid_stripe_common(c, ix, d_bases, d_seq_off, d_read_seq0, max_read_bytes, max_read_windows);
+    const uint64_t *d_zs;
+    int rc = readid_stripe_common(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, max_read_bytes, max_read_windows, &d_zs);
     if (rc) return rc;
     if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
     if ((uint64_t)colour_base + ix->n_colors > n_colors_total) return fail(CID_ERR_INVALID, "stripe [%u, +%u) outside %u colours", colour_base, ix->n_colors, n_colors_total);
     if (n_reads == 0) return CID_OK;
     if (!d_zero_acc || !d_report || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
     StripeArgs sa;
-    sa.zero_in = d_zero_acc; sa.zero_stride = (uint32_t)max_read_windows; sa.colour_base = colour_base; sa.report_width = n_colors_total + 1;
+    sa.zero_in = d_zero_acc; sa.zero_start = d_zs; sa.colour_base = colour_base; sa.report_width = n_colors_total + 1;
     sa.write_nohits = write_nohits ? 1u : 0u;
     return readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, max_read_bytes, max_read_windows, nullptr, false,
                            d_report, d_n_kmers, d_status, sa);
 }
 
-// uploads the batch, runs the LDS or the sort-based kernel; leaves report / n_kmers / status in the ctx's device scratch
-static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
-                            const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t **d_report_out,
-                            uint32_t **d_nk_out, uint8_t **d_status_out) {
-    int rc = check_ready(c, ix);
-    if (rc) return rc;
-    if (!seq_off || !read_seq0) return fail(CID_ERR_INVALID, "null argument");
-    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
-    if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
-    const uint64_t total_bases = seq_off[n_seqs];
-    if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
-    // LDS sizing by the longest read(-pair) the LDS kernel will see
+// Which kernel takes which read of a batch: route empty = the LDS kernels take all of them; else route[r] = 1 sends read r through
+// the sort-based path.  max_bytes / max_win: the LDS sizing, over the reads the LDS kernels will see.  Validates the offsets.
+struct ReadRoute {
+    std::vector<uint8_t> route;
+    uint64_t max_bytes = 0, max_win = 0;
+    size_t n_long = 0;
+};
+static int readid_route(const cid_index *ix, const uint64_t *seq_off, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
+                        uint32_t start_sample, ReadRoute &rr) {
     auto read_size = [&](size_t r, uint64_t &bytes, uint64_t &win) {
         const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
         win = 0;
@@ -1046,21 +1053,134 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
         if (win > max_win) max_win = win;
     }
     // routing: reads whose set would leave k_readid fewer than two waves per workgroup go through the sort-based path
-    std::vector<uint8_t> route;   // empty = one path for the whole batch
-    size_t n_long = 0;
+    rr.route.clear();
+    rr.n_long = 0;
     if (readid_need(ix, stride_d, start_sample, max_bytes, max_win) > kLdsReadBytesMax) {
-        route.assign(n_reads, 0);
+        rr.route.assign(n_reads, 0);
         max_bytes = max_win = 0;
         for (size_t r = 0; r < n_reads; ++r) {
             uint64_t bytes, win;
             read_size(r, bytes, win);
-            if (readid_need(ix, stride_d, start_sample, bytes, win) > kLdsReadBytesMax) { route[r] = 1; ++n_long; }
+            if (readid_need(ix, stride_d, start_sample, bytes, win) > kLdsReadBytesMax) { rr.route[r] = 1; ++rr.n_long; }
             else {
                 if (bytes > max_bytes) max_bytes = bytes;
                 if (win > max_win) max_win = win;
             }
         }
     }
+    rr.max_bytes = max_bytes; rr.max_win = max_win;
+    return CID_OK;
+}
+
+// The two stripe passes for ANY read length and stripe width: d_bases resident, offsets on the host.  Per stripe the reads are routed
+// between the LDS kernels and the sort-based path exactly as cid_readid_count routes them (the mask of a read's q-th distinct k-mer
+// sits at the same word whichever kernel writes it, so different stripes may route a read differently).  Masks: one word per
+// window, read r's at [prefix of the windows of reads 0..r-1] (cid_readid_stripe_mask_words words in all).
+static int stripe_mask_starts(uint32_t k, uint32_t stride_d, const uint64_t *seq_off, const uint64_t *read_seq0, size_t n_reads, std::vector<uint64_t> &zs) {
+    zs.assign(n_reads + 1, 0);
+    for (size_t r = 0; r < n_reads; ++r) {
+        if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
+        uint64_t win = 0;
+        for (uint64_t s = read_seq0[r]; s < read_seq0[r + 1]; ++s) {
+            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
+            const uint64_t len = seq_off[s + 1] - seq_off[s];
+            if (len >= k) win += (len - k) / stride_d + 1;
+        }
+        zs[r + 1] = zs[r] + win;
+    }
+    return CID_OK;
+}
+
+int cid_readid_stripe_mask_words(uint32_t k_size, uint32_t stride_d, const uint64_t *seq_off, const uint64_t *read_seq0, size_t n_reads, uint64_t *n_words) {
+    if (!seq_off || !read_seq0 || !n_words) return fail(CID_ERR_INVALID, "null argument");
+    if (stride_d == 0 || k_size == 0) return fail(CID_ERR_INVALID, "k_size and stride_d must be >= 1");
+    std::vector<uint64_t> zs;
+    const int rc = stripe_mask_starts(k_size, stride_d, seq_off, read_seq0, n_reads, zs);
+    if (rc) return rc;
+    *n_words = zs[n_reads] + 1;   // never empty
+    return CID_OK;
+}
+
+static int readid_stripe_pass(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0,
+                              size_t n_reads, uint32_t stride_d, uint32_t start_sample, StripeArgs sa, uint32_t *d_report, uint32_t *d_n_kmers,
+                              uint8_t *d_status) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!seq_off || !read_seq0) return fail(CID_ERR_INVALID, "null argument");
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    if (n_reads == 0) return CID_OK;
+    if (!d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
+    if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
+    if (seq_off[n_seqs] && !d_bases) return fail(CID_ERR_INVALID, "null bases");
+    ReadRoute rr;
+    if ((rc = readid_route(ix, seq_off, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
+    std::vector<uint64_t> zs;
+    if ((rc = stripe_mask_starts(ix->k, stride_d, seq_off, read_seq0, n_reads, zs))) return rc;
+    if (zs[n_reads] >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
+    const bool all_long = rr.n_long == n_reads, mixed = rr.n_long > 0 && !all_long;
+    HIP_TRY(hipSetDevice(c->device));
+    void *d_so, *d_r0, *d_zs;
+    rc = slot_reserve(c, S_SEQOFF, (n_seqs + 1) * 8, &d_so); if (rc) return rc;
+    rc = slot_reserve(c, S_READ0, (n_reads + 1) * 8, &d_r0); if (rc) return rc;
+    rc = slot_reserve(c, S_ZSTART, (n_reads + 1) * 8, &d_zs); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_zs, zs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    sa.zero_start = (const uint64_t *)d_zs;
+    if (rr.n_long) {   // first: it writes a status for every read (2 = the other kernels')
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = cid::readid_long(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, mixed ? rr.route.data() : nullptr, false,
+                              d_report, d_n_kmers, d_status, sa);
+        if (rc) return rc;
+    }
+    if (!all_long) {
+        void *d_skip = nullptr;
+        if (mixed) {
+            rc = slot_reserve(c, S_ROUTE, n_reads, &d_skip); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(d_skip, rr.route.data(), n_reads, hipMemcpyHostToDevice, c->stream));
+        }
+        rc = readid_dev_impl(c, ix, d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample, rr.max_bytes,
+                             rr.max_win ? rr.max_win : 1, (const uint8_t *)d_skip, false, d_report, d_n_kmers, d_status, sa);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors leave scope
+    return rc;
+}
+
+int cid_readid_stripe_zero(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0,
+                           size_t n_reads, uint32_t stride_d, uint32_t *d_zero_acc, uint32_t *d_n_kmers, uint8_t *d_status) {
+    if (n_reads && !d_zero_acc) return fail(CID_ERR_INVALID, "null argument");
+    StripeArgs sa;
+    sa.zero_acc = d_zero_acc; sa.report_width = ix ? ix->n_colors + 1 : 0;
+    return readid_stripe_pass(c, ix, d_bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, 0, sa,
+                              reinterpret_cast<uint32_t *>(d_zero_acc) /* never written in this pass */, d_n_kmers, d_status);
+}
+
+int cid_readid_stripe_count(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0,
+                            size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t colour_base, uint32_t n_colors_total, int write_nohits,
+                            const uint32_t *d_zero_acc, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status) {
+    if (n_reads && (!d_zero_acc || !d_report)) return fail(CID_ERR_INVALID, "null argument");
+    if (ix && (uint64_t)colour_base + ix->n_colors > n_colors_total) return fail(CID_ERR_INVALID, "stripe [%u, +%u) outside %u colours", colour_base, ix->n_colors, n_colors_total);
+    StripeArgs sa;
+    sa.zero_in = d_zero_acc; sa.colour_base = colour_base; sa.report_width = n_colors_total + 1; sa.write_nohits = write_nohits ? 1u : 0u;
+    return readid_stripe_pass(c, ix, d_bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, sa, d_report, d_n_kmers, d_status);
+}
+
+// uploads the batch, runs the LDS or the sort-based kernel; leaves report / n_kmers / status in the ctx's device scratch
+static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+                            const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t **d_report_out,
+                            uint32_t **d_nk_out, uint8_t **d_status_out) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!seq_off || !read_seq0) return fail(CID_ERR_INVALID, "null argument");
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
+    const uint64_t total_bases = seq_off[n_seqs];
+    if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
+    ReadRoute rr;
+    if ((rc = readid_route(ix, seq_off, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
+    const std::vector<uint8_t> &route = rr.route;
+    const uint64_t max_bytes = rr.max_bytes, max_win = rr.max_win;
+    const size_t n_long = rr.n_long;
     const bool all_long = n_long == n_reads, mixed = n_long > 0 && !all_long;
     HIP_TRY(hipSetDevice(c->device));
     void *d_bases, *d_so, *d_r0, *d_rep, *d_nk;

@@ -393,45 +393,28 @@ int cid_group_stripes_readid_count_sparse(cid_group *g, cid_index *const *stripe
     if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
     const uint64_t total_bases = seq_off[n_seqs];
     if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
-    const uint32_t k = stripes[0]->k;
-    uint64_t max_bytes = 0, max_win = 0;
-    for (size_t r = 0; r < n_reads; ++r) {
-        if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
-        uint64_t win = 0;
-        for (uint64_t s = read_seq0[r]; s < read_seq0[r + 1]; ++s) {
-            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
-            const uint64_t len = seq_off[s + 1] - seq_off[s];
-            if (len >= k) win += (len - k) / stride_d + 1;
-        }
-        const uint64_t bytes = read_seq0[r + 1] > read_seq0[r] ? seq_off[read_seq0[r + 1]] - seq_off[read_seq0[r]] : 0;
-        if (bytes > max_bytes) max_bytes = bytes;
-        if (win > max_win) max_win = win;
-    }
-    if (max_win == 0) max_win = 1;
+    uint64_t zn64 = 0;   // one mask word per k-mer window of the batch (validates the offsets too)
+    if ((rc = cid_readid_stripe_mask_words(stripes[0]->k, stride_d, seq_off, read_seq0, n_reads, &zn64))) return rc;
     uint32_t widest = 0;
     for (int r = 0; r < st.n; ++r) widest = stripes[r]->n_colors > widest ? stripes[r]->n_colors : widest;
-    if ((double)n_reads * ((double)widest + 1.0) * 4.0 > 64.0 * (double)(1ull << 30) || (double)n_reads * (double)max_win * 4.0 > 64.0 * (double)(1ull << 30))
+    if ((double)n_reads * ((double)widest + 1.0) * 4.0 > 64.0 * (double)(1ull << 30) || (double)zn64 * 4.0 > 64.0 * (double)(1ull << 30))
         return fail(CID_ERR_UNSUPPORTED, "%zu reads need more than 64 GiB of report rows or k-mer masks per GPU: use smaller batches", n_reads);
-    const size_t zn = n_reads * (size_t)max_win;
+    const size_t zn = (size_t)zn64;
     std::vector<uint32_t *> d_z(st.n, nullptr);
-    struct Dev { const uint8_t *bases; const uint64_t *so, *r0; uint32_t *nk; uint8_t *status; };
+    struct Dev { const uint8_t *bases; uint32_t *nk; uint8_t *status; };
     std::vector<Dev> dv(st.n);
-    rc = for_each_rank(g, [&](int r) -> int {   // upload + zero pass
+    rc = for_each_rank(g, [&](int r) -> int {   // upload + zero pass (reads of any length: routed per stripe, cid_readid_stripe_zero)
         cid_ctx *c = g->ctx[r];
         HIP_TRY(hipSetDevice(c->device));
-        void *d_b, *d_so, *d_r0, *d_nk, *d_zz;
+        void *d_b, *d_nk, *d_zz;
         int e = cid::slot_reserve(c, S_BASES, total_bases + 16, &d_b); if (e) return e;
-        e = cid::slot_reserve(c, S_SEQOFF, (n_seqs + 1) * 8, &d_so); if (e) return e;
-        e = cid::slot_reserve(c, S_READ0, (n_reads + 1) * 8, &d_r0); if (e) return e;
         e = cid::slot_reserve(c, S_NK, n_reads * 4 + n_reads + 16, &d_nk); if (e) return e;
         e = cid::slot_reserve(c, S_UC, zn * 4, &d_zz); if (e) return e;
         if (total_bases) HIP_TRY(hipMemcpyAsync(d_b, bases, total_bases, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(d_zz, 0xFF, zn * 4, c->stream));
-        dv[r] = Dev{(const uint8_t *)d_b, (const uint64_t *)d_so, (const uint64_t *)d_r0, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4};
+        dv[r] = Dev{(const uint8_t *)d_b, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4};
         d_z[r] = (uint32_t *)d_zz;
-        return cid_readid_stripe_zero_dev(c, stripes[r], dv[r].bases, dv[r].so, dv[r].r0, n_reads, stride_d, max_bytes, max_win, d_z[r], dv[r].nk, dv[r].status);
+        return cid_readid_stripe_zero(c, stripes[r], dv[r].bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, d_z[r], dv[r].nk, dv[r].status);
     });
     if (rc) return rc;
     if ((rc = reduce_u32(g, d_z.data(), zn, false, true))) return rc;
@@ -442,8 +425,8 @@ int cid_group_stripes_readid_count_sparse(cid_group *g, cid_index *const *stripe
         void *d_rep;
         int e = cid::slot_reserve(c, S_REPORT, n_reads * ((size_t)Cr + 1) * 4, &d_rep); if (e) return e;
         HIP_TRY(hipMemsetAsync(d_rep, 0, n_reads * ((size_t)Cr + 1) * 4, c->stream));
-        e = cid_readid_stripe_count_dev(c, stripes[r], dv[r].bases, dv[r].so, dv[r].r0, n_reads, stride_d, start_sample, max_bytes, max_win, 0, Cr,
-                                        r == 0 ? 1 : 0, d_z[r], (uint32_t *)d_rep, dv[r].nk, dv[r].status);
+        e = cid_readid_stripe_count(c, stripes[r], dv[r].bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, 0, Cr,
+                                    r == 0 ? 1 : 0, d_z[r], (uint32_t *)d_rep, dv[r].nk, dv[r].status);
         if (e) return e;
         cid::ctx_free(c, c->sp_start); c->sp_start = nullptr;
         cid::ctx_free(c, c->sp_col); c->sp_col = nullptr;

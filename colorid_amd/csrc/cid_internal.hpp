@@ -30,12 +30,21 @@ const uint64_t *index_matrix(const cid_index *ix);
 // Bloom insert of 2-bit codes already on the device into one colour (build.rs:62-66 with the k-mer map on the GPU)
 int index_insert_codes(cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t colour);
 
+// read_id over colour stripes (ReadIdParams::zero_acc ...): which pass this launch is, and where its results go; all zero = a whole index
+struct StripePass {
+    uint32_t *zero_acc = nullptr;
+    const uint32_t *zero_in = nullptr;
+    const uint64_t *zero_start = nullptr;   // device, [n_reads]
+    uint32_t colour_base = 0, report_width = 0, write_nohits = 0;
+    bool on() const { return zero_acc || zero_in; }
+};
+
 // read_id for reads that do not fit (or badly fit) the LDS kernel (cid_kmerset.hip): sort-based per-read k-mer sets.
 // route == NULL: every read; else only reads with route[r] != 0 — the others get status 2 and nothing else is written for
 // them.  clear_wide: zero the whole report first when rows are wider than 128 words (those kernels count in place).
 int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                 size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
-                uint32_t *d_n_kmers, uint8_t *d_status);
+                uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp = StripePass());
 
 // a5 / a4 on k-mers that are already on the device as 2-bit codes (k <= 32); outputs go to HOST buffers
 int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,

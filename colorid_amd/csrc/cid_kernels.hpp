@@ -88,13 +88,15 @@ struct ReadIdParams {
     // colour stripes (this index = colours [colour_base, colour_base + n_colors) of a wider one; all three NULL/0 otherwise).
     // "A row is absent" (read_id_mt_pe.rs:81-89, :126-128) means: all-zero in EVERY stripe, so the rule runs in two passes:
     //   zero pass  (zero_acc != NULL): every distinct k-mer of every read is looked up, nothing is counted;
-    //              zero_acc[read * zero_stride + q] &= bit s set iff row s of the read's q-th k-mer is all-zero in this stripe;
+    //              zero_acc[zero_start[read] + q] &= bit s set iff row s of the read's q-th k-mer is all-zero in this stripe
+    //              (q = rank in the read's first-occurrence order — the same in the LDS kernels and in k_readid_list, so a read
+    //              may take a different kernel in different stripes; zero_start = any prefix leaving >= windows(read) words per read);
     //   count pass (zero_in  != NULL): the ordered search, with "absent" read from the accumulated masks instead of this stripe's rows;
     //              report rows are report_width wide, this stripe's colours land at [colour_base ..), the no-hits entry at
     //              [report_width - 1] is written by the stripe with write_nohits set.
     uint32_t *zero_acc;
     const uint32_t *zero_in;
-    uint32_t zero_stride;
+    const uint64_t *zero_start;   // [n_reads]
     uint32_t colour_base, report_width, write_nohits;
 };
 
@@ -112,6 +114,11 @@ struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in
     uint32_t *report;
     uint32_t *n_kmers;
     const uint8_t *status;        // set by the caller: 1 = too_short, 2 = not this kernel's read (k_readid handles it)
+    // colour stripes, as in ReadIdParams (all NULL/0: a whole index)
+    uint32_t *zero_acc;
+    const uint32_t *zero_in;
+    const uint64_t *zero_start;
+    uint32_t colour_base, report_width, write_nohits;
 };
 
 size_t search_smem_bytes(const SearchParams &p);

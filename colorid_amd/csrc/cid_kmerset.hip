@@ -508,7 +508,7 @@ __global__ void k_keep_gt(const uint32_t *counts, uint64_t t, uint32_t *keep, ui
 // d_bases resident; host seq_off / read_seq0.  Writes report / n_kmers / status to DEVICE arrays.
 int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                 size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
-                uint32_t *d_n_kmers, uint8_t *d_status) {
+                uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp) {
     const uint32_t k = index_k(ix);
     hipStream_t st = ctx_stream(c);
     const uint32_t msz = index_m_size(ix);           // > 0: the sets hold minimizers of length msz
@@ -614,7 +614,9 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     p.list_codes = d_list.p; p.list_start = d_lstart.p; p.n_reads = n_reads; p.start_sample = start_sample;
     p.bases = general ? d_bases : nullptr; p.upper = msz != 0;
     p.hist_pad = p.rs > 128 ? 4u * p.rs : (uint32_t)((C1 + 3) & ~(size_t)3);
-    if (p.rs > 128 && clear_wide) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, st));   // wide rows count in place
+    if (p.rs > 128 && clear_wide && !sp.on()) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, st));   // wide rows count in place
+    p.zero_acc = sp.zero_acc; p.zero_in = sp.zero_in; p.zero_start = sp.zero_start;   // a colour stripe's pass: the caller zeroed the report
+    p.colour_base = sp.colour_base; p.report_width = sp.report_width; p.write_nohits = sp.write_nohits;
     p.wave_bytes = (uint32_t)((4ull * kWave * p.n_hash + 4ull * p.hist_pad + 15) & ~15ull);
     if ((size_t)(kBlock / kWave) * p.wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
     p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status;

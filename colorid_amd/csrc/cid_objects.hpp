@@ -6,7 +6,7 @@
 
 namespace cid {
 namespace slots {
-enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_REDO, S_QUEUE, S_COUNT };
+enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_REDO, S_QUEUE, S_ZSTART, S_COUNT };
 }
 }  // namespace cid
 

@@ -4,11 +4,20 @@
 
 namespace cid {
 
+// Colour stripes: zacc / zin point at this read's slice of ReadIdParams::zero_acc / zero_in (NULL = not that pass)
+struct StripeRead { uint32_t *zacc; const uint32_t *zin; };
+
 // read_id over wide rows: the chunk's distinct k-mers one at a time, in order; counts go straight to the (pre-zeroed)
 // report row.  s_words / s_R: rs u64 words each per wave (the AND word of the current k-mer, the colours of the first S).
-__device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, uint32_t rs, uint32_t w64, uint32_t n, uint32_t C, uint32_t S,
+// STRIPED: the row is one colour stripe's — zero pass: record which seeds' rows are all-zero here, count nothing; count pass:
+// "absent" comes from the masks accumulated over all stripes, colours land at colour_base, the no-hits column (nohits_col)
+// is written by one stripe only.
+template <bool STRIPED = false>
+__device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, uint32_t rs, uint32_t w64, uint32_t n, uint32_t S,
                                                          const uint32_t *ridx, uint64_t *s_words, uint64_t *s_R, uint32_t *row_out,
-                                                         uint64_t dmask, uint32_t nd, bool &stopped, int lane) {
+                                                         uint64_t dmask, uint32_t nd, bool &stopped, int lane, uint32_t nohits_col,
+                                                         StripeRead sr = StripeRead{nullptr, nullptr}, uint32_t colour_base = 0,
+                                                         uint32_t write_nohits = 1) {
     if (stopped || !dmask) return;
     const uint32_t steps = rs / 128u;
     const uint32_t seeds = n >= 32 ? ~0u : ((1u << n) - 1u);
@@ -25,8 +34,16 @@ __device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, ui
             s_words[col_word + 1] = a.y;
             zml &= zm;
         }
-        if (wave_and_u32(zml) & seeds) {  // absent row: *report.entry(no_hits_num) += 1; break
-            if (lane == 0) atomicAdd(&row_out[C], 1u);
+        uint32_t absent = wave_and_u32(zml) & seeds;
+        if constexpr (STRIPED) {
+            if (sr.zacc) {   // zero pass
+                if (lane == 0) sr.zacc[q] &= absent;
+                continue;
+            }
+            if (sr.zin) absent = sr.zin[q];   // all-zero in every stripe
+        }
+        if (absent) {  // absent row: *report.entry(no_hits_num) += 1; break
+            if (lane == 0 && write_nohits) atomicAdd(&row_out[nohits_col], 1u);
             stopped = true;
             return;
         }
@@ -38,8 +55,8 @@ __device__ __forceinline__ void readid_search_chunk_wide(const uint64_t *mat, ui
                 if (q < S) { s_R[col_word] |= x; s_R[col_word + 1] |= y; }
                 else { x &= s_R[col_word]; y &= s_R[col_word + 1]; }
             }
-            while (x) { atomicAdd(&row_out[col_word * 64u + (uint32_t)__builtin_ctzll(x)], 1u); x &= x - 1; }
-            while (y) { atomicAdd(&row_out[col_word * 64u + 64u + (uint32_t)__builtin_ctzll(y)], 1u); y &= y - 1; }
+            while (x) { atomicAdd(&row_out[colour_base + col_word * 64u + (uint32_t)__builtin_ctzll(x)], 1u); x &= x - 1; }
+            while (y) { atomicAdd(&row_out[colour_base + col_word * 64u + 64u + (uint32_t)__builtin_ctzll(y)], 1u); y &= y - 1; }
         }
     }
 }
@@ -69,9 +86,6 @@ constexpr int kReadPlanesDense = 2;
 // The in-order search (read_id_mt_pe.rs:66-102 classic / :104-165 sampled) over a dense run of distinct k-mers: k-mer j (0 <= j < count, order index q_base + j) has its row
 // numbers at ridx[s*stride + j].  U sub-passes (U * 64/LPR k-mers) have all their row loads issued before the first is
 // consumed: a read's search is a chain of dependent gather rounds, and what bounds the kernel is how many of them there are.
-// Colour stripes: zacc / zin point at this read's slice of ReadIdParams::zero_acc / zero_in (NULL = not that pass)
-struct StripeRead { uint32_t *zacc; const uint32_t *zin; };
-
 template <int LOG_LPR, bool NARROW, int U, int PLANES = kReadPlanes, bool STRIPED = false>
 __device__ __forceinline__ void readid_search_run(const uint64_t *mat, uint32_t rs, uint32_t n, uint32_t C, uint32_t S, const uint32_t *ridx,
                                                   uint32_t stride, uint32_t count, uint32_t q_base, uint32_t *hist, bool &stopped,
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         constexpr bool striped = STRIPED;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
         uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
         StripeRead sr{nullptr, nullptr};
-        if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
+        if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + p.zero_start[read] : nullptr, p.zero_in ? p.zero_in + p.zero_start[read] : nullptr};
         if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
             if constexpr (!WIDE)  // (wide rows: the host zeroes the whole report before the launch)
                 if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
@@ -367,7 +381,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 if constexpr (WIDE) {
                     wave_lds_fence();
                     uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
-                    readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
+                    readid_search_chunk_wide<STRIPED>(p.mat, p.rs, p.w64, n, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane,
+                                                      STRIPED ? p.report_width - 1 : C, sr, STRIPED ? p.colour_base : 0u, STRIPED ? p.write_nohits : 1u);
                 }
                 nd += (uint32_t)__popcll(dmask);
             }
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
         constexpr bool striped = STRIPED;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
         uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
         StripeRead sr{nullptr, nullptr};
-        if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + read * (uint64_t)p.zero_stride : nullptr, p.zero_in ? p.zero_in + read * (uint64_t)p.zero_stride : nullptr};
+        if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + p.zero_start[read] : nullptr, p.zero_in ? p.zero_in + p.zero_start[read] : nullptr};
         if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
             if constexpr (!WIDE)
                 if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
@@ -544,7 +559,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_readid_bytes(ReadIdParams p) {
                 if constexpr (WIDE) {
                     wave_lds_fence();
                     uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
-                    readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
+                    readid_search_chunk_wide<STRIPED>(p.mat, p.rs, p.w64, n, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane,
+                                                      STRIPED ? p.report_width - 1 : C, sr, STRIPED ? p.colour_base : 0u, STRIPED ? p.write_nohits : 1u);
                 } else if (valid && !dup) {
                     const uint32_t q = nd + (uint32_t)__popcll(dmask & lt_mask);
                     for (uint32_t sd = 0; sd < n; ++sd) rall[sd * rcap + q] = ridx[sd * kWave + lane];
@@ -573,7 +589,7 @@ struct BaseReader {  // a key that lives in HBM as a stretch of the read (forwar
     __device__ __forceinline__ uint64_t rd64(uint32_t o) const { return (uint64_t)rd32(o) | ((uint64_t)rd32(o + 4) << 32); }
 };
 
-template <int LOG_LPR, bool NARROW, bool WIDE = false>
+template <int LOG_LPR, bool NARROW, bool WIDE = false, bool STRIPED = false>
 __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -586,15 +602,18 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
     const uint32_t col_word = NARROW ? 0u : 2u * (lane & ((1 << LOG_LPR) - 1));
     for (uint64_t read = (uint64_t)blockIdx.x * waves + wave; read < p.n_reads; read += (uint64_t)gridDim.x * waves) {
         wave_lds_fence();
-        uint32_t *row_out = p.report + read * (uint64_t)(C + 1);
+        // striped passes: the caller zeroes the (report_width-wide) report once, rows are only added to
+        uint32_t *row_out = STRIPED ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
         if (p.status[read] == 2) continue;
         if (p.status[read] == 1) {  // too_short, decided on the host side of the call
-            if constexpr (!WIDE)
+            if constexpr (!WIDE && !STRIPED)
                 for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) p.n_kmers[read] = 0;
             continue;
         }
         const uint64_t d0 = p.list_start[read], d1 = p.list_start[read + 1];
+        StripeRead sr{nullptr, nullptr};
+        if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + p.zero_start[read] : nullptr, p.zero_in ? p.zero_in + p.zero_start[read] : nullptr};
         uint32_t nd = 0;
         bool stopped = false;
         VCount<kReadPlanes, NARROW> vc;
@@ -621,17 +640,27 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
             wave_lds_fence();
             if constexpr (WIDE) {
                 uint64_t *s_words = reinterpret_cast<uint64_t *>(hist), *s_R = s_words + p.rs;
-                readid_search_chunk_wide(p.mat, p.rs, p.w64, n, C, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane);
+                readid_search_chunk_wide<STRIPED>(p.mat, p.rs, p.w64, n, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane,
+                                                  STRIPED ? p.report_width - 1 : C, sr, STRIPED ? p.colour_base : 0u, STRIPED ? p.write_nohits : 1u);
             } else {   // the chunk's entries are dense from lane 0
-                readid_search_run<LOG_LPR, NARROW, kReadRunUnroll>(p.mat, NARROW ? 1u : 2u << LOG_LPR, n, C, S, ridx, (uint32_t)kWave,
-                                                                   (uint32_t)__popcll(dmask), nd, hist, stopped, vc, R, lane);
+                readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, kReadPlanes, STRIPED>(p.mat, NARROW ? 1u : 2u << LOG_LPR, n, C, S, ridx, (uint32_t)kWave,
+                                                                                         (uint32_t)__popcll(dmask), nd, hist, stopped, vc, R, lane, sr);
             }
             nd += (uint32_t)__popcll(dmask);
         }
         if constexpr (!WIDE) {
             vc.drain(hist, col_word);
             wave_lds_fence();
-            for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+            if constexpr (STRIPED) {
+                if (p.zero_acc) {   // zero pass: nothing was counted
+                    for (uint32_t c = lane; c <= C; c += kWave) hist[c] = 0;
+                } else {            // this stripe's colours inside the wide row; the no-hits entry from one stripe only
+                    for (uint32_t c = lane; c < C; c += kWave) { row_out[p.colour_base + c] = hist[c]; hist[c] = 0; }
+                    if (lane == 0) { if (p.write_nohits) row_out[p.report_width - 1] = hist[C]; hist[C] = 0; }
+                }
+            } else {
+                for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+            }
         }
         if (lane == 0) p.n_kmers[read] = (uint32_t)(d1 - d0);
     }
@@ -656,7 +685,7 @@ static hipError_t launch_readid_one(KernelT kernel, const ReadIdParams &p, int w
 // colour-stripe passes (zero_acc / zero_in set): separate instantiations, so that the plain kernels carry none of that logic
 template <bool MINI>
 static hipError_t launch_readid_packed_striped(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
-    if (p.rs > 128) return hipErrorInvalidValue;
+    if (p.rs > 128) return launch_readid_one(k_readid<0, false, true, MINI, false, true>, p, wpb, grid, stream);
     if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, MINI, false, true>, p, wpb, grid, stream);
     switch (log2u(p.rs / 2)) {
     case 0: return launch_readid_one(k_readid<0, false, false, MINI, false, true>, p, wpb, grid, stream);
@@ -721,7 +750,7 @@ hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t
 // byte-string keys: the reads listed in p.redo_list (count on the device), or all of them
 hipError_t launch_readid_bytes(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
     if (p.zero_acc || p.zero_in) {
-        if (p.rs > 128) return hipErrorInvalidValue;
+        if (p.rs > 128) return launch_readid_one(k_readid_bytes<0, false, true, true>, p, wpb, grid, stream);
         if (p.rs == 1) return launch_readid_one(k_readid_bytes<0, true, false, true>, p, wpb, grid, stream);
         switch (log2u(p.rs / 2)) {
         case 0: return launch_readid_one(k_readid_bytes<0, false, false, true>, p, wpb, grid, stream);
@@ -759,20 +788,25 @@ static hipError_t launch_readid_list_one(KernelT kernel, const ReadIdListParams 
     return hipGetLastError();
 }
 
-hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream) {
-    if (p.n_reads == 0) return hipSuccess;
-    if (p.rs > 128) return launch_readid_list_one(k_readid_list<0, false, true>, p, grid, stream);
-    if (p.rs == 1) return launch_readid_list_one(k_readid_list<0, true>, p, grid, stream);
+template <bool STRIPED>
+static hipError_t launch_readid_list_sel(const ReadIdListParams &p, int grid, hipStream_t stream) {
+    if (p.rs > 128) return launch_readid_list_one(k_readid_list<0, false, true, STRIPED>, p, grid, stream);
+    if (p.rs == 1) return launch_readid_list_one(k_readid_list<0, true, false, STRIPED>, p, grid, stream);
     switch (log2u(p.rs / 2)) {
-    case 0: return launch_readid_list_one(k_readid_list<0, false>, p, grid, stream);
-    case 1: return launch_readid_list_one(k_readid_list<1, false>, p, grid, stream);
-    case 2: return launch_readid_list_one(k_readid_list<2, false>, p, grid, stream);
-    case 3: return launch_readid_list_one(k_readid_list<3, false>, p, grid, stream);
-    case 4: return launch_readid_list_one(k_readid_list<4, false>, p, grid, stream);
-    case 5: return launch_readid_list_one(k_readid_list<5, false>, p, grid, stream);
-    case 6: return launch_readid_list_one(k_readid_list<6, false>, p, grid, stream);
+    case 0: return launch_readid_list_one(k_readid_list<0, false, false, STRIPED>, p, grid, stream);
+    case 1: return launch_readid_list_one(k_readid_list<1, false, false, STRIPED>, p, grid, stream);
+    case 2: return launch_readid_list_one(k_readid_list<2, false, false, STRIPED>, p, grid, stream);
+    case 3: return launch_readid_list_one(k_readid_list<3, false, false, STRIPED>, p, grid, stream);
+    case 4: return launch_readid_list_one(k_readid_list<4, false, false, STRIPED>, p, grid, stream);
+    case 5: return launch_readid_list_one(k_readid_list<5, false, false, STRIPED>, p, grid, stream);
+    case 6: return launch_readid_list_one(k_readid_list<6, false, false, STRIPED>, p, grid, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream) {
+    if (p.n_reads == 0) return hipSuccess;
+    return (p.zero_acc || p.zero_in) ? launch_readid_list_sel<true>(p, grid, stream) : launch_readid_list_sel<false>(p, grid, stream);
 }
 
 }  // namespace cid

@@ -171,3 +171,37 @@ class StripedIndex:
         if _active():
             all_reduce_sum(rep)       # the ranks' columns are disjoint; the no-hits column comes from rank 0 only
         return rep, nk, st
+
+    def readid_count_routed(self, d_bases: torch.Tensor, seq_off, read_seq0, stride_d: int, start_sample: int):
+        """read_id over the stripes for reads of any length (long reads, contigs, mixed batches) and stripes of any width:
+        `d_bases` on the device, `seq_off` / `read_seq0` numpy uint64 on the host (cid_readid_stripe_zero / _count route every read
+        between the LDS kernels and the sort-based path, per stripe).  Returns what readid_count returns."""
+        import ctypes
+        import numpy as np
+        dev = d_bases.device
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        read_seq0 = np.ascontiguousarray(read_seq0, dtype=np.uint64)
+        n_reads, n_seqs = len(read_seq0) - 1, len(seq_off) - 1
+        nw = ctypes.c_uint64(0)
+        check(self.lib.cid_readid_stripe_mask_words(self.stripes[0][0].k, stride_d, seq_off.ctypes.data, read_seq0.ctypes.data, n_reads, ctypes.byref(nw)))
+        zero = torch.full((nw.value,), -1, dtype=torch.int32, device=dev)
+        rep = torch.zeros((n_reads, self.n_colors + 1), dtype=torch.int32, device=dev)
+        nk = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+        st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+        args = (vp(d_bases.data_ptr()), seq_off.ctypes.data, n_seqs, read_seq0.ctypes.data, n_reads, stride_d)
+        self._to_ctx(dev)
+        for ix, _ in self.stripes:
+            check(self.lib.cid_readid_stripe_zero(self.ctx.h, ix.h, *args, vp(zero.data_ptr()), vp(nk.data_ptr()), vp(st.data_ptr())))
+        rank = dist.get_rank() if _active() else 0
+        if _active():
+            self._to_torch(dev)
+            zero, _ = reduce_perfect_facts(zero, torch.zeros(1, dtype=torch.int64, device=dev))
+            zero = zero.contiguous()
+            self._to_ctx(dev)
+        for i, (ix, base) in enumerate(self.stripes):
+            check(self.lib.cid_readid_stripe_count(self.ctx.h, ix.h, *args, start_sample, base, self.n_colors, 1 if (rank == 0 and i == 0) else 0,
+                                                   vp(zero.data_ptr()), vp(rep.data_ptr()), vp(nk.data_ptr()), vp(st.data_ptr())))
+        self._to_torch(dev)
+        if _active():
+            all_reduce_sum(rep)
+        return rep, nk, st

@@ -158,6 +158,21 @@ int cid_readid_stripe_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_b
                                 size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint64_t max_read_bytes, uint64_t max_read_windows,
                                 uint32_t colour_base, uint32_t n_colors_total, int write_nohits, const uint32_t *d_zero_acc, uint32_t *d_report,
                                 uint32_t *d_n_kmers, uint8_t *d_status);
+/* The same two passes for reads of ANY length (long reads, contigs, batches that mix them with short reads) over stripes of any
+ * width: the bases are resident, the offsets are host arrays, and every call routes the batch between the LDS kernels and the
+ * sort-based long-read path exactly as cid_readid_count does (src/read_id_mt_pe.rs:431-465 stream_fasta's records included).
+ * The masks are one u32 per k-mer window, read r's at word [windows of reads 0..r-1] + q — the same word whichever kernel writes
+ * it, so a read may be routed differently in stripes of different width; cid_readid_stripe_mask_words gives the array's length
+ * (preset it to 0xFFFFFFFF; AND the arrays of other GPUs between the passes, as above). */
+int cid_readid_stripe_mask_words(uint32_t k_size, uint32_t stride_d, const uint64_t *seq_off, const uint64_t *read_seq0, size_t n_reads,
+                                 uint64_t *n_words);
+int cid_readid_stripe_zero(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs,
+                           const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t *d_zero_acc, uint32_t *d_n_kmers,
+                           uint8_t *d_status);
+int cid_readid_stripe_count(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs,
+                            const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t colour_base,
+                            uint32_t n_colors_total, int write_nohits, const uint32_t *d_zero_acc, uint32_t *d_report,
+                            uint32_t *d_n_kmers, uint8_t *d_status);
 
 /* ---- a10 (next row): canonical k-mer counting on the GPU — replaces the
  *      FnvHashMap<String,usize> producers of `search`: kmerize_vector (src/kmer.rs:87-125, mode 0: has_no_n filter,

@@ -119,6 +119,40 @@ def test_striped_group_readid_equals_oracle(orc, devices, n_colors):
     g.close()
 
 
+@pytest.mark.parametrize("devices,n_colors", [([0, 0], 384), ([0, 0, 0], 17_000)])
+def test_striped_group_readid_long_reads(orc, devices, n_colors):
+    """cid_group_stripes_readid_count_sparse with reads too long for a wave's LDS (sort-based path), mixed with short ones; the
+    17 000-colour case gives two ranks a stripe of more than 8192 colours (wide-row kernels) — against the oracle on the unsplit index."""
+    import colorid_amd
+    rng = np.random.default_rng(n_colors)
+    k, m = 21, 60_013
+    genomes = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20_000)].tobytes() for _ in range(3)]
+    oix = orc.Index(m, 2, k, n_colors)
+    for c in range(n_colors):
+        oix.set_color(c, f"acc{c}", 1000)
+    for gi, gen in enumerate(genomes):
+        kms = orc.Kmers(k)
+        kms.kmerize_vector(gen[:15_000], 1)
+        for key in kms.keys():
+            for c in (gi, n_colors // 2 + gi, n_colors - 1 - gi):
+                oix.insert(c, key.tobytes())
+    g = colorid_amd.Group(devices)
+    st = _striped(g, oix)
+    reads = [[genomes[0]], [genomes[1][:9_000], genomes[2][2_000:12_000]], [genomes[0][50:200]], [b"AC"], [genomes[2][:3_000].lower()],
+             [genomes[1][:4_000] + b"N" * 25 + genomes[0][:6_000]]]
+    reads += sample_reads(orc, rng, genomes, 40, 150, False)
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    for d, S in ((1, 3), (1, 0), (6, 2)):
+        want = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+        rs, col, cnt, nk, stt = st.readid_count_sparse(bases, seq_off, read_seq0, d, S)
+        assert np.array_equal(nk, want[1]) and np.array_equal(stt, want[2])
+        rows, cols = np.nonzero(want[0])
+        assert np.array_equal(rs, np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=len(want[0])))]).astype(np.uint64))
+        assert np.array_equal(col, cols.astype(np.uint32)) and np.array_equal(cnt, want[0][rows, cols])
+        assert want[0][0, 0] > 1000 and (cols == n_colors).any()
+    g.close()
+
+
 def test_striped_group_refuses_misuse(orc):
     import ctypes as C
 

@@ -132,3 +132,69 @@ def test_readid_over_stripes_equals_whole_index(orc, hip_ctx, n_colors, bounds, 
     assert stopped_somewhere and total_counts > 5000     # the absent-row stop was exercised, and colours were counted
     for hx, _ in stripes:
         hx.close()
+
+
+def _genome_index(orc, rng, m, n_hash, k, n_colors, genomes, colours_of):
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.01, zero_row_frac=0.02)
+    for gi, g in enumerate(genomes):
+        km = orc.Kmers(k)
+        km.kmerize_vector(g, 1)
+        for key in km.keys():
+            for c in colours_of(gi):
+                oix.insert(int(c), key.tobytes())
+    return oix
+
+
+@pytest.mark.parametrize("n_colors,bounds,k", [(300, [(0, 128), (128, 300)], 21),                # narrow stripes of different width
+                                               (9100, [(0, 8832), (8832, 9100)], 21),             # a wide-row stripe (> 8192 colours) + a narrow one
+                                               (17000, [(0, 8448), (8448, 17000)], 21),           # two wide-row stripes
+                                               (200, [(0, 64), (64, 200)], 40)])                  # k > 32: byte-string keys
+def test_readid_routed_over_stripes_any_length(orc, hip_ctx, n_colors, bounds, k):
+    """cid_readid_stripe_zero / _count: reads of any length over stripes of any width == the oracle on the whole index.  Long reads
+    (whole genomes, a chimera, long pairs) take the sort-based path, short ones the LDS kernels — per stripe, so the narrow and the
+    wide stripe of one index route the same read differently — and the k-mer masks of both land in one array."""
+    from colorid_amd.striped import StripedIndex
+    from test_gpu_readid import pack_reads
+    rng = np.random.default_rng(n_colors + k)
+    m, n_hash = 40_009, 2
+    genomes = [np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 30_000)].tobytes() for _ in range(3)]
+    oix = _genome_index(orc, rng, m, n_hash, k, n_colors, [g[:25_000] for g in genomes],
+                        lambda gi: (gi, n_colors - 1 - gi, bounds[0][1] + gi))        # colours on both sides of the stripe cut
+    low = bytearray(genomes[1][:20_000])
+    low[3000:3600] = bytes(low[3000:3600]).lower()
+    reads = [[genomes[0]], [genomes[1][:12_000], genomes[2][5_000:20_000]], [genomes[0][100:250]], [b"ACG"], [bytes(low)],
+             [genomes[2][:2_000]], [genomes[2][:5_000] * 2 + b"N" * 30 + genomes[0][:4_000]], [genomes[1][200:330], genomes[1][400:520]],
+             [genomes[0][7:157].lower()], [b"N" * 3_000]]
+    for i in range(60):
+        g = genomes[i % 3]
+        L = int(rng.choice([40, 150, 700, 2600, 6000]))
+        s0 = int(rng.integers(0, len(g) - L))
+        reads.append([g[s0:s0 + L]] if i % 3 else [g[s0:s0 + L], g[s0:s0 + min(L, 300)]])
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    stripes = stripe_indices(hip_ctx, orc, oix, bounds)
+    si = StripedIndex(hip_ctx, stripes, n_colors)
+    db = torch.from_numpy(bases.copy()).cuda()
+    stopped_somewhere = False
+    for d, S in ((1, 3), (1, 0), (5, 2)):
+        want = oix.readid_counts(bases, seq_off, read_seq0, d, S)
+        rep, nk, st = si.readid_count_routed(db, seq_off, read_seq0, d, S)
+        assert np.array_equal(st.cpu().numpy(), want[2]) and np.array_equal(nk.cpu().numpy().view(np.uint32), want[1])
+        got = rep.cpu().numpy().view(np.uint32)
+        bad = np.flatnonzero((got != want[0]).any(axis=1))
+        assert len(bad) == 0, (d, S, bad[:5], np.flatnonzero(got[bad[0]] != want[0][bad[0]])[:8])
+        assert want[0][0, 0] > 1000 and want[0][0, n_colors - 1] > 1000     # the whole genome hits its colours in both stripes
+        stopped_somewhere |= bool(want[0][:, n_colors].any())
+    assert stopped_somewhere
+    # an empty batch, and misuse
+    from colorid_amd._lib import vp
+    import ctypes
+    lib = si.lib
+    so0 = np.zeros(1, np.uint64)
+    assert lib.cid_readid_stripe_zero(hip_ctx.h, stripes[0][0].h, None, so0.ctypes.data, 0, so0.ctypes.data, 0, 1, None, None, None) == 0
+    nw = ctypes.c_uint64(0)
+    assert lib.cid_readid_stripe_mask_words(k, 0, seq_off.ctypes.data, read_seq0.ctypes.data, len(reads), ctypes.byref(nw)) == -1
+    z = torch.zeros(8, dtype=torch.int32, device="cuda")
+    assert lib.cid_readid_stripe_count(hip_ctx.h, stripes[1][0].h, vp(db.data_ptr()), seq_off.ctypes.data, len(seq_off) - 1, read_seq0.ctypes.data,
+                                       len(reads), 1, 0, n_colors, n_colors, 1, vp(z.data_ptr()), vp(z.data_ptr()), vp(z.data_ptr()), vp(z.data_ptr())) == -1
+    for hx, _ in stripes:
+        hx.close()
