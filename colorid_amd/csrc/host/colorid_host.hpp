@@ -50,11 +50,18 @@ class LineReader {   // inflates on its own thread, a few MiB ahead of the calle
   public:
     explicit LineReader(const std::string &path);
     ~LineReader();
+    // Start inflating `path` now, up to ~256 MiB of text ahead: the next LineReader opened on the same path takes the stream
+    // over.  The CLI calls this before it loads the index, so that gzip decoding runs beside the index load instead of after it.
+    static void prefetch(const std::string &path);
+    static void drop_prefetched();   // end of a command: stop the streams nobody took
     LineReader(const LineReader &) = delete;
     LineReader &operator=(const LineReader &) = delete;
     bool next(std::string &line);
+    // the same line as a view: valid until the next call on this reader (it points into the decoded block, or into the reader's
+    // own buffer for a line that straddles two blocks) — no per-line copy
+    bool next(const char *&ptr, size_t &len);
+    struct Impl;   // (defined in fastx_kmers.cpp)
   private:
-    struct Impl;
     Impl *p_;
 };
 

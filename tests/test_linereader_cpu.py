@@ -70,10 +70,13 @@ def test_linereader_same_lines_for_every_container(shim, tmp_path, n_reads):
     outs = {}
     for name, p in paths.items():
         for threads in (("8",) if "bgzf" not in name else ("8", "3", "1")):
-            r = subprocess.run([shim, str(p)], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads))
-            assert r.returncode == 0, (name, r.stderr)
-            outs[(name, threads)] = r.stdout.split()
-    want = outs[("plain", "8")]
+            # the copying call, the view call (lines as pointers into the decoded blocks), both alternating, and a stream that was
+            # started ahead of its reader (LineReader::prefetch: what the CLI does while the index loads)
+            for mode in ("copy", "view", "mixed", "prefetch"):
+                r = subprocess.run([shim, str(p), mode], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads))
+                assert r.returncode == 0, (name, mode, r.stderr)
+                outs[(name, threads, mode)] = r.stdout.split()
+    want = outs[("plain", "8", "copy")]
     assert int(want[0]) == text.count(b"\n") + (1 if text and not text.endswith(b"\n") else 0)
     assert int(want[1]) == len(text) - text.count(b"\n")
     for key, got in outs.items():

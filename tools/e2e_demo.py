@@ -49,7 +49,7 @@ dt, out, err = run("info", "-b", f"{W}/idx.bxi")
 res["info_s"] = dt
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-g", "-f", "0", "-p", "0.005")
 res["search_g_total_s"] = dt; res["search_g_rows"] = len(out.strip().splitlines()) - 1
-res["search_stderr"] = [l for l in err.splitlines() if "Index loaded" in l or "k-mers in query" in l or "Search:" in l]
+res["search_stderr"] = [l for l in err.splitlines() if "Index loaded" in l or "k-mers in query" in l or "Search:" in l or "timing:" in l]
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-f", "0", "-p", "0.005")   # default report: mean / mode / unique
 res["search_default_total_s"] = dt; res["search_default_rows"] = len(out.strip().splitlines()) - 1
 dt, out, err = run("read_id", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-n", f"{W}/rid")
