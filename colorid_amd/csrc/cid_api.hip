@@ -1311,6 +1311,18 @@ int cid_tune(const char *name, long value) {
     return fail(CID_ERR_INVALID, "unknown tunable '%s'", name);
 }
 
+// The runtime loads a translation unit's device code on the first launch of one of its kernels — ~60 ms for the read_id kernels,
+// paid inside the first cid_readid_count* call.  This call pays it ahead of time and may run on another host thread than the one
+// using the ctx (it touches no stream, no ctx state): the CLI runs it beside the index load.
+int cid_warmup(cid_ctx *c, unsigned what) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (what & CID_WARM_READID) HIP_TRY(cid::warm_readid());
+    if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_search());
+    if (what & (CID_WARM_READID | CID_WARM_SEARCH)) HIP_TRY(cid::warm_kmerset());
+    return CID_OK;
+}
+
 int cid_timer_start(cid_ctx *c) {
     if (!c) return fail(CID_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));

@@ -75,4 +75,9 @@ int index_get_records(cid_ctx *c, const cid_index *ix, uint64_t row_begin, uint6
 int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_t n_rows, uint64_t **d_row_start, uint32_t **d_colours,
                    uint32_t **d_counts, uint64_t *n_entries);
 
+// load a translation unit's code object ahead of its first kernel launch (cid_warmup)
+hipError_t warm_readid();
+hipError_t warm_search();
+hipError_t warm_kmerset();
+
 }  // namespace cid

@@ -853,6 +853,11 @@ int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_
     return CID_OK;
 }
 
+hipError_t warm_kmerset() {   // see warm_readid (cid_readid.hip): this file's kernels serve k-mer counting, the sort-based read_id path and the sparse reports
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_row_nnz));
+}
+
 }  // namespace cid
 
 static int finalize_general(cid_kmerset *ks) {

@@ -809,4 +809,11 @@ hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t s
     return (p.zero_acc || p.zero_in) ? launch_readid_list_sel<true>(p, grid, stream) : launch_readid_list_sel<false>(p, grid, stream);
 }
 
+// the first use of a kernel loads its translation unit's whole code object (tens of milliseconds for this file's instantiations):
+// asking for a kernel's attributes does the same without a launch (cid_warmup)
+hipError_t warm_readid() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_readid_check_caps));
+}
+
 }  // namespace cid

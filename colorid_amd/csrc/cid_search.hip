@@ -503,4 +503,9 @@ hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {
     CID_LAUNCH_BY_LAYOUT(k_search_perfect, log_lpr, narrow, grid, shmem, stream, p);
 }
 
+hipError_t warm_search() {   // see warm_readid
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_unique_finalize));
+}
+
 }  // namespace cid

@@ -60,10 +60,41 @@ class LineReader {   // inflates on its own thread, a few MiB ahead of the calle
     // the same line as a view: valid until the next call on this reader (it points into the decoded block, or into the reader's
     // own buffer for a line that straddles two blocks) — no per-line copy
     bool next(const char *&ptr, size_t &len);
+    // Block interface, for a caller that splits the text itself (RecordChunker; not to be mixed with next() on one reader): the
+    // next decoded block, its text at [kHeadroom, blk.size()) — the bytes in front are the caller's to fill (the tail of the
+    // previous block).  Blocks go back with recycle().
+    static constexpr size_t kHeadroom = 1u << 16;
+    bool next_block(std::vector<char> &blk);
+    void recycle(std::vector<char> &&blk);
     struct Impl;   // (defined in fastx_kmers.cpp)
   private:
     Impl *p_;
 };
+
+// Whole FASTQ records (groups of four lines, counted from the start of the file as the reference's `line_count % 4` does) of one
+// input, a decoded block at a time: the text [begin, rec_end.back()) of buf, record r ending just past its fourth newline at
+// rec_end[r].  Lines that do not complete a record at the end of the input are dropped, as the line loops never push them
+// (read_id_mt_pe.rs:862-895).  Finding the boundaries is one memchr per line; the records of a chunk are then parsed in parallel.
+struct RecChunk {
+    std::vector<char> buf;
+    size_t begin = 0;
+    std::vector<uint32_t> rec_end;
+    size_t records() const { return rec_end.size(); }
+    size_t rec_begin(size_t r) const { return r ? rec_end[r - 1] : begin; }
+};
+class RecordChunker {
+  public:
+    explicit RecordChunker(LineReader &r) : r_(r) {}
+    bool next(RecChunk &c);              // false at the end of the input
+    void recycle(RecChunk &c) { if (!c.buf.empty()) r_.recycle(std::move(c.buf)); c.buf = std::vector<char>(); c.rec_end.clear(); }
+  private:
+    LineReader &r_;
+    std::string carry_;                  // the lines after the last whole record of the previous block
+    uint64_t carry_lines_ = 0;           // newlines inside carry_
+    bool done_ = false;
+};
+
+void debug_records(const std::string &f1, const std::string *f2, uint8_t q);   // CPU tests: the reads as the record pipeline packs them
 
 // GPU k-mer maps (cid_kmerset, k <= 32; COLORID_HOST_KMERS=1 forces the host map).  count_fastq_gpu returns nullptr when
 // the file holds lower-case bases (their case is kept, so they cannot be packed): the caller counts on the host.

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -29,7 +30,9 @@ static long secs_since(Clock::time_point t0) { return (long)std::chrono::duratio
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 // COLORID_TIMING=1: sub-second phase times on stderr (the reference's own timers print whole seconds)
 static bool g_timing = getenv("COLORID_TIMING") != nullptr;
-static double g_ms_gpu = 0, g_ms_poll = 0;
+static double g_ms_gpu = 0, g_ms_poll = 0, g_ms_gpu_count = 0;
+static uint64_t g_entries = 0;
+static double g_ms_wait[4] = {0, 0, 0, 0};   // parser blocked by a full queue | GPU stage idle | GPU stage blocked by the poll | poll idle
 
 // ---------------------------------------------------------------------------------------------- several GPUs
 static cid_group *g_group = nullptr;
@@ -62,45 +65,84 @@ static int hot_search_perfect_set(cid_ctx *ctx, const Bigsi &b, const cid_kmerse
 
 double false_prob(double m, double k, double n) { return std::pow(1.0 - std::pow(M_E, -((k * (n + 0.5)) / (m - 1.0))), k); }
 
-static double binomial_mass(uint64_t n, double p, uint64_t x) {  // probability::Binomial::mass, log-space
+// probability::Binomial::mass in log space.  The poll evaluates it ~10 times per read (once per candidate colour), so the pieces that
+// repeat are tabulated — ln Gamma(i + 1) for small i, ln p and ln(1 - p) per distinct p — by the very calls the direct formula makes:
+// the tabulated form returns the same doubles.
+static const std::vector<double> &lgamma_table() {
+    static const std::vector<double> t = [] {
+        std::vector<double> v(1u << 16);
+        int sg;   // lgamma_r: plain lgamma writes the global signgam, and several poll threads run at once
+        for (size_t i = 0; i < v.size(); ++i) v[i] = lgamma_r((double)i + 1.0, &sg);
+        return v;
+    }();
+    return t;
+}
+static inline double lgamma1p_int(uint64_t i) {   // ln Gamma(i + 1)
+    const std::vector<double> &t = lgamma_table();
+    if (i < t.size()) return t[i];
+    int sg;
+    return lgamma_r((double)i + 1.0, &sg);
+}
+static double binomial_mass(uint64_t n, double p, uint64_t x) {
     if (x > n) return 0.0;
     if (p <= 0.0) return x == 0 ? 1.0 : 0.0;
     if (p >= 1.0) return x == n ? 1.0 : 0.0;
-    int sg;   // lgamma_r: several poll threads run this at once (plain lgamma writes the global signgam)
-    const double lc = lgamma_r((double)n + 1.0, &sg) - lgamma_r((double)x + 1.0, &sg) - lgamma_r((double)(n - x) + 1.0, &sg);
-    return std::exp(lc + (double)x * std::log(p) + (double)(n - x) * std::log1p(-p));
+    struct Logs { double p = -1.0, lp = 0.0, l1mp = 0.0; };
+    static thread_local Logs memo[1024];   // one p per colour (its false-positive rate); direct-mapped on the bits of p
+    uint64_t bits;
+    memcpy(&bits, &p, 8);
+    Logs &m = memo[(bits * 0x9E3779B97F4A7C15ull) >> 54];
+    if (m.p != p) { m.p = p; m.lp = std::log(p); m.l1mp = std::log1p(-p); }
+    const double lc = lgamma1p_int(n) - lgamma1p_int(x) - lgamma1p_int(n - x);
+    return std::exp(lc + (double)x * m.lp + (double)(n - x) * m.l1mp);
 }
 
 static bool not_fp_significant(uint64_t observations, double p_false, double fp_correct, uint64_t hits) {  // read_id_mt_pe.rs:168-181
     const double critical = (double)observations * p_false;
-    const double mpf = binomial_mass(observations, p_false, hits);
-    return ((double)hits < critical) || (((double)hits > critical) && (mpf >= fp_correct));
+    // ((hits < critical) || ((hits > critical) && (mpf >= fp_correct))): the mass only matters above the critical value
+    if ((double)hits < critical) return true;
+    if (!((double)hits > critical)) return false;
+    return binomial_mass(observations, p_false, hits) >= fp_correct;
 }
 
-Classification kmer_poll_plus(const uint32_t *colours, const uint32_t *counts, size_t n_entries, uint64_t kmer_length, const Bigsi &b,
-                              const std::vector<double> &fp, double fp_correct) {
-    // `report` as the sparse list of its non-zero entries in ascending colour id (colour C = no_hits_num)
-    const size_t C = b.colors.size();
-    if (n_entries == 0 || (n_entries == 1 && colours[0] == C)) return {"no_hits", 0, kmer_length, "accept", 0};  // :197-205, :332-340
+// kmer_poll_plus (read_id_mt_pe.rs:187-251) on a read's sparse report — its non-zero entries in ascending colour id (colour C =
+// no_hits_num): which entries are significant (sig[e]) and, among those, the highest count and how many entries hold it
+struct Poll { int kind; uint64_t best, n_top; uint32_t first_top; };   // kind: 0 no_hits, 1 no_significant_hits, 2 the top colours
+static Poll poll_core(const uint32_t *colours, const uint32_t *counts, size_t n_entries, uint64_t kmer_length, size_t C, const std::vector<double> &fp,
+                      double fp_correct, uint8_t *sig) {
+    if (n_entries == 0 || (n_entries == 1 && colours[0] == C)) return {0, 0, 0, 0};  // :197-205, :332-340
     uint64_t best = 0, n_sig = 0;
-    std::vector<uint8_t> sig(n_entries, 0);
     for (size_t e = 0; e < n_entries; ++e) {
+        sig[e] = 0;
         if (colours[e] == C) continue;
         if (not_fp_significant(kmer_length, fp[colours[e]], fp_correct, counts[e])) continue;
         sig[e] = 1;
         ++n_sig;
         best = std::max<uint64_t>(best, counts[e]);
     }
-    if (n_sig == 0) return {"no_significant_hits", 0, kmer_length, "reject", 0};  // :216-223
-    std::string label;
+    if (n_sig == 0) return {1, 0, 0, 0};  // :216-223
     uint64_t n_top = 0;
+    uint32_t first = 0;
+    for (size_t e = 0; e < n_entries; ++e) {
+        sig[e] = sig[e] && counts[e] == best;
+        if (sig[e] && n_top++ == 0) first = colours[e];
+    }
+    return {2, best, n_top, first};
+}
+
+Classification kmer_poll_plus(const uint32_t *colours, const uint32_t *counts, size_t n_entries, uint64_t kmer_length, const Bigsi &b,
+                              const std::vector<double> &fp, double fp_correct) {
+    std::vector<uint8_t> sig(n_entries + 1, 0);
+    const Poll p = poll_core(colours, counts, n_entries, kmer_length, b.colors.size(), fp, fp_correct, sig.data());
+    if (p.kind == 0) return {"no_hits", 0, kmer_length, "accept", 0};
+    if (p.kind == 1) return {"no_significant_hits", 0, kmer_length, "reject", 0};
+    std::string label;
     for (size_t e = 0; e < n_entries; ++e)
-        if (sig[e] && counts[e] == best) {
-            if (n_top) label += ",";
+        if (sig[e]) {
+            if (!label.empty()) label += ",";
             label += b.colors[colours[e]];
-            ++n_top;
         }
-    return {label, best, kmer_length, n_top == 1 ? "accept" : "reject", n_top};
+    return {label, p.best, kmer_length, p.n_top == 1 ? "accept" : "reject", p.n_top};
 }
 
 // The tally of <prefix>_counts.txt, kept while the rows of <prefix>_reads.txt are written: the reference re-reads the file it
@@ -208,6 +250,129 @@ struct SeqBatch {
     void clear() { bases.clear(); off.assign(1, 0); }
 };
 
+namespace {
+
+struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
+    std::string id_chars;                 // the ids, NUL-terminated, back to back (no allocation per read)
+    std::vector<uint64_t> id_off;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> seq_off{0};
+    std::vector<uint64_t> read_seq0{0};
+    void push(const std::string &id, const std::string *seqs, size_t n) {
+        begin(id);
+        for (size_t s = 0; s < n; ++s) {
+            bases.insert(bases.end(), seqs[s].begin(), seqs[s].end());
+            seq_off.push_back(bases.size());
+        }
+        end();
+    }
+    // the same in pieces: begin(id), one mate(...) per sequence (quality-masked while it is copied), end()
+    void begin(const char *id, size_t n) { id_off.push_back(id_chars.size()); id_chars.append(id, n); id_chars.push_back('\0'); }
+    void begin(const std::string &id) { begin(id.data(), id.size()); }
+    void mate(const char *seq, size_t slen, const char *qual, size_t qlen, uint8_t q) { append_masked(bases, seq, slen, qual, qlen, q); seq_off.push_back(bases.size()); }
+    // the reads of `o` after this batch's own (pieces parsed on other threads, in input order)
+    void append(const ReadBatch &o) {
+        const uint64_t id0 = id_chars.size(), b0 = bases.size(), s0 = seq_off.size() - 1;
+        id_chars.append(o.id_chars);
+        for (uint64_t v : o.id_off) id_off.push_back(id0 + v);
+        bases.insert(bases.end(), o.bases.begin(), o.bases.end());
+        for (size_t i = 1; i < o.seq_off.size(); ++i) seq_off.push_back(b0 + o.seq_off[i]);
+        for (size_t i = 1; i < o.read_seq0.size(); ++i) read_seq0.push_back(s0 + o.read_seq0[i]);
+    }
+    void end() { read_seq0.push_back(seq_off.size() - 1); }
+    const char *id(size_t r) const { return id_chars.data() + id_off[r]; }
+    size_t size() const { return id_off.size(); }
+    // long reads: a batch also closes once it holds this many bases (the library numbers a batch's k-mer windows in 32 bits;
+    // batch boundaries never change a read's result)
+    bool heavy() const { return bases.size() >= (256u << 20); }
+    void clear() { id_chars.clear(); id_off.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
+};
+
+// ---- FASTQ text -> packed batches on several threads.  RecordChunker cuts each input's decoded blocks at record boundaries (one
+// memchr per line, on the calling thread); the records of a chunk — for pairs: as many records of either file's current chunk as
+// both have — are split into lines, quality-masked (seq.rs:36-56) and packed by COLORID_PARSE_THREADS threads; the
+// pieces reach `sink` in input order.  The same reads in the same order as the line loops of read_id_mt_pe.rs:862-895 / :927-975
+// and kmer.rs:481-503 / :619-647: a record is pushed at its fourth line; for pairs the walk ends with the shorter file.
+// (default 2: on a 16-CPU share of a GPU box more packers take cycles from the inflating threads and from the GPU stage's host side —
+// tools/exp_readid_stages.sh, 3 runs per setting: 2 packers + 8 poll threads 108-131 ms per million reads, 4 + 8: 130-143, 1 + 8: 152-178)
+const int g_parse_threads = [] { const char *e = getenv("COLORID_PARSE_THREADS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+
+struct Line { const char *p; size_t n; };
+inline void record_lines(const RecChunk &c, size_t r, Line out[4]) {
+    const char *p = c.buf.data() + c.rec_begin(r), *end = c.buf.data() + c.rec_end[r];
+    for (int i = 0; i < 4; ++i) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));   // there: the chunker counted four of them
+        size_t n = (size_t)(nl - p);
+        if (n && p[n - 1] == '\r') --n;
+        out[i] = Line{p, n};
+        p = nl + 1;
+    }
+}
+ReadBatch pack_records(const RecChunk *c1, size_t a0, const RecChunk *c2, size_t b0, size_t n, uint8_t q, bool want_ids) {
+    ReadBatch rb;
+    const size_t text = c1->rec_end[a0 + n - 1] - c1->rec_begin(a0);
+    rb.bases.reserve((c2 ? 2 : 1) * (text / 2 + 64));
+    rb.seq_off.reserve((c2 ? 2 : 1) * n + 1);
+    rb.read_seq0.reserve(n + 1);
+    if (want_ids) { rb.id_off.reserve(n); rb.id_chars.reserve(text / 4 + 64); }
+    Line l[4], m[4];
+    for (size_t i = 0; i < n; ++i) {
+        record_lines(*c1, a0 + i, l);
+        if (want_ids) rb.begin(l[0].p, l[0].n); else rb.id_off.push_back(0);
+        rb.mate(l[1].p, l[1].n, l[3].p, l[3].n, q);
+        if (c2) {
+            record_lines(*c2, b0 + i, m);
+            rb.mate(m[1].p, m[1].n, m[3].p, m[3].n, q);
+        }
+        rb.end();
+    }
+    return rb;
+}
+
+template <typename Sink>
+void stream_fastq_records(const std::string &f1, const std::string *f2, uint8_t q, bool want_ids, Sink &&sink) {
+    LineReader r1(f1);
+    std::unique_ptr<LineReader> r2(f2 ? new LineReader(*f2) : nullptr);
+    RecordChunker k1(r1);
+    std::unique_ptr<RecordChunker> k2(r2 ? new RecordChunker(*r2) : nullptr);
+    auto fresh = [](RecordChunker &k) {   // a chunk whose buffer returns to its reader when the last piece cut from it is packed
+        RecordChunker *kp = &k;
+        return std::shared_ptr<RecChunk>(new RecChunk, [kp](RecChunk *c) { kp->recycle(*c); delete c; });
+    };
+    std::deque<std::future<ReadBatch>> inflight;
+    auto drain_one = [&] { ReadBatch piece = inflight.front().get(); inflight.pop_front(); sink(std::move(piece)); };
+    std::shared_ptr<RecChunk> c1, c2;
+    size_t p1 = 0, p2 = 0;
+    for (;;) {
+        if (!c1 || p1 == c1->records()) { c1 = fresh(k1); p1 = 0; if (!k1.next(*c1)) break; }
+        size_t n = c1->records() - p1;
+        if (k2) {
+            if (!c2 || p2 == c2->records()) { c2 = fresh(*k2); p2 = 0; if (!k2->next(*c2)) break; }
+            n = std::min(n, c2->records() - p2);
+        }
+        while (inflight.size() >= (size_t)g_parse_threads) drain_one();
+        inflight.push_back(std::async(std::launch::async, [c1, p1, c2, p2, n, q, want_ids] { return pack_records(c1.get(), p1, c2.get(), p2, n, q, want_ids); }));
+        p1 += n; p2 += n;
+    }
+    while (!inflight.empty()) drain_one();
+}
+
+}  // namespace
+
+// host-only helper of the CPU tests: what the record pipeline hands to the GPU calls, one line per read — id, then its masked mates
+void debug_records(const std::string &f1, const std::string *f2, uint8_t q) {
+    stream_fastq_records(f1, f2, q, true, [&](ReadBatch &&piece) {
+        for (size_t r = 0; r < piece.size(); ++r) {
+            fputs(piece.id(r), stdout);
+            for (uint64_t sq = piece.read_seq0[r]; sq < piece.read_seq0[r + 1]; ++sq) {
+                fputc('\t', stdout);
+                fwrite(piece.bases.data() + piece.seq_off[sq], 1, (size_t)(piece.seq_off[sq + 1] - piece.seq_off[sq]), stdout);
+            }
+            fputc('\n', stdout);
+        }
+    });
+}
+
 cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs) {
     cid_kmerset *ks = nullptr;
     CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
@@ -222,33 +387,23 @@ cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::st
 // false = a batch held lower-case bases (CID_ERR_UNSUPPORTED): count the file on the host
 template <typename Add>
 static bool stream_fastq_batches(const std::string &f1, const std::string *f2, uint8_t q, Add &&add) {
-    LineReader r1(f1);
-    LineReader *r2 = f2 ? new LineReader(*f2) : nullptr;
     SeqBatch sb;
-    std::string s1, s2;
-    const char *l1 = nullptr, *l2 = nullptr;   // views into the readers' blocks
-    size_t n1 = 0, n2 = 0;
-    uint64_t line_count = 1;
     bool ok = true;
     auto flush = [&]() {
-        if (sb.n() == 0) return;
+        if (sb.n() == 0 || !ok) return;
         const int rc = add(sb);
         if (rc == CID_ERR_UNSUPPORTED) ok = false;
         else if (rc != CID_OK) die("cid_kmerset_add_seqs: %s", cid_last_error());
         sb.clear();
     };
-    while (ok && r1.next(l1, n1)) {
-        if (r2 && !r2->next(l2, n2)) break;
-        if (line_count % 4 == 2) { s1.assign(l1, n1); if (r2) s2.assign(l2, n2); }
-        else if (line_count % 4 == 0) {
-            sb.push_masked(s1, l1, n1, q);
-            if (r2) sb.push_masked(s2, l2, n2, q);
-            if (sb.bases.size() >= (256u << 20)) flush();
-        }
-        ++line_count;
-    }
-    if (ok) flush();
-    delete r2;
+    stream_fastq_records(f1, f2, q, false, [&](ReadBatch &&piece) {
+        if (!ok) return;   // (the rest of the file is still read: the caller falls back to the host map, which reads it again)
+        const uint64_t b0 = sb.bases.size();
+        sb.bases.insert(sb.bases.end(), piece.bases.begin(), piece.bases.end());
+        for (size_t i = 1; i < piece.seq_off.size(); ++i) sb.off.push_back(b0 + piece.seq_off[i]);
+        if (sb.bases.size() >= (256u << 20)) flush();
+    });
+    flush();
     return ok;
 }
 
@@ -481,32 +636,6 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
 
 namespace {
 
-struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
-    std::string id_chars;                 // the ids, NUL-terminated, back to back (no allocation per read)
-    std::vector<uint64_t> id_off;
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> seq_off{0};
-    std::vector<uint64_t> read_seq0{0};
-    void push(const std::string &id, const std::string *seqs, size_t n) {
-        begin(id);
-        for (size_t s = 0; s < n; ++s) {
-            bases.insert(bases.end(), seqs[s].begin(), seqs[s].end());
-            seq_off.push_back(bases.size());
-        }
-        end();
-    }
-    // the same in pieces: begin(id), one mate(...) per sequence (quality-masked while it is copied), end()
-    void begin(const std::string &id) { id_off.push_back(id_chars.size()); id_chars.append(id.data(), id.size()); id_chars.push_back('\0'); }
-    void mate(const std::string &seq, const char *qual, size_t qlen, uint8_t q) { append_masked(bases, seq.data(), seq.size(), qual, qlen, q); seq_off.push_back(bases.size()); }
-    void end() { read_seq0.push_back(seq_off.size() - 1); }
-    const char *id(size_t r) const { return id_chars.data() + id_off[r]; }
-    size_t size() const { return id_off.size(); }
-    // long reads: a batch also closes once it holds this many bases (the library numbers a batch's k-mer windows in 32 bits;
-    // batch boundaries never change a read's result)
-    bool heavy() const { return bases.size() >= (256u << 20); }
-    void clear() { id_chars.clear(); id_off.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
-};
-
 // parallel_vec (read_id_mt_pe.rs:282-363) in two stages: counts on the GPU ...
 struct Counted {   // one batch after the GPU stage: each read's non-zero (colour, count) entries
     ReadBatch rb;
@@ -532,9 +661,11 @@ void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t star
     else
         CID_TRY(cid_readid_count_sparse(ctx, b.index, rb.bases.data(), rb.seq_off.data(), rb.seq_off.size() - 1, rb.read_seq0.data(), n,
                                         (uint32_t)d, (uint32_t)start_sample, c.nk.data(), c.status.data(), &n_entries));
+    g_ms_gpu_count += ms_since(t_gpu);
     c.row_start.resize(n + 1);
     c.colours.resize(n_entries);
     c.counts.resize(n_entries);
+    g_entries += n_entries;
     if (g_group) CID_TRY(cid_group_readid_sparse_fetch(g_group, c.row_start.data(), c.colours.data(), c.counts.data()));
     else CID_TRY(cid_readid_sparse_fetch(ctx, c.row_start.data(), c.colours.data(), c.counts.data()));
     g_ms_gpu += ms_since(t_gpu);
@@ -543,30 +674,47 @@ void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t star
 // ... and the poll (kmer_poll_plus per read, read_id_mt_pe.rs:168-251) + the rows of <prefix>_reads.txt on the host: the reads of a
 // batch are independent, so COLORID_POLL_THREADS (default 8) threads format contiguous slices of it and the slices are written in order
 static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+static inline void append_u64(std::string &o, uint64_t v) {
+    char t[24];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) o.push_back(t[--n]);
+}
 void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::vector<double> &fp, FILE *out,
                 std::map<std::string, uint64_t> &tally, bool &tally_ok) {
-    const size_t n = c.rb.size();
+    const size_t n = c.rb.size(), C = b.colors.size();
     const auto t_poll = Clock::now();
-    const size_t nt = std::min<size_t>((size_t)g_poll_threads, (n + 1023) / 1024);
+    const size_t nt = std::min<size_t>((size_t)g_poll_threads, (n + 4095) / 4096);
     std::vector<std::string> text(nt);
-    std::vector<std::map<std::string, uint64_t>> part(nt);
-    std::vector<uint64_t> n_short(nt, 0);
-    std::vector<uint8_t> tabs(nt, 0);
+    // the tally of <prefix>_counts.txt: an accepted read counts under its label — one accession, "no_hits" or "too_short" — every other under "reject"
+    std::vector<std::vector<uint64_t>> acc(nt, std::vector<uint64_t>(C + 3, 0));   // [C] no_hits, [C+1] too_short, [C+2] reject
     if (memchr(c.rb.id_chars.data(), '\t', c.rb.id_chars.size())) tally_ok = false;
     auto work = [&](size_t t) {
         std::string &o = text[t];
-        char num[96];
-        for (size_t r = n * t / nt; r < n * (t + 1) / nt; ++r) {
+        const size_t r0 = n * t / nt, r1 = n * (t + 1) / nt;
+        o.reserve((r1 - r0) * 48 + (c.rb.id_off[r1 - 1] - c.rb.id_off[r0]) + 64);
+        std::vector<uint8_t> sig(64);
+        std::vector<uint64_t> &a = acc[t];
+        for (size_t r = r0; r < r1; ++r) {
             o += c.rb.id(r);
-            if (c.status[r] == 1) { o += "\ttoo_short\t0\t0\taccept\t0\n"; ++n_short[t]; continue; }
-            const Classification cl = kmer_poll_plus(c.colours.data() + c.row_start[r], c.counts.data() + c.row_start[r],
-                                                     (size_t)(c.row_start[r + 1] - c.row_start[r]), c.nk[r], b, fp, fp_correct);
-            if (cl.label.find('\t') != std::string::npos) tabs[t] = 1;
-            if (strcmp(cl.verdict, "accept") == 0) part[t][cl.label] += 1; else part[t]["reject"] += 1;
-            o += '\t'; o += cl.label;
-            snprintf(num, sizeof num, "\t%llu\t%llu\t%s\t%llu\n", (unsigned long long)cl.count, (unsigned long long)cl.kmer_length, cl.verdict,
-                     (unsigned long long)cl.n_top);
-            o += num;
+            if (c.status[r] == 1) { o += "\ttoo_short\t0\t0\taccept\t0\n"; ++a[C + 1]; continue; }
+            const size_t e0 = (size_t)c.row_start[r], ne = (size_t)(c.row_start[r + 1] - c.row_start[r]);
+            if (sig.size() < ne + 1) sig.resize(ne + 1);
+            const Poll p = poll_core(c.colours.data() + e0, c.counts.data() + e0, ne, c.nk[r], C, fp, fp_correct, sig.data());
+            o += '\t';
+            if (p.kind == 0) { o += "no_hits"; ++a[C]; }
+            else if (p.kind == 1) { o += "no_significant_hits"; ++a[C + 2]; }
+            else {
+                bool first = true;
+                for (size_t e = 0; e < ne; ++e)
+                    if (sig[e]) { if (!first) o += ','; first = false; o += b.colors[c.colours[e0 + e]]; }
+                ++a[p.n_top == 1 ? p.first_top : C + 2];
+            }
+            o += '\t'; append_u64(o, p.best);
+            o += '\t'; append_u64(o, c.nk[r]);
+            o += (p.kind == 0 || (p.kind == 2 && p.n_top == 1)) ? "\taccept\t" : "\treject\t";
+            append_u64(o, p.n_top);
+            o += '\n';
         }
     };
     std::vector<std::thread> th;
@@ -575,9 +723,11 @@ void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::
     for (auto &x : th) x.join();
     for (const std::string &o : text) fwrite(o.data(), 1, o.size(), out);
     for (size_t t = 0; t < nt; ++t) {
-        for (auto &kv : part[t]) tally[kv.first] += kv.second;
-        if (n_short[t]) tally["too_short"] += n_short[t];
-        if (tabs[t]) tally_ok = false;
+        const std::vector<uint64_t> &a = acc[t];
+        for (size_t col = 0; col < C; ++col) if (a[col]) tally[b.colors[col]] += a[col];
+        if (a[C]) tally["no_hits"] += a[C];
+        if (a[C + 1]) tally["too_short"] += a[C + 1];
+        if (a[C + 2]) tally["reject"] += a[C + 2];
     }
     g_ms_poll += ms_since(t_poll);
 }
@@ -596,12 +746,16 @@ class BatchClassifier {
     BatchClassifier(cid_ctx *ctx, const Bigsi &b, size_t d, double fp_correct, size_t start_sample, const std::vector<double> &fp, FILE *out,
                     const char *progress_fmt)
         : ctx_(ctx), b_(b), d_(d), fp_correct_(fp_correct), start_sample_(start_sample), fp_(fp), out_(out), progress_fmt_(progress_fmt),
-          counter_([this] { run_count(); }), poller_([this] { run_poll(); }) {}
+          counter_([this] { run_count(); }), poller_([this] { run_poll(); }) {
+        for (const std::string &name : b.colors) if (name.find('\t') != std::string::npos) tally_ok_ = false;
+    }
     // hands `rb` over and leaves an empty batch in its place; waits while kDepth batches are queued
     void submit(ReadBatch &rb) {
         if (rb.size() == 0) return;
         std::unique_lock<std::mutex> lk(mu_);
+        const auto tw = Clock::now();
         cv_room_.wait(lk, [&] { return queue_.size() < kDepth; });
+        g_ms_wait[0] += ms_since(tw);
         queue_.push_back(std::move(rb));
         if (!spare_.empty()) { rb = std::move(spare_.back()); spare_.pop_back(); }
         else rb = ReadBatch();
@@ -627,7 +781,9 @@ class BatchClassifier {
             std::unique_ptr<Counted> c(new Counted);
             {
                 std::unique_lock<std::mutex> lk(mu_);
+                const auto tw = Clock::now();
                 cv_work_.wait(lk, [&] { return done_ || !queue_.empty(); });
+                g_ms_wait[1] += ms_since(tw);
                 if (queue_.empty()) break;
                 c->rb = std::move(queue_.front());
                 queue_.pop_front();
@@ -635,7 +791,9 @@ class BatchClassifier {
             }
             count_batch(ctx_, b_, *c, d_, start_sample_);
             std::unique_lock<std::mutex> lk(mu_);
+            const auto tw = Clock::now();
             cv_polled_.wait(lk, [&] { return counted_.size() < kDepth; });
+            g_ms_wait[2] += ms_since(tw);
             counted_.push_back(std::move(c));
             cv_counted_.notify_one();
         }
@@ -648,7 +806,9 @@ class BatchClassifier {
             std::unique_ptr<Counted> c;
             {
                 std::unique_lock<std::mutex> lk(mu_);
+                const auto tw = Clock::now();
                 cv_counted_.wait(lk, [&] { return count_done_ || !counted_.empty(); });
+                g_ms_wait[3] += ms_since(tw);
                 if (counted_.empty()) return;
                 c = std::move(counted_.front());
                 counted_.pop_front();
@@ -690,30 +850,18 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     const std::vector<double> fp = false_prob_map(b);
     FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
     if (!out) die("could not create outfile!");
-    LineReader r(fq[0]);
     ReadBatch rb;
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
-    std::string id, seq;
-    const char *line = nullptr;   // a view into the reader's block
-    size_t len = 0;
-    uint64_t line_count = 1;
-    const uint64_t lines_per_batch = (uint64_t)batch * 4;
-    while (r.next(line, len)) {
-        if (line_count % 4 == 1) id.assign(line, len);
-        else if (line_count % 4 == 2) seq.assign(line, len);
-        else if (line_count % 4 == 0) {
-            rb.begin(id);
-            rb.mate(seq, line, len, qual_offset);   // qual_mask while the read is packed
-            rb.end();
-        }
-        ++line_count;
-        if (line_count % lines_per_batch == 0 || rb.heavy()) classifier.submit(rb);
-    }
+    stream_fastq_records(fq[0], nullptr, qual_offset, true, [&](ReadBatch &&piece) {
+        if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
+        if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);   // (batches close on piece boundaries: at least `batch` reads each)
+    });
     classifier.submit(rb);
     const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
-    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll);
+    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms; waits: parser on a full queue %.0f ms, GPU stage idle %.0f ms, "
+                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries);
 }
 
 void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
@@ -722,35 +870,18 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     const std::vector<double> fp = false_prob_map(b);
     FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
     if (!out) die("could not create outfile!");
-    LineReader r1(fq[0]), r2(fq[1]);
     ReadBatch rb;
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
-    std::string id, seqs[2];
-    const char *l1 = nullptr, *l2 = nullptr;   // views into the readers' blocks
-    size_t n1 = 0, n2 = 0;
-    uint64_t line_count = 1;
-    const uint64_t lines_per_batch = (uint64_t)batch * 4;
-    while (r1.next(l1, n1)) {
-        const bool has2 = r2.next(l2, n2);
-        if (line_count % 4 == 1) id.assign(l1, n1);
-        else if (line_count % 4 == 2) {
-            if (!has2) break;
-            seqs[0].assign(l1, n1); seqs[1].assign(l2, n2);
-        } else if (line_count % 4 == 0) {
-            if (!has2) break;
-            rb.begin(id);
-            rb.mate(seqs[0], l1, n1, qual_offset);   // qual_mask while the pair is packed
-            rb.mate(seqs[1], l2, n2, qual_offset);
-            rb.end();
-        }
-        ++line_count;
-        if (line_count % lines_per_batch == 0 || rb.heavy()) classifier.submit(rb);
-    }
+    stream_fastq_records(fq[0], &fq[1], qual_offset, true, [&](ReadBatch &&piece) {
+        if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
+        if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);
+    });
     classifier.submit(rb);
     const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu read pairs in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
-    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll);
+    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms; waits: parser on a full queue %.0f ms, GPU stage idle %.0f ms, "
+                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries);
 }
 
 void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,

@@ -96,7 +96,7 @@ void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, st
 // COLORID_GZ_THREADS (default 8) inflating threads, each writing at its member's offset of the output block (the members'
 // uncompressed sizes are in their trailers).  Single-stream gzip has no such boundaries and stays on one zlib thread.
 struct LineReader::Impl {
-    static constexpr size_t kBlock = 4u << 20;
+    static constexpr size_t kBlock = 4u << 20, kHead = LineReader::kHeadroom;   // a block's text starts at kHead
     size_t depth = 4;              // blocks in flight (prefetched streams: ~256 MiB worth)
     gzFile gz = nullptr;
     FILE *raw = nullptr;           // BGZF mode: the compressed file itself
@@ -133,7 +133,7 @@ struct LineReader::Impl {
 
     void push(std::vector<char> &&blk, bool last) {
         std::lock_guard<std::mutex> lk(mu);
-        if (!blk.empty()) full.push_back(std::move(blk));
+        if (blk.size() > kHead) full.push_back(std::move(blk));
         if (last) eof = true;
         cv_full.notify_one();
     }
@@ -149,14 +149,14 @@ struct LineReader::Impl {
         for (;;) {
             std::vector<char> blk;
             if (!take_free(blk)) return;
-            blk.resize(kBlock);
+            blk.resize(kHead + kBlock);
             size_t got = 0;
             while (got < kBlock) {   // gzread may return short counts at member boundaries
-                const int n = gzread(gz, blk.data() + got, (unsigned)(kBlock - got));
+                const int n = gzread(gz, blk.data() + kHead + got, (unsigned)(kBlock - got));
                 if (n <= 0) break;
                 got += (size_t)n;
             }
-            blk.resize(got);
+            blk.resize(kHead + got);
             const bool last = got < kBlock;
             push(std::move(blk), last);
             if (last) return;
@@ -202,7 +202,7 @@ struct LineReader::Impl {
                 scan = in_pos + msz;
             }
             in_pos = scan;
-            blk.resize(out_total);
+            blk.resize(kHead + out_total);
             if (!mem.empty()) {
                 const int nt = (int)std::min<size_t>((size_t)gz_threads, mem.size());
                 std::vector<std::thread> th;
@@ -215,7 +215,7 @@ struct LineReader::Impl {
                         const Member &m = mem[i];
                         inflateReset(&zs);
                         zs.next_in = in.data() + m.in_off; zs.avail_in = (uInt)m.in_len;
-                        zs.next_out = reinterpret_cast<Bytef *>(blk.data() + m.out_off); zs.avail_out = (uInt)m.out_len;
+                        zs.next_out = reinterpret_cast<Bytef *>(blk.data() + kHead + m.out_off); zs.avail_out = (uInt)m.out_len;
                         const int rc = inflate(&zs, Z_FINISH);
                         if (rc != Z_STREAM_END || zs.total_out != m.out_len) { bad[t] = 1; break; }   // zlib checked the member's CRC-32
                     }
@@ -237,9 +237,22 @@ struct LineReader::Impl {
         if (full.empty()) { cur = std::vector<char>(); pos = 0; return false; }
         cur = std::move(full.front());
         full.pop_front();
-        pos = 0;
+        pos = kHead;
         cv_free.notify_one();
         return true;
+    }
+    bool take_block(std::vector<char> &blk) {   // the block interface: ownership moves to the caller
+        std::unique_lock<std::mutex> lk(mu);
+        cv_full.wait(lk, [&] { return eof || !full.empty(); });
+        if (full.empty()) return false;
+        blk = std::move(full.front());
+        full.pop_front();
+        cv_free.notify_one();
+        return true;
+    }
+    void give_back(std::vector<char> &&blk) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (free_blocks.size() < depth + 8) free_blocks.push_back(std::move(blk));
     }
 };
 
@@ -349,6 +362,61 @@ bool LineReader::next(const char *&ptr, size_t &len) {
     ptr = p_->carry.data(); len = p_->carry.size();   // last line without a newline
     if (len && ptr[len - 1] == '\r') --len;
     return true;
+}
+
+bool LineReader::next_block(std::vector<char> &blk) { return p_->take_block(blk); }
+void LineReader::recycle(std::vector<char> &&blk) { p_->give_back(std::move(blk)); }
+
+bool RecordChunker::next(RecChunk &c) {
+    c.rec_end.clear();
+    for (;;) {
+        if (done_) return false;
+        std::vector<char> blk;
+        const bool have = r_.next_block(blk);
+        if (!have) {   // end of input: what is left is at most three lines and perhaps a fourth without its newline
+            done_ = true;
+            if (carry_.empty()) return false;
+            if (carry_.back() != '\n') carry_.push_back('\n');   // BufRead::lines() yields an unterminated last line too
+            blk.assign(LineReader::kHeadroom, 0);
+        }
+        // the previous block's tail goes in front of this block's text: into the headroom, or (a record longer than that) into a new buffer
+        size_t begin = LineReader::kHeadroom;
+        if (!carry_.empty()) {
+            if (carry_.size() <= LineReader::kHeadroom && have) {
+                begin -= carry_.size();
+                memcpy(blk.data() + begin, carry_.data(), carry_.size());
+            } else {
+                std::vector<char> joined(LineReader::kHeadroom + carry_.size() + (blk.size() - LineReader::kHeadroom));
+                memcpy(joined.data() + LineReader::kHeadroom, carry_.data(), carry_.size());
+                memcpy(joined.data() + LineReader::kHeadroom + carry_.size(), blk.data() + LineReader::kHeadroom, blk.size() - LineReader::kHeadroom);
+                if (have) r_.recycle(std::move(blk));
+                blk.swap(joined);
+            }
+        }
+        if (blk.size() >= (1ull << 32)) die("a FASTQ record of more than 4 GiB");
+        // newlines from where the carried lines end; every fourth one closes a record
+        const char *base = blk.data(), *end = base + blk.size();
+        const char *p = base + begin + carry_.size();
+        uint64_t lines = carry_lines_;
+        if (!have) { p = base + begin; lines = 0; }   // (the final carry is scanned whole: its last newline was just added)
+        while (p < end) {
+            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            if (!nl) break;
+            p = nl + 1;
+            if ((++lines & 3u) == 0) c.rec_end.push_back((uint32_t)(p - base));
+        }
+        const size_t boundary = c.rec_end.empty() ? begin : c.rec_end.back();
+        carry_.assign(base + boundary, (size_t)(end - (base + boundary)));
+        carry_lines_ = lines & 3u;
+        if (!have) carry_.clear();
+        if (c.rec_end.empty()) {   // no whole record yet (very long reads): keep reading
+            if (have) r_.recycle(std::move(blk));
+            continue;
+        }
+        c.buf = std::move(blk);
+        c.begin = begin;
+        return true;
+    }
 }
 
 void qual_mask(std::string &seq, const std::string &qual, uint8_t q) {

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "colorid_host.hpp"
 
@@ -139,6 +140,18 @@ Gpus make_gpus(const Args &a) {
     return g;
 }
 
+// The device code of the kernels a command will launch is loaded on a helper thread while the index loads (cid_warmup): the
+// runtime would otherwise load it inside the first search / read_id call (~60 ms for the read_id kernels).
+std::thread warm_async(const Gpus &g, unsigned what) {
+    std::vector<cid_ctx *> ctxs;
+    if (g.group) {
+        int n = 0;
+        cid_group_size(g.group, &n);
+        for (int r = 0; r < n; ++r) { cid_ctx *c = nullptr; if (cid_group_ctx(g.group, r, &c) == CID_OK) ctxs.push_back(c); }
+    } else ctxs.push_back(g.ctx);
+    return std::thread([ctxs, what] { for (cid_ctx *c : ctxs) (void)cid_warmup(c, what); });   // (a failure here shows up in the first real call)
+}
+
 void replicate(Gpus &g, Bigsi &b) {   // after the index is loaded on rank 0
     if (!g.group) return;
     if (g.striped) { set_stripes(g.group, g.replicas); return; }   // load_index put the stripes in place
@@ -250,9 +263,11 @@ int cmd_search(int argc, char **argv) {
     }
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
+    std::thread warm = warm_async(gpus, CID_WARM_SEARCH);
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
+    warm.join();
     phase_done("index load");
     if (a.flags.count("perfect_search")) {
         if (a.flags.count("multi_fasta")) perfect_search::batch_search_mf(ctx, files1, b);
@@ -305,9 +320,11 @@ int cmd_read_id(int argc, char **argv) {
         for (size_t i = 0; i < fq.size() && i < 2; ++i) LineReader::prefetch(fq[i]);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
+    std::thread warm = warm_async(gpus, CID_WARM_READID);
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
+    warm.join();
     phase_done("index load");
     if (ends_with(fq[0], ".gz")) {
         if (fq.size() > 1) read_id_mt_pe::per_read_stream_pe(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
@@ -386,6 +403,14 @@ int cmd_debug_kmers(int argc, char **argv) {
     return 0;
 }
 
+// host-only helper used by the CPU tests: the reads of a FASTQ file (pair) as the record pipeline packs them for read_id / search
+int cmd_debug_records(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, {{'q', "query", true, true}, {'Q', "quality", true, false}});
+    const std::vector<std::string> q = a.values.at("query");
+    debug_records(q[0], q.size() > 1 ? &q[1] : nullptr, num_or<uint8_t>(a, "quality", 15));
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -402,6 +427,7 @@ int main(int argc, char **argv) {
     if (cmd == "read_id") return cmd_read_id(argc, argv);
     if (cmd == "hashcheck") return cmd_hashcheck(argc, argv);
     if (cmd == "debug-kmers") return cmd_debug_kmers(argc, argv);
+    if (cmd == "debug-records") return cmd_debug_records(argc, argv);
     if (cmd == "batch_id" || cmd == "read_filter") die("'%s' is outside the accelerated query path; use the reference binary", cmd.c_str());
     die("error: Found argument '%s' which wasn't expected", cmd.c_str());
 }

@@ -353,6 +353,12 @@ int cid_group_stripes_readid_count_sparse(cid_group *, cid_index *const *stripes
  *   "order_bits"      0..32  cid_kmerset_order_for_index groups by this many leading bits of the first row's position
  *                     (0 = by its exact 128-byte line) */
 int cid_tune(const char *name, long value);
+/* Loads the device code of the read_id and/or search kernels now instead of inside the first call that launches one of them (the
+ * runtime loads a code object on first use: ~60 ms for the read_id kernels).  Touches no stream and no ctx state: it may run on
+ * another host thread while the ctx loads an index (what the CLI does). */
+#define CID_WARM_READID 1u
+#define CID_WARM_SEARCH 2u
+int cid_warmup(cid_ctx *, unsigned what);
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */
 

@@ -194,3 +194,97 @@ def test_line_reader_edge_cases(orc, genomes, tmp_path):
         pass
     got, _ = parse_kmers(run("debug-kmers", "-q", empty, "-k", "27", "--mode", "fq", "-Q", "15")[0])
     assert got == {}
+
+
+def _line_loop_reads(texts, q):
+    """The reference's line loops restated (read_id_mt_pe.rs:862-895 single-end, :927-975 paired; seq.rs:36-56 qual_mask): lines as
+    BufRead::lines() yields them, a record pushed at every fourth line, for pairs until the shorter file ends."""
+    def lines(t):
+        ls = t.split(b"\n")
+        if ls and ls[-1] == b"":
+            ls.pop()
+        return [x[:-1] if x.endswith(b"\r") else x for x in ls]
+
+    def mask(seq, qual):
+        if q == 0:
+            return seq
+        assert len(seq) >= len(qual)
+        return bytes(b"N"[0] if w < q + 33 else s for s, w in zip(seq, qual))
+    ls = [lines(t) for t in texts]
+    out = []
+    n = min(len(x) for x in ls)
+    for r in range(n // 4):
+        out.append((ls[0][4 * r], [mask(x[4 * r + 1], x[4 * r + 3]) for x in ls]))
+    return out
+
+
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_record_pipeline_equals_the_line_loops(tmp_path, threads):
+    """`read_id` / `search` cut the decoded FASTQ text into whole records and pack them on several threads (RecordChunker +
+    pack_records): the reads, their order, their ids and the quality masking must be those of the reference's line-by-line loops —
+    over block boundaries (4 MiB decode blocks, 777-byte BGZF members), CRLF, records longer than a block and longer than the
+    64 KiB carry headroom, a last line without its newline, trailing lines that complete no record, files of different length."""
+    import gzip
+    from test_linereader_cpu import write_bgzf
+    rng = np.random.default_rng(int(threads))
+    env = dict(os.environ, COLORID_PARSE_THREADS=threads)
+
+    def fastq(n, eol=b"\n", long_at=(), seed=0):
+        r = np.random.default_rng(seed)
+        out = []
+        for i in range(n):
+            L = int(r.integers(1, 300)) if i not in long_at else int(r.integers(70_000, 5_000_000))
+            s = bytes(r.choice(list(b"ACGTNacgt"), size=L).astype(np.uint8))
+            w = bytes(r.integers(33, 75, size=L).astype(np.uint8))
+            out.append(b"@r%d/x y" % i + eol + s + eol + b"+" + eol + w + eol)
+        return b"".join(out)
+
+    def got_reads(paths, q):
+        p = subprocess.run([BIN, "debug-records", "-q", *[str(x) for x in paths], "-Q", str(q)], capture_output=True, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-500:]
+        out = p.stdout[len(BANNER):]
+        res = []
+        for line in out.split(b"\n")[:-1]:
+            f = line.split(b"\t")
+            res.append((f[0], f[1:]))
+        return res
+
+    cases = {
+        "big": fastq(40_000, seed=1),                                    # ~ 12 MB: several 4 MiB blocks
+        "crlf": fastq(3_000, eol=b"\r\n", seed=2),
+        "long": fastq(60, long_at=(3, 17, 18, 59), seed=3),              # records longer than the headroom and than a block
+        "nolast": fastq(500, seed=4)[:-1],                               # the last quality line has no newline
+        "trailing": fastq(500, seed=5) + b"@partial\nACGT\n",            # two lines that complete no record
+        "empty": b"",
+        "one": fastq(1, seed=6),
+    }
+    for tag, text in cases.items():
+        for q in (15, 0):
+            want = _line_loop_reads([text], q)
+            for kind in ("plain", "gz", "bgzf"):
+                if kind != "gz" and tag in ("long",) and q == 0:
+                    continue
+                path = tmp_path / f"{tag}_{kind}.fastq{'' if kind == 'plain' else '.gz'}"
+                if kind == "plain":
+                    path.write_bytes(text)
+                elif kind == "gz":
+                    with gzip.open(path, "wb", compresslevel=1) as f:
+                        f.write(text)
+                else:
+                    write_bgzf(path, text, block=777 if len(text) < 1_000_000 else 65280, level=1)
+                got = got_reads([path], q)
+                assert len(got) == len(want), (tag, kind, q, len(got), len(want))
+                bad = [i for i in range(len(want)) if got[i] != want[i]]
+                assert not bad, (tag, kind, q, bad[:3])
+    # pairs: files of different length (and a mate file that ends inside a record): the walk ends with the shorter one
+    a, b = fastq(30_000, seed=7), fastq(30_000, seed=8)
+    cut = b[: len(b) * 2 // 3]
+    for second in (b, cut, b""):
+        pa, pb = tmp_path / "p1.fastq.gz", tmp_path / "p2.fastq.gz"
+        with gzip.open(pa, "wb", compresslevel=1) as f:
+            f.write(a)
+        write_bgzf(pb, second, level=1)
+        want = _line_loop_reads([a, second], 15)
+        got = got_reads([pa, pb], 15)
+        assert len(got) == len(want) and all(g == w for g, w in zip(got, want)), (len(second), len(got), len(want))
+    assert len(_line_loop_reads([a, cut], 15)) < 30_000
