@@ -2,6 +2,7 @@
 // and the index builder (src/build.rs:15-130) with the Bloom inserts done on the GPU.
 #include <algorithm>
 #include <cstring>
+#include <future>
 #include <thread>
 
 #include <unistd.h>
@@ -288,13 +289,28 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
     CID_TRY(cid_index_create(ctx, bloom, (uint32_t)hashes, (uint32_t)k, (uint32_t)b.colors.size(), hash_variant, &b.index));
     if (m_size) CID_TRY(cid_index_set_minimizer(b.index, (uint32_t)m_size));   // the inserts below then key on find_minimizer(kmer, m)
     uint32_t colour = 0, counter = 1;
-    for (auto &kv : refs) {
+    // the NEXT accession's input is read (FASTA) or starts inflating (fastq.gz) on a helper thread while the GPU counts and inserts
+    // this one's k-mers
+    auto gz_of = [](const std::vector<std::string> &v) { return v.size() == 2 || (v[0].size() >= 2 && v[0].compare(v[0].size() - 2, 2, "gz") == 0); };
+    std::future<std::vector<std::string>> ahead;
+    auto look_ahead = [&](std::map<std::string, std::vector<std::string>>::const_iterator it) {
+        if (it == refs.end() || !gpu_counting_enabled(k)) return;
+        const std::vector<std::string> &v = it->second;
+        if (gz_of(v)) for (const std::string &f : v) LineReader::prefetch(f);
+        else { const std::string path = v[0]; ahead = std::async(std::launch::async, [path] { return read_fasta(path); }); }
+    };
+    look_ahead(refs.begin());
+    for (auto it = refs.begin(); it != refs.end(); ++it) {
+        const auto &kv = *it;
         fprintf(stderr, "Adding %s to index (%u/%zu)\n", kv.first.c_str(), counter++, refs.size());
         const std::vector<std::string> &v = kv.second;
-        const bool is_gz = v.size() == 2 || (v[0].size() >= 2 && v[0].compare(v[0].size() - 2, 2, "gz") == 0);
+        const bool is_gz = gz_of(v);
         cid_kmerset *ks = nullptr;
+        std::vector<std::string> fasta_now;
+        if (gpu_counting_enabled(k) && !is_gz) fasta_now = ahead.get();
+        look_ahead(std::next(it));
         if (gpu_counting_enabled(k))
-            ks = is_gz ? count_fastq_gpu(ctx, k, v[0], v.size() == 2 ? &v[1] : nullptr, quality) : count_fasta_gpu(ctx, k, read_fasta(v[0]));
+            ks = is_gz ? count_fastq_gpu(ctx, k, v[0], v.size() == 2 ? &v[1] : nullptr, quality) : count_fasta_gpu(ctx, k, fasta_now);
         if (ks) {  // the accession's k-mer map never leaves HBM: count, clean, Bloom-insert
             if (is_gz) {
                 uint64_t t = (uint64_t)(cutoff < 0 ? 0 : cutoff);
@@ -325,6 +341,7 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
         }
         ++colour;
     }
+    LineReader::drop_prefetched();
     return b;
 }
 

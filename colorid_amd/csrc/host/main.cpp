@@ -230,11 +230,14 @@ int cmd_build(int argc, char **argv) {
         printf("Build with minimizers, minimizer size: %llu\n", (unsigned long long)m_value);
     }
     cid_ctx *ctx = make_ctx(a);
+    phase_done("GPU context");
     Bigsi b = build_single(ctx, a.one("refs"), num_or<uint64_t>(a, "bloom", 50000000), num_or<uint64_t>(a, "num_hashes", 4),
                            num_or<uint64_t>(a, "kmer", 31), num_or<uint8_t>(a, "quality", 15), num_or<int64_t>(a, "filter", -1),
                            hash_variant(a), m_value);
+    phase_done("accessions counted and inserted");
     printf("Saving BIGSI to file.\n");
     save_bigsi(a.one("bigsi") + (minimizer ? ".mxi" : ".bxi"), b);
+    phase_done("index written");
     cid_index_destroy(b.index);
     cid_ctx_destroy(ctx);
     return 0;

@@ -45,6 +45,7 @@ def run(*args):
 
 dt, out, err = run("build", "-s", "50000000", "-n", "4", "-k", "31", "-b", f"{W}/idx", "-r", f"{W}/refs.tsv")
 res["build_s"] = dt; res["bxi_GB"] = os.path.getsize(f"{W}/idx.bxi") / 1e9
+res["build_stderr"] = [l for l in err.splitlines() if "timing:" in l]
 dt, out, err = run("info", "-b", f"{W}/idx.bxi")
 res["info_s"] = dt
 dt, out, err = run("search", "-b", f"{W}/idx.bxi", "-q", f"{W}/reads.fastq.gz", "-g", "-f", "0", "-p", "0.005")
