@@ -1320,6 +1320,7 @@ int cid_warmup(cid_ctx *c, unsigned what) {
     if (what & CID_WARM_READID) HIP_TRY(cid::warm_readid());
     if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_search());
     if (what & (CID_WARM_READID | CID_WARM_SEARCH)) HIP_TRY(cid::warm_kmerset());
+    if (what & CID_WARM_INFLATE) HIP_TRY(cid::warm_inflate());
     return CID_OK;
 }
 

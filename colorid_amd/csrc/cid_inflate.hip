@@ -1,0 +1,437 @@
+// Block-gzip (BGZF) members inflated on the GPU: the input side of `read_id` / `search` on fastq.gz files written by bgzip / htslib /
+// Illumina's converters (SURVEY.md §8f.3 "gz decode"; the reference inflates with flate2's MultiGzDecoder on one thread,
+// src/read_id_mt_pe.rs:848-856, src/kmer.rs:469-476).  A BGZF file is a series of independent gzip members of at most 64 KiB of text,
+// each carrying its compressed size in a "BC" extra field — so a batch of members is a batch of independent DEFLATE streams.
+//
+// One wave per member.  DEFLATE is serial inside a stream, so lane 0 decodes (Huffman tables, bit reader and the member's whole
+// output live in LDS: every dependent access is an LDS access, none goes to HBM) while the wave as a whole moves the data: the
+// compressed bytes stream from HBM into a 2 KiB LDS ring in 1 KiB wave-wide loads between lane 0's decode runs, the finished text
+// leaves as coalesced 16-byte stores, and the member's CRC-32 is computed by all 64 lanes over 1 KiB slices of the LDS image and folded
+// with the "append 1024 zero bytes" operator.  2 members per CU at a time (70 KiB of LDS each), 512 on the chip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/colorid_hip.h"
+#include "cid_objects.hpp"
+
+namespace cid {
+
+struct BgzfMember { uint32_t in_off, in_len, out_off, out_len; };   // in_off: the member's first byte (its gzip header) in the batch
+
+constexpr int kLitBits = 10, kDistBits = 8;
+constexpr uint32_t kRing = 2048, kOutCap = 65536 + 16;
+// per-wave LDS: out image | input ring | lit table | dist table | canonical-decode arrays | code lengths
+constexpr uint32_t kLdsOut = 0, kLdsRing = kOutCap, kLdsLit = kLdsRing + kRing, kLdsDist = kLdsLit + 2u * (1u << kLitBits),
+                   kLdsCnt = kLdsDist + 2u * (1u << kDistBits), kLdsLens = kLdsCnt + 2u * (16 + 288 + 16 + 32), kLdsBytes = kLdsLens + 320;
+
+struct CrcShift { uint32_t m[32]; };   // column j: the CRC register 1 << j after 1024 zero bytes
+
+enum : uint32_t { ST_OK = 0, ST_BAD_HEADER = 1, ST_BAD_BLOCK = 2, ST_BAD_CODE = 3, ST_OVERRUN_IN = 4, ST_OVERRUN_OUT = 5, ST_BAD_LEN = 6, ST_BAD_CRC = 7 };
+
+// lane 0's view of the compressed stream.  The ring is read a 32-bit word at a time and one word AHEAD of the bit buffer, so the LDS
+// round trip of a refill overlaps the decoding of the bits already buffered: after refill() the buffer holds 33 .. 64 bits, more than
+// any one step takes (a length code with its extra bits: 20; a distance code with its extra bits: 28).
+struct BitReader {
+    const uint32_t *ring;   // kRing / 4 words
+    uint32_t wpos;          // the next word of the stream to load (the one before it sits in `ahead`)
+    uint64_t buf;
+    uint32_t cnt;
+    uint32_t ahead;
+    __device__ __forceinline__ void start() { wpos = 1; buf = 0; cnt = 0; ahead = ring[0]; }
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32) {
+            buf |= (uint64_t)ahead << cnt;
+            cnt += 32;
+            ahead = ring[wpos & (kRing / 4 - 1)];
+            ++wpos;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }   // n <= 16
+    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+    // bytes of the stream that are used up: everything before the first byte with a bit still in the buffer (or in `ahead`)
+    __device__ __forceinline__ uint32_t consumed_bytes() const { return (wpos - 1) * 4 - cnt / 8; }
+};
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32 - n); }
+
+// canonical Huffman tables from code lengths: a 2^bits direct table (entry = sym << 4 | len; 0 = a longer code) and the count /
+// symbol arrays of the bit-by-bit decoder for codes longer than `bits`.  false: over-subscribed or incomplete (more than one code)
+__device__ bool build_tables(const uint8_t *lens, uint32_t n_sym, uint16_t *tab, uint32_t bits, uint16_t *cnt, uint16_t *sym) {
+    for (uint32_t i = 0; i < 16; ++i) cnt[i] = 0;
+    for (uint32_t s = 0; s < n_sym; ++s) cnt[lens[s]]++;
+    for (uint32_t i = 0; i < (1u << bits); ++i) tab[i] = 0;
+    if (cnt[0] == n_sym) return true;   // no codes at all (a distance tree may be empty)
+    int left = 1;
+    for (uint32_t l = 1; l < 16; ++l) {
+        left <<= 1;
+        left -= cnt[l];
+        if (left < 0) return false;
+    }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (uint32_t l = 1; l < 15; ++l) offs[l + 1] = offs[l] + cnt[l];
+    uint32_t next_code[16];
+    uint32_t code = 0;   // RFC 1951 3.2.2: code = (code + bl_count[bits-1]) << 1, with bl_count[0] = 0
+    for (uint32_t l = 1; l < 16; ++l) { code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1; next_code[l] = code; }
+    for (uint32_t s = 0; s < n_sym; ++s) {
+        const uint32_t l = lens[s];
+        if (!l) continue;
+        sym[offs[l]++] = (uint16_t)s;
+        const uint32_t c = next_code[l]++;
+        if (l <= bits) {
+            const uint32_t r = rev_bits(c, l);
+            for (uint32_t i = r; i < (1u << bits); i += 1u << l) tab[i] = (uint16_t)((s << 4) | l);
+        }
+    }
+    return left == 0 || (n_sym - cnt[0]) == 1;   // complete, or the single-code tree zlib allows for distances
+}
+
+// one symbol: direct table, else bit by bit over the canonical code (puff-style); -1 = invalid code
+__device__ __forceinline__ int decode_sym(BitReader &br, const uint16_t *tab, uint32_t bits, const uint16_t *cnt, const uint16_t *sym) {
+    const uint32_t e = tab[br.peek(bits)];
+    if (e) { br.drop(e & 15u); return (int)(e >> 4); }
+    int code = 0, first = 0, index = 0;
+    uint64_t b = br.buf;
+    for (uint32_t l = 1; l < 16; ++l) {
+        code |= (int)(b & 1u);
+        b >>= 1;
+        const int c = cnt[l];
+        if (code - c < first) { br.drop(l); return sym[index + (code - first)]; }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// lane 0's decoder state between its runs (the wave refills the input ring in between)
+struct Decoder {
+    uint32_t phase;     // 0 block header next, 1 symbols of a Huffman block, 2 bytes of a stored block, 3 done
+    uint32_t last;      // BFINAL of the current block
+    uint32_t stored_left;
+    uint32_t out_pos;
+    uint32_t status;
+};
+
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const BgzfMember *members, uint32_t n_members, uint8_t *out, uint32_t *status,
+                                                     CrcShift shift) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x;
+    uint8_t *s_out = smem + kLdsOut;
+    uint8_t *s_ring = smem + kLdsRing;
+    uint16_t *s_lit = reinterpret_cast<uint16_t *>(smem + kLdsLit);
+    uint16_t *s_dist = reinterpret_cast<uint16_t *>(smem + kLdsDist);
+    uint16_t *s_lcnt = reinterpret_cast<uint16_t *>(smem + kLdsCnt), *s_lsym = s_lcnt + 16, *s_dcnt = s_lsym + 288, *s_dsym = s_dcnt + 16;
+    uint8_t *s_lens = smem + kLdsLens;
+
+    for (uint32_t mi = blockIdx.x; mi < n_members; mi += gridDim.x) {
+        const BgzfMember mem = members[mi];
+        const uint8_t *src = in + mem.in_off;
+        const uint32_t skew = mem.out_off & 15u;          // the LDS image is laid out with the destination's 16-byte phase
+        uint8_t *img = s_out + skew;
+        // gzip header (RFC 1952): 1f 8b 08 FLG(4 = FEXTRA) mtime(4) xfl os | XLEN | extra ... ; trailer CRC32 ISIZE
+        uint32_t st = ST_OK, data0 = 0, data_len = 0, want_crc = 0;
+        if (mem.in_len < 28 || mem.out_len > 65536u) st = ST_BAD_HEADER;
+        else {
+            if (src[0] != 0x1f || src[1] != 0x8b || src[2] != 8 || src[3] != 4) st = ST_BAD_HEADER;
+            const uint32_t xlen = src[10] | ((uint32_t)src[11] << 8);
+            data0 = 12 + xlen;
+            if (data0 + 8 > mem.in_len) st = ST_BAD_HEADER;
+            else {
+                data_len = mem.in_len - 8 - data0;
+                const uint8_t *t = src + mem.in_len - 8;
+                want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                if (isize != mem.out_len) st = ST_BAD_LEN;
+            }
+        }
+        st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+        if (st != ST_OK) { if (lane == 0) status[mi] = st; continue; }
+        const uint8_t *data = src + data0;
+
+        BitReader br{reinterpret_cast<const uint32_t *>(s_ring), 1, 0, 0, 0};
+        bool started = false;
+        Decoder d{0, 0, 0, 0, ST_OK};
+        uint32_t fill = 0;   // wave-uniform: bytes of the stream in the ring
+        __builtin_amdgcn_wave_barrier();
+        for (;;) {   // wave-uniform loop: refill the ring, then lane 0 decodes until it has used ~half of it
+            const uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane((int)br.consumed_bytes());
+            while (fill < data_len && fill + 1024 <= used + kRing) {   // 1 KiB per step: 64 lanes x 16 bytes
+                const uint32_t o = fill + 16u * (uint32_t)lane;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (o + 16 <= data_len) {
+                    const uint8_t *p = data + o;
+                    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) {
+                        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+                        v = make_uint4(q[0], q[1], q[2], q[3]);
+                    } else {
+                        uint32_t w[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) w[k] = p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
+                        v = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                } else if (o < data_len) {
+                    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (uint32_t b = 0; b < 16; ++b) if (o + b < data_len) w[b >> 2] |= (uint32_t)data[o + b] << (8u * (b & 3u));
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                *reinterpret_cast<uint4 *>(s_ring + (o & (kRing - 1))) = v;
+                fill += 1024;
+            }
+            if (fill > data_len) fill = data_len;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) {
+                if (!started) { br.start(); started = true; }
+                const uint32_t run_end = br.consumed_bytes() + 400;   // a step starts below this mark; the longest one (a dynamic block header) takes < 600 bytes, and the ring holds >= 1024 ahead (or the stream's end)
+                while (d.phase != 3 && d.status == ST_OK && br.consumed_bytes() < run_end) {
+                    br.refill();
+                    if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
+                    if (d.phase == 0) {   // block header
+                        d.last = br.take(1);
+                        const uint32_t type = br.take(2);
+                        if (type == 0) {   // stored: skip to the byte boundary, LEN NLEN
+                            br.drop(br.cnt & 7u);
+                            br.refill();
+                            const uint32_t len = br.take(16), nlen = br.take(16);
+                            if ((len ^ 0xFFFFu) != nlen) { d.status = ST_BAD_BLOCK; break; }
+                            d.stored_left = len;
+                            d.phase = 2;
+                        } else if (type == 1) {   // fixed Huffman codes (RFC 1951 3.2.6)
+                            for (uint32_t s = 0; s < 144; ++s) s_lens[s] = 8;
+                            for (uint32_t s = 144; s < 256; ++s) s_lens[s] = 9;
+                            for (uint32_t s = 256; s < 280; ++s) s_lens[s] = 7;
+                            for (uint32_t s = 280; s < 288; ++s) s_lens[s] = 8;
+                            build_tables(s_lens, 288, s_lit, kLitBits, s_lcnt, s_lsym);
+                            for (uint32_t s = 0; s < 30; ++s) s_lens[s] = 5;
+                            build_tables(s_lens, 30, s_dist, kDistBits, s_dcnt, s_dsym);
+                            d.phase = 1;
+                        } else if (type == 2) {   // dynamic: HLIT HDIST HCLEN, the code-length code, then the two trees' lengths
+                            const uint32_t hlit = br.take(5) + 257, hdist = br.take(5) + 1, hclen = br.take(4) + 4;
+                            if (hlit > 286 || hdist > 30) { d.status = ST_BAD_BLOCK; break; }
+                            for (uint32_t i = 0; i < 19; ++i) s_lens[i] = 0;
+                            for (uint32_t i = 0; i < hclen; ++i) { br.refill(); s_lens[c_clen_order[i]] = (uint8_t)br.take(3); }
+                            // the code-length code decodes through the dist table's storage (7-bit direct table)
+                            if (!build_tables(s_lens, 19, s_dist, 7, s_dcnt, s_dsym)) { d.status = ST_BAD_BLOCK; break; }
+                            uint32_t i = 0;
+                            bool bad = false;
+                            while (i < hlit + hdist) {
+                                br.refill();
+                                const int sym = decode_sym(br, s_dist, 7, s_dcnt, s_dsym);
+                                if (sym < 0) { bad = true; break; }
+                                if (sym < 16) { s_lens[i++] = (uint8_t)sym; continue; }
+                                uint32_t rep, val = 0;
+                                if (sym == 16) { if (i == 0) { bad = true; break; } val = s_lens[i - 1]; rep = 3 + br.take(2); }
+                                else if (sym == 17) rep = 3 + br.take(3);
+                                else rep = 11 + br.take(7);
+                                if (i + rep > hlit + hdist) { bad = true; break; }
+                                while (rep--) s_lens[i++] = (uint8_t)val;
+                            }
+                            if (bad || s_lens[256] == 0) { d.status = ST_BAD_BLOCK; break; }
+                            // distance lengths sit behind the literal/length ones: build that tree first (its storage was the scratch above)
+                            uint8_t dl[30];
+                            for (uint32_t s = 0; s < hdist; ++s) dl[s] = s_lens[hlit + s];
+                            if (!build_tables(s_lens, hlit, s_lit, kLitBits, s_lcnt, s_lsym)) { d.status = ST_BAD_BLOCK; break; }
+                            for (uint32_t s = 0; s < hdist; ++s) s_lens[s] = dl[s];
+                            if (!build_tables(s_lens, hdist, s_dist, kDistBits, s_dcnt, s_dsym)) { d.status = ST_BAD_BLOCK; break; }
+                            d.phase = 1;
+                        } else { d.status = ST_BAD_BLOCK; break; }
+                    } else if (d.phase == 1) {   // literal / length-distance symbols
+                        const int sym = decode_sym(br, s_lit, kLitBits, s_lcnt, s_lsym);
+                        if (sym < 0) { d.status = ST_BAD_CODE; break; }
+                        if (sym < 256) {
+                            if (d.out_pos >= mem.out_len) { d.status = ST_OVERRUN_OUT; break; }
+                            img[d.out_pos++] = (uint8_t)sym;
+                        } else if (sym == 256) {
+                            d.phase = d.last ? 3u : 0u;
+                        } else {
+                            if (sym > 285) { d.status = ST_BAD_CODE; break; }
+                            const uint32_t len = c_len_base[sym - 257] + br.take(c_len_extra[sym - 257]);
+                            br.refill();
+                            const int ds = decode_sym(br, s_dist, kDistBits, s_dcnt, s_dsym);
+                            if (ds < 0 || ds > 29) { d.status = ST_BAD_CODE; break; }
+                            const uint32_t dist = c_dist_base[ds] + br.take(c_dist_extra[ds]);
+                            if (dist > d.out_pos) { d.status = ST_BAD_CODE; break; }
+                            if (d.out_pos + len > mem.out_len) { d.status = ST_OVERRUN_OUT; break; }
+                            uint8_t *o = img + d.out_pos;
+                            const uint8_t *f = o - dist;
+                            if (dist >= 8) {   // eight bytes at a time: the loads of a piece are issued together, none depends on the piece's stores
+                                for (uint32_t i = 0; i < len; i += 8) {
+                                    uint8_t t[8];
+#pragma unroll
+                                    for (uint32_t j = 0; j < 8; ++j) t[j] = f[i + j];          // (may read up to 7 bytes past the match: inside the image)
+#pragma unroll
+                                    for (uint32_t j = 0; j < 8; ++j) if (i + j < len) o[i + j] = t[j];
+                                }
+                            } else {           // a short period (runs, dinucleotide repeats, quality plateaus): the pattern rotates in a register
+                                uint64_t pat = 0;
+                                for (uint32_t j = 0; j < dist; ++j) pat |= (uint64_t)f[j] << (8 * j);
+                                const uint32_t top = 8 * (dist - 1);
+                                for (uint32_t i = 0; i < len; ++i) {
+                                    const uint32_t b = (uint32_t)pat & 0xFFu;
+                                    o[i] = (uint8_t)b;
+                                    pat = (pat >> 8) | ((uint64_t)b << top);
+                                }
+                            }
+                            d.out_pos += len;
+                        }
+                    } else {   // stored bytes
+                        uint32_t n = d.stored_left < 256u ? d.stored_left : 256u;
+                        if (d.out_pos + n > mem.out_len) { d.status = ST_OVERRUN_OUT; break; }
+                        for (uint32_t i = 0; i < n; ++i) { br.refill(); img[d.out_pos++] = (uint8_t)br.take(8); }
+                        d.stored_left -= n;
+                        if (d.stored_left == 0) d.phase = d.last ? 3u : 0u;
+                    }
+                }
+                if (d.status == ST_OK && d.phase == 3 && br.consumed_bytes() > data_len) d.status = ST_OVERRUN_IN;
+            }
+            const uint32_t phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.phase);
+            st = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.status);
+            if (phase == 3 || st != ST_OK) break;
+        }
+        const uint32_t produced = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.out_pos);
+        if (st == ST_OK && produced != mem.out_len) st = ST_BAD_LEN;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (st == ST_OK) {
+            // CRC-32 (RFC 1952 8): slices aligned to the END of the text, so that every slice but the first is exactly 1024 bytes;
+            // lane l takes slice l; the table (256 words) is built in the ring's storage
+            uint32_t *tab = reinterpret_cast<uint32_t *>(s_ring);
+            for (uint32_t i = lane; i < 256; i += 64) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+                tab[i] = c;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t len = mem.out_len;
+            const uint32_t n_slices = (len + 1023u) / 1024u;                // <= 64
+            const uint32_t first_len = len - (n_slices ? (n_slices - 1u) * 1024u : 0u);
+            uint32_t c = 0;
+            if ((uint32_t)lane < n_slices) {
+                const uint32_t b0 = lane == 0 ? 0u : first_len + ((uint32_t)lane - 1u) * 1024u;
+                const uint32_t b1 = lane == 0 ? first_len : b0 + 1024u;
+                c = lane == 0 ? 0xFFFFFFFFu : 0u;
+                for (uint32_t i = b0; i < b1; ++i) c = tab[(c ^ img[i]) & 0xFFu] ^ (c >> 8);
+            }
+            uint32_t reg = 0xFFFFFFFFu;   // (an empty member: CRC 0)
+            for (uint32_t s = 0; s < n_slices; ++s) {
+                const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)s);
+                if (s == 0) reg = cs;
+                else {
+                    uint32_t r = 0;
+                    for (uint32_t j = 0; j < 32; ++j) r ^= shift.m[j] & (0u - ((reg >> j) & 1u));
+                    reg = r ^ cs;
+                }
+            }
+            if ((reg ^ 0xFFFFFFFFu) != want_crc) st = ST_BAD_CRC;
+        }
+        if (st == ST_OK) {   // the text leaves in 16-byte pieces aligned to the destination
+            uint8_t *dst = out + mem.out_off;
+            const uint32_t len = mem.out_len;
+            const uint32_t head = len < ((16u - skew) & 15u) ? len : ((16u - skew) & 15u);
+            if ((uint32_t)lane < head) dst[lane] = img[lane];
+            const uint32_t body = (len - head) / 16u;
+            const uint4 *sv = reinterpret_cast<const uint4 *>(img + head);   // 16-byte aligned in LDS: skew + head == 0 mod 16
+            uint4 *dv = reinterpret_cast<uint4 *>(dst + head);
+            for (uint32_t i = lane; i < body; i += 64) dv[i] = sv[i];
+            const uint32_t tail0 = head + body * 16u;
+            if (tail0 + (uint32_t)lane < len) dst[tail0 + lane] = img[tail0 + lane];
+        }
+        if (lane == 0) status[mi] = st;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+static CrcShift make_crc_shift() {
+    uint32_t tab[256];
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        tab[i] = c;
+    }
+    CrcShift s;
+    for (uint32_t j = 0; j < 32; ++j) {
+        uint32_t c = 1u << j;
+        for (int i = 0; i < 1024; ++i) c = tab[c & 0xFFu] ^ (c >> 8);
+        s.m[j] = c;
+    }
+    return s;
+}
+
+hipError_t warm_inflate() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_bgzf_inflate));
+}
+
+}  // namespace cid
+
+using cid::fail;
+using namespace cid::slots;
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return cid::fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+                                const uint32_t *text_off, const uint32_t *text_len, size_t n_members, uint8_t *text, size_t text_bytes,
+                                size_t *bad_member) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    if (bad_member) *bad_member = (size_t)-1;
+    if (n_members == 0) return CID_OK;
+    if (!members || !member_off || !member_len || !text_off || !text_len || (text_bytes && !text)) return fail(CID_ERR_INVALID, "null argument");
+    if (n_bytes >= (1ull << 32) || text_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "a batch of BGZF members is limited to 4 GiB");
+    std::vector<cid::BgzfMember> mem(n_members);
+    for (size_t i = 0; i < n_members; ++i) {
+        if ((uint64_t)member_off[i] + member_len[i] > n_bytes) return fail(CID_ERR_INVALID, "member %zu lies outside the batch", i);
+        if (text_len[i] > 65536u || (uint64_t)text_off[i] + text_len[i] > text_bytes) return fail(CID_ERR_INVALID, "member %zu: text range outside the output", i);
+        mem[i] = cid::BgzfMember{member_off[i], member_len[i], text_off[i], text_len[i]};
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    static const cid::CrcShift shift = cid::make_crc_shift();
+    void *d_in, *d_mem, *d_out, *d_st;
+    int rc = cid::slot_reserve(c, S_KMERS, n_bytes + 16, &d_in); if (rc) return rc;
+    rc = cid::slot_reserve(c, S_MISC, n_members * sizeof(cid::BgzfMember), &d_mem); if (rc) return rc;
+    rc = cid::slot_reserve(c, S_BASES, text_bytes + 16, &d_out); if (rc) return rc;
+    rc = cid::slot_reserve(c, S_FREQ, n_members * 4, &d_st); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_in, members, n_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cid::k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cid::kLdsBytes));
+    unsigned grid = (unsigned)n_members;
+    const unsigned cap = (unsigned)c->n_cu * 2u * 4u;   // two members per CU at a time; a few rounds per block
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(cid::k_bgzf_inflate, dim3(grid), dim3(64), cid::kLdsBytes, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem,
+                       (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st, shift);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> st(n_members);
+    HIP_TRY(hipMemcpyAsync(st.data(), d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));
+    if (text_bytes) HIP_TRY(hipMemcpyAsync(text, d_out, text_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n_members; ++i)
+        if (st[i] != cid::ST_OK) {
+            if (bad_member) *bad_member = i;
+            static const char *const why[] = {"", "not a BGZF member header", "invalid DEFLATE block", "invalid Huffman code", "compressed data ends early",
+                                              "more text than the member's ISIZE", "text length differs from ISIZE", "CRC-32 mismatch"};
+            return fail(CID_ERR_INVALID, "corrupt gzip member %zu: %s", i, why[st[i] < 8 ? st[i] : 0]);
+        }
+    return CID_OK;
+}

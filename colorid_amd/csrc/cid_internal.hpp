@@ -79,5 +79,6 @@ int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_
 hipError_t warm_readid();
 hipError_t warm_search();
 hipError_t warm_kmerset();
+hipError_t warm_inflate();
 
 }  // namespace cid

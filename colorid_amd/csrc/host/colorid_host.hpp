@@ -54,6 +54,9 @@ class LineReader {   // inflates on its own thread, a few MiB ahead of the calle
     // over.  The CLI calls this before it loads the index, so that gzip decoding runs beside the index load instead of after it.
     static void prefetch(const std::string &path);
     static void drop_prefetched();   // end of a command: stop the streams nobody took
+    // Block-gzip (BGZF) input is inflated on GPU `device` (cid_bgzf_inflate: one wave per member) instead of on COLORID_GZ_THREADS
+    // host threads; < 0 = on the host.  Applies to readers opened afterwards; each reader thread uses a context of its own.
+    static void inflate_on_gpu(int device);
     LineReader(const LineReader &) = delete;
     LineReader &operator=(const LineReader &) = delete;
     bool next(std::string &line);

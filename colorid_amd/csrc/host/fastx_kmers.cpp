@@ -163,10 +163,18 @@ struct LineReader::Impl {
         }
     }
 
-    // BGZF: batches of members worth ~16 MiB of text, inflated by gz_threads threads
+    // BGZF: batches of members worth ~16 MiB of text, inflated by gz_threads threads — or, with a GPU set (inflate_on_gpu), batches of
+    // ~64 MiB (a thousand members: two rounds of the 512 the chip decodes at a time) by cid_bgzf_inflate on a context of this thread
     struct Member { size_t in_off, in_len, out_off, out_len; };
+    int gpu_device = -1;
+    cid_ctx *gpu_ctx = nullptr;
     void run_bgzf() {
-        constexpr size_t kBatchOut = 16u << 20;
+        if (gpu_device >= 0 && cid_ctx_create(gpu_device, &gpu_ctx) != CID_OK) {
+            fprintf(stderr, "note: no GPU context for the gzip members (%s): inflating on the host\n", cid_last_error());
+            gpu_ctx = nullptr;
+        }
+        if (gpu_ctx) (void)cid_warmup(gpu_ctx, CID_WARM_INFLATE);
+        const size_t kBatchOut = gpu_ctx ? (64u << 20) : (16u << 20);
         std::vector<unsigned char> in;        // compressed bytes of the batch (plus the unread tail of the last fread)
         size_t in_have = 0, in_pos = 0;
         bool file_end = false;
@@ -181,7 +189,7 @@ struct LineReader::Impl {
         };
         for (;;) {
             std::vector<char> blk;
-            if (!take_free(blk)) return;
+            if (!take_free(blk)) break;
             std::vector<Member> mem;
             size_t out_total = 0;
             // the unread tail moves to the front once per batch (never inside one: members are addressed by offset)
@@ -203,7 +211,14 @@ struct LineReader::Impl {
             }
             in_pos = scan;
             blk.resize(kHead + out_total);
-            if (!mem.empty()) {
+            if (!mem.empty() && gpu_ctx) {
+                std::vector<uint32_t> mo(mem.size()), ml(mem.size()), to(mem.size()), tl(mem.size());
+                for (size_t i = 0; i < mem.size(); ++i) { mo[i] = (uint32_t)mem[i].in_off; ml[i] = (uint32_t)mem[i].in_len; to[i] = (uint32_t)mem[i].out_off; tl[i] = (uint32_t)mem[i].out_len; }
+                size_t bad = 0;
+                if (cid_bgzf_inflate(gpu_ctx, in.data(), in_pos, mo.data(), ml.data(), to.data(), tl.data(), mem.size(),
+                                     reinterpret_cast<uint8_t *>(blk.data() + kHead), out_total, &bad) != CID_OK)
+                    die("corrupt gzip member (inflate / CRC-32 failed): %s", cid_last_error());
+            } else if (!mem.empty()) {
                 const int nt = (int)std::min<size_t>((size_t)gz_threads, mem.size());
                 std::vector<std::thread> th;
                 std::vector<int> bad(nt, 0);
@@ -227,8 +242,9 @@ struct LineReader::Impl {
                 for (int t = 0; t < nt; ++t) if (bad[t]) die("corrupt gzip member (inflate / CRC-32 failed)");
             }
             push(std::move(blk), last);
-            if (last) return;
+            if (last) break;
         }
+        if (gpu_ctx) { cid_ctx_destroy(gpu_ctx); gpu_ctx = nullptr; }
     }
     bool refill() {   // false at end of input
         std::unique_lock<std::mutex> lk(mu);
@@ -256,6 +272,9 @@ struct LineReader::Impl {
     }
 };
 
+static int g_inflate_device = [] { const char *e = getenv("COLORID_GPU_INFLATE"); return e && atoi(e) > 0 ? 0 : -1; }();
+void LineReader::inflate_on_gpu(int device) { g_inflate_device = device; }
+
 static std::mutex g_prefetch_mu;
 static std::vector<std::pair<std::string, LineReader::Impl *>> g_prefetched;
 
@@ -267,6 +286,8 @@ static LineReader::Impl *open_stream(const std::string &path, bool ahead) {
         p->raw = fopen(path.c_str(), "rb");
         if (!p->raw) die("file not found: %s", path.c_str());
         if (ahead) p->depth = 16;   // batches of 16 MiB of text
+        p->gpu_device = g_inflate_device;
+        if (p->gpu_device >= 0) p->depth = 4;   // (batches of 64 MiB)
         p->worker = std::thread([p] { p->run_bgzf(); });
         return p;
     }

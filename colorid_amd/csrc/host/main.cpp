@@ -259,6 +259,7 @@ int cmd_search(int argc, char **argv) {
         fprintf(stderr, "Error: An index with minimizers (.mxi) is used, but not available for this function\n");
         return 0;
     }
+    if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
     // gzip decoding of the first query starts now and runs beside GPU start-up and the index load
     if (!a.flags.count("perfect_search") && ends_with(files1[0], "gz")) {
         LineReader::prefetch(files1[0]);
@@ -317,6 +318,7 @@ int cmd_read_id(int argc, char **argv) {
     const size_t bitvector_sample = num_or<size_t>(a, "bitvector_sample", 3);
     const std::string prefix = a.one("prefix");
     if (down_sample == 0 || batch == 0) die("attempt to calculate the remainder with a divisor of zero");
+    if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
     // gzip decoding starts now and runs beside GPU start-up (~0.2 s) and the index load: measured against starting it after the
     // context exists, the classification phase of 1 M reads ends 130 ms earlier
     if (ends_with(fq[0], ".gz"))

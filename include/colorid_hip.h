@@ -356,8 +356,19 @@ int cid_tune(const char *name, long value);
 /* Loads the device code of the read_id and/or search kernels now instead of inside the first call that launches one of them (the
  * runtime loads a code object on first use: ~60 ms for the read_id kernels).  Touches no stream and no ctx state: it may run on
  * another host thread while the ctx loads an index (what the CLI does). */
+/* ---- input side: block-gzip (BGZF) members inflated on the GPU.  A BGZF file (bgzip, htslib, Illumina's
+ *      converters) is a series of independent gzip members of at most 64 KiB of text, each with its compressed size in a "BC"
+ *      extra field and its text size (ISIZE) in its trailer; the reference inflates such a file like any gzip stream, on one
+ *      thread (flate2 MultiGzDecoder, src/read_id_mt_pe.rs:848-856, src/kmer.rs:469-476).  `members` holds n_members whole members
+ *      (header, DEFLATE data, CRC-32, ISIZE) at member_off / member_len; member i's text (text_len[i] = its ISIZE) is written to
+ *      text + text_off[i].  Every member is checked as zlib checks it — block structure, Huffman codes, ISIZE and CRC-32; the
+ *      first bad one is reported (CID_ERR_INVALID, *bad_member = its index).  Host buffers in and out; one call is one batch. ---- */
+int cid_bgzf_inflate(cid_ctx *, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+                     const uint32_t *text_off, const uint32_t *text_len, size_t n_members, uint8_t *text, size_t text_bytes,
+                     size_t *bad_member);
 #define CID_WARM_READID 1u
 #define CID_WARM_SEARCH 2u
+#define CID_WARM_INFLATE 4u
 int cid_warmup(cid_ctx *, unsigned what);
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */

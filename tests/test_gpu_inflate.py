@@ -1,0 +1,158 @@
+"""cid_bgzf_inflate: block-gzip members inflated on the GPU (one wave per member, DEFLATE decoded out of LDS) against zlib — every block
+type (stored, fixed and dynamic Huffman codes), every compression level and strategy, member sizes 0 … 65536, texts from
+incompressible to one repeated byte, arbitrary destination alignment; and corrupt members (data, CRC-32, ISIZE, truncation) are
+reported by index as the CPU path (zlib) reports them."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bgzf_member(text: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, extra_subfield=False) -> bytes:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    body = co.compress(text) + co.flush()
+    extra = (b"XY" + struct.pack("<H", 3) + b"abc" if extra_subfield else b"") + b"BC" + struct.pack("<H", 2)
+    xlen = len(extra) + 2
+    bsize = 12 + xlen + len(body) + 8 - 1
+    assert bsize < 65536 + 30000
+    return (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", xlen) + extra + struct.pack("<H", bsize & 0xFFFF) + body +
+            struct.pack("<II", zlib.crc32(text) & 0xFFFFFFFF, len(text)))
+
+
+def inflate(lib, ctx, members, texts_len, text_off=None):
+    blob = b"".join(members)
+    off = np.cumsum([0] + [len(m) for m in members[:-1]]).astype(np.uint32) if members else np.zeros(0, np.uint32)
+    ln = np.array([len(m) for m in members], np.uint32)
+    tl = np.array(texts_len, np.uint32)
+    to = np.cumsum(np.concatenate([[0], tl[:-1]])).astype(np.uint32) if text_off is None else np.array(text_off, np.uint32)
+    total = int((to + tl).max()) if len(tl) else 0
+    out = np.zeros(total + 1, np.uint8)
+    buf = np.frombuffer(blob + b"\0", np.uint8)
+    bad = C.c_size_t(0)
+    rc = lib.cid_bgzf_inflate(ctx.h, buf.ctypes.data, len(blob), off.ctypes.data, ln.ctypes.data, to.ctypes.data, tl.ctypes.data, len(members),
+                              out.ctypes.data, total, C.byref(bad))
+    return rc, out[:total].tobytes(), bad.value, to
+
+
+def fastq_text(rng, n):
+    out = []
+    for i in range(n):
+        L = int(rng.integers(50, 151))
+        out.append(b"@read%d/1\n" % i + bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8)) + b"\n+\n" +
+                   bytes(rng.choice(list(b"FFFFFF:,#"), size=L).astype(np.uint8)) + b"\n")
+    return b"".join(out)
+
+
+def test_inflate_equals_zlib_over_block_types_and_shapes(hip_ctx):
+    lib = hip_ctx.lib
+    rng = np.random.default_rng(1)
+    fq = fastq_text(rng, 3000)
+    texts, members = [], []
+    shapes = [(b"", 6), (b"A", 6), (b"ACGT" * 5, 1), (fq[:65280], 6), (fq[1000:66536], 9), (fq[:65280], 1), (fq[:40000], 0),
+              (bytes(rng.integers(0, 256, 65536).astype(np.uint8)), 6),      # incompressible: stored blocks inside a level-6 stream
+              (bytes(rng.integers(0, 256, 70).astype(np.uint8)), 0),
+              (b"\n" * 65536, 6), (b"AC" * 30000, 9), (b"ACGTTGCA" * 8000 + fq[:1000], 4),   # long overlapping matches
+              (bytes(rng.integers(0, 4, 65536).astype(np.uint8)), 6),        # 2-bit alphabet: short codes, deep trees for the rest
+              (bytes(rng.choice([65, 67], size=50000, p=[0.999, 0.001]).astype(np.uint8)), 6)]
+    for t, lv in shapes:
+        texts.append(t); members.append(bgzf_member(t, lv))
+    for strat in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+        for t in (fq[:65280], fq[70000:70100], b"N" * 3000 + fq[:5000]):
+            texts.append(t); members.append(bgzf_member(t, 6, strat))
+    texts.append(fq[:12345]); members.append(bgzf_member(fq[:12345], 6, extra_subfield=True))     # another extra subfield before "BC"
+    for _ in range(40):                                                                            # random cuts of the FASTQ text
+        a = int(rng.integers(0, len(fq) - 65536)); n = int(rng.integers(1, 65537))
+        texts.append(fq[a:a + n]); members.append(bgzf_member(fq[a:a + n], int(rng.integers(1, 10))))
+    rc, out, bad, to = inflate(lib, hip_ctx, members, [len(t) for t in texts])
+    assert rc == 0, lib.cid_last_error()
+    assert out == b"".join(texts)
+    # texts written at odd offsets (the kernel stores 16-byte pieces aligned to the destination), with gaps between them
+    offs, pos = [], 3
+    for t in texts:
+        offs.append(pos); pos += len(t) + int(rng.integers(0, 40))
+    rc, out, bad, to = inflate(lib, hip_ctx, members, [len(t) for t in texts], text_off=offs)
+    assert rc == 0, lib.cid_last_error()
+    for t, o in zip(texts, offs):
+        assert out[o:o + len(t)] == t
+    # an empty batch
+    assert lib.cid_bgzf_inflate(hip_ctx.h, None, 0, None, None, None, None, 0, None, 0, None) == 0
+
+
+def test_inflate_a_million_reads_worth_of_members(hip_ctx):
+    lib = hip_ctx.lib
+    rng = np.random.default_rng(2)
+    fq = fastq_text(rng, 60_000)                       # ~ 18 MB of text = 280 members of 65280 bytes
+    texts = [fq[i:i + 65280] for i in range(0, len(fq), 65280)]
+    members = [bgzf_member(t, 1 + i % 9) for i, t in enumerate(texts)]
+    rc, out, bad, to = inflate(lib, hip_ctx, members * 4, [len(t) for t in texts] * 4)
+    assert rc == 0, lib.cid_last_error()
+    assert out == fq * 4
+
+
+def test_inflate_reports_corrupt_members(hip_ctx):
+    lib = hip_ctx.lib
+    rng = np.random.default_rng(3)
+    fq = fastq_text(rng, 2000)
+    texts = [fq[i:i + 30000] for i in range(0, 150000, 30000)]
+    good = [bgzf_member(t, 6) for t in texts]
+
+    def expect_bad(members, lens, which, what):
+        rc, out, bad, to = inflate(lib, hip_ctx, members, lens)
+        assert rc == -1 and bad == which and what in lib.cid_last_error(), (rc, bad, lib.cid_last_error())
+
+    lens = [len(t) for t in texts]
+    m = list(good); b = bytearray(m[2]); b[-6] ^= 0x01; m[2] = bytes(b)                      # CRC-32 field
+    expect_bad(m, lens, 2, b"CRC-32")
+    m = list(good); ln = list(lens); ln[3] -= 1                                               # the caller's length differs from ISIZE
+    expect_bad(m, ln, 3, b"ISIZE")
+    m = list(good); b = bytearray(m[1]); b[3] = 0; m[1] = bytes(b)                           # no FEXTRA flag: not a BGZF header
+    expect_bad(m, lens, 1, b"header")
+    hits = 0
+    for pos in (40, 200, 1000, 3000, 5000):                                                  # a flipped bit inside the DEFLATE data: some check must fire
+        m = list(good); b = bytearray(m[4]); b[pos] ^= 0x10; m[4] = bytes(b)
+        rc, out, bad, to = inflate(lib, hip_ctx, m, lens)
+        assert rc == -1 and bad == 4
+        hits += 1
+    assert hits == 5
+    m = list(good); body = m[0][:-8]; m[0] = body[:len(body) // 2] + m[0][-8:]               # truncated DEFLATE data (header and trailer intact)
+    rc, out, bad, to = inflate(lib, hip_ctx, m, lens)
+    assert rc == -1 and bad == 0
+    # everything still works afterwards
+    rc, out, bad, to = inflate(lib, hip_ctx, good, lens)
+    assert rc == 0 and out == b"".join(texts)
+
+
+def test_line_reader_with_gpu_inflate_reads_the_same_lines(tmp_path):
+    """The CLI's reader with COLORID_GPU_INFLATE=1 (BGZF members decoded by cid_bgzf_inflate on a context of the reader thread) yields
+    the lines of the plain file — members of 65280 and of 777 bytes, with and without the end-of-file marker — and dies on a corrupt member."""
+    import os
+    import subprocess
+    from test_linereader_cpu import ROOT, HERE, write_bgzf, _fastq
+    exe = str(tmp_path / "lr_shim")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(HERE, "cpu_shim", "linereader_shim.cpp"),
+                    os.path.join(ROOT, "colorid_amd", "csrc", "host", "fastx_kmers.cpp"), "-L" + os.path.join(ROOT, "colorid_amd"),
+                    "-lcolorid_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "colorid_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    rng = np.random.default_rng(11)
+    text = _fastq(rng, 150_000)                  # ~ 50 MB: crosses the 64 MiB batch only with the small members below; several batches of 777-byte members
+    plain = tmp_path / "a.fastq"
+    plain.write_bytes(text)
+    want = subprocess.run([exe, str(plain)], capture_output=True, text=True, check=True).stdout
+    for block, eof in ((65280, True), (777, False), (4096, True)):
+        p = tmp_path / f"b{block}.fastq.gz"
+        write_bgzf(p, text if block != 777 else text[:3_000_000], block=block, level=1, eof_marker=eof)
+        ref = want if block != 777 else subprocess.run([exe, str(tmp_path / "c.fastq")], capture_output=True, text=True,
+                                                        check=(tmp_path / "c.fastq").write_bytes(text[:3_000_000]) > 0).stdout
+        for mode in ("view", "prefetch"):
+            r = subprocess.run([exe, str(p), mode], capture_output=True, text=True, env=dict(os.environ, COLORID_GPU_INFLATE="1"))
+            assert r.returncode == 0, r.stderr[-300:]
+            assert r.stdout == ref, (block, mode)
+    bad = tmp_path / "bad.fastq.gz"
+    raw = bytearray((tmp_path / "b65280.fastq.gz").read_bytes())
+    raw[len(raw) // 2] ^= 0x55
+    bad.write_bytes(bytes(raw))
+    r = subprocess.run([exe, str(bad)], capture_output=True, text=True, env=dict(os.environ, COLORID_GPU_INFLATE="1"))
+    assert r.returncode == 101 and "corrupt gzip member" in r.stderr

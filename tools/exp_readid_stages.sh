@@ -4,11 +4,13 @@
 W=/tmp/cid_e2e
 BIN=colorid_amd/bin/colorid
 f=${1:-reads.bgzf.fastq.gz}
-for gz in 8 4; do for parse in 1 2 4; do for poll in 2 4 8; do
-  line="gz=$gz parse=$parse poll=$poll :"
+for cfg in "COLORID_GZ_THREADS=8 COLORID_PARSE_THREADS=2" "COLORID_GPU_INFLATE=1 COLORID_PARSE_THREADS=2" "COLORID_GPU_INFLATE=1 COLORID_PARSE_THREADS=4" "COLORID_GPU_INFLATE=1 COLORID_PARSE_THREADS=6" "COLORID_GPU_INFLATE=1 COLORID_PARSE_THREADS=8"; do
+  line="$cfg :"
   for rep in 1 2 3; do
-    t=$(env COLORID_TIMING=1 COLORID_GZ_THREADS=$gz COLORID_PARSE_THREADS=$parse COLORID_POLL_THREADS=$poll $BIN read_id -b $W/idx.bxi -q $W/$f -n $W/rid_x 2>&1 >/dev/null | grep -o "timing: total [0-9]* ms" | grep -o "[0-9]*")
+    t=$(env COLORID_TIMING=1 $cfg $BIN read_id -b $W/idx.bxi -q $W/$f -n $W/rid_x 2>&1 >/dev/null | grep -o "timing: total [0-9]* ms" | grep -o "[0-9]*")
     line="$line $t"
   done
   echo "$line"
-done; done; done
+  cmp $W/rid_x_reads.txt $W/rid_b_reads.txt && echo "  same rows"
+done
+env COLORID_TIMING=1 COLORID_GPU_INFLATE=1 COLORID_PARSE_THREADS=4 $BIN read_id -b $W/idx.bxi -q $W/$f -n $W/rid_x 2>&1 >/dev/null | grep "timing:" | cut -c1-330
