@@ -2,6 +2,7 @@
 // This is host staging for the GPU path: the reference counts k-mers on the CPU too (String keys + FNV);
 // here keys live packed in one arena and are hashed 8 bytes at a time.
 #include <unistd.h>
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <cmath>
@@ -87,6 +88,26 @@ std::vector<std::string> read_fasta(const std::string &path) {
 void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, std::vector<std::string> &seqs) {
     read_fasta_impl(path, &labels, seqs);
 }
+
+// libdeflate (whole-buffer DEFLATE: a BGZF member is one) inflates 2-3x faster than zlib; it is used when the host has it
+// (dlopen of libdeflate.so.0 — no build-time dependency), checks CRC-32 and ISIZE like zlib, and COLORID_LIBDEFLATE=0 turns it off
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*gzip)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        const char *e = getenv("COLORID_LIBDEFLATE");
+        if (e && atoi(e) == 0) return;
+        void *lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return;
+        alloc = reinterpret_cast<void *(*)()>(dlsym(lib, "libdeflate_alloc_decompressor"));
+        gzip = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(dlsym(lib, "libdeflate_gzip_decompress"));
+        release = reinterpret_cast<void (*)(void *)>(dlsym(lib, "libdeflate_free_decompressor"));
+        ok = alloc && gzip && release;
+    }
+};
+static const LibDeflate &libdeflate() { static const LibDeflate l; return l; }
 
 // Decoded text travels in blocks through a small bounded queue: zlib runs on the reader's own thread while the caller
 // splits lines, masks qualities and feeds the GPU.  gzread() continues across gzip members like MultiGzDecoder and reads
@@ -223,6 +244,18 @@ struct LineReader::Impl {
                 std::vector<std::thread> th;
                 std::vector<int> bad(nt, 0);
                 auto work = [&](int t) {
+                    const LibDeflate &ld = libdeflate();
+                    if (ld.ok) {
+                        void *dc = ld.alloc();
+                        if (dc) {
+                            for (size_t i = (size_t)t; i < mem.size(); i += (size_t)nt) {
+                                const Member &m = mem[i];   // exact output size given, no "actual" pointer: anything else than ISIZE bytes is an error
+                                if (ld.gzip(dc, in.data() + m.in_off, m.in_len, blk.data() + kHead + m.out_off, m.out_len, nullptr) != 0) { bad[t] = 1; break; }
+                            }
+                            ld.release(dc);
+                            return;
+                        }
+                    }
                     z_stream zs;
                     memset(&zs, 0, sizeof zs);
                     if (inflateInit2(&zs, 15 + 16) != Z_OK) { bad[t] = 1; return; }

@@ -135,7 +135,7 @@ def test_line_reader_with_gpu_inflate_reads_the_same_lines(tmp_path):
     exe = str(tmp_path / "lr_shim")
     subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(HERE, "cpu_shim", "linereader_shim.cpp"),
                     os.path.join(ROOT, "colorid_amd", "csrc", "host", "fastx_kmers.cpp"), "-L" + os.path.join(ROOT, "colorid_amd"),
-                    "-lcolorid_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "colorid_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                    "-lcolorid_hip", "-lz", "-ldl", "-Wl,-rpath," + os.path.join(ROOT, "colorid_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
     rng = np.random.default_rng(11)
     text = _fastq(rng, 150_000)                  # ~ 50 MB: crosses the 64 MiB batch only with the small members below; several batches of 777-byte members
     plain = tmp_path / "a.fastq"

@@ -33,7 +33,7 @@ def shim(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("lr") / "lr_shim")
     subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(HERE, "cpu_shim", "linereader_shim.cpp"),
                     os.path.join(ROOT, "colorid_amd", "csrc", "host", "fastx_kmers.cpp"), "-L" + os.path.join(ROOT, "colorid_amd"),
-                    "-lcolorid_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "colorid_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                    "-lcolorid_hip", "-lz", "-ldl", "-Wl,-rpath," + os.path.join(ROOT, "colorid_amd"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return exe
 
 
@@ -76,6 +76,10 @@ def test_linereader_same_lines_for_every_container(shim, tmp_path, n_reads):
                 r = subprocess.run([shim, str(p), mode], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads))
                 assert r.returncode == 0, (name, mode, r.stderr)
                 outs[(name, threads, mode)] = r.stdout.split()
+            if "bgzf" in name:   # BGZF members go through libdeflate when the host has it: the same lines with zlib
+                r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads, COLORID_LIBDEFLATE="0"))
+                assert r.returncode == 0, (name, r.stderr)
+                outs[(name, threads, "zlib")] = r.stdout.split()
     want = outs[("plain", "8", "copy")]
     assert int(want[0]) == text.count(b"\n") + (1 if text and not text.endswith(b"\n") else 0)
     assert int(want[1]) == len(text) - text.count(b"\n")
@@ -91,5 +95,6 @@ def test_linereader_reports_a_corrupt_bgzf_member(shim, tmp_path):
     raw = bytearray(p.read_bytes())
     raw[len(raw) // 2] ^= 0x55                  # somewhere inside a member's deflate stream (or its CRC)
     p.write_bytes(bytes(raw))
-    r = subprocess.run([shim, str(p)], capture_output=True, text=True)
-    assert r.returncode == 101 and ("corrupt gzip member" in r.stderr or "BGZF" in r.stderr or "truncated" in r.stderr)
+    for env in ({}, {"COLORID_LIBDEFLATE": "0"}):     # libdeflate (when present) and zlib both check the member's CRC-32
+        r = subprocess.run([shim, str(p)], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 101 and ("corrupt gzip member" in r.stderr or "BGZF" in r.stderr or "truncated" in r.stderr)
