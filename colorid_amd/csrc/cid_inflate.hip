@@ -3,11 +3,13 @@
 // src/read_id_mt_pe.rs:848-856, src/kmer.rs:469-476).  A BGZF file is a series of independent gzip members of at most 64 KiB of text,
 // each carrying its compressed size in a "BC" extra field — so a batch of members is a batch of independent DEFLATE streams.
 //
-// One wave per member.  DEFLATE is serial inside a stream, so lane 0 decodes (Huffman tables, bit reader and the member's whole
-// output live in LDS: every dependent access is an LDS access, none goes to HBM) while the wave as a whole moves the data: the
-// compressed bytes stream from HBM into a 2 KiB LDS ring in 1 KiB wave-wide loads between lane 0's decode runs, the finished text
-// leaves as coalesced 16-byte stores, and the member's CRC-32 is computed by all 64 lanes over 1 KiB slices of the LDS image and folded
-// with the "append 1024 zero bytes" operator.  2 members per CU at a time (70 KiB of LDS each), 512 on the chip.
+// One wave per member.  DEFLATE is serial inside a stream, so lane 0 decodes; what its dependent chain touches at every symbol — the
+// Huffman tables and the bit reader's input ring — lives in LDS (5.6 KiB per member), the text is written in place in HBM: a literal
+// is a store nobody waits for, a match reads bytes the same lane stored earlier (L2-resident), and that latency is hidden by the
+// other members: ~28 of them fit a CU, so the 4 800 members of a million reads are all in flight at once (the first version kept each
+// member's 64 KiB image in LDS: 2 members per CU, 104 ms per million reads).  The wave as a whole moves the data: compressed bytes
+// stream into the ring in 1 KiB wave-wide loads between lane 0's decode runs, and the member's CRC-32 is computed by all 64 lanes
+// over 1 KiB slices of the text and folded with the "append 1024 zero bytes" operator.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,9 +24,9 @@ namespace cid {
 struct BgzfMember { uint32_t in_off, in_len, out_off, out_len; };   // in_off: the member's first byte (its gzip header) in the batch
 
 constexpr int kLitBits = 10, kDistBits = 8;
-constexpr uint32_t kRing = 2048, kOutCap = 65536 + 16;
-// per-wave LDS: out image | input ring | lit table | dist table | canonical-decode arrays | code lengths
-constexpr uint32_t kLdsOut = 0, kLdsRing = kOutCap, kLdsLit = kLdsRing + kRing, kLdsDist = kLdsLit + 2u * (1u << kLitBits),
+constexpr uint32_t kRing = 2048;
+// per-wave LDS: input ring | lit table | dist table | canonical-decode arrays | code lengths
+constexpr uint32_t kLdsRing = 0, kLdsLit = kLdsRing + kRing, kLdsDist = kLdsLit + 2u * (1u << kLitBits),
                    kLdsCnt = kLdsDist + 2u * (1u << kDistBits), kLdsLens = kLdsCnt + 2u * (16 + 288 + 16 + 32), kLdsBytes = kLdsLens + 320;
 
 struct CrcShift { uint32_t m[32]; };   // column j: the CRC register 1 << j after 1024 zero bytes
@@ -128,7 +130,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
                                                      CrcShift shift) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
-    uint8_t *s_out = smem + kLdsOut;
     uint8_t *s_ring = smem + kLdsRing;
     uint16_t *s_lit = reinterpret_cast<uint16_t *>(smem + kLdsLit);
     uint16_t *s_dist = reinterpret_cast<uint16_t *>(smem + kLdsDist);
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
     for (uint32_t mi = blockIdx.x; mi < n_members; mi += gridDim.x) {
         const BgzfMember mem = members[mi];
         const uint8_t *src = in + mem.in_off;
-        const uint32_t skew = mem.out_off & 15u;          // the LDS image is laid out with the destination's 16-byte phase
-        uint8_t *img = s_out + skew;
+        uint8_t *img = out + mem.out_off;                 // the text is written in place: literals are stores nobody waits for, a match
+                                                          // reads what this lane wrote earlier (L2-resident), and the other waves of the SIMD hide that latency
         // gzip header (RFC 1952): 1f 8b 08 FLG(4 = FEXTRA) mtime(4) xfl os | XLEN | extra ... ; trailer CRC32 ISIZE
         uint32_t st = ST_OK, data0 = 0, data_len = 0, want_crc = 0;
         if (mem.in_len < 28 || mem.out_len > 65536u) st = ST_BAD_HEADER;
@@ -250,6 +251,21 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
                             d.phase = 1;
                         } else { d.status = ST_BAD_BLOCK; break; }
                     } else if (d.phase == 1) {   // literal / length-distance symbols
+                        // literals with a short code, one after the other: table word, store, drop — the bounds are a word count
+                        // (the run's budget) and the output's end; anything else falls through to the general step below
+                        {
+                            const uint32_t w_end = (run_end + 3) / 4 + 1;
+                            uint32_t op = d.out_pos;
+                            for (;;) {
+                                br.refill();
+                                const uint32_t e = s_lit[br.peek(kLitBits)];
+                                if (e - 1u >= (256u << 4) - 1u || op >= mem.out_len || br.wpos >= w_end) break;   // not a short-coded literal (e == 0: a long code)
+                                img[op++] = (uint8_t)(e >> 4);
+                                br.drop(e & 15u);
+                            }
+                            d.out_pos = op;
+                            if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
+                        }
                         const int sym = decode_sym(br, s_lit, kLitBits, s_lcnt, s_lsym);
                         if (sym < 0) { d.status = ST_BAD_CODE; break; }
                         if (sym < 256) {
@@ -341,18 +357,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
             }
             if ((reg ^ 0xFFFFFFFFu) != want_crc) st = ST_BAD_CRC;
         }
-        if (st == ST_OK) {   // the text leaves in 16-byte pieces aligned to the destination
-            uint8_t *dst = out + mem.out_off;
-            const uint32_t len = mem.out_len;
-            const uint32_t head = len < ((16u - skew) & 15u) ? len : ((16u - skew) & 15u);
-            if ((uint32_t)lane < head) dst[lane] = img[lane];
-            const uint32_t body = (len - head) / 16u;
-            const uint4 *sv = reinterpret_cast<const uint4 *>(img + head);   // 16-byte aligned in LDS: skew + head == 0 mod 16
-            uint4 *dv = reinterpret_cast<uint4 *>(dst + head);
-            for (uint32_t i = lane; i < body; i += 64) dv[i] = sv[i];
-            const uint32_t tail0 = head + body * 16u;
-            if (tail0 + (uint32_t)lane < len) dst[tail0 + lane] = img[tail0 + lane];
-        }
         if (lane == 0) status[mi] = st;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -417,7 +421,7 @@ extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_byt
     HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cid::k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cid::kLdsBytes));
     unsigned grid = (unsigned)n_members;
-    const unsigned cap = (unsigned)c->n_cu * 2u * 4u;   // two members per CU at a time; a few rounds per block
+    const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // ~28 members per CU at a time; a few rounds per block
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(cid::k_bgzf_inflate, dim3(grid), dim3(64), cid::kLdsBytes, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem,
                        (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st, shift);

@@ -195,7 +195,7 @@ struct LineReader::Impl {
             gpu_ctx = nullptr;
         }
         if (gpu_ctx) (void)cid_warmup(gpu_ctx, CID_WARM_INFLATE);
-        const size_t kBatchOut = gpu_ctx ? (64u << 20) : (16u << 20);
+        const size_t kBatchOut = gpu_ctx ? ((size_t)(getenv("COLORID_GPU_INFLATE_MB") ? atoi(getenv("COLORID_GPU_INFLATE_MB")) : 128) << 20) : (16u << 20);
         std::vector<unsigned char> in;        // compressed bytes of the batch (plus the unread tail of the last fread)
         size_t in_have = 0, in_pos = 0;
         bool file_end = false;
