@@ -293,9 +293,8 @@ struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
 // both have — are split into lines, quality-masked (seq.rs:36-56) and packed by COLORID_PARSE_THREADS threads; the
 // pieces reach `sink` in input order.  The same reads in the same order as the line loops of read_id_mt_pe.rs:862-895 / :927-975
 // and kmer.rs:481-503 / :619-647: a record is pushed at its fourth line; for pairs the walk ends with the shorter file.
-// (default 2: on a 16-CPU share of a GPU box more packers take cycles from the inflating threads and from the GPU stage's host side —
-// tools/exp_readid_stages.sh, 3 runs per setting: 2 packers + 8 poll threads 108-131 ms per million reads, 4 + 8: 130-143, 1 + 8: 152-178)
-const int g_parse_threads = [] { const char *e = getenv("COLORID_PARSE_THREADS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+// (default: an eighth of cpu_budget(), at most 4 — 2 on a 16-CPU share of a GPU box)
+const int g_parse_threads = [] { const char *e = getenv("COLORID_PARSE_THREADS"); const int v = e ? atoi(e) : std::min(4, cpu_budget() / 8); return v < 1 ? 1 : v; }();
 
 struct Line { const char *p; size_t n; };
 inline void record_lines(const RecChunk &c, size_t r, Line out[4]) {
@@ -673,7 +672,7 @@ void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t star
 
 // ... and the poll (kmer_poll_plus per read, read_id_mt_pe.rs:168-251) + the rows of <prefix>_reads.txt on the host: the reads of a
 // batch are independent, so COLORID_POLL_THREADS (default 8) threads format contiguous slices of it and the slices are written in order
-static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : std::min(8, cpu_budget() / 4); return v < 1 ? 1 : v; }();
 static inline void append_u64(std::string &o, uint64_t v) {
     char t[24];
     int n = 0;

@@ -89,6 +89,25 @@ void read_fasta_mf(const std::string &path, std::vector<std::string> &labels, st
     read_fasta_impl(path, &labels, seqs);
 }
 
+int cpu_budget() {
+    static const int budget = [] {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");   // cgroup v2: "<quota> <period>" in microseconds, or "max <period>"
+        if (f) {
+            char q[32];
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long cpus = (atol(q) + period - 1) / period;
+                if (cpus >= 1 && cpus < hw) hw = (int)cpus;
+            }
+            fclose(f);
+        }
+        return hw;
+    }();
+    return budget;
+}
+
 // libdeflate (whole-buffer DEFLATE: a BGZF member is one) inflates 2-3x faster than zlib; it is used when the host has it
 // (dlopen of libdeflate.so.0 — no build-time dependency), checks CRC-32 and ISIZE like zlib, and COLORID_LIBDEFLATE=0 turns it off
 struct LibDeflate {
@@ -121,7 +140,7 @@ struct LineReader::Impl {
     size_t depth = 4;              // blocks in flight (prefetched streams: ~256 MiB worth)
     gzFile gz = nullptr;
     FILE *raw = nullptr;           // BGZF mode: the compressed file itself
-    int gz_threads = 8;
+    int gz_threads = std::min(8, std::max(1, cpu_budget() / 5));   // COLORID_GZ_THREADS overrides
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv_full, cv_free;
@@ -315,7 +334,8 @@ static LineReader::Impl *open_stream(const std::string &path, bool ahead) {
     LineReader::Impl *p = new LineReader::Impl;
     const char *gt = getenv("COLORID_GZ_THREADS");
     if (gt) p->gz_threads = atoi(gt);
-    if (p->gz_threads > 1 && LineReader::Impl::is_bgzf(path)) {
+    if (p->gz_threads < 1) p->gz_threads = 1;
+    if (LineReader::Impl::is_bgzf(path)) {   // (one thread too: whole members through libdeflate beat a zlib stream)
         p->raw = fopen(path.c_str(), "rb");
         if (!p->raw) die("file not found: %s", path.c_str());
         if (ahead) p->depth = 16;   // batches of 16 MiB of text
