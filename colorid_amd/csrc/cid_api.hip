@@ -185,6 +185,23 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 }  // namespace
 
+namespace cid {
+static const bool kUsePin = getenv("CID_PIN_STAGING") ? atoi(getenv("CID_PIN_STAGING")) != 0 : true;
+uint8_t *pin_reserve(cid_ctx *c, size_t bytes) {
+    if (!kUsePin || bytes > kPinMax) return nullptr;
+    if (bytes <= c->pin_bytes) return c->pin;
+    if (c->pin) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
+    size_t want = bytes + bytes / 2;
+    if (want < (16u << 20)) want = 16u << 20;
+    if (want > kPinMax) want = kPinMax;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    c->pin = (uint8_t *)p;
+    c->pin_bytes = want;
+    return c->pin;
+}
+}  // namespace cid
+
 extern "C" {
 
 const char *cid_last_error(void) { return g_err; }
@@ -206,6 +223,10 @@ int cid_ctx_create(int device_id, cid_ctx **out) {
     if (n <= 0) return fail(CID_ERR_HIP, "no HIP device (this library has no CPU path)");
     if (device_id < 0 || device_id >= n) return fail(CID_ERR_INVALID, "device %d of %d", device_id, n);
     HIP_TRY(hipSetDevice(device_id));
+    if (const char *sy = getenv("COLORID_SYNC")) {   // how host threads wait for the device (before the device's first use): spin | yield | block
+        const unsigned f = !strcmp(sy, "spin") ? hipDeviceScheduleSpin : !strcmp(sy, "yield") ? hipDeviceScheduleYield : !strcmp(sy, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        (void)hipSetDeviceFlags(f);   // (refused once the device is active: the first context decides)
+    }
     cid_ctx *c = new (std::nothrow) cid_ctx();
     if (!c) return fail(CID_ERR_NOMEM, "ctx");
     c->device = device_id;
@@ -253,6 +274,7 @@ void cid_ctx_destroy(cid_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->pin) (void)hipHostFree(c->pin);
     delete c;
 }
 
@@ -1190,9 +1212,23 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
     rc = slot_reserve(c, S_READ0, (n_reads + 1) * 8, &d_r0); if (rc) return rc;
     rc = slot_reserve(c, S_REPORT, n_reads * C1 * 4, &d_rep); if (rc) return rc;
     rc = slot_reserve(c, S_NK, n_reads * 4 + n_reads + 16, &d_nk); if (rc) return rc;
-    if (total_bases) HIP_TRY(hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    {   // the batch goes through the ctx's pinned arena when it fits (cid::pin_reserve); the arena's tail is left for the results
+        const size_t b_so = (total_bases + 15) & ~(size_t)15, b_r0 = b_so + (n_seqs + 1) * 8, b_end = b_r0 + (n_reads + 1) * 8;
+        uint8_t *pin = cid::pin_reserve(c, b_end + n_reads * 5 + 64);
+        if (pin) {
+            HIP_TRY(hipStreamSynchronize(c->stream));   // (the arena may still feed the previous call's copies)
+            if (total_bases) memcpy(pin, bases, total_bases);
+            memcpy(pin + b_so, seq_off, (n_seqs + 1) * 8);
+            memcpy(pin + b_r0, read_seq0, (n_reads + 1) * 8);
+            if (total_bases) HIP_TRY(hipMemcpyAsync(d_bases, pin, total_bases, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_so, pin + b_so, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_r0, pin + b_r0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        } else {
+            if (total_bases) HIP_TRY(hipMemcpyAsync(d_bases, bases, total_bases, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        }
+    }
     uint8_t *d_status = (uint8_t *)d_nk + n_reads * 4;
     if (ix->rs > 128 && mixed) HIP_TRY(hipMemsetAsync(d_rep, 0, n_reads * C1 * 4, c->stream));   // both kernels count in place
     if (n_long) {   // first: it writes a status for every read (2 = the other kernel's)
@@ -1279,9 +1315,17 @@ int cid_readid_count_sparse(cid_ctx *c, const cid_index *ix, const uint8_t *base
     rc = cid::compact_report(c, d_rep, ix->n_colors + 1, n_reads, &c->sp_start, &c->sp_col, &c->sp_cnt, &c->sp_entries);
     if (rc) return rc;
     c->sp_rows = n_reads;
-    HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(status, d_st, n_reads, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (uint8_t *pin = cid::pin_reserve(c, n_reads * 5 + 64)) {   // (inputs are on the device by now: the arena is free again)
+        HIP_TRY(hipMemcpyAsync(pin, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(pin + n_reads * 4, d_st, n_reads, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(n_kmers, pin, n_reads * 4);
+        memcpy(status, pin + n_reads * 4, n_reads);
+    } else {
+        HIP_TRY(hipMemcpyAsync(n_kmers, d_nk, n_reads * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(status, d_st, n_reads, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     *n_entries = c->sp_entries;
     return CID_OK;
 }
@@ -1291,6 +1335,19 @@ int cid_readid_sparse_fetch(cid_ctx *c, uint64_t *row_start, uint32_t *colours, 
     if (c->sp_rows == 0) { row_start[0] = 0; return CID_OK; }
     if (c->sp_entries && (!colours || !counts)) return fail(CID_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    const size_t b_rs = (c->sp_rows + 1) * 8, b_e = c->sp_entries * 4;
+    if (uint8_t *pin = cid::pin_reserve(c, b_rs + 2 * b_e + 64)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyAsync(pin, c->sp_start, b_rs, hipMemcpyDeviceToHost, c->stream));
+        if (b_e) {
+            HIP_TRY(hipMemcpyAsync(pin + b_rs, c->sp_col, b_e, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(pin + b_rs + b_e, c->sp_cnt, b_e, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(row_start, pin, b_rs);
+        if (b_e) { memcpy(colours, pin + b_rs, b_e); memcpy(counts, pin + b_rs + b_e, b_e); }
+        return CID_OK;
+    }
     HIP_TRY(hipMemcpy(row_start, c->sp_start, (c->sp_rows + 1) * 8, hipMemcpyDeviceToHost));
     if (c->sp_entries) {
         HIP_TRY(hipMemcpy(colours, c->sp_col, c->sp_entries * 4, hipMemcpyDeviceToHost));

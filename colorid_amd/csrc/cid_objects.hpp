@@ -25,6 +25,9 @@ struct cid_ctx {
     struct Block { void *p; size_t bytes; bool used; };
     std::vector<Block> blocks;
     size_t idle_bytes = 0;
+    // pinned host arena: the host-pointer read_id calls stage their (small) arrays through it — see cid::pin_reserve
+    uint8_t *pin = nullptr;
+    size_t pin_bytes = 0;
     // second stream + events for the host-pointer entry points: the H2D copy of chunk i+1 runs beside the kernel of chunk i
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -43,6 +46,12 @@ struct cid_index {
 namespace cid {
 // grow-only per-role device buffers of a ctx
 int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out);
+// A pinned host buffer of the ctx (grow-only).  A copy between device and the CALLER's pageable memory makes the runtime pin and
+// unpin the caller's pages — a fixed cost per array of ~0.4 ms once other threads of the process fault pages at the same time (the
+// CLI's inflating and packing threads: a read_id call of 50 000 reads took 5 ms instead of 1.1 ms).  Arrays of a few MB are cheaper
+// copied through this arena.  NULL when the request is larger than kPinMax: the caller then lets the runtime handle its memory.
+uint8_t *pin_reserve(cid_ctx *c, size_t bytes);
+constexpr size_t kPinMax = 64u << 20;
 // a5 launch on device-resident inputs/outputs (zeroes the counters first); asynchronous on the ctx stream
 int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, const uint32_t *d_freq,
                         size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour,
