@@ -46,8 +46,7 @@ void kmers_from_fq_qual(const std::string &path, uint8_t q, KmerMap &out);      
 void kmers_fq_pe_qual(const std::string &p1, const std::string &p2, uint8_t q, KmerMap &out);  // kmer.rs:581-655
 
 // CPUs this process may keep busy: the cgroup's CPU quota (cpu.max) when there is one, else the hardware's thread count.  The
-// host pipeline sizes its pools from it (a fifth for inflating block-gzip members, a quarter for the poll, an eighth for packing
-// records): more runnable threads than the quota get the whole process throttled for the rest of the scheduling period, which on a
+// host pipeline sizes its pools from it (a third for inflating block-gzip members, a fifth for packing records): more runnable threads than the quota get the whole process throttled for the rest of the scheduling period, which on a
 // 16-CPU share of a GPU box cost more than the extra threads brought (tools/exp_readid_stages.sh).
 int cpu_budget();
 

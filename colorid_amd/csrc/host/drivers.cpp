@@ -30,7 +30,7 @@ static long secs_since(Clock::time_point t0) { return (long)std::chrono::duratio
 static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 // COLORID_TIMING=1: sub-second phase times on stderr (the reference's own timers print whole seconds)
 static bool g_timing = getenv("COLORID_TIMING") != nullptr;
-static double g_ms_gpu = 0, g_ms_poll = 0, g_ms_gpu_count = 0;
+static double g_ms_gpu = 0, g_ms_poll = 0, g_ms_gpu_count = 0, g_ms_write = 0;
 static uint64_t g_entries = 0;
 static double g_ms_wait[4] = {0, 0, 0, 0};   // parser blocked by a full queue | GPU stage idle | GPU stage blocked by the poll | poll idle
 
@@ -293,8 +293,8 @@ struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
 // both have — are split into lines, quality-masked (seq.rs:36-56) and packed by COLORID_PARSE_THREADS threads; the
 // pieces reach `sink` in input order.  The same reads in the same order as the line loops of read_id_mt_pe.rs:862-895 / :927-975
 // and kmer.rs:481-503 / :619-647: a record is pushed at its fourth line; for pairs the walk ends with the shorter file.
-// (default: an eighth of cpu_budget(), at most 4 — 2 on a 16-CPU share of a GPU box)
-const int g_parse_threads = [] { const char *e = getenv("COLORID_PARSE_THREADS"); const int v = e ? atoi(e) : std::min(4, cpu_budget() / 8); return v < 1 ? 1 : v; }();
+// (default: a fifth of cpu_budget(), at most 4 — 3 on a 16-CPU share of a GPU box)
+const int g_parse_threads = [] { const char *e = getenv("COLORID_PARSE_THREADS"); const int v = e ? atoi(e) : std::min(4, cpu_budget() / 5); return v < 1 ? 1 : v; }();
 
 struct Line { const char *p; size_t n; };
 inline void record_lines(const RecChunk &c, size_t r, Line out[4]) {
@@ -307,8 +307,8 @@ inline void record_lines(const RecChunk &c, size_t r, Line out[4]) {
         p = nl + 1;
     }
 }
-ReadBatch pack_records(const RecChunk *c1, size_t a0, const RecChunk *c2, size_t b0, size_t n, uint8_t q, bool want_ids) {
-    ReadBatch rb;
+ReadBatch pack_records(ReadBatch rb, const RecChunk *c1, size_t a0, const RecChunk *c2, size_t b0, size_t n, uint8_t q, bool want_ids) {
+    rb.clear();   // (a recycled batch keeps its buffers: no fresh pages to fault in)
     const size_t text = c1->rec_end[a0 + n - 1] - c1->rec_begin(a0);
     rb.bases.reserve((c2 ? 2 : 1) * (text / 2 + 64));
     rb.seq_off.reserve((c2 ? 2 : 1) * n + 1);
@@ -328,8 +328,9 @@ ReadBatch pack_records(const RecChunk *c1, size_t a0, const RecChunk *c2, size_t
     return rb;
 }
 
-template <typename Sink>
-void stream_fastq_records(const std::string &f1, const std::string *f2, uint8_t q, bool want_ids, Sink &&sink) {
+inline ReadBatch no_spare() { return ReadBatch(); }
+template <typename Sink, typename Spare = ReadBatch (*)()>
+void stream_fastq_records(const std::string &f1, const std::string *f2, uint8_t q, bool want_ids, Sink &&sink, Spare &&spare = no_spare) {
     LineReader r1(f1);
     std::unique_ptr<LineReader> r2(f2 ? new LineReader(*f2) : nullptr);
     RecordChunker k1(r1);
@@ -350,7 +351,8 @@ void stream_fastq_records(const std::string &f1, const std::string *f2, uint8_t 
             n = std::min(n, c2->records() - p2);
         }
         while (inflight.size() >= (size_t)g_parse_threads) drain_one();
-        inflight.push_back(std::async(std::launch::async, [c1, p1, c2, p2, n, q, want_ids] { return pack_records(c1.get(), p1, c2.get(), p2, n, q, want_ids); }));
+        std::shared_ptr<ReadBatch> buf(new ReadBatch(spare()));   // a batch whose buffers an earlier round already grew (or an empty one)
+        inflight.push_back(std::async(std::launch::async, [buf, c1, p1, c2, p2, n, q, want_ids] { return pack_records(std::move(*buf), c1.get(), p1, c2.get(), p2, n, q, want_ids); }));
         p1 += n; p2 += n;
     }
     while (!inflight.empty()) drain_one();
@@ -672,7 +674,9 @@ void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t star
 
 // ... and the poll (kmer_poll_plus per read, read_id_mt_pe.rs:168-251) + the rows of <prefix>_reads.txt on the host: the reads of a
 // batch are independent, so COLORID_POLL_THREADS (default 8) threads format contiguous slices of it and the slices are written in order
-static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : std::min(8, cpu_budget() / 4); return v < 1 ? 1 : v; }();
+// (default 1: the poll of a million reads is 50 ms on one thread, and slicing a batch over several did not shorten it on the GPU box —
+// 207 ms per 4 M reads on one thread, 213-224 ms on four — while the CPUs are worth more to the inflating and packing threads)
+static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
 static inline void append_u64(std::string &o, uint64_t v) {
     char t[24];
     int n = 0;
@@ -684,9 +688,16 @@ void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::
     const size_t n = c.rb.size(), C = b.colors.size();
     const auto t_poll = Clock::now();
     const size_t nt = std::min<size_t>((size_t)g_poll_threads, (n + 4095) / 4096);
-    std::vector<std::string> text(nt);
+    // (the slices' text buffers and tallies live across batches: a fresh 2 MB string per slice and batch is 600 page faults, and page
+    // faults of several threads at once serialise in the kernel — four poll threads were SLOWER than one until these were kept)
+    static thread_local std::vector<std::string> text_tl;
+    static thread_local std::vector<std::vector<uint64_t>> acc_tl;
+    std::vector<std::string> &text = text_tl;              // (references: the slices' threads must see THIS thread's vectors, and a
+    std::vector<std::vector<uint64_t>> &acc = acc_tl;      //  thread_local named inside their lambda would be their own)
+    if (text.size() < nt) text.resize(nt);
+    if (acc.size() < nt) acc.resize(nt);
     // the tally of <prefix>_counts.txt: an accepted read counts under its label — one accession, "no_hits" or "too_short" — every other under "reject"
-    std::vector<std::vector<uint64_t>> acc(nt, std::vector<uint64_t>(C + 3, 0));   // [C] no_hits, [C+1] too_short, [C+2] reject
+    for (size_t t = 0; t < nt; ++t) { text[t].clear(); acc[t].assign(C + 3, 0); }   // [C] no_hits, [C+1] too_short, [C+2] reject
     if (memchr(c.rb.id_chars.data(), '\t', c.rb.id_chars.size())) tally_ok = false;
     auto work = [&](size_t t) {
         std::string &o = text[t];
@@ -720,7 +731,9 @@ void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::
     for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
     if (nt) work(0);
     for (auto &x : th) x.join();
-    for (const std::string &o : text) fwrite(o.data(), 1, o.size(), out);
+    const auto t_write = Clock::now();
+    for (size_t t = 0; t < nt; ++t) fwrite(text[t].data(), 1, text[t].size(), out);
+    g_ms_write += ms_since(t_write);
     for (size_t t = 0; t < nt; ++t) {
         const std::vector<uint64_t> &a = acc[t];
         for (size_t col = 0; col < C; ++col) if (a[col]) tally[b.colors[col]] += a[col];
@@ -761,6 +774,14 @@ class BatchClassifier {
         rb.clear();
         cv_work_.notify_one();
     }
+    // a batch whose buffers are already grown (its reads were polled), for the record packers; an empty one when none is free
+    ReadBatch spare() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (spare_.empty()) return ReadBatch();
+        ReadBatch rb = std::move(spare_.back());
+        spare_.pop_back();
+        return rb;
+    }
     uint64_t finish() {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -777,9 +798,11 @@ class BatchClassifier {
     static constexpr size_t kDepth = 2;
     void run_count() {
         for (;;) {
-            std::unique_ptr<Counted> c(new Counted);
+            std::unique_ptr<Counted> c;
             {
                 std::unique_lock<std::mutex> lk(mu_);
+                if (!free_counted_.empty()) { c = std::move(free_counted_.back()); free_counted_.pop_back(); }
+                else c.reset(new Counted);
                 const auto tw = Clock::now();
                 cv_work_.wait(lk, [&] { return done_ || !queue_.empty(); });
                 g_ms_wait[1] += ms_since(tw);
@@ -818,7 +841,9 @@ class BatchClassifier {
             fprintf(stderr, progress_fmt_, (unsigned long long)n_reads_);
             c->rb.clear();
             std::lock_guard<std::mutex> lk(mu_);
-            spare_.push_back(std::move(c->rb));
+            if (spare_.size() < 16) spare_.push_back(std::move(c->rb));
+            c->rb = ReadBatch();
+            free_counted_.push_back(std::move(c));   // its result vectors keep their capacity for a later batch
         }
     }
     cid_ctx *ctx_;
@@ -833,6 +858,7 @@ class BatchClassifier {
     std::condition_variable cv_work_, cv_room_, cv_counted_, cv_polled_;
     std::deque<ReadBatch> queue_;
     std::deque<std::unique_ptr<Counted>> counted_;
+    std::vector<std::unique_ptr<Counted>> free_counted_;
     std::vector<ReadBatch> spare_;
     bool done_ = false, count_done_ = false;
     uint64_t n_reads_ = 0;   // the polling thread's, read by finish() after the join
@@ -854,13 +880,13 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     stream_fastq_records(fq[0], nullptr, qual_offset, true, [&](ReadBatch &&piece) {
         if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
         if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);   // (batches close on piece boundaries: at least `batch` reads each)
-    });
+    }, [&] { return classifier.spare(); });
     classifier.submit(rb);
     const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
     if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms; waits: parser on a full queue %.0f ms, GPU stage idle %.0f ms, "
-                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries);
+                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched; of poll + write: writing %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries, g_ms_write);
 }
 
 void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
@@ -874,13 +900,13 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     stream_fastq_records(fq[0], &fq[1], qual_offset, true, [&](ReadBatch &&piece) {
         if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
         if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);
-    });
+    }, [&] { return classifier.spare(); });
     classifier.submit(rb);
     const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu read pairs in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
     if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms; waits: parser on a full queue %.0f ms, GPU stage idle %.0f ms, "
-                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries);
+                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched; of poll + write: writing %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries, g_ms_write);
 }
 
 void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,

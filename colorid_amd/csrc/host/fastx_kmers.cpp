@@ -140,7 +140,7 @@ struct LineReader::Impl {
     size_t depth = 4;              // blocks in flight (prefetched streams: ~256 MiB worth)
     gzFile gz = nullptr;
     FILE *raw = nullptr;           // BGZF mode: the compressed file itself
-    int gz_threads = std::min(8, std::max(1, cpu_budget() / 5));   // COLORID_GZ_THREADS overrides
+    int gz_threads = std::min(8, std::max(1, cpu_budget() / 3));   // COLORID_GZ_THREADS overrides
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv_full, cv_free;
@@ -441,6 +441,41 @@ bool LineReader::next(const char *&ptr, size_t &len) {
 bool LineReader::next_block(std::vector<char> &blk) { return p_->take_block(blk); }
 void LineReader::recycle(std::vector<char> &&blk) { p_->give_back(std::move(blk)); }
 
+// Newlines of [p, end): every fourth one (counting from `lines` seen before) closes a FASTQ record, whose end offset (relative to
+// `base`) is appended.  FASTQ lines are short — an id of ten bytes, 150 bases — so one memchr call per line is mostly call overhead
+// (4 M calls per million reads, ~90 ms on the reading thread); 32 bytes at a time with AVX2 compare + movemask, the set bits walked
+// with tzcnt, takes a quarter of that.  Returns the new line count.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static uint64_t scan_records_avx2(const char *base, const char *p, const char *end, uint64_t lines, std::vector<uint32_t> &rec_end) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    for (; p + 32 <= end; p += 32) {
+        uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i *>(p)), nl));
+        while (m) {
+            const uint32_t b = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            if ((++lines & 3u) == 0) rec_end.push_back((uint32_t)(p + b + 1 - base));
+        }
+    }
+    for (; p < end; ++p)
+        if (*p == '\n' && (++lines & 3u) == 0) rec_end.push_back((uint32_t)(p + 1 - base));
+    return lines;
+}
+#endif
+static uint64_t scan_records(const char *base, const char *p, const char *end, uint64_t lines, std::vector<uint32_t> &rec_end) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("COLORID_NO_AVX2");
+    if (avx2) return scan_records_avx2(base, p, end, lines, rec_end);
+#endif
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        if (!nl) break;
+        p = nl + 1;
+        if ((++lines & 3u) == 0) rec_end.push_back((uint32_t)(p - base));
+    }
+    return lines;
+}
+
 bool RecordChunker::next(RecChunk &c) {
     c.rec_end.clear();
     for (;;) {
@@ -473,12 +508,7 @@ bool RecordChunker::next(RecChunk &c) {
         const char *p = base + begin + carry_.size();
         uint64_t lines = carry_lines_;
         if (!have) { p = base + begin; lines = 0; }   // (the final carry is scanned whole: its last newline was just added)
-        while (p < end) {
-            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
-            if (!nl) break;
-            p = nl + 1;
-            if ((++lines & 3u) == 0) c.rec_end.push_back((uint32_t)(p - base));
-        }
+        lines = scan_records(base, p, end, lines, c.rec_end);
         const size_t boundary = c.rec_end.empty() ? begin : c.rec_end.back();
         carry_.assign(base + boundary, (size_t)(end - (base + boundary)));
         carry_lines_ = lines & 3u;

@@ -220,6 +220,41 @@ def test_read_id_fastq(orc, env, pe, dflag, bflag, batch):
     assert f"Classified {len(want)} read" in err
 
 
+@pytest.mark.parametrize("pe", [False, True])
+def test_read_id_threaded_host_pipeline_writes_the_same_rows(orc, env, pe):
+    """Batches big enough for every host pool to split its work — several inflating threads (BGZF input), record-packing threads, a
+    poll sliced over threads (>= 8192 reads per batch), batches recycled between the stages — against the same run on one thread of
+    each, and against the oracle on a sample of the rows."""
+    from test_linereader_cpu import write_bgzf
+    d, bxi, oix, genomes = env
+    n = 40_000
+    files = []
+    recs = []
+    for mate in range(2 if pe else 1):
+        rng = np.random.default_rng(77)
+        r = synth_fastq_records(rng, genomes, n, 150, mate=mate)
+        recs.append(r)
+        text = b"".join(b"@" + a[0] + b"\n" + a[1] + b"\n+\n" + a[2] + b"\n" for a in r)
+        f = str(d / f"thr_{int(pe)}_{mate}.fastq.gz")
+        write_bgzf(f, text, level=1)
+        files.append(f)
+    outs = []
+    for tag, envv in (("one", {"COLORID_GZ_THREADS": "1", "COLORID_PARSE_THREADS": "1", "COLORID_POLL_THREADS": "1"}),
+                      ("many", {"COLORID_GZ_THREADS": "5", "COLORID_PARSE_THREADS": "4", "COLORID_POLL_THREADS": "4"})):
+        prefix = str(d / f"thr_{int(pe)}_{tag}")
+        p = subprocess.run([BIN, "read_id", "-b", bxi, "-q", *files, "-n", prefix, "-c", "20000"], capture_output=True, text=True, env=dict(os.environ, **envv))
+        assert p.returncode == 0, p.stderr[-500:]
+        outs.append((open(prefix + "_reads.txt").read(), open(prefix + "_counts.txt").read()))
+    assert outs[0] == outs[1]
+    rows = outs[0][0].splitlines()
+    assert len(rows) == n
+    sample = list(range(0, n, 97))
+    ids = ["@" + recs[0][i][0].decode() for i in sample]
+    masked = [[orc.qual_mask(r[i][1], r[i][2], 15) for r in recs] for i in sample]
+    want = expected_readid(orc, oix, ids, masked, 1, 3)
+    assert [rows[i] for i in sample] == want
+
+
 def test_read_id_fasta(orc, env):
     d, bxi, oix, genomes = env
     # stream_fasta keeps line breaks inside the sequence (read_id_mt_pe.rs:480-494): 70-column records
