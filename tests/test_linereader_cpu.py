@@ -76,6 +76,10 @@ def test_linereader_same_lines_for_every_container(shim, tmp_path, n_reads):
                 r = subprocess.run([shim, str(p), mode], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads))
                 assert r.returncode == 0, (name, mode, r.stderr)
                 outs[(name, threads, mode)] = r.stdout.split()
+            if name in ("gz", "multi"):   # single-stream gzip: zlib's raw inflate + libdeflate's CRC-32 when the host has libdeflate, gzread otherwise
+                r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, COLORID_LIBDEFLATE="0"))
+                assert r.returncode == 0, (name, r.stderr)
+                outs[(name, threads, "gzread")] = r.stdout.split()
             if "bgzf" in name:   # BGZF members go through libdeflate when the host has it: the same lines with zlib
                 r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads, COLORID_LIBDEFLATE="0"))
                 assert r.returncode == 0, (name, r.stderr)
@@ -98,3 +102,45 @@ def test_linereader_reports_a_corrupt_bgzf_member(shim, tmp_path):
     for env in ({}, {"COLORID_LIBDEFLATE": "0"}):     # libdeflate (when present) and zlib both check the member's CRC-32
         r = subprocess.run([shim, str(p)], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 101 and ("corrupt gzip member" in r.stderr or "BGZF" in r.stderr or "truncated" in r.stderr)
+
+
+def test_linereader_single_stream_gzip_containers(shim, tmp_path):
+    """Single-stream gzip through the container parser of the libdeflate path (and through gzread): header fields (extra, name,
+    comment, header CRC), an empty member between two others, trailing bytes that are no member; and a corrupt stream, a wrong CRC-32
+    and a truncated file are reported."""
+    rng = np.random.default_rng(5)
+    text = _fastq(rng, 20_000)
+    plain = tmp_path / "p.fastq"
+    plain.write_bytes(text)
+    want = subprocess.run([shim, str(plain)], capture_output=True, text=True, check=True).stdout
+
+    def member(data, flg=0, level=6):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(data) + co.flush()
+        hdr = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\0\xff"
+        if flg & 4:
+            hdr += struct.pack("<H", 5) + b"hello"
+        if flg & 8:
+            hdr += b"name.fastq\0"
+        if flg & 16:
+            hdr += b"a comment\0"
+        if flg & 2:
+            hdr += struct.pack("<H", zlib.crc32(hdr) & 0xFFFF)
+        return hdr + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+    third = len(text) // 3
+    good = member(text[:third], 4 | 8 | 16 | 2) + member(b"") + member(text[third:2 * third], 8, level=1) + member(text[2 * third:], 0, level=9)
+    cases = {"fields": good, "trailing": good + b"\0" * 37 + b"not a member"}
+    for tag, blob in cases.items():
+        p = tmp_path / f"{tag}.fastq.gz"
+        p.write_bytes(blob)
+        for env in ({}, {"COLORID_LIBDEFLATE": "0"}):
+            r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, **env))
+            assert r.returncode == 0 and r.stdout == want, (tag, env, r.stderr[-200:])
+    bad = bytearray(good); bad[len(good) // 2] ^= 0x40
+    crc = bytearray(good); crc[-8] ^= 1
+    for tag, blob in (("flip", bytes(bad)), ("crc", bytes(crc)), ("cut", good[:len(good) - 20])):
+        p = tmp_path / f"bad_{tag}.fastq.gz"
+        p.write_bytes(blob)
+        r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True)
+        assert r.returncode == 101 and ("gzip member" in r.stderr), (tag, r.returncode, r.stderr[-200:])
