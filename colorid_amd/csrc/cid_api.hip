@@ -1145,9 +1145,19 @@ static int readid_stripe_pass(cid_ctx *c, const cid_index *ix, const uint8_t *d_
     rc = slot_reserve(c, S_SEQOFF, (n_seqs + 1) * 8, &d_so); if (rc) return rc;
     rc = slot_reserve(c, S_READ0, (n_reads + 1) * 8, &d_r0); if (rc) return rc;
     rc = slot_reserve(c, S_ZSTART, (n_reads + 1) * 8, &d_zs); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_so, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_r0, read_seq0, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_zs, zs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    {   // the three offset arrays through the pinned arena when they fit (cid::pin_reserve)
+        const size_t b0 = (n_seqs + 1) * 8, b1 = (n_reads + 1) * 8;
+        const uint8_t *so_src = reinterpret_cast<const uint8_t *>(seq_off), *r0_src = reinterpret_cast<const uint8_t *>(read_seq0),
+                      *zs_src = reinterpret_cast<const uint8_t *>(zs.data());
+        if (uint8_t *pin = cid::pin_reserve(c, b0 + 2 * b1 + 64)) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            memcpy(pin, seq_off, b0); memcpy(pin + b0, read_seq0, b1); memcpy(pin + b0 + b1, zs.data(), b1);
+            so_src = pin; r0_src = pin + b0; zs_src = pin + b0 + b1;
+        }
+        HIP_TRY(hipMemcpyAsync(d_so, so_src, b0, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_r0, r0_src, b1, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_zs, zs_src, b1, hipMemcpyHostToDevice, c->stream));
+    }
     sa.zero_start = (const uint64_t *)d_zs;
     if (rr.n_long) {   // first: it writes a status for every read (2 = the other kernels')
         HIP_TRY(hipStreamSynchronize(c->stream));

@@ -288,8 +288,8 @@ struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
     void clear() { id_chars.clear(); id_off.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
 };
 
-// ---- FASTQ text -> packed batches on several threads.  RecordChunker cuts each input's decoded blocks at record boundaries (one
-// memchr per line, on the calling thread); the records of a chunk — for pairs: as many records of either file's current chunk as
+// ---- FASTQ text -> packed batches on several threads.  RecordChunker cuts each input's decoded blocks at record boundaries (a
+// newline scan on the calling thread); the records of a chunk — for pairs: as many records of either file's current chunk as
 // both have — are split into lines, quality-masked (seq.rs:36-56) and packed by COLORID_PARSE_THREADS threads; the
 // pieces reach `sink` in input order.  The same reads in the same order as the line loops of read_id_mt_pe.rs:862-895 / :927-975
 // and kmer.rs:481-503 / :619-647: a record is pushed at its fourth line; for pairs the walk ends with the shorter file.
