@@ -240,12 +240,14 @@ def test_read_id_threaded_host_pipeline_writes_the_same_rows(orc, env, pe):
         files.append(f)
     outs = []
     for tag, envv in (("one", {"COLORID_GZ_THREADS": "1", "COLORID_PARSE_THREADS": "1", "COLORID_POLL_THREADS": "1"}),
-                      ("many", {"COLORID_GZ_THREADS": "5", "COLORID_PARSE_THREADS": "4", "COLORID_POLL_THREADS": "4"})):
+                      ("many", {"COLORID_GZ_THREADS": "5", "COLORID_PARSE_THREADS": "4", "COLORID_POLL_THREADS": "4"}),
+                      ("zlib", {"COLORID_LIBDEFLATE": "0", "COLORID_NO_AVX2": "1", "CID_PIN_STAGING": "0"}),          # every fallback at once
+                      ("gpu", {"COLORID_GPU_INFLATE": "1", "COLORID_GPU_INFLATE_MB": "1"})):                          # members inflated on the GPU, several batches
         prefix = str(d / f"thr_{int(pe)}_{tag}")
         p = subprocess.run([BIN, "read_id", "-b", bxi, "-q", *files, "-n", prefix, "-c", "20000"], capture_output=True, text=True, env=dict(os.environ, **envv))
         assert p.returncode == 0, p.stderr[-500:]
         outs.append((open(prefix + "_reads.txt").read(), open(prefix + "_counts.txt").read()))
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
     rows = outs[0][0].splitlines()
     assert len(rows) == n
     sample = list(range(0, n, 97))
