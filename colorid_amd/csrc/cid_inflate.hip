@@ -3,13 +3,16 @@
 // src/read_id_mt_pe.rs:848-856, src/kmer.rs:469-476).  A BGZF file is a series of independent gzip members of at most 64 KiB of text,
 // each carrying its compressed size in a "BC" extra field — so a batch of members is a batch of independent DEFLATE streams.
 //
-// One wave per member.  DEFLATE is serial inside a stream, so lane 0 decodes; what its dependent chain touches at every symbol — the
+// DEFLATE is serial inside a stream, so one lane decodes a member; what its dependent chain touches at every symbol — the
 // Huffman tables and the bit reader's input ring — lives in LDS (5.6 KiB per member), the text is written in place in HBM: a literal
 // is a store nobody waits for, a match reads bytes the same lane stored earlier (L2-resident), and that latency is hidden by the
 // other members: ~28 of them fit a CU, so the 4 800 members of a million reads are all in flight at once (the first version kept each
 // member's 64 KiB image in LDS: 2 members per CU, 104 ms per million reads).  The wave as a whole moves the data: compressed bytes
-// stream into the ring in 1 KiB wave-wide loads between lane 0's decode runs, and the member's CRC-32 is computed by all 64 lanes
-// over 1 KiB slices of the text and folded with the "append 1024 zero bytes" operator.
+// stream into the ring in 1 KiB wave-wide loads between the decoding lanes' runs, and a member's CRC-32 is computed by all 64 lanes
+// over 1 KiB slices of the text and folded with the "append 1024 zero bytes" operator.  A wave carries TWO members on its first two
+// lanes: the kernel is bound by instruction issue, and two decoders that share an instruction stream wherever their steps coincide
+// finish a million reads' members in 19.6 ms against 42.7 ms one per wave (4 and 8 per wave: 21.8 ms — the divergence eats the rest;
+// the floor of a launch is the 12 ms a single member takes).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -126,216 +129,252 @@ struct Decoder {
     uint32_t status;
 };
 
+// the LDS of one member's decoder
+struct LaneLds {
+    uint8_t *ring;
+    uint16_t *lit, *dist, *lcnt, *lsym, *dcnt, *dsym;
+    uint8_t *lens;
+    __device__ explicit LaneLds(uint8_t *base)
+        : ring(base + kLdsRing), lit(reinterpret_cast<uint16_t *>(base + kLdsLit)), dist(reinterpret_cast<uint16_t *>(base + kLdsDist)),
+          lcnt(reinterpret_cast<uint16_t *>(base + kLdsCnt)), lsym(lcnt + 16), dcnt(lsym + 288), dsym(dcnt + 16), lens(base + kLdsLens) {}
+};
+
+// one run of a member's decoder: steps are taken while they START within 400 bytes of the run's first one (the ring holds >= 1024 bytes
+// ahead, or the stream's end; the longest step — a dynamic block header — takes < 600)
+__device__ void decode_run(BitReader &br, Decoder &d, const LaneLds &L, uint8_t *img, uint32_t out_len, uint32_t data_len) {
+    uint16_t *const s_lit = L.lit, *const s_dist = L.dist, *const s_lcnt = L.lcnt, *const s_lsym = L.lsym, *const s_dcnt = L.dcnt, *const s_dsym = L.dsym;
+    uint8_t *const s_lens = L.lens;
+    const uint32_t run_end = br.consumed_bytes() + 400;   // a step starts below this mark; the longest one (a dynamic block header) takes < 600 bytes, and the ring holds >= 1024 ahead (or the stream's end)
+    while (d.phase != 3 && d.status == ST_OK && br.consumed_bytes() < run_end) {
+        br.refill();
+        if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
+        if (d.phase == 0) {   // block header
+            d.last = br.take(1);
+            const uint32_t type = br.take(2);
+            if (type == 0) {   // stored: skip to the byte boundary, LEN NLEN
+                br.drop(br.cnt & 7u);
+                br.refill();
+                const uint32_t len = br.take(16), nlen = br.take(16);
+                if ((len ^ 0xFFFFu) != nlen) { d.status = ST_BAD_BLOCK; break; }
+                d.stored_left = len;
+                d.phase = 2;
+            } else if (type == 1) {   // fixed Huffman codes (RFC 1951 3.2.6)
+                for (uint32_t s = 0; s < 144; ++s) s_lens[s] = 8;
+                for (uint32_t s = 144; s < 256; ++s) s_lens[s] = 9;
+                for (uint32_t s = 256; s < 280; ++s) s_lens[s] = 7;
+                for (uint32_t s = 280; s < 288; ++s) s_lens[s] = 8;
+                build_tables(s_lens, 288, s_lit, kLitBits, s_lcnt, s_lsym);
+                for (uint32_t s = 0; s < 30; ++s) s_lens[s] = 5;
+                build_tables(s_lens, 30, s_dist, kDistBits, s_dcnt, s_dsym);
+                d.phase = 1;
+            } else if (type == 2) {   // dynamic: HLIT HDIST HCLEN, the code-length code, then the two trees' lengths
+                const uint32_t hlit = br.take(5) + 257, hdist = br.take(5) + 1, hclen = br.take(4) + 4;
+                if (hlit > 286 || hdist > 30) { d.status = ST_BAD_BLOCK; break; }
+                for (uint32_t i = 0; i < 19; ++i) s_lens[i] = 0;
+                for (uint32_t i = 0; i < hclen; ++i) { br.refill(); s_lens[c_clen_order[i]] = (uint8_t)br.take(3); }
+                // the code-length code decodes through the dist table's storage (7-bit direct table)
+                if (!build_tables(s_lens, 19, s_dist, 7, s_dcnt, s_dsym)) { d.status = ST_BAD_BLOCK; break; }
+                uint32_t i = 0;
+                bool bad = false;
+                while (i < hlit + hdist) {
+                    br.refill();
+                    const int sym = decode_sym(br, s_dist, 7, s_dcnt, s_dsym);
+                    if (sym < 0) { bad = true; break; }
+                    if (sym < 16) { s_lens[i++] = (uint8_t)sym; continue; }
+                    uint32_t rep, val = 0;
+                    if (sym == 16) { if (i == 0) { bad = true; break; } val = s_lens[i - 1]; rep = 3 + br.take(2); }
+                    else if (sym == 17) rep = 3 + br.take(3);
+                    else rep = 11 + br.take(7);
+                    if (i + rep > hlit + hdist) { bad = true; break; }
+                    while (rep--) s_lens[i++] = (uint8_t)val;
+                }
+                if (bad || s_lens[256] == 0) { d.status = ST_BAD_BLOCK; break; }
+                // distance lengths sit behind the literal/length ones: build that tree first (its storage was the scratch above)
+                uint8_t dl[30];
+                for (uint32_t s = 0; s < hdist; ++s) dl[s] = s_lens[hlit + s];
+                if (!build_tables(s_lens, hlit, s_lit, kLitBits, s_lcnt, s_lsym)) { d.status = ST_BAD_BLOCK; break; }
+                for (uint32_t s = 0; s < hdist; ++s) s_lens[s] = dl[s];
+                if (!build_tables(s_lens, hdist, s_dist, kDistBits, s_dcnt, s_dsym)) { d.status = ST_BAD_BLOCK; break; }
+                d.phase = 1;
+            } else { d.status = ST_BAD_BLOCK; break; }
+        } else if (d.phase == 1) {   // literal / length-distance symbols
+            // literals with a short code, one after the other: table word, store, drop — the bounds are a word count
+            // (the run's budget) and the output's end; anything else falls through to the general step below
+            {
+                const uint32_t w_end = (run_end + 3) / 4 + 1;
+                uint32_t op = d.out_pos;
+                for (;;) {
+                    br.refill();
+                    const uint32_t e = s_lit[br.peek(kLitBits)];
+                    if (e - 1u >= (256u << 4) - 1u || op >= out_len || br.wpos >= w_end) break;   // not a short-coded literal (e == 0: a long code)
+                    img[op++] = (uint8_t)(e >> 4);
+                    br.drop(e & 15u);
+                }
+                d.out_pos = op;
+                if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
+            }
+            const int sym = decode_sym(br, s_lit, kLitBits, s_lcnt, s_lsym);
+            if (sym < 0) { d.status = ST_BAD_CODE; break; }
+            if (sym < 256) {
+                if (d.out_pos >= out_len) { d.status = ST_OVERRUN_OUT; break; }
+                img[d.out_pos++] = (uint8_t)sym;
+            } else if (sym == 256) {
+                d.phase = d.last ? 3u : 0u;
+            } else {
+                if (sym > 285) { d.status = ST_BAD_CODE; break; }
+                const uint32_t len = c_len_base[sym - 257] + br.take(c_len_extra[sym - 257]);
+                br.refill();
+                const int ds = decode_sym(br, s_dist, kDistBits, s_dcnt, s_dsym);
+                if (ds < 0 || ds > 29) { d.status = ST_BAD_CODE; break; }
+                const uint32_t dist = c_dist_base[ds] + br.take(c_dist_extra[ds]);
+                if (dist > d.out_pos) { d.status = ST_BAD_CODE; break; }
+                if (d.out_pos + len > out_len) { d.status = ST_OVERRUN_OUT; break; }
+                uint8_t *o = img + d.out_pos;
+                const uint8_t *f = o - dist;
+                if (dist >= 8) {   // eight bytes at a time: the loads of a piece are issued together, none depends on the piece's stores
+                    for (uint32_t i = 0; i < len; i += 8) {
+                        uint8_t t[8];
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; ++j) t[j] = f[i + j];          // (may read up to 7 bytes past the match: inside the image)
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; ++j) if (i + j < len) o[i + j] = t[j];
+                    }
+                } else {           // a short period (runs, dinucleotide repeats, quality plateaus): the pattern rotates in a register
+                    uint64_t pat = 0;
+                    for (uint32_t j = 0; j < dist; ++j) pat |= (uint64_t)f[j] << (8 * j);
+                    const uint32_t top = 8 * (dist - 1);
+                    for (uint32_t i = 0; i < len; ++i) {
+                        const uint32_t b = (uint32_t)pat & 0xFFu;
+                        o[i] = (uint8_t)b;
+                        pat = (pat >> 8) | ((uint64_t)b << top);
+                    }
+                }
+                d.out_pos += len;
+            }
+        } else {   // stored bytes
+            uint32_t n = d.stored_left < 256u ? d.stored_left : 256u;
+            if (d.out_pos + n > out_len) { d.status = ST_OVERRUN_OUT; break; }
+            for (uint32_t i = 0; i < n; ++i) { br.refill(); img[d.out_pos++] = (uint8_t)br.take(8); }
+            d.stored_left -= n;
+            if (d.stored_left == 0) d.phase = d.last ? 3u : 0u;
+        }
+    }
+    if (d.status == ST_OK && d.phase == 3 && br.consumed_bytes() > data_len) d.status = ST_OVERRUN_IN;
+}
+
+// LPW members per wave, decoded by its first LPW lanes side by side (the same instruction stream wherever their steps coincide: the
+// kernel is bound by instruction issue, so sharing it is worth more than the divergence costs); the wave-wide parts — ring refills,
+// CRC-32 — take the members one after the other.
+template <int LPW>
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const BgzfMember *members, uint32_t n_members, uint8_t *out, uint32_t *status,
                                                      CrcShift shift) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
-    uint8_t *s_ring = smem + kLdsRing;
-    uint16_t *s_lit = reinterpret_cast<uint16_t *>(smem + kLdsLit);
-    uint16_t *s_dist = reinterpret_cast<uint16_t *>(smem + kLdsDist);
-    uint16_t *s_lcnt = reinterpret_cast<uint16_t *>(smem + kLdsCnt), *s_lsym = s_lcnt + 16, *s_dcnt = s_lsym + 288, *s_dsym = s_dcnt + 16;
-    uint8_t *s_lens = smem + kLdsLens;
+    const LaneLds L(smem + (size_t)(lane < LPW ? lane : 0) * kLdsBytes);
 
-    for (uint32_t mi = blockIdx.x; mi < n_members; mi += gridDim.x) {
-        const BgzfMember mem = members[mi];
+    for (uint32_t base = blockIdx.x * LPW; base < n_members; base += gridDim.x * LPW) {
+        const uint32_t mi = base + (uint32_t)lane;
+        const bool mine = lane < LPW && mi < n_members;
+        const BgzfMember mem = mine ? members[mi] : BgzfMember{0, 0, 0, 0};
         const uint8_t *src = in + mem.in_off;
         uint8_t *img = out + mem.out_off;                 // the text is written in place: literals are stores nobody waits for, a match
                                                           // reads what this lane wrote earlier (L2-resident), and the other waves of the SIMD hide that latency
         // gzip header (RFC 1952): 1f 8b 08 FLG(4 = FEXTRA) mtime(4) xfl os | XLEN | extra ... ; trailer CRC32 ISIZE
         uint32_t st = ST_OK, data0 = 0, data_len = 0, want_crc = 0;
-        if (mem.in_len < 28 || mem.out_len > 65536u) st = ST_BAD_HEADER;
-        else {
-            if (src[0] != 0x1f || src[1] != 0x8b || src[2] != 8 || src[3] != 4) st = ST_BAD_HEADER;
-            const uint32_t xlen = src[10] | ((uint32_t)src[11] << 8);
-            data0 = 12 + xlen;
-            if (data0 + 8 > mem.in_len) st = ST_BAD_HEADER;
+        if (mine) {
+            if (mem.in_len < 28 || mem.out_len > 65536u) st = ST_BAD_HEADER;
             else {
-                data_len = mem.in_len - 8 - data0;
-                const uint8_t *t = src + mem.in_len - 8;
-                want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-                const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-                if (isize != mem.out_len) st = ST_BAD_LEN;
+                if (src[0] != 0x1f || src[1] != 0x8b || src[2] != 8 || src[3] != 4) st = ST_BAD_HEADER;
+                const uint32_t xlen = src[10] | ((uint32_t)src[11] << 8);
+                data0 = 12 + xlen;
+                if (data0 + 8 > mem.in_len) st = ST_BAD_HEADER;
+                else {
+                    data_len = mem.in_len - 8 - data0;
+                    const uint8_t *t = src + mem.in_len - 8;
+                    want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                    const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                    if (isize != mem.out_len) st = ST_BAD_LEN;
+                }
             }
         }
-        st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
-        if (st != ST_OK) { if (lane == 0) status[mi] = st; continue; }
         const uint8_t *data = src + data0;
-
-        BitReader br{reinterpret_cast<const uint32_t *>(s_ring), 1, 0, 0, 0};
+        bool running = mine && st == ST_OK;
+        BitReader br{reinterpret_cast<const uint32_t *>(L.ring), 1, 0, 0, 0};
         bool started = false;
         Decoder d{0, 0, 0, 0, ST_OK};
-        uint32_t fill = 0;   // wave-uniform: bytes of the stream in the ring
+        uint32_t fill = 0;   // bytes of this lane's stream in its ring
         __builtin_amdgcn_wave_barrier();
-        for (;;) {   // wave-uniform loop: refill the ring, then lane 0 decodes until it has used ~half of it
-            const uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane((int)br.consumed_bytes());
-            while (fill < data_len && fill + 1024 <= used + kRing) {   // 1 KiB per step: 64 lanes x 16 bytes
-                const uint32_t o = fill + 16u * (uint32_t)lane;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (o + 16 <= data_len) {
-                    const uint8_t *p = data + o;
-                    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) {
-                        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
-                        v = make_uint4(q[0], q[1], q[2], q[3]);
-                    } else {
-                        uint32_t w[4];
+        for (;;) {   // wave-uniform loop: the rings are refilled by the whole wave, member by member; then the lanes decode a run each
+            const uint32_t used_l = br.consumed_bytes();
+            const uint32_t dlo = (uint32_t)reinterpret_cast<uintptr_t>(data), dhi = (uint32_t)(reinterpret_cast<uintptr_t>(data) >> 32);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) w[k] = p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
+            for (int m = 0; m < LPW; ++m) {
+                if (!__builtin_amdgcn_readlane((int)running, m)) continue;
+                const uint32_t used = (uint32_t)__builtin_amdgcn_readlane((int)used_l, m), dl = (uint32_t)__builtin_amdgcn_readlane((int)data_len, m);
+                uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)fill, m);
+                const uint8_t *dm = reinterpret_cast<const uint8_t *>((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, m) |
+                                                                      ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, m) << 32));
+                uint8_t *ring_m = smem + (size_t)m * kLdsBytes + kLdsRing;
+                while (fl < dl && fl + 1024 <= used + kRing) {   // 1 KiB per step: 64 lanes x 16 bytes
+                    const uint32_t o = fl + 16u * (uint32_t)lane;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (o + 16 <= dl) {
+                        const uint8_t *p = dm + o;
+                        if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) {
+                            const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+                            v = make_uint4(q[0], q[1], q[2], q[3]);
+                        } else {
+                            uint32_t w[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w[k] = p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
+                            v = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    } else if (o < dl) {
+                        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (uint32_t b = 0; b < 16; ++b) if (o + b < dl) w[b >> 2] |= (uint32_t)dm[o + b] << (8u * (b & 3u));
                         v = make_uint4(w[0], w[1], w[2], w[3]);
                     }
-                } else if (o < data_len) {
-                    uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (uint32_t b = 0; b < 16; ++b) if (o + b < data_len) w[b >> 2] |= (uint32_t)data[o + b] << (8u * (b & 3u));
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                    *reinterpret_cast<uint4 *>(ring_m + (o & (kRing - 1))) = v;
+                    fl += 1024;
                 }
-                *reinterpret_cast<uint4 *>(s_ring + (o & (kRing - 1))) = v;
-                fill += 1024;
+                if (fl > dl) fl = dl;
+                if (lane == m) fill = fl;
             }
-            if (fill > data_len) fill = data_len;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane == 0) {
+            if (running) {
                 if (!started) { br.start(); started = true; }
-                const uint32_t run_end = br.consumed_bytes() + 400;   // a step starts below this mark; the longest one (a dynamic block header) takes < 600 bytes, and the ring holds >= 1024 ahead (or the stream's end)
-                while (d.phase != 3 && d.status == ST_OK && br.consumed_bytes() < run_end) {
-                    br.refill();
-                    if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
-                    if (d.phase == 0) {   // block header
-                        d.last = br.take(1);
-                        const uint32_t type = br.take(2);
-                        if (type == 0) {   // stored: skip to the byte boundary, LEN NLEN
-                            br.drop(br.cnt & 7u);
-                            br.refill();
-                            const uint32_t len = br.take(16), nlen = br.take(16);
-                            if ((len ^ 0xFFFFu) != nlen) { d.status = ST_BAD_BLOCK; break; }
-                            d.stored_left = len;
-                            d.phase = 2;
-                        } else if (type == 1) {   // fixed Huffman codes (RFC 1951 3.2.6)
-                            for (uint32_t s = 0; s < 144; ++s) s_lens[s] = 8;
-                            for (uint32_t s = 144; s < 256; ++s) s_lens[s] = 9;
-                            for (uint32_t s = 256; s < 280; ++s) s_lens[s] = 7;
-                            for (uint32_t s = 280; s < 288; ++s) s_lens[s] = 8;
-                            build_tables(s_lens, 288, s_lit, kLitBits, s_lcnt, s_lsym);
-                            for (uint32_t s = 0; s < 30; ++s) s_lens[s] = 5;
-                            build_tables(s_lens, 30, s_dist, kDistBits, s_dcnt, s_dsym);
-                            d.phase = 1;
-                        } else if (type == 2) {   // dynamic: HLIT HDIST HCLEN, the code-length code, then the two trees' lengths
-                            const uint32_t hlit = br.take(5) + 257, hdist = br.take(5) + 1, hclen = br.take(4) + 4;
-                            if (hlit > 286 || hdist > 30) { d.status = ST_BAD_BLOCK; break; }
-                            for (uint32_t i = 0; i < 19; ++i) s_lens[i] = 0;
-                            for (uint32_t i = 0; i < hclen; ++i) { br.refill(); s_lens[c_clen_order[i]] = (uint8_t)br.take(3); }
-                            // the code-length code decodes through the dist table's storage (7-bit direct table)
-                            if (!build_tables(s_lens, 19, s_dist, 7, s_dcnt, s_dsym)) { d.status = ST_BAD_BLOCK; break; }
-                            uint32_t i = 0;
-                            bool bad = false;
-                            while (i < hlit + hdist) {
-                                br.refill();
-                                const int sym = decode_sym(br, s_dist, 7, s_dcnt, s_dsym);
-                                if (sym < 0) { bad = true; break; }
-                                if (sym < 16) { s_lens[i++] = (uint8_t)sym; continue; }
-                                uint32_t rep, val = 0;
-                                if (sym == 16) { if (i == 0) { bad = true; break; } val = s_lens[i - 1]; rep = 3 + br.take(2); }
-                                else if (sym == 17) rep = 3 + br.take(3);
-                                else rep = 11 + br.take(7);
-                                if (i + rep > hlit + hdist) { bad = true; break; }
-                                while (rep--) s_lens[i++] = (uint8_t)val;
-                            }
-                            if (bad || s_lens[256] == 0) { d.status = ST_BAD_BLOCK; break; }
-                            // distance lengths sit behind the literal/length ones: build that tree first (its storage was the scratch above)
-                            uint8_t dl[30];
-                            for (uint32_t s = 0; s < hdist; ++s) dl[s] = s_lens[hlit + s];
-                            if (!build_tables(s_lens, hlit, s_lit, kLitBits, s_lcnt, s_lsym)) { d.status = ST_BAD_BLOCK; break; }
-                            for (uint32_t s = 0; s < hdist; ++s) s_lens[s] = dl[s];
-                            if (!build_tables(s_lens, hdist, s_dist, kDistBits, s_dcnt, s_dsym)) { d.status = ST_BAD_BLOCK; break; }
-                            d.phase = 1;
-                        } else { d.status = ST_BAD_BLOCK; break; }
-                    } else if (d.phase == 1) {   // literal / length-distance symbols
-                        // literals with a short code, one after the other: table word, store, drop — the bounds are a word count
-                        // (the run's budget) and the output's end; anything else falls through to the general step below
-                        {
-                            const uint32_t w_end = (run_end + 3) / 4 + 1;
-                            uint32_t op = d.out_pos;
-                            for (;;) {
-                                br.refill();
-                                const uint32_t e = s_lit[br.peek(kLitBits)];
-                                if (e - 1u >= (256u << 4) - 1u || op >= mem.out_len || br.wpos >= w_end) break;   // not a short-coded literal (e == 0: a long code)
-                                img[op++] = (uint8_t)(e >> 4);
-                                br.drop(e & 15u);
-                            }
-                            d.out_pos = op;
-                            if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
-                        }
-                        const int sym = decode_sym(br, s_lit, kLitBits, s_lcnt, s_lsym);
-                        if (sym < 0) { d.status = ST_BAD_CODE; break; }
-                        if (sym < 256) {
-                            if (d.out_pos >= mem.out_len) { d.status = ST_OVERRUN_OUT; break; }
-                            img[d.out_pos++] = (uint8_t)sym;
-                        } else if (sym == 256) {
-                            d.phase = d.last ? 3u : 0u;
-                        } else {
-                            if (sym > 285) { d.status = ST_BAD_CODE; break; }
-                            const uint32_t len = c_len_base[sym - 257] + br.take(c_len_extra[sym - 257]);
-                            br.refill();
-                            const int ds = decode_sym(br, s_dist, kDistBits, s_dcnt, s_dsym);
-                            if (ds < 0 || ds > 29) { d.status = ST_BAD_CODE; break; }
-                            const uint32_t dist = c_dist_base[ds] + br.take(c_dist_extra[ds]);
-                            if (dist > d.out_pos) { d.status = ST_BAD_CODE; break; }
-                            if (d.out_pos + len > mem.out_len) { d.status = ST_OVERRUN_OUT; break; }
-                            uint8_t *o = img + d.out_pos;
-                            const uint8_t *f = o - dist;
-                            if (dist >= 8) {   // eight bytes at a time: the loads of a piece are issued together, none depends on the piece's stores
-                                for (uint32_t i = 0; i < len; i += 8) {
-                                    uint8_t t[8];
-#pragma unroll
-                                    for (uint32_t j = 0; j < 8; ++j) t[j] = f[i + j];          // (may read up to 7 bytes past the match: inside the image)
-#pragma unroll
-                                    for (uint32_t j = 0; j < 8; ++j) if (i + j < len) o[i + j] = t[j];
-                                }
-                            } else {           // a short period (runs, dinucleotide repeats, quality plateaus): the pattern rotates in a register
-                                uint64_t pat = 0;
-                                for (uint32_t j = 0; j < dist; ++j) pat |= (uint64_t)f[j] << (8 * j);
-                                const uint32_t top = 8 * (dist - 1);
-                                for (uint32_t i = 0; i < len; ++i) {
-                                    const uint32_t b = (uint32_t)pat & 0xFFu;
-                                    o[i] = (uint8_t)b;
-                                    pat = (pat >> 8) | ((uint64_t)b << top);
-                                }
-                            }
-                            d.out_pos += len;
-                        }
-                    } else {   // stored bytes
-                        uint32_t n = d.stored_left < 256u ? d.stored_left : 256u;
-                        if (d.out_pos + n > mem.out_len) { d.status = ST_OVERRUN_OUT; break; }
-                        for (uint32_t i = 0; i < n; ++i) { br.refill(); img[d.out_pos++] = (uint8_t)br.take(8); }
-                        d.stored_left -= n;
-                        if (d.stored_left == 0) d.phase = d.last ? 3u : 0u;
-                    }
-                }
-                if (d.status == ST_OK && d.phase == 3 && br.consumed_bytes() > data_len) d.status = ST_OVERRUN_IN;
+                decode_run(br, d, L, img, mem.out_len, data_len);
+                if (d.phase == 3 || d.status != ST_OK) running = false;
             }
-            const uint32_t phase = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.phase);
-            st = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.status);
-            if (phase == 3 || st != ST_OK) break;
+            if (!__any(running)) break;
         }
-        const uint32_t produced = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.out_pos);
-        if (st == ST_OK && produced != mem.out_len) st = ST_BAD_LEN;
+        if (mine && st == ST_OK) st = d.status;
+        if (mine && st == ST_OK && d.out_pos != mem.out_len) st = ST_BAD_LEN;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (st == ST_OK) {
-            // CRC-32 (RFC 1952 8): slices aligned to the END of the text, so that every slice but the first is exactly 1024 bytes;
-            // lane l takes slice l; the table (256 words) is built in the ring's storage
-            uint32_t *tab = reinterpret_cast<uint32_t *>(s_ring);
-            for (uint32_t i = lane; i < 256; i += 64) {
-                uint32_t c = i;
-                for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-                tab[i] = c;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t len = mem.out_len;
+        // CRC-32 (RFC 1952 8) of every member that decoded, by all 64 lanes: slices aligned to the END of the text, so that every slice
+        // but the first is exactly 1024 bytes; lane l takes slice l; the table (256 words) is built in the first ring's storage
+        uint32_t *tab = reinterpret_cast<uint32_t *>(smem + kLdsRing);
+        for (uint32_t i = lane; i < 256; i += 64) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+            tab[i] = c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t ilo = (uint32_t)reinterpret_cast<uintptr_t>(img), ihi = (uint32_t)(reinterpret_cast<uintptr_t>(img) >> 32);
+        const uint32_t ok_l = mine && st == ST_OK;
+#pragma unroll
+        for (int m = 0; m < LPW; ++m) {
+            if (!__builtin_amdgcn_readlane((int)ok_l, m)) continue;
+            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)mem.out_len, m);
+            const uint8_t *im = reinterpret_cast<const uint8_t *>((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)ilo, m) |
+                                                                  ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)ihi, m) << 32));
             const uint32_t n_slices = (len + 1023u) / 1024u;                // <= 64
             const uint32_t first_len = len - (n_slices ? (n_slices - 1u) * 1024u : 0u);
             uint32_t c = 0;
@@ -343,7 +382,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
                 const uint32_t b0 = lane == 0 ? 0u : first_len + ((uint32_t)lane - 1u) * 1024u;
                 const uint32_t b1 = lane == 0 ? first_len : b0 + 1024u;
                 c = lane == 0 ? 0xFFFFFFFFu : 0u;
-                for (uint32_t i = b0; i < b1; ++i) c = tab[(c ^ img[i]) & 0xFFu] ^ (c >> 8);
+                for (uint32_t i = b0; i < b1; ++i) c = tab[(c ^ im[i]) & 0xFFu] ^ (c >> 8);
             }
             uint32_t reg = 0xFFFFFFFFu;   // (an empty member: CRC 0)
             for (uint32_t s = 0; s < n_slices; ++s) {
@@ -355,9 +394,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
                     reg = r ^ cs;
                 }
             }
-            if ((reg ^ 0xFFFFFFFFu) != want_crc) st = ST_BAD_CRC;
+            if (lane == m && (reg ^ 0xFFFFFFFFu) != want_crc) st = ST_BAD_CRC;
         }
-        if (lane == 0) status[mi] = st;
+        if (mine) status[mi] = st;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -380,9 +419,10 @@ static CrcShift make_crc_shift() {
     return s;
 }
 
+constexpr int kInflateLanes = 2;
 hipError_t warm_inflate() {
     hipFuncAttributes a;
-    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_bgzf_inflate));
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_bgzf_inflate<kInflateLanes>));
 }
 
 }  // namespace cid
@@ -419,12 +459,20 @@ extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_byt
     rc = cid::slot_reserve(c, S_FREQ, n_members * 4, &d_st); if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d_in, members, n_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cid::k_bgzf_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cid::kLdsBytes));
-    unsigned grid = (unsigned)n_members;
-    const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // ~28 members per CU at a time; a few rounds per block
+    static const int lanes = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : cid::kInflateLanes;   // members per wave: 1, 2, 4 or 8
+    const unsigned lpw = lanes == 1 ? 1u : lanes == 4 ? 4u : lanes == 8 ? 8u : 2u;
+    unsigned grid = (unsigned)((n_members + lpw - 1) / lpw);
+    const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // a few rounds per block at most
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(cid::k_bgzf_inflate, dim3(grid), dim3(64), cid::kLdsBytes, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem,
-                       (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st, shift);
+    const size_t lds = (size_t)lpw * cid::kLdsBytes;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem, (uint32_t)n_members,
+                           (uint8_t *)d_out, (uint32_t *)d_st, shift);
+    };
+    if (lpw == 1) launch(cid::k_bgzf_inflate<1>);
+    else if (lpw == 4) launch(cid::k_bgzf_inflate<4>);
+    else if (lpw == 8) launch(cid::k_bgzf_inflate<8>);
+    else launch(cid::k_bgzf_inflate<2>);
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> st(n_members);
     HIP_TRY(hipMemcpyAsync(st.data(), d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));
