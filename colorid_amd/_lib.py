@@ -55,6 +55,8 @@ SIGNATURES = {
                                           vp, vp, vp, vp]),
     "cid_warmup": (C.c_int, [vp, C.c_uint]),
     "cid_bgzf_inflate": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "cid_bgzf_inflate_start": (C.c_int, [vp, vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t, C.c_size_t]),
+    "cid_bgzf_inflate_finish": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cid_kmerset_create": (C.c_int, [vp, C.c_uint32, C.POINTER(vp)]),
     "cid_kmerset_add_seqs": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int]),
     "cid_kmerset_finalize": (C.c_int, [vp, C.POINTER(C.c_uint64)]),

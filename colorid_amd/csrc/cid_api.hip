@@ -187,13 +187,13 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 namespace cid {
 static const bool kUsePin = getenv("CID_PIN_STAGING") ? atoi(getenv("CID_PIN_STAGING")) != 0 : true;
-uint8_t *pin_reserve(cid_ctx *c, size_t bytes) {
-    if (!kUsePin || bytes > kPinMax) return nullptr;
+uint8_t *pin_reserve(cid_ctx *c, size_t bytes, size_t cap) {
+    if (!kUsePin || bytes > cap) return nullptr;
     if (bytes <= c->pin_bytes) return c->pin;
     if (c->pin) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
     size_t want = bytes + bytes / 2;
     if (want < (16u << 20)) want = 16u << 20;
-    if (want > kPinMax) want = kPinMax;
+    if (want > cap) want = cap;
     void *p = nullptr;
     if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
     c->pin = (uint8_t *)p;

@@ -436,13 +436,16 @@ using namespace cid::slots;
         if (e_ != hipSuccess) return cid::fail(CID_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
-                                const uint32_t *text_off, const uint32_t *text_len, size_t n_members, uint8_t *text, size_t text_bytes,
-                                size_t *bad_member) {
+// start: the members go to the device (through the ctx's pinned arena when they fit, so that the caller's buffer is free again when
+// this returns), the kernel and the copies of the text and of the members' status back into the arena are queued on the ctx stream;
+// finish: waits, checks every member, copies the text out.  Two contexts taking turns keep two batches in flight.
+extern "C" int cid_bgzf_inflate_start(cid_ctx *c, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+                                      const uint32_t *text_off, const uint32_t *text_len, size_t n_members, size_t text_bytes) {
     if (!c) return fail(CID_ERR_INVALID, "null ctx");
-    if (bad_member) *bad_member = (size_t)-1;
-    if (n_members == 0) return CID_OK;
-    if (!members || !member_off || !member_len || !text_off || !text_len || (text_bytes && !text)) return fail(CID_ERR_INVALID, "null argument");
+    if (c->inflate.open) return fail(CID_ERR_STATE, "cid_bgzf_inflate_start: the previous batch has not been finished");
+    c->inflate.n_members = n_members; c->inflate.text_bytes = text_bytes; c->inflate.staged = false;
+    if (n_members == 0) { c->inflate.open = true; return CID_OK; }
+    if (!members || !member_off || !member_len || !text_off || !text_len) return fail(CID_ERR_INVALID, "null argument");
     if (n_bytes >= (1ull << 32) || text_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "a batch of BGZF members is limited to 4 GiB");
     std::vector<cid::BgzfMember> mem(n_members);
     for (size_t i = 0; i < n_members; ++i) {
@@ -457,8 +460,21 @@ extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_byt
     rc = cid::slot_reserve(c, S_MISC, n_members * sizeof(cid::BgzfMember), &d_mem); if (rc) return rc;
     rc = cid::slot_reserve(c, S_BASES, text_bytes + 16, &d_out); if (rc) return rc;
     rc = cid::slot_reserve(c, S_FREQ, n_members * 4, &d_st); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_in, members, n_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
+    // arena: members | member table | text | status
+    const size_t b_mem = (n_bytes + 63) & ~(size_t)63, b_text = b_mem + ((n_members * sizeof(cid::BgzfMember) + 63) & ~(size_t)63),
+                 b_st = b_text + ((text_bytes + 63) & ~(size_t)63), b_end = b_st + n_members * 4;
+    uint8_t *pin = cid::pin_reserve(c, b_end + 64, 512u << 20);
+    if (pin) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(pin, members, n_bytes);
+        memcpy(pin + b_mem, mem.data(), n_members * sizeof(cid::BgzfMember));
+        HIP_TRY(hipMemcpyAsync(d_in, pin, n_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_mem, pin + b_mem, n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
+    } else {   // (no arena: the caller's buffers are read before this returns)
+        HIP_TRY(hipMemcpyAsync(d_in, members, n_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     static const int lanes = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : cid::kInflateLanes;   // members per wave: 1, 2, 4 or 8
     const unsigned lpw = lanes == 1 ? 1u : lanes == 4 ? 4u : lanes == 8 ? 8u : 2u;
     unsigned grid = (unsigned)((n_members + lpw - 1) / lpw);
@@ -474,10 +490,34 @@ extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_byt
     else if (lpw == 8) launch(cid::k_bgzf_inflate<8>);
     else launch(cid::k_bgzf_inflate<2>);
     HIP_TRY(hipGetLastError());
+    c->inflate.d_out = d_out; c->inflate.d_st = d_st;
+    if (pin) {
+        HIP_TRY(hipMemcpyAsync(pin + b_st, d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));
+        if (text_bytes) HIP_TRY(hipMemcpyAsync(pin + b_text, d_out, text_bytes, hipMemcpyDeviceToHost, c->stream));
+        c->inflate.staged = true; c->inflate.pin_text = b_text; c->inflate.pin_status = b_st;
+    }
+    c->inflate.open = true;
+    return CID_OK;
+}
+
+extern "C" int cid_bgzf_inflate_finish(cid_ctx *c, uint8_t *text, size_t text_bytes, size_t *bad_member) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    if (bad_member) *bad_member = (size_t)-1;
+    if (!c->inflate.open) return fail(CID_ERR_STATE, "cid_bgzf_inflate_finish without a start");
+    c->inflate.open = false;
+    const size_t n_members = c->inflate.n_members;
+    if (n_members == 0) return CID_OK;
+    if (text_bytes != c->inflate.text_bytes || (text_bytes && !text)) return fail(CID_ERR_INVALID, "text buffer differs from the one announced at the start");
+    HIP_TRY(hipSetDevice(c->device));
     std::vector<uint32_t> st(n_members);
-    HIP_TRY(hipMemcpyAsync(st.data(), d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));
-    if (text_bytes) HIP_TRY(hipMemcpyAsync(text, d_out, text_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->inflate.staged) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memcpy(st.data(), c->pin + c->inflate.pin_status, n_members * 4);
+    } else {
+        HIP_TRY(hipMemcpyAsync(st.data(), c->inflate.d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));
+        if (text_bytes) HIP_TRY(hipMemcpyAsync(text, c->inflate.d_out, text_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     for (size_t i = 0; i < n_members; ++i)
         if (st[i] != cid::ST_OK) {
             if (bad_member) *bad_member = i;
@@ -485,5 +525,16 @@ extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_byt
                                               "more text than the member's ISIZE", "text length differs from ISIZE", "CRC-32 mismatch"};
             return fail(CID_ERR_INVALID, "corrupt gzip member %zu: %s", i, why[st[i] < 8 ? st[i] : 0]);
         }
+    if (c->inflate.staged && text_bytes) memcpy(text, c->pin + c->inflate.pin_text, text_bytes);
     return CID_OK;
+}
+
+extern "C" int cid_bgzf_inflate(cid_ctx *c, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+                                const uint32_t *text_off, const uint32_t *text_len, size_t n_members, uint8_t *text, size_t text_bytes,
+                                size_t *bad_member) {
+    if (bad_member) *bad_member = (size_t)-1;
+    if (n_members && text_bytes && !text) return fail(CID_ERR_INVALID, "null argument");
+    const int rc = cid_bgzf_inflate_start(c, members, n_bytes, member_off, member_len, text_off, text_len, n_members, text_bytes);
+    if (rc) { if (c) c->inflate.open = false; return rc; }
+    return cid_bgzf_inflate_finish(c, text, text_bytes, bad_member);
 }

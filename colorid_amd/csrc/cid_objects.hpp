@@ -28,6 +28,8 @@ struct cid_ctx {
     // pinned host arena: the host-pointer read_id calls stage their (small) arrays through it — see cid::pin_reserve
     uint8_t *pin = nullptr;
     size_t pin_bytes = 0;
+    // a cid_bgzf_inflate_start waiting for its _finish
+    struct { size_t n_members = 0, text_bytes = 0, pin_text = 0, pin_status = 0; void *d_out = nullptr, *d_st = nullptr; bool open = false, staged = false; } inflate;
     // second stream + events for the host-pointer entry points: the H2D copy of chunk i+1 runs beside the kernel of chunk i
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -50,8 +52,8 @@ int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out);
 // unpin the caller's pages — a fixed cost per array of ~0.4 ms once other threads of the process fault pages at the same time (the
 // CLI's inflating and packing threads: a read_id call of 50 000 reads took 5 ms instead of 1.1 ms).  Arrays of a few MB are cheaper
 // copied through this arena.  NULL when the request is larger than kPinMax: the caller then lets the runtime handle its memory.
-uint8_t *pin_reserve(cid_ctx *c, size_t bytes);
 constexpr size_t kPinMax = 64u << 20;
+uint8_t *pin_reserve(cid_ctx *c, size_t bytes, size_t cap = kPinMax);
 // a5 launch on device-resident inputs/outputs (zeroes the counters first); asynchronous on the ctx stream
 int search_count_launch(cid_ctx *c, const cid_index *ix, const uint8_t *d_kmers, const uint64_t *d_codes, const uint32_t *d_freq,
                         size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq, uint32_t *d_unique_colour,

@@ -5,6 +5,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <thread>
+#include <mutex>
+#include <functional>
+#include <deque>
+#include <condition_variable>
 #include <string>
 #include <vector>
 
@@ -49,6 +54,61 @@ void kmers_fq_pe_qual(const std::string &p1, const std::string &p2, uint8_t q, K
 // host pipeline sizes its pools from it (a third for inflating block-gzip members, a fifth for packing records): more runnable threads than the quota get the whole process throttled for the rest of the scheduling period, which on a
 // 16-CPU share of a GPU box cost more than the extra threads brought (tools/exp_readid_stages.sh).
 int cpu_budget();
+
+// A few persistent worker threads.  The pipeline used to start threads per batch (inflating a batch's members, packing a chunk's
+// records, polling a batch's slices): a thread's start and end map and unmap its stack, and in a process whose other threads fault
+// pages all the time those calls queue on the address-space lock — two poll threads per batch were twice as SLOW as one.
+class TaskPool {
+  public:
+    explicit TaskPool(int n_threads) {
+        for (int i = 0; i < n_threads; ++i) threads_.emplace_back([this] { run(); });
+    }
+    ~TaskPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    TaskPool(const TaskPool &) = delete;
+    TaskPool &operator=(const TaskPool &) = delete;
+    void submit(std::function<void()> fn) {
+        { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(fn)); }
+        cv_.notify_one();
+    }
+    // fn(0) .. fn(n-1), the caller taking part; returns when all are done
+    void parallel_for(size_t n, const std::function<void(size_t)> &fn) {
+        if (n == 0) return;
+        struct Latch { std::mutex m; std::condition_variable c; size_t left; } latch;
+        latch.left = n - 1;
+        for (size_t i = 1; i < n; ++i)
+            submit([&fn, &latch, i] {
+                fn(i);
+                std::lock_guard<std::mutex> lk(latch.m);
+                if (--latch.left == 0) latch.c.notify_one();
+            });
+        fn(0);
+        std::unique_lock<std::mutex> lk(latch.m);
+        latch.c.wait(lk, [&] { return latch.left == 0; });
+    }
+  private:
+    void run() {
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                fn = std::move(q_.front());
+                q_.pop_front();
+            }
+            fn();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    std::vector<std::thread> threads_;
+    bool stop_ = false;
+};
 
 // gz/plain line reader with BufRead::lines() semantics (strips \n and \r\n)
 class LineReader {   // inflates on its own thread, a few MiB ahead of the caller (two mates of a pair decode in parallel)

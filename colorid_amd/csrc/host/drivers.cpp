@@ -339,6 +339,7 @@ void stream_fastq_records(const std::string &f1, const std::string *f2, uint8_t 
         RecordChunker *kp = &k;
         return std::shared_ptr<RecChunk>(new RecChunk, [kp](RecChunk *c) { kp->recycle(*c); delete c; });
     };
+    TaskPool pool(g_parse_threads);   // the packers
     std::deque<std::future<ReadBatch>> inflight;
     auto drain_one = [&] { ReadBatch piece = inflight.front().get(); inflight.pop_front(); sink(std::move(piece)); };
     std::shared_ptr<RecChunk> c1, c2;
@@ -352,7 +353,9 @@ void stream_fastq_records(const std::string &f1, const std::string *f2, uint8_t 
         }
         while (inflight.size() >= (size_t)g_parse_threads) drain_one();
         std::shared_ptr<ReadBatch> buf(new ReadBatch(spare()));   // a batch whose buffers an earlier round already grew (or an empty one)
-        inflight.push_back(std::async(std::launch::async, [buf, c1, p1, c2, p2, n, q, want_ids] { return pack_records(std::move(*buf), c1.get(), p1, c2.get(), p2, n, q, want_ids); }));
+        auto task = std::make_shared<std::packaged_task<ReadBatch()>>([buf, c1, p1, c2, p2, n, q, want_ids] { return pack_records(std::move(*buf), c1.get(), p1, c2.get(), p2, n, q, want_ids); });
+        inflight.push_back(task->get_future());
+        pool.submit([task] { (*task)(); });
         p1 += n; p2 += n;
     }
     while (!inflight.empty()) drain_one();
@@ -674,9 +677,8 @@ void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t star
 
 // ... and the poll (kmer_poll_plus per read, read_id_mt_pe.rs:168-251) + the rows of <prefix>_reads.txt on the host: the reads of a
 // batch are independent, so COLORID_POLL_THREADS (default 8) threads format contiguous slices of it and the slices are written in order
-// (default 1: the poll of a million reads is 50 ms on one thread, and slicing a batch over several did not shorten it on the GPU box —
-// 207 ms per 4 M reads on one thread, 213-224 ms on four — while the CPUs are worth more to the inflating and packing threads)
-static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+// (default 2: the poll of a million reads is 50 ms on one thread, 30 ms on two — enough to stay ahead of the GPU stage)
+static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : std::min(2, std::max(1, cpu_budget() / 8)); return v < 1 ? 1 : v; }();
 static inline void append_u64(std::string &o, uint64_t v) {
     char t[24];
     int n = 0;
@@ -689,7 +691,7 @@ void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::
     const auto t_poll = Clock::now();
     const size_t nt = std::min<size_t>((size_t)g_poll_threads, (n + 4095) / 4096);
     // (the slices' text buffers and tallies live across batches: a fresh 2 MB string per slice and batch is 600 page faults, and page
-    // faults of several threads at once serialise in the kernel — four poll threads were SLOWER than one until these were kept)
+    // faults of several threads at once serialise in the kernel)
     static thread_local std::vector<std::string> text_tl;
     static thread_local std::vector<std::vector<uint64_t>> acc_tl;
     std::vector<std::string> &text = text_tl;              // (references: the slices' threads must see THIS thread's vectors, and a
@@ -700,7 +702,10 @@ void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::
     for (size_t t = 0; t < nt; ++t) { text[t].clear(); acc[t].assign(C + 3, 0); }   // [C] no_hits, [C+1] too_short, [C+2] reject
     if (memchr(c.rb.id_chars.data(), '\t', c.rb.id_chars.size())) tally_ok = false;
     auto work = [&](size_t t) {
-        std::string &o = text[t];
+        // (the slice's string is moved onto this thread's stack while it grows: the headers of text[0], text[1], ... share cache lines,
+        // and every append writes its string's size — two slices polled side by side took twice as long as one after the other)
+        std::string o;
+        o.swap(text[t]);
         const size_t r0 = n * t / nt, r1 = n * (t + 1) / nt;
         o.reserve((r1 - r0) * 48 + (c.rb.id_off[r1 - 1] - c.rb.id_off[r0]) + 64);
         std::vector<uint8_t> sig(64);
@@ -726,11 +731,12 @@ void poll_batch(const Bigsi &b, const Counted &c, double fp_correct, const std::
             append_u64(o, p.n_top);
             o += '\n';
         }
+        o.swap(text[t]);
     };
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t);
-    if (nt) work(0);
-    for (auto &x : th) x.join();
+    static thread_local std::unique_ptr<TaskPool> pool;   // the polling thread's helpers
+    if (nt > 1 && !pool) pool.reset(new TaskPool(g_poll_threads - 1));
+    if (nt > 1) pool->parallel_for(nt, work);
+    else if (nt) work(0);
     const auto t_write = Clock::now();
     for (size_t t = 0; t < nt; ++t) fwrite(text[t].data(), 1, text[t].size(), out);
     g_ms_write += ms_since(t_write);

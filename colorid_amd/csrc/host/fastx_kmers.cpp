@@ -11,6 +11,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -315,15 +316,26 @@ struct LineReader::Impl {
     // BGZF: batches of members worth ~16 MiB of text, inflated by gz_threads threads — or, with a GPU set (inflate_on_gpu), batches of
     // ~64 MiB (a thousand members: two rounds of the 512 the chip decodes at a time) by cid_bgzf_inflate on a context of this thread
     struct Member { size_t in_off, in_len, out_off, out_len; };
+    std::unique_ptr<TaskPool> pool;   // the inflating threads of a BGZF reader (created by its worker thread, which is one of them)
     int gpu_device = -1;
-    cid_ctx *gpu_ctx = nullptr;
+    cid_ctx *gpu_ctx = nullptr, *gpu_ctx2 = nullptr;   // two contexts take turns: a batch is decoded and copied back while the next one is read and submitted
+    struct Pending { std::vector<char> blk; size_t out_total; bool last; cid_ctx *ctx; };
+    void finish_pending(Pending &p) {
+        size_t bad = 0;
+        if (cid_bgzf_inflate_finish(p.ctx, reinterpret_cast<uint8_t *>(p.blk.data() + kHead), p.out_total, &bad) != CID_OK)
+            die("corrupt gzip member (inflate / CRC-32 failed): %s", cid_last_error());
+        push(std::move(p.blk), p.last);
+    }
     void run_bgzf() {
-        if (gpu_device >= 0 && cid_ctx_create(gpu_device, &gpu_ctx) != CID_OK) {
+        if (gpu_device >= 0 && (cid_ctx_create(gpu_device, &gpu_ctx) != CID_OK || cid_ctx_create(gpu_device, &gpu_ctx2) != CID_OK)) {
             fprintf(stderr, "note: no GPU context for the gzip members (%s): inflating on the host\n", cid_last_error());
-            gpu_ctx = nullptr;
+            if (gpu_ctx) cid_ctx_destroy(gpu_ctx);
+            gpu_ctx = gpu_ctx2 = nullptr;
         }
         if (gpu_ctx) (void)cid_warmup(gpu_ctx, CID_WARM_INFLATE);
-        const size_t kBatchOut = gpu_ctx ? ((size_t)(getenv("COLORID_GPU_INFLATE_MB") ? atoi(getenv("COLORID_GPU_INFLATE_MB")) : 128) << 20) : (16u << 20);
+        const size_t kBatchOut = gpu_ctx ? ((size_t)(getenv("COLORID_GPU_INFLATE_MB") ? atoi(getenv("COLORID_GPU_INFLATE_MB")) : 64) << 20) : (16u << 20);
+        std::deque<Pending> pending;
+        size_t turn = 0;
         std::vector<unsigned char> in;        // compressed bytes of the batch (plus the unread tail of the last fread)
         size_t in_have = 0, in_pos = 0;
         bool file_end = false;
@@ -360,16 +372,19 @@ struct LineReader::Impl {
             }
             in_pos = scan;
             blk.resize(kHead + out_total);
-            if (!mem.empty() && gpu_ctx) {
+            if (gpu_ctx) {   // submit this batch, then hand over the one submitted before it (its kernel ran meanwhile)
                 std::vector<uint32_t> mo(mem.size()), ml(mem.size()), to(mem.size()), tl(mem.size());
                 for (size_t i = 0; i < mem.size(); ++i) { mo[i] = (uint32_t)mem[i].in_off; ml[i] = (uint32_t)mem[i].in_len; to[i] = (uint32_t)mem[i].out_off; tl[i] = (uint32_t)mem[i].out_len; }
-                size_t bad = 0;
-                if (cid_bgzf_inflate(gpu_ctx, in.data(), in_pos, mo.data(), ml.data(), to.data(), tl.data(), mem.size(),
-                                     reinterpret_cast<uint8_t *>(blk.data() + kHead), out_total, &bad) != CID_OK)
+                cid_ctx *cx = (turn++ & 1) ? gpu_ctx2 : gpu_ctx;
+                if (cid_bgzf_inflate_start(cx, in.data(), in_pos, mo.data(), ml.data(), to.data(), tl.data(), mem.size(), out_total) != CID_OK)
                     die("corrupt gzip member (inflate / CRC-32 failed): %s", cid_last_error());
+                pending.push_back(Pending{std::move(blk), out_total, last, cx});
+                while (pending.size() > (last ? 0u : 1u)) { finish_pending(pending.front()); pending.pop_front(); }
+                if (last) break;
+                continue;
             } else if (!mem.empty()) {
                 const int nt = (int)std::min<size_t>((size_t)gz_threads, mem.size());
-                std::vector<std::thread> th;
+                if (!pool && gz_threads > 1) pool.reset(new TaskPool(gz_threads - 1));   // (this thread takes a share too)
                 std::vector<int> bad(nt, 0);
                 auto work = [&](int t) {
                     const LibDeflate &ld = libdeflate();
@@ -397,15 +412,17 @@ struct LineReader::Impl {
                     }
                     inflateEnd(&zs);
                 };
-                for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-                work(0);
-                for (auto &x : th) x.join();
+                if (pool) pool->parallel_for((size_t)nt, [&](size_t t) { work((int)t); });
+                else work(0);
                 for (int t = 0; t < nt; ++t) if (bad[t]) die("corrupt gzip member (inflate / CRC-32 failed)");
             }
             push(std::move(blk), last);
             if (last) break;
         }
+        // (asked to stop with a batch in flight: its context is finished before it is destroyed)
+        for (Pending &p : pending) { size_t bad = 0; (void)cid_bgzf_inflate_finish(p.ctx, reinterpret_cast<uint8_t *>(p.blk.data() + kHead), p.out_total, &bad); }
         if (gpu_ctx) { cid_ctx_destroy(gpu_ctx); gpu_ctx = nullptr; }
+        if (gpu_ctx2) { cid_ctx_destroy(gpu_ctx2); gpu_ctx2 = nullptr; }
     }
     bool refill() {   // false at end of input
         std::unique_lock<std::mutex> lk(mu);

@@ -366,6 +366,11 @@ int cid_tune(const char *name, long value);
 int cid_bgzf_inflate(cid_ctx *, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
                      const uint32_t *text_off, const uint32_t *text_len, size_t n_members, uint8_t *text, size_t text_bytes,
                      size_t *bad_member);
+/* The same call in two halves, for a reader that keeps two batches in flight on two contexts: _start queues the upload, the kernel
+ * and the copies back (the caller's `members` buffer is free again when it returns); _finish waits, checks and hands out the text. */
+int cid_bgzf_inflate_start(cid_ctx *, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+                           const uint32_t *text_off, const uint32_t *text_len, size_t n_members, size_t text_bytes);
+int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t *bad_member);
 #define CID_WARM_READID 1u
 #define CID_WARM_SEARCH 2u
 #define CID_WARM_INFLATE 4u
