@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -70,7 +73,62 @@ class StdoutToStderr {
 
 }  // namespace cidg
 
+namespace cidg {
+// One persistent host thread per rank (beyond rank 0, which runs on the caller's thread): a group call used to start and join N
+// threads, and a thread's start and end map and unmap its stack — calls that queue on the address-space lock of a process whose
+// other threads fault pages (the CLI's readers and packers); per batch of a read_id run that cost more than the call's own work.
+class RankThreads {
+  public:
+    ~RankThreads() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_go_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    // body(r) for r = 0 .. n-1; rank 0 on the calling thread
+    void run(int n, const std::function<void(int)> &body) {
+        if (n <= 1) { if (n == 1) body(0); return; }
+        std::unique_lock<std::mutex> lk(mu_);
+        while ((int)threads_.size() < n - 1) {
+            const int r = (int)threads_.size() + 1;
+            threads_.emplace_back([this, r] { loop(r); });
+            seen_.push_back(gen_);
+        }
+        body_ = &body; n_ = n; left_ = n - 1; ++gen_;
+        lk.unlock();
+        cv_go_.notify_all();
+        body(0);
+        lk.lock();
+        cv_done_.wait(lk, [&] { return left_ == 0; });
+        body_ = nullptr;
+    }
+  private:
+    void loop(int r) {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_go_.wait(lk, [&] { return stop_ || seen_[(size_t)r - 1] != gen_; });
+            if (stop_) return;
+            seen_[(size_t)r - 1] = gen_;
+            if (r >= n_ || !body_) continue;   // (a call over fewer ranks than there are threads)
+            const std::function<void(int)> *b = body_;
+            lk.unlock();
+            (*b)(r);
+            lk.lock();
+            if (--left_ == 0) cv_done_.notify_one();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_go_, cv_done_;
+    std::vector<std::thread> threads_;
+    std::vector<uint64_t> seen_;
+    const std::function<void(int)> *body_ = nullptr;
+    uint64_t gen_ = 0;
+    int n_ = 0, left_ = 0;
+    bool stop_ = false;
+};
+}  // namespace cidg
+
 struct cid_group {
+    cidg::RankThreads rank_threads;
     std::vector<cid_ctx *> ctx;
     std::vector<int> dev;
     bool use_rccl = false;
@@ -113,12 +171,7 @@ int for_each_rank(cid_group *g, F &&fn) {
         rc[r] = fn(r);
         if (rc[r] != CID_OK) msg[r] = cid_last_error();
     };
-    if (n == 1) body(0);
-    else {
-        std::vector<std::thread> th;
-        for (int r = 0; r < n; ++r) th.emplace_back(body, r);
-        for (auto &t : th) t.join();
-    }
+    g->rank_threads.run(n, body);
     for (int r = 0; r < n; ++r)
         if (rc[r] != CID_OK) return fail(rc[r], "rank %d (device %d): %s", r, g->dev[r], msg[r].c_str());
     return CID_OK;
