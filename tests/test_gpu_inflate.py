@@ -126,6 +126,59 @@ def test_inflate_reports_corrupt_members(hip_ctx):
     assert rc == 0 and out == b"".join(texts)
 
 
+def test_inflate_in_two_halves_on_two_contexts(hip_ctx):
+    """cid_bgzf_inflate_start / _finish: two batches in flight on two contexts (what the CLI's reader does), the caller's member buffer
+    overwritten right after _start; misuse (finish without start, a second start, a text buffer of another size) is refused."""
+    import colorid_amd
+    lib = hip_ctx.lib
+    other = colorid_amd.Context(0)
+    rng = np.random.default_rng(21)
+    fq = fastq_text(rng, 8000)
+    batches = []
+    for b in range(4):
+        texts = [fq[i:i + 60000] for i in range(b * 1000, len(fq) - 60000, 240000)]
+        members = [bgzf_member(t, 1 + b) for t in texts]
+        batches.append((texts, members))
+    ctxs = [hip_ctx, other]
+    pend = []
+    outs = []
+
+    def finish(item):
+        cx, texts, total = item
+        out = np.zeros(total + 1, np.uint8)
+        bad = C.c_size_t(0)
+        assert lib.cid_bgzf_inflate_finish(cx.h, out.ctypes.data, total, C.byref(bad)) == 0, lib.cid_last_error()
+        outs.append((out[:total].tobytes(), b"".join(texts)))
+
+    for i, (texts, members) in enumerate(batches):
+        blob = np.frombuffer(b"".join(members) + b"\0", np.uint8).copy()
+        off = np.cumsum([0] + [len(m) for m in members[:-1]]).astype(np.uint32)
+        ln = np.array([len(m) for m in members], np.uint32)
+        tl = np.array([len(t) for t in texts], np.uint32)
+        to = np.cumsum(np.concatenate([[0], tl[:-1]])).astype(np.uint32)
+        cx = ctxs[i & 1]
+        assert lib.cid_bgzf_inflate_start(cx.h, blob.ctypes.data, len(blob) - 1, off.ctypes.data, ln.ctypes.data, to.ctypes.data, tl.ctypes.data, len(members), int(tl.sum())) == 0
+        blob[:] = 0xAA                                            # the members were taken before _start returned
+        if i == 0:
+            assert lib.cid_bgzf_inflate_start(cx.h, blob.ctypes.data, len(blob) - 1, off.ctypes.data, ln.ctypes.data, to.ctypes.data, tl.ctypes.data, len(members), int(tl.sum())) == -5   # CID_ERR_STATE
+        pend.append((cx, texts, int(tl.sum())))
+        if len(pend) == 2:
+            finish(pend.pop(0))
+    while pend:
+        finish(pend.pop(0))
+    assert len(outs) == 4 and all(a == b for a, b in outs)
+    bad = C.c_size_t(0)
+    z = np.zeros(8, np.uint8)
+    assert lib.cid_bgzf_inflate_finish(other.h, z.ctypes.data, 8, C.byref(bad)) == -5          # no start (CID_ERR_STATE)
+    texts, members = batches[0]
+    blob = np.frombuffer(b"".join(members) + b"\0", np.uint8)
+    off = np.cumsum([0] + [len(m) for m in members[:-1]]).astype(np.uint32); ln = np.array([len(m) for m in members], np.uint32)
+    tl = np.array([len(t) for t in texts], np.uint32); to = np.cumsum(np.concatenate([[0], tl[:-1]])).astype(np.uint32)
+    assert lib.cid_bgzf_inflate_start(other.h, blob.ctypes.data, len(blob) - 1, off.ctypes.data, ln.ctypes.data, to.ctypes.data, tl.ctypes.data, len(members), int(tl.sum())) == 0
+    assert lib.cid_bgzf_inflate_finish(other.h, z.ctypes.data, 8, C.byref(bad)) == -1          # another text size than announced
+    other.close()
+
+
 def test_line_reader_with_gpu_inflate_reads_the_same_lines(tmp_path):
     """The CLI's reader with COLORID_GPU_INFLATE=1 (BGZF members decoded by cid_bgzf_inflate on a context of the reader thread) yields
     the lines of the plain file — members of 65280 and of 777 bytes, with and without the end-of-file marker — and dies on a corrupt member."""
