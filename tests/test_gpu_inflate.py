@@ -209,3 +209,58 @@ def test_line_reader_with_gpu_inflate_reads_the_same_lines(tmp_path):
     bad.write_bytes(bytes(raw))
     r = subprocess.run([exe, str(bad)], capture_output=True, text=True, env=dict(os.environ, COLORID_GPU_INFLATE="1"))
     assert r.returncode == 101 and "corrupt gzip member" in r.stderr
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("INFLATE_FUZZ_SEED0", 0)), int(__import__("os").environ.get("INFLATE_FUZZ_SEED0", 0)) + int(__import__("os").environ.get("INFLATE_FUZZ_N", 6))))
+def test_inflate_fuzz_valid_and_garbage_members(hip_ctx, seed):
+    """Random texts (alphabets of 1 … 256 symbols, runs, repeats, FASTQ) at random sizes, levels and strategies decode to themselves; members
+    with random bytes for their DEFLATE data, or valid ones with a few bytes overwritten, are either reported or — when the damage
+    happens to decode and the CRC-32 still matches, which it practically never does — returned as zlib would return them.  The
+    kernel always comes back: every step of its decoder consumes input or fails."""
+    lib = hip_ctx.lib
+    rng = np.random.default_rng(7000 + seed)
+    texts, members = [], []
+    for _ in range(48):
+        kind = int(rng.integers(0, 5))
+        n = int(rng.integers(0, 65537))
+        if kind == 0:
+            t = bytes(rng.integers(0, int(rng.integers(1, 257)), n).astype(np.uint8))
+        elif kind == 1:
+            t = (bytes(rng.integers(65, 91, int(rng.integers(1, 40))).astype(np.uint8)) * 70000)[:n]
+        elif kind == 2:
+            t = fastq_text(rng, 450)[:n]
+        elif kind == 3:
+            a = np.repeat(rng.integers(0, 256, n // 7 + 1).astype(np.uint8), rng.integers(1, 30, n // 7 + 1))[:n]
+            t = bytes(a)
+        else:
+            t = bytes(rng.choice(np.frombuffer(b"ACGTN\n", np.uint8), n, p=[0.24, 0.24, 0.24, 0.24, 0.03, 0.01]))
+        strat = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 5))]
+        texts.append(t); members.append(bgzf_member(t, int(rng.integers(0, 10)), strat))
+    rc, out, bad, to = inflate(lib, hip_ctx, members, [len(t) for t in texts])
+    assert rc == 0, lib.cid_last_error()
+    assert out == b"".join(texts)
+    # damaged members: the call reports the first one zlib would also refuse
+    dam = list(members)
+    first_bad = None
+    for i in range(0, len(dam), 5):
+        m = bytearray(dam[i])
+        body0, body1 = 18, len(m) - 8
+        if body1 - body0 < 4:
+            continue
+        if i % 10 == 0:
+            m[body0:body1] = bytes(rng.integers(0, 256, body1 - body0).astype(np.uint8))      # garbage instead of DEFLATE data
+        else:
+            for p in rng.integers(body0, body1, 3):
+                m[int(p)] ^= int(rng.integers(1, 256))
+        dam[i] = bytes(m)
+        try:
+            ok = zlib.decompress(dam[i], 31) == texts[i]
+        except zlib.error:
+            ok = False
+        if not ok and first_bad is None:
+            first_bad = i
+    rc, out, bad, to = inflate(lib, hip_ctx, dam, [len(t) for t in texts])
+    if first_bad is None:
+        assert rc == 0
+    else:
+        assert rc == -1 and bad == first_bad, (rc, bad, first_bad, lib.cid_last_error())
