@@ -410,7 +410,15 @@ int cid_group_stripes_readid_count_sparse(cid_group *g, cid_index *const *stripe
         int e = cid::slot_reserve(c, S_BASES, total_bases + 16, &d_b); if (e) return e;
         e = cid::slot_reserve(c, S_NK, n_reads * 4 + n_reads + 16, &d_nk); if (e) return e;
         e = cid::slot_reserve(c, S_UC, zn * 4, &d_zz); if (e) return e;
-        if (total_bases) HIP_TRY(hipMemcpyAsync(d_b, bases, total_bases, hipMemcpyHostToDevice, c->stream));
+        if (total_bases) {   // through the rank's pinned arena when the batch fits (cid::pin_reserve)
+            const uint8_t *src = bases;
+            if (uint8_t *pin = cid::pin_reserve(c, total_bases)) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                memcpy(pin, bases, total_bases);
+                src = pin;
+            }
+            HIP_TRY(hipMemcpyAsync(d_b, src, total_bases, hipMemcpyHostToDevice, c->stream));
+        }
         HIP_TRY(hipMemsetAsync(d_zz, 0xFF, zn * 4, c->stream));
         dv[r] = Dev{(const uint8_t *)d_b, (uint32_t *)d_nk, (uint8_t *)d_nk + n_reads * 4};
         d_z[r] = (uint32_t *)d_zz;
