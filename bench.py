@@ -186,14 +186,24 @@ def fill_background_fast(dev, mat_ptr, m, rs, n_colours, p, seed, digits=8):
 
 
 def box_clocks():
-    """sclk / mclk of GPU 0 as rocm-smi reports them right now (the pool's boxes differ by a few per cent on the same binary)."""
-    import subprocess
+    """Current sclk / mclk / fclk of the first GPU, read from sysfs (the pool's boxes differ by a few per cent on the same binary).
+    No child process: this process has initialised the GPU (and may run under rocprofv3's preload), where spawning
+    `rocm-smi` — a `#!/usr/bin/env python3` script — is the exec hop the GPU boxes forbid."""
+    import glob
+    import re
+    out = {}
     try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
-        card = next(iter(json.loads(out).values()))
-        return {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower()}
-    except Exception as e:  # noqa: BLE001 - best effort, never fails the bench
-        return {"error": str(e)[:80]}
+        for name in ("sclk", "mclk", "fclk"):
+            for path in sorted(glob.glob(f"/sys/class/drm/card*/device/pp_dpm_{name}")):
+                with open(path) as f:
+                    cur = [ln for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
+                if cur:
+                    mhz = re.search(r"(\d+)\s*mhz", cur[0], re.I)
+                    out[f"{name}_mhz"] = int(mhz.group(1)) if mhz else cur[0].strip()
+                    break
+    except OSError as e:  # best effort, never fails the bench
+        out["error"] = str(e)[:80]
+    return out or {"error": "no pp_dpm_* files under /sys/class/drm"}
 
 
 def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):

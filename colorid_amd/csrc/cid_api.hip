@@ -115,6 +115,9 @@ const uint64_t *index_matrix(const cid_index *ix) { return ix->mat; }
 
 namespace cid {
 int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
+    // a started cid_bgzf_inflate batch owns these four slots (and the pinned arena) until its _finish
+    if (c->inflate.open && (s == S_KMERS || s == S_MISC || s == S_BASES || s == S_FREQ))
+        return fail(CID_ERR_STATE, "a cid_bgzf_inflate_start on this ctx is waiting for its _finish: this call would overwrite its buffers");
     if (bytes == 0) bytes = 16;
     if (c->slot_bytes[s] < bytes) {
         if (c->slot[s]) HIP_TRY(hipFree(c->slot[s]));
@@ -189,6 +192,7 @@ namespace cid {
 static const bool kUsePin = getenv("CID_PIN_STAGING") ? atoi(getenv("CID_PIN_STAGING")) != 0 : true;
 uint8_t *pin_reserve(cid_ctx *c, size_t bytes, size_t cap) {
     if (!kUsePin || bytes > cap) return nullptr;
+    if (c->inflate.open) return nullptr;   // the arena holds a started inflate batch's text and status: callers copy without it
     if (bytes <= c->pin_bytes) return c->pin;
     if (c->pin) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
     size_t want = bytes + bytes / 2;
@@ -1053,7 +1057,7 @@ struct ReadRoute {
     uint64_t max_bytes = 0, max_win = 0;
     size_t n_long = 0;
 };
-static int readid_route(const cid_index *ix, const uint64_t *seq_off, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
+static int readid_route(const cid_index *ix, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
                         uint32_t start_sample, ReadRoute &rr) {
     auto read_size = [&](size_t r, uint64_t &bytes, uint64_t &win) {
         const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
@@ -1065,8 +1069,9 @@ static int readid_route(const cid_index *ix, const uint64_t *seq_off, const uint
         bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
     };
     uint64_t max_bytes = 0, max_win = 0;
-    for (size_t r = 0; r < n_reads; ++r) {
+    for (size_t r = 0; r < n_reads; ++r) {   // (both bounds before seq_off is read through them)
         if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
+        if (read_seq0[r + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs at read %zu", r);
         for (uint64_t s = read_seq0[r]; s < read_seq0[r + 1]; ++s)
             if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
         uint64_t bytes, win;
@@ -1098,10 +1103,11 @@ static int readid_route(const cid_index *ix, const uint64_t *seq_off, const uint
 // between the LDS kernels and the sort-based path exactly as cid_readid_count routes them (the mask of a read's q-th distinct k-mer
 // sits at the same word whichever kernel writes it, so different stripes may route a read differently).  Masks: one word per
 // window, read r's at [prefix of the windows of reads 0..r-1] (cid_readid_stripe_mask_words words in all).
-static int stripe_mask_starts(uint32_t k, uint32_t stride_d, const uint64_t *seq_off, const uint64_t *read_seq0, size_t n_reads, std::vector<uint64_t> &zs) {
+static int stripe_mask_starts(uint32_t k, uint32_t stride_d, const uint64_t *seq_off, uint64_t n_seqs, const uint64_t *read_seq0, size_t n_reads, std::vector<uint64_t> &zs) {
     zs.assign(n_reads + 1, 0);
     for (size_t r = 0; r < n_reads; ++r) {
         if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
+        if (read_seq0[r + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs at read %zu", r);
         uint64_t win = 0;
         for (uint64_t s = read_seq0[r]; s < read_seq0[r + 1]; ++s) {
             if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
@@ -1117,7 +1123,7 @@ int cid_readid_stripe_mask_words(uint32_t k_size, uint32_t stride_d, const uint6
     if (!seq_off || !read_seq0 || !n_words) return fail(CID_ERR_INVALID, "null argument");
     if (stride_d == 0 || k_size == 0) return fail(CID_ERR_INVALID, "k_size and stride_d must be >= 1");
     std::vector<uint64_t> zs;
-    const int rc = stripe_mask_starts(k_size, stride_d, seq_off, read_seq0, n_reads, zs);
+    const int rc = stripe_mask_starts(k_size, stride_d, seq_off, ~0ull /* the caller vouches for seq_off's length */, read_seq0, n_reads, zs);
     if (rc) return rc;
     *n_words = zs[n_reads] + 1;   // never empty
     return CID_OK;
@@ -1135,9 +1141,9 @@ static int readid_stripe_pass(cid_ctx *c, const cid_index *ix, const uint8_t *d_
     if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
     if (seq_off[n_seqs] && !d_bases) return fail(CID_ERR_INVALID, "null bases");
     ReadRoute rr;
-    if ((rc = readid_route(ix, seq_off, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
+    if ((rc = readid_route(ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
     std::vector<uint64_t> zs;
-    if ((rc = stripe_mask_starts(ix->k, stride_d, seq_off, read_seq0, n_reads, zs))) return rc;
+    if ((rc = stripe_mask_starts(ix->k, stride_d, seq_off, n_seqs, read_seq0, n_reads, zs))) return rc;
     if (zs[n_reads] >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
     const bool all_long = rr.n_long == n_reads, mixed = rr.n_long > 0 && !all_long;
     HIP_TRY(hipSetDevice(c->device));
@@ -1209,7 +1215,7 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
     const uint64_t total_bases = seq_off[n_seqs];
     if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
     ReadRoute rr;
-    if ((rc = readid_route(ix, seq_off, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
+    if ((rc = readid_route(ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
     const std::vector<uint8_t> &route = rr.route;
     const uint64_t max_bytes = rr.max_bytes, max_win = rr.max_win;
     const size_t n_long = rr.n_long;

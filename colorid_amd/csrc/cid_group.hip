@@ -348,8 +348,9 @@ int cid_group_readid_count_sparse(cid_group *g, cid_index *const *replicas, cons
         shard_bounds(n_reads, r, n, &lo, &hi);
         const size_t nr = hi - lo;
         g->sp_rows[r] = nr; g->sp_entries[r] = 0;
-        // the shard re-based to its own offsets
-        if (read_seq0[lo] > read_seq0[hi]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic");
+        // the shard re-based to its own offsets (every entry checked before seq_off is read through it)
+        for (size_t i = lo; i < hi; ++i)
+            if (read_seq0[i] > read_seq0[i + 1] || read_seq0[i + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 not monotonic or past n_seqs at read %zu", i);
         const uint64_t s0 = read_seq0[lo], s1 = read_seq0[hi];
         std::vector<uint64_t> so(s1 - s0 + 1), r0(nr + 1);
         for (size_t i = 0; i <= s1 - s0; ++i) {

@@ -390,7 +390,8 @@ int cid_group_stripes_readid_count_sparse(cid_group *g, cid_index *const *stripe
     g->sp_base = st.base;
     for (int r = 0; r < st.n; ++r) { g->sp_rows[r] = n_reads; g->sp_entries[r] = 0; g->ctx[r]->sp_rows = 0; g->ctx[r]->sp_entries = 0; }
     if (n_reads == 0) return CID_OK;
-    if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
+    for (size_t r = 0; r < n_reads; ++r)   // before seq_off is read through any entry
+        if (read_seq0[r] > read_seq0[r + 1] || read_seq0[r + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 not monotonic or past n_seqs at read %zu", r);
     const uint64_t total_bases = seq_off[n_seqs];
     if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
     uint64_t zn64 = 0;   // one mask word per k-mer window of the batch (validates the offsets too)

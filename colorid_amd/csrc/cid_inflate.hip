@@ -64,8 +64,10 @@ struct BitReader {
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32 - n); }
 
 // canonical Huffman tables from code lengths: a 2^bits direct table (entry = sym << 4 | len; 0 = a longer code) and the count /
-// symbol arrays of the bit-by-bit decoder for codes longer than `bits`.  false: over-subscribed or incomplete (more than one code)
-__device__ bool build_tables(const uint8_t *lens, uint32_t n_sym, uint16_t *tab, uint32_t bits, uint16_t *cnt, uint16_t *sym) {
+// symbol arrays of the bit-by-bit decoder for codes longer than `bits`.  false: over-subscribed or incomplete — zlib's inflate_table
+// rule: an incomplete set is accepted only when it is ONE code of length 1 (max == 1), and never for the code-length code
+// (`allow_single` false, its type CODES)
+__device__ bool build_tables(const uint8_t *lens, uint32_t n_sym, uint16_t *tab, uint32_t bits, uint16_t *cnt, uint16_t *sym, bool allow_single = true) {
     for (uint32_t i = 0; i < 16; ++i) cnt[i] = 0;
     for (uint32_t s = 0; s < n_sym; ++s) cnt[lens[s]]++;
     for (uint32_t i = 0; i < (1u << bits); ++i) tab[i] = 0;
@@ -92,7 +94,7 @@ __device__ bool build_tables(const uint8_t *lens, uint32_t n_sym, uint16_t *tab,
             for (uint32_t i = r; i < (1u << bits); i += 1u << l) tab[i] = (uint16_t)((s << 4) | l);
         }
     }
-    return left == 0 || (n_sym - cnt[0]) == 1;   // complete, or the single-code tree zlib allows for distances
+    return left == 0 || (allow_single && (n_sym - cnt[0]) == 1 && cnt[1] == 1);
 }
 
 // one symbol: direct table, else bit by bit over the canonical code (puff-style); -1 = invalid code
@@ -173,7 +175,7 @@ __device__ void decode_run(BitReader &br, Decoder &d, const LaneLds &L, uint8_t 
                 for (uint32_t i = 0; i < 19; ++i) s_lens[i] = 0;
                 for (uint32_t i = 0; i < hclen; ++i) { br.refill(); s_lens[c_clen_order[i]] = (uint8_t)br.take(3); }
                 // the code-length code decodes through the dist table's storage (7-bit direct table)
-                if (!build_tables(s_lens, 19, s_dist, 7, s_dcnt, s_dsym)) { d.status = ST_BAD_BLOCK; break; }
+                if (!build_tables(s_lens, 19, s_dist, 7, s_dcnt, s_dsym, false)) { d.status = ST_BAD_BLOCK; break; }
                 uint32_t i = 0;
                 bool bad = false;
                 while (i < hlit + hdist) {

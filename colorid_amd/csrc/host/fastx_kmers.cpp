@@ -360,13 +360,18 @@ struct LineReader::Impl {
             while (out_total < kBatchOut) {
                 in_pos = scan;
                 if (!need(18)) { if (in_have - in_pos != 0) die("truncated gzip member header"); last = true; break; }
+                {   // the whole extra field (it may hold other subfields before "BC") before it is parsed
+                    const unsigned char *h = in.data() + in_pos;
+                    const size_t xlen = h[10] | ((size_t)h[11] << 8);
+                    if (h[0] == 0x1f && h[1] == 0x8b && (h[3] & 4) && !need(12 + xlen)) die("truncated gzip member header");
+                }
                 const size_t msz = bgzf_member_size(in.data() + in_pos, in_have - in_pos);
                 if (msz < 26) die("not a block-gzip (BGZF) member inside a BGZF file: mixed gzip streams are not supported in one file");
                 if (!need(msz)) die("truncated gzip member");
                 const unsigned char *t = in.data() + in_pos + msz - 4;
                 const size_t isize = t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
                 if (isize > (1u << 16)) die("BGZF member larger than 64 KiB");
-                if (isize) mem.push_back(Member{in_pos, msz, out_total, isize});   // (an empty member — the BGZF end marker — holds nothing)
+                mem.push_back(Member{in_pos, msz, out_total, isize});   // (empty members — the BGZF end marker — too: their DEFLATE data and CRC-32 are checked like any other's)
                 out_total += isize;
                 scan = in_pos + msz;
             }

@@ -367,7 +367,10 @@ int cid_bgzf_inflate(cid_ctx *, const uint8_t *members, size_t n_bytes, const ui
                      const uint32_t *text_off, const uint32_t *text_len, size_t n_members, uint8_t *text, size_t text_bytes,
                      size_t *bad_member);
 /* The same call in two halves, for a reader that keeps two batches in flight on two contexts: _start queues the upload, the kernel
- * and the copies back (the caller's `members` buffer is free again when it returns); _finish waits, checks and hands out the text. */
+ * and the copies back (the caller's `members` buffer is free again when it returns); _finish waits, checks and hands out the text.
+ * Between the two the batch lives in the ctx's scratch: every other host-pointer entry point on the SAME ctx (cid_search_count,
+ * cid_search_perfect, cid_readid_count*, cid_readid_stripe_*, cid_index_insert_kmers, a second _start ...) fails with CID_ERR_STATE
+ * instead of overwriting it; the *_dev calls on caller-owned device memory and cid_readid_sparse_fetch stay usable. */
 int cid_bgzf_inflate_start(cid_ctx *, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
                            const uint32_t *text_off, const uint32_t *text_len, size_t n_members, size_t text_bytes);
 int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t *bad_member);

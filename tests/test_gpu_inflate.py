@@ -264,3 +264,116 @@ def test_inflate_fuzz_valid_and_garbage_members(hip_ctx, seed):
         assert rc == 0
     else:
         assert rc == -1 and bad == first_bad, (rc, bad, first_bad, lib.cid_last_error())
+
+
+class _Bits:
+    """DEFLATE bit packing: header fields LSB first, Huffman codes MSB first."""
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, value, nbits):
+        self.acc |= value << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 0xFF); self.acc >>= 8; self.n -= 8
+
+    def code(self, code, nbits):
+        for i in range(nbits - 1, -1, -1):
+            self.put((code >> i) & 1, 1)
+
+    def bytes(self):
+        return bytes(self.out) + (bytes([self.acc & 0xFF]) if self.n else b"")
+
+
+def _dynamic_block(lit_lens, dist_len, symbols):
+    """One final dynamic-Huffman block: literal/length code lengths {symbol: len} (symbols <= 257), ONE distance code (symbol 0) of
+    length dist_len, then `symbols` = list of ('lit', s) / ('match3', None: length 3 at distance 1) / ('eob', None)."""
+    lens = [lit_lens.get(s, 0) for s in range(258)] + [dist_len]
+    # canonical codes
+    def canon(ls):
+        codes, code = {}, 0
+        for L in range(1, 16):
+            for s, l in enumerate(ls):
+                if l == L:
+                    codes[s] = (code, L); code += 1
+            code <<= 1
+        return codes
+    lit_codes = canon(lens[:258])
+    # run-length the 259 lengths with symbols 0..15 and 18 (11..138 zeros) / 17 (3..10 zeros)
+    seq, i = [], 0
+    while i < len(lens):
+        if lens[i] == 0:
+            j = i
+            while j < len(lens) and lens[j] == 0:
+                j += 1
+            run = j - i
+            while run >= 11:
+                r = min(run, 138); seq.append((18, r - 11, 7)); run -= r
+            if run >= 3:
+                seq.append((17, run - 3, 3)); run = 0
+            seq += [(0, 0, 0)] * run
+            i = j
+        else:
+            seq.append((lens[i], 0, 0)); i += 1
+    used = sorted({s for s, _, _ in seq})
+    # a complete code over the used code-length symbols: the first gets length 1 ... the last two share the longest
+    cl = {}
+    for idx, s in enumerate(used):
+        cl[s] = min(idx + 1, len(used) - 1) if len(used) > 1 else 1
+    cl_codes = canon([cl.get(s, 0) for s in range(19)])
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    hclen = max(i for i, s in enumerate(order) if cl.get(s, 0)) + 1
+    hclen = max(hclen, 4)
+    b = _Bits()
+    b.put(1, 1); b.put(2, 2); b.put(258 - 257, 5); b.put(0, 5); b.put(hclen - 4, 4)
+    for s in order[:hclen]:
+        b.put(cl.get(s, 0), 3)
+    for s, extra, nb in seq:
+        b.code(*cl_codes[s])
+        if nb:
+            b.put(extra, nb)
+    for kind, s in symbols:
+        if kind == "lit":
+            b.code(*lit_codes[s])
+        elif kind == "eob":
+            b.code(*lit_codes[256])
+        else:   # length 3 (symbol 257, no extra bits), distance 1 (distance symbol 0, no extra bits): the single distance code is all zeros
+            b.code(*lit_codes[257])
+            b.code(0, dist_len)
+    return b.bytes()
+
+
+def _member_of_deflate(body, text):
+    extra = b"BC" + struct.pack("<H", 2)
+    bsize = 12 + len(extra) + 2 + len(body) + 8 - 1
+    return (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", len(extra) + 2) + extra + struct.pack("<H", bsize) + body +
+            struct.pack("<II", zlib.crc32(text) & 0xFFFFFFFF, len(text)))
+
+
+def test_incomplete_code_sets_are_judged_as_zlib_judges_them(hip_ctx):
+    """zlib's inflate_table accepts an incomplete Huffman set only when it is ONE code of length 1 (never for the code-length code):
+    hand-assembled dynamic blocks with a single distance / literal code of length 1 (valid) and of length 2 (invalid)."""
+    lib = hip_ctx.lib
+    cases = []
+    full = {65: 1, 256: 2, 257: 2}
+    stream = [("lit", 65)] * 3 + [("match3", None), ("eob", None)]
+    cases.append((_dynamic_block(full, 1, stream), b"AAAAAA"))            # one distance code of length 1: fine
+    cases.append((_dynamic_block(full, 2, stream), b"AAAAAA"))            # one distance code of length 2: "invalid distances set"
+    cases.append((_dynamic_block({256: 1}, 1, [("eob", None)]), b""))     # literal tree = the end-of-block code alone, length 1: fine
+    cases.append((_dynamic_block({256: 2}, 1, [("eob", None)]), b""))     # ... of length 2: "invalid literal/lengths set"
+    verdicts = []
+    for body, text in cases:
+        try:
+            ok = zlib.decompress(body, -15) == text
+        except zlib.error:
+            ok = False
+        verdicts.append(ok)
+    assert verdicts == [True, False, True, False], verdicts               # (what this zlib says; the GPU must say the same)
+    for (body, text), ok in zip(cases, verdicts):
+        rc, out, bad, _ = inflate(lib, hip_ctx, [_member_of_deflate(body, text)], [len(text)])
+        assert (rc == 0 and out == text) if ok else (rc == -1 and bad == 0), (ok, rc, out, lib.cid_last_error())
+    # in a batch the first member zlib refuses is the one reported
+    good = bgzf_member(b"ACGT" * 100)
+    members = [good, _member_of_deflate(*cases[0]), _member_of_deflate(*cases[1]), good]
+    rc, out, bad, _ = inflate(lib, hip_ctx, members, [400, 6, 6, 400])
+    assert rc == -1 and bad == 2
