@@ -206,6 +206,19 @@ def box_clocks():
     return out or {"error": "no pp_dpm_* files under /sys/class/drm"}
 
 
+def per_rank_times(dev, world, kernel_ms, collective_ms, step_ms):
+    """[{rank, kernel_ms, collective_ms, step_ms}] over all ranks (rank 0 prints them): a scaling loss can be attributed to the
+    kernel (slower box, HBM placement), to the collective (xGMI / RCCL) or to neither (launch gaps, the barrier)."""
+    mine = torch.tensor([kernel_ms, collective_ms, step_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    return [{"rank": r, "kernel_ms": round(float(t[0]), 4), "collective_ms": round(float(t[1]), 4), "step_ms": round(float(t[2]), 4)}
+            for r, t in enumerate(allr)]
+
+
 def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
     """BASELINE configs[4]: m = 2^30, n = 3, 512 colours per GPU (64 GiB resident per rank; 4096 colours = 512 GiB over 8 GPUs).
     Every rank sees every k-mer (the distinct canonical 31-mers of the same 1 M reads), searches its own stripe
@@ -237,7 +250,7 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
     uc = torch.empty(K, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(a.steps)]
 
     def step(i=None):
         fact.zero_(); hits.zero_(); nu.zero_(); sf.zero_()
@@ -246,8 +259,12 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
         si.search_count_local(kmers, fact, hits)
         if i is not None:
             ev[i][1].record(stream)
-        reduce_stripe_facts(fact, hits)
+        reduce_stripe_facts(fact, hits)      # (torch's RCCL stream; the current stream waits for it before the next record)
+        if i is not None:
+            ev[i][2].record(stream)
         si.unique_finalize(fact, freq, nu, sf, uc)
+        if i is not None:
+            ev[i][3].record(stream)
 
     for _ in range(a.warmup):
         step()
@@ -262,7 +279,10 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    coll_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    fin_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+    ranks = per_rank_times(dev, world, kern_ms, coll_ms, elapsed / a.steps * 1e3)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -284,6 +304,7 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
                        "stripe_bytes": m * rs * 8, "background_density": p_bg,
                        "parallelism": f"colour stripes over {world} GPU(s); one all-reduce(SUM) of 4 B per k-mer + 8*C_total bytes per step",
                        "collective_bytes_per_step": 4 * K + 8 * C_total, "setup_s": round(t_setup, 1), "consistent": bool(ok), "box": box_clocks()},
+            "per_rank": ranks, "kernel_ms": kern_ms, "collective_ms": coll_ms, "finalize_ms": fin_ms,
             "roofline": {"bound": "hbm", "kernel": "k_search_count (stripe mode)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_kmer": alg, "kernel_ms": kern_ms, "kmers_per_launch": K},
             "cpu_baseline": None,
@@ -372,7 +393,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(a.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -380,12 +401,15 @@ def main():
         ev[i][0].record(stream)
         launch()
         ev[i][1].record(stream)
-        allreduce_counts(out)
+        allreduce_counts(out)        # (torch's RCCL stream; the current stream waits for it before the next record)
+        ev[i][2].record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    coll_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    ranks = per_rank_times(dev, world, kern_ms, coll_ms, elapsed / a.steps * 1e3)
     tot_k = torch.tensor([K], dtype=torch.int64, device=dev)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -417,6 +441,7 @@ def main():
                          "traffic": a.traffic_bytes if a.traffic_bytes is not None else profiled_traffic(K, C, m, n, k),
                          "alg_bytes_per_kmer": alg_bytes_per_kmer,
                          "kernel_ms": kern_ms, "kmers_per_launch": K},
+            "per_rank": ranks, "kernel_ms": kern_ms, "collective_ms": coll_ms,
         }
         tr = result["roofline"]["traffic"]
         if tr:   # the PMC traffic of profiles/ at this run's kernel time: what the kernel really moves (every 32-byte row costs a 128-byte line)

@@ -3,7 +3,8 @@
 // parallel boundary is the rayon map over reads, src/read_id_mt_pe.rs:300-302, `-t`, src/main.rs:718-721).  The one exchange step
 // of the proportional search is the sum of the 3*C per-accession counters: RCCL ncclAllReduce over xGMI, issued for all ranks
 // from this process inside one ncclGroupStart/End (librccl is loaded on first use with dlopen: the library has no link-time
-// dependency on it).  A device id may be listed more than once — several ranks on one GPU, which RCCL refuses — then, or with
+// dependency on it; the library never redirects a file descriptor — RCCL's version banner goes wherever RCCL writes it, at communicator
+// creation only, and a host that prints result rows to stdout wraps cid_group_create itself as host/main.cpp does).  A device id may be listed more than once — several ranks on one GPU, which RCCL refuses — then, or with
 // COLORID_REDUCE=host, the 24*C bytes per rank are summed through the host.  Perfect search: AND of the ranks' W words on the
 // host (RCCL has no bitwise reduction).  read_id: no exchange; rows are concatenated in input order.
 // Host code only: every kernel launch goes through the single-GPU entry points.
@@ -23,7 +24,6 @@ int allreduce_sum(cid_group *g, void *const *d_bufs, size_t count, int elem_byte
     const int n = (int)g->ctx.size();
     if (n == 1 && !g->use_rccl) return CID_OK;
     if (g->use_rccl) {
-        StdoutToStderr quiet;
         int e = g->rccl.GroupStart();
         for (int r = 0; r < n && e == 0; ++r) {
             HIP_TRY(hipSetDevice(g->dev[r]));
@@ -101,8 +101,7 @@ int cid_group_create(const int *device_ids, int n_devices, cid_group **out) {
     if (want && distinct) {
         if (!g->rccl.load()) { cid_group_destroy(g); return fail(CID_ERR_HIP, "cannot load librccl.so (set COLORID_REDUCE=host to sum through the host): %s", dlerror()); }
         g->comms.assign(n_devices, nullptr);
-        int e;
-        { StdoutToStderr quiet; e = g->rccl.CommInitAll(g->comms.data(), n_devices, device_ids); }
+        const int e = g->rccl.CommInitAll(g->comms.data(), n_devices, device_ids);
         if (e) { g->comms.clear(); const char *m = g->rccl.GetErrorString(e); cid_group_destroy(g); return fail(CID_ERR_HIP, "ncclCommInitAll: %s", m); }
         g->use_rccl = true;
     }
@@ -132,10 +131,12 @@ int cid_group_uses_rccl(const cid_group *g, int *yes) {
 
 void cid_group_destroy(cid_group *g) {
     if (!g) return;
-    {
-        StdoutToStderr quiet;
-        for (size_t r = 0; r < g->comms.size(); ++r)
-            if (g->comms[r]) { (void)hipSetDevice(g->dev[r]); (void)g->rccl.CommDestroy(g->comms[r]); }
+    for (size_t r = 0; r < g->comms.size(); ++r)
+        if (g->comms[r]) { (void)hipSetDevice(g->dev[r]); (void)g->rccl.CommDestroy(g->comms[r]); }
+    for (size_t r = 0; r < g->ev_ready.size(); ++r) {
+        (void)hipSetDevice(g->dev[r]);
+        if (g->ev_ready[r]) (void)hipEventDestroy(g->ev_ready[r]);
+        if (g->ev_reduced[r]) (void)hipEventDestroy(g->ev_reduced[r]);
     }
     for (cid_ctx *c : g->ctx) cid_ctx_destroy(c);
     delete g;

@@ -3,7 +3,6 @@
 #include "../../include/colorid_hip.h"
 
 #include <dlfcn.h>
-#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +32,7 @@ struct Rccl {
     int (*CommInitAll)(void **, int, const int *) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -46,30 +46,14 @@ struct Rccl {
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd && GetErrorString;
+        return CommInitAll && CommDestroy && AllReduce && AllGather && GroupStart && GroupEnd && GetErrorString;
     }
 };
 constexpr int kNcclUint32 = 3, kNcclUint64 = 5, kNcclSum = 0;
-
-// RCCL prints a version banner to the C stdout; a drop-in `colorid search` must print result rows only.  While an object of this
-// class lives, fd 1 is fd 2: what the wrapped call leaves in the stdout buffer (or writes directly) lands on stderr.
-class StdoutToStderr {
-  public:
-    StdoutToStderr() {
-        fflush(stdout);
-        saved_ = dup(1);
-        if (saved_ >= 0) dup2(2, 1);
-    }
-    ~StdoutToStderr() {
-        fflush(stdout);
-        if (saved_ >= 0) { dup2(saved_, 1); close(saved_); }
-    }
-  private:
-    int saved_;
-};
 
 }  // namespace cidg
 
@@ -134,6 +118,8 @@ struct cid_group {
     bool use_rccl = false;
     cidg::Rccl rccl;
     std::vector<void *> comms;
+    // per rank: "my buffer is ready" / "my slice is reduced" events of the striped reductions (cid_group_stripes.hip), made on first use
+    std::vector<hipEvent_t> ev_ready, ev_reduced;
     // sparse read_id results of the last cid_group_readid_count_sparse (per rank: rows and entries)
     std::vector<uint64_t> sp_rows, sp_entries;
     // colour stripes (cid_group_stripes_*): first colour of every rank's stripe + the total, of the last striped read_id call
@@ -190,7 +176,8 @@ inline int check_replicas(const cid_group *g, cid_index *const *replicas) {
 }
 
 // sum of one u64[count] (elem_bytes 8) or u32[count] (4) device array per rank, every rank ends with the total; RCCL on the
-// ranks' ctx streams, or through the host (synchronous)
+// ranks' ctx streams, or through the host (synchronous).  Touches no file descriptor: what RCCL may print (its version banner,
+// NCCL_DEBUG output) is printed at communicator creation, which a host that needs a clean stdout wraps itself (host/main.cpp)
 int allreduce_sum(cid_group *g, void *const *d_bufs, size_t count, int elem_bytes);
 // the colour-striped half of cid_group_readid_sparse_fetch (cid_group_stripes.hip)
 int stripes_sparse_fetch(cid_group *g, uint64_t *row_start, uint32_t *colours, uint32_t *counts);

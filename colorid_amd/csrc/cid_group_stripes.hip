@@ -3,12 +3,13 @@
 // 4096 colours = 512 GiB, 64 GiB per GPU).  Every rank sees every query k-mer / read; per-colour counts of a stripe are final; what
 // needs all stripes is exchanged once per call:
 //   search        : one u32 per k-mer (n << 26 | colour + 1, cid_search.hip) SUMMED over the ranks — RCCL ncclAllReduce over xGMI
-//                   (or peer copies + an add kernel when device ids repeat) — then k_unique_finalize on rank 0;
+//                   (a reduce-scatter of peer copies when device ids repeat) — then k_unique_finalize on rank 0;
 //   perfect search: one u32 per k-mer (seeds whose row is all-zero in the stripe) ANDed over the ranks (RCCL has no bitwise
-//                   reduction: peer copies into rank 0 + an AND kernel), the stripes' AND words concatenated on the host;
-//   read_id       : the zero pass's masks (one u32 per read and distinct k-mer) ANDed the same way and sent back to every rank, then
+//                   reduction: ncclAllGather + a local AND on every rank; reduce-scatter of peer copies when device ids repeat),
+//                   the stripes' AND words concatenated on the host;
+//   read_id       : the zero pass's masks (one u32 per read and distinct k-mer) ANDed the same way, on every rank, then
 //                   the count pass; every rank compacts its own columns, the host splices the ranks' (colour, count) lists per read.
-// Host code + three elementwise kernels; every search / read_id kernel launch goes through the single-GPU stripe entry points.
+// Host code + two elementwise kernels; every search / read_id kernel launch goes through the single-GPU stripe entry points.
 #include "cid_group.hpp"
 
 #include <new>
@@ -21,13 +22,17 @@ using namespace cidg;
 
 namespace {
 
-__global__ void k_add_u32(uint32_t *dst, const uint32_t *src, uint64_t n) {
+// dst[i] (op)= src[j * stride + i] for j < n_src; ASSIGN: dst[i] = the fold of the n_src sources alone (dst's old value is one of them)
+template <bool SUM, bool ASSIGN>
+__global__ void k_fold_u32(uint32_t *dst, const uint32_t *src, uint32_t n_src, uint64_t stride, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
-}
-__global__ void k_and_u32(uint32_t *dst, const uint32_t *src, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] &= src[i];
+    if (i >= n) return;
+    uint32_t v = ASSIGN ? (SUM ? 0u : 0xFFFFFFFFu) : dst[i];
+    for (uint32_t j = 0; j < n_src; ++j) {
+        const uint32_t x = src[(uint64_t)j * stride + i];
+        v = SUM ? v + x : v & x;
+    }
+    dst[i] = v;
 }
 // flag[0] |= 1 if any word has one of `mask`'s bits
 __global__ void k_any_masked(const uint32_t *v, uint64_t n, uint32_t mask, int *flag) {
@@ -63,43 +68,121 @@ int check_stripes(const cid_group *g, cid_index *const *stripes, Stripes &st) {
     return CID_OK;
 }
 
-// d_bufs[r]: u32[count] on rank r.  Rank 0 ends with the element-wise SUM / AND over the ranks; with `everywhere` so does every rank.
-// Peer copies into a scratch block of rank 0 (64 MiB at a time) and one elementwise kernel per chunk; synchronous.
+hipError_t copy_between(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t stream) {
+    return dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream) : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream);
+}
+
+int group_events(cid_group *g) {
+    const size_t n = g->ctx.size();
+    if (g->ev_ready.size() == n) return CID_OK;
+    g->ev_ready.assign(n, nullptr);
+    g->ev_reduced.assign(n, nullptr);
+    for (size_t r = 0; r < n; ++r) {
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_ready[r], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g->ev_reduced[r], hipEventDisableTiming));
+    }
+    return CID_OK;
+}
+
+// AND over ranks with every rank on its own GPU: RCCL has no bitwise reduction, so every rank all-gathers the ranks' arrays (ring /
+// direct over xGMI, RCCL's choice) 16 M words at a time and folds them locally — no rank is a funnel, every rank ends with the result
+int and_by_allgather(cid_group *g, uint32_t *const *d_bufs, size_t count) {
+    const int n = (int)g->ctx.size();
+    const size_t chunk = (size_t)16 << 20;   // elements: n x 64 MiB of scratch per rank
+    const size_t ce = count < chunk ? count : chunk;
+    std::vector<void *> tmp(n, nullptr);
+    int rc = CID_OK;
+    for (int r = 0; r < n && rc == CID_OK; ++r) { HIP_TRY(hipSetDevice(g->dev[r])); rc = cid::ctx_alloc(g->ctx[r], ce * 4 * (size_t)n, &tmp[r]); }
+    for (size_t i0 = 0; i0 < count && rc == CID_OK; i0 += chunk) {
+        const size_t ne = count - i0 < chunk ? count - i0 : chunk;
+        int e = g->rccl.GroupStart();
+        for (int r = 0; r < n && e == 0; ++r) {
+            if (hipSetDevice(g->dev[r]) != hipSuccess) { e = -1; break; }
+            e = g->rccl.AllGather(d_bufs[r] + i0, tmp[r], ne, kNcclUint32, g->comms[r], g->ctx[r]->stream);
+        }
+        const int e2 = g->rccl.GroupEnd();
+        if (e || e2) { rc = fail(CID_ERR_HIP, "ncclAllGather: %s", e > 0 || e2 ? g->rccl.GetErrorString(e > 0 ? e : e2) : "hipSetDevice failed"); break; }
+        for (int r = 0; r < n; ++r) {   // rank j's words sit at tmp + j * ne
+            if (hipSetDevice(g->dev[r]) != hipSuccess) { rc = fail(CID_ERR_HIP, "hipSetDevice"); break; }
+            hipLaunchKernelGGL((k_fold_u32<false, true>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, g->ctx[r]->stream, d_bufs[r] + i0,
+                               (const uint32_t *)tmp[r], (uint32_t)n, (uint64_t)ne, (uint64_t)ne);
+            if (hipGetLastError() != hipSuccess) { rc = fail(CID_ERR_HIP, "stripe reduction: fold kernel"); break; }
+        }
+    }
+    for (int r = 0; r < n; ++r) {
+        (void)hipSetDevice(g->dev[r]);
+        if (hipStreamSynchronize(g->ctx[r]->stream) != hipSuccess && rc == CID_OK) rc = fail(CID_ERR_HIP, "stripe reduction: stream");
+        cid::ctx_free(g->ctx[r], tmp[r]);
+    }
+    return rc;
+}
+
+// d_bufs[r]: u32[count] on rank r, produced on rank r's ctx stream.  Afterwards rank 0 — with `everywhere` every rank — holds the
+// element-wise SUM / AND over the ranks.  SUM with RCCL: one ncclAllReduce.  AND with RCCL: all-gather + local fold.  Otherwise
+// (device ids repeat, or COLORID_STRIPE_REDUCE=peer) a reduce-scatter / all-gather of peer copies with no funnel: the array is cut
+// into one slice per rank; rank r pulls slice r of every peer on ITS OWN stream once the peer's "ready" event has fired, folds the
+// n - 1 copies into its own words with one kernel and records "reduced"; then whoever needs the result (every rank, or rank 0 alone)
+// pulls the reduced slices from their owners.  Every GPU moves 2 (n-1)/n of the array instead of rank 0 moving (n-1) arrays, all
+// links work at once, and the host waits once per rank at the end — never inside the loops.
 int reduce_u32(cid_group *g, uint32_t *const *d_bufs, size_t count, bool sum, bool everywhere) {
     const int n = (int)g->ctx.size();
     if (count == 0) return CID_OK;
-    if (sum && g->use_rccl) return allreduce_sum(g, reinterpret_cast<void *const *>(d_bufs), count, 4);   // (also with one rank: COLORID_REDUCE=rccl)
+    static const bool force_peer = getenv("COLORID_STRIPE_REDUCE") && !strcmp(getenv("COLORID_STRIPE_REDUCE"), "peer");
+    if (g->use_rccl && !force_peer)   // (also with one rank: COLORID_REDUCE=rccl)
+        return sum ? allreduce_sum(g, reinterpret_cast<void *const *>(d_bufs), count, 4) : and_by_allgather(g, d_bufs, count);
     if (n == 1) return CID_OK;
-    for (int r = 0; r < n; ++r) { HIP_TRY(hipSetDevice(g->dev[r])); HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream)); }
-    cid_ctx *c0 = g->ctx[0];
-    HIP_TRY(hipSetDevice(c0->device));
-    const size_t chunk = (size_t)16 << 20;   // elements
-    void *d_tmp;
-    int rc = cid::ctx_alloc(c0, (count < chunk ? count : chunk) * 4, &d_tmp);
+    int rc = group_events(g);
     if (rc) return rc;
-    for (int r = 1; r < n; ++r)
-        for (size_t i0 = 0; i0 < count; i0 += chunk) {
-            const size_t ne = count - i0 < chunk ? count - i0 : chunk;
-            hipError_t e = g->dev[r] == c0->device ? hipMemcpyAsync(d_tmp, d_bufs[r] + i0, ne * 4, hipMemcpyDeviceToDevice, c0->stream)
-                                                   : hipMemcpyPeerAsync(d_tmp, c0->device, d_bufs[r] + i0, g->dev[r], ne * 4, c0->stream);
-            if (e == hipSuccess) {
-                if (sum) hipLaunchKernelGGL(k_add_u32, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c0->stream, d_bufs[0] + i0, (const uint32_t *)d_tmp, (uint64_t)ne);
-                else hipLaunchKernelGGL(k_and_u32, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c0->stream, d_bufs[0] + i0, (const uint32_t *)d_tmp, (uint64_t)ne);
-                e = hipGetLastError();
-            }
-            if (e != hipSuccess) { cid::ctx_free(c0, d_tmp); return fail(CID_ERR_HIP, "stripe reduction: %s", hipGetErrorString(e)); }
+    std::vector<size_t> lo(n), hi(n);
+    std::vector<void *> tmp(n, nullptr);
+    for (int r = 0; r < n; ++r) {
+        shard_bounds(count, r, n, &lo[r], &hi[r]);
+        HIP_TRY(hipSetDevice(g->dev[r]));
+        HIP_TRY(hipEventRecord(g->ev_ready[r], g->ctx[r]->stream));
+    }
+    auto fail_sync = [&](int code) {   // leave nothing in flight that reads a buffer the caller is about to reuse
+        for (int r = 0; r < n; ++r) { (void)hipSetDevice(g->dev[r]); (void)hipStreamSynchronize(g->ctx[r]->stream); cid::ctx_free(g->ctx[r], tmp[r]); }
+        return code;
+    };
+    for (int r = 0; r < n; ++r) {   // reduce-scatter: rank r owns [lo_r, hi_r)
+        const size_t ne = hi[r] - lo[r];
+        if (ne == 0) continue;
+        cid_ctx *c = g->ctx[r];
+        if (hipSetDevice(c->device) != hipSuccess) return fail_sync(fail(CID_ERR_HIP, "hipSetDevice"));
+        if ((rc = cid::ctx_alloc(c, ne * 4 * (size_t)(n - 1), &tmp[r]))) return fail_sync(rc);
+        int slot = 0;
+        for (int p = 0; p < n; ++p) {
+            if (p == r) continue;
+            hipError_t e = hipStreamWaitEvent(c->stream, g->ev_ready[p], 0);
+            if (e == hipSuccess) e = copy_between((uint32_t *)tmp[r] + (size_t)slot * ne, c->device, d_bufs[p] + lo[r], g->dev[p], ne * 4, c->stream);
+            if (e != hipSuccess) return fail_sync(fail(CID_ERR_HIP, "stripe reduction (rank %d <- rank %d): %s", r, p, hipGetErrorString(e)));
+            ++slot;
         }
-    hipError_t e = hipStreamSynchronize(c0->stream);
-    cid::ctx_free(c0, d_tmp);
-    if (e != hipSuccess) return fail(CID_ERR_HIP, "stripe reduction: %s", hipGetErrorString(e));
-    if (everywhere)
-        for (int r = 1; r < n; ++r) {
-            HIP_TRY(hipSetDevice(g->dev[r]));
-            if (g->dev[r] == c0->device) HIP_TRY(hipMemcpyAsync(d_bufs[r], d_bufs[0], count * 4, hipMemcpyDeviceToDevice, g->ctx[r]->stream));
-            else HIP_TRY(hipMemcpyPeerAsync(d_bufs[r], g->dev[r], d_bufs[0], c0->device, count * 4, g->ctx[r]->stream));
-            HIP_TRY(hipStreamSynchronize(g->ctx[r]->stream));
+        if (sum) hipLaunchKernelGGL((k_fold_u32<true, false>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, d_bufs[r] + lo[r], (const uint32_t *)tmp[r], (uint32_t)(n - 1), (uint64_t)ne, (uint64_t)ne);
+        else hipLaunchKernelGGL((k_fold_u32<false, false>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, d_bufs[r] + lo[r], (const uint32_t *)tmp[r], (uint32_t)(n - 1), (uint64_t)ne, (uint64_t)ne);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(g->ev_reduced[r], c->stream);
+        if (e != hipSuccess) return fail_sync(fail(CID_ERR_HIP, "stripe reduction (rank %d): %s", r, hipGetErrorString(e)));
+    }
+    for (int p = 0; p < (everywhere ? n : 1); ++p) {   // all-gather (or gather on rank 0): the reduced slices travel from their owners
+        cid_ctx *c = g->ctx[p];
+        if (hipSetDevice(c->device) != hipSuccess) return fail_sync(fail(CID_ERR_HIP, "hipSetDevice"));
+        for (int r = 0; r < n; ++r) {
+            if (r == p || hi[r] == lo[r]) continue;
+            hipError_t e = hipStreamWaitEvent(c->stream, g->ev_reduced[r], 0);
+            if (e == hipSuccess) e = copy_between(d_bufs[p] + lo[r], c->device, d_bufs[r] + lo[r], g->dev[r], (hi[r] - lo[r]) * 4, c->stream);
+            if (e != hipSuccess) return fail_sync(fail(CID_ERR_HIP, "stripe reduction (rank %d <- rank %d): %s", p, r, hipGetErrorString(e)));
         }
-    return CID_OK;
+    }
+    rc = CID_OK;
+    for (int r = 0; r < n; ++r) {   // one wait per rank: afterwards no stream reads another rank's buffer any more
+        (void)hipSetDevice(g->dev[r]);
+        const hipError_t e = hipStreamSynchronize(g->ctx[r]->stream);
+        if (e != hipSuccess && rc == CID_OK) rc = fail(CID_ERR_HIP, "stripe reduction (rank %d): %s", r, hipGetErrorString(e));
+        cid::ctx_free(g->ctx[r], tmp[r]);
+    }
+    return rc;
 }
 
 // where a rank finds the query k-mers: a host array (uploaded by every rank) or a device-resident set (peer copies)

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <unistd.h>
 
 #include "colorid_host.hpp"
 
@@ -111,6 +112,25 @@ void phase_done(const char *what) {
     last = now;
 }
 
+// RCCL prints its version banner (and whatever NCCL_DEBUG asks for) to the C stdout while communicators are made and destroyed; a
+// drop-in `colorid search` prints result rows only.  The library never touches a file descriptor, so the CLI does it here, around
+// those two calls and nowhere near the searches: while an object of this class lives, fd 1 is fd 2.  (Nothing else of this process
+// writes to stdout at those two moments: the banner row is printed before, the result rows between them.)
+class StdoutToStderr {
+  public:
+    StdoutToStderr() {
+        fflush(stdout);
+        saved_ = dup(1);
+        if (saved_ >= 0) dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved_ >= 0) { dup2(saved_, 1); close(saved_); }
+    }
+  private:
+    int saved_;
+};
+
 Gpus make_gpus(const Args &a) {
     Gpus g;
     if (a.has("threads"))
@@ -128,7 +148,10 @@ Gpus make_gpus(const Args &a) {
         if (cid_ctx_create(dev, &g.ctx) != CID_OK) die("cannot open GPU %d: %s (colorid has no CPU search path)", dev, cid_last_error());
         return g;
     }
-    if (cid_group_create(ids.data(), (int)ids.size(), &g.group) != CID_OK) die("cannot open %zu GPUs: %s", ids.size(), cid_last_error());
+    {
+        StdoutToStderr quiet;
+        if (cid_group_create(ids.data(), (int)ids.size(), &g.group) != CID_OK) die("cannot open %zu GPUs: %s", ids.size(), cid_last_error());
+    }
     if (cid_group_ctx(g.group, 0, &g.ctx) != CID_OK) die("%s", cid_last_error());
     int rccl = 0;
     cid_group_uses_rccl(g.group, &rccl);
@@ -166,7 +189,7 @@ void release(Gpus &g, Bigsi &b) {
     for (cid_index *ix : g.replicas)
         if (ix && ix != b.index) cid_index_destroy(ix);
     if (b.index) cid_index_destroy(b.index);
-    if (g.group) cid_group_destroy(g.group);   // owns the contexts
+    if (g.group) { StdoutToStderr quiet; cid_group_destroy(g.group); }   // owns the contexts
     else cid_ctx_destroy(g.ctx);
 }
 

@@ -267,7 +267,10 @@ int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, c
  *      (several ranks on one GPU — RCCL refuses that) or COLORID_REDUCE=host is set, the 24*n_colors bytes per rank are summed
  *      through the host instead.  Perfect search ANDs the ranks' words on the host (RCCL has no bitwise reduction); read_id
  *      needs no exchange, its rows are concatenated in input order.  Results are identical to the single-GPU calls.
- *      A group and its ranks' contexts are used from one host thread at a time (the calls run one thread per rank inside). ---- */
+ *      A group and its ranks' contexts are used from one host thread at a time (the calls run one thread per rank inside).
+ *      The library never redirects a file descriptor: RCCL may print its version banner (and NCCL_DEBUG output) to stdout while
+ *      cid_group_create / cid_group_destroy make and free the communicators — never during a search; a host that prints result
+ *      rows to stdout points fd 1 elsewhere around those two calls (colorid's CLI does, host/main.cpp). ---- */
 typedef struct cid_group cid_group;
 int cid_group_create(const int *device_ids, int n_devices, cid_group **out);
 int cid_group_size(const cid_group *, int *n_ranks);
@@ -317,13 +320,15 @@ int cid_group_search_perfect_parts(cid_group *, cid_index *const *replicas, cons
 
 /* ---- colour stripes over a group (BASELINE configs[4]): rank r holds the colours [base_r, base_{r+1}) of EVERY row —
  *      an index larger than one GPU's HBM.  Every rank sees every query k-mer / read; per call ONE exchange: the packed per-k-mer
- *      facts summed (RCCL all-reduce, 4 bytes per k-mer), the perfect search's / read_id's zero-row masks ANDed (peer copies).
+ *      facts summed (RCCL all-reduce, 4 bytes per k-mer), the perfect search's / read_id's zero-row masks ANDed on every rank
+ *      (RCCL all-gather + a local AND; when device ids repeat both reductions run as a reduce-scatter / all-gather of peer copies
+ *      on the ranks' own streams — no rank is a funnel).
  *      `stripes` = n_ranks handles, stripes[r] made from rank r's ctx; all but the last hold whole 64-colour words.
  *   create: balanced runs of 64-colour words (CID_ERR_INVALID when there are fewer words than ranks); fill with _put_records (the
  *      records of the whole .bxi: every rank keeps its own words) or _put_rows, then cid_index_finalize each stripe; destroy each
  *      with cid_index_destroy.  The call families mirror cid_group_search_* / cid_group_readid_*; outputs have n_colors_total
  *      entries (W32_total words), the sparse report's colours are global (no-hits entry = n_colors_total, last in its read).
- *      read_id handles reads that fit a wave's LDS and stripes of <= 8192 colours (CID_ERR_UNSUPPORTED otherwise). ---- */
+ *      read_id takes reads of any length and stripes of any width (routed per stripe as cid_readid_stripe_zero / _count do). ---- */
 int cid_group_stripes_create(cid_group *, uint64_t bloom_size, uint32_t num_hash, uint32_t k_size, uint32_t n_colors_total, int hash_variant,
                              cid_index **stripes /* n_ranks */);
 int cid_group_stripes_base(const cid_group *, cid_index *const *stripes, uint32_t *colour_base /* n_ranks + 1 */);

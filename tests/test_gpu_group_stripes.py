@@ -236,6 +236,11 @@ def test_cli_placement_striped_equals_single_gpu(orc, tmp_path):
         cli("read_id", "-b", pre + ".bxi", "-q", *q, "-n", str(tmp_path / f"str_{tag}"), "-c", "700", "--devices", "0,0,0", "--placement", "striped")
         assert open(tmp_path / f"one_{tag}_reads.txt").read() == open(tmp_path / f"str_{tag}_reads.txt").read()
         assert open(tmp_path / f"one_{tag}_counts.txt").read() == open(tmp_path / f"str_{tag}_counts.txt").read()
+        # the zero-row masks through RCCL (ncclAllGather + local AND on every rank) with one rank: what N distinct GPUs take
+        _, err = cli("read_id", "-b", pre + ".bxi", "-q", *q, "-n", str(tmp_path / f"rccl_{tag}"), "-c", "700", "--devices", "0", "--placement", "striped",
+                     env={"COLORID_REDUCE": "rccl"})
+        assert "with RCCL all-reduce" in err
+        assert open(tmp_path / f"one_{tag}_reads.txt").read() == open(tmp_path / f"rccl_{tag}_reads.txt").read()
     # more ranks than 64-colour words: refused with the reason
     p = subprocess.run([BIN, *cases["perfect"], "--devices", "0,0,0,0,0", "--placement", "striped"], capture_output=True, text=True)
     assert p.returncode != 0 and "fewer than the 5 ranks" in p.stderr
