@@ -113,7 +113,7 @@ SIGNATURES = {
     "cid_group_stripes_search_perfect_set": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.POINTER(C.c_int)]),
     "cid_group_stripes_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,
                                                         C.POINTER(C.c_uint64)]),
-    "cid_tune": (C.c_int, [C.c_char_p, C.c_long]),
+    "cid_ctx_tune": (C.c_int, [vp, C.c_char_p, C.c_long]),
     "cid_timer_start": (C.c_int, [vp]),
     "cid_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
 }
@@ -125,6 +125,21 @@ class CidError(RuntimeError):
         self.code = code
 
 
+def open_library(path):
+    """A configured handle on one build of the library (the shipped one, or libcolorid_hip_tune.so for the A/B tests and tools)."""
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        if path != os.path.join(_HERE, "libcolorid_hip.so") and not hasattr(lib, name):
+            continue  # an older build loaded on purpose for an A/B measurement
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+TUNE_LIB_PATH = os.path.join(_HERE, "libcolorid_hip_tune.so")   # `make -C colorid_amd/csrc tune`: + the two rejected schedulings
+
+
 def load_library():
     """Return the loaded C-ABI library; raise if it has not been built (no fallback exists)."""
     global _LIB
@@ -134,15 +149,8 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  colorid_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("COLORID_HIP_LIB") and not hasattr(lib, name):
-            continue  # an older build loaded on purpose for an A/B measurement
-        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
-        fn.restype = res
-        fn.argtypes = args
-    _LIB = lib
-    return lib
+    _LIB = open_library(LIB_PATH)
+    return _LIB
 
 
 def check(rc):

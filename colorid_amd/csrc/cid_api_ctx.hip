@@ -1,0 +1,249 @@
+// C ABI of libcolorid_hip.so (see include/colorid_hip.h), part 1: errors, contexts and their scratch memory, per-context tunables,
+// warm-up and timers.  Host-side plumbing only — there is no CPU compute path in this library.
+#include "cid_api_common.hpp"
+
+using cid::fail;
+using namespace cid::slots;
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+namespace cid {
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int ctx_alloc(cid_ctx *c, size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    int best = -1;   // the smallest idle block that fits without wasting more than half of itself
+    for (size_t i = 0; i < c->blocks.size(); ++i) {
+        const cid_ctx::Block &b = c->blocks[i];
+        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20) && (best < 0 || b.bytes < c->blocks[best].bytes)) best = (int)i;
+    }
+    if (best >= 0) {
+        c->blocks[best].used = true;
+        c->idle_bytes -= c->blocks[best].bytes;
+        *out = c->blocks[best].p;
+        return CID_OK;
+    }
+    const size_t want = bytes + bytes / 8;   // batches vary a little in size: leave room for the next one
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    size_t got = want;
+    if (e != hipSuccess) {   // give the idle blocks back and ask for exactly what is needed
+        (void)hipGetLastError();
+        for (size_t i = 0; i < c->blocks.size();) {
+            if (!c->blocks[i].used) { (void)hipFree(c->blocks[i].p); c->blocks.erase(c->blocks.begin() + (long)i); }
+            else ++i;
+        }
+        c->idle_bytes = 0;
+        got = bytes;
+        e = hipMalloc(&p, got);
+        if (e != hipSuccess) return fail(CID_ERR_NOMEM, "hipMalloc(%zu): %s", got, hipGetErrorString(e));
+    }
+    c->blocks.push_back(cid_ctx::Block{p, got, true});
+    *out = p;
+    return CID_OK;
+}
+void ctx_free(cid_ctx *c, void *p) {
+    if (!p) return;
+    constexpr size_t kMaxIdle = 64ull << 30;   // of 288 GB; beyond that blocks really go back
+    for (size_t i = 0; i < c->blocks.size(); ++i) {
+        if (c->blocks[i].p != p) continue;
+        if (c->idle_bytes + c->blocks[i].bytes > kMaxIdle) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(p);
+            c->blocks.erase(c->blocks.begin() + (long)i);
+        } else {
+            c->blocks[i].used = false;
+            c->idle_bytes += c->blocks[i].bytes;
+        }
+        return;
+    }
+    (void)hipFree(p);   // not one of ours
+}
+int ctx_device(const cid_ctx *c) { return c->device; }
+hipStream_t ctx_stream(const cid_ctx *c) { return c->stream; }
+int ctx_order_bits(const cid_ctx *c) { return c->tune.order_bits; }
+
+int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
+    // a started cid_bgzf_inflate batch owns these four slots (and the pinned arena) until its _finish
+    if (c->inflate.open && (s == S_KMERS || s == S_MISC || s == S_BASES || s == S_FREQ))
+        return fail(CID_ERR_STATE, "a cid_bgzf_inflate_start on this ctx is waiting for its _finish: this call would overwrite its buffers");
+    if (bytes == 0) bytes = 16;
+    if (c->slot_bytes[s] < bytes) {
+        if (c->slot[s]) HIP_TRY(hipFree(c->slot[s]));
+        c->slot[s] = nullptr;
+        c->slot_bytes[s] = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&c->slot[s], want);
+        if (e != hipSuccess) return fail(CID_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        c->slot_bytes[s] = want;
+    }
+    *out = c->slot[s];
+    return CID_OK;
+}
+static const bool kUsePin = getenv("CID_PIN_STAGING") ? atoi(getenv("CID_PIN_STAGING")) != 0 : true;
+uint8_t *pin_reserve(cid_ctx *c, size_t bytes, size_t cap) {
+    if (!kUsePin || bytes > cap) return nullptr;
+    if (c->inflate.open) return nullptr;   // the arena holds a started inflate batch's text and status: callers copy without it
+    if (bytes <= c->pin_bytes) return c->pin;
+    if (c->pin) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
+    size_t want = bytes + bytes / 2;
+    if (want < (16u << 20)) want = 16u << 20;
+    if (want > cap) want = cap;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    c->pin = (uint8_t *)p;
+    c->pin_bytes = want;
+    return c->pin;
+}
+}  // namespace cid
+
+extern "C" {
+
+const char *cid_last_error(void) { return g_err; }
+int cid_abi_version(void) { return 3; }
+
+int cid_device_count(int *n) {
+    if (!n) return fail(CID_ERR_INVALID, "null out");
+    *n = 0;
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) { *n = 0; return fail(CID_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return CID_OK;
+}
+
+int cid_ctx_create(int device_id, cid_ctx **out) {
+    if (!out) return fail(CID_ERR_INVALID, "null out");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(CID_ERR_HIP, "no HIP device (this library has no CPU path)");
+    if (device_id < 0 || device_id >= n) return fail(CID_ERR_INVALID, "device %d of %d", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    if (const char *sy = getenv("COLORID_SYNC")) {   // how host threads wait for the device (before the device's first use): spin | yield | block
+        const unsigned f = !strcmp(sy, "spin") ? hipDeviceScheduleSpin : !strcmp(sy, "yield") ? hipDeviceScheduleYield : !strcmp(sy, "block")
+            ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        (void)hipSetDeviceFlags(f);   // (refused once the device is active: the first context decides)
+    }
+    cid_ctx *c = new (std::nothrow) cid_ctx();
+    if (!c) return fail(CID_ERR_NOMEM, "ctx");
+    c->device = device_id;
+    if (const char *e = getenv("CID_SEARCH_UNROLL")) c->tune.search_unroll = atoi(e) == 1 ? 1 : 2;
+    if (const char *e = getenv("CID_READID_PACKED_TABLE")) c->tune.readid_packed_table = atoi(e) != 0;
+#ifdef CID_TUNE_BUILD
+    if (const char *e = getenv("CID_SEARCH_PERSIST")) c->tune.search_persist = atoi(e) != 0;
+    if (const char *e = getenv("CID_SEARCH_MIXED")) c->tune.search_mixed = atoi(e) != 0;
+#endif
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(CID_ERR_HIP, "stream/event creation failed");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return CID_OK;
+}
+
+int cid_ctx_set_stream(cid_ctx *c, void *hip_stream) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return CID_OK;
+}
+
+int cid_ctx_synchronize(cid_ctx *c) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CID_OK;
+}
+
+void cid_ctx_destroy(cid_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < S_COUNT; ++s)
+        if (c->slot[s]) (void)hipFree(c->slot[s]);
+    for (const cid_ctx::Block &b : c->blocks) (void)hipFree(b.p);   // includes the sparse read_id result
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_copied[i]) (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+    }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->pin) (void)hipHostFree(c->pin);
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------ tunables + timing
+
+// Measurement / test switches of ONE context (see cid_tunables): no process-wide state, two contexts may differ.
+int cid_ctx_tune(cid_ctx *c, const char *name, long value) {
+    if (!c || !name) return fail(CID_ERR_INVALID, "null argument");
+    if (!strcmp(name, "search_unroll")) {
+        if (value != 1 && value != 2) return fail(CID_ERR_INVALID, "search_unroll is 1 or 2");
+        c->tune.search_unroll = (int)value;
+        return CID_OK;
+    }
+    if (!strcmp(name, "readid_packed_table")) { c->tune.readid_packed_table = value != 0; return CID_OK; }
+    if (!strcmp(name, "order_bits")) {
+        if (value < 0 || value > 32) return fail(CID_ERR_INVALID, "order_bits 0..32");
+        c->tune.order_bits = (int)value;
+        return CID_OK;
+    }
+    if (!strcmp(name, "search_persist") || !strcmp(name, "search_mixed")) {
+#ifdef CID_TUNE_BUILD
+        (name[7] == 'p' ? c->tune.search_persist : c->tune.search_mixed) = value != 0;
+        return CID_OK;
+#else
+        return fail(CID_ERR_UNSUPPORTED, "'%s' is a rejected scheduling of k_search_count kept for reproducibility: its kernels are only in a "
+                    "`make TUNE=1` build (libcolorid_hip_tune.so)", name);
+#endif
+    }
+    return fail(CID_ERR_INVALID, "unknown tunable '%s'", name);
+}
+
+// The runtime loads a translation unit's device code on the first launch of one of its kernels — ~60 ms for the read_id kernels,
+// paid inside the first cid_readid_count* call.  This call pays it ahead of time and may run on another host thread than the one
+// using the ctx (it touches no stream, no ctx state): the CLI runs it beside the index load.
+int cid_warmup(cid_ctx *c, unsigned what) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    if (what & CID_WARM_READID) HIP_TRY(cid::warm_readid());
+    if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_search());
+    if (what & (CID_WARM_READID | CID_WARM_SEARCH)) HIP_TRY(cid::warm_kmerset());
+    if (what & CID_WARM_INFLATE) HIP_TRY(cid::warm_inflate());
+    return CID_OK;
+}
+
+int cid_timer_start(cid_ctx *c) {
+    if (!c) return fail(CID_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return CID_OK;
+}
+
+int cid_timer_stop_ms(cid_ctx *c, float *elapsed_ms) {
+    if (!c || !elapsed_ms) return fail(CID_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return CID_OK;
+}
+
+}  // extern "C"

@@ -97,9 +97,15 @@ int cid_group_create(const int *device_ids, int n_devices, cid_group **out) {
     // RCCL when every rank has its own GPU (one rank too, if asked for: COLORID_REDUCE=rccl exercises the plumbing on one GPU)
     const char *mode = getenv("COLORID_REDUCE");
     const bool want = mode ? strcmp(mode, "rccl") == 0 : n_devices > 1;
-    if (want && mode && strcmp(mode, "rccl") == 0 && !distinct) { cid_group_destroy(g); return fail(CID_ERR_INVALID, "COLORID_REDUCE=rccl needs distinct devices"); }
+    if (want && mode && strcmp(mode, "rccl") == 0 && !distinct) {
+        cid_group_destroy(g);
+        return fail(CID_ERR_INVALID, "COLORID_REDUCE=rccl needs distinct devices");
+    }
     if (want && distinct) {
-        if (!g->rccl.load()) { cid_group_destroy(g); return fail(CID_ERR_HIP, "cannot load librccl.so (set COLORID_REDUCE=host to sum through the host): %s", dlerror()); }
+        if (!g->rccl.load()) {
+            cid_group_destroy(g);
+            return fail(CID_ERR_HIP, "cannot load librccl.so (set COLORID_REDUCE=host to sum through the host): %s", dlerror());
+        }
         g->comms.assign(n_devices, nullptr);
         const int e = g->rccl.CommInitAll(g->comms.data(), n_devices, device_ids);
         if (e) { g->comms.clear(); const char *m = g->rccl.GetErrorString(e); cid_group_destroy(g); return fail(CID_ERR_HIP, "ncclCommInitAll: %s", m); }
@@ -351,7 +357,8 @@ int cid_group_readid_count_sparse(cid_group *g, cid_index *const *replicas, cons
         g->sp_rows[r] = nr; g->sp_entries[r] = 0;
         // the shard re-based to its own offsets (every entry checked before seq_off is read through it)
         for (size_t i = lo; i < hi; ++i)
-            if (read_seq0[i] > read_seq0[i + 1] || read_seq0[i + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 not monotonic or past n_seqs at read %zu", i);
+            if (read_seq0[i] > read_seq0[i + 1] || read_seq0[i + 1] > n_seqs) return fail(CID_ERR_INVALID,
+                "read_seq0 not monotonic or past n_seqs at read %zu", i);
         const uint64_t s0 = read_seq0[lo], s1 = read_seq0[hi];
         std::vector<uint64_t> so(s1 - s0 + 1), r0(nr + 1);
         for (size_t i = 0; i <= s1 - s0; ++i) {

@@ -66,7 +66,8 @@ extern "C" {
 int cid_group_kmerset_create(cid_group *g, uint32_t k_size, cid_group_kmerset **out) {
     if (!g || !out) return fail(CID_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (k_size == 0 || k_size > 32) return fail(CID_ERR_UNSUPPORTED, "the group k-mer set packs k-mers into 2-bit codes: k_size 1..32 (count larger k on one GPU)");
+    if (k_size == 0 || k_size > 32) return fail(CID_ERR_UNSUPPORTED,
+                                                "the group k-mer set packs k-mers into 2-bit codes: k_size 1..32 (count larger k on one GPU)");
     cid_group_kmerset *s = new (std::nothrow) cid_group_kmerset();
     if (!s) return fail(CID_ERR_NOMEM, "group k-mer set");
     s->g = g; s->k = k_size;
@@ -187,7 +188,8 @@ int cid_group_kmerset_finalize(cid_group_kmerset *s, uint64_t *n_distinct) {
             });
             // (all copies have landed before any rank's old arrays are replaced)
             if (rc == CID_OK)
-                rc = for_each_rank(g, [&](int j) { return cid::kmerset_assign_merged(s->part[j], (const uint64_t *)in_codes[j], (const uint32_t *)in_counts[j], total[j]); });
+                rc = for_each_rank(g, [&](int j) { return cid::kmerset_assign_merged(s->part[j], (const uint64_t *)in_codes[j],
+                    (const uint32_t *)in_counts[j], total[j]); });
             for (int j = 0; j < n; ++j) {
                 if (in_codes[j]) cid::ctx_free(g->ctx[j], in_codes[j]);
                 if (in_counts[j]) cid::ctx_free(g->ctx[j], in_counts[j]);

@@ -59,17 +59,20 @@ int check_stripes(const cid_group *g, cid_index *const *stripes, Stripes &st) {
             stripes[r]->mod.flags != stripes[0]->mod.flags)
             return fail(CID_ERR_INVALID, "stripe %d differs from stripe 0 in shape", r);
         if (stripes[r]->m_size) return fail(CID_ERR_UNSUPPORTED, "minimizer (.mxi) indexes are not striped");
-        if (r + 1 < st.n && stripes[r]->n_colors % 64u) return fail(CID_ERR_INVALID, "stripe %d: %u colours, not whole 64-colour words", r, stripes[r]->n_colors);
+        if (r + 1 < st.n && stripes[r]->n_colors % 64u) return fail(CID_ERR_INVALID, "stripe %d: %u colours, not whole 64-colour words", r,
+                                                                    stripes[r]->n_colors);
         st.base[r + 1] = st.base[r] + stripes[r]->n_colors;
     }
     st.total = st.base[st.n];
-    if (st.total > (1u << 20)) return fail(CID_ERR_UNSUPPORTED, "%u colours: the packed per-k-mer fact holds colour + 1 in 26 bits, stripes stop at 2^20", st.total);
+    if (st.total > (1u << 20)) return fail(CID_ERR_UNSUPPORTED,
+                                           "%u colours: the packed per-k-mer fact holds colour + 1 in 26 bits, stripes stop at 2^20", st.total);
     if (st.n > 31) return fail(CID_ERR_UNSUPPORTED, "%d ranks: the summed per-k-mer facts hold at most 31", st.n);
     return CID_OK;
 }
 
 hipError_t copy_between(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t stream) {
-    return dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream) : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream);
+    return dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream) : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev,
+        bytes, stream);
 }
 
 int group_events(cid_group *g) {
@@ -159,8 +162,10 @@ int reduce_u32(cid_group *g, uint32_t *const *d_bufs, size_t count, bool sum, bo
             if (e != hipSuccess) return fail_sync(fail(CID_ERR_HIP, "stripe reduction (rank %d <- rank %d): %s", r, p, hipGetErrorString(e)));
             ++slot;
         }
-        if (sum) hipLaunchKernelGGL((k_fold_u32<true, false>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, d_bufs[r] + lo[r], (const uint32_t *)tmp[r], (uint32_t)(n - 1), (uint64_t)ne, (uint64_t)ne);
-        else hipLaunchKernelGGL((k_fold_u32<false, false>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, d_bufs[r] + lo[r], (const uint32_t *)tmp[r], (uint32_t)(n - 1), (uint64_t)ne, (uint64_t)ne);
+        if (sum) hipLaunchKernelGGL((k_fold_u32<true, false>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, d_bufs[r] + lo[r],
+                                    (const uint32_t *)tmp[r], (uint32_t)(n - 1), (uint64_t)ne, (uint64_t)ne);
+        else hipLaunchKernelGGL((k_fold_u32<false, false>), dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, d_bufs[r] + lo[r],
+                                (const uint32_t *)tmp[r], (uint32_t)(n - 1), (uint64_t)ne, (uint64_t)ne);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(g->ev_reduced[r], c->stream);
         if (e != hipSuccess) return fail_sync(fail(CID_ERR_HIP, "stripe reduction (rank %d): %s", r, hipGetErrorString(e)));
@@ -339,7 +344,8 @@ int stripes_search_perfect(cid_group *g, cid_index *const *stripes, const Query 
     rc = cid::slot_reserve(c0, S_MISC, 16, &d_flag); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d_flag, 0, 4, c0->stream));
     const uint32_t seeds = stripes[0]->n_hash >= 32 ? ~0u : ((1u << stripes[0]->n_hash) - 1u);
-    hipLaunchKernelGGL(k_any_masked, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c0->stream, (const uint32_t *)d_zero[0], (uint64_t)K, seeds, (int *)d_flag);
+    hipLaunchKernelGGL(k_any_masked, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, c0->stream, (const uint32_t *)d_zero[0], (uint64_t)K, seeds,
+                       (int *)d_flag);
     HIP_TRY(hipGetLastError());
     int miss = 0;
     HIP_TRY(hipMemcpyAsync(&miss, d_flag, 4, hipMemcpyDeviceToHost, c0->stream));

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(kBlock) void k_insert_kmers(InsertParams p) {
             wave_lds_fence();
             if (have) {
                 const uint32_t c = p.colour_of_kmer ? p.colour_of_kmer[first + lane] : p.colour;
-                if (c < p.n_colors) xxh3_seeds(mimg, (uint32_t)lane * p.m_size, p.m_size, p.n_hash, HashSel::of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
+                if (c < p.n_colors)
+                    xxh3_seeds(mimg, (uint32_t)lane * p.m_size, p.m_size, p.n_hash, HashSel::of(p.mod), [&](uint32_t, uint64_t h) { set_bit(c, h); });
             }
             continue;
         }

@@ -118,7 +118,8 @@ __device__ __forceinline__ int decode_sym(BitReader &br, const uint16_t *tab, ui
 
 __constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
+                                         6145, 8193, 12289, 16385, 24577};
 __constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
@@ -146,7 +147,8 @@ struct LaneLds {
 __device__ void decode_run(BitReader &br, Decoder &d, const LaneLds &L, uint8_t *img, uint32_t out_len, uint32_t data_len) {
     uint16_t *const s_lit = L.lit, *const s_dist = L.dist, *const s_lcnt = L.lcnt, *const s_lsym = L.lsym, *const s_dcnt = L.dcnt, *const s_dsym = L.dsym;
     uint8_t *const s_lens = L.lens;
-    const uint32_t run_end = br.consumed_bytes() + 400;   // a step starts below this mark; the longest one (a dynamic block header) takes < 600 bytes, and the ring holds >= 1024 ahead (or the stream's end)
+    // a step starts below this mark; the longest one (a dynamic block header) takes < 600 bytes, and the ring holds >= 1024 ahead (or the stream's end)
+    const uint32_t run_end = br.consumed_bytes() + 400;
     while (d.phase != 3 && d.status == ST_OK && br.consumed_bytes() < run_end) {
         br.refill();
         if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
                         } else {
                             uint32_t w[4];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) w[k] = p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
+                            for (int k = 0; k < 4; ++k)
+                                w[k] = p[4 * k] | ((uint32_t)p[4 * k + 1] << 8) | ((uint32_t)p[4 * k + 2] << 16) | ((uint32_t)p[4 * k + 3] << 24);
                             v = make_uint4(w[0], w[1], w[2], w[3]);
                         }
                     } else if (o < dl) {
@@ -448,11 +451,13 @@ extern "C" int cid_bgzf_inflate_start(cid_ctx *c, const uint8_t *members, size_t
     c->inflate.n_members = n_members; c->inflate.text_bytes = text_bytes; c->inflate.staged = false;
     if (n_members == 0) { c->inflate.open = true; return CID_OK; }
     if (!members || !member_off || !member_len || !text_off || !text_len) return fail(CID_ERR_INVALID, "null argument");
-    if (n_bytes >= (1ull << 32) || text_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "a batch of BGZF members is limited to 4 GiB");
+    if (n_bytes >= (1ull << 32) || text_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED,
+        "a batch of BGZF members is limited to 4 GiB");
     std::vector<cid::BgzfMember> mem(n_members);
     for (size_t i = 0; i < n_members; ++i) {
         if ((uint64_t)member_off[i] + member_len[i] > n_bytes) return fail(CID_ERR_INVALID, "member %zu lies outside the batch", i);
-        if (text_len[i] > 65536u || (uint64_t)text_off[i] + text_len[i] > text_bytes) return fail(CID_ERR_INVALID, "member %zu: text range outside the output", i);
+        if (text_len[i] > 65536u || (uint64_t)text_off[i] + text_len[i] > text_bytes) return fail(CID_ERR_INVALID,
+            "member %zu: text range outside the output", i);
         mem[i] = cid::BgzfMember{member_off[i], member_len[i], text_off[i], text_len[i]};
     }
     HIP_TRY(hipSetDevice(c->device));

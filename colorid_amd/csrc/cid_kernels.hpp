@@ -1,4 +1,4 @@
-// Kernel parameter blocks and launchers shared by the kernel files (cid_search / cid_readid / cid_index .hip) and the ABI (cid_api.hip, cid_kmerset.hip).
+// Kernel parameter blocks and launchers shared by the kernel files (cid_search / cid_readid / cid_index .hip) and the ABI (cid_api_*.hip, cid_kmerset.hip).
 #pragma once
 #include "cid_device.hpp"
 

@@ -18,8 +18,6 @@
 
 namespace cid {
 
-int g_order_bits = 0;
-
 struct Segment {  // consecutive windows of one sequence: window w starts at base_off + w*stride
     uint64_t base_off;  // offset of the first window's first base in `bases`
     uint64_t out_off;   // where the window codes go
@@ -219,7 +217,8 @@ int compact(cid_kmerset *ks) {
     if (ks->n_raw == 0) return CID_OK;
     hipStream_t st = cid::ctx_stream(ks->ctx);
     const size_t total = ks->n + ks->n_raw;
-    if (total >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "%zu k-mer windows and distinct k-mers in one merge (limit 2^32 - 1): add fewer sequences per set", total);
+    if (total >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED,
+                                           "%zu k-mer windows and distinct k-mers in one merge (limit 2^32 - 1): add fewer sequences per set", total);
     DevBuf<uint64_t> uniq(ks->ctx);
     DevBuf<uint32_t> agg(ks->ctx);
     DevBuf<uint64_t> d_count(ks->ctx);
@@ -261,7 +260,8 @@ int compact(cid_kmerset *ks) {
         int sat = 0;
         HIP_TRY(hipMemcpyAsync(&sat, ks->d_flags + 1, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (sat) return fail(CID_ERR_UNSUPPORTED, "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
+        if (sat) return fail(CID_ERR_UNSUPPORTED,
+                             "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
     }
     uint64_t n_runs = 0;
     HIP_TRY(hipMemcpy(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost));
@@ -310,7 +310,8 @@ int cid::kmerset_assign_merged(cid_kmerset *ks, const uint64_t *d_codes_in, cons
         HIP_TRY(hipMemcpyAsync(&sat, ks->d_flags + 1, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (sat) return fail(CID_ERR_UNSUPPORTED, "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
+        if (sat) return fail(CID_ERR_UNSUPPORTED,
+                             "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
     }
     if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
     if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
@@ -700,7 +701,8 @@ int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, 
     DevBuf<uint64_t> ovf(c), keys_sorted(c), keys_u(c), n_runs(c);
     DevBuf<unsigned long long> best(c), ovf_count(c);
     int rc;
-    if ((rc = table.alloc((size_t)C * (FL ? FL : 1))) || (rc = ovf.alloc(n)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2)) || (rc = n_runs.alloc(1))) return rc;
+    if ((rc = table.alloc((size_t)C * (FL ? FL : 1))) || (rc = ovf.alloc(n)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2))
+        || (rc = n_runs.alloc(1))) return rc;
     HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)C * (FL ? FL : 1) * 4, st));
     HIP_TRY(hipMemsetAsync(best.p, 0, (size_t)C * 8, st));
     HIP_TRY(hipMemsetAsync(ovf_count.p, 0, 16, st));
@@ -1154,7 +1156,7 @@ int cid_kmerset_clean(cid_kmerset *ks, uint64_t t) {
 }
 
 // Device arrays in, device arrays out (asynchronous on the ctx stream): the n k-mers (2-bit codes + multiplicities) grouped by the
-// 128-byte index line of their first row (cid_tune "order_bits" > 0: by that many leading bits of its position instead).  The
+// 128-byte index line of their first row (cid_ctx_tune "order_bits" > 0: by that many leading bits of its position instead).  The
 // codes and the multiplicities each ride through their own stable radix sort on that key (same permutation), restricted to the
 // key's significant bits: no index array, no random gather.
 int cid_order_codes_for_index_dev(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n,
@@ -1168,7 +1170,7 @@ int cid_order_codes_for_index_dev(cid_ctx *c, const cid_index *ix, const uint64_
     const uint32_t rs = cid::index_rs(ix);
     uint32_t line_shift = 0;
     while ((rs << line_shift) < 16) ++line_shift;   // rows per 128-byte line = 16 / rs
-    const uint32_t bucket_bits = (uint32_t)cid::g_order_bits;
+    const uint32_t bucket_bits = (uint32_t)cid::ctx_order_bits(c);
     const uint64_t max_key = bucket_bits ? ((1ull << bucket_bits) - 1) : ((cid::index_mod(ix).m - 1) >> line_shift);
     unsigned end_bit = 1;
     while (end_bit < 32 && (max_key >> end_bit)) ++end_bit;

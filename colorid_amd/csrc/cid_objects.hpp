@@ -1,4 +1,4 @@
-// The objects behind the ABI's opaque handles, shared by the translation units that implement them (cid_api.hip, cid_group.hip).
+// The objects behind the ABI's opaque handles, shared by the translation units that implement them (cid_api_*.hip, cid_group*.hip).
 #pragma once
 #include <vector>
 
@@ -6,12 +6,25 @@
 
 namespace cid {
 namespace slots {
-enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_REDO, S_QUEUE, S_ZSTART, S_COUNT };
+enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES, S_SEQOFF, S_READ0, S_REPORT, S_NK, S_ROUTE, S_REDO, S_QUEUE,
+           S_ZSTART, S_COUNT };
 }
 }  // namespace cid
 
+// Per-context tunables (cid_ctx_tune): measurement and test switches, read once from the environment when the ctx is made.
+// Defaults are the shipped configuration; none of them changes a result.
+struct cid_tunables {
+    int search_unroll = 2;            // k_search_count on 64- / 128-byte rows: sub-passes whose row loads are issued together (2: -1.5 %)
+    bool readid_packed_table = true;  // k_readid: 8-byte k-mer-set slots where they buy a sixth wave per SIMD (paired reads, k <= 31)
+    int order_bits = 0;               // cid_kmerset_order_for_index: 0 = by the first row's 128-byte line, b = by its b leading bits
+    // the two measured-and-rejected schedulings of k_search_count; only a `make TUNE=1` build contains their kernels
+    bool search_persist = false;      // persistent grid, one work queue per XCD
+    bool search_mixed = false;        // 32-byte rows: each k-mer's last row through the scalar cache
+};
+
 struct cid_ctx {
     int device = 0;
+    cid_tunables tune;
     int n_cu = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -29,7 +42,11 @@ struct cid_ctx {
     uint8_t *pin = nullptr;
     size_t pin_bytes = 0;
     // a cid_bgzf_inflate_start waiting for its _finish
-    struct { size_t n_members = 0, text_bytes = 0, pin_text = 0, pin_status = 0; void *d_out = nullptr, *d_st = nullptr; bool open = false, staged = false; } inflate;
+    struct {
+        size_t n_members = 0, text_bytes = 0, pin_text = 0, pin_status = 0;
+        void *d_out = nullptr, *d_st = nullptr;
+        bool open = false, staged = false;
+    } inflate;
     // second stream + events for the host-pointer entry points: the H2D copy of chunk i+1 runs beside the kernel of chunk i
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};

@@ -633,7 +633,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
                     xxh3_seeds_from(BaseReader{p.bases + (e >> 1), k, (uint32_t)(e & 1ull), p.upper}, k, n, HashSel::of(p.mod),
                                     [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
                 } else {
-                    xxh3_seeds_from(CodeReader{rev_fields(e, k)}, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+                    xxh3_seeds_from(CodeReader{rev_fields(e, k)}, k, n, HashSel::of(p.mod),
+                                    [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
                 }
             }
             const uint64_t dmask = __ballot(have);
@@ -736,10 +737,13 @@ static hipError_t launch_readid_packed(const ReadIdParams &p, int wpb, int grid,
 hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t stream) {
     const int grid = (int)((p.n_reads + p.reads_per_block - 1) / p.reads_per_block);
     if (p.zero_acc || p.zero_in)
-        return p.m_size ? launch_readid_packed_striped<true>(p, waves_per_block, grid, stream) : launch_readid_packed_striped<false>(p, waves_per_block, grid, stream);
-    const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block > 20 &&   // more waves fit a CU than the 96-VGPR build can run (5 per SIMD)
+        return p.m_size ? launch_readid_packed_striped<true>(p, waves_per_block, grid, stream) : launch_readid_packed_striped<false>(p,
+            waves_per_block, grid, stream);
+    // more waves fit a CU than the 96-VGPR build can run (5 per SIMD)
+    const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block > 20 &&
                        ((p.mod.flags >> 8) & 0xFFu) == kHashV08;
-    if (p.idx_bits) return dense && !p.m_size ? launch_readid_packed_table(p, waves_per_block, grid, stream) : hipErrorInvalidValue;   // (the host lays the 8-byte slots out only then)
+    // (the host lays the 8-byte slots out only then)
+    if (p.idx_bits) return dense && !p.m_size ? launch_readid_packed_table(p, waves_per_block, grid, stream) : hipErrorInvalidValue;
     if (p.m_size)
         return dense ? launch_readid_packed<true, true>(p, waves_per_block, grid, stream)
                      : launch_readid_packed<true, false>(p, waves_per_block, grid, stream);

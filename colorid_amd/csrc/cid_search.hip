@@ -138,6 +138,7 @@ __global__ __launch_bounds__(kBlock, UNROLL == 1 ? 4 : 3) void k_search_count(Se
             V16 a{0, 0};
             uint32_t zm;
             bool mixed = false;
+#ifdef CID_TUNE_BUILD
             if constexpr (LOG_LPR == 1 && !NARROW) {   // 32-byte rows: the last row of every k-mer through the scalar cache
                 if (p.mixed && p.n_hash >= 2 && p.n_hash <= 4) {
                     mixed = true;
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(kBlock, UNROLL == 1 ? 4 : 3) void k_search_count(Se
                     if (live) a = m;
                 }
             }
+#endif
             if (!mixed && live && col_live) a = gather_and<NARROW, false>(p.mat, p.rs, ridx, kk, col_word, p.n_hash, zm);
             after_gather(kk, live, a);
         }
@@ -455,10 +457,12 @@ hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
     const size_t shmem = search_smem_bytes(p);
     int grid = grid_for(p.n_kmers, p.tiles_per_block);
     if (grid == 0) return hipSuccess;
+#ifdef CID_TUNE_BUILD   // the rejected schedulings exist only in libcolorid_hip_tune.so
     if (p.queues) {
         if (p.persist_grid < grid) grid = p.persist_grid;
         CID_LAUNCH_BY_LAYOUT2(k_search_count, log_lpr, narrow, true, grid, shmem, stream, p);
     }
+#endif
     // rows of 64 and 128 bytes (a sub-pass covers only 16 or 8 k-mers): two sub-passes' row loads in flight per lane, -1.5 %
     // (tools/exp_unroll.py); wider rows gain nothing from it
     if (p.unroll == 2 && !narrow && log_lpr == 2) return launch_one(k_search_count<2, false, false, 2>, grid, shmem, stream, p);
@@ -466,6 +470,7 @@ hipError_t launch_search_count(const SearchParams &p, hipStream_t stream) {
     CID_LAUNCH_BY_LAYOUT2(k_search_count, log_lpr, narrow, false, grid, shmem, stream, p);
 }
 
+#ifdef CID_TUNE_BUILD
 // how many blocks of the persistent kernel are resident at once (per CU, by LDS and registers)
 int search_count_blocks_per_cu(const SearchParams &p) {
     const size_t shmem = search_smem_bytes(p);
@@ -489,6 +494,7 @@ int search_count_blocks_per_cu(const SearchParams &p) {
     }
     return nb;
 }
+#endif
 
 hipError_t launch_search_perfect(const SearchParams &p, hipStream_t stream) {
     if (p.rs > 128) {

@@ -14,8 +14,8 @@ def _p(a):
 
 
 class Context:
-    def __init__(self, device_id=0):
-        self.lib = load_library()
+    def __init__(self, device_id=0, lib=None):
+        self.lib = lib if lib is not None else load_library()   # lib: another build of the library (_lib.open_library), A/B tests
         h = vp()
         check(self.lib.cid_ctx_create(device_id, C.byref(h)))
         self.h = h
@@ -29,6 +29,13 @@ class Context:
 
     def synchronize(self):
         check(self.lib.cid_ctx_synchronize(self.h))
+
+    def tune(self, name, value):
+        """cid_ctx_tune: a measurement / test switch of this context (include/colorid_hip.h)"""
+        rc = self.lib.cid_ctx_tune(self.h, name.encode() if isinstance(name, str) else name, int(value))
+        if rc != 0:
+            from ._lib import CidError
+            raise CidError(rc, self.lib.cid_last_error().decode(errors="replace"))
 
     def timer_start(self):
         check(self.lib.cid_timer_start(self.h))

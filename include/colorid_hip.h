@@ -351,13 +351,18 @@ int cid_group_stripes_readid_count_sparse(cid_group *, cid_index *const *stripes
                                           uint32_t *n_kmers, uint8_t *status, uint64_t *n_entries);
 
 /* ---- measurement helpers (bench only): HIP-event timing on the ctx stream ---- */
-/* process-wide tunables for A/B measurements (tools/, bench.py); unknown names give CID_ERR_INVALID:
- *   "search_persist"  0/1  k_search_count as a persistent grid with one work queue per XCD
- *   "search_mixed"    0/1  k_search_count on 32-byte rows: each k-mer's last row through the scalar cache (64-byte lines)
- *   "search_unroll"   1/2  k_search_count on 64- and 128-byte rows: sub-passes whose row loads are issued together (default 2)
- *   "order_bits"      0..32  cid_kmerset_order_for_index groups by this many leading bits of the first row's position
- *                     (0 = by its exact 128-byte line) */
-int cid_tune(const char *name, long value);
+/* Measurement / test switches of ONE context (no process-wide state; read once from the environment variable named in brackets when
+ * the ctx is made).  None of them changes a result.  Unknown names give CID_ERR_INVALID:
+ *   "search_unroll"        1/2    k_search_count on 64- and 128-byte rows: sub-passes whose row loads are issued together (default 2)
+ *                                 [CID_SEARCH_UNROLL]
+ *   "readid_packed_table"  0/1    k_readid: 8-byte k-mer-set slots where they buy a sixth wave per SIMD (default 1) [CID_READID_PACKED_TABLE]
+ *   "order_bits"           0..32  cid_kmerset_order_for_index / cid_order_codes_for_index_dev group by this many leading bits of the
+ *                                 first row's position (0 = by its exact 128-byte line, the default)
+ *   "search_persist", "search_mixed"  0/1  the two measured-and-REJECTED schedulings of k_search_count (persistent grid with one work
+ *                                 queue per XCD; each k-mer's last 32-byte row through the scalar cache).  Their kernels are only in
+ *                                 libcolorid_hip_tune.so (`make -C colorid_amd/csrc tune`); the shipped library answers
+ *                                 CID_ERR_UNSUPPORTED. */
+int cid_ctx_tune(cid_ctx *, const char *name, long value);
 /* Loads the device code of the read_id and/or search kernels now instead of inside the first call that launches one of them (the
  * runtime loads a code object on first use: ~60 ms for the read_id kernels).  Touches no stream and no ctx state: it may run on
  * another host thread while the ctx loads an index (what the CLI does). */

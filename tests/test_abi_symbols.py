@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/colorid_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.cid_abi_version() == 2
+    assert lib.cid_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device():

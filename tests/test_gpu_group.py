@@ -171,8 +171,9 @@ def test_round2_entry_points_refuse_misuse(orc, hip_ctx):
     assert lib.cid_group_create(None, 2, C.byref(gh)) == -1
     assert lib.cid_group_create((C.c_int * 1)(0), 0, C.byref(gh)) == -1
     assert lib.cid_group_create((C.c_int * 1)(99), 1, C.byref(gh)) < 0 and not gh.value          # no such device
-    assert lib.cid_tune(b"no_such_knob", 1) == -1 and b"unknown tunable" in lib.cid_last_error()
-    assert lib.cid_tune(b"order_bits", 40) == -1
+    assert lib.cid_ctx_tune(hip_ctx.h, b"no_such_knob", 1) == -1 and b"unknown tunable" in lib.cid_last_error()
+    assert lib.cid_ctx_tune(hip_ctx.h, b"order_bits", 40) == -1 and lib.cid_ctx_tune(hip_ctx.h, b"search_unroll", 3) == -1
+    assert lib.cid_ctx_tune(hip_ctx.h, b"search_persist", 1) == -4 and lib.cid_ctx_tune(None, b"order_bits", 0) == -1
     rng = np.random.default_rng(3)
     oix = random_index(orc, rng, 5003, 2, 21, 70, density=0.2, zero_row_frac=0.1)
     g = colorid_amd.Group([0, 0])

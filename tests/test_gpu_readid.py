@@ -298,7 +298,7 @@ def test_readid_more_than_two_mates(orc, phage):
 @pytest.mark.parametrize("k,n_colors", [(21, 256), (27, 100), (9, 300)])
 def test_readid_set_slot_layouts_are_bit_exact(orc, hip_ctx, packed, k, n_colors):
     """k_readid's per-read k-mer set with 12-byte slots and with one u64 per slot (code << idx_bits | first window index; taken for
-    read pairs whose 12-byte table would cost the sixth wave per SIMD; cid_tune "readid_packed_table"): paired 150-bp reads with
+    read pairs whose 12-byte table would cost the sixth wave per SIMD; cid_ctx_tune "readid_packed_table"): paired 150-bp reads with
     repeats (the same k-mer in both mates: the earlier window must win), N runs, short mates — against the oracle."""
     from colorid_amd._lib import check as cid_check
     rng = np.random.default_rng(k * 100 + n_colors + packed)
@@ -318,10 +318,10 @@ def test_readid_set_slot_layouts_are_bit_exact(orc, hip_ctx, packed, k, n_colors
     reads.append([g0[100:250], g0[180:330]])                       # overlapping mates
     reads.append([(g0[300:320] * 8)[:150], (g0[300:320] * 8)[:150]])   # a 20-base period: few distinct k-mers, many windows
     hx = to_hip_index(hip_ctx, oix)
-    cid_check(hip_ctx.lib.cid_tune(b"readid_packed_table", packed))
+    hip_ctx.tune("readid_packed_table", packed)
     try:
         for d, S in ((1, 3), (1, 0), (2, 5)):
             check(oix, hx, reads, d, S)
     finally:
-        cid_check(hip_ctx.lib.cid_tune(b"readid_packed_table", 1))
+        hip_ctx.tune("readid_packed_table", 1)
     hx.close()

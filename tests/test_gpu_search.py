@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) with the oracle: bit-exact integers on the same seeded inputs.
 Covers a5 (cid_search_count) and a4 (cid_search_perfect) over row widths, hash counts, k-mer lengths,
 ragged tiles, absent rows and empty inputs; plus put_rows/get_rows round trips."""
+import os
+
 import numpy as np
 import pytest
 
@@ -340,24 +342,43 @@ def test_more_error_behaviour(orc, hip_ctx):
     hx.close()
 
 
-@pytest.mark.parametrize("tunable", [b"search_persist", b"search_mixed"])
+@pytest.fixture(scope="module")
+def tune_ctx():
+    """a context of libcolorid_hip_tune.so: the shipped library + the two rejected schedulings of k_search_count (`make tune`)"""
+    import colorid_amd
+    from colorid_amd import _lib
+    if not os.path.exists(_lib.TUNE_LIB_PATH):
+        pytest.skip("libcolorid_hip_tune.so is not built (make -C colorid_amd/csrc tune)")
+    ctx = colorid_amd.Context(0, lib=_lib.open_library(_lib.TUNE_LIB_PATH))
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("tunable", ["search_persist", "search_mixed"])
 @pytest.mark.parametrize("n_colors,n_hash", [(256, 4), (200, 3), (129, 2), (64, 4), (1024, 4)])
-def test_alternative_schedulings_are_bit_exact(orc, hip_ctx, tunable, n_colors, n_hash):
-    """The two measured-and-not-adopted variants of k_search_count stay bit-exact behind cid_tune: the persistent grid with one
-    work queue per XCD, and (32-byte rows) the last row of each k-mer fetched through the scalar cache."""
-    from colorid_amd._lib import check
+def test_alternative_schedulings_are_bit_exact(orc, hip_ctx, tune_ctx, tunable, n_colors, n_hash):
+    """The two measured-and-not-adopted variants of k_search_count stay bit-exact in the TUNE build (cid_ctx_tune): the persistent
+    grid with one work queue per XCD, and (32-byte rows) the last row of each k-mer fetched through the scalar cache.  The shipped
+    library does not contain them and says so."""
+    import colorid_amd
+    with pytest.raises(colorid_amd.CidError) as ei:
+        hip_ctx.tune(tunable, 1)
+    assert ei.value.code == -4 and "TUNE=1" in str(ei.value)
     rng = np.random.default_rng(n_colors * 7 + n_hash)
     oix = random_index(orc, rng, 60_013, n_hash, 31, n_colors, density=0.2, zero_row_frac=0.05)
     kmers = random_kmers(rng, 70_001, 31)            # > 2^16: the persistent path engages
     plant(oix, rng, kmers[:5000], frac=0.9)
     freq = rng.integers(1, 20, size=len(kmers)).astype(np.uint32)
     want = oix.search_count(kmers, freq.astype(np.uint64))
-    hx = to_hip_index(hip_ctx, oix)
-    check(hip_ctx.lib.cid_tune(tunable, 1))
+    hx = to_hip_index(tune_ctx, oix)
+    tune_ctx.tune(tunable, 1)
     try:
         got = hx.search_count(kmers, freq)
     finally:
-        check(hip_ctx.lib.cid_tune(tunable, 0))
+        tune_ctx.tune(tunable, 0)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    got = hx.search_count(kmers, freq)               # and the TUNE build's default scheduling
     for w, g in zip(want, got):
         assert np.array_equal(w, g)
     hx.close()
@@ -366,9 +387,8 @@ def test_alternative_schedulings_are_bit_exact(orc, hip_ctx, tunable, n_colors, 
 @pytest.mark.parametrize("unroll", [1, 2])
 @pytest.mark.parametrize("n_colors,n_hash", [(512, 3), (320, 4), (1024, 4), (700, 2), (1000, 5)])
 def test_search_count_unroll_is_bit_exact(orc, hip_ctx, unroll, n_colors, n_hash):
-    """Rows of 64 and 128 bytes: k_search_count with one and with two sub-passes' row loads in flight (cid_tune "search_unroll";
+    """Rows of 64 and 128 bytes: k_search_count with one and with two sub-passes' row loads in flight (cid_ctx_tune "search_unroll";
     2 is the default) against the oracle, ragged last tile, colours that do not fill the row (320, 700, 1000), 5 seeds."""
-    from colorid_amd._lib import check
     rng = np.random.default_rng(n_colors * 11 + n_hash)
     oix = random_index(orc, rng, 40_009, n_hash, 31, n_colors, density=0.25, zero_row_frac=0.05)
     kmers = random_kmers(rng, 20_003, 31)
@@ -376,11 +396,11 @@ def test_search_count_unroll_is_bit_exact(orc, hip_ctx, unroll, n_colors, n_hash
     freq = rng.integers(1, 20, size=len(kmers)).astype(np.uint32)
     want = oix.search_count(kmers, freq.astype(np.uint64))
     hx = to_hip_index(hip_ctx, oix)
-    check(hip_ctx.lib.cid_tune(b"search_unroll", unroll))
+    hip_ctx.tune("search_unroll", unroll)
     try:
         got = hx.search_count(kmers, freq)
     finally:
-        check(hip_ctx.lib.cid_tune(b"search_unroll", 2))
+        hip_ctx.tune("search_unroll", 2)
     for w, g in zip(want, got):
         assert np.array_equal(w, g)
     hx.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """read_id throughput against read length (host-pointer sparse call, i.e. H2D of the reads and D2H of the sparse report
 included): which of the two per-read set builders — the per-wave LDS table (k_readid) or the sort-based lists
-(readid_long + k_readid_list) — takes which reads.  The library routes per read (cid_api.hip: kLdsReadBytesMax); the
+(readid_long + k_readid_list) — takes which reads.  The library routes per read (cid_api_readid.hip: kLdsReadBytesMax); the
 table in profiles/r01_readlen.md was measured with a temporary switch that forced the sort path.
 Usage: python tools/bench_readlen.py [--bases 150000000]"""
 import argparse, json, math, os, subprocess, sys, time

@@ -13,7 +13,9 @@ from colorid_amd._lib import check, vp
 
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
-ctx = colorid_amd.Context(0); ctx.set_stream(stream.cuda_stream)
+from colorid_amd import _lib as _cl   # the TUNE build holds the persistent scheduling (make -C colorid_amd/csrc tune)
+ctx = colorid_amd.Context(0, lib=_cl.open_library(_cl.TUNE_LIB_PATH))
+ctx.set_stream(stream.cuda_stream)
 lib = ctx.lib
 C, n, k, m = int(os.environ.get("EXP_C", 256)), 4, 31, 50_000_000
 hx = colorid_amd.Index(ctx, m, n, k, C)
@@ -55,7 +57,7 @@ kk, ff, cc = bench.make_reads_kmers(dev, 42, 1_000_000, 150, k, C, 0.01)
 K0 = kk.shape[0]
 uc0 = torch.empty(K0, dtype=torch.int32, device=dev)
 for persist in (0, 1):
-    check(lib.cid_tune(b"search_persist", persist))
+    ctx.tune("search_persist", persist)
     def run_ascii():
         hx.search_count_dev(kk.data_ptr(), ff.data_ptr(), K0, out.data_ptr(), out.data_ptr() + 8 * C, out.data_ptr() + 16 * C, uc0.data_ptr())
     run_ascii(); run_ascii(); torch.cuda.synchronize()
@@ -74,11 +76,11 @@ for name, bits in orders:
     ks = make_set()
     t_re = 0.0
     if bits is not None:
-        check(lib.cid_tune(b"order_bits", bits))
+        ctx.tune("order_bits", bits)
         torch.cuda.synchronize(); t = time.perf_counter(); ks.order_for_index(hx); t_re = time.perf_counter() - t
     row = {"order": name, "reorder_ms": round(t_re * 1e3, 2)}
     for persist in (0, 1):
-        check(lib.cid_tune(b"search_persist", persist))
+        ctx.tune("search_persist", persist)
         ms, o, K = timed(ks)
         if ref is None:
             ref = o

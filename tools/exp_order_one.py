@@ -12,7 +12,9 @@ order, persist = sys.argv[1], int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
-ctx = colorid_amd.Context(0); ctx.set_stream(stream.cuda_stream)
+from colorid_amd import _lib as _cl   # the TUNE build holds the persistent scheduling (make -C colorid_amd/csrc tune)
+ctx = colorid_amd.Context(0, lib=_cl.open_library(_cl.TUNE_LIB_PATH))
+ctx.set_stream(stream.cuda_stream)
 lib = ctx.lib
 C, n, k, m = 256, 4, 31, 50_000_000
 hx = colorid_amd.Index(ctx, m, n, k, C)
@@ -27,9 +29,9 @@ ks = colorid_amd.KmerSet(ctx, k)
 check(lib.cid_kmerset_add_seqs(ks.h, host_reads.ctypes.data_as(vp), so.ctypes.data_as(vp), host_reads.shape[0], 0))
 ks.finalize()
 if order != "none":
-    check(lib.cid_tune(b"order_bits", int(order)))
+    ctx.tune("order_bits", int(order))
     ks.order_for_index(hx)
-check(lib.cid_tune(b"search_persist", persist))
+ctx.tune("search_persist", persist)
 d_codes, d_counts, nn = vp(), vp(), ctypes.c_uint64(0)
 check(lib.cid_kmerset_device_arrays(ks.h, ctypes.byref(d_codes), ctypes.byref(d_counts), ctypes.byref(nn)))
 K = nn.value

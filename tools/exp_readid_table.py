@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_readid's per-read k-mer set with 12-byte slots (code + window index) and with ONE u64 per slot (code << idx_bits | index;
-cid_tune "readid_packed_table"), A/B in one process on configs[2]'s shape (m = 30 M, n = 2, k = 21, 256 colours, 1 M x 150 bp),
+cid_ctx_tune "readid_packed_table"), A/B in one process on configs[2]'s shape (m = 30 M, n = 2, k = 21, 256 colours, 1 M x 150 bp),
 single-end and paired, and at k = 27 / k = 31 (31 cannot pack).  Reports must be identical.
 usage: python tools/exp_readid_table.py [out.jsonl]"""
 import json, math, os, sys
@@ -33,7 +33,7 @@ for k in (21, 27, 31):
         ref = None
         for rnd in range(2):
             for packed in (0, 1):
-                check(lib.cid_tune(b"readid_packed_table", packed))
+                ctx.tune("readid_packed_table", packed)
                 ms = []
                 for rep_i in range(8):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,6 +48,6 @@ for k in (21, 27, 31):
                 row = {"k": k, "mates": mates, "packed_table": packed, "round": rnd, "ms": round(sorted(ms[2:])[3], 3), "same_report": same}
                 print(json.dumps(row), flush=True)
                 if out_f: out_f.write(json.dumps(row) + "\n"); out_f.flush()
-        check(lib.cid_tune(b"readid_packed_table", 1))
+        ctx.tune("readid_packed_table", 1)
         del hx, reads, bases, rep, ref
         torch.cuda.empty_cache()

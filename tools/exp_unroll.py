@@ -32,7 +32,7 @@ for C, n, m in ((256, 4, 50_000_000), (512, 3, 1 << 28), (1024, 4, 50_000_000), 
     for use_codes in (False, True):
         for rnd in range(2):
             for prefetch, unroll in variants:
-                check(lib.cid_tune(b"search_prefetch", prefetch)); check(lib.cid_tune(b"search_unroll", unroll))
+                ctx.tune("search_unroll", unroll)
                 ms = []
                 for rep in range(8):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,6 +53,6 @@ for C, n, m in ((256, 4, 50_000_000), (512, 3, 1 << 28), (1024, 4, 50_000_000), 
                        "unroll": unroll, "round": rnd, "ms": round(t, 3), "same_result": same, "G_rows_per_s": round(K * n / t / 1e6, 2)}
                 print(json.dumps(row), flush=True)
                 if out_f: out_f.write(json.dumps(row) + "\n"); out_f.flush()
-    check(lib.cid_tune(b"search_unroll", 1)); check(lib.cid_tune(b"search_prefetch", 1))
+    ctx.tune("search_unroll", 1); 
     del hx, kk, ff, cc, codes, out, uc, ref
     torch.cuda.empty_cache()
