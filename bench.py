@@ -186,14 +186,26 @@ def fill_background_fast(dev, mat_ptr, m, rs, n_colours, p, seed, digits=8):
 
 
 def box_clocks():
-    """Current sclk / mclk / fclk of the first GPU, read from sysfs (the pool's boxes differ by a few per cent on the same binary).
-    No child process: this process has initialised the GPU (and may run under rocprofv3's preload), where spawning
-    `rocm-smi` — a `#!/usr/bin/env python3` script — is the exec hop the GPU boxes forbid."""
+    """Current sclk / mclk / fclk of the first GPU, read from sysfs (the pool's boxes differ by a few per cent on the same binary):
+    the hwmon frequency inputs where the driver has them, else the starred level of pp_dpm_*.  No child process: this process has
+    initialised the GPU (and may run under rocprofv3's preload), where spawning `rocm-smi` — a `#!/usr/bin/env python3` script —
+    is the exec hop the GPU boxes forbid."""
     import glob
     import re
     out = {}
     try:
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq*_input")):
+            try:
+                with open(path) as f:
+                    hz = int(f.read().strip())
+                with open(path.replace("_input", "_label")) as f:
+                    label = f.read().strip()
+            except (OSError, ValueError):
+                continue
+            out.setdefault(f"{label}_mhz", round(hz / 1e6))
         for name in ("sclk", "mclk", "fclk"):
+            if f"{name}_mhz" in out:
+                continue
             for path in sorted(glob.glob(f"/sys/class/drm/card*/device/pp_dpm_{name}")):
                 with open(path) as f:
                     cur = [ln for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
@@ -203,13 +215,15 @@ def box_clocks():
                     break
     except OSError as e:  # best effort, never fails the bench
         out["error"] = str(e)[:80]
-    return out or {"error": "no pp_dpm_* files under /sys/class/drm"}
+    return out or {"error": "no clock files under /sys/class/drm"}
 
 
 def clocks_under_load(launch_async):
-    """box_clocks() read WHILE a few untimed launches of the hot kernel are in flight (an idle GPU reports its parked clocks)."""
-    for _ in range(3):
+    """box_clocks() read WHILE untimed launches of the hot kernel are in flight (an idle GPU reports its parked clocks; the
+    management firmware's reading lags the load by some tens of milliseconds)."""
+    for _ in range(12):
         launch_async()
+    time.sleep(0.06)
     clocks = box_clocks()
     torch.cuda.synchronize()
     return clocks

@@ -71,6 +71,10 @@ void ctx_free(cid_ctx *c, void *p) {
 int ctx_device(const cid_ctx *c) { return c->device; }
 hipStream_t ctx_stream(const cid_ctx *c) { return c->stream; }
 int ctx_order_bits(const cid_ctx *c) { return c->tune.order_bits; }
+int ctx_n_cu(const cid_ctx *c) { return c->n_cu; }
+hipStream_t ctx_own_stream(const cid_ctx *c) { return c->own_stream; }
+hipStream_t ctx_copy_stream(const cid_ctx *c) { return c->copy_stream; }
+hipEvent_t ctx_event(const cid_ctx *c, int i) { return i == 0 ? c->ev_copied[0] : c->ev_done[0]; }
 
 int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
     // a started cid_bgzf_inflate batch owns these four slots (and the pinned arena) until its _finish

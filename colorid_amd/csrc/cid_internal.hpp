@@ -12,7 +12,12 @@ namespace cid {
 int fail(int code, const char *fmt, ...);  // records the thread's last error message, returns `code`
 int ctx_device(const cid_ctx *c);
 hipStream_t ctx_stream(const cid_ctx *c);
-int ctx_order_bits(const cid_ctx *c);   // cid_ctx_tune "order_bits"
+int ctx_order_bits(const cid_ctx *c);
+int ctx_n_cu(const cid_ctx *c);
+// the ctx's own stream, its second (copy) stream and two untimed events for calls that overlap an upload with kernels; free between calls
+hipStream_t ctx_own_stream(const cid_ctx *c);
+hipStream_t ctx_copy_stream(const cid_ctx *c);
+hipEvent_t ctx_event(const cid_ctx *c, int i);   // cid_ctx_tune "order_bits"
 // Device scratch that survives the call: hipMalloc of a GiB-sized block costs tens of milliseconds here (the driver clears
 // it), so blocks go back to a per-ctx cache instead of hipFree and the next batch takes them again.  All users run on the
 // ctx stream, which orders a block's last kernel before its next owner's first.  Objects holding such blocks

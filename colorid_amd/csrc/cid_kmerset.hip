@@ -15,6 +15,7 @@
 
 #include "../../include/colorid_hip.h"
 #include "cid_internal.hpp"
+#include "cid_partition.hpp"
 
 namespace cid {
 
@@ -43,8 +44,12 @@ __device__ __forceinline__ uint64_t bits_at_dev(const uint32_t *w, uint32_t bit,
 
 // mode 0: kmerize_vector (has_no_n filter; compare raw bytes, then upper-case; src/kmer.rs:104-117)
 // mode 1: fastq body (has_no_n filter; raw case kept, so a lower-case base cannot be packed: flags[0] is raised)
+// segs == NULL: segment sg is sequence sg of a batch of short sequences (reads: at most kSegWindows windows each) — its bases at
+// seq_off[sg] (relative to `bases`' first byte, which is seq_off[0] of the batch), its codes at win_off[sg]; nothing per read comes
+// from the host but the offsets it already has.
 __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, const Segment *segs, uint32_t n_segs, uint32_t k,
-                                                       int mode, uint64_t sentinel, uint64_t *out, int *flags) {
+                                                       int mode, uint64_t sentinel, uint64_t *out, int *flags,
+                                                       const uint64_t *seq_off = nullptr, const uint64_t *win_off = nullptr, uint64_t base0 = 0) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr uint32_t kBytes = kSegWindows + 32 + 96;                  // bases of one segment (+ slack)
@@ -53,7 +58,13 @@ __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, con
     uint32_t *s_bad = s_pack + (kBytes / 16 + 4);
     uint32_t *s_low = s_bad + (kBytes / 32 + 4);
     for (uint32_t sg = blockIdx.x * 4 + wave; sg < n_segs; sg += gridDim.x * 4) {
-        const Segment seg = segs[sg];
+        Segment seg;
+        if (segs) seg = segs[sg];
+        else {
+            const uint64_t b0 = seq_off[sg], len = seq_off[sg + 1] - b0;
+            if (len < k) continue;   // (wave-uniform)
+            seg = Segment{b0 - base0, win_off[sg], (uint32_t)(len - k + 1), 1u};
+        }
         const uint32_t nb = (seg.n_win - 1) * seg.stride + k;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -115,6 +126,13 @@ __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, con
     }
 }
 
+// windows of every sequence (0 when it is shorter than k): the input of the scan that places each read's codes
+__global__ void k_seq_windows(const uint64_t *seq_off, uint64_t n_seqs, uint32_t k, uint64_t *n_win) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seqs) return;
+    const uint64_t len = seq_off[s + 1] - seq_off[s];
+    n_win[s] = len >= k ? len - k + 1 : 0;
+}
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -212,6 +230,104 @@ struct SatAdd {   // u32 multiplicities saturate instead of wrapping
     __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { const uint32_t s = a + b; return s < a ? 0xFFFFFFFFu : s; }
 };
 
+// ---- the k-mer set's sort (cid_partition.hpp): MSD radix partition passes until the runs fit a workgroup's LDS, then every run is
+// finished on its CU.  `a` holds the n codes (sentinels = keys with a bit at or above `top` included) and is overwritten; `b` is
+// scratch of the same size.  On return *sorted (a or b) holds the *n_real real codes in ascending order — the sentinels are dropped,
+// not carried.  CID_ERR_UNSUPPORTED = not this path's case (small input, wide codes): the caller sorts with rocPRIM's LSD radix sort.
+static const bool kMsdSort = getenv("CID_KMERSET_MSD_SORT") ? atoi(getenv("CID_KMERSET_MSD_SORT")) != 0 : true;
+int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, unsigned top, uint64_t **sorted, size_t *n_real) {
+    using namespace cid;
+    // (CID_KMERSET_MSD_MIN: the tests send small inputs through these kernels too; below a million keys the launches cost more than they save)
+    const char *min_env = getenv("CID_KMERSET_MSD_MIN");
+    const size_t min_n = min_env ? strtoull(min_env, nullptr, 10) : (size_t)1 << 20;
+    if (!kMsdSort || top >= 64 || top < 12 || n < min_n || n < 2 || n >= (1ull << 32)) return CID_ERR_UNSUPPORTED;
+    // the prefix the partition passes consume: enough bits for runs of 1300 .. 2600 keys (a workgroup sorts up to 4096 in 32 KiB of LDS)
+    unsigned prefix = 1;
+    while (prefix < top - 8 && ((uint64_t)n >> prefix) > 2600) ++prefix;
+    const unsigned levels = (prefix + kPartBits - 1) / kPartBits;
+    if (levels > 3) return CID_ERR_UNSUPPORTED;
+    unsigned lbits[3] = {0, 0, 0};
+    for (unsigned l = 0; l < levels; ++l) lbits[l] = l + 1 < levels ? kPartBits : prefix - kPartBits * (levels - 1);
+    const uint32_t n_runs = 1u << prefix;
+    uint32_t S_last = 1;                                   // segments entering the last partition level
+    for (unsigned l = 0; l + 1 < levels; ++l) S_last <<= lbits[l];
+    const uint32_t max_tiles = part_max_tiles((uint32_t)n, S_last);
+    constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (sentinels) [1] big runs [2] largest run [3] hard runs
+    DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c);
+    DevBuf<uint8_t> scan_tmp(c);
+    int rc;
+    if ((rc = seg_a.alloc((size_t)n_runs + 1)) || (rc = seg_b.alloc((size_t)n_runs + 1)) || (rc = tile_base.alloc((size_t)S_last + 1)) ||
+        (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)))
+        return rc;
+    size_t scan_tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tb, table.p, table.p, 0u, (size_t)max_tiles * kPartBins, rocprim::plus<uint32_t>(), st));
+    if ((rc = scan_tmp.alloc(scan_tb))) return rc;
+    HIP_TRY(hipMemsetAsync(info.p, 0, kInfo * 4, st));
+    const uint32_t seg0[2] = {0u, (uint32_t)n};
+    HIP_TRY(hipMemcpyAsync(seg_a.p, seg0, 8, hipMemcpyHostToDevice, st));
+    const unsigned grid = (unsigned)cid::ctx_n_cu(c) * 8u;
+    uint64_t *src = a, *dst = b;
+    uint32_t *seg = seg_a.p, *seg_next = seg_b.p;
+    uint32_t S = 1;
+    unsigned consumed = 0;
+    for (unsigned l = 0; l < levels; ++l) {
+        const uint32_t bits = lbits[l], shift = top - consumed - bits, bins = 1u << bits;
+        const uint32_t level_top = l == 0 ? top : 64u;    // the first level leaves the sentinels behind
+        const size_t table_n = (size_t)part_max_tiles((uint32_t)n, S) * bins;
+        HIP_TRY(hipMemsetAsync(table.p, 0, table_n * 4, st));
+        hipLaunchKernelGGL(k_part_tiles, dim3(1), dim3(kPartBlock), 0, st, seg, S, tile_base.p);
+        hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(kPartBlock), 0, st, src, seg, tile_base.p, S, shift, bits, level_top, table.p, info.p);
+        HIP_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_tb, table.p, table.p, 0u, table_n, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, tile_base.p, S, shift, bits, level_top, table.p);
+        hipLaunchKernelGGL(k_part_offsets, dim3((S * bins + 256) / 256), dim3(256), 0, st, table.p, tile_base.p, S, bits, (uint32_t)n, info.p, seg_next);
+        HIP_TRY(hipGetLastError());
+        std::swap(src, dst);
+        std::swap(seg, seg_next);
+        S *= bins;
+        consumed += bits;
+    }
+    // src: partitioned, seg[0 .. n_runs]: the runs.  How large are they?
+    hipLaunchKernelGGL(k_run_sizes, dim3((n_runs + 255) / 256), dim3(256), 0, st, seg, n_runs, 8192u, info.p + 1, info.p + kInfo, kBigCap, info.p + 2);
+    uint32_t h_info[kInfo + kBigCap];
+    HIP_TRY(hipMemcpyAsync(h_info, info.p, sizeof(h_info), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t dropped = h_info[0], n_big = h_info[1], largest = h_info[2];
+    const size_t kept = n - dropped;
+    const unsigned rest = top - consumed;                 // bits the runs still have to be sorted on
+    if (n_big > kBigCap) {   // badly skewed codes (low-complexity sequence): LSD radix sort of the partitioned array, all bits
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, src, dst, kept, 0u, top, st));
+        DevBuf<uint8_t> tmp(c);
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, src, dst, kept, 0u, top, st));
+        *sorted = dst; *n_real = kept;
+        return CID_OK;
+    }
+    // the bucket kernel takes every run it can (evenly spread keys), names the others in `hard`; the radix kernel sorts those
+    hipLaunchKernelGGL(k_run_bucket_sort<8>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, info.p + 3, hard.p);
+    if (largest > 2048) hipLaunchKernelGGL(k_run_bucket_sort<16>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 2049u, info.p + 3, hard.p);
+    if (largest <= 2048) hipLaunchKernelGGL(k_run_sort<8>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 2048u, hard.p, info.p + 3);
+    else if (largest <= 4096) hipLaunchKernelGGL(k_run_sort<16>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 4096u, hard.p, info.p + 3);
+    else hipLaunchKernelGGL(k_run_sort<32>, dim3(grid / 4), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 8192u, hard.p, info.p + 3);
+    HIP_TRY(hipGetLastError());
+    if (n_big) {   // runs beyond 8192 keys: one LSD radix sort each, on the bits they still differ in
+        std::vector<uint32_t> h_seg(2 * (size_t)n_big);
+        for (uint32_t i = 0; i < n_big; ++i) HIP_TRY(hipMemcpyAsync(&h_seg[2 * i], seg + h_info[kInfo + i], 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, src, dst, kept, 0u, rest, st));   // (an upper bound: no run is larger than the array)
+        DevBuf<uint8_t> tmp(c);
+        if ((rc = tmp.alloc(tb))) return rc;
+        for (uint32_t i = 0; i < n_big; ++i) {
+            const uint32_t lo = h_seg[2 * i], sz = h_seg[2 * i + 1] - lo;
+            size_t tbi = tb;
+            HIP_TRY(rocprim::radix_sort_keys(tmp.p, tbi, src + lo, dst + lo, sz, 0u, rest ? rest : 1u, st));
+        }
+    }
+    *sorted = dst; *n_real = kept;
+    return CID_OK;
+}
+
 // merge the raw window codes into (codes, counts): sort + run-length (first merge) or sort pairs + reduce by key
 int compact(cid_kmerset *ks) {
     if (ks->n_raw == 0) return CID_OK;
@@ -228,15 +344,29 @@ int compact(cid_kmerset *ks) {
     if (ks->n == 0) {
         DevBuf<uint64_t> sorted(ks->ctx);
         if ((rc = sorted.alloc(total))) return rc;
-        HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
-        DevBuf<uint8_t> tmp(ks->ctx);
-        if ((rc = tmp.alloc(tmp_bytes))) return rc;
-        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
-        size_t tmp2 = 0;
-        HIP_TRY(rocprim::run_length_encode(nullptr, tmp2, sorted.p, total, uniq.p, agg.p, d_count.p, st));
-        DevBuf<uint8_t> t2(ks->ctx);
-        if ((rc = t2.alloc(tmp2))) return rc;
-        HIP_TRY(rocprim::run_length_encode(t2.p, tmp2, sorted.p, total, uniq.p, agg.p, d_count.p, st));
+        const uint64_t *in_order = sorted.p;
+        size_t n_sorted = total;
+        uint64_t *msd_out = nullptr;
+        // k <= 31: every real code is below bit end_bit - 1, the sentinel is that bit — the MSD sort drops it (ks->raw is overwritten)
+        rc = ks->k <= 31 ? msd_sort(ks->ctx, st, ks->raw, sorted.p, total, ks->end_bit - 1, &msd_out, &n_sorted) : CID_ERR_UNSUPPORTED;
+        if (rc == CID_OK) in_order = msd_out;
+        else if (rc != CID_ERR_UNSUPPORTED) return rc;
+        else {
+            n_sorted = total;
+            HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
+            DevBuf<uint8_t> tmp(ks->ctx);
+            if ((rc = tmp.alloc(tmp_bytes))) return rc;
+            HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
+        }
+        if (n_sorted == 0) {   // nothing but invalid windows
+            HIP_TRY(hipMemsetAsync(d_count.p, 0, 8, st));
+        } else {
+            size_t tmp2 = 0;
+            HIP_TRY(rocprim::run_length_encode(nullptr, tmp2, in_order, n_sorted, uniq.p, agg.p, d_count.p, st));
+            DevBuf<uint8_t> t2(ks->ctx);
+            if ((rc = t2.alloc(tmp2))) return rc;
+            HIP_TRY(rocprim::run_length_encode(t2.p, tmp2, in_order, n_sorted, uniq.p, agg.p, d_count.p, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
     } else {
         DevBuf<uint64_t> kin(ks->ctx), kout(ks->ctx);
@@ -990,55 +1120,97 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         ks->g_n += total_bases;
         return CID_OK;
     }
-    std::vector<cid::Segment> segs;
-    uint64_t n_win_total = 0;
+    // sizes first: the windows of the batch and its longest sequence
+    uint64_t n_win_total = 0, max_len = 0;
     for (size_t s = 0; s < n_seqs; ++s) {
         if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic");
         const uint64_t len = seq_off[s + 1] - seq_off[s];
-        if (len < ks->k) continue;
-        const uint64_t nw = len - ks->k + 1;
-        for (uint64_t w0 = 0; w0 < nw; w0 += cid::kSegWindows) {
-            const uint32_t m = (uint32_t)(nw - w0 < cid::kSegWindows ? nw - w0 : cid::kSegWindows);
-            segs.push_back(cid::Segment{seq_off[s] + w0, ks->n_raw + n_win_total, m, 1});
-            n_win_total += m;
-        }
+        max_len = len > max_len ? len : max_len;
+        n_win_total += len >= ks->k ? len - ks->k + 1 : 0;
     }
     if (n_win_total == 0) return CID_OK;
-    HIP_TRY(hipSetDevice(cid::ctx_device(ks->ctx)));
-    hipStream_t st = cid::ctx_stream(ks->ctx);
+    cid_ctx *c = ks->ctx;
+    HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+    hipStream_t st = cid::ctx_stream(c);
     if (ks->n_raw + n_win_total > ks->cap_raw) {
         size_t want = (ks->n_raw + n_win_total) * 3 / 2;
-        DevBuf<uint64_t> nb(ks->ctx);
+        DevBuf<uint64_t> nb(c);
         int rc = nb.alloc(want);
         if (rc) return rc;
         // on the ctx stream and waited for: a device-to-device hipMemcpy on the null stream returns before it has run, and the block
         // freed below is handed out again at once (as this call's d_bases) — the copy then read ASCII bases as codes
         if (ks->n_raw) HIP_TRY(hipMemcpyAsync(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (ks->raw) cid::ctx_free(ks->ctx, ks->raw);
+        if (ks->raw) cid::ctx_free(c, ks->raw);
         ks->raw = nb.release();
         ks->cap_raw = want;
     }
-    DevBuf<uint8_t> d_bases(ks->ctx);
-    DevBuf<cid::Segment> d_segs(ks->ctx);
-    int rc;
-    if ((rc = d_bases.alloc(total_bases)) || (rc = d_segs.alloc(segs.size()))) return rc;
-    HIP_TRY(hipMemcpyAsync(d_bases.p, bases, total_bases, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(cid::Segment), hipMemcpyHostToDevice, st));
     constexpr uint32_t kBytes = cid::kSegWindows + 32 + 96;
     const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
-    unsigned grid = (unsigned)((segs.size() + 3) / 4);
-    if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases.p, d_segs.p, (uint32_t)segs.size(), ks->k, mode,
-                       ks->sentinel, ks->raw, ks->d_flags);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    ks->n_raw += n_win_total;
-    if (mode == 1) {
-        int flag = 0;
-        HIP_TRY(hipMemcpy(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost));
-        if (flag) return fail(CID_ERR_UNSUPPORTED, "lower-case bases in a case-preserving (fastq) k-mer count: count on the host");
+    DevBuf<uint8_t> d_bases(c);
+    int rc;
+    if ((rc = d_bases.alloc(total_bases))) return rc;
+    int flag = 0;
+    if (max_len <= cid::kSegWindows + ks->k - 1) {
+        // Reads: one segment per sequence, derived on the device from the offsets (no per-read host work, no 24-byte segment record
+        // per read over PCIe); the bases go up in slices of ~32 MiB on the ctx's copy stream and each slice's windows are extracted
+        // while the next slice is still on the bus — what remains of the call is the PCIe time of the bases.
+        DevBuf<uint64_t> d_off(c), d_win(c);
+        if ((rc = d_off.alloc(n_seqs + 1)) || (rc = d_win.alloc(n_seqs + 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_off.p, seq_off, (n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(cid::k_seq_windows, dim3(grid_for_n(n_seqs)), dim3(256), 0, st, d_off.p, (uint64_t)n_seqs, ks->k, d_win.p);
+        size_t tb = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_win.p, d_win.p, (uint64_t)ks->n_raw, n_seqs, rocprim::plus<uint64_t>(), st));
+        DevBuf<uint8_t> tmp(c);
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, d_win.p, d_win.p, (uint64_t)ks->n_raw, n_seqs, rocprim::plus<uint64_t>(), st));
+        const bool piped = st == cid::ctx_own_stream(c);     // a borrowed stream: keep everything on it
+        hipStream_t cs = piped ? cid::ctx_copy_stream(c) : st;
+        hipEvent_t ev_scan = cid::ctx_event(c, 0), ev_done = cid::ctx_event(c, 1);
+        if (piped) { HIP_TRY(hipEventRecord(ev_scan, st)); HIP_TRY(hipStreamWaitEvent(cs, ev_scan, 0)); }   // (d_bases may still be read by an earlier kernel of the ctx stream)
+        const uint64_t slice_bytes = 32ull << 20;
+        for (size_t s0 = 0; s0 < n_seqs;) {
+            size_t s1 = s0;
+            while (s1 < n_seqs && seq_off[s1] - seq_off[s0] < slice_bytes) ++s1;
+            const uint64_t b0 = seq_off[s0], nb = seq_off[s1] - b0;
+            if (nb) HIP_TRY(hipMemcpyAsync(d_bases.p + (b0 - seq_off[0]), bases + b0, nb, hipMemcpyHostToDevice, cs));
+            if (piped) { HIP_TRY(hipEventRecord(ev_done, cs)); HIP_TRY(hipStreamWaitEvent(st, ev_done, 0)); }
+            unsigned grid = (unsigned)((s1 - s0 + 3) / 4);
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases.p, (const cid::Segment *)nullptr, (uint32_t)(s1 - s0), ks->k, mode,
+                               ks->sentinel, ks->raw, ks->d_flags, d_off.p + s0, d_win.p + s0, seq_off[0]);
+            HIP_TRY(hipGetLastError());
+            s0 = s1;
+        }
+        if (mode == 1) HIP_TRY(hipMemcpyAsync(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {   // long sequences (genomes, contigs): cut into segments of kSegWindows windows on the host — a handful per megabase
+        std::vector<cid::Segment> segs;
+        uint64_t placed = 0;
+        for (size_t s = 0; s < n_seqs; ++s) {
+            const uint64_t len = seq_off[s + 1] - seq_off[s];
+            if (len < ks->k) continue;
+            const uint64_t nw = len - ks->k + 1;
+            for (uint64_t w0 = 0; w0 < nw; w0 += cid::kSegWindows) {
+                const uint32_t m = (uint32_t)(nw - w0 < cid::kSegWindows ? nw - w0 : cid::kSegWindows);
+                segs.push_back(cid::Segment{seq_off[s] - seq_off[0] + w0, ks->n_raw + placed, m, 1});
+                placed += m;
+            }
+        }
+        DevBuf<cid::Segment> d_segs(c);
+        if ((rc = d_segs.alloc(segs.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_bases.p, bases + seq_off[0], total_bases - seq_off[0], hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(cid::Segment), hipMemcpyHostToDevice, st));
+        unsigned grid = (unsigned)((segs.size() + 3) / 4);
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases.p, d_segs.p, (uint32_t)segs.size(), ks->k, mode,
+                           ks->sentinel, ks->raw, ks->d_flags);
+        HIP_TRY(hipGetLastError());
+        if (mode == 1) HIP_TRY(hipMemcpyAsync(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
+    ks->n_raw += n_win_total;
+    if (mode == 1 && flag) return fail(CID_ERR_UNSUPPORTED, "lower-case bases in a case-preserving (fastq) k-mer count: count on the host");
     if (ks->n_raw > ks->compact_at) return compact(ks);
     return CID_OK;
 }

@@ -270,3 +270,49 @@ def test_many_add_calls_on_a_used_context(orc, hip_ctx):
                 om.kmerize_vector(s, 1)
             assert ks.as_dict() == om.as_dict(), (k, rnd)
             ks.close() if hasattr(ks, "close") else None
+
+
+@pytest.mark.parametrize("k", [6, 11, 21, 27, 31])
+@pytest.mark.parametrize("flavour", ["random", "deep", "repeats", "one_kmer", "ns", "mixed"])
+def test_msd_sort_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour):
+    """The k-mer set's own sort (cid_partition.hpp: MSD radix partition passes, then every run finished in LDS) on inputs small enough
+    for the oracle — CID_KMERSET_MSD_MIN=1 sends them through the kernels large sets take: evenly spread codes (the LDS bucket sort),
+    every k-mer many times (deep coverage: the radix kernel for crowded runs), low-complexity sequence (runs beyond a workgroup's LDS:
+    the per-run fallback), a single k-mer, N runs (sentinels dropped by the first pass), and all of it at once."""
+    import colorid_amd
+    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
+    rng = np.random.default_rng(k * 31 + len(flavour))
+    if flavour == "random":
+        seqs = [rand_seq(rng, 60_000), rand_seq(rng, 45_000)]
+    elif flavour == "deep":                                    # 2 kb of sequence read 150 times over
+        g = rand_seq(rng, 2000)
+        seqs = [g[s:s + 150] for s in rng.integers(0, len(g) - 150, 2000)]
+    elif flavour == "repeats":                                 # a 7-base unit with rare substitutions: few distinct, similar k-mers
+        unit = np.frombuffer((rand_seq(rng, 7) * 9000)[:60_000], np.uint8).copy()
+        hit = rng.random(len(unit)) < 0.002
+        unit[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        seqs = [unit.tobytes(), b"A" * 30_000, b"AC" * 10_000]
+    elif flavour == "one_kmer":
+        seqs = [b"A" * (k + 20_000)]
+    elif flavour == "ns":
+        seqs = [rand_seq(rng, 50_000, b"ACGTN"), b"N" * 5000, rand_seq(rng, 20_000, b"ACGTNNNN")]
+    else:
+        g = rand_seq(rng, 3000)
+        seqs = [rand_seq(rng, 40_000), b"T" * 9000, rand_seq(rng, 10_000, b"ACGTN")] + [g[s:s + 200] for s in rng.integers(0, 2800, 300)]
+    for mode in (0, 1):
+        want = orc.Kmers(k)
+        for s in seqs:
+            if mode == 0:
+                want.kmerize_vector(s, 1)
+            else:
+                want.kmerize_fq_read(s, b"I" * len(s), 0)
+        ks = colorid_amd.KmerSet(hip_ctx, k)
+        ks.add_seqs(seqs, mode)
+        assert ks.finalize() == len(want)
+        km, cnt = ks.download()
+        assert ks.as_dict() == want.as_dict()
+        order = [bytes(r) for r in km]
+        assert order == sorted(order)                         # ascending code == ascending ASCII (A < C < G < T)
+        assert int(cnt.sum()) == int(want.counts().sum())
+        ks.close()
+    monkeypatch.setenv("CID_KMERSET_MSD_SORT", "0")            # (read once per process: no effect here; the default path is the one tested)
