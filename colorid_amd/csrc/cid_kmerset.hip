@@ -328,35 +328,37 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
     return CID_OK;
 }
 
-// merge the raw window codes into (codes, counts): sort + run-length (first merge) or sort pairs + reduce by key
+// merge the raw window codes into (codes, counts): the batch is sorted and run-length counted (distinct codes + multiplicities,
+// sentinel dropped); a set that already holds k-mers is then MERGED with it — two sorted lists, one pass (rocprim::merge), equal
+// neighbours added (reduce_by_key) — instead of re-sorting everything it holds with every batch
 int compact(cid_kmerset *ks) {
     if (ks->n_raw == 0) return CID_OK;
     hipStream_t st = cid::ctx_stream(ks->ctx);
-    const size_t total = ks->n + ks->n_raw;
-    if (total >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED,
-                                           "%zu k-mer windows and distinct k-mers in one merge (limit 2^32 - 1): add fewer sequences per set", total);
-    DevBuf<uint64_t> uniq(ks->ctx);
+    const size_t batch = ks->n_raw;
+    if (ks->n + batch >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED,
+                                                   "%zu k-mer windows and distinct k-mers in one merge (limit 2^32 - 1): add fewer sequences per set", ks->n + batch);
+    DevBuf<uint64_t> uniq(ks->ctx), d_count(ks->ctx);
     DevBuf<uint32_t> agg(ks->ctx);
-    DevBuf<uint64_t> d_count(ks->ctx);
     int rc;
-    if ((rc = uniq.alloc(total)) || (rc = agg.alloc(total)) || (rc = d_count.alloc(1))) return rc;
-    size_t tmp_bytes = 0;
-    if (ks->n == 0) {
+    if ((rc = uniq.alloc(batch)) || (rc = agg.alloc(batch)) || (rc = d_count.alloc(1))) return rc;
+    uint64_t n_runs = 0;
+    {
         DevBuf<uint64_t> sorted(ks->ctx);
-        if ((rc = sorted.alloc(total))) return rc;
+        if ((rc = sorted.alloc(batch))) return rc;
         const uint64_t *in_order = sorted.p;
-        size_t n_sorted = total;
+        size_t n_sorted = batch;
         uint64_t *msd_out = nullptr;
         // k <= 31: every real code is below bit end_bit - 1, the sentinel is that bit — the MSD sort drops it (ks->raw is overwritten)
-        rc = ks->k <= 31 ? msd_sort(ks->ctx, st, ks->raw, sorted.p, total, ks->end_bit - 1, &msd_out, &n_sorted) : CID_ERR_UNSUPPORTED;
+        rc = ks->k <= 31 ? msd_sort(ks->ctx, st, ks->raw, sorted.p, batch, ks->end_bit - 1, &msd_out, &n_sorted) : CID_ERR_UNSUPPORTED;
         if (rc == CID_OK) in_order = msd_out;
         else if (rc != CID_ERR_UNSUPPORTED) return rc;
         else {
-            n_sorted = total;
-            HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
+            n_sorted = batch;
+            size_t tmp_bytes = 0;
+            HIP_TRY(rocprim::radix_sort_keys(nullptr, tmp_bytes, ks->raw, sorted.p, batch, 0u, ks->end_bit, st));
             DevBuf<uint8_t> tmp(ks->ctx);
             if ((rc = tmp.alloc(tmp_bytes))) return rc;
-            HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ks->raw, sorted.p, total, 0u, ks->end_bit, st));
+            HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ks->raw, sorted.p, batch, 0u, ks->end_bit, st));
         }
         if (n_sorted == 0) {   // nothing but invalid windows
             HIP_TRY(hipMemsetAsync(d_count.p, 0, 8, st));
@@ -367,45 +369,55 @@ int compact(cid_kmerset *ks) {
             if ((rc = t2.alloc(tmp2))) return rc;
             HIP_TRY(rocprim::run_length_encode(t2.p, tmp2, in_order, n_sorted, uniq.p, agg.p, d_count.p, st));
         }
+        HIP_TRY(hipMemcpyAsync(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-    } else {
-        DevBuf<uint64_t> kin(ks->ctx), kout(ks->ctx);
-        DevBuf<uint32_t> vin(ks->ctx), vout(ks->ctx);
-        if ((rc = kin.alloc(total)) || (rc = kout.alloc(total)) || (rc = vin.alloc(total)) || (rc = vout.alloc(total))) return rc;
-        HIP_TRY(hipMemcpyAsync(kin.p, ks->codes, ks->n * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(kin.p + ks->n, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(vin.p, ks->counts, ks->n * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(cid::k_fill_u32, dim3(grid_for_n(ks->n_raw)), dim3(256), 0, st, vin.p + ks->n, 1u, (uint64_t)ks->n_raw);
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin.p, kout.p, vin.p, vout.p, total, 0u, ks->end_bit, st));
-        DevBuf<uint8_t> tmp(ks->ctx);
-        if ((rc = tmp.alloc(tmp_bytes))) return rc;
-        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kin.p, kout.p, vin.p, vout.p, total, 0u, ks->end_bit, st));
-        size_t tmp2 = 0;
-        HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
-        DevBuf<uint8_t> t2(ks->ctx);
-        if ((rc = t2.alloc(tmp2))) return rc;
-        HIP_TRY(rocprim::reduce_by_key(t2.p, tmp2, kout.p, vout.p, total, uniq.p, agg.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
-        // multiplicities are u32 (the reference: usize): a sum that saturated cannot be reported faithfully
-        hipLaunchKernelGGL(cid::k_flag_saturated, dim3(grid_for_n(total)), dim3(256), 0, st, agg.p, d_count.p, ks->d_flags + 1);
-        int sat = 0;
-        HIP_TRY(hipMemcpyAsync(&sat, ks->d_flags + 1, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (sat) return fail(CID_ERR_UNSUPPORTED,
-                             "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
+        if (n_runs > 0) {  // the sentinel (invalid windows) sorts last: drop it (the MSD sort has done so already)
+            uint64_t last = 0;
+            HIP_TRY(hipMemcpy(&last, uniq.p + (n_runs - 1), 8, hipMemcpyDeviceToHost));
+            if (last == ks->sentinel) --n_runs;
+        }
     }
-    uint64_t n_runs = 0;
-    HIP_TRY(hipMemcpy(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost));
-    if (n_runs > 0) {  // the sentinel (invalid windows) sorts last: drop it
-        uint64_t last = 0;
-        HIP_TRY(hipMemcpy(&last, uniq.p + (n_runs - 1), 8, hipMemcpyDeviceToHost));
-        if (last == ks->sentinel) --n_runs;
-    }
-    if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
-    if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
-    ks->codes = uniq.release();
-    ks->counts = agg.release();
-    ks->n = n_runs;
     ks->n_raw = 0;
+    if (ks->n == 0) {
+        if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
+        if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
+        ks->codes = uniq.release();
+        ks->counts = agg.release();
+        ks->n = n_runs;
+        return CID_OK;
+    }
+    if (n_runs == 0) return CID_OK;
+    const size_t total = ks->n + n_runs;
+    DevBuf<uint64_t> mk(ks->ctx), ok(ks->ctx);
+    DevBuf<uint32_t> mv(ks->ctx), ov(ks->ctx);
+    if ((rc = mk.alloc(total)) || (rc = mv.alloc(total)) || (rc = ok.alloc(total)) || (rc = ov.alloc(total))) return rc;
+    size_t tb = 0;
+    HIP_TRY(rocprim::merge(nullptr, tb, ks->codes, uniq.p, mk.p, ks->counts, agg.p, mv.p, ks->n, (size_t)n_runs, rocprim::less<uint64_t>(), st));
+    {
+        DevBuf<uint8_t> tmp(ks->ctx);
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(rocprim::merge(tmp.p, tb, ks->codes, uniq.p, mk.p, ks->counts, agg.p, mv.p, ks->n, (size_t)n_runs, rocprim::less<uint64_t>(), st));
+    }
+    size_t tmp2 = 0;
+    HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, mk.p, mv.p, total, ok.p, ov.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
+    DevBuf<uint8_t> t2(ks->ctx);
+    if ((rc = t2.alloc(tmp2))) return rc;
+    HIP_TRY(rocprim::reduce_by_key(t2.p, tmp2, mk.p, mv.p, total, ok.p, ov.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
+    // multiplicities are u32 (the reference: usize): a sum that saturated cannot be reported faithfully
+    HIP_TRY(hipMemsetAsync(ks->d_flags + 1, 0, 4, st));
+    hipLaunchKernelGGL(cid::k_flag_saturated, dim3(grid_for_n(total)), dim3(256), 0, st, ov.p, d_count.p, ks->d_flags + 1);
+    int sat = 0;
+    uint64_t n_merged = 0;
+    HIP_TRY(hipMemcpyAsync(&sat, ks->d_flags + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&n_merged, d_count.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sat) return fail(CID_ERR_UNSUPPORTED,
+                         "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
+    cid::ctx_free(ks->ctx, ks->codes);
+    cid::ctx_free(ks->ctx, ks->counts);
+    ks->codes = ok.release();
+    ks->counts = ov.release();
+    ks->n = n_merged;
     return CID_OK;
 }
 
