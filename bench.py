@@ -49,16 +49,19 @@ def hip_memcpy(dst, src, nbytes, kind):
 
 
 def profiled_traffic(K, C, m, n, k):
-    """HBM bytes per launch of k_search_count from the committed rocprofv3 --pmc passes (profiles/), if they
-    were taken on this exact workload; None otherwise (PMC counters cannot be read from inside the timed run)."""
+    """(HBM bytes per launch of k_search_count, where the figure comes from) — PMC counters cannot be read from inside the timed
+    run, so the bytes are those of the committed rocprofv3 --pmc passes (profiles/) when they were taken on this exact workload;
+    (None, reason) otherwise.  The source string goes into the JSON line so that a reader sees it was NOT measured in this run."""
+    path = os.path.join("profiles", "pmc_search_count.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_search_count.json")) as f:
+        with open(os.path.join(ROOT, path)) as f:
             pj = json.load(f)
         if (pj["kmers_per_launch"], pj["n_colors"], pj["bloom_size"], pj["num_hash"], pj["k_size"]) == (K, C, m, n, k):
-            return float(pj["traffic_bytes"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+            return float(pj["traffic_bytes"]), (f"{path} (lease tag {pj.get('tag', '?')}): separate rocprofv3 --pmc passes over this workload, "
+                                                "TCC_EA0_RDREQ/WRREQ with the guide's gfx950 corrections; not measured in this run")
+        return None, f"{path} holds another workload"
+    except (OSError, KeyError, ValueError) as e:
+        return None, f"no committed PMC passes ({type(e).__name__})"
 
 
 def parse_args():
@@ -461,7 +464,9 @@ def main():
                        "setup_s": round(t_setup, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_search_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": a.traffic_bytes if a.traffic_bytes is not None else profiled_traffic(K, C, m, n, k),
+                         "traffic": a.traffic_bytes if a.traffic_bytes is not None else profiled_traffic(K, C, m, n, k)[0],
+                         "traffic_source": "--traffic-bytes (a rocprofv3 --pmc pass of the caller)" if a.traffic_bytes is not None
+                                           else profiled_traffic(K, C, m, n, k)[1],
                          "alg_bytes_per_kmer": alg_bytes_per_kmer,
                          "kernel_ms": kern_ms, "kmers_per_launch": K},
             "per_rank": ranks, "kernel_ms": kern_ms, "collective_ms": coll_ms,
@@ -514,6 +519,8 @@ def main():
                         "producer), in_step_ms = grouping + search inside one step; neither is the headline value"}
             del oc, of
             result["config"]["box"] = clocks_under_load(launch)
+        if world == 1 and not a.codes and not a.no_variants:
+            result["e2e"] = e2e_reads_to_report(a, dev, ctx, hx, out, C, k)
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
     if result is not None:
@@ -523,6 +530,43 @@ def main():
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
+    """What a user of `colorid search` sees of the GPU, PCIe included (never `value`): the step's reads start in HOST memory, go up,
+    are counted into the distinct canonical k-mers on the device (cid_kmerset), searched (the headline kernel on 2-bit codes) and
+    reduced to the per-accession report — hits, unique k-mers, their multiplicities' sum and MODE — which is all that comes back."""
+    import colorid_amd
+    from colorid_amd._lib import check, vp
+    _, _, _, reads = make_reads_kmers(dev, 42, a.reads, a.read_len, k, C, a.error_rate, return_reads=True)
+    host_reads = reads.cpu().numpy()
+    del reads
+    so = (np.arange(host_reads.shape[0] + 1, dtype=np.uint64) * a.read_len)
+    times, parts, hits = [], [], None
+    for _ in range(6):
+        ks = colorid_amd.KmerSet(ctx, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        check(ks.lib.cid_kmerset_add_seqs(ks.h, vp(host_reads.ctypes.data), vp(so.ctypes.data), host_reads.shape[0], 0))
+        t1 = time.perf_counter()
+        nd = ks.finalize()
+        t2 = time.perf_counter()
+        rep = ks.search_count_report(hx)
+        t3 = time.perf_counter()
+        times.append(t3 - t0)
+        parts.append((t1 - t0, t2 - t1, t3 - t2))
+        hits = rep[0]
+        ks.close()
+    best = int(np.argmin(times))
+    same = bool(np.array_equal(hits.astype(np.int64), counters[:C].cpu().numpy()))   # the headline step's hits (same reads, same index)
+    return {"reads": int(host_reads.shape[0]), "distinct_kmers": int(nd), "ms": times[best] * 1e3,
+            "reads_per_s": host_reads.shape[0] / times[best], "kmers_per_s": nd / times[best],
+            "phases_ms": {"upload_and_window_codes": parts[best][0] * 1e3, "sort_and_count": parts[best][1] * 1e3,
+                          "search_and_report": parts[best][2] * 1e3},
+            "all_ms": [round(t * 1e3, 2) for t in times], "same_hits_as_headline": same,
+            "note": "reads in pageable host memory -> H2D -> cid_kmerset (window codes, sort, run-length) -> cid_search_count_set_report "
+                    "(search + per-accession hits / unique / sum / mode on the device) -> 4*C numbers to the host; best of 6 calls, the "
+                    "first of which pays the scratch allocations; PCIe-inclusive, not the headline value"}
 
 
 def cpu_baseline(a, hx, mat_ptr, kmers, freq, C, n, k, m, rs):

@@ -5,4 +5,4 @@ The product is the C-ABI library ``libcolorid_hip.so`` (include/colorid_hip.h) p
 it contains no compute and no CPU fallback: without the built HIP library every call raises.
 """
 from ._lib import CidError, load_library  # noqa: F401
-from .hip import Context, Group, Index, KmerSet  # noqa: F401
+from .hip import Context, FastqReader, Group, Index, KmerSet  # noqa: F401

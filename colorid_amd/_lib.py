@@ -114,6 +114,12 @@ SIGNATURES = {
     "cid_group_stripes_readid_count_sparse": (C.c_int, [vp, C.POINTER(vp), vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp,
                                                         C.POINTER(C.c_uint64)]),
     "cid_ctx_tune": (C.c_int, [vp, C.c_char_p, C.c_long]),
+    "cid_fastq_create": (C.c_int, [vp, C.c_int, C.c_uint32, C.POINTER(vp)]),
+    "cid_fastq_push_bgzf": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.c_int]),
+    "cid_fastq_push_text": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int]),
+    "cid_fastq_classify": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cid_fastq_fetch": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cid_fastq_destroy": (None, [vp]),
     "cid_timer_start": (C.c_int, [vp]),
     "cid_timer_stop_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
 }

@@ -1,0 +1,427 @@
+// The FASTQ front end of read_id on the device (include/colorid_hip.h "cid_fastq"): what the reference does per read on
+// the host before its search — inflate the gzip stream (flate2 MultiGzDecoder, src/read_id_mt_pe.rs:848-856), walk the lines four at a
+// time (:862-879: header, sequence, '+', quality), mask low-quality bases (seq::qual_mask, src/seq.rs:36-56), collect (id, [seq(, mate)])
+// (:868-879, :927-975) — happens here for a whole stretch of the file at once, and the reads never exist in host memory:
+//   block-gzip members (compressed) --H2D--> k_bgzf_inflate --> text in HBM (behind the unfinished tail of the stretch before)
+//   newline positions (one stream compaction) --> every fourth line ends a record --> per record: id / sequence / quality spans, the
+//   masked length, the read's bytes and k-mer windows --> exclusive scans --> bases | seq_off | read_seq0 exactly as cid_readid_count_dev
+//   takes them, and the id lines NUL-terminated back to back --> k_readid ... --> sparse (colour, count) rows.
+// Up go the compressed bytes (~60 MB per million 150-bp reads), down come per read: the id, n_kmers, status and a handful of entries.
+// Two files = read pairs: record r of either file makes read r; a call takes as many records as both hold, the rest waits on the device.
+// Host code + a few elementwise kernels; inflate and classification are the existing kernels.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <new>
+#include <vector>
+
+#include "cid_api_common.hpp"
+
+using cid::fail;
+
+namespace cid {
+
+struct IsNewline {
+    const uint8_t *text;
+    __device__ bool operator()(uint32_t i) const { return text[i] == '\n'; }
+};
+
+struct FqFile {   // device view of one input's text for the kernels
+    const uint8_t *text;
+    const uint32_t *nl;       // positions of the line ends, ascending
+    const uint64_t *n_nl;     // how many
+    uint32_t len;             // bytes of text
+};
+
+// BufRead::lines() yields an unterminated last line too: at the end of the input a text that does not end in '\n' gets a line end
+// at its length
+__global__ void k_fq_tail(const uint8_t *text, uint32_t len, uint32_t *nl, uint64_t *n_nl) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && len && text[len - 1] != '\n') { nl[*n_nl] = len; *n_nl += 1; }
+}
+
+struct FqStats {
+    uint64_t n_rec;          // complete records both files hold
+    uint64_t boundary[2];    // per file: the first byte behind its record n_rec - 1
+    uint32_t max_bytes, max_win, err;
+};
+__global__ void k_fq_nrec(FqFile f0, FqFile f1, int n_files, FqStats *st) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t n = *f0.n_nl / 4;
+    if (n_files == 2 && *f1.n_nl / 4 < n) n = *f1.n_nl / 4;
+    st->n_rec = n;
+    st->boundary[0] = n ? f0.nl[4 * n - 1] + 1ull : 0ull;
+    st->boundary[1] = (n_files == 2 && n) ? f1.nl[4 * n - 1] + 1ull : 0ull;
+    st->max_bytes = 0; st->max_win = 0; st->err = 0;
+}
+
+struct FqSpan { uint32_t seq, qual, len; };   // where a sequence and its quality line start in the text, and the masked length
+
+// line `i` of a file: [begin, end) without its '\n' and without one '\r' before it (lines() strips "\r\n" too)
+__device__ __forceinline__ void fq_line(const FqFile &f, uint64_t i, uint32_t &b, uint32_t &e) {
+    b = i ? f.nl[i - 1] + 1u : 0u;
+    e = f.nl[i];
+    if (e > b && f.text[e - 1] == '\r') --e;
+}
+
+// one thread per read: the spans of its sequence(s), the id span (first file), the read's size for the classification kernel's LDS
+__global__ void k_fq_records(FqFile f0, FqFile f1, int n_files, uint32_t quality, uint32_t k, uint32_t stride_d, FqStats *st, FqSpan *span,
+                             uint64_t *seq_len, uint32_t *id_begin, uint64_t *id_len) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = st->n_rec;
+    uint32_t bytes = 0, win = 0;
+    bool err = false;
+    if (r < n) {
+        for (int f = 0; f < n_files; ++f) {
+            const FqFile &F = f ? f1 : f0;
+            uint32_t b0, e0, b1, e1, b3, e3;
+            fq_line(F, 4 * r, b0, e0);
+            fq_line(F, 4 * r + 1, b1, e1);
+            fq_line(F, 4 * r + 3, b3, e3);
+            const uint32_t slen = e1 - b1, qlen = e3 - b3;
+            // seq::qual_mask (seq.rs:36-56): -Q 0 keeps the sequence; otherwise one base per quality character — the result has the
+            // quality line's length, and a sequence shorter than it is the reference's "could not get the next nt" panic
+            const uint32_t out = quality ? qlen : slen;
+            if (quality && slen < qlen) err = true;
+            span[r * n_files + f] = FqSpan{b1, b3, out};
+            seq_len[r * n_files + f] = out;
+            if (f == 0) { id_begin[r] = b0; id_len[r] = (uint64_t)(e0 - b0) + 1; }   // + the terminating NUL
+            bytes += out;
+            win += out >= k ? (out - k) / stride_d + 1 : 0;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t ob = __shfl_xor(bytes, d, 64), ow = __shfl_xor(win, d, 64);
+        bytes = ob > bytes ? ob : bytes;
+        win = ow > win ? ow : win;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bytes) atomicMax(&st->max_bytes, bytes);
+        if (win) atomicMax(&st->max_win, win);
+    }
+    if (err) atomicOr(&st->err, 1u);
+}
+
+// one wave per sequence: its bases, quality-masked, to bases[seq_off[s] ..)
+__global__ __launch_bounds__(256) void k_fq_pack(FqFile f0, FqFile f1, int n_files, uint32_t quality, uint64_t n_seqs, const FqSpan *span,
+                                                 const uint64_t *seq_off, uint8_t *bases) {
+    const int lane = threadIdx.x & 63;
+    const uint8_t maxq = (uint8_t)(quality + 33);
+    for (uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < n_seqs; s += (uint64_t)gridDim.x * 4) {
+        const FqSpan sp = span[s];
+        const uint8_t *text = (n_files == 2 && (s & 1)) ? f1.text : f0.text;
+        uint8_t *out = bases + seq_off[s];
+        for (uint32_t j = lane; j < sp.len; j += 64) {
+            uint8_t b = text[sp.seq + j];
+            if (quality && text[sp.qual + j] < maxq) b = 'N';
+            out[j] = b;
+        }
+    }
+}
+// one wave per read: its id line + NUL to ids[id_off[r] ..)
+__global__ __launch_bounds__(256) void k_fq_ids(FqFile f0, uint64_t n_reads, const uint32_t *id_begin, const uint64_t *id_off, uint8_t *ids) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_reads; r += (uint64_t)gridDim.x * 4) {
+        const uint64_t o = id_off[r], n = id_off[r + 1] - o - 1;
+        const uint8_t *src = f0.text + id_begin[r];
+        for (uint64_t j = lane; j < n; j += 64) ids[o + j] = src[j];
+        if (lane == 0) ids[o + n] = 0;
+    }
+}
+__global__ void k_fq_read_seq0(uint64_t *read_seq0, uint64_t n_reads, uint32_t n_files) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_reads) read_seq0[r] = r * n_files;
+}
+
+}  // namespace cid
+
+struct cid_fastq {
+    cid_ctx *ctx = nullptr;
+    int n_files = 1;
+    uint32_t quality = 0;
+    struct File {
+        uint8_t *text = nullptr;       // carry (the unfinished tail of the stretch before) + the text pushed since
+        size_t cap = 0, len = 0;
+        bool last = false;
+        // members pushed and not yet checked
+        uint32_t *d_status = nullptr;
+        size_t n_members = 0, members_seen = 0;
+    } f[2];
+    // the last classify's results (device), fetched by cid_fastq_fetch
+    uint64_t n_reads = 0, id_bytes = 0;
+    uint32_t *d_nk = nullptr;
+    uint8_t *d_status = nullptr, *d_ids = nullptr;
+    uint64_t *d_id_off = nullptr;
+};
+
+namespace {
+
+template <typename T>
+struct Buf {   // scoped scratch from the ctx's block cache
+    cid_ctx *c;
+    T *p = nullptr;
+    explicit Buf(cid_ctx *ctx) : c(ctx) {}
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    ~Buf() { if (p) cid::ctx_free(c, p); }
+    int alloc(size_t n) { void *q = nullptr; const int rc = cid::ctx_alloc(c, (n ? n : 1) * sizeof(T), &q); p = static_cast<T *>(q); return rc; }
+    T *release() { T *q = p; p = nullptr; return q; }
+};
+
+// room for `extra` more bytes of text behind what the file holds (+ slack for the line end added at the end of the input)
+int text_reserve(cid_fastq *fq, int file, size_t extra) {
+    cid_fastq::File &F = fq->f[file];
+    const size_t want = F.len + extra + 64;
+    if (want >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 4 GiB of FASTQ text in one call: push smaller stretches");
+    if (want <= F.cap) return CID_OK;
+    cid_ctx *c = fq->ctx;
+    const size_t cap = want + want / 4;
+    void *nb = nullptr;
+    int rc = cid::ctx_alloc(c, cap, &nb);
+    if (rc) return rc;
+    if (F.len) HIP_TRY(hipMemcpyAsync(nb, F.text, F.len, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // (the old block goes back to the cache, whose next owner may write at once)
+    if (F.text) cid::ctx_free(c, F.text);
+    F.text = (uint8_t *)nb;
+    F.cap = cap;
+    return CID_OK;
+}
+
+void drop_results(cid_fastq *fq) {
+    cid_ctx *c = fq->ctx;
+    cid::ctx_free(c, fq->d_nk); fq->d_nk = nullptr;
+    cid::ctx_free(c, fq->d_status); fq->d_status = nullptr;
+    cid::ctx_free(c, fq->d_ids); fq->d_ids = nullptr;
+    cid::ctx_free(c, fq->d_id_off); fq->d_id_off = nullptr;
+    fq->n_reads = fq->id_bytes = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cid_fastq_create(cid_ctx *c, int n_files, uint32_t quality, cid_fastq **out) {
+    if (!c || !out) return fail(CID_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (n_files != 1 && n_files != 2) return fail(CID_ERR_INVALID, "1 file (single-end) or 2 (read pairs)");
+    if (quality > 93) return fail(CID_ERR_INVALID, "quality %u: phred + 33 must stay a printable character", quality);
+    cid_fastq *fq = new (std::nothrow) cid_fastq();
+    if (!fq) return fail(CID_ERR_NOMEM, "fastq");
+    fq->ctx = c; fq->n_files = n_files; fq->quality = quality;
+    *out = fq;
+    return CID_OK;
+}
+
+void cid_fastq_destroy(cid_fastq *fq) {
+    if (!fq) return;
+    cid_ctx *c = fq->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drop_results(fq);
+    for (int i = 0; i < 2; ++i) { cid::ctx_free(c, fq->f[i].text); cid::ctx_free(c, fq->f[i].d_status); }
+    delete fq;
+}
+
+int cid_fastq_push_text(cid_fastq *fq, int file, const uint8_t *text, size_t n_bytes, int last) {
+    if (!fq || file < 0 || file >= fq->n_files || (n_bytes && !text)) return fail(CID_ERR_INVALID, "bad argument");
+    cid_fastq::File &F = fq->f[file];
+    if (F.last) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
+    cid_ctx *c = fq->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = text_reserve(fq, file, n_bytes);
+    if (rc) return rc;
+    if (n_bytes) {
+        HIP_TRY(hipMemcpyAsync(F.text + F.len, text, n_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's buffer is free again
+    }
+    F.len += n_bytes;
+    F.last = last != 0;
+    return CID_OK;
+}
+
+int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+                        const uint32_t *text_len, size_t n_members, int last) {
+    if (!fq || file < 0 || file >= fq->n_files) return fail(CID_ERR_INVALID, "bad argument");
+    if (n_members && (!members || !member_off || !member_len || !text_len)) return fail(CID_ERR_INVALID, "null argument");
+    cid_fastq::File &F = fq->f[file];
+    if (F.last) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
+    if (F.n_members) return fail(CID_ERR_STATE, "file %d: one block-gzip push per classify call", file);
+    if (n_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "a push of BGZF members is limited to 4 GiB");
+    cid_ctx *c = fq->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<cid::BgzfMember> mem(n_members);
+    uint64_t text_total = 0;
+    for (size_t i = 0; i < n_members; ++i) {
+        if ((uint64_t)member_off[i] + member_len[i] > n_bytes) return fail(CID_ERR_INVALID, "member %zu lies outside the push", i);
+        if (text_len[i] > 65536u) return fail(CID_ERR_INVALID, "member %zu: more than 64 KiB of text", i);
+        text_total += text_len[i];
+    }
+    int rc = text_reserve(fq, file, text_total);
+    if (rc) return rc;
+    uint64_t at = F.len;
+    for (size_t i = 0; i < n_members; ++i) { mem[i] = cid::BgzfMember{member_off[i], member_len[i], (uint32_t)at, text_len[i]}; at += text_len[i]; }
+    if (n_members) {
+        Buf<uint8_t> d_in(c);
+        Buf<cid::BgzfMember> d_mem(c);
+        if ((rc = d_in.alloc(n_bytes + 16)) || (rc = d_mem.alloc(n_members))) return rc;
+        cid::ctx_free(c, F.d_status); F.d_status = nullptr;
+        void *st = nullptr;
+        if ((rc = cid::ctx_alloc(c, n_members * 4, &st))) return rc;
+        F.d_status = (uint32_t *)st;
+        HIP_TRY(hipMemcpyAsync(d_in.p, members, n_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_mem.p, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(cid::bgzf_inflate_launch(c, d_in.p, d_mem.p, (uint32_t)n_members, F.text, F.d_status));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's buffers (and `mem`) are free again; d_in / d_mem return to the cache
+        F.n_members = n_members;
+    }
+    F.len = at;
+    F.last = last != 0;
+    return CID_OK;
+}
+
+int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t *n_reads, uint64_t *n_entries,
+                       uint64_t *id_bytes) {
+    if (!fq || !n_reads || !n_entries || !id_bytes) return fail(CID_ERR_INVALID, "null argument");
+    *n_reads = *n_entries = *id_bytes = 0;
+    cid_ctx *c = fq->ctx;
+    int rc = cid::check_ready(c, ix);
+    if (rc) return rc;
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    drop_results(fq);
+    c->sp_rows = 0; c->sp_entries = 0;
+    const int nf = fq->n_files;
+    // the members inflated since the last call: every one is checked as zlib checks it; the first corrupt one is an error
+    for (int f = 0; f < nf; ++f) {
+        cid_fastq::File &F = fq->f[f];
+        if (!F.n_members) continue;
+        std::vector<uint32_t> h(F.n_members);
+        HIP_TRY(hipMemcpyAsync(h.data(), F.d_status, F.n_members * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < F.n_members; ++i)
+            if (h[i]) return fail(CID_ERR_INVALID, "corrupt gzip member %zu of file %d: %s", F.members_seen + i, f, cid::bgzf_status_text(h[i]));
+        F.members_seen += F.n_members;
+        F.n_members = 0;
+    }
+    // line ends of either text
+    Buf<uint32_t> nl[2] = {Buf<uint32_t>(c), Buf<uint32_t>(c)};
+    Buf<uint64_t> n_nl(c);
+    Buf<cid::FqStats> stats(c);
+    if ((rc = n_nl.alloc(2)) || (rc = stats.alloc(1))) return rc;
+    HIP_TRY(hipMemsetAsync(n_nl.p, 0, 16, st));
+    cid::FqFile F[2] = {{nullptr, nullptr, n_nl.p, 0}, {nullptr, nullptr, n_nl.p + 1, 0}};
+    for (int f = 0; f < nf; ++f) {
+        cid_fastq::File &src = fq->f[f];
+        if ((rc = nl[f].alloc(src.len + 2))) return rc;
+        F[f] = cid::FqFile{src.text, nl[f].p, n_nl.p + f, (uint32_t)src.len};
+        if (src.len) {
+            size_t tb = 0;
+            HIP_TRY(rocprim::select(nullptr, tb, rocprim::counting_iterator<uint32_t>(0), nl[f].p, n_nl.p + f, src.len, cid::IsNewline{src.text}, st));
+            Buf<uint8_t> tmp(c);
+            if ((rc = tmp.alloc(tb))) return rc;
+            HIP_TRY(rocprim::select(tmp.p, tb, rocprim::counting_iterator<uint32_t>(0), nl[f].p, n_nl.p + f, src.len, cid::IsNewline{src.text}, st));
+            if (src.last) hipLaunchKernelGGL(cid::k_fq_tail, dim3(1), dim3(64), 0, st, src.text, (uint32_t)src.len, nl[f].p, n_nl.p + f);
+        }
+    }
+    hipLaunchKernelGGL(cid::k_fq_nrec, dim3(1), dim3(64), 0, st, F[0], F[1], nf, stats.p);
+    HIP_TRY(hipGetLastError());
+    cid::FqStats hs;
+    HIP_TRY(hipMemcpyAsync(&hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t n = hs.n_rec, n_seqs = n * (uint64_t)nf;
+    uint64_t total_bases = 0, total_ids = 0;
+    if (n) {
+        if (n >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "more than 2^31 reads in one call: push smaller stretches");
+        Buf<cid::FqSpan> span(c);
+        Buf<uint64_t> seq_off(c), read_seq0(c), id_off(c);
+        Buf<uint32_t> id_begin(c);
+        if ((rc = span.alloc(n_seqs)) || (rc = seq_off.alloc(n_seqs + 1)) || (rc = read_seq0.alloc(n + 1)) || (rc = id_off.alloc(n + 1)) ||
+            (rc = id_begin.alloc(n)))
+            return rc;
+        HIP_TRY(hipMemsetAsync(seq_off.p + n_seqs, 0, 8, st));
+        HIP_TRY(hipMemsetAsync(id_off.p + n, 0, 8, st));
+        hipLaunchKernelGGL(cid::k_fq_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F[0], F[1], nf, fq->quality, ix->k, stride_d, stats.p,
+                           span.p, seq_off.p, id_begin.p, id_off.p);
+        size_t tb1 = 0, tb2 = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb1, seq_off.p, seq_off.p, 0ull, n_seqs + 1, rocprim::plus<uint64_t>(), st));
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, id_off.p, id_off.p, 0ull, n + 1, rocprim::plus<uint64_t>(), st));
+        Buf<uint8_t> tmp(c);
+        if ((rc = tmp.alloc(tb1 > tb2 ? tb1 : tb2))) return rc;
+        HIP_TRY(rocprim::exclusive_scan(tmp.p, tb1, seq_off.p, seq_off.p, 0ull, n_seqs + 1, rocprim::plus<uint64_t>(), st));
+        HIP_TRY(rocprim::exclusive_scan(tmp.p, tb2, id_off.p, id_off.p, 0ull, n + 1, rocprim::plus<uint64_t>(), st));
+        HIP_TRY(hipMemcpyAsync(&hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&total_bases, seq_off.p + n_seqs, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&total_ids, id_off.p + n, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (hs.err) return fail(CID_ERR_INVALID, "ERROR: could not get the next nt in the sequence (a quality line longer than its sequence, src/seq.rs:43-45)");
+        Buf<uint8_t> bases(c), ids(c), status(c);
+        Buf<uint32_t> report(c), nk(c);
+        const size_t C1 = (size_t)ix->n_colors + 1;
+        if ((double)n * (double)C1 * 4.0 > 64.0 * (double)(1ull << 30))
+            return fail(CID_ERR_UNSUPPORTED, "%llu reads x %u colours need more than 64 GiB of dense report rows on the device: push smaller stretches",
+                        (unsigned long long)n, ix->n_colors);
+        if ((rc = bases.alloc(total_bases + 16)) || (rc = ids.alloc(total_ids)) || (rc = report.alloc(n * C1)) || (rc = nk.alloc(n)) ||
+            (rc = status.alloc(n)))
+            return rc;
+        unsigned grid = (unsigned)((n_seqs + 3) / 4);
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(cid::k_fq_pack, dim3(grid), dim3(256), 0, st, F[0], F[1], nf, fq->quality, n_seqs, span.p, seq_off.p, bases.p);
+        hipLaunchKernelGGL(cid::k_fq_ids, dim3(grid), dim3(256), 0, st, F[0], n, id_begin.p, id_off.p, ids.p);
+        hipLaunchKernelGGL(cid::k_fq_read_seq0, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, read_seq0.p, n, (uint32_t)nf);
+        HIP_TRY(hipGetLastError());
+        // a6-a10 on the packed batch (the LDS kernels: reads that do not fit a wave's LDS are not this front end's input)
+        rc = cid_readid_count_dev(c, ix, bases.p, seq_off.p, read_seq0.p, n, stride_d, start_sample, hs.max_bytes, hs.max_win ? hs.max_win : 1,
+                                  report.p, nk.p, status.p);
+        if (rc) return rc;
+        cid::ctx_free(c, c->sp_start); c->sp_start = nullptr;
+        cid::ctx_free(c, c->sp_col); c->sp_col = nullptr;
+        cid::ctx_free(c, c->sp_cnt); c->sp_cnt = nullptr;
+        rc = cid::compact_report(c, report.p, ix->n_colors + 1, n, &c->sp_start, &c->sp_col, &c->sp_cnt, &c->sp_entries);
+        if (rc) return rc;
+        c->sp_rows = n;
+        fq->d_nk = nk.release(); fq->d_status = status.release(); fq->d_ids = ids.release(); fq->d_id_off = id_off.release();
+        fq->n_reads = n; fq->id_bytes = total_ids;
+        HIP_TRY(hipStreamSynchronize(st));   // the scratch above returns to the cache
+    }
+    // what is left of either text moves to the front: the next push continues behind it
+    for (int f = 0; f < nf; ++f) {
+        cid_fastq::File &src = fq->f[f];
+        if (hs.boundary[f] > src.len) hs.boundary[f] = src.len;   // (the line end added at the end of the input sits AT the length)
+        const size_t keep = src.len - (size_t)hs.boundary[f];
+        if (hs.boundary[f] && keep) {
+            Buf<uint8_t> tmp(c);
+            if ((rc = tmp.alloc(keep))) return rc;
+            HIP_TRY(hipMemcpyAsync(tmp.p, src.text + hs.boundary[f], keep, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(src.text, tmp.p, keep, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        src.len = keep;
+    }
+    // at the end of EVERY input what is left — lines that do not complete a record; for pairs the longer file's extra records — is
+    // dropped: the line loops never push it (read_id_mt_pe.rs:862-895, :927-975: the walk ends with the shorter file)
+    bool all_last = true;
+    for (int f = 0; f < nf; ++f) all_last = all_last && fq->f[f].last;
+    if (all_last) for (int f = 0; f < nf; ++f) fq->f[f].len = 0;
+    *n_reads = n;
+    *n_entries = c->sp_entries;
+    *id_bytes = total_ids;
+    return CID_OK;
+}
+
+int cid_fastq_fetch(cid_fastq *fq, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,
+                    char *ids) {
+    if (!fq || !row_start) return fail(CID_ERR_INVALID, "null argument");
+    cid_ctx *c = fq->ctx;
+    if (fq->n_reads == 0) { row_start[0] = 0; return CID_OK; }
+    if (!n_kmers || !status || !id_off || !ids) return fail(CID_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t n = fq->n_reads;
+    HIP_TRY(hipMemcpyAsync(n_kmers, fq->d_nk, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(status, fq->d_status, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(id_off, fq->d_id_off, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ids, fq->d_ids, fq->id_bytes, hipMemcpyDeviceToHost, c->stream));
+    return cid_readid_sparse_fetch(c, row_start, colours, counts);   // (synchronises the stream)
+}
+
+}  // extern "C"

@@ -24,7 +24,6 @@
 
 namespace cid {
 
-struct BgzfMember { uint32_t in_off, in_len, out_off, out_len; };   // in_off: the member's first byte (its gzip header) in the batch
 
 constexpr int kLitBits = 10, kDistBits = 8;
 constexpr uint32_t kRing = 2048;
@@ -430,6 +429,29 @@ hipError_t warm_inflate() {
     return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_bgzf_inflate<kInflateLanes>));
 }
 
+// the kernel on device-resident members: text to d_out + member.out_off, one status word per member; asynchronous on the ctx stream
+hipError_t bgzf_inflate_launch(cid_ctx *c, const uint8_t *d_in, const BgzfMember *d_mem, uint32_t n_members, uint8_t *d_out, uint32_t *d_st) {
+    if (n_members == 0) return hipSuccess;
+    static const CrcShift shift = make_crc_shift();
+    static const int lanes = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : kInflateLanes;   // members per wave: 1, 2, 4 or 8
+    const unsigned lpw = lanes == 1 ? 1u : lanes == 4 ? 4u : lanes == 8 ? 8u : 2u;
+    unsigned grid = (unsigned)((n_members + lpw - 1) / lpw);
+    const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // a few rounds per block at most
+    if (grid > cap) grid = cap;
+    const size_t lds = (size_t)lpw * kLdsBytes;
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, c->stream, d_in, d_mem, n_members, d_out, d_st, shift); };
+    if (lpw == 1) launch(k_bgzf_inflate<1>);
+    else if (lpw == 4) launch(k_bgzf_inflate<4>);
+    else if (lpw == 8) launch(k_bgzf_inflate<8>);
+    else launch(k_bgzf_inflate<2>);
+    return hipGetLastError();
+}
+const char *bgzf_status_text(uint32_t st) {
+    static const char *const why[] = {"", "not a BGZF member header", "invalid DEFLATE block", "invalid Huffman code", "compressed data ends early",
+                                      "more text than the member's ISIZE", "text length differs from ISIZE", "CRC-32 mismatch"};
+    return why[st < 8 ? st : 0];
+}
+
 }  // namespace cid
 
 using cid::fail;
@@ -461,7 +483,6 @@ extern "C" int cid_bgzf_inflate_start(cid_ctx *c, const uint8_t *members, size_t
         mem[i] = cid::BgzfMember{member_off[i], member_len[i], text_off[i], text_len[i]};
     }
     HIP_TRY(hipSetDevice(c->device));
-    static const cid::CrcShift shift = cid::make_crc_shift();
     void *d_in, *d_mem, *d_out, *d_st;
     int rc = cid::slot_reserve(c, S_KMERS, n_bytes + 16, &d_in); if (rc) return rc;
     rc = cid::slot_reserve(c, S_MISC, n_members * sizeof(cid::BgzfMember), &d_mem); if (rc) return rc;
@@ -482,21 +503,7 @@ extern "C" int cid_bgzf_inflate_start(cid_ctx *c, const uint8_t *members, size_t
         HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    static const int lanes = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : cid::kInflateLanes;   // members per wave: 1, 2, 4 or 8
-    const unsigned lpw = lanes == 1 ? 1u : lanes == 4 ? 4u : lanes == 8 ? 8u : 2u;
-    unsigned grid = (unsigned)((n_members + lpw - 1) / lpw);
-    const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // a few rounds per block at most
-    if (grid > cap) grid = cap;
-    const size_t lds = (size_t)lpw * cid::kLdsBytes;
-    auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem, (uint32_t)n_members,
-                           (uint8_t *)d_out, (uint32_t *)d_st, shift);
-    };
-    if (lpw == 1) launch(cid::k_bgzf_inflate<1>);
-    else if (lpw == 4) launch(cid::k_bgzf_inflate<4>);
-    else if (lpw == 8) launch(cid::k_bgzf_inflate<8>);
-    else launch(cid::k_bgzf_inflate<2>);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(cid::bgzf_inflate_launch(c, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem, (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st));
     c->inflate.d_out = d_out; c->inflate.d_st = d_st;
     if (pin) {
         HIP_TRY(hipMemcpyAsync(pin + b_st, d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));
@@ -528,9 +535,7 @@ extern "C" int cid_bgzf_inflate_finish(cid_ctx *c, uint8_t *text, size_t text_by
     for (size_t i = 0; i < n_members; ++i)
         if (st[i] != cid::ST_OK) {
             if (bad_member) *bad_member = i;
-            static const char *const why[] = {"", "not a BGZF member header", "invalid DEFLATE block", "invalid Huffman code", "compressed data ends early",
-                                              "more text than the member's ISIZE", "text length differs from ISIZE", "CRC-32 mismatch"};
-            return fail(CID_ERR_INVALID, "corrupt gzip member %zu: %s", i, why[st[i] < 8 ? st[i] : 0]);
+            return fail(CID_ERR_INVALID, "corrupt gzip member %zu: %s", i, cid::bgzf_status_text(st[i]));
         }
     if (c->inflate.staged && text_bytes) memcpy(text, c->pin + c->inflate.pin_text, text_bytes);
     return CID_OK;

@@ -574,3 +574,50 @@ class GroupKmerSet:
             self.h = None
             if self in getattr(self.g, "_ksets", []):
                 self.g._ksets.remove(self)
+
+
+class FastqReader:
+    """cid_fastq: FASTQ text or block-gzip members -> records -> quality-masked reads -> classification counts, all on the device."""
+
+    def __init__(self, ctx, n_files=1, quality=0):
+        self.ctx, self.lib, self.n_files = ctx, ctx.lib, n_files
+        h = vp()
+        check(self.lib.cid_fastq_create(ctx.h, n_files, quality, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    def push_text(self, file, text: bytes, last=False):
+        buf = np.frombuffer(text, np.uint8) if len(text) else np.zeros(1, np.uint8)
+        check(self.lib.cid_fastq_push_text(self.h, file, _p(buf), len(text), 1 if last else 0))
+
+    def push_bgzf(self, file, members, text_lens, last=False):
+        """members: list of whole BGZF members (bytes); text_lens: their ISIZE"""
+        blob = np.frombuffer(b"".join(members) + b"\0", np.uint8)
+        ln = np.array([len(m) for m in members], np.uint32)
+        off = (np.cumsum(np.concatenate([[0], ln[:-1]])) if len(ln) else np.zeros(0)).astype(np.uint32)
+        tl = np.array(text_lens, np.uint32)
+        check(self.lib.cid_fastq_push_bgzf(self.h, file, _p(blob), len(blob) - 1, _p(off), _p(ln), _p(tl), len(members), 1 if last else 0))
+
+    def classify(self, index, d=1, start_sample=3):
+        """-> (ids [list of bytes], n_kmers, status, row_start, colours, counts) of every complete record pushed so far"""
+        n, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.cid_fastq_classify(self.h, index.h, d, start_sample, C.byref(n), C.byref(ne), C.byref(nb)))
+        nk = np.zeros(n.value, np.uint32)
+        st = np.zeros(n.value, np.uint8)
+        rs = np.zeros(n.value + 1, np.uint64)
+        col = np.zeros(ne.value, np.uint32)
+        cnt = np.zeros(ne.value, np.uint32)
+        io = np.zeros(n.value + 1, np.uint64)
+        ids = np.zeros(max(nb.value, 1), np.uint8)
+        check(self.lib.cid_fastq_fetch(self.h, _p(nk), _p(st), _p(rs), _p(col), _p(cnt), _p(io), _p(ids)))
+        raw = ids.tobytes()
+        names = [raw[int(io[r]):int(io[r + 1]) - 1] for r in range(n.value)]
+        return names, nk, st, rs, col, cnt
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cid_fastq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

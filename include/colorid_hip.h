@@ -384,6 +384,34 @@ int cid_bgzf_inflate(cid_ctx *, const uint8_t *members, size_t n_bytes, const ui
 int cid_bgzf_inflate_start(cid_ctx *, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
                            const uint32_t *text_off, const uint32_t *text_len, size_t n_members, size_t text_bytes);
 int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t *bad_member);
+/* ---- the FASTQ front end of read_id on the device: what the reference does per read before its search — inflate
+ *      (src/read_id_mt_pe.rs:848-856), take the lines four at a time (:862-879 / pairs :927-975: header, sequence, '+', quality; lines()
+ *      strips "\n" and "\r\n"; an unterminated last line counts), seq::qual_mask (src/seq.rs:36-56) and the (id, [seq(, mate)]) batch
+ *      — done for a whole stretch of the input at once, in HBM: the compressed bytes go up, and per read the id line, n_kmers,
+ *      status and the non-zero (colour, count) entries come back; the reads themselves never exist in host memory.
+ *        create        n_files = 1 (single-end) or 2 (record r of either file = read pair r); quality = -Q (0: no masking)
+ *        push_bgzf     the next whole block-gzip members of one file (as cid_bgzf_inflate takes them; text_len[i] = member i's ISIZE);
+ *                      at most one such push per file between two classify calls.  push_text: already-decoded text instead (plain
+ *                      FASTQ, or a gzip stream inflated by the host) — any number of pushes, cut anywhere.  last != 0: the file ends here.
+ *        classify      every complete record pushed so far (for pairs: as many as both files hold) through cid_readid_count_dev's
+ *                      kernels and the sparse-report compaction; what is left of the text waits on the device for the next push.
+ *                      Corrupt members -> CID_ERR_INVALID naming the first one; a quality line longer than its sequence ->
+ *                      CID_ERR_INVALID (the reference's "could not get the next nt" panic); reads that do not fit a wave's LDS
+ *                      (several kilobases) -> CID_ERR_UNSUPPORTED: classify such input through cid_readid_count_sparse.
+ *        fetch         n_kmers / status [n_reads], row_start [n_reads + 1] + colours / counts [n_entries] as cid_readid_sparse_fetch
+ *                      gives them, id_off [n_reads + 1] and ids [id_bytes]: read r's header line (with its '@'), NUL-terminated,
+ *                      at ids + id_off[r].
+ *      One cid_fastq per input (pair); it borrows the ctx's stream and scratch: destroy it before the ctx. ---- */
+typedef struct cid_fastq cid_fastq;
+int cid_fastq_create(cid_ctx *, int n_files, uint32_t quality, cid_fastq **out);
+int cid_fastq_push_bgzf(cid_fastq *, int file, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+                        const uint32_t *text_len, size_t n_members, int last);
+int cid_fastq_push_text(cid_fastq *, int file, const uint8_t *text, size_t n_bytes, int last);
+int cid_fastq_classify(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, uint64_t *n_reads, uint64_t *n_entries,
+                       uint64_t *id_bytes);
+int cid_fastq_fetch(cid_fastq *, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,
+                    char *ids);
+void cid_fastq_destroy(cid_fastq *);
 #define CID_WARM_READID 1u
 #define CID_WARM_SEARCH 2u
 #define CID_WARM_INFLATE 4u

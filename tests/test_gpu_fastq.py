@@ -1,0 +1,187 @@
+"""cid_fastq — the FASTQ front end of read_id on the device (inflate -> lines -> records -> qual_mask -> packed reads -> k_readid) —
+against the host's way of doing the same: records cut out of the text by a restatement of the reference's line loops
+(read_id_mt_pe.rs:862-879 single-end, :927-975 pairs: four lines per record, lines() strips "\\n" and "\\r\\n", an unterminated last line
+counts, leftovers are dropped, the walk ends with the shorter file), quality-masked by the oracle's qual_mask (seq.rs:36-56), packed and
+classified through cid_readid_count_sparse — and against the oracle's own per-read counts.  The text reaches the device cut at arbitrary
+points (push_text) and as block-gzip members whose boundaries fall inside records (push_bgzf)."""
+import numpy as np
+import pytest
+
+from test_gpu_inflate import bgzf_member
+from test_gpu_readid import pack_reads
+from util import random_index, synth_fastq_records, to_hip_index
+
+pytestmark = pytest.mark.gpu
+
+
+def fastq_text(records, eol=b"\n", last_newline=True, plus=b"+"):
+    out = bytearray()
+    for i, (rid, seq, qual) in enumerate(records):
+        out += b"@" + rid + eol + seq + eol + plus + eol + qual
+        if i + 1 < len(records) or last_newline:
+            out += eol
+    return bytes(out)
+
+
+def line_loop_records(text):
+    """the reference's reader: lines (\\n or \\r\\n stripped; an unterminated last line too), four per record, leftovers dropped"""
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines = [ln[:-1] if ln.endswith(b"\r") else ln for ln in lines]
+    return [(lines[i], lines[i + 1], lines[i + 3]) for i in range(0, len(lines) - 3, 4)]
+
+
+def expected(orc, hx, texts, q, d, S):
+    recs = [line_loop_records(t) for t in texts]
+    n = min(len(r) for r in recs)
+    reads = [[orc.qual_mask(r[i][1], r[i][2], q) for r in recs] for i in range(n)]
+    ids = [recs[0][i][0] for i in range(n)]
+    bases, so, r0 = pack_reads(reads)
+    rs, col, cnt, nk, st = hx.readid_count_sparse(bases, so, r0, d, S)
+    return ids, (nk, st, rs, col, cnt), (bases, so, r0)
+
+
+def collect(fr, hx, d, S, acc):
+    ids, nk, st, rs, col, cnt = fr.classify(hx, d, S)
+    acc["ids"] += ids
+    acc["nk"].append(nk); acc["st"].append(st)
+    for r in range(len(ids)):
+        acc["rows"].append(list(zip(col[int(rs[r]):int(rs[r + 1])].tolist(), cnt[int(rs[r]):int(rs[r + 1])].tolist())))
+
+
+def check_equal(acc, want_ids, want):
+    nk, st, rs, col, cnt = want
+    assert acc["ids"] == want_ids
+    assert np.array_equal(np.concatenate(acc["nk"]) if acc["nk"] else np.zeros(0, np.uint32), nk)
+    assert np.array_equal(np.concatenate(acc["st"]) if acc["st"] else np.zeros(0, np.uint8), st)
+    rows = [list(zip(col[int(rs[r]):int(rs[r + 1])].tolist(), cnt[int(rs[r]):int(rs[r + 1])].tolist())) for r in range(len(want_ids))]
+    assert acc["rows"] == rows
+
+
+@pytest.fixture(scope="module")
+def world(orc, hip_ctx):
+    rng = np.random.default_rng(11)
+    genomes = [bytes(rng.choice(list(b"ACGT"), size=6000).astype(np.uint8)) for _ in range(5)]
+    oix = random_index(orc, rng, 40_009, 3, 21, 130, density=0.02, zero_row_frac=0.2)
+    for gi, g in enumerate(genomes):
+        km = orc.Kmers(21)
+        km.kmerize_vector(g, 1)
+        for key in km.keys():
+            oix.insert(gi * 7, key.tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    yield oix, hx, genomes
+    hx.close()
+
+
+@pytest.mark.parametrize("eol,last_newline", [(b"\n", True), (b"\r\n", True), (b"\n", False), (b"\r\n", False)])
+@pytest.mark.parametrize("q", [0, 15])
+def test_text_pushed_in_pieces_single_end(orc, hip_ctx, world, eol, last_newline, q):
+    import colorid_amd
+    oix, hx, genomes = world
+    rng = np.random.default_rng(len(eol) * 10 + q + int(last_newline))
+    recs = synth_fastq_records(rng, genomes, 900, 150, lower_rate=0.0)
+    recs.insert(5, (b"empty read", b"", b""))
+    recs.insert(9, (b"read with\ttab and a very long name " + b"x" * 300, genomes[0][:150], b"I" * 150))
+    text = fastq_text(recs, eol, last_newline) + (b"" if last_newline else b"")
+    if last_newline:
+        text += b"@dangling header" + eol + b"ACGT" + eol           # two lines that complete no record: dropped
+    want_ids, want, packed = expected(orc, hx, [text], q, 1, 3)
+    assert len(want_ids) == len(recs)
+    # the oracle itself on the host-packed reads
+    orep = oix.readid_counts(*packed, 1, 3)
+    grep = hx.readid_count(*packed, 1, 3)
+    assert all(np.array_equal(a, b) for a, b in zip(grep, orep))
+    for pieces in (1, 7, 60):
+        fr = colorid_amd.FastqReader(hip_ctx, 1, q)
+        cuts = sorted(rng.integers(0, len(text), pieces - 1).tolist()) if pieces > 1 else []
+        acc = {"ids": [], "nk": [], "st": [], "rows": []}
+        prev = 0
+        for j, cut in enumerate(cuts + [len(text)]):
+            fr.push_text(0, text[prev:cut], last=(cut == len(text)))
+            prev = cut
+            if j % 3 == 2 or cut == len(text):
+                collect(fr, hx, 1, 3, acc)
+        check_equal(acc, want_ids, want)
+        ids, nk, st, rs, col, cnt = fr.classify(hx, 1, 3)           # nothing is left
+        assert ids == [] and len(nk) == 0
+        fr.close()
+
+
+@pytest.mark.parametrize("q,d,S", [(15, 1, 3), (0, 2, 0), (20, 1, 5)])
+def test_pairs_from_two_files(orc, hip_ctx, world, q, d, S):
+    import colorid_amd
+    oix, hx, genomes = world
+    rng = np.random.default_rng(q + d)
+    r1 = synth_fastq_records(np.random.default_rng(5 + q), genomes, 700, 140, mate=0, lower_rate=0.0)
+    r2 = synth_fastq_records(np.random.default_rng(5 + q), genomes, 700, 140, mate=1, lower_rate=0.0)
+    t1 = fastq_text(r1, b"\n", True)
+    t2 = fastq_text(r2[:650], b"\r\n", False)                        # the second file is shorter: the walk ends with it
+    want_ids, want, packed = expected(orc, hx, [t1, t2], q, d, S)
+    assert len(want_ids) == 650
+    orep = oix.readid_counts(*packed, d, S)
+    grep = hx.readid_count(*packed, d, S)
+    assert all(np.array_equal(a, b) for a, b in zip(grep, orep))
+    fr = colorid_amd.FastqReader(hip_ctx, 2, q)
+    acc = {"ids": [], "nk": [], "st": [], "rows": []}
+    c1 = sorted(rng.integers(0, len(t1), 9).tolist()) + [len(t1)]
+    c2 = sorted(rng.integers(0, len(t2), 4).tolist()) + [len(t2)]
+    p1 = p2 = 0
+    i1 = i2 = 0
+    while i1 < len(c1) or i2 < len(c2):                              # the two files advance at different paces
+        if i1 < len(c1):
+            fr.push_text(0, t1[p1:c1[i1]], last=(i1 == len(c1) - 1)); p1 = c1[i1]; i1 += 1
+        if i2 < len(c2) and (i1 % 2 == 0 or i1 >= len(c1)):
+            fr.push_text(1, t2[p2:c2[i2]], last=(i2 == len(c2) - 1)); p2 = c2[i2]; i2 += 1
+        collect(fr, hx, d, S, acc)
+    check_equal(acc, want_ids, want)
+    fr.close()
+
+
+def test_block_gzip_members_cut_records(orc, hip_ctx, world):
+    import colorid_amd
+    oix, hx, genomes = world
+    rng = np.random.default_rng(3)
+    recs = synth_fastq_records(rng, genomes, 3000, 150, lower_rate=0.0)
+    text = fastq_text(recs)
+    want_ids, want, _ = expected(orc, hx, [text], 15, 1, 3)
+    # members of irregular sizes (1 byte .. 64 KiB), an empty one, every compression level: record and line boundaries fall anywhere
+    members, lens, pos = [], [], 0
+    while pos < len(text):
+        n = int(rng.choice([1, 7, 300, 5000, 30000, 65536]))
+        chunk = text[pos:pos + n]
+        members.append(bgzf_member(chunk, level=int(rng.integers(0, 10)), extra_subfield=bool(rng.integers(0, 2))))
+        lens.append(len(chunk))
+        pos += n
+        if rng.random() < 0.05:
+            members.append(bgzf_member(b"")); lens.append(0)
+    members.append(bgzf_member(b"")); lens.append(0)                 # the BGZF end marker
+    fr = colorid_amd.FastqReader(hip_ctx, 1, 15)
+    acc = {"ids": [], "nk": [], "st": [], "rows": []}
+    i = 0
+    while i < len(members):
+        j = min(len(members), i + int(rng.integers(1, 12)))
+        fr.push_bgzf(0, members[i:j], lens[i:j], last=(j == len(members)))
+        collect(fr, hx, 1, 3, acc)
+        i = j
+    check_equal(acc, want_ids, want)
+    fr.close()
+    # a corrupt member is named; a quality line longer than its sequence is the reference's panic
+    fr = colorid_amd.FastqReader(hip_ctx, 1, 15)
+    bad = bytearray(members[2]); bad[-6] ^= 1
+    fr.push_bgzf(0, members[:2] + [bytes(bad)], lens[:3])
+    with pytest.raises(colorid_amd.CidError) as ei:
+        fr.classify(hx)
+    assert ei.value.code == -1 and "member 2" in str(ei.value) and "CRC-32" in str(ei.value)
+    fr.close()
+    fr = colorid_amd.FastqReader(hip_ctx, 1, 15)
+    fr.push_text(0, b"@r\nACGT\n+\nIIIIII\n", last=True)
+    with pytest.raises(colorid_amd.CidError) as ei:
+        fr.classify(hx)
+    assert ei.value.code == -1 and "next nt" in str(ei.value)
+    fr.close()
+    fr = colorid_amd.FastqReader(hip_ctx, 1, 0)                      # without masking the same record is fine: the sequence as it is
+    fr.push_text(0, b"@r\nACGT\n+\nIIIIII\n", last=True)
+    ids, nk, st, *_ = fr.classify(hx)
+    assert ids == [b"@r"] and st[0] == 1                             # 4 bases < k: too_short
+    fr.close()
