@@ -140,6 +140,28 @@ class LineReader {   // inflates on its own thread, a few MiB ahead of the calle
 };
 
 // Whole FASTQ records (groups of four lines, counted from the start of the file as the reference's `line_count % 4` does) of one
+// Block-gzip (BGZF) input for the device front end (cid_fastq_*): the file's members still COMPRESSED, in stretches worth about
+// `text_target` bytes of text — the reading thread only walks the members' headers (their sizes are in the "BC" extra field, the
+// text sizes in the trailers) a stretch or two ahead of the caller; inflate, line split, record split and masking happen on the GPU.
+struct BgzfStretch {
+    std::vector<unsigned char> bytes;              // whole members, back to back
+    std::vector<uint32_t> off, len, text_len;      // member i = bytes[off[i], +len[i]), its text has text_len[i] bytes
+    uint64_t text_bytes = 0;
+    bool last = false;                             // the file ends with this stretch
+};
+class BgzfMemberReader {
+  public:
+    BgzfMemberReader(const std::string &path, size_t text_target);
+    ~BgzfMemberReader();
+    BgzfMemberReader(const BgzfMemberReader &) = delete;
+    BgzfMemberReader &operator=(const BgzfMemberReader &) = delete;
+    bool next(BgzfStretch &s);                     // false after the stretch that had last == true; `s`'s buffers are recycled
+    static bool is_bgzf(const std::string &path);
+    struct Impl;
+  private:
+    Impl *p_;
+};
+
 // input, a decoded block at a time: the text [begin, rec_end.back()) of buf, record r ending just past its fourth newline at
 // rec_end[r].  Lines that do not complete a record at the end of the input are dropped, as the line loops never push them
 // (read_id_mt_pe.rs:862-895).  Finding the boundaries is one memchr per line; the records of a chunk are then parsed in parallel.
@@ -214,6 +236,8 @@ void batch_search(cid_ctx *, const std::vector<std::string> &files1, const std::
                   int64_t filter, double cov, bool gene_search, uint8_t qual_offset);     // batch_search_pe.rs:9-179
 }
 namespace read_id_mt_pe {
+// block-gzip (BGZF) fastq input on one GPU takes the device front end (cid_fastq_*) unless COLORID_DEVICE_FASTQ=0
+bool device_fastq_wanted(const std::vector<std::string> &fq, size_t n_files);
 void per_read_stream_se(cid_ctx *, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct, size_t batch,
                         const std::string &prefix, uint8_t qual_offset, size_t start_sample);   // read_id_mt_pe.rs:835-951
 void per_read_stream_pe(cid_ctx *, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct, size_t batch,

@@ -678,7 +678,11 @@ void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t star
 // ... and the poll (kmer_poll_plus per read, read_id_mt_pe.rs:168-251) + the rows of <prefix>_reads.txt on the host: the reads of a
 // batch are independent, so COLORID_POLL_THREADS (default 8) threads format contiguous slices of it and the slices are written in order
 // (default 2: the poll of a million reads is 50 ms on one thread, 30 ms on two — enough to stay ahead of the GPU stage)
-static const int g_poll_threads = [] { const char *e = getenv("COLORID_POLL_THREADS"); const int v = e ? atoi(e) : std::min(2, std::max(1, cpu_budget() / 8)); return v < 1 ? 1 : v; }();
+static int g_poll_threads = [] {
+    const char *e = getenv("COLORID_POLL_THREADS");
+    const int v = e ? atoi(e) : std::min(2, std::max(1, cpu_budget() / 8));
+    return v < 1 ? 1 : v;
+}();
 static inline void append_u64(std::string &o, uint64_t v) {
     char t[24];
     int n = 0;
@@ -788,6 +792,22 @@ class BatchClassifier {
         spare_.pop_back();
         return rb;
     }
+    // the device front end (cid_fastq) hands over batches that are counted already: an empty Counted to fill, and its way to the poll
+    std::unique_ptr<Counted> take_counted() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (free_counted_.empty()) return std::unique_ptr<Counted>(new Counted);
+        std::unique_ptr<Counted> c = std::move(free_counted_.back());
+        free_counted_.pop_back();
+        return c;
+    }
+    void push_counted(std::unique_ptr<Counted> c) {
+        std::unique_lock<std::mutex> lk(mu_);
+        const auto tw = Clock::now();
+        cv_polled_.wait(lk, [&] { return counted_.size() < kDepth; });
+        g_ms_wait[2] += ms_since(tw);
+        counted_.push_back(std::move(c));
+        cv_counted_.notify_one();
+    }
     uint64_t finish() {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -875,6 +895,79 @@ class BatchClassifier {
 
 }  // namespace
 
+static void print_read_id_timing(const Clock::time_point &t0) {
+    if (!g_timing) return;
+    fprintf(stderr,
+            "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms; waits: parser on a full queue %.0f ms, "
+            "GPU stage idle %.0f ms, GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, "
+            "%llu (colour, count) entries fetched; of poll + write: writing %.0f ms\n",
+            ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries,
+            g_ms_write);
+}
+
+// ---- block-gzip input through the device front end (cid_fastq_*): the members go up compressed — read from the file a stretch ahead by
+// BgzfMemberReader — and come back classified: per read the id line, n_kmers, status and its (colour, count) entries, ready for the
+// poll.  No inflating threads, no record packers: the host reads the file, polls and writes.  COLORID_DEVICE_FASTQ=0 keeps the host
+// front end; several GPUs (--gpus / --placement) use it too.
+bool read_id_mt_pe::device_fastq_wanted(const std::vector<std::string> &fq, size_t n_files) {
+    const char *e = getenv("COLORID_DEVICE_FASTQ");
+    if ((e && atoi(e) == 0) || g_group) return false;
+    for (size_t i = 0; i < n_files; ++i)
+        if (!BgzfMemberReader::is_bgzf(fq[i])) return false;
+    return true;
+}
+namespace {
+// false: the input is not this path's (reads too long for the LDS kernels) and nothing has been written yet — the caller falls back
+bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, size_t n_files, const Bigsi &b, size_t d, size_t start_sample,
+                             uint8_t qual_offset, BatchClassifier &classifier) {
+    cid_fastq *fr = nullptr;
+    CID_TRY(cid_fastq_create(ctx, (int)n_files, qual_offset, &fr));
+    // a stretch: ~48 MiB of text (150 000 reads of 150 bp), fewer when the dense report rows of its reads would pass 2 GiB
+    size_t target = (size_t)(getenv("COLORID_DEVICE_FASTQ_MB") ? atoi(getenv("COLORID_DEVICE_FASTQ_MB")) : 48) << 20;
+    const size_t by_rows = ((size_t)2 << 30) / ((b.colors.size() + 1) * 4) * 300;
+    if (target > by_rows) target = by_rows < ((size_t)1 << 20) ? ((size_t)1 << 20) : by_rows;
+    std::unique_ptr<BgzfMemberReader> rd[2];
+    for (size_t i = 0; i < n_files; ++i) rd[i].reset(new BgzfMemberReader(fq[i], target));
+    BgzfStretch st[2];
+    bool more[2] = {true, n_files == 2};
+    bool first = true;
+    while (more[0] || more[1]) {
+        const auto t_gpu = Clock::now();
+        for (size_t i = 0; i < n_files; ++i) {
+            if (!more[i]) continue;
+            if (!rd[i]->next(st[i])) { more[i] = false; continue; }
+            CID_TRY(cid_fastq_push_bgzf(fr, (int)i, st[i].bytes.data(), st[i].bytes.size(), st[i].off.data(), st[i].len.data(), st[i].text_len.data(),
+                                        st[i].off.size(), st[i].last ? 1 : 0));
+            if (st[i].last) more[i] = false;
+        }
+        uint64_t n = 0, ne = 0, idb = 0;
+        const int rc = cid_fastq_classify(fr, b.index, (uint32_t)d, (uint32_t)start_sample, &n, &ne, &idb);
+        if (rc == CID_ERR_UNSUPPORTED && first) {
+            fprintf(stderr, "note: %s — using the host front end\n", cid_last_error());
+            cid_fastq_destroy(fr);
+            return false;
+        }
+        if (rc != CID_OK) die("%s%s", cid_last_error(), rc == CID_ERR_UNSUPPORTED ? " (rerun with COLORID_DEVICE_FASTQ=0)" : "");
+        g_ms_gpu_count += ms_since(t_gpu);
+        first = false;
+        if (n == 0) { g_ms_gpu += ms_since(t_gpu); continue; }
+        std::unique_ptr<Counted> c = classifier.take_counted();
+        c->rb.clear();
+        c->nk.resize(n); c->status.resize(n); c->row_start.resize(n + 1); c->colours.resize(ne); c->counts.resize(ne);
+        c->rb.id_off.resize(n + 1);
+        c->rb.id_chars.resize(idb);
+        CID_TRY(cid_fastq_fetch(fr, c->nk.data(), c->status.data(), c->row_start.data(), c->colours.data(), c->counts.data(), c->rb.id_off.data(),
+                                &c->rb.id_chars[0]));
+        c->rb.id_off.resize(n);   // (ReadBatch counts its reads by the ids)
+        g_entries += ne;
+        g_ms_gpu += ms_since(t_gpu);
+        classifier.push_counted(std::move(c));
+    }
+    cid_fastq_destroy(fr);
+    return true;
+}
+}  // namespace
+
 void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
                                        size_t batch, const std::string &prefix, uint8_t qual_offset, size_t start_sample) {
     const auto t0 = Clock::now();
@@ -882,7 +975,10 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
     if (!out) die("could not create outfile!");
     ReadBatch rb;
+    const bool on_device = device_fastq_wanted(fq, 1);
+    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(8, cpu_budget() / 2));   // no inflating / packing threads beside them
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
+    if (!on_device || !classify_bgzf_on_device(ctx, fq, 1, b, d, start_sample, qual_offset, classifier))
     stream_fastq_records(fq[0], nullptr, qual_offset, true, [&](ReadBatch &&piece) {
         if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
         if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);   // (batches close on piece boundaries: at least `batch` reads each)
@@ -891,8 +987,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
-    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms; waits: parser on a full queue %.0f ms, GPU stage idle %.0f ms, "
-                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched; of poll + write: writing %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries, g_ms_write);
+    print_read_id_timing(t0);
 }
 
 void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,
@@ -902,7 +997,10 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
     if (!out) die("could not create outfile!");
     ReadBatch rb;
+    const bool on_device = device_fastq_wanted(fq, 2);
+    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(8, cpu_budget() / 2));
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
+    if (!on_device || !classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, classifier))
     stream_fastq_records(fq[0], &fq[1], qual_offset, true, [&](ReadBatch &&piece) {
         if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
         if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);
@@ -911,8 +1009,7 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu read pairs in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
-    if (g_timing) fprintf(stderr, "timing: total %.0f ms, GPU calls (copies + kernels) %.0f ms, poll + write %.0f ms; waits: parser on a full queue %.0f ms, GPU stage idle %.0f ms, "
-                          "GPU stage on the poll %.0f ms, poll idle %.0f ms; of the GPU calls: counting %.0f ms, %llu (colour, count) entries fetched; of poll + write: writing %.0f ms\n", ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries, g_ms_write);
+    print_read_id_timing(t0);
 }
 
 void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct,

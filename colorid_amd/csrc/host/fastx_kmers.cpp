@@ -613,6 +613,108 @@ static uint64_t scan_records(const char *base, const char *p, const char *end, u
     return lines;
 }
 
+// ---------------------------------------------------------------------------------------------- BgzfMemberReader
+struct BgzfMemberReader::Impl {
+    FILE *raw = nullptr;
+    size_t text_target;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_full, cv_free;
+    std::deque<BgzfStretch> full, spare;
+    bool eof = false, stop = false, handed_last = false;
+    std::vector<unsigned char> tail;   // bytes read from the file behind the last whole member of the stretch before
+    static constexpr size_t kDepth = 2;
+
+    void run() {
+        bool file_end = false;
+        for (;;) {
+            BgzfStretch s;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_free.wait(lk, [&] { return stop || full.size() < kDepth; });
+                if (stop) return;
+                if (!spare.empty()) { s = std::move(spare.front()); spare.pop_front(); }
+            }
+            s.off.clear(); s.len.clear(); s.text_len.clear(); s.text_bytes = 0; s.last = false;
+            s.bytes.assign(tail.begin(), tail.end());
+            tail.clear();
+            size_t pos = 0;   // the first byte not yet assigned to a member
+            auto need = [&](size_t bytes) {   // make s.bytes[pos, pos + bytes) available if the file has them
+                while (s.bytes.size() - pos < bytes && !file_end) {
+                    const size_t have = s.bytes.size(), chunk = 4u << 20;
+                    s.bytes.resize(have + chunk);
+                    const size_t n = fread(s.bytes.data() + have, 1, chunk, raw);
+                    s.bytes.resize(have + n);
+                    if (n == 0) file_end = true;
+                }
+                return s.bytes.size() - pos >= bytes;
+            };
+            while (s.text_bytes < text_target) {
+                if (!need(18)) {
+                    if (s.bytes.size() - pos != 0) die("truncated gzip member header");
+                    s.last = true;
+                    break;
+                }
+                {
+                    const unsigned char *h = s.bytes.data() + pos;
+                    const size_t xlen = h[10] | ((size_t)h[11] << 8);
+                    if (h[0] == 0x1f && h[1] == 0x8b && (h[3] & 4) && !need(12 + xlen)) die("truncated gzip member header");
+                }
+                const size_t msz = LineReader::Impl::bgzf_member_size(s.bytes.data() + pos, s.bytes.size() - pos);
+                if (msz < 26) die("not a block-gzip (BGZF) member inside a BGZF file: mixed gzip streams are not supported in one file");
+                if (!need(msz)) die("truncated gzip member");
+                const unsigned char *t = s.bytes.data() + pos + msz - 4;
+                const size_t isize = t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                if (isize > (1u << 16)) die("BGZF member larger than 64 KiB");
+                s.off.push_back((uint32_t)pos); s.len.push_back((uint32_t)msz); s.text_len.push_back((uint32_t)isize);
+                s.text_bytes += isize;
+                pos += msz;
+                if (pos >= (3ull << 30)) break;   // (offsets are 32-bit)
+            }
+            tail.assign(s.bytes.begin() + (long)pos, s.bytes.end());
+            s.bytes.resize(pos);
+            const bool last = s.last;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                full.push_back(std::move(s));
+                if (last) eof = true;
+            }
+            cv_full.notify_one();
+            if (last) return;
+        }
+    }
+};
+
+BgzfMemberReader::BgzfMemberReader(const std::string &path, size_t text_target) : p_(new Impl) {
+    p_->text_target = text_target ? text_target : 1;
+    p_->raw = fopen(path.c_str(), "rb");
+    if (!p_->raw) die("file not found: %s", path.c_str());
+    p_->worker = std::thread([this] { p_->run(); });
+}
+BgzfMemberReader::~BgzfMemberReader() {
+    {
+        std::lock_guard<std::mutex> lk(p_->mu);
+        p_->stop = true;
+    }
+    p_->cv_free.notify_all();
+    if (p_->worker.joinable()) p_->worker.join();
+    if (p_->raw) fclose(p_->raw);
+    delete p_;
+}
+bool BgzfMemberReader::next(BgzfStretch &s) {
+    std::unique_lock<std::mutex> lk(p_->mu);
+    if (p_->handed_last) return false;
+    if (!s.bytes.empty() || s.bytes.capacity()) { p_->spare.push_back(std::move(s)); s = BgzfStretch(); }
+    p_->cv_full.wait(lk, [&] { return !p_->full.empty(); });
+    s = std::move(p_->full.front());
+    p_->full.pop_front();
+    if (s.last) p_->handed_last = true;
+    lk.unlock();
+    p_->cv_free.notify_one();
+    return true;
+}
+bool BgzfMemberReader::is_bgzf(const std::string &path) { return LineReader::Impl::is_bgzf(path); }
+
 bool RecordChunker::next(RecChunk &c) {
     c.rec_end.clear();
     for (;;) {

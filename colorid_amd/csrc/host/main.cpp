@@ -344,11 +344,14 @@ int cmd_read_id(int argc, char **argv) {
     if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
     // gzip decoding starts now and runs beside GPU start-up (~0.2 s) and the index load: measured against starting it after the
     // context exists, the classification phase of 1 M reads ends 130 ms earlier
-    if (ends_with(fq[0], ".gz"))
+    // (block-gzip input on one GPU goes up compressed and is inflated there, cid_fastq_*: nothing to decode ahead on the host)
+    const bool one_gpu = !a.has("gpus") && !a.has("devices") && !a.has("placement") && !getenv("COLORID_REDUCE");
+    const bool device_front_end = ends_with(fq[0], ".gz") && one_gpu && read_id_mt_pe::device_fastq_wanted(fq, fq.size() > 1 ? 2 : 1);
+    if (ends_with(fq[0], ".gz") && !device_front_end)
         for (size_t i = 0; i < fq.size() && i < 2; ++i) LineReader::prefetch(fq[i]);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_READID);
+    std::thread warm = warm_async(gpus, CID_WARM_READID | (device_front_end ? CID_WARM_INFLATE : 0u));
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);

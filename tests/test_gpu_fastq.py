@@ -185,3 +185,51 @@ def test_block_gzip_members_cut_records(orc, hip_ctx, world):
     ids, nk, st, *_ = fr.classify(hx)
     assert ids == [b"@r"] and st[0] == 1                             # 4 bases < k: too_short
     fr.close()
+
+
+def _write_bgzf(path, text, rng):
+    """block-gzip file: members of irregular sizes (records and lines cut anywhere) + the end marker"""
+    with open(path, "wb") as f:
+        pos = 0
+        while pos < len(text):
+            n = int(rng.choice([200, 5000, 40000, 65280]))
+            f.write(bgzf_member(text[pos:pos + n], level=int(rng.integers(1, 7))))
+            pos += n
+        f.write(bgzf_member(b""))
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paired):
+    """`colorid read_id` on block-gzip input: the device front end (default on one GPU) writes the same _reads.txt / _counts.txt as the host
+    front end (COLORID_DEVICE_FASTQ=0), single-end and paired, several stretches per file (COLORID_DEVICE_FASTQ_MB=1), -Q and -d."""
+    import os
+    import subprocess
+
+    from test_gpu_cli import BIN, PHAGES, REFS
+    tsv = tmp_path / "ref_file.txt"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES))
+    pre = str(tmp_path / "phage")
+    p = subprocess.run([BIN, "build", "-s", "750000", "-n", "4", "-k", "27", "-b", pre, "-r", str(tsv)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    genomes = [b"".join(orc.read_fasta(os.path.join(REFS, n + ".fasta"))) for n in PHAGES]
+    rng = np.random.default_rng(8)
+    r1 = synth_fastq_records(np.random.default_rng(21), genomes, 12000, 150, mate=0, lower_rate=0.0)
+    r2 = synth_fastq_records(np.random.default_rng(21), genomes, 12000, 150, mate=1, lower_rate=0.0)
+    f1, f2 = str(tmp_path / "r_1.fastq.gz"), str(tmp_path / "r_2.fastq.gz")
+    _write_bgzf(f1, fastq_text(r1), rng)
+    _write_bgzf(f2, fastq_text(r2[:11500], b"\r\n", False), rng)
+    q = [f1, f2] if paired else [f1]
+    outs = {}
+    for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {}), ("dev_small", {"COLORID_DEVICE_FASTQ_MB": "1"})):
+        for extra in ([], ["-Q", "0", "-d", "3", "-B", "0"]):
+            name = str(tmp_path / f"{tag}{len(extra)}")
+            p = subprocess.run([BIN, "read_id", "-b", pre + ".bxi", "-q", *q, "-n", name, *extra], capture_output=True, text=True,
+                               env=dict(os.environ, COLORID_TIMING="1", **env))
+            assert p.returncode == 0, p.stderr[-2000:]
+            outs[(tag, len(extra))] = (open(name + "_reads.txt").read(), open(name + "_counts.txt").read(), p.stderr)
+    for extra in (0, 6):
+        host = outs[("host", extra)]
+        assert host[0].count("\n") == (11500 if paired else 12000)
+        for tag in ("dev", "dev_small"):
+            assert outs[(tag, extra)][0] == host[0] and outs[(tag, extra)][1] == host[1], (tag, extra)
+    assert "accept" in outs[("dev", 0)][0]
