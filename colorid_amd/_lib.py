@@ -23,6 +23,8 @@ SIGNATURES = {
     "cid_abi_version": (C.c_int, []),
     "cid_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "cid_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "cid_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+    "cid_pinned_free": (None, [vp]),
     "cid_ctx_set_stream": (C.c_int, [vp, vp]),
     "cid_ctx_synchronize": (C.c_int, [vp]),
     "cid_ctx_destroy": (None, [vp]),
@@ -117,7 +119,7 @@ SIGNATURES = {
     "cid_fastq_create": (C.c_int, [vp, C.c_int, C.c_uint32, C.POINTER(vp)]),
     "cid_fastq_push_bgzf": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.c_int]),
     "cid_fastq_push_text": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int]),
-    "cid_fastq_classify": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cid_fastq_classify": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cid_fastq_fetch": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "cid_fastq_destroy": (None, [vp]),
     "cid_timer_start": (C.c_int, [vp]),

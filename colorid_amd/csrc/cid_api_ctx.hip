@@ -161,6 +161,19 @@ int cid_ctx_create(int device_id, cid_ctx **out) {
     return CID_OK;
 }
 
+// Page-locked host memory for buffers that travel to the device again and again (a reader's text or member buffers): copies from it
+// run at the bus rate and truly asynchronously; the runtime pins and unpins pageable memory around every copy instead.
+int cid_pinned_alloc(size_t bytes, void **out) {
+    if (!out) return fail(CID_ERR_INVALID, "null out");
+    *out = nullptr;
+    const hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; (void)hipGetLastError(); return fail(CID_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    return CID_OK;
+}
+void cid_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int cid_ctx_set_stream(cid_ctx *c, void *hip_stream) {
     if (!c) return fail(CID_ERR_INVALID, "null ctx");
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;

@@ -13,6 +13,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <deque>
 #include <new>
 #include <vector>
 
@@ -25,6 +26,10 @@ namespace cid {
 struct IsNewline {
     const uint8_t *text;
     __device__ bool operator()(uint32_t i) const { return text[i] == '\n'; }
+};
+struct NewlineFlag {
+    const uint8_t *text;
+    __device__ uint64_t operator()(uint32_t i) const { return text[i] == '\n' ? 1ull : 0ull; }
 };
 
 struct FqFile {   // device view of one input's text for the kernels
@@ -139,13 +144,26 @@ struct cid_fastq {
     cid_ctx *ctx = nullptr;
     int n_files = 1;
     uint32_t quality = 0;
-    struct File {
-        uint8_t *text = nullptr;       // carry (the unfinished tail of the stretch before) + the text pushed since
-        size_t cap = 0, len = 0;
-        bool last = false;
-        // members pushed and not yet checked
+    // block-gzip pushes are inflated on a stream of their own, ahead of the classification of the stretch before: a stream of
+    // DEFLATE is decoded serially (one lane), so a launch takes ~14 ms however few members it holds — time the other stream fills
+    hipStream_t inflate_stream = nullptr;
+    hipStream_t text_stream = nullptr;      // host-inflated text travels beside the inflate kernels, not behind them
+    struct Staged {           // one push_bgzf: its text (members' texts back to back) once `done` has fired
+        uint8_t *text = nullptr;
+        size_t bytes = 0;
         uint32_t *d_status = nullptr;
-        size_t n_members = 0, members_seen = 0;
+        size_t n_members = 0;
+        void *d_in = nullptr, *d_mem = nullptr;
+        hipEvent_t done = nullptr;
+        bool last = false;
+    };
+    struct File {
+        uint8_t *text = nullptr;       // carry (the unfinished tail of the stretch before) + the text appended since
+        size_t cap = 0, len = 0;
+        bool last = false, push_closed = false;
+        std::deque<Staged> staged;
+        hipEvent_t copy_pending = nullptr;   // the H2D of a CID_FASTQ_KEEP text push still to be waited for (owned by its Staged entry)
+        size_t members_seen = 0;
     } f[2];
     // the last classify's results (device), fetched by cid_fastq_fetch
     uint64_t n_reads = 0, id_bytes = 0;
@@ -187,6 +205,13 @@ int text_reserve(cid_fastq *fq, int file, size_t extra) {
     return CID_OK;
 }
 
+void free_staged(cid_fastq *fq, cid_fastq::Staged &sg) {   // (after its event has been waited for on the host)
+    cid_ctx *c = fq->ctx;
+    cid::ctx_free(c, sg.text); cid::ctx_free(c, sg.d_status); cid::ctx_free(c, sg.d_in); cid::ctx_free(c, sg.d_mem);
+    if (sg.done) (void)hipEventDestroy(sg.done);
+    sg = cid_fastq::Staged();
+}
+
 void drop_results(cid_fastq *fq) {
     cid_ctx *c = fq->ctx;
     cid::ctx_free(c, fq->d_nk); fq->d_nk = nullptr;
@@ -208,6 +233,12 @@ int cid_fastq_create(cid_ctx *c, int n_files, uint32_t quality, cid_fastq **out)
     cid_fastq *fq = new (std::nothrow) cid_fastq();
     if (!fq) return fail(CID_ERR_NOMEM, "fastq");
     fq->ctx = c; fq->n_files = n_files; fq->quality = quality;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&fq->inflate_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&fq->text_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (fq->inflate_stream) (void)hipStreamDestroy(fq->inflate_stream);
+        delete fq;
+        return fail(CID_ERR_HIP, "stream creation failed");
+    }
     *out = fq;
     return CID_OK;
 }
@@ -217,35 +248,64 @@ void cid_fastq_destroy(cid_fastq *fq) {
     cid_ctx *c = fq->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (fq->inflate_stream) (void)hipStreamSynchronize(fq->inflate_stream);
+    if (fq->text_stream) (void)hipStreamSynchronize(fq->text_stream);
     drop_results(fq);
-    for (int i = 0; i < 2; ++i) { cid::ctx_free(c, fq->f[i].text); cid::ctx_free(c, fq->f[i].d_status); }
+    for (int i = 0; i < 2; ++i) {
+        cid::ctx_free(c, fq->f[i].text);
+        for (cid_fastq::Staged &sg : fq->f[i].staged) free_staged(fq, sg);
+    }
+    if (fq->inflate_stream) (void)hipStreamDestroy(fq->inflate_stream);
+    if (fq->text_stream) (void)hipStreamDestroy(fq->text_stream);
     delete fq;
 }
 
-int cid_fastq_push_text(cid_fastq *fq, int file, const uint8_t *text, size_t n_bytes, int last) {
+// A push of either kind waits its turn as a Staged entry: the bytes travel on the reader's own stream, the text is appended by the
+// classify call that takes it — so host-inflated text and device-inflated members of one file may alternate in any order.
+int cid_fastq_push_text(cid_fastq *fq, int file, const uint8_t *text, size_t n_bytes, int flags) {
     if (!fq || file < 0 || file >= fq->n_files || (n_bytes && !text)) return fail(CID_ERR_INVALID, "bad argument");
+    const int last = flags & CID_FASTQ_LAST;
     cid_fastq::File &F = fq->f[file];
-    if (F.last) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
+    if (F.copy_pending) {   // the CID_FASTQ_KEEP push before this one: its buffer is the caller's again from here on
+        const hipError_t e = hipEventSynchronize(F.copy_pending);
+        F.copy_pending = nullptr;
+        if (e != hipSuccess) return fail(CID_ERR_HIP, "cid_fastq_push_text: %s", hipGetErrorString(e));
+    }
+    if (F.push_closed) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
+    if (F.staged.size() >= 64) return fail(CID_ERR_STATE, "file %d: 64 pushes are waiting for classify calls", file);
+    if (n_bytes >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "a push is limited to 4 GiB of text");
     cid_ctx *c = fq->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = text_reserve(fq, file, n_bytes);
-    if (rc) return rc;
+    cid_fastq::Staged sg;
+    sg.bytes = n_bytes; sg.last = last != 0;
     if (n_bytes) {
-        HIP_TRY(hipMemcpyAsync(F.text + F.len, text, n_bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's buffer is free again
+        void *p = nullptr;
+        const int rc = cid::ctx_alloc(c, n_bytes + 16, &p);
+        if (rc) return rc;
+        sg.text = (uint8_t *)p;
+        hipEvent_t behind = cid::ctx_event(c, 0);
+        hipError_t e = hipEventRecord(behind, c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(fq->text_stream, behind, 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sg.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMemcpyAsync(sg.text, text, n_bytes, hipMemcpyHostToDevice, fq->text_stream);
+        if (e == hipSuccess) e = hipEventRecord(sg.done, fq->text_stream);
+        if (e == hipSuccess && (flags & CID_FASTQ_KEEP)) F.copy_pending = sg.done;   // (page-locked source: the copy runs on beside the caller)
+        else if (e == hipSuccess) e = hipEventSynchronize(sg.done);                   // the caller's buffer is free again
+        if (e != hipSuccess) { free_staged(fq, sg); return fail(CID_ERR_HIP, "cid_fastq_push_text: %s", hipGetErrorString(e)); }
     }
-    F.len += n_bytes;
-    F.last = last != 0;
+    F.staged.push_back(sg);
+    F.push_closed = sg.last;
     return CID_OK;
 }
 
 int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
-                        const uint32_t *text_len, size_t n_members, int last) {
+                        const uint32_t *text_len, size_t n_members, int flags) {
+    const int last = flags & CID_FASTQ_LAST;
     if (!fq || file < 0 || file >= fq->n_files) return fail(CID_ERR_INVALID, "bad argument");
     if (n_members && (!members || !member_off || !member_len || !text_len)) return fail(CID_ERR_INVALID, "null argument");
     cid_fastq::File &F = fq->f[file];
-    if (F.last) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
-    if (F.n_members) return fail(CID_ERR_STATE, "file %d: one block-gzip push per classify call", file);
+    if (F.push_closed) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
+    if (F.staged.size() >= 64) return fail(CID_ERR_STATE, "file %d: 64 pushes are waiting for classify calls", file);
     if (n_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "a push of BGZF members is limited to 4 GiB");
     cid_ctx *c = fq->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -254,33 +314,48 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
     for (size_t i = 0; i < n_members; ++i) {
         if ((uint64_t)member_off[i] + member_len[i] > n_bytes) return fail(CID_ERR_INVALID, "member %zu lies outside the push", i);
         if (text_len[i] > 65536u) return fail(CID_ERR_INVALID, "member %zu: more than 64 KiB of text", i);
+        mem[i] = cid::BgzfMember{member_off[i], member_len[i], (uint32_t)text_total, text_len[i]};
         text_total += text_len[i];
     }
-    int rc = text_reserve(fq, file, text_total);
-    if (rc) return rc;
-    uint64_t at = F.len;
-    for (size_t i = 0; i < n_members; ++i) { mem[i] = cid::BgzfMember{member_off[i], member_len[i], (uint32_t)at, text_len[i]}; at += text_len[i]; }
+    if (text_total >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "a push of BGZF members is limited to 4 GiB of text");
+    cid_fastq::Staged sg;
+    sg.bytes = (size_t)text_total; sg.n_members = n_members; sg.last = last != 0;
     if (n_members) {
-        Buf<uint8_t> d_in(c);
-        Buf<cid::BgzfMember> d_mem(c);
-        if ((rc = d_in.alloc(n_bytes + 16)) || (rc = d_mem.alloc(n_members))) return rc;
-        cid::ctx_free(c, F.d_status); F.d_status = nullptr;
-        void *st = nullptr;
-        if ((rc = cid::ctx_alloc(c, n_members * 4, &st))) return rc;
-        F.d_status = (uint32_t *)st;
-        HIP_TRY(hipMemcpyAsync(d_in.p, members, n_bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_mem.p, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(cid::bgzf_inflate_launch(c, d_in.p, d_mem.p, (uint32_t)n_members, F.text, F.d_status));
-        HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's buffers (and `mem`) are free again; d_in / d_mem return to the cache
-        F.n_members = n_members;
+        void *p = nullptr;
+        int rc;
+        if ((rc = cid::ctx_alloc(c, text_total + 16, &p))) return rc;
+        sg.text = (uint8_t *)p;
+        if ((rc = cid::ctx_alloc(c, n_members * 4, &p))) { free_staged(fq, sg); return rc; }
+        sg.d_status = (uint32_t *)p;
+        if ((rc = cid::ctx_alloc(c, n_bytes + 16, &sg.d_in)) || (rc = cid::ctx_alloc(c, n_members * sizeof(cid::BgzfMember), &sg.d_mem))) { free_staged(fq, sg); return rc; }
+        // the blocks may have just come back from work queued on the ctx stream: the inflate stream starts behind it
+        // (the members travel on the text stream: the inflate stream may still be busy with the push before, and the copy need not wait for it)
+        hipEvent_t behind = cid::ctx_event(c, 0);
+        hipError_t e = hipEventRecord(behind, c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(fq->text_stream, behind, 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sg.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMemcpyAsync(sg.d_in, members, n_bytes, hipMemcpyHostToDevice, fq->text_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sg.d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, fq->text_stream);
+        hipEvent_t copied = cid::ctx_event(c, 1);
+        if (e == hipSuccess) e = hipEventRecord(copied, fq->text_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(fq->inflate_stream, copied, 0);
+        if (e == hipSuccess) e = cid::bgzf_inflate_launch(c, fq->inflate_stream, (const uint8_t *)sg.d_in, (const cid::BgzfMember *)sg.d_mem, (uint32_t)n_members, sg.text,
+                                                          sg.d_status);
+        if (e == hipSuccess) e = hipEventRecord(sg.done, fq->inflate_stream);
+        if (e == hipSuccess) e = hipEventSynchronize(copied);   // the caller's buffers (and `mem`) are free again; the kernel runs on
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(fq->inflate_stream);
+            free_staged(fq, sg);
+            return fail(CID_ERR_HIP, "cid_fastq_push_bgzf: %s", hipGetErrorString(e));
+        }
     }
-    F.len = at;
-    F.last = last != 0;
+    F.staged.push_back(sg);
+    F.push_closed = sg.last;
     return CID_OK;
 }
 
-int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t *n_reads, uint64_t *n_entries,
-                       uint64_t *id_bytes) {
+int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
+                       uint64_t *n_entries, uint64_t *id_bytes) {
     if (!fq || !n_reads || !n_entries || !id_bytes) return fail(CID_ERR_INVALID, "null argument");
     *n_reads = *n_entries = *id_bytes = 0;
     cid_ctx *c = fq->ctx;
@@ -292,17 +367,39 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
     drop_results(fq);
     c->sp_rows = 0; c->sp_entries = 0;
     const int nf = fq->n_files;
-    // the members inflated since the last call: every one is checked as zlib checks it; the first corrupt one is an error
+    // the block-gzip pushes this call takes (per file the oldest max_pushes; <= 0: all): wait for their inflate, check every member as
+    // zlib checks it (the first corrupt one is an error), append their text behind what the file holds
     for (int f = 0; f < nf; ++f) {
         cid_fastq::File &F = fq->f[f];
-        if (!F.n_members) continue;
-        std::vector<uint32_t> h(F.n_members);
-        HIP_TRY(hipMemcpyAsync(h.data(), F.d_status, F.n_members * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (size_t i = 0; i < F.n_members; ++i)
-            if (h[i]) return fail(CID_ERR_INVALID, "corrupt gzip member %zu of file %d: %s", F.members_seen + i, f, cid::bgzf_status_text(h[i]));
-        F.members_seen += F.n_members;
-        F.n_members = 0;
+        for (int taken = 0; !F.staged.empty() && (max_pushes <= 0 || taken < max_pushes); ++taken) {
+            cid_fastq::Staged sg = F.staged.front();
+            F.staged.pop_front();
+            if (sg.done) {
+                if (F.copy_pending == sg.done) F.copy_pending = nullptr;
+                hipError_t e = hipEventSynchronize(sg.done);
+                if (e == hipSuccess && sg.n_members) {
+                    std::vector<uint32_t> h(sg.n_members);
+                    e = hipMemcpyAsync(h.data(), sg.d_status, sg.n_members * 4, hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    for (size_t i = 0; e == hipSuccess && i < sg.n_members; ++i)
+                        if (h[i]) {
+                            const size_t at = F.members_seen + i;
+                            free_staged(fq, sg);
+                            return fail(CID_ERR_INVALID, "corrupt gzip member %zu of file %d: %s", at, f, cid::bgzf_status_text(h[i]));
+                        }
+                    F.members_seen += sg.n_members;
+                }
+                if (e != hipSuccess) { free_staged(fq, sg); return fail(CID_ERR_HIP, "cid_fastq_classify: %s", hipGetErrorString(e)); }
+                if ((rc = text_reserve(fq, f, sg.bytes))) { free_staged(fq, sg); return rc; }
+                if (sg.bytes) {
+                    const hipError_t e2 = hipMemcpyAsync(F.text + F.len, sg.text, sg.bytes, hipMemcpyDeviceToDevice, st);
+                    if (e2 != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { free_staged(fq, sg); return fail(CID_ERR_HIP, "cid_fastq_classify: text append"); }
+                }
+                F.len += sg.bytes;
+            }
+            if (sg.last) F.last = true;
+            free_staged(fq, sg);
+        }
     }
     // line ends of either text
     Buf<uint32_t> nl[2] = {Buf<uint32_t>(c), Buf<uint32_t>(c)};
@@ -313,7 +410,19 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
     cid::FqFile F[2] = {{nullptr, nullptr, n_nl.p, 0}, {nullptr, nullptr, n_nl.p + 1, 0}};
     for (int f = 0; f < nf; ++f) {
         cid_fastq::File &src = fq->f[f];
-        if ((rc = nl[f].alloc(src.len + 2))) return rc;
+        // how many line ends: counted first, so that their positions take 4 bytes per LINE of scratch, not 4 per byte of text
+        uint64_t lines = 0;
+        if (src.len) {
+            auto is_nl = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), cid::NewlineFlag{src.text});
+            size_t tbr = 0;
+            HIP_TRY(rocprim::reduce(nullptr, tbr, is_nl, n_nl.p + f, (uint64_t)0, src.len, rocprim::plus<uint64_t>(), st));
+            Buf<uint8_t> tmpr(c);
+            if ((rc = tmpr.alloc(tbr))) return rc;
+            HIP_TRY(rocprim::reduce(tmpr.p, tbr, is_nl, n_nl.p + f, (uint64_t)0, src.len, rocprim::plus<uint64_t>(), st));
+            HIP_TRY(hipMemcpyAsync(&lines, n_nl.p + f, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if ((rc = nl[f].alloc(lines + 2))) return rc;
         F[f] = cid::FqFile{src.text, nl[f].p, n_nl.p + f, (uint32_t)src.len};
         if (src.len) {
             size_t tb = 0;

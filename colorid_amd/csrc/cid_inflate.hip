@@ -430,7 +430,8 @@ hipError_t warm_inflate() {
 }
 
 // the kernel on device-resident members: text to d_out + member.out_off, one status word per member; asynchronous on the ctx stream
-hipError_t bgzf_inflate_launch(cid_ctx *c, const uint8_t *d_in, const BgzfMember *d_mem, uint32_t n_members, uint8_t *d_out, uint32_t *d_st) {
+hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_in, const BgzfMember *d_mem, uint32_t n_members, uint8_t *d_out,
+                               uint32_t *d_st) {
     if (n_members == 0) return hipSuccess;
     static const CrcShift shift = make_crc_shift();
     static const int lanes = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : kInflateLanes;   // members per wave: 1, 2, 4 or 8
@@ -439,7 +440,7 @@ hipError_t bgzf_inflate_launch(cid_ctx *c, const uint8_t *d_in, const BgzfMember
     const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // a few rounds per block at most
     if (grid > cap) grid = cap;
     const size_t lds = (size_t)lpw * kLdsBytes;
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, c->stream, d_in, d_mem, n_members, d_out, d_st, shift); };
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, stream, d_in, d_mem, n_members, d_out, d_st, shift); };
     if (lpw == 1) launch(k_bgzf_inflate<1>);
     else if (lpw == 4) launch(k_bgzf_inflate<4>);
     else if (lpw == 8) launch(k_bgzf_inflate<8>);
@@ -503,7 +504,7 @@ extern "C" int cid_bgzf_inflate_start(cid_ctx *c, const uint8_t *members, size_t
         HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(cid::bgzf_inflate_launch(c, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem, (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st));
+    HIP_TRY(cid::bgzf_inflate_launch(c, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem, (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st));
     c->inflate.d_out = d_out; c->inflate.d_st = d_st;
     if (pin) {
         HIP_TRY(hipMemcpyAsync(pin + b_st, d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));

@@ -81,9 +81,10 @@ int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_
                    uint32_t **d_counts, uint64_t *n_entries);
 
 // block-gzip members on the device (cid_inflate.hip): member i = in[in_off, +in_len) (header, DEFLATE data, CRC-32, ISIZE), its text to
-// out[out_off, +out_len); status[i] = 0 or the reason it is corrupt.  Asynchronous on the ctx stream.
+// out[out_off, +out_len); status[i] = 0 or the reason it is corrupt.  Asynchronous on `stream`.
 struct BgzfMember { uint32_t in_off, in_len, out_off, out_len; };
-hipError_t bgzf_inflate_launch(cid_ctx *c, const uint8_t *d_in, const BgzfMember *d_mem, uint32_t n_members, uint8_t *d_out, uint32_t *d_st);
+hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_in, const BgzfMember *d_mem, uint32_t n_members, uint8_t *d_out,
+                               uint32_t *d_st);
 const char *bgzf_status_text(uint32_t st);
 
 // load a translation unit's code object ahead of its first kernel launch (cid_warmup)

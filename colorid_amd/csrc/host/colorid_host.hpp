@@ -10,6 +10,7 @@
 #include <functional>
 #include <deque>
 #include <condition_variable>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -143,20 +144,65 @@ class LineReader {   // inflates on its own thread, a few MiB ahead of the calle
 // Block-gzip (BGZF) input for the device front end (cid_fastq_*): the file's members still COMPRESSED, in stretches worth about
 // `text_target` bytes of text — the reading thread only walks the members' headers (their sizes are in the "BC" extra field, the
 // text sizes in the trailers) a stretch or two ahead of the caller; inflate, line split, record split and masking happen on the GPU.
+struct ByteBuf {   // a growable byte buffer that never zero-fills what it is about to overwrite (fread targets of tens of MB)
+    unsigned char *p = nullptr;
+    size_t n = 0, cap = 0;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf &) = delete;
+    ByteBuf &operator=(const ByteBuf &) = delete;
+    ByteBuf(ByteBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ByteBuf &operator=(ByteBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+    ~ByteBuf() { free(p); }
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        size_t c = cap ? cap : (size_t)1 << 20;
+        while (c < want) c += c / 2;
+        unsigned char *q = static_cast<unsigned char *>(realloc(p, c));
+        if (!q) die("out of memory (%zu bytes)", c);
+        p = q; cap = c;
+    }
+    unsigned char *data() { return p; }
+    const unsigned char *data() const { return p; }
+    size_t size() const { return n; }
+};
+struct PinnedBuf {   // page-locked bytes from the library (cid_pinned_alloc; plain malloc when that fails), grown, never shrunk
+    unsigned char *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    PinnedBuf(PinnedBuf &&o) noexcept : p(o.p), cap(o.cap), pinned(o.pinned) { o.p = nullptr; o.cap = 0; }
+    PinnedBuf &operator=(PinnedBuf &&o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; pinned = o.pinned; o.p = nullptr; o.cap = 0; } return *this; }
+    ~PinnedBuf() { release(); }
+    void release();
+    void reserve(size_t want);   // (contents are not kept)
+};
 struct BgzfStretch {
-    std::vector<unsigned char> bytes;              // whole members, back to back
+    ByteBuf bytes;                                 // whole members, back to back
     std::vector<uint32_t> off, len, text_len;      // member i = bytes[off[i], +len[i]), its text has text_len[i] bytes
     uint64_t text_bytes = 0;
     bool last = false;                             // the file ends with this stretch
+    // the members [device_members, off.size()) are inflated already, by the reader's host threads: their text, back to back
+    size_t device_members = 0;
+    PinnedBuf host_text;
+    size_t host_text_bytes = 0;
 };
 class BgzfMemberReader {
   public:
-    BgzfMemberReader(const std::string &path, size_t text_target);
+    // host_share: the fraction of every stretch's text that `host_threads` threads of the reader inflate themselves (0: none)
+    BgzfMemberReader(const std::string &path, size_t text_target, double host_share = 0.0, int host_threads = 0);
     ~BgzfMemberReader();
     BgzfMemberReader(const BgzfMemberReader &) = delete;
     BgzfMemberReader &operator=(const BgzfMemberReader &) = delete;
     bool next(BgzfStretch &s);                     // false after the stretch that had last == true; `s`'s buffers are recycled
     static bool is_bgzf(const std::string &path);
+    // Start reading `path` now (the CLI calls this before the GPU context and the index exist); open() hands the running reader over
+    // — or starts one — to whoever classifies the file.  drop_prefetched(): readers nobody took.
+    static void prefetch(const std::string &path, size_t text_target, double host_share, int host_threads);
+    static std::unique_ptr<BgzfMemberReader> open(const std::string &path, size_t text_target, double host_share, int host_threads);
+    static void drop_prefetched();
+    size_t text_target() const;
     struct Impl;
   private:
     Impl *p_;
@@ -238,6 +284,9 @@ void batch_search(cid_ctx *, const std::vector<std::string> &files1, const std::
 namespace read_id_mt_pe {
 // block-gzip (BGZF) fastq input on one GPU takes the device front end (cid_fastq_*) unless COLORID_DEVICE_FASTQ=0
 bool device_fastq_wanted(const std::vector<std::string> &fq, size_t n_files);
+size_t device_fastq_stretch_bytes(size_t n_colors);   // text per stretch (n_colors == 0: before the index is known)
+double device_fastq_host_share();                     // share of a stretch's text inflated by the reader's host threads
+int device_fastq_host_threads(size_t n_files);
 void per_read_stream_se(cid_ctx *, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct, size_t batch,
                         const std::string &prefix, uint8_t qual_offset, size_t start_sample);   // read_id_mt_pe.rs:835-951
 void per_read_stream_pe(cid_ctx *, const std::vector<std::string> &fq, const Bigsi &b, size_t d, double fp_correct, size_t batch,

@@ -910,11 +910,39 @@ static void print_read_id_timing(const Clock::time_point &t0) {
 // poll.  No inflating threads, no record packers: the host reads the file, polls and writes.  COLORID_DEVICE_FASTQ=0 keeps the host
 // front end; several GPUs (--gpus / --placement) use it too.
 bool read_id_mt_pe::device_fastq_wanted(const std::vector<std::string> &fq, size_t n_files) {
+    // default: single-end input.  Pairs are inflate-bound on either path (twice the text per read pair for the same threads) and measured
+    // no faster through the device (4 M pairs: 0.39-0.45 s host front end, 0.39-0.51 s device): COLORID_DEVICE_FASTQ=1 asks for it.
     const char *e = getenv("COLORID_DEVICE_FASTQ");
-    if ((e && atoi(e) == 0) || g_group) return false;
+    if ((e && atoi(e) == 0) || (!e && n_files > 1) || g_group) return false;
     for (size_t i = 0; i < n_files; ++i)
         if (!BgzfMemberReader::is_bgzf(fq[i])) return false;
     return true;
+}
+// a stretch: ~256 MiB of text (800 000 reads of 150 bp: a DEFLATE stream decodes serially, so a launch takes ~14 ms however few members
+// it holds), fewer when the dense report rows of its reads would pass 8 GiB
+size_t read_id_mt_pe::device_fastq_stretch_bytes(size_t n_colors) {
+    size_t target = (size_t)(getenv("COLORID_DEVICE_FASTQ_MB") ? atoi(getenv("COLORID_DEVICE_FASTQ_MB")) : 256) << 20;
+    const size_t by_rows = ((size_t)8 << 30) / ((n_colors + 1) * 4) * 300;
+    if (target > by_rows) target = by_rows < ((size_t)1 << 20) ? ((size_t)1 << 20) : by_rows;
+    return target;
+}
+// DEFLATE decodes serially inside a member, so the device inflates a member per lane at ~10 GB/s of text in all, while the cores the
+// host front end would spend on inflating and packing are idle: the reader's threads inflate this share of every stretch (the rest
+// goes up compressed).  Measured on a 16-CPU share (tools/exp_frontend.sh): see DESIGN.md.
+double read_id_mt_pe::device_fastq_host_share() {
+    if (const char *e = getenv("COLORID_DEVICE_FASTQ_HOST_SHARE")) { const double v = atof(e); return v < 0.0 ? 0.0 : v > 1.0 ? 1.0 : v; }
+    // a host thread inflates ~0.7 GB/s of text, the device ~10 GB/s beside the classification it also runs: with the eight threads a
+    // 16-CPU share leaves, an even split keeps both sides busy (16 M reads, tools/exp_frontend_16m.sh: 0.71-0.73 s at share 0.5, 0.84-0.90 s
+    // with the host inflating everything, 0.89-0.96 s with the device inflating everything; host front end 1.02-1.21 s)
+    const double v = (double)device_fastq_host_threads(1) * 0.0625;
+    return v > 1.0 ? 1.0 : v;
+}
+int read_id_mt_pe::device_fastq_host_threads(size_t n_files) {
+    // the process's CPU share (cgroup quota) minus the threads that are busy anyway — four polling, the readers, the GPU stage, the
+    // writer: a process whose runnable threads exceed its quota is throttled as a whole, GPU stage included
+    const char *e = getenv("COLORID_GZ_THREADS");
+    const int v = e ? atoi(e) : std::max(1, (cpu_budget() - 8) / (int)(n_files ? n_files : 1));
+    return v < 1 ? 1 : v > 12 ? 12 : v;
 }
 namespace {
 // false: the input is not this path's (reads too long for the LDS kernels) and nothing has been written yet — the caller falls back
@@ -922,26 +950,43 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
                              uint8_t qual_offset, BatchClassifier &classifier) {
     cid_fastq *fr = nullptr;
     CID_TRY(cid_fastq_create(ctx, (int)n_files, qual_offset, &fr));
-    // a stretch: ~48 MiB of text (150 000 reads of 150 bp), fewer when the dense report rows of its reads would pass 2 GiB
-    size_t target = (size_t)(getenv("COLORID_DEVICE_FASTQ_MB") ? atoi(getenv("COLORID_DEVICE_FASTQ_MB")) : 48) << 20;
-    const size_t by_rows = ((size_t)2 << 30) / ((b.colors.size() + 1) * 4) * 300;
-    if (target > by_rows) target = by_rows < ((size_t)1 << 20) ? ((size_t)1 << 20) : by_rows;
+    const size_t target = read_id_mt_pe::device_fastq_stretch_bytes(b.colors.size());
     std::unique_ptr<BgzfMemberReader> rd[2];
-    for (size_t i = 0; i < n_files; ++i) rd[i].reset(new BgzfMemberReader(fq[i], target));
-    BgzfStretch st[2];
+    for (size_t i = 0; i < n_files; ++i)   // (reading since before the index load, main.cpp)
+        rd[i] = BgzfMemberReader::open(fq[i], target, read_id_mt_pe::device_fastq_host_share(), read_id_mt_pe::device_fastq_host_threads(n_files));
+    BgzfStretch st[2][2];   // per file two stretches in turn: the one pushed last stays untouched while its text is still on the bus
+    size_t turn[2] = {0, 0};
     bool more[2] = {true, n_files == 2};
+    size_t pending[2] = {0, 0};   // stretches pushed and not yet taken by a classify call
+    double ms_read = 0, ms_push = 0, ms_classify = 0, ms_fetch = 0;
+    auto push_next = [&](size_t i) {
+        if (!more[i]) return;
+        const auto tr = Clock::now();
+        BgzfStretch &sx = st[i][turn[i]++ & 1];
+        const bool got = rd[i]->next(sx);
+        ms_read += ms_since(tr);
+        if (!got) { more[i] = false; return; }
+        const auto tp = Clock::now();
+        // the device's members first, then the text the reader's threads inflated (two pushes: classify takes both)
+        const bool host_part = sx.host_text_bytes > 0;
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), sx.bytes.size(), sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
+                                    sx.last && !host_part ? CID_FASTQ_LAST : 0));
+        if (host_part)
+            CID_TRY(cid_fastq_push_text(fr, (int)i, sx.host_text.p, sx.host_text_bytes, (sx.last ? CID_FASTQ_LAST : 0) | (sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));
+        if (sx.last) more[i] = false;
+        ms_push += ms_since(tp);
+        ++pending[i];
+    };
+    auto t_gpu = Clock::now();
+    for (size_t i = 0; i < n_files; ++i) push_next(i);
     bool first = true;
-    while (more[0] || more[1]) {
-        const auto t_gpu = Clock::now();
-        for (size_t i = 0; i < n_files; ++i) {
-            if (!more[i]) continue;
-            if (!rd[i]->next(st[i])) { more[i] = false; continue; }
-            CID_TRY(cid_fastq_push_bgzf(fr, (int)i, st[i].bytes.data(), st[i].bytes.size(), st[i].off.data(), st[i].len.data(), st[i].text_len.data(),
-                                        st[i].off.size(), st[i].last ? 1 : 0));
-            if (st[i].last) more[i] = false;
-        }
+    while (pending[0] || pending[1]) {
+        for (size_t i = 0; i < n_files; ++i) push_next(i);   // the stretch after this one: inflated while this one is classified
         uint64_t n = 0, ne = 0, idb = 0;
-        const int rc = cid_fastq_classify(fr, b.index, (uint32_t)d, (uint32_t)start_sample, &n, &ne, &idb);
+        const auto tc = Clock::now();
+        const int rc = cid_fastq_classify(fr, b.index, (uint32_t)d, (uint32_t)start_sample, 2, &n, &ne, &idb);
+        ms_classify += ms_since(tc);
+        for (size_t i = 0; i < n_files; ++i) if (pending[i]) --pending[i];
         if (rc == CID_ERR_UNSUPPORTED && first) {
             fprintf(stderr, "note: %s — using the host front end\n", cid_last_error());
             cid_fastq_destroy(fr);
@@ -950,20 +995,27 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
         if (rc != CID_OK) die("%s%s", cid_last_error(), rc == CID_ERR_UNSUPPORTED ? " (rerun with COLORID_DEVICE_FASTQ=0)" : "");
         g_ms_gpu_count += ms_since(t_gpu);
         first = false;
-        if (n == 0) { g_ms_gpu += ms_since(t_gpu); continue; }
-        std::unique_ptr<Counted> c = classifier.take_counted();
-        c->rb.clear();
-        c->nk.resize(n); c->status.resize(n); c->row_start.resize(n + 1); c->colours.resize(ne); c->counts.resize(ne);
-        c->rb.id_off.resize(n + 1);
-        c->rb.id_chars.resize(idb);
-        CID_TRY(cid_fastq_fetch(fr, c->nk.data(), c->status.data(), c->row_start.data(), c->colours.data(), c->counts.data(), c->rb.id_off.data(),
-                                &c->rb.id_chars[0]));
-        c->rb.id_off.resize(n);   // (ReadBatch counts its reads by the ids)
-        g_entries += ne;
-        g_ms_gpu += ms_since(t_gpu);
-        classifier.push_counted(std::move(c));
+        if (n) {
+            std::unique_ptr<Counted> c = classifier.take_counted();
+            c->rb.clear();
+            c->nk.resize(n); c->status.resize(n); c->row_start.resize(n + 1); c->colours.resize(ne); c->counts.resize(ne);
+            c->rb.id_off.resize(n + 1);
+            c->rb.id_chars.resize(idb);
+            const auto tf = Clock::now();
+            CID_TRY(cid_fastq_fetch(fr, c->nk.data(), c->status.data(), c->row_start.data(), c->colours.data(), c->counts.data(), c->rb.id_off.data(),
+                                    &c->rb.id_chars[0]));
+            ms_fetch += ms_since(tf);
+            c->rb.id_off.resize(n);   // (ReadBatch counts its reads by the ids)
+            g_entries += ne;
+            g_ms_gpu += ms_since(t_gpu);
+            classifier.push_counted(std::move(c));
+        } else g_ms_gpu += ms_since(t_gpu);
+        t_gpu = Clock::now();
     }
     cid_fastq_destroy(fr);
+    if (g_timing)
+        fprintf(stderr, "timing: device front end: waiting for the file reader %.0f ms, push (H2D of the members) %.0f ms, classify %.0f ms, fetch %.0f ms\n",
+                ms_read, ms_push, ms_classify, ms_fetch);
     return true;
 }
 }  // namespace
@@ -976,7 +1028,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 1);
-    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(8, cpu_budget() / 2));   // no inflating / packing threads beside them
+    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(4, cpu_budget() / 4));   // no packing threads beside them
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
     if (!on_device || !classify_bgzf_on_device(ctx, fq, 1, b, d, start_sample, qual_offset, classifier))
     stream_fastq_records(fq[0], nullptr, qual_offset, true, [&](ReadBatch &&piece) {
@@ -998,7 +1050,7 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 2);
-    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(8, cpu_budget() / 2));
+    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(4, cpu_budget() / 4));
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
     if (!on_device || !classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, classifier))
     stream_fastq_records(fq[0], &fq[1], qual_offset, true, [&](ReadBatch &&piece) {

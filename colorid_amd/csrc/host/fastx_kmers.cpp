@@ -614,7 +614,74 @@ static uint64_t scan_records(const char *base, const char *p, const char *end, u
 }
 
 // ---------------------------------------------------------------------------------------------- BgzfMemberReader
+// page-locked memory is slow to get and to give back (hipHostMalloc / hipHostFree of 256 MiB: tens of milliseconds each): buffers a
+// reader lets go of wait in a pool for the next one — never returned to the runtime, the process ends with the command
+namespace {
+std::mutex g_pin_mu;
+std::vector<std::pair<unsigned char *, size_t>> g_pin_pool;
+}
+void PinnedBuf::release() {
+    if (!p) return;
+    if (pinned) { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_pool.emplace_back(p, cap); }
+    else free(p);
+    p = nullptr; cap = 0;
+}
+void PinnedBuf::reserve(size_t want) {
+    if (want <= cap) return;
+    release();
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pin_pool.size(); ++i)
+            if (g_pin_pool[i].second >= want) {
+                p = g_pin_pool[i].first; cap = g_pin_pool[i].second; pinned = true;
+                g_pin_pool.erase(g_pin_pool.begin() + (long)i);
+                return;
+            }
+    }
+    size_t c = want + want / 8 + 4096;
+    void *q = nullptr;
+    if (cid_pinned_alloc(c, &q) == CID_OK) { p = static_cast<unsigned char *>(q); pinned = true; }
+    else { p = static_cast<unsigned char *>(malloc(c)); pinned = false; if (!p) die("out of memory (%zu bytes)", c); }
+    cap = c;
+}
+
+// members [m0, m1) of `s` inflated into out (their texts back to back) by the pool's threads and this one; every member's CRC-32 and
+// ISIZE are checked (libdeflate when the host has it, else zlib)
+static void inflate_members_host(TaskPool *pool, int n_threads, const BgzfStretch &s, size_t m0, size_t m1, unsigned char *out) {
+    if (m1 <= m0) return;
+    std::vector<size_t> at(m1 - m0 + 1, 0);
+    for (size_t i = m0; i < m1; ++i) at[i - m0 + 1] = at[i - m0] + s.text_len[i];
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, n_threads), m1 - m0);
+    std::vector<int> bad(nt, 0);
+    auto work = [&](int t) {
+        const LibDeflate &ld = libdeflate();
+        void *dc = ld.ok ? ld.alloc() : nullptr;
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (!dc && inflateInit2(&zs, 15 + 16) != Z_OK) { bad[t] = 1; return; }
+        for (size_t i = m0 + (size_t)t; i < m1; i += (size_t)nt) {
+            unsigned char *dst = out + at[i - m0];
+            if (dc) {   // exact output size given, no "actual" pointer: anything else than ISIZE bytes is an error
+                if (ld.gzip(dc, s.bytes.p + s.off[i], s.len[i], dst, s.text_len[i], nullptr) != 0) { bad[t] = 1; break; }
+            } else {
+                inflateReset(&zs);
+                zs.next_in = const_cast<Bytef *>(s.bytes.p + s.off[i]); zs.avail_in = (uInt)s.len[i];
+                zs.next_out = dst; zs.avail_out = (uInt)s.text_len[i];
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.total_out != s.text_len[i]) { bad[t] = 1; break; }   // zlib checked the member's CRC-32
+            }
+        }
+        if (dc) ld.release(dc); else inflateEnd(&zs);
+    };
+    if (pool && nt > 1) pool->parallel_for((size_t)nt, [&](size_t t) { work((int)t); });
+    else for (int t = 0; t < nt; ++t) work(t);
+    for (int t = 0; t < nt; ++t) if (bad[t]) die("corrupt gzip member (inflate / CRC-32 failed)");
+}
+
 struct BgzfMemberReader::Impl {
+    double host_share = 0.0;
+    int host_threads = 0;
+    std::unique_ptr<TaskPool> pool;
     FILE *raw = nullptr;
     size_t text_target;
     std::thread worker;
@@ -627,6 +694,7 @@ struct BgzfMemberReader::Impl {
 
     void run() {
         bool file_end = false;
+        size_t guess = 0;   // compressed bytes of the stretch before: the next one is read with one fread of about that size
         for (;;) {
             BgzfStretch s;
             {
@@ -636,34 +704,38 @@ struct BgzfMemberReader::Impl {
                 if (!spare.empty()) { s = std::move(spare.front()); spare.pop_front(); }
             }
             s.off.clear(); s.len.clear(); s.text_len.clear(); s.text_bytes = 0; s.last = false;
-            s.bytes.assign(tail.begin(), tail.end());
+            s.bytes.reserve(tail.size() + (guess ? guess + guess / 8 : (size_t)8 << 20));
+            if (!tail.empty()) memcpy(s.bytes.p, tail.data(), tail.size());
+            s.bytes.n = tail.size();
             tail.clear();
             size_t pos = 0;   // the first byte not yet assigned to a member
             auto need = [&](size_t bytes) {   // make s.bytes[pos, pos + bytes) available if the file has them
-                while (s.bytes.size() - pos < bytes && !file_end) {
-                    const size_t have = s.bytes.size(), chunk = 4u << 20;
-                    s.bytes.resize(have + chunk);
-                    const size_t n = fread(s.bytes.data() + have, 1, chunk, raw);
-                    s.bytes.resize(have + n);
+                while (s.bytes.n - pos < bytes && !file_end) {
+                    size_t chunk = (size_t)8 << 20;
+                    if (guess > s.bytes.n + chunk) chunk = guess - s.bytes.n;   // the bulk of a stretch in one read
+                    if (s.bytes.n - pos + chunk < bytes) chunk = bytes;
+                    s.bytes.reserve(s.bytes.n + chunk);
+                    const size_t n = fread(s.bytes.p + s.bytes.n, 1, chunk, raw);
+                    s.bytes.n += n;
                     if (n == 0) file_end = true;
                 }
-                return s.bytes.size() - pos >= bytes;
+                return s.bytes.n - pos >= bytes;
             };
             while (s.text_bytes < text_target) {
                 if (!need(18)) {
-                    if (s.bytes.size() - pos != 0) die("truncated gzip member header");
+                    if (s.bytes.n - pos != 0) die("truncated gzip member header");
                     s.last = true;
                     break;
                 }
                 {
-                    const unsigned char *h = s.bytes.data() + pos;
+                    const unsigned char *h = s.bytes.p + pos;
                     const size_t xlen = h[10] | ((size_t)h[11] << 8);
                     if (h[0] == 0x1f && h[1] == 0x8b && (h[3] & 4) && !need(12 + xlen)) die("truncated gzip member header");
                 }
-                const size_t msz = LineReader::Impl::bgzf_member_size(s.bytes.data() + pos, s.bytes.size() - pos);
+                const size_t msz = LineReader::Impl::bgzf_member_size(s.bytes.p + pos, s.bytes.n - pos);
                 if (msz < 26) die("not a block-gzip (BGZF) member inside a BGZF file: mixed gzip streams are not supported in one file");
                 if (!need(msz)) die("truncated gzip member");
-                const unsigned char *t = s.bytes.data() + pos + msz - 4;
+                const unsigned char *t = s.bytes.p + pos + msz - 4;
                 const size_t isize = t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
                 if (isize > (1u << 16)) die("BGZF member larger than 64 KiB");
                 s.off.push_back((uint32_t)pos); s.len.push_back((uint32_t)msz); s.text_len.push_back((uint32_t)isize);
@@ -671,8 +743,23 @@ struct BgzfMemberReader::Impl {
                 pos += msz;
                 if (pos >= (3ull << 30)) break;   // (offsets are 32-bit)
             }
-            tail.assign(s.bytes.begin() + (long)pos, s.bytes.end());
-            s.bytes.resize(pos);
+            tail.assign(s.bytes.p + pos, s.bytes.p + s.bytes.n);
+            s.bytes.n = pos;
+            guess = pos;
+            // the host's share of the stretch: the LAST members' text (the device's members come first in the text)
+            s.device_members = s.off.size();
+            s.host_text_bytes = 0;
+            if (host_share > 0.0 && !s.off.empty()) {
+                const uint64_t want = (uint64_t)((double)s.text_bytes * host_share);
+                size_t m0 = s.off.size();
+                uint64_t got = 0;
+                while (m0 > 0 && got < want) { --m0; got += s.text_len[m0]; }
+                s.device_members = m0;
+                s.host_text_bytes = (size_t)got;
+                s.host_text.reserve(s.host_text_bytes + 64);
+                if (!pool && host_threads > 1) pool.reset(new TaskPool(host_threads - 1));
+                inflate_members_host(pool.get(), host_threads, s, m0, s.off.size(), s.host_text.p);
+            }
             const bool last = s.last;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -685,8 +772,10 @@ struct BgzfMemberReader::Impl {
     }
 };
 
-BgzfMemberReader::BgzfMemberReader(const std::string &path, size_t text_target) : p_(new Impl) {
+BgzfMemberReader::BgzfMemberReader(const std::string &path, size_t text_target, double host_share, int host_threads) : p_(new Impl) {
     p_->text_target = text_target ? text_target : 1;
+    p_->host_share = host_share < 0.0 ? 0.0 : host_share > 1.0 ? 1.0 : host_share;
+    p_->host_threads = host_threads;
     p_->raw = fopen(path.c_str(), "rb");
     if (!p_->raw) die("file not found: %s", path.c_str());
     p_->worker = std::thread([this] { p_->run(); });
@@ -704,7 +793,7 @@ BgzfMemberReader::~BgzfMemberReader() {
 bool BgzfMemberReader::next(BgzfStretch &s) {
     std::unique_lock<std::mutex> lk(p_->mu);
     if (p_->handed_last) return false;
-    if (!s.bytes.empty() || s.bytes.capacity()) { p_->spare.push_back(std::move(s)); s = BgzfStretch(); }
+    if (s.bytes.cap) { p_->spare.push_back(std::move(s)); s = BgzfStretch(); }
     p_->cv_full.wait(lk, [&] { return !p_->full.empty(); });
     s = std::move(p_->full.front());
     p_->full.pop_front();
@@ -714,6 +803,33 @@ bool BgzfMemberReader::next(BgzfStretch &s) {
     return true;
 }
 bool BgzfMemberReader::is_bgzf(const std::string &path) { return LineReader::Impl::is_bgzf(path); }
+size_t BgzfMemberReader::text_target() const { return p_->text_target; }
+
+namespace {
+std::mutex g_bgzf_mu;
+std::vector<std::pair<std::string, std::unique_ptr<BgzfMemberReader>>> g_bgzf_ahead;
+}
+void BgzfMemberReader::prefetch(const std::string &path, size_t text_target, double host_share, int host_threads) {
+    std::unique_ptr<BgzfMemberReader> r(new BgzfMemberReader(path, text_target, host_share, host_threads));
+    std::lock_guard<std::mutex> lk(g_bgzf_mu);
+    g_bgzf_ahead.emplace_back(path, std::move(r));
+}
+std::unique_ptr<BgzfMemberReader> BgzfMemberReader::open(const std::string &path, size_t text_target, double host_share, int host_threads) {
+    {
+        std::lock_guard<std::mutex> lk(g_bgzf_mu);
+        for (size_t i = 0; i < g_bgzf_ahead.size(); ++i)
+            if (g_bgzf_ahead[i].first == path && g_bgzf_ahead[i].second->text_target() <= text_target) {   // (a larger stretch than allowed: start over)
+                std::unique_ptr<BgzfMemberReader> r = std::move(g_bgzf_ahead[i].second);
+                g_bgzf_ahead.erase(g_bgzf_ahead.begin() + (long)i);
+                return r;
+            }
+    }
+    return std::unique_ptr<BgzfMemberReader>(new BgzfMemberReader(path, text_target, host_share, host_threads));
+}
+void BgzfMemberReader::drop_prefetched() {
+    std::lock_guard<std::mutex> lk(g_bgzf_mu);
+    g_bgzf_ahead.clear();
+}
 
 bool RecordChunker::next(RecChunk &c) {
     c.rec_end.clear();

@@ -349,6 +349,9 @@ int cmd_read_id(int argc, char **argv) {
     const bool device_front_end = ends_with(fq[0], ".gz") && one_gpu && read_id_mt_pe::device_fastq_wanted(fq, fq.size() > 1 ? 2 : 1);
     if (ends_with(fq[0], ".gz") && !device_front_end)
         for (size_t i = 0; i < fq.size() && i < 2; ++i) LineReader::prefetch(fq[i]);
+    if (device_front_end)   // the compressed members are read ahead instead (a stretch or two: the reader's queue), beside GPU start-up and the index load
+        for (size_t i = 0; i < fq.size() && i < 2; ++i) BgzfMemberReader::prefetch(fq[i], read_id_mt_pe::device_fastq_stretch_bytes(0), read_id_mt_pe::device_fastq_host_share(),
+                                       read_id_mt_pe::device_fastq_host_threads(fq.size() > 1 ? 2 : 1));
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
     std::thread warm = warm_async(gpus, CID_WARM_READID | (device_front_end ? CID_WARM_INFLATE : 0u));
@@ -367,6 +370,7 @@ int cmd_read_id(int argc, char **argv) {
     read_counts_five_fields(prefix + "_reads.txt", prefix);
     phase_done("counts file");
     LineReader::drop_prefetched();
+    BgzfMemberReader::drop_prefetched();
     release(gpus, b);
     phase_done("release");
     return 0;

@@ -588,7 +588,7 @@ class FastqReader:
 
     def push_text(self, file, text: bytes, last=False):
         buf = np.frombuffer(text, np.uint8) if len(text) else np.zeros(1, np.uint8)
-        check(self.lib.cid_fastq_push_text(self.h, file, _p(buf), len(text), 1 if last else 0))
+        check(self.lib.cid_fastq_push_text(self.h, file, _p(buf), len(text), 1 if last else 0))   # CID_FASTQ_LAST
 
     def push_bgzf(self, file, members, text_lens, last=False):
         """members: list of whole BGZF members (bytes); text_lens: their ISIZE"""
@@ -598,10 +598,11 @@ class FastqReader:
         tl = np.array(text_lens, np.uint32)
         check(self.lib.cid_fastq_push_bgzf(self.h, file, _p(blob), len(blob) - 1, _p(off), _p(ln), _p(tl), len(members), 1 if last else 0))
 
-    def classify(self, index, d=1, start_sample=3):
-        """-> (ids [list of bytes], n_kmers, status, row_start, colours, counts) of every complete record pushed so far"""
+    def classify(self, index, d=1, start_sample=3, max_pushes=0):
+        """-> (ids [list of bytes], n_kmers, status, row_start, colours, counts) of every complete record held (after taking per file
+        the oldest max_pushes waiting block-gzip pushes; 0 = all)"""
         n, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        check(self.lib.cid_fastq_classify(self.h, index.h, d, start_sample, C.byref(n), C.byref(ne), C.byref(nb)))
+        check(self.lib.cid_fastq_classify(self.h, index.h, d, start_sample, max_pushes, C.byref(n), C.byref(ne), C.byref(nb)))
         nk = np.zeros(n.value, np.uint32)
         st = np.zeros(n.value, np.uint8)
         rs = np.zeros(n.value + 1, np.uint64)

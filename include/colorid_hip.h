@@ -58,6 +58,10 @@ int cid_device_count(int *n_devices);
 
 /* ---- context ---- */
 int cid_ctx_create(int device_id, cid_ctx **out);
+/* Page-locked host memory for buffers a host hands to the library over and over (batches of reads, a reader's text): copies from it
+ * run at the bus rate; pageable memory is pinned and unpinned by the runtime around every copy.  Needs no ctx. */
+int cid_pinned_alloc(size_t bytes, void **out);
+void cid_pinned_free(void *p);
 /* Borrow an existing hipStream_t (e.g. the caller's framework stream); NULL restores the ctx's own stream. */
 int cid_ctx_set_stream(cid_ctx *, void *hip_stream);
 int cid_ctx_synchronize(cid_ctx *);
@@ -390,11 +394,17 @@ int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t 
  *      — done for a whole stretch of the input at once, in HBM: the compressed bytes go up, and per read the id line, n_kmers,
  *      status and the non-zero (colour, count) entries come back; the reads themselves never exist in host memory.
  *        create        n_files = 1 (single-end) or 2 (record r of either file = read pair r); quality = -Q (0: no masking)
- *        push_bgzf     the next whole block-gzip members of one file (as cid_bgzf_inflate takes them; text_len[i] = member i's ISIZE);
- *                      at most one such push per file between two classify calls.  push_text: already-decoded text instead (plain
- *                      FASTQ, or a gzip stream inflated by the host) — any number of pushes, cut anywhere.  last != 0: the file ends here.
- *        classify      every complete record pushed so far (for pairs: as many as both files hold) through cid_readid_count_dev's
- *                      kernels and the sparse-report compaction; what is left of the text waits on the device for the next push.
+ *        push_bgzf     the next whole block-gzip members of one file (as cid_bgzf_inflate takes them; text_len[i] = member i's ISIZE).
+ *                      Returns once the bytes are on the device: the members are inflated on a stream of the reader's own, beside
+ *                      whatever the ctx stream is doing — push stretch i + 1, THEN classify stretch i (max_pushes = 1), and the
+ *                      serial latency of DEFLATE (a launch takes ~14 ms however small) hides behind the classification before it.
+ *                      push_text: already-decoded text instead (plain FASTQ, a gzip stream or block-gzip members inflated by the
+ *                      host), cut anywhere.  Pushes of either kind wait their turn in order (up to 64 per file): a host with
+ *                      spare cores inflates part of a stretch's members itself and lets the device take the rest.
+ *                      flags: CID_FASTQ_LAST = the file ends with this push.
+ *        classify      per file the oldest max_pushes waiting pushes (<= 0: all of them) join the text; every complete
+ *                      record then held (for pairs: as many as both files hold) goes through cid_readid_count_dev's kernels and
+ *                      the sparse-report compaction; what is left of the text waits on the device for the next call.
  *                      Corrupt members -> CID_ERR_INVALID naming the first one; a quality line longer than its sequence ->
  *                      CID_ERR_INVALID (the reference's "could not get the next nt" panic); reads that do not fit a wave's LDS
  *                      (several kilobases) -> CID_ERR_UNSUPPORTED: classify such input through cid_readid_count_sparse.
@@ -403,12 +413,15 @@ int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t 
  *                      at ids + id_off[r].
  *      One cid_fastq per input (pair); it borrows the ctx's stream and scratch: destroy it before the ctx. ---- */
 typedef struct cid_fastq cid_fastq;
+#define CID_FASTQ_LAST 1   /* push flags: the file ends with this push */
+#define CID_FASTQ_KEEP 2   /* push_text: the buffer (page-locked, cid_pinned_alloc) stays untouched until the next push on this file or the
+                            * classify call that takes this one — the copy then runs beside the caller instead of being waited for */
 int cid_fastq_create(cid_ctx *, int n_files, uint32_t quality, cid_fastq **out);
 int cid_fastq_push_bgzf(cid_fastq *, int file, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
-                        const uint32_t *text_len, size_t n_members, int last);
-int cid_fastq_push_text(cid_fastq *, int file, const uint8_t *text, size_t n_bytes, int last);
-int cid_fastq_classify(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, uint64_t *n_reads, uint64_t *n_entries,
-                       uint64_t *id_bytes);
+                        const uint32_t *text_len, size_t n_members, int flags);
+int cid_fastq_push_text(cid_fastq *, int file, const uint8_t *text, size_t n_bytes, int flags);
+int cid_fastq_classify(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
+                       uint64_t *n_entries, uint64_t *id_bytes);
 int cid_fastq_fetch(cid_fastq *, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,
                     char *ids);
 void cid_fastq_destroy(cid_fastq *);

@@ -166,6 +166,28 @@ def test_block_gzip_members_cut_records(orc, hip_ctx, world):
         i = j
     check_equal(acc, want_ids, want)
     fr.close()
+    # the way the CLI drives it: stretch i + 1 is pushed (and inflates on the reader's own stream) before stretch i is classified
+    fr = colorid_amd.FastqReader(hip_ctx, 1, 15)
+    acc = {"ids": [], "nk": [], "st": [], "rows": []}
+    cuts = list(range(0, len(members), 9)) + [len(members)]
+    waiting = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        fr.push_bgzf(0, members[a:b], lens[a:b], last=(b == len(members)))
+        waiting += 1
+        if waiting == 3:
+            ids, nk, st, rs, col, cnt = fr.classify(hx, 1, 3, max_pushes=1)
+            acc["ids"] += ids; acc["nk"].append(nk); acc["st"].append(st)
+            acc["rows"] += [list(zip(col[int(rs[r]):int(rs[r + 1])].tolist(), cnt[int(rs[r]):int(rs[r + 1])].tolist())) for r in range(len(ids))]
+            waiting -= 1
+    while waiting:
+        ids, nk, st, rs, col, cnt = fr.classify(hx, 1, 3, max_pushes=1)
+        acc["ids"] += ids; acc["nk"].append(nk); acc["st"].append(st)
+        acc["rows"] += [list(zip(col[int(rs[r]):int(rs[r + 1])].tolist(), cnt[int(rs[r]):int(rs[r + 1])].tolist())) for r in range(len(ids))]
+        waiting -= 1
+    check_equal(acc, want_ids, want)
+    with pytest.raises(colorid_amd.CidError):
+        fr.push_bgzf(0, members[:1], lens[:1])                       # the file was closed by its last push
+    fr.close()
     # a corrupt member is named; a quality line longer than its sequence is the reference's panic
     fr = colorid_amd.FastqReader(hip_ctx, 1, 15)
     bad = bytearray(members[2]); bad[-6] ^= 1
@@ -220,7 +242,8 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
     _write_bgzf(f2, fastq_text(r2[:11500], b"\r\n", False), rng)
     q = [f1, f2] if paired else [f1]
     outs = {}
-    for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {}), ("dev_small", {"COLORID_DEVICE_FASTQ_MB": "1"})):
+    for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {"COLORID_DEVICE_FASTQ": "1"}), ("dev_small", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_MB": "1"}),
+                     ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}), ("dev_host_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "1"})):
         for extra in ([], ["-Q", "0", "-d", "3", "-B", "0"]):
             name = str(tmp_path / f"{tag}{len(extra)}")
             p = subprocess.run([BIN, "read_id", "-b", pre + ".bxi", "-q", *q, "-n", name, *extra], capture_output=True, text=True,
@@ -230,6 +253,6 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
     for extra in (0, 6):
         host = outs[("host", extra)]
         assert host[0].count("\n") == (11500 if paired else 12000)
-        for tag in ("dev", "dev_small"):
+        for tag in ("dev", "dev_small", "dev_gpu_inflate", "dev_host_inflate"):
             assert outs[(tag, extra)][0] == host[0] and outs[(tag, extra)][1] == host[1], (tag, extra)
     assert "accept" in outs[("dev", 0)][0]
