@@ -210,8 +210,14 @@ __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, u
 // A read with a lower-case base (its case must be kept) is appended to p.redo_list for k_readid_bytes.
 // PACKED (p.idx_bits > 0; 2k + idx_bits <= 63): a table slot is ONE u64, canonical code << idx_bits | smallest window index — 8
 // instead of 12 bytes per slot, which is what lets paired 150-bp reads at k = 21 keep six waves per SIMD.
-template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE, bool STRIPED = false, bool PACKED = false>
+// TWO (p.two_reads; PACKED only, 2k + 1 + idx_bits <= 63): a wave takes reads 2i and 2i + 1 TOGETHER when both are one sequence of
+// at least k bases — their windows are listed as one sequence (130 + 130 windows are five 64-lane passes, not six), the slot key
+// carries the read as one more bit, so the list comes out as read 2i's distinct k-mers followed by read 2i + 1's, and the search runs
+// over the two stretches one after the other.  Any other read (several sequences, too short, lower-case bases, marked skip) is taken
+// alone by the same code.  The LDS regions are sized for two reads.
+template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE, bool STRIPED = false, bool PACKED = false, bool TWO = false>
 __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p) {
+    static_assert(!TWO || (PACKED && !WIDE && !MINI && !STRIPED), "two reads per wave: packed table, narrow rows, whole k-mers, whole index");
     constexpr int PLANES = DENSE ? kReadPlanesDense : kReadPlanes;
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
@@ -245,10 +251,23 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
 
     const uint64_t r_begin = (uint64_t)blockIdx.x * p.reads_per_block;
     const uint64_t r_end = r_begin + p.reads_per_block < p.n_reads ? r_begin + p.reads_per_block : p.n_reads;
-    for (uint64_t read = r_begin + wave; read < r_end; read += waves) {
+    constexpr uint64_t RSTEP = TWO ? 2 : 1;
+    for (uint64_t unit = r_begin + RSTEP * wave; unit < r_end; unit += RSTEP * waves) {
+      bool joint = false;          // TWO: reads unit and unit + 1 are listed together
+      uint32_t n_sub = 1;
+      if constexpr (TWO) {
+          if (unit + 1 < r_end) {
+              const uint64_t q0 = p.read_seq0[unit], q2 = p.read_seq0[unit + 2];
+              joint = q2 == q0 + 2 && p.read_seq0[unit + 1] == q0 + 1 && !(p.skip && (p.skip[unit] | p.skip[unit + 1]));
+              if (joint) joint = p.seq_off[q0 + 1] - p.seq_off[q0] >= k && p.seq_off[q0 + 2] - p.seq_off[q0 + 1] >= k;
+              n_sub = joint ? 1u : 2u;
+          }
+      }
+      for (uint32_t sub = 0; sub < n_sub; ++sub) {
+        const uint64_t read = unit + sub;
         if (p.skip && p.skip[read]) continue;
         wave_lds_fence();
-        const uint64_t s0 = p.read_seq0[read], s1 = p.read_seq0[read + 1];
+        const uint64_t s0 = p.read_seq0[read], s1 = TWO && joint ? s0 + 2 : p.read_seq0[read + 1];
         const uint64_t g0 = p.seq_off[s0];
         const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
         constexpr bool striped = STRIPED;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
@@ -269,6 +288,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             lower = lower || (good_base(b) && (b & 0x20u));
         }
         if (__any(lower)) {   // the byte-string kernel takes this read
+            if constexpr (TWO)
+                if (joint) { joint = false; n_sub = 2; sub = ~0u; continue; }   // one of the two: each on its own, from the first
             if (lane == 0) p.redo_list[atomicAdd(p.redo_count, 1u)] = (uint32_t)read;
             continue;
         }
@@ -294,6 +315,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         wave_lds_fence();
 
         uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
+        uint32_t nd_first = 0; // TWO, joint: those of the first read
         bool stopped = false;  // an absent row was met: nothing after it is searched
         VCount<PLANES, NARROW> vc;
         vc.clear();
@@ -352,11 +374,13 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 uint32_t slot = (uint32_t)((msb * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
                 if constexpr (PACKED) {
                     if (valid) {
-                        const unsigned long long mine = ((unsigned long long)msb << p.idx_bits) | (unsigned long long)wi;
+                        // (TWO: the same code in the other read is another key)
+                        const unsigned long long key = TWO ? ((unsigned long long)msb << 1) | (joint && wi >= nw0 ? 1ull : 0ull) : (unsigned long long)msb;
+                        const unsigned long long mine = (key << p.idx_bits) | (unsigned long long)wi;
                         while (true) {
                             const unsigned long long old = atomicCAS(&t_key[slot], ~0ull, mine);
                             if (old == ~0ull) break;
-                            if ((old >> p.idx_bits) == msb) { atomicMin(&t_key[slot], mine); break; }   // same code: keep the earlier window
+                            if ((old >> p.idx_bits) == key) { atomicMin(&t_key[slot], mine); break; }   // same code: keep the earlier window
                             slot = (slot + 1) & tmask;
                         }
                     }
@@ -384,6 +408,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                     readid_search_chunk_wide<STRIPED>(p.mat, p.rs, p.w64, n, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane,
                                                       STRIPED ? p.report_width - 1 : C, sr, STRIPED ? p.colour_base : 0u, STRIPED ? p.write_nohits : 1u);
                 }
+                if constexpr (TWO)   // the first read's windows are the lanes below nw0 - c0
+                    if (c0 < nw0) nd_first += (uint32_t)__popcll(nw0 - c0 >= (uint32_t)kWave ? dmask : dmask & ((1ull << (nw0 - c0)) - 1ull));
                 nd += (uint32_t)__popcll(dmask);
             }
         }
@@ -394,10 +420,25 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
                 wave_lds_fence();
             }
+            if constexpr (TWO) {
+                if (joint) {   // two stretches of the list, two report rows
+                    readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES, STRIPED>(p.mat, RS, n, C, S, rall, rcap, nd_first, 0u, hist, stopped, vc, R, lane, sr);
+                    readid_finish_read<NARROW, WIDE, PLANES, STRIPED>(vc, hist, col_word, row_out, C, lane, p);
+                    if (lane == 0) { p.n_kmers[read] = nd_first; p.status[read] = 0; p.n_kmers[read + 1] = nd - nd_first; p.status[read + 1] = 0; }
+                    wave_lds_fence();
+                    stopped = false;
+                    vc.clear();
+                    R = V16{0, 0};
+                    readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES, STRIPED>(p.mat, RS, n, C, S, rall + nd_first, rcap, nd - nd_first, 0u, hist, stopped, vc, R, lane, sr);
+                    readid_finish_read<NARROW, WIDE, PLANES, STRIPED>(vc, hist, col_word, row_out + (C + 1), C, lane, p);
+                    continue;
+                }
+            }
             readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES, STRIPED>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
         }
         readid_finish_read<NARROW, WIDE, PLANES, STRIPED>(vc, hist, col_word, row_out, C, lane, p);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
+      }
     }
 }
 
@@ -701,7 +742,22 @@ static hipError_t launch_readid_packed_striped(const ReadIdParams &p, int wpb, i
 }
 
 // the one-u64-per-slot set (p.idx_bits > 0): only built for the six-waves-per-SIMD kernel of whole k-mer indexes
+static hipError_t launch_readid_two(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
+    if (p.rs > 128) return hipErrorInvalidValue;
+    if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, false, true, false, true, true>, p, wpb, grid, stream);
+    switch (log2u(p.rs / 2)) {
+    case 0: return launch_readid_one(k_readid<0, false, false, false, true, false, true, true>, p, wpb, grid, stream);
+    case 1: return launch_readid_one(k_readid<1, false, false, false, true, false, true, true>, p, wpb, grid, stream);
+    case 2: return launch_readid_one(k_readid<2, false, false, false, true, false, true, true>, p, wpb, grid, stream);
+    case 3: return launch_readid_one(k_readid<3, false, false, false, true, false, true, true>, p, wpb, grid, stream);
+    case 4: return launch_readid_one(k_readid<4, false, false, false, true, false, true, true>, p, wpb, grid, stream);
+    case 5: return launch_readid_one(k_readid<5, false, false, false, true, false, true, true>, p, wpb, grid, stream);
+    case 6: return launch_readid_one(k_readid<6, false, false, false, true, false, true, true>, p, wpb, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
 static hipError_t launch_readid_packed_table(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
+    if (p.two_reads) return launch_readid_two(p, wpb, grid, stream);
     if (p.rs > 128) return hipErrorInvalidValue;
     if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, false, true, false, true>, p, wpb, grid, stream);
     switch (log2u(p.rs / 2)) {

@@ -325,3 +325,49 @@ def test_readid_set_slot_layouts_are_bit_exact(orc, hip_ctx, packed, k, n_colors
     finally:
         hip_ctx.tune("readid_packed_table", 1)
     hx.close()
+
+
+@pytest.mark.parametrize("two", [0, 1])
+@pytest.mark.parametrize("k,n_colors,read_len", [(21, 256, 150), (9, 300, 150), (31, 64, 100), (27, 100, 150)])
+def test_readid_two_reads_per_wave_is_bit_exact(orc, hip_ctx, two, k, n_colors, read_len):
+    """k_readid<..., TWO> (cid_ctx_tune "readid_two_reads"): two adjacent single-sequence reads listed by one wave, the read as one
+    more bit of the set's key.  Single-end batches in which neighbours share every k-mer (the sets must stay per read), one of the two
+    is too short / lower-case / all N / a read of several sequences, an odd read count — against the oracle, with the switch on and
+    off ((27, 150): 124 windows, where pairing saves no pass and the kernel is not taken)."""
+    rng = np.random.default_rng(k * 1000 + n_colors + two)
+    genomes = [bytes(rng.choice(list(b"ACGT"), size=5000).astype(np.uint8)) for _ in range(6)]
+    oix = orc.Index(50_021, 2, k, n_colors)
+    for c in range(n_colors):
+        oix.set_color(c, f"a{c}", 500)
+    for gi, gen in enumerate(genomes[:5]):          # genome 5 is in no accession: its reads stop at their first k-mer
+        km = orc.Kmers(k)
+        km.kmerize_vector(gen, 1)
+        for key in km.keys():
+            oix.insert(gi, key.tobytes())
+            oix.insert(n_colors - 1 - gi, key.tobytes())
+    L = read_len
+    reads = sample_reads(orc, rng, genomes, 300, L, False, lower_rate=0.05)
+    g0, g5 = genomes[0], genomes[5]
+    reads += [[g0[100:100 + L]], [g0[100:100 + L]]]                     # the same read twice in a row
+    reads += [[g0[200:200 + L]], [g5[200:200 + L]]]                     # a hit beside a miss, both orders
+    reads += [[g5[300:300 + L]], [g0[300:300 + L]]]
+    reads += [[g0[400:400 + L]], [b"ACG"]]                              # too short second / first
+    reads += [[b"AC"], [g0[500:500 + L]]]
+    reads += [[g0[600:600 + L].lower()], [g0[600:600 + L]]]             # lower-case first / second
+    reads += [[g0[700:700 + L]], [g0[700:700 + L - 1] + b"a"]]
+    reads += [[g0[800:800 + L], g0[900:900 + L]], [g0[800:800 + L]]]   # a pair beside a single read
+    reads += [[g0[1000:1000 + L]], [b"N" * L]]
+    reads += [[g0[1100:1100 + L]], [g0[1100:1100 + k]]]                 # one window
+    reads += [[(g0[1200:1217] * 10)[:L]], [(g0[1200:1217] * 10)[:L]]]   # 17-base period: few distinct k-mers, many windows
+    reads += [[g0[1300:1300 + L]]]
+    if len(reads) % 2 == 0:
+        reads += [[g0[1400:1400 + L]]]                                  # odd count: the last read has no partner
+    hx = to_hip_index(hip_ctx, oix)
+    hip_ctx.tune("readid_two_reads", two)
+    try:
+        for d, S in ((1, 3), (1, 0), (2, 5), (1, 200)):
+            check(oix, hx, reads, d, S)
+        check(oix, hx, reads[1:], 1, 3)                                 # the pairs shifted by one read
+    finally:
+        hip_ctx.tune("readid_two_reads", 1)
+    hx.close()
