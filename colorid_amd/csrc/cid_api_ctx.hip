@@ -141,7 +141,6 @@ int cid_ctx_create(int device_id, cid_ctx **out) {
     c->device = device_id;
     if (const char *e = getenv("CID_SEARCH_UNROLL")) c->tune.search_unroll = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("CID_READID_PACKED_TABLE")) c->tune.readid_packed_table = atoi(e) != 0;
-    if (const char *e = getenv("CID_READID_TWO_READS")) c->tune.readid_two_reads = atoi(e) != 0;
 #ifdef CID_TUNE_BUILD
     if (const char *e = getenv("CID_SEARCH_PERSIST")) c->tune.search_persist = atoi(e) != 0;
     if (const char *e = getenv("CID_SEARCH_MIXED")) c->tune.search_mixed = atoi(e) != 0;
@@ -218,7 +217,11 @@ int cid_ctx_tune(cid_ctx *c, const char *name, long value) {
         return CID_OK;
     }
     if (!strcmp(name, "readid_packed_table")) { c->tune.readid_packed_table = value != 0; return CID_OK; }
-    if (!strcmp(name, "readid_two_reads")) { c->tune.readid_two_reads = value != 0; return CID_OK; }
+    if (!strcmp(name, "readid_blocks_per_cu")) {
+        if (value < 1 || value > 4096) return fail(CID_ERR_INVALID, "readid_blocks_per_cu must be 1..4096");
+        c->tune.readid_blocks_per_cu = (int)value;
+        return CID_OK;
+    }
     if (!strcmp(name, "order_bits")) {
         if (value < 0 || value > 32) return fail(CID_ERR_INVALID, "order_bits 0..32");
         c->tune.order_bits = (int)value;

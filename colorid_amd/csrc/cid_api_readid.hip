@@ -13,7 +13,7 @@ extern "C" {
 // LDS layout of k_readid (bytes_kernel = false) or k_readid_bytes for reads of at most max_bytes bases / max_win windows;
 // returns the bytes one wave needs (the kernels carve the same regions in the same order)
 static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                            bool bytes_kernel, cid::ReadIdParams &p, bool packed_table = false, bool two_reads = false) {
+                            bool bytes_kernel, cid::ReadIdParams &p, bool packed_table = false) {
     p = cid::ReadIdParams{};
     p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
     p.mod = ix->mod;
@@ -31,14 +31,13 @@ static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t sta
     if (packed_table) {   // one u64 per slot: code << idx_bits | window index
         uint32_t ib = 1;
         while ((1ull << ib) <= p.win_cap) ++ib;
-        if (2u * ix->k + ib + (two_reads ? 1u : 0u) > 63u) return ~(size_t)0;   // (two reads per wave: the read is one more key bit)
+        if (2u * ix->k + ib > 63u) return ~(size_t)0;
         p.idx_bits = ib;
-        p.two_reads = two_reads ? 1u : 0u;
         slot_bytes = 8;
     }
     const size_t chunk_rows = 4ull * cid::kWave * ix->n_hash;                     // one chunk's row numbers
     const size_t rall_bytes = wide ? 0 : 4ull * p.win_cap * ix->n_hash;           // rows of the read's distinct k-mers (wide rows search chunk by chunk)
-    size_t wave_bytes = (size_t)p.bases_cap + rall_bytes;
+    size_t wave_bytes = (bytes_kernel ? (size_t)p.bases_cap : 0) + rall_bytes;     // (k_readid keeps no byte image of the read)
     if (bytes_kernel)   // histogram, tags, window infos, k-mer image (+ minimizer image and the distinct minimizer strings)
         wave_bytes += 4ull * p.hist_pad + chunk_rows + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
                       (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);
@@ -95,29 +94,6 @@ static int readid_params(const cid_ctx *c, const cid_index *ix, uint32_t stride_
         choose(true);
         if (best <= classic || best <= 20) choose(false);   // worth it only with more waves than the 96-VGPR (5 per SIMD) build runs
     }
-    // Two reads per wave (k_readid<..., TWO>): where single reads waste a 64-lane listing pass that two reads' windows together do not
-    // (130 windows: 3 + 3 passes alone, 5 together) and the doubled regions still leave six waves per SIMD.  configs[2], 1 M x 150 bp
-    // single-end: see DESIGN.md §4.
-    if (can_pack && c->tune.readid_two_reads && max_win > 0 && wave_bytes <= kLdsBytes) {
-        const uint64_t alone = (max_win + cid::kWave - 1) / cid::kWave, together = (2 * max_win + cid::kWave - 1) / cid::kWave;
-        if (2 * alone > together) {
-            cid::ReadIdParams one = p;
-            const int waves_one = waves;
-            const size_t bytes_one = wave_bytes;
-            wave_bytes = readid_layout(ix, stride_d, start_sample, 2 * max_bytes, 2 * max_win, false, p, true, true);
-            size_t best_two = 0;
-            int waves_two = 1;
-            if (wave_bytes != ~(size_t)0)
-                for (int w = 4; w >= 1; --w) {
-                    if ((size_t)w * wave_bytes > kLdsBytes) continue;
-                    size_t blocks = kLdsBytes / ((size_t)w * wave_bytes);
-                    if (blocks > 32u / (size_t)w) blocks = 32u / (size_t)w;
-                    if (blocks * (size_t)w > best_two) { best_two = blocks * (size_t)w; waves_two = w; }
-                }
-            if (best_two >= 24) waves = waves_two;
-            else { p = one; waves = waves_one; wave_bytes = bytes_one; }
-        }
-    }
     if (wave_bytes > kLdsBytes)
         return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %zu B of LDS per wave (> 160 KiB): "
                     "use the host-pointer calls, which route such reads through the sort-based path", (unsigned long long)max_bytes,
@@ -145,10 +121,9 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
         p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status; p.skip = d_skip;
         p.zero_acc = sa.zero_acc; p.zero_in = sa.zero_in; p.zero_start = sa.zero_start;
         p.colour_base = sa.colour_base; p.report_width = sa.report_width; p.write_nohits = sa.write_nohits;
-        uint64_t rpb = n_reads / ((uint64_t)c->n_cu * 16);
+        uint64_t rpb = n_reads / ((uint64_t)c->n_cu * (uint64_t)c->tune.readid_blocks_per_cu);   // (16 -> 64 per CU: -3 %, the tail of the grid)
         if (rpb < (uint64_t)waves) rpb = waves;
         if (rpb > 256) rpb = 256;
-        if (p.two_reads) rpb = std::max<uint64_t>((rpb + 1) & ~1ull, 2ull * (uint64_t)waves);   // whole pairs, every wave with one
         p.reads_per_block = (uint32_t)rpb;
     };
     if (ix->rs > 128 && clear_wide)   // wide rows count in place

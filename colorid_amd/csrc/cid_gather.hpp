@@ -282,6 +282,14 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 }
 
 
+// A value every lane of the wave holds alike, moved to scalar registers.  (A load through a wave-uniform address comes back in a
+// vector register, and what is computed from it stays there, when stores of the kernel may alias it: per-read offsets and sizes
+// handled this way cost k_readid a dozen VGPRs and the spills that go with them.)
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
+    return ((uint64_t)wave_uniform((uint32_t)(v >> 32)) << 32) | wave_uniform((uint32_t)v);
+}
+
 // ------------------------------------------------------------------------------------------------ bases as bytes
 __device__ __forceinline__ bool good_base(uint32_t b) {  // src/seq.rs:59-64
     const uint32_t u = b & 0xDFu;
@@ -318,6 +326,22 @@ __device__ __forceinline__ uint32_t find_minimizer_bytes(const uint8_t *seq, uin
     return best;
 }
 __device__ __forceinline__ uint8_t upper_base(uint32_t b) { return (uint8_t)((b >= 'a' && b <= 'z') ? b - 32u : b); }
+
+// Four bases held in one dword: their 2-bit codes (A 0, C 1, G 2, T 3 in either case; any other byte: what its bits 1-2 say) as 8 bits,
+// and one bit per base for "none of ACGTacgt" (seq.rs:59-64) and for "bit 5 set" (lower case, if it is a base at all).
+__device__ __forceinline__ uint32_t byte_tops_to_nibble(uint32_t y) {   // bits 7, 15, 23, 31 -> bits 0..3
+    y >>= 7;
+    return (y | (y >> 7) | (y >> 14) | (y >> 21)) & 0xFu;
+}
+__device__ __forceinline__ void pack_four_bases(uint32_t w, uint32_t &code8, uint32_t &bad4, uint32_t &low4) {
+    uint32_t x = (w >> 1) & 0x03030303u;            // A 00, C 01, T 10, G 11
+    x ^= (x >> 1) & 0x01010101u;                    // A 0, C 1, G 2, T 3
+    code8 = (x | (x >> 6) | (x >> 12) | (x >> 18)) & 0xFFu;
+    const uint32_t u = w & 0xDFDFDFDFu;
+    auto nz = [](uint32_t z) { return ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z; };   // bit 7 of each byte: the byte is not zero
+    bad4 = byte_tops_to_nibble(nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u) & 0x80808080u);
+    low4 = byte_tops_to_nibble((w << 2) & 0x80808080u);
+}
 
 // `nbits` (<= 64) bits starting at bit `bit` of a little-endian dword array (readable 2 dwords past the end)
 __device__ __forceinline__ uint64_t bits_at(const uint32_t *w, uint32_t bit, uint32_t nbits) {

@@ -79,7 +79,6 @@ struct ReadIdParams {
     uint32_t idx_bits;          // > 0: one u64 per slot, code << idx_bits | first window index (2k + idx_bits <= 63; k_readid<..., PACKED>)
     uint32_t wave_bytes;        // LDS bytes per wave
     uint32_t reads_per_block;
-    uint32_t two_reads;         // launcher only: the regions hold two reads, k_readid<..., TWO> lists adjacent single-sequence reads together
     uint32_t *report;           // [n_reads][n_colors+1]
     uint32_t *n_kmers;          // [n_reads]
     uint8_t *status;            // [n_reads]

@@ -16,7 +16,7 @@ enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES
 struct cid_tunables {
     int search_unroll = 2;            // k_search_count on 64- / 128-byte rows: sub-passes whose row loads are issued together (2: -1.5 %)
     bool readid_packed_table = true;  // k_readid: 8-byte k-mer-set slots where they buy a sixth wave per SIMD (paired reads, k <= 31)
-    bool readid_two_reads = true;     // k_readid: two single-sequence reads per wave where that saves a 64-lane listing pass (150-bp reads)
+    int readid_blocks_per_cu = 64;    // k_readid: a batch is cut into about this many workgroups per CU (each takes a stretch of reads)
     int order_bits = 0;               // cid_kmerset_order_for_index: 0 = by the first row's 128-byte line, b = by its b leading bits
     // the two measured-and-rejected schedulings of k_search_count; only a `make TUNE=1` build contains their kernels
     bool search_persist = false;      // persistent grid, one work queue per XCD

@@ -80,7 +80,7 @@ constexpr int kReadRunUnroll = 1;
 // register budgets: 3 planes in 96 VGPRs (5 waves per SIMD), or 2 planes in 80 VGPRs (6 waves per SIMD) when six workgroups'
 // LDS fit a CU — configs[2], 1 M x 150 bp single-end: 5.8 ms vs 6.1 ms; paired reads need more LDS and stay on the first.
 constexpr int kReadPlanes = 3;
-constexpr int kReadPlanesDense = 2;
+constexpr int kReadPlanesDense = 3;
 
 
 // The in-order search (read_id_mt_pe.rs:66-102 classic / :104-165 sampled) over a dense run of distinct k-mers: k-mer j (0 <= j < count, order index q_base + j) has its row
@@ -203,34 +203,27 @@ __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, u
     }
 }
 
-// ---- k_readid: reads without lower-case bases, k <= 32.  Per-wave LDS, not WIDE: bases | rall (win_cap*n) | table keys +
+// ---- k_readid: reads without lower-case bases, k <= 32.  Per-wave LDS, not WIDE: rall (win_cap*n) | table keys +
 // indices | 2-bit bases | bad-base bits — the per-colour histogram of the search phase lives IN the table's region (the table is
 // dead once the read's set is complete; the region is max(table, histogram) bytes), which is what lets paired 150-bp reads run
-// 5 waves per SIMD instead of 4.  WIDE: bases | ridx (64*n) | hist | table | ... (the search interleaves with the set building).
+// 5 waves per SIMD instead of 4.  WIDE: ridx (64*n) | hist | table | ... (the search interleaves with the set building).
 // A read with a lower-case base (its case must be kept) is appended to p.redo_list for k_readid_bytes.
 // PACKED (p.idx_bits > 0; 2k + idx_bits <= 63): a table slot is ONE u64, canonical code << idx_bits | smallest window index — 8
 // instead of 12 bytes per slot, which is what lets paired 150-bp reads at k = 21 keep six waves per SIMD.
-// TWO (p.two_reads; PACKED only, 2k + 1 + idx_bits <= 63): a wave takes reads 2i and 2i + 1 TOGETHER when both are one sequence of
-// at least k bases — their windows are listed as one sequence (130 + 130 windows are five 64-lane passes, not six), the slot key
-// carries the read as one more bit, so the list comes out as read 2i's distinct k-mers followed by read 2i + 1's, and the search runs
-// over the two stretches one after the other.  Any other read (several sequences, too short, lower-case bases, marked skip) is taken
-// alone by the same code.  The LDS regions are sized for two reads.
-template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE, bool STRIPED = false, bool PACKED = false, bool TWO = false>
+template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE, bool STRIPED = false, bool PACKED = false>
 __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p) {
-    static_assert(!TWO || (PACKED && !WIDE && !MINI && !STRIPED), "two reads per wave: packed table, narrow rows, whole k-mers, whole index");
     constexpr int PLANES = DENSE ? kReadPlanesDense : kReadPlanes;
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
     constexpr uint32_t RS = NARROW ? 1u : 2u * LPR;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = (int)wave_uniform((uint32_t)threadIdx.x >> 6);   // (the per-read scalars below then live in SGPRs)
     const int waves = blockDim.x >> 6;
     const uint32_t C = p.n_colors, k = p.k, n = p.n_hash, S = p.start_sample;
     const uint32_t klen = MINI ? p.m_size : k;   // length of the hashed key
 
     uint8_t *wb = smem + (size_t)wave * p.wave_bytes;
-    uint8_t *s_bases = wb;                                                     // bases_cap
-    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.bases_cap);           // WIDE: 64*n, this chunk's rows
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb);                         // WIDE: 64*n, this chunk's rows
     const uint32_t rcap = p.win_cap;
     constexpr bool SEPARATE = WIDE || !CID_READID_ALIAS;                       // histogram in a region of its own
     uint32_t *rall = ridx + (WIDE ? kWave * n : 0u) + (SEPARATE ? p.hist_pad : 0u);   // not WIDE: win_cap*n, rows of the read's distinct k-mers in order
@@ -251,25 +244,12 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
 
     const uint64_t r_begin = (uint64_t)blockIdx.x * p.reads_per_block;
     const uint64_t r_end = r_begin + p.reads_per_block < p.n_reads ? r_begin + p.reads_per_block : p.n_reads;
-    constexpr uint64_t RSTEP = TWO ? 2 : 1;
-    for (uint64_t unit = r_begin + RSTEP * wave; unit < r_end; unit += RSTEP * waves) {
-      bool joint = false;          // TWO: reads unit and unit + 1 are listed together
-      uint32_t n_sub = 1;
-      if constexpr (TWO) {
-          if (unit + 1 < r_end) {
-              const uint64_t q0 = p.read_seq0[unit], q2 = p.read_seq0[unit + 2];
-              joint = q2 == q0 + 2 && p.read_seq0[unit + 1] == q0 + 1 && !(p.skip && (p.skip[unit] | p.skip[unit + 1]));
-              if (joint) joint = p.seq_off[q0 + 1] - p.seq_off[q0] >= k && p.seq_off[q0 + 2] - p.seq_off[q0 + 1] >= k;
-              n_sub = joint ? 1u : 2u;
-          }
-      }
-      for (uint32_t sub = 0; sub < n_sub; ++sub) {
-        const uint64_t read = unit + sub;
-        if (p.skip && p.skip[read]) continue;
+    for (uint64_t read = r_begin + wave; read < r_end; read += waves) {
+        if (p.skip && wave_uniform((uint32_t)p.skip[read])) continue;
         wave_lds_fence();
-        const uint64_t s0 = p.read_seq0[read], s1 = TWO && joint ? s0 + 2 : p.read_seq0[read + 1];
-        const uint64_t g0 = p.seq_off[s0];
-        const uint32_t first_len = s1 > s0 ? (uint32_t)(p.seq_off[s0 + 1] - g0) : 0u;
+        const uint64_t s0 = wave_uniform(p.read_seq0[read]), s1 = wave_uniform(p.read_seq0[read + 1]);
+        const uint64_t g0 = wave_uniform(p.seq_off[s0]);
+        const uint32_t first_len = s1 > s0 ? (uint32_t)(wave_uniform(p.seq_off[s0 + 1]) - g0) : 0u;
         constexpr bool striped = STRIPED;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
         uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
         StripeRead sr{nullptr, nullptr};
@@ -280,42 +260,49 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 1; }
             continue;
         }
-        const uint32_t tb = (uint32_t)(p.seq_off[s1] - g0);
+        const uint32_t tb = (uint32_t)(wave_uniform(p.seq_off[s1]) - g0);
+        // The read's bases come in as aligned 16-byte pieces, one per lane (150 bases: ten or eleven lanes, ONE load), and go to LDS
+        // as 2-bit codes (16 per dword) + one "not a base" bit each; positions count from the aligned start (`shift` bytes before the
+        // read).  Nothing else of the read is kept: hash inputs are re-expanded from the codes.
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(p.bases + g0);
+        const uint32_t shift = (uint32_t)(a0 & 15u), span = shift + tb;
+        const uint4 *src = reinterpret_cast<const uint4 *>(a0 - shift);
         bool lower = false;
-        for (uint32_t i = lane; i < tb; i += kWave) {
-            const uint8_t b = p.bases[g0 + i];
-            s_bases[i] = b;
-            lower = lower || (good_base(b) && (b & 0x20u));
-        }
-        if (__any(lower)) {   // the byte-string kernel takes this read
-            if constexpr (TWO)
-                if (joint) { joint = false; n_sub = 2; sub = ~0u; continue; }   // one of the two: each on its own, from the first
-            if (lane == 0) p.redo_list[atomicAdd(p.redo_count, 1u)] = (uint32_t)read;
-            continue;
-        }
-        wave_lds_fence();
-        // 16 bases per lane-step: 2-bit codes (A,C,G,T = 0..3, anything else 0 + its bad bit)
-        for (uint32_t j0 = 0; j0 * 16 < tb + 64; j0 += kWave) {
+        for (uint32_t j0 = 0; j0 * 16 < span + 64; j0 += kWave) {
             const uint32_t j = j0 + lane;
-            uint32_t code = 0, bad = 0;
-            for (uint32_t t = 0; t < 16; ++t) {
-                const uint32_t i = j * 16 + t;
-                const uint32_t b = i < tb ? s_bases[i] : 'N';
-                const uint32_t c2 = (b >> 1) & 3u;            // A 00, C 01, T 10, G 11  ->  swap G/T below
-                code |= (c2 ^ (c2 >> 1)) << (2 * t);          // A 0, C 1, G 2, T 3
-                bad |= (good_base(b) ? 0u : 1u) << t;
+            uint32_t code = 0, bad = 0xFFFFu;
+            if (j * 16 < span) {
+                const uint4 q = src[j];
+                const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                uint32_t low = 0;
+                bad = 0;
+#pragma unroll
+                for (int dw = 0; dw < 4; ++dw) {
+                    uint32_t c8, b4, l4;
+                    pack_four_bases(w[dw], c8, b4, l4);
+                    code |= c8 << (8 * dw);
+                    bad |= b4 << (4 * dw);
+                    low |= l4 << (4 * dw);
+                }
+                const uint32_t lo = shift > j * 16 ? (shift - j * 16 < 16u ? shift - j * 16 : 16u) : 0u;   // this lane's bytes [lo, hi) are the read's
+                const uint32_t hi = span - j * 16 < 16u ? span - j * 16 : 16u;
+                bad = (bad | ~(((1u << hi) - 1u) & ~((1u << lo) - 1u))) & 0xFFFFu;
+                lower = lower || (low & ~bad) != 0;   // a lower-case base: its case must be kept
             }
             const uint32_t bad_hi = __shfl_down(bad, 1, kWave);
-            if (j * 16 < tb + 64) {
+            if (j * 16 < span + 64) {
                 s_pack[j] = code;
                 if (!(lane & 1)) s_bad[j >> 1] = bad | (bad_hi << 16);
             }
+        }
+        if (__any(lower)) {   // the byte-string kernel takes this read
+            if (lane == 0) p.redo_list[atomicAdd(p.redo_count, 1u)] = (uint32_t)read;
+            continue;
         }
         for (uint32_t t = lane; t < p.table_slots; t += kWave) { t_key[t] = ~0ull; if constexpr (!PACKED) t_idx[t] = ~0u; }
         wave_lds_fence();
 
         uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
-        uint32_t nd_first = 0; // TWO, joint: those of the first read
         bool stopped = false;  // an absent row was met: nothing after it is searched
         VCount<PLANES, NARROW> vc;
         vc.clear();
@@ -332,13 +319,13 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         const uint32_t nw0 = (first_len - k) / p.stride_d + 1;
         uint32_t off1 = 0, nw1 = 0;
         if (n_mates >= 2) {
-            off1 = (uint32_t)(p.seq_off[s0 + 1] - g0);
-            const uint32_t len1 = (uint32_t)(p.seq_off[s0 + 2] - p.seq_off[s0 + 1]);
+            off1 = first_len;
+            const uint32_t len1 = (uint32_t)(wave_uniform(p.seq_off[s0 + 2]) - g0) - first_len;
             nw1 = len1 >= k ? (len1 - k) / p.stride_d + 1 : 0u;
         }
         uint32_t wtot = nw0 + nw1;
         for (uint64_t s = s0 + 2; s < s1; ++s) {   // reads of more than two mates (never from the CLI): counted here, located below
-            const uint32_t len = (uint32_t)(p.seq_off[s + 1] - p.seq_off[s]);
+            const uint32_t len = (uint32_t)wave_uniform(p.seq_off[s + 1] - p.seq_off[s]);
             if (len >= k) wtot += (len - k) / p.stride_d + 1;
         }
         {
@@ -355,6 +342,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                         base += nws;
                     }
                 }
+                pos += shift;
                 constexpr uint32_t wbase = 0;
                 const uint32_t nw = wtot;
                 if constexpr (WIDE) wave_lds_fence();  // the previous chunk's gathers are done with ridx
@@ -374,13 +362,11 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 uint32_t slot = (uint32_t)((msb * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
                 if constexpr (PACKED) {
                     if (valid) {
-                        // (TWO: the same code in the other read is another key)
-                        const unsigned long long key = TWO ? ((unsigned long long)msb << 1) | (joint && wi >= nw0 ? 1ull : 0ull) : (unsigned long long)msb;
-                        const unsigned long long mine = (key << p.idx_bits) | (unsigned long long)wi;
+                        const unsigned long long mine = ((unsigned long long)msb << p.idx_bits) | (unsigned long long)wi;
                         while (true) {
                             const unsigned long long old = atomicCAS(&t_key[slot], ~0ull, mine);
                             if (old == ~0ull) break;
-                            if ((old >> p.idx_bits) == key) { atomicMin(&t_key[slot], mine); break; }   // same code: keep the earlier window
+                            if ((old >> p.idx_bits) == msb) { atomicMin(&t_key[slot], mine); break; }   // same code: keep the earlier window
                             slot = (slot + 1) & tmask;
                         }
                     }
@@ -408,8 +394,6 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                     readid_search_chunk_wide<STRIPED>(p.mat, p.rs, p.w64, n, S, ridx, s_words, s_R, row_out, dmask, nd, stopped, lane,
                                                       STRIPED ? p.report_width - 1 : C, sr, STRIPED ? p.colour_base : 0u, STRIPED ? p.write_nohits : 1u);
                 }
-                if constexpr (TWO)   // the first read's windows are the lanes below nw0 - c0
-                    if (c0 < nw0) nd_first += (uint32_t)__popcll(nw0 - c0 >= (uint32_t)kWave ? dmask : dmask & ((1ull << (nw0 - c0)) - 1ull));
                 nd += (uint32_t)__popcll(dmask);
             }
         }
@@ -420,25 +404,10 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
                 wave_lds_fence();
             }
-            if constexpr (TWO) {
-                if (joint) {   // two stretches of the list, two report rows
-                    readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES, STRIPED>(p.mat, RS, n, C, S, rall, rcap, nd_first, 0u, hist, stopped, vc, R, lane, sr);
-                    readid_finish_read<NARROW, WIDE, PLANES, STRIPED>(vc, hist, col_word, row_out, C, lane, p);
-                    if (lane == 0) { p.n_kmers[read] = nd_first; p.status[read] = 0; p.n_kmers[read + 1] = nd - nd_first; p.status[read + 1] = 0; }
-                    wave_lds_fence();
-                    stopped = false;
-                    vc.clear();
-                    R = V16{0, 0};
-                    readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES, STRIPED>(p.mat, RS, n, C, S, rall + nd_first, rcap, nd - nd_first, 0u, hist, stopped, vc, R, lane, sr);
-                    readid_finish_read<NARROW, WIDE, PLANES, STRIPED>(vc, hist, col_word, row_out + (C + 1), C, lane, p);
-                    continue;
-                }
-            }
             readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, PLANES, STRIPED>(p.mat, RS, n, C, S, rall, rcap, nd, 0u, hist, stopped, vc, R, lane, sr);
         }
         readid_finish_read<NARROW, WIDE, PLANES, STRIPED>(vc, hist, col_word, row_out, C, lane, p);
         if (lane == 0) { p.n_kmers[read] = nd; p.status[read] = 0; }
-      }
     }
 }
 
@@ -742,22 +711,7 @@ static hipError_t launch_readid_packed_striped(const ReadIdParams &p, int wpb, i
 }
 
 // the one-u64-per-slot set (p.idx_bits > 0): only built for the six-waves-per-SIMD kernel of whole k-mer indexes
-static hipError_t launch_readid_two(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
-    if (p.rs > 128) return hipErrorInvalidValue;
-    if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, false, true, false, true, true>, p, wpb, grid, stream);
-    switch (log2u(p.rs / 2)) {
-    case 0: return launch_readid_one(k_readid<0, false, false, false, true, false, true, true>, p, wpb, grid, stream);
-    case 1: return launch_readid_one(k_readid<1, false, false, false, true, false, true, true>, p, wpb, grid, stream);
-    case 2: return launch_readid_one(k_readid<2, false, false, false, true, false, true, true>, p, wpb, grid, stream);
-    case 3: return launch_readid_one(k_readid<3, false, false, false, true, false, true, true>, p, wpb, grid, stream);
-    case 4: return launch_readid_one(k_readid<4, false, false, false, true, false, true, true>, p, wpb, grid, stream);
-    case 5: return launch_readid_one(k_readid<5, false, false, false, true, false, true, true>, p, wpb, grid, stream);
-    case 6: return launch_readid_one(k_readid<6, false, false, false, true, false, true, true>, p, wpb, grid, stream);
-    default: return hipErrorInvalidValue;
-    }
-}
 static hipError_t launch_readid_packed_table(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
-    if (p.two_reads) return launch_readid_two(p, wpb, grid, stream);
     if (p.rs > 128) return hipErrorInvalidValue;
     if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, false, true, false, true>, p, wpb, grid, stream);
     switch (log2u(p.rs / 2)) {

@@ -327,14 +327,12 @@ def test_readid_set_slot_layouts_are_bit_exact(orc, hip_ctx, packed, k, n_colors
     hx.close()
 
 
-@pytest.mark.parametrize("two", [0, 1])
 @pytest.mark.parametrize("k,n_colors,read_len", [(21, 256, 150), (9, 300, 150), (31, 64, 100), (27, 100, 150)])
-def test_readid_two_reads_per_wave_is_bit_exact(orc, hip_ctx, two, k, n_colors, read_len):
-    """k_readid<..., TWO> (cid_ctx_tune "readid_two_reads"): two adjacent single-sequence reads listed by one wave, the read as one
-    more bit of the set's key.  Single-end batches in which neighbours share every k-mer (the sets must stay per read), one of the two
-    is too short / lower-case / all N / a read of several sequences, an odd read count — against the oracle, with the switch on and
-    off ((27, 150): 124 windows, where pairing saves no pass and the kernel is not taken)."""
-    rng = np.random.default_rng(k * 1000 + n_colors + two)
+def test_readid_single_end_edge_reads(orc, hip_ctx, k, n_colors, read_len):
+    """Single-end batches through k_readid's aligned 16-byte base loads (reads start at every offset mod 16): neighbours that share
+    every k-mer (the sets are per read), reads that are too short / lower-case / all N / of several sequences / one window long,
+    a read whose k-mers are in no accession (stops at its first), an odd read count, the batch shifted by one read."""
+    rng = np.random.default_rng(k * 1000 + n_colors)
     genomes = [bytes(rng.choice(list(b"ACGT"), size=5000).astype(np.uint8)) for _ in range(6)]
     oix = orc.Index(50_021, 2, k, n_colors)
     for c in range(n_colors):
@@ -363,11 +361,7 @@ def test_readid_two_reads_per_wave_is_bit_exact(orc, hip_ctx, two, k, n_colors, 
     if len(reads) % 2 == 0:
         reads += [[g0[1400:1400 + L]]]                                  # odd count: the last read has no partner
     hx = to_hip_index(hip_ctx, oix)
-    hip_ctx.tune("readid_two_reads", two)
-    try:
-        for d, S in ((1, 3), (1, 0), (2, 5), (1, 200)):
-            check(oix, hx, reads, d, S)
-        check(oix, hx, reads[1:], 1, 3)                                 # the pairs shifted by one read
-    finally:
-        hip_ctx.tune("readid_two_reads", 1)
+    for d, S in ((1, 3), (1, 0), (2, 5), (1, 200)):
+        check(oix, hx, reads, d, S)
+    check(oix, hx, reads[1:], 1, 3)                                     # every read at another offset
     hx.close()
