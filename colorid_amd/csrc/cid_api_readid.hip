@@ -37,7 +37,9 @@ static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t sta
     }
     const size_t chunk_rows = 4ull * cid::kWave * ix->n_hash;                     // one chunk's row numbers
     const size_t rall_bytes = wide ? 0 : 4ull * p.win_cap * ix->n_hash;           // rows of the read's distinct k-mers (wide rows search chunk by chunk)
-    size_t wave_bytes = (bytes_kernel ? (size_t)p.bases_cap : 0) + rall_bytes;     // (k_readid keeps no byte image of the read)
+    // k_readid keeps no byte image of the read, but the raw bases of the NEXT one (LDS-DMA, one 16-byte piece per lane)
+    p.stage_bytes = bytes_kernel ? 0u : std::min<uint32_t>(p.bases_cap, 16u * cid::kWave);
+    size_t wave_bytes = (bytes_kernel ? (size_t)p.bases_cap : (size_t)p.stage_bytes) + rall_bytes;
     if (bytes_kernel)   // histogram, tags, window infos, k-mer image (+ minimizer image and the distinct minimizer strings)
         wave_bytes += 4ull * p.hist_pad + chunk_rows + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
                       (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);

@@ -80,7 +80,7 @@ constexpr int kReadRunUnroll = 1;
 // register budgets: 3 planes in 96 VGPRs (5 waves per SIMD), or 2 planes in 80 VGPRs (6 waves per SIMD) when six workgroups'
 // LDS fit a CU — configs[2], 1 M x 150 bp single-end: 5.8 ms vs 6.1 ms; paired reads need more LDS and stay on the first.
 constexpr int kReadPlanes = 3;
-constexpr int kReadPlanesDense = 3;
+constexpr int kReadPlanesDense = 2;
 
 
 // The in-order search (read_id_mt_pe.rs:66-102 classic / :104-165 sampled) over a dense run of distinct k-mers: k-mer j (0 <= j < count, order index q_base + j) has its row
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
     const uint32_t klen = MINI ? p.m_size : k;   // length of the hashed key
 
     uint8_t *wb = smem + (size_t)wave * p.wave_bytes;
-    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb);                         // WIDE: 64*n, this chunk's rows
+    uint4 *s_stage = reinterpret_cast<uint4 *>(wb);                            // stage_bytes: the NEXT read's bases, raw (LDS-DMA lands here)
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(wb + p.stage_bytes);         // WIDE: 64*n, this chunk's rows
     const uint32_t rcap = p.win_cap;
     constexpr bool SEPARATE = WIDE || !CID_READID_ALIAS;                       // histogram in a region of its own
     uint32_t *rall = ridx + (WIDE ? kWave * n : 0u) + (SEPARATE ? p.hist_pad : 0u);   // not WIDE: win_cap*n, rows of the read's distinct k-mers in order
@@ -244,23 +245,47 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
 
     const uint64_t r_begin = (uint64_t)blockIdx.x * p.reads_per_block;
     const uint64_t r_end = r_begin + p.reads_per_block < p.n_reads ? r_begin + p.reads_per_block : p.n_reads;
-    for (uint64_t read = r_begin + wave; read < r_end; read += waves) {
-        if (p.skip && wave_uniform((uint32_t)p.skip[read])) continue;
+    // Where a read starts and how long it is takes two dependent loads (read_seq0 -> seq_off) before its bases can be asked for: lane l
+    // fetches them for the wave's l-th read, 64 reads at a time, and each read picks its own up with v_readlane.  The bases of the
+    // read AFTER the current one are asked for (LDS-DMA into s_stage) before the current read's search, so that they arrive behind
+    // its row gathers; a read then starts from LDS.
+    uint64_t L_g0 = 0;                        // lane l: seq_off[first sequence] of read r_begin + wave + (batch * 64 + l) * waves
+    uint32_t L_first = 0, L_tb = 0, L_mates = 0;   // its first sequence's length, all its bases, its sequences | skip << 31
+    bool staged = false;                      // s_stage holds this read's first 64 pieces
+    uint32_t it = kWave;
+    for (uint64_t read = r_begin + wave; read < r_end; read += waves, ++it) {
+        if (it == (uint32_t)kWave) {
+            it = 0;
+            const uint64_t r = read + (uint64_t)lane * waves;
+            L_g0 = 0; L_first = L_tb = L_mates = 0;
+            if (r < r_end) {
+                const uint64_t a = p.read_seq0[r], b = p.read_seq0[r + 1];
+                L_g0 = p.seq_off[a];
+                L_first = b > a ? (uint32_t)(p.seq_off[a + 1] - L_g0) : 0u;
+                L_tb = (uint32_t)(p.seq_off[b] - L_g0);
+                L_mates = (uint32_t)(b - a < 0x7FFFFFFFull ? b - a : 0x7FFFFFFFull) | ((p.skip && p.skip[r]) ? 0x80000000u : 0u);
+            }
+        }
+        const bool from_stage = staged;
+        staged = false;
+        const uint32_t mates_skip = (uint32_t)__builtin_amdgcn_readlane((int)L_mates, (int)it);
+        if (mates_skip >> 31) continue;
         wave_lds_fence();
-        const uint64_t s0 = wave_uniform(p.read_seq0[read]), s1 = wave_uniform(p.read_seq0[read + 1]);
-        const uint64_t g0 = wave_uniform(p.seq_off[s0]);
-        const uint32_t first_len = s1 > s0 ? (uint32_t)(wave_uniform(p.seq_off[s0 + 1]) - g0) : 0u;
+        const uint32_t n_mates = mates_skip;
+        const uint64_t g0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(L_g0 >> 32), (int)it) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)L_g0, (int)it);
+        const uint32_t first_len = (uint32_t)__builtin_amdgcn_readlane((int)L_first, (int)it);
         constexpr bool striped = STRIPED;   // striped passes: the caller zeroes the (wide) report once, rows are only added to
         uint32_t *row_out = striped ? p.report + read * (uint64_t)p.report_width : p.report + read * (uint64_t)(C + 1);
         StripeRead sr{nullptr, nullptr};
         if constexpr (STRIPED) sr = StripeRead{p.zero_acc ? p.zero_acc + p.zero_start[read] : nullptr, p.zero_in ? p.zero_in + p.zero_start[read] : nullptr};
-        if (s1 == s0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
+        if (n_mates == 0 || first_len < k) {  // too_short: only the first mate is tested (read_id_mt_pe.rs:305)
             if constexpr (!WIDE)  // (wide rows: the host zeroes the whole report before the launch)
                 if (!striped) for (uint32_t c = lane; c <= C; c += kWave) row_out[c] = 0;
             if (lane == 0) { p.n_kmers[read] = 0; p.status[read] = 1; }
             continue;
         }
-        const uint32_t tb = (uint32_t)(wave_uniform(p.seq_off[s1]) - g0);
+        const uint32_t tb = (uint32_t)__builtin_amdgcn_readlane((int)L_tb, (int)it);
         // The read's bases come in as aligned 16-byte pieces, one per lane (150 bases: ten or eleven lanes, ONE load), and go to LDS
         // as 2-bit codes (16 per dword) + one "not a base" bit each; positions count from the aligned start (`shift` bytes before the
         // read).  Nothing else of the read is kept: hash inputs are re-expanded from the codes.
@@ -272,7 +297,13 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             const uint32_t j = j0 + lane;
             uint32_t code = 0, bad = 0xFFFFu;
             if (j * 16 < span) {
-                const uint4 q = src[j];
+                uint4 q;
+                if (from_stage && j0 == 0) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA of the previous iteration has landed
+                    q = s_stage[lane];
+                } else {
+                    q = src[j];
+                }
                 const uint32_t w[4] = {q.x, q.y, q.z, q.w};
                 uint32_t low = 0;
                 bad = 0;
@@ -299,6 +330,21 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
             if (lane == 0) p.redo_list[atomicAdd(p.redo_count, 1u)] = (uint32_t)read;
             continue;
         }
+        // the next read's bases: on their way (LDS-DMA, no registers) while this read is listed and searched
+        if (p.stage_bytes && it + 1 < (uint32_t)kWave && read + waves < r_end) {
+            const uint32_t nms = (uint32_t)__builtin_amdgcn_readlane((int)L_mates, (int)(it + 1));
+            const uint64_t ng0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(L_g0 >> 32), (int)(it + 1)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)L_g0, (int)(it + 1));
+            const uintptr_t na = reinterpret_cast<uintptr_t>(p.bases + ng0);
+            const uint32_t nspan = (uint32_t)(na & 15u) + (uint32_t)__builtin_amdgcn_readlane((int)L_tb, (int)(it + 1));
+            if (nms - 1u < 0x7FFFFFFFu && nspan <= p.stage_bytes) {   // a read with sequences, not skipped, that fits the stage
+                wave_lds_fence();   // this read's pieces have been taken out of s_stage
+                if ((uint32_t)lane * 16u < nspan)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void *>((na & ~(uintptr_t)15) + 16u * (uint32_t)lane),
+                                                     (__attribute__((address_space(3))) void *)s_stage, 16, 0, 0);
+                staged = true;
+            }
+        }
         for (uint32_t t = lane; t < p.table_slots; t += kWave) { t_key[t] = ~0ull; if constexpr (!PACKED) t_idx[t] = ~0u; }
         wave_lds_fence();
 
@@ -315,15 +361,15 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
         // The read's windows as ONE sequence over its mates (mate 1's first: the first-occurrence order), cut into chunks of 64:
         // a chunk may straddle the mate boundary, so 2 x 130 windows are 5 chunks, not 6 (each chunk is a wave-wide pass).
         // A mate shorter than k contributes nothing.
-        const uint32_t n_mates = (uint32_t)(s1 - s0);
         const uint32_t nw0 = (first_len - k) / p.stride_d + 1;
         uint32_t off1 = 0, nw1 = 0;
         if (n_mates >= 2) {
             off1 = first_len;
-            const uint32_t len1 = (uint32_t)(wave_uniform(p.seq_off[s0 + 2]) - g0) - first_len;
+            const uint32_t len1 = n_mates == 2 ? tb - first_len : (uint32_t)(wave_uniform(p.seq_off[wave_uniform(p.read_seq0[read]) + 2]) - g0) - first_len;
             nw1 = len1 >= k ? (len1 - k) / p.stride_d + 1 : 0u;
         }
         uint32_t wtot = nw0 + nw1;
+        const uint64_t s0 = n_mates > 2 ? wave_uniform(p.read_seq0[read]) : 0ull, s1 = s0 + n_mates;   // (only reads of three or more sequences look at these)
         for (uint64_t s = s0 + 2; s < s1; ++s) {   // reads of more than two mates (never from the CLI): counted here, located below
             const uint32_t len = (uint32_t)wave_uniform(p.seq_off[s + 1] - p.seq_off[s]);
             if (len >= k) wtot += (len - k) / p.stride_d + 1;
