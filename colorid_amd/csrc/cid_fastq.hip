@@ -146,7 +146,8 @@ struct cid_fastq {
     uint32_t quality = 0;
     // block-gzip pushes are inflated on a stream of their own, ahead of the classification of the stretch before: a stream of
     // DEFLATE is decoded serially (one lane), so a launch takes ~14 ms however few members it holds — time the other stream fills
-    hipStream_t inflate_stream = nullptr;
+    hipStream_t inflate_streams[2] = {nullptr, nullptr};   // pushes alternate: a launch's floor is the decoding time of ONE member, two launches overlap theirs
+    uint64_t n_inflates = 0;
     hipStream_t text_stream = nullptr;      // host-inflated text travels beside the inflate kernels, not behind them
     struct Staged {           // one push_bgzf: its text (members' texts back to back) once `done` has fired
         uint8_t *text = nullptr;
@@ -233,9 +234,10 @@ int cid_fastq_create(cid_ctx *c, int n_files, uint32_t quality, cid_fastq **out)
     cid_fastq *fq = new (std::nothrow) cid_fastq();
     if (!fq) return fail(CID_ERR_NOMEM, "fastq");
     fq->ctx = c; fq->n_files = n_files; fq->quality = quality;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&fq->inflate_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&fq->inflate_streams[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&fq->inflate_streams[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&fq->text_stream, hipStreamNonBlocking) != hipSuccess) {
-        if (fq->inflate_stream) (void)hipStreamDestroy(fq->inflate_stream);
+        for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamDestroy(st);
         delete fq;
         return fail(CID_ERR_HIP, "stream creation failed");
     }
@@ -248,14 +250,14 @@ void cid_fastq_destroy(cid_fastq *fq) {
     cid_ctx *c = fq->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (fq->inflate_stream) (void)hipStreamSynchronize(fq->inflate_stream);
+    for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamSynchronize(st);
     if (fq->text_stream) (void)hipStreamSynchronize(fq->text_stream);
     drop_results(fq);
     for (int i = 0; i < 2; ++i) {
         cid::ctx_free(c, fq->f[i].text);
         for (cid_fastq::Staged &sg : fq->f[i].staged) free_staged(fq, sg);
     }
-    if (fq->inflate_stream) (void)hipStreamDestroy(fq->inflate_stream);
+    for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamDestroy(st);
     if (fq->text_stream) (void)hipStreamDestroy(fq->text_stream);
     delete fq;
 }
@@ -337,14 +339,15 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
         if (e == hipSuccess) e = hipMemcpyAsync(sg.d_in, members, n_bytes, hipMemcpyHostToDevice, fq->text_stream);
         if (e == hipSuccess) e = hipMemcpyAsync(sg.d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, fq->text_stream);
         hipEvent_t copied = cid::ctx_event(c, 1);
+        hipStream_t inflate_stream = fq->inflate_streams[fq->n_inflates++ & 1];
         if (e == hipSuccess) e = hipEventRecord(copied, fq->text_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(fq->inflate_stream, copied, 0);
-        if (e == hipSuccess) e = cid::bgzf_inflate_launch(c, fq->inflate_stream, (const uint8_t *)sg.d_in, (const cid::BgzfMember *)sg.d_mem, (uint32_t)n_members, sg.text,
+        if (e == hipSuccess) e = hipStreamWaitEvent(inflate_stream, copied, 0);
+        if (e == hipSuccess) e = cid::bgzf_inflate_launch(c, inflate_stream, (const uint8_t *)sg.d_in, (const cid::BgzfMember *)sg.d_mem, (uint32_t)n_members, sg.text,
                                                           sg.d_status);
-        if (e == hipSuccess) e = hipEventRecord(sg.done, fq->inflate_stream);
+        if (e == hipSuccess) e = hipEventRecord(sg.done, inflate_stream);
         if (e == hipSuccess) e = hipEventSynchronize(copied);   // the caller's buffers (and `mem`) are free again; the kernel runs on
         if (e != hipSuccess) {
-            (void)hipStreamSynchronize(fq->inflate_stream);
+            (void)hipStreamSynchronize(inflate_stream);
             free_staged(fq, sg);
             return fail(CID_ERR_HIP, "cid_fastq_push_bgzf: %s", hipGetErrorString(e));
         }

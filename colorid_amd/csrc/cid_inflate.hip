@@ -3,16 +3,18 @@
 // src/read_id_mt_pe.rs:848-856, src/kmer.rs:469-476).  A BGZF file is a series of independent gzip members of at most 64 KiB of text,
 // each carrying its compressed size in a "BC" extra field — so a batch of members is a batch of independent DEFLATE streams.
 //
-// DEFLATE is serial inside a stream, so one lane decodes a member; what its dependent chain touches at every symbol — the
-// Huffman tables and the bit reader's input ring — lives in LDS (5.6 KiB per member), the text is written in place in HBM: a literal
-// is a store nobody waits for, a match reads bytes the same lane stored earlier (L2-resident), and that latency is hidden by the
-// other members: ~28 of them fit a CU, so the 4 800 members of a million reads are all in flight at once (the first version kept each
-// member's 64 KiB image in LDS: 2 members per CU, 104 ms per million reads).  The wave as a whole moves the data: compressed bytes
-// stream into the ring in 1 KiB wave-wide loads between the decoding lanes' runs, and a member's CRC-32 is computed by all 64 lanes
-// over 1 KiB slices of the text and folded with the "append 1024 zero bytes" operator.  A wave carries TWO members on its first two
-// lanes: the kernel is bound by instruction issue, and two decoders that share an instruction stream wherever their steps coincide
-// finish a million reads' members in 19.6 ms against 42.7 ms one per wave (4 and 8 per wave: 21.8 ms — the divergence eats the rest;
-// the floor of a launch is the 12 ms a single member takes).
+// DEFLATE is serial inside a stream, so one lane decodes a member: its chain of dependent steps is what a launch cannot be shorter than.
+// Everything that chain touches at every symbol — the Huffman tables, the bit reader's input ring — lives in LDS (7.5 KiB per member),
+// and nothing in it waits for HBM: a literal is a store nobody waits for, and a match is NOT copied by the decoder (reading the source
+// would wait for every earlier store — a round trip to L2 per match) but left as a token (position, length, distance) for the whole
+// wave, which copies a run's matches 64 at a time behind one fence per round (copy_matches; round 3: 64 KiB of FASTQ text took a lane
+// 13.7 ms with the copies in the chain, 7.9 ms without, 4.5 ms when the wave carries one member).  The wave also moves the data in:
+// compressed bytes stream into the ring in 1 KiB wave-wide loads between the decoding lanes' runs; and it checks the result: a member's
+// CRC-32 is computed by all 64 lanes over 1 KiB slices of the text (slicing by 4) and folded with the "append 1024 zero bytes" operator.
+// ~20 members fit a CU, so the 4 800 members of a million reads are all in flight at once (the first version kept each member's 64 KiB
+// image in LDS: 2 members per CU, 104 ms per million reads).  A wave carries TWO members on its first two lanes when the launch can fill
+// the chip: two decoders that share an instruction stream wherever their steps coincide finish a million reads' members in 9.3 ms
+// against 14.3 ms one per wave (4 and 8 per wave: 13.7 / 30.6 ms — the divergence eats the rest); a small launch takes one per wave.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,9 +29,11 @@ namespace cid {
 
 constexpr int kLitBits = 10, kDistBits = 8;
 constexpr uint32_t kRing = 2048;
-// per-wave LDS: input ring | lit table | dist table | canonical-decode arrays | code lengths
+// per-member LDS: input ring | literal/length table | dist table | canonical-decode arrays | code lengths | match tokens
+constexpr uint32_t kTokens = 256;   // matches a run may leave for the wave to copy
 constexpr uint32_t kLdsRing = 0, kLdsLit = kLdsRing + kRing, kLdsDist = kLdsLit + 2u * (1u << kLitBits),
-                   kLdsCnt = kLdsDist + 2u * (1u << kDistBits), kLdsLens = kLdsCnt + 2u * (16 + 288 + 16 + 32), kLdsBytes = kLdsLens + 320;
+                   kLdsCnt = kLdsDist + 2u * (1u << kDistBits), kLdsLens = kLdsCnt + 2u * (16 + 288 + 16 + 32), kLdsTok = kLdsLens + 320,
+                   kLdsBytes = kLdsTok + 8u * kTokens;
 
 struct CrcShift { uint32_t m[32]; };   // column j: the CRC register 1 << j after 1024 zero bytes
 
@@ -115,11 +119,6 @@ __device__ __forceinline__ int decode_sym(BitReader &br, const uint16_t *tab, ui
     return -1;
 }
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
-                                         6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // lane 0's decoder state between its runs (the wave refills the input ring in between)
@@ -129,6 +128,7 @@ struct Decoder {
     uint32_t stored_left;
     uint32_t out_pos;
     uint32_t status;
+    uint32_t n_tok;     // matches of this run waiting in the token list
 };
 
 // the LDS of one member's decoder
@@ -136,9 +136,11 @@ struct LaneLds {
     uint8_t *ring;
     uint16_t *lit, *dist, *lcnt, *lsym, *dcnt, *dsym;
     uint8_t *lens;
+    uint2 *tok;   // kTokens matches: x = position in the text | length << 16, y = distance
     __device__ explicit LaneLds(uint8_t *base)
         : ring(base + kLdsRing), lit(reinterpret_cast<uint16_t *>(base + kLdsLit)), dist(reinterpret_cast<uint16_t *>(base + kLdsDist)),
-          lcnt(reinterpret_cast<uint16_t *>(base + kLdsCnt)), lsym(lcnt + 16), dcnt(lsym + 288), dsym(dcnt + 16), lens(base + kLdsLens) {}
+          lcnt(reinterpret_cast<uint16_t *>(base + kLdsCnt)), lsym(lcnt + 16), dcnt(lsym + 288), dsym(dcnt + 16), lens(base + kLdsLens),
+          tok(reinterpret_cast<uint2 *>(base + kLdsTok)) {}
 };
 
 // one run of a member's decoder: steps are taken while they START within 400 bytes of the run's first one (the ring holds >= 1024 bytes
@@ -148,7 +150,7 @@ __device__ void decode_run(BitReader &br, Decoder &d, const LaneLds &L, uint8_t 
     uint8_t *const s_lens = L.lens;
     // a step starts below this mark; the longest one (a dynamic block header) takes < 600 bytes, and the ring holds >= 1024 ahead (or the stream's end)
     const uint32_t run_end = br.consumed_bytes() + 400;
-    while (d.phase != 3 && d.status == ST_OK && br.consumed_bytes() < run_end) {
+    while (d.phase != 3 && d.status == ST_OK && br.consumed_bytes() < run_end && d.n_tok < kTokens) {
         br.refill();
         if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
         if (d.phase == 0) {   // block header
@@ -201,20 +203,45 @@ __device__ void decode_run(BitReader &br, Decoder &d, const LaneLds &L, uint8_t 
                 d.phase = 1;
             } else { d.status = ST_BAD_BLOCK; break; }
         } else if (d.phase == 1) {   // literal / length-distance symbols
-            // literals with a short code, one after the other: table word, store, drop — the bounds are a word count
-            // (the run's budget) and the output's end; anything else falls through to the general step below
+            // The common steps — a literal, or a match whose two codes are short — in one tight loop: table word, store or token, drop.
+            // It stops WITHOUT having consumed anything at whatever else comes (a long code, the end of the block, an invalid symbol, the
+            // output's end, the run's budget of input words or tokens), and the general step below takes that symbol or reports it.
             {
                 const uint32_t w_end = (run_end + 3) / 4 + 1;
-                uint32_t op = d.out_pos;
+                uint32_t op = d.out_pos, nt = d.n_tok;
                 for (;;) {
                     br.refill();
                     const uint32_t e = s_lit[br.peek(kLitBits)];
-                    if (e - 1u >= (256u << 4) - 1u || op >= out_len || br.wpos >= w_end) break;   // not a short-coded literal (e == 0: a long code)
-                    img[op++] = (uint8_t)(e >> 4);
-                    br.drop(e & 15u);
+                    if (e == 0 || br.wpos >= w_end) break;
+                    const uint32_t sym = e >> 4;
+                    if (sym < 256u) {
+                        if (op >= out_len) break;
+                        img[op++] = (uint8_t)sym;
+                        br.drop(e & 15u);
+                        continue;
+                    }
+                    if (sym - 257u > 28u || nt >= kTokens) break;
+                    BitReader b2 = br;   // (committed only when the whole match was taken here)
+                    b2.drop(e & 15u);
+                    const uint32_t li = sym - 257u;
+                    const uint32_t lx = li < 8u || li == 28u ? 0u : (li >> 2) - 1u;
+                    const uint32_t len = (li < 8u ? 3u + li : li == 28u ? 258u : ((4u + (li & 3u)) << lx) + 3u) + b2.take(lx);
+                    b2.refill();
+                    const uint32_t de = s_dist[b2.peek(kDistBits)];
+                    const uint32_t ds = de >> 4;
+                    if (de == 0 || ds > 29u) break;
+                    b2.drop(de & 15u);
+                    const uint32_t dx = ds < 4u ? 0u : (ds >> 1) - 1u;
+                    const uint32_t dist = (ds < 4u ? 1u + ds : ((2u + (ds & 1u)) << dx) + 1u) + b2.take(dx);
+                    if (dist > op || op + len > out_len) break;
+                    L.tok[nt++] = make_uint2(op | (len << 16), dist);
+                    op += len;
+                    br = b2;
                 }
                 d.out_pos = op;
+                d.n_tok = nt;
                 if (br.consumed_bytes() > data_len) { d.status = ST_OVERRUN_IN; break; }
+                if (nt >= kTokens) continue;   // (the outer loop ends the run)
             }
             const int sym = decode_sym(br, s_lit, kLitBits, s_lcnt, s_lsym);
             if (sym < 0) { d.status = ST_BAD_CODE; break; }
@@ -225,33 +252,22 @@ __device__ void decode_run(BitReader &br, Decoder &d, const LaneLds &L, uint8_t 
                 d.phase = d.last ? 3u : 0u;
             } else {
                 if (sym > 285) { d.status = ST_BAD_CODE; break; }
-                const uint32_t len = c_len_base[sym - 257] + br.take(c_len_extra[sym - 257]);
+                // base and extra bits by arithmetic (RFC 1951 3.2.5's tables are regular): a table in constant memory indexed per lane is a
+                // vector load, two round trips to the cache per match inside the dependent chain
+                const uint32_t li = (uint32_t)sym - 257u;
+                const uint32_t lx = li < 8u || li == 28u ? 0u : (li >> 2) - 1u;
+                const uint32_t lb = li < 8u ? 3u + li : li == 28u ? 258u : ((4u + (li & 3u)) << lx) + 3u;
+                const uint32_t len = lb + br.take(lx);
                 br.refill();
                 const int ds = decode_sym(br, s_dist, kDistBits, s_dcnt, s_dsym);
                 if (ds < 0 || ds > 29) { d.status = ST_BAD_CODE; break; }
-                const uint32_t dist = c_dist_base[ds] + br.take(c_dist_extra[ds]);
+                const uint32_t dx = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
+                const uint32_t dist = (ds < 4 ? 1u + (uint32_t)ds : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u) + br.take(dx);
                 if (dist > d.out_pos) { d.status = ST_BAD_CODE; break; }
                 if (d.out_pos + len > out_len) { d.status = ST_OVERRUN_OUT; break; }
-                uint8_t *o = img + d.out_pos;
-                const uint8_t *f = o - dist;
-                if (dist >= 8) {   // eight bytes at a time: the loads of a piece are issued together, none depends on the piece's stores
-                    for (uint32_t i = 0; i < len; i += 8) {
-                        uint8_t t[8];
-#pragma unroll
-                        for (uint32_t j = 0; j < 8; ++j) t[j] = f[i + j];          // (may read up to 7 bytes past the match: inside the image)
-#pragma unroll
-                        for (uint32_t j = 0; j < 8; ++j) if (i + j < len) o[i + j] = t[j];
-                    }
-                } else {           // a short period (runs, dinucleotide repeats, quality plateaus): the pattern rotates in a register
-                    uint64_t pat = 0;
-                    for (uint32_t j = 0; j < dist; ++j) pat |= (uint64_t)f[j] << (8 * j);
-                    const uint32_t top = 8 * (dist - 1);
-                    for (uint32_t i = 0; i < len; ++i) {
-                        const uint32_t b = (uint32_t)pat & 0xFFu;
-                        o[i] = (uint8_t)b;
-                        pat = (pat >> 8) | ((uint64_t)b << top);
-                    }
-                }
+                // the copy is the wave's (copy_matches): a match read here would wait for every store before it — a round trip to L2 per
+                // match inside the one dependent chain the member has
+                L.tok[d.n_tok++] = make_uint2(d.out_pos | (len << 16), dist);
                 d.out_pos += len;
             }
         } else {   // stored bytes
@@ -264,6 +280,78 @@ __device__ void decode_run(BitReader &br, Decoder &d, const LaneLds &L, uint8_t 
     }
     if (d.status == ST_OK && d.phase == 3 && br.consumed_bytes() > data_len) d.status = ST_OVERRUN_IN;
 }
+
+// The matches a run left behind, copied by the whole wave, 64 at a time, one lane each.  A match may go when every byte it reads is final:
+// literals are (the decoder stored them; the fence at the top of a round covers them), and so is everything below the first match still
+// waiting, because the matches before that one went in earlier rounds.  So per round: the first waiting match, and every later one that
+// reads only below it.  Block-gzip text rarely needs a third round (a line that repeats the line before it); a run of one byte — each
+// match reading the one before — degrades to a round per match and is still 258 bytes a round.
+__device__ void copy_matches(const uint2 *tok, uint32_t n, uint8_t *img, int lane) {
+    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+        const uint32_t t = b0 + (uint32_t)lane;
+        bool waiting = t < n;
+        const uint2 tk = waiting ? tok[t] : make_uint2(0, 1);
+        const uint32_t o = tk.x & 0xFFFFu, len = tk.x >> 16, dist = tk.y;
+        const uint32_t read_end = o - dist + (len < dist ? len : dist);   // one past the last byte it reads
+        for (;;) {
+            const uint64_t wm = __ballot(waiting);
+            if (!wm) break;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // stores so far (literals, earlier rounds) have landed
+            const int first = __builtin_ctzll(wm);
+            const uint32_t o_first = (uint32_t)__builtin_amdgcn_readlane((int)o, first);
+            if (waiting && (lane == first || read_end <= o_first)) {
+                uint8_t *dst = img + o;
+                const uint8_t *f = dst - dist;
+                auto put_tail = [](uint8_t *q, uint64_t v, uint32_t r) {   // the low r (< 8) bytes of v
+                    if (r & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(q, &w, 4); q += 4; v >>= 32; }
+                    if (r & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(q, &h, 2); q += 2; v >>= 16; }
+                    if (r & 1u) *q = (uint8_t)v;
+                };
+                if (dist >= 8) {   // eight bytes per load and store (any alignment); a piece reads nothing the same piece writes
+                    uint32_t i = 0;
+                    for (; i + 8 <= len; i += 8) {
+                        uint64_t v;
+                        __builtin_memcpy(&v, f + i, 8);
+                        __builtin_memcpy(dst + i, &v, 8);
+                    }
+                    if (i < len) {
+                        uint64_t v;
+                        __builtin_memcpy(&v, f + i, 8);   // (reads up to 7 bytes past the match's source: still below dst + len, inside the image)
+                        put_tail(dst + i, v, len - i);
+                    }
+                } else {           // a short period (runs, dinucleotide repeats, quality plateaus): the pattern repeats in a register
+                    uint64_t pat = 0;
+                    for (uint32_t j = 0; j < dist; ++j) pat |= (uint64_t)f[j] << (8 * j);
+                    if ((8u % dist) == 0) {   // periods 1, 2, 4: every eight bytes are the same eight
+                        uint64_t rep = pat;
+                        for (uint32_t w = dist; w < 8; w <<= 1) rep |= rep << (8 * w);
+                        uint32_t i = 0;
+                        for (; i + 8 <= len; i += 8) __builtin_memcpy(dst + i, &rep, 8);
+                        put_tail(dst + i, rep, len - i);
+                    } else {
+                        const uint32_t top = 8 * (dist - 1);
+                        for (uint32_t i = 0; i < len; ++i) {
+                            const uint32_t b = (uint32_t)pat & 0xFFu;
+                            dst[i] = (uint8_t)b;
+                            pat = (pat >> 8) | ((uint64_t)b << top);
+                        }
+                    }
+                }
+                waiting = false;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+
+#ifdef CID_INFLATE_STAMPS   // tools/inflate_probe.hip: cycles of wave 0 of every block per part of the kernel
+__device__ unsigned long long g_inflate_stamps[8];
+#define CID_STAMP(slot, t0) do { if (lane == 0) atomicAdd(&g_inflate_stamps[slot], (unsigned long long)(__builtin_readcyclecounter() - (t0))); } while (0)
+#define CID_NOW() __builtin_readcyclecounter()
+#else
+#define CID_STAMP(slot, t0) do { (void)(t0); } while (0)
+#define CID_NOW() 0ull
+#endif
 
 // LPW members per wave, decoded by its first LPW lanes side by side (the same instruction stream wherever their steps coincide: the
 // kernel is bound by instruction issue, so sharing it is worth more than the divergence costs); the wave-wide parts — ring refills,
@@ -304,10 +392,11 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
         bool running = mine && st == ST_OK;
         BitReader br{reinterpret_cast<const uint32_t *>(L.ring), 1, 0, 0, 0};
         bool started = false;
-        Decoder d{0, 0, 0, 0, ST_OK};
+        Decoder d{0, 0, 0, 0, ST_OK, 0};
         uint32_t fill = 0;   // bytes of this lane's stream in its ring
         __builtin_amdgcn_wave_barrier();
         for (;;) {   // wave-uniform loop: the rings are refilled by the whole wave, member by member; then the lanes decode a run each
+            const unsigned long long t_fill = CID_NOW();
             const uint32_t used_l = br.consumed_bytes();
             const uint32_t dlo = (uint32_t)reinterpret_cast<uintptr_t>(data), dhi = (uint32_t)(reinterpret_cast<uintptr_t>(data) >> 32);
 #pragma unroll
@@ -348,13 +437,35 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            CID_STAMP(0, t_fill);
+            const unsigned long long t_dec = CID_NOW();
             if (running) {
                 if (!started) { br.start(); started = true; }
                 decode_run(br, d, L, img, mem.out_len, data_len);
                 if (d.phase == 3 || d.status != ST_OK) running = false;
             }
+            CID_STAMP(1, t_dec);
+            const unsigned long long t_copy = CID_NOW();
+            // the runs' matches, member by member, by all 64 lanes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {
+                const uint32_t ilo = (uint32_t)reinterpret_cast<uintptr_t>(img), ihi = (uint32_t)(reinterpret_cast<uintptr_t>(img) >> 32);
+#pragma unroll
+                for (int m = 0; m < LPW; ++m) {
+                    const uint32_t nt = (uint32_t)__builtin_amdgcn_readlane((int)d.n_tok, m);
+                    if (!nt) continue;
+                    uint8_t *im = reinterpret_cast<uint8_t *>((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)ilo, m) |
+                                                              ((uintptr_t)(uint32_t)__builtin_amdgcn_readlane((int)ihi, m) << 32));
+                    copy_matches(reinterpret_cast<const uint2 *>(smem + (size_t)m * kLdsBytes + kLdsTok), nt, im, lane);
+                }
+                d.n_tok = 0;
+            }
+            CID_STAMP(2, t_copy);
             if (!__any(running)) break;
         }
+        const unsigned long long t_crc = CID_NOW();
         if (mine && st == ST_OK) st = d.status;
         if (mine && st == ST_OK && d.out_pos != mem.out_len) st = ST_BAD_LEN;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -362,11 +473,20 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // CRC-32 (RFC 1952 8) of every member that decoded, by all 64 lanes: slices aligned to the END of the text, so that every slice
         // but the first is exactly 1024 bytes; lane l takes slice l; the table (256 words) is built in the first ring's storage
+        // (four tables, "slicing by 4": a 32-bit word of text per step, its four look-ups independent of each other — the chain through
+        // the CRC register is one LDS round trip per four bytes instead of one per byte)
         uint32_t *tab = reinterpret_cast<uint32_t *>(smem + kLdsRing);
         for (uint32_t i = lane; i < 256; i += 64) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
             tab[i] = c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = lane; i < 256; i += 64) {
+            uint32_t c = tab[i];
+            for (int t = 1; t < 4; ++t) { c = tab[c & 0xFFu] ^ (c >> 8); tab[256 * t + i] = c; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -386,7 +506,14 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
                 const uint32_t b0 = lane == 0 ? 0u : first_len + ((uint32_t)lane - 1u) * 1024u;
                 const uint32_t b1 = lane == 0 ? first_len : b0 + 1024u;
                 c = lane == 0 ? 0xFFFFFFFFu : 0u;
-                for (uint32_t i = b0; i < b1; ++i) c = tab[(c ^ im[i]) & 0xFFu] ^ (c >> 8);
+                uint32_t i = b0;
+                for (; i < b1 && ((b1 - i) & 3u); ++i) c = tab[(c ^ im[i]) & 0xFFu] ^ (c >> 8);   // (only the first slice is not a multiple of 4)
+                for (; i < b1; i += 4) {
+                    uint32_t w;
+                    __builtin_memcpy(&w, im + i, 4);
+                    c ^= w;
+                    c = tab[768 + (c & 0xFFu)] ^ tab[512 + ((c >> 8) & 0xFFu)] ^ tab[256 + ((c >> 16) & 0xFFu)] ^ tab[c >> 24];
+                }
             }
             uint32_t reg = 0xFFFFFFFFu;   // (an empty member: CRC 0)
             for (uint32_t s = 0; s < n_slices; ++s) {
@@ -401,6 +528,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
             if (lane == m && (reg ^ 0xFFFFFFFFu) != want_crc) st = ST_BAD_CRC;
         }
         if (mine) status[mi] = st;
+        CID_STAMP(3, t_crc);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -434,7 +562,12 @@ hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_
                                uint32_t *d_st) {
     if (n_members == 0) return hipSuccess;
     static const CrcShift shift = make_crc_shift();
-    static const int lanes = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : kInflateLanes;   // members per wave: 1, 2, 4 or 8
+    // members per wave (CID_INFLATE_LANES: 1, 2, 4 or 8).  Two decoders share a wave's instruction stream where their steps coincide, which
+    // doubles what a full chip decodes per unit time, but each runs at 0.6 of the speed it has alone: a launch that leaves the chip mostly
+    // idle anyway (<= 1 280 members = five waves per CU) takes one per wave (256 members: 4.5 against 7.9 ms, 1 024: 5.5 against 8.4,
+    // the 4 794 of a million reads: 14.3 against 9.3 — tools/exp_inflate_lanes.sh)
+    static const int lanes_env = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : 0;
+    const int lanes = lanes_env ? lanes_env : n_members <= 1280u ? 1 : kInflateLanes;
     const unsigned lpw = lanes == 1 ? 1u : lanes == 4 ? 4u : lanes == 8 ? 8u : 2u;
     unsigned grid = (unsigned)((n_members + lpw - 1) / lpw);
     const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // a few rounds per block at most

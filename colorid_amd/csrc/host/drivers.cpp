@@ -910,10 +910,11 @@ static void print_read_id_timing(const Clock::time_point &t0) {
 // poll.  No inflating threads, no record packers: the host reads the file, polls and writes.  COLORID_DEVICE_FASTQ=0 keeps the host
 // front end; several GPUs (--gpus / --placement) use it too.
 bool read_id_mt_pe::device_fastq_wanted(const std::vector<std::string> &fq, size_t n_files) {
-    // default: single-end input.  Pairs are inflate-bound on either path (twice the text per read pair for the same threads) and measured
-    // no faster through the device (4 M pairs: 0.39-0.45 s host front end, 0.39-0.51 s device): COLORID_DEVICE_FASTQ=1 asks for it.
+    // default: on, for single-end input (16 M reads: 0.66-0.70 s against 1.05-1.11 s through the host front end on a 16-CPU share) and
+    // for pairs (4 M pairs: 0.33-0.34 s against 0.36-0.38 s) — profiles/r03_frontend_16m.txt; COLORID_DEVICE_FASTQ=0 keeps the host's
     const char *e = getenv("COLORID_DEVICE_FASTQ");
-    if ((e && atoi(e) == 0) || (!e && n_files > 1) || g_group) return false;
+    if ((e && atoi(e) == 0) || g_group) return false;
+    (void)n_files;
     for (size_t i = 0; i < n_files; ++i)
         if (!BgzfMemberReader::is_bgzf(fq[i])) return false;
     return true;
@@ -948,13 +949,18 @@ namespace {
 // false: the input is not this path's (reads too long for the LDS kernels) and nothing has been written yet — the caller falls back
 bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, size_t n_files, const Bigsi &b, size_t d, size_t start_sample,
                              uint8_t qual_offset, BatchClassifier &classifier) {
+    const auto t_enter = Clock::now();
     cid_fastq *fr = nullptr;
     CID_TRY(cid_fastq_create(ctx, (int)n_files, qual_offset, &fr));
     const size_t target = read_id_mt_pe::device_fastq_stretch_bytes(b.colors.size());
     std::unique_ptr<BgzfMemberReader> rd[2];
     for (size_t i = 0; i < n_files; ++i)   // (reading since before the index load, main.cpp)
         rd[i] = BgzfMemberReader::open(fq[i], target, read_id_mt_pe::device_fastq_host_share(), read_id_mt_pe::device_fastq_host_threads(n_files));
-    BgzfStretch st[2][2];   // per file two stretches in turn: the one pushed last stays untouched while its text is still on the bus
+    // stretches pushed ahead of the one being classified: their inflate launches (alternating streams in the library) overlap, which
+    // matters because a launch cannot be shorter than the decoding of one member (~14 ms) however few members it holds
+    const size_t ahead = [] { const char *e = getenv("COLORID_DEVICE_FASTQ_AHEAD"); const long v = e ? atol(e) : 1; return (size_t)(v < 1 ? 1 : v > 6 ? 6 : v); }();
+    std::vector<BgzfStretch> st[2];   // per file ahead + 1 stretches in turn: the one pushed last stays untouched while its text is still on the bus
+    st[0].resize(ahead + 1); st[1].resize(ahead + 1);
     size_t turn[2] = {0, 0};
     bool more[2] = {true, n_files == 2};
     size_t pending[2] = {0, 0};   // stretches pushed and not yet taken by a classify call
@@ -962,7 +968,7 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
     auto push_next = [&](size_t i) {
         if (!more[i]) return;
         const auto tr = Clock::now();
-        BgzfStretch &sx = st[i][turn[i]++ & 1];
+        BgzfStretch &sx = st[i][turn[i]++ % (ahead + 1)];
         const bool got = rd[i]->next(sx);
         ms_read += ms_since(tr);
         if (!got) { more[i] = false; return; }
@@ -979,9 +985,11 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
     };
     auto t_gpu = Clock::now();
     for (size_t i = 0; i < n_files; ++i) push_next(i);
+    const double ms_setup = ms_since(t_enter);
     bool first = true;
     while (pending[0] || pending[1]) {
-        for (size_t i = 0; i < n_files; ++i) push_next(i);   // the stretch after this one: inflated while this one is classified
+        for (size_t i = 0; i < n_files; ++i)   // the stretches after this one: inflated while this one is classified
+            while (more[i] && pending[i] < ahead + 1) push_next(i);
         uint64_t n = 0, ne = 0, idb = 0;
         const auto tc = Clock::now();
         const int rc = cid_fastq_classify(fr, b.index, (uint32_t)d, (uint32_t)start_sample, 2, &n, &ne, &idb);
@@ -1014,8 +1022,8 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
     }
     cid_fastq_destroy(fr);
     if (g_timing)
-        fprintf(stderr, "timing: device front end: waiting for the file reader %.0f ms, push (H2D of the members) %.0f ms, classify %.0f ms, fetch %.0f ms\n",
-                ms_read, ms_push, ms_classify, ms_fetch);
+        fprintf(stderr, "timing: device front end: waiting for the file reader %.0f ms, push (H2D of the members) %.0f ms, classify %.0f ms, fetch %.0f ms; "
+                "%.0f ms until the first stretch was pushed, %.0f ms in all\n", ms_read, ms_push, ms_classify, ms_fetch, ms_setup, ms_since(t_enter));
     return true;
 }
 }  // namespace
@@ -1036,7 +1044,9 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
         if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);   // (batches close on piece boundaries: at least `batch` reads each)
     }, [&] { return classifier.spare(); });
     classifier.submit(rb);
+    const auto t_drain = Clock::now();
     const uint64_t read_count = classifier.finish();
+    if (g_timing) fprintf(stderr, "timing: %.0f ms from the end of the input to the last row written\n", ms_since(t_drain));
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
     print_read_id_timing(t0);

@@ -243,6 +243,7 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
     q = [f1, f2] if paired else [f1]
     outs = {}
     for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {"COLORID_DEVICE_FASTQ": "1"}), ("dev_small", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_MB": "1"}),
+                     ("dev_ahead", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_AHEAD": "3"}), ("dev_default", {}),
                      ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}), ("dev_host_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "1"})):
         for extra in ([], ["-Q", "0", "-d", "3", "-B", "0"]):
             name = str(tmp_path / f"{tag}{len(extra)}")
@@ -253,6 +254,7 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
     for extra in (0, 6):
         host = outs[("host", extra)]
         assert host[0].count("\n") == (11500 if paired else 12000)
-        for tag in ("dev", "dev_small", "dev_gpu_inflate", "dev_host_inflate"):
+        for tag in ("dev", "dev_small", "dev_ahead", "dev_default", "dev_gpu_inflate", "dev_host_inflate"):
             assert outs[(tag, extra)][0] == host[0] and outs[(tag, extra)][1] == host[1], (tag, extra)
+            assert "device front end" in outs[(tag, extra)][2], tag      # (the timing line of the path that ran)
     assert "accept" in outs[("dev", 0)][0]
