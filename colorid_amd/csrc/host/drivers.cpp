@@ -1038,6 +1038,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     const bool on_device = device_fastq_wanted(fq, 1);
     if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(4, cpu_budget() / 4));   // no packing threads beside them
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
+    if (g_timing) fprintf(stderr, "timing: %.0f ms of set-up before the first read\n", ms_since(t0));
     if (!on_device || !classify_bgzf_on_device(ctx, fq, 1, b, d, start_sample, qual_offset, classifier))
     stream_fastq_records(fq[0], nullptr, qual_offset, true, [&](ReadBatch &&piece) {
         if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
@@ -1046,8 +1047,10 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     classifier.submit(rb);
     const auto t_drain = Clock::now();
     const uint64_t read_count = classifier.finish();
-    if (g_timing) fprintf(stderr, "timing: %.0f ms from the end of the input to the last row written\n", ms_since(t_drain));
+    const double ms_drain = ms_since(t_drain);
+    const auto t_close = Clock::now();
     fclose(out);
+    if (g_timing) fprintf(stderr, "timing: %.0f ms from the end of the input to the last row written, %.0f ms closing the output\n", ms_drain, ms_since(t_close));
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
     print_read_id_timing(t0);
 }
