@@ -61,6 +61,7 @@ SIGNATURES = {
     "cid_bgzf_inflate_finish": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cid_kmerset_create": (C.c_int, [vp, C.c_uint32, C.POINTER(vp)]),
     "cid_kmerset_add_seqs": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int]),
+    "cid_kmerset_add_seqs_dev": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_int]),
     "cid_kmerset_finalize": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "cid_kmerset_size": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "cid_kmerset_count_histogram": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -120,6 +121,7 @@ SIGNATURES = {
     "cid_fastq_push_bgzf": (C.c_int, [vp, C.c_int, vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.c_int]),
     "cid_fastq_push_text": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int]),
     "cid_fastq_classify": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cid_fastq_count_kmers": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_uint64)]),
     "cid_fastq_fetch": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "cid_fastq_destroy": (None, [vp]),
     "cid_timer_start": (C.c_int, [vp]),

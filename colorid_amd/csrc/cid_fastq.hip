@@ -357,12 +357,16 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
     return CID_OK;
 }
 
-int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
-                       uint64_t *n_entries, uint64_t *id_bytes) {
-    if (!fq || !n_reads || !n_entries || !id_bytes) return fail(CID_ERR_INVALID, "null argument");
+}  // extern "C"
+
+// One step over the text pushed so far: whole records -> masked, packed reads in HBM, which go either through read_id's kernels (ix:
+// per-read counts, sparse report, ids kept for cid_fastq_fetch) or into a k-mer set (ks: `search`'s query k-mers, kmer.rs:461-510 /
+// :581-655 — every read of either file, windows with an N dropped, case kept).
+static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint32_t k, uint32_t stride_d, uint32_t start_sample, int max_pushes,
+                      uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes) {
     *n_reads = *n_entries = *id_bytes = 0;
     cid_ctx *c = fq->ctx;
-    int rc = cid::check_ready(c, ix);
+    int rc = ix ? cid::check_ready(c, ix) : CID_OK;
     if (rc) return rc;
     if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
     HIP_TRY(hipSetDevice(c->device));
@@ -453,7 +457,7 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
             return rc;
         HIP_TRY(hipMemsetAsync(seq_off.p + n_seqs, 0, 8, st));
         HIP_TRY(hipMemsetAsync(id_off.p + n, 0, 8, st));
-        hipLaunchKernelGGL(cid::k_fq_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F[0], F[1], nf, fq->quality, ix->k, stride_d, stats.p,
+        hipLaunchKernelGGL(cid::k_fq_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F[0], F[1], nf, fq->quality, k, stride_d, stats.p,
                            span.p, seq_off.p, id_begin.p, id_off.p);
         size_t tb1 = 0, tb2 = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb1, seq_off.p, seq_off.p, 0ull, n_seqs + 1, rocprim::plus<uint64_t>(), st));
@@ -469,6 +473,15 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
         if (hs.err) return fail(CID_ERR_INVALID, "ERROR: could not get the next nt in the sequence (a quality line longer than its sequence, src/seq.rs:43-45)");
         Buf<uint8_t> bases(c), ids(c), status(c);
         Buf<uint32_t> report(c), nk(c);
+        unsigned grid = (unsigned)((n_seqs + 3) / 4);
+        if (grid > 16384) grid = 16384;
+        if (ks) {   // the reads' k-mers into the set: no ids, no report
+            if ((rc = bases.alloc(total_bases + 16))) return rc;
+            hipLaunchKernelGGL(cid::k_fq_pack, dim3(grid), dim3(256), 0, st, F[0], F[1], nf, fq->quality, n_seqs, span.p, seq_off.p, bases.p);
+            HIP_TRY(hipGetLastError());
+            if ((rc = cid_kmerset_add_seqs_dev(ks, bases.p, seq_off.p, n_seqs, hs.max_bytes, 1))) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+        } else {
         const size_t C1 = (size_t)ix->n_colors + 1;
         if ((double)n * (double)C1 * 4.0 > 64.0 * (double)(1ull << 30))
             return fail(CID_ERR_UNSUPPORTED, "%llu reads x %u colours need more than 64 GiB of dense report rows on the device: push smaller stretches",
@@ -476,8 +489,6 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
         if ((rc = bases.alloc(total_bases + 16)) || (rc = ids.alloc(total_ids)) || (rc = report.alloc(n * C1)) || (rc = nk.alloc(n)) ||
             (rc = status.alloc(n)))
             return rc;
-        unsigned grid = (unsigned)((n_seqs + 3) / 4);
-        if (grid > 16384) grid = 16384;
         hipLaunchKernelGGL(cid::k_fq_pack, dim3(grid), dim3(256), 0, st, F[0], F[1], nf, fq->quality, n_seqs, span.p, seq_off.p, bases.p);
         hipLaunchKernelGGL(cid::k_fq_ids, dim3(grid), dim3(256), 0, st, F[0], n, id_begin.p, id_off.p, ids.p);
         hipLaunchKernelGGL(cid::k_fq_read_seq0, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, read_seq0.p, n, (uint32_t)nf);
@@ -495,6 +506,7 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
         fq->d_nk = nk.release(); fq->d_status = status.release(); fq->d_ids = ids.release(); fq->d_id_off = id_off.release();
         fq->n_reads = n; fq->id_bytes = total_ids;
         HIP_TRY(hipStreamSynchronize(st));   // the scratch above returns to the cache
+        }
     }
     // what is left of either text moves to the front: the next push continues behind it
     for (int f = 0; f < nf; ++f) {
@@ -516,9 +528,24 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
     for (int f = 0; f < nf; ++f) all_last = all_last && fq->f[f].last;
     if (all_last) for (int f = 0; f < nf; ++f) fq->f[f].len = 0;
     *n_reads = n;
-    *n_entries = c->sp_entries;
-    *id_bytes = total_ids;
+    *n_entries = ks ? 0 : c->sp_entries;
+    *id_bytes = ks ? 0 : total_ids;
     return CID_OK;
+}
+
+extern "C" {
+
+int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
+                       uint64_t *n_entries, uint64_t *id_bytes) {
+    if (!fq || !ix || !n_reads || !n_entries || !id_bytes) return fail(CID_ERR_INVALID, "null argument");
+    return fastq_step(fq, ix, nullptr, ix->k, stride_d, start_sample, max_pushes, n_reads, n_entries, id_bytes);
+}
+
+int cid_fastq_count_kmers(cid_fastq *fq, cid_kmerset *ks, int max_pushes, uint64_t *n_reads) {
+    if (!fq || !ks || !n_reads) return fail(CID_ERR_INVALID, "null argument");
+    if (cid::kmerset_ctx(ks) != fq->ctx) return fail(CID_ERR_INVALID, "the k-mer set and the reader belong to different contexts");
+    uint64_t ne = 0, idb = 0;
+    return fastq_step(fq, nullptr, ks, cid::kmerset_k(ks), 1, 0, max_pushes, n_reads, &ne, &idb);
 }
 
 int cid_fastq_fetch(cid_fastq *fq, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,

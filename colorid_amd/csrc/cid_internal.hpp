@@ -24,6 +24,8 @@ hipEvent_t ctx_event(const cid_ctx *c, int i);   // cid_ctx_tune "order_bits"
 // (cid_kmerset, sparse read_id results) must be destroyed before their ctx.
 int ctx_alloc(cid_ctx *c, size_t bytes, void **out);
 void ctx_free(cid_ctx *c, void *p);
+uint32_t kmerset_k(const cid_kmerset *ks);
+cid_ctx *kmerset_ctx(const cid_kmerset *ks);
 uint32_t index_k(const cid_index *ix);
 uint32_t index_rs(const cid_index *ix);
 ModMagic index_mod(const cid_index *ix);

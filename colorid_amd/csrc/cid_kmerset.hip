@@ -175,7 +175,9 @@ struct cid_kmerset {
     uint64_t *codes = nullptr; uint32_t *counts = nullptr; size_t n = 0;  // distinct k-mers, ascending code unless reordered
     int *d_flags = nullptr;
     bool finalized = false;
-    size_t compact_at = 1ull << 30;   // merge the unsorted window buffer into the set beyond this many codes (8 GiB)
+    // merge the unsorted window buffer into the set beyond this many codes (2 GiB).  (8 GiB until round 3: the buffer then regrows through
+    // 1.3 / 1.9 / 2.9 / 4.3 / 6.5 / 9.7 GB blocks, and those hipMallocs made a 16 M-read query's count take 0.25 s or 1.9 s from run to run)
+    size_t compact_at = 1ull << 28;
     // k > 32: keys are byte strings.  The sequences stay resident until finalize (g_bases, g_segs), where every window's key is
     // described as a stretch of them, sorted on a 4-bit-per-base image (LSD radix, 16 bases per pass) and run-length counted; the
     // finished set is n x k ASCII bytes (`ascii`) + counts, and feeds the byte-string kernels.
@@ -186,6 +188,12 @@ struct cid_kmerset {
     uint64_t g_windows = 0;
     uint8_t *ascii = nullptr;
 };
+
+namespace cid {   // (for the FASTQ front end, cid_fastq.hip)
+uint32_t kmerset_k(const cid_kmerset *ks) { return ks->k; }
+cid_ctx *kmerset_ctx(const cid_kmerset *ks) { return ks->ctx; }
+}
+
 
 namespace cid {
 int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, const uint32_t **counts, uint64_t *n, uint32_t *k) {
@@ -1221,6 +1229,60 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         if (mode == 1) HIP_TRY(hipMemcpyAsync(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    ks->n_raw += n_win_total;
+    if (mode == 1 && flag) return fail(CID_ERR_UNSUPPORTED, "lower-case bases in a case-preserving (fastq) k-mer count: count on the host");
+    if (ks->n_raw > ks->compact_at) return compact(ks);
+    return CID_OK;
+}
+
+// add_seqs for reads that are already on the device (the FASTQ front end's packed batch): d_seq_off[n_seqs + 1] are offsets into d_bases;
+// every sequence at most max_len bases, which must fit one segment (reads, not genomes)
+int cid_kmerset_add_seqs_dev(cid_kmerset *ks, const uint8_t *d_bases, const uint64_t *d_seq_off, size_t n_seqs, uint64_t max_len, int mode) {
+    if (!ks || !d_seq_off || (mode != 0 && mode != 1)) return fail(CID_ERR_INVALID, "bad argument");
+    if (ks->finalized) return fail(CID_ERR_STATE, "k-mer set already finalized");
+    if (ks->general) return fail(CID_ERR_UNSUPPORTED, "cid_kmerset_add_seqs_dev takes k <= 32 (byte-string sets keep the host-pointer call)");
+    if (max_len > cid::kSegWindows + ks->k - 1)
+        return fail(CID_ERR_UNSUPPORTED, "cid_kmerset_add_seqs_dev takes reads of at most %u bases (longer sequences: cid_kmerset_add_seqs)", cid::kSegWindows + ks->k - 1);
+    if (n_seqs == 0) return CID_OK;
+    if (!d_bases) return fail(CID_ERR_INVALID, "null bases");
+    cid_ctx *c = ks->ctx;
+    HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+    hipStream_t st = cid::ctx_stream(c);
+    int rc;
+    DevBuf<uint64_t> d_win(c);
+    if ((rc = d_win.alloc(n_seqs + 1))) return rc;
+    HIP_TRY(hipMemsetAsync(d_win.p + n_seqs, 0, 8, st));
+    hipLaunchKernelGGL(cid::k_seq_windows, dim3(grid_for_n(n_seqs)), dim3(256), 0, st, d_seq_off, (uint64_t)n_seqs, ks->k, d_win.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, d_win.p, d_win.p, (uint64_t)ks->n_raw, n_seqs + 1, rocprim::plus<uint64_t>(), st));
+    DevBuf<uint8_t> tmp(c);
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, d_win.p, d_win.p, (uint64_t)ks->n_raw, n_seqs + 1, rocprim::plus<uint64_t>(), st));
+    uint64_t end = 0;
+    HIP_TRY(hipMemcpyAsync(&end, d_win.p + n_seqs, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t n_win_total = end - ks->n_raw;
+    if (n_win_total == 0) return CID_OK;
+    if (end > ks->cap_raw) {
+        size_t want = end * 3 / 2;
+        DevBuf<uint64_t> nb(c);
+        if ((rc = nb.alloc(want))) return rc;
+        if (ks->n_raw) HIP_TRY(hipMemcpyAsync(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (ks->raw) cid::ctx_free(c, ks->raw);
+        ks->raw = nb.release();
+        ks->cap_raw = want;
+    }
+    constexpr uint32_t kBytes = cid::kSegWindows + 32 + 96;
+    const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
+    unsigned grid = (unsigned)((n_seqs + 3) / 4);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, (const cid::Segment *)nullptr, (uint32_t)n_seqs, ks->k, mode, ks->sentinel, ks->raw,
+                       ks->d_flags, d_seq_off, (const uint64_t *)d_win.p, (uint64_t)0);
+    HIP_TRY(hipGetLastError());
+    int flag = 0;
+    if (mode == 1) HIP_TRY(hipMemcpyAsync(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     ks->n_raw += n_win_total;
     if (mode == 1 && flag) return fail(CID_ERR_UNSUPPORTED, "lower-case bases in a case-preserving (fastq) k-mer count: count on the host");
     if (ks->n_raw > ks->compact_at) return compact(ks);

@@ -411,10 +411,73 @@ static bool stream_fastq_batches(const std::string &f1, const std::string *f2, u
     return ok;
 }
 
+// Block-gzip input through the device FASTQ front end: the members go up compressed (the reader's spare threads inflate their share),
+// records are cut, masked and packed on the device and their k-mers go straight into the set — no text comes back.  false: the input
+// is not for this path (CID_ERR_UNSUPPORTED: lower-case bases, reads longer than a segment) and `ks` holds a partial count.
+static bool count_bgzf_on_device(cid_ctx *ctx, cid_kmerset *ks, const std::vector<std::string> &fq, uint8_t q) {
+    const size_t n_files = fq.size();
+    cid_fastq *fr = nullptr;
+    CID_TRY(cid_fastq_create(ctx, (int)n_files, q, &fr));
+    const size_t target = read_id_mt_pe::device_fastq_stretch_bytes(0);
+    std::unique_ptr<BgzfMemberReader> rd[2];
+    for (size_t i = 0; i < n_files; ++i)
+        rd[i] = BgzfMemberReader::open(fq[i], target, read_id_mt_pe::device_fastq_host_share(), read_id_mt_pe::device_fastq_host_threads(n_files));
+    BgzfStretch st[2][2];   // per file two stretches in turn: the one pushed last stays untouched while its text is still on the bus
+    size_t turn[2] = {0, 0}, pending[2] = {0, 0};
+    bool more[2] = {true, n_files == 2};
+    double ms_read = 0, ms_push = 0, ms_count = 0;
+    auto push_next = [&](size_t i) {
+        if (!more[i]) return;
+        const auto tr = Clock::now();
+        BgzfStretch &sx = st[i][turn[i]++ & 1];
+        const bool got = rd[i]->next(sx);
+        ms_read += ms_since(tr);
+        if (!got) { more[i] = false; return; }
+        const auto tp = Clock::now();
+        const bool host_part = sx.host_text_bytes > 0;
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), sx.bytes.size(), sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
+                                    sx.last && !host_part ? CID_FASTQ_LAST : 0));
+        if (host_part)
+            CID_TRY(cid_fastq_push_text(fr, (int)i, sx.host_text.p, sx.host_text_bytes, (sx.last ? CID_FASTQ_LAST : 0) | (sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));
+        if (sx.last) more[i] = false;
+        ms_push += ms_since(tp);
+        ++pending[i];
+    };
+    for (size_t i = 0; i < n_files; ++i) push_next(i);
+    bool ok = true;
+    while (ok && (pending[0] || pending[1])) {
+        for (size_t i = 0; i < n_files; ++i) push_next(i);   // the stretch after this one: inflated while this one is counted
+        uint64_t n = 0;
+        const auto tc = Clock::now();
+        const int rc = cid_fastq_count_kmers(fr, ks, 2, &n);
+        ms_count += ms_since(tc);
+        for (size_t i = 0; i < n_files; ++i) if (pending[i]) --pending[i];
+        if (rc == CID_ERR_UNSUPPORTED) ok = false;
+        else if (rc != CID_OK) die("%s", cid_last_error());
+    }
+    cid_fastq_destroy(fr);
+    if (g_timing) fprintf(stderr, "timing: device front end: waiting for the file reader %.0f ms, push (H2D of the members) %.0f ms, counting %.0f ms\n", ms_read, ms_push, ms_count);
+    return ok;
+}
+
 // nullptr = the file holds lower-case bases: count it on the host
 cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q) {
     cid_kmerset *ks = nullptr;
     CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
+    {
+        std::vector<std::string> fq{f1};
+        if (f2) fq.push_back(*f2);
+        if (k <= 32 && read_id_mt_pe::device_fastq_wanted(fq, fq.size())) {
+            const auto t_dev = Clock::now();
+            if (count_bgzf_on_device(ctx, ks, fq, q)) {
+                CID_TRY(cid_kmerset_finalize(ks, nullptr));
+                if (g_timing) fprintf(stderr, "timing: query k-mers counted through the device front end in %.0f ms\n", ms_since(t_dev));
+                return ks;
+            }
+            cid_kmerset_destroy(ks);   // (a partial count) — the host reads the files again
+            CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
+        }
+    }
     const bool ok = stream_fastq_batches(f1, f2, q, [&](const SeqBatch &sb) { return cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 1); });
     if (!ok) { cid_kmerset_destroy(ks); return nullptr; }
     CID_TRY(cid_kmerset_finalize(ks, nullptr));

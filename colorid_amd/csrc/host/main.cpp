@@ -283,10 +283,20 @@ int cmd_search(int argc, char **argv) {
         return 0;
     }
     if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
-    // gzip decoding of the first query starts now and runs beside GPU start-up and the index load
+    // gzip decoding of the first query starts now and runs beside GPU start-up and the index load; a block-gzip query on one GPU goes
+    // up compressed instead (cid_fastq_count_kmers: its members are read ahead, the k-mer map is counted from text that never leaves HBM)
     if (!a.flags.count("perfect_search") && ends_with(files1[0], "gz")) {
-        LineReader::prefetch(files1[0]);
-        if (!files2.empty()) LineReader::prefetch(files2[0]);
+        std::vector<std::string> fq{files1[0]};
+        if (!files2.empty()) fq.push_back(files2[0]);
+        const bool one_gpu = !a.has("gpus") && !a.has("devices") && !a.has("placement") && !getenv("COLORID_REDUCE");
+        const bool host_kmers = getenv("COLORID_HOST_KMERS") != nullptr;
+        if (one_gpu && !host_kmers && read_id_mt_pe::device_fastq_wanted(fq, fq.size())) {
+            for (const std::string &f : fq)
+                BgzfMemberReader::prefetch(f, read_id_mt_pe::device_fastq_stretch_bytes(0), read_id_mt_pe::device_fastq_host_share(),
+                                           read_id_mt_pe::device_fastq_host_threads(fq.size()));
+        } else {
+            for (const std::string &f : fq) LineReader::prefetch(f);
+        }
     }
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
@@ -304,6 +314,7 @@ int cmd_search(int argc, char **argv) {
     }
     phase_done("search");
     LineReader::drop_prefetched();
+    BgzfMemberReader::drop_prefetched();
     release(gpus, b);
     phase_done("release");
     return 0;

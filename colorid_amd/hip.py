@@ -210,6 +210,10 @@ class KmerSet:
         bases = np.frombuffer(b"".join(seqs), np.uint8) if seqs else np.zeros(0, np.uint8)
         check(self.lib.cid_kmerset_add_seqs(self.h, _p(bases), _p(off), len(seqs), mode))
 
+    def add_seqs_dev(self, d_bases, d_seq_off, n_seqs, max_len, mode=0):
+        """reads already in HBM: device pointers to the bases and to n_seqs + 1 offsets into them"""
+        check(self.lib.cid_kmerset_add_seqs_dev(self.h, vp(d_bases), vp(d_seq_off), n_seqs, max_len, mode))
+
     def finalize(self):
         n = C.c_uint64(0)
         check(self.lib.cid_kmerset_finalize(self.h, C.byref(n)))
@@ -614,6 +618,12 @@ class FastqReader:
         raw = ids.tobytes()
         names = [raw[int(io[r]):int(io[r + 1]) - 1] for r in range(n.value)]
         return names, nk, st, rs, col, cnt
+
+    def count_kmers(self, kmerset, max_pushes=0):
+        """every complete record held adds its reads' k-mers to `kmerset` (search's fastq producers); -> reads taken"""
+        n = C.c_uint64(0)
+        check(self.lib.cid_fastq_count_kmers(self.h, kmerset.h, max_pushes, C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -193,6 +193,9 @@ int cid_readid_stripe_count(cid_ctx *, const cid_index *, const uint8_t *d_bases
 typedef struct cid_kmerset cid_kmerset;
 int cid_kmerset_create(cid_ctx *, uint32_t k_size, cid_kmerset **out);
 int cid_kmerset_add_seqs(cid_kmerset *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode);
+/* the same for reads already in HBM (k_size <= 32): d_seq_off[n_seqs + 1] are offsets into d_bases, no sequence longer than max_len
+ * (<= one segment of windows: reads, not genomes — CID_ERR_UNSUPPORTED otherwise) */
+int cid_kmerset_add_seqs_dev(cid_kmerset *, const uint8_t *d_bases, const uint64_t *d_seq_off, size_t n_seqs, uint64_t max_len, int mode);
 int cid_kmerset_finalize(cid_kmerset *, uint64_t *n_distinct);
 int cid_kmerset_size(const cid_kmerset *, uint64_t *n_distinct);
 int cid_kmerset_count_histogram(const cid_kmerset *, uint32_t *multiplicity, uint64_t *n_kmers, size_t cap, size_t *n_bins);
@@ -412,6 +415,11 @@ int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t 
  *        fetch         n_kmers / status [n_reads], row_start [n_reads + 1] + colours / counts [n_entries] as cid_readid_sparse_fetch
  *                      gives them, id_off [n_reads + 1] and ids [id_bytes]: read r's header line (with its '@'), NUL-terminated,
  *                      at ids + id_off[r].
+ *        count_kmers   the same step with a k-mer set as the sink instead of an index: the whole records pushed so far are masked and
+ *                      packed as for classify, and every read of either file adds its k-mers to `set` (cid_kmerset_add_seqs_dev, mode 1:
+ *                      the fastq producers of `search`, src/kmer.rs:461-510 single-end / :581-655 pairs — the walk over a pair of files
+ *                      ends with the shorter one).  Nothing to fetch.  CID_ERR_UNSUPPORTED: a read holds a lower-case base (its case
+ *                      would have to be kept: count that input through cid_kmerset_add_seqs / on the host) or is longer than a segment.
  *      One cid_fastq per input (pair); it borrows the ctx's stream and scratch: destroy it before the ctx. ---- */
 typedef struct cid_fastq cid_fastq;
 #define CID_FASTQ_LAST 1   /* push flags: the file ends with this push */
@@ -423,6 +431,7 @@ int cid_fastq_push_bgzf(cid_fastq *, int file, const uint8_t *members, size_t n_
 int cid_fastq_push_text(cid_fastq *, int file, const uint8_t *text, size_t n_bytes, int flags);
 int cid_fastq_classify(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
                        uint64_t *n_entries, uint64_t *id_bytes);
+int cid_fastq_count_kmers(cid_fastq *, cid_kmerset *set, int max_pushes, uint64_t *n_reads);
 int cid_fastq_fetch(cid_fastq *, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,
                     char *ids);
 void cid_fastq_destroy(cid_fastq *);

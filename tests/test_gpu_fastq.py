@@ -258,3 +258,107 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
             assert outs[(tag, extra)][0] == host[0] and outs[(tag, extra)][1] == host[1], (tag, extra)
             assert "device front end" in outs[(tag, extra)][2], tag      # (the timing line of the path that ran)
     assert "accept" in outs[("dev", 0)][0]
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("q", [0, 15])
+def test_count_kmers_equals_the_oracles_fastq_maps(orc, hip_ctx, world, paired, q):
+    """cid_fastq_count_kmers — `search`'s fastq k-mer maps (kmer.rs:461-510 single-end, :581-655 pairs) from text on the device: records
+    cut anywhere by pushes and by block-gzip members, \\r\\n in the second file, which is shorter (the walk ends with it), quality
+    masking, reads with N, an empty read; the set equals the oracle's map filled read by read (kmerize_fq_read).  A lower-case base is
+    refused (its case would have to be kept) and so is a read longer than a segment."""
+    import colorid_amd
+    _, _, genomes = world
+    k = 21
+    rng = np.random.default_rng(40 + q + int(paired))
+    r1 = synth_fastq_records(np.random.default_rng(9 + q), genomes, 1500, 150, mate=0, lower_rate=0.0)
+    r2 = synth_fastq_records(np.random.default_rng(9 + q), genomes, 1500, 150, mate=1, lower_rate=0.0)
+    r1.insert(3, (b"empty", b"", b""))
+    r2.insert(3, (b"empty", b"", b""))
+    texts = [fastq_text(r1)] + ([fastq_text(r2[:1400], b"\r\n", False)] if paired else [])
+    recs = [line_loop_records(t) for t in texts]
+    n = min(len(r) for r in recs)
+    want = orc.Kmers(k)
+    for i in range(n):
+        for r in recs:
+            want.kmerize_fq_read(r[i][1], r[i][2], q)
+    want = want.as_dict()
+    assert len(want) > 20_000
+    for how in ("text", "bgzf"):
+        fr = colorid_amd.FastqReader(hip_ctx, len(texts), q)
+        ks = colorid_amd.KmerSet(hip_ctx, k)
+        taken = 0
+        if how == "text":
+            cuts = [sorted(rng.integers(0, len(t), 6).tolist()) + [len(t)] for t in texts]
+            pos = [0] * len(texts)
+            for step in range(7):
+                for f, t in enumerate(texts):
+                    fr.push_text(f, t[pos[f]:cuts[f][step]], last=(step == 6)); pos[f] = cuts[f][step]
+                if step % 2 == 1 or step == 6:
+                    taken += fr.count_kmers(ks)
+        else:
+            for f, t in enumerate(texts):
+                members, lens, p = [], [], 0
+                while p < len(t):
+                    m = int(rng.choice([300, 5000, 30000, 65536]))
+                    members.append(bgzf_member(t[p:p + m], level=int(rng.integers(1, 10)))); lens.append(len(t[p:p + m])); p += m
+                half = len(members) // 2
+                fr.push_bgzf(f, members[:half], lens[:half])
+                fr.push_bgzf(f, members[half:], lens[half:], last=True)
+            taken += fr.count_kmers(ks, max_pushes=1)
+            taken += fr.count_kmers(ks)
+        assert taken == n
+        ks.finalize()
+        got = ks.as_dict()
+        assert got == want, (how, len(got), len(want))
+        fr.close()
+    fr = colorid_amd.FastqReader(hip_ctx, 1, q)
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    fr.push_text(0, b"@r\n" + genomes[0][:100] + b"acgt" + genomes[0][104:150] + b"\n+\n" + b"I" * 150 + b"\n", last=True)
+    with pytest.raises(colorid_amd.CidError) as ei:
+        fr.count_kmers(ks)
+    assert ei.value.code == -4 and "lower-case" in str(ei.value)
+    fr.close()
+    fr = colorid_amd.FastqReader(hip_ctx, 1, 0)
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    long_read = (genomes[1] * 3)[:9000]
+    fr.push_text(0, b"@long\n" + long_read + b"\n+\n" + b"I" * 9000 + b"\n", last=True)
+    with pytest.raises(colorid_amd.CidError) as ei:
+        fr.count_kmers(ks)
+    assert ei.value.code == -4
+    fr.close()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_search_counts_block_gzip_queries_on_the_device(orc, tmp_path, paired):
+    """`colorid search` with a block-gzip fastq query: the k-mer map comes from the device front end (cid_fastq_count_kmers) and the
+    report equals the host front end's (COLORID_DEVICE_FASTQ=0), default report and -g, with and without the host inflating a share."""
+    import os
+    import subprocess
+
+    from test_gpu_cli import BIN, PHAGES, REFS
+    tsv = tmp_path / "ref_file.txt"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES))
+    pre = str(tmp_path / "phage")
+    p = subprocess.run([BIN, "build", "-s", "750000", "-n", "4", "-k", "27", "-b", pre, "-r", str(tsv)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    genomes = [b"".join(orc.read_fasta(os.path.join(REFS, n + ".fasta"))) for n in PHAGES]
+    rng = np.random.default_rng(18)
+    r1 = synth_fastq_records(np.random.default_rng(31), genomes[:2], 9000, 150, mate=0, lower_rate=0.0)
+    r2 = synth_fastq_records(np.random.default_rng(31), genomes[:2], 9000, 150, mate=1, lower_rate=0.0)
+    f1, f2 = str(tmp_path / "q_1.fastq.gz"), str(tmp_path / "q_2.fastq.gz")
+    _write_bgzf(f1, fastq_text(r1), rng)
+    _write_bgzf(f2, fastq_text(r2[:8800], b"\r\n", False), rng)
+    q = [f1, f2] if paired else [f1]
+    outs = {}
+    for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {}), ("dev_small", {"COLORID_DEVICE_FASTQ_MB": "1"}),
+                     ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ_HOST_SHARE": "0"})):
+        for extra in (["-f", "1", "-p", "0.01"], ["-g", "-f", "0", "-p", "0.3"], ["-Q", "0", "-f", "2", "-p", "0.01"]):
+            p = subprocess.run([BIN, "search", "-b", pre + ".bxi", "-q", q[0], *(["-r", q[1]] if paired else []), *extra], capture_output=True, text=True,
+                               env=dict(os.environ, COLORID_TIMING="1", **env))
+            assert p.returncode == 0, p.stderr[-2000:]
+            assert ("through the device front end" in p.stderr) == (tag != "host"), (tag, p.stderr[-1500:])
+            outs[(tag, tuple(extra))] = sorted(p.stdout.splitlines())
+    for key, rows in outs.items():
+        assert rows == outs[("host", key[1])], key
+    assert any("Listeria_phage_B021" in r for r in outs[("dev", ("-f", "1", "-p", "0.01"))])
