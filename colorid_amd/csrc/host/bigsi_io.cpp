@@ -296,7 +296,11 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
     auto look_ahead = [&](std::map<std::string, std::vector<std::string>>::const_iterator it) {
         if (it == refs.end() || !gpu_counting_enabled(k)) return;
         const std::vector<std::string> &v = it->second;
-        if (gz_of(v)) for (const std::string &f : v) LineReader::prefetch(f);
+        if (gz_of(v) && k <= 32 && read_id_mt_pe::device_fastq_wanted(v, v.size())) {   // block gzip: the members go up compressed (count_fastq_gpu)
+            for (const std::string &f : v)
+                BgzfMemberReader::prefetch(f, read_id_mt_pe::device_fastq_stretch_bytes(0), read_id_mt_pe::device_fastq_host_share(),
+                                           read_id_mt_pe::device_fastq_host_threads(v.size()));
+        } else if (gz_of(v)) for (const std::string &f : v) LineReader::prefetch(f);
         else { const std::string path = v[0]; ahead = std::async(std::launch::async, [path] { return read_fasta(path); }); }
     };
     look_ahead(refs.begin());
@@ -342,6 +346,7 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
         ++colour;
     }
     LineReader::drop_prefetched();
+    BgzfMemberReader::drop_prefetched();
     return b;
 }
 

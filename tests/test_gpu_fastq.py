@@ -362,3 +362,31 @@ def test_cli_search_counts_block_gzip_queries_on_the_device(orc, tmp_path, paire
     for key, rows in outs.items():
         assert rows == outs[("host", key[1])], key
     assert any("Listeria_phage_B021" in r for r in outs[("dev", ("-f", "1", "-p", "0.01"))])
+
+
+def test_cli_build_counts_block_gzip_accessions_on_the_device(orc, tmp_path):
+    """`colorid build` with block-gzip fastq accessions (paired, single, next to a FASTA one; auto cutoff and -f 2): the accessions'
+    k-mer maps come from the device front end and the .bxi is byte-identical to the oracle's and to the host front end's."""
+    import os
+    import subprocess
+
+    from test_gpu_cli import BIN, PHAGES, REFS
+    genome = b"".join(orc.read_fasta(os.path.join(REFS, PHAGES[0] + ".fasta")))[:4000]
+    rng = np.random.default_rng(77)
+    r1 = synth_fastq_records(np.random.default_rng(3), [genome], 2500, 120, mate=0, lower_rate=0.0)
+    r2 = synth_fastq_records(np.random.default_rng(3), [genome], 2500, 120, mate=1, lower_rate=0.0)
+    f1, f2, f3 = str(tmp_path / "a_1.fastq.gz"), str(tmp_path / "a_2.fastq.gz"), str(tmp_path / "b.fastq.gz")
+    _write_bgzf(f1, fastq_text(r1), rng); _write_bgzf(f2, fastq_text(r2), rng); _write_bgzf(f3, fastq_text(r1[:1500]), rng)
+    tsv = tmp_path / "refs.tsv"
+    tsv.write_text(f"pe_sample\t{f1}\t{f2}\nse_sample\t{f3}\nphage\t{os.path.join(REFS, PHAGES[1] + '.fasta')}\n")
+    for flt in ([], ["-f", "2"]):
+        oix = orc.Index.build_single(str(tsv), 200003, 3, 21, 15, int(flt[1]) if flt else -1)
+        ref = str(tmp_path / ("oracle" + "".join(flt) + ".bxi"))
+        oix.save(ref)
+        for tag, env in (("dev", {}), ("host", {"COLORID_DEVICE_FASTQ": "0"})):
+            pre = str(tmp_path / (tag + "".join(flt)))
+            p = subprocess.run([BIN, "build", "-s", "200003", "-n", "3", "-k", "21", "-b", pre, "-r", str(tsv), *flt], capture_output=True, text=True,
+                               env=dict(os.environ, COLORID_TIMING="1", **env))
+            assert p.returncode == 0, p.stderr[-2000:]
+            assert ("through the device front end" in p.stderr) == (tag == "dev"), p.stderr[-1500:]
+            assert open(pre + ".bxi", "rb").read() == open(ref, "rb").read(), (tag, flt)
