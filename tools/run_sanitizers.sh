@@ -27,6 +27,17 @@ def fq(path, n, mate):
             s=g[p:p+L] if mate==0 else g[p+100:p+100+L]
             f.write(b"@r%d/%d\n"%(i,mate+1)+s+b"\n+\n"+b"I"*len(s)+b"\n")
 fq(f"{W}/r_1.fastq.gz",60000,0); fq(f"{W}/r_2.fastq.gz",60000,1)
+# the same reads as block-gzip files (round 3: the device FASTQ front end of read_id / search / build takes these)
+import struct, zlib
+def bgzf(src, dst):
+    text = gzip.open(src, "rb").read()
+    with open(dst, "wb") as f:
+        for i in list(range(0, len(text), 65280)) + [None]:
+            c = b"" if i is None else text[i:i + 65280]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15); body = co.compress(c) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) + body +
+                    struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c)))
+bgzf(f"{W}/r_1.fastq.gz", f"{W}/b_1.fastq.gz"); bgzf(f"{W}/r_2.fastq.gz", f"{W}/b_2.fastq.gz")
 PY
 for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
   echo "=== $B"
@@ -45,6 +56,15 @@ for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
   $B search -b $W/ix130.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 --devices 0,0,0 --placement striped > $W/s4.out 2> $W/s4.err; echo "search striped 3 ranks rc=$?"; grep -c . $W/s4.out; sort $W/s4a.out > $W/s4a.sorted; sort $W/s4.out | cmp - $W/s4a.sorted && echo "same rows as one GPU"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/s4.err | head -5
   $B read_id -b $W/ix130.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid4a -c 5000 > $W/r4a.out 2> $W/r4a.err; echo "read_id 130 one GPU rc=$?"
   $B read_id -b $W/ix130.bxi -q $W/r_1.fastq.gz $W/r_2.fastq.gz -n $W/rid4 -c 5000 --devices 0,0 --placement striped > $W/r4.out 2> $W/r4.err; echo "read_id striped 2 ranks rc=$?"; cmp $W/rid4a_reads.txt $W/rid4_reads.txt && echo "same rows as one GPU"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/r4.err | head -5
+  # round 3: block-gzip input through the device front end (reader thread + its inflating pool, pinned buffer pool, pushes one stretch ahead, the
+  # poll threads behind it), small stretches so that several are in flight; search's and build's k-mer maps through the same reader
+  export COLORID_DEVICE_FASTQ_MB=1
+  $B read_id -b $W/ix.bxi -q $W/b_1.fastq.gz -n $W/ridb1 -c 777 > $W/rb1.out 2> $W/rb1.err; echo "read_id SE block gzip rc=$?"; cmp $W/rid1_reads.txt $W/ridb1_reads.txt && echo "same rows as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rb1.err | head -5
+  COLORID_DEVICE_FASTQ_AHEAD=3 $B read_id -b $W/ix.bxi -q $W/b_1.fastq.gz $W/b_2.fastq.gz -n $W/ridb -c 5000 > $W/rb.out 2> $W/rb.err; echo "read_id PE block gzip rc=$?"; cmp $W/rid_reads.txt $W/ridb_reads.txt && echo "same rows as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rb.err | head -5
+  $B search -b $W/ix.bxi -q $W/b_1.fastq.gz -r $W/b_2.fastq.gz -f 0 -p 0.01 > $W/sb.out 2> $W/sb.err; echo "search block gzip rc=$?"; cut -f2- $W/sb.out | sort > $W/sb.sorted; $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 2> /dev/null | cut -f2- | sort | cmp - $W/sb.sorted && echo "same report as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/sb.err | head -5
+  printf "reads\t$W/b_1.fastq.gz\t$W/b_2.fastq.gz\ngenome0\t$W/g0.fasta\n" > $W/refs_fq.tsv
+  $B build -s 2000000 -n 3 -k 27 -b $W/ixfq -r $W/refs_fq.tsv > $W/bfq.out 2> $W/bfq.err; echo "build from block gzip rc=$?"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/bfq.err | head -5
+  unset COLORID_DEVICE_FASTQ_MB
   $B hashcheck -b $W/ix.bxi -r $W/refs.tsv > $W/h.out 2> $W/h.err; echo "hashcheck rc=$?"; grep verdict $W/h.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/h.err | head -5
 done
 # TSan: the HIP/HSA runtime is not instrumented and reports races between its own threads (objects it allocates inside an API call
