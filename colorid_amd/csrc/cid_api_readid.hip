@@ -13,7 +13,8 @@ extern "C" {
 // LDS layout of k_readid (bytes_kernel = false) or k_readid_bytes for reads of at most max_bytes bases / max_win windows;
 // returns the bytes one wave needs (the kernels carve the same regions in the same order)
 static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                            bool bytes_kernel, cid::ReadIdParams &p, bool packed_table = false) {
+                            bool bytes_kernel, cid::ReadIdParams &p, int slot_kind = 0 /* 0: key + index, 1: one u64, 2: one u32 position */) {
+    const bool packed_table = slot_kind == 1;
     p = cid::ReadIdParams{};
     p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
     p.mod = ix->mod;
@@ -35,6 +36,7 @@ static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t sta
         p.idx_bits = ib;
         slot_bytes = 8;
     }
+    if (slot_kind == 2) { p.slot4 = 1; slot_bytes = 4; }
     const size_t chunk_rows = 4ull * cid::kWave * ix->n_hash;                     // one chunk's row numbers
     const size_t rall_bytes = wide ? 0 : 4ull * p.win_cap * ix->n_hash;           // rows of the read's distinct k-mers (wide rows search chunk by chunk)
     // k_readid keeps no byte image of the read, but the raw bases of the NEXT one (LDS-DMA, one 16-byte piece per lane)
@@ -72,8 +74,8 @@ constexpr size_t kLdsReadBytesMax = kLdsBytes / 2;
 static int readid_params(const cid_ctx *c, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
                          bool bytes_kernel, cid::ReadIdParams &p, int &waves, bool striped = false) {
     size_t wave_bytes = 0, best = 0;
-    auto choose = [&](bool packed_table) {
-        wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, p, packed_table);
+    auto choose = [&](int slot_kind) {
+        wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, p, slot_kind);
         // waves per workgroup: whatever puts the most waves on a CU (160 KiB of LDS, at most 8 workgroups of this size... 32 waves)
         waves = 1;
         best = 0;
@@ -90,11 +92,15 @@ static int readid_params(const cid_ctx *c, const cid_index *ix, uint32_t stride_
     // k <= 27: 10.6 -> 10.1 ms per million pairs, tools/exp_readid_table.py)
     const bool can_pack = !bytes_kernel && c->tune.readid_packed_table && ix->rs <= 128 && !ix->m_size && ix->k <= 31 &&
                           ((ix->mod.flags >> 8) & 0xFFu) == CID_HASH_XXH3_V08 && !striped;
-    choose(false);
-    if (best < 24 && can_pack) {   // (where six waves per SIMD fit anyway the 12-byte slots are marginally faster: 6.02 vs 6.07 ms single-end)
+    // ... and where the code leaves no room for the index (k = 28..32) the slot holds a position only (4 bytes; the probe reads the k-mer back)
+    const bool can_slot4 = !bytes_kernel && c->tune.readid_packed_table && ix->rs <= 128 && !ix->m_size && ix->k <= 32 &&
+                           ((ix->mod.flags >> 8) & 0xFFu) == CID_HASH_XXH3_V08 && !striped;
+    choose(0);
+    if (best < 24 && (can_pack || can_slot4)) {   // (where six waves per SIMD fit anyway the 12-byte slots are marginally faster: 6.02 vs 6.07 ms single-end)
         const size_t classic = best;
-        choose(true);
-        if (best <= classic || best <= 20) choose(false);   // worth it only with more waves than the 96-VGPR (5 per SIMD) build runs
+        if (can_pack) choose(1);
+        if ((!can_pack || wave_bytes == ~(size_t)0 || best < 24) && can_slot4) choose(2);
+        if (best <= classic || best <= 20) choose(0);   // worth it only with more waves than the 96-VGPR (5 per SIMD) build runs
     }
     if (wave_bytes > kLdsBytes)
         return fail(CID_ERR_UNSUPPORTED, "a read(-pair) of %llu bases / %llu windows needs %zu B of LDS per wave (> 160 KiB): "

@@ -77,6 +77,7 @@ struct ReadIdParams {
     uint32_t hist_pad;          // n_colors+1 rounded up to a multiple of 4
     uint32_t table_slots;       // power of two >= 1.5 x win_cap: the packed path's per-read k-mer set
     uint32_t idx_bits;          // > 0: one u64 per slot, code << idx_bits | first window index (2k + idx_bits <= 63; k_readid<..., PACKED>)
+    uint32_t slot4;             // > 0: one u32 per slot, the earliest position of a window holding the slot's k-mer (k_readid<..., SLOT4>)
     uint32_t stage_bytes;       // k_readid: LDS bytes per wave for the next read's raw bases (multiple of 16, <= 1024; 0 = no read-ahead)
     uint32_t wave_bytes;        // LDS bytes per wave
     uint32_t reads_per_block;

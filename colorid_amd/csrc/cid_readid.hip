@@ -210,8 +210,13 @@ __device__ __forceinline__ void readid_finish_read(VCount<PLANES, NARROW> &vc, u
 // A read with a lower-case base (its case must be kept) is appended to p.redo_list for k_readid_bytes.
 // PACKED (p.idx_bits > 0; 2k + idx_bits <= 63): a table slot is ONE u64, canonical code << idx_bits | smallest window index — 8
 // instead of 12 bytes per slot, which is what lets paired 150-bp reads at k = 21 keep six waves per SIMD.
-template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE, bool STRIPED = false, bool PACKED = false>
+// SLOT4 (p.slot4): a table slot is ONE u32 — the smallest POSITION (in bases from the aligned start of the read: it grows with the window
+// index) of a window holding the slot's k-mer; the code itself is not stored but read back from the packed bases when a probe meets an
+// occupied slot.  4 instead of 12 bytes per slot for the k-mers whose codes leave no room for an index beside them (k = 28..32): read pairs
+// at those k keep six waves per SIMD.
+template <int LOG_LPR, bool NARROW, bool WIDE, bool MINI, bool DENSE, bool STRIPED = false, bool PACKED = false, bool SLOT4 = false>
 __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p) {
+    static_assert(!(PACKED && SLOT4) && !(SLOT4 && (MINI || WIDE || STRIPED)), "one slot layout; position slots: whole k-mers, narrow rows, whole index");
     constexpr int PLANES = DENSE ? kReadPlanesDense : kReadPlanes;
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr int LPR = 1 << LOG_LPR;
@@ -231,7 +236,8 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
     unsigned long long *t_key = reinterpret_cast<unsigned long long *>(rall + (WIDE ? 0u : rcap * n));   // table_slots
     uint32_t *t_idx = reinterpret_cast<uint32_t *>(t_key + p.table_slots);     // table_slots
     uint32_t *hist = SEPARATE ? ridx + (WIDE ? kWave * n : 0u) : reinterpret_cast<uint32_t *>(t_key);   // hist_pad; else: shares the table's region
-    constexpr uint32_t SLOT = PACKED ? 8u : 12u;
+    constexpr uint32_t SLOT = SLOT4 ? 4u : PACKED ? 8u : 12u;
+    uint32_t *t_pos = reinterpret_cast<uint32_t *>(t_key);                     // SLOT4: table_slots positions
     const uint32_t region = SEPARATE ? SLOT * p.table_slots : (SLOT * p.table_slots > 4u * p.hist_pad ? SLOT * p.table_slots : 4u * p.hist_pad);
     uint32_t *s_pack = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(t_key) + region);   // bases_cap/16 + 4 dwords, 16 bases each
     uint32_t *s_bad = s_pack + (p.bases_cap / 16 + 4);                         // bases_cap/32 + 4 dwords, 1 bit per base
@@ -345,7 +351,11 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 staged = true;
             }
         }
-        for (uint32_t t = lane; t < p.table_slots; t += kWave) { t_key[t] = ~0ull; if constexpr (!PACKED) t_idx[t] = ~0u; }
+        if constexpr (SLOT4) {
+            for (uint32_t t = lane; t < p.table_slots; t += kWave) t_pos[t] = ~0u;
+        } else {
+            for (uint32_t t = lane; t < p.table_slots; t += kWave) { t_key[t] = ~0ull; if constexpr (!PACKED) t_idx[t] = ~0u; }
+        }
         wave_lds_fence();
 
         uint32_t nd = 0;       // distinct k-mers so far == the reference's `counter`
@@ -406,7 +416,18 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                 }
                 // exact set with first-occurrence order: slot key = canonical code, slot value = smallest window index
                 uint32_t slot = (uint32_t)((msb * 0x9E3779B97F4A7C15ull) >> 40) & tmask;
-                if constexpr (PACKED) {
+                if constexpr (SLOT4) {
+                    if (valid) {
+                        while (true) {
+                            const uint32_t old = atomicCAS(&t_pos[slot], ~0u, pos);
+                            if (old == ~0u) break;
+                            uint64_t other = 0;   // the k-mer of the window that sits there
+                            canonical_code(bits_at(s_pack, 2 * old, 2 * k), k, &other);
+                            if (other == msb) { atomicMin(&t_pos[slot], pos); break; }   // same k-mer: keep the earlier window
+                            slot = (slot + 1) & tmask;
+                        }
+                    }
+                } else if constexpr (PACKED) {
                     if (valid) {
                         const unsigned long long mine = ((unsigned long long)msb << p.idx_bits) | (unsigned long long)wi;
                         while (true) {
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(kBlock, DENSE ? 6 : 5) void k_readid(ReadIdParams p
                     atomicMin(&t_idx[slot], wbase + wi);
                 }
                 wave_lds_fence();
-                const bool distinct = valid && (PACKED ? (uint32_t)(t_key[slot] & ((1ull << p.idx_bits) - 1ull)) == wi : t_idx[slot] == wbase + wi);
+                const bool distinct = valid && (SLOT4 ? t_pos[slot] == pos : PACKED ? (uint32_t)(t_key[slot] & ((1ull << p.idx_bits) - 1ull)) == wi : t_idx[slot] == wbase + wi);
                 const uint64_t dmask = __ballot(distinct);
                 if (distinct) {   // WIDE: this chunk's slot; else the read's list at the k-mer's order index
                     uint32_t *dst = WIDE ? ridx + lane : rall + nd + (uint32_t)__popcll(dmask & lt_mask);
@@ -757,6 +778,20 @@ static hipError_t launch_readid_packed_striped(const ReadIdParams &p, int wpb, i
 }
 
 // the one-u64-per-slot set (p.idx_bits > 0): only built for the six-waves-per-SIMD kernel of whole k-mer indexes
+static hipError_t launch_readid_slot4(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
+    if (p.rs > 128) return hipErrorInvalidValue;
+    if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, false, true, false, false, true>, p, wpb, grid, stream);
+    switch (log2u(p.rs / 2)) {
+    case 0: return launch_readid_one(k_readid<0, false, false, false, true, false, false, true>, p, wpb, grid, stream);
+    case 1: return launch_readid_one(k_readid<1, false, false, false, true, false, false, true>, p, wpb, grid, stream);
+    case 2: return launch_readid_one(k_readid<2, false, false, false, true, false, false, true>, p, wpb, grid, stream);
+    case 3: return launch_readid_one(k_readid<3, false, false, false, true, false, false, true>, p, wpb, grid, stream);
+    case 4: return launch_readid_one(k_readid<4, false, false, false, true, false, false, true>, p, wpb, grid, stream);
+    case 5: return launch_readid_one(k_readid<5, false, false, false, true, false, false, true>, p, wpb, grid, stream);
+    case 6: return launch_readid_one(k_readid<6, false, false, false, true, false, false, true>, p, wpb, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
 static hipError_t launch_readid_packed_table(const ReadIdParams &p, int wpb, int grid, hipStream_t stream) {
     if (p.rs > 128) return hipErrorInvalidValue;
     if (p.rs == 1) return launch_readid_one(k_readid<0, true, false, false, true, false, true>, p, wpb, grid, stream);
@@ -799,6 +834,7 @@ hipError_t launch_readid(const ReadIdParams &p, int waves_per_block, hipStream_t
     const bool dense = ((160u * 1024u) / ((size_t)waves_per_block * p.wave_bytes)) * (size_t)waves_per_block > 20 &&
                        ((p.mod.flags >> 8) & 0xFFu) == kHashV08;
     // (the host lays the 8-byte slots out only then)
+    if (p.slot4) return dense && !p.m_size ? launch_readid_slot4(p, waves_per_block, grid, stream) : hipErrorInvalidValue;
     if (p.idx_bits) return dense && !p.m_size ? launch_readid_packed_table(p, waves_per_block, grid, stream) : hipErrorInvalidValue;
     if (p.m_size)
         return dense ? launch_readid_packed<true, true>(p, waves_per_block, grid, stream)

@@ -362,7 +362,8 @@ int cid_group_stripes_readid_count_sparse(cid_group *, cid_index *const *stripes
  * the ctx is made).  None of them changes a result.  Unknown names give CID_ERR_INVALID:
  *   "search_unroll"        1/2    k_search_count on 64- and 128-byte rows: sub-passes whose row loads are issued together (default 2)
  *                                 [CID_SEARCH_UNROLL]
- *   "readid_packed_table"  0/1    k_readid: 8-byte k-mer-set slots where they buy a sixth wave per SIMD (default 1) [CID_READID_PACKED_TABLE]
+ *   "readid_packed_table"  0/1    k_readid: 8-byte (k <= 27 or so) or 4-byte (position only) k-mer-set slots where they buy a sixth wave per SIMD;
+ *                                 0 keeps the 12-byte slots (default 1) [CID_READID_PACKED_TABLE]
  *   "readid_blocks_per_cu" 1..4096  k_readid: a batch is cut into about this many workgroups per CU (default 64)
  *   "order_bits"           0..32  cid_kmerset_order_for_index / cid_order_codes_for_index_dev group by this many leading bits of the
  *                                 first row's position (0 = by its exact 128-byte line, the default)

@@ -295,10 +295,12 @@ def test_readid_more_than_two_mates(orc, phage):
 
 
 @pytest.mark.parametrize("packed", [0, 1])
-@pytest.mark.parametrize("k,n_colors", [(21, 256), (27, 100), (9, 300)])
+@pytest.mark.parametrize("k,n_colors", [(21, 256), (27, 100), (9, 300), (31, 256), (29, 64), (32, 130)])
 def test_readid_set_slot_layouts_are_bit_exact(orc, hip_ctx, packed, k, n_colors):
     """k_readid's per-read k-mer set with 12-byte slots and with one u64 per slot (code << idx_bits | first window index; taken for
-    read pairs whose 12-byte table would cost the sixth wave per SIMD; cid_ctx_tune "readid_packed_table"): paired 150-bp reads with
+    read pairs whose 12-byte table would cost the sixth wave per SIMD; at k = 28..32, where the code leaves no room for the index, one u32 per slot:
+    the earliest position of a window holding the k-mer, the code read back from the packed bases on a probe; cid_ctx_tune "readid_packed_table" = 0
+    keeps the 12-byte slots): paired 150-bp reads with
     repeats (the same k-mer in both mates: the earlier window must win), N runs, short mates — against the oracle."""
     from colorid_amd._lib import check as cid_check
     rng = np.random.default_rng(k * 100 + n_colors + packed)

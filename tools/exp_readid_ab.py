@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """cid_readid_count_dev of TWO BUILDS of the library in one process (same box, same reads, same index contents), alternating:
 configs[2]'s shape (m = 30 M, n = 2, 256 colours, 1 M x 150 bp), single-end and paired.  Reports must be identical.
+CAVEAT: each build searches its OWN copy of the index, and where an allocation lands in HBM moves k_readid by up to +-5 % (two copies of
+ONE build measured 9.15 against 9.65 ms): differences below that are not evidence — switch inside one build with cid_ctx_tune where a switch
+exists (tools/exp_readid_tune.py: same index, same context).
 usage: python tools/exp_readid_ab.py OTHER.so [out.jsonl]     (OTHER.so e.g. a build of an earlier commit; relative to the repo root)
 env EXP_CASES=k:len[:mates],...   EXP_TUNE_NEW=name=value,...  (cid_ctx_tune settings of the current build)"""
 import json, math, os, sys
