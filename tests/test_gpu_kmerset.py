@@ -80,6 +80,56 @@ def test_fastq_mode_and_lowercase_refusal(orc, hip_ctx):
         colorid_amd.KmerSet(hip_ctx, 129)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_add_seqs_dev_equals_add_seqs(orc, hip_ctx, mode):
+    """cid_kmerset_add_seqs_dev: reads already in HBM (the FASTQ front end's packed batch) give the set the host-pointer call gives —
+    ragged reads, reads shorter than k, empty ones, N runs, several calls growing the window buffer; refusals: a sequence longer than a
+    segment, a byte-string set (k > 32), a lower-case base in fastq mode."""
+    import torch
+
+    import colorid_amd
+    rng = np.random.default_rng(31 + mode)
+    k = 27
+    seqs = [rand_seq(rng, int(rng.integers(0, 400)), b"ACGTN" if i % 5 == 0 else b"ACGT") for i in range(4000)] + [b"", b"ACGT" * 5]
+    if mode == 0:
+        seqs += [rand_seq(rng, 120, b"ACGTacgt") for _ in range(50)]          # FASTA mode upper-cases
+    a = colorid_amd.KmerSet(hip_ctx, k)
+    b = colorid_amd.KmerSet(hip_ctx, k)
+    dev = torch.device("cuda", 0)
+    for part in (seqs[:1500], seqs[1500:1501], seqs[1501:]):
+        a.add_seqs(part, mode)
+        off = np.zeros(len(part) + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in part])
+        d_bases = torch.from_numpy(np.frombuffer(b"".join(part) + b"\0", np.uint8).copy()).to(dev)
+        d_off = torch.from_numpy(off).to(dev)
+        torch.cuda.synchronize()
+        b.add_seqs_dev(d_bases.data_ptr(), d_off.data_ptr(), len(part), max(len(x) for x in part), mode)
+    a.finalize(); b.finalize()
+    assert len(a) == len(b) > 100_000 and a.as_dict() == b.as_dict()
+    c = colorid_amd.KmerSet(hip_ctx, k)
+    long_seq = rand_seq(rng, 5000, b"ACGT")
+    d_bases = torch.from_numpy(np.frombuffer(long_seq, np.uint8).copy()).to(dev)
+    d_off = torch.tensor([0, 5000], dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    with pytest.raises(colorid_amd.CidError) as ei:
+        c.add_seqs_dev(d_bases.data_ptr(), d_off.data_ptr(), 1, 5000, mode)
+    assert ei.value.code == -4
+    if mode == 1:
+        low = rand_seq(rng, 150, b"acgt")
+        d_bases = torch.from_numpy(np.frombuffer(low, np.uint8).copy()).to(dev)
+        d_off = torch.tensor([0, 150], dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        with pytest.raises(colorid_amd.CidError) as ei:
+            c.add_seqs_dev(d_bases.data_ptr(), d_off.data_ptr(), 1, 150, 1)
+        assert ei.value.code == -4 and "lower-case" in str(ei.value)
+    g = colorid_amd.KmerSet(hip_ctx, 40)
+    with pytest.raises(colorid_amd.CidError) as ei:
+        g.add_seqs_dev(d_bases.data_ptr(), d_off.data_ptr(), 1, 150, mode)
+    assert ei.value.code == -4
+    for s_ in (a, b, c, g):
+        s_.close()
+
+
 @pytest.mark.parametrize("k", [33, 40, 48, 49, 64, 100, 128])
 def test_byte_string_sets_k_above_32(orc, hip_ctx, k):
     """k > 32 (src/kmer.rs:87-125 and :461-510 at k >= 33): keys are byte strings — sorted on a 4-bit-per-base image, run-length

@@ -367,3 +367,24 @@ def test_readid_single_end_edge_reads(orc, hip_ctx, k, n_colors, read_len):
         check(oix, hx, reads, d, S)
     check(oix, hx, reads[1:], 1, 3)                                     # every read at another offset
     hx.close()
+
+
+def test_readid_grid_cut_does_not_change_rows(orc, phage, hip_ctx):
+    """cid_ctx_tune "readid_blocks_per_cu": however a batch is cut into workgroups (one read per wave ... the whole batch in a few
+    workgroups), the rows are the same — the offsets a wave fetches 64 reads at a time and the bases it asks for one read ahead must
+    follow the cut.  Values outside 1..4096 and unknown names are refused."""
+    import colorid_amd
+    oix, hx, genomes = phage
+    rng = np.random.default_rng(5)
+    reads = sample_reads(orc, rng, genomes, 700, 150, False) + sample_reads(orc, rng, genomes, 300, 150, True)
+    try:
+        for bpc in (1, 3, 64, 4096):
+            hip_ctx.tune("readid_blocks_per_cu", bpc)
+            check(oix, hx, reads, 1, 3)
+        for bad in (0, 4097, -1):
+            with pytest.raises(colorid_amd.CidError):
+                hip_ctx.tune("readid_blocks_per_cu", bad)
+        with pytest.raises(colorid_amd.CidError):
+            hip_ctx.tune("no_such_switch", 1)
+    finally:
+        hip_ctx.tune("readid_blocks_per_cu", 64)
