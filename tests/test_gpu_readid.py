@@ -388,3 +388,44 @@ def test_readid_grid_cut_does_not_change_rows(orc, phage, hip_ctx):
             hip_ctx.tune("no_such_switch", 1)
     finally:
         hip_ctx.tune("readid_blocks_per_cu", 64)
+
+
+def test_readid_more_than_64_reads_per_wave(orc, hip_ctx):
+    """A wave fetches its reads' offsets 64 reads at a time (one lane each) and the next read's bases one read ahead: 1 800-base reads
+    (n = 2, k = 21: 66 KB of LDS per wave) leave two waves per workgroup, and 40 000 of them cut into one workgroup per CU give each
+    wave 78 reads — the second fetch, and the read-ahead across it.  Rows equal those of the finest cut (one fetch per wave), and the
+    oracle's on a sample."""
+    rng = np.random.default_rng(12)
+    k, n_colors = 21, 70
+    genomes = [bytes(rng.choice(list(b"ACGT"), size=30_000).astype(np.uint8)) for _ in range(3)]
+    oix = orc.Index(200_003, 2, k, n_colors)
+    for c in range(n_colors):
+        oix.set_color(c, f"a{c}", 500)
+    for gi, gen in enumerate(genomes[:2]):
+        km = orc.Kmers(k)
+        km.kmerize_vector(gen, 1)
+        for key in km.keys():
+            oix.insert(gi, key.tobytes())
+            oix.insert(n_colors - 1 - gi, key.tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    g = b"".join(genomes)
+    n = 40_000
+    starts = rng.integers(0, len(g) - 1800, n)
+    lens = np.where(rng.random(n) < 0.7, 1800, rng.integers(k, 1800, n))
+    reads = [[g[int(s):int(s) + int(L)]] for s, L in zip(starts, lens)]
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    try:
+        hip_ctx.tune("readid_blocks_per_cu", 4096)
+        fine = hx.readid_count(bases, seq_off, read_seq0, 1, 3)
+        hip_ctx.tune("readid_blocks_per_cu", 1)
+        coarse = hx.readid_count(bases, seq_off, read_seq0, 1, 3)
+    finally:
+        hip_ctx.tune("readid_blocks_per_cu", 64)
+    for a, b in zip(fine, coarse):
+        assert np.array_equal(a, b)
+    sample = sorted(rng.choice(n, 600, replace=False).tolist())
+    sb, so, sr = pack_reads([reads[i] for i in sample])
+    want = oix.readid_counts(sb, so, sr, 1, 3)
+    assert np.array_equal(want[0], coarse[0][sample]) and np.array_equal(want[1], coarse[1][sample]) and np.array_equal(want[2], coarse[2][sample])
+    assert int(want[1].max()) > 1500          # (the reads were not cut short on the way)
+    hx.close()
