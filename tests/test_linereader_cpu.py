@@ -80,6 +80,10 @@ def test_linereader_same_lines_for_every_container(shim, tmp_path, n_reads):
                 r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, COLORID_LIBDEFLATE="0"))
                 assert r.returncode == 0, (name, r.stderr)
                 outs[(name, threads, "gzread")] = r.stdout.split()
+                # ... and zlib's raw inflate instead of the CLI's own decoder (fast_inflate.hpp) inside that reader
+                r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, COLORID_FAST_INFLATE="0"))
+                assert r.returncode == 0, (name, r.stderr)
+                outs[(name, threads, "zlib_raw")] = r.stdout.split()
             if "bgzf" in name:   # BGZF members go through libdeflate when the host has it: the same lines with zlib
                 r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, COLORID_GZ_THREADS=threads, COLORID_LIBDEFLATE="0"))
                 assert r.returncode == 0, (name, r.stderr)
@@ -134,7 +138,7 @@ def test_linereader_single_stream_gzip_containers(shim, tmp_path):
     for tag, blob in cases.items():
         p = tmp_path / f"{tag}.fastq.gz"
         p.write_bytes(blob)
-        for env in ({}, {"COLORID_LIBDEFLATE": "0"}):
+        for env in ({}, {"COLORID_LIBDEFLATE": "0"}, {"COLORID_FAST_INFLATE": "0"}):
             r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, **env))
             assert r.returncode == 0 and r.stdout == want, (tag, env, r.stderr[-200:])
     bad = bytearray(good); bad[len(good) // 2] ^= 0x40
@@ -142,5 +146,6 @@ def test_linereader_single_stream_gzip_containers(shim, tmp_path):
     for tag, blob in (("flip", bytes(bad)), ("crc", bytes(crc)), ("cut", good[:len(good) - 20])):
         p = tmp_path / f"bad_{tag}.fastq.gz"
         p.write_bytes(blob)
-        r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True)
-        assert r.returncode == 101 and ("gzip member" in r.stderr), (tag, r.returncode, r.stderr[-200:])
+        for env in ({}, {"COLORID_FAST_INFLATE": "0"}):
+            r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, **env))
+            assert r.returncode == 101 and ("gzip member" in r.stderr), (tag, env, r.returncode, r.stderr[-200:])
