@@ -120,6 +120,7 @@ class LineReader {   // inflates on its own thread, a few MiB ahead of the calle
     // over.  The CLI calls this before it loads the index, so that gzip decoding runs beside the index load instead of after it.
     static void prefetch(const std::string &path);
     static void drop_prefetched();   // end of a command: stop the streams nobody took
+    static double blocked_ms();      // COLORID_TIMING: time the decoding threads waited for their consumer (all readers so far)
     // Block-gzip (BGZF) input is inflated on GPU `device` (cid_bgzf_inflate: one wave per member) instead of on COLORID_GZ_THREADS
     // host threads; < 0 = on the host.  Applies to readers opened afterwards; each reader thread uses a context of its own.
     static void inflate_on_gpu(int device);

@@ -389,6 +389,7 @@ static void print_read_id_timing(const Clock::time_point &t0) {
             "%llu (colour, count) entries fetched; of poll + write: writing %.0f ms\n",
             ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries,
             g_ms_write);
+    fprintf(stderr, "timing: the input's decoding threads waited %.0f ms for the parser to take their blocks\n", LineReader::blocked_ms());
 }
 
 // ---- block-gzip input through the device front end (cid_fastq_*): the members go up compressed — read from the file a stretch ahead by

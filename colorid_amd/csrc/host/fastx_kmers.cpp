@@ -15,6 +15,9 @@
 #include <mutex>
 #include <thread>
 
+#include <atomic>
+#include <chrono>
+
 #include "colorid_host.hpp"
 #include "fast_inflate.hpp"
 
@@ -139,6 +142,10 @@ static const LibDeflate &libdeflate() { static const LibDeflate l; return l; }
 // converters): the members of a batch are independent, so the reader thread only walks the headers and hands the batch's members to
 // COLORID_GZ_THREADS (default 8) inflating threads, each writing at its member's offset of the output block (the members'
 // uncompressed sizes are in their trailers).  Single-stream gzip has no such boundaries and stays on one zlib thread.
+// COLORID_TIMING: how long the decoding threads of all readers stood still because their consumer had not taken the blocks before
+static std::atomic<uint64_t> g_reader_blocked_us{0};
+double LineReader::blocked_ms() { return (double)g_reader_blocked_us.load() / 1e3; }
+
 struct LineReader::Impl {
     static constexpr size_t kBlock = 4u << 20, kHead = LineReader::kHeadroom;   // a block's text starts at kHead
     size_t depth = 4;              // blocks in flight (prefetched streams: ~256 MiB worth)
@@ -191,7 +198,9 @@ struct LineReader::Impl {
     }
     bool take_free(std::vector<char> &blk) {   // false: asked to stop
         std::unique_lock<std::mutex> lk(mu);
+        const auto tw = std::chrono::steady_clock::now();
         cv_free.wait(lk, [&] { return stop || full.size() < depth; });
+        g_reader_blocked_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw).count();
         if (stop) return false;
         if (!free_blocks.empty()) { blk = std::move(free_blocks.front()); free_blocks.pop_front(); }
         return true;

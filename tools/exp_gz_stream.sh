@@ -11,7 +11,7 @@ for lvl in (1,6):
         for _ in range(4): f.write(text)
 PY
 ls -la $W/reads4.l1.fastq.gz $W/reads4.l6.fastq.gz
-run() { cfg=$1; shift; for rep in 1 2 3; do echo "$cfg [$(basename $1)]: $(env $cfg COLORID_TIMING=1 $BIN read_id -b $W/idx.bxi -q "$@" -n $W/rid_g 2>&1 >/dev/null | tr '\r' '\n' | grep -E "timing: (classification|total)" | sed 's/; of the GPU calls.*//; s/timing: //' | tr '\n' '|' | cut -c1-260)"; done; }
+run() { cfg=$1; shift; for rep in 1 2 3; do echo "$cfg [$(basename $1)]: $(env $cfg COLORID_TIMING=1 $BIN read_id -b $W/idx.bxi -q "$@" -n $W/rid_g 2>&1 >/dev/null | tr '\r' '\n' | grep -E "timing: (classification|total|the input)" | sed 's/; of the GPU calls.*//; s/timing: //' | tr '\n' '|' | cut -c1-260)"; done; }
 for lvl in 1 6; do
   run "COLORID_FAST_INFLATE=0" $W/reads4.l$lvl.fastq.gz
   cp $W/rid_g_reads.txt $W/rid_gz_zlib.txt
