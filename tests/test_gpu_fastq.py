@@ -390,3 +390,35 @@ def test_cli_build_counts_block_gzip_accessions_on_the_device(orc, tmp_path):
             assert p.returncode == 0, p.stderr[-2000:]
             assert ("through the device front end" in p.stderr) == (tag == "dev"), p.stderr[-1500:]
             assert open(pre + ".bxi", "rb").read() == open(ref, "rb").read(), (tag, flt)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_read_id_minimizer_index_block_gzip(orc, tmp_path, paired):
+    """A minimizer index (.mxi) and block-gzip reads, some of them lower-case (the byte-string kernel takes those): the device front end
+    and the host front end write the same rows."""
+    import os
+    import subprocess
+
+    from test_gpu_cli import BIN, PHAGES, REFS
+    tsv = tmp_path / "ref_file.txt"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES))
+    pre = str(tmp_path / "mini")
+    p = subprocess.run([BIN, "build", "-s", "750000", "-n", "4", "-k", "27", "-b", pre, "-r", str(tsv), "-m", "-v", "15"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    genomes = [b"".join(orc.read_fasta(os.path.join(REFS, n + ".fasta"))) for n in PHAGES]
+    rng = np.random.default_rng(91)
+    r1 = synth_fastq_records(np.random.default_rng(61), genomes, 4000, 150, mate=0, lower_rate=0.03)
+    r2 = synth_fastq_records(np.random.default_rng(61), genomes, 4000, 150, mate=1, lower_rate=0.03)
+    f1, f2 = str(tmp_path / "m_1.fastq.gz"), str(tmp_path / "m_2.fastq.gz")
+    _write_bgzf(f1, fastq_text(r1), rng)
+    _write_bgzf(f2, fastq_text(r2), rng)
+    q = [f1, f2] if paired else [f1]
+    outs = {}
+    for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {"COLORID_DEVICE_FASTQ_MB": "1"})):
+        name = str(tmp_path / tag)
+        p = subprocess.run([BIN, "read_id", "-b", pre + ".mxi", "-q", *q, "-n", name], capture_output=True, text=True, env=dict(os.environ, COLORID_TIMING="1", **env))
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert ("device front end" in p.stderr) == (tag == "dev")
+        outs[tag] = (open(name + "_reads.txt").read(), open(name + "_counts.txt").read())
+    assert outs["dev"] == outs["host"]
+    assert outs["host"][0].count("\n") == 4000 and outs["host"][0].count("Listeria_phage") > 2500
