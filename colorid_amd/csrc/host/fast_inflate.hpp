@@ -20,7 +20,7 @@ class FastInflate {
   public:
     enum Result { kNeedInput = 0, kOutputFull = 1, kStreamEnd = 2, kError = -1 };
     static constexpr size_t kMargin = 1024;    // > the longest step's input (a dynamic block header: < 600 bytes)
-    static constexpr size_t kOutSlack = 258 + 16;
+    static constexpr size_t kOutSlack = 258 + 24;
 
     void reset() { bitbuf_ = 0; bitcnt_ = 0; mode_ = kHeader; final_ = false; stored_left_ = 0; produced_ = 0; error_ = ""; }
     uint64_t produced() const { return produced_; }
@@ -209,8 +209,14 @@ class FastInflate {
                     uint8_t *const end = out + len;
                     refill();                                        // the next symbol's entry is on its way while the match is copied
                     e = litlen_[bitbuf & ((1u << kLitBits) - 1)];
-                    if (dist >= 8) {
-                        do { uint64_t w; memcpy(&w, src, 8); memcpy(out, &w, 8); src += 8; out += 8; } while (out < end);
+                    if (dist >= 8) {   // sixteen bytes at once cover most matches of FASTQ text (the second eight may read what the first wrote)
+                        uint64_t w;
+                        memcpy(&w, src, 8); memcpy(out, &w, 8);
+                        memcpy(&w, src + 8, 8); memcpy(out + 8, &w, 8);
+                        if (len > 16) {
+                            src += 16; out += 16;
+                            do { memcpy(&w, src, 8); memcpy(out, &w, 8); src += 8; out += 8; } while (out < end);
+                        }
                     } else if (dist == 1) {
                         memset(out, *src, len);
                     } else {
