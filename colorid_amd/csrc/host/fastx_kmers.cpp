@@ -268,11 +268,68 @@ struct LineReader::Impl {
         FastInflate fz;
         std::vector<char> hist(32768);
         size_t hist_n = 0;
+        // With the fast decoder the CRC-32 of the text (a tenth of the decoding thread's time even at libdeflate's speed) runs on a thread of
+        // its own: a block goes to it with the list of its members' pieces, and from there to the consumer.  As before, a member's blocks
+        // are handed on as they fill; the mismatch is reported when the member's last piece has been summed.
+        struct CrcPiece { size_t off, len; bool ends_member; uint32_t want; };
+        struct CrcJob { std::vector<char> blk; std::vector<CrcPiece> pieces; bool last = false, stop = false; };
+        std::mutex cmu;
+        std::condition_variable ccv_job, ccv_room;
+        std::deque<CrcJob> cq;
+        std::vector<CrcPiece> pieces;   // of the block being filled
+        size_t piece_start = 0;         // where the current member's text starts in it
+        std::thread crc_thread;
+        if (use_fast)
+            crc_thread = std::thread([&] {
+                uint32_t c = 0;
+                for (;;) {
+                    CrcJob job;
+                    {
+                        std::unique_lock<std::mutex> lk(cmu);
+                        ccv_job.wait(lk, [&] { return !cq.empty(); });
+                        job = std::move(cq.front());
+                        cq.pop_front();
+                    }
+                    ccv_room.notify_one();
+                    if (job.stop) return;
+                    for (const CrcPiece &pc : job.pieces) {
+                        c = ld.crc32(c, job.blk.data() + kHead + pc.off, pc.len);
+                        if (pc.ends_member) {
+                            if (c != pc.want) die("corrupt gzip member (inflate / CRC-32 failed)");
+                            c = 0;
+                        }
+                    }
+                    push(std::move(job.blk), job.last);
+                }
+            });
+        struct CrcJoin {   // (every way out of this function ends the CRC thread first)
+            std::thread &t; std::mutex &mu; std::condition_variable &cv; std::deque<CrcJob> &q;
+            ~CrcJoin() {
+                if (!t.joinable()) return;
+                { std::lock_guard<std::mutex> lk(mu); CrcJob j; j.stop = true; q.push_back(std::move(j)); }
+                cv.notify_one();
+                t.join();
+            }
+        } crc_join{crc_thread, cmu, ccv_job, cq};
         auto flush_block = [&](bool last) {
             blk.resize(kHead + got);
-            push(std::move(blk), last);
+            if (use_fast) {
+                CrcJob job;
+                job.blk = std::move(blk);
+                job.pieces.swap(pieces);
+                job.last = last;
+                {
+                    std::unique_lock<std::mutex> lk(cmu);
+                    ccv_room.wait(lk, [&] { return cq.size() < 2; });
+                    cq.push_back(std::move(job));
+                }
+                ccv_job.notify_one();
+            } else {
+                push(std::move(blk), last);
+            }
             blk = std::vector<char>();
             got = 0;
+            piece_start = 0;
             have_blk = false;
         };
         for (;;) {   // one member per round
@@ -308,7 +365,6 @@ struct LineReader::Impl {
                     in.pos = (size_t)(ip - in.buf.data());
                     if (r == FastInflate::kError) die("corrupt gzip member (inflate failed: %s)", fz.error());
                     const size_t made = (size_t)(op - op0);
-                    crc = ld.crc32(crc, op0, made);
                     got += made;
                     total += made;
                     if (r == FastInflate::kStreamEnd) break;
@@ -319,6 +375,7 @@ struct LineReader::Impl {
                     // the block is full (to within a longest match): its last 32 KiB stay with the reader for the next block's matches
                     hist_n = got < hist.size() ? got : hist.size();
                     memcpy(hist.data(), blk.data() + kHead + got - hist_n, hist_n);
+                    pieces.push_back(CrcPiece{piece_start, got - piece_start, false, 0});
                     flush_block(false);
                 }
                 hist_n = 0;   // (the next member's matches cannot reach in front of its own text)
@@ -352,12 +409,22 @@ struct LineReader::Impl {
             const uint32_t want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
             const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
             in.pos += 8;
-            if (want_crc != crc || isize != (uint32_t)total) die("corrupt gzip member (inflate / CRC-32 failed)");
+            if (use_fast) {   // the sum is the CRC thread's to compare: the member's last piece goes with the block it lies in
+                if (isize != (uint32_t)total) die("corrupt gzip member (inflate / CRC-32 failed)");
+                if (!have_blk) {   // (a member that ended exactly with a block, or an empty one: the piece needs a block to travel in)
+                    if (!take_free(blk)) { inflateEnd(&zs); return; }
+                    blk.resize(kHead + kBlock);
+                    got = 0;
+                    piece_start = 0;
+                    have_blk = true;
+                }
+                pieces.push_back(CrcPiece{piece_start, got - piece_start, true, want_crc});
+                piece_start = got;
+            } else if (want_crc != crc || isize != (uint32_t)total) die("corrupt gzip member (inflate / CRC-32 failed)");
         }
         inflateEnd(&zs);
         if (!have_blk) { blk = std::vector<char>(); got = 0; }
-        blk.resize(kHead + got);
-        push(std::move(blk), true);
+        flush_block(true);
     }
 
     // BGZF: batches of members worth ~16 MiB of text, inflated by gz_threads threads — or, with a GPU set (inflate_on_gpu), batches of
