@@ -189,21 +189,20 @@ class FastInflate {
                         break;
                     }
                 }
-                {   // a length: base in bits 16..24, extra-bit count in bits 8..12
-                    bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu);
-                    const uint32_t xb = e >> 8 & 0x1Fu;
-                    const uint32_t len = (e >> 16 & 0x1FFu) + (uint32_t)(bitbuf & ((1u << xb) - 1));
-                    bitbuf >>= xb; bitcnt -= xb;
+                {   // a length: base in bits 16..24, extra-bit count in bits 8..12; bits 0..7 count the code AND its extra bits, so the bit
+                    // buffer — the one chain every step hangs on — moves once per code, and the extra bits are picked off beside it
+                    const uint32_t xb = e >> 8 & 0x1Fu, tb = e & 0xFFu;
+                    const uint32_t len = (e >> 16 & 0x1FFu) + ((uint32_t)(bitbuf >> (tb - xb)) & ((1u << xb) - 1));
+                    bitbuf >>= tb; bitcnt -= tb;
                     uint32_t d = dist_[bitbuf & ((1u << kDistBits) - 1)];
                     if (d & kDistSub) {
                         bitbuf >>= kDistBits; bitcnt -= kDistBits;
                         d = dist_[(d >> 12 & 0x1FFFu) + (uint32_t)(bitbuf & ((1u << (d >> 8 & 0xFu)) - 1))];
                     }
                     if ((d & 0xFFu) == 0) { error_ = "invalid distance code"; failed = true; break; }
-                    bitbuf >>= (d & 0xFFu); bitcnt -= (d & 0xFFu);
-                    const uint32_t dxb = d >> 8 & 0xFu;
-                    const uint32_t dist = (d >> 12 & 0x7FFFu) + (uint32_t)(bitbuf & ((1u << dxb) - 1));
-                    bitbuf >>= dxb; bitcnt -= dxb;
+                    const uint32_t dxb = d >> 8 & 0xFu, dtb = d & 0xFFu;
+                    const uint32_t dist = (d >> 12 & 0x7FFFu) + ((uint32_t)(bitbuf >> (dtb - dxb)) & ((1u << dxb) - 1));
+                    bitbuf >>= dtb; bitcnt -= dtb;
                     const uint8_t *src = out - dist;
                     if (src < first_byte) { error_ = "invalid distance too far back"; failed = true; break; }
                     uint8_t *const end = out + len;
@@ -250,7 +249,7 @@ class FastInflate {
     enum Mode { kHeader, kStored, kHuff, kDone };
     static constexpr uint32_t kLitBits = 11, kDistBits = 8, kPreBits = 7;
     static constexpr uint32_t kLitEntries = 2048 + 4096, kDistEntries = 256 + 2048, kPreEntries = 128;
-    // entry: bits 0..7 = code bits this look-up uses up (0: no such code); then one of
+    // entry: bits 0..7 = bits this look-up uses up — the code's, and for lengths and distances their extra bits too (0: no such code); then one of
     //   kLiteral            bits 16..23 the byte
     //   kSpecial            end of block, or with kSubtable: bits 16..28 first entry of the sub-table, bits 8..11 its index bits
     //   (neither)           litlen: bits 16..24 length base, bits 8..12 extra bits; pre (code-length code): bits 16.. the symbol
@@ -319,8 +318,10 @@ class FastInflate {
             bool ok;
             const uint32_t body = entry_for(s, litlen, pre, ok);
             const uint32_t r = rcode[s];
+            // (length and distance entries count their extra bits with the code's: see the decoding loop)
+            const uint32_t extra = pre || (body & (kLiteral | kSpecial)) ? 0u : (litlen ? body >> 8 & 0x1Fu : body >> 8 & 0xFu);
             if (l <= tbits) {
-                const uint32_t e = ok ? (body | l) : invalid;
+                const uint32_t e = ok ? (body | (l + extra)) : invalid;
                 for (uint32_t i = r; i < (1u << tbits); i += 1u << l) tab[i] = e;
                 continue;
             }
@@ -334,7 +335,7 @@ class FastInflate {
                 next_free += 1u << sb;
             }
             const uint32_t start = tab[prefix] >> sub_shift & 0x1FFFu;
-            const uint32_t e = ok ? (body | (l - tbits)) : invalid;
+            const uint32_t e = ok ? (body | (l - tbits + extra)) : invalid;
             for (uint32_t i = r >> tbits; i < (1u << sb); i += 1u << (l - tbits)) tab[start + i] = e;
         }
         return true;
