@@ -70,6 +70,7 @@ SIGNATURES = {
     "cid_order_codes_for_index_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
     "cid_kmerset_download": (C.c_int, [vp, vp, vp]),
     "cid_kmerset_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "cid_kmerset_device_ascii": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),
     "cid_kmerset_destroy": (None, [vp]),
     "cid_index_insert_kmerset": (C.c_int, [vp, vp, C.c_uint32]),
     "cid_search_count_set": (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),

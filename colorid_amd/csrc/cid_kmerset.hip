@@ -163,6 +163,29 @@ __global__ void k_row0_line(const uint64_t *codes, uint32_t k, ModMagic mm, uint
     keys[i] = bucket_bits ? (uint32_t)(((uint64_t)row0 << bucket_bits) / mm.m) : row0 >> line_shift;
     if (idx) idx[i] = (uint32_t)i;
 }
+// the same key for the k-mers of a byte-string set (k > 32): k ASCII bytes each, hashed as they are
+struct BytesReader {
+    const uint8_t *b;
+    __device__ __forceinline__ uint32_t rd8(uint32_t o) const { return b[o]; }
+    __device__ __forceinline__ uint32_t rd32(uint32_t o) const { return rd8(o) | (rd8(o + 1) << 8) | (rd8(o + 2) << 16) | (rd8(o + 3) << 24); }
+    __device__ __forceinline__ uint64_t rd64(uint32_t o) const { return (uint64_t)rd32(o) | ((uint64_t)rd32(o + 4) << 32); }
+};
+__global__ void k_row0_line_ascii(const uint8_t *ascii, uint32_t k, ModMagic mm, uint32_t line_shift, uint32_t bucket_bits, uint32_t *keys, uint32_t *idx,
+                                  uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t row0 = 0;
+    xxh3_seeds_from(BytesReader{ascii + i * k}, k, 1, HashSel::of(mm), [&](uint32_t, uint64_t h) { row0 = (uint32_t)mod_m(h, mm); });
+    keys[i] = bucket_bits ? (uint32_t)(((uint64_t)row0 << bucket_bits) / mm.m) : row0 >> line_shift;
+    idx[i] = (uint32_t)i;
+}
+__global__ void k_permute_rows(const uint8_t *rows_in, const uint32_t *counts_in, const uint32_t *idx, uint32_t k, uint8_t *rows_out, uint32_t *counts_out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t j = idx[i];
+    for (uint32_t t = 0; t < k; ++t) rows_out[i * k + t] = rows_in[j * k + t];
+    counts_out[i] = counts_in[j];
+}
 
 }  // namespace cid
 
@@ -1440,7 +1463,37 @@ int cid_kmerset_order_for_index(cid_kmerset *ks, const cid_index *ix) {
     if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
     if (ks->n == 0) return CID_OK;
     if (cid::index_k(ix) != ks->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", ks->k, cid::index_k(ix));
-    if (ks->general) return fail(CID_ERR_UNSUPPORTED, "ordering is defined for 2-bit-code sets (k_size <= 32)");
+    if (ks->general) {   // byte strings: the same key from the ASCII k-mer, the rows permuted
+        if (ks->n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mers");
+        cid_ctx *c = ks->ctx;
+        HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+        hipStream_t st = cid::ctx_stream(c);
+        const uint32_t rs = cid::index_rs(ix);
+        uint32_t line_shift = 0;
+        while ((rs << line_shift) < 16) ++line_shift;
+        const uint32_t bucket_bits = (uint32_t)cid::ctx_order_bits(c);
+        const uint64_t max_key = bucket_bits ? ((1ull << bucket_bits) - 1) : ((cid::index_mod(ix).m - 1) >> line_shift);
+        unsigned end_bit = 1;
+        while (end_bit < 32 && (max_key >> end_bit)) ++end_bit;
+        DevBuf<uint32_t> keys(c), keys2(c), idx(c), idx2(c), cnt(c);
+        DevBuf<uint8_t> rows(c), tmp(c);
+        int rc;
+        if ((rc = keys.alloc(ks->n)) || (rc = keys2.alloc(ks->n)) || (rc = idx.alloc(ks->n)) || (rc = idx2.alloc(ks->n)) || (rc = cnt.alloc(ks->n)) ||
+            (rc = rows.alloc(ks->n * ks->k)))
+            return rc;
+        hipLaunchKernelGGL(cid::k_row0_line_ascii, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->ascii, ks->k, cid::index_mod(ix), line_shift, bucket_bits, keys.p,
+                           idx.p, (uint64_t)ks->n);
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, end_bit, st));
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys.p, keys2.p, idx.p, idx2.p, ks->n, 0u, end_bit, st));
+        hipLaunchKernelGGL(cid::k_permute_rows, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->ascii, ks->counts, idx2.p, ks->k, rows.p, cnt.p, (uint64_t)ks->n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        cid::ctx_free(c, ks->ascii); cid::ctx_free(c, ks->counts);
+        ks->ascii = rows.release(); ks->counts = cnt.release();
+        return CID_OK;
+    }
     DevBuf<uint32_t> on(ks->ctx);
     DevBuf<uint64_t> oc(ks->ctx);
     int rc;
@@ -1475,8 +1528,16 @@ int cid_kmerset_download(const cid_kmerset *ks, uint8_t *kmers_ascii, uint32_t *
 
 int cid_kmerset_device_arrays(const cid_kmerset *ks, void **d_codes, void **d_counts, uint64_t *n) {
     if (!ks || !d_codes || !d_counts || !n) return fail(CID_ERR_INVALID, "null argument");
-    if (ks->general) return fail(CID_ERR_UNSUPPORTED, "a k_size > 32 set holds byte strings, not 2-bit codes");
+    if (ks->general) return fail(CID_ERR_UNSUPPORTED, "a k_size > 32 set holds byte strings, not 2-bit codes: cid_kmerset_device_ascii");
     *d_codes = ks->codes; *d_counts = ks->counts; *n = ks->n;
+    return CID_OK;
+}
+
+int cid_kmerset_device_ascii(const cid_kmerset *ks, void **d_kmers_ascii, void **d_counts, uint64_t *n) {
+    if (!ks || !d_kmers_ascii || !d_counts || !n) return fail(CID_ERR_INVALID, "null argument");
+    if (!ks->finalized) return fail(CID_ERR_STATE, "k-mer set not finalized");
+    if (!ks->general) return fail(CID_ERR_UNSUPPORTED, "a k_size <= 32 set holds 2-bit codes: cid_kmerset_device_arrays");
+    *d_kmers_ascii = ks->ascii; *d_counts = ks->counts; *n = ks->n;
     return CID_OK;
 }
 

@@ -238,6 +238,12 @@ class KmerSet:
     def order_for_index(self, index):
         check(self.lib.cid_kmerset_order_for_index(self.h, index.h))
 
+    def device_ascii(self):
+        """k > 32: (device pointer to the n x k ASCII k-mers, device pointer to the multiplicities, n)"""
+        a, c, n = vp(), vp(), C.c_uint64(0)
+        check(self.lib.cid_kmerset_device_ascii(self.h, C.byref(a), C.byref(c), C.byref(n)))
+        return a.value, c.value, n.value
+
     def download(self):
         n = len(self)
         km = np.zeros((n, self.k), np.uint8)

@@ -209,9 +209,12 @@ int cid_kmerset_order_for_index(cid_kmerset *, const cid_index *);
  * pays when a set is searched more than once. */
 int cid_order_codes_for_index_dev(cid_ctx *, const cid_index *, const uint64_t *d_codes, const uint32_t *d_counts, size_t n_kmers,
                                   uint64_t *d_codes_out, uint32_t *d_counts_out);
-/* Host copies in set order: n_distinct x k_size ASCII bytes and/or multiplicities (either may be NULL). */
+/* Host copies in set order: n_distinct x k_size ASCII bytes and/or multiplicities (either may be NULL).
+ * cid_kmerset_order_for_index works on 2-bit-code sets and on byte-string sets (k_size > 32: the rows are permuted) alike. */
 int cid_kmerset_download(const cid_kmerset *, uint8_t *kmers_ascii, uint32_t *counts);
 int cid_kmerset_device_arrays(const cid_kmerset *, void **d_codes, void **d_counts, uint64_t *n_distinct);
+/* the same for a byte-string set (k_size 33..128): n_distinct x k_size ASCII bytes, in set order */
+int cid_kmerset_device_ascii(const cid_kmerset *, void **d_kmers_ascii, void **d_counts, uint64_t *n_distinct);
 void cid_kmerset_destroy(cid_kmerset *);
 /* Bloom insert of a whole finalized set into one colour: one accession of `build` without the k-mers leaving HBM
  * (src/build.rs:54-99 with the map on the GPU). */

@@ -222,7 +222,7 @@ def test_phage_fixture_counts(orc, hip_ctx):
         ks.close()
 
 
-@pytest.mark.parametrize("n_colors,n_hash,k", [(4, 4, 27), (256, 4, 31), (1024, 3, 21), (65, 2, 32)])
+@pytest.mark.parametrize("n_colors,n_hash,k", [(4, 4, 27), (256, 4, 31), (1024, 3, 21), (65, 2, 32), (100, 3, 40), (256, 2, 64)])
 def test_search_over_device_set(orc, hip_ctx, n_colors, n_hash, k):
     import colorid_amd
     rng = np.random.default_rng(n_colors + k)
