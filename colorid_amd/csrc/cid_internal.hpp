@@ -93,6 +93,7 @@ const char *bgzf_status_text(uint32_t st);
 hipError_t warm_readid();
 hipError_t warm_search();
 hipError_t warm_kmerset();
+hipError_t warm_reports();
 hipError_t warm_inflate();
 
 }  // namespace cid

@@ -1,0 +1,304 @@
+// Device-side tails of the searches and of read_id that are NOT the k-mer set (cid_kmerset.hip) — a translation unit of their own, so
+// that a command loads only the code object it uses (the k-mer set's, with its rocPRIM sorts, is 18 MB: 0.2 s of start-up):
+//   * the mode of the unique-hit k-mer frequencies per colour (reports.rs:65-77) and its mergeable histogram form;
+//   * rows of the index -> .bxi records (bigsi.rs / the build's save step);
+//   * dense read_id report rows -> sparse (colour, count) entries per read.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <utility>
+#include <vector>
+
+#include "../../include/colorid_hip.h"
+#include "cid_internal.hpp"
+#include "cid_devbuf.hpp"
+
+// ------------------------------------------------------------------------------------------------ modes of the unique-hit frequencies
+// reports.rs:65-77 on the vectors batch_search_pe.rs:75-82 fills: per colour, the most frequent multiplicity among the k-mers that
+// hit exactly that colour (ties -> the smallest value; the reference's tie is HashMap order).  Done on the device so that neither
+// the per-k-mer unique colours nor the multiplicities (4 + 4 bytes per k-mer) have to cross PCIe for the report.
+//   small multiplicities (f < FL): a colour x FL table of counts, privatised per workgroup in LDS, flushed with global atomics;
+//   the rest: appended as (colour << 32 | f) keys, then sorted and run-length counted;
+//   every (colour, f, count) cell proposes count << 32 | ~f to an atomicMax per colour: highest count wins, ties go to the smaller f.
+namespace cid {
+
+__global__ __launch_bounds__(256) void k_mode_hist(const uint32_t *uc, const uint32_t *freq, uint64_t n, uint32_t C, uint32_t FL, uint64_t per_block,
+                                                   uint32_t *table, uint64_t *ovf, unsigned long long *ovf_count) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t *cells = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t n_cells = C * FL;
+    for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x) cells[i] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
+    const uint64_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = i0; base < i1; base += blockDim.x) {   // block-uniform trip count: the ballot below sees whole waves
+        const uint64_t i = base + threadIdx.x;
+        bool big = false;
+        uint64_t key = 0;
+        if (i < i1) {
+            const uint32_t c = uc[i];
+            if (c != 0xFFFFFFFFu) {
+                const uint32_t f = freq ? freq[i] : 1u;
+                if (f < FL) atomicAdd(&cells[c * FL + f], 1u);
+                else { big = true; key = ((uint64_t)c << 32) | f; }
+            }
+        }
+        const uint64_t m = __ballot(big);
+        if (m) {
+            unsigned long long at = 0;
+            if (lane == 0) at = atomicAdd(ovf_count, (unsigned long long)__popcll(m));
+            at = (unsigned long long)__shfl((long long)at, 0, 64);
+            if (big) ovf[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x)
+        if (cells[i]) atomicAdd(&table[i], cells[i]);
+}
+__global__ void k_mode_pick_table(const uint32_t *table, uint32_t C, uint32_t FL, unsigned long long *best) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * FL) return;
+    const uint32_t v = table[i];
+    if (v) atomicMax(&best[i / FL], ((unsigned long long)v << 32) | (0xFFFFFFFFu - (i % FL)));
+}
+__global__ void k_mode_pick_runs(const uint64_t *keys, const uint32_t *runs, const uint64_t *n_runs, unsigned long long *best) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_runs) return;
+    const uint64_t k = keys[i];
+    atomicMax(&best[k >> 32], ((unsigned long long)runs[i] << 32) | (0xFFFFFFFFu - (uint32_t)k));
+}
+__global__ void k_mode_final(const unsigned long long *best, uint32_t C, uint64_t *modes) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) modes[c] = best[c] ? (uint64_t)(0xFFFFFFFFu - (uint32_t)best[c]) : 0ull;
+}
+
+int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes) {
+    hipStream_t st = ctx_stream(c);
+    if (n == 0) { HIP_TRY(hipMemsetAsync(d_modes, 0, (size_t)C * 8, st)); return CID_OK; }
+    if (n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mers");
+    uint32_t FL = 64;
+    while (FL > 1 && (uint64_t)C * FL > 16384) FL >>= 1;     // the per-workgroup table: at most 64 KiB of LDS
+    if ((uint64_t)C * FL > 16384) FL = 0;                     // very many colours: every (colour, f) goes through the sort
+    DevBuf<uint32_t> table(c), runs(c);
+    DevBuf<uint64_t> ovf(c), keys_sorted(c), keys_u(c), n_runs(c);
+    DevBuf<unsigned long long> best(c), ovf_count(c);
+    int rc;
+    if ((rc = table.alloc((size_t)C * (FL ? FL : 1))) || (rc = ovf.alloc(n)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2))
+        || (rc = n_runs.alloc(1))) return rc;
+    HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)C * (FL ? FL : 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(best.p, 0, (size_t)C * 8, st));
+    HIP_TRY(hipMemsetAsync(ovf_count.p, 0, 16, st));
+    const unsigned blocks = 1024;
+    uint64_t per_block = (n + blocks - 1) / blocks;
+    per_block = (per_block + 255) / 256 * 256;
+    const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
+    const size_t shmem = (size_t)C * FL * 4;
+    if (shmem > 64 * 1024) return fail(CID_ERR_UNSUPPORTED, "mode table");
+    hipLaunchKernelGGL(k_mode_hist, dim3(grid), dim3(256), shmem, st, d_uc, d_freq, n, C, FL, per_block, table.p, ovf.p, ovf_count.p);
+    if (FL) hipLaunchKernelGGL(k_mode_pick_table, dim3((C * FL + 255) / 256), dim3(256), 0, st, table.p, C, FL, best.p);
+    unsigned long long n_ovf = 0;
+    HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_ovf) {
+        if ((rc = keys_sorted.alloc(n_ovf)) || (rc = keys_u.alloc(n_ovf)) || (rc = runs.alloc(n_ovf))) return rc;
+        size_t tb = 0, tb2 = 0;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, ovf.p, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st));
+        HIP_TRY(rocprim::run_length_encode(nullptr, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st));
+        DevBuf<uint8_t> tmp(c);
+        if ((rc = tmp.alloc(tb > tb2 ? tb : tb2))) return rc;
+        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, ovf.p, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st));
+        HIP_TRY(rocprim::run_length_encode(tmp.p, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st));
+        hipLaunchKernelGGL(k_mode_pick_runs, dim3(grid_for_n(n_ovf)), dim3(256), 0, st, keys_u.p, runs.p, n_runs.p, best.p);
+    }
+    hipLaunchKernelGGL(k_mode_final, dim3((C + 255) / 256), dim3(256), 0, st, best.p, C, d_modes);
+    HIP_TRY(hipStreamSynchronize(st));   // the scratch goes out of scope
+    return CID_OK;
+}
+
+}  // namespace cid
+
+// ------------------------------------------------------------------------------------------------ rows -> .bxi records
+// save_bigsi (bigsi.rs:51-57 / build.rs:123-127): the non-zero rows of a row range, in ascending order, as the bincode
+// records the file holds — { u64 row ; u64 W32 ; W32 x u32 ; u64 n_colors } — formatted on the device so that the host only
+// writes the bytes.
+namespace cid {
+
+__global__ void k_row_nonzero(const uint64_t *mat, uint32_t rs, uint64_t row_begin, uint64_t n, uint32_t *flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { flags[i] = 0; return; }   // slot n receives the total
+    const uint64_t *row = mat + (row_begin + i) * rs;
+    uint64_t any = 0;
+    for (uint32_t w = 0; w < rs; ++w) any |= row[w];
+    flags[i] = any ? 1u : 0u;
+}
+__global__ void k_emit_records(const uint32_t *mat32, uint32_t rs, uint32_t w32, uint32_t n_colors, uint64_t row_begin, uint64_t n,
+                               const uint32_t *flags, const uint32_t *pos, uint32_t *out32) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const uint64_t row = row_begin + i;
+    uint32_t *rec = out32 + (uint64_t)pos[i] * (6ull + w32);
+    rec[0] = (uint32_t)row; rec[1] = (uint32_t)(row >> 32);
+    rec[2] = w32; rec[3] = 0;
+    const uint32_t *src = mat32 + row * (2ull * rs);
+    for (uint32_t w = 0; w < w32; ++w) rec[4 + w] = src[w];
+    rec[4 + w32] = n_colors; rec[5 + w32] = 0;
+}
+
+// host buffer `records` holds up to n_rows records; *n_records = the number written
+int index_get_records(cid_ctx *c, const cid_index *ix, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records) {
+    *n_records = 0;
+    if (n_rows == 0) return CID_OK;
+    if (n_rows >= (1ull << 32)) return fail(CID_ERR_INVALID, "at most 2^32-1 rows per call");
+    hipStream_t st = ctx_stream(c);
+    const uint32_t w32 = (index_n_colors(ix) + 31) / 32, rs = index_rs(ix);
+    const size_t rec = 24 + 4ull * w32;
+    DevBuf<uint32_t> flags(c), pos(c);
+    DevBuf<uint8_t> out(c), tmp(c);
+    int rc;
+    if ((rc = flags.alloc(n_rows + 1)) || (rc = pos.alloc(n_rows + 1)) || (rc = out.alloc(n_rows * rec))) return rc;
+    hipLaunchKernelGGL(k_row_nonzero, dim3(grid_for_n(n_rows + 1)), dim3(256), 0, st, index_matrix(ix), rs, row_begin, n_rows, flags.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, flags.p, pos.p, 0u, n_rows + 1, rocprim::plus<uint32_t>(), st));
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, flags.p, pos.p, 0u, n_rows + 1, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(k_emit_records, dim3(grid_for_n(n_rows)), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(index_matrix(ix)), rs, w32,
+                       index_n_colors(ix), row_begin, n_rows, flags.p, pos.p, reinterpret_cast<uint32_t *>(out.p));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, pos.p + n_rows, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (total) HIP_TRY(hipMemcpy(records, out.p, (size_t)total * rec, hipMemcpyDeviceToHost));
+    *n_records = total;
+    return CID_OK;
+}
+
+}  // namespace cid
+
+// ------------------------------------------------------------------------------------------------ sparse read_id reports
+// A report row has n_colors+1 counters but only a handful are non-zero: compact the dense rows (left in HBM by
+// k_readid) into per-read (colour, count) lists in ascending colour order, so that only those cross PCIe.
+namespace cid {
+
+__global__ __launch_bounds__(256) void k_row_nnz(const uint32_t *report, uint32_t width, uint64_t n_rows, uint32_t *nnz) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t *r = report + row * width;
+    uint32_t n = 0;
+    for (uint32_t c0 = 0; c0 < width; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        n += (uint32_t)__popcll(__ballot(c < width && r[c] != 0));
+    }
+    if (lane == 0) nnz[row] = n;
+}
+__global__ __launch_bounds__(256) void k_row_compact(const uint32_t *report, uint32_t width, uint64_t n_rows, const uint64_t *row_start,
+                                                     uint32_t *colours, uint32_t *counts) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t *r = report + row * width;
+    uint64_t out = row_start[row];
+    for (uint32_t c0 = 0; c0 < width; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < width ? r[c] : 0u;
+        const uint64_t m = __ballot(v != 0);
+        if (v) {
+            const uint64_t o = out + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+            colours[o] = c;
+            counts[o] = v;
+        }
+        out += (uint64_t)__popcll(m);
+    }
+}
+
+// d_report: n_rows x width dense counters (device).  Leaves row_start (u64[n_rows+1]) and the entry arrays in the buffers
+// it allocates; the caller owns (and frees) them.
+int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_t n_rows, uint64_t **d_row_start, uint32_t **d_colours,
+                   uint32_t **d_counts, uint64_t *n_entries) {
+    hipStream_t st = ctx_stream(c);
+    DevBuf<uint32_t> nnz(c), col(c), cnt(c);
+    DevBuf<uint64_t> start(c);
+    int rc;
+    if ((rc = nnz.alloc(n_rows + 1)) || (rc = start.alloc(n_rows + 1))) return rc;
+    HIP_TRY(hipMemsetAsync(nnz.p, 0, (n_rows + 1) * 4, st));
+    if (n_rows) hipLaunchKernelGGL(k_row_nnz, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, d_report, width, n_rows, nnz.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
+    DevBuf<uint8_t> tmp(c);
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpy(&total, start.p + n_rows, 8, hipMemcpyDeviceToHost));
+    if ((rc = col.alloc(total)) || (rc = cnt.alloc(total))) return rc;
+    if (n_rows) hipLaunchKernelGGL(k_row_compact, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, d_report, width, n_rows, start.p, col.p, cnt.p);
+    HIP_TRY(hipStreamSynchronize(st));
+    *d_row_start = start.release(); *d_colours = col.release(); *d_counts = cnt.release(); *n_entries = total;
+    return CID_OK;
+}
+
+hipError_t warm_reports() {   // see warm_readid (cid_readid.hip)
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_row_nnz));
+}
+
+}  // namespace cid
+
+namespace cid {
+__global__ void k_colour_freq_keys(const uint32_t *uc, const uint32_t *freq, uint64_t n, uint64_t *keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = uc[i];
+    keys[i] = c == 0xFFFFFFFFu ? ~0ull : (((uint64_t)c << 32) | (freq ? freq[i] : 1u));
+}
+// The (colour, multiplicity) histogram of the k-mers that hit exactly one colour, as sorted keys colour << 32 | multiplicity with
+// the number of k-mers each: what the mode of reports.rs:65-77 is taken from, in a form that ADDS over disjoint parts of a k-mer set
+// (a mode does not) — cid_group_search_count_parts_report merges the ranks' histograms.  Host vectors; synchronous.
+int unique_freq_hist(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, std::vector<uint64_t> &keys, std::vector<uint32_t> &counts) {
+    keys.clear(); counts.clear();
+    if (n == 0) return CID_OK;
+    if (n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 - 1 k-mers in one part");
+    HIP_TRY(hipSetDevice(ctx_device(c)));
+    hipStream_t st = ctx_stream(c);
+    DevBuf<uint64_t> kin(c), kout(c), uniq(c), d_count(c);
+    DevBuf<uint32_t> runs(c);
+    int rc;
+    if ((rc = kin.alloc(n)) || (rc = kout.alloc(n)) || (rc = uniq.alloc(n)) || (rc = runs.alloc(n)) || (rc = d_count.alloc(1))) return rc;
+    hipLaunchKernelGGL(k_colour_freq_keys, dim3(grid_for_n(n)), dim3(256), 0, st, d_uc, d_freq, n, kin.p);
+    size_t tb = 0;
+    HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, kin.p, kout.p, n, 0u, 64u, st));
+    DevBuf<uint8_t> tmp(c);
+    if ((rc = tmp.alloc(tb))) return rc;
+    HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, kin.p, kout.p, n, 0u, 64u, st));
+    size_t tb2 = 0;
+    HIP_TRY(rocprim::run_length_encode(nullptr, tb2, kout.p, n, uniq.p, runs.p, d_count.p, st));
+    DevBuf<uint8_t> tmp2(c);
+    if ((rc = tmp2.alloc(tb2))) return rc;
+    HIP_TRY(rocprim::run_length_encode(tmp2.p, tb2, kout.p, n, uniq.p, runs.p, d_count.p, st));
+    uint64_t nb = 0;
+    HIP_TRY(hipMemcpyAsync(&nb, d_count.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    keys.resize(nb); counts.resize(nb);
+    HIP_TRY(hipMemcpyAsync(keys.data(), uniq.p, nb * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(counts.data(), runs.p, nb * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (nb && keys.back() == ~0ull) { keys.pop_back(); counts.pop_back(); }   // the k-mers without a unique colour
+    return CID_OK;
+}
+}  // namespace cid
+
+extern "C" {
+
+int cid_unique_freq_modes_dev(cid_ctx *c, const uint32_t *d_unique_colour, const uint32_t *d_freq, size_t n_kmers, uint32_t n_colors, uint64_t *d_modes) {
+    if (!c || !d_modes || n_colors == 0 || (n_kmers && !d_unique_colour)) return fail(CID_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(cid::ctx_device(c)));
+    return cid::unique_freq_modes(c, d_unique_colour, d_freq, n_kmers, n_colors, d_modes);
+}
+
+}  // extern "C"
