@@ -215,7 +215,7 @@ void save_bigsi(const std::string &path, const Bigsi &b) {
 }
 
 // tab_to_map (build.rs:15-31): accession \t file [\t file2]; later lines overwrite earlier ones
-static std::map<std::string, std::vector<std::string>> tab_to_map(const std::string &ref_tsv) {
+std::map<std::string, std::vector<std::string>> tab_to_map(const std::string &ref_tsv) {
     std::map<std::string, std::vector<std::string>> refs;  // std::map iterates sorted == accessions.sort() (build.rs:105)
     LineReader r(ref_tsv);
     std::string line;

@@ -258,6 +258,9 @@ Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uin
 // For every hash variant v and every accession of ref_tsv that is a colour of b: the fraction of the accession's k-mers (counted
 // as build does, build.rs:54-99) whose n rows are all set in its colour.  Prints one line per (variant, accession); worst[v] = the
 // smallest fraction under variant v.  Returns the number of accessions checked.
+// build.rs:15-31: `name \t file [\t file2]` per line, a later line of the same name replaces the earlier one (the sample sheet of
+// `build -r`, `hashcheck -r` and `batch_id -q`); iterated in name order
+std::map<std::string, std::vector<std::string>> tab_to_map(const std::string &tsv);
 size_t hashcheck(cid_ctx *ctx, Bigsi &b, const std::string &ref_tsv, uint8_t quality, const char *const *variant_names, std::vector<double> &worst);
 
 // ---------------------------------------------------------------- reports.rs / read_id tail

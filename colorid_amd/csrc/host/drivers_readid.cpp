@@ -390,6 +390,10 @@ static void print_read_id_timing(const Clock::time_point &t0) {
             ms_since(t0), g_ms_gpu, g_ms_poll, g_ms_wait[0], g_ms_wait[1], g_ms_wait[2], g_ms_wait[3], g_ms_gpu_count, (unsigned long long)g_entries,
             g_ms_write);
     fprintf(stderr, "timing: the input's decoding threads waited %.0f ms for the parser to take their blocks\n", LineReader::blocked_ms());
+    // batch_id runs one stream per sample in the same process: the next one's line starts from zero
+    g_ms_gpu = g_ms_poll = g_ms_gpu_count = g_ms_write = 0;
+    g_entries = 0;
+    for (double &w : g_ms_wait) w = 0;
 }
 
 // ---- block-gzip input through the device front end (cid_fastq_*): the members go up compressed — read from the file a stretch ahead by

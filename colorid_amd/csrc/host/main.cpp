@@ -1,10 +1,10 @@
 // `colorid` command line: the reference's drop-in surface for the query path (src/main.rs) —
-//   search  (src/main.rs:127-217, :555-628)   read_id (:241-328, :704-868)
+//   search  (src/main.rs:127-217, :555-628)   read_id (:241-328, :704-868)   batch_id (:329-418, :869-888: read_id over a sample sheet)
 //   build   (:31-126, :466-554; needed to produce .bxi files)   info (:218-240, :630-703)
 // Same flag letters, defaults, stdout/stderr/file formats.  Extra flags: --device N, --gpus N | --devices a,b,.. (search, read_id:
 // the query is sharded over the GPUs), --hash xxh3_v08|xxh3_v07.  Extra command:
 // hashcheck (which hash variant was an index built with).
-// Minimizer indices (.mxi): build -m [-v M], info, read_id.  Not provided (outside the query path): batch_id, read_filter.
+// Minimizer indices (.mxi): build -m [-v M], info, read_id, batch_id.  Not provided (outside the query path): read_filter.
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -337,6 +337,59 @@ int cmd_info(int argc, char **argv) {
     return 0;
 }
 
+// the knobs read_id and batch_id share (main.rs:704-717 and :869-886 read the same flags with the same defaults)
+struct ClassifyFlags {
+    size_t down_sample, batch, bitvector_sample;
+    double fp_correct;
+    uint8_t quality;
+};
+
+ClassifyFlags classify_flags(const Args &a) {
+    ClassifyFlags f;
+    f.down_sample = num_or<size_t>(a, "down_sample", 1);
+    f.fp_correct = std::pow(10.0, -num_or<double>(a, "fp_correct", 3.0));
+    f.quality = num_or<uint8_t>(a, "quality", 15);
+    f.batch = num_or<size_t>(a, "batch", 50000);
+    f.bitvector_sample = num_or<size_t>(a, "bitvector_sample", 3);
+    if (f.down_sample == 0 || f.batch == 0) die("attempt to calculate the remainder with a divisor of zero");
+    return f;
+}
+
+bool one_gpu_run(const Args &a) { return !a.has("gpus") && !a.has("devices") && !a.has("placement") && !getenv("COLORID_REDUCE"); }
+
+// block-gzip input on one GPU goes up compressed and is inflated there (cid_fastq_*)
+bool wants_device_front_end(const Args &a, const std::vector<std::string> &fq) {
+    return ends_with(fq[0], ".gz") && one_gpu_run(a) && read_id_mt_pe::device_fastq_wanted(fq, fq.size() > 1 ? 2 : 1);
+}
+
+// Start reading a sample's files before whoever classifies them asks: gzip decoding (or, for the device front end, reading the
+// compressed members: a stretch or two, the reader's queue) then runs beside GPU start-up and the index load — measured against
+// starting it after the context exists, the classification phase of 1 M reads ends 130 ms earlier — or, in batch_id, beside the
+// tail of the sample before.
+void read_ahead(const std::vector<std::string> &fq, bool device_front_end) {
+    if (!ends_with(fq[0], ".gz")) return;
+    for (size_t i = 0; i < fq.size() && i < 2; ++i) {
+        if (device_front_end)
+            BgzfMemberReader::prefetch(fq[i], read_id_mt_pe::device_fastq_stretch_bytes(0), read_id_mt_pe::device_fastq_host_share(),
+                                       read_id_mt_pe::device_fastq_host_threads(fq.size() > 1 ? 2 : 1));
+        else
+            LineReader::prefetch(fq[i]);
+    }
+}
+
+// one sample through the classifier: PREFIX_reads.txt, then PREFIX_counts.txt from it (main.rs:790-866, read_id_batch.rs:37-95)
+void classify_sample(cid_ctx *ctx, Bigsi &b, const std::vector<std::string> &fq, const std::string &prefix, const ClassifyFlags &f) {
+    if (ends_with(fq[0], ".gz")) {
+        if (fq.size() > 1) read_id_mt_pe::per_read_stream_pe(ctx, fq, b, f.down_sample, f.fp_correct, f.batch, prefix, f.quality, f.bitvector_sample);
+        else read_id_mt_pe::per_read_stream_se(ctx, fq, b, f.down_sample, f.fp_correct, f.batch, prefix, f.quality, f.bitvector_sample);
+    } else {
+        read_id_mt_pe::stream_fasta(ctx, fq, b, f.down_sample, f.fp_correct, f.batch, prefix, f.bitvector_sample);
+    }
+    phase_done("classification");
+    read_counts_five_fields(prefix + "_reads.txt", prefix);
+    phase_done("counts file");
+}
+
 int cmd_read_id(int argc, char **argv) {
     const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'q', "query", true, true}, {'c', "batch", true, false},
                                                      {'t', "threads", true, false}, {'n', "prefix", true, false}, {'d', "down_sample", true, false},
@@ -345,24 +398,11 @@ int cmd_read_id(int argc, char **argv) {
     for (const char *req : {"bigsi", "query", "prefix"})
         if (!a.has(req)) die("error: The following required arguments were not provided: --%s", req);
     const std::vector<std::string> fq = a.values.at("query");
-    const size_t down_sample = num_or<size_t>(a, "down_sample", 1);
-    const double fp_correct = std::pow(10.0, -num_or<double>(a, "fp_correct", 3.0));
-    const uint8_t quality = num_or<uint8_t>(a, "quality", 15);
-    const size_t batch = num_or<size_t>(a, "batch", 50000);
-    const size_t bitvector_sample = num_or<size_t>(a, "bitvector_sample", 3);
+    const ClassifyFlags flags = classify_flags(a);
     const std::string prefix = a.one("prefix");
-    if (down_sample == 0 || batch == 0) die("attempt to calculate the remainder with a divisor of zero");
     if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
-    // gzip decoding starts now and runs beside GPU start-up (~0.2 s) and the index load: measured against starting it after the
-    // context exists, the classification phase of 1 M reads ends 130 ms earlier
-    // (block-gzip input on one GPU goes up compressed and is inflated there, cid_fastq_*: nothing to decode ahead on the host)
-    const bool one_gpu = !a.has("gpus") && !a.has("devices") && !a.has("placement") && !getenv("COLORID_REDUCE");
-    const bool device_front_end = ends_with(fq[0], ".gz") && one_gpu && read_id_mt_pe::device_fastq_wanted(fq, fq.size() > 1 ? 2 : 1);
-    if (ends_with(fq[0], ".gz") && !device_front_end)
-        for (size_t i = 0; i < fq.size() && i < 2; ++i) LineReader::prefetch(fq[i]);
-    if (device_front_end)   // the compressed members are read ahead instead (a stretch or two: the reader's queue), beside GPU start-up and the index load
-        for (size_t i = 0; i < fq.size() && i < 2; ++i) BgzfMemberReader::prefetch(fq[i], read_id_mt_pe::device_fastq_stretch_bytes(0), read_id_mt_pe::device_fastq_host_share(),
-                                       read_id_mt_pe::device_fastq_host_threads(fq.size() > 1 ? 2 : 1));
+    const bool device_front_end = wants_device_front_end(a, fq);
+    read_ahead(fq, device_front_end);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
     std::thread warm = warm_async(gpus, CID_WARM_READID | (device_front_end ? CID_WARM_INFLATE : 0u));
@@ -371,15 +411,48 @@ int cmd_read_id(int argc, char **argv) {
     replicate(gpus, b);
     warm.join();
     phase_done("index load");
-    if (ends_with(fq[0], ".gz")) {
-        if (fq.size() > 1) read_id_mt_pe::per_read_stream_pe(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
-        else read_id_mt_pe::per_read_stream_se(ctx, fq, b, down_sample, fp_correct, batch, prefix, quality, bitvector_sample);
-    } else {
-        read_id_mt_pe::stream_fasta(ctx, fq, b, down_sample, fp_correct, batch, prefix, bitvector_sample);
+    classify_sample(ctx, b, fq, prefix, flags);
+    LineReader::drop_prefetched();
+    BgzfMemberReader::drop_prefetched();
+    release(gpus, b);
+    phase_done("release");
+    return 0;
+}
+
+// batch_id (main.rs:869-888 -> read_id_batch.rs:7-181): a sample sheet `name \t reads1 [\t reads2]`; the index is loaded ONCE and
+// every sample goes through read_id's streamers with the prefix NAME_TAG.  The reference walks its FnvHashMap of samples in
+// hash order; here they go in name order — every sample writes its own two files, so the order shows only on stderr.
+// On this machine the point of the subcommand is the fixed cost: one GPU context and one index upload for the whole sheet,
+// and the next sample's files are read ahead while the current one is classified.
+int cmd_batch_id(int argc, char **argv) {
+    const Args a = parse(argc, argv, 2, with_common({{'b', "bigsi", true, false}, {'q', "query", true, false}, {'T', "tag", true, false},
+                                                     {'c', "batch", true, false}, {'t', "threads", true, false}, {'d', "down_sample", true, false},
+                                                     {'H', "high_mem_load", false, false}, {'p', "fp_correct", true, false},
+                                                     {'Q', "quality", true, false}, {'B', "bitvector_sample", true, false}}));
+    for (const char *req : {"bigsi", "query", "tag"})
+        if (!a.has(req)) die("error: The following required arguments were not provided: --%s", req);
+    const ClassifyFlags flags = classify_flags(a);
+    const std::string tag = a.one("tag");
+    const auto sheet = tab_to_map(a.one("query"));
+    std::vector<std::pair<std::string, std::vector<std::string>>> samples(sheet.begin(), sheet.end());
+    if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
+    std::vector<char> on_device(samples.size(), 0);
+    bool any_on_device = false;
+    for (size_t i = 0; i < samples.size(); ++i) any_on_device |= (on_device[i] = wants_device_front_end(a, samples[i].second));
+    if (!samples.empty()) read_ahead(samples[0].second, on_device[0]);
+    Gpus gpus = make_gpus(a);
+    phase_done("GPU context");
+    std::thread warm = warm_async(gpus, CID_WARM_READID | (any_on_device ? CID_WARM_INFLATE : 0u));
+    cid_ctx *ctx = gpus.ctx;
+    Bigsi b = load_index(ctx, a, false, &gpus);
+    replicate(gpus, b);
+    warm.join();
+    phase_done("index load");
+    for (size_t i = 0; i < samples.size(); ++i) {
+        fprintf(stderr, "Classifying %s\n", samples[i].first.c_str());
+        if (i + 1 < samples.size()) read_ahead(samples[i + 1].second, on_device[i + 1]);
+        classify_sample(ctx, b, samples[i].second, samples[i].first + "_" + tag, flags);
     }
-    phase_done("classification");
-    read_counts_five_fields(prefix + "_reads.txt", prefix);
-    phase_done("counts file");
     LineReader::drop_prefetched();
     BgzfMemberReader::drop_prefetched();
     release(gpus, b);
@@ -463,7 +536,7 @@ int main(int argc, char **argv) {
     // src/main.rs:16-20: init_log() prints this banner on stdout before anything else
     printf("\n ************** initializing logger *****************\n\n");
     if (argc < 2) {
-        fprintf(stderr, "colorid 0.1.4.3 (MI355X)\nUSAGE:\n    colorid <build|search|info|read_id|hashcheck> [FLAGS]\n");
+        fprintf(stderr, "colorid 0.1.4.3 (MI355X)\nUSAGE:\n    colorid <build|search|info|read_id|batch_id|hashcheck> [FLAGS]\n");
         return 1;
     }
     const std::string cmd = argv[1];
@@ -474,6 +547,7 @@ int main(int argc, char **argv) {
     if (cmd == "hashcheck") return cmd_hashcheck(argc, argv);
     if (cmd == "debug-kmers") return cmd_debug_kmers(argc, argv);
     if (cmd == "debug-records") return cmd_debug_records(argc, argv);
-    if (cmd == "batch_id" || cmd == "read_filter") die("'%s' is outside the accelerated query path; use the reference binary", cmd.c_str());
+    if (cmd == "batch_id") return cmd_batch_id(argc, argv);
+    if (cmd == "read_filter") die("'%s' is outside the accelerated query path; use the reference binary", cmd.c_str());
     die("error: Found argument '%s' which wasn't expected", cmd.c_str());
 }

@@ -276,6 +276,62 @@ def test_read_id_fasta(orc, env):
     assert open(prefix + "_reads.txt").read().splitlines() == want
 
 
+def test_batch_id_sample_sheet(orc, env, tmp_path):
+    """batch_id (main.rs:869-888, read_id_batch.rs:7-181): a sheet `name \\t reads1 [\\t reads2]`, the index loaded once, every sample
+    through read_id's streamers under the prefix NAME_TAG: single-stream gzip single-end, block-gzip pairs (the device FASTQ front
+    end), a FASTA sample, a name given twice (the later line wins, build.rs:15-31) — each sample's two files against the oracle and
+    against what `read_id -n` writes for the same files."""
+    from test_linereader_cpu import write_bgzf
+    d, bxi, oix, genomes = env
+    rng = np.random.default_rng(401)
+    se = synth_fastq_records(rng, genomes, 900, 150, mate=0)
+    rng = np.random.default_rng(402)
+    p1 = synth_fastq_records(rng, genomes, 1200, 150, mate=0)
+    rng = np.random.default_rng(402)
+    p2 = synth_fastq_records(rng, genomes, 1200, 150, mate=1)
+    f_se = str(tmp_path / "s_se.fastq.gz")
+    write_fastq_gz(f_se, se, multi_member=True)
+    f_p = []
+    for mate, recs in enumerate((p1, p2)):
+        f = str(tmp_path / f"s_pe_{mate + 1}.fastq.gz")
+        write_bgzf(f, b"".join(b"@" + a[0] + b"\n" + a[1] + b"\n+\n" + a[2] + b"\n" for a in recs), level=6)
+        f_p.append(f)
+    fa = []
+    for i in range(40):
+        g = genomes[i % 4]
+        st = int(rng.integers(0, len(g) - 400))
+        fa.append((f">ctg{i}".encode(), g[st:st + int(rng.integers(30, 400))] + b"\n"))
+    f_fa = str(tmp_path / "s_contigs.fasta")
+    open(f_fa, "wb").write(b"".join(h + b"\n" + body for h, body in fa))
+    sheet = tmp_path / "samples.tsv"
+    sheet.write_text(f"zeta\t{f_fa}\nalpha\t{f_fa}\nmid\t{f_p[0]}\t{f_p[1]}\nalpha\t{f_se}\n")     # alpha: the later line replaces the earlier
+    out, err = run("batch_id", "-b", bxi, "-q", str(sheet), "-T", "run7", "-c", "500", cwd=str(tmp_path))
+    assert [l for l in err.splitlines() if l.startswith("Classifying ")] == ["Classifying alpha", "Classifying mid", "Classifying zeta"]
+    assert err.count("Index loaded in") == 1
+    want = {
+        "alpha": expected_readid(orc, oix, ["@" + r[0].decode() for r in se], [[orc.qual_mask(a[1], a[2], 15)] for a in se], 1, 3),
+        "mid": expected_readid(orc, oix, ["@" + r[0].decode() for r in p1],
+                               [[orc.qual_mask(a[1], a[2], 15), orc.qual_mask(b[1], b[2], 15)] for a, b in zip(p1, p2)], 1, 3),
+        "zeta": expected_readid(orc, oix, [h.decode() for h, _ in fa], [[body] for _, body in fa], 1, 3),
+    }
+    queries = {"alpha": [f_se], "mid": f_p, "zeta": [f_fa]}
+    for name, rows in want.items():
+        got = open(tmp_path / f"{name}_run7_reads.txt").read()
+        assert got.splitlines() == rows
+        counts = open(tmp_path / f"{name}_run7_counts.txt").read()
+        assert sorted(counts.splitlines()) == counts_file(rows)
+        single = str(tmp_path / f"single_{name}")
+        run("read_id", "-b", bxi, "-q", *queries[name], "-n", single, "-c", "500")
+        assert open(single + "_reads.txt").read() == got and open(single + "_counts.txt").read() == counts
+    # a sheet needs -T, and a sample whose file is missing ends the run with an error (the reference panics on the open)
+    p = subprocess.run([BIN, "batch_id", "-b", bxi, "-q", str(sheet)], capture_output=True, text=True)
+    assert p.returncode != 0 and "--tag" in p.stderr
+    bad = tmp_path / "bad.tsv"
+    bad.write_text(f"gone\t{tmp_path}/nothing_here.fastq.gz\n")
+    p = subprocess.run([BIN, "batch_id", "-b", bxi, "-q", str(bad), "-T", "x"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode != 0
+
+
 def test_k_above_32_uses_host_map(orc, env, tmp_path):
     """k > 32 cannot be packed in 64 bits: build / search / read_id use byte-string k-mers — counted on the GPU (sorted on a
     4-bit-per-base image), or in the host map with COLORID_HOST_KMERS=1; read_id takes the LDS byte path."""
