@@ -125,6 +125,13 @@ def test_cli_errors():
     assert p.returncode != 0 and ("GPU" in p.stderr or "index" in p.stderr)
     p = subprocess.run([BIN, "search", "-q", "x.fasta"], capture_output=True, text=True)
     assert p.returncode != 0 and "required" in p.stderr
+    # batch_id (main.rs:329-418): -b, -q and -T are required; a sheet that is not there ends the run before any GPU work
+    p = subprocess.run([BIN, "batch_id", "-b", "/nonexistent.bxi", "-q", "sheet.tsv"], capture_output=True, text=True)
+    assert p.returncode != 0 and "--tag" in p.stderr
+    p = subprocess.run([BIN, "batch_id", "-b", "/nonexistent.bxi", "-q", "/nonexistent_sheet.tsv", "-T", "t"], capture_output=True, text=True)
+    assert p.returncode != 0
+    p = subprocess.run([BIN, "read_filter"], capture_output=True, text=True)
+    assert p.returncode != 0 and "outside the accelerated query path" in p.stderr
 
 
 def test_bxi_loader_rejects_malformed_files(orc, tmp_path):
