@@ -250,6 +250,7 @@ int cid_warmup(cid_ctx *c, unsigned what) {
     if (what & (CID_WARM_READID | CID_WARM_SEARCH)) HIP_TRY(cid::warm_reports());   // sparse report rows / modes: a small code object
     if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_kmerset());                         // the k-mer set's sorts: 18 MB, 0.2 s to load
     if (what & CID_WARM_INFLATE) HIP_TRY(cid::warm_inflate());
+    if (what & CID_WARM_FASTQ) HIP_TRY(cid::warm_fastq());                            // 3.9 MB: its scans and selects are rocPRIM's
     return CID_OK;
 }
 

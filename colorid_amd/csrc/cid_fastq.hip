@@ -138,6 +138,12 @@ __global__ void k_fq_read_seq0(uint64_t *read_seq0, uint64_t n_reads, uint32_t n
     if (r <= n_reads) read_seq0[r] = r * n_files;
 }
 
+// start-up: this unit's code object (its own kernels + rocPRIM's scans and selects) loaded ahead of the first stretch
+hipError_t warm_fastq() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_fq_read_seq0));
+}
+
 }  // namespace cid
 
 struct cid_fastq {

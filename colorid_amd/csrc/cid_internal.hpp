@@ -95,5 +95,6 @@ hipError_t warm_search();
 hipError_t warm_kmerset();
 hipError_t warm_reports();
 hipError_t warm_inflate();
+hipError_t warm_fastq();
 
 }  // namespace cid

@@ -285,12 +285,14 @@ int cmd_search(int argc, char **argv) {
     if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
     // gzip decoding of the first query starts now and runs beside GPU start-up and the index load; a block-gzip query on one GPU goes
     // up compressed instead (cid_fastq_count_kmers: its members are read ahead, the k-mer map is counted from text that never leaves HBM)
+    unsigned warm_what = CID_WARM_SEARCH;
     if (!a.flags.count("perfect_search") && ends_with(files1[0], "gz")) {
         std::vector<std::string> fq{files1[0]};
         if (!files2.empty()) fq.push_back(files2[0]);
         const bool one_gpu = !a.has("gpus") && !a.has("devices") && !a.has("placement") && !getenv("COLORID_REDUCE");
         const bool host_kmers = getenv("COLORID_HOST_KMERS") != nullptr;
         if (one_gpu && !host_kmers && read_id_mt_pe::device_fastq_wanted(fq, fq.size())) {
+            warm_what |= CID_WARM_INFLATE | CID_WARM_FASTQ;
             for (const std::string &f : fq)
                 BgzfMemberReader::prefetch(f, read_id_mt_pe::device_fastq_stretch_bytes(0), read_id_mt_pe::device_fastq_host_share(),
                                            read_id_mt_pe::device_fastq_host_threads(fq.size()));
@@ -300,7 +302,7 @@ int cmd_search(int argc, char **argv) {
     }
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_SEARCH);
+    std::thread warm = warm_async(gpus, warm_what);
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
@@ -405,7 +407,7 @@ int cmd_read_id(int argc, char **argv) {
     read_ahead(fq, device_front_end);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_READID | (device_front_end ? CID_WARM_INFLATE : 0u));
+    std::thread warm = warm_async(gpus, CID_WARM_READID | (device_front_end ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
@@ -442,7 +444,7 @@ int cmd_batch_id(int argc, char **argv) {
     if (!samples.empty()) read_ahead(samples[0].second, on_device[0]);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_READID | (any_on_device ? CID_WARM_INFLATE : 0u));
+    std::thread warm = warm_async(gpus, CID_WARM_READID | (any_on_device ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);

@@ -442,6 +442,7 @@ void cid_fastq_destroy(cid_fastq *);
 #define CID_WARM_READID 1u
 #define CID_WARM_SEARCH 2u
 #define CID_WARM_INFLATE 4u
+#define CID_WARM_FASTQ 8u /* the FASTQ front end (cid_fastq_*): its record / packing kernels and scans */
 int cid_warmup(cid_ctx *, unsigned what);
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */
