@@ -123,6 +123,8 @@ SIGNATURES = {
     "cid_fastq_push_text": (C.c_int, [vp, C.c_int, vp, C.c_size_t, C.c_int]),
     "cid_fastq_classify": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cid_fastq_count_kmers": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_uint64)]),
+    "cid_fastq_classify_begin": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int]),
+    "cid_fastq_classify_end": (C.c_int, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cid_fastq_fetch": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "cid_fastq_destroy": (None, [vp]),
     "cid_timer_start": (C.c_int, [vp]),

@@ -13,6 +13,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
 #include <deque>
 #include <new>
 #include <vector>
@@ -177,9 +178,37 @@ struct cid_fastq {
     uint32_t *d_nk = nullptr;
     uint8_t *d_status = nullptr, *d_ids = nullptr;
     uint64_t *d_id_off = nullptr;
+    // a step in two halves (cid_fastq_classify_begin / _end): everything up to the launch of the classifier, then the report's
+    // compaction — between them the caller's thread is free while the classifier runs (fetch the step before, push the next stretch)
+    struct Inflight {
+        bool active = false, classify = false;
+        uint64_t n = 0, total_ids = 0;
+        uint32_t n_colors = 0;
+        uint64_t boundary[2] = {0, 0};
+        uint32_t *report = nullptr, *nk = nullptr;
+        uint8_t *status = nullptr, *ids = nullptr;
+        uint64_t *id_off = nullptr;
+        std::vector<void *> scratch;   // what the kernels in flight read: back to the cache in _end
+    } infl;
+    hipStream_t fetch_stream = nullptr;   // results leave beside the classifier of the NEXT step, not behind it
+    // CID_FASTQ_TIMING=1: host time per part of a step, printed when the reader is destroyed
+    bool timing = false;
+    double ms_part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t n_steps = 0;
 };
 
 namespace {
+struct PartClock {   // adds the time since its start (or the last lap) to a part of the step
+    cid_fastq *fq;
+    std::chrono::steady_clock::time_point t;
+    explicit PartClock(cid_fastq *f) : fq(f), t(std::chrono::steady_clock::now()) {}
+    void lap(int part) {
+        if (!fq->timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fq->ms_part[part] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+    }
+};
 
 template <typename T>
 struct Buf {   // scoped scratch from the ctx's block cache
@@ -228,6 +257,14 @@ void drop_results(cid_fastq *fq) {
     fq->n_reads = fq->id_bytes = 0;
 }
 
+void drop_inflight(cid_fastq *fq) {   // (after the stream has drained)
+    cid_ctx *c = fq->ctx;
+    cid_fastq::Inflight &in = fq->infl;
+    for (void *p : in.scratch) cid::ctx_free(c, p);
+    cid::ctx_free(c, in.report); cid::ctx_free(c, in.nk); cid::ctx_free(c, in.status); cid::ctx_free(c, in.ids); cid::ctx_free(c, in.id_off);
+    in = cid_fastq::Inflight();
+}
+
 }  // namespace
 
 extern "C" {
@@ -240,10 +277,19 @@ int cid_fastq_create(cid_ctx *c, int n_files, uint32_t quality, cid_fastq **out)
     cid_fastq *fq = new (std::nothrow) cid_fastq();
     if (!fq) return fail(CID_ERR_NOMEM, "fastq");
     fq->ctx = c; fq->n_files = n_files; fq->quality = quality;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&fq->inflate_streams[0], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&fq->inflate_streams[1], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&fq->text_stream, hipStreamNonBlocking) != hipSuccess) {
+    fq->timing = getenv("CID_FASTQ_TIMING") && atoi(getenv("CID_FASTQ_TIMING")) > 0;
+    // the inflate launches run beside the classifier's kernels, which fill every CU: on a queue of the highest priority their few
+    // long-lived waves are placed as soon as a classifier block retires instead of waiting their turn (CID_INFLATE_PRIORITY=0: equal)
+    int prio_low = 0, prio_high = 0;
+    const bool want_prio = !(getenv("CID_INFLATE_PRIORITY") && atoi(getenv("CID_INFLATE_PRIORITY")) == 0);
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_high = 0;
+    const int prio = want_prio ? prio_high : 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithPriority(&fq->inflate_streams[0], hipStreamNonBlocking, prio) != hipSuccess ||
+        hipStreamCreateWithPriority(&fq->inflate_streams[1], hipStreamNonBlocking, prio) != hipSuccess ||
+        hipStreamCreateWithFlags(&fq->text_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&fq->fetch_stream, hipStreamNonBlocking) != hipSuccess) {
         for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamDestroy(st);
+        if (fq->text_stream) (void)hipStreamDestroy(fq->text_stream);
         delete fq;
         return fail(CID_ERR_HIP, "stream creation failed");
     }
@@ -253,18 +299,25 @@ int cid_fastq_create(cid_ctx *c, int n_files, uint32_t quality, cid_fastq **out)
 
 void cid_fastq_destroy(cid_fastq *fq) {
     if (!fq) return;
+    if (fq->timing)
+        fprintf(stderr, "cid_fastq: %llu steps; host ms: waiting for the inflate %.1f, member checks + text append %.1f, line ends + record count %.1f, "
+                "records + scans %.1f, pack + launch of the classifier %.1f, report compaction + drain %.1f, carry %.1f\n", (unsigned long long)fq->n_steps,
+                fq->ms_part[0], fq->ms_part[1], fq->ms_part[2], fq->ms_part[3], fq->ms_part[4], fq->ms_part[5], fq->ms_part[6]);
     cid_ctx *c = fq->ctx;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamSynchronize(st);
     if (fq->text_stream) (void)hipStreamSynchronize(fq->text_stream);
+    if (fq->fetch_stream) (void)hipStreamSynchronize(fq->fetch_stream);
     drop_results(fq);
+    drop_inflight(fq);
     for (int i = 0; i < 2; ++i) {
         cid::ctx_free(c, fq->f[i].text);
         for (cid_fastq::Staged &sg : fq->f[i].staged) free_staged(fq, sg);
     }
     for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamDestroy(st);
     if (fq->text_stream) (void)hipStreamDestroy(fq->text_stream);
+    if (fq->fetch_stream) (void)hipStreamDestroy(fq->fetch_stream);
     delete fq;
 }
 
@@ -368,18 +421,20 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
 // One step over the text pushed so far: whole records -> masked, packed reads in HBM, which go either through read_id's kernels (ix:
 // per-read counts, sparse report, ids kept for cid_fastq_fetch) or into a k-mer set (ks: `search`'s query k-mers, kmer.rs:461-510 /
 // :581-655 — every read of either file, windows with an N dropped, case kept).
-static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint32_t k, uint32_t stride_d, uint32_t start_sample, int max_pushes,
-                      uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes) {
-    *n_reads = *n_entries = *id_bytes = 0;
+// First half of a step: the staged pushes' text joins the file's, lines -> records -> packed reads, and the classifier (or the k-mer
+// set's extraction) is LAUNCHED; nothing here waits for it.
+static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint32_t k, uint32_t stride_d, uint32_t start_sample, int max_pushes) {
     cid_ctx *c = fq->ctx;
+    if (fq->infl.active) return fail(CID_ERR_INVALID, "cid_fastq_classify_begin: the step before has not been ended");
     int rc = ix ? cid::check_ready(c, ix) : CID_OK;
     if (rc) return rc;
     if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    drop_results(fq);
-    c->sp_rows = 0; c->sp_entries = 0;
     const int nf = fq->n_files;
+    cid_fastq::Inflight &in = fq->infl;
+    PartClock pc(fq);
+    ++fq->n_steps;
     // the block-gzip pushes this call takes (per file the oldest max_pushes; <= 0: all): wait for their inflate, check every member as
     // zlib checks it (the first corrupt one is an error), append their text behind what the file holds
     for (int f = 0; f < nf; ++f) {
@@ -390,6 +445,7 @@ static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint3
             if (sg.done) {
                 if (F.copy_pending == sg.done) F.copy_pending = nullptr;
                 hipError_t e = hipEventSynchronize(sg.done);
+                pc.lap(0);
                 if (e == hipSuccess && sg.n_members) {
                     std::vector<uint32_t> h(sg.n_members);
                     e = hipMemcpyAsync(h.data(), sg.d_status, sg.n_members * 4, hipMemcpyDeviceToHost, st);
@@ -414,6 +470,7 @@ static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint3
             free_staged(fq, sg);
         }
     }
+    pc.lap(1);
     // line ends of either text
     Buf<uint32_t> nl[2] = {Buf<uint32_t>(c), Buf<uint32_t>(c)};
     Buf<uint64_t> n_nl(c);
@@ -451,8 +508,10 @@ static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint3
     cid::FqStats hs;
     HIP_TRY(hipMemcpyAsync(&hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    pc.lap(2);
     const uint64_t n = hs.n_rec, n_seqs = n * (uint64_t)nf;
     uint64_t total_bases = 0, total_ids = 0;
+    auto keep = [&in](auto &buf) { if (buf.p) in.scratch.push_back(buf.release()); };
     if (n) {
         if (n >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "more than 2^31 reads in one call: push smaller stretches");
         Buf<cid::FqSpan> span(c);
@@ -476,6 +535,7 @@ static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint3
         HIP_TRY(hipMemcpyAsync(&total_bases, seq_off.p + n_seqs, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&total_ids, id_off.p + n, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        pc.lap(3);
         if (hs.err) return fail(CID_ERR_INVALID, "ERROR: could not get the next nt in the sequence (a quality line longer than its sequence, src/seq.rs:43-45)");
         Buf<uint8_t> bases(c), ids(c), status(c);
         Buf<uint32_t> report(c), nk(c);
@@ -487,6 +547,7 @@ static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint3
             HIP_TRY(hipGetLastError());
             if ((rc = cid_kmerset_add_seqs_dev(ks, bases.p, seq_off.p, n_seqs, hs.max_bytes, 1))) return rc;
             HIP_TRY(hipStreamSynchronize(st));
+            pc.lap(4);
         } else {
         const size_t C1 = (size_t)ix->n_colors + 1;
         if ((double)n * (double)C1 * 4.0 > 64.0 * (double)(1ull << 30))
@@ -503,40 +564,88 @@ static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint3
         rc = cid_readid_count_dev(c, ix, bases.p, seq_off.p, read_seq0.p, n, stride_d, start_sample, hs.max_bytes, hs.max_win ? hs.max_win : 1,
                                   report.p, nk.p, status.p);
         if (rc) return rc;
+        pc.lap(4);
+        in.classify = true;
+        in.n_colors = ix->n_colors;
+        in.report = report.release(); in.nk = nk.release(); in.status = status.release(); in.ids = ids.release(); in.id_off = id_off.release();
+        }
+        // what the kernels in flight still read stays until _end has seen the stream drain
+        keep(span); keep(seq_off); keep(read_seq0); keep(id_off); keep(id_begin); keep(tmp); keep(bases); keep(ids); keep(status); keep(report); keep(nk);
+    }
+    keep(nl[0]); keep(nl[1]); keep(n_nl); keep(stats);
+    in.active = true;
+    in.n = n; in.total_ids = total_ids;
+    for (int f = 0; f < nf; ++f) in.boundary[f] = hs.boundary[f];
+    return CID_OK;
+}
+
+// Second half: the report's sparse rows (the classifier has to be through for their sizes), the results published for cid_fastq_fetch —
+// those of the step before are dropped here, not in _begin — and the unfinished tail of either text carried to the front.
+static int fastq_end(cid_fastq *fq, uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes) {
+    *n_reads = *n_entries = *id_bytes = 0;
+    cid_ctx *c = fq->ctx;
+    cid_fastq::Inflight &in = fq->infl;
+    if (!in.active) return fail(CID_ERR_INVALID, "cid_fastq_classify_end without a begin");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int nf = fq->n_files;
+    int rc = CID_OK;
+    PartClock pc(fq);
+    const uint64_t n = in.n;
+    if (in.classify) {
+        if (fq->fetch_stream) HIP_TRY(hipStreamSynchronize(fq->fetch_stream));   // (a fetch of the step before never outlives its call; belt and braces)
+        drop_results(fq);
         cid::ctx_free(c, c->sp_start); c->sp_start = nullptr;
         cid::ctx_free(c, c->sp_col); c->sp_col = nullptr;
         cid::ctx_free(c, c->sp_cnt); c->sp_cnt = nullptr;
-        rc = cid::compact_report(c, report.p, ix->n_colors + 1, n, &c->sp_start, &c->sp_col, &c->sp_cnt, &c->sp_entries);
-        if (rc) return rc;
+        c->sp_rows = 0; c->sp_entries = 0;
+        rc = cid::compact_report(c, in.report, in.n_colors + 1, n, &c->sp_start, &c->sp_col, &c->sp_cnt, &c->sp_entries);
+        if (rc) { (void)hipStreamSynchronize(st); drop_inflight(fq); return rc; }
         c->sp_rows = n;
-        fq->d_nk = nk.release(); fq->d_status = status.release(); fq->d_ids = ids.release(); fq->d_id_off = id_off.release();
-        fq->n_reads = n; fq->id_bytes = total_ids;
-        HIP_TRY(hipStreamSynchronize(st));   // the scratch above returns to the cache
-        }
+        fq->d_nk = in.nk; fq->d_status = in.status; fq->d_ids = in.ids; fq->d_id_off = in.id_off;
+        in.nk = nullptr; in.status = nullptr; in.ids = nullptr; in.id_off = nullptr;
+        fq->n_reads = n; fq->id_bytes = in.total_ids;
+    } else {
+        drop_results(fq);
+        c->sp_rows = 0; c->sp_entries = 0;
     }
+    HIP_TRY(hipStreamSynchronize(st));   // the scratch of the step returns to the cache
+    pc.lap(5);
+    uint64_t boundary[2] = {in.boundary[0], in.boundary[1]};
+    const uint64_t total_ids = in.total_ids;
+    const bool classified = in.classify;
+    drop_inflight(fq);
     // what is left of either text moves to the front: the next push continues behind it
     for (int f = 0; f < nf; ++f) {
         cid_fastq::File &src = fq->f[f];
-        if (hs.boundary[f] > src.len) hs.boundary[f] = src.len;   // (the line end added at the end of the input sits AT the length)
-        const size_t keep = src.len - (size_t)hs.boundary[f];
-        if (hs.boundary[f] && keep) {
+        if (boundary[f] > src.len) boundary[f] = src.len;   // (the line end added at the end of the input sits AT the length)
+        const size_t left = src.len - (size_t)boundary[f];
+        if (boundary[f] && left) {
             Buf<uint8_t> tmp(c);
-            if ((rc = tmp.alloc(keep))) return rc;
-            HIP_TRY(hipMemcpyAsync(tmp.p, src.text + hs.boundary[f], keep, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(src.text, tmp.p, keep, hipMemcpyDeviceToDevice, st));
+            if ((rc = tmp.alloc(left))) return rc;
+            HIP_TRY(hipMemcpyAsync(tmp.p, src.text + boundary[f], left, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(src.text, tmp.p, left, hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
-        src.len = keep;
+        src.len = left;
     }
     // at the end of EVERY input what is left — lines that do not complete a record; for pairs the longer file's extra records — is
     // dropped: the line loops never push it (read_id_mt_pe.rs:862-895, :927-975: the walk ends with the shorter file)
     bool all_last = true;
     for (int f = 0; f < nf; ++f) all_last = all_last && fq->f[f].last;
     if (all_last) for (int f = 0; f < nf; ++f) fq->f[f].len = 0;
+    pc.lap(6);
     *n_reads = n;
-    *n_entries = ks ? 0 : c->sp_entries;
-    *id_bytes = ks ? 0 : total_ids;
+    *n_entries = classified ? c->sp_entries : 0;
+    *id_bytes = classified ? total_ids : 0;
     return CID_OK;
+}
+
+static int fastq_step(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint32_t k, uint32_t stride_d, uint32_t start_sample, int max_pushes,
+                      uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes) {
+    *n_reads = *n_entries = *id_bytes = 0;
+    const int rc = fastq_begin(fq, ix, ks, k, stride_d, start_sample, max_pushes);
+    return rc ? rc : fastq_end(fq, n_reads, n_entries, id_bytes);
 }
 
 extern "C" {
@@ -545,6 +654,16 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
                        uint64_t *n_entries, uint64_t *id_bytes) {
     if (!fq || !ix || !n_reads || !n_entries || !id_bytes) return fail(CID_ERR_INVALID, "null argument");
     return fastq_step(fq, ix, nullptr, ix->k, stride_d, start_sample, max_pushes, n_reads, n_entries, id_bytes);
+}
+
+int cid_fastq_classify_begin(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, int max_pushes) {
+    if (!fq || !ix) return fail(CID_ERR_INVALID, "null argument");
+    return fastq_begin(fq, ix, nullptr, ix->k, stride_d, start_sample, max_pushes);
+}
+
+int cid_fastq_classify_end(cid_fastq *fq, uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes) {
+    if (!fq || !n_reads || !n_entries || !id_bytes) return fail(CID_ERR_INVALID, "null argument");
+    return fastq_end(fq, n_reads, n_entries, id_bytes);
 }
 
 int cid_fastq_count_kmers(cid_fastq *fq, cid_kmerset *ks, int max_pushes, uint64_t *n_reads) {
@@ -561,12 +680,23 @@ int cid_fastq_fetch(cid_fastq *fq, uint32_t *n_kmers, uint8_t *status, uint64_t 
     if (fq->n_reads == 0) { row_start[0] = 0; return CID_OK; }
     if (!n_kmers || !status || !id_off || !ids) return fail(CID_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    // _end has seen the ctx's stream drain: the results are complete, and they travel on a stream of their own so that a classifier
+    // launched since (cid_fastq_classify_begin of the next step) is not waited for
     const uint64_t n = fq->n_reads;
-    HIP_TRY(hipMemcpyAsync(n_kmers, fq->d_nk, n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(status, fq->d_status, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(id_off, fq->d_id_off, (n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(ids, fq->d_ids, fq->id_bytes, hipMemcpyDeviceToHost, c->stream));
-    return cid_readid_sparse_fetch(c, row_start, colours, counts);   // (synchronises the stream)
+    if (c->sp_rows != n) return fail(CID_ERR_INVALID, "cid_fastq_fetch: another sparse call has replaced this step's report rows");
+    if (c->sp_entries && (!colours || !counts)) return fail(CID_ERR_INVALID, "null argument");
+    hipStream_t fs = fq->fetch_stream;
+    HIP_TRY(hipMemcpyAsync(n_kmers, fq->d_nk, n * 4, hipMemcpyDeviceToHost, fs));
+    HIP_TRY(hipMemcpyAsync(status, fq->d_status, n, hipMemcpyDeviceToHost, fs));
+    HIP_TRY(hipMemcpyAsync(id_off, fq->d_id_off, (n + 1) * 8, hipMemcpyDeviceToHost, fs));
+    HIP_TRY(hipMemcpyAsync(ids, fq->d_ids, fq->id_bytes, hipMemcpyDeviceToHost, fs));
+    HIP_TRY(hipMemcpyAsync(row_start, c->sp_start, (n + 1) * 8, hipMemcpyDeviceToHost, fs));
+    if (c->sp_entries) {
+        HIP_TRY(hipMemcpyAsync(colours, c->sp_col, c->sp_entries * 4, hipMemcpyDeviceToHost, fs));
+        HIP_TRY(hipMemcpyAsync(counts, c->sp_cnt, c->sp_entries * 4, hipMemcpyDeviceToHost, fs));
+    }
+    HIP_TRY(hipStreamSynchronize(fs));
+    return CID_OK;
 }
 
 }  // extern "C"

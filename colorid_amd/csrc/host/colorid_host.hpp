@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <thread>
 #include <mutex>

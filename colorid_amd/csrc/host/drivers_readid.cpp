@@ -279,6 +279,7 @@ class BatchClassifier {
         return rb;
     }
     // the device front end (cid_fastq) hands over batches that are counted already: an empty Counted to fill, and its way to the poll
+    void ids_stay_with_counted(bool on) { std::lock_guard<std::mutex> lk(mu_); ids_stay_ = on; }
     std::unique_ptr<Counted> take_counted() {
         std::lock_guard<std::mutex> lk(mu_);
         if (free_counted_.empty()) return std::unique_ptr<Counted>(new Counted);
@@ -351,10 +352,12 @@ class BatchClassifier {
             poll_batch(b_, *c, fp_correct_, fp_, out_, tally_, tally_ok_);
             n_reads_ += c->rb.size();
             fprintf(stderr, progress_fmt_, (unsigned long long)n_reads_);
-            c->rb.clear();
             std::lock_guard<std::mutex> lk(mu_);
-            if (spare_.size() < 16) spare_.push_back(std::move(c->rb));
-            c->rb = ReadBatch();
+            if (!ids_stay_) {   // (the device front end fills a Counted's ids itself: they stay with it, sized, for the next stretch)
+                c->rb.clear();
+                if (spare_.size() < 16) spare_.push_back(std::move(c->rb));
+                c->rb = ReadBatch();
+            }
             free_counted_.push_back(std::move(c));   // its result vectors keep their capacity for a later batch
         }
     }
@@ -372,7 +375,7 @@ class BatchClassifier {
     std::deque<std::unique_ptr<Counted>> counted_;
     std::vector<std::unique_ptr<Counted>> free_counted_;
     std::vector<ReadBatch> spare_;
-    bool done_ = false, count_done_ = false;
+    bool done_ = false, count_done_ = false, ids_stay_ = false;
     uint64_t n_reads_ = 0;   // the polling thread's, read by finish() after the join
     std::map<std::string, uint64_t> tally_;   // (label or "reject") -> reads, for <prefix>_counts.txt
     bool tally_ok_ = true;
@@ -443,6 +446,7 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
     const auto t_enter = Clock::now();
     cid_fastq *fr = nullptr;
     CID_TRY(cid_fastq_create(ctx, (int)n_files, qual_offset, &fr));
+    classifier.ids_stay_with_counted(true);
     const size_t target = read_id_mt_pe::device_fastq_stretch_bytes(b.colors.size());
     std::unique_ptr<BgzfMemberReader> rd[2];
     for (size_t i = 0; i < n_files; ++i)   // (reading since before the index load, main.cpp)
@@ -455,7 +459,7 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
     size_t turn[2] = {0, 0};
     bool more[2] = {true, n_files == 2};
     size_t pending[2] = {0, 0};   // stretches pushed and not yet taken by a classify call
-    double ms_read = 0, ms_push = 0, ms_classify = 0, ms_fetch = 0;
+    double ms_read = 0, ms_push = 0, ms_classify = 0, ms_fetch = 0, ms_buffers = 0, ms_handover = 0;
     auto push_next = [&](size_t i) {
         if (!more[i]) return;
         const auto tr = Clock::now();
@@ -477,44 +481,67 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
     auto t_gpu = Clock::now();
     for (size_t i = 0; i < n_files; ++i) push_next(i);
     const double ms_setup = ms_since(t_enter);
+    // One step = cid_fastq_classify_begin (records cut and packed, the classifier launched) ... cid_fastq_classify_end (its report
+    // compacted).  Between the two the classifier runs for ~10 ms per stretch and this thread has the GPU-free work to do: fetching
+    // the results of the step BEFORE (they stay valid until the next _end, and travel on a stream of their own) and pushing the
+    // stretch after the next.  Done the other way round — classify, fetch, push, in a row — the GPU idled ~5 ms of every 18.
     bool first = true;
-    while (pending[0] || pending[1]) {
-        for (size_t i = 0; i < n_files; ++i)   // the stretches after this one: inflated while this one is classified
-            while (more[i] && pending[i] < ahead + 1) push_next(i);
-        uint64_t n = 0, ne = 0, idb = 0;
-        const auto tc = Clock::now();
-        const int rc = cid_fastq_classify(fr, b.index, (uint32_t)d, (uint32_t)start_sample, 2, &n, &ne, &idb);
-        ms_classify += ms_since(tc);
-        for (size_t i = 0; i < n_files; ++i) if (pending[i]) --pending[i];
-        if (rc == CID_ERR_UNSUPPORTED && first) {
-            fprintf(stderr, "note: %s — using the host front end\n", cid_last_error());
-            cid_fastq_destroy(fr);
-            return false;
+    uint64_t have_n = 0, have_ne = 0, have_idb = 0;   // an ended step whose results are still on the device
+    bool have = false;
+    for (;;) {
+        for (size_t i = 0; i < n_files; ++i)   // (only the start: ahead + 1 stretches on their way before the first step)
+            while (first && more[i] && pending[i] < ahead + 1) push_next(i);
+        const bool begin = pending[0] || pending[1];
+        if (begin) {
+            const auto tc = Clock::now();
+            const int rc = cid_fastq_classify_begin(fr, b.index, (uint32_t)d, (uint32_t)start_sample, 2);
+            ms_classify += ms_since(tc);
+            for (size_t i = 0; i < n_files; ++i) if (pending[i]) --pending[i];
+            if (rc == CID_ERR_UNSUPPORTED && first) {
+                fprintf(stderr, "note: %s — using the host front end\n", cid_last_error());
+                cid_fastq_destroy(fr);
+                classifier.ids_stay_with_counted(false);
+                return false;
+            }
+            if (rc != CID_OK) die("%s%s", cid_last_error(), rc == CID_ERR_UNSUPPORTED ? " (rerun with COLORID_DEVICE_FASTQ=0)" : "");
+            first = false;
         }
-        if (rc != CID_OK) die("%s%s", cid_last_error(), rc == CID_ERR_UNSUPPORTED ? " (rerun with COLORID_DEVICE_FASTQ=0)" : "");
-        g_ms_gpu_count += ms_since(t_gpu);
-        first = false;
-        if (n) {
+        if (have && have_n) {
+            const auto tb = Clock::now();
             std::unique_ptr<Counted> c = classifier.take_counted();
-            c->rb.clear();
-            c->nk.resize(n); c->status.resize(n); c->row_start.resize(n + 1); c->colours.resize(ne); c->counts.resize(ne);
-            c->rb.id_off.resize(n + 1);
-            c->rb.id_chars.resize(idb);
+            c->rb.bases.clear(); c->rb.seq_off.assign(1, 0); c->rb.read_seq0.assign(1, 0);   // (the ids keep their size: a recycled batch is not filled with zeros again)
+            c->nk.resize(have_n); c->status.resize(have_n); c->row_start.resize(have_n + 1); c->colours.resize(have_ne); c->counts.resize(have_ne);
+            c->rb.id_off.resize(have_n + 1);
+            c->rb.id_chars.resize(have_idb);
             const auto tf = Clock::now();
+            ms_buffers += ms_since(tb);
             CID_TRY(cid_fastq_fetch(fr, c->nk.data(), c->status.data(), c->row_start.data(), c->colours.data(), c->counts.data(), c->rb.id_off.data(),
                                     &c->rb.id_chars[0]));
             ms_fetch += ms_since(tf);
-            c->rb.id_off.resize(n);   // (ReadBatch counts its reads by the ids)
-            g_entries += ne;
-            g_ms_gpu += ms_since(t_gpu);
+            c->rb.id_off.resize(have_n);   // (ReadBatch counts its reads by the ids)
+            g_entries += have_ne;
+            const auto th = Clock::now();
             classifier.push_counted(std::move(c));
-        } else g_ms_gpu += ms_since(t_gpu);
+            ms_handover += ms_since(th);
+        }
+        have = false;
+        for (size_t i = 0; i < n_files; ++i)   // the stretches after this one: inflated while this one is classified
+            while (more[i] && pending[i] < ahead + 1) push_next(i);
+        if (!begin) break;
+        const auto tc = Clock::now();
+        const int rc = cid_fastq_classify_end(fr, &have_n, &have_ne, &have_idb);
+        ms_classify += ms_since(tc);
+        if (rc != CID_OK) die("%s", cid_last_error());
+        have = true;
+        g_ms_gpu_count += ms_since(t_gpu);
+        g_ms_gpu += ms_since(t_gpu);
         t_gpu = Clock::now();
     }
     cid_fastq_destroy(fr);
     if (g_timing)
-        fprintf(stderr, "timing: device front end: waiting for the file reader %.0f ms, push (H2D of the members) %.0f ms, classify %.0f ms, fetch %.0f ms; "
-                "%.0f ms until the first stretch was pushed, %.0f ms in all\n", ms_read, ms_push, ms_classify, ms_fetch, ms_setup, ms_since(t_enter));
+        fprintf(stderr, "timing: device front end: waiting for the file reader %.0f ms, push (H2D of the members) %.0f ms, classify %.0f ms, fetch %.0f ms "
+                "(+ %.0f ms sizing its buffers), handing the rows to the poll %.0f ms; %.0f ms until the first stretch was pushed, %.0f ms in all\n",
+                ms_read, ms_push, ms_classify, ms_fetch, ms_buffers, ms_handover, ms_setup, ms_since(t_enter));
     return true;
 }
 }  // namespace

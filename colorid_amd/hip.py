@@ -613,6 +613,23 @@ class FastqReader:
         the oldest max_pushes waiting block-gzip pushes; 0 = all)"""
         n, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         check(self.lib.cid_fastq_classify(self.h, index.h, d, start_sample, max_pushes, C.byref(n), C.byref(ne), C.byref(nb)))
+        return self._fetch(n, ne, nb)
+
+    def classify_begin(self, index, d=1, start_sample=3, max_pushes=0):
+        """first half of classify: records cut and packed, the classifier launched; the results of the step before stay fetchable"""
+        check(self.lib.cid_fastq_classify_begin(self.h, index.h, d, start_sample, max_pushes))
+
+    def classify_end(self):
+        """second half: -> (n_reads, n_entries, id_bytes) of the step; fetch() then returns its results"""
+        n, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.cid_fastq_classify_end(self.h, C.byref(n), C.byref(ne), C.byref(nb)))
+        return n, ne, nb
+
+    def fetch(self, sizes):
+        """the results of the last ended step (sizes: what classify_end returned), as classify returns them"""
+        return self._fetch(*sizes)
+
+    def _fetch(self, n, ne, nb):
         nk = np.zeros(n.value, np.uint32)
         st = np.zeros(n.value, np.uint8)
         rs = np.zeros(n.value + 1, np.uint64)

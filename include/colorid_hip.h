@@ -416,6 +416,12 @@ int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t 
  *                      Corrupt members -> CID_ERR_INVALID naming the first one; a quality line longer than its sequence ->
  *                      CID_ERR_INVALID (the reference's "could not get the next nt" panic); reads that do not fit a wave's LDS
  *                      (several kilobases) -> CID_ERR_UNSUPPORTED: classify such input through cid_readid_count_sparse.
+ *        classify_begin / classify_end   the same step in two halves, for a caller that has something to do while the classifier runs:
+ *                      _begin takes the pushes, cuts and packs the records and LAUNCHES the classifier; _end waits for it, compacts
+ *                      the report and publishes the step's results (sizes as classify returns them).  Between the two the caller
+ *                      may push the next stretch and fetch the step BEFORE: a step's results stay fetchable until the next _end,
+ *                      and fetch travels on a stream of its own (it does not wait for the classifier in flight).  One step in flight
+ *                      at a time: _begin, then _end; classify = _begin + _end.
  *        fetch         n_kmers / status [n_reads], row_start [n_reads + 1] + colours / counts [n_entries] as cid_readid_sparse_fetch
  *                      gives them, id_off [n_reads + 1] and ids [id_bytes]: read r's header line (with its '@'), NUL-terminated,
  *                      at ids + id_off[r].
@@ -435,6 +441,8 @@ int cid_fastq_push_bgzf(cid_fastq *, int file, const uint8_t *members, size_t n_
 int cid_fastq_push_text(cid_fastq *, int file, const uint8_t *text, size_t n_bytes, int flags);
 int cid_fastq_classify(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
                        uint64_t *n_entries, uint64_t *id_bytes);
+int cid_fastq_classify_begin(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes);
+int cid_fastq_classify_end(cid_fastq *, uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes);
 int cid_fastq_count_kmers(cid_fastq *, cid_kmerset *set, int max_pushes, uint64_t *n_reads);
 int cid_fastq_fetch(cid_fastq *, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,
                     char *ids);

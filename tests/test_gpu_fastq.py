@@ -108,6 +108,47 @@ def test_text_pushed_in_pieces_single_end(orc, hip_ctx, world, eol, last_newline
         fr.close()
 
 
+def test_step_in_two_halves_keeps_the_results_of_the_step_before(orc, hip_ctx, world):
+    """cid_fastq_classify_begin / _end: the results of step i are fetched AFTER step i + 1 has begun (its classifier in flight, more text
+    pushed meanwhile) and still are step i's; fetched twice they are the same; _end without _begin and two _begins in a row are errors."""
+    import colorid_amd
+    oix, hx, genomes = world
+    rng = np.random.default_rng(77)
+    recs = synth_fastq_records(rng, genomes, 1500, 150, lower_rate=0.0)
+    text = fastq_text(recs)
+    want_ids, want, _ = expected(orc, hx, [text], 15, 1, 3)
+    fr = colorid_amd.FastqReader(hip_ctx, 1, 15)
+    with pytest.raises(colorid_amd.CidError):
+        fr.classify_end()
+    cuts = sorted(rng.integers(0, len(text), 5).tolist()) + [len(text)]
+    acc = {"ids": [], "nk": [], "st": [], "rows": []}
+
+    def take(sizes):
+        ids, nk, st, rs, col, cnt = fr.fetch(sizes)
+        again = fr.fetch(sizes)
+        assert again[0] == ids and all(np.array_equal(a, b) for a, b in zip(again[1:], (nk, st, rs, col, cnt)))
+        acc["ids"] += ids
+        acc["nk"].append(nk); acc["st"].append(st)
+        for r in range(len(ids)):
+            acc["rows"].append(list(zip(col[int(rs[r]):int(rs[r + 1])].tolist(), cnt[int(rs[r]):int(rs[r + 1])].tolist())))
+
+    fr.push_text(0, text[:cuts[0]])
+    pending = None
+    for j in range(len(cuts)):
+        fr.classify_begin(hx, 1, 3)
+        if j == 0:
+            with pytest.raises(colorid_amd.CidError):
+                fr.classify_begin(hx, 1, 3)
+        if j + 1 < len(cuts):
+            fr.push_text(0, text[cuts[j]:cuts[j + 1]], last=(j + 2 == len(cuts)))     # the next piece goes up while the step is in flight
+        if pending is not None:
+            take(pending)                                                                # the step BEFORE, fetched beside this one's classifier
+        pending = fr.classify_end()
+    take(pending)
+    check_equal(acc, want_ids, want)
+    fr.close()
+
+
 @pytest.mark.parametrize("q,d,S", [(15, 1, 3), (0, 2, 0), (20, 1, 5)])
 def test_pairs_from_two_files(orc, hip_ctx, world, q, d, S):
     import colorid_amd
