@@ -1,5 +1,7 @@
 // C ABI of libcolorid_hip.so (see include/colorid_hip.h), part 1: errors, contexts and their scratch memory, per-context tunables,
 // warm-up and timers.  Host-side plumbing only — there is no CPU compute path in this library.
+#include <mutex>
+
 #include "cid_api_common.hpp"
 
 using cid::fail;
@@ -74,6 +76,30 @@ int ctx_order_bits(const cid_ctx *c) { return c->tune.order_bits; }
 int ctx_n_cu(const cid_ctx *c) { return c->n_cu; }
 hipStream_t ctx_own_stream(const cid_ctx *c) { return c->own_stream; }
 hipStream_t ctx_copy_stream(const cid_ctx *c) { return c->copy_stream; }
+
+hipError_t ctx_side_streams(cid_ctx *c, hipStream_t out[4]) {
+    static std::mutex mu;   // (the warm-up thread and the thread that creates the reader may both come first)
+    std::lock_guard<std::mutex> lk(mu);
+    if (!c->side_streams[3]) {
+        hipError_t e = hipSetDevice(c->device);
+        if (e != hipSuccess) return e;
+        // the inflate launches run beside the classifier's kernels, which fill every CU: on a queue of the highest priority their few
+        // long-lived waves are placed as soon as a classifier block retires instead of waiting their turn (CID_INFLATE_PRIORITY=0: equal)
+        int prio_low = 0, prio_high = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_high = 0;
+        const bool want_prio = !(getenv("CID_INFLATE_PRIORITY") && atoi(getenv("CID_INFLATE_PRIORITY")) == 0);
+        hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+            e = i < 2 ? hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, want_prio ? prio_high : 0) : hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (hipStream_t x : s) if (x) (void)hipStreamDestroy(x);
+            return e;
+        }
+        for (int i = 0; i < 4; ++i) c->side_streams[i] = s[i];
+    }
+    for (int i = 0; i < 4; ++i) out[i] = c->side_streams[i];
+    return hipSuccess;
+}
 hipEvent_t ctx_event(const cid_ctx *c, int i) { return i == 0 ? c->ev_copied[0] : c->ev_done[0]; }
 
 int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
@@ -199,6 +225,7 @@ void cid_ctx_destroy(cid_ctx *c) {
         if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
     }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (hipStream_t s : c->side_streams) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -250,6 +277,7 @@ int cid_warmup(cid_ctx *c, unsigned what) {
     if (what & (CID_WARM_READID | CID_WARM_SEARCH)) HIP_TRY(cid::warm_reports());   // sparse report rows / modes: a small code object
     if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_kmerset());                         // the k-mer set's sorts: 18 MB, 0.2 s to load
     if (what & CID_WARM_INFLATE) HIP_TRY(cid::warm_inflate());
+    if (what & CID_WARM_FASTQ) { hipStream_t s[4]; HIP_TRY(cid::ctx_side_streams(c, s)); }
     if (what & CID_WARM_FASTQ) HIP_TRY(cid::warm_fastq());                            // 3.9 MB: its scans and selects are rocPRIM's
     return CID_OK;
 }

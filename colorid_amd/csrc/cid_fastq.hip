@@ -278,21 +278,12 @@ int cid_fastq_create(cid_ctx *c, int n_files, uint32_t quality, cid_fastq **out)
     if (!fq) return fail(CID_ERR_NOMEM, "fastq");
     fq->ctx = c; fq->n_files = n_files; fq->quality = quality;
     fq->timing = getenv("CID_FASTQ_TIMING") && atoi(getenv("CID_FASTQ_TIMING")) > 0;
-    // the inflate launches run beside the classifier's kernels, which fill every CU: on a queue of the highest priority their few
-    // long-lived waves are placed as soon as a classifier block retires instead of waiting their turn (CID_INFLATE_PRIORITY=0: equal)
-    int prio_low = 0, prio_high = 0;
-    const bool want_prio = !(getenv("CID_INFLATE_PRIORITY") && atoi(getenv("CID_INFLATE_PRIORITY")) == 0);
-    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_high = 0;
-    const int prio = want_prio ? prio_high : 0;
-    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithPriority(&fq->inflate_streams[0], hipStreamNonBlocking, prio) != hipSuccess ||
-        hipStreamCreateWithPriority(&fq->inflate_streams[1], hipStreamNonBlocking, prio) != hipSuccess ||
-        hipStreamCreateWithFlags(&fq->text_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&fq->fetch_stream, hipStreamNonBlocking) != hipSuccess) {
-        for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamDestroy(st);
-        if (fq->text_stream) (void)hipStreamDestroy(fq->text_stream);
+    hipStream_t side[4];
+    if (cid::ctx_side_streams(c, side) != hipSuccess) {
         delete fq;
         return fail(CID_ERR_HIP, "stream creation failed");
     }
+    fq->inflate_streams[0] = side[0]; fq->inflate_streams[1] = side[1]; fq->text_stream = side[2]; fq->fetch_stream = side[3];
     *out = fq;
     return CID_OK;
 }
@@ -315,10 +306,7 @@ void cid_fastq_destroy(cid_fastq *fq) {
         cid::ctx_free(c, fq->f[i].text);
         for (cid_fastq::Staged &sg : fq->f[i].staged) free_staged(fq, sg);
     }
-    for (hipStream_t st : fq->inflate_streams) if (st) (void)hipStreamDestroy(st);
-    if (fq->text_stream) (void)hipStreamDestroy(fq->text_stream);
-    if (fq->fetch_stream) (void)hipStreamDestroy(fq->fetch_stream);
-    delete fq;
+    delete fq;   // (the side streams are the context's)
 }
 
 // A push of either kind waits its turn as a Staged entry: the bytes travel on the reader's own stream, the text is appended by the

@@ -96,5 +96,6 @@ hipError_t warm_kmerset();
 hipError_t warm_reports();
 hipError_t warm_inflate();
 hipError_t warm_fastq();
+hipError_t ctx_side_streams(cid_ctx *c, hipStream_t out[4]);   // created on first use; any thread
 
 }  // namespace cid

@@ -51,6 +51,9 @@ struct cid_ctx {
     // second stream + events for the host-pointer entry points: the H2D copy of chunk i+1 runs beside the kernel of chunk i
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    // the FASTQ front end's side streams (two for inflate launches, on a queue of the highest priority; text up; results down): made once
+    // per context — a priority queue costs ~15 ms to create — by cid_warmup(CID_WARM_FASTQ) or the first cid_fastq_create
+    hipStream_t side_streams[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct cid_index {

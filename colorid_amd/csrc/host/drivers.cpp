@@ -164,7 +164,9 @@ static bool count_bgzf_on_device(cid_ctx *ctx, cid_kmerset *ks, const std::vecto
         if (!got) { more[i] = false; return; }
         const auto tp = Clock::now();
         const bool host_part = sx.host_text_bytes > 0;
-        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), sx.bytes.size(), sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
+        // (only the device's members travel: they come first in the stretch; the rest was inflated here)
+        const size_t dev_bytes = sx.device_members ? (size_t)sx.off[sx.device_members - 1] + sx.len[sx.device_members - 1] : 0;
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
                                     sx.last && !host_part ? CID_FASTQ_LAST : 0));
         if (host_part)
             CID_TRY(cid_fastq_push_text(fr, (int)i, sx.host_text.p, sx.host_text_bytes, (sx.last ? CID_FASTQ_LAST : 0) | (sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));

@@ -429,7 +429,9 @@ double read_id_mt_pe::device_fastq_host_share() {
     // a host thread inflates ~0.7 GB/s of text, the device ~10 GB/s beside the classification it also runs: with the eight threads a
     // 16-CPU share leaves, an even split keeps both sides busy (16 M reads, tools/exp_frontend_16m.sh: 0.71-0.73 s at share 0.5, 0.84-0.90 s
     // with the host inflating everything, 0.89-0.96 s with the device inflating everything; host front end 1.02-1.21 s)
-    const double v = (double)device_fastq_host_threads(1) * 0.0625;
+    // (round 3, after the step was cut in two halves and the GPU side of a stretch fell to 13 ms: the host's half had become what the
+    // loop waited for — 16 M reads 0.44-0.51 s at 0.5, 0.41-0.44 s at 0.3, tools/exp_frontend_poll.sh)
+    const double v = (double)device_fastq_host_threads(1) * 0.0375;
     return v > 1.0 ? 1.0 : v;
 }
 int read_id_mt_pe::device_fastq_host_threads(size_t n_files) {
@@ -470,7 +472,9 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
         const auto tp = Clock::now();
         // the device's members first, then the text the reader's threads inflated (two pushes: classify takes both)
         const bool host_part = sx.host_text_bytes > 0;
-        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), sx.bytes.size(), sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
+        // (only the device's members travel: they come first in the stretch; the rest was inflated here)
+        const size_t dev_bytes = sx.device_members ? (size_t)sx.off[sx.device_members - 1] + sx.len[sx.device_members - 1] : 0;
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
                                     sx.last && !host_part ? CID_FASTQ_LAST : 0));
         if (host_part)
             CID_TRY(cid_fastq_push_text(fr, (int)i, sx.host_text.p, sx.host_text_bytes, (sx.last ? CID_FASTQ_LAST : 0) | (sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));
@@ -554,7 +558,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 1);
-    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(4, cpu_budget() / 4));   // no packing threads beside them
+    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));   // no packing threads beside them: a stretch's poll on 4 threads takes 18 ms, the GPU side 13
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
     if (g_timing) fprintf(stderr, "timing: %.0f ms of set-up before the first read\n", ms_since(t0));
     if (!on_device || !classify_bgzf_on_device(ctx, fq, 1, b, d, start_sample, qual_offset, classifier))
@@ -581,7 +585,7 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 2);
-    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(4, cpu_budget() / 4));
+    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
     if (!on_device || !classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, classifier))
     stream_fastq_records(fq[0], &fq[1], qual_offset, true, [&](ReadBatch &&piece) {
