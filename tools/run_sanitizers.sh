@@ -64,6 +64,9 @@ for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
   $B search -b $W/ix.bxi -q $W/b_1.fastq.gz -r $W/b_2.fastq.gz -f 0 -p 0.01 > $W/sb.out 2> $W/sb.err; echo "search block gzip rc=$?"; cut -f2- $W/sb.out | sort > $W/sb.sorted; $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 2> /dev/null | cut -f2- | sort | cmp - $W/sb.sorted && echo "same report as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/sb.err | head -5
   printf "reads\t$W/b_1.fastq.gz\t$W/b_2.fastq.gz\ngenome0\t$W/g0.fasta\n" > $W/refs_fq.tsv
   $B build -s 2000000 -n 3 -k 27 -b $W/ixfq -r $W/refs_fq.tsv > $W/bfq.out 2> $W/bfq.err; echo "build from block gzip rc=$?"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/bfq.err | head -5
+  # batch_id: a sheet of three samples (gzip stream, block-gzip pair through the device front end with the next sample read ahead, FASTA), one index load
+  printf "$W/s_gz\t$W/r_1.fastq.gz\n$W/s_bgzf\t$W/b_1.fastq.gz\t$W/b_2.fastq.gz\n$W/s_fa\t$W/g0.fasta\n" > $W/sheet.tsv   # (a sample's name is the prefix of its files)
+  $B batch_id -b $W/ix.bxi -q $W/sheet.tsv -T san -c 5000 > $W/bid.out 2> $W/bid.err; echo "batch_id rc=$?"; cmp $W/rid_reads.txt $W/s_bgzf_san_reads.txt && echo "batch_id: the pair's rows as read_id wrote them"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/bid.err | head -5
   unset COLORID_DEVICE_FASTQ_MB
   $B hashcheck -b $W/ix.bxi -r $W/refs.tsv > $W/h.out 2> $W/h.err; echo "hashcheck rc=$?"; grep verdict $W/h.out; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/h.err | head -5
 done
