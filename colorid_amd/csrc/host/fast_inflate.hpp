@@ -247,6 +247,7 @@ class FastInflate {
     }
 
     enum Mode { kHeader, kStored, kHuff, kDone };
+  public:   // the tables' layout and their builder are shared with the block-parallel decoder (par_gunzip.hpp)
     static constexpr uint32_t kLitBits = 11, kDistBits = 8, kPreBits = 7;
     static constexpr uint32_t kLitEntries = 2048 + 4096, kDistEntries = 256 + 2048, kPreEntries = 128;
     // entry: bits 0..7 = bits this look-up uses up — the code's, and for lengths and distances their extra bits too (0: no such code); then one of
@@ -282,7 +283,7 @@ class FastInflate {
     // canonical Huffman code -> two-level table (index = the next bits of the stream, first bit lowest).  zlib's rules: over-subscribed
     // sets are refused; an incomplete set is accepted only as ONE code of length 1 (never for the code-length code); an empty distance
     // set is fine.  Entries no code reaches read "0 bits": the decoder reports them as invalid codes.
-    bool build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t tbits, uint32_t cap, bool litlen, bool pre = false) {
+    static bool build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t tbits, uint32_t cap, bool litlen, bool pre = false) {
         const uint32_t invalid = litlen ? kSpecial : 0u;
         uint32_t count[16] = {0};
         for (uint32_t s = 0; s < n; ++s) count[lens[s]]++;
@@ -341,6 +342,7 @@ class FastInflate {
         return true;
     }
 
+  private:
     uint64_t bitbuf_ = 0;
     uint32_t bitcnt_ = 0;
     Mode mode_ = kHeader;

@@ -20,6 +20,7 @@
 
 #include "colorid_host.hpp"
 #include "fast_inflate.hpp"
+#include "par_gunzip.hpp"
 
 namespace colorid {
 
@@ -266,6 +267,10 @@ struct LineReader::Impl {
         bool have_blk = false, first = true;
         const bool use_fast = !(getenv("COLORID_FAST_INFLATE") && atoi(getenv("COLORID_FAST_INFLATE")) == 0);   // 0: zlib's inflate
         FastInflate fz;
+        // COLORID_PAR_GZIP=0: one thread decodes a gzip stream (FastInflate) as before
+        bool par_on = use_fast && gz_threads >= 3 && !(getenv("COLORID_PAR_GZIP") && atoi(getenv("COLORID_PAR_GZIP")) == 0);
+        int par_small = 0;
+        std::unique_ptr<TaskPool> par_pool;
         std::vector<char> hist(32768);
         size_t hist_n = 0;
         // With the fast decoder the CRC-32 of the text (a tenth of the decoding thread's time even at libdeflate's speed) runs on a thread of
@@ -349,7 +354,50 @@ struct LineReader::Impl {
             inflateReset(&zs);
             uint32_t crc = 0;
             uint64_t total = 0;
-            if (use_fast) {   // the member's DEFLATE stream through FastInflate (fast_inflate.hpp): 1.6x zlib's inflate on FASTQ text
+            if (use_fast && par_on) {
+                // the member's DEFLATE stream on gz_threads threads (par_gunzip.hpp: chunks that find a block boundary of their own and decode
+                // from it with the text before them unknown, put right in order afterwards).  The text's CRC-32 stays with the CRC thread.
+                if (!par_pool) par_pool.reset(new TaskPool(gz_threads - 1));
+                ParallelInflate pi((size_t)1 << 20, (size_t)gz_threads * 2);
+                bool stopped = false;
+                auto reader = [&](uint8_t *dst, size_t cap) -> size_t { return fread(dst, 1, cap, raw); };
+                auto sink = [&](const uint8_t *t, size_t n) -> bool {
+                    while (n) {
+                        if (!have_blk) {
+                            if (!take_free(blk)) { stopped = true; return false; }
+                            blk.resize(kHead + kBlock);
+                            got = 0;
+                            have_blk = true;
+                        }
+                        const size_t k = std::min(n, kBlock - got);
+                        memcpy(blk.data() + kHead + got, t, k);
+                        got += k; t += k; n -= k; total += k;
+                        if (got == kBlock) {
+                            pieces.push_back(CrcPiece{piece_start, got - piece_start, false, 0});
+                            flush_block(false);
+                        }
+                    }
+                    return true;
+                };
+                auto pfor = [&](size_t n, const std::function<void(size_t)> &fn) { par_pool->parallel_for(n, fn); };
+                auto no_crc = [](uint32_t, const uint8_t *, size_t) -> uint32_t { return 0; };
+                auto no_comb = [](uint32_t, uint32_t, uint64_t) -> uint32_t { return 0; };
+                const bool ok = pi.run(in.buf.data() + in.pos, in.avail(), reader, sink, pfor, no_crc, no_comb);
+                if (stopped) { inflateEnd(&zs); return; }
+                if (!ok) die("corrupt gzip member (inflate failed: %s)", pi.error());
+                if (getenv("COLORID_TIMING"))
+                    fprintf(stderr, "timing: gzip member of %llu bytes of text decoded on %d threads: %llu chunks in %llu rounds, %llu started inside the stream and were taken, "
+                            "%llu stretches decoded again serially\n", (unsigned long long)pi.total(), gz_threads, (unsigned long long)pi.stats.chunks,
+                            (unsigned long long)pi.stats.rounds, (unsigned long long)pi.stats.accepted, (unsigned long long)pi.stats.serial);
+                // what was read beyond the stream (the trailer, the members behind it) goes back to the reader
+                const std::vector<uint8_t> &rest = pi.leftover();
+                in.buf.assign(std::max<size_t>(rest.size() + (1u << 20), 2u << 20) + RawIn::kPad, 0);
+                if (!rest.empty()) memcpy(in.buf.data(), rest.data(), rest.size());
+                in.pos = 0; in.end = rest.size(); in.eof = false;
+                hist_n = 0;
+                // a file of many small members gains nothing here (each one's chunks start from scratch): the serial decoder takes over
+                if (pi.stats.rounds <= 1 && ++par_small >= 4) par_on = false;
+            } else if (use_fast) {   // the member's DEFLATE stream through FastInflate (fast_inflate.hpp): 1.6x zlib's inflate on FASTQ text
                 fz.reset();
                 for (;;) {
                     if (!have_blk) {

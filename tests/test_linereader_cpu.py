@@ -149,3 +149,44 @@ def test_linereader_single_stream_gzip_containers(shim, tmp_path):
         for env in ({}, {"COLORID_FAST_INFLATE": "0"}):
             r = subprocess.run([shim, str(p), "view"], capture_output=True, text=True, env=dict(os.environ, **env))
             assert r.returncode == 101 and ("gzip member" in r.stderr), (tag, env, r.returncode, r.stderr[-200:])
+
+
+def test_linereader_single_stream_gzip_on_several_threads(shim, tmp_path):
+    """par_gunzip.hpp inside LineReader (COLORID_GZ_THREADS >= 3): a gzip stream of several rounds of chunks, at two levels; the same
+    text as three members (one of them small); bytes behind the last member; against the serial decoder (COLORID_PAR_GZIP=0) and the
+    plain text.  A flipped byte, a wrong CRC-32 and a cut file are reported as by the serial decoder."""
+    rng = np.random.default_rng(21)
+    n = 260_000
+    L = 100
+    seqs = rng.choice(np.frombuffer(b"ACGT", np.uint8), (n, L))
+    quals = rng.integers(35, 74, (n, L)).astype(np.uint8)
+    text = b"".join(b"@r%d\n" % i + seqs[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n" for i in range(n))      # ~56 MB: ~30 MB compressed
+    plain = tmp_path / "big.fastq"
+    plain.write_bytes(text)
+    want = subprocess.run([shim, str(plain)], capture_output=True, text=True, check=True).stdout
+
+    def member(data, level):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return b"\x1f\x8b\x08\0\0\0\0\0\0\xff" + co.compress(data) + co.flush() + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+    cut1, cut2 = len(text) // 2, len(text) // 2 + 70_000
+    blobs = {"one_l1": member(text, 1), "one_l6": member(text, 6),
+             "three": member(text[:cut1], 6) + member(text[cut1:cut2], 1) + member(text[cut2:], 6) + b"\0" * 11 + b"trailing"}
+    par = dict(os.environ, COLORID_GZ_THREADS="4")
+    for tag, blob in blobs.items():
+        p = tmp_path / f"{tag}.fastq.gz"
+        p.write_bytes(blob)
+        for env in (par, dict(par, COLORID_PAR_GZIP="0")):
+            r = subprocess.run([shim, str(p)], capture_output=True, text=True, env=dict(env, COLORID_TIMING="1"))
+            assert r.returncode == 0 and r.stdout == want, (tag, env.get("COLORID_PAR_GZIP"), r.stderr[-200:])
+            taken = [int(l.split(" rounds, ")[1].split()[0]) for l in r.stderr.splitlines() if "decoded on 4 threads" in l]
+            assert (sum(taken) >= 10) == ("COLORID_PAR_GZIP" not in env), (tag, taken)
+    good = blobs["one_l6"]
+    bad = bytearray(good); bad[len(good) // 2] ^= 0x40
+    crc = bytearray(good); crc[-8] ^= 1
+    for tag, blob in (("flip", bytes(bad)), ("crc", bytes(crc)), ("cut", good[:len(good) - 20]), ("cut_half", good[:len(good) // 2])):
+        p = tmp_path / f"bad_{tag}.fastq.gz"
+        p.write_bytes(blob)
+        for env in (par, dict(par, COLORID_PAR_GZIP="0")):
+            r = subprocess.run([shim, str(p)], capture_output=True, text=True, env=env)
+            assert r.returncode == 101 and ("gzip member" in r.stderr), (tag, env.get("COLORID_PAR_GZIP"), r.returncode, r.stderr[-200:])
