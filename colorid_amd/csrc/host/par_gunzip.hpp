@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
@@ -314,6 +315,7 @@ class ParallelInflate {
         std::vector<uint8_t> window;               // the last <= 32 KiB of the text so far
         crc_ = 0; total_ = 0; left_.clear(); error_.clear();
         const size_t round_bytes = chunk_ * n_chunks_;
+        std::future<bool> delivery;   // (its destructor waits: no exit of this function leaves the thread behind)
         std::vector<Seg> segs(n_chunks_);
         std::vector<MarkerInflate> dec(n_chunks_);
         std::vector<RawBuf<uint16_t>> scratch(n_chunks_);
@@ -436,6 +438,8 @@ class ParallelInflate {
                 while (j < nt && segs[j].start != at && !(segs[j].start != ~(uint64_t)0 && segs[j].start > at)) ++j;
             }
             // ---- the round's text: markers replaced, narrowed, summed — on the threads — then out, in order
+            // (the text of the round before may still be on its way to the sink: its buffers are written next)
+            if (delivery.valid() && !delivery.get()) { error_ = "stopped"; return false; }
             if (text_.size() < pieces.size()) text_.resize(pieces.size());
             std::vector<uint32_t> sums(pieces.size());
             pfor(pieces.size(), [&](size_t i) {
@@ -448,15 +452,22 @@ class ParallelInflate {
                 else for (size_t x = 0; x < sg.n; ++x) t[x] = resolve(o[x], wb);
                 sums[i] = crc32(0, t, sg.n);
             });
+            std::vector<size_t> lens(pieces.size());
             for (size_t i = 0; i < pieces.size(); ++i) {
-                const size_t n = pieces[i].seg->n;
-                crc_ = crc_combine(crc_, sums[i], n);
-                total_ += n;
-                if (n && !sink(text_[i].data(), n)) { error_ = "stopped"; return false; }
+                lens[i] = pieces[i].seg->n;
+                crc_ = crc_combine(crc_, sums[i], lens[i]);
+                total_ += lens[i];
             }
+            // the round's text leaves on a thread of its own (the sink may wait for whoever takes it) while the next round is decoded
+            delivery = std::async(std::launch::async, [this, lens, &sink]() -> bool {
+                for (size_t i = 0; i < lens.size(); ++i)
+                    if (lens[i] && !sink(text_[i].data(), lens[i])) return false;
+                return true;
+            });
             window = windows.back();
             in.resize(n_in);
             if (stream_end) {
+                if (!delivery.get()) { error_ = "stopped"; return false; }
                 const size_t used = (size_t)((at + 7) >> 3);
                 left_.assign(in.begin() + (std::ptrdiff_t)std::min(used, n_in), in.end());
                 return true;
