@@ -269,7 +269,7 @@ struct LineReader::Impl {
         FastInflate fz;
         // COLORID_PAR_GZIP=0: one thread decodes a gzip stream (FastInflate) as before
         // threads: COLORID_GZ_THREADS, else half of the CPUs the process may use, at most 8 (a gzip stream has no packing-heavy BGZF batches
-        // beside it; measured on a 16-CPU share, 4 M reads: 1.14-1.18 s on 5 threads, 0.79-0.81 s on 8, serial 1.86-1.93 s, zlib 2.8-2.95 s)
+        // beside it; measured on a 16-CPU share, 4 M reads: 1.14-1.18 s on 5 threads, 0.61-0.62 s on 8, serial 1.79-1.93 s, zlib 2.8-2.95 s)
         const int par_threads = getenv("COLORID_GZ_THREADS") ? gz_threads : std::min(8, std::max(gz_threads, cpu_budget() / 2));
         bool par_on = use_fast && par_threads >= 3 && !(getenv("COLORID_PAR_GZIP") && atoi(getenv("COLORID_PAR_GZIP")) == 0);
         int par_small = 0;

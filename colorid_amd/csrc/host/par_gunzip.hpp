@@ -316,18 +316,33 @@ class ParallelInflate {
         crc_ = 0; total_ = 0; left_.clear(); error_.clear();
         const size_t round_bytes = chunk_ * n_chunks_;
         std::future<bool> delivery;   // (its destructor waits: no exit of this function leaves the thread behind)
+        std::future<std::vector<uint8_t>> ahead;
+        auto read_more = [&]() {   // a round's worth of compressed bytes behind `in`: what was read ahead, else from the reader now
+            if (ahead.valid()) {
+                const std::vector<uint8_t> v = ahead.get();
+                if (v.empty()) eof = true;
+                in.insert(in.end(), v.begin(), v.end());
+                return;
+            }
+            const size_t at = in.size();
+            in.resize(at + round_bytes);
+            const size_t n = reader(in.data() + at, round_bytes);
+            in.resize(at + n);
+            if (n == 0) eof = true;
+        };
         std::vector<Seg> segs(n_chunks_);
         std::vector<MarkerInflate> dec(n_chunks_);
         std::vector<RawBuf<uint16_t>> scratch(n_chunks_);
         for (;;) {
             // ---- fill: a round's worth of compressed bytes behind what is left of the round before
-            while (!eof && in.size() < round_bytes + chunk_) {
-                const size_t at = in.size();
-                in.resize(at + round_bytes);
-                const size_t n = reader(in.data() + at, round_bytes);
-                in.resize(at + n);
-                if (n == 0) eof = true;
-            }
+            while (!eof && in.size() < round_bytes + chunk_) read_more();
+            // (the next round's bytes are read while this one is decoded: the file is read by one thread at 3-4 GB/s, a sixth of a round)
+            if (!eof && !ahead.valid())
+                ahead = std::async(std::launch::async, [&reader, round_bytes]() {
+                    std::vector<uint8_t> v(round_bytes);
+                    v.resize(reader(v.data(), round_bytes));
+                    return v;
+                });
             const size_t n_in = in.size();
             in.resize(n_in + 64, 0);   // (padding the decoders may read)
             ++stats.rounds;
@@ -470,6 +485,7 @@ class ParallelInflate {
                 if (!delivery.get()) { error_ = "stopped"; return false; }
                 const size_t used = (size_t)((at + 7) >> 3);
                 left_.assign(in.begin() + (std::ptrdiff_t)std::min(used, n_in), in.end());
+                if (ahead.valid()) { const std::vector<uint8_t> v = ahead.get(); left_.insert(left_.end(), v.begin(), v.end()); }
                 return true;
             }
             if (!progress) {
@@ -479,11 +495,7 @@ class ParallelInflate {
                 const size_t drop0 = (size_t)(at >> 3);
                 in.erase(in.begin(), in.begin() + (std::ptrdiff_t)drop0);
                 start_bit = at & 7;
-                const size_t at0 = in.size();
-                in.resize(at0 + round_bytes);
-                const size_t n = reader(in.data() + at0, round_bytes);
-                in.resize(at0 + n);
-                if (n == 0) eof = true;
+                read_more();
                 continue;
             }
             // ---- carry: the bytes from the boundary on
