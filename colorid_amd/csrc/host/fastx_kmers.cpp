@@ -145,6 +145,7 @@ static const LibDeflate &libdeflate() { static const LibDeflate l; return l; }
 // uncompressed sizes are in their trailers).  Single-stream gzip has no such boundaries and stays on one zlib thread.
 // COLORID_TIMING: how long the decoding threads of all readers stood still because their consumer had not taken the blocks before
 static std::atomic<uint64_t> g_reader_blocked_us{0};
+static std::atomic<int> g_gzip_streams{0};   // gzip-stream readers alive: the mates of a pair share the threads their streams are decoded on
 double LineReader::blocked_ms() { return (double)g_reader_blocked_us.load() / 1e3; }
 
 struct LineReader::Impl {
@@ -268,9 +269,12 @@ struct LineReader::Impl {
         const bool use_fast = !(getenv("COLORID_FAST_INFLATE") && atoi(getenv("COLORID_FAST_INFLATE")) == 0);   // 0: zlib's inflate
         FastInflate fz;
         // COLORID_PAR_GZIP=0: one thread decodes a gzip stream (FastInflate) as before
-        // threads: COLORID_GZ_THREADS, else half of the CPUs the process may use, at most 8 (a gzip stream has no packing-heavy BGZF batches
-        // beside it; measured on a 16-CPU share, 4 M reads: 1.14-1.18 s on 5 threads, 0.61-0.62 s on 8, serial 1.79-1.93 s, zlib 2.8-2.95 s)
-        const int par_threads = getenv("COLORID_GZ_THREADS") ? gz_threads : std::min(8, std::max(gz_threads, cpu_budget() / 2));
+        // threads: COLORID_GZ_THREADS, else as many as the process has CPUs (at most 16), shared between the gzip streams open at once (the
+        // mates of a pair) — they run in lockstep with idle stretches, beside the packing and polling threads: measured on a 16-CPU share,
+        // 4 M reads with forty quality letters, 0.64-0.67 s on 8 threads, 0.50-0.57 s on 12, 0.46-0.48 s on 16 (serial 1.8-1.9 s, zlib
+        // 2.8-2.95 s); 4 M pairs 0.67-0.68 s on 8 + 8, 1.18-1.30 s on 4 + 4
+        struct Alive { ~Alive() { --g_gzip_streams; } } alive;   // (counted in at open_stream)
+        int par_threads = getenv("COLORID_GZ_THREADS") ? gz_threads : std::min(16, std::max(gz_threads, cpu_budget()));
         bool par_on = use_fast && par_threads >= 3 && !(getenv("COLORID_PAR_GZIP") && atoi(getenv("COLORID_PAR_GZIP")) == 0);
         int par_small = 0;
         std::unique_ptr<TaskPool> par_pool;
@@ -360,7 +364,10 @@ struct LineReader::Impl {
             if (use_fast && par_on) {
                 // the member's DEFLATE stream on gz_threads threads (par_gunzip.hpp: chunks that find a block boundary of their own and decode
                 // from it with the text before them unknown, put right in order afterwards).  The text's CRC-32 stays with the CRC thread.
-                if (!par_pool) par_pool.reset(new TaskPool(par_threads - 1));
+                if (!par_pool) {   // (the first member's body: both readers of a pair exist by now)
+                    if (!getenv("COLORID_GZ_THREADS")) par_threads = std::max(3, par_threads / std::max(1, g_gzip_streams.load()));
+                    par_pool.reset(new TaskPool(par_threads - 1));
+                }
                 ParallelInflate pi((size_t)1 << 20, (size_t)par_threads * 2);
                 bool stopped = false;
                 auto reader = [&](uint8_t *dst, size_t cap) -> size_t { return fread(dst, 1, cap, raw); };
@@ -644,6 +651,7 @@ static LineReader::Impl *open_stream(const std::string &path, bool ahead) {
     if (libdeflate().ok && LineReader::Impl::is_gzip(path)) {   // zlib's raw inflate + libdeflate's CRC-32 (run_gzip)
         p->raw = fopen(path.c_str(), "rb");
         if (!p->raw) die("file not found: %s", path.c_str());
+        ++g_gzip_streams;   // (run_gzip counts itself out)
         p->worker = std::thread([p] { p->run_gzip(); });
         return p;
     }
