@@ -141,7 +141,6 @@ class MarkerInflate {
             // ---- the block's symbols (the loop of FastInflate::body, sixteen bits a symbol: the next entry is looked up one step ahead, up
             // to three literals go on one refill, matches are copied eight symbols at a time)
             {
-                bool block_end = false;
                 refill();
                 uint32_t e = litlen_[bitbuf & ((1u << FastInflate::kLitBits) - 1)];
                 for (;;) {
@@ -187,13 +186,11 @@ class MarkerInflate {
                             if (e & FastInflate::kSpecial) {   // end of block (sub-tables do not nest) or an unused code
                                 if ((e & 0xFFu) == 0) return fail("invalid literal/length code");
                                 bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu);
-                                block_end = true;
                                 break;
                             }
                         } else {
                             if ((e & 0xFFu) == 0) return fail("invalid literal/length code");
                             bitbuf >>= (e & 0xFFu); bitcnt -= (e & 0xFFu);
-                            block_end = true;
                             break;
                         }
                     }
@@ -223,7 +220,6 @@ class MarkerInflate {
                         o = end;
                     }
                 }
-                (void)block_end;
             }
             if (past_end()) { oc.r = kNeedInput; return oc; }
             if (final) {
