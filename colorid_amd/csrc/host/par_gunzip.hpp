@@ -18,6 +18,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <future>
 #include <memory>
@@ -394,8 +395,7 @@ class ParallelInflate {
                 for (size_t i = from; i < sg.n; ++i) wn.push_back(resolve(o[i], wb));
                 windows.push_back(std::move(wn));
             };
-            std::vector<Seg> extra;   // serial re-decodes (kept alive until the round's text has left)
-            extra.reserve(nt + 2);
+            std::deque<Seg> extra;    // serial re-decodes (a deque: the round's pieces point at them, and there may be any number)
             size_t j = 0;
             bool progress = false;
             while (j < nt && !stream_end) {
@@ -419,8 +419,8 @@ class ParallelInflate {
                     if (segs[j].start == at) continue;
                 }
                 if (j == 0 && !usable && sg.oc.r == MarkerInflate::kError) { error_ = sg.oc.error; return false; }
-                if (j == 0 && !usable && sg.oc.r == MarkerInflate::kOutputFull) { error_ = "internal: a block's text does not fit its buffer"; return false; }
-                if (j == 0 && !usable) break;   // kNeedInput without a whole block: more input (or a bigger round) is needed
+                // (chunk 0 with a block whose text does not fit its buffer — long runs of one letter — goes to the serial branch, which grows it)
+                if (j == 0 && !usable && sg.oc.r != MarkerInflate::kOutputFull) break;   // kNeedInput without a whole block: more input (or a bigger round) is needed
                 // decode serially from `at` to the next start behind it (or as far as the input goes)
                 uint64_t stop = ~(uint64_t)0;
                 size_t k = j;
@@ -428,14 +428,18 @@ class ParallelInflate {
                 extra.emplace_back();
                 Seg &ex = extra.back();
                 const size_t span = (size_t)(((stop == ~(uint64_t)0 ? (uint64_t)n_in * 8 : stop) - at) >> 3) + 1;
-                const size_t cap = span * 8 + (2u << 20);
-                ex.out.need(MarkerInflate::kWindow + cap);
-                uint16_t *o = ex.out.data() + MarkerInflate::kWindow;
+                size_t cap = span * 8 + (2u << 20);
                 const std::vector<uint8_t> &wb = windows.back();
-                for (size_t i = 0; i < wb.size(); ++i) o[-(std::ptrdiff_t)wb.size() + (std::ptrdiff_t)i] = wb[i];
                 ex.start = at;
-                ex.oc = dec[0].decode(in.data(), n_in, at, stop, o, cap, wb.size(), false);
-                ex.n = ex.oc.n_out;
+                for (;;) {   // (a single block of long matches can hold megabytes of text: the buffer grows until one fits)
+                    ex.out.need(MarkerInflate::kWindow + cap);
+                    uint16_t *o = ex.out.data() + MarkerInflate::kWindow;
+                    for (size_t i = 0; i < wb.size(); ++i) o[-(std::ptrdiff_t)wb.size() + (std::ptrdiff_t)i] = wb[i];
+                    ex.oc = dec[0].decode(in.data(), n_in, at, stop, o, cap, wb.size(), false);
+                    ex.n = ex.oc.n_out;
+                    if (ex.oc.r != MarkerInflate::kOutputFull || ex.n > 0 || cap >= ((size_t)1 << 30)) break;
+                    cap *= 4;
+                }
                 ++stats.serial;
                 if (ex.oc.r == MarkerInflate::kError) { error_ = ex.oc.error; return false; }
                 if (ex.oc.r == MarkerInflate::kOutputFull && ex.n == 0) { error_ = "internal: a block's text does not fit its buffer"; return false; }

@@ -104,3 +104,16 @@ def test_parallel_inflate_refuses_what_zlib_refuses(shim, tmp_path):
             zlib.decompress(blob, -15)
         p, got = run(shim, tmp_path, blob, 65536, 4, 2, 1 << 20)
         assert p.returncode == 2
+
+
+def test_parallel_inflate_long_runs(shim, tmp_path):
+    """Text that compresses a thousandfold: single blocks hold megabytes of text (a buffer sized by the compressed span does not take one —
+    it grows), a round of chunks is decoded again serially many times over (more serial stretches than chunks)."""
+    for text in ((b"ACGT" * 50 + b"\n") * 60_000, b"A" * 9_000_000, b"@r\n" + b"N" * 6_000_000 + b"\n+\n" + b"#" * 6_000_000 + b"\n"):
+        for level in (1, 6):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            raw = co.compress(text) + co.flush()
+            for chunk, nc, th in ((65536, 4, 3), (65536, 2, 2), (200000, 8, 4)):
+                p, got = run(shim, tmp_path, raw + b"12345678", chunk, nc, th, 1 << 20)
+                assert p.returncode == 0, (len(text), level, chunk, p.stderr[-300:])
+                assert got == text and int(p.stdout.split()[5]) == 8, (len(text), level, chunk)
