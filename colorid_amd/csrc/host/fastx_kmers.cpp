@@ -368,7 +368,10 @@ struct LineReader::Impl {
                     if (!getenv("COLORID_GZ_THREADS")) par_threads = std::max(3, par_threads / std::max(1, g_gzip_streams.load()));
                     par_pool.reset(new TaskPool(par_threads - 1));
                 }
-                ParallelInflate pi((size_t)1 << 20, (size_t)par_threads * 2);
+                // (COLORID_GZ_CHUNK_KB / COLORID_GZ_CHUNKS_PER_THREAD: the experiment's knobs)
+                const size_t chunk_kb = getenv("COLORID_GZ_CHUNK_KB") ? (size_t)atol(getenv("COLORID_GZ_CHUNK_KB")) : 1024;
+                const size_t per_thread = getenv("COLORID_GZ_CHUNKS_PER_THREAD") ? (size_t)atol(getenv("COLORID_GZ_CHUNKS_PER_THREAD")) : 2;
+                ParallelInflate pi(chunk_kb << 10, (size_t)par_threads * (per_thread ? per_thread : 1));
                 bool stopped = false;
                 auto reader = [&](uint8_t *dst, size_t cap) -> size_t { return fread(dst, 1, cap, raw); };
                 auto sink = [&](const uint8_t *t, size_t n) -> bool {
