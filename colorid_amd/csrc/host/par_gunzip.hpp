@@ -47,6 +47,27 @@ class MarkerInflate {
     // text_only: a literal that is not printable ASCII / tab / line end fails the decode (a wrong start dies quickly on FASTQ text)
     Outcome decode(const uint8_t *buf, size_t n_bytes, uint64_t start_bit, uint64_t stop_bit, uint16_t *out, size_t out_cap, size_t back, bool text_only,
                    size_t max_blocks = ~(size_t)0) {
+        // the same loop compiled twice, as FastInflate's: with BMI2 where the CPU has it
+        static const bool bmi2 = __builtin_cpu_supports("bmi2") != 0;
+        return bmi2 ? decode_bmi2(buf, n_bytes, start_bit, stop_bit, out, out_cap, back, text_only, max_blocks)
+                    : decode_plain(buf, n_bytes, start_bit, stop_bit, out, out_cap, back, text_only, max_blocks);
+    }
+
+    static bool text_byte(uint32_t b) { return (b >= 32 && b < 127) || b == '\n' || b == '\r' || b == '\t'; }
+    struct TextTable { bool ok[256]; TextTable() { for (uint32_t b = 0; b < 256; ++b) ok[b] = text_byte(b); } bool operator[](uint32_t b) const { return ok[b]; } };
+    static inline const TextTable kText{};
+
+  private:
+    Outcome decode_plain(const uint8_t *buf, size_t n_bytes, uint64_t start_bit, uint64_t stop_bit, uint16_t *out, size_t out_cap, size_t back, bool text_only,
+                         size_t max_blocks) {
+        return decode_body(buf, n_bytes, start_bit, stop_bit, out, out_cap, back, text_only, max_blocks);
+    }
+    __attribute__((target("bmi2"))) Outcome decode_bmi2(const uint8_t *buf, size_t n_bytes, uint64_t start_bit, uint64_t stop_bit, uint16_t *out, size_t out_cap,
+                                                       size_t back, bool text_only, size_t max_blocks) {
+        return decode_body(buf, n_bytes, start_bit, stop_bit, out, out_cap, back, text_only, max_blocks);
+    }
+    __attribute__((always_inline)) inline Outcome decode_body(const uint8_t *buf, size_t n_bytes, uint64_t start_bit, uint64_t stop_bit, uint16_t *out, size_t out_cap,
+                                                              size_t back, bool text_only, size_t max_blocks) {
         Outcome oc;
         const uint8_t *in = buf + (start_bit >> 3);
         const uint8_t *const in_end = buf + n_bytes;
@@ -232,11 +253,6 @@ class MarkerInflate {
         }
     }
 
-    static bool text_byte(uint32_t b) { return (b >= 32 && b < 127) || b == '\n' || b == '\r' || b == '\t'; }
-    struct TextTable { bool ok[256]; TextTable() { for (uint32_t b = 0; b < 256; ++b) ok[b] = text_byte(b); } bool operator[](uint32_t b) const { return ok[b]; } };
-    static inline const TextTable kText{};
-
-  private:
     uint32_t litlen_[FastInflate::kLitEntries], dist_[FastInflate::kDistEntries], pre_[FastInflate::kPreEntries];
 };
 
