@@ -12,8 +12,14 @@ index   : synthetic: Bernoulli(p) background bits, p = 1 - exp(
 step    : one pass of the hot path over the rank's whole k-mer batch (+ the RCCL all-reduce of the 3*C
           per-colour counters when N > 1).  N > 1: reads are sharded over ranks, the index is replicated.
 
-Launch: `python bench.py [--gpus 1]`, or for N > 1
-        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`.
+Launch: `python bench.py [--gpus N]` — for N > 1 without a launcher (WORLD_SIZE unset) this process starts N fresh children
+        itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`
+        as a subprocess, decided before anything here touches the GPU), relays rank 0's JSON line and exits with the children's
+        code; fewer than N devices => exit 2 with a one-line reason.  The driver's own torch.distributed.run launch works as before.
+        BENCH_BACKEND=gloo (default nccl = RCCL over xGMI): the exchange steps go through host memory and the ranks may share
+        a device (rank r uses device r mod device_count) — how tests/test_gpu_bench_launch.py runs the N > 1 branches on one GPU.
+        --emulate-world W (one rank): the same W shards / stripes, searched one after the other by one rank; its `counters`
+        digest must equal the W-rank run's.
 """
 import argparse
 import json
@@ -88,6 +94,9 @@ def parse_args():
     ap.add_argument("--stripe-colours", type=int, default=512)
     ap.add_argument("--stripe-log2-bloom", type=int, default=30)
     ap.add_argument("--stripe-hashes", type=int, default=3)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one rank stands in for W: the index holds all W shards' plants (or all W stripes) and the W shards are searched "
+                         "one after the other into the same counters; the `counters` digest equals the W-rank run's (the N > 1 test)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -188,64 +197,163 @@ def fill_background_fast(dev, mat_ptr, m, rs, n_colours, p, seed, digits=8):
     return q / (1 << digits)
 
 
-def box_clocks():
-    """Current sclk / mclk / fclk of the first GPU, read from sysfs (the pool's boxes differ by a few per cent on the same binary):
-    the hwmon frequency inputs where the driver has them, else the starred level of pp_dpm_*.  No child process: this process has
-    initialised the GPU (and may run under rocprofv3's preload), where spawning `rocm-smi` — a `#!/usr/bin/env python3` script —
-    is the exec hop the GPU boxes forbid."""
+def gpu_sysfs_dir(device_index):
+    """/sys/bus/pci/devices/<bus id> of HIP device `device_index` (hipDeviceGetPCIBusId): a box shows the sysfs nodes of all of the
+    host's cards, but only the one this process was given is under load — `card0` is usually somebody else's idle GPU."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = ctypes.create_string_buffer(64)
+    if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+        return None
+    path = os.path.join("/sys/bus/pci/devices", buf.value.decode().lower())
+    return path if os.path.isdir(path) else None
+
+
+def box_clocks(sysfs_dir):
+    """Current sclk / mclk / fclk (MHz) of the card at `sysfs_dir`: the hwmon frequency inputs where the driver has them, else the
+    starred level of pp_dpm_*.  No child process: this process has initialised the GPU (and may run under rocprofv3's preload),
+    where spawning `rocm-smi` — a `#!/usr/bin/env python3` script — is the exec hop the GPU boxes forbid."""
     import glob
     import re
     out = {}
-    try:
-        for path in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq*_input")):
-            try:
-                with open(path) as f:
-                    hz = int(f.read().strip())
-                with open(path.replace("_input", "_label")) as f:
-                    label = f.read().strip()
-            except (OSError, ValueError):
-                continue
-            out.setdefault(f"{label}_mhz", round(hz / 1e6))
-        for name in ("sclk", "mclk", "fclk"):
-            if f"{name}_mhz" in out:
-                continue
-            for path in sorted(glob.glob(f"/sys/class/drm/card*/device/pp_dpm_{name}")):
-                with open(path) as f:
-                    cur = [ln for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
-                if cur:
-                    mhz = re.search(r"(\d+)\s*mhz", cur[0], re.I)
-                    out[f"{name}_mhz"] = int(mhz.group(1)) if mhz else cur[0].strip()
-                    break
-    except OSError as e:  # best effort, never fails the bench
-        out["error"] = str(e)[:80]
-    return out or {"error": "no clock files under /sys/class/drm"}
+    for path in sorted(glob.glob(os.path.join(sysfs_dir, "hwmon/hwmon*/freq*_input"))):
+        try:
+            with open(path) as f:
+                hz = int(f.read().strip())
+            with open(path.replace("_input", "_label")) as f:
+                label = f.read().strip()
+        except (OSError, ValueError):
+            continue
+        out.setdefault(label, round(hz / 1e6))
+    for name in ("sclk", "mclk", "fclk"):
+        if name in out:
+            continue
+        try:
+            with open(os.path.join(sysfs_dir, f"pp_dpm_{name}")) as f:
+                cur = [ln for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
+        except OSError:
+            continue
+        if cur:
+            mhz = re.search(r"(\d+)\s*mhz", cur[0], re.I)
+            if mhz:
+                out[name] = int(mhz.group(1))
+    return out
 
 
-def clocks_under_load(launch_async):
-    """box_clocks() read WHILE untimed launches of the hot kernel are in flight (an idle GPU reports its parked clocks; the
-    management firmware's reading lags the load by some tens of milliseconds)."""
-    for _ in range(12):
-        launch_async()
-    time.sleep(0.06)
-    clocks = box_clocks()
-    torch.cuda.synchronize()
-    return clocks
+class ClockSampler:
+    """Samples box_clocks() of THIS process's card from a thread while the timed steps run (an idle GPU reports its parked clocks,
+    and the management firmware's reading lags the load by some tens of milliseconds: one reading after the loop says nothing).
+    result(): per clock the median and the maximum over the samples taken under load, and how many there were."""
+
+    def __init__(self, device_index, period_s=0.01):
+        import threading
+        self.dir = None
+        try:
+            self.dir = gpu_sysfs_dir(device_index)
+        except OSError:
+            pass
+        self.period, self.samples, self._stop = period_s, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True) if self.dir else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            c = box_clocks(self.dir)
+            if c:
+                self.samples.append(c)
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._t:
+            self._t.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._t:
+            self._t.join()
+
+    def result(self):
+        if not self.dir:
+            return {"error": "no sysfs node for this HIP device"}
+        if not self.samples:
+            return {"error": f"no clock files under {self.dir}"}
+        out = {"sysfs": self.dir, "samples_under_load": len(self.samples)}
+        for name in sorted({k for c in self.samples for k in c}):
+            v = sorted(c[name] for c in self.samples if name in c)
+            out[f"{name}_mhz"] = {"median": v[len(v) // 2], "max": v[-1]}
+        return out
 
 
-def per_rank_times(dev, world, kernel_ms, collective_ms, step_ms):
-    """[{rank, kernel_ms, collective_ms, step_ms}] over all ranks (rank 0 prints them): a scaling loss can be attributed to the
-    kernel (slower box, HBM placement), to the collective (xGMI / RCCL) or to neither (launch gaps, the barrier)."""
-    mine = torch.tensor([kernel_ms, collective_ms, step_ms], dtype=torch.float64, device=dev)
+def host_collective(dev):
+    """The device small bookkeeping tensors of the collectives live on: RCCL ("nccl") wants device tensors; gloo (BENCH_BACKEND=gloo,
+    the one-GPU rehearsal of the N > 1 branches) reduces / gathers host tensors."""
+    return torch.device("cpu") if dist.is_initialized() and dist.get_backend() == "gloo" else dev
+
+
+def per_rank_times(dev, world, kernel_ms, collective_ms, step_ms, kmers):
+    """[{rank, kmers, kernel_ms, collective_ms, step_ms}] over all ranks (rank 0 prints them): a scaling loss can be attributed to
+    the kernel (slower box, HBM placement), to the collective (xGMI / RCCL) or to neither (launch gaps, the barrier)."""
+    mine = torch.tensor([kernel_ms, collective_ms, step_ms, float(kmers)], dtype=torch.float64, device=host_collective(dev))
     if world > 1:
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
     else:
         allr = [mine]
-    return [{"rank": r, "kernel_ms": round(float(t[0]), 4), "collective_ms": round(float(t[1]), 4), "step_ms": round(float(t[2]), 4)}
-            for r, t in enumerate(allr)]
+    return [{"rank": r, "kmers": int(t[3]), "kernel_ms": round(float(t[0]), 4), "collective_ms": round(float(t[1]), 4),
+             "step_ms": round(float(t[2]), 4)} for r, t in enumerate(allr)]
 
 
-def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
+def max_over_ranks(dev, world, seconds):
+    el = torch.tensor([seconds], dtype=torch.float64, device=host_collective(dev))
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item())
+
+
+def counters_digest(*tensors):
+    """sha256 over the per-accession counters of the last step + their sums: a W-rank run and `--emulate-world W` must agree."""
+    import hashlib
+    h = hashlib.sha256()
+    sums = []
+    for t in tensors:
+        a = t.detach().cpu().numpy().astype(np.int64)
+        h.update(a.tobytes())
+        sums.append(int(a.sum()))
+    return {"sha256": h.hexdigest(), "sums": sums}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD `torch.distributed.run` (this process has
+    not touched the GPU: torch.cuda.device_count() does not initialise it), pass rank 0's JSON line through, return the exit code."""
+    import socket
+    import subprocess
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (backend == "nccl" and ndev < a.gpus):
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible GPUs, this box has {ndev} (RCCL puts one rank on one device; "
+              "BENCH_BACKEND=gloo lets ranks share a device for a functional rehearsal)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    for ln in lines:
+        print(ln, flush=True)
+    return proc.returncode
+
+
+def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
     """BASELINE configs[4]: m = 2^30, n = 3, 512 colours per GPU (64 GiB resident per rank; 4096 colours = 512 GiB over 8 GPUs).
     Every rank sees every k-mer (the distinct canonical 31-mers of the same 1 M reads), searches its own stripe
     (cid_search_count_stripe_dev), then ONE all-reduce(SUM) of the packed per-k-mer facts (4 B per k-mer, RCCL over xGMI) + the tiny
@@ -254,21 +362,27 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
     import colorid_amd
     from colorid_amd.striped import StripedIndex, reduce_stripe_facts
     Cs, n, k, m = a.stripe_colours, a.stripe_hashes, a.k, 1 << a.stripe_log2_bloom
-    C_total = Cs * world
+    n_stripes = a.emulate_world or world
+    my_stripes = list(range(n_stripes)) if a.emulate_world else [rank]
+    C_total = Cs * n_stripes
     t_setup = time.time()
-    hx = colorid_amd.Index(ctx, m, n, k, Cs)
-    ptr, rs = hx.device_matrix()
-    p_bg = fill_background_fast(dev, ptr, m, rs, Cs, 1.0 - math.exp(-n * 5_000_000 / m), seed=7 + rank)
     kmers, freq, colour = make_reads_kmers(dev, 42, a.reads, a.read_len, k, C_total, a.error_rate)   # the same k-mers on every rank
     K = kmers.shape[0]
-    base = rank * Cs
-    mine = torch.where((colour >= base) & (colour < base + Cs), colour - base, torch.full_like(colour, Cs)).contiguous()
-    torch.cuda.synchronize()
-    hx.insert_kmers_dev(kmers.data_ptr(), mine.data_ptr(), K)
-    ctx.synchronize()
-    hx.finalize()
-    del mine, colour
-    si = StripedIndex(ctx, [(hx, base)], C_total)
+    held = []
+    for r in my_stripes:
+        hx = colorid_amd.Index(ctx, m, n, k, Cs)
+        ptr, rs = hx.device_matrix()
+        p_bg = fill_background_fast(dev, ptr, m, rs, Cs, 1.0 - math.exp(-n * 5_000_000 / m), seed=7 + r)
+        base = r * Cs
+        mine = torch.where((colour >= base) & (colour < base + Cs), colour - base, torch.full_like(colour, Cs)).contiguous()
+        torch.cuda.synchronize()
+        hx.insert_kmers_dev(kmers.data_ptr(), mine.data_ptr(), K)
+        ctx.synchronize()
+        hx.finalize()
+        held.append((hx, base))
+        del mine
+    del colour
+    si = StripedIndex(ctx, held, C_total)
     fact = torch.zeros(K, dtype=torch.int32, device=dev)
     hits = torch.zeros(C_total, dtype=torch.int64, device=dev)
     nu = torch.zeros(C_total, dtype=torch.int64, device=dev)
@@ -298,6 +412,7 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    clocks = ClockSampler(device_index).start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
@@ -305,14 +420,13 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if clocks:
+        clocks.stop()
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     coll_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     fin_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
-    ranks = per_rank_times(dev, world, kern_ms, coll_ms, elapsed / a.steps * 1e3)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    ranks = per_rank_times(dev, world, kern_ms, coll_ms, elapsed / a.steps * 1e3, K)
+    elapsed = max_over_ranks(dev, world, elapsed)
     if rank == 0:
         w64 = (Cs + 63) // 64
         alg = n * w64 * 8 + k + 4 + 4   # rows + k-mer bytes + the k-mer's packed fact read and written
@@ -324,12 +438,15 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
             "value": K * a.steps / elapsed, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"configs[4] (NOT the metric's config): m=2^{a.stripe_log2_bloom} n={n} k={k}, {Cs} colours per GPU x {world} GPU(s) = "
+            "config": {"workload": f"configs[4] (NOT the metric's config): m=2^{a.stripe_log2_bloom} n={n} k={k}, {Cs} colours per stripe x {n_stripes} stripe(s) on {world} GPU(s) = "
                                    f"{C_total} colours colour-striped, the {K} distinct canonical k-mers of {a.reads} synthetic {a.read_len}bp reads seen by every GPU",
                        "placement": "striped", "kmers": K, "bloom_size": m, "num_hash": n, "k_size": k, "n_colors_total": C_total,
                        "stripe_bytes": m * rs * 8, "background_density": p_bg,
                        "parallelism": f"colour stripes over {world} GPU(s); one all-reduce(SUM) of 4 B per k-mer + 8*C_total bytes per step",
-                       "collective_bytes_per_step": 4 * K + 8 * C_total, "setup_s": round(t_setup, 1), "consistent": bool(ok), "box": clocks_under_load(step)},
+                       "collective_bytes_per_step": 4 * K + 8 * C_total, "setup_s": round(t_setup, 1), "consistent": bool(ok),
+                       "backend": (dist.get_backend() if dist.is_initialized() else None), "emulate_world": a.emulate_world or None,
+                       "total_kmers": K, "box": clocks.result()},
+            "counters": counters_digest(hits, nu, sf),
             "per_rank": ranks, "kernel_ms": kern_ms, "collective_ms": coll_ms, "finalize_ms": fin_ms,
             "roofline": {"bound": "hbm", "kernel": "k_search_count (stripe mode)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_kmer": alg, "kernel_ms": kern_ms, "kmers_per_launch": K},
@@ -337,7 +454,8 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
         }
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
-    hx.close()
+    for hx, _ in held:
+        hx.close()
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -345,6 +463,8 @@ def bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream):
 
 def main():
     a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))       # before any GPU call: the ranks are fresh child processes
     # stdout carries exactly one line, the JSON: RCCL prints a version banner to C stdout (late, when that is a pipe), so
     # everything else this process or its libraries write to fd 1 goes to stderr
     sys.stdout.flush()
@@ -353,19 +473,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-        a.gpus = world
+    a.gpus = world
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit(f"BENCH_BACKEND={backend}: nccl (RCCL) or gloo")
+    if a.emulate_world and world != 1:
+        raise SystemExit("--emulate-world is a one-rank run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path (the oracle is only the cpu_baseline leg)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path with one rank
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the collective path with one rank
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import colorid_amd
-    ctx = colorid_amd.Context(local_rank)
+    ctx = colorid_amd.Context(device_index)
     # One explicit (non-null) stream for torch ops, RCCL and our kernels: torch.cuda.Event then brackets the
     # kernel on the stream it is launched on.
     stream = torch.cuda.Stream(device=dev)
@@ -374,40 +500,44 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     if a.placement == "striped":
-        return bench_striped(a, json_out, world, rank, local_rank, dev, ctx, stream)
+        return bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream)
     C, n, k, m = a.colours, a.hashes, a.k, a.bloom
     t_setup = time.time()
     hx = colorid_amd.Index(ctx, m, n, k, C)
     ptr, rs = hx.device_matrix()
     p_bg = a.density if a.density is not None else 1.0 - math.exp(-n * a.genome_len / m)
     fill_background(dev, ptr, m, rs, C, p_bg, seed=7)
-    mine = None
-    for r in range(world):  # the replicated index holds every rank's planted k-mers
+    n_shards = a.emulate_world or world
+    my_shards = list(range(n_shards)) if a.emulate_world else [rank]
+    shards = []                      # (ascii k-mers, multiplicities, 2-bit codes, planted colour) of the shards this rank searches
+    for r in range(n_shards):  # the replicated index holds every shard's planted k-mers
         kk, ff, cc, codes = make_reads_kmers(dev, 42 + r, a.reads, a.read_len, k, C, a.error_rate, return_codes=True)
         torch.cuda.synchronize()
         hx.insert_kmers_dev(kk.data_ptr(), cc.data_ptr(), kk.shape[0])
         ctx.synchronize()
-        if r == rank:
-            mine = (kk, ff, codes)
-        del cc
+        if r in my_shards:
+            shards.append((kk, ff, codes, cc))
+        del kk, ff, cc, codes
     hx.finalize()
-    kmers, freq, codes = mine
-    K = kmers.shape[0]
+    kmers, freq, codes, planted = shards[0]
+    K = sum(sh[0].shape[0] for sh in shards)
     out = torch.zeros(3 * C, dtype=torch.int64, device=dev)  # hits | n_unique | sum_unique_freq (u64 on the device)
-    uc = torch.empty(K, dtype=torch.int32, device=dev)
+    ucs = [torch.empty(sh[0].shape[0], dtype=torch.int32, device=dev) for sh in shards]
+    uc = ucs[0]
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
+    from colorid_amd._lib import check, vp
     from colorid_amd.dist import allreduce_counts
 
-    def launch():
-        if a.codes:
-            from colorid_amd._lib import check, vp
-            check(hx.lib.cid_search_count_codes_dev(ctx.h, hx.h, vp(codes.data_ptr()), vp(freq.data_ptr()), K, vp(out.data_ptr()),
-                                                    vp(out.data_ptr() + 8 * C), vp(out.data_ptr() + 16 * C), vp(uc.data_ptr())))
-        else:
-            hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C,
-                                out.data_ptr() + 16 * C, uc.data_ptr())
+    def launch():                    # the counters accumulate: one launch per shard held (one, except under --emulate-world)
+        for (kk, ff, cd, _), u in zip(shards, ucs):
+            if a.codes:
+                check(hx.lib.cid_search_count_codes_dev(ctx.h, hx.h, vp(cd.data_ptr()), vp(ff.data_ptr()), kk.shape[0], vp(out.data_ptr()),
+                                                        vp(out.data_ptr() + 8 * C), vp(out.data_ptr() + 16 * C), vp(u.data_ptr())))
+            else:
+                hx.search_count_dev(kk.data_ptr(), ff.data_ptr(), kk.shape[0], out.data_ptr(), out.data_ptr() + 8 * C,
+                                    out.data_ptr() + 16 * C, u.data_ptr())
 
     def step():
         out.zero_()            # every step is one whole query: fresh counters, search, reduction
@@ -420,7 +550,10 @@ def main():
     if world > 1:
         dist.barrier()
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(a.steps)]
+    clocks = ClockSampler(device_index) if rank == 0 else None
     torch.cuda.synchronize()
+    if clocks:
+        clocks.start()
     t0 = time.perf_counter()
     for i in range(a.steps):
         out.zero_()
@@ -433,15 +566,13 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if clocks:
+        clocks.stop()
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     coll_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    ranks = per_rank_times(dev, world, kern_ms, coll_ms, elapsed / a.steps * 1e3)
-    tot_k = torch.tensor([K], dtype=torch.int64, device=dev)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot_k)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    total_kmers, elapsed = int(tot_k.item()), float(el.item())
+    ranks = per_rank_times(dev, world, kern_ms, coll_ms, elapsed / a.steps * 1e3, K)
+    total_kmers = sum(r["kmers"] for r in ranks)
+    elapsed = max_over_ranks(dev, world, elapsed)
 
     result = None
     if rank == 0:
@@ -461,7 +592,9 @@ def main():
                        "kmers_per_gpu": K, "bloom_size": m, "num_hash": n, "k_size": k, "n_colors": C,
                        "row_bytes": rs * 8, "index_bytes": m * rs * 8, "background_density": p_bg,
                        "parallelism": f"reads sharded over {world} GPU(s), index replicated, all-reduce(3C u64)",
-                       "setup_s": round(t_setup, 1)},
+                       "backend": (dist.get_backend() if dist.is_initialized() else None), "emulate_world": a.emulate_world or None,
+                       "total_kmers": total_kmers, "setup_s": round(t_setup, 1), "box": clocks.result()},
+            "counters": counters_digest(out[:C], out[C:2 * C], out[2 * C:]),
             "roofline": {"bound": "hbm", "kernel": "k_search_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": a.traffic_bytes if a.traffic_bytes is not None else profiled_traffic(K, C, m, n, k)[0],
@@ -475,10 +608,9 @@ def main():
         if tr:   # the PMC traffic of profiles/ at this run's kernel time: what the kernel really moves (every 32-byte row costs a 128-byte line)
             result["roofline"]["traffic_GBs"] = tr / (kern_ms * 1e-3) / 1e9
             result["roofline"]["traffic_frac"] = tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if world == 1 and not a.codes and not a.no_variants:
+        if world == 1 and not a.codes and not a.no_variants and not a.emulate_world:
             # for the record, not the headline: the same query with the k-mers as the 2-bit codes that GPU k-mer counting
             # produces (what `colorid search` feeds the kernel for k <= 32): 8 instead of k input bytes per k-mer
-            from colorid_amd._lib import check, vp
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for i in range(12):
                 if i == 2:
@@ -518,10 +650,11 @@ def main():
                 "note": "2-bit codes grouped by the 128-byte index line of their first row; search_ms = the search alone (ordering done by the "
                         "producer), in_step_ms = grouping + search inside one step; neither is the headline value"}
             del oc, of
-            result["config"]["box"] = clocks_under_load(launch)
-        if world == 1 and not a.codes and not a.no_variants:
             result["e2e"] = e2e_reads_to_report(a, dev, ctx, hx, out, C, k)
-        if world == 1 and not a.no_cpu_baseline:
+            # the other kernels of the path in the same driver-run line (side records, never `value`)
+            result["rows128"] = side_rows128(a, dev, ctx, stream, kmers, freq, planted)
+            result["readid"] = side_readid(a, dev, ctx, stream, with_oracle=not a.no_cpu_baseline)
+        if world == 1 and not a.no_cpu_baseline and not a.emulate_world:
             result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
     if result is not None:
         json_out.write(json.dumps(result) + "\n")
@@ -567,6 +700,126 @@ def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
             "note": "reads in pageable host memory -> H2D -> cid_kmerset (window codes, sort, run-length) -> cid_search_count_set_report "
                     "(search + per-accession hits / unique / sum / mode on the device) -> 4*C numbers to the host; best of 6 calls, the "
                     "first of which pays the scratch allocations; PCIe-inclusive, not the headline value"}
+
+
+def side_rows128(a, dev, ctx, stream, kmers, freq, planted, C=1024):
+    """The headline batch against 128-byte rows: BASELINE configs[3]'s index (m, n, k of the headline, C = 1024: 6.4 GB), the same
+    k-mers planted into the same colours.  At 32-byte rows every row costs a 128-byte HBM line (the headline's 0.25); here a row IS a
+    line, so the same kernel family shows what the gather does when nothing is over-fetched."""
+    import colorid_amd
+    n, k, m = a.hashes, a.k, a.bloom
+    hx = colorid_amd.Index(ctx, m, n, k, C)
+    ptr, rs = hx.device_matrix()
+    p_bg = fill_background_fast(dev, ptr, m, rs, C, 1.0 - math.exp(-n * a.genome_len / m), seed=11)
+    K = kmers.shape[0]
+    torch.cuda.synchronize()
+    hx.insert_kmers_dev(kmers.data_ptr(), planted.data_ptr(), K)
+    ctx.synchronize()
+    hx.finalize()
+    out = torch.zeros(3 * C, dtype=torch.int64, device=dev)
+    uc = torch.empty(K, dtype=torch.int32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    steps = 10
+    for i in range(steps + 2):
+        if i == 2:
+            e0.record(stream)
+        out.zero_()
+        hx.search_count_dev(kmers.data_ptr(), freq.data_ptr(), K, out.data_ptr(), out.data_ptr() + 8 * C, out.data_ptr() + 16 * C, uc.data_ptr())
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    alg = n * rs * 8 + k + 4 + 4
+    # the planted k-mers are found in their colour, and every unique k-mer is counted once
+    found = int(out[:C].sum().item()) >= int((planted < a.colours).sum().item())
+    ok = found and int(out[C:2 * C].sum().item()) == int((uc != -1).sum().item())
+    hx.close()
+    del out, uc
+    return {"kernel": "k_search_count (128-byte rows)", "n_colors": C, "row_bytes": rs * 8, "index_bytes": m * rs * 8, "kmers": K, "ms": ms,
+            "kmers_per_s": K / ms * 1e3, "alg_bytes_per_kmer": alg, "achieved_GBs": alg * K / ms / 1e6, "frac": alg * K / ms / 1e6 / HBM_PEAK_GBS,
+            "background_density": p_bg, "consistent": bool(ok),
+            "note": f"the headline's k-mers against m={m} n={n} C={C} (configs[3]'s index), {steps} steps; not the headline value"}
+
+
+def side_readid(a, dev, ctx, stream, with_oracle, reads=1_000_000, L=150):
+    """cid_readid_count_dev (`read_id -d 1 -B 3`, read_id_mt_pe.rs:104-165,282-363) on BASELINE configs[2]'s shape: m = 30,000,000, n = 2,
+    k = 21, 256 colours, 1 M single-end reads and 1 M pairs of 150 bp resident in HBM; per-read rows of a sample checked against
+    the oracle, which is also timed on every host core (the reference runs this loop under rayon)."""
+    import colorid_amd
+    C, n, k, m, d, B = 256, 2, 21, 30_000_000, 1, 3
+    hx = colorid_amd.Index(ctx, m, n, k, C)
+    ptr, rs = hx.device_matrix()
+    p_bg = 1.0 - math.exp(-n * 5_000_000 / m)
+    fill_background(dev, ptr, m, rs, C, p_bg, seed=7)
+    kk, _, cc, seqs = make_reads_kmers(dev, 42, 2 * reads, L, k, C, a.error_rate, return_reads=True)
+    torch.cuda.synchronize()
+    hx.insert_kmers_dev(kk.data_ptr(), cc.data_ptr(), kk.shape[0])
+    ctx.synchronize()
+    hx.finalize()
+    del kk, cc
+    bases = seqs.reshape(-1).contiguous()
+    rec = {"config": {"bloom_size": m, "num_hash": n, "k_size": k, "n_colors": C, "row_bytes": rs * 8, "stride_d": d, "start_sample": B,
+                      "background_density": p_bg, "read_len": L},
+           "note": "configs[2]'s shape, reads resident in HBM, 10 steps each; alg bytes = n rows of 32 B per distinct k-mer of a read + the "
+                   "read's bases in + its report row out; not the headline value"}
+    oix = None
+    for name, mates in (("single_end", 1), ("paired", 2)):
+        n_seq = reads * mates
+        seq_off = (torch.arange(n_seq + 1, device=dev, dtype=torch.int64) * L).contiguous()
+        read0 = (torch.arange(reads + 1, device=dev, dtype=torch.int64) * mates).contiguous()
+        report = torch.empty((reads, C + 1), dtype=torch.int32, device=dev)
+        nk = torch.empty(reads, dtype=torch.int32, device=dev)
+        st = torch.empty(reads, dtype=torch.uint8, device=dev)
+        max_bytes, max_win = L * mates, ((L - k) // d + 1) * mates
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        steps = 10
+        for i in range(steps + 2):
+            if i == 2:
+                e0.record(stream)
+            hx.readid_count_dev(bases.data_ptr(), seq_off.data_ptr(), read0.data_ptr(), reads, d, B, max_bytes, max_win,
+                                report.data_ptr(), nk.data_ptr(), st.data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        nk_sum = int(nk.to(torch.int64).sum().item())
+        alg = nk_sum * n * rs * 8 + n_seq * L + reads * (C + 1) * 4
+        r = {"reads": reads, "mates": mates, "ms": ms, "reads_per_s": reads / ms * 1e3, "distinct_kmers_per_s": nk_sum / ms * 1e3,
+             "row_gathers_per_s": nk_sum * n / ms * 1e3, "alg_bytes": alg, "achieved_GBs": alg / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBS}
+        if with_oracle:
+            if oix is None:
+                oix = cpu_baseline_readid_index(ptr, m, n, k, C, rs)
+            r.update(cpu_baseline_readid(oix, bases, seq_off, read0, report, nk, reads, mates, max_bytes, d, B))
+        rec[name] = r
+        del report, nk, st, seq_off, read0
+    hx.close()
+    return rec
+
+
+def cpu_baseline_readid_index(mat_ptr, m, n, k, C, rs):
+    """host copy of the device matrix as the oracle's index (the checker's side of side_readid)"""
+    from oracle import orc
+    rows = np.empty((m, rs * 2), np.uint32)
+    hip_memcpy(rows.ctypes.data, mat_ptr, rows.nbytes, 2)
+    oix = orc.Index(m, n, k, C)
+    oix.rows()[:] = rows[:, :oix.w32]
+    return oix
+
+
+def cpu_baseline_readid(oix, bases, seq_off, read0, report, nk, reads, mates, max_bytes, d, B):
+    """The oracle's per-read loop (orc_readid_counts: read_id_mt_pe.rs:66-165,282-363 restated) on every host core — the reference
+    runs it under rayon — over a bounded sample of the same reads; also the bit-exactness check of the device rows."""
+    ncpu = os.cpu_count() or 1
+    S = min(reads, 4000 * min(ncpu, 64) // mates)
+    hb = bases[:S * max_bytes].cpu().numpy()
+    so = seq_off[:S * mates + 1].cpu().numpy().astype(np.uint64)
+    r0 = read0[:S + 1].cpu().numpy().astype(np.uint64)
+    t = time.perf_counter()
+    want = oix.readid_counts(hb, so, r0, d, B, n_threads=ncpu)
+    dt = time.perf_counter() - t
+    exact = bool(np.array_equal(want[0], report[:S].cpu().numpy().view(np.uint32)) and
+                 np.array_equal(want[1], nk[:S].cpu().numpy().view(np.uint32)))
+    return {"bit_exact": exact,
+            "cpu_baseline": {"value": S / dt, "unit": "reads/s", "cores": ncpu, "kind": "port",
+                             "sample": f"first {S} reads, oracle/liborc.so orc_readid_counts on {ncpu} threads (rayon analogue), {dt:.2f}s"}}
 
 
 def cpu_baseline(a, hx, mat_ptr, kmers, freq, C, n, k, m, rs):

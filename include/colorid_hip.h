@@ -27,6 +27,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the declarations between this push and the pop at the end of the
+ * file are its dynamic symbols (csrc/export.map says the same to the linker). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define CID_OK 0
 #define CID_ERR_INVALID (-1)     /* bad argument */
@@ -455,6 +460,9 @@ int cid_warmup(cid_ctx *, unsigned what);
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

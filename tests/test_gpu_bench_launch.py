@@ -1,0 +1,70 @@
+"""bench.py's N > 1 branches, executed: `python bench.py --gpus 2` starts its own two ranks (fresh child processes through
+torch.distributed.run), here with BENCH_BACKEND=gloo so that both ranks can share the one GPU of the test box (RCCL refuses two
+ranks on one device; on an 8-GPU node the same code runs with the default backend nccl = RCCL over xGMI).  The real HIP path runs
+in every rank; only the exchange step takes the host route.
+
+  * read-sharded / index-replicated (the reference's only parallel boundary is the rayon map over reads,
+    src/read_id_mt_pe.rs:300-302, src/main.rs:718-721): one JSON line, n_gpus 2, two per_rank records, total k-mers = the sum
+    of the shards, and the all-reduced per-accession counters equal those of ONE rank searching both shards (--emulate-world 2);
+  * colour-striped (§8e.2, BASELINE configs[4]): the same, the one rank then holding both stripes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOY = ["--reads", "20000", "--bloom", "1000003", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants"]
+TOY_STRIPED = TOY + ["--placement", "striped", "--stripe-log2-bloom", "20", "--stripe-colours", "128"]
+
+
+def run_bench(args, backend=None, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    if backend:
+        env["BENCH_BACKEND"] = backend
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=env, timeout=timeout, cwd=ROOT)
+    return p
+
+
+def one_json_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [TOY, TOY_STRIPED], ids=["replicated", "striped"])
+def test_two_ranks_equal_one_rank_over_both_shards(extra):
+    two = one_json_line(run_bench(["--gpus", "2"] + extra, backend="gloo"))
+    one = one_json_line(run_bench(["--emulate-world", "2"] + extra))
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["backend"] == "gloo"
+    assert len(two["per_rank"]) == 2 and [r["rank"] for r in two["per_rank"]] == [0, 1]
+    assert all(r["kmers"] > 0 and r["kernel_ms"] > 0 for r in two["per_rank"])
+    striped = "--placement" in extra
+    if striped:   # every rank sees every k-mer; the query does not grow with N
+        assert two["per_rank"][0]["kmers"] == two["per_rank"][1]["kmers"] == two["config"]["total_kmers"] == one["config"]["total_kmers"]
+        assert two["config"]["n_colors_total"] == one["config"]["n_colors_total"] == 256
+        assert two["config"]["consistent"] and one["config"]["consistent"]
+    else:         # the shards (reads seeded per rank) add up
+        assert two["config"]["total_kmers"] == sum(r["kmers"] for r in two["per_rank"]) == one["per_rank"][0]["kmers"]
+    # value = the units all ranks processed / the slowest rank's time
+    assert two["value"] == pytest.approx(two["config"]["total_kmers"] * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"]), rel=1e-9)
+    assert two["counters"]["sums"][0] > 0
+    assert two["counters"] == one["counters"]
+
+
+def test_nccl_without_enough_devices_is_a_one_line_refusal():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present: the RCCL launch itself is tests/test_gpu_multi.py's business")
+    p = run_bench(["--gpus", "2"] + TOY)
+    assert p.returncode == 2 and p.stdout == ""
+    err = [ln for ln in p.stderr.splitlines() if ln.strip()]
+    assert len(err) == 1 and "needs 2 visible GPUs" in err[0] and "Traceback" not in p.stderr
