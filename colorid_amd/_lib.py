@@ -67,6 +67,7 @@ SIGNATURES = {
     "cid_kmerset_count_histogram": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "cid_kmerset_clean": (C.c_int, [vp, C.c_uint64]),
     "cid_kmerset_order_for_index": (C.c_int, [vp, vp]),
+    "cid_kmerset_set_target_index": (C.c_int, [vp, vp]),
     "cid_order_codes_for_index_dev": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
     "cid_kmerset_download": (C.c_int, [vp, vp, vp]),
     "cid_kmerset_device_arrays": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]),

@@ -49,16 +49,20 @@ __global__ void k_fq_tail(const uint8_t *text, uint32_t len, uint32_t *nl, uint6
 struct FqStats {
     uint64_t n_rec;          // complete records both files hold
     uint64_t boundary[2];    // per file: the first byte behind its record n_rec - 1
-    uint32_t max_bytes, max_win, err;
+    uint64_t file_rec[2];    // per file: the complete records its text holds
+    uint32_t max_bytes, max_win, err;   // max_bytes / max_win: per READ (both mates together: the classification kernel's LDS sizing)
+    uint32_t max_seq;                   // the longest single sequence (the k-mer set's per-sequence limit)
 };
 __global__ void k_fq_nrec(FqFile f0, FqFile f1, int n_files, FqStats *st) {
     if (threadIdx.x || blockIdx.x) return;
     uint64_t n = *f0.n_nl / 4;
     if (n_files == 2 && *f1.n_nl / 4 < n) n = *f1.n_nl / 4;
+    st->file_rec[0] = *f0.n_nl / 4;
+    st->file_rec[1] = n_files == 2 ? *f1.n_nl / 4 : 0;
     st->n_rec = n;
     st->boundary[0] = n ? f0.nl[4 * n - 1] + 1ull : 0ull;
     st->boundary[1] = (n_files == 2 && n) ? f1.nl[4 * n - 1] + 1ull : 0ull;
-    st->max_bytes = 0; st->max_win = 0; st->err = 0;
+    st->max_bytes = 0; st->max_win = 0; st->err = 0; st->max_seq = 0;
 }
 
 struct FqSpan { uint32_t seq, qual, len; };   // where a sequence and its quality line start in the text, and the masked length
@@ -75,7 +79,7 @@ __global__ void k_fq_records(FqFile f0, FqFile f1, int n_files, uint32_t quality
                              uint64_t *seq_len, uint32_t *id_begin, uint64_t *id_len) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n = st->n_rec;
-    uint32_t bytes = 0, win = 0;
+    uint32_t bytes = 0, win = 0, longest = 0;
     bool err = false;
     if (r < n) {
         for (int f = 0; f < n_files; ++f) {
@@ -93,15 +97,18 @@ __global__ void k_fq_records(FqFile f0, FqFile f1, int n_files, uint32_t quality
             seq_len[r * n_files + f] = out;
             if (f == 0) { id_begin[r] = b0; id_len[r] = (uint64_t)(e0 - b0) + 1; }   // + the terminating NUL
             bytes += out;
+            longest = out > longest ? out : longest;
             win += out >= k ? (out - k) / stride_d + 1 : 0;
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t ob = __shfl_xor(bytes, d, 64), ow = __shfl_xor(win, d, 64);
+        const uint32_t ob = __shfl_xor(bytes, d, 64), ow = __shfl_xor(win, d, 64), ol = __shfl_xor(longest, d, 64);
         bytes = ob > bytes ? ob : bytes;
         win = ow > win ? ow : win;
+        longest = ol > longest ? ol : longest;
     }
     if ((threadIdx.x & 63) == 0) {
+        if (longest) atomicMax(&st->max_seq, longest);
         if (bytes) atomicMax(&st->max_bytes, bytes);
         if (win) atomicMax(&st->max_win, win);
     }
@@ -169,6 +176,10 @@ struct cid_fastq {
         uint8_t *text = nullptr;       // carry (the unfinished tail of the stretch before) + the text appended since
         size_t cap = 0, len = 0;
         bool last = false, push_closed = false;
+        // pairs: the mate file has ended and every record of it has been paired — what this file still holds or pushes has no mate and
+        // is dropped instead of piling up on the device (a truncated R2 beside a whole R1; the reference's walk ends with the shorter
+        // file, read_id_mt_pe.rs:727-760, kmer.rs:596-650)
+        bool surplus = false;
         std::deque<Staged> staged;
         hipEvent_t copy_pending = nullptr;   // the H2D of a CID_FASTQ_KEEP text push still to be waited for (owned by its Staged entry)
         size_t members_seen = 0;
@@ -185,6 +196,7 @@ struct cid_fastq {
         uint64_t n = 0, total_ids = 0;
         uint32_t n_colors = 0;
         uint64_t boundary[2] = {0, 0};
+        bool spent[2] = {false, false};   // the file is `last` and this step pairs every record it holds
         uint32_t *report = nullptr, *nk = nullptr;
         uint8_t *status = nullptr, *ids = nullptr;
         uint64_t *id_off = nullptr;
@@ -321,6 +333,7 @@ int cid_fastq_push_text(cid_fastq *fq, int file, const uint8_t *text, size_t n_b
         if (e != hipSuccess) return fail(CID_ERR_HIP, "cid_fastq_push_text: %s", hipGetErrorString(e));
     }
     if (F.push_closed) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
+    if (F.surplus) { F.push_closed = last != 0; if (last) F.last = true; return CID_OK; }   // no mates left for it: nothing travels
     if (F.staged.size() >= 64) return fail(CID_ERR_STATE, "file %d: 64 pushes are waiting for classify calls", file);
     if (n_bytes >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "a push is limited to 4 GiB of text");
     cid_ctx *c = fq->ctx;
@@ -354,6 +367,7 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
     if (n_members && (!members || !member_off || !member_len || !text_len)) return fail(CID_ERR_INVALID, "null argument");
     cid_fastq::File &F = fq->f[file];
     if (F.push_closed) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
+    if (F.surplus) { F.push_closed = last != 0; if (last) F.last = true; return CID_OK; }   // no mates left for it: nothing travels
     if (F.staged.size() >= 64) return fail(CID_ERR_STATE, "file %d: 64 pushes are waiting for classify calls", file);
     if (n_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "a push of BGZF members is limited to 4 GiB");
     cid_ctx *c = fq->ctx;
@@ -447,6 +461,7 @@ static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint
                     F.members_seen += sg.n_members;
                 }
                 if (e != hipSuccess) { free_staged(fq, sg); return fail(CID_ERR_HIP, "cid_fastq_classify: %s", hipGetErrorString(e)); }
+                if (F.surplus) sg.bytes = 0;   // (pushed before the mate file was known to be spent)
                 if ((rc = text_reserve(fq, f, sg.bytes))) { free_staged(fq, sg); return rc; }
                 if (sg.bytes) {
                     const hipError_t e2 = hipMemcpyAsync(F.text + F.len, sg.text, sg.bytes, hipMemcpyDeviceToDevice, st);
@@ -533,7 +548,7 @@ static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint
             if ((rc = bases.alloc(total_bases + 16))) return rc;
             hipLaunchKernelGGL(cid::k_fq_pack, dim3(grid), dim3(256), 0, st, F[0], F[1], nf, fq->quality, n_seqs, span.p, seq_off.p, bases.p);
             HIP_TRY(hipGetLastError());
-            if ((rc = cid_kmerset_add_seqs_dev(ks, bases.p, seq_off.p, n_seqs, hs.max_bytes, 1))) return rc;
+            if ((rc = cid_kmerset_add_seqs_dev(ks, bases.p, seq_off.p, n_seqs, hs.max_seq, 1))) return rc;
             HIP_TRY(hipStreamSynchronize(st));
             pc.lap(4);
         } else {
@@ -563,7 +578,10 @@ static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint
     keep(nl[0]); keep(nl[1]); keep(n_nl); keep(stats);
     in.active = true;
     in.n = n; in.total_ids = total_ids;
-    for (int f = 0; f < nf; ++f) in.boundary[f] = hs.boundary[f];
+    for (int f = 0; f < nf; ++f) {
+        in.boundary[f] = hs.boundary[f];
+        in.spent[f] = fq->f[f].last && fq->f[f].staged.empty() && hs.file_rec[f] == hs.n_rec;
+    }
     return CID_OK;
 }
 
@@ -600,6 +618,7 @@ static int fastq_end(cid_fastq *fq, uint64_t *n_reads, uint64_t *n_entries, uint
     HIP_TRY(hipStreamSynchronize(st));   // the scratch of the step returns to the cache
     pc.lap(5);
     uint64_t boundary[2] = {in.boundary[0], in.boundary[1]};
+    const bool spent[2] = {in.spent[0], in.spent[1]};
     const uint64_t total_ids = in.total_ids;
     const bool classified = in.classify;
     drop_inflight(fq);
@@ -622,6 +641,9 @@ static int fastq_end(cid_fastq *fq, uint64_t *n_reads, uint64_t *n_entries, uint
     bool all_last = true;
     for (int f = 0; f < nf; ++f) all_last = all_last && fq->f[f].last;
     if (all_last) for (int f = 0; f < nf; ++f) fq->f[f].len = 0;
+    if (nf == 2)
+        for (int f = 0; f < 2; ++f)
+            if (spent[f]) { fq->f[1 - f].surplus = true; fq->f[1 - f].len = 0; }
     pc.lap(6);
     *n_reads = n;
     *n_entries = classified ? c->sp_entries : 0;

@@ -48,9 +48,27 @@ __device__ __forceinline__ uint64_t bits_at_dev(const uint32_t *w, uint32_t bit,
 // segs == NULL: segment sg is sequence sg of a batch of short sequences (reads: at most kSegWindows windows each) — its bases at
 // seq_off[sg] (relative to `bases`' first byte, which is seq_off[0] of the batch), its codes at win_off[sg]; nothing per read comes
 // from the host but the offsets it already has.
+// KEYED (a set built for an index, cid_kmerset_set_target_index): every window's row0_key goes to key_out next to its code.
+struct KeyFor {   // the index the keys are for
+    ModMagic mm;
+    uint64_t scale;   // floor((2^32 - 1) * 2^32 / bloom_size)
+};
+// The sort key of a k-mer in such a set: monotone in the row its first hash (seed 0) selects, spread evenly over [0, 2^32 - 1) —
+// never kNoKey, and distinct rows get distinct keys (bloom_size <= 2^32 - 1).  `lsb`: the canonical k-mer, LSB-first (as it is hashed).
+__device__ __forceinline__ uint32_t row0_key(uint64_t lsb, uint32_t k, const KeyFor &kf) {
+    uint32_t row0 = 0;
+    xxh3_seeds_from(CodeReader{lsb}, k, 1, HashSel::of(kf.mm), [&](uint32_t, uint64_t h) { row0 = (uint32_t)mod_m(h, kf.mm); });
+    return (uint32_t)(((uint64_t)row0 * kf.scale) >> 32);
+}
+__global__ void k_row0_keys(const uint64_t *codes, uint32_t k, KeyFor kf, uint32_t *keys, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = row0_key(rev_fields(codes[i], k), k, kf);
+}
+
+template <bool KEYED>
 __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, const Segment *segs, uint32_t n_segs, uint32_t k,
                                                        int mode, uint64_t sentinel, uint64_t *out, int *flags,
-                                                       const uint64_t *seq_off = nullptr, const uint64_t *win_off = nullptr, uint64_t base0 = 0) {
+                                                       const uint64_t *seq_off, const uint64_t *win_off, uint64_t base0, uint32_t *key_out, KeyFor kf) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr uint32_t kBytes = kSegWindows + 32 + 96;                  // bases of one segment (+ slack)
@@ -123,6 +141,7 @@ __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, con
                 result = msb;
             }
             out[seg.out_off + wi] = result;
+            if constexpr (KEYED) key_out[seg.out_off + wi] = result == sentinel ? kNoKey : row0_key(rev_fields(result, k), k, kf);
         }
     }
 }
@@ -199,6 +218,11 @@ struct cid_kmerset {
     uint64_t *codes = nullptr; uint32_t *counts = nullptr; size_t n = 0;  // distinct k-mers, ascending code unless reordered
     int *d_flags = nullptr;
     bool finalized = false;
+    // built FOR an index (cid_kmerset_set_target_index): every window carries row0_key of that index (raw_key, parallel to raw) and the
+    // set comes out ordered by (row0_key, code) — the order in which the search's first-row fetches share 128-byte lines
+    bool targeted = false;
+    cid::KeyFor key_for{};
+    uint32_t *raw_key = nullptr;
     // merge the unsorted window buffer into the set beyond this many codes (2 GiB).  (8 GiB until round 3: the buffer then regrows through
     // 1.3 / 1.9 / 2.9 / 4.3 / 6.5 / 9.7 GB blocks, and those hipMallocs made a 16 M-read query's count take 0.25 s or 1.9 s from run to run)
     size_t compact_at = 1ull << 28;
@@ -330,6 +354,117 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
     return CID_OK;
 }
 
+// The same sort for a set built FOR an index: (key, code) pairs, partitioned on the key's leading bits, the runs finished in LDS on
+// (rest of the key, code).  keys_a / codes_a hold the n windows (keys of kNoKey = no k-mer) and are overwritten; keys_b / codes_b
+// are scratch.  On return *sorted (codes_a or codes_b) holds the *n_real real codes in (key, code) order.  The keys are evenly
+// spread by construction (row0_key), so the runs all have about n >> prefix members.
+struct KeyCodeLess {   // (row0_key, code) pairs, as a targeted set is ordered
+    __host__ __device__ bool operator()(const rocprim::tuple<uint32_t, uint64_t> &a, const rocprim::tuple<uint32_t, uint64_t> &b) const {
+        const uint32_t ka = rocprim::get<0>(a), kb = rocprim::get<0>(b);
+        return ka < kb || (ka == kb && rocprim::get<1>(a) < rocprim::get<1>(b));
+    }
+};
+int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_a, uint32_t *keys_b, uint64_t *codes_b, size_t n, unsigned code_bits,
+                  uint64_t **sorted, size_t *n_real) {
+    using namespace cid;
+    const char *min_env = getenv("CID_KMERSET_MSD_MIN");
+    const size_t min_n = min_env ? strtoull(min_env, nullptr, 10) : (size_t)1 << 20;
+    if (!kMsdSort || n < min_n || n < 2 || n >= (1ull << 32)) return CID_ERR_UNSUPPORTED;
+    unsigned prefix = 1;
+    while (prefix < 24 && ((uint64_t)n >> prefix) > 1900) ++prefix;   // runs of ~950 .. 1900 pairs: k_run_bucket_sort_pair<8> takes up to 2048
+    const unsigned levels = (prefix + kPartBits - 1) / kPartBits;
+    unsigned lbits[3] = {0, 0, 0};
+    for (unsigned l = 0; l < levels; ++l) lbits[l] = l + 1 < levels ? kPartBits : prefix - kPartBits * (levels - 1);
+    const uint32_t n_runs = 1u << prefix;
+    uint32_t S_last = 1;
+    for (unsigned l = 0; l + 1 < levels; ++l) S_last <<= lbits[l];
+    const uint32_t max_tiles = part_max_tiles((uint32_t)n, S_last);
+    constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (no k-mer) [1] big runs [2] largest run [3] hard runs
+    DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c);
+    DevBuf<uint8_t> scan_tmp(c);
+    int rc;
+    if ((rc = seg_a.alloc((size_t)n_runs + 1)) || (rc = seg_b.alloc((size_t)n_runs + 1)) || (rc = tile_base.alloc((size_t)S_last + 1)) ||
+        (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)))
+        return rc;
+    size_t scan_tb = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, scan_tb, table.p, table.p, 0u, (size_t)max_tiles * kPartBins, rocprim::plus<uint32_t>(), st));
+    if ((rc = scan_tmp.alloc(scan_tb))) return rc;
+    HIP_TRY(hipMemsetAsync(info.p, 0, kInfo * 4, st));
+    const uint32_t seg0[2] = {0u, (uint32_t)n};
+    HIP_TRY(hipMemcpyAsync(seg_a.p, seg0, 8, hipMemcpyHostToDevice, st));
+    const unsigned grid = (unsigned)cid::ctx_n_cu(c) * 8u;
+    uint32_t *ksrc = keys_a, *kdst = keys_b;
+    uint64_t *src = codes_a, *dst = codes_b;
+    uint32_t *seg = seg_a.p, *seg_next = seg_b.p;
+    uint32_t S = 1;
+    unsigned consumed = 0;
+    for (unsigned l = 0; l < levels; ++l) {
+        const uint32_t bits = lbits[l], shift = 32 - consumed - bits, bins = 1u << bits;
+        const size_t table_n = (size_t)part_max_tiles((uint32_t)n, S) * bins;
+        HIP_TRY(hipMemsetAsync(table.p, 0, table_n * 4, st));
+        hipLaunchKernelGGL(k_part_tiles, dim3(1), dim3(kPartBlock), 0, st, seg, S, tile_base.p);
+        hipLaunchKernelGGL(k_part_hist_key, dim3(grid), dim3(kPartBlock), 0, st, ksrc, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u, table.p, info.p);
+        HIP_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_tb, table.p, table.p, 0u, table_n, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(k_part_scatter_pair, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, kdst, dst, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u,
+                           table.p);
+        hipLaunchKernelGGL(k_part_offsets, dim3((S * bins + 256) / 256), dim3(256), 0, st, table.p, tile_base.p, S, bits, (uint32_t)n, info.p, seg_next);
+        HIP_TRY(hipGetLastError());
+        std::swap(src, dst);
+        std::swap(ksrc, kdst);
+        std::swap(seg, seg_next);
+        S *= bins;
+        consumed += bits;
+    }
+    hipLaunchKernelGGL(k_run_sizes, dim3((n_runs + 255) / 256), dim3(256), 0, st, seg, n_runs, 8192u, info.p + 1, info.p + kInfo, kBigCap, info.p + 2);
+    uint32_t h_info[kInfo + kBigCap];
+    HIP_TRY(hipMemcpyAsync(h_info, info.p, sizeof(h_info), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t dropped = h_info[0], n_big = h_info[1], largest = h_info[2];
+    const size_t kept = n - dropped;
+    const PairOrder ord{32u - consumed, code_bits};
+    // two stable LSD sorts = the (key, code) order, for what the LDS kernels do not take: first by code, then by the key's rest
+    auto lsd_pair = [&](size_t lo, size_t sz) -> int {
+        size_t tb1 = 0, tb2 = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb1, src + lo, dst + lo, ksrc + lo, kdst + lo, sz, 0u, code_bits, st));
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb2, kdst + lo, ksrc + lo, dst + lo, src + lo, sz, 0u, ord.kbits ? ord.kbits : 1u, st));
+        DevBuf<uint8_t> tmp(c);
+        int rc2 = tmp.alloc(tb1 > tb2 ? tb1 : tb2);
+        if (rc2) return rc2;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb1, src + lo, dst + lo, ksrc + lo, kdst + lo, sz, 0u, code_bits, st));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb2, kdst + lo, ksrc + lo, dst + lo, src + lo, sz, 0u, ord.kbits ? ord.kbits : 1u, st));
+        HIP_TRY(hipMemcpyAsync(dst + lo, src + lo, sz * 8, hipMemcpyDeviceToDevice, st));   // the result belongs in dst, like the LDS kernels'
+        HIP_TRY(hipStreamSynchronize(st));   // (tmp is released on return)
+        return CID_OK;
+    };
+    if (n_big > kBigCap) {   // one row taking a large share of the windows (low-complexity sequence): everything through the LSD sorts
+        size_t tb1 = 0, tb2 = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb1, src, dst, ksrc, kdst, kept, 0u, code_bits, st));
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb2, kdst, ksrc, dst, src, kept, 0u, 32u, st));
+        DevBuf<uint8_t> tmp(c);
+        if ((rc = tmp.alloc(tb1 > tb2 ? tb1 : tb2))) return rc;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb1, src, dst, ksrc, kdst, kept, 0u, code_bits, st));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb2, kdst, ksrc, dst, src, kept, 0u, 32u, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *sorted = src; *n_real = kept;
+        return CID_OK;
+    }
+    hipLaunchKernelGGL(k_run_bucket_sort_pair<8>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, info.p + 3, hard.p);
+    if (largest > 2048) hipLaunchKernelGGL(k_run_bucket_sort_pair<16>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 2049u, info.p + 3, hard.p);
+    if (largest <= 2048) hipLaunchKernelGGL(k_run_sort_pair<8>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 2048u, hard.p, info.p + 3);
+    else if (largest <= 4096) hipLaunchKernelGGL(k_run_sort_pair<16>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 4096u, hard.p, info.p + 3);
+    else hipLaunchKernelGGL(k_run_sort_pair<32>, dim3(grid / 4), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 8192u, hard.p, info.p + 3);
+    HIP_TRY(hipGetLastError());
+    if (n_big) {   // runs beyond 8192 pairs (one row's k-mers at deep coverage)
+        std::vector<uint32_t> h_seg(2 * (size_t)n_big);
+        for (uint32_t i = 0; i < n_big; ++i) HIP_TRY(hipMemcpyAsync(&h_seg[2 * i], seg + h_info[kInfo + i], 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint32_t i = 0; i < n_big; ++i)
+            if ((rc = lsd_pair(h_seg[2 * i], h_seg[2 * i + 1] - h_seg[2 * i]))) return rc;
+    }
+    *sorted = dst; *n_real = kept;
+    return CID_OK;
+}
+
 // merge the raw window codes into (codes, counts): the batch is sorted and run-length counted (distinct codes + multiplicities,
 // sentinel dropped); a set that already holds k-mers is then MERGED with it — two sorted lists, one pass (rocprim::merge), equal
 // neighbours added (reduce_by_key) — instead of re-sorting everything it holds with every batch
@@ -350,6 +485,25 @@ int compact(cid_kmerset *ks) {
         const uint64_t *in_order = sorted.p;
         size_t n_sorted = batch;
         uint64_t *msd_out = nullptr;
+        if (ks->targeted) {   // (key, code) order
+            DevBuf<uint32_t> key_b(ks->ctx);
+            if ((rc = key_b.alloc(batch))) return rc;
+            rc = msd_sort_pair(ks->ctx, st, ks->raw_key, ks->raw, key_b.p, sorted.p, batch, 2 * ks->k, &msd_out, &n_sorted);
+            if (rc == CID_OK) in_order = msd_out;
+            else if (rc != CID_ERR_UNSUPPORTED) return rc;
+            else {   // small batches: two stable LSD sorts, by code and then by key; the windows without a k-mer (kNoKey, sentinel) sort last
+                n_sorted = batch;
+                size_t tb1 = 0, tb2 = 0;
+                HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb1, ks->raw, sorted.p, ks->raw_key, key_b.p, batch, 0u, ks->end_bit, st));
+                HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb2, key_b.p, ks->raw_key, sorted.p, ks->raw, batch, 0u, 32u, st));
+                DevBuf<uint8_t> tmp(ks->ctx);
+                if ((rc = tmp.alloc(tb1 > tb2 ? tb1 : tb2))) return rc;
+                HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb1, ks->raw, sorted.p, ks->raw_key, key_b.p, batch, 0u, ks->end_bit, st));
+                HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb2, key_b.p, ks->raw_key, sorted.p, ks->raw, batch, 0u, 32u, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                in_order = ks->raw;
+            }
+        } else {
         // k <= 31: every real code is below bit end_bit - 1, the sentinel is that bit — the MSD sort drops it (ks->raw is overwritten)
         rc = ks->k <= 31 ? msd_sort(ks->ctx, st, ks->raw, sorted.p, batch, ks->end_bit - 1, &msd_out, &n_sorted) : CID_ERR_UNSUPPORTED;
         if (rc == CID_OK) in_order = msd_out;
@@ -361,6 +515,7 @@ int compact(cid_kmerset *ks) {
             DevBuf<uint8_t> tmp(ks->ctx);
             if ((rc = tmp.alloc(tmp_bytes))) return rc;
             HIP_TRY(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ks->raw, sorted.p, batch, 0u, ks->end_bit, st));
+        }
         }
         if (n_sorted == 0) {   // nothing but invalid windows
             HIP_TRY(hipMemsetAsync(d_count.p, 0, 8, st));
@@ -394,11 +549,27 @@ int compact(cid_kmerset *ks) {
     DevBuf<uint32_t> mv(ks->ctx), ov(ks->ctx);
     if ((rc = mk.alloc(total)) || (rc = mv.alloc(total)) || (rc = ok.alloc(total)) || (rc = ov.alloc(total))) return rc;
     size_t tb = 0;
+    if (ks->targeted) {   // both lists are in (row0_key, code) order: merged on that pair (the keys are recomputed from the codes, not kept)
+        DevBuf<uint32_t> ka(ks->ctx), kb(ks->ctx), kout(ks->ctx);
+        if ((rc = ka.alloc(ks->n)) || (rc = kb.alloc(n_runs)) || (rc = kout.alloc(total))) return rc;
+        hipLaunchKernelGGL(cid::k_row0_keys, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, ks->key_for, ka.p, (uint64_t)ks->n);
+        hipLaunchKernelGGL(cid::k_row0_keys, dim3(grid_for_n(n_runs)), dim3(256), 0, st, uniq.p, ks->k, ks->key_for, kb.p, (uint64_t)n_runs);
+        HIP_TRY(hipGetLastError());
+        auto in_a = rocprim::make_zip_iterator(rocprim::make_tuple(ka.p, ks->codes));
+        auto in_b = rocprim::make_zip_iterator(rocprim::make_tuple(kb.p, uniq.p));
+        auto out_k = rocprim::make_zip_iterator(rocprim::make_tuple(kout.p, mk.p));
+        HIP_TRY(rocprim::merge(nullptr, tb, in_a, in_b, out_k, ks->counts, agg.p, mv.p, ks->n, (size_t)n_runs, KeyCodeLess(), st));
+        DevBuf<uint8_t> tmp(ks->ctx);
+        if ((rc = tmp.alloc(tb))) return rc;
+        HIP_TRY(rocprim::merge(tmp.p, tb, in_a, in_b, out_k, ks->counts, agg.p, mv.p, ks->n, (size_t)n_runs, KeyCodeLess(), st));
+        HIP_TRY(hipStreamSynchronize(st));   // (ka / kb / kout are released here)
+    } else {
     HIP_TRY(rocprim::merge(nullptr, tb, ks->codes, uniq.p, mk.p, ks->counts, agg.p, mv.p, ks->n, (size_t)n_runs, rocprim::less<uint64_t>(), st));
     {
         DevBuf<uint8_t> tmp(ks->ctx);
         if ((rc = tmp.alloc(tb))) return rc;
         HIP_TRY(rocprim::merge(tmp.p, tb, ks->codes, uniq.p, mk.p, ks->counts, agg.p, mv.p, ks->n, (size_t)n_runs, rocprim::less<uint64_t>(), st));
+    }
     }
     size_t tmp2 = 0;
     HIP_TRY(rocprim::reduce_by_key(nullptr, tmp2, mk.p, mv.p, total, ok.p, ov.p, d_count.p, SatAdd(), rocprim::equal_to<uint64_t>(), st));
@@ -706,8 +877,8 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
             const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
             unsigned grid = (unsigned)((segs.size() + 3) / 4);
             if (grid > 8192) grid = 8192;
-            hipLaunchKernelGGL(k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel_k,
-                               d_codes.p, d_lower.p);
+            hipLaunchKernelGGL(k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel_k,
+                               d_codes.p, d_lower.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr, KeyFor{});
             int lower = 0;
             HIP_TRY(hipMemcpyAsync(&lower, d_lower.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -853,6 +1024,41 @@ int kmerset_view_ascii(const cid_kmerset *ks, cid_ctx **ctx, const uint8_t **asc
 }
 }  // namespace cid
 
+namespace {
+// the window-code kernel for a set: keyed when the set is built for an index
+void launch_extract(const cid_kmerset *ks, hipStream_t st, unsigned grid, size_t shmem, const uint8_t *bases, const cid::Segment *segs, uint32_t n_segs, int mode,
+                    const uint64_t *seq_off, const uint64_t *win_off, uint64_t base0) {
+    if (ks->targeted)
+        hipLaunchKernelGGL(cid::k_extract_codes<true>, dim3(grid), dim3(256), shmem, st, bases, segs, n_segs, ks->k, mode, ks->sentinel, ks->raw, ks->d_flags, seq_off,
+                           win_off, base0, ks->raw_key, ks->key_for);
+    else
+        hipLaunchKernelGGL(cid::k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, bases, segs, n_segs, ks->k, mode, ks->sentinel, ks->raw, ks->d_flags, seq_off,
+                           win_off, base0, (uint32_t *)nullptr, cid::KeyFor{});
+}
+// room for `want_n` window codes (and their keys) in the unsorted buffer, what it holds kept
+int grow_raw(cid_kmerset *ks, size_t need_n, hipStream_t st) {
+    if (need_n <= ks->cap_raw) return CID_OK;
+    cid_ctx *c = ks->ctx;
+    const size_t want = need_n * 3 / 2;
+    DevBuf<uint64_t> nb(c);
+    DevBuf<uint32_t> nk(c);
+    int rc = nb.alloc(want);
+    if (rc) return rc;
+    if (ks->targeted && (rc = nk.alloc(want))) return rc;
+    // on the ctx stream and waited for: a device-to-device hipMemcpy on the null stream returns before it has run, and the block
+    // freed below is handed out again at once (as this call's d_bases) — the copy then read ASCII bases as codes
+    if (ks->n_raw) HIP_TRY(hipMemcpyAsync(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
+    if (ks->n_raw && ks->targeted) HIP_TRY(hipMemcpyAsync(nk.p, ks->raw_key, ks->n_raw * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ks->raw) cid::ctx_free(c, ks->raw);
+    if (ks->raw_key) cid::ctx_free(c, ks->raw_key);
+    ks->raw = nb.release();
+    ks->raw_key = ks->targeted ? nk.release() : nullptr;
+    ks->cap_raw = want;
+    return CID_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int cid_kmerset_create(cid_ctx *c, uint32_t k_size, cid_kmerset **out) {
@@ -923,23 +1129,11 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
     cid_ctx *c = ks->ctx;
     HIP_TRY(hipSetDevice(cid::ctx_device(c)));
     hipStream_t st = cid::ctx_stream(c);
-    if (ks->n_raw + n_win_total > ks->cap_raw) {
-        size_t want = (ks->n_raw + n_win_total) * 3 / 2;
-        DevBuf<uint64_t> nb(c);
-        int rc = nb.alloc(want);
-        if (rc) return rc;
-        // on the ctx stream and waited for: a device-to-device hipMemcpy on the null stream returns before it has run, and the block
-        // freed below is handed out again at once (as this call's d_bases) — the copy then read ASCII bases as codes
-        if (ks->n_raw) HIP_TRY(hipMemcpyAsync(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (ks->raw) cid::ctx_free(c, ks->raw);
-        ks->raw = nb.release();
-        ks->cap_raw = want;
-    }
+    int rc;
+    if ((rc = grow_raw(ks, ks->n_raw + n_win_total, st))) return rc;
     constexpr uint32_t kBytes = cid::kSegWindows + 32 + 96;
     const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
     DevBuf<uint8_t> d_bases(c);
-    int rc;
     if ((rc = d_bases.alloc(total_bases))) return rc;
     int flag = 0;
     if (max_len <= cid::kSegWindows + ks->k - 1) {
@@ -968,8 +1162,7 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
             if (piped) { HIP_TRY(hipEventRecord(ev_done, cs)); HIP_TRY(hipStreamWaitEvent(st, ev_done, 0)); }
             unsigned grid = (unsigned)((s1 - s0 + 3) / 4);
             if (grid > 8192) grid = 8192;
-            hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases.p, (const cid::Segment *)nullptr, (uint32_t)(s1 - s0), ks->k, mode,
-                               ks->sentinel, ks->raw, ks->d_flags, d_off.p + s0, d_win.p + s0, seq_off[0]);
+            launch_extract(ks, st, grid, shmem, d_bases.p, nullptr, (uint32_t)(s1 - s0), mode, d_off.p + s0, d_win.p + s0, seq_off[0]);
             HIP_TRY(hipGetLastError());
             s0 = s1;
         }
@@ -994,8 +1187,7 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         HIP_TRY(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(cid::Segment), hipMemcpyHostToDevice, st));
         unsigned grid = (unsigned)((segs.size() + 3) / 4);
         if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases.p, d_segs.p, (uint32_t)segs.size(), ks->k, mode,
-                           ks->sentinel, ks->raw, ks->d_flags);
+        launch_extract(ks, st, grid, shmem, d_bases.p, d_segs.p, (uint32_t)segs.size(), mode, nullptr, nullptr, 0);
         HIP_TRY(hipGetLastError());
         if (mode == 1) HIP_TRY(hipMemcpyAsync(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1034,22 +1226,12 @@ int cid_kmerset_add_seqs_dev(cid_kmerset *ks, const uint8_t *d_bases, const uint
     HIP_TRY(hipStreamSynchronize(st));
     const uint64_t n_win_total = end - ks->n_raw;
     if (n_win_total == 0) return CID_OK;
-    if (end > ks->cap_raw) {
-        size_t want = end * 3 / 2;
-        DevBuf<uint64_t> nb(c);
-        if ((rc = nb.alloc(want))) return rc;
-        if (ks->n_raw) HIP_TRY(hipMemcpyAsync(nb.p, ks->raw, ks->n_raw * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (ks->raw) cid::ctx_free(c, ks->raw);
-        ks->raw = nb.release();
-        ks->cap_raw = want;
-    }
+    if ((rc = grow_raw(ks, end, st))) return rc;
     constexpr uint32_t kBytes = cid::kSegWindows + 32 + 96;
     const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
     unsigned grid = (unsigned)((n_seqs + 3) / 4);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(cid::k_extract_codes, dim3(grid), dim3(256), shmem, st, d_bases, (const cid::Segment *)nullptr, (uint32_t)n_seqs, ks->k, mode, ks->sentinel, ks->raw,
-                       ks->d_flags, d_seq_off, (const uint64_t *)d_win.p, (uint64_t)0);
+    launch_extract(ks, st, grid, shmem, d_bases, nullptr, (uint32_t)n_seqs, mode, d_seq_off, d_win.p, 0);
     HIP_TRY(hipGetLastError());
     int flag = 0;
     if (mode == 1) HIP_TRY(hipMemcpyAsync(&flag, ks->d_flags, 4, hipMemcpyDeviceToHost, st));
@@ -1057,6 +1239,23 @@ int cid_kmerset_add_seqs_dev(cid_kmerset *ks, const uint8_t *d_bases, const uint
     ks->n_raw += n_win_total;
     if (mode == 1 && flag) return fail(CID_ERR_UNSUPPORTED, "lower-case bases in a case-preserving (fastq) k-mer count: count on the host");
     if (ks->n_raw > ks->compact_at) return compact(ks);
+    return CID_OK;
+}
+
+// Build the set FOR an index (before the first sequence is added): it then comes out ordered by (first row in that index, code)
+// instead of by code — the search's first-row fetches of neighbouring k-mers share 128-byte lines of the matrix — at the cost of
+// four more bytes per window through the sort.  Contents, counts and every result are the same; only the order differs.
+int cid_kmerset_set_target_index(cid_kmerset *ks, const cid_index *ix) {
+    if (!ks || !ix) return fail(CID_ERR_INVALID, "null argument");
+    if (ks->finalized || ks->n_raw || ks->n || ks->g_n) return fail(CID_ERR_STATE, "cid_kmerset_set_target_index comes before the first sequences");
+    if (cid::index_k(ix) != ks->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", ks->k, cid::index_k(ix));
+    if (ks->general) return CID_OK;   // byte-string sets keep their order (cid_kmerset_order_for_index groups them afterwards)
+    if (getenv("CID_KMERSET_TARGET") && atoi(getenv("CID_KMERSET_TARGET")) == 0) return CID_OK;   // A/B: the code-ordered set
+    const cid::ModMagic mm = cid::index_mod(ix);
+    if (mm.m >= 0xFFFFFFFFull) return CID_OK;     // the key needs bloom_size < 2^32 - 1 to stay below kNoKey: such a set keeps code order
+    ks->targeted = true;
+    ks->key_for.mm = mm;
+    ks->key_for.scale = 0xFFFFFFFF00000000ull / mm.m;
     return CID_OK;
 }
 
@@ -1076,6 +1275,7 @@ int cid_kmerset_finalize(cid_kmerset *ks, uint64_t *n_distinct) {
     int rc = compact(ks);
     if (rc) return rc;
     if (ks->raw) { cid::ctx_free(ks->ctx, ks->raw); ks->raw = nullptr; ks->cap_raw = 0; }
+    if (ks->raw_key) { cid::ctx_free(ks->ctx, ks->raw_key); ks->raw_key = nullptr; }
     ks->finalized = true;
     if (n_distinct) *n_distinct = ks->n;
     return CID_OK;
@@ -1293,6 +1493,7 @@ void cid_kmerset_destroy(cid_kmerset *ks) {
     if (!ks) return;
     (void)hipSetDevice(cid::ctx_device(ks->ctx));
     if (ks->raw) cid::ctx_free(ks->ctx, ks->raw);
+    if (ks->raw_key) cid::ctx_free(ks->ctx, ks->raw_key);
     if (ks->codes) cid::ctx_free(ks->ctx, ks->codes);
     if (ks->counts) cid::ctx_free(ks->ctx, ks->counts);
     if (ks->g_bases) cid::ctx_free(ks->ctx, ks->g_bases);

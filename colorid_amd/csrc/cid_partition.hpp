@@ -364,6 +364,315 @@ __global__ void k_run_sizes(const uint32_t *run_off, uint32_t n_runs, uint32_t c
     }
 }
 
+// ---------------------------------------------------------------------------------------------- (u32 key, u64 value) pairs
+// The same partition and run sorts for a k-mer set that is built FOR an index (cid_kmerset_set_target_index): every window carries,
+// next to its 2-bit code, a 32-bit key derived from the row its first hash selects (cid_kmerset.hip: row0_key — monotone in the row
+// number and spread evenly over 32 bits).  The partition passes consume the key's leading bits, the runs are finished in LDS on
+// (rest of the key, code): the set comes out ordered by (first row, code).  Equal k-mers share the key, so they are still adjacent
+// and the run-length count is unchanged, while the search's first-row fetches of neighbouring k-mers fall into the same 128-byte
+// lines.  A key of all ones marks "no k-mer here" (row0_key never produces it) and is left out by the first level.
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kPartBlock) void k_part_hist_key(const uint32_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
+                                                               uint32_t shift, uint32_t bits, uint32_t first_level, uint32_t *table, uint32_t *n_dropped) {
+    __shared__ uint32_t s_cnt[kPartBins], s_drop;
+    const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_drop = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < t.count; i += kPartBlock) {
+            const uint32_t key = keys[t.first + i];
+            if (first_level && key == kNoKey) atomicAdd(&s_drop, 1u);
+            else atomicAdd(&s_cnt[(key >> shift) & (bins - 1)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < bins) table[t.table_at + threadIdx.x * t.table_stride] = s_cnt[threadIdx.x];
+        if (threadIdx.x == 0 && s_drop) atomicAdd(n_dropped, s_drop);
+        __syncthreads();
+    }
+}
+
+// Keys and values are staged side by side in LDS (48 KiB: three workgroups per CU) and leave as one run per digit each.
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter_pair(const uint32_t *keys, const uint64_t *vals, uint32_t *keys_out, uint64_t *vals_out,
+                                                                   const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S, uint32_t shift,
+                                                                   uint32_t bits, uint32_t first_level, const uint32_t *table) {
+    __shared__ uint64_t s_val[kPartTile];
+    __shared__ uint32_t s_key[kPartTile];
+    __shared__ uint32_t s_cnt[kPartBins], s_pre[kPartBins], s_cur[kPartBins], s_goff[kPartBins], s_wave[kPartBlock / 64];
+    constexpr uint32_t PER = kPartTile / kPartBlock;
+    const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        s_cnt[threadIdx.x] = 0;
+        s_goff[threadIdx.x] = threadIdx.x < bins ? table[t.table_at + threadIdx.x * t.table_stride] : 0u;
+        __syncthreads();
+        uint32_t k[PER];
+        uint64_t v[PER];
+        bool keep[PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {   // all of the tile's loads in flight before the first is used
+            const uint32_t i = j * kPartBlock + threadIdx.x;
+            k[j] = i < t.count ? keys[t.first + i] : kNoKey;
+            v[j] = i < t.count ? vals[t.first + i] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t i = j * kPartBlock + threadIdx.x;
+            keep[j] = i < t.count && !(first_level && k[j] == kNoKey);
+            if (keep[j]) atomicAdd(&s_cnt[(k[j] >> shift) & (bins - 1)], 1u);
+        }
+        __syncthreads();
+        {   // exclusive prefix of the 256 bin counts: one bin per thread, a wave scan + the waves' totals
+            const uint32_t c = s_cnt[threadIdx.x];
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(incl, d, 64);
+                if ((int)(threadIdx.x & 63) >= d) incl += u;
+            }
+            if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t base = 0;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += s_wave[w];
+            s_pre[threadIdx.x] = base + incl - c;
+            s_cur[threadIdx.x] = base + incl - c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            if (keep[j]) {
+                const uint32_t at = atomicAdd(&s_cur[(k[j] >> shift) & (bins - 1)], 1u);
+                s_val[at] = v[j];
+                s_key[at] = k[j];
+            }
+        }
+        __syncthreads();
+        const uint32_t kept = s_pre[kPartBins - 1] + s_cnt[kPartBins - 1];
+        for (uint32_t i = threadIdx.x; i < kept; i += kPartBlock) {
+            const uint32_t key = s_key[i];
+            const uint32_t d = (key >> shift) & (bins - 1);
+            const uint32_t to = s_goff[d] + (i - s_pre[d]);
+            vals_out[to] = s_val[i];
+            keys_out[to] = key;
+        }
+        __syncthreads();
+    }
+}
+
+// A pair's place in its run: by the `kbits` low bits of the key, then by the value (`vbits` significant bits).
+struct PairOrder {
+    uint32_t kbits, vbits;
+    __device__ __forceinline__ uint32_t kmask() const { return kbits >= 32 ? 0xFFFFFFFFu : ((1u << kbits) - 1u); }
+    // the leading kBucketBits of (key's low kbits ++ value's vbits)
+    __device__ __forceinline__ uint32_t bucket(uint32_t key, uint64_t val, uint32_t bucket_bits) const {
+        const uint32_t kk = key & kmask();
+        if (kbits >= bucket_bits) return kk >> (kbits - bucket_bits);
+        const uint32_t take = bucket_bits - kbits;    // the rest comes from the top of the value
+        const uint32_t top = vbits >= take ? (uint32_t)(val >> (vbits - take)) : (uint32_t)(val << (take - vbits));
+        return (kk << take) | (top & ((1u << take) - 1u));
+    }
+};
+
+// k_run_bucket_sort for pairs: the run's values come out in (key, value) order; the keys are not written (nothing after the sort
+// needs them).  The bucket of a pair = the leading 11 bits of what the run still differs in.
+template <int MAXR>
+__global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint32_t *keys, const uint64_t *vals, uint64_t *out, const uint32_t *run_off,
+                                                                      uint32_t n_runs, PairOrder ord, uint32_t min_size, uint32_t *n_hard, uint32_t *hard_list) {
+    __shared__ uint64_t s_val[kPartBlock * MAXR];
+    __shared__ uint32_t s_key[kPartBlock * MAXR];
+    __shared__ uint32_t s_pre[kBuckets + 1], s_cur[kBuckets];
+    __shared__ uint32_t s_wave[4], s_work[4];
+    constexpr uint32_t BPT = kBuckets / kPartBlock;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t total_bits = ord.kbits + ord.vbits;
+    const uint32_t bbits = total_bits < kBucketBits ? total_bits : kBucketBits;
+    const uint32_t kmask = ord.kmask();
+    for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
+        const uint32_t start = run_off[run], N = run_off[run + 1] - start;
+        if (N < min_size) continue;
+        if (N > kPartBlock * MAXR) {
+            if (threadIdx.x == 0 && MAXR == 16) hard_list[atomicAdd(n_hard, 1u)] = run;
+            continue;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < BPT; ++j) s_cur[threadIdx.x * BPT + j] = 0;
+        __syncthreads();
+        uint64_t val[MAXR];
+        uint32_t key[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const uint32_t p = (uint32_t)r * kPartBlock + threadIdx.x;
+            val[r] = 0; key[r] = 0;
+            if (p < N) {
+                key[r] = keys[start + p] & kmask;
+                val[r] = vals[start + p];
+                atomicAdd(&s_cur[ord.bucket(key[r], val[r], bbits)], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            uint32_t c[BPT], sum = 0, sq = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < BPT; ++j) { c[j] = s_cur[threadIdx.x * BPT + j]; sum += c[j]; sq += c[j] * c[j]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += u;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d, 64);
+            if (lane == 63) s_wave[w] = incl;
+            if (lane == 0) s_work[w] = sq;
+            __syncthreads();
+            uint32_t base = incl - sum;
+            for (uint32_t ww = 0; ww < w; ++ww) base += s_wave[ww];
+#pragma unroll
+            for (uint32_t j = 0; j < BPT; ++j) { s_pre[threadIdx.x * BPT + j] = base; s_cur[threadIdx.x * BPT + j] = base; base += c[j]; }
+            if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = base;
+        }
+        __syncthreads();
+        if (s_work[0] + s_work[1] + s_work[2] + s_work[3] > kBucketWork * N) {   // (uniform) crowded buckets: the radix kernel's run
+            if (threadIdx.x == 0) hard_list[atomicAdd(n_hard, 1u)] = run;
+            __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if ((uint32_t)r * kPartBlock + threadIdx.x < N) {
+                const uint32_t at = atomicAdd(&s_cur[ord.bucket(key[r], val[r], bbits)], 1u);
+                s_val[at] = val[r];
+                s_key[at] = key[r];
+            }
+        __syncthreads();
+        uint32_t dest[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const uint32_t p = (uint32_t)r * kPartBlock + threadIdx.x;
+            dest[r] = p;
+            if (p < N) {
+                const uint64_t v = s_val[p];
+                const uint32_t k = s_key[p];
+                val[r] = v;
+                const uint32_t bkt = ord.bucket(k, v, bbits);
+                const uint32_t lo = s_pre[bkt], hi = s_pre[bkt + 1];
+                uint32_t rank = 0;
+                for (uint32_t q = lo; q < hi; ++q) {
+                    const uint64_t ov = s_val[q];
+                    const uint32_t ok = s_key[q];
+                    rank += (ok < k || (ok == k && (ov < v || (ov == v && q < p)))) ? 1u : 0u;
+                }
+                dest[r] = lo + rank;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if ((uint32_t)r * kPartBlock + threadIdx.x < N) s_val[dest[r]] = val[r];
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < N; p += kPartBlock) out[start + p] = s_val[p];
+        __syncthreads();
+    }
+}
+
+// k_run_sort for pairs (the robust path of the runs the bucket kernel names): a stable LSD radix sort in LDS over the value's digits,
+// then over the key's remaining bits.
+template <int MAXR>
+__global__ __launch_bounds__(kPartBlock) void k_run_sort_pair(const uint32_t *keys, const uint64_t *vals, uint64_t *out, const uint32_t *run_off, uint32_t n_runs,
+                                                               PairOrder ord, uint32_t min_size, uint32_t max_size, const uint32_t *list, const uint32_t *list_n) {
+    __shared__ uint64_t s_val[kPartBlock * MAXR];
+    __shared__ uint32_t s_key[kPartBlock * MAXR];
+    __shared__ uint32_t s_cnt[4][kPartBins];
+    __shared__ uint32_t s_wave[4];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t vpasses = (ord.vbits + 7) / 8, kpasses = (ord.kbits + 7) / 8;
+    const uint32_t kmask = ord.kmask();
+    const uint32_t n_todo = list ? *list_n : n_runs;
+    for (uint32_t at = blockIdx.x; at < n_todo; at += gridDim.x) {
+        const uint32_t run = list ? list[at] : at;
+        const uint32_t start = run_off[run], N = run_off[run + 1] - start;
+        if (N < min_size || N > max_size) continue;
+        const uint32_t rounds = (N + kPartBlock - 1) / kPartBlock;
+        const uint32_t chunk = rounds * 64;
+        uint64_t val[MAXR];
+        uint32_t key[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const uint32_t p = w * chunk + (uint32_t)r * 64 + lane;
+            const bool in = (uint32_t)r < rounds && p < N;
+            val[r] = in ? vals[start + p] : 0ull;
+            key[r] = in ? (keys[start + p] & kmask) : 0u;
+        }
+        for (uint32_t pass = 0; pass < vpasses + kpasses; ++pass) {
+            const bool on_val = pass < vpasses;
+            const uint32_t shift = 8 * (on_val ? pass : pass - vpasses);
+            const uint32_t left = (on_val ? ord.vbits : ord.kbits) - shift;
+            const uint32_t dmask = left >= 8 ? 0xFFu : ((1u << left) - 1u);
+            s_cnt[0][threadIdx.x] = 0; s_cnt[1][threadIdx.x] = 0; s_cnt[2][threadIdx.x] = 0; s_cnt[3][threadIdx.x] = 0;
+            __syncthreads();
+            uint32_t woff[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                woff[r] = 0;
+                if ((uint32_t)r < rounds) {
+                    const bool valid = w * chunk + (uint32_t)r * 64 + lane < N;
+                    const uint32_t d = (on_val ? (uint32_t)(val[r] >> shift) : (key[r] >> shift)) & dmask;
+                    uint64_t m = __ballot(valid);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        const uint64_t bal = __ballot((d >> b) & 1u);
+                        m &= ((d >> b) & 1u) ? bal : ~bal;
+                    }
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    uint32_t old = 0;
+                    if (valid && below == 0) old = atomicAdd(&s_cnt[w][d], (uint32_t)__popcll((unsigned long long)m));
+                    old = __shfl(old, valid ? __ffsll((unsigned long long)m) - 1 : (int)lane, 64);
+                    woff[r] = old + below;
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t c0 = s_cnt[0][threadIdx.x], c1 = s_cnt[1][threadIdx.x], c2 = s_cnt[2][threadIdx.x], c3 = s_cnt[3][threadIdx.x];
+                const uint32_t v = c0 + c1 + c2 + c3;
+                uint32_t incl = v;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const uint32_t u = __shfl_up(incl, dd, 64);
+                    if ((int)lane >= dd) incl += u;
+                }
+                if (lane == 63) s_wave[w] = incl;
+                __syncthreads();
+                uint32_t base = incl - v;
+                for (uint32_t ww = 0; ww < w; ++ww) base += s_wave[ww];
+                s_cnt[0][threadIdx.x] = base; s_cnt[1][threadIdx.x] = base + c0; s_cnt[2][threadIdx.x] = base + c0 + c1;
+                s_cnt[3][threadIdx.x] = base + c0 + c1 + c2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r)
+                if ((uint32_t)r < rounds && w * chunk + (uint32_t)r * 64 + lane < N) {
+                    const uint32_t d = (on_val ? (uint32_t)(val[r] >> shift) : (key[r] >> shift)) & dmask;
+                    const uint32_t to = s_cnt[w][d] + woff[r];
+                    s_val[to] = val[r];
+                    s_key[to] = key[r];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const uint32_t p = w * chunk + (uint32_t)r * 64 + lane;
+                if ((uint32_t)r < rounds && p < N) { val[r] = s_val[p]; key[r] = s_key[p]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const uint32_t p = w * chunk + (uint32_t)r * 64 + lane;
+            if ((uint32_t)r < rounds && p < N) out[start + p] = val[r];
+        }
+    }
+}
+
 inline uint32_t part_max_tiles(uint32_t n, uint32_t S) { return n / kPartTile + S + 1; }
 
 }  // namespace cid

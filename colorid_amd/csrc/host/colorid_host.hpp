@@ -237,8 +237,9 @@ void debug_records(const std::string &f1, const std::string *f2, uint8_t q);   /
 // GPU k-mer maps (cid_kmerset, k <= 32; COLORID_HOST_KMERS=1 forces the host map).  count_fastq_gpu returns nullptr when
 // the file holds lower-case bases (their case is kept, so they cannot be packed): the caller counts on the host.
 bool gpu_counting_enabled(uint64_t k);
-cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs);
-cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q);
+// `target`: the index the set is going to be searched in (cid_kmerset_set_target_index: ordered for it at no extra pass); null = code order
+cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs, const cid_index *target = nullptr);
+cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q, const cid_index *target = nullptr);
 int64_t auto_cutoff_gpu(cid_kmerset *ks);   // kmer.rs:866-942 from the device histogram
 
 // ---------------------------------------------------------------- bigsi.rs

@@ -106,9 +106,10 @@ void debug_records(const std::string &f1, const std::string *f2, uint8_t q) {
     });
 }
 
-cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs) {
+cid_kmerset *count_fasta_gpu(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs, const cid_index *target) {
     cid_kmerset *ks = nullptr;
     CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
+    if (target) CID_TRY(cid_kmerset_set_target_index(ks, target));
     SeqBatch sb;
     for (const std::string &s : seqs) sb.push(s);
     CID_TRY(cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 0));
@@ -166,10 +167,11 @@ static bool count_bgzf_on_device(cid_ctx *ctx, cid_kmerset *ks, const std::vecto
         const bool host_part = sx.host_text_bytes > 0;
         // (only the device's members travel: they come first in the stretch; the rest was inflated here)
         const size_t dev_bytes = sx.device_members ? (size_t)sx.off[sx.device_members - 1] + sx.len[sx.device_members - 1] : 0;
-        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
-                                    sx.last && !host_part ? CID_FASTQ_LAST : 0));
-        if (host_part)
-            CID_TRY(cid_fastq_push_text(fr, (int)i, sx.host_text.p, sx.host_text_bytes, (sx.last ? CID_FASTQ_LAST : 0) | (sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members, 0));
+        // ALWAYS the second push, also when it is empty: a classify step takes two pushes per file = exactly one stretch, and the wait
+        // for the copy of the stretch before (CID_FASTQ_KEEP) happens here, before the reader gets that stretch's buffer back
+        CID_TRY(cid_fastq_push_text(fr, (int)i, host_part ? sx.host_text.p : nullptr, host_part ? sx.host_text_bytes : 0,
+                                    (sx.last ? CID_FASTQ_LAST : 0) | (host_part && sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));
         if (sx.last) more[i] = false;
         ms_push += ms_since(tp);
         ++pending[i];
@@ -192,9 +194,10 @@ static bool count_bgzf_on_device(cid_ctx *ctx, cid_kmerset *ks, const std::vecto
 }
 
 // nullptr = the file holds lower-case bases: count it on the host
-cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q) {
+cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q, const cid_index *target) {
     cid_kmerset *ks = nullptr;
     CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
+    if (target) CID_TRY(cid_kmerset_set_target_index(ks, target));
     {
         std::vector<std::string> fq{f1};
         if (f2) fq.push_back(*f2);
@@ -207,6 +210,7 @@ cid_kmerset *count_fastq_gpu(cid_ctx *ctx, uint64_t k, const std::string &f1, co
             }
             cid_kmerset_destroy(ks);   // (a partial count) — the host reads the files again
             CID_TRY(cid_kmerset_create(ctx, (uint32_t)k, &ks));
+            if (target) CID_TRY(cid_kmerset_set_target_index(ks, target));
         }
     }
     const bool ok = stream_fastq_batches(f1, f2, q, [&](const SeqBatch &sb) { return cid_kmerset_add_seqs(ks, sb.bases.data(), sb.off.data(), sb.n(), 1); });
@@ -257,9 +261,9 @@ struct GpuSet {
 };
 static bool count_over_group(uint64_t k) { return g_group && !g_striped && k <= 32 && !getenv("COLORID_ONE_GPU_KMERS"); }
 
-static GpuSet count_fasta_set(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs) {
+static GpuSet count_fasta_set(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs, const cid_index *target) {
     GpuSet gs;
-    if (!count_over_group(k)) { gs.one = count_fasta_gpu(ctx, k, seqs); return gs; }
+    if (!count_over_group(k)) { gs.one = count_fasta_gpu(ctx, k, seqs, target); return gs; }
     CID_TRY(cid_group_kmerset_create(g_group, (uint32_t)k, &gs.many));
     SeqBatch sb;
     for (const std::string &s : seqs) sb.push(s);
@@ -267,9 +271,9 @@ static GpuSet count_fasta_set(cid_ctx *ctx, uint64_t k, const std::vector<std::s
     CID_TRY(cid_group_kmerset_finalize(gs.many, nullptr));
     return gs;
 }
-static GpuSet count_fastq_set(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q) {
+static GpuSet count_fastq_set(cid_ctx *ctx, uint64_t k, const std::string &f1, const std::string *f2, uint8_t q, const cid_index *target) {
     GpuSet gs;
-    if (!count_over_group(k)) { gs.one = count_fastq_gpu(ctx, k, f1, f2, q); return gs; }
+    if (!count_over_group(k)) { gs.one = count_fastq_gpu(ctx, k, f1, f2, q, target); return gs; }
     CID_TRY(cid_group_kmerset_create(g_group, (uint32_t)k, &gs.many));
     const bool ok = stream_fastq_batches(f1, f2, q, [&](const SeqBatch &sb) { return cid_group_kmerset_add_seqs(gs.many, sb.bases.data(), sb.off.data(), sb.n(), 1); });
     if (!ok) { gs.destroy(); return gs; }
@@ -311,7 +315,7 @@ void perfect_search::batch_search(cid_ctx *ctx, const std::vector<std::string> &
     for (const std::string &file : files) {
         fprintf(stderr, "Counting k-mers, this may take a while!\n");
         if (gpu_counting(b)) {
-            GpuSet ks = count_fasta_set(ctx, b.k_size, read_fasta(file));
+            GpuSet ks = count_fasta_set(ctx, b.k_size, read_fasta(file), b.index);
             const uint64_t n = ks.size();
             fprintf(stderr, "%llu kmers in query\n", (unsigned long long)n);
             if (n == 0) {
@@ -376,8 +380,8 @@ void batch_search_pe::batch_search(cid_ctx *ctx, const std::vector<std::string> 
         size_t n_kmers = 0;
         GpuSet ks;
         if (gpu_counting(b)) {
-            ks = gz ? count_fastq_set(ctx, b.k_size, file1, files2.empty() ? nullptr : &files2[i], qual_offset)
-                    : count_fasta_set(ctx, b.k_size, read_fasta(file1));
+            ks = gz ? count_fastq_set(ctx, b.k_size, file1, files2.empty() ? nullptr : &files2[i], qual_offset, b.index)
+                    : count_fasta_set(ctx, b.k_size, read_fasta(file1), b.index);
         }
         if (ks) {  // the k-mer map lives on the device(s)
             uint64_t t = fasta_gene ? 0 : (uint64_t)(filter < 0 ? 0 : filter);

@@ -2,6 +2,7 @@
 //   read_id_mt_pe::per_read_stream_se/_pe, stream_fasta (src/read_id_mt_pe.rs) -> cid_readid_count* / cid_fastq_*
 // plus the CPU-side tail (kmer_poll_plus, the counts file of src/reports.rs).  File formats follow the reference.
 #include "drivers_common.hpp"
+#include <unistd.h>
 
 namespace colorid {
 
@@ -442,8 +443,13 @@ int read_id_mt_pe::device_fastq_host_threads(size_t n_files) {
     return v < 1 ? 1 : v > 12 ? 12 : v;
 }
 namespace {
-// false: the input is not this path's (reads too long for the LDS kernels) and nothing has been written yet — the caller falls back
-bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, size_t n_files, const Bigsi &b, size_t d, size_t start_sample,
+// kFrontEndDone: every read went through the device front end.  kFrontEndNotMine: the input is not this path's (reads too long for the
+// LDS kernels, a step over the dense-row limit) — in the FIRST step, nothing has been written: the caller takes the host front end.
+// kFrontEndRestart: the same in a LATER step, rows of the earlier stretches are already on their way to the output: the caller
+// finishes the classifier, empties the output and runs the whole input through the host front end (which takes such reads) — an input
+// that the host path completes is never a hard failure here.
+enum FrontEnd { kFrontEndDone, kFrontEndNotMine, kFrontEndRestart };
+FrontEnd classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, size_t n_files, const Bigsi &b, size_t d, size_t start_sample,
                              uint8_t qual_offset, BatchClassifier &classifier) {
     const auto t_enter = Clock::now();
     cid_fastq *fr = nullptr;
@@ -474,10 +480,11 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
         const bool host_part = sx.host_text_bytes > 0;
         // (only the device's members travel: they come first in the stretch; the rest was inflated here)
         const size_t dev_bytes = sx.device_members ? (size_t)sx.off[sx.device_members - 1] + sx.len[sx.device_members - 1] : 0;
-        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
-                                    sx.last && !host_part ? CID_FASTQ_LAST : 0));
-        if (host_part)
-            CID_TRY(cid_fastq_push_text(fr, (int)i, sx.host_text.p, sx.host_text_bytes, (sx.last ? CID_FASTQ_LAST : 0) | (sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members, 0));
+        // ALWAYS the second push, also when it is empty: a classify step takes two pushes per file = exactly one stretch, and the wait
+        // for the copy of the stretch before (CID_FASTQ_KEEP) happens here, before the reader gets that stretch's buffer back
+        CID_TRY(cid_fastq_push_text(fr, (int)i, host_part ? sx.host_text.p : nullptr, host_part ? sx.host_text_bytes : 0,
+                                    (sx.last ? CID_FASTQ_LAST : 0) | (host_part && sx.host_text.pinned ? CID_FASTQ_KEEP : 0)));
         if (sx.last) more[i] = false;
         ms_push += ms_since(tp);
         ++pending[i];
@@ -490,6 +497,7 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
     // the results of the step BEFORE (they stay valid until the next _end, and travel on a stream of their own) and pushing the
     // stretch after the next.  Done the other way round — classify, fetch, push, in a row — the GPU idled ~5 ms of every 18.
     bool first = true;
+    size_t n_steps = 0;
     uint64_t have_n = 0, have_ne = 0, have_idb = 0;   // an ended step whose results are still on the device
     bool have = false;
     for (;;) {
@@ -501,14 +509,18 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
             const int rc = cid_fastq_classify_begin(fr, b.index, (uint32_t)d, (uint32_t)start_sample, 2);
             ms_classify += ms_since(tc);
             for (size_t i = 0; i < n_files; ++i) if (pending[i]) --pending[i];
-            if (rc == CID_ERR_UNSUPPORTED && first) {
-                fprintf(stderr, "note: %s — using the host front end\n", cid_last_error());
+            const char *fail_at = getenv("COLORID_DEVICE_FASTQ_FAIL_AT_STEP");   // tests: the step that meets an input the device path refuses
+            const bool refused = rc == CID_ERR_UNSUPPORTED || (rc == CID_OK && fail_at && (size_t)atol(fail_at) == n_steps);
+            if (refused) {
+                fprintf(stderr, "note: %s — %s\n", rc == CID_OK ? "COLORID_DEVICE_FASTQ_FAIL_AT_STEP" : cid_last_error(),
+                        first ? "using the host front end" : "starting over with the host front end");
                 cid_fastq_destroy(fr);
                 classifier.ids_stay_with_counted(false);
-                return false;
+                return first ? kFrontEndNotMine : kFrontEndRestart;
             }
-            if (rc != CID_OK) die("%s%s", cid_last_error(), rc == CID_ERR_UNSUPPORTED ? " (rerun with COLORID_DEVICE_FASTQ=0)" : "");
+            if (rc != CID_OK) die("%s", cid_last_error());
             first = false;
+            ++n_steps;
         }
         if (have && have_n) {
             const auto tb = Clock::now();
@@ -546,7 +558,13 @@ bool classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &fq, s
         fprintf(stderr, "timing: device front end: waiting for the file reader %.0f ms, push (H2D of the members) %.0f ms, classify %.0f ms, fetch %.0f ms "
                 "(+ %.0f ms sizing its buffers), handing the rows to the poll %.0f ms; %.0f ms until the first stretch was pushed, %.0f ms in all\n",
                 ms_read, ms_push, ms_classify, ms_fetch, ms_buffers, ms_handover, ms_setup, ms_since(t_enter));
-    return true;
+    return kFrontEndDone;
+}
+
+// the rows written so far belong to a run that is being started over: an empty output again
+void empty_output(FILE *out) {
+    if (fflush(out) != 0 || ftruncate(fileno(out), 0) != 0) die("could not empty the outfile for the restart");
+    rewind(out);
 }
 }  // namespace
 
@@ -559,16 +577,23 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 1);
     if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));   // no packing threads beside them: a stretch's poll on 4 threads takes 18 ms, the GPU side 13
-    BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
+    auto make_classifier = [&] { return std::unique_ptr<BatchClassifier>(new BatchClassifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r")); };
+    std::unique_ptr<BatchClassifier> classifier = make_classifier();
     if (g_timing) fprintf(stderr, "timing: %.0f ms of set-up before the first read\n", ms_since(t0));
-    if (!on_device || !classify_bgzf_on_device(ctx, fq, 1, b, d, start_sample, qual_offset, classifier))
+    FrontEnd fe = on_device ? classify_bgzf_on_device(ctx, fq, 1, b, d, start_sample, qual_offset, *classifier) : kFrontEndNotMine;
+    if (fe == kFrontEndRestart) {
+        classifier->finish();
+        empty_output(out);
+        classifier = make_classifier();
+    }
+    if (fe != kFrontEndDone)
     stream_fastq_records(fq[0], nullptr, qual_offset, true, [&](ReadBatch &&piece) {
         if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
-        if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);   // (batches close on piece boundaries: at least `batch` reads each)
-    }, [&] { return classifier.spare(); });
-    classifier.submit(rb);
+        if (rb.size() >= batch || rb.heavy()) classifier->submit(rb);   // (batches close on piece boundaries: at least `batch` reads each)
+    }, [&] { return classifier->spare(); });
+    classifier->submit(rb);
     const auto t_drain = Clock::now();
-    const uint64_t read_count = classifier.finish();
+    const uint64_t read_count = classifier->finish();
     const double ms_drain = ms_since(t_drain);
     const auto t_close = Clock::now();
     fclose(out);
@@ -586,14 +611,21 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 2);
     if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));
-    BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r");
-    if (!on_device || !classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, classifier))
+    auto make_classifier = [&] { return std::unique_ptr<BatchClassifier>(new BatchClassifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r")); };
+    std::unique_ptr<BatchClassifier> classifier = make_classifier();
+    FrontEnd fe = on_device ? classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, *classifier) : kFrontEndNotMine;
+    if (fe == kFrontEndRestart) {
+        classifier->finish();
+        empty_output(out);
+        classifier = make_classifier();
+    }
+    if (fe != kFrontEndDone)
     stream_fastq_records(fq[0], &fq[1], qual_offset, true, [&](ReadBatch &&piece) {
         if (rb.size() == 0) rb = std::move(piece); else rb.append(piece);
-        if (rb.size() >= batch || rb.heavy()) classifier.submit(rb);
-    }, [&] { return classifier.spare(); });
-    classifier.submit(rb);
-    const uint64_t read_count = classifier.finish();
+        if (rb.size() >= batch || rb.heavy()) classifier->submit(rb);
+    }, [&] { return classifier->spare(); });
+    classifier->submit(rb);
+    const uint64_t read_count = classifier->finish();
     fclose(out);
     fprintf(stderr, "Classified %llu read pairs in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
     print_read_id_timing(t0);

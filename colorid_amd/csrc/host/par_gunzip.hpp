@@ -261,6 +261,9 @@ template <typename Scratch>
 inline uint64_t find_block(const uint8_t *buf, size_t n_bytes, uint64_t from_bit, uint64_t to_bit, MarkerInflate &mi, Scratch &scratch) {
     constexpr size_t kTrial = MarkerInflate::kWindow + (1u << 22);
     scratch.need(kTrial);
+    // the unknown window before the trial position holds markers, as in the real chunk decode: a match reaching back into it copies
+    // defined values (the trial's verdict does not depend on them; an indeterminate read would still be one)
+    for (size_t i = 0; i < MarkerInflate::kWindow; ++i) scratch.data()[i] = (uint16_t)(256 + i);
     for (uint64_t p = from_bit; p < to_bit; ++p) {
         const size_t byte = (size_t)(p >> 3);
         if (byte + 16 > n_bytes) return ~(uint64_t)0;

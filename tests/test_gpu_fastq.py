@@ -302,6 +302,46 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
 
 
 @pytest.mark.parametrize("paired", [False, True])
+def test_cli_read_id_device_front_end_gives_way_mid_run(orc, tmp_path, paired):
+    """A stretch the device front end refuses (a read too long for the LDS kernels, a step over the dense-row limit) is not a hard
+    failure: in the first step nothing has been written and the host front end takes over; in a LATER step the rows written so far are
+    discarded and the whole input runs through the host front end — same _reads.txt / _counts.txt as COLORID_DEVICE_FASTQ=0.  The
+    refusal is injected (COLORID_DEVICE_FASTQ_FAIL_AT_STEP) at steps 0, 1 and 3 of a run of several stretches; R2 is shorter than R1."""
+    import os
+    import subprocess
+
+    from test_gpu_cli import BIN, PHAGES, REFS
+    tsv = tmp_path / "ref_file.txt"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES))
+    pre = str(tmp_path / "phage")
+    p = subprocess.run([BIN, "build", "-s", "750000", "-n", "4", "-k", "27", "-b", pre, "-r", str(tsv)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    genomes = [b"".join(orc.read_fasta(os.path.join(REFS, n + ".fasta"))) for n in PHAGES]
+    rng = np.random.default_rng(9)
+    r1 = synth_fastq_records(np.random.default_rng(22), genomes, 16000, 150, mate=0, lower_rate=0.0)
+    r2 = synth_fastq_records(np.random.default_rng(22), genomes, 16000, 150, mate=1, lower_rate=0.0)
+    f1, f2 = str(tmp_path / "r_1.fastq.gz"), str(tmp_path / "r_2.fastq.gz")
+    _write_bgzf(f1, fastq_text(r1), rng)
+    _write_bgzf(f2, fastq_text(r2[:9000]), rng)          # a truncated R2: R1's surplus has no mates
+    q = [f1, f2] if paired else [f1]
+    outs = {}
+    for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {"COLORID_DEVICE_FASTQ_MB": "1"}),
+                     ("fail0", {"COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_FAIL_AT_STEP": "0"}),
+                     ("fail1", {"COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_FAIL_AT_STEP": "1"}),
+                     ("fail3", {"COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_FAIL_AT_STEP": "3", "COLORID_DEVICE_FASTQ_AHEAD": "2"})):
+        name = str(tmp_path / tag)
+        p = subprocess.run([BIN, "read_id", "-b", pre + ".bxi", "-q", *q, "-n", name], capture_output=True, text=True, env=dict(os.environ, COLORID_TIMING="1", **env))
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        outs[tag] = (open(name + "_reads.txt").read(), open(name + "_counts.txt").read(), p.stderr)
+    host = outs["host"]
+    assert host[0].count("\n") == (9000 if paired else 16000)
+    for tag in ("dev", "fail0", "fail1", "fail3"):
+        assert outs[tag][0] == host[0] and outs[tag][1] == host[1], tag
+    assert "using the host front end" in outs["fail0"][2]
+    assert "starting over with the host front end" in outs["fail1"][2] and "starting over with the host front end" in outs["fail3"][2]
+
+
+@pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("q", [0, 15])
 def test_count_kmers_equals_the_oracles_fastq_maps(orc, hip_ctx, world, paired, q):
     """cid_fastq_count_kmers — `search`'s fastq k-mer maps (kmer.rs:461-510 single-end, :581-655 pairs) from text on the device: records

@@ -16,9 +16,15 @@ reads = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(n_reads, L))]
 reads = np.ascontiguousarray(reads)
 so = (np.arange(n_reads + 1, dtype=np.uint64) * L)
 ctx = colorid_amd.Context(0)
+target = None
+if os.environ.get("EXP_TARGET"):     # the set built FOR an index (cid_kmerset_set_target_index): m = 50 M, n = 4, 256 colours
+    target = colorid_amd.Index(ctx, 50_000_000, 4, k, 256)
+    target.finalize()
 rows = []
 for it in range(int(os.environ.get("EXP_ITERS", 5))):
     ks = colorid_amd.KmerSet(ctx, k)
+    if target is not None:
+        ks.set_target_index(target)
     t0 = time.perf_counter()
     check(ks.lib.cid_kmerset_add_seqs(ks.h, reads.ctypes.data_as(vp), so.ctypes.data_as(vp), n_reads, 0))
     t1 = time.perf_counter()
