@@ -65,6 +65,19 @@ __device__ __forceinline__ PartTile part_tile(const uint32_t *seg_off, const uin
     return t;
 }
 
+// Which tiles a workgroup of a scatter kernel takes.  The runs a tile writes continue, byte for byte, the runs of the tile before it
+// (same digit), so neighbouring tiles fill the same 128-byte lines.  Workgroups are dealt to the eight XCDs in turn (blockIdx & 7) and
+// every XCD has an L2 of its own: with tile = blockIdx (+ k * gridDim) those two halves of a line are always written through two
+// different L2s.  Here XCD x walks the x-th eighth of the tiles, its workgroups side by side on neighbouring tiles, so a line's halves
+// meet in one L2 and leave as one full-line write.  (gridDim.x must be a multiple of 8.)
+struct XcdWalk {
+    uint32_t chunk;   // tiles per XCD
+    __device__ explicit XcdWalk(uint32_t n_tiles) : chunk((n_tiles + 7u) / 8u) {}
+    __device__ uint32_t first() const { return blockIdx.x >> 3; }
+    __device__ uint32_t stride() const { return gridDim.x >> 3; }
+    __device__ uint32_t tile(uint32_t it) const { return (blockIdx.x & 7u) * chunk + it; }
+};
+
 // `top` < 64: keys with a bit at or above `top` (the k-mer set's "no k-mer here" sentinel) are left out of the partition — counted
 // into *n_dropped by the first level, skipped by the scatter — so that every digit below `top` orders real keys only.
 __global__ __launch_bounds__(kPartBlock) void k_part_hist(const uint64_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
@@ -73,13 +86,22 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(const uint64_t *keys, 
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        constexpr uint32_t PER = kPartTile / kPartBlock;
+        uint64_t k[PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {   // the tile's loads in flight together
+            const uint32_t i = j * kPartBlock + threadIdx.x;
+            k[j] = i < t.count ? keys[t.first + i] : 0ull;
+        }
         s_cnt[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_drop = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < t.count; i += kPartBlock) {
-            const uint64_t key = keys[t.first + i];
-            if (top < 64 && (key >> top)) atomicAdd(&s_drop, 1u);
-            else atomicAdd(&s_cnt[(uint32_t)(key >> shift) & (bins - 1)], 1u);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            if (j * kPartBlock + threadIdx.x < t.count) {
+                if (top < 64 && (k[j] >> top)) atomicAdd(&s_drop, 1u);
+                else atomicAdd(&s_cnt[(uint32_t)(k[j] >> shift) & (bins - 1)], 1u);
+            }
         }
         __syncthreads();
         if (threadIdx.x < bins) table[t.table_at + threadIdx.x * t.table_stride] = s_cnt[threadIdx.x];
@@ -94,7 +116,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(const uint64_t *key
     __shared__ uint32_t s_cnt[kPartBins], s_pre[kPartBins], s_cur[kPartBins], s_goff[kPartBins], s_wave[kPartBlock / 64];
     constexpr uint32_t PER = kPartTile / kPartBlock;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const XcdWalk walk(n_tiles);
+    for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
+        const uint32_t tile = walk.tile(it);
+        if (tile >= n_tiles) break;
         const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
         s_cnt[threadIdx.x] = 0;
         s_goff[threadIdx.x] = threadIdx.x < bins ? table[t.table_at + threadIdx.x * t.table_stride] : 0u;
@@ -264,7 +289,8 @@ template <int MAXR>
 __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort(const uint64_t *in, uint64_t *out, const uint32_t *run_off, uint32_t n_runs, uint32_t bits,
                                                                  uint32_t min_size, uint32_t *n_hard, uint32_t *hard_list) {
     __shared__ uint64_t s_key[kPartBlock * MAXR];
-    __shared__ uint32_t s_pre[kBuckets + 1], s_cur[kBuckets];
+    __shared__ uint16_t s_pre[kBuckets + 1];   // (a run holds at most 4096 keys: 16 bits, and a workgroup more per CU)
+    __shared__ uint32_t s_cur[kBuckets];
     __shared__ uint32_t s_wave[4], s_work[4];
     constexpr uint32_t BPT = kBuckets / kPartBlock;   // buckets per thread
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -309,8 +335,8 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort(const uint64_t *
             uint32_t base = incl - sum;
             for (uint32_t ww = 0; ww < w; ++ww) base += s_wave[ww];
 #pragma unroll
-            for (uint32_t j = 0; j < BPT; ++j) { s_pre[threadIdx.x * BPT + j] = base; s_cur[threadIdx.x * BPT + j] = base; base += c[j]; }
-            if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = base;
+            for (uint32_t j = 0; j < BPT; ++j) { s_pre[threadIdx.x * BPT + j] = (uint16_t)base; s_cur[threadIdx.x * BPT + j] = base; base += c[j]; }
+            if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = (uint16_t)base;
         }
         __syncthreads();
         if (s_work[0] + s_work[1] + s_work[2] + s_work[3] > kBucketWork * N) {   // (uniform) crowded buckets: the radix kernel's run
@@ -376,16 +402,26 @@ constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 __global__ __launch_bounds__(kPartBlock) void k_part_hist_key(const uint32_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
                                                                uint32_t shift, uint32_t bits, uint32_t first_level, uint32_t *table, uint32_t *n_dropped) {
     __shared__ uint32_t s_cnt[kPartBins], s_drop;
+    constexpr uint32_t PER = kPartTile / kPartBlock;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        uint32_t k[PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {   // the tile's loads in flight together
+            const uint32_t i = j * kPartBlock + threadIdx.x;
+            k[j] = i < t.count ? keys[t.first + i] : kNoKey;
+        }
         s_cnt[threadIdx.x] = 0;
         if (threadIdx.x == 0) s_drop = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < t.count; i += kPartBlock) {
-            const uint32_t key = keys[t.first + i];
-            if (first_level && key == kNoKey) atomicAdd(&s_drop, 1u);
-            else atomicAdd(&s_cnt[(key >> shift) & (bins - 1)], 1u);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const uint32_t i = j * kPartBlock + threadIdx.x;
+            if (i < t.count) {
+                if (first_level && k[j] == kNoKey) atomicAdd(&s_drop, 1u);
+                else atomicAdd(&s_cnt[(k[j] >> shift) & (bins - 1)], 1u);
+            }
         }
         __syncthreads();
         if (threadIdx.x < bins) table[t.table_at + threadIdx.x * t.table_stride] = s_cnt[threadIdx.x];
@@ -403,7 +439,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter_pair(const uint32_t
     __shared__ uint32_t s_cnt[kPartBins], s_pre[kPartBins], s_cur[kPartBins], s_goff[kPartBins], s_wave[kPartBlock / 64];
     constexpr uint32_t PER = kPartTile / kPartBlock;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const XcdWalk walk(n_tiles);
+    for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
+        const uint32_t tile = walk.tile(it);
+        if (tile >= n_tiles) break;
         const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
         s_cnt[threadIdx.x] = 0;
         s_goff[threadIdx.x] = threadIdx.x < bins ? table[t.table_at + threadIdx.x * t.table_stride] : 0u;
@@ -482,7 +521,8 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint3
                                                                       uint32_t n_runs, PairOrder ord, uint32_t min_size, uint32_t *n_hard, uint32_t *hard_list) {
     __shared__ uint64_t s_val[kPartBlock * MAXR];
     __shared__ uint32_t s_key[kPartBlock * MAXR];
-    __shared__ uint32_t s_pre[kBuckets + 1], s_cur[kBuckets];
+    __shared__ uint16_t s_pre[kBuckets + 1];   // (a run holds at most 4096 keys: 16 bits, and a workgroup more per CU)
+    __shared__ uint32_t s_cur[kBuckets];
     __shared__ uint32_t s_wave[4], s_work[4];
     constexpr uint32_t BPT = kBuckets / kPartBlock;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -530,8 +570,8 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint3
             uint32_t base = incl - sum;
             for (uint32_t ww = 0; ww < w; ++ww) base += s_wave[ww];
 #pragma unroll
-            for (uint32_t j = 0; j < BPT; ++j) { s_pre[threadIdx.x * BPT + j] = base; s_cur[threadIdx.x * BPT + j] = base; base += c[j]; }
-            if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = base;
+            for (uint32_t j = 0; j < BPT; ++j) { s_pre[threadIdx.x * BPT + j] = (uint16_t)base; s_cur[threadIdx.x * BPT + j] = base; base += c[j]; }
+            if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = (uint16_t)base;
         }
         __syncthreads();
         if (s_work[0] + s_work[1] + s_work[2] + s_work[3] > kBucketWork * N) {   // (uniform) crowded buckets: the radix kernel's run

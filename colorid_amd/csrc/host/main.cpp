@@ -185,7 +185,15 @@ void replicate(Gpus &g, Bigsi &b) {   // after the index is loaded on rank 0
     set_group(g.group, g.replicas);
 }
 
+// The process is about to end and its results are written and closed: freeing gigabytes of HBM object by object, unloading the code
+// objects and the runtime's own teardown buy nothing — the driver reclaims a process's memory in one go — but cost 0.1-0.2 s of a
+// 0.7 s `read_id`.  One-GPU runs therefore skip release() and leave through leave(); COLORID_FULL_TEARDOWN=1 (the sanitizer runs,
+// anybody embedding the drivers) keeps the orderly way, and so do multi-GPU runs (RCCL communicators are shut down properly).
+bool g_orderly_exit = getenv("COLORID_FULL_TEARDOWN") != nullptr;
+
 void release(Gpus &g, Bigsi &b) {
+    if (!g_orderly_exit && !g.group) { cid_ctx_synchronize(g.ctx); return; }
+    g_orderly_exit = true;
     for (cid_index *ix : g.replicas)
         if (ix && ix != b.index) cid_index_destroy(ix);
     if (b.index) cid_index_destroy(b.index);
@@ -532,6 +540,15 @@ int cmd_debug_records(int argc, char **argv) {
     return 0;
 }
 
+// the end of a subcommand: everything it printed leaves the stdio buffers, then the process ends without the teardown (see release())
+int leave(int rc) {
+    phase_done("subcommand returned");
+    fflush(stdout);
+    fflush(stderr);
+    if (!g_orderly_exit) _exit(rc);
+    return rc;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -542,14 +559,14 @@ int main(int argc, char **argv) {
         return 1;
     }
     const std::string cmd = argv[1];
-    if (cmd == "build") return cmd_build(argc, argv);
-    if (cmd == "search") return cmd_search(argc, argv);
-    if (cmd == "info") return cmd_info(argc, argv);
-    if (cmd == "read_id") return cmd_read_id(argc, argv);
-    if (cmd == "hashcheck") return cmd_hashcheck(argc, argv);
+    if (cmd == "build") return leave(cmd_build(argc, argv));
+    if (cmd == "search") return leave(cmd_search(argc, argv));
+    if (cmd == "info") return leave(cmd_info(argc, argv));
+    if (cmd == "read_id") return leave(cmd_read_id(argc, argv));
+    if (cmd == "hashcheck") return leave(cmd_hashcheck(argc, argv));
     if (cmd == "debug-kmers") return cmd_debug_kmers(argc, argv);
     if (cmd == "debug-records") return cmd_debug_records(argc, argv);
-    if (cmd == "batch_id") return cmd_batch_id(argc, argv);
+    if (cmd == "batch_id") return leave(cmd_batch_id(argc, argv));
     if (cmd == "read_filter") die("'%s' is outside the accelerated query path; use the reference binary", cmd.c_str());
     die("error: Found argument '%s' which wasn't expected", cmd.c_str());
 }

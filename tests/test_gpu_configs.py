@@ -7,6 +7,11 @@ configs[0]  `build` + `search -s` at k = 31, -s 50,000,000, -n 4 on 46 accession
 configs[3]  one GPU's share of "100 M reads over 8 GPUs": 12.5 M x 150 bp reads = 1.5 G k-mer windows counted by cid_kmerset in
             >= 8 incremental merges (/root/reference/src/kmer.rs:461-510 the fastq map, :826-837 clean_map's input) and searched
             against m = 50 M x 1024 colours (/root/reference/src/batch_search_pe.rs:24-105).
+configs[2]  `build -k 21 -s 30000000 -n 2` on 256 synthetic genomes of 5 Mbp + `read_id` on 1 M synthetic reads (the stated fastq,
+            test_data/SRR548019.fastq.gz, is absent from the reference tree), single-end and paired, as a single-stream .fastq.gz and
+            as block gzip: /root/reference/src/build.rs:33-130, src/read_id_mt_pe.rs:66-165 (counts), :187-251 (kmer_poll_plus),
+            :835-951 / :701-832 (the streams), src/reports.rs:98-120 (_counts.txt) — _reads.txt rows of a 3,000-read sample against
+            the oracle reading the .bxi the CLI wrote.
 """
 import ctypes as C
 import json
@@ -184,6 +189,161 @@ def test_config_a_build_and_perfect_search_at_full_size(orc, hip_ctx, tmp_path):
     t.pop("t0")
     _record_timings("r03_config_a_full.json", {"config": "configs[0]: build + search -s, k=31 m=50M n=4, 46 accessions x 2.9 Mbp, query K=%d" % K,
                                                 "bxi_bytes": os.path.getsize(bxi), "phases_ms": t})
+
+
+def _fastq_blob(ids_width, reads, quals):
+    """fixed-width FASTQ text: '@r%0*d\n' + bases + '\n+\n' + quals + '\n' per read, built column-wise"""
+    n, L = reads.shape
+    w = 2 + ids_width + 1 + L + 3 + L + 1
+    rec = np.empty((n, w), np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    num = np.arange(n, dtype=np.int64)
+    for j in range(ids_width):
+        rec[:, 2 + ids_width - 1 - j] = 48 + (num // 10 ** j) % 10
+    c = 2 + ids_width
+    rec[:, c] = 10
+    rec[:, c + 1:c + 1 + L] = reads
+    rec[:, c + 1 + L:c + 4 + L] = np.frombuffer(b"\n+\n", np.uint8)
+    rec[:, c + 4 + L:c + 4 + 2 * L] = quals
+    rec[:, w - 1] = 10
+    return rec.reshape(-1).tobytes()
+
+
+def _write_bgzf_blocks(path, blob, block=65280):
+    import zlib
+    with open(path, "wb") as f:
+        for i in range(0, len(blob), block):
+            c = blob[i:i + block]
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = co.compress(c) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1))
+            f.write(body + struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+def test_config_c_build_and_read_id_at_full_size(orc, tmp_path):
+    import subprocess
+    import zlib
+
+    from test_gpu_cli import BANNER, BIN, counts_file
+
+    def cli(*args, env=None):
+        p = subprocess.run([BIN, *args], capture_output=True, text=True, env=dict(os.environ, COLORID_TIMING="1", **(env or {})))
+        assert p.returncode == 0, p.stderr[-3000:]
+        assert p.stdout.startswith(BANNER)
+        return p.stdout[len(BANNER):], p.stderr
+
+    t = {"t0": time.perf_counter()}
+
+    def lap(name):
+        now = time.perf_counter()
+        t[name] = round((now - t["t0"]) * 1e3)
+        t["t0"] = now
+
+    n_acc, m, n, k, Lg, R, L = 256, 30_000_000, 2, 21, 5_000_000, 1_000_000, 150
+    rng = np.random.default_rng(2026)
+    meta = ACGT[rng.integers(0, 4, n_acc * Lg, dtype=np.uint8)]
+    lines = []
+    for i in range(n_acc):
+        fa = tmp_path / f"g{i:03d}.fasta"
+        with open(fa, "wb") as f:
+            f.write(b">genome%03d\n" % i)
+            f.write(meta[i * Lg:(i + 1) * Lg].tobytes())
+            f.write(b"\n")
+        lines.append(f"genome{i:03d}\t{fa}\n")
+    tsv = tmp_path / "refs.tsv"
+    tsv.write_text("".join(lines))
+    lap("make_genomes_ms")
+    pre = str(tmp_path / "cfg2")
+    _, err_b = cli("build", "-k", str(k), "-s", str(m), "-n", str(n), "-b", pre, "-r", str(tsv))
+    bxi = pre + ".bxi"
+    lap("cli_build_ms")
+    # reads: fragments of 300-500 bp, mate 1 from the fragment's start, mate 2 the reverse complement of its end; 1 % substitutions,
+    # N at 0.3 % of the bases, phred < 15 at 4 % (masked to N by -Q 15), one read in 64 drawn from no genome at all
+    gsel = rng.integers(0, n_acc, R)
+    frag = rng.integers(300, 500, R)
+    st = gsel.astype(np.int64) * Lg + rng.integers(0, Lg - 500, R)
+    ar = np.arange(L, dtype=np.int64)
+    r1 = meta[st[:, None] + ar[None, :]]
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    r2 = comp[meta[(st + frag)[:, None] - 1 - ar[None, :]]]
+    alien = np.flatnonzero(rng.random(R) < 1 / 64)
+    r1[alien] = ACGT[rng.integers(0, 4, (len(alien), L), dtype=np.uint8)]
+    r2[alien] = ACGT[rng.integers(0, 4, (len(alien), L), dtype=np.uint8)]
+    quals = []
+    for rd in (r1, r2):
+        e = rng.random(rd.shape) < 0.01
+        rd[e] = ACGT[rng.integers(0, 4, int(e.sum()), dtype=np.uint8)]
+        rd[rng.random(rd.shape) < 0.003] = ord("N")
+        q = np.full(rd.shape, ord("I"), np.uint8)
+        lq = rng.random(rd.shape) < 0.04
+        q[lq] = rng.integers(33, 48, int(lq.sum()), dtype=np.uint8)
+        quals.append(q)
+    del meta
+    blobs = [_fastq_blob(7, r1, quals[0]), _fastq_blob(7, r2, quals[1])]
+    files = {}
+    for mate, blob in enumerate(blobs):
+        plain = str(tmp_path / f"reads_{mate + 1}.fastq.gz")
+        co = zlib.compressobj(1, zlib.DEFLATED, 31)           # one gzip stream, as `gzip -1` writes it
+        with open(plain, "wb") as f:
+            f.write(co.compress(blob)); f.write(co.flush())
+        bg = str(tmp_path / f"reads_{mate + 1}.bgzf.fastq.gz")
+        _write_bgzf_blocks(bg, blob)
+        files[("plain", mate)], files[("bgzf", mate)] = plain, bg
+    del blobs
+    lap("make_reads_ms")
+    outs, errs = {}, {}
+    for kind in ("plain", "bgzf"):
+        for pe in (False, True):
+            prefix = str(tmp_path / f"rid_{kind}_{int(pe)}")
+            q = [files[(kind, 0)]] + ([files[(kind, 1)]] if pe else [])
+            _, e = cli("read_id", "-b", bxi, "-q", *q, "-n", prefix)
+            outs[(kind, pe)] = (open(prefix + "_reads.txt").read().splitlines(), open(prefix + "_counts.txt").read().splitlines())
+            errs[(kind, pe)] = [ln.split("\r")[-1] for ln in e.splitlines() if "timing:" in ln or "Classified" in ln]
+            lap(f"cli_read_id_{kind}_{'pe' if pe else 'se'}_ms")
+    for pe in (False, True):
+        assert outs[("plain", pe)] == outs[("bgzf", pe)]                      # the two front ends write the same files
+        rows = outs[("plain", pe)][0]
+        assert len(rows) == R
+        assert sorted(outs[("plain", pe)][1]) == counts_file(rows)            # reports.rs:98-120 over all million rows
+    # the oracle on the index file the CLI wrote, for a sample spread over the input (batch starts, middles and the tail)
+    oix = orc.Index.read(bxi)
+    assert (oix.m, oix.n_hash, oix.k, oix.n_colors) == (m, n, k, n_acc)
+    lap("oracle_reads_bxi_ms")
+    sample = np.r_[0:1000, 49_990:50_010, 499_000:500_000, R - 980:R]
+    labels = set()
+    for pe in (False, True):
+        masked = [[orc.qual_mask(r1[i].tobytes(), quals[0][i].tobytes(), 15)] + ([orc.qual_mask(r2[i].tobytes(), quals[1][i].tobytes(), 15)] if pe else [])
+                  for i in sample]
+        seqs = [s for rd in masked for s in rd]
+        seq_off = np.zeros(len(seqs) + 1, np.uint64)
+        seq_off[1:] = np.cumsum([len(s) for s in seqs])
+        read0 = np.arange(len(masked) + 1, dtype=np.uint64) * (2 if pe else 1)
+        rep, nk, st_ = oix.readid_counts(np.frombuffer(b"".join(seqs), np.uint8), seq_off, read0, 1, 3, n_threads=8)
+        got = outs[("plain", pe)][0]
+        for j, i in enumerate(sample):
+            rid = "@r%07d" % i
+            if st_[j] == 1:
+                want = f"{rid}\ttoo_short\t0\t0\taccept\t0"
+            else:
+                lab, cnt, kl, verdict, ntop = oix.kmer_poll_plus(rep[j].astype(np.uint64), int(nk[j]), 1e-3)
+                want = f"{rid}\t{lab}\t{cnt}\t{kl}\t{verdict}\t{ntop}"
+                labels.add((lab, verdict))
+            assert got[i] == want, (pe, i)
+    lap("oracle_sample_ms")
+    # the classification means something: most reads go to the genome they were cut from, the reads from nowhere do not
+    se_rows = outs[("plain", False)][0]
+    aliens = set(alien.tolist())
+    right = sum(1 for i in sample if i not in aliens and se_rows[i].split("\t")[1] == "genome%03d" % gsel[i])
+    assert right > 0.8 * len(sample)
+    turned_away = sum(1 for i in alien[:400] if se_rows[i].split("\t")[4] == "reject" or se_rows[i].split("\t")[1] in ("no_hits", "too_short"))
+    assert turned_away > 0.9 * 400
+    assert len(labels) > 100
+    t.pop("t0")
+    _record_timings("r04_config_c_full.json", {"config": "configs[2]: build -k 21 -s 30000000 -n 2 on 256 x 5 Mbp + read_id on 1 M reads (SE, PE; single-stream gzip, block gzip)",
+                                                "bxi_bytes": os.path.getsize(bxi), "sample_reads_checked": int(len(sample)) * 2, "phases_ms": t,
+                                                "build_stderr": [ln for ln in err_b.splitlines() if "timing:" in ln], "read_id_stderr": {f"{k_}_{'pe' if p_ else 'se'}": v for (k_, p_), v in errs.items()}})
 
 
 def _canon_codes(torch, reads, k):
