@@ -253,6 +253,8 @@ struct Bigsi {  // BigsyMapNew minus the map, which lives on the device
 // stripes != nullptr: the index goes to the ranks of `group` as colour stripes (cid_group_stripes_*) instead of to one GPU; b.index stays null
 Bigsi read_bigsi(cid_ctx *ctx, const std::string &path, int hash_variant, bool meta_only = false, cid_group *group = nullptr,
                  std::vector<cid_index *> *stripes = nullptr);  // bigsi.rs:59-69
+// map the index file and start touching its pages — call it before the GPU context is made; read_bigsi then uploads from the mapping
+void bigsi_read_ahead(const std::string &path);
 void save_bigsi(const std::string &path, const Bigsi &b);                                           // bigsi.rs:51-57
 Bigsi build_single(cid_ctx *ctx, const std::string &ref_tsv, uint64_t bloom, uint64_t hashes, uint64_t k, uint8_t quality,
                    int64_t cutoff, int hash_variant, uint64_t m_size = 0);   // build.rs:15-130; m_size > 0: build_single_mini :396-492

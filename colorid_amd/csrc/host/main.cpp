@@ -133,6 +133,7 @@ class StdoutToStderr {
 
 Gpus make_gpus(const Args &a) {
     Gpus g;
+    if (a.has("bigsi")) bigsi_read_ahead(a.one("bigsi"));   // the index file's pages come in beside the runtime's start-up
     if (a.has("threads"))
         fprintf(stderr, "note: -t %s is ignored: the search runs on the GPU (--gpus N shards the query over N GPUs)\n", a.one("threads").c_str());
     const std::vector<int> ids = device_list(a);
