@@ -84,7 +84,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(const uint64_t *keys, 
                                                            uint32_t shift, uint32_t bits, uint32_t top, uint32_t *table, uint32_t *n_dropped) {
     __shared__ uint32_t s_cnt[kPartBins], s_drop;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const XcdWalk walk(n_tiles);   // (the table's entries of neighbouring tiles share lines, like the scatter's runs)
+    for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
+        const uint32_t tile = walk.tile(it);
+        if (tile >= n_tiles) break;
         const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
         constexpr uint32_t PER = kPartTile / kPartBlock;
         uint64_t k[PER];
@@ -404,7 +407,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist_key(const uint32_t *ke
     __shared__ uint32_t s_cnt[kPartBins], s_drop;
     constexpr uint32_t PER = kPartTile / kPartBlock;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const XcdWalk walk(n_tiles);
+    for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
+        const uint32_t tile = walk.tile(it);
+        if (tile >= n_tiles) break;
         const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
         uint32_t k[PER];
 #pragma unroll

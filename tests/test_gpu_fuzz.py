@@ -163,6 +163,76 @@ def test_kmerset_random_inputs(orc, hip_ctx, seed):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24)) // 2))
+def test_kmerset_for_an_index_random_inputs(orc, hip_ctx, seed, monkeypatch):
+    """A k-mer set built FOR an index (cid_kmerset_set_target_index) on random sequence sets and index sizes — one row, a handful of rows
+    (every window in a few runs: the per-run fallbacks), powers of two, primes — through the partition kernels (CID_KMERSET_MSD_MIN=1) or
+    the two LSD sorts, in one batch or merged from several: same contents as the oracle's map, (first-row key, code) order, the same
+    report as the code-ordered set."""
+    import colorid_amd
+    from util import random_index, to_hip_index
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(1, 33))
+    m = int(rng.choice([1, 2, 7, 64, 4001, 65_536, 1_000_003, (1 << 20) + 3, 50_000_017]))
+    if seed % 2:
+        monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
+    if seed % 3 == 0:
+        monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", str(int(rng.choice([500, 3000, 20000]))))
+    alphabets = [b"ACGT", b"ACGTN", b"ACGTacgt", b"AC", b"ACGTRY"]
+    seqs = []
+    for _ in range(int(rng.integers(1, 10))):
+        L = int(rng.choice([0, 1, k - 1, k, k + 1, 50, 300, 2047 + k, 2049 + k, 5000, 40_000]))
+        a = alphabets[rng.integers(0, len(alphabets))]
+        s = np.frombuffer(a, np.uint8)[rng.integers(0, len(a), max(L, 0))].tobytes()
+        if rng.random() < 0.3 and len(s) > 10:
+            s = s[:len(s) // 2] * 3
+        seqs.append(s)
+    want = orc.Kmers(k)
+    for s in seqs:
+        want.kmerize_vector(s, 1)
+    C = int(rng.choice([3, 64, 70, 300]))
+    n_hash = int(rng.integers(1, 5))
+    if m <= 1_000_003:
+        oix = random_index(orc, rng, m, n_hash, k, C, density=0.05, zero_row_frac=0.1)
+        keys = want.keys()
+        for j in rng.choice(len(keys), size=min(len(keys), 200), replace=False) if len(keys) else []:
+            oix.insert(int(rng.integers(0, C)), keys[j].tobytes())
+        hx = to_hip_index(hip_ctx, oix)
+    else:
+        oix = None
+        hx = colorid_amd.Index(hip_ctx, m, n_hash, k, C)
+        hx.finalize()
+    sets = []
+    for targeted in (True, False):
+        ks = colorid_amd.KmerSet(hip_ctx, k)
+        if targeted:
+            ks.set_target_index(hx)
+        cut = int(rng.integers(0, len(seqs) + 1))
+        ks.add_seqs(seqs[:cut], 0)
+        ks.add_seqs(seqs[cut:], 0)
+        assert ks.finalize() == len(want)
+        sets.append(ks)
+    tk, pk = sets
+    km, cnt = tk.download()
+    assert {bytes(km[i]): int(cnt[i]) for i in range(len(cnt))} == want.as_dict()
+    scale = 0xFFFFFFFF00000000 // m
+    order = [(((orc.xxh3(bytes(r), 0) % m) * scale) >> 32, bytes(r)) for r in km[:3000]]
+    assert order == sorted(order)
+    if len(want):
+        rt, rp = tk.search_count_report(hx), pk.search_count_report(hx)
+        for a, b in zip(rt, rp):
+            assert np.array_equal(a, b)
+        if oix is not None:
+            w = oix.search_count(km, cnt.astype(np.uint64))
+            g = tk.search_count(hx)
+            for a, b in zip(w, g):
+                assert np.array_equal(a, b)
+        t = int(rng.integers(0, 4))
+        tk.clean(t)
+        assert tk.as_dict() == want.clean_map(t).as_dict()
+    tk.close(); pk.close(); hx.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24)) // 2))
 def test_group_random_shapes(orc, seed):
     """The same random shapes through the multi-rank calls (1-4 ranks sharing the one GPU): a replicated index with the query
     sharded (cid_group_search_*), the k-mer set counted over the ranks (cid_group_kmerset + _search_*_parts), and the index cut into
