@@ -42,7 +42,7 @@ _HIP = None
 
 
 def hip_memcpy(dst, src, nbytes, kind):
-    """hipMemcpy between library-owned and torch-owned memory (kind: 2 = D2H, 3 = D2D); synchronous."""
+    """hipMemcpy between library-owned and torch-owned memory (kind: 2 = D2H, 3 = D2D); synchronous (D2D: made so)."""
     global _HIP
     import ctypes
     if _HIP is None:
@@ -50,6 +50,11 @@ def hip_memcpy(dst, src, nbytes, kind):
         _HIP.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         _HIP.hipMemcpy.restype = ctypes.c_int
     rc = _HIP.hipMemcpy(dst, src, nbytes, kind)
+    if rc == 0 and kind == 3:
+        # a device-to-device hipMemcpy returns before it has run: without this wait the caller's next torch op may reuse the source
+        # block (the caching allocator hands it out again at once) and the copy reads the NEXT chunk's bytes — the index background
+        # then differs from run to run and from rank to rank
+        rc = _HIP.hipDeviceSynchronize()
     if rc != 0:
         raise RuntimeError(f"hipMemcpy failed: {rc}")
 

@@ -503,6 +503,37 @@ def test_config_d_one_gpus_share_of_the_query(orc, hip_ctx):
 
     whole, uc = search(codes, counts)
     t6 = lap("search_whole_set_ms", t5)
+    # the same share counted FOR this index (cid_kmerset_set_target_index: what `colorid search` does) — 8 merges on the (first-row key,
+    # code) pair: the same k-mers and multiplicities in another order, the same counters from the search, (key, code) order
+    os.environ["CID_KMERSET_COMPACT_WINDOWS"] = str(160_000_000)
+    try:
+        kt = colorid_amd.KmerSet(hip_ctx, k)
+    finally:
+        del os.environ["CID_KMERSET_COMPACT_WINDOWS"]
+    kt.set_target_index(hx)
+    for c in range(CH):
+        check(lib.cid_kmerset_add_seqs(kt.h, vp(host[c].ctypes.data), vp(seq_off.ctypes.data), per, 1))
+    assert kt.finalize() == K
+    dc, dn, nn = vp(), vp(), C.c_uint64(0)
+    check(lib.cid_kmerset_device_arrays(kt.h, C.byref(dc), C.byref(dn), C.byref(nn)))
+    t_codes = torch.empty(K, dtype=torch.int64, device=dev)
+    t_counts = torch.empty(K, dtype=torch.int32, device=dev)
+    bench.hip_memcpy(t_codes.data_ptr(), dc.value, K * 8, 3)
+    bench.hip_memcpy(t_counts.data_ptr(), dn.value, K * 4, 3)
+    t6 = lap("kmerset_count_for_index_ms", t6)
+    whole_t, uc_t = search(t_codes, t_counts)
+    t6 = lap("search_set_built_for_index_ms", t6)
+    assert torch.equal(whole_t, whole)
+    by_code = torch.argsort(t_codes)
+    assert torch.equal(t_codes[by_code], codes) and torch.equal(t_counts[by_code], counts) and torch.equal(uc_t[by_code], uc)
+    del by_code
+    at = int(K // 2)
+    win = _codes_to_ascii(torch, t_codes[at:at + 20_000], k).cpu().numpy()
+    keyed = [(((orc.xxh3(win[j].tobytes(), 0) % m) * (0xFFFFFFFF00000000 // m)) >> 32, win[j].tobytes()) for j in range(len(win))]
+    assert keyed == sorted(keyed)
+    del t_codes, t_counts, whole_t, uc_t
+    kt.close()
+    t6 = lap("set_built_for_index_checks_ms", t6)
     again, uc_again = search(codes, counts)
     assert torch.equal(whole, again) and torch.equal(uc, uc_again)
     cut = K // 3 + 11
@@ -534,7 +565,7 @@ def test_config_d_one_gpus_share_of_the_query(orc, hip_ctx):
     assert (got[3] != 0xFFFFFFFF).sum() > 1000 and want[0].sum() > S
     lap("oracle_search_sample_ms", t7)
     t["total_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
-    _record_timings("r03_config_d_share.json", {
+    _record_timings("r04_config_d_share.json", {
         "config": "configs[3], one GPU's share: 12.5 M x 150 bp reads (%d windows) -> cid_kmerset in %d add_seqs calls, merged every 160 M windows; "
                   "m=50M n=4 k=31 C=1024" % (R * nw, CH),
         "distinct_kmers": K, "singletons": int(cnts[0]), "phases_ms": t,

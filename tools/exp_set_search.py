@@ -20,11 +20,12 @@ stream = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(stream)
 ctx = colorid_amd.Context(0)
 ctx.set_stream(stream.cuda_stream)
-C, n, k, m = 256, 4, 31, 50_000_000
+C, n, k, m = int(os.environ.get('EXP_COLOURS', 256)), 4, 31, 50_000_000
+R = int(os.environ.get('EXP_READS', 1_000_000))
 hx = colorid_amd.Index(ctx, m, n, k, C)
 ptr, rs = hx.device_matrix()
-bench.fill_background(dev, ptr, m, rs, C, 1.0 - math.exp(-n * 3_000_000 / m), seed=7)
-kk, ff, cc, reads = bench.make_reads_kmers(dev, 42, 1_000_000, 150, k, C, 0.01, return_reads=True)
+bench.fill_background_fast(dev, ptr, m, rs, C, 1.0 - math.exp(-n * 3_000_000 / m), seed=7)
+kk, ff, cc, reads = bench.make_reads_kmers(dev, 42, R, 150, k, C, 0.01, return_reads=True)
 torch.cuda.synchronize()
 hx.insert_kmers_dev(kk.data_ptr(), cc.data_ptr(), kk.shape[0])
 ctx.synchronize()
