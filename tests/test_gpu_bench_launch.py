@@ -39,18 +39,18 @@ def one_json_line(p):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("extra", [TOY, TOY_STRIPED], ids=["replicated", "striped"])
-def test_two_ranks_equal_one_rank_over_both_shards(extra):
-    two = one_json_line(run_bench(["--gpus", "2"] + extra, backend="gloo"))
-    one = one_json_line(run_bench(["--emulate-world", "2"] + extra))
-    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+@pytest.mark.parametrize("extra,world", [(TOY, 2), (TOY_STRIPED, 2), (TOY, 4), (TOY_STRIPED, 3)], ids=["replicated-2", "striped-2", "replicated-4", "striped-3"])
+def test_n_ranks_equal_one_rank_over_all_shards(extra, world):
+    two = one_json_line(run_bench(["--gpus", str(world)] + extra, backend="gloo"))
+    one = one_json_line(run_bench(["--emulate-world", str(world)] + extra))
+    assert two["n_gpus"] == world and one["n_gpus"] == 1
     assert two["config"]["backend"] == "gloo"
-    assert len(two["per_rank"]) == 2 and [r["rank"] for r in two["per_rank"]] == [0, 1]
+    assert len(two["per_rank"]) == world and [r["rank"] for r in two["per_rank"]] == list(range(world))
     assert all(r["kmers"] > 0 and r["kernel_ms"] > 0 for r in two["per_rank"])
     striped = "--placement" in extra
     if striped:   # every rank sees every k-mer; the query does not grow with N
-        assert two["per_rank"][0]["kmers"] == two["per_rank"][1]["kmers"] == two["config"]["total_kmers"] == one["config"]["total_kmers"]
-        assert two["config"]["n_colors_total"] == one["config"]["n_colors_total"] == 256
+        assert {r["kmers"] for r in two["per_rank"]} == {two["config"]["total_kmers"]} == {one["config"]["total_kmers"]}
+        assert two["config"]["n_colors_total"] == one["config"]["n_colors_total"] == 128 * world
         assert two["config"]["consistent"] and one["config"]["consistent"]
     else:         # the shards (reads seeded per rank) add up
         assert two["config"]["total_kmers"] == sum(r["kmers"] for r in two["per_rank"]) == one["per_rank"][0]["kmers"]
