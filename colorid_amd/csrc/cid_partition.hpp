@@ -311,14 +311,13 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort(const uint64_t *
         __syncthreads();
         uint64_t key[MAXR];
 #pragma unroll
-        for (int r = 0; r < MAXR; ++r) {
+        for (int r = 0; r < MAXR; ++r) {   // the run's loads in flight together, before the first LDS atomic
             const uint32_t p = (uint32_t)r * kPartBlock + threadIdx.x;
-            key[r] = 0;
-            if (p < N) {
-                key[r] = in[start + p];
-                atomicAdd(&s_cur[(uint32_t)(key[r] >> bshift) & bmask], 1u);
-            }
+            key[r] = p < N ? in[start + p] : 0ull;
         }
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if ((uint32_t)r * kPartBlock + threadIdx.x < N) atomicAdd(&s_cur[(uint32_t)(key[r] >> bshift) & bmask], 1u);
         __syncthreads();
         {   // exclusive prefix over the 2048 bucket counts (8 per thread), and the comparisons the buckets will take: sum of count^2
             uint32_t c[BPT], sum = 0, sq = 0;
@@ -548,15 +547,14 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint3
         uint64_t val[MAXR];
         uint32_t key[MAXR];
 #pragma unroll
-        for (int r = 0; r < MAXR; ++r) {
+        for (int r = 0; r < MAXR; ++r) {   // the run's loads in flight together, before the first LDS atomic
             const uint32_t p = (uint32_t)r * kPartBlock + threadIdx.x;
-            val[r] = 0; key[r] = 0;
-            if (p < N) {
-                key[r] = keys[start + p] & kmask;
-                val[r] = vals[start + p];
-                atomicAdd(&s_cur[ord.bucket(key[r], val[r], bbits)], 1u);
-            }
+            key[r] = p < N ? keys[start + p] & kmask : 0u;
+            val[r] = p < N ? vals[start + p] : 0ull;
         }
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if ((uint32_t)r * kPartBlock + threadIdx.x < N) atomicAdd(&s_cur[ord.bucket(key[r], val[r], bbits)], 1u);
         __syncthreads();
         {
             uint32_t c[BPT], sum = 0, sq = 0;
