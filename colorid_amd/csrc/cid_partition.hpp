@@ -130,14 +130,14 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(const uint64_t *key
         uint64_t k[PER];
         bool keep[PER];
 #pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) {
+        for (uint32_t j = 0; j < PER; ++j) {   // all of the tile's loads in flight before the first LDS atomic
             const uint32_t i = j * kPartBlock + threadIdx.x;
-            keep[j] = false;
-            if (i < t.count) {
-                k[j] = keys[t.first + i];
-                keep[j] = !(top < 64 && (k[j] >> top));
-                if (keep[j]) atomicAdd(&s_cnt[(uint32_t)(k[j] >> shift) & (bins - 1)], 1u);
-            }
+            k[j] = i < t.count ? keys[t.first + i] : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            keep[j] = j * kPartBlock + threadIdx.x < t.count && !(top < 64 && (k[j] >> top));
+            if (keep[j]) atomicAdd(&s_cnt[(uint32_t)(k[j] >> shift) & (bins - 1)], 1u);
         }
         __syncthreads();
         {   // exclusive prefix of the 256 bin counts: one bin per thread, a wave scan + the waves' totals
