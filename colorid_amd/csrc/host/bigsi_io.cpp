@@ -122,7 +122,9 @@ void bigsi_read_ahead(const std::string &path) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return;   // (the loader reports it)
     struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size < (off_t)(64 << 20)) { close(fd); return; }   // small files: nothing to gain
+    // small files: nothing to gain; files beyond 64 GiB (a striped index of several GPUs' worth) stay with the sequential buffered
+    // reader: four threads touching such a file ahead of the loader would fight it for the disk and the page cache
+    if (fstat(fd, &st) != 0 || st.st_size < (off_t)(64 << 20) || st.st_size > (off_t)(64ll << 30)) { close(fd); return; }
     void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (m == MAP_FAILED) return;
