@@ -1153,7 +1153,7 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         hipStream_t cs = piped ? cid::ctx_copy_stream(c) : st;
         hipEvent_t ev_scan = cid::ctx_event(c, 0), ev_done = cid::ctx_event(c, 1);
         if (piped) { HIP_TRY(hipEventRecord(ev_scan, st)); HIP_TRY(hipStreamWaitEvent(cs, ev_scan, 0)); }   // (d_bases may still be read by an earlier kernel of the ctx stream)
-        const uint64_t slice_bytes = 32ull << 20;
+        static const uint64_t slice_bytes = (uint64_t)(getenv("CID_KMERSET_SLICE_MB") ? atoi(getenv("CID_KMERSET_SLICE_MB")) : 32) << 20;   // (experiments)
         for (size_t s0 = 0; s0 < n_seqs;) {
             size_t s1 = s0;
             while (s1 < n_seqs && seq_off[s1] - seq_off[s0] < slice_bytes) ++s1;
