@@ -12,6 +12,22 @@ index   : synthetic: Bernoulli(p) background bits, p = 1 - exp(
 step    : one pass of the hot path over the rank's whole k-mer batch (+ the RCCL all-reduce of the 3*C
           per-colour counters when N > 1).  N > 1: reads are sharded over ranks, the index is replicated.
 
+Side records of the one JSON line (N = 1 only; never `value`; the line stays under 5 KB):
+  config.codes_input       the same query as 2-bit codes (cid_search_count_codes_dev), 10 steps
+  config.producer_ordered  2-bit codes grouped by the 128-byte index line of their first row as a separate pass: search_ms = the
+                           search alone, in_step_ms = grouping + search inside one step
+  config.box               this card's clocks, sampled from its sysfs node while the timed steps run
+  e2e                      reads in pageable host memory -> H2D -> cid_kmerset built FOR the index (window codes + first-row keys,
+                           sort on (key, code), run-length) -> cid_search_count_set_report (hits / unique / sum / mode per accession
+                           on the device) -> 4*C numbers to the host; best of 6 calls; PCIe-inclusive
+  e2e.code_ordered         the same without cid_kmerset_set_target_index (round 3's path)
+  rows128                  the headline's k-mers against m, n of the headline and 1024 colours (configs[3]'s index: 128-byte rows)
+  readid                   cid_readid_count_dev on configs[2]'s shape (m = 30 M, n = 2, k = 21, 256 colours), 1 M reads and 1 M pairs
+                           resident; alg bytes = n rows of 32 B per distinct k-mer of a read + its bases in + its report row out;
+                           cpu_baseline = the oracle's read loop on every host core (the reference runs it under rayon)
+  cpu_baseline             oracle/liborc.so: orc_search_count on 1 thread (the reference's `search` is single-threaded), .all_cores,
+                           .faithful_structure (a hash map of rows as in bigsi.rs:19-27, one heap clone per k-mer)
+
 Launch: `python bench.py [--gpus N]` — for N > 1 without a launcher (WORLD_SIZE unset) this process starts N fresh children
         itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`
         as a subprocess, decided before anything here touches the GPU), relays rank 0's JSON line and exits with the children's
@@ -631,8 +647,7 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize()
             ms_codes = e0.elapsed_time(e1) / 10
-            result["config"]["codes_input"] = {"ms_per_step": ms_codes, "kmers_per_s": K / ms_codes * 1e3,
-                                               "note": "2-bit-code input (cid_search_count_codes_dev), 10 steps, not the headline value"}
+            result["config"]["codes_input"] = {"ms_per_step": ms_codes, "kmers_per_s": K / ms_codes * 1e3}
             # and with the k-mers grouped by the index line of their first row (cid_order_codes_for_index_dev): the grouping timed on
             # its own, then the search over the grouped k-mers — a quarter of the row fetches become hits in lines just fetched
             oc, of = torch.empty_like(codes), torch.empty_like(freq)
@@ -656,9 +671,7 @@ def main():
             torch.cuda.synchronize()
             result["config"]["producer_ordered"] = {
                 "search_ms": ms_search, "kmers_per_s": K / ms_search * 1e3, "grouping_ms": ms_order,
-                "in_step_ms": ms_order + ms_search, "same_counts": bool(torch.equal(ordered_counts, out)),
-                "note": "2-bit codes grouped by the 128-byte index line of their first row; search_ms = the search alone (ordering done by the "
-                        "producer), in_step_ms = grouping + search inside one step; neither is the headline value"}
+                "in_step_ms": ms_order + ms_search, "same_counts": bool(torch.equal(ordered_counts, out))}
             del oc, of
             result["e2e"] = e2e_reads_to_report(a, dev, ctx, hx, out, C, k)
             # the other kernels of the path in the same driver-run line (side records, never `value`)
@@ -717,11 +730,7 @@ def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
             "all_ms": [round(t * 1e3, 2) for t in times], "same_hits_as_headline": same,
             "code_ordered": {"ms": c_times[c_best] * 1e3, "same_hits": bool(np.array_equal(hits, c_hits)),
                              "phases_ms": {"upload_and_window_codes": c_parts[c_best][0] * 1e3, "sort_and_count": c_parts[c_best][1] * 1e3,
-                                           "search_and_report": c_parts[c_best][2] * 1e3},
-                             "note": "the same without cid_kmerset_set_target_index (the set in code order, as until round 3)"},
-            "note": "reads in pageable host memory -> H2D -> cid_kmerset built FOR the index (window codes + first-row keys, sort on (key, code), "
-                    "run-length) -> cid_search_count_set_report (search + per-accession hits / unique / sum / mode on the device) -> 4*C "
-                    "numbers to the host; best of 6 calls; PCIe-inclusive, not the headline value"}
+                                           "search_and_report": c_parts[c_best][2] * 1e3}}}
 
 
 def side_rows128(a, dev, ctx, stream, kmers, freq, planted, C=1024):
@@ -758,8 +767,7 @@ def side_rows128(a, dev, ctx, stream, kmers, freq, planted, C=1024):
     del out, uc
     return {"kernel": "k_search_count (128-byte rows)", "n_colors": C, "row_bytes": rs * 8, "index_bytes": m * rs * 8, "kmers": K, "ms": ms,
             "kmers_per_s": K / ms * 1e3, "alg_bytes_per_kmer": alg, "achieved_GBs": alg * K / ms / 1e6, "frac": alg * K / ms / 1e6 / HBM_PEAK_GBS,
-            "background_density": p_bg, "consistent": bool(ok),
-            "note": f"the headline's k-mers against m={m} n={n} C={C} (configs[3]'s index), {steps} steps; not the headline value"}
+            "background_density": p_bg, "consistent": bool(ok)}
 
 
 def side_readid(a, dev, ctx, stream, with_oracle, reads=1_000_000, L=150):
@@ -780,9 +788,7 @@ def side_readid(a, dev, ctx, stream, with_oracle, reads=1_000_000, L=150):
     del kk, cc
     bases = seqs.reshape(-1).contiguous()
     rec = {"config": {"bloom_size": m, "num_hash": n, "k_size": k, "n_colors": C, "row_bytes": rs * 8, "stride_d": d, "start_sample": B,
-                      "background_density": p_bg, "read_len": L},
-           "note": "configs[2]'s shape, reads resident in HBM, 10 steps each; alg bytes = n rows of 32 B per distinct k-mer of a read + the "
-                   "read's bases in + its report row out; not the headline value"}
+                      "background_density": p_bg, "read_len": L}}
     oix = None
     for name, mates in (("single_end", 1), ("paired", 2)):
         n_seq = reads * mates
@@ -841,7 +847,7 @@ def cpu_baseline_readid(oix, bases, seq_off, read0, report, nk, reads, mates, ma
                  np.array_equal(want[1], nk[:S].cpu().numpy().view(np.uint32)))
     return {"bit_exact": exact,
             "cpu_baseline": {"value": S / dt, "unit": "reads/s", "cores": ncpu, "kind": "port",
-                             "sample": f"first {S} reads, oracle/liborc.so orc_readid_counts on {ncpu} threads (rayon analogue), {dt:.2f}s"}}
+                             "sample": f"first {S} reads, orc_readid_counts, {dt:.2f}s"}}
 
 
 def cpu_baseline(a, hx, mat_ptr, kmers, freq, C, n, k, m, rs):
@@ -896,12 +902,10 @@ def cpu_baseline(a, hx, mat_ptr, kmers, freq, C, n, k, m, rs):
     orc.sparse_free(sparse)
     exact = exact and all(np.array_equal(w, g) for w, g in zip(want3, hx.search_count(hk[:S3], hf[:S3].astype(np.uint32))[:3]))
     base = {"value": S / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-            "sample": f"first {S} of the {K} query k-mers, same index copied to host; oracle/liborc.so "
-                      f"orc_search_count, 1 thread (reference `search` is single-threaded), {dt:.1f}s; host has {ncpu} cores",
+            "sample": f"first {S} of the {K} query k-mers, orc_search_count on a host copy of the index, {dt:.1f}s; host has {ncpu} cores",
             "all_cores": {"value": S2 / dt2, "cores": ncpu, "sample": f"first {S2} k-mers, orc_search_count_mt, {dt2:.1f}s"},
             "faithful_structure": {"value": S3 / dt3, "cores": 1,
-                                   "sample": f"first {S3} k-mers, orc_search_count_sparse (hash map of rows as in bigsi.rs:19-27, "
-                                             f"one heap clone per k-mer), {dt3:.1f}s after {dt_map:.1f}s building the map"}}
+                                   "sample": f"first {S3} k-mers, orc_search_count_sparse, {dt3:.1f}s after {dt_map:.1f}s building the map"}}
     return base, bool(exact)
 
 
