@@ -63,9 +63,11 @@ def test_group_search_equals_single_rank_and_oracle(orc, hip_ctx, devices, n_col
         gw, gm = g.search_perfect(sel)
         assert gm == pm and np.array_equal(gw, pw)
     # device-resident k-mer sets (2-bit codes, or byte strings for k > 32): counted on rank 0, sliced to the ranks device-to-device
-    if True:
-        seqs = [bytes(rng.choice(list(b"ACGT"), size=3000).astype(np.uint8)) for _ in range(5)] + [sub[:200].tobytes()]
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=3000).astype(np.uint8)) for _ in range(5)] + [sub[:200].tobytes()]
+    for targeted in (False, True):      # in code order, and built FOR rank 0's replica (cid_kmerset_set_target_index): the ranks take slices of either
         ks = colorid_amd.KmerSet(g.ctxs[0], k)
+        if targeted:
+            ks.set_target_index(hx)
         ks.add_seqs(seqs, 0)
         ks.finalize()
         single = ks.search_count(hx)
@@ -77,6 +79,7 @@ def test_group_search_equals_single_rank_and_oracle(orc, hip_ctx, devices, n_col
         km, cnt = ks.download()
         w = oix.search_count(km, cnt.astype(np.uint64))
         assert all(np.array_equal(a, b) for a, b in zip(w, multi))
+        ks.close()
     g.close()
 
 
