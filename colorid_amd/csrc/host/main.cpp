@@ -190,7 +190,10 @@ void replicate(Gpus &g, Bigsi &b) {   // after the index is loaded on rank 0
 // objects and the runtime's own teardown buy nothing — the driver reclaims a process's memory in one go — but cost 0.1-0.2 s of a
 // 0.7 s `read_id`.  One-GPU runs therefore skip release() and leave through leave(); COLORID_FULL_TEARDOWN=1 (the sanitizer runs,
 // anybody embedding the drivers) keeps the orderly way, and so do multi-GPU runs (RCCL communicators are shut down properly).
-bool g_orderly_exit = getenv("COLORID_FULL_TEARDOWN") != nullptr;
+// Under a profiler or any other preloaded tool (rocprofv3 preloads its tool library and writes its files from an exit handler) the
+// process leaves the orderly way too: an `_exit` would take the tool's output with it.
+bool g_orderly_exit = getenv("COLORID_FULL_TEARDOWN") != nullptr || getenv("LD_PRELOAD") != nullptr || getenv("ROCP_TOOL_LIBRARIES") != nullptr ||
+                      getenv("ROCPROFILER_LIBRARY_CTOR") != nullptr;
 
 void release(Gpus &g, Bigsi &b) {
     if (!g_orderly_exit && !g.group) { cid_ctx_synchronize(g.ctx); return; }
