@@ -74,6 +74,35 @@ def world(orc, hip_ctx):
     hx.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_line_ends_at_every_alignment(orc, hip_ctx, world, seed):
+    """the front end's own line-end kernels (k_nl_count / k_nl_positions: 16-byte pieces, 1 KiB rounds, 8 KiB chunks): names of random
+    length put the newlines at every offset inside a piece and the texts' ends at every distance from a round's and a chunk's end;
+    empty lines, a text of a single byte, texts cut so that a step sees 0 ... 3 dangling lines."""
+    import colorid_amd
+    oix, hx, genomes = world
+    rng = np.random.default_rng(900 + seed)
+    recs = []
+    for i in range(int(rng.integers(1, 400))):
+        name = b"r%d" % i + b"n" * int(rng.integers(0, 40))
+        L = int(rng.choice([0, 1, 15, 16, 17, 21, 150, 1000]))
+        g = genomes[int(rng.integers(len(genomes)))]
+        recs.append((name, g[:L], b"I" * L))
+    text = fastq_text(recs, b"\n", bool(seed % 2))
+    want_ids, want, _ = expected(orc, hx, [text], 0, 1, 3)
+    for pieces in (1, 2, 13):
+        fr = colorid_amd.FastqReader(hip_ctx, 1, 0)
+        cuts = sorted(rng.integers(0, len(text) + 1, pieces - 1).tolist()) if pieces > 1 else []
+        acc = {"ids": [], "nk": [], "st": [], "rows": []}
+        prev = 0
+        for cut in cuts + [len(text)]:
+            fr.push_text(0, text[prev:cut], last=(cut == len(text)))
+            prev = cut
+            collect(fr, hx, 1, 3, acc)                                # a step after every push: carries of every length
+        check_equal(acc, want_ids, want)
+        fr.close()
+
+
 @pytest.mark.parametrize("eol,last_newline", [(b"\n", True), (b"\r\n", True), (b"\n", False), (b"\r\n", False)])
 @pytest.mark.parametrize("q", [0, 15])
 def test_text_pushed_in_pieces_single_end(orc, hip_ctx, world, eol, last_newline, q):
