@@ -16,7 +16,7 @@ Side records of the one JSON line (N = 1 only; never `value`; the line stays und
   config.codes_input       the same query as 2-bit codes (cid_search_count_codes_dev), 10 steps
   config.producer_ordered  2-bit codes grouped by the 128-byte index line of their first row as a separate pass: search_ms = the
                            search alone, in_step_ms = grouping + search inside one step
-  config.box               this card's clocks, sampled from its sysfs node while the timed steps run
+  config.box               this card's clocks, sampled from its sysfs node during a pass of headline launches AFTER the timed steps
   e2e                      reads in pageable host memory -> H2D -> cid_kmerset built FOR the index (window codes + first-row keys,
                            sort on (key, code), run-length) -> cid_search_count_set_report (hits / unique / sum / mode per accession
                            on the device) -> 4*C numbers to the host; best of 6 calls; PCIe-inclusive
@@ -75,20 +75,39 @@ def hip_memcpy(dst, src, nbytes, kind):
         raise RuntimeError(f"hipMemcpy failed: {rc}")
 
 
-def profiled_traffic(K, C, m, n, k):
-    """(HBM bytes per launch of k_search_count, where the figure comes from) — PMC counters cannot be read from inside the timed
-    run, so the bytes are those of the committed rocprofv3 --pmc passes (profiles/) when they were taken on this exact workload;
-    (None, reason) otherwise.  The source string goes into the JSON line so that a reader sees it was NOT measured in this run."""
-    path = os.path.join("profiles", "pmc_search_count.json")
+def pmc_path(kernel, C, m, n, k):
+    """profiles/pmc/<kernel>_C<colours>_m<bloom>_n<hashes>_k<k>.json: ONE file per (kernel, workload), written by tools/pmc_store.py
+    from the committed counter rows.  (Round 4 kept one fixed file name for every workload; the C = 1024 pass overwrote the headline's
+    and the driver-run line lost its traffic figure.)"""
+    return os.path.join("profiles", "pmc", f"{kernel}_C{C}_m{m}_n{n}_k{k}.json")
+
+
+def profiled_traffic(K, C, m, n, k, kernel="k_search_count"):
+    """(HBM bytes per launch of `kernel`, where the figure comes from) — PMC counters cannot be read from inside the timed run, so
+    the bytes are those of the committed rocprofv3 --pmc passes over THIS workload (profiles/pmc/, keyed by workload); (None, reason)
+    when no such pass is committed.  The source string goes into the JSON line so that a reader sees it was NOT measured in this run."""
+    path = pmc_path(kernel, C, m, n, k)
     try:
         with open(os.path.join(ROOT, path)) as f:
             pj = json.load(f)
-        if (pj["kmers_per_launch"], pj["n_colors"], pj["bloom_size"], pj["num_hash"], pj["k_size"]) == (K, C, m, n, k):
-            return float(pj["traffic_bytes"]), (f"{path} (lease tag {pj.get('tag', '?')}): separate rocprofv3 --pmc passes over this workload, "
-                                                "TCC_EA0_RDREQ/WRREQ with the guide's gfx950 corrections; not measured in this run")
-        return None, f"{path} holds another workload"
+        if (pj["n_colors"], pj["bloom_size"], pj["num_hash"], pj["k_size"]) != (C, m, n, k):
+            return None, f"{path} names another workload inside than in its file name"
+        if pj["kmers_per_launch"] != K:
+            return None, f"{path} was taken at {pj['kmers_per_launch']} k-mers per launch, this run has {K}"
+        return float(pj["traffic_bytes"]), (f"{path} (lease tag {pj.get('tag', '?')}): separate rocprofv3 --pmc passes over this workload, "
+                                            "TCC_EA0_RDREQ by request size + WRITE_SIZE with the guide's gfx950 corrections; not measured in this run")
     except (OSError, KeyError, ValueError) as e:
-        return None, f"no committed PMC passes ({type(e).__name__})"
+        return None, f"no committed PMC passes for this workload ({path}: {type(e).__name__})"
+
+
+def traffic_fields(rec, ms, K, C, m, n, k, kernel="k_search_count"):
+    """traffic / traffic_source / traffic_GBs / traffic_frac of a record whose kernel took `ms` per launch"""
+    tr, src = profiled_traffic(K, C, m, n, k, kernel)
+    rec["traffic"], rec["traffic_source"] = tr, src
+    if tr:
+        rec["traffic_GBs"] = tr / (ms * 1e-3) / 1e9
+        rec["traffic_frac"] = tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return rec
 
 
 def parse_args():
@@ -305,6 +324,18 @@ class ClockSampler:
         return out
 
 
+def clocks_under_load(device_index, launch, steps=12):
+    """The card's clocks while the headline kernel runs — in a pass of its own AFTER the timed steps (local launches only, no
+    collective: the other ranks are not in it).  Round 4 ran the sampler thread inside the timed region of rank 0: a Python thread
+    that takes the GIL and queries the SMU through sysfs competes with the launch loop of exactly the rank whose clock is reported."""
+    cs = ClockSampler(device_index, period_s=0.02).start()
+    for _ in range(steps):
+        launch()
+    torch.cuda.synchronize()
+    cs.stop()
+    return cs.result()
+
+
 def host_collective(dev):
     """The device small bookkeeping tensors of the collectives live on: RCCL ("nccl") wants device tensors; gloo (BENCH_BACKEND=gloo,
     the one-GPU rehearsal of the N > 1 branches) reduces / gathers host tensors."""
@@ -433,7 +464,6 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    clocks = ClockSampler(device_index).start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
@@ -441,8 +471,9 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if clocks:
-        clocks.stop()
+    digest = counters_digest(hits, nu, sf)   # the timed steps' result, before the clock pass adds further launches into `hits`
+    n_hits = int(hits.sum().item())
+    clocks = clocks_under_load(device_index, lambda: si.search_count_local(kmers, fact, hits)) if rank == 0 else None
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     coll_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     fin_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
@@ -453,7 +484,7 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
         alg = n * w64 * 8 + k + 4 + 4   # rows + k-mer bytes + the k-mer's packed fact read and written
         achieved = alg * K / (kern_ms * 1e-3) / 1e9
         # consistency: every unique k-mer is counted once, and the planted k-mers are found
-        ok = int(nu.sum().item()) == int((uc != -1).sum().item()) and int(hits.sum().item()) >= int(0.6 * K)
+        ok = int(nu.sum().item()) == int((uc != -1).sum().item()) and n_hits >= int(0.6 * K)
         result = {
             "metric": "query k-mers/s on 50M-bit n=4 256-colour BIGSI; bit-exact hits vs CPU",
             "value": K * a.steps / elapsed, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -466,13 +497,14 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
                        "parallelism": f"colour stripes over {world} GPU(s); one all-reduce(SUM) of 4 B per k-mer + 8*C_total bytes per step",
                        "collective_bytes_per_step": 4 * K + 8 * C_total, "setup_s": round(t_setup, 1), "consistent": bool(ok),
                        "backend": (dist.get_backend() if dist.is_initialized() else None), "emulate_world": a.emulate_world or None,
-                       "total_kmers": K, "box": clocks.result()},
-            "counters": counters_digest(hits, nu, sf),
+                       "total_kmers": K, "box": clocks},
+            "counters": digest,
             "per_rank": ranks, "kernel_ms": kern_ms, "collective_ms": coll_ms, "finalize_ms": fin_ms,
             "roofline": {"bound": "hbm", "kernel": "k_search_count (stripe mode)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_kmer": alg, "kernel_ms": kern_ms, "kmers_per_launch": K},
             "cpu_baseline": None,
         }
+        traffic_fields(result["roofline"], kern_ms, K, Cs, m, n, k, kernel="k_search_count_stripe")
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
     for hx, _ in held:
@@ -576,10 +608,7 @@ def main():
     if world > 1:
         dist.barrier()
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(a.steps)]
-    clocks = ClockSampler(device_index) if rank == 0 else None
     torch.cuda.synchronize()
-    if clocks:
-        clocks.start()
     t0 = time.perf_counter()
     for i in range(a.steps):
         out.zero_()
@@ -592,8 +621,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if clocks:
-        clocks.stop()
+    final_counters = out.clone()     # the timed steps' result (the clock pass below launches without the reduction)
+    clocks = clocks_under_load(device_index, launch) if rank == 0 else None
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     coll_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     ranks = per_rank_times(dev, world, kern_ms, coll_ms, elapsed / a.steps * 1e3, K)
@@ -619,21 +648,22 @@ def main():
                        "row_bytes": rs * 8, "index_bytes": m * rs * 8, "background_density": p_bg,
                        "parallelism": f"reads sharded over {world} GPU(s), index replicated, all-reduce(3C u64)",
                        "backend": (dist.get_backend() if dist.is_initialized() else None), "emulate_world": a.emulate_world or None,
-                       "total_kmers": total_kmers, "setup_s": round(t_setup, 1), "box": clocks.result()},
-            "counters": counters_digest(out[:C], out[C:2 * C], out[2 * C:]),
+                       "total_kmers": total_kmers, "setup_s": round(t_setup, 1), "box": clocks},
+            "counters": counters_digest(final_counters[:C], final_counters[C:2 * C], final_counters[2 * C:]),
             "roofline": {"bound": "hbm", "kernel": "k_search_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": a.traffic_bytes if a.traffic_bytes is not None else profiled_traffic(K, C, m, n, k)[0],
-                         "traffic_source": "--traffic-bytes (a rocprofv3 --pmc pass of the caller)" if a.traffic_bytes is not None
-                                           else profiled_traffic(K, C, m, n, k)[1],
+                         "traffic": None, "traffic_source": None,
                          "alg_bytes_per_kmer": alg_bytes_per_kmer,
                          "kernel_ms": kern_ms, "kmers_per_launch": K},
             "per_rank": ranks, "kernel_ms": kern_ms, "collective_ms": coll_ms,
         }
-        tr = result["roofline"]["traffic"]
-        if tr:   # the PMC traffic of profiles/ at this run's kernel time: what the kernel really moves (every 32-byte row costs a 128-byte line)
-            result["roofline"]["traffic_GBs"] = tr / (kern_ms * 1e-3) / 1e9
-            result["roofline"]["traffic_frac"] = tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # the PMC traffic of profiles/pmc/ at this run's kernel time: what the kernel really moves (every 32-byte row costs a 128-byte line)
+        if a.traffic_bytes is not None:
+            result["roofline"].update({"traffic": a.traffic_bytes, "traffic_source": "--traffic-bytes (a rocprofv3 --pmc pass of the caller)",
+                                       "traffic_GBs": a.traffic_bytes / (kern_ms * 1e-3) / 1e9,
+                                       "traffic_frac": a.traffic_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        else:
+            traffic_fields(result["roofline"], kern_ms, shards[0][0].shape[0], C, m, n, k)
         if world == 1 and not a.codes and not a.no_variants and not a.emulate_world:
             # for the record, not the headline: the same query with the k-mers as the 2-bit codes that GPU k-mer counting
             # produces (what `colorid search` feeds the kernel for k <= 32): 8 instead of k input bytes per k-mer
@@ -765,9 +795,10 @@ def side_rows128(a, dev, ctx, stream, kmers, freq, planted, C=1024):
     ok = found and int(out[C:2 * C].sum().item()) == int((uc != -1).sum().item())
     hx.close()
     del out, uc
-    return {"kernel": "k_search_count (128-byte rows)", "n_colors": C, "row_bytes": rs * 8, "index_bytes": m * rs * 8, "kmers": K, "ms": ms,
-            "kmers_per_s": K / ms * 1e3, "alg_bytes_per_kmer": alg, "achieved_GBs": alg * K / ms / 1e6, "frac": alg * K / ms / 1e6 / HBM_PEAK_GBS,
-            "background_density": p_bg, "consistent": bool(ok)}
+    rec = {"kernel": "k_search_count (128-byte rows)", "n_colors": C, "row_bytes": rs * 8, "index_bytes": m * rs * 8, "kmers": K, "ms": ms,
+           "kmers_per_s": K / ms * 1e3, "alg_bytes_per_kmer": alg, "achieved_GBs": alg * K / ms / 1e6, "frac": alg * K / ms / 1e6 / HBM_PEAK_GBS,
+           "background_density": p_bg, "consistent": bool(ok)}
+    return traffic_fields(rec, ms, K, C, m, n, k)
 
 
 def side_readid(a, dev, ctx, stream, with_oracle, reads=1_000_000, L=150):

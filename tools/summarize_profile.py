@@ -2,7 +2,8 @@
 """Turn gpurun_out/<tag>/ (written by tools/profile_bench.sh) into the committed evidence under profiles/:
    profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (our kernels + the top rows)
    profiles/<tag>_pmc_search_count.csv  per-dispatch counter rows of k_search_count (all PMC passes)
-   profiles/pmc_search_count.json    HBM traffic per launch, corrected as MI355X_MICROARCH.md §HBM prescribes
+   profiles/pmc/k_search_count_C<colours>_m<bloom>_n<hashes>_k<k>.json   HBM traffic per launch of THIS workload (tools/pmc_store.py),
+                                     corrected as MI355X_MICROARCH.md §HBM prescribes; bench.py looks its workload up by that name
    profiles/<tag>_summary.md         the numbers side by side
 """
 import collections
@@ -55,11 +56,12 @@ rd_fetch = 2 * 1024 * mean.get("FETCH_SIZE", 0)
 wr = 1024 * mean.get("WRITE_SIZE", 0)
 traffic = rd + wr
 alg = bench["roofline"]["alg_bytes_per_kmer"] * K
-out = {"kernel": "k_search_count", "tag": tag, "kmers_per_launch": K, "n_colors": bench["config"]["n_colors"],
-       "bloom_size": bench["config"]["bloom_size"], "num_hash": bench["config"]["num_hash"], "k_size": bench["config"]["k_size"],
-       "traffic_bytes": traffic, "read_bytes_rdreq": rd, "read_bytes_fetch_size_x2": rd_fetch, "write_bytes": wr,
-       "algorithmic_bytes": alg, "rocprof_avg_kernel_ns": avg_ns, "counters_mean_per_launch": mean}
-json.dump(out, open(os.path.join(dst, "pmc_search_count.json"), "w"), indent=1)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_store  # noqa: E402
+cfg = bench["config"]
+print("wrote", pmc_store.write("k_search_count", cfg["n_colors"], cfg["bloom_size"], cfg["num_hash"], cfg["k_size"], K,
+                               bench["roofline"]["alg_bytes_per_kmer"], mean, avg_ns, tag,
+                               [f"profiles/{tag}_pmc_search_count.csv", f"profiles/{tag}_kernel_stats.csv"], ks["Name"]))
 
 row_bytes = bench["config"]["row_bytes"]
 n_hash = bench["config"]["num_hash"]

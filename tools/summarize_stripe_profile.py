@@ -26,6 +26,12 @@ K = d["config"]["kmers"]; alg = d["roofline"]["alg_bytes_per_kmer"] * K
 rd = 128 * m["TCC_EA0_RDREQ_128B_sum"] + 64 * m["TCC_EA0_RDREQ_64B_sum"] + 32 * m["TCC_EA0_RDREQ_32B_sum"]; wr = 1024 * m["WRITE_SIZE"]
 avg = float(ks["AverageNs"])
 json.dump(d, open(f"{dst}/{tag}_bench_striped_1gpu.json", "w"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_store  # noqa: E402
+c = d["config"]
+print("wrote", pmc_store.write("k_search_count_stripe", c["n_colors_total"], c["bloom_size"], c["num_hash"], c["k_size"], K,
+                               d["roofline"]["alg_bytes_per_kmer"], m, avg, f"{tag}_stripe",
+                               [f"profiles/{tag}_stripe_pmc_search_count.csv", f"profiles/{tag}_stripe_kernel_stats.csv"], ks["Name"]))
 open(f"{dst}/{tag}_stripe_summary.md", "w").write(f"""# {tag}_stripe: k_search_count in stripe mode on MI355X — rocprofv3 evidence
 
 `tools/profile_stripe.sh`: `rocprofv3 --kernel-trace --stats -- python3 bench.py --placement striped --no-cpu-baseline --steps 10 --warmup 2`,
