@@ -25,6 +25,7 @@ Side records of the one JSON line (N = 1 only; never `value`; the line stays und
   readid                   cid_readid_count_dev on configs[2]'s shape (m = 30 M, n = 2, k = 21, 256 colours), 1 M reads and 1 M pairs
                            resident; alg bytes = n rows of 32 B per distinct k-mer of a read + its bases in + its report row out;
                            cpu_baseline = the oracle's read loop on every host core (the reference runs it under rayon)
+  readid_long              cid_readid_count_resident on the same index: 150 Mbases as 10 kb reads and as a 2 kb / 10 kb / 100 kb mix
   cpu_baseline             oracle/liborc.so: orc_search_count on 1 thread (the reference's `search` is single-threaded), .all_cores,
                            .faithful_structure (a hash map of rows as in bigsi.rs:19-27, one heap clone per k-mer)
 
@@ -137,6 +138,7 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one rank stands in for W: the index holds all W shards' plants (or all W stripes) and the W shards are searched "
                          "one after the other into the same counters; the `counters` digest equals the W-rank run's (the N > 1 test)")
+    ap.add_argument("--only", default=None, help="profiling: run just this side record (readid_long) and print it as the JSON line")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
     return ap.parse_args()
@@ -552,6 +554,12 @@ def main():
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
 
+    if a.only:          # a side record alone (profiling passes: every dispatch of the run belongs to it); not the driver's line
+        fn = {"readid_long": side_readid_long, "readid": side_readid}[a.only]
+        json_out.write(json.dumps({"only": a.only, a.only: fn(a, dev, ctx, stream, with_oracle=not a.no_cpu_baseline)}) + "\n")
+        json_out.flush()
+        ctx.close()
+        return
     if a.placement == "striped":
         return bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream)
     C, n, k, m = a.colours, a.hashes, a.k, a.bloom
@@ -707,6 +715,7 @@ def main():
             # the other kernels of the path in the same driver-run line (side records, never `value`)
             result["rows128"] = side_rows128(a, dev, ctx, stream, kmers, freq, planted)
             result["readid"] = side_readid(a, dev, ctx, stream, with_oracle=not a.no_cpu_baseline)
+            result["readid_long"] = side_readid_long(a, dev, ctx, stream, with_oracle=not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline and not a.emulate_world:
             result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
     if result is not None:
@@ -851,6 +860,77 @@ def side_readid(a, dev, ctx, stream, with_oracle, reads=1_000_000, L=150):
         del report, nk, st, seq_off, read0
     hx.close()
     return rec
+
+
+def side_readid_long(a, dev, ctx, stream, with_oracle, total_bases=150_000_000):
+    """Long reads through cid_readid_count_resident (read_id_mt_pe.rs:104-165,282-363 takes any read length; kmer.rs:221-243): configs[2]'s
+    index, 150 Mbases resident in HBM as 10 kb reads and as a 2 kb / 10 kb / 100 kb mix (a third of the bases each; the 2 kb reads are
+    routed to the per-wave LDS kernel inside the same batch).  ms = wall time of one call, host side included (the offsets are host
+    arrays: routing and the work lists are made on the host), mean of 5 after 2; rows of a sample of reads against the oracle."""
+    import colorid_amd
+    C, n, k, m, d, B = 256, 2, 21, 30_000_000, 1, 3
+    hx = colorid_amd.Index(ctx, m, n, k, C)
+    ptr, rs = hx.device_matrix()
+    p_bg = 1.0 - math.exp(-n * 5_000_000 / m)
+    fill_background(dev, ptr, m, rs, C, p_bg, seed=7)
+    hx.finalize()
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    lut = torch.tensor(list(b"ACGT"), device=dev, dtype=torch.uint8)
+    bases = lut[torch.randint(0, 4, (total_bases,), device=dev, generator=g)].contiguous()
+    rec = {"config": {"bloom_size": m, "num_hash": n, "k_size": k, "n_colors": C, "row_bytes": rs * 8, "stride_d": d, "start_sample": B,
+                      "background_density": p_bg, "bases": total_bases}}
+    third = total_bases // 3
+    shapes = {"reads_10kb": [(10_000, total_bases // 10_000)],
+              "mix_2k_10k_100k": [(2_000, third // 2_000), (10_000, third // 10_000), (100_000, third // 100_000)]}
+    oix = None
+    for name, parts in shapes.items():
+        lens = np.concatenate([np.full(cnt, L, np.uint64) for L, cnt in parts])
+        np.random.default_rng(7).shuffle(lens)          # the mix: lengths interleaved, as a sequencer delivers them
+        reads = int(lens.size)
+        seq_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        read0 = np.arange(reads + 1, dtype=np.uint64)
+        report = torch.empty((reads, C + 1), dtype=torch.int32, device=dev)
+        nk = torch.empty(reads, dtype=torch.int32, device=dev)
+        st = torch.empty(reads, dtype=torch.uint8, device=dev)
+        times = []
+        for i in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hx.readid_count_resident(bases.data_ptr(), seq_off, read0, d, B, report.data_ptr(), nk.data_ptr(), st.data_ptr())
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        ms = float(np.mean(times[2:]))
+        nk_sum = int(nk.to(torch.int64).sum().item())
+        nb = int(seq_off[-1])
+        alg = nk_sum * n * rs * 8 + nb + reads * (C + 1) * 4
+        r = {"reads": reads, "lengths": [[int(L), int(c)] for L, c in parts], "ms": ms, "all_ms": [round(t, 2) for t in times],
+             "bases_per_s": nb / ms * 1e3, "distinct_kmers": nk_sum,
+             "row_gathers_per_s": nk_sum * n / ms * 1e3, "alg_bytes": alg, "achieved_GBs": alg / ms / 1e6, "frac": alg / ms / 1e6 / HBM_PEAK_GBS}
+        if with_oracle:
+            if oix is None:
+                oix = cpu_baseline_readid_index(ptr, m, n, k, C, rs)
+            r.update(cpu_baseline_readid_long(oix, bases, seq_off, read0, report, nk, d, B))
+        rec[name] = r
+        del report, nk, st
+    hx.close()
+    return rec
+
+
+def cpu_baseline_readid_long(oix, bases, seq_off, read0, report, nk, d, B, sample_bases=12_000_000):
+    """the oracle's read loop (orc_readid_counts) on every host core over the first reads of the batch (about sample_bases bases:
+    the oracle keeps a hash set per read, a few hundred thousand windows per second and core); bit-exactness of the device rows"""
+    ncpu = os.cpu_count() or 1
+    S = int(max(1, min(len(read0) - 1, np.searchsorted(seq_off, sample_bases))))
+    hb = bases[:int(seq_off[S])].cpu().numpy()
+    t = time.perf_counter()
+    want = oix.readid_counts(hb, seq_off[:S + 1].copy(), read0[:S + 1].copy(), d, B, n_threads=min(ncpu, S))
+    dt = time.perf_counter() - t
+    exact = bool(np.array_equal(want[0], report[:S].cpu().numpy().view(np.uint32)) and
+                 np.array_equal(want[1], nk[:S].cpu().numpy().view(np.uint32)))
+    return {"bit_exact": exact,
+            "cpu_baseline": {"value": int(seq_off[S]) / dt, "unit": "bases/s", "cores": min(ncpu, S), "kind": "port",
+                             "sample": f"first {S} reads ({int(seq_off[S])} bases), orc_readid_counts, {dt:.2f}s"}}
 
 
 def cpu_baseline_readid_index(mat_ptr, m, n, k, C, rs):

@@ -82,6 +82,7 @@ SIGNATURES = {
     "cid_readid_count_sparse": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(C.c_uint64)]),
     "cid_readid_sparse_fetch": (C.c_int, [vp, vp, vp, vp]),
     "cid_readid_count_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp]),
+    "cid_readid_count_resident": (C.c_int, [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp, vp, vp]),
     "cid_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
     "cid_group_size": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "cid_group_ctx": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),

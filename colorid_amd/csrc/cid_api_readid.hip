@@ -399,7 +399,69 @@ int cid_readid_stripe_count(cid_ctx *c, const cid_index *ix, const uint8_t *d_ba
     return readid_stripe_pass(c, ix, d_bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, sa, d_report, d_n_kmers, d_status);
 }
 
-// uploads the batch, runs the LDS or the sort-based kernel; leaves report / n_kmers / status in the ctx's device scratch
+// bases resident, offsets on the host: routes every read between the LDS kernels and the long-read path, uploads the offsets,
+// runs the kernels into the caller's device arrays.  `d_so` / `d_r0` non-null: the offsets are on the device already (the caller
+// uploaded them together with the bases).
+static int readid_resident(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs,
+                           const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, void *d_so, void *d_r0,
+                           uint32_t *d_rep, uint32_t *d_nk, uint8_t *d_status) {
+    int rc;
+    ReadRoute rr;
+    if ((rc = readid_route(ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
+    const std::vector<uint8_t> &route = rr.route;
+    const size_t n_long = rr.n_long;
+    const bool all_long = n_long == n_reads, mixed = n_long > 0 && !all_long;
+    const size_t C1 = (size_t)ix->n_colors + 1;
+    if (!all_long && !d_so) {
+        rc = slot_reserve(c, S_SEQOFF, (n_seqs + 1) * 8, &d_so); if (rc) return rc;
+        rc = slot_reserve(c, S_READ0, (n_reads + 1) * 8, &d_r0); if (rc) return rc;
+        const size_t b0 = (n_seqs + 1) * 8, b1 = (n_reads + 1) * 8;
+        const uint8_t *so_src = reinterpret_cast<const uint8_t *>(seq_off), *r0_src = reinterpret_cast<const uint8_t *>(read_seq0);
+        if (uint8_t *pin = cid::pin_reserve(c, b0 + b1 + 64)) {
+            HIP_TRY(hipStreamSynchronize(c->stream));   // (the arena may still feed the previous call's copies)
+            memcpy(pin, seq_off, b0); memcpy(pin + b0, read_seq0, b1);
+            so_src = pin; r0_src = pin + b0;
+        }
+        HIP_TRY(hipMemcpyAsync(d_so, so_src, b0, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_r0, r0_src, b1, hipMemcpyHostToDevice, c->stream));
+    }
+    if (ix->rs > 128 && mixed) HIP_TRY(hipMemsetAsync(d_rep, 0, n_reads * C1 * 4, c->stream));   // both kernels count in place
+    if (n_long) {   // first: it writes a status for every read (2 = the other kernel's)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = cid::readid_long(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, mixed ? route.data() : nullptr, !mixed, d_rep,
+                              d_nk, d_status);
+        if (rc) return rc;
+    }
+    if (!all_long) {
+        void *d_skip = nullptr;
+        if (mixed) {
+            rc = slot_reserve(c, S_ROUTE, n_reads, &d_skip); if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(d_skip, route.data(), n_reads, hipMemcpyHostToDevice, c->stream));
+        }
+        rc = readid_dev_impl(c, ix, d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample, rr.max_bytes,
+                             rr.max_win ? rr.max_win : 1, (const uint8_t *)d_skip, !mixed, d_rep, d_nk, d_status);
+        if (mixed) HIP_TRY(hipStreamSynchronize(c->stream));   // `route` leaves scope
+    }
+    return rc;
+}
+
+int cid_readid_count_resident(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs,
+                              const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t *d_report,
+                              uint32_t *d_n_kmers, uint8_t *d_status) {
+    int rc = check_ready(c, ix);
+    if (rc) return rc;
+    if (!seq_off || !read_seq0) return fail(CID_ERR_INVALID, "null argument");
+    if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
+    if (n_reads == 0) return CID_OK;
+    if (!d_report || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
+    if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
+    if (seq_off[n_seqs] && !d_bases) return fail(CID_ERR_INVALID, "null bases");
+    HIP_TRY(hipSetDevice(c->device));
+    return readid_resident(c, ix, d_bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, nullptr, nullptr, d_report, d_n_kmers,
+                           d_status);
+}
+
+// uploads the batch, runs the LDS kernels or the long-read path; leaves report / n_kmers / status in the ctx's device scratch
 static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
                             const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample, uint32_t **d_report_out,
                             uint32_t **d_nk_out, uint8_t **d_status_out) {
@@ -410,12 +472,6 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
     if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
     const uint64_t total_bases = seq_off[n_seqs];
     if (total_bases && !bases) return fail(CID_ERR_INVALID, "null bases");
-    ReadRoute rr;
-    if ((rc = readid_route(ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
-    const std::vector<uint8_t> &route = rr.route;
-    const uint64_t max_bytes = rr.max_bytes, max_win = rr.max_win;
-    const size_t n_long = rr.n_long;
-    const bool all_long = n_long == n_reads, mixed = n_long > 0 && !all_long;
     HIP_TRY(hipSetDevice(c->device));
     void *d_bases, *d_so, *d_r0, *d_rep, *d_nk;
     const size_t C1 = (size_t)ix->n_colors + 1;
@@ -442,25 +498,10 @@ static int readid_to_device(cid_ctx *c, const cid_index *ix, const uint8_t *base
         }
     }
     uint8_t *d_status = (uint8_t *)d_nk + n_reads * 4;
-    if (ix->rs > 128 && mixed) HIP_TRY(hipMemsetAsync(d_rep, 0, n_reads * C1 * 4, c->stream));   // both kernels count in place
-    if (n_long) {   // first: it writes a status for every read (2 = the other kernel's)
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        rc = cid::readid_long(c, ix, (const uint8_t *)d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample,
-                              mixed ? route.data() : nullptr, !mixed, (uint32_t *)d_rep, (uint32_t *)d_nk, d_status);
-        if (rc) return rc;
-    }
-    if (!all_long) {
-        void *d_skip = nullptr;
-        if (mixed) {
-            rc = slot_reserve(c, S_ROUTE, n_reads, &d_skip); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(d_skip, route.data(), n_reads, hipMemcpyHostToDevice, c->stream));
-        }
-        rc = readid_dev_impl(c, ix, (const uint8_t *)d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample,
-                             max_bytes, max_win, (const uint8_t *)d_skip, !mixed, (uint32_t *)d_rep, (uint32_t *)d_nk, d_status);
-        if (mixed) HIP_TRY(hipStreamSynchronize(c->stream));   // `route` leaves scope
-    }
+    rc = readid_resident(c, ix, (const uint8_t *)d_bases, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, d_so, d_r0, (uint32_t *)d_rep,
+                         (uint32_t *)d_nk, d_status);
     if (rc) return rc;
-    *d_report_out = (uint32_t *)d_rep; *d_nk_out = (uint32_t *)d_nk; *d_status_out = (uint8_t *)d_nk + n_reads * 4;
+    *d_report_out = (uint32_t *)d_rep; *d_nk_out = (uint32_t *)d_nk; *d_status_out = d_status;
     return CID_OK;
 }
 

@@ -182,6 +182,13 @@ class Index:
         check(self.lib.cid_readid_count_dev(self.ctx.h, self.h, vp(d_bases), vp(d_seq_off), vp(d_read_seq0), n_reads, d,
                                             start_sample, max_read_bytes, max_read_windows, vp(d_report), vp(d_nk), vp(d_status)))
 
+    def readid_count_resident(self, d_bases, seq_off, read_seq0, d, start_sample, d_report, d_nk, d_status):
+        """bases in HBM, offsets (numpy u64) on the host: reads of any length (long reads take the long-read path)"""
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        read_seq0 = np.ascontiguousarray(read_seq0, np.uint64)
+        check(self.lib.cid_readid_count_resident(self.ctx.h, self.h, vp(d_bases), _p(seq_off), len(seq_off) - 1, _p(read_seq0),
+                                                 len(read_seq0) - 1, d, start_sample, vp(d_report), vp(d_nk), vp(d_status)))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.cid_index_destroy(self.h)

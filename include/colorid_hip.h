@@ -282,6 +282,14 @@ int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, c
                          uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_report, uint32_t *d_n_kmers,
                          uint8_t *d_status);
 
+/* The bases already in HBM (the caller uploaded or produced them), the offsets on the host: reads of ANY length — each read is
+ * routed, inside the batch, to the per-wave LDS kernels or to the long-read path (src/read_id_mt_pe.rs:282-363 takes any read
+ * length; src/kmer.rs:221-243).  Asynchronous on the ctx stream except where a mixed batch's routing table leaves scope; results go
+ * to the caller's DEVICE arrays report[n_reads x (n_colors+1)], n_kmers[n_reads], status[n_reads] (status 1 = too_short). */
+int cid_readid_count_resident(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs,
+                              const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
+                              uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status);
+
 /* ---- several GPUs of one node: the reference's parallel boundary is the rayon map over reads
  *      (src/read_id_mt_pe.rs:300-302, `-t`, src/main.rs:718-721); here the reads / distinct k-mers of a query are sharded in
  *      contiguous balanced ranges over N contexts, one per GPU, each with its own replica of the index (1.6-6.4 GB of 288 GB).
