@@ -46,12 +46,18 @@ struct StripePass {
     bool on() const { return zero_acc || zero_in; }
 };
 
-// read_id for reads that do not fit (or badly fit) the LDS kernel (cid_kmerset.hip): sort-based per-read k-mer sets.
-// route == NULL: every read; else only reads with route[r] != 0 — the others get status 2 and nothing else is written for
-// them.  clear_wide: zero the whole report first when rows are wider than 128 words (those kernels count in place).
+// read_id for reads that do not fit (or badly fit) a wave's LDS (cid_readlong.hip): per-read k-mer sets by workgroup-wide LDS hash
+// tables, the ordered search by slices of a read.  route == NULL: every read; else only reads with route[r] != 0 — the others get
+// status 2 and nothing else is written for them.  clear_wide: zero the whole report first when rows are wider than 128 words (those
+// kernels count in place).  Waits for the stream once, at its end.
 int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                 size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
                 uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp = StripePass());
+// the same by a global radix sort of every window of the batch (cid_kmerset.hip; round 1's path): byte-string keys — k > 32, or a
+// lower-case base among the long reads — and what readid_long hands back
+int readid_long_sorted(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
+                       size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
+                       uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp = StripePass());
 
 // a5 / a4 on k-mers that are already on the device as 2-bit codes (k <= 32); outputs go to HOST buffers
 int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,

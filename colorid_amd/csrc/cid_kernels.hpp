@@ -8,6 +8,7 @@ constexpr int kBlock = 256;  // 4 waves; every wave works on its own 64-k-mer ti
 #ifndef CID_READID_ALIAS
 #define CID_READID_ALIAS 1   // k_readid: the search-phase histogram shares the hash table's LDS region (0: separate regions, A/B builds)
 #endif
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;   // a k-mer set built for an index: the sort key of a window without a k-mer (cid_partition.hpp, cid_windows.hpp)
 constexpr int kPlanes = 8;   // bit-sliced per-colour counters per lane: drained every 255 k-mers
 
 struct SearchParams {
@@ -122,6 +123,34 @@ struct ReadIdListParams {  // k_readid_list: per-read distinct k-mers already in
     const uint64_t *zero_start;
     uint32_t colour_base, report_width, write_nohits;
 };
+
+// The long-read path's in-order search (k_readid_slices): a read's ordered list of distinct k-mers is cut into slices of consecutive
+// windows, one wave per slice; reads cut into several slices leave partial rows that k_readid_combine adds up in slice order.
+struct ReadSlice {
+    uint32_t read;
+    uint32_t w0, w1;   // the slice's windows [w0, w1), numbered over the whole batch
+    uint32_t part;     // index of the slice inside its read | 1 << 31 when the read has more than one slice
+};
+struct ReadCombine { uint32_t read, first_slice, n_slices, pad; };
+struct ReadIdSliceParams {
+    const uint64_t *mat;
+    uint32_t rs, w64, n_colors, n_hash, k;   // k = length of the listed keys (k-mers, or minimizers for a .mxi index)
+    ModMagic mod;
+    const uint64_t *list_codes;   // canonical 2-bit codes of every read's distinct k-mers, first-occurrence order, read after read
+    const uint64_t *list_start;   // [n_reads+1]
+    const uint32_t *bitmap;       // bit w: window w is the first occurrence of its k-mer in its read
+    const uint32_t *word_prefix;  // exclusive prefix of the bitmap words' popcounts: rank(w) = word_prefix[w >> 5] + popc(bits below w)
+    const ReadSlice *slices;
+    uint32_t n_slices;
+    uint32_t start_sample;
+    uint32_t hist_pad, wave_bytes;
+    uint32_t *report;
+    uint32_t *n_kmers;
+    uint32_t *partial;            // [n_slices][n_colors + 2]: counts | no-hits | stopped — only rows of multi-slice reads are written
+};
+hipError_t launch_readid_slices(const ReadIdSliceParams &p, int grid, hipStream_t stream);
+hipError_t launch_readid_combine(const ReadCombine *d_comb, uint32_t n_comb, const uint32_t *d_partial, uint32_t n_colors, uint32_t *d_report,
+                                 hipStream_t stream);
 
 size_t search_smem_bytes(const SearchParams &p);
 hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream);

@@ -399,7 +399,7 @@ __global__ void k_run_sizes(const uint32_t *run_off, uint32_t n_runs, uint32_t c
 // (rest of the key, code): the set comes out ordered by (first row, code).  Equal k-mers share the key, so they are still adjacent
 // and the run-length count is unchanged, while the search's first-row fetches of neighbouring k-mers fall into the same 128-byte
 // lines.  A key of all ones marks "no k-mer here" (row0_key never produces it) and is left out by the first level.
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+// (kNoKey: cid_kernels.hpp)
 
 __global__ __launch_bounds__(kPartBlock) void k_part_hist_key(const uint32_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
                                                                uint32_t shift, uint32_t bits, uint32_t first_level, uint32_t *table, uint32_t *n_dropped) {

@@ -744,6 +744,96 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
     }
 }
 
+// ---- k_readid_slices: the long-read path's search.  The per-read lists of distinct k-mers (first-occurrence order) are walked
+// by one wave per SLICE — the k-mers whose first occurrence lies in a stretch of consecutive windows — so that a 100 kb read is
+// searched by a few dozen waves instead of one.  The reference's rules run over a read's k-mers in order (read_id_mt_pe.rs:66-165):
+//   * `-B S`: the colour set R of the first S k-mers — a later slice gathers those S k-mers again to know R (S <= 64 when reads are cut);
+//   * an absent row ends the read: a slice records whether it stopped, k_readid_combine adds the slices' rows up to the first that did.
+// The list entries of the NEXT chunk are asked for before the current chunk's rows: under load a dependent global load costs as much
+// as a gather round (k_readid_list pays one per 64 k-mers).
+template <int LOG_LPR, bool NARROW>
+__global__ __launch_bounds__(kBlock, 5) void k_readid_slices(ReadIdSliceParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr uint32_t RS = NARROW ? 1u : 2u << LOG_LPR;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const uint32_t C = p.n_colors, k = p.k, n = p.n_hash, S = p.start_sample;
+    uint32_t *ridx = reinterpret_cast<uint32_t *>(smem + (size_t)wave * p.wave_bytes);
+    uint32_t *hist = ridx + kWave * n;
+    for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
+    const uint32_t col_word = NARROW ? 0u : 2u * (lane & ((1 << LOG_LPR) - 1));
+    auto rank = [&](uint32_t w) -> uint64_t {
+        return (uint64_t)p.word_prefix[w >> 5] + (uint32_t)__popc(p.bitmap[w >> 5] & ((1u << (w & 31u)) - 1u));
+    };
+    auto hash_to_ridx = [&](uint64_t code) {
+        xxh3_seeds_from(CodeReader{rev_fields(code, k)}, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+    };
+    for (uint32_t sl = blockIdx.x * waves + wave; sl < p.n_slices; sl += gridDim.x * waves) {
+        wave_lds_fence();
+        const ReadSlice s = p.slices[sl];
+        const bool multi = (s.part >> 31) != 0;
+        const uint32_t part = s.part & 0x7FFFFFFFu;
+        const uint64_t dread = p.list_start[s.read];
+        const uint64_t d0 = rank(s.w0), d1 = rank(s.w1);
+        const uint32_t q_base = (uint32_t)(d0 - dread);
+        uint32_t *row_out = multi ? p.partial + (uint64_t)sl * (C + 2) : p.report + (uint64_t)s.read * (C + 1);
+        bool stopped = false;
+        VCount<kReadPlanes, NARROW> vc;
+        vc.clear();
+        V16 R{0, 0};
+        if (S > 0 && q_base > 0) {   // the colours of the read's first min(S, q_base) k-mers (they lie in earlier slices)
+            const uint32_t t = q_base < S ? q_base : S;   // <= 64: the host cuts reads only then
+            if ((uint32_t)lane < t) hash_to_ridx(p.list_codes[dread + lane]);
+            wave_lds_fence();
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, kReadPlanes, false>(p.mat, RS, n, C, S, ridx, (uint32_t)kWave, t, 0u, hist, stopped, vc, R, lane);
+            vc.clear();   // only R is wanted: those k-mers are counted by the slices that hold them
+            wave_lds_fence();
+            for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
+            // stopped: an earlier slice stops there too and the combine step never reaches this one; nothing to search
+        }
+        uint64_t code_next = d0 + lane < d1 ? p.list_codes[d0 + lane] : 0ull;
+        for (uint64_t c0 = d0; c0 < d1 && !stopped; c0 += kWave) {
+            const bool have = c0 + lane < d1;
+            const uint64_t code = code_next;
+            code_next = c0 + kWave + lane < d1 ? p.list_codes[c0 + kWave + lane] : 0ull;
+            wave_lds_fence();
+            if (have) hash_to_ridx(code);
+            const uint32_t cnt = d1 - c0 < (uint64_t)kWave ? (uint32_t)(d1 - c0) : (uint32_t)kWave;
+            wave_lds_fence();
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, kReadPlanes, false>(p.mat, RS, n, C, S, ridx, (uint32_t)kWave, cnt, q_base + (uint32_t)(c0 - d0), hist,
+                                                                                   stopped, vc, R, lane);
+        }
+        vc.drain(hist, col_word);
+        wave_lds_fence();
+        for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
+        if (lane == 0) {
+            if (multi) row_out[C + 1] = stopped ? 1u : 0u;
+            if (part == 0) p.n_kmers[s.read] = (uint32_t)(p.list_start[s.read + 1] - dread);
+        }
+    }
+}
+
+// one wave per read that was cut into several slices: the slices' rows in order, up to and including the first that stopped
+__global__ __launch_bounds__(kBlock) void k_readid_combine(const ReadCombine *comb, uint32_t n_comb, const uint32_t *partial, uint32_t C, uint32_t *report) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_comb) return;
+    const ReadCombine rc = comb[i];
+    uint32_t last = rc.n_slices;   // slices that count
+    for (uint32_t j0 = 0; j0 < rc.n_slices && last == rc.n_slices; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        const bool st = j < rc.n_slices && partial[(uint64_t)(rc.first_slice + j) * (C + 2) + C + 1] != 0;
+        const uint64_t bm = __ballot(st);
+        if (bm) last = j0 + (uint32_t)__builtin_ctzll(bm) + 1;
+    }
+    for (uint32_t c = lane; c <= C; c += kWave) {
+        uint32_t acc = 0;
+        for (uint32_t j = 0; j < last; ++j) acc += partial[(uint64_t)(rc.first_slice + j) * (C + 2) + c];
+        report[(uint64_t)rc.read * (C + 1) + c] = acc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 
@@ -903,6 +993,38 @@ static hipError_t launch_readid_list_sel(const ReadIdListParams &p, int grid, hi
 hipError_t launch_readid_list(const ReadIdListParams &p, int grid, hipStream_t stream) {
     if (p.n_reads == 0) return hipSuccess;
     return (p.zero_acc || p.zero_in) ? launch_readid_list_sel<true>(p, grid, stream) : launch_readid_list_sel<false>(p, grid, stream);
+}
+
+template <typename KernelT>
+static hipError_t launch_readid_slices_one(KernelT kernel, const ReadIdSliceParams &p, int grid, hipStream_t stream) {
+    const size_t shmem = (size_t)(kBlock / kWave) * p.wave_bytes;
+    if (shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), shmem, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_readid_slices(const ReadIdSliceParams &p, int grid, hipStream_t stream) {   // rows of at most 1 KiB (rs <= 128), whole indices
+    if (p.n_slices == 0) return hipSuccess;
+    if (p.rs > 128) return hipErrorInvalidValue;
+    if (p.rs == 1) return launch_readid_slices_one(k_readid_slices<0, true>, p, grid, stream);
+    switch (log2u(p.rs / 2)) {
+    case 0: return launch_readid_slices_one(k_readid_slices<0, false>, p, grid, stream);
+    case 1: return launch_readid_slices_one(k_readid_slices<1, false>, p, grid, stream);
+    case 2: return launch_readid_slices_one(k_readid_slices<2, false>, p, grid, stream);
+    case 3: return launch_readid_slices_one(k_readid_slices<3, false>, p, grid, stream);
+    case 4: return launch_readid_slices_one(k_readid_slices<4, false>, p, grid, stream);
+    case 5: return launch_readid_slices_one(k_readid_slices<5, false>, p, grid, stream);
+    case 6: return launch_readid_slices_one(k_readid_slices<6, false>, p, grid, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_readid_combine(const ReadCombine *d_comb, uint32_t n_comb, const uint32_t *d_partial, uint32_t n_colors, uint32_t *d_report,
+                                 hipStream_t stream) {
+    if (n_comb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_readid_combine, dim3((n_comb + 3) / 4), dim3(kBlock), 0, stream, d_comb, n_comb, d_partial, n_colors, d_report);
+    return hipGetLastError();
 }
 
 // the first use of a kernel loads its translation unit's whole code object (tens of milliseconds for this file's instantiations):

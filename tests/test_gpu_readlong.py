@@ -1,0 +1,150 @@
+"""The long-read read_id path (cid_readlong.hip: workgroup-wide LDS hash tables -> first-occurrence bitmap -> ordered lists -> the
+search by slices of a read) against the oracle's restatement of read_id_mt_pe.rs:66-165,282-363 / kmer.rs:221-243, bit-exact:
+row widths of 8 B ... 1 KiB, reads of 3 kb ... 1.2 Mb, breaks (absent rows) in every slice position, `-B S` from 0 to beyond a read,
+strides, pairs, N stretches, repeats, minimizer indices, the resident entry point, and round 1's sorting path as a second witness."""
+import numpy as np
+import pytest
+
+from test_gpu_readid import pack_reads
+from util import ACGT, random_index, to_hip_index
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(rng, n):
+    return ACGT[rng.integers(0, 4, n)].tobytes()
+
+
+def compare(oix, hx, reads, d, S, what=""):
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    want = oix.readid_counts(bases, seq_off, read_seq0, d, S, n_threads=8)
+    got = hx.readid_count(bases, seq_off, read_seq0, d, S)
+    assert np.array_equal(want[2], got[2]), ("status", what)
+    assert np.array_equal(want[1], got[1]), ("n_kmers", what, np.flatnonzero(want[1] != got[1])[:5], want[1][:8], got[1][:8])
+    bad = np.flatnonzero((want[0] != got[0]).any(axis=1))
+    assert len(bad) == 0, (what, bad[:5], want[0][bad[0]][:12], got[0][bad[0]][:12], want[0][bad[0]][-1], got[0][bad[0]][-1])
+    return want
+
+
+def long_reads(rng, genome):
+    """reads that exercise the path: every table size, several buckets, several slices, repeats, N runs, pairs"""
+    L = len(genome)
+    reads = [[genome[:3_000]], [genome[1_000:5_200]], [genome[2_000:12_000]], [genome[:40_000]], [genome[5_000:5_000 + 70_000]],
+             [genome[:20_000], genome[10_000:35_000]],                        # a long pair sharing k-mers across mates
+             [genome[:6_000] * 5],                                            # 30 kb with every k-mer five times
+             [b"N" * 9_000 + genome[100:9_000]],                              # the first two slices hold no k-mer at all
+             [genome[:4_200] + b"N" * 30 + genome[:4_200] + b"N" + genome[4_000:9_000]],
+             [b"ACGTTGCA" * 2_000],                                           # 16 kb, eight distinct windows
+             [b"A" * 50_000],
+             [genome[L - 3_500:]], [b"ACG"], [genome[:100]]]
+    return reads
+
+
+@pytest.mark.parametrize("n_colors,n_hash,k", [(256, 2, 21), (40, 3, 31), (100, 1, 15), (1000, 2, 27), (8192, 2, 21), (300, 4, 32)])
+def test_long_reads_every_row_width(orc, hip_ctx, n_colors, n_hash, k):
+    rng = np.random.default_rng(n_colors + k)
+    m = 200_003 if n_colors < 1000 else 10_007
+    # a few absent rows: a read of thousands of k-mers stops somewhere inside — in its first slice or in a later one
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.05, zero_row_frac=0.0002 if n_colors < 1000 else 0.002)
+    genome = rnd(rng, 160_000)
+    hx = to_hip_index(hip_ctx, oix)
+    reads = long_reads(rng, genome)
+    stops = 0
+    for d, S in ((1, 3), (1, 0), (3, 1), (1, 64), (1, 65), (2, 5000)):
+        rep = compare(oix, hx, reads, d, S, (n_colors, d, S))[0]
+        stops += int((rep[:, n_colors] > 0).sum())
+    assert stops > 0   # the absent-row stop was taken somewhere
+    hx.close()
+
+
+def test_breaks_in_every_slice_position(orc, hip_ctx):
+    """one absent row planted at a chosen place of a 30 kb read: the rows stop exactly there, whichever slice holds it"""
+    rng = np.random.default_rng(11)
+    n_colors, n_hash, k, m = 256, 2, 21, 400_009
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.1, zero_row_frac=0.0)
+    genome = rnd(rng, 30_000)
+    rows = oix.rows()
+    keep = rows.copy()
+    hx = None
+    for pos in (0, 1, 2, 3, 63, 64, 4095, 4096, 4097, 8191, 12_288, 20_000, 29_979):
+        rows[:] = keep
+        km = genome[pos:pos + k]
+        rc = km.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]
+        canon = min(km, rc)
+        rows[orc.xxh3(canon, 1) % m, :] = 0   # the row of its second hash
+        if hx is not None:
+            hx.close()
+        hx = to_hip_index(hip_ctx, oix)
+        for S in (0, 3):
+            rep = compare(oix, hx, [[genome], [genome[:10_000]], [genome[pos:]]], 1, S, (pos, S))[0]
+            assert rep[0, n_colors] == 1
+    hx.close()
+
+
+def test_megabase_read_and_many_buckets(orc, hip_ctx):
+    rng = np.random.default_rng(3)
+    n_colors, n_hash, k, m = 64, 2, 21, 1_000_003
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.2, zero_row_frac=0.0)
+    hx = to_hip_index(hip_ctx, oix)
+    g = rnd(rng, 1_200_000)
+    reads = [[g], [g[:300_000] + g[:300_000]], [g[:5_000]]]
+    rep, nk, st = compare(oix, hx, reads, 1, 3)
+    assert nk[0] > 1_190_000 and nk[1] < 300_100
+    hx.close()
+
+
+def test_minimizer_index_long_reads(orc, hip_ctx):
+    rng = np.random.default_rng(21)
+    n_colors, n_hash, k, m, msz = 128, 2, 27, 150_001, 15
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.1, zero_row_frac=0.0005)
+    oix.set_minimizer(msz)
+    import colorid_amd
+    hx = colorid_amd.Index(hip_ctx, m, n_hash, k, n_colors).set_minimizer(msz)
+    hx.put_dense(oix.rows())
+    hx.finalize()
+    genome = rnd(rng, 90_000)
+    for d, S in ((1, 3), (2, 0)):
+        compare(oix, hx, long_reads(rng, genome), d, S, ("mini", d, S))
+    hx.close()
+
+
+def test_resident_call_and_the_sorting_path_agree(orc, hip_ctx):
+    import torch
+    import colorid_amd
+    rng = np.random.default_rng(8)
+    n_colors, n_hash, k, m = 256, 2, 21, 300_007
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.1, zero_row_frac=0.0003)
+    hx = to_hip_index(hip_ctx, oix)
+    genome = rnd(rng, 120_000)
+    reads = long_reads(rng, genome) + [[genome[i:i + 150]] for i in range(0, 6_000, 150)]     # short reads routed to the LDS kernel
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    want = oix.readid_counts(bases, seq_off, read_seq0, 1, 3, n_threads=8)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(bases.copy()).to(dev)
+    n = len(reads)
+    outs = []
+    for lds in (1, 0):   # this round's path, then round 1's global sort
+        hip_ctx.tune("readid_long_lds", lds)
+        rep = torch.full((n, n_colors + 1), 77, dtype=torch.int32, device=dev)
+        nk = torch.full((n,), 77, dtype=torch.int32, device=dev)
+        st = torch.full((n,), 77, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        hx.readid_count_resident(d_bases.data_ptr(), seq_off, read_seq0, 1, 3, rep.data_ptr(), nk.data_ptr(), st.data_ptr())
+        hip_ctx.synchronize()
+        outs.append((rep.cpu().numpy().view(np.uint32), nk.cpu().numpy().view(np.uint32), st.cpu().numpy()))
+    hip_ctx.tune("readid_long_lds", 1)
+    for got in outs:
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+    hx.close()
+
+
+def test_lower_case_among_long_reads_falls_back(orc, hip_ctx):
+    rng = np.random.default_rng(13)
+    n_colors, n_hash, k, m = 256, 2, 21, 100_003
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.1, zero_row_frac=0.0)
+    hx = to_hip_index(hip_ctx, oix)
+    g = rnd(rng, 50_000)
+    low = bytearray(g[:30_000])
+    low[12_345:12_400] = bytes(low[12_345:12_400]).lower()
+    compare(oix, hx, [[g[:20_000]], [bytes(low)], [g[100:260]], [g[:9_000].lower(), g[:9000]]], 1, 3)
+    hx.close()
