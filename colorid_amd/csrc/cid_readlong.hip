@@ -13,6 +13,7 @@
 //   k_long_scatter       the flagged windows' codes, in window order = first-occurrence order, read after read
 //   k_readid_slices      the in-order search, one wave per slice of a read (cid_readid.hip); k_readid_combine adds the slices up
 //
+// A read's windows start at a multiple of 32 in the batch's numbering (the code array has unused gaps): its bitmap words are its own.
 // No host round trip between the kernels: the list is sized by the window count (an upper bound), ranks stay on the device.
 // Byte-string keys (k > 32, or a lower-case base: its case is kept), rows wider than 1 KiB and colour-stripe
 // passes keep round 1's path (cid_kmerset.hip: readid_long_sorted) — with this file's lists where the keys pack.
@@ -30,8 +31,8 @@ namespace cid {
 
 constexpr uint32_t kLongIdxBits = 22, kLongTagBits = 10, kLongEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kLongMaxWin = (1u << kLongIdxBits) - 2;       // windows of one read the 4-byte slots can number
-constexpr uint32_t kLongSlotsBig = 32768, kLongBlockBig = 1024;   // 128 KiB of LDS, one workgroup of 16 waves per CU
-constexpr uint32_t kLongSlotsSmall = 8192, kLongBlockSmall = 256; // 32 KiB: reads of up to kLongSmallWin windows, four workgroups per CU
+constexpr uint32_t kLongSlotsBig = 32768, kLongBlockBig = 1024, kLongBmBig = 4096;   // 128 + 16 KiB of LDS, one workgroup of 16 waves per CU
+constexpr uint32_t kLongSlotsSmall = 8192, kLongBlockSmall = 256, kLongBmSmall = 128; // 32.5 KiB: reads of up to kLongSmallWin windows, four workgroups per CU
 constexpr uint32_t kLongSmallWin = 4096;
 constexpr uint32_t kLongFill = kLongSlotsBig / 2;                 // distinct k-mers a pass over a big table is planned for
 constexpr uint32_t kLongMaxLevel = 7;
@@ -48,18 +49,19 @@ __device__ __forceinline__ uint64_t long_mix(uint64_t x) {   // a bijection of t
 
 // One workgroup per work item at a time; XCD x walks the x-th eighth of the items so that the passes over one read's codes meet in
 // one L2 (workgroups are dealt to the XCDs in turn).  gridDim.x is a multiple of 8.
-__global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart, const LongItem *items, uint32_t n_items, uint64_t sentinel,
-                                   uint32_t slots, uint32_t *bitmap, int *flags) {
-    extern __shared__ uint32_t table[];
+__global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongItem *items, uint32_t n_items, uint64_t sentinel,
+                                   uint32_t slots, uint32_t bm_words, uint32_t *bitmap, int *flags) {
+    extern __shared__ uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
     __shared__ int s_over;
-    const uint32_t mask = slots - 1;
+    uint32_t *bm = table + slots;
+    const uint32_t mask = slots - 1, bm_bits = bm_words * 32u;
     const uint32_t chunk = (n_items + 7u) / 8u;
     for (uint32_t it = blockIdx.x >> 3; it < chunk; it += gridDim.x >> 3) {
         const uint32_t item = (blockIdx.x & 7u) * chunk + it;
         if (item >= n_items) break;
         const LongItem im = items[item];
         const uint64_t w0 = wstart[im.read];
-        const uint32_t nw = (uint32_t)(wstart[im.read + 1] - w0);
+        const uint32_t nw = (uint32_t)(wend[im.read] - w0);   // (wstart[read + 1] lies beyond the padding)
         const uint64_t *rc = codes + w0;
         uint32_t level = 0;
         for (uint32_t sub = 0; sub < (1u << level); ++sub) {
@@ -100,14 +102,30 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                 __syncthreads();
                 continue;
             }
-            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
-                const uint32_t cur = table[s];
-                if (cur != kLongEmpty) {
-                    const uint64_t w = w0 + (cur >> kLongTagBits);
-                    atomicOr(&bitmap[w >> 5], 1u << (w & 31u));
+            // The winners' bits: put together in LDS, a stretch of bm_bits windows at a time, and written out as whole words (a read's
+            // windows start at a multiple of 32, so its words are its own).  One global atomicOr per BIT took 4.4 of this kernel's
+            // 5.4 ms on 150 Mbases of 10 kb reads: the atomics of a read all fall into its dozen of 128-byte lines.
+            const bool own_words = im.n_buckets == 1 && level == 0;   // else other passes add to the same words
+            for (uint32_t c0 = 0; c0 < nw; c0 += bm_bits) {
+                for (uint32_t i = threadIdx.x; i < bm_words; i += blockDim.x) bm[i] = 0;
+                __syncthreads();
+                for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+                    const uint32_t cur = table[s];
+                    if (cur != kLongEmpty) {
+                        const uint32_t w = (cur >> kLongTagBits) - c0;
+                        if (w < bm_bits) atomicOr(&bm[w >> 5], 1u << (w & 31u));
+                    }
                 }
+                __syncthreads();
+                const uint32_t words = (nw - c0 + 31u) / 32u < bm_words ? (nw - c0 + 31u) / 32u : bm_words;
+                uint32_t *out = bitmap + ((w0 + c0) >> 5);
+                for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
+                    const uint32_t v = bm[i];
+                    if (own_words) out[i] = v;
+                    else if (v) atomicOr(&out[i], v);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 }
@@ -157,7 +175,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     const bool own_search = rs <= 128 && !sp.on();   // k_readid_slices; else the lists feed k_readid_list
     const bool cut = start_sample <= 64;              // a later slice gathers the first S k-mers again
     // windows are numbered read by read, mate by mate
-    std::vector<uint64_t> wstart(n_reads + 1, 0);
+    std::vector<uint64_t> wstart(n_reads + 1, 0), wend(n_reads, 0);
     std::vector<uint8_t> status(n_reads, 0);
     std::vector<Segment> segs;
     std::vector<LongItem> items_small, items_big;
@@ -168,6 +186,8 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     for (size_t r = 0; r < n_reads; ++r) {
         wstart[r] = W;
         if (route && !route[r]) { status[r] = 2; continue; }
+        W = (W + 31) & ~(uint64_t)31;   // (its bitmap words are its own)
+        wstart[r] = W;
         const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
         if (s1 == s0 || seq_off[s0 + 1] - seq_off[s0] < k) { status[r] = 1; continue; }   // too_short (first mate only)
         for (uint64_t s = s0; s < s1; ++s) {
@@ -181,6 +201,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
             }
         }
         const uint64_t win = W - wstart[r];
+        wend[r] = W;
         if (win > kLongMaxWin)   // (a 4 Mb read: the slots number 2^22 windows)
             return readid_long_sorted(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, route, clear_wide, d_report, d_n_kmers,
                                       d_status, sp);
@@ -204,7 +225,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     if (n_reads >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "more than 2^31 reads in one batch");
     const size_t C1 = (size_t)C + 1;
     const uint64_t n_words = W / 32 + 1;   // (rank(W) reads the word after the last window's)
-    DevBuf<uint64_t> d_wstart(c), d_codes(c), d_list(c), d_lstart(c), d_scan(c);
+    DevBuf<uint64_t> d_wstart(c), d_wend(c), d_codes(c), d_list(c), d_lstart(c), d_scan(c);
     DevBuf<uint32_t> d_bitmap(c), d_prefix(c), d_partial(c);
     DevBuf<Segment> d_segs(c);
     DevBuf<LongItem> d_items(c);
@@ -213,13 +234,14 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     DevBuf<int> d_flags(c);
     int rc;
     const size_t n_items = items_small.size() + items_big.size();
-    if ((rc = d_wstart.alloc(n_reads + 1)) || (rc = d_codes.alloc(W + 1)) || (rc = d_list.alloc(W + 1)) || (rc = d_lstart.alloc(n_reads + 1)) ||
+    if ((rc = d_wstart.alloc(n_reads + 1)) || (rc = d_wend.alloc(n_reads)) || (rc = d_codes.alloc(W + 1)) || (rc = d_list.alloc(W + 1)) || (rc = d_lstart.alloc(n_reads + 1)) ||
         (rc = d_scan.alloc(scan_state_words(n_words))) || (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
         (rc = d_segs.alloc(segs.size())) || (rc = d_items.alloc(n_items)) || (rc = d_slices.alloc(slices.size())) ||
         (rc = d_combs.alloc(combs.size())) || (rc = d_partial.alloc(combs.empty() ? 1 : slices.size() * (C1 + 1))) || (rc = d_flags.alloc(4)))
         return rc;
     HIP_TRY(hipMemcpyAsync(d_status, status.data(), n_reads, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_wstart.p, wstart.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_wend.p, wend.data(), n_reads * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_flags.p, 0, 16, st));
     HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, n_words * 4, st));
     int h_flags[4] = {0, 0, 0, 0};
@@ -240,15 +262,15 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         if (!items_small.empty()) {
             unsigned g = n_cu * 4u;   // four 32-KiB workgroups per CU
             g = (g + 7u) & ~7u;
-            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockSmall), kLongSlotsSmall * 4, st, d_codes.p, d_wstart.p, d_items.p,
-                               (uint32_t)items_small.size(), sentinel, kLongSlotsSmall, d_bitmap.p, d_flags.p);
+            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockSmall), (kLongSlotsSmall + kLongBmSmall) * 4, st, d_codes.p, d_wstart.p, d_wend.p, d_items.p,
+                               (uint32_t)items_small.size(), sentinel, kLongSlotsSmall, kLongBmSmall, d_bitmap.p, d_flags.p);
         }
         if (!items_big.empty()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_first_flags), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(kLongSlotsBig * 4)));
+                                        (int)((kLongSlotsBig + kLongBmBig) * 4)));
             unsigned g = (n_cu + 7u) & ~7u;
-            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), kLongSlotsBig * 4, st, d_codes.p, d_wstart.p,
-                               d_items.p + items_small.size(), (uint32_t)items_big.size(), sentinel, kLongSlotsBig, d_bitmap.p, d_flags.p);
+            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), (kLongSlotsBig + kLongBmBig) * 4, st, d_codes.p, d_wstart.p, d_wend.p,
+                               d_items.p + items_small.size(), (uint32_t)items_big.size(), sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p);
         }
         HIP_TRY(hipGetLastError());
         if (!own_search) {   // wide rows and stripe passes add into rows in place: what would send the batch to the sorting path (see the
