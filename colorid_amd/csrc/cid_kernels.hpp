@@ -136,8 +136,8 @@ struct ReadIdSliceParams {
     const uint64_t *mat;
     uint32_t rs, w64, n_colors, n_hash, k;   // k = length of the listed keys (k-mers, or minimizers for a .mxi index)
     ModMagic mod;
-    const uint64_t *list_codes;   // canonical 2-bit codes of every read's distinct k-mers, first-occurrence order, read after read
-    const uint64_t *list_start;   // [n_reads+1]
+    const uint64_t *codes;        // every window's canonical 2-bit code (windows numbered over the batch; a read's start at a multiple of 32)
+    const uint64_t *wstart, *wend;   // [n_reads]: a read's windows [wstart, wend)
     const uint32_t *bitmap;       // bit w: window w is the first occurrence of its k-mer in its read
     const uint32_t *word_prefix;  // exclusive prefix of the bitmap words' popcounts: rank(w) = word_prefix[w >> 5] + popc(bits below w)
     const ReadSlice *slices;

@@ -744,13 +744,15 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
     }
 }
 
-// ---- k_readid_slices: the long-read path's search.  The per-read lists of distinct k-mers (first-occurrence order) are walked
-// by one wave per SLICE — the k-mers whose first occurrence lies in a stretch of consecutive windows — so that a 100 kb read is
-// searched by a few dozen waves instead of one.  The reference's rules run over a read's k-mers in order (read_id_mt_pe.rs:66-165):
+// ---- k_readid_slices: the long-read path's search.  A read's distinct k-mers in first-occurrence order are the windows whose bit is
+// set in the first-occurrence bitmap, in window order; they are walked by one wave per SLICE (a stretch of consecutive windows), so a
+// 100 kb read is searched by a few dozen waves instead of one.  No list is materialised: the wave takes 64 consecutive windows, the
+// flagged lanes are this chunk's k-mers in order (a ballot compacts them), their rows go to LDS and through the same in-order run as
+// k_readid's.  The reference's rules run over a read's k-mers in order (read_id_mt_pe.rs:66-165):
 //   * `-B S`: the colour set R of the first S k-mers — a later slice gathers those S k-mers again to know R (S <= 64 when reads are cut);
 //   * an absent row ends the read: a slice records whether it stopped, k_readid_combine adds the slices' rows up to the first that did.
-// The list entries of the NEXT chunk are asked for before the current chunk's rows: under load a dependent global load costs as much
-// as a gather round (k_readid_list pays one per 64 k-mers).
+// The codes and bitmap words of the NEXT 64 windows are asked for before the current chunk's rows: under load a dependent global load
+// costs as much as a gather round (k_readid_list pays one per 64 k-mers).
 template <int LOG_LPR, bool NARROW>
 __global__ __launch_bounds__(kBlock, 5) void k_readid_slices(ReadIdSliceParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -763,28 +765,37 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_slices(ReadIdSliceParams p
     uint32_t *hist = ridx + kWave * n;
     for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
     const uint32_t col_word = NARROW ? 0u : 2u * (lane & ((1 << LOG_LPR) - 1));
-    auto rank = [&](uint32_t w) -> uint64_t {
-        return (uint64_t)p.word_prefix[w >> 5] + (uint32_t)__popc(p.bitmap[w >> 5] & ((1u << (w & 31u)) - 1u));
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    auto rank = [&](uint32_t w) -> uint32_t {
+        return p.word_prefix[w >> 5] + (uint32_t)__popc(p.bitmap[w >> 5] & ((1u << (w & 31u)) - 1u));
     };
-    auto hash_to_ridx = [&](uint64_t code) {
-        xxh3_seeds_from(CodeReader{rev_fields(code, k)}, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + lane] = (uint32_t)mod_m(h, p.mod); });
+    auto hash_to = [&](uint64_t code, uint32_t q) {
+        xxh3_seeds_from(CodeReader{rev_fields(code, k)}, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + q] = (uint32_t)mod_m(h, p.mod); });
     };
     for (uint32_t sl = blockIdx.x * waves + wave; sl < p.n_slices; sl += gridDim.x * waves) {
         wave_lds_fence();
         const ReadSlice s = p.slices[sl];
         const bool multi = (s.part >> 31) != 0;
         const uint32_t part = s.part & 0x7FFFFFFFu;
-        const uint64_t dread = p.list_start[s.read];
-        const uint64_t d0 = rank(s.w0), d1 = rank(s.w1);
-        const uint32_t q_base = (uint32_t)(d0 - dread);
+        const uint32_t r0 = (uint32_t)p.wstart[s.read], r1 = (uint32_t)p.wend[s.read];   // the read's windows
+        const uint32_t dread = rank(r0);
+        uint32_t q_run = rank(s.w0) - dread;   // order index of the slice's first k-mer inside its read
         uint32_t *row_out = multi ? p.partial + (uint64_t)sl * (C + 2) : p.report + (uint64_t)s.read * (C + 1);
         bool stopped = false;
         VCount<kReadPlanes, NARROW> vc;
         vc.clear();
         V16 R{0, 0};
-        if (S > 0 && q_base > 0) {   // the colours of the read's first min(S, q_base) k-mers (they lie in earlier slices)
-            const uint32_t t = q_base < S ? q_base : S;   // <= 64: the host cuts reads only then
-            if ((uint32_t)lane < t) hash_to_ridx(p.list_codes[dread + lane]);
+        if (S > 0 && q_run > 0) {   // the colours of the read's first min(S, q_run) k-mers (they lie in earlier slices)
+            const uint32_t t = q_run < S ? q_run : S;   // <= 64: the host cuts reads only then
+            uint32_t have = 0;
+            for (uint32_t w = r0; have < t && w < r1; w += kWave) {   // (they exist: q_run counts them)
+                const uint32_t mine = w + lane;
+                const bool flag = mine < r1 && ((p.bitmap[mine >> 5] >> (mine & 31u)) & 1u);
+                const uint64_t fm = __ballot(flag);
+                const uint32_t q = have + (uint32_t)__popcll(fm & lt_mask);
+                if (flag && q < t) hash_to(p.codes[mine], q);
+                have += (uint32_t)__popcll(fm);
+            }
             wave_lds_fence();
             readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, kReadPlanes, false>(p.mat, RS, n, C, S, ridx, (uint32_t)kWave, t, 0u, hist, stopped, vc, R, lane);
             vc.clear();   // only R is wanted: those k-mers are counted by the slices that hold them
@@ -792,24 +803,31 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_slices(ReadIdSliceParams p
             for (uint32_t c = lane; c < p.hist_pad; c += kWave) hist[c] = 0;
             // stopped: an earlier slice stops there too and the combine step never reaches this one; nothing to search
         }
-        uint64_t code_next = d0 + lane < d1 ? p.list_codes[d0 + lane] : 0ull;
-        for (uint64_t c0 = d0; c0 < d1 && !stopped; c0 += kWave) {
-            const bool have = c0 + lane < d1;
+        uint32_t wn = s.w0 + lane;
+        uint64_t code_next = wn < s.w1 ? p.codes[wn] : 0ull;
+        uint32_t word_next = wn < s.w1 ? p.bitmap[wn >> 5] : 0u;
+        for (uint32_t w = s.w0; w < s.w1 && !stopped; w += kWave) {
+            const uint32_t mine = w + lane;
             const uint64_t code = code_next;
-            code_next = c0 + kWave + lane < d1 ? p.list_codes[c0 + kWave + lane] : 0ull;
+            const bool flag = mine < s.w1 && ((word_next >> (mine & 31u)) & 1u);
+            wn = mine + kWave;
+            code_next = wn < s.w1 ? p.codes[wn] : 0ull;
+            word_next = wn < s.w1 ? p.bitmap[wn >> 5] : 0u;
+            const uint64_t fm = __ballot(flag);
+            if (!fm) continue;   // (wave-uniform: 64 windows without a first occurrence)
             wave_lds_fence();
-            if (have) hash_to_ridx(code);
-            const uint32_t cnt = d1 - c0 < (uint64_t)kWave ? (uint32_t)(d1 - c0) : (uint32_t)kWave;
+            if (flag) hash_to(code, (uint32_t)__popcll(fm & lt_mask));
+            const uint32_t cnt = (uint32_t)__popcll(fm);
             wave_lds_fence();
-            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, kReadPlanes, false>(p.mat, RS, n, C, S, ridx, (uint32_t)kWave, cnt, q_base + (uint32_t)(c0 - d0), hist,
-                                                                                   stopped, vc, R, lane);
+            readid_search_run<LOG_LPR, NARROW, kReadRunUnroll, kReadPlanes, false>(p.mat, RS, n, C, S, ridx, (uint32_t)kWave, cnt, q_run, hist, stopped, vc, R, lane);
+            q_run += cnt;
         }
         vc.drain(hist, col_word);
         wave_lds_fence();
         for (uint32_t c = lane; c <= C; c += kWave) { row_out[c] = hist[c]; hist[c] = 0; }
         if (lane == 0) {
             if (multi) row_out[C + 1] = stopped ? 1u : 0u;
-            if (part == 0) p.n_kmers[s.read] = (uint32_t)(p.list_start[s.read + 1] - dread);
+            if (part == 0) p.n_kmers[s.read] = rank(r1) - dread;
         }
     }
 }

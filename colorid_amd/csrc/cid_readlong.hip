@@ -10,11 +10,13 @@
 //                        in a bitmap over the batch's windows.  P = windows / 16 384, so a pass fills half of a 32 768-slot table;
 //                        a pass that overflows anyway is redone on sub-buckets (a further hash bit per level).
 //   scan (cid_scan.hpp)  exclusive prefix of the bitmap words' popcounts: rank(w) of any window without a second pass
-//   k_long_scatter       the flagged windows' codes, in window order = first-occurrence order, read after read
-//   k_readid_slices      the in-order search, one wave per slice of a read (cid_readid.hip); k_readid_combine adds the slices up
+//   k_readid_slices      the in-order search, one wave per slice of a read, straight from the bitmap and the code array: the flagged
+//                        windows in window order ARE the read's k-mers in first-occurrence order (cid_readid.hip); k_readid_combine
+//                        adds a read's slices up
+//   (k_long_scatter      the same k-mers as lists, for k_readid_list: rows wider than 1 KiB and colour-stripe passes)
 //
 // A read's windows start at a multiple of 32 in the batch's numbering (the code array has unused gaps): its bitmap words are its own.
-// No host round trip between the kernels: the list is sized by the window count (an upper bound), ranks stay on the device.
+// No host round trip between the kernels: nothing is sized by a count only the device knows.
 // Byte-string keys (k > 32, or a lower-case base: its case is kept), rows wider than 1 KiB and colour-stripe
 // passes keep round 1's path (cid_kmerset.hip: readid_long_sorted) — with this file's lists where the keys pack.
 #include <cstring>
@@ -234,7 +236,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     DevBuf<int> d_flags(c);
     int rc;
     const size_t n_items = items_small.size() + items_big.size();
-    if ((rc = d_wstart.alloc(n_reads + 1)) || (rc = d_wend.alloc(n_reads)) || (rc = d_codes.alloc(W + 1)) || (rc = d_list.alloc(W + 1)) || (rc = d_lstart.alloc(n_reads + 1)) ||
+    if ((rc = d_wstart.alloc(n_reads + 1)) || (rc = d_wend.alloc(n_reads)) || (rc = d_codes.alloc(W + 1)) ||
         (rc = d_scan.alloc(scan_state_words(n_words))) || (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
         (rc = d_segs.alloc(segs.size())) || (rc = d_items.alloc(n_items)) || (rc = d_slices.alloc(slices.size())) ||
         (rc = d_combs.alloc(combs.size())) || (rc = d_partial.alloc(combs.empty() ? 1 : slices.size() * (C1 + 1))) || (rc = d_flags.alloc(4)))
@@ -282,10 +284,13 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         }
     }
     HIP_TRY(scan_launch(PopcIn{d_bitmap.p}, PrefixOut{d_prefix.p}, n_words, d_scan.p, st));
-    if (W) hipLaunchKernelGGL(k_long_scatter, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, d_bitmap.p, d_prefix.p, d_list.p, (uint64_t)W);
-    hipLaunchKernelGGL(k_long_list_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, d_wstart.p, d_bitmap.p, d_prefix.p, d_lstart.p,
-                       (uint32_t)n_reads);
-    HIP_TRY(hipGetLastError());
+    if (!own_search) {   // k_readid_list walks lists
+        if ((rc = d_list.alloc(W + 1)) || (rc = d_lstart.alloc(n_reads + 1))) return rc;
+        if (W) hipLaunchKernelGGL(k_long_scatter, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, d_bitmap.p, d_prefix.p, d_list.p, (uint64_t)W);
+        hipLaunchKernelGGL(k_long_list_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, d_wstart.p, d_bitmap.p, d_prefix.p, d_lstart.p,
+                           (uint32_t)n_reads);
+        HIP_TRY(hipGetLastError());
+    }
     const uint32_t hist_pad = rs > 128 ? 4u * rs : (uint32_t)((C1 + 3) & ~(size_t)3);
     const uint32_t wave_bytes = (uint32_t)((4ull * kWave * n_hash + 4ull * hist_pad + 15) & ~15ull);
     if ((size_t)(kBlock / kWave) * wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
@@ -294,7 +299,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         if (!combs.empty()) HIP_TRY(hipMemcpyAsync(d_combs.p, combs.data(), combs.size() * sizeof(ReadCombine), hipMemcpyHostToDevice, st));
         ReadIdSliceParams p{};
         p.mat = index_matrix(ix); p.rs = rs; p.w64 = (C + 63) / 64; p.n_colors = C; p.n_hash = n_hash; p.k = key_len; p.mod = index_mod(ix);
-        p.list_codes = d_list.p; p.list_start = d_lstart.p; p.bitmap = d_bitmap.p; p.word_prefix = d_prefix.p;
+        p.codes = d_codes.p; p.wstart = d_wstart.p; p.wend = d_wend.p; p.bitmap = d_bitmap.p; p.word_prefix = d_prefix.p;
         p.slices = d_slices.p; p.n_slices = (uint32_t)slices.size(); p.start_sample = start_sample;
         p.hist_pad = hist_pad; p.wave_bytes = wave_bytes;
         p.report = d_report; p.n_kmers = d_n_kmers; p.partial = d_partial.p;
