@@ -13,69 +13,78 @@ extern "C" {
 // LDS layout of k_readid (bytes_kernel = false) or k_readid_bytes for reads of at most max_bytes bases / max_win windows;
 // returns the bytes one wave needs (the kernels carve the same regions in the same order)
 static size_t readid_layout(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
-                            bool bytes_kernel, cid::ReadIdParams &p, int slot_kind = 0 /* 0: key + index, 1: one u64, 2: one u32 position */) {
+                            bool bytes_kernel, cid::ReadIdParams *pp, int slot_kind = 0 /* 0: key + index, 1: one u64, 2: one u32 position */) {
+    // (pp == NULL: only the size is wanted — the routing asks once per read, and clearing a parameter block per question cost a
+    // millisecond per hundred thousand reads)
     const bool packed_table = slot_kind == 1;
-    p = cid::ReadIdParams{};
-    p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
-    p.mod = ix->mod;
-    p.stride_d = stride_d; p.start_sample = start_sample;
-    p.m_size = ix->m_size;
     if (max_bytes > (1ull << 30) || max_win > (1ull << 30)) return ~(size_t)0;
     const bool wide = ix->rs > 128;
-    p.bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
-    p.win_cap = (uint32_t)((max_win + 3) & ~3ull);
-    if (p.win_cap < 4) p.win_cap = 4;
-    p.hist_pad = wide ? 4u * ix->rs : ((ix->n_colors + 1 + 3) & ~3u);   // wide rows: AND word + sampled-colour set
-    p.table_slots = 64;
-    while (p.table_slots < p.win_cap + p.win_cap / 2) p.table_slots <<= 1;
+    const uint32_t bases_cap = (uint32_t)((max_bytes + 16 + 15) & ~15ull);
+    uint32_t win_cap = (uint32_t)((max_win + 3) & ~3ull);
+    if (win_cap < 4) win_cap = 4;
+    const uint32_t hist_pad = wide ? 4u * ix->rs : ((ix->n_colors + 1 + 3) & ~3u);   // wide rows: AND word + sampled-colour set
+    uint32_t table_slots = 64;
+    while (table_slots < win_cap + win_cap / 2) table_slots <<= 1;
     size_t slot_bytes = 12;
+    uint32_t idx_bits = 0;
     if (packed_table) {   // one u64 per slot: code << idx_bits | window index
         uint32_t ib = 1;
-        while ((1ull << ib) <= p.win_cap) ++ib;
+        while ((1ull << ib) <= win_cap) ++ib;
         if (2u * ix->k + ib > 63u) return ~(size_t)0;
-        p.idx_bits = ib;
+        idx_bits = ib;
         slot_bytes = 8;
     }
-    if (slot_kind == 2) { p.slot4 = 1; slot_bytes = 4; }
+    if (slot_kind == 2) slot_bytes = 4;
     const size_t chunk_rows = 4ull * cid::kWave * ix->n_hash;                     // one chunk's row numbers
-    const size_t rall_bytes = wide ? 0 : 4ull * p.win_cap * ix->n_hash;           // rows of the read's distinct k-mers (wide rows search chunk by chunk)
+    const size_t rall_bytes = wide ? 0 : 4ull * win_cap * ix->n_hash;             // rows of the read's distinct k-mers (wide rows search chunk by chunk)
     // k_readid keeps no byte image of the read, but the raw bases of the NEXT one (LDS-DMA, one 16-byte piece per lane)
-    p.stage_bytes = bytes_kernel ? 0u : std::min<uint32_t>(p.bases_cap, 16u * cid::kWave);
-    size_t wave_bytes = (bytes_kernel ? (size_t)p.bases_cap : (size_t)p.stage_bytes) + rall_bytes;
+    const uint32_t stage_bytes = bytes_kernel ? 0u : std::min<uint32_t>(bases_cap, 16u * cid::kWave);
+    size_t wave_bytes = (bytes_kernel ? (size_t)bases_cap : (size_t)stage_bytes) + rall_bytes;
     if (bytes_kernel)   // histogram, tags, window infos, k-mer image (+ minimizer image and the distinct minimizer strings)
-        wave_bytes += 4ull * p.hist_pad + chunk_rows + 8ull * p.win_cap + cid::kmer_img_bytes(ix->k) +
-                      (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)p.win_cap * ix->m_size + 15) & ~15ull) : 0);
+        wave_bytes += 4ull * hist_pad + chunk_rows + 8ull * win_cap + cid::kmer_img_bytes(ix->k) +
+                      (ix->m_size ? cid::kmer_img_bytes(ix->m_size) + (((size_t)win_cap * ix->m_size + 15) & ~15ull) : 0);
     else if (wide)      // chunk rows, histogram, hash table keys + indices, 2-bit bases, bad-base bits
-        wave_bytes += chunk_rows + 4ull * p.hist_pad + 12ull * p.table_slots + 4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
+        wave_bytes += chunk_rows + 4ull * hist_pad + 12ull * table_slots + 4ull * (bases_cap / 16 + 4) + 4ull * (bases_cap / 32 + 4);
     else                // the histogram shares the hash table's region (k_readid)
-        wave_bytes += (CID_READID_ALIAS ? std::max<size_t>(slot_bytes * p.table_slots, 4ull * p.hist_pad) : slot_bytes * p.table_slots + 4ull * p.hist_pad) +
-                      4ull * (p.bases_cap / 16 + 4) + 4ull * (p.bases_cap / 32 + 4);
+        wave_bytes += (CID_READID_ALIAS ? std::max<size_t>(slot_bytes * table_slots, 4ull * hist_pad) : slot_bytes * table_slots + 4ull * hist_pad) +
+                      4ull * (bases_cap / 16 + 4) + 4ull * (bases_cap / 32 + 4);
     wave_bytes = (wave_bytes + 15) & ~15ull;
-    p.wave_bytes = (uint32_t)(wave_bytes < 0xFFFFFFF0ull ? wave_bytes : 0xFFFFFFF0ull);
+    if (pp) {
+        cid::ReadIdParams &p = *pp;
+        p = cid::ReadIdParams{};
+        p.mat = ix->mat; p.rs = ix->rs; p.w64 = ix->w64; p.n_colors = ix->n_colors; p.n_hash = ix->n_hash; p.k = ix->k;
+        p.mod = ix->mod;
+        p.stride_d = stride_d; p.start_sample = start_sample;
+        p.m_size = ix->m_size;
+        p.bases_cap = bases_cap; p.win_cap = win_cap; p.hist_pad = hist_pad; p.table_slots = table_slots; p.idx_bits = idx_bits;
+        p.slot4 = slot_kind == 2 ? 1u : 0u;
+        p.stage_bytes = stage_bytes;
+        p.wave_bytes = (uint32_t)(wave_bytes < 0xFFFFFFF0ull ? wave_bytes : 0xFFFFFFF0ull);
+    }
     return wave_bytes;
 }
 // what a read needs of the LDS kernels: k <= 32 reads may end up in either of them
 static size_t readid_need(const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win) {
-    cid::ReadIdParams p;
-    const size_t b = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, true, p);
+    const size_t b = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, true, nullptr);
     if (ix->k > 32) return b;
-    const size_t a = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, false, p);
+    const size_t a = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, false, nullptr);
     return a > b ? a : b;
 }
 
 constexpr size_t kLdsBytes = 160u * 1024u;
 // device scratch for dense read_id report rows per launch: cid_readid_count slices larger batches, the sparse form refuses them
 static size_t kDenseReportBytes = getenv("CID_DENSE_REPORT_BYTES") ? strtoull(getenv("CID_DENSE_REPORT_BYTES"), nullptr, 10) : (2ull << 30);
-// k_readid keeps a read's set in one wave's LDS.  With fewer than two waves per workgroup (one per CU) the gathers are no
-// longer hidden and the sort-based path is faster (tools/bench_readlen.py: 150 Mbases of 4 kb reads 50.7 vs 24.5 ms; 2 kb
-// reads, two waves, 30.3 vs 36.7 ms), so such reads are routed there.
-constexpr size_t kLdsReadBytesMax = kLdsBytes / 2;
+// k_readid keeps a read's set in one wave's LDS.  With fewer than five waves per CU its gathers are no longer hidden and the long-read
+// path (cid_readlong.hip) is faster: 150 Mbases resident, configs[2]'s index, ms per call k_readid / long path (tools/exp_readlen_route.py,
+// profiles/r05_readlen_route.jsonl): 600 bases 6.6 / 11.2, 800 bases (five waves) 8.8 / 10.4, 1000 bases (four waves) 13.0 / 10.0,
+// 2600 bases 25.0 / 8.3.  (Round 1's sorting path took 20 ms whatever the length: the rule then was "fewer than two waves".)
+constexpr size_t kLdsReadBytesMax = kLdsBytes / 5;
 
 static int readid_params(const cid_ctx *c, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
                          bool bytes_kernel, cid::ReadIdParams &p, int &waves, bool striped = false) {
     size_t wave_bytes = 0, best = 0;
     auto choose = [&](int slot_kind) {
-        wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, p, slot_kind);
+        wave_bytes = readid_layout(ix, stride_d, start_sample, max_bytes, max_win, bytes_kernel, &p, slot_kind);
         // waves per workgroup: whatever puts the most waves on a CU (160 KiB of LDS, at most 8 workgroups of this size... 32 waves)
         waves = 1;
         best = 0;
@@ -251,7 +260,7 @@ struct ReadRoute {
     uint64_t max_bytes = 0, max_win = 0;
     size_t n_long = 0;
 };
-static int readid_route(const cid_index *ix, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
+static int readid_route(const cid_ctx *c, const cid_index *ix, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
                         uint32_t start_sample, ReadRoute &rr) {
     auto read_size = [&](size_t r, uint64_t &bytes, uint64_t &win) {
         const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
@@ -273,16 +282,21 @@ static int readid_route(const cid_index *ix, const uint64_t *seq_off, size_t n_s
         if (bytes > max_bytes) max_bytes = bytes;
         if (win > max_win) max_win = win;
     }
-    // routing: reads whose set would leave k_readid fewer than two waves per workgroup go through the sort-based path
+    // routing: reads whose set would leave k_readid fewer than two waves per workgroup take the long-read path (cid_readlong.hip);
+    // cid_ctx_tune "readid_long_from" = L: every read of at least L bases does (measurements)
     rr.route.clear();
     rr.n_long = 0;
-    if (readid_need(ix, stride_d, start_sample, max_bytes, max_win) > kLdsReadBytesMax) {
+    const long from = c->tune.readid_long_from;
+    auto is_long = [&](uint64_t bytes, uint64_t win) {
+        return from >= 0 ? bytes >= (uint64_t)from : readid_need(ix, stride_d, start_sample, bytes, win) > kLdsReadBytesMax;
+    };
+    if (is_long(max_bytes, max_win)) {
         rr.route.assign(n_reads, 0);
         max_bytes = max_win = 0;
         for (size_t r = 0; r < n_reads; ++r) {
             uint64_t bytes, win;
             read_size(r, bytes, win);
-            if (readid_need(ix, stride_d, start_sample, bytes, win) > kLdsReadBytesMax) { rr.route[r] = 1; ++rr.n_long; }
+            if (is_long(bytes, win)) { rr.route[r] = 1; ++rr.n_long; }
             else {
                 if (bytes > max_bytes) max_bytes = bytes;
                 if (win > max_win) max_win = win;
@@ -336,7 +350,7 @@ static int readid_stripe_pass(cid_ctx *c, const cid_index *ix, const uint8_t *d_
     if (read_seq0[n_reads] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs");
     if (seq_off[n_seqs] && !d_bases) return fail(CID_ERR_INVALID, "null bases");
     ReadRoute rr;
-    if ((rc = readid_route(ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
+    if ((rc = readid_route(c, ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
     std::vector<uint64_t> zs;
     if ((rc = stripe_mask_starts(ix->k, stride_d, seq_off, n_seqs, read_seq0, n_reads, zs))) return rc;
     if (zs[n_reads] >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
@@ -407,7 +421,7 @@ static int readid_resident(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
                            uint32_t *d_rep, uint32_t *d_nk, uint8_t *d_status) {
     int rc;
     ReadRoute rr;
-    if ((rc = readid_route(ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
+    if ((rc = readid_route(c, ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
     const std::vector<uint8_t> &route = rr.route;
     const size_t n_long = rr.n_long;
     const bool all_long = n_long == n_reads, mixed = n_long > 0 && !all_long;

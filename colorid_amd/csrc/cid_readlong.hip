@@ -56,7 +56,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
     extern __shared__ uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
     __shared__ int s_over;
     uint32_t *bm = table + slots;
-    const uint32_t mask = slots - 1, bm_bits = bm_words * 32u;
+    const uint32_t max_slots = slots, bm_bits = bm_words * 32u;
     const uint32_t chunk = (n_items + 7u) / 8u;
     for (uint32_t it = blockIdx.x >> 3; it < chunk; it += gridDim.x >> 3) {
         const uint32_t item = (blockIdx.x & 7u) * chunk + it;
@@ -65,6 +65,10 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
         const uint64_t w0 = wstart[im.read];
         const uint32_t nw = (uint32_t)(wend[im.read] - w0);   // (wstart[read + 1] lies beyond the padding)
         const uint64_t *rc = codes + w0;
+        // a short read takes a corner of the table: clearing and sweeping it is what a pass costs beyond its inserts
+        slots = 1024;
+        while (slots < max_slots && slots < 2u * nw) slots <<= 1;
+        const uint32_t mask = slots - 1;
         uint32_t level = 0;
         for (uint32_t sub = 0; sub < (1u << level); ++sub) {
             for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) table[s] = kLongEmpty;
@@ -227,52 +231,62 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     if (n_reads >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "more than 2^31 reads in one batch");
     const size_t C1 = (size_t)C + 1;
     const uint64_t n_words = W / 32 + 1;   // (rank(W) reads the word after the last window's)
-    DevBuf<uint64_t> d_wstart(c), d_wend(c), d_codes(c), d_list(c), d_lstart(c), d_scan(c);
+    // the host-made arrays travel as ONE block, before the first kernel, through the ctx's pinned arena when they fit: a copy out of
+    // pageable memory makes the runtime wait for the stream, and one issued between two kernels stalls the launch of the second
+    struct Part { const void *src; size_t bytes, off; };
+    Part parts[7] = {{wstart.data(), (n_reads + 1) * 8, 0}, {wend.data(), n_reads * 8, 0}, {segs.data(), segs.size() * sizeof(Segment), 0},
+                     {items_small.data(), items_small.size() * sizeof(LongItem), 0}, {items_big.data(), items_big.size() * sizeof(LongItem), 0},
+                     {slices.data(), slices.size() * sizeof(ReadSlice), 0}, {combs.data(), combs.size() * sizeof(ReadCombine), 0}};
+    size_t meta_bytes = (n_reads + 15) & ~(size_t)15;   // the status bytes lead the block
+    for (Part &pt : parts) { pt.off = meta_bytes; meta_bytes += (pt.bytes + 15) & ~(size_t)15; }
+    DevBuf<uint64_t> d_codes(c), d_list(c), d_lstart(c), d_scan(c);
     DevBuf<uint32_t> d_bitmap(c), d_prefix(c), d_partial(c);
-    DevBuf<Segment> d_segs(c);
-    DevBuf<LongItem> d_items(c);
-    DevBuf<ReadSlice> d_slices(c);
-    DevBuf<ReadCombine> d_combs(c);
+    DevBuf<uint8_t> d_meta(c);
     DevBuf<int> d_flags(c);
     int rc;
-    const size_t n_items = items_small.size() + items_big.size();
-    if ((rc = d_wstart.alloc(n_reads + 1)) || (rc = d_wend.alloc(n_reads)) || (rc = d_codes.alloc(W + 1)) ||
-        (rc = d_scan.alloc(scan_state_words(n_words))) || (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
-        (rc = d_segs.alloc(segs.size())) || (rc = d_items.alloc(n_items)) || (rc = d_slices.alloc(slices.size())) ||
-        (rc = d_combs.alloc(combs.size())) || (rc = d_partial.alloc(combs.empty() ? 1 : slices.size() * (C1 + 1))) || (rc = d_flags.alloc(4)))
+    if ((rc = d_meta.alloc(meta_bytes + 16)) || (rc = d_codes.alloc(W + 1)) || (rc = d_scan.alloc(scan_state_words(n_words))) ||
+        (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
+        (rc = d_partial.alloc(combs.empty() ? 1 : slices.size() * (C1 + 1))) || (rc = d_flags.alloc(4)))
         return rc;
-    HIP_TRY(hipMemcpyAsync(d_status, status.data(), n_reads, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_wstart.p, wstart.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_wend.p, wend.data(), n_reads * 8, hipMemcpyHostToDevice, st));
+    const uint64_t *d_wstart = reinterpret_cast<const uint64_t *>(d_meta.p + parts[0].off), *d_wend = reinterpret_cast<const uint64_t *>(d_meta.p + parts[1].off);
+    const Segment *d_segs = reinterpret_cast<const Segment *>(d_meta.p + parts[2].off);
+    const LongItem *d_items_small = reinterpret_cast<const LongItem *>(d_meta.p + parts[3].off), *d_items_big = reinterpret_cast<const LongItem *>(d_meta.p + parts[4].off);
+    const ReadSlice *d_slices = reinterpret_cast<const ReadSlice *>(d_meta.p + parts[5].off);
+    const ReadCombine *d_combs = reinterpret_cast<const ReadCombine *>(d_meta.p + parts[6].off);
+    if (uint8_t *pin = pin_reserve(c, meta_bytes + 64)) {
+        HIP_TRY(hipStreamSynchronize(st));   // (the arena may still feed an earlier copy)
+        memcpy(pin, status.data(), n_reads);
+        for (const Part &pt : parts) if (pt.bytes) memcpy(pin + pt.off, pt.src, pt.bytes);
+        HIP_TRY(hipMemcpyAsync(d_meta.p, pin, meta_bytes, hipMemcpyHostToDevice, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_meta.p, status.data(), n_reads, hipMemcpyHostToDevice, st));
+        for (const Part &pt : parts) if (pt.bytes) HIP_TRY(hipMemcpyAsync(d_meta.p + pt.off, pt.src, pt.bytes, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(d_status, d_meta.p, n_reads, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(d_flags.p, 0, 16, st));
     HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, n_words * 4, st));
     int h_flags[4] = {0, 0, 0, 0};
     if (W) {
-        HIP_TRY(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice, st));
-        if (!items_small.empty())
-            HIP_TRY(hipMemcpyAsync(d_items.p, items_small.data(), items_small.size() * sizeof(LongItem), hipMemcpyHostToDevice, st));
-        if (!items_big.empty())
-            HIP_TRY(hipMemcpyAsync(d_items.p + items_small.size(), items_big.data(), items_big.size() * sizeof(LongItem), hipMemcpyHostToDevice, st));
         constexpr uint32_t kBytes = kSegWindows + 32 + 96;
         const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
         unsigned grid = (unsigned)((segs.size() + 3) / 4);
         if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel_k, d_codes.p,
+        hipLaunchKernelGGL(k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, d_bases, d_segs, (uint32_t)segs.size(), k, 1, sentinel_k, d_codes.p,
                            d_flags.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr, KeyFor{});
         if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
         const unsigned n_cu = (unsigned)ctx_n_cu(c);
         if (!items_small.empty()) {
             unsigned g = n_cu * 4u;   // four 32-KiB workgroups per CU
             g = (g + 7u) & ~7u;
-            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockSmall), (kLongSlotsSmall + kLongBmSmall) * 4, st, d_codes.p, d_wstart.p, d_wend.p, d_items.p,
+            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockSmall), (kLongSlotsSmall + kLongBmSmall) * 4, st, d_codes.p, d_wstart, d_wend, d_items_small,
                                (uint32_t)items_small.size(), sentinel, kLongSlotsSmall, kLongBmSmall, d_bitmap.p, d_flags.p);
         }
         if (!items_big.empty()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_first_flags), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)((kLongSlotsBig + kLongBmBig) * 4)));
             unsigned g = (n_cu + 7u) & ~7u;
-            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), (kLongSlotsBig + kLongBmBig) * 4, st, d_codes.p, d_wstart.p, d_wend.p,
-                               d_items.p + items_small.size(), (uint32_t)items_big.size(), sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p);
+            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), (kLongSlotsBig + kLongBmBig) * 4, st, d_codes.p, d_wstart, d_wend,
+                               d_items_big, (uint32_t)items_big.size(), sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p);
         }
         HIP_TRY(hipGetLastError());
         if (!own_search) {   // wide rows and stripe passes add into rows in place: what would send the batch to the sorting path (see the
@@ -287,7 +301,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     if (!own_search) {   // k_readid_list walks lists
         if ((rc = d_list.alloc(W + 1)) || (rc = d_lstart.alloc(n_reads + 1))) return rc;
         if (W) hipLaunchKernelGGL(k_long_scatter, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, d_bitmap.p, d_prefix.p, d_list.p, (uint64_t)W);
-        hipLaunchKernelGGL(k_long_list_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, d_wstart.p, d_bitmap.p, d_prefix.p, d_lstart.p,
+        hipLaunchKernelGGL(k_long_list_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, d_wstart, d_bitmap.p, d_prefix.p, d_lstart.p,
                            (uint32_t)n_reads);
         HIP_TRY(hipGetLastError());
     }
@@ -295,19 +309,17 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     const uint32_t wave_bytes = (uint32_t)((4ull * kWave * n_hash + 4ull * hist_pad + 15) & ~15ull);
     if ((size_t)(kBlock / kWave) * wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
     if (own_search) {
-        if (!slices.empty()) HIP_TRY(hipMemcpyAsync(d_slices.p, slices.data(), slices.size() * sizeof(ReadSlice), hipMemcpyHostToDevice, st));
-        if (!combs.empty()) HIP_TRY(hipMemcpyAsync(d_combs.p, combs.data(), combs.size() * sizeof(ReadCombine), hipMemcpyHostToDevice, st));
         ReadIdSliceParams p{};
         p.mat = index_matrix(ix); p.rs = rs; p.w64 = (C + 63) / 64; p.n_colors = C; p.n_hash = n_hash; p.k = key_len; p.mod = index_mod(ix);
-        p.codes = d_codes.p; p.wstart = d_wstart.p; p.wend = d_wend.p; p.bitmap = d_bitmap.p; p.word_prefix = d_prefix.p;
-        p.slices = d_slices.p; p.n_slices = (uint32_t)slices.size(); p.start_sample = start_sample;
+        p.codes = d_codes.p; p.wstart = d_wstart; p.wend = d_wend; p.bitmap = d_bitmap.p; p.word_prefix = d_prefix.p;
+        p.slices = d_slices; p.n_slices = (uint32_t)slices.size(); p.start_sample = start_sample;
         p.hist_pad = hist_pad; p.wave_bytes = wave_bytes;
         p.report = d_report; p.n_kmers = d_n_kmers; p.partial = d_partial.p;
         uint64_t grid = (slices.size() + 3) / 4;
         const uint64_t cap = (uint64_t)ctx_n_cu(c) * 32;
         if (grid > cap) grid = cap;
         HIP_TRY(launch_readid_slices(p, (int)grid, st));
-        HIP_TRY(launch_readid_combine(d_combs.p, (uint32_t)combs.size(), d_partial.p, C, d_report, st));
+        HIP_TRY(launch_readid_combine(d_combs, (uint32_t)combs.size(), d_partial.p, C, d_report, st));
         hipLaunchKernelGGL(k_long_short_rows, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, d_status, (uint32_t)n_reads, C, d_report, d_n_kmers);
         HIP_TRY(hipGetLastError());
     } else {
