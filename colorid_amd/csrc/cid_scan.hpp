@@ -24,39 +24,21 @@ __device__ __forceinline__ uint64_t scan_wave_sum(uint64_t v) {
     return v;
 }
 
-template <typename In, typename Out>
-__global__ __launch_bounds__(kScanBlock) void k_scan_lookback(In in, Out out, uint64_t n, uint64_t *state) {
-    __shared__ uint64_t s_wave[kScanBlock / 64];
-    __shared__ uint64_t s_tile, s_excl;
-    const uint64_t tiles = scan_tiles(n);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The ticket of this workgroup's tile (tiles are handed out in launch order: a tile's predecessors have all started).
+__device__ __forceinline__ uint64_t scan_ticket(uint64_t *state, uint64_t tiles) {
+    __shared__ uint64_t s_tile;
     if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<unsigned long long *>(&state[tiles]), 1ull);
     __syncthreads();
-    const uint64_t tile = s_tile;
-    if (tile >= tiles) return;
-    // blocked arrangement: thread t owns kScanPer consecutive elements
-    const uint64_t i0 = tile * kScanTile + (uint64_t)threadIdx.x * kScanPer;
-    uint64_t v[kScanPer], mine = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < kScanPer; ++j) {
-        v[j] = i0 + j < n ? in(i0 + j) : 0ull;
-        mine += v[j];
-    }
-    uint64_t inc = mine;   // inclusive scan over the wave's lanes
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t up = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += up;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    uint64_t wave_base = 0, tile_sum = 0;
-#pragma unroll
-    for (int w = 0; w < (int)(kScanBlock / 64); ++w) {
-        if (w < wave) wave_base += s_wave[w];
-        tile_sum += s_wave[w];
-    }
-    if (wave == 0) {   // publish the aggregate, look back, publish the inclusive prefix
+    return s_tile;
+}
+
+// The decoupled look-back of one tile, called by every thread of the workgroup with the tile's total: publishes the aggregate, sums the
+// predecessors' words 64 at a time until one carries an inclusive prefix, publishes the tile's own inclusive prefix; returns the tile's
+// exclusive prefix to every thread.  The last tile leaves the grand total in state[tiles + 1].
+__device__ __forceinline__ uint64_t scan_lookback_block(uint64_t *state, uint64_t tile, uint64_t tiles, uint64_t tile_sum) {
+    __shared__ uint64_t s_excl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
         uint64_t excl = 0;
         if (tile == 0) {
             if (lane == 0) __hip_atomic_store(&state[0], (2ull << 62) | (tile_sum & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -87,7 +69,47 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_lookback(In in, Out out, ui
         }
     }
     __syncthreads();
-    uint64_t run = s_excl + wave_base + (inc - mine);
+    return s_excl;
+}
+
+// Inclusive scan of one value per thread over the workgroup: returns this thread's exclusive prefix inside the tile, *tile_sum = the tile's total.
+__device__ __forceinline__ uint64_t scan_block_exclusive(uint64_t mine, uint64_t *tile_sum) {
+    __shared__ uint64_t s_wave[kScanBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < (int)(kScanBlock / 64); ++w) {
+        if (w < wave) wave_base += s_wave[w];
+        total += s_wave[w];
+    }
+    *tile_sum = total;
+    return wave_base + (inc - mine);
+}
+
+template <typename In, typename Out>
+__global__ __launch_bounds__(kScanBlock) void k_scan_lookback(In in, Out out, uint64_t n, uint64_t *state) {
+    const uint64_t tiles = scan_tiles(n);
+    const uint64_t tile = scan_ticket(state, tiles);
+    if (tile >= tiles) return;
+    // blocked arrangement: thread t owns kScanPer consecutive elements
+    const uint64_t i0 = tile * kScanTile + (uint64_t)threadIdx.x * kScanPer;
+    uint64_t v[kScanPer], mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kScanPer; ++j) {
+        v[j] = i0 + j < n ? in(i0 + j) : 0ull;
+        mine += v[j];
+    }
+    uint64_t tile_sum;
+    const uint64_t local = scan_block_exclusive(mine, &tile_sum);
+    uint64_t run = scan_lookback_block(state, tile, tiles, tile_sum) + local;
 #pragma unroll
     for (uint32_t j = 0; j < kScanPer; ++j) {
         if (i0 + j < n) out(i0 + j, run, v[j]);

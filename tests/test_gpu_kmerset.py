@@ -189,9 +189,13 @@ def test_byte_string_sets_k_above_32(orc, hip_ctx, k):
     ks.close()
 
 
-def test_incremental_merge_path(orc, hip_ctx, monkeypatch):
+@pytest.mark.parametrize("cold_sort", [False, True])
+def test_incremental_merge_path(orc, hip_ctx, monkeypatch, cold_sort):
+    """later batches are merged into the set (cid_kmerset_cold.hip); cold_sort: the batches themselves through the LSD sorts there too"""
     import colorid_amd
     monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "20000")   # force sort-pairs + reduce-by-key merges
+    if cold_sort:
+        monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1000000000")
     rng = np.random.default_rng(3)
     genome = rand_seq(rng, 30000)
     batches = [[genome[s:s + 400] for s in rng.integers(0, len(genome) - 400, 200)] for _ in range(6)]
@@ -204,6 +208,29 @@ def test_incremental_merge_path(orc, hip_ctx, monkeypatch):
     assert ks.finalize() == len(want)
     assert ks.as_dict() == want.as_dict()
     assert want.counts().max() > 5
+    ks.close()
+
+
+def test_histogram_with_multiplicities_beyond_the_lds_bins(orc, hip_ctx):
+    """cid_kmerset_count_histogram: multiplicities below 4096 are counted in LDS, the rest listed — a 300-base unit read 9000 times"""
+    import colorid_amd
+    rng = np.random.default_rng(17)
+    unit, rare = rand_seq(rng, 300), rand_seq(rng, 5000)
+    ks = colorid_amd.KmerSet(hip_ctx, 21)
+    want = orc.Kmers(21)
+    seqs = [unit] * 9000 + [unit[:150]] * 700 + [rare]
+    for s in (unit, unit[:150], rare):
+        want.kmerize_vector(s, 1)
+    ks.add_seqs(seqs, 0)
+    assert ks.finalize() == len(want)
+    got = ks.as_dict()
+    assert max(got.values()) >= 9700
+    import collections
+    hist = collections.Counter(got.values())
+    vals, cnts = ks.histogram()
+    assert list(vals) == sorted(hist) and [int(c) for c in cnts] == [hist[v] for v in sorted(hist)]
+    ks.clean(4095)
+    assert len(ks) == sum(c for v, c in hist.items() if v > 4095) and all(v > 4095 for v in ks.as_dict().values())
     ks.close()
 
 

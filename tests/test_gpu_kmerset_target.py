@@ -81,9 +81,10 @@ def test_targeted_msd_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavo
     hx.close()
 
 
-def test_small_sets_take_the_two_lsd_sorts(orc, hip_ctx):
-    """below CID_KMERSET_MSD_MIN windows: sort by code, then stably by key"""
+def test_small_sets_take_the_two_lsd_sorts(orc, hip_ctx, monkeypatch):
+    """below CID_KMERSET_MSD_MIN windows (the cold path, cid_kmerset_cold.hip): sort by code, then stably by key"""
     import colorid_amd
+    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1000000000")
     rng = np.random.default_rng(5)
     g = rand_seq(rng, 5000)
     seqs = [g[s:s + 150] for s in rng.integers(0, len(g) - 150, 300)] + [rand_seq(rng, 700, b"ACGTN"), b"ACG"]
@@ -105,8 +106,7 @@ def test_small_sets_take_the_two_lsd_sorts(orc, hip_ctx):
 def test_incremental_merge_keeps_the_target_order(orc, hip_ctx, monkeypatch, msd):
     import colorid_amd
     monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "20000")   # a merge every few batches
-    if msd:
-        monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
+    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1" if msd else "1000000000")
     rng = np.random.default_rng(3)
     genome = rand_seq(rng, 30000)
     batches = [[genome[s:s + 400] for s in rng.integers(0, len(genome) - 400, 200)] for _ in range(6)]
