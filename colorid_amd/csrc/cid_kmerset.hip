@@ -333,7 +333,7 @@ int compact(cid_kmerset *ks) {
         } else {
             DevBuf<uint64_t> rle_state(ks->ctx);
             DevBuf<uint32_t> rle_tiles(ks->ctx);
-            if ((rc = rle_state.alloc(cid::scan_state_words(n_sorted))) || (rc = rle_tiles.alloc(3 * cid::scan_tiles(n_sorted)))) return rc;
+            if ((rc = rle_state.alloc(cid::rle_tiles(n_sorted) + 2)) || (rc = rle_tiles.alloc(3 * cid::rle_tiles(n_sorted)))) return rc;
             HIP_TRY(cid::rle_launch(in_order, (uint32_t)n_sorted, uniq.p, agg.p, rle_state.p, rle_tiles.p, d_count.p, st));
         }
         HIP_TRY(hipMemcpyAsync(&n_runs, d_count.p, 8, hipMemcpyDeviceToHost, st));
