@@ -71,6 +71,15 @@ int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, c
 int kmerset_assign_merged(cid_kmerset *ks, const uint64_t *d_codes_in, const uint32_t *d_counts_in, size_t total);
 // d_modes[c] = the most frequent multiplicity among the k-mers whose unique colour is c (ties -> the smallest; 0 = none); asynchronous
 int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes);
+// the same in two asynchronous steps (cid_reports.hip): after _begin d_modes holds the modes over the multiplicities below the table's
+// width and w->ovf_count[0] (device) the number of k-mers beyond it; _finish counts those in when there are any and frees w's arrays
+struct ModeWork {
+    uint64_t *ovf = nullptr;
+    unsigned long long *best = nullptr, *ovf_count = nullptr;
+    uint32_t C = 0;
+};
+int unique_freq_modes_begin(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes, ModeWork *w);
+int unique_freq_modes_finish(cid_ctx *c, ModeWork *w, unsigned long long n_ovf, uint64_t *d_modes);
 // sorted (colour << 32 | multiplicity) keys and their k-mer counts over the k-mers with a unique colour (host vectors; synchronous)
 int unique_freq_hist(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, std::vector<uint64_t> &keys, std::vector<uint32_t> &counts);
 int kmerset_view_ascii(const cid_kmerset *ks, cid_ctx **ctx, const uint8_t **ascii, const uint32_t **counts, uint64_t *n, uint32_t *k);   // k > 32 sets

@@ -501,11 +501,14 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         DevBuf<uint64_t> scan_state(c);
         if ((rc = scan_state.alloc(cid::scan_state_words(n_seqs)))) return rc;
         HIP_TRY(cid::scan_launch(U64In{d_win.p}, U64OutPlus{d_win.p, (uint64_t)ks->n_raw}, n_seqs, scan_state.p, st));   // where each read's codes go
-        const bool piped = st == cid::ctx_own_stream(c);     // a borrowed stream: keep everything on it
+        const bool piped = cid::ctx_copy_stream(c) != nullptr;   // (also beside a borrowed stream: the scratch is the ctx's own, events order the two streams)
         hipStream_t cs = piped ? cid::ctx_copy_stream(c) : st;
         hipEvent_t ev_scan = cid::ctx_event(c, 0), ev_done = cid::ctx_event(c, 1);
         if (piped) { HIP_TRY(hipEventRecord(ev_scan, st)); HIP_TRY(hipStreamWaitEvent(cs, ev_scan, 0)); }   // (d_bases may still be read by an earlier kernel of the ctx stream)
         static const uint64_t slice_bytes = (uint64_t)(getenv("CID_KMERSET_SLICE_MB") ? atoi(getenv("CID_KMERSET_SLICE_MB")) : 32) << 20;   // (experiments)
+        // (A ring of pinned slots filled by 2-8 helper threads, the DMA engine taking a slot as soon as it is full, was tried in round 5: 4.6-4.9 ms
+        // for the 150 MB of a million reads against 3.85 ms for these copies straight out of the caller's pageable memory — the host's memcpy
+        // is the slower pipe; profiles/HISTORY.md.)
         for (size_t s0 = 0; s0 < n_seqs;) {
             size_t s1 = s0;
             while (s1 < n_seqs && seq_off[s1] - seq_off[s0] < slice_bytes) ++s1;
@@ -793,17 +796,29 @@ int cid_search_count_set_report(cid_ctx *c, const cid_index *ix, const cid_kmers
     DevBuf<uint32_t> uc(ks->ctx);
     DevBuf<uint64_t> out(ks->ctx);
     int rc;
-    if ((rc = uc.alloc(ks->n)) || (rc = out.alloc((size_t)4 * C))) return rc;
+    if ((rc = uc.alloc(ks->n)) || (rc = out.alloc((size_t)4 * C + 2))) return rc;
     if (ks->general) rc = cid_search_count_dev(c, ix, ks->ascii, ks->counts, ks->n, out.p, out.p + C, out.p + 2 * C, uc.p);
     else rc = cid_search_count_codes_dev(c, ix, ks->codes, ks->counts, ks->n, out.p, out.p + C, out.p + 2 * C, uc.p);
     if (rc) return rc;
-    if ((rc = cid::unique_freq_modes(c, uc.p, ks->counts, ks->n, C, out.p + 3 * C))) return rc;
+    // ONE copy, ONE wait: the three counter arrays, the modes as they stand and the number of multiplicities the mode table did not hold
+    // come back together; only when there are such k-mers (deep coverage) a second step counts them in.  (Round 4: two waits, four copies.)
+    cid::ModeWork w;
+    if ((rc = cid::unique_freq_modes_begin(c, uc.p, ks->counts, ks->n, C, out.p + 3 * C, &w))) { (void)cid::unique_freq_modes_finish(c, &w, 0, out.p + 3 * C); return rc; }
     hipStream_t st = cid::ctx_stream(c);
-    HIP_TRY(hipMemcpyAsync(hits, out.p, (size_t)C * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(n_unique, out.p + C, (size_t)C * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(sum_unique_freq, out.p + 2 * C, (size_t)C * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(mode_unique_freq, out.p + 3 * C, (size_t)C * 8, hipMemcpyDeviceToHost, st));
+    std::vector<uint64_t> h((size_t)4 * C + 1);
+    HIP_TRY(hipMemcpyAsync(out.p + 4 * C, w.ovf_count, 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h.data(), out.p, ((size_t)4 * C + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const unsigned long long n_ovf = h[(size_t)4 * C];
+    if ((rc = cid::unique_freq_modes_finish(c, &w, n_ovf, out.p + 3 * C))) return rc;
+    if (n_ovf) {
+        HIP_TRY(hipMemcpyAsync(h.data() + 3 * (size_t)C, out.p + 3 * C, (size_t)C * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    memcpy(hits, h.data(), (size_t)C * 8);
+    memcpy(n_unique, h.data() + C, (size_t)C * 8);
+    memcpy(sum_unique_freq, h.data() + 2 * (size_t)C, (size_t)C * 8);
+    memcpy(mode_unique_freq, h.data() + 3 * (size_t)C, (size_t)C * 8);
     return CID_OK;
 }
 

@@ -78,47 +78,81 @@ __global__ void k_mode_final(const unsigned long long *best, uint32_t C, uint64_
     if (c < C) modes[c] = best[c] ? (uint64_t)(0xFFFFFFFFu - (uint32_t)best[c]) : 0ull;
 }
 
-int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes) {
+// begin: the table pass and the modes as they stand WITHOUT the multiplicities of FL and more (those are listed in w->ovf, their number
+// lands in w->ovf_count[0]); finish: counts the listed ones in (a sort: rocPRIM) when there are any, and frees the work arrays.  Both are
+// asynchronous: a caller fetches the number of listed entries together with its other results and waits ONCE when there are none.
+int unique_freq_modes_begin(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes, ModeWork *w) {
     hipStream_t st = ctx_stream(c);
-    if (n == 0) { HIP_TRY(hipMemsetAsync(d_modes, 0, (size_t)C * 8, st)); return CID_OK; }
+    *w = ModeWork{};
+    w->C = C;
     if (n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mers");
     uint32_t FL = 64;
     while (FL > 1 && (uint64_t)C * FL > 16384) FL >>= 1;     // the per-workgroup table: at most 64 KiB of LDS
     if ((uint64_t)C * FL > 16384) FL = 0;                     // very many colours: every (colour, f) goes through the sort
-    DevBuf<uint32_t> table(c), runs(c);
-    DevBuf<uint64_t> ovf(c), keys_sorted(c), keys_u(c), n_runs(c);
+    DevBuf<uint32_t> table(c);
+    DevBuf<uint64_t> ovf(c);
     DevBuf<unsigned long long> best(c), ovf_count(c);
     int rc;
-    if ((rc = table.alloc((size_t)C * (FL ? FL : 1))) || (rc = ovf.alloc(n)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2))
-        || (rc = n_runs.alloc(1))) return rc;
+    if ((rc = table.alloc((size_t)C * (FL ? FL : 1))) || (rc = ovf.alloc(n ? n : 1)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2))) return rc;
     HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)C * (FL ? FL : 1) * 4, st));
     HIP_TRY(hipMemsetAsync(best.p, 0, (size_t)C * 8, st));
     HIP_TRY(hipMemsetAsync(ovf_count.p, 0, 16, st));
-    const unsigned blocks = 1024;
-    uint64_t per_block = (n + blocks - 1) / blocks;
-    per_block = (per_block + 255) / 256 * 256;
-    const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
-    const size_t shmem = (size_t)C * FL * 4;
-    if (shmem > 64 * 1024) return fail(CID_ERR_UNSUPPORTED, "mode table");
-    hipLaunchKernelGGL(k_mode_hist, dim3(grid), dim3(256), shmem, st, d_uc, d_freq, n, C, FL, per_block, table.p, ovf.p, ovf_count.p);
-    if (FL) hipLaunchKernelGGL(k_mode_pick_table, dim3((C * FL + 255) / 256), dim3(256), 0, st, table.p, C, FL, best.p);
-    unsigned long long n_ovf = 0;
-    HIP_TRY(hipMemcpyAsync(&n_ovf, ovf_count.p, 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (n_ovf) {
-        if ((rc = keys_sorted.alloc(n_ovf)) || (rc = keys_u.alloc(n_ovf)) || (rc = runs.alloc(n_ovf))) return rc;
-        size_t tb = 0, tb2 = 0;
-        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, ovf.p, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st));
-        HIP_TRY(rocprim::run_length_encode(nullptr, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st));
-        DevBuf<uint8_t> tmp(c);
-        if ((rc = tmp.alloc(tb > tb2 ? tb : tb2))) return rc;
-        HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, ovf.p, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st));
-        HIP_TRY(rocprim::run_length_encode(tmp.p, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st));
-        hipLaunchKernelGGL(k_mode_pick_runs, dim3(grid_for_n(n_ovf)), dim3(256), 0, st, keys_u.p, runs.p, n_runs.p, best.p);
+    if (n) {
+        const unsigned blocks = 1024;
+        uint64_t per_block = (n + blocks - 1) / blocks;
+        per_block = (per_block + 255) / 256 * 256;
+        const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
+        const size_t shmem = (size_t)C * FL * 4;
+        if (shmem > 64 * 1024) return fail(CID_ERR_UNSUPPORTED, "mode table");
+        hipLaunchKernelGGL(k_mode_hist, dim3(grid), dim3(256), shmem, st, d_uc, d_freq, n, C, FL, per_block, table.p, ovf.p, ovf_count.p);
+        if (FL) hipLaunchKernelGGL(k_mode_pick_table, dim3((C * FL + 255) / 256), dim3(256), 0, st, table.p, C, FL, best.p);
     }
     hipLaunchKernelGGL(k_mode_final, dim3((C + 255) / 256), dim3(256), 0, st, best.p, C, d_modes);
-    HIP_TRY(hipStreamSynchronize(st));   // the scratch goes out of scope
-    return CID_OK;
+    HIP_TRY(hipGetLastError());
+    w->ovf = ovf.release(); w->best = best.release(); w->ovf_count = ovf_count.release();
+    return CID_OK;   // (the table goes back to the ctx's block cache: later work on the stream is ordered behind its readers)
+}
+
+int unique_freq_modes_finish(cid_ctx *c, ModeWork *w, unsigned long long n_ovf, uint64_t *d_modes) {
+    hipStream_t st = ctx_stream(c);
+    int rc = CID_OK;
+    if (n_ovf) {
+        DevBuf<uint32_t> runs(c);
+        DevBuf<uint64_t> keys_sorted(c), keys_u(c), n_runs(c);
+        DevBuf<uint8_t> tmp(c);
+        size_t tb = 0, tb2 = 0;
+        if ((rc = keys_sorted.alloc(n_ovf)) || (rc = keys_u.alloc(n_ovf)) || (rc = runs.alloc(n_ovf)) || (rc = n_runs.alloc(1))) goto out;
+        if (rocprim::radix_sort_keys(nullptr, tb, w->ovf, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st) != hipSuccess ||
+            rocprim::run_length_encode(nullptr, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st) != hipSuccess) {
+            rc = fail(CID_ERR_HIP, "rocprim size query");
+            goto out;
+        }
+        if ((rc = tmp.alloc(tb > tb2 ? tb : tb2))) goto out;
+        if (rocprim::radix_sort_keys(tmp.p, tb, w->ovf, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st) != hipSuccess ||
+            rocprim::run_length_encode(tmp.p, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st) != hipSuccess) {
+            rc = fail(CID_ERR_HIP, "rocprim sort / run-length");
+            goto out;
+        }
+        hipLaunchKernelGGL(k_mode_pick_runs, dim3(grid_for_n(n_ovf)), dim3(256), 0, st, keys_u.p, runs.p, n_runs.p, w->best);
+        hipLaunchKernelGGL(k_mode_final, dim3((w->C + 255) / 256), dim3(256), 0, st, w->best, w->C, d_modes);
+        if (hipGetLastError() != hipSuccess) rc = fail(CID_ERR_HIP, "mode kernels");
+    }
+out:
+    if (w->ovf) ctx_free(c, w->ovf);
+    if (w->best) ctx_free(c, w->best);
+    if (w->ovf_count) ctx_free(c, w->ovf_count);
+    *w = ModeWork{};
+    return rc;
+}
+
+int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, uint64_t n, uint32_t C, uint64_t *d_modes) {
+    ModeWork w;
+    int rc = unique_freq_modes_begin(c, d_uc, d_freq, n, C, d_modes, &w);
+    if (rc) { (void)unique_freq_modes_finish(c, &w, 0, d_modes); return rc; }
+    unsigned long long n_ovf = 0;
+    HIP_TRY(hipMemcpyAsync(&n_ovf, w.ovf_count, 8, hipMemcpyDeviceToHost, ctx_stream(c)));
+    HIP_TRY(hipStreamSynchronize(ctx_stream(c)));
+    return unique_freq_modes_finish(c, &w, n_ovf, d_modes);
 }
 
 }  // namespace cid
