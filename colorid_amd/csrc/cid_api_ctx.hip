@@ -168,6 +168,7 @@ int cid_ctx_create(int device_id, cid_ctx **out) {
     if (const char *e = getenv("CID_SEARCH_UNROLL")) c->tune.search_unroll = atoi(e) == 1 ? 1 : 2;
     if (const char *e = getenv("CID_READID_PACKED_TABLE")) c->tune.readid_packed_table = atoi(e) != 0;
     if (const char *e = getenv("CID_READID_LONG_LDS")) c->tune.readid_long_lds = atoi(e) != 0;
+    if (const char *e = getenv("CID_FASTQ_REFUSE_AT_STEP")) c->tune.fastq_refuse_at_step = atol(e);
 #ifdef CID_TUNE_BUILD
     if (const char *e = getenv("CID_SEARCH_PERSIST")) c->tune.search_persist = atoi(e) != 0;
     if (const char *e = getenv("CID_SEARCH_MIXED")) c->tune.search_mixed = atoi(e) != 0;
@@ -245,6 +246,7 @@ int cid_ctx_tune(cid_ctx *c, const char *name, long value) {
         return CID_OK;
     }
     if (!strcmp(name, "readid_packed_table")) { c->tune.readid_packed_table = value != 0; return CID_OK; }
+    if (!strcmp(name, "fastq_refuse_at_step")) { c->tune.fastq_refuse_at_step = value; return CID_OK; }
     if (!strcmp(name, "readid_long_from")) { c->tune.readid_long_from = value; return CID_OK; }
     if (!strcmp(name, "readid_long_lds")) { c->tune.readid_long_lds = value != 0; return CID_OK; }
     if (!strcmp(name, "readid_blocks_per_cu")) {

@@ -204,6 +204,7 @@ hipError_t warm_fastq() {
 struct cid_fastq {
     cid_ctx *ctx = nullptr;
     int n_files = 1;
+    uint64_t n_classify_steps = 0;
     uint32_t quality = 0;
     // block-gzip pushes are inflated on a stream of their own, ahead of the classification of the stretch before: a stream of
     // DEFLATE is decoded serially (one lane), so a launch takes ~14 ms however few members it holds — time the other stream fills
@@ -719,6 +720,11 @@ int cid_fastq_classify(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, ui
 
 int cid_fastq_classify_begin(cid_fastq *fq, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, int max_pushes) {
     if (!fq || !ix) return fail(CID_ERR_INVALID, "null argument");
+    if (fq->ctx->tune.fastq_refuse_at_step >= 0 && (long)fq->n_classify_steps == fq->ctx->tune.fastq_refuse_at_step) {   // (cid_ctx_tune: tests of the callers' way out)
+        ++fq->n_classify_steps;
+        return fail(CID_ERR_UNSUPPORTED, "cid_ctx_tune fastq_refuse_at_step: this step is refused");
+    }
+    ++fq->n_classify_steps;
     return fastq_begin(fq, ix, nullptr, ix->k, stride_d, start_sample, max_pushes);
 }
 

@@ -606,6 +606,9 @@ int cid_kmerset_set_target_index(cid_kmerset *ks, const cid_index *ix) {
     if (getenv("CID_KMERSET_TARGET") && atoi(getenv("CID_KMERSET_TARGET")) == 0) return CID_OK;   // A/B: the code-ordered set
     const cid::ModMagic mm = cid::index_mod(ix);
     if (mm.m >= 0xFFFFFFFFull) return CID_OK;     // the key needs bloom_size < 2^32 - 1 to stay below kNoKey: such a set keeps code order
+    // a small index: the keys take only bloom_size values, the partition's runs collapse to a few crowded ones (one LSD sort each, cold path),
+    // and an index of a megabyte sits in L2 whatever the order of the queries — such a set keeps code order too
+    if (mm.m < (1ull << 20) && !getenv("CID_KMERSET_TARGET_SMALL")) return CID_OK;
     ks->targeted = true;
     ks->key_for.mm = mm;
     ks->key_for.scale = 0xFFFFFFFF00000000ull / mm.m;

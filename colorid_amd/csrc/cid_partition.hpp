@@ -69,13 +69,16 @@ __device__ __forceinline__ PartTile part_tile(const uint32_t *seg_off, const uin
 // (same digit), so neighbouring tiles fill the same 128-byte lines.  Workgroups are dealt to the eight XCDs in turn (blockIdx & 7) and
 // every XCD has an L2 of its own: with tile = blockIdx (+ k * gridDim) those two halves of a line are always written through two
 // different L2s.  Here XCD x walks the x-th eighth of the tiles, its workgroups side by side on neighbouring tiles, so a line's halves
-// meet in one L2 and leave as one full-line write.  (gridDim.x must be a multiple of 8.)
+// meet in one L2 and leave as one full-line write.  (Grids that are not a multiple of 8 walk tile = blockIdx + k * gridDim.)
 struct XcdWalk {
-    uint32_t chunk;   // tiles per XCD
-    __device__ explicit XcdWalk(uint32_t n_tiles) : chunk((n_tiles + 7u) / 8u) {}
-    __device__ uint32_t first() const { return blockIdx.x >> 3; }
-    __device__ uint32_t stride() const { return gridDim.x >> 3; }
-    __device__ uint32_t tile(uint32_t it) const { return (blockIdx.x & 7u) * chunk + it; }
+    uint32_t chunk;   // tiles per XCD (n_tiles when the grid is not a multiple of 8: then every workgroup strides over all tiles)
+    bool split;
+    __device__ explicit XcdWalk(uint32_t n_tiles) : chunk((n_tiles + 7u) / 8u), split(gridDim.x >= 8u && (gridDim.x & 7u) == 0u) {
+        if (!split) chunk = n_tiles;   // (a grid of fewer than 8 workgroups would never advance; one that is not a multiple of 8 would visit tiles twice)
+    }
+    __device__ uint32_t first() const { return split ? blockIdx.x >> 3 : blockIdx.x; }
+    __device__ uint32_t stride() const { return split ? gridDim.x >> 3 : gridDim.x; }
+    __device__ uint32_t tile(uint32_t it) const { return split ? (blockIdx.x & 7u) * chunk + it : it; }
 };
 
 // `top` < 64: keys with a bit at or above `top` (the k-mer set's "no k-mer here" sentinel) are left out of the partition — counted

@@ -1,6 +1,7 @@
 // The reference's read_id drivers with the hot loop replaced by C-ABI calls:
 //   read_id_mt_pe::per_read_stream_se/_pe, stream_fasta (src/read_id_mt_pe.rs) -> cid_readid_count* / cid_fastq_*
 // plus the CPU-side tail (kmer_poll_plus, the counts file of src/reports.rs).  File formats follow the reference.
+#include <sys/stat.h>
 #include "drivers_common.hpp"
 #include <unistd.h>
 
@@ -385,6 +386,11 @@ class BatchClassifier {
 
 }  // namespace
 
+static void reset_read_id_timing() {
+    g_ms_gpu = g_ms_poll = g_ms_gpu_count = g_ms_write = 0;
+    g_entries = 0;
+    for (double &w : g_ms_wait) w = 0;
+}
 static void print_read_id_timing(const Clock::time_point &t0) {
     if (!g_timing) return;
     fprintf(stderr,
@@ -395,9 +401,7 @@ static void print_read_id_timing(const Clock::time_point &t0) {
             g_ms_write);
     fprintf(stderr, "timing: the input's decoding threads waited %.0f ms for the parser to take their blocks\n", LineReader::blocked_ms());
     // batch_id runs one stream per sample in the same process: the next one's line starts from zero
-    g_ms_gpu = g_ms_poll = g_ms_gpu_count = g_ms_write = 0;
-    g_entries = 0;
-    for (double &w : g_ms_wait) w = 0;
+    reset_read_id_timing();
 }
 
 // ---- block-gzip input through the device front end (cid_fastq_*): the members go up compressed — read from the file a stretch ahead by
@@ -509,11 +513,8 @@ FrontEnd classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &f
             const int rc = cid_fastq_classify_begin(fr, b.index, (uint32_t)d, (uint32_t)start_sample, 2);
             ms_classify += ms_since(tc);
             for (size_t i = 0; i < n_files; ++i) if (pending[i]) --pending[i];
-            const char *fail_at = getenv("COLORID_DEVICE_FASTQ_FAIL_AT_STEP");   // tests: the step that meets an input the device path refuses
-            const bool refused = rc == CID_ERR_UNSUPPORTED || (rc == CID_OK && fail_at && (size_t)atol(fail_at) == n_steps);
-            if (refused) {
-                fprintf(stderr, "note: %s — %s\n", rc == CID_OK ? "COLORID_DEVICE_FASTQ_FAIL_AT_STEP" : cid_last_error(),
-                        first ? "using the host front end" : "starting over with the host front end");
+            if (rc == CID_ERR_UNSUPPORTED) {   // (tests inject one through the library: cid_ctx_tune fastq_refuse_at_step / CID_FASTQ_REFUSE_AT_STEP)
+                fprintf(stderr, "note: %s — %s\n", cid_last_error(), first ? "using the host front end" : "starting over with the host front end");
                 cid_fastq_destroy(fr);
                 classifier.ids_stay_with_counted(false);
                 return first ? kFrontEndNotMine : kFrontEndRestart;
@@ -561,10 +562,16 @@ FrontEnd classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &f
     return kFrontEndDone;
 }
 
-// the rows written so far belong to a run that is being started over: an empty output again
+// the rows written so far belong to a run that is being started over: an empty output again, and the abandoned run's share of the
+// `timing:` lines forgotten.  An output that cannot be emptied (a FIFO, a character device: what was written is gone) ends the run.
 void empty_output(FILE *out) {
-    if (fflush(out) != 0 || ftruncate(fileno(out), 0) != 0) die("could not empty the outfile for the restart");
+    struct stat sb;
+    if (fflush(out) != 0 || fstat(fileno(out), &sb) != 0) die("could not empty the outfile for the restart");
+    if (!S_ISREG(sb.st_mode)) die("the device front end gave up mid-run and %s_reads.txt is not a regular file: rows already written cannot be taken back; "
+                                  "run again with COLORID_DEVICE_FASTQ=0", "<prefix>");
+    if (ftruncate(fileno(out), 0) != 0) die("could not empty the outfile for the restart");
     rewind(out);
+    reset_read_id_timing();
 }
 }  // namespace
 

@@ -5,6 +5,8 @@
 // the query is sharded over the GPUs), --hash xxh3_v08|xxh3_v07.  Extra command:
 // hashcheck (which hash variant was an index built with).
 // Minimizer indices (.mxi): build -m [-v M], info, read_id, batch_id.  Not provided (outside the query path): read_filter.
+#include <cctype>
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -17,6 +19,31 @@
 using namespace colorid;
 
 namespace {
+
+// Which way a run leaves is decided once, here, and `colorid --help` says how:
+//   COLORID_FAST_EXIT=1      always the short way;  COLORID_FAST_EXIT=0 or COLORID_FULL_TEARDOWN=1: always the orderly way;
+//   neither set              the short way unless something in the process may still have output to write at exit: a preloaded library
+//                            (LD_PRELOAD, /etc/ld.so.preload), a profiler's tool library (rocprofv3 writes its files from an exit handler),
+//                            coverage counters (LLVM_PROFILE_FILE, GCOV_PREFIX).
+// Either way every output file is closed and stdout / stderr are flushed — and checked — before (leave()).
+bool tool_may_write_at_exit() {
+    for (const char *v : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "LLVM_PROFILE_FILE", "GCOV_PREFIX"})
+        if (const char *e = getenv(v)) if (*e) return true;
+    if (FILE *f = fopen("/etc/ld.so.preload", "r")) {
+        int ch;
+        bool any = false;
+        while ((ch = fgetc(f)) != EOF) if (!isspace(ch)) { any = true; break; }
+        fclose(f);
+        if (any) return true;
+    }
+    return false;
+}
+bool decide_orderly_exit() {
+    if (const char *e = getenv("COLORID_FAST_EXIT")) return atoi(e) == 0;
+    return getenv("COLORID_FULL_TEARDOWN") != nullptr || tool_may_write_at_exit();
+}
+bool g_orderly_exit = decide_orderly_exit();
+
 
 struct Args {
     std::map<std::string, std::vector<std::string>> values;  // canonical long name -> values
@@ -152,6 +179,7 @@ Gpus make_gpus(const Args &a) {
     {
         StdoutToStderr quiet;
         if (cid_group_create(ids.data(), (int)ids.size(), &g.group) != CID_OK) die("cannot open %zu GPUs: %s", ids.size(), cid_last_error());
+        g_orderly_exit = true;   // (RCCL communicators are alive from here on: such a run always leaves through release())
     }
     if (cid_group_ctx(g.group, 0, &g.ctx) != CID_OK) die("%s", cid_last_error());
     int rccl = 0;
@@ -190,10 +218,6 @@ void replicate(Gpus &g, Bigsi &b) {   // after the index is loaded on rank 0
 // objects and the runtime's own teardown buy nothing — the driver reclaims a process's memory in one go — but cost 0.1-0.2 s of a
 // 0.7 s `read_id`.  One-GPU runs therefore skip release() and leave through leave(); COLORID_FULL_TEARDOWN=1 (the sanitizer runs,
 // anybody embedding the drivers) keeps the orderly way, and so do multi-GPU runs (RCCL communicators are shut down properly).
-// Under a profiler or any other preloaded tool (rocprofv3 preloads its tool library and writes its files from an exit handler) the
-// process leaves the orderly way too: an `_exit` would take the tool's output with it.
-bool g_orderly_exit = getenv("COLORID_FULL_TEARDOWN") != nullptr || getenv("LD_PRELOAD") != nullptr || getenv("ROCP_TOOL_LIBRARIES") != nullptr ||
-                      getenv("ROCPROFILER_LIBRARY_CTOR") != nullptr;
 
 void release(Gpus &g, Bigsi &b) {
     if (!g_orderly_exit && !g.group) { cid_ctx_synchronize(g.ctx); return; }
@@ -547,8 +571,12 @@ int cmd_debug_records(int argc, char **argv) {
 // the end of a subcommand: everything it printed leaves the stdio buffers, then the process ends without the teardown (see release())
 int leave(int rc) {
     phase_done("subcommand returned");
-    fflush(stdout);
-    fflush(stderr);
+    // a result that did not reach its pipe or disk is a failed run, whichever way the process leaves (EX_IOERR)
+    const bool lost = fflush(nullptr) != 0 || ferror(stdout);
+    if (lost) {
+        fprintf(stderr, "colorid: writing the output failed: %s\n", strerror(errno));
+        if (rc == 0) rc = 74;
+    }
     if (!g_orderly_exit) _exit(rc);
     return rc;
 }
@@ -563,6 +591,19 @@ int main(int argc, char **argv) {
         return 1;
     }
     const std::string cmd = argv[1];
+    if (cmd == "--help" || cmd == "-h" || cmd == "help") {
+        printf("colorid 0.1.4.3 (MI355X)\nUSAGE:\n    colorid <build|search|info|read_id|batch_id|hashcheck> [FLAGS]      (flags: colorid <subcommand> --help)\n\n"
+               "ENVIRONMENT:\n"
+               "    COLORID_FAST_EXIT=1      leave without the GPU runtime's teardown once the results are written, closed and flushed\n"
+               "                             (-0.05 to -0.15 s per run); =0, or COLORID_FULL_TEARDOWN=1: always the orderly exit\n"
+               "                             unset: the short way, unless a preloaded library, a profiler's tool library or coverage\n"
+               "                             counters are present (they write at exit) or several GPUs are in use (RCCL is shut down)\n"
+               "                             this run would leave: %s\n"
+               "    COLORID_INDEX_MMAP=0     read the index through a buffered reader instead of a mapping\n"
+               "    COLORID_DEVICE_FASTQ=0   FASTQ text on the host front end only\n",
+               g_orderly_exit ? "the orderly way" : "the short way");
+        return 0;
+    }
     if (cmd == "build") return leave(cmd_build(argc, argv));
     if (cmd == "search") return leave(cmd_search(argc, argv));
     if (cmd == "info") return leave(cmd_info(argc, argv));

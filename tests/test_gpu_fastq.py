@@ -335,7 +335,7 @@ def test_cli_read_id_device_front_end_gives_way_mid_run(orc, tmp_path, paired):
     """A stretch the device front end refuses (a read too long for the LDS kernels, a step over the dense-row limit) is not a hard
     failure: in the first step nothing has been written and the host front end takes over; in a LATER step the rows written so far are
     discarded and the whole input runs through the host front end — same _reads.txt / _counts.txt as COLORID_DEVICE_FASTQ=0.  The
-    refusal is injected (COLORID_DEVICE_FASTQ_FAIL_AT_STEP) at steps 0, 1 and 3 of a run of several stretches; R2 is shorter than R1."""
+    refusal is injected (CID_FASTQ_REFUSE_AT_STEP) at steps 0, 1 and 3 of a run of several stretches; R2 is shorter than R1."""
     import os
     import subprocess
 
@@ -355,9 +355,9 @@ def test_cli_read_id_device_front_end_gives_way_mid_run(orc, tmp_path, paired):
     q = [f1, f2] if paired else [f1]
     outs = {}
     for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {"COLORID_DEVICE_FASTQ_MB": "1"}),
-                     ("fail0", {"COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_FAIL_AT_STEP": "0"}),
-                     ("fail1", {"COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_FAIL_AT_STEP": "1"}),
-                     ("fail3", {"COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_FAIL_AT_STEP": "3", "COLORID_DEVICE_FASTQ_AHEAD": "2"})):
+                     ("fail0", {"COLORID_DEVICE_FASTQ_MB": "1", "CID_FASTQ_REFUSE_AT_STEP": "0"}),
+                     ("fail1", {"COLORID_DEVICE_FASTQ_MB": "1", "CID_FASTQ_REFUSE_AT_STEP": "1"}),
+                     ("fail3", {"COLORID_DEVICE_FASTQ_MB": "1", "CID_FASTQ_REFUSE_AT_STEP": "3", "COLORID_DEVICE_FASTQ_AHEAD": "2"})):
         name = str(tmp_path / tag)
         p = subprocess.run([BIN, "read_id", "-b", pre + ".bxi", "-q", *q, "-n", name], capture_output=True, text=True, env=dict(os.environ, COLORID_TIMING="1", **env))
         assert p.returncode == 0, (tag, p.stderr[-2000:])

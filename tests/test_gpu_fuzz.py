@@ -170,6 +170,7 @@ def test_kmerset_for_an_index_random_inputs(orc, hip_ctx, seed, monkeypatch):
     report as the code-ordered set."""
     import colorid_amd
     from util import random_index, to_hip_index
+    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")   # (by default a set for an index below 2^20 rows keeps code order)
     rng = np.random.default_rng(7000 + seed)
     k = int(rng.integers(1, 33))
     m = int(rng.choice([1, 2, 7, 64, 4001, 65_536, 1_000_003, (1 << 20) + 3, 50_000_017]))

@@ -25,6 +25,12 @@ def assert_target_order(orc, km, m):
     assert keys == sorted(keys)      # ascending (first-row key, code); code order == ASCII order for ACGT
 
 
+@pytest.fixture(autouse=True)
+def _small_indices_are_targeted_too(monkeypatch):
+    """the library leaves a set for an index below 2^20 rows in code order (nothing to gain, crowded runs); the tests' indices are small"""
+    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")
+
+
 def empty_index(hip_ctx, m, n_hash, k, n_colors=8):
     import colorid_amd
     hx = colorid_amd.Index(hip_ctx, m, n_hash, k, n_colors)
