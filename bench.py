@@ -138,6 +138,10 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="one rank stands in for W: the index holds all W shards' plants (or all W stripes) and the W shards are searched "
                          "one after the other into the same counters; the `counters` digest equals the W-rank run's (the N > 1 test)")
+    ap.add_argument("--scale-check", action="store_true",
+                    help="compare the run's `counters` digest with the one committed under tests/golden/scale_digests.json for this workload and "
+                         "this number of ranks (made by --emulate-world runs on one GPU, tools/make_scale_digests.py): the line gets a "
+                         "`scale_check` record and the exit code is 1 on a mismatch — the first thing to run on an N-GPU node")
     ap.add_argument("--only", default=None, help="profiling: run just this side record (readid_long) and print it as the JSON line")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if known")
@@ -376,6 +380,28 @@ def counters_digest(*tensors):
     return {"sha256": h.hexdigest(), "sums": sums}
 
 
+def workload_key(a):
+    """the parameters that decide the counters, as one string: the key of tests/golden/scale_digests.json"""
+    if a.placement == "striped":
+        return (f"striped:reads={a.reads}:len={a.read_len}:k={a.k}:colours={a.stripe_colours}:log2bloom={a.stripe_log2_bloom}:hashes={a.stripe_hashes}:"
+                f"err={a.error_rate}:density={a.density}")
+    return (f"replicated:reads={a.reads}:len={a.read_len}:bloom={a.bloom}:hashes={a.hashes}:k={a.k}:colours={a.colours}:genome={a.genome_len}:"
+            f"err={a.error_rate}:density={a.density}:codes={int(a.codes)}")
+
+
+def scale_check(a, n_ranks, counters):
+    """{"key", "ranks", "expected", "got", "ok"}: ok None = no digest is committed for this workload and rank count"""
+    rec = {"key": workload_key(a), "ranks": n_ranks, "got": counters["sha256"], "expected": None, "ok": None}
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "scale_digests.json")) as f:
+            rec["expected"] = json.load(f).get(rec["key"], {}).get(str(n_ranks))
+    except (OSError, ValueError):
+        pass
+    if rec["expected"] is not None:
+        rec["ok"] = rec["expected"] == rec["got"]
+    return rec
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD `torch.distributed.run` (this process has
     not touched the GPU: torch.cuda.device_count() does not initialise it), pass rank 0's JSON line through, return the exit code."""
@@ -423,7 +449,9 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
     kmers, freq, colour = make_reads_kmers(dev, 42, a.reads, a.read_len, k, C_total, a.error_rate)   # the same k-mers on every rank
     K = kmers.shape[0]
     held = []
+    setup_phases = {"kmers_s": round(time.time() - t_setup, 2), "stripes_s": []}
     for r in my_stripes:
+        t_stripe = time.time()
         hx = colorid_amd.Index(ctx, m, n, k, Cs)
         ptr, rs = hx.device_matrix()
         p_bg = fill_background_fast(dev, ptr, m, rs, Cs, a.density if a.density is not None else 1.0 - math.exp(-n * 5_000_000 / m), seed=7 + r)
@@ -434,6 +462,7 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
         ctx.synchronize()
         hx.finalize()
         held.append((hx, base))
+        setup_phases["stripes_s"].append(round(time.time() - t_stripe, 2))
         del mine
     del colour
     si = StripedIndex(ctx, held, C_total)
@@ -497,7 +526,7 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
                        "placement": "striped", "kmers": K, "bloom_size": m, "num_hash": n, "k_size": k, "n_colors_total": C_total,
                        "stripe_bytes": m * rs * 8, "background_density": p_bg,
                        "parallelism": f"colour stripes over {world} GPU(s); one all-reduce(SUM) of 4 B per k-mer + 8*C_total bytes per step",
-                       "collective_bytes_per_step": 4 * K + 8 * C_total, "setup_s": round(t_setup, 1), "consistent": bool(ok),
+                       "collective_bytes_per_step": 4 * K + 8 * C_total, "setup_s": round(t_setup, 1), "setup_phases": setup_phases, "consistent": bool(ok),
                        "backend": (dist.get_backend() if dist.is_initialized() else None), "emulate_world": a.emulate_world or None,
                        "total_kmers": K, "box": clocks},
             "counters": digest,
@@ -507,13 +536,17 @@ def bench_striped(a, json_out, world, rank, device_index, dev, ctx, stream):
             "cpu_baseline": None,
         }
         traffic_fields(result["roofline"], kern_ms, K, Cs, m, n, k, kernel="k_search_count_stripe")
+        if a.scale_check:
+            result["scale_check"] = scale_check(a, n_stripes, digest)
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
+        exit_code = 1 if a.scale_check and result["scale_check"]["ok"] is False else 0
     for hx, _ in held:
         hx.close()
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    return exit_code if rank == 0 else 0
 
 
 def main():
@@ -568,10 +601,13 @@ def main():
     ptr, rs = hx.device_matrix()
     p_bg = a.density if a.density is not None else 1.0 - math.exp(-n * a.genome_len / m)
     fill_background(dev, ptr, m, rs, C, p_bg, seed=7)
+    torch.cuda.synchronize()
+    setup_phases = {"background_s": round(time.time() - t_setup, 2), "shards_s": []}   # every rank plants ALL shards: N of these per rank
     n_shards = a.emulate_world or world
     my_shards = list(range(n_shards)) if a.emulate_world else [rank]
     shards = []                      # (ascii k-mers, multiplicities, 2-bit codes, planted colour) of the shards this rank searches
     for r in range(n_shards):  # the replicated index holds every shard's planted k-mers
+        t_shard = time.time()
         kk, ff, cc, codes = make_reads_kmers(dev, 42 + r, a.reads, a.read_len, k, C, a.error_rate, return_codes=True)
         torch.cuda.synchronize()
         hx.insert_kmers_dev(kk.data_ptr(), cc.data_ptr(), kk.shape[0])
@@ -579,6 +615,7 @@ def main():
         if r in my_shards:
             shards.append((kk, ff, codes, cc))
         del kk, ff, cc, codes
+        setup_phases["shards_s"].append(round(time.time() - t_shard, 2))
     hx.finalize()
     kmers, freq, codes, planted = shards[0]
     K = sum(sh[0].shape[0] for sh in shards)
@@ -656,7 +693,7 @@ def main():
                        "row_bytes": rs * 8, "index_bytes": m * rs * 8, "background_density": p_bg,
                        "parallelism": f"reads sharded over {world} GPU(s), index replicated, all-reduce(3C u64)",
                        "backend": (dist.get_backend() if dist.is_initialized() else None), "emulate_world": a.emulate_world or None,
-                       "total_kmers": total_kmers, "setup_s": round(t_setup, 1), "box": clocks},
+                       "total_kmers": total_kmers, "setup_s": round(t_setup, 1), "setup_phases": setup_phases, "box": clocks},
             "counters": counters_digest(final_counters[:C], final_counters[C:2 * C], final_counters[2 * C:]),
             "roofline": {"bound": "hbm", "kernel": "k_search_count", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -718,13 +755,18 @@ def main():
             result["readid_long"] = side_readid_long(a, dev, ctx, stream, with_oracle=not a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline and not a.emulate_world:
             result["cpu_baseline"], result["bit_exact"] = cpu_baseline(a, hx, ptr, kmers, freq, C, n, k, m, rs)
+    exit_code = 0
     if result is not None:
+        if a.scale_check:
+            result["scale_check"] = scale_check(a, n_shards, result["counters"])
+            exit_code = 1 if result["scale_check"]["ok"] is False else 0
         json_out.write(json.dumps(result) + "\n")
         json_out.flush()
     hx.close()
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    return exit_code
 
 
 def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
@@ -1021,4 +1063,4 @@ def cpu_baseline(a, hx, mat_ptr, kmers, freq, C, n, k, m, rs):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

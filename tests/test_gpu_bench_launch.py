@@ -60,6 +60,39 @@ def test_n_ranks_equal_one_rank_over_all_shards(extra, world):
     assert two["counters"] == one["counters"]
 
 
+@pytest.mark.parametrize("extra,n", [(TOY, 2), (TOY, 8), (TOY_STRIPED, 3), (TOY_STRIPED, 8), ([], 2), ([], 8), (["--placement", "striped", "--stripe-log2-bloom", "27"], 4)],
+                         ids=["toy-2", "toy-8", "toy-striped-3", "toy-striped-8", "default-2", "default-8", "striped27-4"])
+def test_scale_check_reproduces_the_committed_digests(extra, n):
+    """tests/golden/scale_digests.json (tools/make_scale_digests.py): what `bench.py --gpus N --scale-check` must find on an N-GPU node,
+    reproduced here by one rank standing in for N — at the toys' sizes, at the default workload and at the striped placement's check size"""
+    fast = [] if "--no-variants" in extra else ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-variants"]
+    one = one_json_line(run_bench(["--emulate-world", str(n), "--scale-check"] + extra + fast))
+    sc = one["scale_check"]
+    assert sc["ok"] is True and sc["ranks"] == n and sc["expected"] == sc["got"] == one["counters"]["sha256"], sc
+    assert one["config"]["setup_s"] < 60 and one["config"]["setup_phases"]
+
+
+def test_scale_check_fails_loudly_on_other_counters(tmp_path):
+    """two gloo ranks with --scale-check: ok; the same asked to reproduce a digest that is not theirs: exit code 1, ok false in the line"""
+    good = one_json_line(run_bench(["--gpus", "2", "--scale-check"] + TOY, backend="gloo"))
+    assert good["scale_check"]["ok"] is True and good["scale_check"]["ranks"] == 2
+    none = one_json_line(run_bench(["--emulate-world", "2", "--scale-check", "--reads", "20001"] + TOY[2:]))
+    assert none["scale_check"]["ok"] is None and none["scale_check"]["expected"] is None     # no digest committed for this workload: reported, not failed
+    import json as _json
+    golden = os.path.join(ROOT, "tests", "golden", "scale_digests.json")
+    keep = open(golden).read()
+    try:
+        g = _json.loads(keep)
+        g[good["scale_check"]["key"]]["2"] = "0" * 64
+        open(golden, "w").write(_json.dumps(g))
+        p = run_bench(["--emulate-world", "2", "--scale-check"] + TOY)
+        assert p.returncode == 1
+        bad = _json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+        assert bad["scale_check"]["ok"] is False
+    finally:
+        open(golden, "w").write(keep)
+
+
 def test_nccl_without_enough_devices_is_a_one_line_refusal():
     import torch
     if torch.cuda.device_count() >= 2:

@@ -129,5 +129,27 @@ def test_one_process_per_gpu_rccl(tmp_path, n_gpus):
     if n_devices() < n_gpus:
         pytest.skip(f"needs {n_gpus} GPUs")
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(n_gpus, _free_port(), str(tmp_path)), nprocs=n_gpus, join=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (the host driver only supports dmabuf IPC: RCCL between processes needs it)
+    mp.spawn(_worker, args=(n_gpus, _free_port(), str(tmp_path)), nprocs=n_gpus, join=True)   # fresh interpreters (spawn): children, not an exec of this process
     assert open(tmp_path / "result.txt").read() == "ok"
+
+
+@pytest.mark.parametrize("n_gpus", [2, 4, 8])
+@pytest.mark.timeout(900)
+def test_bench_self_launch_over_rccl_reproduces_the_digests(n_gpus):
+    """`python bench.py --gpus N --scale-check` with the default backend (RCCL): the launcher starts its own N ranks as child processes
+    before anything touches the GPU, and the all-reduced counters carry the digest one GPU standing in for N committed
+    (tests/golden/scale_digests.json) — replicated and colour-striped"""
+    if n_devices() < n_gpus:
+        pytest.skip(f"needs {n_gpus} GPUs")
+    import json
+    import subprocess
+    fast = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-variants", "--scale-check"]
+    for extra in ([], ["--placement", "striped", "--stripe-log2-bloom", "27"]):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n_gpus)] + fast + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, env=env, cwd=ROOT, timeout=800)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["n_gpus"] == n_gpus and line["config"]["backend"] == "nccl" and line["scale_check"]["ok"] is True, line["scale_check"]
+        assert len(line["per_rank"]) == n_gpus and line["config"]["setup_s"] < 60
