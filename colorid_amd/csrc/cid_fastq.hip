@@ -216,7 +216,7 @@ struct cid_fastq {
         size_t bytes = 0;
         uint32_t *d_status = nullptr;
         size_t n_members = 0;
-        void *d_in = nullptr, *d_mem = nullptr;
+        void *d_in = nullptr, *d_mem = nullptr, *d_scratch = nullptr;
         hipEvent_t done = nullptr;
         bool last = false;
     };
@@ -304,6 +304,7 @@ int text_reserve(cid_fastq *fq, int file, size_t extra) {
 void free_staged(cid_fastq *fq, cid_fastq::Staged &sg) {   // (after its event has been waited for on the host)
     cid_ctx *c = fq->ctx;
     cid::ctx_free(c, sg.text); cid::ctx_free(c, sg.d_status); cid::ctx_free(c, sg.d_in); cid::ctx_free(c, sg.d_mem);
+    if (sg.d_scratch) cid::ctx_free(c, sg.d_scratch);
     if (sg.done) (void)hipEventDestroy(sg.done);
     sg = cid_fastq::Staged();
 }
@@ -439,6 +440,7 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
         if ((rc = cid::ctx_alloc(c, n_members * 4, &p))) { free_staged(fq, sg); return rc; }
         sg.d_status = (uint32_t *)p;
         if ((rc = cid::ctx_alloc(c, n_bytes + 16, &sg.d_in)) || (rc = cid::ctx_alloc(c, n_members * sizeof(cid::BgzfMember), &sg.d_mem))) { free_staged(fq, sg); return rc; }
+        if (cid::ctx_alloc(c, cid::bgzf_inflate_scratch_bytes((uint32_t)n_members), &sg.d_scratch) != CID_OK) sg.d_scratch = nullptr;   // (refused: one lane per member)
         // the blocks may have just come back from work queued on the ctx stream: the inflate stream starts behind it
         // (the members travel on the text stream: the inflate stream may still be busy with the push before, and the copy need not wait for it)
         hipEvent_t behind = cid::ctx_event(c, 0);
@@ -452,7 +454,7 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
         if (e == hipSuccess) e = hipEventRecord(copied, fq->text_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(inflate_stream, copied, 0);
         if (e == hipSuccess) e = cid::bgzf_inflate_launch(c, inflate_stream, (const uint8_t *)sg.d_in, (const cid::BgzfMember *)sg.d_mem, (uint32_t)n_members, sg.text,
-                                                          sg.d_status);
+                                                          sg.d_status, sg.d_scratch);
         if (e == hipSuccess) e = hipEventRecord(sg.done, inflate_stream);
         if (e == hipSuccess) e = hipEventSynchronize(copied);   // the caller's buffers (and `mem`) are free again; the kernel runs on
         if (e != hipSuccess) {

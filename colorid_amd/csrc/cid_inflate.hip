@@ -101,7 +101,8 @@ __device__ bool build_tables(const uint8_t *lens, uint32_t n_sym, uint16_t *tab,
 }
 
 // one symbol: direct table, else bit by bit over the canonical code (puff-style); -1 = invalid code
-__device__ __forceinline__ int decode_sym(BitReader &br, const uint16_t *tab, uint32_t bits, const uint16_t *cnt, const uint16_t *sym) {
+template <typename Reader>
+__device__ __forceinline__ int decode_sym(Reader &br, const uint16_t *tab, uint32_t bits, const uint16_t *cnt, const uint16_t *sym) {
     const uint32_t e = tab[br.peek(bits)];
     if (e) { br.drop(e & 15u); return (int)(e >> 4); }
     int code = 0, first = 0, index = 0;
@@ -358,14 +359,15 @@ __device__ unsigned long long g_inflate_stamps[8];
 // CRC-32 — take the members one after the other.
 template <int LPW>
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const BgzfMember *members, uint32_t n_members, uint8_t *out, uint32_t *status,
-                                                     CrcShift shift) {
+                                                     CrcShift shift, const uint32_t *retry /* NULL, or [0] count [1 ..] the members to take */) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x;
     const LaneLds L(smem + (size_t)(lane < LPW ? lane : 0) * kLdsBytes);
+    if (retry) n_members = retry[0];   // (what k_bgzf_inflate_wave left)
 
     for (uint32_t base = blockIdx.x * LPW; base < n_members; base += gridDim.x * LPW) {
-        const uint32_t mi = base + (uint32_t)lane;
-        const bool mine = lane < LPW && mi < n_members;
+        const bool mine = lane < LPW && base + (uint32_t)lane < n_members;
+        const uint32_t mi = !mine ? 0u : retry ? retry[1 + base + (uint32_t)lane] : base + (uint32_t)lane;
         const BgzfMember mem = mine ? members[mi] : BgzfMember{0, 0, 0, 0};
         const uint8_t *src = in + mem.in_off;
         uint8_t *img = out + mem.out_off;                 // the text is written in place: literals are stores nobody waits for, a match
@@ -535,6 +537,379 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *in, const Bg
     }
 }
 
+// ------------------------------------------------------------------------------------------------ one member per WAVE
+// k_bgzf_inflate above keeps 62 lanes of every wave waiting for one DEFLATE chain.  Huffman codes fall into step: a decoder started at
+// an arbitrary bit of a block of FASTQ text sits on a true symbol boundary after 8 symbols at the median, 51 at the 99th percentile
+// (tools/exp_inflate_sync.py, profiles/r05_inflate_sync_probe.json).  So the 64 lanes cut a block's bits into 64 chunks and decode them
+// at once, from guessed starts:
+//   a pass      lane i decodes from its start u_i up to the end of its chunk and notes where it lands in the next chunk (e_i), how many
+//               bytes and matches that makes, and whether it met the end of the block;
+//   the check   lane 0's start is true; lane i + 1's was true if it EQUALS e_i of a lane that was true.  The first lane that fails gets
+//               e_i as its start (every other lane its neighbour's latest landing point) and the pass is repeated — two passes when
+//               every guess fell into step inside its own chunk, which is the rule;
+//   the writing prefix sums of the bytes and matches give every chunk its place: the lanes decode once more, literals go to the text,
+//               matches to a token list in HBM (sorted by position), and copy_matches resolves them wave-wide as before.
+// Anything out of the ordinary — a stored block, a member whose compressed bits do not fit 2^19, no agreement after kWaveMaxPasses, any
+// invalid code on the true path — hands the member to the one-lane kernel (status kRetry, a retry list), which also owns the error codes.
+constexpr uint32_t kRetry = 100;           // status of a member left for the one-lane kernel
+constexpr uint32_t kWaveTokens = 21848;    // matches of one member at most: three bytes each of 65 536
+constexpr uint32_t kWaveMaxPasses = 12;
+
+struct GBits {   // a lane's view of the compressed stream in HBM: 32-bit words, two of them read ahead of the bit buffer
+    const uint32_t *w;
+    uint32_t n_words;   // words that exist (beyond them: zeros)
+    uint32_t wpos, cnt, a0, a1, pos;   // pos: the next bit, counted from w
+    uint64_t buf;
+    __device__ __forceinline__ uint32_t ld(uint32_t i) const { return i < n_words ? w[i] : 0u; }
+    __device__ __forceinline__ void start(uint32_t bit) {
+        wpos = bit >> 5;
+        const uint32_t sh = bit & 31u;
+        buf = (uint64_t)(ld(wpos) >> sh);
+        cnt = 32u - sh;
+        a0 = ld(wpos + 1); a1 = ld(wpos + 2);
+        wpos += 3;
+        pos = bit;
+    }
+    __device__ __forceinline__ void refill() {
+        if (cnt <= 32) {
+            buf |= (uint64_t)a0 << cnt;
+            cnt += 32;
+            a0 = a1;
+            a1 = ld(wpos++);
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(uint32_t n) { buf >>= n; cnt -= n; pos += n; }
+    __device__ __forceinline__ uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+struct ChunkEnd { uint32_t end_pos, n_out, n_tok, flags; };   // flags: 1 = the end of the block was met (end_pos: the bit after it), 2 = not a valid code
+
+// The wave kernel's tables: 12 / 10 bits wide instead of 10 / 8.  64 lanes decode different symbols in lockstep, so a code longer than the
+// direct table sends the WHOLE wave through the bit-by-bit loop whenever any lane meets one — with 10 / 8 bits that was most iterations
+// (2 200 cycles per symbol step); and the tables are filled by the wave, an index per lane, instead of by one lane's nest of loops
+// (367 k cycles per member for the headers alone).
+constexpr int kWLitBits = 11, kWDistBits = 9;
+constexpr uint32_t kWLit = 0, kWDist = kWLit + 2u * (1u << kWLitBits), kWCnt = kWDist + 2u * (1u << kWDistBits), kWLens = kWCnt + 2u * (16 + 288 + 16 + 32),
+                   kWClen = kWLens + 320, kWRun = kWClen + 2u * (128 + 16 + 20), kWaveLdsBytes = kWRun + 4u * 32;
+struct WaveLds {
+    uint16_t *lit, *dist, *lcnt, *lsym, *dcnt, *dsym, *ctab, *ccnt, *csym;
+    uint8_t *lens;
+    uint32_t *run;   // 32 words of scratch for the table builder
+    __device__ explicit WaveLds(uint8_t *base)
+        : lit(reinterpret_cast<uint16_t *>(base + kWLit)), dist(reinterpret_cast<uint16_t *>(base + kWDist)), lcnt(reinterpret_cast<uint16_t *>(base + kWCnt)),
+          lsym(lcnt + 16), dcnt(lsym + 288), dsym(dcnt + 16), ctab(reinterpret_cast<uint16_t *>(base + kWClen)), ccnt(ctab + 128), csym(ccnt + 16),
+          lens(base + kWLens), run(reinterpret_cast<uint32_t *>(base + kWRun)) {}
+};
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// build_tables by all 64 lanes (same tables, same verdict): the lengths are counted with LDS atomics, the symbols are ranked inside their length
+// by ballots, and every index of the direct table finds its own code by walking the canonical code (what decode_sym's slow path does per symbol)
+__device__ __noinline__ bool wave_build_tables(const uint8_t *lens, uint32_t n_sym, uint16_t *tab, uint32_t bits, uint16_t *cnt, uint16_t *sym, uint32_t *run, int lane,
+                                  bool allow_single = true) {
+    if (lane < 32) run[lane] = 0;
+    wave_sync_lds();
+    for (uint32_t s = lane; s < n_sym; s += 64) atomicAdd(&run[lens[s]], 1u);
+    wave_sync_lds();
+    uint32_t c[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) c[l] = run[l];
+    wave_sync_lds();
+    if (lane < 16) cnt[lane] = (uint16_t)c[lane];
+    if (c[0] == n_sym) {   // no codes at all (a distance tree may be empty)
+        for (uint32_t i = lane; i < (1u << bits); i += 64) tab[i] = 0;
+        wave_sync_lds();
+        return true;
+    }
+    int left = 1;
+    bool over = false;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { left <<= 1; left -= (int)c[l]; over = over || left < 0; }
+    if (over) return false;
+    uint32_t offs[16];
+    offs[0] = 0; offs[1] = 0;
+#pragma unroll
+    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + c[l];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (uint32_t base = 0; base < n_sym; base += 64) {   // symbols in order: a symbol's place is its rank among the symbols of its length
+        const uint32_t s = base + (uint32_t)lane;
+        const uint32_t l = s < n_sym ? lens[s] : 0u;
+#pragma unroll
+        for (int len = 1; len < 16; ++len) {
+            const uint64_t m = __ballot(l == (uint32_t)len);
+            if (l == (uint32_t)len) sym[offs[len] + (uint32_t)__popcll(m & lt)] = (uint16_t)s;
+            offs[len] += (uint32_t)__popcll(m);
+        }
+    }
+    wave_sync_lds();
+    for (uint32_t i = lane; i < (1u << bits); i += 64) {
+        int code = 0, first = 0, index = 0;
+        uint32_t e = 0;
+#pragma unroll 1
+        for (uint32_t l = 1; l <= bits; ++l) {
+            code |= (int)((i >> (l - 1)) & 1u);
+            const int n = (int)cnt[l];   // (bits <= 12: LDS, written above — a register array indexed by l would live in scratch memory)
+            if (code - n < first) { e = ((uint32_t)sym[index + (code - first)] << 4) | l; break; }
+            index += n;
+            first += n;
+            first <<= 1;
+            code <<= 1;
+        }
+        tab[i] = (uint16_t)e;
+    }
+    wave_sync_lds();
+    return left == 0 || (allow_single && (n_sym - c[0]) == 1 && c[1] == 1);
+}
+
+// one lane's chunk: symbols from br.pos while they START below `limit`.  WRITE: literals to img[out_off ..], matches to tok[tok_off ..]
+template <bool WRITE>
+__device__ ChunkEnd decode_chunk(GBits &br, uint32_t limit, const WaveLds &L, uint8_t *img, uint32_t out_off, uint32_t out_len, uint2 *tok, uint32_t tok_off) {
+    ChunkEnd r{0, 0, 0, 0};
+    while (br.pos < limit) {
+        br.refill();
+        const int sym = decode_sym(br, L.lit, kWLitBits, L.lcnt, L.lsym);
+        if (sym < 0) { r.flags = 2; break; }
+        if (sym < 256) {
+            if (WRITE) {
+                if (out_off + r.n_out >= out_len) { r.flags = 2; break; }
+                img[out_off + r.n_out] = (uint8_t)sym;
+            }
+            ++r.n_out;
+        } else if (sym == 256) {
+            r.flags = 1;
+            break;
+        } else {
+            if (sym > 285) { r.flags = 2; break; }
+            const uint32_t li = (uint32_t)sym - 257u;
+            const uint32_t lx = li < 8u || li == 28u ? 0u : (li >> 2) - 1u;
+            const uint32_t len = (li < 8u ? 3u + li : li == 28u ? 258u : ((4u + (li & 3u)) << lx) + 3u) + br.take(lx);
+            br.refill();
+            const int ds = decode_sym(br, L.dist, kWDistBits, L.dcnt, L.dsym);
+            if (ds < 0 || ds > 29) { r.flags = 2; break; }
+            const uint32_t dx = ds < 4 ? 0u : ((uint32_t)ds >> 1) - 1u;
+            const uint32_t dist = (ds < 4 ? 1u + (uint32_t)ds : ((2u + ((uint32_t)ds & 1u)) << dx) + 1u) + br.take(dx);
+            if (WRITE) {
+                const uint32_t at = out_off + r.n_out;
+                if (dist > at || at + len > out_len) { r.flags = 2; break; }
+                tok[tok_off + r.n_tok] = make_uint2(at | (len << 16), dist);
+            }
+            r.n_out += len;
+            ++r.n_tok;
+        }
+        if (r.n_out > (1u << 20)) { r.flags = 2; break; }   // (a guessed start decoding nonsense: nothing of it is used)
+    }
+    r.end_pos = br.pos;
+    return r;
+}
+
+// lane 0: the header of the block at `bit` up to its code lengths (L.lens: the literal/length tree's hlit lengths, then the distance tree's hdist);
+// returns the first bit of the symbols, or 0 = not this kernel's case (a stored block, an invalid header)
+__device__ __noinline__ uint32_t wave_block_header(const uint32_t *w, uint32_t n_words, uint32_t bit, const WaveLds &L, uint32_t *last, uint32_t *hlit_out, uint32_t *hdist_out) {
+    GBits br{w, n_words, 0, 0, 0, 0, 0, 0};
+    br.start(bit);
+    br.refill();
+    *last = br.take(1);
+    const uint32_t type = br.take(2);
+    uint8_t *const s_lens = L.lens;
+    if (type == 1) {   // fixed codes (RFC 1951 3.2.6)
+        for (uint32_t s = 0; s < 144; ++s) s_lens[s] = 8;
+        for (uint32_t s = 144; s < 256; ++s) s_lens[s] = 9;
+        for (uint32_t s = 256; s < 280; ++s) s_lens[s] = 7;
+        for (uint32_t s = 280; s < 288; ++s) s_lens[s] = 8;
+        for (uint32_t s = 0; s < 30; ++s) s_lens[288 + s] = 5;
+        *hlit_out = 288; *hdist_out = 30;
+        return br.pos;
+    }
+    if (type != 2) return 0;
+    const uint32_t hlit = br.take(5) + 257, hdist = br.take(5) + 1, hclen = br.take(4) + 4;
+    if (hlit > 286 || hdist > 30) return 0;
+    uint8_t cl[19];
+    for (uint32_t i = 0; i < 19; ++i) cl[i] = 0;
+    for (uint32_t i = 0; i < hclen; ++i) { br.refill(); cl[c_clen_order[i]] = (uint8_t)br.take(3); }
+    if (!build_tables(cl, 19, L.ctab, 7, L.ccnt, L.csym, false)) return 0;
+    uint32_t i = 0;
+    while (i < hlit + hdist) {
+        br.refill();
+        const int sym = decode_sym(br, L.ctab, 7, L.ccnt, L.csym);
+        if (sym < 0) return 0;
+        if (sym < 16) { s_lens[i++] = (uint8_t)sym; continue; }
+        uint32_t rep, val = 0;
+        if (sym == 16) { if (i == 0) return 0; val = s_lens[i - 1]; rep = 3 + br.take(2); }
+        else if (sym == 17) rep = 3 + br.take(3);
+        else rep = 11 + br.take(7);
+        if (i + rep > hlit + hdist) return 0;
+        while (rep--) s_lens[i++] = (uint8_t)val;
+    }
+    if (s_lens[256] == 0) return 0;
+    *hlit_out = hlit; *hdist_out = hdist;
+    return br.pos;
+}
+
+
+__global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const uint8_t *in, const BgzfMember *members, uint32_t n_members, uint8_t *out, uint32_t *status,
+                                                          CrcShift shift, uint2 *tok_all, uint32_t *retry /* [0] count, [1 ..] members */) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x;
+    const WaveLds L(smem);
+    for (uint32_t mi = blockIdx.x; mi < n_members; mi += gridDim.x) {
+        wave_sync_lds();
+        const BgzfMember mem = members[mi];
+        const uint8_t *src = in + mem.in_off;
+        uint8_t *img = out + mem.out_off;
+        uint2 *tok = tok_all + (size_t)mi * kWaveTokens;
+        // gzip header (RFC 1952), as in k_bgzf_inflate; anything unexpected is the one-lane kernel's to report
+        bool mine_ok = mem.in_len >= 28 && mem.out_len <= 65536u && src[0] == 0x1f && src[1] == 0x8b && src[2] == 8 && src[3] == 4;
+        uint32_t data0 = 0, data_len = 0, want_crc = 0;
+        if (mine_ok) {
+            const uint32_t xlen = src[10] | ((uint32_t)src[11] << 8);
+            data0 = 12 + xlen;
+            if (data0 + 8 > mem.in_len) mine_ok = false;
+            else {
+                data_len = mem.in_len - 8 - data0;
+                const uint8_t *t = src + mem.in_len - 8;
+                want_crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                const uint32_t isize = t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                if (isize != mem.out_len) mine_ok = false;
+            }
+        }
+        if (data_len >= (1u << 16)) mine_ok = false;
+        const uintptr_t dptr = reinterpret_cast<uintptr_t>(src + data0);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(dptr & ~(uintptr_t)3);
+        const uint32_t bit0 = 8u * (uint32_t)(dptr & 3u), end_bit = bit0 + 8u * data_len;
+        const uint32_t n_words = (end_bit + 31u) / 32u + 2u;   // (the trailer's 8 bytes follow the data: still inside the member)
+        uint32_t bit = bit0, out_pos = 0, n_tok = 0;
+        bool ok = mine_ok, final = false;
+        while (ok && !final) {
+            // ---- the block's header and tables: lane 0
+            const unsigned long long t_hdr = CID_NOW();
+            uint32_t sym0 = 0, last = 0, hlit = 0, hdist = 0;
+            if (lane == 0) sym0 = wave_block_header(w, n_words, bit, L, &last, &hlit, &hdist);
+            sym0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym0);
+            last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+            hlit = (uint32_t)__builtin_amdgcn_readfirstlane((int)hlit);
+            hdist = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdist);
+            wave_sync_lds();
+            if (sym0 == 0 || sym0 >= end_bit) { ok = false; break; }
+            if (!wave_build_tables(L.lens, hlit, L.lit, kWLitBits, L.lcnt, L.lsym, L.run, lane) ||
+                !wave_build_tables(L.lens + hlit, hdist, L.dist, kWDistBits, L.dcnt, L.dsym, L.run, lane)) { ok = false; break; }
+            CID_STAMP(4, t_hdr);
+            const unsigned long long t_pass = CID_NOW();
+            // ---- the passes
+            const uint32_t chunk = (end_bit - sym0 + 63u) / 64u < 256u ? 256u : (end_bit - sym0 + 63u) / 64u;
+            const uint32_t limit = lane == 63 ? end_bit : (sym0 + ((uint32_t)lane + 1u) * chunk < end_bit ? sym0 + ((uint32_t)lane + 1u) * chunk : end_bit);
+            uint32_t u = sym0 + (uint32_t)lane * chunk;
+            if (u > end_bit) u = end_bit;
+            ChunkEnd r{0, 0, 0, 0};
+            int E = -1;   // the lane that met the end of the block on the true path
+            for (uint32_t pass = 0; pass < kWaveMaxPasses; ++pass) {
+                GBits br{w, n_words, 0, 0, 0, 0, 0, 0};
+                br.start(u);
+                r = u < limit ? decode_chunk<false>(br, limit, L, nullptr, 0, 0, nullptr, 0) : ChunkEnd{u, 0, 0, 0};
+                const uint32_t e_prev = __shfl_up(r.end_pos, 1, 64);
+                const uint32_t f_prev = __shfl_up(r.flags, 1, 64);
+                const bool link = lane == 0 || (u == e_prev && f_prev == 0);
+                const uint64_t lm = __ballot(link), fm = __ballot(r.flags != 0);
+                const int V = ~lm ? __builtin_ctzll(~lm) : 64;          // lanes 0 .. V-1 started on the true path
+                const int F = fm ? __builtin_ctzll(fm) : 64;            // the first lane that stopped
+                if (F < V) { E = F; break; }
+                if (V == 64) break;                                     // the stream ends without an end of block
+                if (lane >= V) u = e_prev < end_bit ? e_prev : end_bit;
+            }
+            if (E < 0) { ok = false; break; }
+            CID_STAMP(5, t_pass);
+            const unsigned long long t_wr = CID_NOW();
+            const uint32_t flagsE = (uint32_t)__builtin_amdgcn_readlane((int)r.flags, E);
+            if (flagsE != 1u) { ok = false; break; }
+            // ---- where every chunk's bytes and matches go
+            const bool part = lane <= E;
+            uint32_t o_inc = part ? r.n_out : 0u, t_inc = part ? r.n_tok : 0u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t a = __shfl_up(o_inc, o, 64), b = __shfl_up(t_inc, o, 64);
+                if (lane >= o) { o_inc += a; t_inc += b; }
+            }
+            const uint32_t tot_out = (uint32_t)__builtin_amdgcn_readlane((int)o_inc, 63), tot_tok = (uint32_t)__builtin_amdgcn_readlane((int)t_inc, 63);
+            if (out_pos + tot_out > mem.out_len || n_tok + tot_tok > kWaveTokens) { ok = false; break; }
+            // ---- the writing pass
+            uint32_t bad = 0;
+            if (part && u < limit) {
+                GBits br{w, n_words, 0, 0, 0, 0, 0, 0};
+                br.start(u);
+                const ChunkEnd wr = decode_chunk<true>(br, limit, L, img, out_pos + o_inc - r.n_out, mem.out_len, tok, n_tok + t_inc - r.n_tok);
+                bad = (wr.flags & 2u) | (wr.end_pos != r.end_pos ? 2u : 0u);
+            }
+            if (__any(bad != 0)) { ok = false; break; }
+            CID_STAMP(6, t_wr);
+            out_pos += tot_out;
+            n_tok += tot_tok;
+            bit = (uint32_t)__builtin_amdgcn_readlane((int)r.end_pos, E);
+            final = last != 0;
+            wave_sync_lds();
+        }
+        if (ok && (out_pos != mem.out_len || (bit + 7u) / 8u > bit0 / 8u + data_len)) ok = false;
+        if (!ok) {   // the one-lane kernel takes it (and names what is wrong with it, if anything is)
+            if (lane == 0) { status[mi] = kRetry; retry[1 + atomicAdd(&retry[0], 1u)] = mi; }
+            continue;
+        }
+        // ---- the matches, by the whole wave (the literals and the tokens are in HBM: visible to the wave behind a fence)
+        const unsigned long long t_cp = CID_NOW();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        copy_matches(tok, n_tok, img, lane);
+        CID_STAMP(7, t_cp);
+        // ---- CRC-32, as in k_bgzf_inflate (slices of 1 KiB aligned to the text's end, slicing by 4, folded with the shift operator)
+        uint32_t *tab = reinterpret_cast<uint32_t *>(smem + kWLit);   // (4 KiB of the literal/length table's 8: the decoding is over)
+        wave_sync_lds();
+        for (uint32_t i = lane; i < 256; i += 64) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+            tab[i] = c;
+        }
+        wave_sync_lds();
+        for (uint32_t i = lane; i < 256; i += 64) {
+            uint32_t c = tab[i];
+            for (int t = 1; t < 4; ++t) { c = tab[c & 0xFFu] ^ (c >> 8); tab[256 * t + i] = c; }
+        }
+        wave_sync_lds();
+        const uint32_t len = mem.out_len;
+        const uint32_t n_slices = (len + 1023u) / 1024u;
+        const uint32_t first_len = len - (n_slices ? (n_slices - 1u) * 1024u : 0u);
+        uint32_t c = 0;
+        if ((uint32_t)lane < n_slices) {
+            const uint32_t b0 = lane == 0 ? 0u : first_len + ((uint32_t)lane - 1u) * 1024u;
+            const uint32_t b1 = lane == 0 ? first_len : b0 + 1024u;
+            c = lane == 0 ? 0xFFFFFFFFu : 0u;
+            uint32_t i = b0;
+            for (; i < b1 && ((b1 - i) & 3u); ++i) c = tab[(c ^ img[i]) & 0xFFu] ^ (c >> 8);
+            for (; i < b1; i += 4) {
+                uint32_t wd;
+                __builtin_memcpy(&wd, img + i, 4);
+                c ^= wd;
+                c = tab[768 + (c & 0xFFu)] ^ tab[512 + ((c >> 8) & 0xFFu)] ^ tab[256 + ((c >> 16) & 0xFFu)] ^ tab[c >> 24];
+            }
+        }
+        uint32_t reg = 0xFFFFFFFFu;
+        for (uint32_t sl = 0; sl < n_slices; ++sl) {
+            const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)sl);
+            if (sl == 0) reg = cs;
+            else {
+                uint32_t rr = 0;
+                for (uint32_t j = 0; j < 32; ++j) rr ^= shift.m[j] & (0u - ((reg >> j) & 1u));
+                reg = rr ^ cs;
+            }
+        }
+        if (lane == 0) {
+            if ((reg ^ 0xFFFFFFFFu) != want_crc) { status[mi] = kRetry; retry[1 + atomicAdd(&retry[0], 1u)] = mi; }   // (the one-lane kernel confirms or names it)
+            else status[mi] = ST_OK;
+        }
+    }
+}
+
 static CrcShift make_crc_shift() {
     uint32_t tab[256];
     for (uint32_t i = 0; i < 256; ++i) {
@@ -558,10 +933,31 @@ hipError_t warm_inflate() {
 }
 
 // the kernel on device-resident members: text to d_out + member.out_off, one status word per member; asynchronous on the ctx stream
+size_t bgzf_inflate_scratch_bytes(uint32_t n_members) { return (size_t)n_members * kWaveTokens * sizeof(uint2) + ((size_t)n_members + 4) * 4; }
+
 hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_in, const BgzfMember *d_mem, uint32_t n_members, uint8_t *d_out,
-                               uint32_t *d_st) {
+                               uint32_t *d_st, void *d_scratch) {
     if (n_members == 0) return hipSuccess;
     static const CrcShift shift = make_crc_shift();
+    // One member per WAVE first (k_bgzf_inflate_wave: 64 lanes on the chunks of a block); what it leaves — stored blocks, corrupt members, the
+    // rare block whose chunks do not fall into step — goes to the one-lane kernel through the retry list.  CID_INFLATE_WAVE=0, or a caller
+    // without scratch: the one-lane kernel for everything.
+    static const bool wave_env = getenv("CID_INFLATE_WAVE") ? atoi(getenv("CID_INFLATE_WAVE")) != 0 : true;
+    uint32_t *d_retry = nullptr;
+    if (wave_env && d_scratch) {
+        uint2 *d_tok = reinterpret_cast<uint2 *>(d_scratch);
+        d_retry = reinterpret_cast<uint32_t *>(d_tok + (size_t)n_members * kWaveTokens);
+        hipError_t e = hipMemsetAsync(d_retry, 0, 4, stream);
+        if (e != hipSuccess) return e;
+        unsigned grid = n_members;
+        const unsigned cap = (unsigned)c->n_cu * 20u;   // (7.4 KiB of LDS per wave: twenty per CU)
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(k_bgzf_inflate_wave, dim3(grid), dim3(64), kWaveLdsBytes, stream, d_in, d_mem, n_members, d_out, d_st, shift, d_tok, d_retry);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        unsigned rgrid = n_members < 256u ? n_members : 256u;
+        hipLaunchKernelGGL(k_bgzf_inflate<1>, dim3(rgrid), dim3(64), kLdsBytes, stream, d_in, d_mem, n_members, d_out, d_st, shift, (const uint32_t *)d_retry);
+        return hipGetLastError();
+    }
     // members per wave (CID_INFLATE_LANES: 1, 2, 4 or 8).  Two decoders share a wave's instruction stream where their steps coincide, which
     // doubles what a full chip decodes per unit time, but each runs at 0.6 of the speed it has alone: a launch that leaves the chip mostly
     // idle anyway (<= 1 280 members = five waves per CU) takes one per wave (256 members: 4.5 against 7.9 ms, 1 024: 5.5 against 8.4,
@@ -573,7 +969,7 @@ hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_
     const unsigned cap = (unsigned)c->n_cu * 32u * 4u;   // a few rounds per block at most
     if (grid > cap) grid = cap;
     const size_t lds = (size_t)lpw * kLdsBytes;
-    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, stream, d_in, d_mem, n_members, d_out, d_st, shift); };
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, stream, d_in, d_mem, n_members, d_out, d_st, shift, (const uint32_t *)nullptr); };
     if (lpw == 1) launch(k_bgzf_inflate<1>);
     else if (lpw == 4) launch(k_bgzf_inflate<4>);
     else if (lpw == 8) launch(k_bgzf_inflate<8>);
@@ -622,6 +1018,8 @@ extern "C" int cid_bgzf_inflate_start(cid_ctx *c, const uint8_t *members, size_t
     rc = cid::slot_reserve(c, S_MISC, n_members * sizeof(cid::BgzfMember), &d_mem); if (rc) return rc;
     rc = cid::slot_reserve(c, S_BASES, text_bytes + 16, &d_out); if (rc) return rc;
     rc = cid::slot_reserve(c, S_FREQ, n_members * 4, &d_st); if (rc) return rc;
+    void *d_scratch = nullptr;   // (refused: the one-lane kernel takes the batch)
+    if (cid::slot_reserve(c, S_ROWIDS, cid::bgzf_inflate_scratch_bytes((uint32_t)n_members), &d_scratch) != CID_OK) d_scratch = nullptr;
     // arena: members | member table | text | status
     const size_t b_mem = (n_bytes + 63) & ~(size_t)63, b_text = b_mem + ((n_members * sizeof(cid::BgzfMember) + 63) & ~(size_t)63),
                  b_st = b_text + ((text_bytes + 63) & ~(size_t)63), b_end = b_st + n_members * 4;
@@ -637,7 +1035,7 @@ extern "C" int cid_bgzf_inflate_start(cid_ctx *c, const uint8_t *members, size_t
         HIP_TRY(hipMemcpyAsync(d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(cid::bgzf_inflate_launch(c, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem, (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st));
+    HIP_TRY(cid::bgzf_inflate_launch(c, c->stream, (const uint8_t *)d_in, (const cid::BgzfMember *)d_mem, (uint32_t)n_members, (uint8_t *)d_out, (uint32_t *)d_st, d_scratch));
     c->inflate.d_out = d_out; c->inflate.d_st = d_st;
     if (pin) {
         HIP_TRY(hipMemcpyAsync(pin + b_st, d_st, n_members * 4, hipMemcpyDeviceToHost, c->stream));

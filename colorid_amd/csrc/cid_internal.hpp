@@ -100,8 +100,11 @@ int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_
 // block-gzip members on the device (cid_inflate.hip): member i = in[in_off, +in_len) (header, DEFLATE data, CRC-32, ISIZE), its text to
 // out[out_off, +out_len); status[i] = 0 or the reason it is corrupt.  Asynchronous on `stream`.
 struct BgzfMember { uint32_t in_off, in_len, out_off, out_len; };
+// d_scratch: bgzf_inflate_scratch_bytes(n_members) bytes the launch may use until it has run (match tokens of the wave-parallel kernel, its
+// retry list), or NULL (one lane per member)
+size_t bgzf_inflate_scratch_bytes(uint32_t n_members);
 hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_in, const BgzfMember *d_mem, uint32_t n_members, uint8_t *d_out,
-                               uint32_t *d_st);
+                               uint32_t *d_st, void *d_scratch);
 const char *bgzf_status_text(uint32_t st);
 
 // load a translation unit's code object ahead of its first kernel launch (cid_warmup)

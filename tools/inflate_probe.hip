@@ -1,6 +1,7 @@
 // Where k_bgzf_inflate's cycles go: the kernel compiled with CID_INFLATE_STAMPS (cycle counters of lane 0 of every wave, summed per part:
 // ring refill, decode runs, match copies, CRC) over members made here with zlib from synthetic FASTQ text.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCID_INFLATE_STAMPS -Icolorid_amd/csrc tools/inflate_probe.hip -o tools/bin/inflate_probe -lz
+// CID_INFLATE_WAVE=0: the one-lane kernel alone (round 4's); default: one member per wave, 64 lanes on a block's chunks (the stamps then cover the retries only)
 // usage: tools/bin/inflate_probe [members] [level] [kind: 0 random bases + 11 quality letters, 1 repetitive (reads of one 5 kb genome, 4 quality letters), 2 the same reads with 41 skewed quality values]
 #include <zlib.h>
 
@@ -66,6 +67,8 @@ int main(int argc, char **argv) {
     uint8_t *d_in, *d_out; cid::BgzfMember *d_mem; uint32_t *d_st;
     CHECK(hipMalloc(&d_in, in.size() + 16)); CHECK(hipMalloc(&d_out, n_members * 65280 + 16)); CHECK(hipMalloc(&d_mem, mem.size() * sizeof(mem[0])));
     CHECK(hipMalloc(&d_st, n_members * 4));
+    void *d_scratch = nullptr;   // the wave-parallel kernel's match tokens and retry list (CID_INFLATE_WAVE=0: one lane per member)
+    CHECK(hipMalloc(&d_scratch, cid::bgzf_inflate_scratch_bytes((uint32_t)n_members)));
     CHECK(hipMemcpy(d_in, in.data(), in.size(), hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_mem, mem.data(), mem.size() * sizeof(mem[0]), hipMemcpyHostToDevice));
     cid_ctx ctx;
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
@@ -74,8 +77,9 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; ++rep) {
         unsigned long long zero[8] = {0};
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(cid::g_inflate_stamps), zero, sizeof zero));
+        CHECK(hipMemset(d_out, 0, n_members * 65280));
         CHECK(hipEventRecord(e0, 0));
-        CHECK(cid::bgzf_inflate_launch(&ctx, 0, d_in, d_mem, (uint32_t)n_members, d_out, d_st));
+        CHECK(cid::bgzf_inflate_launch(&ctx, 0, d_in, d_mem, (uint32_t)n_members, d_out, d_st, d_scratch));
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipDeviceSynchronize());
         float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -84,12 +88,20 @@ int main(int argc, char **argv) {
         const double waves = (double)((n_members + 1) / 2);
         printf("%zu members, level %d, kind %d: %.2f ms (%.1f MB compressed); cycles per wave: refill %.0fk, decode %.0fk, copies %.0fk, crc %.0fk\n", n_members, level,
                kind, ms, in.size() / 1e6, st[0] / waves / 1e3, st[1] / waves / 1e3, st[2] / waves / 1e3, st[3] / waves / 1e3);
+        if (st[4] + st[5] + st[6] + st[7])
+            printf("    one member per wave, cycles per member: headers + tables %.0fk, passes %.0fk, writing %.0fk, copies %.0fk\n", st[4] / (double)n_members / 1e3,
+                   st[5] / (double)n_members / 1e3, st[6] / (double)n_members / 1e3, st[7] / (double)n_members / 1e3);
     }
     std::vector<uint32_t> stt(n_members);
     std::string out(n_members * 65280, '\0');
     CHECK(hipMemcpy(stt.data(), d_st, n_members * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&out[0], d_out, out.size(), hipMemcpyDeviceToHost));
     size_t bad = 0;
     for (uint32_t v : stt) bad += v != 0;
+    {   // how many members the wave-parallel kernel left for the one-lane kernel
+        uint32_t n_retry = 0;
+        CHECK(hipMemcpy(&n_retry, reinterpret_cast<uint8_t *>(d_scratch) + n_members * (size_t)cid::kWaveTokens * sizeof(uint2), 4, hipMemcpyDeviceToHost));
+        printf("left for the one-lane kernel: %u of %zu members\n", n_retry, n_members);
+    }
     printf("status: %zu bad members; text %s\n", bad, out.compare(0, out.size(), text, 0, out.size()) == 0 ? "identical" : "DIFFERS");
     return bad != 0;
 }
