@@ -26,21 +26,23 @@ namespace {
 //                            (LD_PRELOAD, /etc/ld.so.preload), a profiler's tool library (rocprofv3 writes its files from an exit handler),
 //                            coverage counters (LLVM_PROFILE_FILE, GCOV_PREFIX).
 // Either way every output file is closed and stdout / stderr are flushed — and checked — before (leave()).
+const char *g_exit_reason = "nothing in the process writes at exit";
 bool tool_may_write_at_exit() {
     for (const char *v : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "LLVM_PROFILE_FILE", "GCOV_PREFIX"})
-        if (const char *e = getenv(v)) if (*e) return true;
+        if (const char *e = getenv(v)) if (*e) { g_exit_reason = v; return true; }
     if (FILE *f = fopen("/etc/ld.so.preload", "r")) {
         int ch;
         bool any = false;
         while ((ch = fgetc(f)) != EOF) if (!isspace(ch)) { any = true; break; }
         fclose(f);
-        if (any) return true;
+        if (any) { g_exit_reason = "/etc/ld.so.preload"; return true; }
     }
     return false;
 }
 bool decide_orderly_exit() {
-    if (const char *e = getenv("COLORID_FAST_EXIT")) return atoi(e) == 0;
-    return getenv("COLORID_FULL_TEARDOWN") != nullptr || tool_may_write_at_exit();
+    if (const char *e = getenv("COLORID_FAST_EXIT")) { g_exit_reason = "COLORID_FAST_EXIT"; return atoi(e) == 0; }
+    if (getenv("COLORID_FULL_TEARDOWN")) { g_exit_reason = "COLORID_FULL_TEARDOWN"; return true; }
+    return tool_may_write_at_exit();
 }
 bool g_orderly_exit = decide_orderly_exit();
 
@@ -598,10 +600,10 @@ int main(int argc, char **argv) {
                "                             (-0.05 to -0.15 s per run); =0, or COLORID_FULL_TEARDOWN=1: always the orderly exit\n"
                "                             unset: the short way, unless a preloaded library, a profiler's tool library or coverage\n"
                "                             counters are present (they write at exit) or several GPUs are in use (RCCL is shut down)\n"
-               "                             this run would leave: %s\n"
+               "                             this run would leave: %s (%s)\n"
                "    COLORID_INDEX_MMAP=0     read the index through a buffered reader instead of a mapping\n"
                "    COLORID_DEVICE_FASTQ=0   FASTQ text on the host front end only\n",
-               g_orderly_exit ? "the orderly way" : "the short way");
+               g_orderly_exit ? "the orderly way" : "the short way", g_exit_reason);
         return 0;
     }
     if (cmd == "build") return leave(cmd_build(argc, argv));
