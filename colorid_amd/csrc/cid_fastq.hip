@@ -11,14 +11,13 @@
 // Host code + a few elementwise kernels; inflate and classification are the existing kernels.
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include <chrono>
 #include <deque>
 #include <new>
 #include <vector>
 
 #include "cid_api_common.hpp"
+#include "cid_scan.hpp"
 
 using cid::fail;
 
@@ -542,11 +541,9 @@ static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint
         if (src.len) {
             if ((rc = chunk_off.alloc((size_t)n_chunks + 1))) return rc;
             hipLaunchKernelGGL(cid::k_nl_count, dim3(nl_grid), dim3(256), 0, st, src.text, (uint32_t)src.len, n_chunks, chunk_off.p);
-            size_t tbs = 0;
-            HIP_TRY(rocprim::exclusive_scan(nullptr, tbs, chunk_off.p, chunk_off.p, 0u, (size_t)n_chunks + 1, rocprim::plus<uint32_t>(), st));
-            Buf<uint8_t> tmps(c);
-            if ((rc = tmps.alloc(tbs))) return rc;
-            HIP_TRY(rocprim::exclusive_scan(tmps.p, tbs, chunk_off.p, chunk_off.p, 0u, (size_t)n_chunks + 1, rocprim::plus<uint32_t>(), st));
+            Buf<uint64_t> scan_state(c);
+            if ((rc = scan_state.alloc(cid::scan_state_words((size_t)n_chunks + 1)))) return rc;
+            HIP_TRY(cid::scan_launch(cid::ScanInU32{chunk_off.p}, cid::ScanOutU32{chunk_off.p}, (size_t)n_chunks + 1, scan_state.p, st));
             uint32_t total = 0;
             HIP_TRY(hipMemcpyAsync(&total, chunk_off.p + n_chunks, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -581,13 +578,10 @@ static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint
         HIP_TRY(hipMemsetAsync(id_off.p + n, 0, 8, st));
         hipLaunchKernelGGL(cid::k_fq_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F[0], F[1], nf, fq->quality, k, stride_d, stats.p,
                            span.p, seq_off.p, id_begin.p, id_off.p);
-        size_t tb1 = 0, tb2 = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tb1, seq_off.p, seq_off.p, 0ull, n_seqs + 1, rocprim::plus<uint64_t>(), st));
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tb2, id_off.p, id_off.p, 0ull, n + 1, rocprim::plus<uint64_t>(), st));
-        Buf<uint8_t> tmp(c);
-        if ((rc = tmp.alloc(tb1 > tb2 ? tb1 : tb2))) return rc;
-        HIP_TRY(rocprim::exclusive_scan(tmp.p, tb1, seq_off.p, seq_off.p, 0ull, n_seqs + 1, rocprim::plus<uint64_t>(), st));
-        HIP_TRY(rocprim::exclusive_scan(tmp.p, tb2, id_off.p, id_off.p, 0ull, n + 1, rocprim::plus<uint64_t>(), st));
+        Buf<uint64_t> scan_a(c), scan_b(c);
+        if ((rc = scan_a.alloc(cid::scan_state_words(n_seqs + 1))) || (rc = scan_b.alloc(cid::scan_state_words(n + 1)))) return rc;
+        HIP_TRY(cid::scan_launch(cid::ScanInU64{seq_off.p}, cid::ScanOutU64{seq_off.p, 0ull}, n_seqs + 1, scan_a.p, st));
+        HIP_TRY(cid::scan_launch(cid::ScanInU64{id_off.p}, cid::ScanOutU64{id_off.p, 0ull}, n + 1, scan_b.p, st));
         HIP_TRY(hipMemcpyAsync(&hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&total_bases, seq_off.p + n_seqs, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(&total_ids, id_off.p + n, 8, hipMemcpyDeviceToHost, st));
@@ -627,7 +621,7 @@ static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint
         in.report = report.release(); in.nk = nk.release(); in.status = status.release(); in.ids = ids.release(); in.id_off = id_off.release();
         }
         // what the kernels in flight still read stays until _end has seen the stream drain
-        keep(span); keep(seq_off); keep(read_seq0); keep(id_off); keep(id_begin); keep(tmp); keep(bases); keep(ids); keep(status); keep(report); keep(nk);
+        keep(span); keep(seq_off); keep(read_seq0); keep(id_off); keep(id_begin); keep(scan_a); keep(scan_b); keep(bases); keep(ids); keep(status); keep(report); keep(nk);
     }
     keep(nl[0]); keep(nl[1]); keep(n_nl); keep(stats);
     in.active = true;

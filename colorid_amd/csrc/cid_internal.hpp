@@ -65,6 +65,15 @@ int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes,
 int search_perfect_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, size_t n, uint32_t k, uint32_t *and_words_le,
                          int *any_row_missing);
 
+// rocPRIM behind plain calls (cid_kmerset_cold.hip — the one translation unit that includes it; its code object of some thousand kernels is
+// loaded when the first of these is called): stable LSD radix sorts on bits [b0, b1), a run-length count of sorted keys.  Asynchronous on `st`.
+int cold_sort_keys_u64(cid_ctx *c, hipStream_t st, const uint64_t *in, uint64_t *out, size_t n, unsigned b0, unsigned b1);
+int cold_sort_pairs_u64_u32(cid_ctx *c, hipStream_t st, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned b0,
+                            unsigned b1);
+int cold_sort_pairs_u32_u64(cid_ctx *c, hipStream_t st, const uint32_t *kin, uint32_t *kout, const uint64_t *vin, uint64_t *vout, size_t n, unsigned b0,
+                            unsigned b1);
+int cold_run_length_u64(cid_ctx *c, hipStream_t st, const uint64_t *sorted, size_t n, uint64_t *uniq, uint32_t *runs, uint64_t *d_n_runs);
+
 // a finalized set's device arrays (codes ascending unless reordered; counts u32) and the ctx they live in
 int kmerset_view(const cid_kmerset *ks, cid_ctx **ctx, const uint64_t **codes, const uint32_t **counts, uint64_t *n, uint32_t *k);
 // replace a finalized 2-bit-code set's contents by the merge (sort by code, add counts of equal codes) of `total` pairs on its device

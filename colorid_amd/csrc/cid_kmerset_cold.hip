@@ -500,6 +500,16 @@ int cold_sort_pairs_u32_u64(cid_ctx *c, hipStream_t st, const uint32_t *kin, uin
     return CID_OK;
 }
 
+int cold_run_length_u64(cid_ctx *c, hipStream_t st, const uint64_t *sorted, size_t n, uint64_t *uniq, uint32_t *runs, uint64_t *d_n_runs) {
+    size_t tb = 0;
+    HIP_TRY(rocprim::run_length_encode(nullptr, tb, sorted, n, uniq, runs, d_n_runs, st));
+    DevBuf<uint8_t> tmp(c);
+    int rc = tmp.alloc(tb);
+    if (rc) return rc;
+    HIP_TRY(rocprim::run_length_encode(tmp.p, tb, sorted, n, uniq, runs, d_n_runs, st));
+    return CID_OK;
+}
+
 int kmerset_merge_batch(cid_kmerset *ks, const uint64_t *uniq_p, const uint32_t *agg_p, uint64_t n_runs) {
     hipStream_t st = cid::ctx_stream(ks->ctx);
     struct { const uint64_t *p; } uniq{uniq_p};

@@ -39,12 +39,7 @@ struct cid_kmerset {
 
 namespace cid {
 // ---- cold paths (cid_kmerset_cold.hip).  All run on `st`; scratch comes from the ctx's block cache.
-// stable LSD radix sorts on bits [b0, b1)
-int cold_sort_keys_u64(cid_ctx *c, hipStream_t st, const uint64_t *in, uint64_t *out, size_t n, unsigned b0, unsigned b1);
-int cold_sort_pairs_u64_u32(cid_ctx *c, hipStream_t st, const uint64_t *kin, uint64_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, unsigned b0,
-                            unsigned b1);
-int cold_sort_pairs_u32_u64(cid_ctx *c, hipStream_t st, const uint32_t *kin, uint32_t *kout, const uint64_t *vin, uint64_t *vout, size_t n, unsigned b0,
-                            unsigned b1);
+// (cold_sort_* / cold_run_length_u64: cid_internal.hpp)
 // a finalized-so-far set (ks->codes / counts, ks->n > 0) merged with a sorted, run-length counted batch (uniq / agg, n_runs > 0; the
 // caller keeps owning them): two sorted lists, one pass, equal neighbours added; waits for the stream
 int kmerset_merge_batch(cid_kmerset *ks, const uint64_t *uniq, const uint32_t *agg, uint64_t n_runs);

@@ -5,8 +5,6 @@
 //   * dense read_id report rows -> sparse (colour, count) entries per read.
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +14,7 @@
 
 #include "../../include/colorid_hip.h"
 #include "cid_internal.hpp"
+#include "cid_scan.hpp"
 #include "cid_devbuf.hpp"
 
 // ------------------------------------------------------------------------------------------------ modes of the unique-hit frequencies
@@ -119,20 +118,10 @@ int unique_freq_modes_finish(cid_ctx *c, ModeWork *w, unsigned long long n_ovf, 
     if (n_ovf) {
         DevBuf<uint32_t> runs(c);
         DevBuf<uint64_t> keys_sorted(c), keys_u(c), n_runs(c);
-        DevBuf<uint8_t> tmp(c);
-        size_t tb = 0, tb2 = 0;
         if ((rc = keys_sorted.alloc(n_ovf)) || (rc = keys_u.alloc(n_ovf)) || (rc = runs.alloc(n_ovf)) || (rc = n_runs.alloc(1))) goto out;
-        if (rocprim::radix_sort_keys(nullptr, tb, w->ovf, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st) != hipSuccess ||
-            rocprim::run_length_encode(nullptr, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st) != hipSuccess) {
-            rc = fail(CID_ERR_HIP, "rocprim size query");
-            goto out;
-        }
-        if ((rc = tmp.alloc(tb > tb2 ? tb : tb2))) goto out;
-        if (rocprim::radix_sort_keys(tmp.p, tb, w->ovf, keys_sorted.p, (size_t)n_ovf, 0u, 64u, st) != hipSuccess ||
-            rocprim::run_length_encode(tmp.p, tb2, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p, st) != hipSuccess) {
-            rc = fail(CID_ERR_HIP, "rocprim sort / run-length");
-            goto out;
-        }
+        // (cid_kmerset_cold.hip: the rocPRIM unit is loaded only when a query has multiplicities beyond the table)
+        if ((rc = cold_sort_keys_u64(c, st, w->ovf, keys_sorted.p, (size_t)n_ovf, 0u, 64u)) ||
+            (rc = cold_run_length_u64(c, st, keys_sorted.p, (size_t)n_ovf, keys_u.p, runs.p, n_runs.p))) goto out;
         hipLaunchKernelGGL(k_mode_pick_runs, dim3(grid_for_n(n_ovf)), dim3(256), 0, st, keys_u.p, runs.p, n_runs.p, w->best);
         hipLaunchKernelGGL(k_mode_final, dim3((w->C + 255) / 256), dim3(256), 0, st, w->best, w->C, d_modes);
         if (hipGetLastError() != hipSuccess) rc = fail(CID_ERR_HIP, "mode kernels");
@@ -198,10 +187,9 @@ int index_get_records(cid_ctx *c, const cid_index *ix, uint64_t row_begin, uint6
     int rc;
     if ((rc = flags.alloc(n_rows + 1)) || (rc = pos.alloc(n_rows + 1)) || (rc = out.alloc(n_rows * rec))) return rc;
     hipLaunchKernelGGL(k_row_nonzero, dim3(grid_for_n(n_rows + 1)), dim3(256), 0, st, index_matrix(ix), rs, row_begin, n_rows, flags.p);
-    size_t tb = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, flags.p, pos.p, 0u, n_rows + 1, rocprim::plus<uint32_t>(), st));
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, flags.p, pos.p, 0u, n_rows + 1, rocprim::plus<uint32_t>(), st));
+    DevBuf<uint64_t> scan_state(c);
+    if ((rc = scan_state.alloc(scan_state_words(n_rows + 1)))) return rc;
+    HIP_TRY(scan_launch(ScanInU32{flags.p}, ScanOutU32{pos.p}, n_rows + 1, scan_state.p, st));
     hipLaunchKernelGGL(k_emit_records, dim3(grid_for_n(n_rows)), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(index_matrix(ix)), rs, w32,
                        index_n_colors(ix), row_begin, n_rows, flags.p, pos.p, reinterpret_cast<uint32_t *>(out.p));
     uint32_t total = 0;
@@ -262,11 +250,9 @@ int compact_report(cid_ctx *c, const uint32_t *d_report, uint32_t width, uint64_
     if ((rc = nnz.alloc(n_rows + 1)) || (rc = start.alloc(n_rows + 1))) return rc;
     HIP_TRY(hipMemsetAsync(nnz.p, 0, (n_rows + 1) * 4, st));
     if (n_rows) hipLaunchKernelGGL(k_row_nnz, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, d_report, width, n_rows, nnz.p);
-    size_t tb = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
-    DevBuf<uint8_t> tmp(c);
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, nnz.p, start.p, (uint64_t)0, n_rows + 1, rocprim::plus<uint64_t>(), st));
+    DevBuf<uint64_t> scan_state(c);
+    if ((rc = scan_state.alloc(scan_state_words(n_rows + 1)))) return rc;
+    HIP_TRY(scan_launch(ScanInU32{nnz.p}, ScanOutU64{start.p, 0ull}, n_rows + 1, scan_state.p, st));
     HIP_TRY(hipStreamSynchronize(st));
     uint64_t total = 0;
     HIP_TRY(hipMemcpy(&total, start.p + n_rows, 8, hipMemcpyDeviceToHost));
@@ -305,16 +291,7 @@ int unique_freq_hist(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, u
     int rc;
     if ((rc = kin.alloc(n)) || (rc = kout.alloc(n)) || (rc = uniq.alloc(n)) || (rc = runs.alloc(n)) || (rc = d_count.alloc(1))) return rc;
     hipLaunchKernelGGL(k_colour_freq_keys, dim3(grid_for_n(n)), dim3(256), 0, st, d_uc, d_freq, n, kin.p);
-    size_t tb = 0;
-    HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, kin.p, kout.p, n, 0u, 64u, st));
-    DevBuf<uint8_t> tmp(c);
-    if ((rc = tmp.alloc(tb))) return rc;
-    HIP_TRY(rocprim::radix_sort_keys(tmp.p, tb, kin.p, kout.p, n, 0u, 64u, st));
-    size_t tb2 = 0;
-    HIP_TRY(rocprim::run_length_encode(nullptr, tb2, kout.p, n, uniq.p, runs.p, d_count.p, st));
-    DevBuf<uint8_t> tmp2(c);
-    if ((rc = tmp2.alloc(tb2))) return rc;
-    HIP_TRY(rocprim::run_length_encode(tmp2.p, tb2, kout.p, n, uniq.p, runs.p, d_count.p, st));
+    if ((rc = cold_sort_keys_u64(c, st, kin.p, kout.p, n, 0u, 64u)) || (rc = cold_run_length_u64(c, st, kout.p, n, uniq.p, runs.p, d_count.p))) return rc;
     uint64_t nb = 0;
     HIP_TRY(hipMemcpyAsync(&nb, d_count.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

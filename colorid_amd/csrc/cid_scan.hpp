@@ -126,4 +126,23 @@ hipError_t scan_launch(In in, Out out, uint64_t n, uint64_t *state, hipStream_t 
     return hipGetLastError();
 }
 
+// plain arrays (in place allowed: a thread reads its elements before it writes them)
+struct ScanInU32 {
+    const uint32_t *p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+struct ScanInU64 {
+    const uint64_t *p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+struct ScanOutU32 {
+    uint32_t *p;
+    __device__ void operator()(uint64_t i, uint64_t excl, uint64_t) const { p[i] = (uint32_t)excl; }
+};
+struct ScanOutU64 {
+    uint64_t *p;
+    uint64_t init;   // added to every prefix
+    __device__ void operator()(uint64_t i, uint64_t excl, uint64_t) const { p[i] = init + excl; }
+};
+
 }  // namespace cid
