@@ -20,6 +20,7 @@ struct cid_tunables {
     int order_bits = 0;               // cid_kmerset_order_for_index: 0 = by the first row's 128-byte line, b = by its b leading bits
     long fastq_refuse_at_step = -1;   // tests: cid_fastq_classify_begin refuses its n-th step (as it does a stretch it cannot take); -1 = never
     long readid_long_from = -1;       // reads of at least this many bases take the long-read path (-1: the shipped rule, readid_route)
+    bool readid_long_deal = true;     // long reads of four buckets and more: their windows dealt to the buckets once (false: every bucket re-reads the read)
     bool readid_long_lds = true;      // long reads: per-read sets by LDS hash tables (cid_readlong.hip); false = round 1's global radix sort
     // the two measured-and-rejected schedulings of k_search_count; only a `make TUNE=1` build contains their kernels
     bool search_persist = false;      // persistent grid, one work queue per XCD

@@ -40,7 +40,11 @@ constexpr uint32_t kLongFill = kLongSlotsBig / 2;                 // distinct k-
 constexpr uint32_t kLongMaxLevel = 7;
 constexpr uint32_t kSliceWindows = 4096;                          // windows per slice of the search
 
-struct LongItem { uint32_t read, bucket, n_buckets, pad; };
+struct LongItem { uint32_t read, bucket, n_buckets, deal; };   // deal: 1 + index of the read's LongDeal, 0 = the pass reads the code array itself
+// A read of several buckets, dealt: its windows are cut into chunks of kDealChunk, every chunk's (code, window) pairs of bucket b lie in
+// segment (b, chunk) of `cap` places — pairs[pair_base + (b * n_chunks + chunk) * cap ..], their number in counts[count_base + b * n_chunks + chunk].
+struct LongDeal { uint64_t pair_base; uint32_t count_base, n_chunks, cap, read; };
+constexpr uint32_t kDealChunk = 16384, kDealFromBuckets = 4;
 
 __device__ __forceinline__ uint64_t long_mix(uint64_t x) {   // a bijection of the 64-bit codes: distinct codes never share all their bits
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -49,10 +53,47 @@ __device__ __forceinline__ uint64_t long_mix(uint64_t x) {   // a bijection of t
     return x;
 }
 
+// The pre-pass of long reads (more than kDealFromBuckets buckets): every bucket's workgroup used to re-read and re-hash ALL the read's
+// windows to find its own — 100 kb reads 11.1 ms, 1 Mb reads 26.9 ms per 150 Mbases against 8.0 at 10 kb.  Here a workgroup takes one
+// chunk of a read and deals its (code, window) pairs to the buckets' segments once (LDS counters hand out the places); a bucket's pass
+// then reads its own pairs only.  A segment has room for the mean + 25 % + 96 (the mixed codes spread evenly: four standard deviations
+// are 12 % at 16 384 / 7 per segment, less at more buckets' smaller means only in absolute terms — hence the + 96); one that
+// overflows anyway raises flags[1] and the batch is redone on the sorting path.
+__global__ __launch_bounds__(256) void k_long_deal(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongDeal *deals, const uint32_t *chunk_deal,
+                                                   const uint32_t *chunk_no, uint32_t n_chunks_all, uint64_t sentinel, uint64_t *pair_code, uint32_t *pair_idx,
+                                                   uint32_t *counts, int *flags) {
+    __shared__ uint32_t s_cnt[256];
+    for (uint32_t ci = blockIdx.x; ci < n_chunks_all; ci += gridDim.x) {
+        const LongDeal d = deals[chunk_deal[ci]];
+        const uint32_t j = chunk_no[ci];
+        const uint64_t w0 = wstart[d.read];
+        const uint32_t nw = (uint32_t)(wend[d.read] - w0);
+        const uint32_t P = (nw + kLongFill - 1) / kLongFill;   // (as the host counted them: <= 256)
+        const uint32_t a = j * kDealChunk, b = a + kDealChunk < nw ? a + kDealChunk : nw;
+        s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t w = a + threadIdx.x; w < b; w += blockDim.x) {
+            const uint64_t code = codes[w0 + w];
+            if (code >= sentinel) continue;
+            const uint32_t bk = (uint32_t)(((long_mix(code) >> 32) * P) >> 32);
+            const uint32_t at = atomicAdd(&s_cnt[bk], 1u);
+            if (at < d.cap) {
+                const uint64_t o = d.pair_base + ((uint64_t)bk * d.n_chunks + j) * d.cap + at;
+                pair_code[o] = code;
+                pair_idx[o] = w;
+            } else atomicOr(&flags[1], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < P) counts[d.count_base + threadIdx.x * d.n_chunks + j] = s_cnt[threadIdx.x] < d.cap ? s_cnt[threadIdx.x] : d.cap;
+        __syncthreads();
+    }
+}
+
 // One workgroup per work item at a time; XCD x walks the x-th eighth of the items so that the passes over one read's codes meet in
 // one L2 (workgroups are dealt to the XCDs in turn).  gridDim.x is a multiple of 8.
 __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongItem *items, uint32_t n_items, uint64_t sentinel,
-                                   uint32_t slots, uint32_t bm_words, uint32_t *bitmap, int *flags) {
+                                   uint32_t slots, uint32_t bm_words, uint32_t *bitmap, int *flags, const LongDeal *deals, const uint64_t *pair_code,
+                                   const uint32_t *pair_idx, const uint32_t *deal_counts) {
     extern __shared__ uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
     __shared__ int s_over;
     uint32_t *bm = table + slots;
@@ -74,12 +115,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
             for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) table[s] = kLongEmpty;
             if (threadIdx.x == 0) s_over = 0;
             __syncthreads();
-            for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
-                const uint64_t code = rc[w];
-                if (code >= sentinel) continue;   // (no k-mer in this window)
-                const uint64_t h = long_mix(code);
-                if (im.n_buckets > 1 && (uint32_t)(((h >> 32) * im.n_buckets) >> 32) != im.bucket) continue;
-                if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
+            auto insert = [&](uint64_t code, uint32_t w, uint64_t h) {
                 const uint32_t tag = (uint32_t)(h >> 15) & ((1u << kLongTagBits) - 1u);
                 const uint32_t mine = (w << kLongTagBits) | tag;
                 uint32_t pos = (uint32_t)h & mask;
@@ -96,6 +132,27 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                     pos = (pos + 1) & mask;
                     if (probes >= slots / 4) { s_over = 1; break; }   // a crowded table: the pass is redone on sub-buckets
                 }
+            };
+            if (im.deal) {   // the bucket's own pairs, chunk after chunk
+                const LongDeal d = deals[im.deal - 1];
+                for (uint32_t j = 0; j < d.n_chunks; ++j) {
+                    const uint32_t n = deal_counts[d.count_base + im.bucket * d.n_chunks + j];
+                    const uint64_t o = d.pair_base + ((uint64_t)im.bucket * d.n_chunks + j) * d.cap;
+                    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                        const uint64_t code = pair_code[o + i];
+                        const uint64_t h = long_mix(code);
+                        if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
+                        insert(code, pair_idx[o + i], h);
+                    }
+                }
+            } else
+            for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
+                const uint64_t code = rc[w];
+                if (code >= sentinel) continue;   // (no k-mer in this window)
+                const uint64_t h = long_mix(code);
+                if (im.n_buckets > 1 && (uint32_t)(((h >> 32) * im.n_buckets) >> 32) != im.bucket) continue;
+                if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
+                insert(code, w, h);
             }
             __syncthreads();
             if (s_over) {   // (workgroup-uniform)
@@ -185,6 +242,10 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     std::vector<uint8_t> status(n_reads, 0);
     std::vector<Segment> segs;
     std::vector<LongItem> items_small, items_big;
+    std::vector<LongDeal> deals;
+    std::vector<uint32_t> chunk_deal, chunk_no;   // the chunks of the dealt reads: which deal, which chunk of it
+    uint64_t n_pairs = 0;
+    uint32_t n_deal_counts = 0;
     std::vector<ReadSlice> slices;
     std::vector<ReadCombine> combs;
     const uint32_t seg_win = kSegWindows / stride_d ? kSegWindows / stride_d : 1;
@@ -214,7 +275,17 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         if (win <= kLongSmallWin) items_small.push_back(LongItem{(uint32_t)r, 0u, 1u, 0u});
         else {
             const uint32_t P = (uint32_t)((win + kLongFill - 1) / kLongFill);
-            for (uint32_t b = 0; b < P; ++b) items_big.push_back(LongItem{(uint32_t)r, b, P, 0u});
+            uint32_t deal = 0;
+            if (P >= kDealFromBuckets && c->tune.readid_long_deal) {
+                const uint32_t nc = (uint32_t)((win + kDealChunk - 1) / kDealChunk);
+                const uint32_t cap = kDealChunk / P + kDealChunk / P / 4 + 96;
+                deals.push_back(LongDeal{n_pairs, n_deal_counts, nc, cap, (uint32_t)r});
+                deal = (uint32_t)deals.size();
+                n_pairs += (uint64_t)P * nc * cap;
+                n_deal_counts += P * nc;
+                for (uint32_t j = 0; j < nc; ++j) { chunk_deal.push_back(deal - 1); chunk_no.push_back(j); }
+            }
+            for (uint32_t b = 0; b < P; ++b) items_big.push_back(LongItem{(uint32_t)r, b, P, deal});
         }
         if (own_search) {
             const uint32_t n_sl = cut ? (uint32_t)((win + kSliceWindows - 1) / kSliceWindows) : 1u;
@@ -234,25 +305,30 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     // the host-made arrays travel as ONE block, before the first kernel, through the ctx's pinned arena when they fit: a copy out of
     // pageable memory makes the runtime wait for the stream, and one issued between two kernels stalls the launch of the second
     struct Part { const void *src; size_t bytes, off; };
-    Part parts[7] = {{wstart.data(), (n_reads + 1) * 8, 0}, {wend.data(), n_reads * 8, 0}, {segs.data(), segs.size() * sizeof(Segment), 0},
-                     {items_small.data(), items_small.size() * sizeof(LongItem), 0}, {items_big.data(), items_big.size() * sizeof(LongItem), 0},
-                     {slices.data(), slices.size() * sizeof(ReadSlice), 0}, {combs.data(), combs.size() * sizeof(ReadCombine), 0}};
+    Part parts[10] = {{wstart.data(), (n_reads + 1) * 8, 0}, {wend.data(), n_reads * 8, 0}, {segs.data(), segs.size() * sizeof(Segment), 0},
+                      {items_small.data(), items_small.size() * sizeof(LongItem), 0}, {items_big.data(), items_big.size() * sizeof(LongItem), 0},
+                      {slices.data(), slices.size() * sizeof(ReadSlice), 0}, {combs.data(), combs.size() * sizeof(ReadCombine), 0},
+                      {deals.data(), deals.size() * sizeof(LongDeal), 0}, {chunk_deal.data(), chunk_deal.size() * 4, 0}, {chunk_no.data(), chunk_no.size() * 4, 0}};
     size_t meta_bytes = (n_reads + 15) & ~(size_t)15;   // the status bytes lead the block
     for (Part &pt : parts) { pt.off = meta_bytes; meta_bytes += (pt.bytes + 15) & ~(size_t)15; }
     DevBuf<uint64_t> d_codes(c), d_list(c), d_lstart(c), d_scan(c);
-    DevBuf<uint32_t> d_bitmap(c), d_prefix(c), d_partial(c);
+    DevBuf<uint32_t> d_bitmap(c), d_prefix(c), d_partial(c), d_pair_idx(c), d_deal_counts(c);
+    DevBuf<uint64_t> d_pair_code(c);
     DevBuf<uint8_t> d_meta(c);
     DevBuf<int> d_flags(c);
     int rc;
     if ((rc = d_meta.alloc(meta_bytes + 16)) || (rc = d_codes.alloc(W + 1)) || (rc = d_scan.alloc(scan_state_words(n_words))) ||
         (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
-        (rc = d_partial.alloc(combs.empty() ? 1 : slices.size() * (C1 + 1))) || (rc = d_flags.alloc(4)))
+        (rc = d_partial.alloc(combs.empty() ? 1 : slices.size() * (C1 + 1))) || (rc = d_flags.alloc(4)) ||
+        (rc = d_pair_code.alloc(n_pairs)) || (rc = d_pair_idx.alloc(n_pairs)) || (rc = d_deal_counts.alloc(n_deal_counts)))
         return rc;
     const uint64_t *d_wstart = reinterpret_cast<const uint64_t *>(d_meta.p + parts[0].off), *d_wend = reinterpret_cast<const uint64_t *>(d_meta.p + parts[1].off);
     const Segment *d_segs = reinterpret_cast<const Segment *>(d_meta.p + parts[2].off);
     const LongItem *d_items_small = reinterpret_cast<const LongItem *>(d_meta.p + parts[3].off), *d_items_big = reinterpret_cast<const LongItem *>(d_meta.p + parts[4].off);
     const ReadSlice *d_slices = reinterpret_cast<const ReadSlice *>(d_meta.p + parts[5].off);
     const ReadCombine *d_combs = reinterpret_cast<const ReadCombine *>(d_meta.p + parts[6].off);
+    const LongDeal *d_deals = reinterpret_cast<const LongDeal *>(d_meta.p + parts[7].off);
+    const uint32_t *d_chunk_deal = reinterpret_cast<const uint32_t *>(d_meta.p + parts[8].off), *d_chunk_no = reinterpret_cast<const uint32_t *>(d_meta.p + parts[9].off);
     if (uint8_t *pin = pin_reserve(c, meta_bytes + 64)) {
         HIP_TRY(hipStreamSynchronize(st));   // (the arena may still feed an earlier copy)
         memcpy(pin, status.data(), n_reads);
@@ -275,18 +351,26 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
                            d_flags.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr, KeyFor{});
         if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
         const unsigned n_cu = (unsigned)ctx_n_cu(c);
+        if (!chunk_deal.empty()) {
+            unsigned g = (unsigned)chunk_deal.size();
+            if (g > n_cu * 8u) g = n_cu * 8u;
+            hipLaunchKernelGGL(k_long_deal, dim3(g), dim3(256), 0, st, d_codes.p, d_wstart, d_wend, d_deals, d_chunk_deal, d_chunk_no, (uint32_t)chunk_deal.size(),
+                               sentinel, d_pair_code.p, d_pair_idx.p, d_deal_counts.p, d_flags.p);
+        }
         if (!items_small.empty()) {
             unsigned g = n_cu * 4u;   // four 32-KiB workgroups per CU
             g = (g + 7u) & ~7u;
             hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockSmall), (kLongSlotsSmall + kLongBmSmall) * 4, st, d_codes.p, d_wstart, d_wend, d_items_small,
-                               (uint32_t)items_small.size(), sentinel, kLongSlotsSmall, kLongBmSmall, d_bitmap.p, d_flags.p);
+                               (uint32_t)items_small.size(), sentinel, kLongSlotsSmall, kLongBmSmall, d_bitmap.p, d_flags.p, d_deals, d_pair_code.p, d_pair_idx.p,
+                               d_deal_counts.p);
         }
         if (!items_big.empty()) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_first_flags), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)((kLongSlotsBig + kLongBmBig) * 4)));
             unsigned g = (n_cu + 7u) & ~7u;
             hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), (kLongSlotsBig + kLongBmBig) * 4, st, d_codes.p, d_wstart, d_wend,
-                               d_items_big, (uint32_t)items_big.size(), sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p);
+                               d_items_big, (uint32_t)items_big.size(), sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p, d_deals, d_pair_code.p,
+                               d_pair_idx.p, d_deal_counts.p);
         }
         HIP_TRY(hipGetLastError());
         if (!own_search) {   // wide rows and stripe passes add into rows in place: what would send the batch to the sorting path (see the

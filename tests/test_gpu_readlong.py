@@ -81,14 +81,20 @@ def test_breaks_in_every_slice_position(orc, hip_ctx):
     hx.close()
 
 
-def test_megabase_read_and_many_buckets(orc, hip_ctx):
+@pytest.mark.parametrize("deal", [1, 0])
+def test_megabase_read_and_many_buckets(orc, hip_ctx, deal):
+    """74 buckets: their windows dealt to them by the pre-pass (k_long_deal), or every bucket's pass re-reading the read"""
+    hip_ctx.tune("readid_long_deal", deal)
     rng = np.random.default_rng(3)
     n_colors, n_hash, k, m = 64, 2, 21, 1_000_003
     oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.2, zero_row_frac=0.0)
     hx = to_hip_index(hip_ctx, oix)
     g = rnd(rng, 1_200_000)
     reads = [[g], [g[:300_000] + g[:300_000]], [g[:5_000]]]
-    rep, nk, st = compare(oix, hx, reads, 1, 3)
+    try:
+        rep, nk, st = compare(oix, hx, reads, 1, 3)
+    finally:
+        hip_ctx.tune("readid_long_deal", 1)
     assert nk[0] > 1_190_000 and nk[1] < 300_100
     hx.close()
 
