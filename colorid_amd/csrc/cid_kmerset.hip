@@ -17,6 +17,7 @@
 #include "cid_partition.hpp"
 #include "cid_scan.hpp"
 #include "cid_rle.hpp"
+#include "cid_merge.hpp"
 #include "cid_kmerset_obj.hpp"
 #include "cid_devbuf.hpp"
 
@@ -354,7 +355,38 @@ int compact(cid_kmerset *ks) {
         return CID_OK;
     }
     if (n_runs == 0) return CID_OK;
-    return cid::kmerset_merge_batch(ks, uniq.p, agg.p, n_runs);   // (cid_kmerset_cold.hip)
+    // the batch joins the set: two sorted lists merged in one pass, equal k-mers' multiplicities added (cid_merge.hpp; rocPRIM's merge +
+    // reduce_by_key until round 5 — kmerset_merge_batch in cid_kmerset_cold.hip, kept as CID_KMERSET_COLD_MERGE=1 for A/B runs)
+    const bool cold_merge = getenv("CID_KMERSET_COLD_MERGE") && atoi(getenv("CID_KMERSET_COLD_MERGE")) != 0;
+    if (cold_merge) return cid::kmerset_merge_batch(ks, uniq.p, agg.p, n_runs);
+    const size_t total = ks->n + n_runs;
+    const uint32_t tiles = cid::merge_tiles(ks->n, n_runs);
+    DevBuf<uint64_t> ok(ks->ctx), split(ks->ctx), mstate(ks->ctx);
+    DevBuf<uint32_t> ov(ks->ctx), ka(ks->ctx), kb(ks->ctx);
+    if ((rc = ok.alloc(total)) || (rc = ov.alloc(total)) || (rc = split.alloc(2 * ((size_t)tiles + 1))) || (rc = mstate.alloc((size_t)tiles + 2))) return rc;
+    if (ks->targeted) {   // both lists are in (row0_key, code) order: merged on that pair (the keys are recomputed from the codes, not kept)
+        if ((rc = ka.alloc(ks->n)) || (rc = kb.alloc(n_runs))) return rc;
+        hipLaunchKernelGGL(cid::k_row0_keys, dim3(grid_for_n(ks->n)), dim3(256), 0, st, ks->codes, ks->k, ks->key_for, ka.p, (uint64_t)ks->n);
+        hipLaunchKernelGGL(cid::k_row0_keys, dim3(grid_for_n(n_runs)), dim3(256), 0, st, uniq.p, ks->k, ks->key_for, kb.p, (uint64_t)n_runs);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemsetAsync(ks->d_flags + 1, 0, 4, st));
+    HIP_TRY(cid::merge_launch(ks->targeted ? ka.p : nullptr, ks->codes, ks->counts, ks->n, ks->targeted ? kb.p : nullptr, uniq.p, agg.p, n_runs, ok.p, ov.p, split.p,
+                              mstate.p, ks->d_flags + 1, st));
+    int sat = 0;
+    uint64_t n_merged = 0;
+    HIP_TRY(hipMemcpyAsync(&sat, ks->d_flags + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&n_merged, mstate.p + tiles + 1, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // multiplicities are u32 (the reference: usize): a sum that saturated cannot be reported faithfully
+    if (sat) return fail(CID_ERR_UNSUPPORTED,
+                         "a k-mer occurs more than 2^32 - 2 times: beyond the u32 multiplicities of the GPU k-mer set (count on the host)");
+    cid::ctx_free(ks->ctx, ks->codes);
+    cid::ctx_free(ks->ctx, ks->counts);
+    ks->codes = ok.release();
+    ks->counts = ov.release();
+    ks->n = n_merged;
+    return CID_OK;
 }
 
 }  // namespace

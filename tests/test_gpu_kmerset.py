@@ -189,13 +189,16 @@ def test_byte_string_sets_k_above_32(orc, hip_ctx, k):
     ks.close()
 
 
-@pytest.mark.parametrize("cold_sort", [False, True])
-def test_incremental_merge_path(orc, hip_ctx, monkeypatch, cold_sort):
-    """later batches are merged into the set (cid_kmerset_cold.hip); cold_sort: the batches themselves through the LSD sorts there too"""
+@pytest.mark.parametrize("cold_sort,cold_merge", [(False, False), (True, False), (False, True)])
+def test_incremental_merge_path(orc, hip_ctx, monkeypatch, cold_sort, cold_merge):
+    """later batches are merged into the set (cid_merge.hpp: merge path, twins joined, one pass); cold_sort: the batches themselves through
+    rocPRIM's LSD sorts; cold_merge: rocPRIM's merge + reduce_by_key (both in cid_kmerset_cold.hip)"""
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "20000")   # force sort-pairs + reduce-by-key merges
+    monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "20000")   # a merge every few batches
     if cold_sort:
         monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1000000000")
+    if cold_merge:
+        monkeypatch.setenv("CID_KMERSET_COLD_MERGE", "1")
     rng = np.random.default_rng(3)
     genome = rand_seq(rng, 30000)
     batches = [[genome[s:s + 400] for s in rng.integers(0, len(genome) - 400, 200)] for _ in range(6)]
@@ -232,6 +235,37 @@ def test_histogram_with_multiplicities_beyond_the_lds_bins(orc, hip_ctx):
     ks.clean(4095)
     assert len(ks) == sum(c for v, c in hist.items() if v > 4095) and all(v > 4095 for v in ks.as_dict().values())
     ks.close()
+
+
+@pytest.mark.parametrize("targeted", [False, True])
+def test_merge_of_large_lists_with_every_kind_of_overlap(orc, hip_ctx, monkeypatch, targeted):
+    """cid_merge.hpp beyond one tile: a set of ~400 k k-mers joined by batches that repeat it wholly, partly and not at all (twins at tile and
+    thread borders occur by the thousand), in code order and built for an index; against one set counted in one go"""
+    import colorid_amd
+    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")
+    rng = np.random.default_rng(23)
+    g1, g2, g3 = rand_seq(rng, 200_000), rand_seq(rng, 150_000), rand_seq(rng, 120_000)
+    batches = [[g1, g2], [g2], [g3, g1[:50_000]], [g1, g2, g3], [rand_seq(rng, 10)], [g3[60_000:]]]
+    k = 25
+    hx = colorid_amd.Index(hip_ctx, 3_000_017, 3, k, 8)
+    hx.finalize()
+    one = colorid_amd.KmerSet(hip_ctx, k)
+    if targeted:
+        one.set_target_index(hx)
+    one.add_seqs([s for b in batches for s in b], 0)
+    n_one = one.finalize()
+    monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "1000")   # every batch is merged into the set as it comes
+    many = colorid_amd.KmerSet(hip_ctx, k)
+    if targeted:
+        many.set_target_index(hx)
+    for b in batches:
+        many.add_seqs(b, 0)
+    assert many.finalize() == n_one and n_one > 400_000
+    k1, c1 = one.download()
+    k2, c2 = many.download()
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2)     # same k-mers, same order, same multiplicities
+    assert int(c1.max()) >= 3
+    one.close(); many.close(); hx.close()
 
 
 def test_phage_fixture_counts(orc, hip_ctx):
