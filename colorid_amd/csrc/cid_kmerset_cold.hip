@@ -3,7 +3,7 @@
 // query of reads against an index (window codes -> the set's own sort -> run-length count -> search: cid_kmerset.hip, cid_partition.hpp,
 // cid_scan.hpp).  The runtime loads a unit's code object on the first launch of one of its kernels: a process that never comes here
 // never pays for it.  What is here: byte-string sets (k > 32: kmer.rs:87-125 on strings), LSD sorts for inputs the MSD partition does
-// not take (badly skewed codes, runs beyond a workgroup's LDS), the merge of a later batch into a set that already holds k-mers,
+// not take (badly skewed codes, runs beyond a workgroup's LDS), rocPRIM's merge of a later batch (CID_KMERSET_COLD_MERGE=1: the A/B copy of cid_merge.hpp),
 // reordering a finished set for an index, the merged ranges of a multi-GPU set, round 1's sort-based long-read path (byte-string keys).
 #include <cstring>
 

@@ -1,6 +1,6 @@
 // The object behind the ABI's cid_kmerset handle and the entry points that connect its two translation units: cid_kmerset.hip — the
 // steady-state path (window codes, the set's own MSD sort, run-length count: this repository's kernels only) — and
-// cid_kmerset_cold.hip — what a query meets rarely or never (byte-string sets, badly skewed or tiny inputs, later batches' merges,
+// cid_kmerset_cold.hip — what a query meets rarely or never (byte-string sets, badly skewed inputs, the A/B copy of the batch merge,
 // reordering after the fact, round 1's long-read sort), built on rocPRIM, whose code object of some thousand kernels is loaded only
 // when one of these is called.
 #pragma once
