@@ -139,7 +139,7 @@ uint8_t *pin_reserve(cid_ctx *c, size_t bytes, size_t cap) {
 extern "C" {
 
 const char *cid_last_error(void) { return g_err; }
-int cid_abi_version(void) { return 3; }
+int cid_abi_version(void) { return 4; }   // 4: + cid_readid_count_resident; bgzf launches take scratch (internal)
 
 int cid_device_count(int *n) {
     if (!n) return fail(CID_ERR_INVALID, "null out");

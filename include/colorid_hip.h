@@ -58,7 +58,7 @@ typedef struct cid_ctx cid_ctx;     /* one HIP device + stream + scratch */
 typedef struct cid_index cid_index; /* device-resident dense bit matrix: bloom_size rows x n_colors bits */
 
 const char *cid_last_error(void);
-int cid_abi_version(void);
+int cid_abi_version(void);   /* 4 (round 5: + cid_readid_count_resident; 3: per-context cid_ctx_tune) */
 int cid_device_count(int *n_devices);
 
 /* ---- context ---- */
@@ -283,9 +283,12 @@ int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, c
                          uint8_t *d_status);
 
 /* The bases already in HBM (the caller uploaded or produced them), the offsets on the host: reads of ANY length — each read is
- * routed, inside the batch, to the per-wave LDS kernels or to the long-read path (src/read_id_mt_pe.rs:282-363 takes any read
- * length; src/kmer.rs:221-243).  Asynchronous on the ctx stream except where a mixed batch's routing table leaves scope; results go
- * to the caller's DEVICE arrays report[n_reads x (n_colors+1)], n_kmers[n_reads], status[n_reads] (status 1 = too_short). */
+ * routed, inside the batch, to the per-wave LDS kernels (up to ~900 bases) or to the long-read path (cid_readlong.hip: per-read k-mer
+ * sets by workgroup-wide LDS hash tables, the ordered search by slices of a read; src/read_id_mt_pe.rs:282-363 takes any read
+ * length; src/kmer.rs:221-243).  A batch of short reads only is asynchronous on the ctx stream; one that holds long reads is waited
+ * for ONCE, at the end of the call (the host-made work lists leave scope there, and a lower-case base among the long reads — their
+ * case is kept — sends the batch through the byte-string path).  Results go to the caller's DEVICE arrays
+ * report[n_reads x (n_colors+1)], n_kmers[n_reads], status[n_reads] (status 1 = too_short). */
 int cid_readid_count_resident(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs,
                               const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                               uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status);

@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/colorid_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.cid_abi_version() == 3
+    assert lib.cid_abi_version() == 4
 
 
 def test_the_library_exports_its_abi_and_nothing_else():
