@@ -154,3 +154,51 @@ def test_lower_case_among_long_reads_falls_back(orc, hip_ctx):
     low[12_345:12_400] = bytes(low[12_345:12_400]).lower()
     compare(oix, hx, [[g[:20_000]], [bytes(low)], [g[100:260]], [g[:9_000].lower(), g[:9000]]], 1, 3)
     hx.close()
+
+
+def _random_long_read(rng, genome, k):
+    """a read of 1 kb ... 120 kb made of stretches of the genome: some repeated, some with N runs, some reverse-complemented"""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    L = int(rng.choice([1_000, 1_500, 3_000, 4_100, 9_000, 16_500, 33_000, 70_000, 120_000]))
+    parts, have = [], 0
+    while have < L:
+        n = int(min(L - have, rng.integers(200, 20_000)))
+        st = int(rng.integers(0, len(genome) - n))
+        p = genome[st:st + n]
+        kind = int(rng.integers(0, 8))
+        if kind == 0:
+            p = p.translate(comp)[::-1]                    # the canonical k-mers of the other strand: the same k-mers
+        elif kind == 1 and parts:
+            p = parts[int(rng.integers(0, len(parts)))][:n]  # an earlier stretch again
+        elif kind == 2:
+            a = bytearray(p); s0 = int(rng.integers(0, n)); a[s0:s0 + int(rng.integers(1, 3 * k))] = b"N" * len(a[s0:s0 + int(rng.integers(1, 3 * k))]); p = bytes(a)
+        elif kind == 3:
+            p = (p[:int(rng.integers(1, 30))] * (n // 1 + 1))[:n]   # a short period
+        parts.append(p); have += len(p)
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FUZZ_SEED0", 0)), int(__import__("os").environ.get("FUZZ_SEED0", 0)) + int(__import__("os").environ.get("FUZZ_N", 10))))
+def test_long_reads_random_shapes(orc, hip_ctx, seed):
+    """random index shapes (k, hashes, colours, absent rows), strides and `-B`, random long reads and pairs of them, short reads between"""
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.choice([11, 15, 21, 25, 31, 32]))
+    n_hash = int(rng.integers(1, 5))
+    C = int(rng.choice([3, 64, 65, 256, 700, 2000]))
+    m = int(rng.choice([20_011, 65_536, 300_007]))
+    oix = random_index(orc, rng, m, n_hash, k, C, density=float(rng.choice([0.02, 0.2])), zero_row_frac=float(rng.choice([0.0, 0.0005, 0.01])))
+    hx = to_hip_index(hip_ctx, oix)
+    genome = rnd(rng, 150_000)
+    reads = []
+    for _ in range(int(rng.integers(3, 9))):
+        r = [_random_long_read(rng, genome, k)]
+        if rng.random() < 0.3:
+            r.append(_random_long_read(rng, genome, k)[:int(rng.integers(1, 30_000))])
+        reads.append(r)
+        if rng.random() < 0.5:
+            st = int(rng.integers(0, len(genome) - 300))
+            reads.append([genome[st:st + int(rng.integers(1, 300))]])
+    d = int(rng.choice([1, 1, 2, 5]))
+    S = int(rng.choice([0, 1, 3, 3, 50, 64, 65, 4000]))
+    compare(oix, hx, reads, d, S, (seed, k, n_hash, C, m, d, S))
+    hx.close()
