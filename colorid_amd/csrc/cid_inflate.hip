@@ -670,6 +670,18 @@ __device__ __noinline__ bool wave_build_tables(const uint8_t *lens, uint32_t n_s
 template <bool WRITE>
 __device__ ChunkEnd decode_chunk(GBits &br, uint32_t limit, const WaveLds &L, uint8_t *img, uint32_t out_off, uint32_t out_len, uint2 *tok, uint32_t tok_off) {
     ChunkEnd r{0, 0, 0, 0};
+    // WRITE: a run of literals leaves eight bytes per store (any alignment), what is left of it when a match or the chunk's end comes in 4 / 2 / 1
+    // (one byte per store made the writing pass the most expensive one under load: 64 lanes x 1 byte to 64 lines per instruction)
+    uint64_t acc = 0;
+    uint32_t n_acc = 0, at_acc = out_off;
+    auto flush = [&]() {
+        uint8_t *q = img + at_acc;
+        uint64_t v = acc;
+        if (n_acc & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(q, &w, 4); q += 4; v >>= 32; }
+        if (n_acc & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(q, &h, 2); q += 2; v >>= 16; }
+        if (n_acc & 1u) *q = (uint8_t)v;
+        acc = 0; n_acc = 0;
+    };
     while (br.pos < limit) {
         br.refill();
         const int sym = decode_sym(br, L.lit, kWLitBits, L.lcnt, L.lsym);
@@ -677,7 +689,8 @@ __device__ ChunkEnd decode_chunk(GBits &br, uint32_t limit, const WaveLds &L, ui
         if (sym < 256) {
             if (WRITE) {
                 if (out_off + r.n_out >= out_len) { r.flags = 2; break; }
-                img[out_off + r.n_out] = (uint8_t)sym;
+                acc |= (uint64_t)(uint32_t)sym << (8u * n_acc);
+                if (++n_acc == 8u) { __builtin_memcpy(img + at_acc, &acc, 8); at_acc += 8; acc = 0; n_acc = 0; }
             }
             ++r.n_out;
         } else if (sym == 256) {
@@ -697,12 +710,15 @@ __device__ ChunkEnd decode_chunk(GBits &br, uint32_t limit, const WaveLds &L, ui
                 const uint32_t at = out_off + r.n_out;
                 if (dist > at || at + len > out_len) { r.flags = 2; break; }
                 tok[tok_off + r.n_tok] = make_uint2(at | (len << 16), dist);
+                if (n_acc) flush();
+                at_acc = at + len;   // the next literal lands behind the match
             }
             r.n_out += len;
             ++r.n_tok;
         }
         if (r.n_out > (1u << 20)) { r.flags = 2; break; }   // (a guessed start decoding nonsense: nothing of it is used)
     }
+    if (WRITE && n_acc) flush();
     r.end_pos = br.pos;
     return r;
 }
