@@ -21,50 +21,68 @@
 // reports.rs:65-77 on the vectors batch_search_pe.rs:75-82 fills: per colour, the most frequent multiplicity among the k-mers that
 // hit exactly that colour (ties -> the smallest value; the reference's tie is HashMap order).  Done on the device so that neither
 // the per-k-mer unique colours nor the multiplicities (4 + 4 bytes per k-mer) have to cross PCIe for the report.
-//   small multiplicities (f < FL): a colour x FL table of counts, privatised per workgroup in LDS, flushed with global atomics;
+//   small multiplicities (f < FL): a table of (colour, f) counts, privatised per workgroup in LDS (mode_cell), flushed with global atomics;
 //   the rest: appended as (colour << 32 | f) keys, then sorted and run-length counted;
 //   every (colour, f, count) cell proposes count << 32 | ~f to an atomicMax per colour: highest count wins, ties go to the smaller f.
 namespace cid {
 
-__global__ __launch_bounds__(256) void k_mode_hist(const uint32_t *uc, const uint32_t *freq, uint64_t n, uint32_t C, uint32_t FL, uint64_t per_block,
-                                                   uint32_t *table, uint64_t *ovf, unsigned long long *ovf_count) {
+// Cell (c, f) lives at f * Cp + ((c + f) & (Cp - 1)), Cp = the power of two at or above max(C, 64): a wave's 64 atomics spread over the LDS
+// banks when the colours differ (every multiplicity 1: reads of a metagenome) AND when the multiplicities differ (one colour: an isolate at
+// coverage) — colour-major cells put the first case into ONE bank, 64 atomics one after the other (0.88 ms per 120 M k-mers; 0.3 since).
+// A wave whose lanes all name the same cell adds its count once.
+constexpr uint32_t kModeBlock = 512, kModePer = 4;
+__device__ __forceinline__ uint32_t mode_cell(uint32_t c, uint32_t f, uint32_t cp_log) { return (f << cp_log) + ((c + f) & ((1u << cp_log) - 1u)); }
+
+__global__ __launch_bounds__(kModeBlock) void k_mode_hist(const uint32_t *uc, const uint32_t *freq, uint64_t n, uint32_t cp_log, uint32_t FL, uint64_t per_block,
+                                                          uint32_t *table, uint64_t *ovf, unsigned long long *ovf_count) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t *cells = reinterpret_cast<uint32_t *>(smem);
-    const uint32_t n_cells = C * FL;
-    for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x) cells[i] = 0;
+    const uint32_t n_cells = FL << cp_log;
+    for (uint32_t i = threadIdx.x; i < n_cells; i += kModeBlock) cells[i] = 0;
     __syncthreads();
     const uint64_t i0 = (uint64_t)blockIdx.x * per_block;
     const uint64_t i1 = i0 + per_block < n ? i0 + per_block : n;
     const int lane = threadIdx.x & 63;
-    for (uint64_t base = i0; base < i1; base += blockDim.x) {   // block-uniform trip count: the ballot below sees whole waves
-        const uint64_t i = base + threadIdx.x;
-        bool big = false;
-        uint64_t key = 0;
-        if (i < i1) {
-            const uint32_t c = uc[i];
-            if (c != 0xFFFFFFFFu) {
-                const uint32_t f = freq ? freq[i] : 1u;
-                if (f < FL) atomicAdd(&cells[c * FL + f], 1u);
-                else { big = true; key = ((uint64_t)c << 32) | f; }
-            }
+    for (uint64_t base = i0; base < i1; base += kModeBlock * kModePer) {   // block-uniform trip count: the ballots below see whole waves
+        uint32_t c[kModePer], f[kModePer];
+#pragma unroll
+        for (uint32_t j = 0; j < kModePer; ++j) {   // the loads of the step leave together
+            const uint64_t i = base + j * kModeBlock + threadIdx.x;
+            c[j] = i < i1 ? uc[i] : 0xFFFFFFFFu;
+            f[j] = (i < i1 && freq) ? freq[i] : 1u;
         }
-        const uint64_t m = __ballot(big);
-        if (m) {
-            unsigned long long at = 0;
-            if (lane == 0) at = atomicAdd(ovf_count, (unsigned long long)__popcll(m));
-            at = (unsigned long long)__shfl((long long)at, 0, 64);
-            if (big) ovf[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+#pragma unroll
+        for (uint32_t j = 0; j < kModePer; ++j) {
+            const bool hit = c[j] != 0xFFFFFFFFu, small = hit && f[j] < FL, big = hit && !small;
+            const uint32_t cell = small ? mode_cell(c[j], f[j], cp_log) : 0xFFFFFFFFu;
+            const uint64_t ms = __ballot(small);
+            if (ms) {
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)cell, (int)__builtin_ctzll(ms));
+                const uint64_t same = __ballot(small && cell == first);
+                if (same == ms) {   // one cell for the whole wave
+                    if (lane == (int)__builtin_ctzll(ms)) atomicAdd(&cells[first], (uint32_t)__popcll(ms));
+                } else if (small) atomicAdd(&cells[cell], 1u);
+            }
+            const uint64_t m = __ballot(big);
+            if (m) {
+                unsigned long long at = 0;
+                if (lane == 0) at = atomicAdd(ovf_count, (unsigned long long)__popcll(m));
+                at = (unsigned long long)__shfl((long long)at, 0, 64);
+                if (big) ovf[at + (uint64_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)c[j] << 32) | f[j];
+            }
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < n_cells; i += kModeBlock)
         if (cells[i]) atomicAdd(&table[i], cells[i]);
 }
-__global__ void k_mode_pick_table(const uint32_t *table, uint32_t C, uint32_t FL, unsigned long long *best) {
+__global__ void k_mode_pick_table(const uint32_t *table, uint32_t C, uint32_t cp_log, uint32_t FL, unsigned long long *best) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * FL) return;
+    if (i >= (FL << cp_log)) return;
     const uint32_t v = table[i];
-    if (v) atomicMax(&best[i / FL], ((unsigned long long)v << 32) | (0xFFFFFFFFu - (i % FL)));
+    if (!v) return;
+    const uint32_t f = i >> cp_log, c = ((i & ((1u << cp_log) - 1u)) - f) & ((1u << cp_log) - 1u);
+    if (c < C) atomicMax(&best[c], ((unsigned long long)v << 32) | (0xFFFFFFFFu - f));
 }
 __global__ void k_mode_pick_runs(const uint64_t *keys, const uint32_t *runs, const uint64_t *n_runs, unsigned long long *best) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,26 +103,30 @@ int unique_freq_modes_begin(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_
     *w = ModeWork{};
     w->C = C;
     if (n >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mers");
+    uint32_t cp_log = 6;
+    while (cp_log < 31 && (1u << cp_log) < C) ++cp_log;       // colours padded to a power of two (mode_cell)
     uint32_t FL = 64;
-    while (FL > 1 && (uint64_t)C * FL > 16384) FL >>= 1;     // the per-workgroup table: at most 64 KiB of LDS
-    if ((uint64_t)C * FL > 16384) FL = 0;                     // very many colours: every (colour, f) goes through the sort
+    while (FL > 1 && ((uint64_t)FL << cp_log) > 16384) FL >>= 1;   // the per-workgroup table: at most 64 KiB of LDS
+    if (((uint64_t)FL << cp_log) > 16384) FL = 0;                  // very many colours: every (colour, f) goes through the sort
+    const size_t n_cells = FL ? (size_t)FL << cp_log : 1;
     DevBuf<uint32_t> table(c);
     DevBuf<uint64_t> ovf(c);
     DevBuf<unsigned long long> best(c), ovf_count(c);
     int rc;
-    if ((rc = table.alloc((size_t)C * (FL ? FL : 1))) || (rc = ovf.alloc(n ? n : 1)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2))) return rc;
-    HIP_TRY(hipMemsetAsync(table.p, 0, (size_t)C * (FL ? FL : 1) * 4, st));
+    if ((rc = table.alloc(n_cells)) || (rc = ovf.alloc(n ? n : 1)) || (rc = best.alloc(C)) || (rc = ovf_count.alloc(2))) return rc;
+    HIP_TRY(hipMemsetAsync(table.p, 0, n_cells * 4, st));
     HIP_TRY(hipMemsetAsync(best.p, 0, (size_t)C * 8, st));
     HIP_TRY(hipMemsetAsync(ovf_count.p, 0, 16, st));
     if (n) {
         const unsigned blocks = 1024;
+        constexpr uint64_t step = (uint64_t)kModeBlock * kModePer;
         uint64_t per_block = (n + blocks - 1) / blocks;
-        per_block = (per_block + 255) / 256 * 256;
+        per_block = (per_block + step - 1) / step * step;
         const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
-        const size_t shmem = (size_t)C * FL * 4;
+        const size_t shmem = FL ? n_cells * 4 : 0;
         if (shmem > 64 * 1024) return fail(CID_ERR_UNSUPPORTED, "mode table");
-        hipLaunchKernelGGL(k_mode_hist, dim3(grid), dim3(256), shmem, st, d_uc, d_freq, n, C, FL, per_block, table.p, ovf.p, ovf_count.p);
-        if (FL) hipLaunchKernelGGL(k_mode_pick_table, dim3((C * FL + 255) / 256), dim3(256), 0, st, table.p, C, FL, best.p);
+        hipLaunchKernelGGL(k_mode_hist, dim3(grid), dim3(kModeBlock), shmem, st, d_uc, d_freq, n, cp_log, FL, per_block, table.p, ovf.p, ovf_count.p);
+        if (FL) hipLaunchKernelGGL(k_mode_pick_table, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, st, table.p, C, cp_log, FL, best.p);
     }
     hipLaunchKernelGGL(k_mode_final, dim3((C + 255) / 256), dim3(256), 0, st, best.p, C, d_modes);
     HIP_TRY(hipGetLastError());

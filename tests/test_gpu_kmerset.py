@@ -321,6 +321,35 @@ def test_search_over_device_set(orc, hip_ctx, n_colors, n_hash, k):
     hx.close(); hx2.close(); ks.close(); sub.close()
 
 
+@pytest.mark.parametrize("n_colors", [256, 77])
+def test_report_modes_of_one_colour_and_one_multiplicity(orc, hip_ctx, n_colors):
+    """Whole waves of k-mers that hit one colour uniquely at one multiplicity (an isolate searched against an index that holds it once): the
+    mode table's wave-wide shortcut (k_mode_hist adds such a wave's count once) next to waves of mixed cells."""
+    import colorid_amd
+    k = 31
+    rng = np.random.default_rng(n_colors)
+    oix = random_index(orc, rng, 200_003, 3, k, n_colors, density=0.0, zero_row_frac=0.0)
+    long_seq, three = rand_seq(rng, 30_000), rand_seq(rng, 9_000)
+    seqs = [long_seq] + [three] * 3 + [rand_seq(rng, 200) for _ in range(40)]
+    ks = colorid_amd.KmerSet(hip_ctx, k)
+    ks.add_seqs(seqs, 0)
+    ks.finalize()
+    km, cnt = ks.download()
+    for colour, s_ in ((5, long_seq), (n_colors - 1, three)):
+        one = orc.Kmers(k)
+        one.kmerize_vector(s_, 1)
+        for key in one.keys():
+            oix.insert(colour, key.tobytes())
+    hx = to_hip_index(hip_ctx, oix)
+    w = oix.search_count(km, cnt.astype(np.uint64))
+    modes = orc.unique_modes(w[3], cnt.astype(np.uint64), n_colors)
+    hits, nu, sf, md = ks.search_count_report(hx)
+    assert np.array_equal(hits, w[0]) and np.array_equal(nu, w[1]) and np.array_equal(sf, w[2]) and np.array_equal(md, modes)
+    assert md[5] == 1 and md[n_colors - 1] == 3 and nu[5] > 29_000 and nu[n_colors - 1] > 8_000
+    hx.close()
+    ks.close()
+
+
 @pytest.mark.parametrize("n_colors,k", [(256, 31), (46, 27), (3000, 21), (20000, 25), (100, 40)])
 def test_report_outputs_on_the_device(orc, hip_ctx, n_colors, k):
     """cid_search_count_set_report: hits / n_unique / sum / MODE per colour (reports.rs:65-77, ties -> smallest value) computed on the

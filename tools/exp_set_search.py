@@ -43,6 +43,15 @@ d_codes, d_counts, nn = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
 check(ks.lib.cid_kmerset_device_arrays(ks.h, ctypes.byref(d_codes), ctypes.byref(d_counts), ctypes.byref(nn)))
 out = torch.zeros(3 * C, dtype=torch.int64, device=dev)
 uc = torch.empty(nd, dtype=torch.int32, device=dev)
+if len(sys.argv) > 3 and sys.argv[3] == "report":   # the report call of bench.py's e2e record (search + modes + one copy), wall time per call
+    import time
+    walls = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        rep = ks.search_count_report(hx)
+        walls.append(round((time.perf_counter() - t0) * 1e3, 3))
+    print(json.dumps({"set": how, "distinct_kmers": int(nd), "report_ms": walls}))
+    sys.exit(0)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for i in range(steps + 1):
     if i == 1:
