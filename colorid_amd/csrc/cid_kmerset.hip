@@ -15,6 +15,7 @@
 #include "../../include/colorid_hip.h"
 #include "cid_internal.hpp"
 #include "cid_partition.hpp"
+#include "cid_rundedupe.hpp"
 #include "cid_scan.hpp"
 #include "cid_rle.hpp"
 #include "cid_merge.hpp"
@@ -112,6 +113,10 @@ struct KeepOut {
     }
 };
 static const bool kMsdSort = getenv("CID_KMERSET_MSD_SORT") ? atoi(getenv("CID_KMERSET_MSD_SORT")) != 0 : true;
+// crowded runs (average comparisons per key in the bucket kernels beyond kCrowdedAt) go through k_run_dedupe_sort; CID_KMERSET_DEDUPE=0: straight
+// to the radix kernel, at round 4's threshold of 32
+static const bool kDedupeSort = getenv("CID_KMERSET_DEDUPE") ? atoi(getenv("CID_KMERSET_DEDUPE")) != 0 : true;
+static const uint32_t kCrowdedAt = getenv("CID_KMERSET_CROWDED_AT") ? (uint32_t)atoi(getenv("CID_KMERSET_CROWDED_AT")) : (kDedupeSort ? 8u : cid::kBucketWork);
 int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, unsigned top, uint64_t **sorted, size_t *n_real) {
     using namespace cid;
     // (CID_KMERSET_MSD_MIN: the tests send small inputs through the cold LSD sorts too.  Until round 4 batches below a million keys went
@@ -131,12 +136,12 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
     uint32_t S_last = 1;                                   // segments entering the last partition level
     for (unsigned l = 0; l + 1 < levels; ++l) S_last <<= lbits[l];
     const uint32_t max_tiles = part_max_tiles((uint32_t)n, S_last);
-    constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (sentinels) [1] big runs [2] largest run [3] hard runs
-    DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c);
+    constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (sentinels) [1] big runs [2] largest run [3] crowded runs (hard) [4] the radix kernel's runs (hard2) [5] runs sampled [6] of them crowded
+    DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c), hard2(c);
     DevBuf<uint64_t> scan_state(c);
     int rc;
     if ((rc = seg_a.alloc((size_t)n_runs + 1)) || (rc = seg_b.alloc((size_t)n_runs + 1)) || (rc = tile_base.alloc((size_t)S_last + 1)) ||
-        (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)))
+        (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)) || (rc = hard2.alloc((size_t)n_runs + 1)))
         return rc;
     if ((rc = scan_state.alloc(scan_state_words((size_t)max_tiles * kPartBins)))) return rc;
     HIP_TRY(hipMemsetAsync(info.p, 0, kInfo * 4, st));
@@ -165,23 +170,41 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
     }
     // src: partitioned, seg[0 .. n_runs]: the runs.  How large are they?
     hipLaunchKernelGGL(k_run_sizes, dim3((n_runs + 255) / 256), dim3(256), 0, st, seg, n_runs, 8192u, info.p + 1, info.p + kInfo, kBigCap, info.p + 2);
+    const unsigned rest = top - consumed;                 // bits the runs still have to be sorted on
+    if (kDedupeSort) hipLaunchKernelGGL((k_run_crowd_sample<false>), dim3(n_runs < kCrowdSample ? n_runs : kCrowdSample), dim3(kPartBlock), 0, st, nullptr, src, seg, n_runs,
+                                        PairOrder{0u, 0u}, rest, kCrowdedAt, info.p + 5);
     uint32_t h_info[kInfo + kBigCap];
     HIP_TRY(hipMemcpyAsync(h_info, info.p, sizeof(h_info), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t dropped = h_info[0], n_big = h_info[1], largest = h_info[2];
+    const bool crowded_batch = h_info[5] >= 8 && 2 * h_info[6] > h_info[5];
     const size_t kept = n - dropped;
-    const unsigned rest = top - consumed;                 // bits the runs still have to be sorted on
     if (n_big > kBigCap) {   // badly skewed codes (low-complexity sequence): LSD radix sort of the partitioned array, all bits
         if ((rc = cold_sort_keys_u64(c, st, src, dst, kept, 0u, top))) return rc;
         *sorted = dst; *n_real = kept;
         return CID_OK;
     }
     // the bucket kernel takes every run it can (evenly spread keys), names the others in `hard`; the radix kernel sorts those
-    hipLaunchKernelGGL(k_run_bucket_sort<8>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, info.p + 3, hard.p);
-    if (largest > 2048) hipLaunchKernelGGL(k_run_bucket_sort<16>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 2049u, info.p + 3, hard.p);
-    if (largest <= 2048) hipLaunchKernelGGL(k_run_sort<8>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 2048u, hard.p, info.p + 3);
-    else if (largest <= 4096) hipLaunchKernelGGL(k_run_sort<16>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 4096u, hard.p, info.p + 3);
-    else hipLaunchKernelGGL(k_run_sort<32>, dim3(grid / 4), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 8192u, hard.p, info.p + 3);
+    // ... and k_run_dedupe_sort (cid_rundedupe.hpp) the crowded ones first: where the crowding is copies of the same k-mers (coverage) it
+    // finishes them, the rest it names in hard2 for the radix kernel.  info[4] = runs in hard2.  A batch whose sampled runs are mostly
+    // crowded (info[5], [6]: reads of an isolate) skips the bucket kernels: every run goes through k_run_dedupe_sort.
+    const uint32_t *radix_list = hard.p, *radix_n = info.p + 3;
+    const bool all_dedupe = kDedupeSort && crowded_batch;
+    if (!all_dedupe) {
+        hipLaunchKernelGGL(k_run_bucket_sort<8>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, info.p + 3, hard.p, kCrowdedAt);
+        if (largest > 2048) hipLaunchKernelGGL(k_run_bucket_sort<16>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 2049u, info.p + 3, hard.p, kCrowdedAt);
+    }
+    if (kDedupeSort) {
+        const uint32_t *list = all_dedupe ? nullptr : hard.p;
+        hipLaunchKernelGGL((k_run_dedupe_sort<8, false>), dim3(grid), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest, 1u, 2048u,
+                           largest <= 2048 ? 1u : 0u, list, info.p + 3, info.p + 4, hard2.p);
+        if (largest > 2048) hipLaunchKernelGGL((k_run_dedupe_sort<16, false>), dim3(grid / 2), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest,
+                                               2049u, 4096u, 1u, list, info.p + 3, info.p + 4, hard2.p);
+        radix_list = hard2.p; radix_n = info.p + 4;
+    }
+    if (largest <= 2048) hipLaunchKernelGGL(k_run_sort<8>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 2048u, radix_list, radix_n);
+    else if (largest <= 4096) hipLaunchKernelGGL(k_run_sort<16>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 4096u, radix_list, radix_n);
+    else hipLaunchKernelGGL(k_run_sort<32>, dim3(grid / 4), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 8192u, radix_list, radix_n);
     HIP_TRY(hipGetLastError());
     if (n_big) {   // runs beyond 8192 keys: one LSD radix sort each, on the bits they still differ in
         std::vector<uint32_t> h_seg(2 * (size_t)n_big);
@@ -215,12 +238,12 @@ int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_
     uint32_t S_last = 1;
     for (unsigned l = 0; l + 1 < levels; ++l) S_last <<= lbits[l];
     const uint32_t max_tiles = part_max_tiles((uint32_t)n, S_last);
-    constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (no k-mer) [1] big runs [2] largest run [3] hard runs
-    DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c);
+    constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (no k-mer) [1] big runs [2] largest run [3] crowded runs (hard) [4] the radix kernel's runs (hard2) [5] runs sampled [6] of them crowded
+    DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c), hard2(c);
     DevBuf<uint64_t> scan_state(c);
     int rc;
     if ((rc = seg_a.alloc((size_t)n_runs + 1)) || (rc = seg_b.alloc((size_t)n_runs + 1)) || (rc = tile_base.alloc((size_t)S_last + 1)) ||
-        (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)))
+        (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)) || (rc = hard2.alloc((size_t)n_runs + 1)))
         return rc;
     if ((rc = scan_state.alloc(scan_state_words((size_t)max_tiles * kPartBins)))) return rc;
     HIP_TRY(hipMemsetAsync(info.p, 0, kInfo * 4, st));
@@ -250,12 +273,15 @@ int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_
         consumed += bits;
     }
     hipLaunchKernelGGL(k_run_sizes, dim3((n_runs + 255) / 256), dim3(256), 0, st, seg, n_runs, 8192u, info.p + 1, info.p + kInfo, kBigCap, info.p + 2);
+    const PairOrder ord{32u - consumed, code_bits};
+    if (kDedupeSort) hipLaunchKernelGGL((k_run_crowd_sample<true>), dim3(n_runs < kCrowdSample ? n_runs : kCrowdSample), dim3(kPartBlock), 0, st, ksrc, src, seg, n_runs, ord, 0u,
+                                        kCrowdedAt, info.p + 5);
     uint32_t h_info[kInfo + kBigCap];
     HIP_TRY(hipMemcpyAsync(h_info, info.p, sizeof(h_info), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t dropped = h_info[0], n_big = h_info[1], largest = h_info[2];
+    const bool crowded_batch = h_info[5] >= 8 && 2 * h_info[6] > h_info[5];
     const size_t kept = n - dropped;
-    const PairOrder ord{32u - consumed, code_bits};
     // two stable LSD sorts = the (key, code) order, for what the LDS kernels do not take: first by code, then by the key's rest
     auto lsd_pair = [&](size_t lo, size_t sz) -> int {
         int rc2;
@@ -270,11 +296,23 @@ int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_
         *sorted = src; *n_real = kept;
         return CID_OK;
     }
-    hipLaunchKernelGGL(k_run_bucket_sort_pair<8>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, info.p + 3, hard.p);
-    if (largest > 2048) hipLaunchKernelGGL(k_run_bucket_sort_pair<16>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 2049u, info.p + 3, hard.p);
-    if (largest <= 2048) hipLaunchKernelGGL(k_run_sort_pair<8>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 2048u, hard.p, info.p + 3);
-    else if (largest <= 4096) hipLaunchKernelGGL(k_run_sort_pair<16>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 4096u, hard.p, info.p + 3);
-    else hipLaunchKernelGGL(k_run_sort_pair<32>, dim3(grid / 4), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 8192u, hard.p, info.p + 3);
+    const uint32_t *radix_list = hard.p, *radix_n = info.p + 3;
+    const bool all_dedupe = kDedupeSort && crowded_batch;   // (see msd_sort; a pair's table slot is 16 bytes: 3072 pairs at most)
+    if (!all_dedupe) {
+        hipLaunchKernelGGL(k_run_bucket_sort_pair<8>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, info.p + 3, hard.p, kCrowdedAt);
+        if (largest > 2048) hipLaunchKernelGGL(k_run_bucket_sort_pair<16>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 2049u, info.p + 3, hard.p, kCrowdedAt);
+    }
+    if (kDedupeSort) {
+        const uint32_t *list = all_dedupe ? nullptr : hard.p;
+        hipLaunchKernelGGL((k_run_dedupe_sort<8, true>), dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 0u, 1u, 2048u, largest <= 2048 ? 1u : 0u, list,
+                           info.p + 3, info.p + 4, hard2.p);
+        if (largest > 2048) hipLaunchKernelGGL((k_run_dedupe_sort<12, true>), dim3(grid / 2), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 0u, 2049u, 3072u, 1u, list,
+                                               info.p + 3, info.p + 4, hard2.p);
+        radix_list = hard2.p; radix_n = info.p + 4;
+    }
+    if (largest <= 2048) hipLaunchKernelGGL(k_run_sort_pair<8>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 2048u, radix_list, radix_n);
+    else if (largest <= 4096) hipLaunchKernelGGL(k_run_sort_pair<16>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 4096u, radix_list, radix_n);
+    else hipLaunchKernelGGL(k_run_sort_pair<32>, dim3(grid / 4), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, 8192u, radix_list, radix_n);
     HIP_TRY(hipGetLastError());
     if (n_big) {   // runs beyond 8192 pairs (one row's k-mers at deep coverage)
         std::vector<uint32_t> h_seg(2 * (size_t)n_big);

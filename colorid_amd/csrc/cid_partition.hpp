@@ -286,14 +286,15 @@ __global__ __launch_bounds__(kPartBlock) void k_run_sort(const uint64_t *in, uin
 // pick one of 2048 buckets — about one DISTINCT key per bucket — by counting, a scan and a scatter through LDS atomics.  Inside a
 // bucket every key finds its own place by comparing itself with the bucket's other members (rank = members that are smaller, or
 // equal and placed before it): the bucket's keys work side by side, so the many copies of one k-mer that reads bring (coverage) cost
-// m comparisons per key, not a serial insertion.  A run whose buckets would take more than kBucketWork comparisons per key on average
-// (repetitive sequence: many keys agreeing in 27+ bits; very deep coverage) is left alone: its number is appended to hard_list for
-// the radix kernel above, whose cost does not depend on the keys.  Capacity 256 * MAXR keys: MAXR = 8 takes the runs of up to 2048
+// m comparisons per key, not a serial insertion.  A run whose buckets would take more than crowded_at comparisons per key on average
+// (deep coverage: many copies of every k-mer; repetitive sequence: many keys agreeing in 27+ bits) is left alone: its number is appended
+// to hard_list for k_run_dedupe_sort (cid_rundedupe.hpp), which hands what is not copies on to the radix kernel above, whose cost does
+// not depend on the keys.  Capacity 256 * MAXR keys: MAXR = 8 takes the runs of up to 2048
 // keys at five workgroups per CU, MAXR = 16 those of 2049 .. 4096 (min_size) and names the larger ones.
 constexpr uint32_t kBucketBits = 11, kBuckets = 1u << kBucketBits, kBucketWork = 32;
 template <int MAXR>
 __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort(const uint64_t *in, uint64_t *out, const uint32_t *run_off, uint32_t n_runs, uint32_t bits,
-                                                                 uint32_t min_size, uint32_t *n_hard, uint32_t *hard_list) {
+                                                                 uint32_t min_size, uint32_t *n_hard, uint32_t *hard_list, uint32_t crowded_at = kBucketWork) {
     __shared__ uint64_t s_key[kPartBlock * MAXR];
     __shared__ uint16_t s_pre[kBuckets + 1];   // (a run holds at most 4096 keys: 16 bits, and a workgroup more per CU)
     __shared__ uint32_t s_cur[kBuckets];
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort(const uint64_t *
             if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = (uint16_t)base;
         }
         __syncthreads();
-        if (s_work[0] + s_work[1] + s_work[2] + s_work[3] > kBucketWork * N) {   // (uniform) crowded buckets: the radix kernel's run
+        if (s_work[0] + s_work[1] + s_work[2] + s_work[3] > crowded_at * N) {   // (uniform) crowded buckets: named for k_run_dedupe_sort / the radix kernel
             if (threadIdx.x == 0) hard_list[atomicAdd(n_hard, 1u)] = run;
             __syncthreads();
             continue;
@@ -526,7 +527,8 @@ struct PairOrder {
 // needs them).  The bucket of a pair = the leading 11 bits of what the run still differs in.
 template <int MAXR>
 __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint32_t *keys, const uint64_t *vals, uint64_t *out, const uint32_t *run_off,
-                                                                      uint32_t n_runs, PairOrder ord, uint32_t min_size, uint32_t *n_hard, uint32_t *hard_list) {
+                                                                      uint32_t n_runs, PairOrder ord, uint32_t min_size, uint32_t *n_hard, uint32_t *hard_list,
+                                                                      uint32_t crowded_at = kBucketWork) {
     __shared__ uint64_t s_val[kPartBlock * MAXR];
     __shared__ uint32_t s_key[kPartBlock * MAXR];
     __shared__ uint16_t s_pre[kBuckets + 1];   // (a run holds at most 4096 keys: 16 bits, and a workgroup more per CU)
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint3
             if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = (uint16_t)base;
         }
         __syncthreads();
-        if (s_work[0] + s_work[1] + s_work[2] + s_work[3] > kBucketWork * N) {   // (uniform) crowded buckets: the radix kernel's run
+        if (s_work[0] + s_work[1] + s_work[2] + s_work[3] > crowded_at * N) {   // (uniform) crowded buckets: named for k_run_dedupe_sort / the radix kernel
             if (threadIdx.x == 0) hard_list[atomicAdd(n_hard, 1u)] = run;
             __syncthreads();
             continue;

@@ -413,11 +413,11 @@ def test_many_add_calls_on_a_used_context(orc, hip_ctx):
 
 
 @pytest.mark.parametrize("k", [6, 11, 21, 27, 31])
-@pytest.mark.parametrize("flavour", ["random", "deep", "repeats", "one_kmer", "ns", "mixed"])
+@pytest.mark.parametrize("flavour", ["random", "deep", "repeats", "one_kmer", "ns", "mixed", "shared_prefix", "deep_errors"])
 def test_msd_sort_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour):
     """The k-mer set's own sort (cid_partition.hpp: MSD radix partition passes, then every run finished in LDS) on inputs small enough
     for the oracle — CID_KMERSET_MSD_MIN=1 sends them through the kernels large sets take: evenly spread codes (the LDS bucket sort),
-    every k-mer many times (deep coverage: the radix kernel for crowded runs), low-complexity sequence (runs beyond a workgroup's LDS:
+    every k-mer many times (deep coverage: k_run_dedupe_sort for crowded runs, the radix kernel for what is not copies), low-complexity sequence (runs beyond a workgroup's LDS:
     the per-run fallback), a single k-mer, N runs (sentinels dropped by the first pass), and all of it at once."""
     import colorid_amd
     monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
@@ -434,6 +434,17 @@ def test_msd_sort_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour):
         seqs = [unit.tobytes(), b"A" * 30_000, b"AC" * 10_000]
     elif flavour == "one_kmer":
         seqs = [b"A" * (k + 20_000)]
+    elif flavour == "shared_prefix":                           # thousands of DIFFERENT k-mers that agree in their first 28 bits: one crowded bucket
+        head = b"A" * min(14, k - 3)                           # that is not copies (k_run_dedupe_sort gives such a run to the radix kernel)
+        seqs = [head + rand_seq(rng, k - len(head)) for _ in range(3500)] + [rand_seq(rng, 20_000)]
+    elif flavour == "deep_errors":                             # coverage with read errors: every true k-mer many times, its one-off variants beside
+        g = np.frombuffer(rand_seq(rng, 3000), np.uint8)       # it in the same buckets (the everyday input: reads of an isolate)
+        seqs = []
+        for s0 in rng.integers(0, len(g) - 150, 3000):
+            r = g[s0:s0 + 150].copy()
+            hit = rng.random(150) < 0.01
+            r[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+            seqs.append(r.tobytes())
     elif flavour == "ns":
         seqs = [rand_seq(rng, 50_000, b"ACGTN"), b"N" * 5000, rand_seq(rng, 20_000, b"ACGTNNNN")]
     else:

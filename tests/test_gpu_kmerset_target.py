@@ -40,10 +40,10 @@ def empty_index(hip_ctx, m, n_hash, k, n_colors=8):
 
 @pytest.mark.parametrize("m", [50_021, 65_536, 4_000_037])
 @pytest.mark.parametrize("k", [6, 21, 31, 32])
-@pytest.mark.parametrize("flavour", ["random", "deep", "repeats", "one_kmer", "ns", "mixed"])
+@pytest.mark.parametrize("flavour", ["random", "deep", "repeats", "one_kmer", "ns", "mixed", "shared_prefix", "deep_errors"])
 def test_targeted_msd_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour, m):
     """the pair kernels of cid_partition.hpp on inputs small enough for the oracle (CID_KMERSET_MSD_MIN=1): evenly spread keys (the LDS
-    bucket sort), deep coverage (crowded buckets: the radix kernel), one row holding most windows (runs beyond a workgroup's LDS: the
+    bucket sort), deep coverage (crowded buckets: k_run_dedupe_sort, the radix kernel for what is not copies), one row holding most windows (runs beyond a workgroup's LDS: the
     per-run LSD sorts), windows without a k-mer (dropped by the first level)"""
     import colorid_amd
     if k == 32 and m != 50_021:
@@ -62,6 +62,17 @@ def test_targeted_msd_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavo
         seqs = [unit.tobytes(), b"A" * 30_000, b"AC" * 10_000]
     elif flavour == "one_kmer":
         seqs = [b"A" * (k + 20_000)]
+    elif flavour == "shared_prefix":                           # thousands of DIFFERENT k-mers that agree in their first 28 bits: one crowded bucket
+        head = b"A" * min(14, k - 3)                           # that is not copies (k_run_dedupe_sort gives such a run to the radix kernel)
+        seqs = [head + rand_seq(rng, k - len(head)) for _ in range(3500)] + [rand_seq(rng, 20_000)]
+    elif flavour == "deep_errors":                             # coverage with read errors: every true k-mer many times, its one-off variants beside
+        g = np.frombuffer(rand_seq(rng, 3000), np.uint8)       # it in the same buckets (the everyday input: reads of an isolate)
+        seqs = []
+        for s0 in rng.integers(0, len(g) - 150, 3000):
+            r = g[s0:s0 + 150].copy()
+            hit = rng.random(150) < 0.01
+            r[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+            seqs.append(r.tobytes())
     elif flavour == "ns":
         seqs = [rand_seq(rng, 50_000, b"ACGTN"), b"N" * 5000, rand_seq(rng, 20_000, b"ACGTNNNN")]
     else:
