@@ -196,10 +196,11 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
     }
     if (kDedupeSort) {
         const uint32_t *list = all_dedupe ? nullptr : hard.p;
+        static const bool big_too = getenv("CID_KMERSET_DEDUPE_BIG") ? atoi(getenv("CID_KMERSET_DEDUPE_BIG")) != 0 : true;
         hipLaunchKernelGGL((k_run_dedupe_sort<8, false>), dim3(grid), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest, 1u, 2048u,
-                           largest <= 2048 ? 1u : 0u, list, info.p + 3, info.p + 4, hard2.p);
-        if (largest > 2048) hipLaunchKernelGGL((k_run_dedupe_sort<16, false>), dim3(grid / 2), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest,
-                                               2049u, 4096u, 1u, list, info.p + 3, info.p + 4, hard2.p);
+                           largest <= 2048 || !big_too ? 1u : 0u, list, info.p + 3, info.p + 4, hard2.p);
+        if (largest > 2048 && big_too) hipLaunchKernelGGL((k_run_dedupe_sort<15, false>), dim3(grid / 2), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest,
+                                               2049u, 3840u, 1u, list, info.p + 3, info.p + 4, hard2.p);
         radix_list = hard2.p; radix_n = info.p + 4;
     }
     if (largest <= 2048) hipLaunchKernelGGL(k_run_sort<8>, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, n_runs, rest, 1u, 2048u, radix_list, radix_n);
@@ -297,7 +298,7 @@ int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_
         return CID_OK;
     }
     const uint32_t *radix_list = hard.p, *radix_n = info.p + 3;
-    const bool all_dedupe = kDedupeSort && crowded_batch;   // (see msd_sort; a pair's table slot is 16 bytes: 3072 pairs at most)
+    const bool all_dedupe = kDedupeSort && crowded_batch;   // (see msd_sort; a pair's table slot is 16 bytes: 3072 pairs at three workgroups per CU)
     if (!all_dedupe) {
         hipLaunchKernelGGL(k_run_bucket_sort_pair<8>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 1u, info.p + 3, hard.p, kCrowdedAt);
         if (largest > 2048) hipLaunchKernelGGL(k_run_bucket_sort_pair<16>, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, dst, seg, n_runs, ord, 2049u, info.p + 3, hard.p, kCrowdedAt);

@@ -1,11 +1,15 @@
 // The run sort of k-mer sets with many copies of every k-mer (reads of an isolate at 30-100x coverage — the reference's everyday input):
 // between k_run_bucket_sort (a key ranks itself against its bucket's members: c comparisons per key in a bucket of c) and k_run_sort
 // (LSD radix in LDS: six to eight passes whatever the keys) sits k_run_dedupe_sort, for the runs the bucket kernel finds crowded.
-// A bucket's stretch of LDS first serves as a table of its DISTINCT keys: a key walks the stretch from its start, claims the first empty
-// slot with a 64-bit compare-and-swap or stops at its own value, and draws its number among the copies from that slot's counter — one
-// or two probes and ONE contended atomic per key where the crowding is copies.  The distinct keys of a bucket (a handful) rank each
-// other, weighted by their counts: that is where each one's copies start; a key's place is that plus its number.  The run leaves
-// sorted, copies included, like the other run sorts' — the run-length count downstream (cid_rle.hpp) is unchanged.
+// A bucket's stretch of LDS first serves as an open-addressing table of its DISTINCT keys: a key starts at a hashed place of the stretch,
+// walks it (wrapping round) to the first empty slot, which it claims with a 64-bit compare-and-swap, or to its own value, and draws its
+// number among the copies from that slot's counter — one or two probes and ONE contended atomic per key where the crowding is copies
+// (in code order a true k-mer's bucket also holds its one-off error variants — a handful at 50x, dozens at 500x — which is why the walk
+// does not start at the stretch's first slot there; a set built for an index scatters the variants by their first-row keys, and its
+// walk does start at the first slot: the filled slots are then a prefix of the stretch and need no list).  Whoever claims a slot appends it
+// to the bucket's list of distinct keys; those rank each other, weighted by their counts: that is where each one's copies start; a key's
+// place is that plus its number.  The run leaves sorted, copies included,
+// like the other run sorts' — the run-length count downstream (cid_rle.hpp) is unchanged.
 //   A key that has not found its slot after kDedupeProbes steps (many DIFFERENT keys in one bucket: low-complexity sequence) gives the run
 //   up: it is named in hard2 for k_run_sort, as are listed runs beyond this kernel's largest launched capacity (name_larger).
 //   1 M reads of a 3 Mb genome (50x, 1 % errors: 33.8 M distinct of 120 M windows): see DESIGN.md §5.
@@ -14,7 +18,7 @@
 
 namespace cid {
 
-constexpr uint32_t kDedupeProbes = 24;
+constexpr uint32_t kDedupeProbes = 48, kDedupeNdWords = (kBuckets + 2) / 3, kDedupeNdMax = 1023;
 
 template <int MAXR, bool PAIR>
 __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *keys, const uint64_t *vals, uint64_t *out, const uint32_t *run_off, uint32_t n_runs, PairOrder ord,
@@ -24,9 +28,15 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
     constexpr unsigned long long EMPTY = ~0ull;   // never a code: codes of k <= 31 stay below 2^62, the k = 32 path does not come here with all ones
     __shared__ uint64_t s_val[CAP];
     __shared__ uint32_t s_key[PAIR ? CAP : 1];
-    __shared__ uint32_t s_cnt[CAP];              // first the buckets' member counts; then per slot: copies counted, then the cursor of their places
+    // s_cnt: first the buckets' member counts; then per slot: its copies (low half) and, at the stretch's i-th place, the slot of the bucket's
+    // i-th distinct key (high half); then per slot: the place of its first copy
+    __shared__ uint32_t s_cnt[CAP];
+    constexpr bool HASHED = !PAIR;               // where a key's walk starts, and how a bucket's distinct keys are found again (see above)
+    __shared__ uint32_t s_nd[HASHED ? kDedupeNdWords : 4];   // distinct keys per bucket, three buckets to a word (ten bits each: a bucket of 1023 gives the run up);
+                                                 // its first four words carry the scan's wave totals before that
     __shared__ uint16_t s_pre[kBuckets + 1];
-    __shared__ uint32_t s_wave[4], s_fail;
+    __shared__ uint32_t s_fail;
+    uint32_t *s_wave = s_nd;
     static_assert(CAP >= kBuckets, "the bucket counts borrow the slot counters");
     constexpr uint32_t BPT = kBuckets / kPartBlock;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -49,6 +59,7 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
             if (name_larger && threadIdx.x == 0) hard2[atomicAdd(n_hard2, 1u)] = run;
             continue;
         }
+        static_assert(CAP <= 4096, "a slot number and a count share a word");
 #pragma unroll
         for (uint32_t j = 0; j < BPT; ++j) s_cnt[threadIdx.x * BPT + j] = 0;
         if (threadIdx.x == 0) s_fail = 0;
@@ -83,7 +94,10 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
             for (uint32_t j = 0; j < BPT; ++j) { s_pre[threadIdx.x * BPT + j] = (uint16_t)base; base += c[j]; }
             if (threadIdx.x == kPartBlock - 1) s_pre[kBuckets] = (uint16_t)base;
         }
-        for (uint32_t p = threadIdx.x; p < CAP; p += kPartBlock) { s_val[p] = EMPTY; s_cnt[p] = 0; }   // (the bucket counts were read before the barrier above)
+        __syncthreads();   // (the wave totals have been read: their words go back to s_nd)
+        for (uint32_t p = threadIdx.x; p < CAP; p += kPartBlock) { s_val[p] = EMPTY; s_cnt[p] = 0; }
+        if (HASHED)
+            for (uint32_t p = threadIdx.x; p < kDedupeNdWords; p += kPartBlock) s_nd[p] = 0;
         __syncthreads();
         uint16_t my[MAXR];     // the slot of this key's value
         uint32_t ord_[MAXR];   // ... and which of the value's copies it is (the order the slot's counter handed out)
@@ -93,20 +107,33 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
             ord_[r] = 0;
             if ((uint32_t)r * kPartBlock + threadIdx.x < N) {
                 const uint32_t bkt = bucket_of(key[r], val[r]);
-                uint32_t slot = s_pre[bkt];
-                const uint32_t hi = s_pre[bkt + 1];
+                const uint32_t lo = s_pre[bkt], hi = s_pre[bkt + 1], c = hi - lo;
+                // where the walk starts: 24 hashed bits scaled to the stretch's length
+                uint32_t slot = HASHED ? lo + ((((uint32_t)((val[r] * 0x9E3779B97F4A7C15ull) >> 40) & 0xFFFFFFu) * c) >> 24) : lo;
                 bool found = false;
+                const uint32_t limit = c < kDedupeProbes ? c : kDedupeProbes;
                 if (val[r] != EMPTY)   // (a value that looks like an empty slot — no k <= 31 code does — sends the run to the radix kernel)
-                for (uint32_t probes = 0; probes < kDedupeProbes && slot < hi; ++probes, ++slot) {
+                for (uint32_t probes = 0; probes < limit; ++probes) {
                     // a plain read first: the copies that come after a value's first one only read (same-address reads are a broadcast,
                     // same-address atomics queue up; a slot never changes once it holds a value).  Only "it is mine" is taken from the
                     // plain read — anything else, a half-written slot included, is settled by the compare-and-swap.
                     unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(&s_val[slot]);
                     if (old != val[r]) old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_val[slot]), EMPTY, (unsigned long long)val[r]);
-                    if (old == EMPTY) { if (PAIR) s_key[slot] = key[r]; found = true; break; }
+                    if (old == EMPTY) {   // claimed: the bucket's next distinct key
+                        if (PAIR) s_key[slot] = key[r];
+                        if (HASHED) {
+                            const uint32_t word = bkt / 3u, sh = (bkt - word * 3u) * 10u;
+                            const uint32_t nd = (atomicAdd(&s_nd[word], 1u << sh) >> sh) & 0x3FFu;
+                            if (nd >= kDedupeNdMax - 1) { s_fail = 1; break; }   // (the field would run over into its neighbour's)
+                            atomicOr(&s_cnt[lo + nd], slot << 16);
+                        }
+                        found = true;
+                        break;
+                    }
                     if (old == val[r]) { found = true; break; }
+                    if (++slot == hi) slot = lo;   // (not HASHED: the walk has been through the whole stretch by then — limit)
                 }
-                if (found) { ord_[r] = atomicAdd(&s_cnt[slot], 1u); my[r] = (uint16_t)slot; }
+                if (found) { ord_[r] = atomicAdd(&s_cnt[slot], 1u) & 0xFFFFu; my[r] = (uint16_t)slot; }
                 else s_fail = 1;
             }
         }
@@ -125,13 +152,23 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
                 const uint64_t v = s_val[p];
                 const uint32_t k = PAIR ? s_key[p] : 0u;
                 const uint32_t bkt = bucket_of(k, v);
-                const uint32_t lo = s_pre[bkt], hi = s_pre[bkt + 1];
+                const uint32_t lo = s_pre[bkt];
                 uint32_t off = 0;
-                for (uint32_t q = lo; q < hi; ++q) {
-                    const uint64_t ov = s_val[q];
-                    if (ov == EMPTY) break;   // the filled slots are a prefix of the stretch
-                    const bool less = PAIR ? (s_key[q] < k || (s_key[q] == k && ov < v)) : ov < v;
-                    off += less ? s_cnt[q] : 0u;
+                if (HASHED) {
+                    const uint32_t word = bkt / 3u;
+                    const uint32_t nd = (s_nd[word] >> ((bkt - word * 3u) * 10u)) & 0x3FFu;
+                    for (uint32_t i = 0; i < nd; ++i) {
+                        const uint32_t q = s_cnt[lo + i] >> 16;
+                        off += s_val[q] < v ? (s_cnt[q] & 0xFFFFu) : 0u;
+                    }
+                } else {
+                    const uint32_t hi = s_pre[bkt + 1];
+                    for (uint32_t q = lo; q < hi; ++q) {
+                        const uint64_t ov = s_val[q];
+                        if (ov == EMPTY) break;   // the filled slots are a prefix of the stretch
+                        const bool less = s_key[q] < k || (s_key[q] == k && ov < v);
+                        off += less ? (s_cnt[q] & 0xFFFFu) : 0u;
+                    }
                 }
                 first[r] = lo + off;
             }
