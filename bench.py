@@ -12,7 +12,7 @@ index   : synthetic: Bernoulli(p) background bits, p = 1 - exp(
 step    : one pass of the hot path over the rank's whole k-mer batch (+ the RCCL all-reduce of the 3*C
           per-colour counters when N > 1).  N > 1: reads are sharded over ranks, the index is replicated.
 
-Side records of the one JSON line (N = 1 only; never `value`; the line stays under 5 KB):
+Side records of the one JSON line (N = 1 only; never `value`; the line stays under 7 KB):
   config.codes_input       the same query as 2-bit codes (cid_search_count_codes_dev), 10 steps
   config.producer_ordered  2-bit codes grouped by the 128-byte index line of their first row as a separate pass: search_ms = the
                            search alone, in_step_ms = grouping + search inside one step
@@ -21,6 +21,7 @@ Side records of the one JSON line (N = 1 only; never `value`; the line stays und
                            sort on (key, code), run-length) -> cid_search_count_set_report (hits / unique / sum / mode per accession
                            on the device) -> 4*C numbers to the host; best of 6 calls; PCIe-inclusive
   e2e.code_ordered         the same without cid_kmerset_set_target_index (round 3's path)
+  e2e.pinned_input         the same as e2e with the reads in page-locked host memory (what the CLI's batches are): the bus at its DMA rate
   rows128                  the headline's k-mers against m, n of the headline and 1024 colours (configs[3]'s index: 128-byte rows)
   readid                   cid_readid_count_dev on configs[2]'s shape (m = 30 M, n = 2, k = 21, 256 colours), 1 M reads and 1 M pairs
                            resident; alg bytes = n rows of 32 B per distinct k-mer of a read + its bases in + its report row out;
@@ -779,7 +780,8 @@ def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
     host_reads = reads.cpu().numpy()
     del reads
     so = (np.arange(host_reads.shape[0] + 1, dtype=np.uint64) * a.read_len)
-    def run(targeted):
+    pinned = torch.from_numpy(host_reads).pin_memory()   # the same reads where a caller keeps them in page-locked memory (the CLI's batches are)
+    def run(targeted, src=host_reads):
         times, parts, hits, nd = [], [], None, 0
         for _ in range(6):
             ks = colorid_amd.KmerSet(ctx, k)
@@ -787,7 +789,7 @@ def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
                 ks.set_target_index(hx)   # what `colorid search` does: the set is ordered for the index by its own sort
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            check(ks.lib.cid_kmerset_add_seqs(ks.h, vp(host_reads.ctypes.data), vp(so.ctypes.data), host_reads.shape[0], 0))
+            check(ks.lib.cid_kmerset_add_seqs(ks.h, vp(src.ctypes.data), vp(so.ctypes.data), host_reads.shape[0], 0))
             t1 = time.perf_counter()
             nd = ks.finalize()
             t2 = time.perf_counter()
@@ -801,6 +803,8 @@ def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
 
     c_times, c_parts, c_hits, _ = run(False)
     times, parts, hits, nd = run(True)
+    p_times, p_parts, p_hits, _ = run(True, pinned.numpy())
+    p_best = int(np.argmin(p_times))
     c_best = int(np.argmin(c_times))
     best = int(np.argmin(times))
     same = bool(np.array_equal(hits.astype(np.int64), counters[:C].cpu().numpy()))   # the headline step's hits (same reads, same index)
@@ -809,6 +813,8 @@ def e2e_reads_to_report(a, dev, ctx, hx, counters, C, k):
             "phases_ms": {"upload_and_window_codes": parts[best][0] * 1e3, "sort_and_count": parts[best][1] * 1e3,
                           "search_and_report": parts[best][2] * 1e3},
             "all_ms": [round(t * 1e3, 2) for t in times], "same_hits_as_headline": same,
+            "pinned_input": {"ms": round(p_times[p_best] * 1e3, 3), "upload_and_window_codes_ms": round(p_parts[p_best][0] * 1e3, 3),
+                             "same_hits": bool(np.array_equal(hits, p_hits))},
             "code_ordered": {"ms": c_times[c_best] * 1e3, "same_hits": bool(np.array_equal(hits, c_hits)),
                              "phases_ms": {"upload_and_window_codes": c_parts[c_best][0] * 1e3, "sort_and_count": c_parts[c_best][1] * 1e3,
                                            "search_and_report": c_parts[c_best][2] * 1e3}}}
