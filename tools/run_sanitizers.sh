@@ -69,7 +69,7 @@ for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
   $B batch_id -b $W/ix.bxi -q $W/sheet.tsv -T san -c 5000 > $W/bid.out 2> $W/bid.err; echo "batch_id rc=$?"; cmp $W/rid_reads.txt $W/s_bgzf_san_reads.txt && echo "batch_id: the pair's rows as read_id wrote them"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/bid.err | head -5
   # round 4: the device front end giving way mid-run (classifier drained, output emptied, the whole input again through the host front end),
   # the orderly teardown (the default leaves with _exit once the outputs are closed), the index uploaded from a mapping (ix130: 132 MB)
-  COLORID_DEVICE_FASTQ_FAIL_AT_STEP=1 $B read_id -b $W/ix.bxi -q $W/b_1.fastq.gz $W/b_2.fastq.gz -n $W/ridf -c 5000 > $W/rf.out 2> $W/rf.err; echo "read_id PE restart rc=$?"; cmp $W/rid_reads.txt $W/ridf_reads.txt && echo "restart: same rows"; grep -c "starting over" $W/rf.err; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rf.err | head -5
+  CID_FASTQ_REFUSE_AT_STEP=2 $B read_id -b $W/ix.bxi -q $W/b_1.fastq.gz $W/b_2.fastq.gz -n $W/ridf -c 5000 > $W/rf.out 2> $W/rf.err; echo "read_id PE restart rc=$?"; cmp $W/rid_reads.txt $W/ridf_reads.txt && echo "restart: same rows"; grep -c "starting over" $W/rf.err; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rf.err | head -5
   COLORID_FULL_TEARDOWN=1 $B read_id -b $W/ix130.bxi -q $W/b_1.fastq.gz -n $W/ridt -c 5000 > $W/rt.out 2> $W/rt.err; echo "read_id orderly teardown rc=$?"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rt.err | head -5
   COLORID_FULL_TEARDOWN=1 COLORID_INDEX_MMAP=0 $B read_id -b $W/ix130.bxi -q $W/b_1.fastq.gz -n $W/ridu -c 5000 > $W/ru.out 2> $W/ru.err; echo "read_id buffered index rc=$?"; cmp $W/ridt_reads.txt $W/ridu_reads.txt && echo "mapped index: same rows as buffered"
   unset COLORID_DEVICE_FASTQ_MB
