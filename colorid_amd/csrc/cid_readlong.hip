@@ -45,6 +45,7 @@ struct LongItem { uint32_t read, bucket, n_buckets, deal; };   // deal: 1 + inde
 // segment (b, chunk) of `cap` places — pairs[pair_base + (b * n_chunks + chunk) * cap ..], their number in counts[count_base + b * n_chunks + chunk].
 struct LongDeal { uint64_t pair_base; uint32_t count_base, n_chunks, cap, read; };
 constexpr uint32_t kDealChunk = 16384, kDealFromBuckets = 4;
+constexpr uint32_t kLongMaxChunks = 256;   // kLongMaxWin / kDealChunk
 
 __device__ __forceinline__ uint64_t long_mix(uint64_t x) {   // a bijection of the 64-bit codes: distinct codes never share all their bits
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
@@ -59,10 +60,15 @@ __device__ __forceinline__ uint64_t long_mix(uint64_t x) {   // a bijection of t
 // then reads its own pairs only.  A segment has room for the mean + 25 % + 96 (the mixed codes spread evenly: four standard deviations
 // are 12 % at 16 384 / 7 per segment, less at more buckets' smaller means only in absolute terms — hence the + 96); one that
 // overflows anyway raises flags[1] and the batch is redone on the sorting path.
-__global__ __launch_bounds__(256) void k_long_deal(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongDeal *deals, const uint32_t *chunk_deal,
-                                                   const uint32_t *chunk_no, uint32_t n_chunks_all, uint64_t sentinel, uint64_t *pair_code, uint32_t *pair_idx,
-                                                   uint32_t *counts, int *flags) {
-    __shared__ uint32_t s_cnt[256];
+constexpr uint32_t kDealBlock = 1024, kDealStageFrom = 24;   // buckets from which a chunk's pairs are grouped in LDS before they are written
+__global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongDeal *deals,
+                                                           const uint32_t *chunk_deal, const uint32_t *chunk_no, uint32_t n_chunks_all, uint64_t sentinel,
+                                                           uint64_t *pair_code, uint32_t *pair_idx, uint32_t *counts, int *flags) {
+    // A chunk's windows are first grouped by bucket in LDS (their numbers only: 64 KiB), then every bucket's pairs leave as one stretch:
+    // written straight from the window loop a wave's 64 pairs went to forty different segments, 8 and 4 bytes at a time — 2.5 ms per 150 M
+    // windows of 1 Mb reads, the price of 64-byte memory transactions for 12 bytes.
+    __shared__ uint32_t s_cnt[256], s_start[257], s_cur[256];
+    __shared__ uint32_t s_idx[kDealChunk];
     for (uint32_t ci = blockIdx.x; ci < n_chunks_all; ci += gridDim.x) {
         const LongDeal d = deals[chunk_deal[ci]];
         const uint32_t j = chunk_no[ci];
@@ -70,20 +76,70 @@ __global__ __launch_bounds__(256) void k_long_deal(const uint64_t *codes, const 
         const uint32_t nw = (uint32_t)(wend[d.read] - w0);
         const uint32_t P = (nw + kLongFill - 1) / kLongFill;   // (as the host counted them: <= 256)
         const uint32_t a = j * kDealChunk, b = a + kDealChunk < nw ? a + kDealChunk : nw;
-        s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        for (uint32_t w = a + threadIdx.x; w < b; w += blockDim.x) {
+        if (P < kDealStageFrom) {   // (uniform) few buckets: a wave's pairs fall into few segments as they are — 100 kb reads 9.4 ms so, 9.9 staged
+            for (uint32_t w = a + threadIdx.x; w < b; w += kDealBlock) {
+                const uint64_t code = codes[w0 + w];
+                if (code >= sentinel) continue;
+                const uint32_t bk = (uint32_t)(((long_mix(code) >> 32) * P) >> 32);
+                const uint32_t at = atomicAdd(&s_cnt[bk], 1u);
+                if (at < d.cap) {
+                    const uint64_t o = d.pair_base + ((uint64_t)bk * d.n_chunks + j) * d.cap + at;
+                    pair_code[o] = code;
+                    pair_idx[o] = w;
+                } else atomicOr(&flags[1], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x < P) counts[d.count_base + threadIdx.x * d.n_chunks + j] = s_cnt[threadIdx.x] < d.cap ? s_cnt[threadIdx.x] : d.cap;
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t w = a + threadIdx.x; w < b; w += kDealBlock) {
             const uint64_t code = codes[w0 + w];
             if (code >= sentinel) continue;
-            const uint32_t bk = (uint32_t)(((long_mix(code) >> 32) * P) >> 32);
-            const uint32_t at = atomicAdd(&s_cnt[bk], 1u);
-            if (at < d.cap) {
-                const uint64_t o = d.pair_base + ((uint64_t)bk * d.n_chunks + j) * d.cap + at;
-                pair_code[o] = code;
-                pair_idx[o] = w;
-            } else atomicOr(&flags[1], 1);
+            atomicAdd(&s_cnt[(uint32_t)(((long_mix(code) >> 32) * P) >> 32)], 1u);
         }
         __syncthreads();
+        if (threadIdx.x < 64) {   // exclusive prefix over the (<= 256) bucket counts: four per lane
+            uint32_t c4[4], sum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) { c4[q] = s_cnt[threadIdx.x * 4 + q]; sum += c4[q]; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o, 64);
+                if ((int)threadIdx.x >= o) inc += up;
+            }
+            uint32_t base = inc - sum;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) { s_start[threadIdx.x * 4 + q] = base; s_cur[threadIdx.x * 4 + q] = base; base += c4[q]; }
+            if (threadIdx.x == 63) s_start[256] = base;
+        }
+        __syncthreads();
+        for (uint32_t w = a + threadIdx.x; w < b; w += kDealBlock) {
+            const uint64_t code = codes[w0 + w];
+            if (code >= sentinel) continue;
+            s_idx[atomicAdd(&s_cur[(uint32_t)(((long_mix(code) >> 32) * P) >> 32)], 1u)] = w;
+        }
+        __syncthreads();
+        const uint32_t total = s_start[256];
+        bool over = false;
+        for (uint32_t p = threadIdx.x; p < total; p += kDealBlock) {
+            uint32_t lo = 0, hi = 256;   // the bucket of place p: s_start[lo] <= p < s_start[lo + 1]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_start[mid] <= p) lo = mid; else hi = mid;
+            }
+            const uint32_t at = p - s_start[lo];
+            if (at < d.cap) {
+                const uint64_t o = d.pair_base + ((uint64_t)lo * d.n_chunks + j) * d.cap + at;
+                const uint32_t w = s_idx[p];
+                pair_code[o] = codes[w0 + w];
+                pair_idx[o] = w;
+            } else over = true;
+        }
+        if (over) atomicOr(&flags[1], 1);
         if (threadIdx.x < P) counts[d.count_base + threadIdx.x * d.n_chunks + j] = s_cnt[threadIdx.x] < d.cap ? s_cnt[threadIdx.x] : d.cap;
         __syncthreads();
     }
@@ -96,6 +152,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                                    const uint32_t *pair_idx, const uint32_t *deal_counts) {
     extern __shared__ uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
     __shared__ int s_over;
+    __shared__ uint32_t s_pref[kLongMaxChunks + 1];   // a dealt bucket: pairs in the segments before chunk j
     uint32_t *bm = table + slots;
     const uint32_t max_slots = slots, bm_bits = bm_words * 32u;
     const uint32_t chunk = (n_items + 7u) / 8u;
@@ -133,17 +190,31 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                     if (probes >= slots / 4) { s_over = 1; break; }   // a crowded table: the pass is redone on sub-buckets
                 }
             };
-            if (im.deal) {   // the bucket's own pairs, chunk after chunk
+            if (im.deal) {   // the bucket's own pairs: its segments (one per chunk of the read, a few hundred pairs each) walked as ONE index space —
+                // chunk after chunk, a segment kept a quarter of the workgroup busy and every chunk paid a memory round trip for its count
+                // (1 Mb reads: 61 chunks, 187 us per bucket against 23 us for a whole 10 kb read)
                 const LongDeal d = deals[im.deal - 1];
-                for (uint32_t j = 0; j < d.n_chunks; ++j) {
-                    const uint32_t n = deal_counts[d.count_base + im.bucket * d.n_chunks + j];
-                    const uint64_t o = d.pair_base + ((uint64_t)im.bucket * d.n_chunks + j) * d.cap;
-                    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-                        const uint64_t code = pair_code[o + i];
-                        const uint64_t h = long_mix(code);
-                        if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
-                        insert(code, pair_idx[o + i], h);
+                if (sub == 0 || level) {   // (the prefix is the same in every pass; the table's clearing barrier above separates the passes)
+                    for (uint32_t j = threadIdx.x; j < d.n_chunks; j += blockDim.x) s_pref[j + 1] = deal_counts[d.count_base + im.bucket * d.n_chunks + j];
+                    if (threadIdx.x == 0) s_pref[0] = 0;
+                    __syncthreads();
+                    if (threadIdx.x == 0)
+                        for (uint32_t j = 0; j < d.n_chunks; ++j) s_pref[j + 1] += s_pref[j];
+                    __syncthreads();
+                }
+                const uint32_t total = s_pref[d.n_chunks];
+                const uint64_t o0 = d.pair_base + (uint64_t)im.bucket * d.n_chunks * d.cap;
+                for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
+                    uint32_t lo = 0, hi = d.n_chunks;   // the chunk whose segment holds pair t: s_pref[lo] <= t < s_pref[lo + 1]
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= t) lo = mid; else hi = mid;
                     }
+                    const uint64_t o = o0 + (uint64_t)lo * d.cap + (t - s_pref[lo]);
+                    const uint64_t code = pair_code[o];
+                    const uint64_t h = long_mix(code);
+                    if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
+                    insert(code, pair_idx[o], h);
                 }
             } else
             for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
@@ -354,7 +425,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         if (!chunk_deal.empty()) {
             unsigned g = (unsigned)chunk_deal.size();
             if (g > n_cu * 8u) g = n_cu * 8u;
-            hipLaunchKernelGGL(k_long_deal, dim3(g), dim3(256), 0, st, d_codes.p, d_wstart, d_wend, d_deals, d_chunk_deal, d_chunk_no, (uint32_t)chunk_deal.size(),
+            hipLaunchKernelGGL(k_long_deal, dim3(g), dim3(kDealBlock), 0, st, d_codes.p, d_wstart, d_wend, d_deals, d_chunk_deal, d_chunk_no, (uint32_t)chunk_deal.size(),
                                sentinel, d_pair_code.p, d_pair_idx.p, d_deal_counts.p, d_flags.p);
         }
         if (!items_small.empty()) {
