@@ -44,7 +44,7 @@ struct LongItem { uint32_t read, bucket, n_buckets, deal; };   // deal: 1 + inde
 // A read of several buckets, dealt: its windows are cut into chunks of kDealChunk, every chunk's (code, window) pairs of bucket b lie in
 // segment (b, chunk) of `cap` places — pairs[pair_base + (b * n_chunks + chunk) * cap ..], their number in counts[count_base + b * n_chunks + chunk].
 struct LongDeal { uint64_t pair_base; uint32_t count_base, n_chunks, cap, read; };
-constexpr uint32_t kDealChunk = 16384, kDealFromBuckets = 4;
+constexpr uint32_t kDealChunk = 16384, kDealFromBuckets = 3;   // (two buckets: 20 kb reads 8.8 ms undealt, 9.2 dealt; three: 40 kb reads 9.6 -> 9.0)
 constexpr uint32_t kLongMaxChunks = 256;   // kLongMaxWin / kDealChunk
 
 __device__ __forceinline__ uint64_t long_mix(uint64_t x) {   // a bijection of the 64-bit codes: distinct codes never share all their bits
