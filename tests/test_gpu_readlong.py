@@ -157,9 +157,10 @@ def test_lower_case_among_long_reads_falls_back(orc, hip_ctx):
 
 
 def _random_long_read(rng, genome, k):
-    """a read of 1 kb ... 120 kb made of stretches of the genome: some repeated, some with N runs, some reverse-complemented"""
+    """a read of 1 kb ... 420 kb (two buckets undealt, three and more dealt, 24 and more with the pairs grouped in LDS first) made of stretches
+    of the genome: some repeated, some with N runs, some reverse-complemented"""
     comp = bytes.maketrans(b"ACGT", b"TGCA")
-    L = int(rng.choice([1_000, 1_500, 3_000, 4_100, 9_000, 16_500, 33_000, 70_000, 120_000]))
+    L = int(rng.choice([1_000, 1_500, 3_000, 4_100, 9_000, 16_500, 33_000, 50_000, 70_000, 120_000, 420_000]))
     parts, have = [], 0
     while have < L:
         n = int(min(L - have, rng.integers(200, 20_000)))
