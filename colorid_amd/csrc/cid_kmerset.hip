@@ -196,10 +196,9 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
     }
     if (kDedupeSort) {
         const uint32_t *list = all_dedupe ? nullptr : hard.p;
-        static const bool big_too = getenv("CID_KMERSET_DEDUPE_BIG") ? atoi(getenv("CID_KMERSET_DEDUPE_BIG")) != 0 : true;
         hipLaunchKernelGGL((k_run_dedupe_sort<8, false>), dim3(grid), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest, 1u, 2048u,
-                           largest <= 2048 || !big_too ? 1u : 0u, list, info.p + 3, info.p + 4, hard2.p);
-        if (largest > 2048 && big_too) hipLaunchKernelGGL((k_run_dedupe_sort<15, false>), dim3(grid / 2), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest,
+                           largest <= 2048 ? 1u : 0u, list, info.p + 3, info.p + 4, hard2.p);
+        if (largest > 2048) hipLaunchKernelGGL((k_run_dedupe_sort<15, false>), dim3(grid / 2), dim3(kPartBlock), 0, st, nullptr, src, dst, seg, n_runs, PairOrder{0u, 0u}, rest,
                                                2049u, 3840u, 1u, list, info.p + 3, info.p + 4, hard2.p);
         radix_list = hard2.p; radix_n = info.p + 4;
     }
