@@ -38,6 +38,7 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
     __shared__ uint32_t s_fail;
     uint32_t *s_wave = s_nd;
     static_assert(CAP >= kBuckets, "the bucket counts borrow the slot counters");
+    static_assert(CAP <= 4096, "a slot number and a count share a word");
     constexpr uint32_t BPT = kBuckets / kPartBlock;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t bbits = 0, kmask = 0, bshift = 0, bmask = 0;
@@ -59,7 +60,6 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
             if (name_larger && threadIdx.x == 0) hard2[atomicAdd(n_hard2, 1u)] = run;
             continue;
         }
-        static_assert(CAP <= 4096, "a slot number and a count share a word");
 #pragma unroll
         for (uint32_t j = 0; j < BPT; ++j) s_cnt[threadIdx.x * BPT + j] = 0;
         if (threadIdx.x == 0) s_fail = 0;
