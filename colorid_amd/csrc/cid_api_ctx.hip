@@ -250,6 +250,7 @@ int cid_ctx_tune(cid_ctx *c, const char *name, long value) {
     if (!strcmp(name, "readid_long_from")) { c->tune.readid_long_from = value; return CID_OK; }
     if (!strcmp(name, "readid_long_deal")) { c->tune.readid_long_deal = value != 0; return CID_OK; }
     if (!strcmp(name, "readid_long_lds")) { c->tune.readid_long_lds = value != 0; return CID_OK; }
+    if (!strcmp(name, "readid_long_fuse")) { c->tune.readid_long_fuse = value != 0; return CID_OK; }
     if (!strcmp(name, "readid_blocks_per_cu")) {
         if (value < 1 || value > 4096) return fail(CID_ERR_INVALID, "readid_blocks_per_cu must be 1..4096");
         c->tune.readid_blocks_per_cu = (int)value;

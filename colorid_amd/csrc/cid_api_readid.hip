@@ -176,6 +176,79 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
     return CID_OK;
 }
 
+// Which kernel takes which read of a batch.  Reads of at least long_from(...) bases take the long-read path (cid_readlong.hip), the others
+// the LDS kernels.  The rule is a threshold on a read's bases alone, so that the device applies it to offsets that never exist on the
+// host (cid::long_route_launch): the smallest read whose set — with the windows a read of that many bases has, (bases - k) / stride + 1 —
+// would leave k_readid fewer than five waves per CU (kLdsReadBytesMax).  cid_ctx_tune "readid_long_from" = L: every read of at least L
+// bases does (measurements).
+static uint64_t long_from(const cid_ctx *c, const cid_index *ix, uint32_t stride_d, uint32_t start_sample) {
+    if (c->tune.readid_long_from >= 0) return (uint64_t)c->tune.readid_long_from;
+    auto need = [&](uint64_t b) { return readid_need(ix, stride_d, start_sample, b, b >= ix->k ? (b - ix->k) / stride_d + 1 : 0); };
+    uint64_t lo = 0, hi = 1ull << 21;   // need(lo) fits, need(hi) does not
+    if (need(hi) <= kLdsReadBytesMax) return ~0ull;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) / 2;
+        if (need(mid) <= kLdsReadBytesMax) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+// validates host offsets; the longest read in bases and in windows
+struct ReadRoute {
+    uint64_t max_bytes = 0, max_win = 0;
+    bool any_long = false;
+};
+static int readid_route(const cid_ctx *c, const cid_index *ix, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
+                        uint32_t start_sample, ReadRoute &rr) {
+    uint64_t max_bytes = 0, max_win = 0;
+    for (size_t r = 0; r < n_reads; ++r) {   // (both bounds before seq_off is read through them)
+        if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
+        if (read_seq0[r + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs at read %zu", r);
+        const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
+        uint64_t win = 0;
+        for (uint64_t s = s0; s < s1; ++s) {
+            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
+            const uint64_t len = seq_off[s + 1] - seq_off[s];
+            if (len >= ix->k) win += (len - ix->k) / stride_d + 1;
+        }
+        const uint64_t bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
+        if (bytes > max_bytes) max_bytes = bytes;
+        if (win > max_win) max_win = win;
+    }
+    rr.max_bytes = max_bytes; rr.max_win = max_win;
+    rr.any_long = max_bytes >= long_from(c, ix, stride_d, start_sample);
+    return CID_OK;
+}
+
+// A batch with long reads, everything on the device: the route (d_route: S_ROUTE), the long-read path for its reads, the LDS kernels for the
+// rest.  cap_*: the maxima a device-pointer caller stated (reads beyond them: status 3), ~0 = none.  h_*: the offsets on the host, or NULL.
+static int readid_routed(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0, size_t n_reads,
+                         uint32_t stride_d, uint32_t start_sample, uint64_t cap_bytes, uint64_t cap_win, bool clear_wide, uint32_t *d_report, uint32_t *d_n_kmers,
+                         uint8_t *d_status, const StripeArgs &sa, const uint64_t *h_seq_off, const uint64_t *h_read_seq0) {
+    int rc;
+    void *d_route;
+    if ((rc = slot_reserve(c, S_ROUTE, n_reads + 16 + 16, &d_route))) return rc;
+    uint32_t *d_stats = reinterpret_cast<uint32_t *>((uint8_t *)d_route + ((n_reads + 15) & ~(size_t)15));
+    if ((rc = cid::long_route_launch(c, d_seq_off, d_read_seq0, n_reads, ix->k, stride_d, long_from(c, ix, stride_d, start_sample), cap_bytes, cap_win,
+                                     (uint8_t *)d_route, d_stats)))
+        return rc;
+    const bool striped = sa.on();
+    const size_t C1 = (size_t)ix->n_colors + 1;
+    // wide rows count in place, and both kernels add into the same report: cleared once, here
+    if (ix->rs > 128 && clear_wide && !striped) HIP_TRY(hipMemsetAsync(d_report, 0, n_reads * C1 * 4, c->stream));
+    uint32_t stats[4] = {0, 0, 0, 0};
+    // first: it writes a status for every read (2 = the other kernels')
+    if ((rc = cid::readid_long(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, (const uint8_t *)d_route, false, d_report, d_n_kmers,
+                               d_status, sa, h_seq_off, h_read_seq0, d_stats, stats)))
+        return rc;
+    if (stats[1])   // the reads of the LDS kernels, sized by the longest of THEM
+        if ((rc = readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, stats[2], stats[3] ? stats[3] : 1,
+                                  (const uint8_t *)d_route, false, d_report, d_n_kmers, d_status, sa)))
+            return rc;
+    if (cap_bytes != ~0ull || cap_win != ~0ull)
+        if ((rc = cid::long_beyond_launch(c, (const uint8_t *)d_route, n_reads, striped ? 0u : (uint32_t)C1, d_report, d_n_kmers, d_status))) return rc;
+    return CID_OK;
+}
+
 int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off,
                          const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                          uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_report, uint32_t *d_n_kmers,
@@ -185,6 +258,10 @@ int cid_readid_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases
     if (stride_d == 0) return fail(CID_ERR_INVALID, "stride_d must be >= 1");
     if (n_reads == 0) return CID_OK;
     if (!d_bases || !d_seq_off || !d_read_seq0 || !d_report || !d_n_kmers || !d_status) return fail(CID_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (max_read_bytes >= long_from(c, ix, stride_d, start_sample))   // reads of any length: the long ones through cid_readlong.hip, in the same call
+        return readid_routed(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, max_read_bytes, max_read_windows, true, d_report,
+                             d_n_kmers, d_status, StripeArgs(), nullptr, nullptr);
     return readid_dev_impl(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, max_read_bytes, max_read_windows, nullptr,
                            true, d_report, d_n_kmers, d_status);
 }
@@ -253,60 +330,6 @@ int cid_readid_stripe_count_dev(cid_ctx *c, const cid_index *ix, const uint8_t *
                            d_report, d_n_kmers, d_status, sa);
 }
 
-// Which kernel takes which read of a batch: route empty = the LDS kernels take all of them; else route[r] = 1 sends read r through
-// the sort-based path.  max_bytes / max_win: the LDS sizing, over the reads the LDS kernels will see.  Validates the offsets.
-struct ReadRoute {
-    std::vector<uint8_t> route;
-    uint64_t max_bytes = 0, max_win = 0;
-    size_t n_long = 0;
-};
-static int readid_route(const cid_ctx *c, const cid_index *ix, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
-                        uint32_t start_sample, ReadRoute &rr) {
-    auto read_size = [&](size_t r, uint64_t &bytes, uint64_t &win) {
-        const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
-        win = 0;
-        for (uint64_t s = s0; s < s1; ++s) {
-            const uint64_t len = seq_off[s + 1] - seq_off[s];
-            if (len >= ix->k) win += (len - ix->k) / stride_d + 1;
-        }
-        bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
-    };
-    uint64_t max_bytes = 0, max_win = 0;
-    for (size_t r = 0; r < n_reads; ++r) {   // (both bounds before seq_off is read through them)
-        if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
-        if (read_seq0[r + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs at read %zu", r);
-        for (uint64_t s = read_seq0[r]; s < read_seq0[r + 1]; ++s)
-            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
-        uint64_t bytes, win;
-        read_size(r, bytes, win);
-        if (bytes > max_bytes) max_bytes = bytes;
-        if (win > max_win) max_win = win;
-    }
-    // routing: reads whose set would leave k_readid fewer than two waves per workgroup take the long-read path (cid_readlong.hip);
-    // cid_ctx_tune "readid_long_from" = L: every read of at least L bases does (measurements)
-    rr.route.clear();
-    rr.n_long = 0;
-    const long from = c->tune.readid_long_from;
-    auto is_long = [&](uint64_t bytes, uint64_t win) {
-        return from >= 0 ? bytes >= (uint64_t)from : readid_need(ix, stride_d, start_sample, bytes, win) > kLdsReadBytesMax;
-    };
-    if (is_long(max_bytes, max_win)) {
-        rr.route.assign(n_reads, 0);
-        max_bytes = max_win = 0;
-        for (size_t r = 0; r < n_reads; ++r) {
-            uint64_t bytes, win;
-            read_size(r, bytes, win);
-            if (is_long(bytes, win)) { rr.route[r] = 1; ++rr.n_long; }
-            else {
-                if (bytes > max_bytes) max_bytes = bytes;
-                if (win > max_win) max_win = win;
-            }
-        }
-    }
-    rr.max_bytes = max_bytes; rr.max_win = max_win;
-    return CID_OK;
-}
-
 // The two stripe passes for ANY read length and stripe width: d_bases resident, offsets on the host.  Per stripe the reads are routed
 // between the LDS kernels and the sort-based path exactly as cid_readid_count routes them (the mask of a read's q-th distinct k-mer
 // sits at the same word whichever kernel writes it, so different stripes may route a read differently).  Masks: one word per
@@ -354,7 +377,6 @@ static int readid_stripe_pass(cid_ctx *c, const cid_index *ix, const uint8_t *d_
     std::vector<uint64_t> zs;
     if ((rc = stripe_mask_starts(ix->k, stride_d, seq_off, n_seqs, read_seq0, n_reads, zs))) return rc;
     if (zs[n_reads] >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
-    const bool all_long = rr.n_long == n_reads, mixed = rr.n_long > 0 && !all_long;
     HIP_TRY(hipSetDevice(c->device));
     void *d_so, *d_r0, *d_zs;
     rc = slot_reserve(c, S_SEQOFF, (n_seqs + 1) * 8, &d_so); if (rc) return rc;
@@ -374,21 +396,12 @@ static int readid_stripe_pass(cid_ctx *c, const cid_index *ix, const uint8_t *d_
         HIP_TRY(hipMemcpyAsync(d_zs, zs_src, b1, hipMemcpyHostToDevice, c->stream));
     }
     sa.zero_start = (const uint64_t *)d_zs;
-    if (rr.n_long) {   // first: it writes a status for every read (2 = the other kernels')
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        rc = cid::readid_long(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, mixed ? rr.route.data() : nullptr, false,
-                              d_report, d_n_kmers, d_status, sa);
-        if (rc) return rc;
-    }
-    if (!all_long) {
-        void *d_skip = nullptr;
-        if (mixed) {
-            rc = slot_reserve(c, S_ROUTE, n_reads, &d_skip); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(d_skip, rr.route.data(), n_reads, hipMemcpyHostToDevice, c->stream));
-        }
+    if (rr.any_long)   // (the mask of a read's q-th distinct k-mer sits at the same word whichever kernel writes it)
+        rc = readid_routed(c, ix, d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample, ~0ull, ~0ull, false, d_report,
+                           d_n_kmers, d_status, sa, seq_off, read_seq0);
+    else
         rc = readid_dev_impl(c, ix, d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample, rr.max_bytes,
-                             rr.max_win ? rr.max_win : 1, (const uint8_t *)d_skip, false, d_report, d_n_kmers, d_status, sa);
-    }
+                             rr.max_win ? rr.max_win : 1, nullptr, false, d_report, d_n_kmers, d_status, sa);
     HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors leave scope
     return rc;
 }
@@ -422,11 +435,7 @@ static int readid_resident(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
     int rc;
     ReadRoute rr;
     if ((rc = readid_route(c, ix, seq_off, n_seqs, read_seq0, n_reads, stride_d, start_sample, rr))) return rc;
-    const std::vector<uint8_t> &route = rr.route;
-    const size_t n_long = rr.n_long;
-    const bool all_long = n_long == n_reads, mixed = n_long > 0 && !all_long;
-    const size_t C1 = (size_t)ix->n_colors + 1;
-    if (!all_long && !d_so) {
+    if (!d_so) {
         rc = slot_reserve(c, S_SEQOFF, (n_seqs + 1) * 8, &d_so); if (rc) return rc;
         rc = slot_reserve(c, S_READ0, (n_reads + 1) * 8, &d_r0); if (rc) return rc;
         const size_t b0 = (n_seqs + 1) * 8, b1 = (n_reads + 1) * 8;
@@ -439,24 +448,11 @@ static int readid_resident(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
         HIP_TRY(hipMemcpyAsync(d_so, so_src, b0, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_r0, r0_src, b1, hipMemcpyHostToDevice, c->stream));
     }
-    if (ix->rs > 128 && mixed) HIP_TRY(hipMemsetAsync(d_rep, 0, n_reads * C1 * 4, c->stream));   // both kernels count in place
-    if (n_long) {   // first: it writes a status for every read (2 = the other kernel's)
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        rc = cid::readid_long(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, mixed ? route.data() : nullptr, !mixed, d_rep,
-                              d_nk, d_status);
-        if (rc) return rc;
-    }
-    if (!all_long) {
-        void *d_skip = nullptr;
-        if (mixed) {
-            rc = slot_reserve(c, S_ROUTE, n_reads, &d_skip); if (rc) return rc;
-            HIP_TRY(hipMemcpyAsync(d_skip, route.data(), n_reads, hipMemcpyHostToDevice, c->stream));
-        }
-        rc = readid_dev_impl(c, ix, d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample, rr.max_bytes,
-                             rr.max_win ? rr.max_win : 1, (const uint8_t *)d_skip, !mixed, d_rep, d_nk, d_status);
-        if (mixed) HIP_TRY(hipStreamSynchronize(c->stream));   // `route` leaves scope
-    }
-    return rc;
+    if (rr.any_long)   // the device routes every read between the long-read path and the LDS kernels and makes the former's work lists
+        return readid_routed(c, ix, d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample, ~0ull, ~0ull, true, d_rep, d_nk,
+                             d_status, StripeArgs(), seq_off, read_seq0);
+    return readid_dev_impl(c, ix, d_bases, (const uint64_t *)d_so, (const uint64_t *)d_r0, n_reads, stride_d, start_sample, rr.max_bytes,
+                           rr.max_win ? rr.max_win : 1, nullptr, true, d_rep, d_nk, d_status);
 }
 
 int cid_readid_count_resident(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, size_t n_seqs,

@@ -611,7 +611,8 @@ static int fastq_begin(cid_fastq *fq, const cid_index *ix, cid_kmerset *ks, uint
         hipLaunchKernelGGL(cid::k_fq_ids, dim3(grid), dim3(256), 0, st, F[0], n, id_begin.p, id_off.p, ids.p);
         hipLaunchKernelGGL(cid::k_fq_read_seq0, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, read_seq0.p, n, (uint32_t)nf);
         HIP_TRY(hipGetLastError());
-        // a6-a10 on the packed batch (the LDS kernels: reads that do not fit a wave's LDS are not this front end's input)
+        // a6-a10 on the packed batch: records of any length (cid_readid_count_dev routes the long ones through cid_readlong.hip, whose
+        // work lists are made on the device from seq_off / read_seq0 — offsets that never exist on the host)
         rc = cid_readid_count_dev(c, ix, bases.p, seq_off.p, read_seq0.p, n, stride_d, start_sample, hs.max_bytes, hs.max_win ? hs.max_win : 1,
                                   report.p, nk.p, status.p);
         if (rc) return rc;

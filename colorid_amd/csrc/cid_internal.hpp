@@ -47,17 +47,27 @@ struct StripePass {
 };
 
 // read_id for reads that do not fit (or badly fit) a wave's LDS (cid_readlong.hip): per-read k-mer sets by workgroup-wide LDS hash
-// tables, the ordered search by slices of a read.  route == NULL: every read; else only reads with route[r] != 0 — the others get
-// status 2 and nothing else is written for them.  clear_wide: zero the whole report first when rows are wider than 128 words (those
-// kernels count in place).  Waits for the stream once, at its end.
-int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
-                size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
-                uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp = StripePass());
-// the same by a global radix sort of every window of the batch (cid_kmerset.hip; round 1's path): byte-string keys — k > 32, or a
-// lower-case base among the long reads — and what readid_long hands back
+// tables, the ordered search by slices of a read.  Everything — bases AND offsets — is on the device; the work lists are made there
+// (round 6).  d_route == NULL: every read; else only reads with d_route[r] == 1 — the others get status 2 and nothing else is written
+// for them.  clear_wide: zero the whole report first when rows are wider than 128 words (those kernels count in place).  h_seq_off /
+// h_read_seq0: the same offsets on the host when the caller has them (NULL: downloaded IF a read needs the sorting path).
+// d_route_stats (4 words, long_route_launch's) come down into route_stats with the plan's totals.  Waits for the stream twice: for the
+// lists' sizes (64 bytes) before its kernels, and at its end.
+int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0,
+                size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *d_route, bool clear_wide, uint32_t *d_report,
+                uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp = StripePass(), const uint64_t *h_seq_off = nullptr,
+                const uint64_t *h_read_seq0 = nullptr, const uint32_t *d_route_stats = nullptr, uint32_t *route_stats = nullptr);
+// d_route[r] = 1: read r has at least long_from bases (the long-read path's), 0: the LDS kernels', 3: beyond cap_bytes / cap_win (what a
+// device-pointer caller stated as maxima; long_beyond_launch gives those status 3 and an empty row).  d_stats[4]: long reads, LDS-kernel
+// reads, the longest of the latter in bases and in windows.  Asynchronous.
+int long_route_launch(cid_ctx *c, const uint64_t *d_seq_off, const uint64_t *d_read_seq0, size_t n_reads, uint32_t k, uint32_t stride_d, uint64_t long_from,
+                      uint64_t cap_bytes, uint64_t cap_win, uint8_t *d_route, uint32_t *d_stats);
+int long_beyond_launch(cid_ctx *c, const uint8_t *d_route, size_t n_reads, uint32_t report_width, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status);
+// the same by a global radix sort of every window of the batch (cid_kmerset_cold.hip; round 1's path): byte-string keys — k > 32, or the
+// reads with a lower-case base that readid_long hands back (merge_status: only the routed reads' statuses are written).  Offsets on the host.
 int readid_long_sorted(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                        size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
-                       uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp = StripePass());
+                       uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp = StripePass(), bool merge_status = false);
 
 // a5 / a4 on k-mers that are already on the device as 2-bit codes (k <= 32); outputs go to HOST buffers
 int search_count_codes(cid_ctx *c, const cid_index *ix, const uint64_t *d_codes, const uint32_t *d_counts, size_t n, uint32_t k,

@@ -454,10 +454,10 @@ void launch_extract(const cid_kmerset *ks, hipStream_t st, unsigned grid, size_t
                     const uint64_t *seq_off, const uint64_t *win_off, uint64_t base0) {
     if (ks->targeted)
         hipLaunchKernelGGL(cid::k_extract_codes<true>, dim3(grid), dim3(256), shmem, st, bases, segs, n_segs, ks->k, mode, ks->sentinel, ks->raw, ks->d_flags, seq_off,
-                           win_off, base0, ks->raw_key, ks->key_for);
+                           win_off, base0, ks->raw_key, ks->key_for, (const uint32_t *)nullptr, (uint8_t *)nullptr);
     else
         hipLaunchKernelGGL(cid::k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, bases, segs, n_segs, ks->k, mode, ks->sentinel, ks->raw, ks->d_flags, seq_off,
-                           win_off, base0, (uint32_t *)nullptr, cid::KeyFor{});
+                           win_off, base0, (uint32_t *)nullptr, cid::KeyFor{}, (const uint32_t *)nullptr, (uint8_t *)nullptr);
 }
 // room for `want_n` window codes (and their keys) in the unsorted buffer, what it holds kept
 int grow_raw(cid_kmerset *ks, size_t need_n, hipStream_t st) {

@@ -284,9 +284,14 @@ __global__ void k_keep_gt(const uint32_t *counts, uint64_t t, uint32_t *keep, ui
 }
 
 // d_bases resident; host seq_off / read_seq0.  Writes report / n_kmers / status to DEVICE arrays.
+__global__ void k_merge_status(const uint8_t *mine, uint8_t *status, uint64_t n, int only_routed) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && (!only_routed || mine[r] != 2)) status[r] = mine[r];
+}
+
 int readid_long_sorted(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,
                        size_t n_reads, uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report,
-                       uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp) {
+                       uint32_t *d_n_kmers, uint8_t *d_status, const StripePass &sp, bool merge_status) {
     const uint32_t k = index_k(ix);
     hipStream_t st = ctx_stream(c);
     const uint32_t msz = index_m_size(ix);           // > 0: the sets hold minimizers of length msz
@@ -320,7 +325,11 @@ int readid_long_sorted(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, 
     wstart[n_reads] = W;
     if (W >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
     const size_t C1 = (size_t)index_n_colors(ix) + 1;
-    HIP_TRY(hipMemcpyAsync(d_status, status.data(), n_reads, hipMemcpyHostToDevice, st));
+    // the statuses this pass works with are its own; the caller's array takes them at the end — all of them, or (merge_status: a few reads
+    // of a batch redone here, cid_readlong.hip) only those of the routed reads
+    DevBuf<uint8_t> d_st(c);
+    if (int rc0 = d_st.alloc(n_reads)) return rc0;
+    HIP_TRY(hipMemcpyAsync(d_st.p, status.data(), n_reads, hipMemcpyHostToDevice, st));
     DevBuf<uint64_t> d_wstart(c), d_codes(c), d_sorted(c), d_list(c), d_lstart(c);
     DevBuf<uint32_t> d_idx(c), d_sidx(c), d_flags(c), d_pos(c);
     DevBuf<Segment> d_segs(c);
@@ -340,7 +349,8 @@ int readid_long_sorted(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, 
             unsigned grid = (unsigned)((segs.size() + 3) / 4);
             if (grid > 8192) grid = 8192;
             hipLaunchKernelGGL(k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, d_bases, d_segs.p, (uint32_t)segs.size(), k, 1, sentinel_k,
-                               d_codes.p, d_lower.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr, KeyFor{});
+                               d_codes.p, d_lower.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr, KeyFor{},
+                               (const uint32_t *)nullptr, (uint8_t *)nullptr);
             int lower = 0;
             HIP_TRY(hipMemcpyAsync(&lower, d_lower.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -397,10 +407,12 @@ int readid_long_sorted(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, 
     p.colour_base = sp.colour_base; p.report_width = sp.report_width; p.write_nohits = sp.write_nohits;
     p.wave_bytes = (uint32_t)((4ull * kWave * p.n_hash + 4ull * p.hist_pad + 15) & ~15ull);
     if ((size_t)(kBlock / kWave) * p.wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
-    p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_status;
+    p.report = d_report; p.n_kmers = d_n_kmers; p.status = d_st.p;
     uint64_t grid = (n_reads + 3) / 4;
     if (grid > 4096) grid = 4096;
     HIP_TRY(launch_readid_list(p, (int)grid, st));
+    hipLaunchKernelGGL(k_merge_status, dim3(grid_for_n(n_reads)), dim3(256), 0, st, d_st.p, d_status, (uint64_t)n_reads, merge_status ? 1 : 0);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     return CID_OK;
 }

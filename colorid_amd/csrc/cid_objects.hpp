@@ -22,6 +22,7 @@ struct cid_tunables {
     long readid_long_from = -1;       // reads of at least this many bases take the long-read path (-1: the shipped rule, readid_route)
     bool readid_long_deal = true;     // long reads of four buckets and more: their windows dealt to the buckets once (false: every bucket re-reads the read)
     bool readid_long_lds = true;      // long reads: per-read sets by LDS hash tables (cid_readlong.hip); false = round 1's global radix sort
+    bool readid_long_fuse = true;     // long reads of one hash table: codes + table in one kernel (k_long_fused); false = k_extract_codes + k_long_first_flags
     // the two measured-and-rejected schedulings of k_search_count; only a `make TUNE=1` build contains their kernels
     bool search_persist = false;      // persistent grid, one work queue per XCD
     bool search_mixed = false;        // 32-byte rows: each k-mer's last row through the scalar cache

@@ -3,12 +3,16 @@
 // (rocPRIM radix sort of (code, window) pairs, 6 passes over 1.8 GB) only to learn, per read, which windows hold the FIRST occurrence
 // of their k-mer.  That is a per-read question, and a read's windows fit a workgroup's LDS once they are cut by a hash of the code:
 //
-//   k_extract_codes      windows -> canonical 2-bit codes (cid_windows.hpp; minimizer indices: -> minimizer codes)
-//   k_long_first_flags   work item = (read, bucket b of P): the read's windows whose mixed code falls in bucket b go through ONE LDS
-//                        hash table of 4-byte slots (window index << 10 | 10-bit tag; the code itself is read back from the code
-//                        array only when a tag matches), atomicMin keeps the smallest window per code; the winners set their bit
-//                        in a bitmap over the batch's windows.  P = windows / 16 384, so a pass fills half of a 32 768-slot table;
-//                        a pass that overflows anyway is redone on sub-buckets (a further hash bit per level).
+//   k_long_route         (callers with mixed batches) which reads are this path's: at least `long_from` bases
+//   k_long_plan / _emit  the plan of the batch, on the device (round 6): classes, window numbering, every work list below — from
+//                        seq_off / read_seq0 in HBM; the host reads back 64 bytes of totals to size the lists
+//   k_long_fused         reads of ONE table (<= 16 384 windows: every 10 kb read): bases -> 2-bit fields in LDS -> rolling canonical codes ->
+//                        LDS hash table of 4-byte slots (window index << 10 | 10-bit tag), atomicMin keeps the smallest window per
+//                        code -> the winners' bits as whole words of the first-occurrence bitmap; the codes leave for k_readid_slices
+//   k_extract_codes      (longer reads, strides that stretch a read beyond the fused kernel's LDS) windows -> canonical 2-bit codes
+//   k_long_deal          reads of three buckets and more: their (code, window) pairs dealt to the buckets' segments once
+//   k_long_first_flags   work item = (read, bucket b of P): the read's windows whose mixed code falls in bucket b through ONE table;
+//                        P = windows / 16 384; a pass that overflows anyway is redone on sub-buckets (a further hash bit per level)
 //   scan (cid_scan.hpp)  exclusive prefix of the bitmap words' popcounts: rank(w) of any window without a second pass
 //   k_readid_slices      the in-order search, one wave per slice of a read, straight from the bitmap and the code array: the flagged
 //                        windows in window order ARE the read's k-mers in first-occurrence order (cid_readid.hip); k_readid_combine
@@ -16,9 +20,9 @@
 //   (k_long_scatter      the same k-mers as lists, for k_readid_list: rows wider than 1 KiB and colour-stripe passes)
 //
 // A read's windows start at a multiple of 32 in the batch's numbering (the code array has unused gaps): its bitmap words are its own.
-// No host round trip between the kernels: nothing is sized by a count only the device knows.
-// Byte-string keys (k > 32, or a lower-case base: its case is kept), rows wider than 1 KiB and colour-stripe
-// passes keep round 1's path (cid_kmerset.hip: readid_long_sorted) — with this file's lists where the keys pack.
+// PER READ (round 6; until round 5 per batch): a read with a lower-case base (its case is kept: byte-string keys), of
+// more than 2^22 - 2 windows, or whose table crowded seven levels deep is marked in redo[] and goes — alone — through round 1's sorting
+// path (cid_kmerset_cold.hip: readid_long_sorted), which also keeps k > 32.
 #include <cstring>
 #include <vector>
 
@@ -54,16 +58,26 @@ __device__ __forceinline__ uint64_t long_mix(uint64_t x) {   // a bijection of t
     return x;
 }
 
+// k_long_fused's table hash: the slot and the tag of a code.  Nothing rests on it being injective (a matching tag is followed by a comparison
+// of the codes), so two 32-bit multiplies do where long_mix spends two 64-bit ones.
+__device__ __forceinline__ uint32_t long_mix32(uint64_t code) {
+    uint32_t x = (uint32_t)code ^ ((uint32_t)(code >> 32) * 0x9E3779B1u);
+    x ^= x >> 15; x *= 0x2C1B3C6Du;
+    x ^= x >> 12; x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return x;
+}
+
 // The pre-pass of long reads (more than kDealFromBuckets buckets): every bucket's workgroup used to re-read and re-hash ALL the read's
 // windows to find its own — 100 kb reads 11.1 ms, 1 Mb reads 26.9 ms per 150 Mbases against 8.0 at 10 kb.  Here a workgroup takes one
 // chunk of a read and deals its (code, window) pairs to the buckets' segments once (LDS counters hand out the places); a bucket's pass
 // then reads its own pairs only.  A segment has room for the mean + 25 % + 96 (the mixed codes spread evenly: four standard deviations
 // are 12 % at 16 384 / 7 per segment, less at more buckets' smaller means only in absolute terms — hence the + 96); one that
-// overflows anyway raises flags[1] and the batch is redone on the sorting path.
+// overflows anyway marks its read (redo[read], flags[1]): that read alone is redone on the sorting path.
 constexpr uint32_t kDealBlock = 1024, kDealStageFrom = 24;   // buckets from which a chunk's pairs are grouped in LDS before they are written
 __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongDeal *deals,
                                                            const uint32_t *chunk_deal, const uint32_t *chunk_no, uint32_t n_chunks_all, uint64_t sentinel,
-                                                           uint64_t *pair_code, uint32_t *pair_idx, uint32_t *counts, int *flags) {
+                                                           uint64_t *pair_code, uint32_t *pair_idx, uint32_t *counts, int *flags, uint8_t *redo) {
     // A chunk's windows are first grouped by bucket in LDS (their numbers only: 64 KiB), then every bucket's pairs leave as one stretch:
     // written straight from the window loop a wave's 64 pairs went to forty different segments, 8 and 4 bytes at a time — 2.5 ms per 150 M
     // windows of 1 Mb reads, the price of 64-byte memory transactions for 12 bytes.
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
                     const uint64_t o = d.pair_base + ((uint64_t)bk * d.n_chunks + j) * d.cap + at;
                     pair_code[o] = code;
                     pair_idx[o] = w;
-                } else atomicOr(&flags[1], 1);
+                } else { redo[d.read] = 1; atomicOr(&flags[1], 1); }
             }
             __syncthreads();
             if (threadIdx.x < P) counts[d.count_base + threadIdx.x * d.n_chunks + j] = s_cnt[threadIdx.x] < d.cap ? s_cnt[threadIdx.x] : d.cap;
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
                 pair_idx[o] = w;
             } else over = true;
         }
-        if (over) atomicOr(&flags[1], 1);
+        if (over) { redo[d.read] = 1; atomicOr(&flags[1], 1); }
         if (threadIdx.x < P) counts[d.count_base + threadIdx.x * d.n_chunks + j] = s_cnt[threadIdx.x] < d.cap ? s_cnt[threadIdx.x] : d.cap;
         __syncthreads();
     }
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
 // one L2 (workgroups are dealt to the XCDs in turn).  gridDim.x is a multiple of 8.
 __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongItem *items, uint32_t n_items, uint64_t sentinel,
                                    uint32_t slots, uint32_t bm_words, uint32_t *bitmap, int *flags, const LongDeal *deals, const uint64_t *pair_code,
-                                   const uint32_t *pair_idx, const uint32_t *deal_counts) {
+                                   const uint32_t *pair_idx, const uint32_t *deal_counts, uint8_t *redo) {
     extern __shared__ uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
     __shared__ int s_over;
     __shared__ uint32_t s_pref[kLongMaxChunks + 1];   // a dealt bucket: pairs in the segments before chunk j
@@ -228,7 +242,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
             __syncthreads();
             if (s_over) {   // (workgroup-uniform)
                 if (level == kLongMaxLevel) {
-                    if (threadIdx.x == 0) atomicOr(&flags[1], 1);   // the host redoes the batch on the sorting path
+                    if (threadIdx.x == 0) { redo[im.read] = 1; atomicOr(&flags[1], 1); }   // the host redoes this read on the sorting path
                     break;
                 }
                 ++level;
@@ -294,13 +308,624 @@ __global__ void k_long_short_rows(const uint8_t *status, uint32_t n_reads, uint3
     if ((threadIdx.x & 63u) == 0) n_kmers[r] = 0;
 }
 
-int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0, size_t n_reads,
-                uint32_t stride_d, uint32_t start_sample, const uint8_t *route, bool clear_wide, uint32_t *d_report, uint32_t *d_n_kmers,
-                uint8_t *d_status, const StripePass &sp) {
-    const uint32_t k = index_k(ix);
-    if (k > 32 || !c->tune.readid_long_lds)
-        return readid_long_sorted(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, route, clear_wide, d_report, d_n_kmers, d_status, sp);
+
+// ------------------------------------------------------------------------------------------------
+// The plan of a batch, made on the device (round 6): which reads this path takes, where their windows are numbered, and every work list
+// of the kernels below — from seq_off / read_seq0 in HBM.  Until round 5 the host walked the offsets and filled ten std::vectors per call
+// (0.6 ms of a 8.2 ms call on 15 000 reads of 10 kb) and the device FASTQ front end, whose offsets never exist on the host, had to
+// refuse long reads altogether.
+//   k_long_plan   one thread per read: its class, its windows; ONE pass of seven decoupled look-back scans (cid_scan.hpp's, a word per
+//                 tile and field) gives every read its place in every list; the last tile leaves the totals
+//   (the host reads the totals — 64 bytes, the one wait before the kernels — and sizes the lists)
+//   k_long_emit   one thread per read: its entries of the lists
+enum LongClass : uint8_t {
+    kClsOther = 0,      // not routed here (status 2)
+    kClsShort = 1,      // the first mate has no window (status 1: too_short)
+    kClsFusedSmall = 2, // one hash table; codes and table in ONE kernel (k_long_fused), 256 threads / 8 192 slots
+    kClsFusedBig = 3,   //   ... 1 024 threads / 32 768 slots
+    kClsItemsSmall = 4, // k_extract_codes + k_long_first_flags: reads whose bases do not fit the fused kernel's LDS (strides), many mates
+    kClsItemsBig = 5,   //   ... and every read of several buckets
+    kClsSorted = 6      // more windows than a 4-byte slot numbers: the sorting path (redo[r] is set from the start)
+};
+constexpr uint32_t kFuseSeqs = 4;                 // sequences (mates) of a read the fused kernel keeps a table of
+constexpr uint32_t kFusePosSmall = 6144, kFusePosBig = 20480;   // positions (bases, each mate padded to its 16-byte pieces) of a read in its LDS
+constexpr uint32_t kPlanFields = 7, kPlanPer = 4, kPlanTile = kScanBlock * kPlanPer;
+struct LongPlanParams {
+    const uint64_t *seq_off, *read_seq0;
+    const uint8_t *route;     // NULL: every read
+    const uint8_t *bases;     // (only its address: the 16-byte pieces of the fused kernel are pieces of the address space)
+    uint64_t n_reads;
+    uint32_t k, stride, seg_win;
+    uint32_t fuse, cut, own_search, deal;
+    // out
+    uint64_t *wstart, *wend;   // [n_reads + 1], [n_reads]
+    uint32_t *win;             // [n_reads]
+    uint8_t *cls, *redo, *status;
+    uint64_t *pre;             // [kPlanFields][n_reads + 1]: exclusive prefixes
+    uint64_t *state;           // [kPlanFields][tiles + 2] look-back words (zeroed)
+    uint64_t *totals;          // [kPlanFields + 1]
+    int *flags;
+};
+struct LongRow { uint32_t win, segs, cls; };
+__device__ __forceinline__ LongRow long_row(const LongPlanParams &p, uint64_t r) {
+    LongRow o{0u, 0u, kClsOther};
+    if (p.route && p.route[r] != 1) return o;
+    const uint64_t s0 = p.read_seq0[r], s1 = p.read_seq0[r + 1];
+    if (s1 <= s0 || p.seq_off[s0 + 1] - p.seq_off[s0] < p.k) { o.cls = kClsShort; return o; }
+    uint64_t win = 0, segs = 0, pos = 0;
+    uint32_t nk = 0;
+    for (uint64_t s = s0; s < s1; ++s) {
+        const uint64_t a = p.seq_off[s], len = p.seq_off[s + 1] - a;
+        if (len < p.k) continue;
+        const uint64_t nw = (len - p.k) / p.stride + 1;
+        win += nw;
+        segs += (nw + p.seg_win - 1) / p.seg_win;
+        pos += (len + ((uint64_t)(uintptr_t)(p.bases + a) & 15u) + 31u) & ~(uint64_t)31;
+        ++nk;
+    }
+    if (win > kLongMaxWin) { o.cls = kClsSorted; return o; }
+    o.win = (uint32_t)win;
+    o.segs = (uint32_t)segs;
+    const bool can_fuse = p.fuse && nk <= kFuseSeqs;
+    if (can_fuse && win <= kLongSmallWin && pos <= kFusePosSmall) o.cls = kClsFusedSmall;
+    else if (can_fuse && win <= kLongFill && pos <= kFusePosBig) o.cls = kClsFusedBig;
+    else o.cls = win <= kLongSmallWin ? kClsItemsSmall : kClsItemsBig;
+    if (o.cls == kClsFusedSmall || o.cls == kClsFusedBig) o.segs = 0;
+    return o;
+}
+// what read r adds to each of the seven lists
+struct LongDealShape { uint32_t P, nc, cap; bool deal; };
+__device__ __forceinline__ LongDealShape long_deal_shape(uint32_t win, uint32_t cls, uint32_t deal_on) {
+    LongDealShape d{0u, 0u, 0u, false};
+    if (cls != kClsItemsBig) return d;
+    d.P = (win + kLongFill - 1) / kLongFill;
+    if (d.P >= kDealFromBuckets && deal_on) {
+        d.deal = true;
+        d.nc = (win + kDealChunk - 1) / kDealChunk;
+        d.cap = kDealChunk / d.P + kDealChunk / d.P / 4 + 96;
+    }
+    return d;
+}
+__device__ __forceinline__ void long_fields(const LongPlanParams &p, const LongRow &row, uint64_t v[kPlanFields]) {
+    const bool windows = row.cls >= kClsFusedSmall && row.cls <= kClsItemsBig;
+    const LongDealShape d = long_deal_shape(row.win, row.cls, p.deal);
+    const uint32_t n_sl = !windows || !p.own_search ? 0u : (p.cut ? (row.win + kSliceWindows - 1) / kSliceWindows : 1u);
+    v[0] = windows ? ((uint64_t)row.win + 31u) & ~(uint64_t)31 : 0ull;                                  // windows (a read's start at a multiple of 32)
+    v[1] = (row.cls == kClsFusedSmall ? 1ull : 0ull) | (row.cls == kClsFusedBig ? 1ull << 32 : 0ull);    // the fused kernel's two lists
+    v[2] = (row.cls == kClsItemsSmall ? 1ull : 0ull) | ((uint64_t)d.P << 32);                            // k_long_first_flags' items
+    v[3] = (uint64_t)n_sl | (n_sl > 1 ? 1ull << 32 : 0ull);                                              // slices | reads of several slices
+    v[4] = (uint64_t)row.segs | (d.deal ? 1ull << 32 : 0ull);                                            // k_extract_codes' segments | deals
+    v[5] = (uint64_t)d.nc | ((uint64_t)d.P * d.nc) << 32;                                                // chunks of dealt reads | their segment counters
+    v[6] = (uint64_t)d.P * d.nc * d.cap;                                                                 // places of dealt pairs
+}
+__global__ __launch_bounds__(kScanBlock) void k_long_plan(LongPlanParams p) {
+    const uint64_t n = p.n_reads + 1;   // (element n_reads: empty — it receives the totals' positions, wstart[n_reads] among them)
+    const uint64_t tiles = (n + kPlanTile - 1) / kPlanTile;
+    const uint64_t tile = scan_ticket(p.state, tiles);
+    if (tile >= tiles) return;
+    const uint64_t i0 = tile * kPlanTile + (uint64_t)threadIdx.x * kPlanPer;
+    LongRow row[kPlanPer];
+    uint64_t v[kPlanPer][kPlanFields];
+#pragma unroll
+    for (uint32_t j = 0; j < kPlanPer; ++j) {
+        row[j] = i0 + j < p.n_reads ? long_row(p, i0 + j) : LongRow{0u, 0u, kClsOther};
+        long_fields(p, row[j], v[j]);
+    }
+#pragma unroll
+    for (uint32_t f = 0; f < kPlanFields; ++f) {
+        uint64_t mine = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPlanPer; ++j) mine += v[j][f];
+        uint64_t tile_sum;
+        const uint64_t local = scan_block_exclusive(mine, &tile_sum);
+        const uint64_t tile_excl = scan_lookback_block(p.state + (size_t)f * (tiles + 2), tile, tiles, tile_sum);
+        uint64_t run = tile_excl + local;
+#pragma unroll
+        for (uint32_t j = 0; j < kPlanPer; ++j) {
+            if (i0 + j < n) p.pre[(size_t)f * n + i0 + j] = run;
+            if (f == 0 && i0 + j < n) {
+                p.wstart[i0 + j] = run;
+                if (i0 + j < p.n_reads) p.wend[i0 + j] = run + row[j].win;
+            }
+            run += v[j][f];
+        }
+        if (tile == tiles - 1 && threadIdx.x == 0) p.totals[f] = tile_excl + tile_sum;
+    }
+    bool any_sorted = false;
+#pragma unroll
+    for (uint32_t j = 0; j < kPlanPer; ++j) {
+        if (i0 + j >= p.n_reads) continue;
+        const uint32_t cls = row[j].cls;
+        p.win[i0 + j] = row[j].win;
+        p.cls[i0 + j] = (uint8_t)cls;
+        p.redo[i0 + j] = cls == kClsSorted ? 1 : 0;
+        p.status[i0 + j] = cls == kClsShort ? 1 : (cls == kClsOther || cls == kClsSorted ? 2 : 0);
+        any_sorted = any_sorted || cls == kClsSorted;
+    }
+    if (any_sorted) atomicOr(&p.flags[2], 1);
+}
+
+// What k_long_fused wants to know of a read, in ONE record (read through list[] -> wstart / wend -> read_seq0 -> seq_off, the workgroup
+// waited for four dependent round trips per read before its first base arrived): its windows, and per mate the 16-byte-aligned address its
+// pieces start at, the position of its first base among the read's staged positions, its length, its first window, its first piece.
+struct FuseItem {
+    uint32_t read, nw, n_seq, n_pieces;
+    uint64_t w0, pad;
+    uint64_t addr[kFuseSeqs];
+    uint32_t first[kFuseSeqs], len[kFuseSeqs], wbase[kFuseSeqs], piece0[kFuseSeqs];
+};
+struct LongLists {
+    FuseItem *fused_small, *fused_big;
+    LongItem *items_small, *items_big;
+    ReadSlice *slices;
+    ReadCombine *combs;
+    Segment *segs;
+    uint32_t *seg_read;
+    LongDeal *deals;
+    uint32_t *chunk_deal, *chunk_no;
+};
+__global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_reads) return;
+    const uint32_t cls = p.cls[r];
+    if (cls < kClsFusedSmall || cls > kClsItemsBig) return;
+    const uint64_t n = p.n_reads + 1;
+    const uint32_t win = p.win[r];
+    const uint64_t w0 = p.wstart[r];
+    auto pre = [&](uint32_t f) { return p.pre[(size_t)f * n + r]; };
+    if (cls == kClsFusedSmall || cls == kClsFusedBig) {
+        FuseItem it{};
+        it.read = (uint32_t)r; it.nw = win; it.w0 = w0;
+        uint32_t ns = 0, wb = 0, piece = 0;
+        const uint64_t q0 = p.read_seq0[r], q1 = p.read_seq0[r + 1];
+        for (uint64_t s = q0; s < q1 && ns < kFuseSeqs; ++s) {
+            const uint64_t a = p.seq_off[s], len = p.seq_off[s + 1] - a;
+            if (len < p.k) continue;
+            const uint64_t addr = (uint64_t)(uintptr_t)(p.bases + a);
+            const uint32_t o = (uint32_t)(addr & 15u);
+            it.addr[ns] = addr - o;
+            it.first[ns] = piece * 16u + o;
+            it.len[ns] = (uint32_t)len;
+            it.wbase[ns] = wb;
+            it.piece0[ns] = piece;
+            wb += (uint32_t)((len - p.k) / p.stride) + 1u;
+            piece += (((uint32_t)len + o + 31u) & ~31u) / 16u;
+            ++ns;
+        }
+        it.n_seq = ns; it.n_pieces = piece;
+        if (cls == kClsFusedSmall) L.fused_small[(uint32_t)pre(1)] = it;
+        else L.fused_big[(uint32_t)(pre(1) >> 32)] = it;
+    }
+    const LongDealShape d = long_deal_shape(win, cls, p.deal);
+    if (cls == kClsItemsSmall) L.items_small[(uint32_t)pre(2)] = LongItem{(uint32_t)r, 0u, 1u, 0u};
+    if (cls == kClsItemsBig) {
+        uint32_t deal = 0;
+        if (d.deal) {
+            const uint32_t di = (uint32_t)(pre(4) >> 32), c0 = (uint32_t)pre(5);
+            L.deals[di] = LongDeal{pre(6), (uint32_t)(pre(5) >> 32), d.nc, d.cap, (uint32_t)r};
+            deal = di + 1;
+            for (uint32_t j = 0; j < d.nc; ++j) { L.chunk_deal[c0 + j] = di; L.chunk_no[c0 + j] = j; }
+        }
+        const uint32_t i0 = (uint32_t)(pre(2) >> 32);
+        for (uint32_t b = 0; b < d.P; ++b) L.items_big[i0 + b] = LongItem{(uint32_t)r, b, d.P, deal};
+    }
+    if (p.own_search) {
+        const uint32_t n_sl = p.cut ? (win + kSliceWindows - 1) / kSliceWindows : 1u;
+        const uint32_t s0 = (uint32_t)pre(3);
+        if (n_sl > 1) L.combs[(uint32_t)(pre(3) >> 32)] = ReadCombine{(uint32_t)r, s0, n_sl, 0u};
+        const uint64_t W1 = w0 + win;
+        for (uint32_t j = 0; j < n_sl; ++j) {
+            const uint64_t a = w0 + (uint64_t)j * kSliceWindows;
+            const uint64_t b = n_sl == 1 ? W1 : (a + kSliceWindows < W1 ? a + kSliceWindows : W1);
+            L.slices[s0 + j] = ReadSlice{(uint32_t)r, (uint32_t)a, (uint32_t)b, j | (n_sl > 1 ? 0x80000000u : 0u)};
+        }
+    }
+    if (cls == kClsItemsSmall || cls == kClsItemsBig) {   // the segments k_extract_codes walks: windows numbered mate by mate
+        uint32_t sg = (uint32_t)pre(4);
+        uint64_t W = w0;
+        const uint64_t q0 = p.read_seq0[r], q1 = p.read_seq0[r + 1];
+        for (uint64_t s = q0; s < q1; ++s) {
+            const uint64_t a = p.seq_off[s], len = p.seq_off[s + 1] - a;
+            if (len < p.k) continue;
+            const uint64_t nw = (len - p.k) / p.stride + 1;
+            for (uint64_t x = 0; x < nw; x += p.seg_win) {
+                const uint32_t m = (uint32_t)(nw - x < p.seg_win ? nw - x : p.seg_win);
+                L.segs[sg] = Segment{a + x * p.stride, W, m, p.stride};
+                L.seg_read[sg] = (uint32_t)r;
+                ++sg;
+                W += m;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_long_fused: reads of ONE hash table (at most 16 384 windows: every 10 kb read) — windows, codes, table and bitmap in one workgroup, straight
+// from the bases.  Round 5 ran k_extract_codes (1.2 GB of codes written per 150 Mbases) and then k_long_first_flags, whose insert loop
+// waited for a global load per window (a round trip per iteration, 16 waves per CU to hide it: 23 us per 10 kb read, 1.37 ms per
+// 150 Mbases) and read the code array back whenever two tags met.  Here a read's bases are staged once as 2-bit fields + bad-base bits
+// in LDS (16-byte pieces of the address space, so every load is aligned whatever the read's offset), a window's code is a few shifts
+// away whenever it is wanted — for the insert, for the tag check of another window, for the code array k_readid_slices walks — and a
+// thread remembers the slot each of its windows ended in: the winners are the windows whose slot still holds their number, their bits
+// leave as ballots (64 consecutive windows = two whole words of the read's own bitmap stretch; no LDS bitmap, no sweep of the table).
+// A read with a lower-case base (its case would have to be kept: SURVEY App. B Q2) or a table that crowds anyway marks redo[read].
+struct LongFuseParams {
+    const FuseItem *items;
+    uint32_t n_list, k, msz, stride, max_slots, pos_cap;
+    uint64_t sentinel;       // of the keys (k-mers, or minimizers)
+    uint64_t *codes;
+    uint32_t *bitmap;
+    uint8_t *redo;
+    int *flags;
+    unsigned long long *prof;   // CID_LONG_PROF builds: [gridDim.x][8] cycles per phase (thread 0's clock)
+};
+#ifdef CID_LONG_PROF
+#define LONG_PROF_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t; prof_t = t_; } } while (0)
+#else
+#define LONG_PROF_MARK(i) do { } while (0)
+#endif
+// this thread's (at most two) 16-byte pieces of a read's bases; a piece of padding behind a mate is never loaded
+template <uint32_t BLOCK>
+__device__ __forceinline__ void fuse_load_pieces(const FuseItem *it, uint4 (&pc)[2]) {
+    const uint32_t ns = it->n_seq, n_pieces = it->n_pieces;
+#pragma unroll
+    for (uint32_t j = 0; j < 2; ++j) {
+        const uint32_t x = threadIdx.x + j * BLOCK;
+        pc[j] = uint4{0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};   // 'N'
+        if (x >= n_pieces) continue;
+        uint32_t q = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < kFuseSeqs; ++t) q += (t < ns && x >= it->piece0[t]) ? 1u : 0u;
+        if (x * 16u < it->first[q] + it->len[q]) pc[j] = *reinterpret_cast<const uint4 *>(it->addr[q] + (uint64_t)(x - it->piece0[q]) * 16u);
+    }
+}
+template <uint32_t BLOCK, uint32_t ITERS>
+__global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
+    extern __shared__ uint32_t table[];   // max_slots, then the 2-bit fields (pos_cap / 16 + 4 words), the bad-base bits (pos_cap / 32 + 4 words), the bitmap
+    __shared__ uint32_t s_first[kFuseSeqs], s_wbase[kFuseSeqs + 1], s_piece0[kFuseSeqs + 1];
+    __shared__ uint32_t s_len[kFuseSeqs];
+    __shared__ int s_over;
+    uint32_t *s_pack = table + p.max_slots;
+    uint32_t *s_bad = s_pack + p.pos_cap / 16 + 4;
+    uint32_t *s_bm = s_bad + p.pos_cap / 32 + 4;   // BLOCK * ITERS / 32 words: the read's first-occurrence bits
+    const uint32_t pack_words = p.pos_cap / 16 + 4, bad_words = p.pos_cap / 32 + 4;
+    const uint32_t k = p.k, stride = p.stride;
+    const uint32_t chunk = (p.n_list + 7u) / 8u;   // (XCD x walks the x-th eighth of the list)
+    const uint32_t item0 = (blockIdx.x & 7u) * chunk, item1 = item0 + chunk < p.n_list ? item0 + chunk : p.n_list;
+    const uint32_t step = gridDim.x >> 3;
+    uint32_t item = item0 + (blockIdx.x >> 3);
+    uint4 pc[2];
+#ifdef CID_LONG_PROF
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
+    if (item < item1) fuse_load_pieces<BLOCK>(p.items + item, pc);
+    for (; item < item1; item += step) {
+        LONG_PROF_MARK(7);
+        const FuseItem *rec = p.items + item;
+        const uint32_t read = rec->read, nw = rec->nw, ns = rec->n_seq, n_pieces = rec->n_pieces;
+        const uint64_t w0 = rec->w0;
+        uint32_t slots = 1024;
+        while (slots < p.max_slots && slots < 2u * nw) slots <<= 1;
+        const uint32_t mask = slots - 1;
+        if (threadIdx.x < kFuseSeqs) {   // the read's mates: where their positions, windows and pieces start
+            const uint32_t t = threadIdx.x;
+            s_first[t] = rec->first[t]; s_len[t] = rec->len[t];
+            s_wbase[t] = t < ns ? rec->wbase[t] : nw;
+            s_piece0[t] = t < ns ? rec->piece0[t] : n_pieces;
+            if (t == 0) { s_wbase[kFuseSeqs] = nw; s_piece0[kFuseSeqs] = n_pieces; s_over = 0; }
+        }
+        for (uint32_t s = threadIdx.x; s < slots; s += BLOCK) table[s] = kLongEmpty;
+        for (uint32_t s = threadIdx.x; s < bad_words; s += BLOCK) s_bad[s] = 0xFFFFFFFFu;
+        for (uint32_t s = threadIdx.x; s < pack_words; s += BLOCK) s_pack[s] = 0u;
+        for (uint32_t s = threadIdx.x; s < BLOCK * ITERS / 32u; s += BLOCK) s_bm[s] = 0u;
+        __syncthreads();
+        LONG_PROF_MARK(0);   // record + clears
+        bool lower = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) {
+            const uint32_t x = threadIdx.x + j * BLOCK;
+            if (x >= n_pieces) continue;
+            uint32_t q = 0;
+            while (q + 1 < ns && x >= s_piece0[q + 1]) ++q;
+            const uint32_t pos = x * 16u;                                   // position of this piece's first byte
+            const uint32_t lo = s_first[q], hi = s_first[q] + s_len[q];      // the mate's bases: positions [lo, hi)
+            if (pos >= hi) continue;                                         // (padding behind the mate: its bits stay "bad")
+            const uint32_t words[4] = {pc[j].x, pc[j].y, pc[j].z, pc[j].w};
+            uint32_t code = 0, bad = 0, low = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t b = (words[t >> 2] >> (8u * (t & 3u))) & 0xFFu;
+                const uint32_t c2 = (b >> 1) & 3u;
+                code |= (c2 ^ (c2 >> 1)) << (2 * t);
+                const bool inside = pos + t >= lo && pos + t < hi;
+                const bool good = inside && good_base_dev(b);
+                bad |= (good ? 0u : 1u) << t;
+                low |= (good ? (b >> 5) & 1u : 0u) << t;
+            }
+            s_pack[x] = code;
+            reinterpret_cast<uint16_t *>(s_bad)[x] = (uint16_t)bad;
+            lower = lower || low != 0;
+        }
+        // the NEXT read's bases are asked for now: they arrive while this read's table is filled
+        if (item + step < item1) fuse_load_pieces<BLOCK>(p.items + item + step, pc);
+        LONG_PROF_MARK(1);   // staging (own part)
+        if (__syncthreads_or(lower ? 1 : 0)) {   // (workgroup-uniform) the byte-string path takes this read
+            if (threadIdx.x == 0) { p.redo[read] = 1; atomicOr(&p.flags[0], 1); }
+            __syncthreads();
+            continue;
+        }
+        auto code_at = [&](uint32_t w, bool &valid) -> uint64_t {   // the key of the read's window w
+            uint32_t q = 0;
+            while (q + 1 < ns && w >= s_wbase[q + 1]) ++q;
+            const uint32_t pos = s_first[q] + (w - s_wbase[q]) * stride;
+            if (bits_at_dev(s_bad, pos, k) != 0) { valid = false; return p.sentinel; }
+            const uint64_t lsb = bits_at_dev(s_pack, 2u * pos, 2u * k);
+            uint64_t msb;
+            canonical_code(lsb, k, &msb);
+            valid = true;
+            return p.msz ? minimizer_code(msb, k, p.msz) : msb;
+        };
+        LONG_PROF_MARK(2);   // barrier behind the staging
+        // A thread takes w_per CONSECUTIVE windows: the forward and the reverse-complement code of a window follow from the window before by
+        // one base each (the strided assignment paid two unaligned 64-bit extractions and a field reversal per window: ~150 instructions a
+        // window, 24 us per 10 kb read with sixteen waves on a CU — the kernel was instruction-bound).
+        const uint32_t w_per = (nw + BLOCK - 1) / BLOCK;   // <= ITERS
+        const uint32_t wa = threadIdx.x * w_per;
+        const uint64_t kmask = code_mask(k);
+        uint32_t slot_of[ITERS];   // where window wa + i ended (kLongEmpty: no k-mer there)
+        uint32_t q = 0, next_base = 0, pos = 0, good_run = 0;
+        uint64_t fwd = 0, rcv = 0;
+        auto prime = [&](uint32_t w) {   // the rolling state at window w: both codes and the run of good bases ending at its last base
+            q = 0;
+            while (q + 1 < ns && w >= s_wbase[q + 1]) ++q;
+            next_base = s_wbase[q + 1];
+            pos = s_first[q] + (w - s_wbase[q]) * stride;
+            const uint64_t lsb = bits_at_dev(s_pack, 2u * pos, 2u * k);
+            fwd = rev_fields(lsb, k);
+            rcv = ~lsb & kmask;
+            const uint64_t badbits = bits_at_dev(s_bad, pos, k);
+            good_run = badbits ? (uint32_t)__clzll((long long)badbits) - (64u - k) : k;   // the bases behind the last bad one
+        };
+        if (wa < nw) prime(wa);
+#pragma unroll
+        for (uint32_t i = 0; i < ITERS; ++i) slot_of[i] = kLongEmpty;
+        // Eight windows at a time, in three sweeps: (1) their codes — LDS reads and shifts only, nothing between them that the scheduler
+        // has to keep in order, (2) their slots asked for with eight compare-and-swaps in a row on the EMPTY value — at a load below a
+        // half most of them win their home slot at once, and the eight round trips overlap — (3) the losers, one by one as before.
+        // (One window after the other, every window paid three dependent LDS round trips: 30 000 cycles per 10 kb read.)
+        constexpr uint32_t kBatch = 8;
+        // A wave whose 64 threads all hold w_per windows of ONE mate at stride 1 (every wave of a read but its last, as a rule) runs the
+        // first sweep as straight-line code: no lane drops out, so nothing splits the eight windows into basic blocks of their own, the
+        // bases and bad-base bits they need are two 64-bit LDS reads for the batch, and their shifts interleave.
+        const bool plain = __all(wa + w_per <= nw && wa + w_per <= next_base && stride == 1) && !p.msz;
+        const uint32_t pos_a = pos;   // position of window wa
+#pragma unroll
+        for (uint32_t b0 = 0; b0 < ITERS; b0 += kBatch) {
+            if (b0 >= w_per) break;   // (workgroup-uniform)
+            uint64_t code[kBatch];
+            uint32_t old[kBatch];
+            if (plain) {
+                // window wa + i (i >= 1) takes in the base at position pos_a + k - 1 + i: this batch's new bases start at P
+                const uint32_t t0 = b0 ? b0 - 1u : 0u, P = pos_a + k + t0;
+                const uint32_t *pw = s_pack + (P >> 4), *bw = s_bad + (P >> 5);
+                const uint64_t nb = (((uint64_t)pw[1] << 32) | pw[0]) >> (2u * (P & 15u));    // >= 17 bases from P on
+                const uint64_t bb = (((uint64_t)bw[1] << 32) | bw[0]) >> (P & 31u);            // >= 33 bad-base bits from P on
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; ++j) {
+                    const uint32_t i = b0 + j;
+                    code[j] = p.sentinel;
+                    if (i >= w_per) break;   // (workgroup-uniform)
+                    if (i) {
+                        const uint32_t t = i - 1u - t0;
+                        const uint32_t c = (uint32_t)(nb >> (2u * t)) & 3u;
+                        fwd = ((fwd << 2) | c) & kmask;
+                        rcv = (rcv >> 2) | ((uint64_t)(3u - c) << (2u * (k - 1u)));
+                        good_run = ((uint32_t)(bb >> t) & 1u) ? 0u : good_run + 1u;
+                    }
+                    const uint64_t cd = fwd < rcv ? fwd : rcv;   // (equal: the same string)
+                    code[j] = good_run >= k ? cd : p.sentinel;
+#ifndef CID_LONG_NOSTORE
+                    p.codes[w0 + wa + i] = code[j];
+#endif
+                }
+            } else
+#pragma unroll
+            for (uint32_t j = 0; j < kBatch; ++j) {
+                const uint32_t i = b0 + j, w = wa + i;
+                code[j] = p.sentinel;
+                if (i >= w_per || w >= nw) continue;
+                if (i) {
+                    if (w == next_base || stride != 1) prime(w);   // the next mate; strides: every window from the bases
+                    else {                                          // one base further
+                        ++pos;
+                        const uint32_t pn = pos + k - 1;
+                        const uint32_t c = (s_pack[pn >> 4] >> (2u * (pn & 15u))) & 3u;
+                        const uint32_t bad = (reinterpret_cast<const uint16_t *>(s_bad)[pn >> 4] >> (pn & 15u)) & 1u;
+                        fwd = ((fwd << 2) | c) & kmask;
+                        rcv = (rcv >> 2) | ((uint64_t)(3u - c) << (2u * (k - 1u)));
+                        good_run = bad ? 0u : good_run + 1u;
+                    }
+                }
+                if (good_run >= k) {
+                    uint64_t cd = fwd < rcv ? fwd : rcv;   // (equal: the same string)
+                    if (p.msz) cd = minimizer_code(cd, k, p.msz);
+                    code[j] = cd;
+                }
+#ifndef CID_LONG_NOSTORE
+                p.codes[w0 + w] = code[j];
+#endif
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kBatch; ++j) {
+                old[j] = 0;
+#ifdef CID_LONG_NOATOMIC
+                continue;
+#endif
+                if (code[j] == p.sentinel) continue;
+                const uint32_t h = long_mix32(code[j]);
+                const uint32_t at = h & mask;
+                slot_of[b0 + j] = at;
+                old[j] = atomicCAS(&table[at], kLongEmpty, ((wa + b0 + j) << kLongTagBits) | (h >> (32u - kLongTagBits)));
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kBatch; ++j) {
+#ifdef CID_LONG_NOATOMIC
+                continue;
+#endif
+                if (code[j] == p.sentinel || old[j] == kLongEmpty) continue;   // no k-mer; or the home slot was free
+                const uint32_t h = long_mix32(code[j]);
+                const uint32_t tag = h >> (32u - kLongTagBits);
+                const uint32_t mine = ((wa + b0 + j) << kLongTagBits) | tag;
+                uint32_t at = slot_of[b0 + j], cur = old[j];
+                for (uint32_t probes = 0;; ++probes) {
+                    if ((cur & ((1u << kLongTagBits) - 1u)) == tag) {
+                        bool v2;
+                        if (code_at(cur >> kLongTagBits, v2) == code[j]) {   // the slot is this k-mer's
+                            atomicMin(&table[at], mine);
+                            break;
+                        }
+                    }
+                    at = (at + 1) & mask;
+                    if (probes >= slots / 4) { s_over = 1; at = kLongEmpty; break; }
+                    cur = atomicCAS(&table[at], kLongEmpty, mine);
+                    if (cur == kLongEmpty) break;
+                }
+                slot_of[b0 + j] = at;
+            }
+        }
+        LONG_PROF_MARK(3);   // windows + inserts (thread 0's own)
+        __syncthreads();
+        LONG_PROF_MARK(4);   // waiting for the others
+        if (s_over) {   // (workgroup-uniform; never seen at a load of a half)
+            if (threadIdx.x == 0) { p.redo[read] = 1; atomicOr(&p.flags[1], 1); }
+            __syncthreads();
+            continue;
+        }
+        // the winners — the windows whose slot still holds their number — as bits of the read's own bitmap words
+        uint32_t bits = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < ITERS; ++i) {
+            if (i >= w_per) break;
+            if (slot_of[i] != kLongEmpty && (table[slot_of[i]] >> kLongTagBits) == wa + i) bits |= 1u << i;
+        }
+        if (bits) {
+            atomicOr(&s_bm[wa >> 5], bits << (wa & 31u));
+            if ((wa & 31u) + w_per > 32u) atomicOr(&s_bm[(wa >> 5) + 1], bits >> (32u - (wa & 31u)));
+        }
+        __syncthreads();
+        uint32_t *out = p.bitmap + (w0 >> 5);
+        for (uint32_t i = threadIdx.x; i < (nw + 31u) / 32u; i += BLOCK) out[i] = s_bm[i];
+        __syncthreads();
+        LONG_PROF_MARK(5);   // winners + bitmap
+    }
+#ifdef CID_LONG_PROF
+    if (threadIdx.x == 0 && p.prof) for (int i = 0; i < 8; ++i) p.prof[(size_t)blockIdx.x * 8 + i] = prof_acc[i];
+#endif
+}
+
+// Which reads of a batch take this path (route[r] = 1), which the LDS kernels (0), which neither (3: beyond the maxima a device-pointer
+// caller stated — status 3, as k_readid_check_caps marks them).  Long = at least `long_from` bases.  stats: {long reads, LDS-kernel reads,
+// the longest of those in bases, in windows}.
+__global__ __launch_bounds__(256) void k_long_route(const uint64_t *seq_off, const uint64_t *read_seq0, uint64_t n_reads, uint32_t k, uint32_t stride,
+                                                    uint64_t long_from, uint64_t cap_bytes, uint64_t cap_win, uint8_t *route, uint32_t *stats) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t is_long = 0, is_short = 0, sb = 0, sw = 0;
+    if (r < n_reads) {
+        const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
+        const uint64_t bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
+        uint64_t win = 0;
+        for (uint64_t s = s0; s < s1; ++s) {
+            const uint64_t len = seq_off[s + 1] - seq_off[s];
+            if (len >= k) win += (len - k) / stride + 1;
+        }
+        const bool beyond = bytes > cap_bytes || win > cap_win;
+        const bool lng = !beyond && bytes >= long_from;
+        route[r] = beyond ? 3 : (lng ? 1 : 0);
+        is_long = lng ? 1u : 0u;
+        is_short = (!beyond && !lng) ? 1u : 0u;
+        if (is_short) { sb = (uint32_t)bytes; sw = (uint32_t)win; }   // (below long_from: small)
+    }
+    const uint32_t nl = (uint32_t)__popcll(__ballot(is_long)), nsh = (uint32_t)__popcll(__ballot(is_short));
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t ob = __shfl_xor(sb, d, 64), ow = __shfl_xor(sw, d, 64);
+        sb = ob > sb ? ob : sb;
+        sw = ow > sw ? ow : sw;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nl) atomicAdd(&stats[0], nl);
+        if (nsh) atomicAdd(&stats[1], nsh);
+        if (sb) atomicMax(&stats[2], sb);
+        if (sw) atomicMax(&stats[3], sw);
+    }
+}
+// the reads beyond a device-pointer caller's stated maxima: status 3, no k-mers, an empty row (report_width == 0: the caller zeroed the rows)
+__global__ __launch_bounds__(256) void k_long_beyond_rows(const uint8_t *route, uint64_t n_reads, uint32_t report_width, uint32_t *report, uint32_t *n_kmers,
+                                                          uint8_t *status) {
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n_reads || route[r] != 3) return;
+    for (uint32_t c = threadIdx.x & 63u; c < report_width; c += 64u) report[r * (uint64_t)report_width + c] = 0;
+    if ((threadIdx.x & 63u) == 0) { n_kmers[r] = 0; status[r] = 3; }
+}
+// list mode (rows counted in place): a read marked for the sorting path is taken out before anything is counted for it
+__global__ void k_long_redo_status(const uint8_t *redo, uint8_t *status, uint64_t n_reads) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads && redo[r]) status[r] = 2;
+}
+
+int long_route_launch(cid_ctx *c, const uint64_t *d_seq_off, const uint64_t *d_read_seq0, size_t n_reads, uint32_t k, uint32_t stride_d, uint64_t long_from,
+                      uint64_t cap_bytes, uint64_t cap_win, uint8_t *d_route, uint32_t *d_stats) {
     hipStream_t st = ctx_stream(c);
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 16, st));
+    hipLaunchKernelGGL(k_long_route, dim3(grid_for_n(n_reads)), dim3(256), 0, st, d_seq_off, d_read_seq0, (uint64_t)n_reads, k, stride_d, long_from, cap_bytes, cap_win,
+                       d_route, d_stats);
+    HIP_TRY(hipGetLastError());
+    return CID_OK;
+}
+int long_beyond_launch(cid_ctx *c, const uint8_t *d_route, size_t n_reads, uint32_t report_width, uint32_t *d_report, uint32_t *d_n_kmers, uint8_t *d_status) {
+    hipLaunchKernelGGL(k_long_beyond_rows, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, ctx_stream(c), d_route, (uint64_t)n_reads, report_width, d_report,
+                       d_n_kmers, d_status);
+    HIP_TRY(hipGetLastError());
+    return CID_OK;
+}
+
+// The sorting path for the reads listed in h_route (all of them: NULL): it walks the offsets on the host — a device-pointer caller's come down first.
+static int long_sorted_for(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0, size_t n_reads,
+                           uint32_t stride_d, uint32_t start_sample, const uint8_t *h_route, bool clear_wide, uint32_t *d_report, uint32_t *d_n_kmers,
+                           uint8_t *d_status, const StripePass &sp, const uint64_t *h_seq_off, const uint64_t *h_read_seq0, bool merge_status) {
+    std::vector<uint64_t> so, r0;
+    if (!h_seq_off || !h_read_seq0) {
+        hipStream_t st = ctx_stream(c);
+        r0.resize(n_reads + 1);
+        HIP_TRY(hipMemcpyAsync(r0.data(), d_read_seq0, (n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        so.resize(r0[n_reads] + 1);
+        HIP_TRY(hipMemcpyAsync(so.data(), d_seq_off, so.size() * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        h_seq_off = so.data(); h_read_seq0 = r0.data();
+    }
+    return readid_long_sorted(c, ix, d_bases, h_seq_off, h_read_seq0, n_reads, stride_d, start_sample, h_route, clear_wide, d_report, d_n_kmers, d_status, sp,
+                              merge_status);
+}
+
+int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *d_seq_off, const uint64_t *d_read_seq0, size_t n_reads,
+                uint32_t stride_d, uint32_t start_sample, const uint8_t *d_route, bool clear_wide, uint32_t *d_report, uint32_t *d_n_kmers,
+                uint8_t *d_status, const StripePass &sp, const uint64_t *h_seq_off, const uint64_t *h_read_seq0, const uint32_t *d_route_stats,
+                uint32_t *route_stats) {
+    const uint32_t k = index_k(ix);
+    hipStream_t st = ctx_stream(c);
+    if (n_reads >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "more than 2^31 reads in one batch");
+    if (k > 32 || !c->tune.readid_long_lds) {   // byte-string keys (or the measurement switch): every routed read through the sorting path
+        std::vector<uint8_t> h_route;
+        if (d_route) {
+            h_route.resize(n_reads);
+            HIP_TRY(hipMemcpyAsync(h_route.data(), d_route, n_reads, hipMemcpyDeviceToHost, st));
+            if (d_route_stats) HIP_TRY(hipMemcpyAsync(route_stats, d_route_stats, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (uint8_t &b : h_route) b = b == 1 ? 1 : 0;
+        }
+        return long_sorted_for(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, d_route ? h_route.data() : nullptr, clear_wide, d_report,
+                               d_n_kmers, d_status, sp, h_seq_off, h_read_seq0, false);
+    }
     const uint32_t msz = index_m_size(ix);
     const uint32_t key_len = msz ? msz : k;
     const uint64_t sentinel_k = k < 32 ? (1ull << (2 * k)) : ~0ull;
@@ -308,176 +933,160 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     const uint32_t C = index_n_colors(ix), rs = index_rs(ix), n_hash = index_n_hash(ix);
     const bool own_search = rs <= 128 && !sp.on();   // k_readid_slices; else the lists feed k_readid_list
     const bool cut = start_sample <= 64;              // a later slice gathers the first S k-mers again
-    // windows are numbered read by read, mate by mate
-    std::vector<uint64_t> wstart(n_reads + 1, 0), wend(n_reads, 0);
-    std::vector<uint8_t> status(n_reads, 0);
-    std::vector<Segment> segs;
-    std::vector<LongItem> items_small, items_big;
-    std::vector<LongDeal> deals;
-    std::vector<uint32_t> chunk_deal, chunk_no;   // the chunks of the dealt reads: which deal, which chunk of it
-    uint64_t n_pairs = 0;
-    uint32_t n_deal_counts = 0;
-    std::vector<ReadSlice> slices;
-    std::vector<ReadCombine> combs;
-    const uint32_t seg_win = kSegWindows / stride_d ? kSegWindows / stride_d : 1;
-    uint64_t W = 0;
-    for (size_t r = 0; r < n_reads; ++r) {
-        wstart[r] = W;
-        if (route && !route[r]) { status[r] = 2; continue; }
-        W = (W + 31) & ~(uint64_t)31;   // (its bitmap words are its own)
-        wstart[r] = W;
-        const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
-        if (s1 == s0 || seq_off[s0 + 1] - seq_off[s0] < k) { status[r] = 1; continue; }   // too_short (first mate only)
-        for (uint64_t s = s0; s < s1; ++s) {
-            const uint64_t len = seq_off[s + 1] - seq_off[s];
-            if (len < k) continue;
-            const uint64_t nw = (len - k) / stride_d + 1;
-            for (uint64_t w0 = 0; w0 < nw; w0 += seg_win) {
-                const uint32_t m = (uint32_t)(nw - w0 < seg_win ? nw - w0 : seg_win);
-                segs.push_back(Segment{seq_off[s] + w0 * stride_d, W, m, stride_d});
-                W += m;
-            }
-        }
-        const uint64_t win = W - wstart[r];
-        wend[r] = W;
-        if (win > kLongMaxWin)   // (a 4 Mb read: the slots number 2^22 windows)
-            return readid_long_sorted(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, route, clear_wide, d_report, d_n_kmers,
-                                      d_status, sp);
-        if (win <= kLongSmallWin) items_small.push_back(LongItem{(uint32_t)r, 0u, 1u, 0u});
-        else {
-            const uint32_t P = (uint32_t)((win + kLongFill - 1) / kLongFill);
-            uint32_t deal = 0;
-            if (P >= kDealFromBuckets && c->tune.readid_long_deal) {
-                const uint32_t nc = (uint32_t)((win + kDealChunk - 1) / kDealChunk);
-                const uint32_t cap = kDealChunk / P + kDealChunk / P / 4 + 96;
-                deals.push_back(LongDeal{n_pairs, n_deal_counts, nc, cap, (uint32_t)r});
-                deal = (uint32_t)deals.size();
-                n_pairs += (uint64_t)P * nc * cap;
-                n_deal_counts += P * nc;
-                for (uint32_t j = 0; j < nc; ++j) { chunk_deal.push_back(deal - 1); chunk_no.push_back(j); }
-            }
-            for (uint32_t b = 0; b < P; ++b) items_big.push_back(LongItem{(uint32_t)r, b, P, deal});
-        }
-        if (own_search) {
-            const uint32_t n_sl = cut ? (uint32_t)((win + kSliceWindows - 1) / kSliceWindows) : 1u;
-            if (n_sl > 1) combs.push_back(ReadCombine{(uint32_t)r, (uint32_t)slices.size(), n_sl, 0u});
-            for (uint32_t j = 0; j < n_sl; ++j) {
-                const uint64_t a = wstart[r] + (uint64_t)j * kSliceWindows;
-                const uint64_t b = n_sl == 1 ? W : (a + kSliceWindows < W ? a + kSliceWindows : W);
-                slices.push_back(ReadSlice{(uint32_t)r, (uint32_t)a, (uint32_t)b, j | (n_sl > 1 ? 0x80000000u : 0u)});
-            }
-        }
-    }
-    wstart[n_reads] = W;
-    if (W >= (1ull << 32) - 64) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
-    if (n_reads >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "more than 2^31 reads in one batch");
     const size_t C1 = (size_t)C + 1;
-    const uint64_t n_words = W / 32 + 1;   // (rank(W) reads the word after the last window's)
-    // the host-made arrays travel as ONE block, before the first kernel, through the ctx's pinned arena when they fit: a copy out of
-    // pageable memory makes the runtime wait for the stream, and one issued between two kernels stalls the launch of the second
-    struct Part { const void *src; size_t bytes, off; };
-    Part parts[10] = {{wstart.data(), (n_reads + 1) * 8, 0}, {wend.data(), n_reads * 8, 0}, {segs.data(), segs.size() * sizeof(Segment), 0},
-                      {items_small.data(), items_small.size() * sizeof(LongItem), 0}, {items_big.data(), items_big.size() * sizeof(LongItem), 0},
-                      {slices.data(), slices.size() * sizeof(ReadSlice), 0}, {combs.data(), combs.size() * sizeof(ReadCombine), 0},
-                      {deals.data(), deals.size() * sizeof(LongDeal), 0}, {chunk_deal.data(), chunk_deal.size() * 4, 0}, {chunk_no.data(), chunk_no.size() * 4, 0}};
-    size_t meta_bytes = (n_reads + 15) & ~(size_t)15;   // the status bytes lead the block
-    for (Part &pt : parts) { pt.off = meta_bytes; meta_bytes += (pt.bytes + 15) & ~(size_t)15; }
-    DevBuf<uint64_t> d_codes(c), d_list(c), d_lstart(c), d_scan(c);
-    DevBuf<uint32_t> d_bitmap(c), d_prefix(c), d_partial(c), d_pair_idx(c), d_deal_counts(c);
-    DevBuf<uint64_t> d_pair_code(c);
-    DevBuf<uint8_t> d_meta(c);
+    const uint64_t n = n_reads + 1;
+    const uint64_t tiles = (n + kPlanTile - 1) / kPlanTile;
+    // ---- the plan
+    DevBuf<uint64_t> d_wstart(c), d_wend(c), d_pre(c), d_state(c), d_totals(c);
+    DevBuf<uint32_t> d_win(c);
+    DevBuf<uint8_t> d_cls(c), d_redo(c);
     DevBuf<int> d_flags(c);
     int rc;
-    if ((rc = d_meta.alloc(meta_bytes + 16)) || (rc = d_codes.alloc(W + 1)) || (rc = d_scan.alloc(scan_state_words(n_words))) ||
-        (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
-        (rc = d_partial.alloc(combs.empty() ? 1 : slices.size() * (C1 + 1))) || (rc = d_flags.alloc(4)) ||
-        (rc = d_pair_code.alloc(n_pairs)) || (rc = d_pair_idx.alloc(n_pairs)) || (rc = d_deal_counts.alloc(n_deal_counts)))
+    if ((rc = d_wstart.alloc(n)) || (rc = d_wend.alloc(n)) || (rc = d_pre.alloc((size_t)kPlanFields * n)) || (rc = d_state.alloc((size_t)kPlanFields * (tiles + 2))) ||
+        (rc = d_totals.alloc(kPlanFields + 1)) || (rc = d_win.alloc(n)) || (rc = d_cls.alloc(n)) || (rc = d_redo.alloc(n)) || (rc = d_flags.alloc(4)))
         return rc;
-    const uint64_t *d_wstart = reinterpret_cast<const uint64_t *>(d_meta.p + parts[0].off), *d_wend = reinterpret_cast<const uint64_t *>(d_meta.p + parts[1].off);
-    const Segment *d_segs = reinterpret_cast<const Segment *>(d_meta.p + parts[2].off);
-    const LongItem *d_items_small = reinterpret_cast<const LongItem *>(d_meta.p + parts[3].off), *d_items_big = reinterpret_cast<const LongItem *>(d_meta.p + parts[4].off);
-    const ReadSlice *d_slices = reinterpret_cast<const ReadSlice *>(d_meta.p + parts[5].off);
-    const ReadCombine *d_combs = reinterpret_cast<const ReadCombine *>(d_meta.p + parts[6].off);
-    const LongDeal *d_deals = reinterpret_cast<const LongDeal *>(d_meta.p + parts[7].off);
-    const uint32_t *d_chunk_deal = reinterpret_cast<const uint32_t *>(d_meta.p + parts[8].off), *d_chunk_no = reinterpret_cast<const uint32_t *>(d_meta.p + parts[9].off);
-    if (uint8_t *pin = pin_reserve(c, meta_bytes + 64)) {
-        HIP_TRY(hipStreamSynchronize(st));   // (the arena may still feed an earlier copy)
-        memcpy(pin, status.data(), n_reads);
-        for (const Part &pt : parts) if (pt.bytes) memcpy(pin + pt.off, pt.src, pt.bytes);
-        HIP_TRY(hipMemcpyAsync(d_meta.p, pin, meta_bytes, hipMemcpyHostToDevice, st));
-    } else {
-        HIP_TRY(hipMemcpyAsync(d_meta.p, status.data(), n_reads, hipMemcpyHostToDevice, st));
-        for (const Part &pt : parts) if (pt.bytes) HIP_TRY(hipMemcpyAsync(d_meta.p + pt.off, pt.src, pt.bytes, hipMemcpyHostToDevice, st));
-    }
-    HIP_TRY(hipMemcpyAsync(d_status, d_meta.p, n_reads, hipMemcpyDeviceToDevice, st));
+    LongPlanParams pp{};
+    pp.seq_off = d_seq_off; pp.read_seq0 = d_read_seq0; pp.route = d_route; pp.bases = d_bases; pp.n_reads = n_reads;
+    pp.k = k; pp.stride = stride_d; pp.seg_win = kSegWindows / stride_d ? kSegWindows / stride_d : 1;
+    pp.fuse = c->tune.readid_long_fuse ? 1u : 0u; pp.cut = cut ? 1u : 0u; pp.own_search = own_search ? 1u : 0u; pp.deal = c->tune.readid_long_deal ? 1u : 0u;
+    pp.wstart = d_wstart.p; pp.wend = d_wend.p; pp.win = d_win.p; pp.cls = d_cls.p; pp.redo = d_redo.p; pp.status = d_status;
+    pp.pre = d_pre.p; pp.state = d_state.p; pp.totals = d_totals.p; pp.flags = d_flags.p;
+    HIP_TRY(hipMemsetAsync(d_state.p, 0, (size_t)kPlanFields * (tiles + 2) * 8, st));
     HIP_TRY(hipMemsetAsync(d_flags.p, 0, 16, st));
+    hipLaunchKernelGGL(k_long_plan, dim3((unsigned)tiles), dim3(kScanBlock), 0, st, pp);
+    HIP_TRY(hipGetLastError());
+    uint64_t t[kPlanFields];
+    HIP_TRY(hipMemcpyAsync(t, d_totals.p, sizeof(t), hipMemcpyDeviceToHost, st));
+    if (d_route_stats) HIP_TRY(hipMemcpyAsync(route_stats, d_route_stats, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the one wait before the kernels: the lists' sizes
+    const uint64_t W = t[0], n_pairs = t[6];
+    if (W >= (1ull << 32) - 64) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
+    const uint32_t n_fs = (uint32_t)t[1], n_fb = (uint32_t)(t[1] >> 32), n_is = (uint32_t)t[2], n_ib = (uint32_t)(t[2] >> 32);
+    const uint32_t n_slices = (uint32_t)t[3], n_combs = (uint32_t)(t[3] >> 32), n_segs = (uint32_t)t[4], n_deals = (uint32_t)(t[4] >> 32);
+    const uint32_t n_chunks = (uint32_t)t[5], n_deal_counts = (uint32_t)(t[5] >> 32);
+    const uint64_t n_words = W / 32 + 1;   // (rank(W) reads the word after the last window's)
+    DevBuf<uint64_t> d_codes(c), d_list(c), d_lstart(c), d_scan(c), d_pair_code(c);
+    DevBuf<uint32_t> d_bitmap(c), d_prefix(c), d_partial(c), d_pair_idx(c), d_deal_counts(c), d_lists32(c);
+    DevBuf<LongItem> d_items(c);
+    DevBuf<FuseItem> d_fuse(c);
+    DevBuf<ReadSlice> d_slices(c);
+    DevBuf<ReadCombine> d_combs(c);
+    DevBuf<Segment> d_segs(c);
+    DevBuf<LongDeal> d_deals(c);
+    if ((rc = d_codes.alloc(W + 1)) || (rc = d_scan.alloc(scan_state_words(n_words))) || (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
+        (rc = d_partial.alloc(n_combs ? (size_t)n_slices * (C1 + 1) : 1)) || (rc = d_pair_code.alloc(n_pairs)) || (rc = d_pair_idx.alloc(n_pairs)) ||
+        (rc = d_deal_counts.alloc(n_deal_counts)) || (rc = d_lists32.alloc((size_t)n_segs + 2 * (size_t)n_chunks)) || (rc = d_fuse.alloc((size_t)n_fs + n_fb)) ||
+        (rc = d_items.alloc((size_t)n_is + n_ib)) || (rc = d_slices.alloc(n_slices)) || (rc = d_combs.alloc(n_combs)) || (rc = d_segs.alloc(n_segs)) ||
+        (rc = d_deals.alloc(n_deals)))
+        return rc;
+    LongLists L{};
+    L.fused_small = d_fuse.p; L.fused_big = d_fuse.p + n_fs; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
+    L.items_small = d_items.p; L.items_big = d_items.p + n_is;
+    L.slices = d_slices.p; L.combs = d_combs.p; L.segs = d_segs.p; L.deals = d_deals.p;
+    hipLaunchKernelGGL(k_long_emit, dim3(grid_for_n(n_reads)), dim3(256), 0, st, pp, L);
     HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, n_words * 4, st));
+    HIP_TRY(hipGetLastError());
     int h_flags[4] = {0, 0, 0, 0};
+    const unsigned n_cu = (unsigned)ctx_n_cu(c);
     if (W) {
-        constexpr uint32_t kBytes = kSegWindows + 32 + 96;
-        const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
-        unsigned grid = (unsigned)((segs.size() + 3) / 4);
-        if (grid > 8192) grid = 8192;
-        hipLaunchKernelGGL(k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, d_bases, d_segs, (uint32_t)segs.size(), k, 1, sentinel_k, d_codes.p,
-                           d_flags.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr, KeyFor{});
-        if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
-        const unsigned n_cu = (unsigned)ctx_n_cu(c);
-        if (!chunk_deal.empty()) {
-            unsigned g = (unsigned)chunk_deal.size();
-            if (g > n_cu * 8u) g = n_cu * 8u;
-            hipLaunchKernelGGL(k_long_deal, dim3(g), dim3(kDealBlock), 0, st, d_codes.p, d_wstart, d_wend, d_deals, d_chunk_deal, d_chunk_no, (uint32_t)chunk_deal.size(),
-                               sentinel, d_pair_code.p, d_pair_idx.p, d_deal_counts.p, d_flags.p);
+        if (n_segs) {   // the reads of several buckets, and those whose bases do not fit the fused kernel: codes first, then the tables
+            constexpr uint32_t kBytes = kSegWindows + 32 + 96;
+            const size_t shmem = 4 * (kBytes + 4 * (kBytes / 16 + 4) + 2 * 4 * (kBytes / 32 + 4));
+            unsigned grid = (n_segs + 3) / 4;
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL(k_extract_codes<false>, dim3(grid), dim3(256), shmem, st, d_bases, (const Segment *)d_segs.p, n_segs, k, 1, sentinel_k, d_codes.p,
+                               d_flags.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr, KeyFor{},
+                               (const uint32_t *)L.seg_read, d_redo.p);
+            // (minimizer indices: over the whole numbering — what the fused kernel writes afterwards are minimizer codes already)
+            if (msz) hipLaunchKernelGGL(k_codes_to_minimizers, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, (uint64_t)W, k, msz, sentinel_k, sentinel);
+            if (n_chunks) {
+                unsigned g = n_chunks;
+                if (g > n_cu * 8u) g = n_cu * 8u;
+                hipLaunchKernelGGL(k_long_deal, dim3(g), dim3(kDealBlock), 0, st, d_codes.p, d_wstart.p, d_wend.p, (const LongDeal *)d_deals.p,
+                                   (const uint32_t *)L.chunk_deal, (const uint32_t *)L.chunk_no, n_chunks, sentinel, d_pair_code.p, d_pair_idx.p, d_deal_counts.p,
+                                   d_flags.p, d_redo.p);
+            }
+            if (n_is) {
+                unsigned g = n_cu * 4u;   // four 32-KiB workgroups per CU
+                g = (g + 7u) & ~7u;
+                hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockSmall), (kLongSlotsSmall + kLongBmSmall) * 4, st, d_codes.p, d_wstart.p, d_wend.p,
+                                   (const LongItem *)L.items_small, n_is, sentinel, kLongSlotsSmall, kLongBmSmall, d_bitmap.p, d_flags.p, (const LongDeal *)d_deals.p,
+                                   d_pair_code.p, d_pair_idx.p, d_deal_counts.p, d_redo.p);
+            }
+            if (n_ib) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_first_flags), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)((kLongSlotsBig + kLongBmBig) * 4)));
+                unsigned g = (n_cu + 7u) & ~7u;
+                hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), (kLongSlotsBig + kLongBmBig) * 4, st, d_codes.p, d_wstart.p, d_wend.p,
+                                   (const LongItem *)L.items_big, n_ib, sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p, (const LongDeal *)d_deals.p,
+                                   d_pair_code.p, d_pair_idx.p, d_deal_counts.p, d_redo.p);
+            }
         }
-        if (!items_small.empty()) {
-            unsigned g = n_cu * 4u;   // four 32-KiB workgroups per CU
-            g = (g + 7u) & ~7u;
-            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockSmall), (kLongSlotsSmall + kLongBmSmall) * 4, st, d_codes.p, d_wstart, d_wend, d_items_small,
-                               (uint32_t)items_small.size(), sentinel, kLongSlotsSmall, kLongBmSmall, d_bitmap.p, d_flags.p, d_deals, d_pair_code.p, d_pair_idx.p,
-                               d_deal_counts.p);
+        LongFuseParams fp{};
+        fp.k = k; fp.msz = msz; fp.stride = stride_d; fp.sentinel = sentinel; fp.codes = d_codes.p; fp.bitmap = d_bitmap.p; fp.redo = d_redo.p; fp.flags = d_flags.p;
+        if (n_fs) {
+            fp.items = L.fused_small; fp.n_list = n_fs; fp.max_slots = kLongSlotsSmall; fp.pos_cap = kFusePosSmall;
+            unsigned g = (n_cu * 4u + 7u) & ~7u;
+            hipLaunchKernelGGL((k_long_fused<kLongBlockSmall, kLongSmallWin / kLongBlockSmall>), dim3(g), dim3(kLongBlockSmall),
+                               (kLongSlotsSmall + kFusePosSmall / 16 + 4 + kFusePosSmall / 32 + 4 + kLongSmallWin / 32) * 4, st, fp);
         }
-        if (!items_big.empty()) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_first_flags), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)((kLongSlotsBig + kLongBmBig) * 4)));
+#ifdef CID_LONG_PROF
+        DevBuf<unsigned long long> d_prof(c);
+        if ((rc = d_prof.alloc((size_t)(n_cu + 8) * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(d_prof.p, 0, (size_t)(n_cu + 8) * 64, st));
+        fp.prof = n_fb ? d_prof.p : nullptr;
+#endif
+        if (n_fb) {
+            fp.items = L.fused_big; fp.n_list = n_fb; fp.max_slots = kLongSlotsBig; fp.pos_cap = kFusePosBig;
+            const int shmem = (int)((kLongSlotsBig + kFusePosBig / 16 + 4 + kFusePosBig / 32 + 4 + kLongFill / 32) * 4);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_fused<kLongBlockBig, kLongFill / kLongBlockBig>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
             unsigned g = (n_cu + 7u) & ~7u;
-            hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), (kLongSlotsBig + kLongBmBig) * 4, st, d_codes.p, d_wstart, d_wend,
-                               d_items_big, (uint32_t)items_big.size(), sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p, d_deals, d_pair_code.p,
-                               d_pair_idx.p, d_deal_counts.p);
+            hipLaunchKernelGGL((k_long_fused<kLongBlockBig, kLongFill / kLongBlockBig>), dim3(g), dim3(kLongBlockBig), shmem, st, fp);
+#ifdef CID_LONG_PROF
+            std::vector<unsigned long long> hp((size_t)g * 8);
+            HIP_TRY(hipMemcpyAsync(hp.data(), d_prof.p, hp.size() * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t b = 0; b < g; ++b) for (int i = 0; i < 8; ++i) sum[i] += hp[b * 8 + i];
+            fprintf(stderr, "k_long_fused<big> %u reads, mean cycles per workgroup: clears %llu, staging %llu, barrier %llu, inserts %llu, wait %llu, winners %llu, loop top %llu\n", n_fb,
+                    sum[0] / g, sum[1] / g, sum[2] / g, sum[3] / g, sum[4] / g, sum[5] / g, sum[7] / g);
+#endif
         }
         HIP_TRY(hipGetLastError());
-        if (!own_search) {   // wide rows and stripe passes add into rows in place: what would send the batch to the sorting path (see the
-            HIP_TRY(hipMemcpyAsync(h_flags, d_flags.p, 8, hipMemcpyDeviceToHost, st));   // end of this function) must be known before anything is counted
-            HIP_TRY(hipStreamSynchronize(st));
-            if (h_flags[0] || h_flags[1])
-                return readid_long_sorted(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, route, clear_wide, d_report, d_n_kmers,
-                                          d_status, sp);
+    }
+    if (!own_search) {   // wide rows and stripe passes add into rows in place: the reads the sorting path will redo are taken out before anything is counted
+        HIP_TRY(hipMemcpyAsync(h_flags, d_flags.p, 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_flags[0] || h_flags[1] || h_flags[2]) {
+            hipLaunchKernelGGL(k_long_redo_status, dim3(grid_for_n(n_reads)), dim3(256), 0, st, d_redo.p, d_status, (uint64_t)n_reads);
+            HIP_TRY(hipGetLastError());
         }
     }
     HIP_TRY(scan_launch(PopcIn{d_bitmap.p}, PrefixOut{d_prefix.p}, n_words, d_scan.p, st));
-    if (!own_search) {   // k_readid_list walks lists
-        if ((rc = d_list.alloc(W + 1)) || (rc = d_lstart.alloc(n_reads + 1))) return rc;
-        if (W) hipLaunchKernelGGL(k_long_scatter, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, d_bitmap.p, d_prefix.p, d_list.p, (uint64_t)W);
-        hipLaunchKernelGGL(k_long_list_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, d_wstart, d_bitmap.p, d_prefix.p, d_lstart.p,
-                           (uint32_t)n_reads);
-        HIP_TRY(hipGetLastError());
-    }
     const uint32_t hist_pad = rs > 128 ? 4u * rs : (uint32_t)((C1 + 3) & ~(size_t)3);
     const uint32_t wave_bytes = (uint32_t)((4ull * kWave * n_hash + 4ull * hist_pad + 15) & ~15ull);
     if ((size_t)(kBlock / kWave) * wave_bytes > 160u * 1024u) return fail(CID_ERR_UNSUPPORTED, "LDS need exceeds 160 KiB");
     if (own_search) {
         ReadIdSliceParams p{};
         p.mat = index_matrix(ix); p.rs = rs; p.w64 = (C + 63) / 64; p.n_colors = C; p.n_hash = n_hash; p.k = key_len; p.mod = index_mod(ix);
-        p.codes = d_codes.p; p.wstart = d_wstart; p.wend = d_wend; p.bitmap = d_bitmap.p; p.word_prefix = d_prefix.p;
-        p.slices = d_slices; p.n_slices = (uint32_t)slices.size(); p.start_sample = start_sample;
+        p.codes = d_codes.p; p.wstart = d_wstart.p; p.wend = d_wend.p; p.bitmap = d_bitmap.p; p.word_prefix = d_prefix.p;
+        p.slices = d_slices.p; p.n_slices = n_slices; p.start_sample = start_sample;
         p.hist_pad = hist_pad; p.wave_bytes = wave_bytes;
         p.report = d_report; p.n_kmers = d_n_kmers; p.partial = d_partial.p;
-        uint64_t grid = (slices.size() + 3) / 4;
+        uint64_t grid = ((uint64_t)n_slices + 3) / 4;
         const uint64_t cap = (uint64_t)ctx_n_cu(c) * 32;
         if (grid > cap) grid = cap;
         HIP_TRY(launch_readid_slices(p, (int)grid, st));
-        HIP_TRY(launch_readid_combine(d_combs, (uint32_t)combs.size(), d_partial.p, C, d_report, st));
+        HIP_TRY(launch_readid_combine(d_combs.p, n_combs, d_partial.p, C, d_report, st));
         hipLaunchKernelGGL(k_long_short_rows, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, d_status, (uint32_t)n_reads, C, d_report, d_n_kmers);
         HIP_TRY(hipGetLastError());
-    } else {
+    } else {   // k_readid_list walks lists
+        if ((rc = d_list.alloc(W + 1)) || (rc = d_lstart.alloc(n_reads + 1))) return rc;
+        if (W) hipLaunchKernelGGL(k_long_scatter, dim3(grid_for_n(W)), dim3(256), 0, st, d_codes.p, d_bitmap.p, d_prefix.p, d_list.p, (uint64_t)W);
+        hipLaunchKernelGGL(k_long_list_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, d_wstart.p, d_bitmap.p, d_prefix.p, d_lstart.p,
+                           (uint32_t)n_reads);
+        HIP_TRY(hipGetLastError());
         ReadIdListParams p{};
         p.mat = index_matrix(ix); p.rs = rs; p.w64 = (C + 63) / 64; p.n_colors = C; p.n_hash = n_hash; p.k = key_len; p.mod = index_mod(ix);
         p.list_codes = d_list.p; p.list_start = d_lstart.p; p.n_reads = n_reads; p.start_sample = start_sample;
@@ -491,12 +1100,17 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         if (grid > 4096) grid = 4096;
         HIP_TRY(launch_readid_list(p, (int)grid, st));
     }
-    // The one wait of the call, at its end: the host arrays above leave scope, and two facts only the kernels know decide whether the
-    // batch has to be redone on the sorting path — a lower-case base among the long reads, or a hash table that overflowed seven levels deep.
-    HIP_TRY(hipMemcpyAsync(h_flags, d_flags.p, 8, hipMemcpyDeviceToHost, st));
+    // The wait at the end of the call: the scratch above leaves scope, and three facts only the kernels know send single reads to the sorting
+    // path — a lower-case base (its case is kept: byte-string keys), a table that crowded seven levels deep, more windows than a slot numbers.
+    HIP_TRY(hipMemcpyAsync(h_flags, d_flags.p, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (h_flags[0] || h_flags[1])
-        return readid_long_sorted(c, ix, d_bases, seq_off, read_seq0, n_reads, stride_d, start_sample, route, clear_wide, d_report, d_n_kmers, d_status, sp);
+    if (h_flags[0] || h_flags[1] || h_flags[2]) {
+        std::vector<uint8_t> h_redo(n_reads);
+        HIP_TRY(hipMemcpyAsync(h_redo.data(), d_redo.p, n_reads, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return long_sorted_for(c, ix, d_bases, d_seq_off, d_read_seq0, n_reads, stride_d, start_sample, h_redo.data(), false, d_report, d_n_kmers, d_status, sp,
+                               h_seq_off, h_read_seq0, true);
+    }
     return CID_OK;
 }
 

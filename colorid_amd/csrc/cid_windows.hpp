@@ -38,6 +38,7 @@ __device__ __forceinline__ uint64_t bits_at_dev(const uint32_t *w, uint32_t bit,
 // seq_off[sg] (relative to `bases`' first byte, which is seq_off[0] of the batch), its codes at win_off[sg]; nothing per read comes
 // from the host but the offsets it already has.
 // KEYED (a set built for an index, cid_kmerset_set_target_index): every window's row0_key goes to key_out next to its code.
+// redo != NULL (with segs): a lower-case base in segment sg also marks redo[seg_read[sg]].
 struct KeyFor {   // the index the keys are for
     ModMagic mm;
     uint64_t scale;   // floor((2^32 - 1) * 2^32 / bloom_size)
@@ -57,7 +58,8 @@ __attribute__((unused)) static __global__ void k_row0_keys(const uint64_t *codes
 template <bool KEYED>
 __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, const Segment *segs, uint32_t n_segs, uint32_t k,
                                                        int mode, uint64_t sentinel, uint64_t *out, int *flags,
-                                                       const uint64_t *seq_off, const uint64_t *win_off, uint64_t base0, uint32_t *key_out, KeyFor kf) {
+                                                       const uint64_t *seq_off, const uint64_t *win_off, uint64_t base0, uint32_t *key_out, KeyFor kf,
+                                                       const uint32_t *seg_read, uint8_t *redo) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr uint32_t kBytes = kSegWindows + 32 + 96;                  // bases of one segment (+ slack)
@@ -83,7 +85,10 @@ __global__ __launch_bounds__(256) void k_extract_codes(const uint8_t *bases, con
             lower = lower || (good_base_dev(b) && (b & 0x20u));
         }
         if (mode == 1 && __any(lower)) {
-            if (lane == 0) atomicOr(&flags[0], 1);
+            if (lane == 0) {
+                atomicOr(&flags[0], 1);
+                if (redo) redo[seg_read[sg]] = 1;   // (the long-read path: the read of this segment alone takes the byte-string path)
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

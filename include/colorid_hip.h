@@ -274,9 +274,13 @@ int cid_readid_count_sparse(cid_ctx *, const cid_index *, const uint8_t *bases, 
                             uint32_t *n_kmers, uint8_t *status, uint64_t *n_entries);
 int cid_readid_sparse_fetch(cid_ctx *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
 
-/* Device-pointer form (asynchronous on the ctx stream).  The caller states the longest read(-pair) of the batch in
- * bytes and in k-mer windows (sum over its mates of (len-k)/d+1 for len >= k): they size the kernel's LDS.  A read that
- * exceeds either is not processed: its status is 3, its row and n_kmers are zero. */
+/* Device-pointer form: bases AND offsets in HBM (what cid_fastq_* hands over).  The caller states the longest read(-pair) of the
+ * batch in bytes and in k-mer windows (sum over its mates of (len-k)/d+1 for len >= k).  A read that exceeds either is not
+ * processed: its status is 3, its row and n_kmers are zero.  Reads of any length (round 6): when the stated maximum is beyond what
+ * a wave's LDS holds well (about 900 bases at d = 1), the device itself routes every read — the long ones through the long-read
+ * kernels (their work lists are made on the device), the others through the LDS kernels — and the call then waits for the stream
+ * (the work lists' sizes come back, and reads with a lower-case base are redone on byte strings); with short reads only it is
+ * asynchronous on the ctx stream, as before. */
 int cid_readid_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_bases, const uint64_t *d_seq_off,
                          const uint64_t *d_read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                          uint64_t max_read_bytes, uint64_t max_read_windows, uint32_t *d_report, uint32_t *d_n_kmers,
@@ -438,8 +442,9 @@ int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t 
  *                      record then held (for pairs: as many as both files hold) goes through cid_readid_count_dev's kernels and
  *                      the sparse-report compaction; what is left of the text waits on the device for the next call.
  *                      Corrupt members -> CID_ERR_INVALID naming the first one; a quality line longer than its sequence ->
- *                      CID_ERR_INVALID (the reference's "could not get the next nt" panic); reads that do not fit a wave's LDS
- *                      (several kilobases) -> CID_ERR_UNSUPPORTED: classify such input through cid_readid_count_sparse.
+ *                      CID_ERR_INVALID (the reference's "could not get the next nt" panic); records of ANY length are taken (round 6: reads too
+ *                      long for a wave's LDS go through the long-read kernels inside the same step, cid_readid_count_dev's routing;
+ *                      until round 5 such a step was refused with CID_ERR_UNSUPPORTED).
  *        classify_begin / classify_end   the same step in two halves, for a caller that has something to do while the classifier runs:
  *                      _begin takes the pushes, cuts and packs the records and LAUNCHES the classifier; _end waits for it, compacts
  *                      the report and publishes the step's results (sizes as classify returns them).  Between the two the caller

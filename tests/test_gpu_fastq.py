@@ -279,6 +279,110 @@ def test_block_gzip_members_cut_records(orc, hip_ctx, world):
     fr.close()
 
 
+def _long_records(rng, genomes, soft_mask=True):
+    """records of 150 b ... 60 kb in one file: short reads between long ones, an empty read, a read of several hash buckets, and (soft_mask)
+    two reads with a lower-case stretch — their case is kept, they alone take the byte-string path"""
+    big = b"".join(genomes) * 3                                       # 90 kb with repeats
+    recs = []
+    for i, L in enumerate([150, 3_000, 150, 12_000, 900, 40_000, 150, 1_100, 60_000, 0, 9_999, 150, 20_000, 2_500, 150]):
+        st = int(rng.integers(0, len(big) - L)) if L else 0
+        seq = bytearray(big[st:st + L])
+        for _ in range(L // 2_000):
+            seq[int(rng.integers(0, L))] = ord("N")
+        if soft_mask and i in (3, 7):
+            a = int(rng.integers(0, L - 60)); seq[a:a + 50] = bytes(seq[a:a + 50]).lower()
+        qual = bytes(rng.choice(list(b"#5I"), size=L, p=[0.02, 0.08, 0.9]).astype(np.uint8)) if L else b""
+        recs.append((b"read%d len=%d" % (i, L), bytes(seq), qual))
+    return recs
+
+
+@pytest.mark.parametrize("q", [0, 15])
+@pytest.mark.parametrize("paired", [False, True])
+def test_long_reads_through_the_device_front_end(orc, hip_ctx, world, q, paired):
+    """Round 6: records of any length through cid_fastq_classify — until round 5 a read that did not fit a wave's LDS was refused
+    (CID_ERR_UNSUPPORTED) and the CLI re-ran the whole input on the host.  Text cut anywhere, block-gzip members cutting records, pairs."""
+    import colorid_amd
+    oix, hx, genomes = world
+    rng = np.random.default_rng(50 + q + int(paired))
+    texts = [fastq_text(_long_records(rng, genomes))]
+    if paired:
+        texts.append(fastq_text(_long_records(rng, genomes, soft_mask=False)[:13], b"\r\n"))
+    want_ids, want, packed = expected(orc, hx, texts, q, 1, 3)
+    assert len(want_ids) == (13 if paired else 15)
+    orep = oix.readid_counts(*packed, 1, 3, n_threads=8)               # the oracle itself on the host-packed reads
+    grep = hx.readid_count(*packed, 1, 3)
+    assert all(np.array_equal(a, b) for a, b in zip(grep, orep))
+    nf = len(texts)
+    for pieces in (1, 9):
+        fr = colorid_amd.FastqReader(hip_ctx, nf, q)
+        acc = {"ids": [], "nk": [], "st": [], "rows": []}
+        cuts = [sorted(rng.integers(0, len(t), pieces - 1).tolist()) + [len(t)] for t in texts]
+        prev = [0] * nf
+        for j in range(pieces):
+            for f in range(nf):
+                fr.push_text(f, texts[f][prev[f]:cuts[f][j]], last=(j == pieces - 1)); prev[f] = cuts[f][j]
+            collect(fr, hx, 1, 3, acc)
+        check_equal(acc, want_ids, want)
+        fr.close()
+    # as block-gzip members
+    fr = colorid_amd.FastqReader(hip_ctx, nf, q)
+    acc = {"ids": [], "nk": [], "st": [], "rows": []}
+    for f in range(nf):
+        members, lens, pos = [], [], 0
+        while pos < len(texts[f]):
+            n = int(rng.choice([3_000, 30_000, 65_280]))
+            members.append(bgzf_member(texts[f][pos:pos + n], level=int(rng.integers(1, 7)))); lens.append(len(texts[f][pos:pos + n])); pos += n
+        members.append(bgzf_member(b"")); lens.append(0)
+        half = len(members) // 2
+        fr.push_bgzf(f, members[:half], lens[:half])
+        fr.push_bgzf(f, members[half:], lens[half:], last=True)
+    collect(fr, hx, 1, 3, acc)
+    check_equal(acc, want_ids, want)
+    fr.close()
+
+
+@pytest.mark.parametrize("kind", ["bgzf", "fasta"])
+def test_cli_read_id_long_reads_no_restart(orc, tmp_path, kind):
+    """`colorid read_id` on long reads — a block-gzip FASTQ of 150 b ... 60 kb records (two of them soft-masked) through the device front
+    end, without giving way to the host front end (round 5 drained, truncated and re-ran the whole input), and a plain FASTA of long
+    records through the host reader: both equal the host front end's / the oracle's rows."""
+    import os
+    import subprocess
+
+    from test_gpu_cli import BIN, PHAGES, REFS
+    tsv = tmp_path / "ref_file.txt"
+    tsv.write_text("".join(f"{n}\t{os.path.join(REFS, n + '.fasta')}\n" for n in PHAGES))
+    pre = str(tmp_path / "phage")
+    p = subprocess.run([BIN, "build", "-s", "750000", "-n", "4", "-k", "27", "-b", pre, "-r", str(tsv)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    genomes = [b"".join(orc.read_fasta(os.path.join(REFS, n + ".fasta"))) for n in PHAGES]
+    rng = np.random.default_rng(15)
+    recs = _long_records(rng, [g[:30_000] for g in genomes[:3]]) * 3
+    recs = [(b"%s copy%d" % (r[0], i), r[1], r[2]) for i, r in enumerate(recs)]
+    if kind == "bgzf":
+        f1 = str(tmp_path / "long.fastq.gz")
+        _write_bgzf(f1, fastq_text(recs), rng)
+    else:
+        f1 = str(tmp_path / "long.fasta")
+        with open(f1, "wb") as f:
+            for rid, seq, _ in recs:
+                f.write(b">" + rid + b"\n" + seq + b"\n")
+    outs = {}
+    for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {"COLORID_DEVICE_FASTQ_MB": "1"}), ("dev_default", {})):
+        name = str(tmp_path / tag)
+        p = subprocess.run([BIN, "read_id", "-b", pre + ".bxi", "-q", f1, "-n", name, "-Q", "0"], capture_output=True, text=True,
+                           env=dict(os.environ, COLORID_TIMING="1", **env))
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        outs[tag] = (open(name + "_reads.txt").read(), open(name + "_counts.txt").read(), p.stderr)
+    assert outs["host"][0].count("\n") == len(recs)
+    for tag in ("dev", "dev_default"):
+        assert outs[tag][0] == outs["host"][0] and outs[tag][1] == outs["host"][1], tag
+        assert "host front end" not in outs[tag][2], outs[tag][2][-1500:]          # neither "using the" nor "starting over with the"
+        if kind == "bgzf":
+            assert "device front end" in outs[tag][2]
+    assert "accept" in outs["host"][0]
+
+
 def _write_bgzf(path, text, rng):
     """block-gzip file: members of irregular sizes (records and lines cut anywhere) + the end marker"""
     with open(path, "wb") as f:

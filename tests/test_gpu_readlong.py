@@ -156,6 +156,107 @@ def test_lower_case_among_long_reads_falls_back(orc, hip_ctx):
     hx.close()
 
 
+def _dev_call(hip_ctx, hx, reads, d, S, max_bytes, max_win, unaligned=0):
+    """cid_readid_count_dev: bases AND offsets on the device (what the FASTQ front end hands over)"""
+    import torch
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    dev = torch.device("cuda", 0)
+    n = len(reads)
+    buf = torch.zeros(len(bases) + 64, dtype=torch.uint8, device=dev)
+    buf[unaligned:unaligned + len(bases)] = torch.from_numpy(bases.copy()).to(dev)
+    d_so = torch.from_numpy(seq_off.astype(np.int64)).to(dev)
+    d_r0 = torch.from_numpy(read_seq0.astype(np.int64)).to(dev)
+    rep = torch.full((n, hx.n_colors + 1), 77, dtype=torch.int32, device=dev)
+    nk = torch.full((n,), 77, dtype=torch.int32, device=dev)
+    st = torch.full((n,), 77, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    hx.readid_count_dev(buf.data_ptr() + unaligned, d_so.data_ptr(), d_r0.data_ptr(), n, d, S, max_bytes, max_win, rep.data_ptr(), nk.data_ptr(), st.data_ptr())
+    hip_ctx.synchronize()
+    return rep.cpu().numpy().view(np.uint32), nk.cpu().numpy().view(np.uint32), st.cpu().numpy()
+
+
+@pytest.mark.parametrize("n_colors,n_hash,k", [(256, 2, 21), (1000, 3, 31), (9000, 2, 21)])
+def test_device_offsets_entry_takes_long_reads(orc, hip_ctx, n_colors, n_hash, k):
+    """Round 6: the device-pointer entry point routes reads of any length itself — route, work lists and window numbering are made on the
+    device from seq_off / read_seq0 in HBM (k_long_route, k_long_plan, k_long_emit); long, short, too-short, empty and paired reads in
+    one call, bases at an odd address; a read beyond the maxima the caller stated gets status 3 and an empty row."""
+    rng = np.random.default_rng(n_colors + 7)
+    m = 200_003 if n_colors < 1000 else 20_011
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.05, zero_row_frac=0.0003)
+    hx = to_hip_index(hip_ctx, oix)
+    genome = rnd(rng, 160_000)
+    shorts = [[genome[i:i + 150]] for i in range(0, 9_000, 150)] + [[genome[i:i + 100], genome[i + 200:i + 330]] for i in range(0, 3_000, 300)]
+    reads = long_reads(rng, genome)[:9] + shorts + long_reads(rng, genome)[9:] + [[]] + [[b"", genome[:5_000]]] + [[genome[:7_000], b"AC", genome[100:8_000]]]
+    rng.shuffle(reads)
+    bases, seq_off, read_seq0 = pack_reads(reads)
+    sizes = [sum(len(s) for s in r) for r in reads]
+    for d, S, unaligned in ((1, 3, 0), (1, 0, 5), (3, 64, 11)):
+        want = oix.readid_counts(bases, seq_off, read_seq0, d, S, n_threads=8)
+        got = _dev_call(hip_ctx, hx, reads, d, S, max(sizes), max(sizes), unaligned)
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), (d, S)
+    # maxima below the two longest reads: those come back with status 3, everything else as before
+    cap = sorted(sizes)[-3]
+    got = _dev_call(hip_ctx, hx, reads, 1, 3, cap, cap)
+    want = oix.readid_counts(bases, seq_off, read_seq0, 1, 3, n_threads=8)
+    over = np.array([sz > cap for sz in sizes])
+    assert over.sum() >= 1
+    assert (got[2][over] == 3).all() and (got[1][over] == 0).all() and (got[0][over] == 0).all()
+    assert np.array_equal(got[2][~over], want[2][~over]) and np.array_equal(got[1][~over], want[1][~over]) and np.array_equal(got[0][~over], want[0][~over])
+    hx.close()
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_soft_masked_reads_go_alone(orc, hip_ctx, fuse):
+    """A lower-case base keeps its case: the read that holds one takes the byte-string (sorting) path — that read alone
+    (round 5: the whole batch).  Long reads with a lower-case stretch in the first, a middle and the last window, a wholly lower-case
+    mate, one of several buckets; upper-case neighbours of every class; with the fused kernel and with k_extract_codes + k_long_first_flags."""
+    hip_ctx.tune("readid_long_fuse", fuse)
+    try:
+        rng = np.random.default_rng(131)
+        n_colors, n_hash, k, m = 256, 2, 21, 100_003
+        oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.1, zero_row_frac=0.0004)
+        hx = to_hip_index(hip_ctx, oix)
+        g = rnd(rng, 90_000)
+
+        def low(b, a, z):
+            x = bytearray(b); x[a:z] = bytes(x[a:z]).lower(); return bytes(x)
+        reads = [[g[:20_000]], [low(g[:30_000], 12_345, 12_400)], [g[100:260]], [g[:9_000].lower(), g[:9_000]], [low(g[3_000:6_500], 0, 1)],
+                 [g[40_000:52_000]], [low(g[:12_000], 11_999, 12_000)], [low(g[:80_000], 70_000, 70_100)], [g[:80_000]], [low(g[500:700], 10, 30)],
+                 [g[20_000:24_000], low(g[30_000:33_000], 5, 9)], [b"N" * 3_000 + low(g[:3_000], 100, 200)]]
+        for d, S in ((1, 3), (1, 0), (2, 70)):
+            compare(oix, hx, reads, d, S, ("soft", fuse, d, S))
+        got = _dev_call(hip_ctx, hx, reads, 1, 3, 80_000, 80_000)
+        bases, seq_off, read_seq0 = pack_reads(reads)
+        want = oix.readid_counts(bases, seq_off, read_seq0, 1, 3, n_threads=8)
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0])
+        hx.close()
+    finally:
+        hip_ctx.tune("readid_long_fuse", 1)
+
+
+def test_fused_and_two_kernel_paths_agree_on_every_class(orc, hip_ctx):
+    """the classes of the device-made plan: one table in the fused kernel (256 and 1 024 threads), the same reads through
+    k_extract_codes + k_long_first_flags (readid_long_fuse = 0), reads of more mates than the fused kernel keeps a table of, strides that
+    stretch a read's bases beyond its LDS, minimizer indices"""
+    import colorid_amd
+    rng = np.random.default_rng(77)
+    n_colors, n_hash, k, m = 200, 2, 25, 150_001
+    oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.1, zero_row_frac=0.0005)
+    hx = to_hip_index(hip_ctx, oix)
+    g = rnd(rng, 120_000)
+    many = [g[i * 1_000:i * 1_000 + 900] for i in range(7)]                 # seven mates: the items route
+    reads = [[g[:3_000]], [g[:4_120]], [g[:4_121]], [g[:16_000]], [g[:16_408]], [g[:16_409]], [g[:40_000]], many, [g[:2_000], b"", g[:1_000], b"ACGT", g[5_000:9_000]],
+             [g[:6_100]], [g[:20_400]], [g[:20_500]], [g[50_000:50_000 + 1_100]] * 4, [g[:3_000]] * 5]
+    for fuse in (1, 0):
+        hip_ctx.tune("readid_long_fuse", fuse)
+        try:
+            for d, S in ((1, 3), (4, 0), (13, 2)):
+                compare(oix, hx, reads, d, S, ("classes", fuse, d, S))
+        finally:
+            hip_ctx.tune("readid_long_fuse", 1)
+    hx.close()
+
+
 def _random_long_read(rng, genome, k):
     """a read of 1 kb ... 420 kb (two buckets undealt, three and more dealt, 24 and more with the pairs grouped in LDS first) made of stretches
     of the genome: some repeated, some with N runs, some reverse-complemented"""
