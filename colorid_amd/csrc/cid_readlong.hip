@@ -581,7 +581,7 @@ __device__ __forceinline__ void fuse_load_pieces(const FuseItem *it, uint4 (&pc)
 }
 template <uint32_t BLOCK, uint32_t ITERS>
 __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
-    extern __shared__ uint32_t table[];   // max_slots, then the 2-bit fields (pos_cap / 16 + 4 words), the bad-base bits (pos_cap / 32 + 4 words), the bitmap
+    extern __shared__ __align__(16) uint32_t table[];   // max_slots, then the 2-bit fields (pos_cap / 16 + 4 words), the bad-base bits (pos_cap / 32 + 4 words), the bitmap
     __shared__ uint32_t s_first[kFuseSeqs], s_wbase[kFuseSeqs + 1], s_piece0[kFuseSeqs + 1];
     __shared__ uint32_t s_len[kFuseSeqs];
     __shared__ int s_over;
@@ -614,7 +614,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
             s_piece0[t] = t < ns ? rec->piece0[t] : n_pieces;
             if (t == 0) { s_wbase[kFuseSeqs] = nw; s_piece0[kFuseSeqs] = n_pieces; s_over = 0; }
         }
-        for (uint32_t s = threadIdx.x; s < slots; s += BLOCK) table[s] = kLongEmpty;
+        for (uint32_t s = threadIdx.x; s < slots / 4u; s += BLOCK)   // (16 bytes a store: slots is a power of two >= 1 024)
+            reinterpret_cast<uint4 *>(table)[s] = uint4{kLongEmpty, kLongEmpty, kLongEmpty, kLongEmpty};
         for (uint32_t s = threadIdx.x; s < bad_words; s += BLOCK) s_bad[s] = 0xFFFFFFFFu;
         for (uint32_t s = threadIdx.x; s < pack_words; s += BLOCK) s_pack[s] = 0u;
         for (uint32_t s = threadIdx.x; s < BLOCK * ITERS / 32u; s += BLOCK) s_bm[s] = 0u;
@@ -672,7 +673,6 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
         const uint32_t w_per = (nw + BLOCK - 1) / BLOCK;   // <= ITERS
         const uint32_t wa = threadIdx.x * w_per;
         const uint64_t kmask = code_mask(k);
-        uint32_t slot_of[ITERS];   // where window wa + i ended (kLongEmpty: no k-mer there)
         uint32_t q = 0, next_base = 0, pos = 0, good_run = 0;
         uint64_t fwd = 0, rcv = 0;
         auto prime = [&](uint32_t w) {   // the rolling state at window w: both codes and the run of good bases ending at its last base
@@ -687,110 +687,48 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
             good_run = badbits ? (uint32_t)__clzll((long long)badbits) - (64u - k) : k;   // the bases behind the last bad one
         };
         if (wa < nw) prime(wa);
-#pragma unroll
-        for (uint32_t i = 0; i < ITERS; ++i) slot_of[i] = kLongEmpty;
-        // Eight windows at a time, in three sweeps: (1) their codes — LDS reads and shifts only, nothing between them that the scheduler
-        // has to keep in order, (2) their slots asked for with eight compare-and-swaps in a row on the EMPTY value — at a load below a
-        // half most of them win their home slot at once, and the eight round trips overlap — (3) the losers, one by one as before.
-        // (One window after the other, every window paid three dependent LDS round trips: 30 000 cycles per 10 kb read.)
-        constexpr uint32_t kBatch = 8;
-        // A wave whose 64 threads all hold w_per windows of ONE mate at stride 1 (every wave of a read but its last, as a rule) runs the
-        // first sweep as straight-line code: no lane drops out, so nothing splits the eight windows into basic blocks of their own, the
-        // bases and bad-base bits they need are two 64-bit LDS reads for the batch, and their shifts interleave.
-        const bool plain = __all(wa + w_per <= nw && wa + w_per <= next_base && stride == 1) && !p.msz;
-        const uint32_t pos_a = pos;   // position of window wa
-#pragma unroll
-        for (uint32_t b0 = 0; b0 < ITERS; b0 += kBatch) {
-            if (b0 >= w_per) break;   // (workgroup-uniform)
-            uint64_t code[kBatch];
-            uint32_t old[kBatch];
-            if (plain) {
-                // window wa + i (i >= 1) takes in the base at position pos_a + k - 1 + i: this batch's new bases start at P
-                const uint32_t t0 = b0 ? b0 - 1u : 0u, P = pos_a + k + t0;
-                const uint32_t *pw = s_pack + (P >> 4), *bw = s_bad + (P >> 5);
-                const uint64_t nb = (((uint64_t)pw[1] << 32) | pw[0]) >> (2u * (P & 15u));    // >= 17 bases from P on
-                const uint64_t bb = (((uint64_t)bw[1] << 32) | bw[0]) >> (P & 31u);            // >= 33 bad-base bits from P on
-#pragma unroll
-                for (uint32_t j = 0; j < kBatch; ++j) {
-                    const uint32_t i = b0 + j;
-                    code[j] = p.sentinel;
-                    if (i >= w_per) break;   // (workgroup-uniform)
-                    if (i) {
-                        const uint32_t t = i - 1u - t0;
-                        const uint32_t c = (uint32_t)(nb >> (2u * t)) & 3u;
-                        fwd = ((fwd << 2) | c) & kmask;
-                        rcv = (rcv >> 2) | ((uint64_t)(3u - c) << (2u * (k - 1u)));
-                        good_run = ((uint32_t)(bb >> t) & 1u) ? 0u : good_run + 1u;
-                    }
-                    const uint64_t cd = fwd < rcv ? fwd : rcv;   // (equal: the same string)
-                    code[j] = good_run >= k ? cd : p.sentinel;
-#ifndef CID_LONG_NOSTORE
-                    p.codes[w0 + wa + i] = code[j];
-#endif
+        // (a ROLLED loop: unrolled sixteen times the kernel is 60 KB of code, the sixteen waves of a workgroup run all over it and the
+        // instruction cache — 64 KB for two CUs — misses: 8.2 ms per 150 Mbases instead of 7.0)
+#pragma unroll 1
+        for (uint32_t i = 0; i < w_per; ++i) {
+            const uint32_t w = wa + i;
+            if (w >= nw) continue;
+            if (i) {
+                if (w == next_base || stride != 1) prime(w);   // the next mate; strides: every window from the bases
+                else {                                          // one base further
+                    ++pos;
+                    const uint32_t pn = pos + k - 1;
+                    const uint32_t c = (s_pack[pn >> 4] >> (2u * (pn & 15u))) & 3u;
+                    const uint32_t bad = (reinterpret_cast<const uint16_t *>(s_bad)[pn >> 4] >> (pn & 15u)) & 1u;
+                    fwd = ((fwd << 2) | c) & kmask;
+                    rcv = (rcv >> 2) | ((uint64_t)(3u - c) << (2u * (k - 1u)));
+                    good_run = bad ? 0u : good_run + 1u;
                 }
-            } else
-#pragma unroll
-            for (uint32_t j = 0; j < kBatch; ++j) {
-                const uint32_t i = b0 + j, w = wa + i;
-                code[j] = p.sentinel;
-                if (i >= w_per || w >= nw) continue;
-                if (i) {
-                    if (w == next_base || stride != 1) prime(w);   // the next mate; strides: every window from the bases
-                    else {                                          // one base further
-                        ++pos;
-                        const uint32_t pn = pos + k - 1;
-                        const uint32_t c = (s_pack[pn >> 4] >> (2u * (pn & 15u))) & 3u;
-                        const uint32_t bad = (reinterpret_cast<const uint16_t *>(s_bad)[pn >> 4] >> (pn & 15u)) & 1u;
-                        fwd = ((fwd << 2) | c) & kmask;
-                        rcv = (rcv >> 2) | ((uint64_t)(3u - c) << (2u * (k - 1u)));
-                        good_run = bad ? 0u : good_run + 1u;
-                    }
-                }
-                if (good_run >= k) {
-                    uint64_t cd = fwd < rcv ? fwd : rcv;   // (equal: the same string)
-                    if (p.msz) cd = minimizer_code(cd, k, p.msz);
-                    code[j] = cd;
-                }
-#ifndef CID_LONG_NOSTORE
-                p.codes[w0 + w] = code[j];
-#endif
             }
-#pragma unroll
-            for (uint32_t j = 0; j < kBatch; ++j) {
-                old[j] = 0;
-#ifdef CID_LONG_NOATOMIC
-                continue;
-#endif
-                if (code[j] == p.sentinel) continue;
-                const uint32_t h = long_mix32(code[j]);
-                const uint32_t at = h & mask;
-                slot_of[b0 + j] = at;
-                old[j] = atomicCAS(&table[at], kLongEmpty, ((wa + b0 + j) << kLongTagBits) | (h >> (32u - kLongTagBits)));
+            uint64_t code = p.sentinel;
+            const bool valid = good_run >= k;
+            if (valid) {
+                code = fwd < rcv ? fwd : rcv;   // (equal: the same string)
+                if (p.msz) code = minimizer_code(code, k, p.msz);
             }
-#pragma unroll
-            for (uint32_t j = 0; j < kBatch; ++j) {
-#ifdef CID_LONG_NOATOMIC
-                continue;
-#endif
-                if (code[j] == p.sentinel || old[j] == kLongEmpty) continue;   // no k-mer; or the home slot was free
-                const uint32_t h = long_mix32(code[j]);
-                const uint32_t tag = h >> (32u - kLongTagBits);
-                const uint32_t mine = ((wa + b0 + j) << kLongTagBits) | tag;
-                uint32_t at = slot_of[b0 + j], cur = old[j];
-                for (uint32_t probes = 0;; ++probes) {
-                    if ((cur & ((1u << kLongTagBits) - 1u)) == tag) {
-                        bool v2;
-                        if (code_at(cur >> kLongTagBits, v2) == code[j]) {   // the slot is this k-mer's
-                            atomicMin(&table[at], mine);
-                            break;
-                        }
+            p.codes[w0 + w] = code;
+            if (!valid) continue;
+            const uint32_t h = long_mix32(code);
+            const uint32_t tag = h >> (32u - kLongTagBits);
+            const uint32_t mine = (w << kLongTagBits) | tag;
+            uint32_t at = h & mask;
+            for (uint32_t probes = 0;; ++probes) {
+                const uint32_t cur = atomicCAS(&table[at], kLongEmpty, mine);   // (at a load below a half most windows win their home slot at once)
+                if (cur == kLongEmpty) break;
+                if ((cur & ((1u << kLongTagBits) - 1u)) == tag) {
+                    bool v2;
+                    if (code_at(cur >> kLongTagBits, v2) == code) {   // the slot is this k-mer's
+                        atomicMin(&table[at], mine);
+                        break;
                     }
-                    at = (at + 1) & mask;
-                    if (probes >= slots / 4) { s_over = 1; at = kLongEmpty; break; }
-                    cur = atomicCAS(&table[at], kLongEmpty, mine);
-                    if (cur == kLongEmpty) break;
                 }
-                slot_of[b0 + j] = at;
+                at = (at + 1) & mask;
+                if (probes >= slots / 4) { s_over = 1; break; }
             }
         }
         LONG_PROF_MARK(3);   // windows + inserts (thread 0's own)
@@ -801,16 +739,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
             __syncthreads();
             continue;
         }
-        // the winners — the windows whose slot still holds their number — as bits of the read's own bitmap words
-        uint32_t bits = 0;
+        // the winners — the smallest window of every k-mer, which is what its slot holds — as bits of the read's own bitmap words
+        for (uint32_t sl = threadIdx.x; sl < slots / 4u; sl += BLOCK) {
+            const uint4 c4 = reinterpret_cast<const uint4 *>(table)[sl];
+            const uint32_t cur[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-        for (uint32_t i = 0; i < ITERS; ++i) {
-            if (i >= w_per) break;
-            if (slot_of[i] != kLongEmpty && (table[slot_of[i]] >> kLongTagBits) == wa + i) bits |= 1u << i;
-        }
-        if (bits) {
-            atomicOr(&s_bm[wa >> 5], bits << (wa & 31u));
-            if ((wa & 31u) + w_per > 32u) atomicOr(&s_bm[(wa >> 5) + 1], bits >> (32u - (wa & 31u)));
+            for (uint32_t t = 0; t < 4; ++t)
+                if (cur[t] != kLongEmpty) atomicOr(&s_bm[cur[t] >> (kLongTagBits + 5u)], 1u << ((cur[t] >> kLongTagBits) & 31u));
         }
         __syncthreads();
         uint32_t *out = p.bitmap + (w0 >> 5);
