@@ -960,6 +960,28 @@ def side_readid_long(a, dev, ctx, stream, with_oracle, total_bases=150_000_000):
                 oix = cpu_baseline_readid_index(ptr, m, n, k, C, rs)
             r.update(cpu_baseline_readid_long(oix, bases, seq_off, read0, report, nk, d, B))
         rec[name] = r
+        if name == "reads_10kb":
+            # Soft-masked reads (a lower-case stretch: its case is kept, SURVEY App. B Q2 — the byte-string path): ONE such read in the batch, and
+            # 1 % of the reads.  Until round 5 one lower-case base sent the whole batch through round 1's global sort (2.5 x the time).
+            soft = {}
+            for tag, every in (("one_read", reads), ("one_pct", 100)):
+                b2 = bases.clone()
+                for r_i in range(7, reads, every):
+                    a = int(seq_off[r_i]) + 4_000
+                    b2[a:a + 300] |= 0x20
+                ts = []
+                for i in range(6):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    hx.readid_count_resident(b2.data_ptr(), seq_off, read0, d, B, report.data_ptr(), nk.data_ptr(), st.data_ptr())
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                soft[tag] = {"soft_masked_reads": len(range(7, reads, every)), "ms": float(np.mean(ts[2:])), "all_ms": [round(t, 2) for t in ts],
+                             "vs_clean": float(np.mean(ts[2:])) / ms}
+                if with_oracle:
+                    soft[tag].update(cpu_baseline_readid_long(oix, b2, seq_off, read0, report, nk, d, B, sample_bases=4_000_000))
+                del b2
+            rec["soft_masked"] = soft
         del report, nk, st
     hx.close()
     return rec

@@ -74,11 +74,12 @@ static size_t readid_need(const cid_index *ix, uint32_t stride_d, uint32_t start
 constexpr size_t kLdsBytes = 160u * 1024u;
 // device scratch for dense read_id report rows per launch: cid_readid_count slices larger batches, the sparse form refuses them
 static size_t kDenseReportBytes = getenv("CID_DENSE_REPORT_BYTES") ? strtoull(getenv("CID_DENSE_REPORT_BYTES"), nullptr, 10) : (2ull << 30);
-// k_readid keeps a read's set in one wave's LDS.  With fewer than five waves per CU its gathers are no longer hidden and the long-read
+// k_readid keeps a read's set in one wave's LDS.  With fewer than six waves per CU its gathers are no longer hidden and the long-read
 // path (cid_readlong.hip) is faster: 150 Mbases resident, configs[2]'s index, ms per call k_readid / long path (tools/exp_readlen_route.py,
-// profiles/r05_readlen_route.jsonl): 600 bases 6.6 / 11.2, 800 bases (five waves) 8.8 / 10.4, 1000 bases (four waves) 13.0 / 10.0,
-// 2600 bases 25.0 / 8.3.  (Round 1's sorting path took 20 ms whatever the length: the rule then was "fewer than two waves".)
-constexpr size_t kLdsReadBytesMax = kLdsBytes / 5;
+// profiles/r06_readlen_route.jsonl): 300 bases 6.5 / 9.5, 600 bases 6.5 / 8.0, 800 bases (five waves) 8.7 / 7.7, 1000 bases (four waves)
+// 12.9 / 7.5, 2000 bases 18.3 / 7.1.  (Round 5's long path took 10.4 at 800 bases: the rule then was "fewer than five waves"; round 1's
+// sorting path took 20 ms whatever the length: "fewer than two".)
+constexpr size_t kLdsReadBytesMax = kLdsBytes / 6;
 
 static int readid_params(const cid_ctx *c, const cid_index *ix, uint32_t stride_d, uint32_t start_sample, uint64_t max_bytes, uint64_t max_win,
                          bool bytes_kernel, cid::ReadIdParams &p, int &waves, bool striped = false) {
@@ -179,7 +180,7 @@ static int readid_dev_impl(cid_ctx *c, const cid_index *ix, const uint8_t *d_bas
 // Which kernel takes which read of a batch.  Reads of at least long_from(...) bases take the long-read path (cid_readlong.hip), the others
 // the LDS kernels.  The rule is a threshold on a read's bases alone, so that the device applies it to offsets that never exist on the
 // host (cid::long_route_launch): the smallest read whose set — with the windows a read of that many bases has, (bases - k) / stride + 1 —
-// would leave k_readid fewer than five waves per CU (kLdsReadBytesMax).  cid_ctx_tune "readid_long_from" = L: every read of at least L
+// would leave k_readid fewer than six waves per CU (kLdsReadBytesMax).  cid_ctx_tune "readid_long_from" = L: every read of at least L
 // bases does (measurements).
 static uint64_t long_from(const cid_ctx *c, const cid_index *ix, uint32_t stride_d, uint32_t start_sample) {
     if (c->tune.readid_long_from >= 0) return (uint64_t)c->tune.readid_long_from;

@@ -147,8 +147,12 @@ struct ReadIdSliceParams {
     uint32_t *report;
     uint32_t *n_kmers;
     uint32_t *partial;            // [n_slices][n_colors + 2]: counts | no-hits | stopped — only rows of multi-slice reads are written
+    // soft-masked reads (k_long_bytes): bytes_read[r] != 0 — read r's entries in `codes` are (byte offset in bases << 1 | reverse complement)
+    // of byte-string k-mers; the plain kernel leaves those reads to the BYTES instantiation and the other way round.  NULL: no such reads
+    const uint8_t *bytes_read;
+    const uint8_t *bases;
 };
-hipError_t launch_readid_slices(const ReadIdSliceParams &p, int grid, hipStream_t stream);
+hipError_t launch_readid_slices(const ReadIdSliceParams &p, int grid, hipStream_t stream, bool bytes = false);
 hipError_t launch_readid_combine(const ReadCombine *d_comb, uint32_t n_comb, const uint32_t *d_partial, uint32_t n_colors, uint32_t *d_report,
                                  hipStream_t stream);
 

@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_list(ReadIdListParams p) {
 //   * an absent row ends the read: a slice records whether it stopped, k_readid_combine adds the slices' rows up to the first that did.
 // The codes and bitmap words of the NEXT 64 windows are asked for before the current chunk's rows: under load a dependent global load
 // costs as much as a gather round (k_readid_list pays one per 64 k-mers).
-template <int LOG_LPR, bool NARROW>
+template <int LOG_LPR, bool NARROW, bool BYTES = false>
 __global__ __launch_bounds__(kBlock, 5) void k_readid_slices(ReadIdSliceParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     constexpr uint32_t RS = NARROW ? 1u : 2u << LOG_LPR;
@@ -770,11 +770,16 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_slices(ReadIdSliceParams p
         return p.word_prefix[w >> 5] + (uint32_t)__popc(p.bitmap[w >> 5] & ((1u << (w & 31u)) - 1u));
     };
     auto hash_to = [&](uint64_t code, uint32_t q) {
-        xxh3_seeds_from(CodeReader{rev_fields(code, k)}, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + q] = (uint32_t)mod_m(h, p.mod); });
+        if constexpr (BYTES)   // a soft-masked read: the k-mer is a stretch of the read, forward or reverse complement, its case kept
+            xxh3_seeds_from(BaseReader{p.bases + (code >> 1), k, (uint32_t)(code & 1ull), 0u}, k, n, HashSel::of(p.mod),
+                            [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + q] = (uint32_t)mod_m(h, p.mod); });
+        else
+            xxh3_seeds_from(CodeReader{rev_fields(code, k)}, k, n, HashSel::of(p.mod), [&](uint32_t sd, uint64_t h) { ridx[sd * kWave + q] = (uint32_t)mod_m(h, p.mod); });
     };
     for (uint32_t sl = blockIdx.x * waves + wave; sl < p.n_slices; sl += gridDim.x * waves) {
         wave_lds_fence();
         const ReadSlice s = p.slices[sl];
+        if (((p.bytes_read && p.bytes_read[s.read]) != 0) != BYTES) continue;   // the other instantiation's read
         const bool multi = (s.part >> 31) != 0;
         const uint32_t part = s.part & 0x7FFFFFFFu;
         const uint32_t r0 = (uint32_t)p.wstart[s.read], r1 = (uint32_t)p.wend[s.read];   // the read's windows
@@ -1023,9 +1028,22 @@ static hipError_t launch_readid_slices_one(KernelT kernel, const ReadIdSlicePara
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), shmem, stream, p);
     return hipGetLastError();
 }
-hipError_t launch_readid_slices(const ReadIdSliceParams &p, int grid, hipStream_t stream) {   // rows of at most 1 KiB (rs <= 128), whole indices
+hipError_t launch_readid_slices(const ReadIdSliceParams &p, int grid, hipStream_t stream, bool bytes) {   // rows of at most 1 KiB (rs <= 128), whole indices
     if (p.n_slices == 0) return hipSuccess;
     if (p.rs > 128) return hipErrorInvalidValue;
+    if (bytes) {   // the soft-masked reads of the batch
+        if (p.rs == 1) return launch_readid_slices_one(k_readid_slices<0, true, true>, p, grid, stream);
+        switch (log2u(p.rs / 2)) {
+        case 0: return launch_readid_slices_one(k_readid_slices<0, false, true>, p, grid, stream);
+        case 1: return launch_readid_slices_one(k_readid_slices<1, false, true>, p, grid, stream);
+        case 2: return launch_readid_slices_one(k_readid_slices<2, false, true>, p, grid, stream);
+        case 3: return launch_readid_slices_one(k_readid_slices<3, false, true>, p, grid, stream);
+        case 4: return launch_readid_slices_one(k_readid_slices<4, false, true>, p, grid, stream);
+        case 5: return launch_readid_slices_one(k_readid_slices<5, false, true>, p, grid, stream);
+        case 6: return launch_readid_slices_one(k_readid_slices<6, false, true>, p, grid, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (p.rs == 1) return launch_readid_slices_one(k_readid_slices<0, true>, p, grid, stream);
     switch (log2u(p.rs / 2)) {
     case 0: return launch_readid_slices_one(k_readid_slices<0, false>, p, grid, stream);

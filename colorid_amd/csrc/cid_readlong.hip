@@ -557,6 +557,8 @@ struct LongFuseParams {
     uint32_t *bitmap;
     uint8_t *redo;
     int *flags;
+    uint32_t *lower_list, *n_lower;   // non-NULL: a read with a lower-case base is listed here (item | big << 31) for k_long_bytes
+    uint32_t big;
     unsigned long long *prof;   // CID_LONG_PROF builds: [gridDim.x][8] cycles per phase (thread 0's clock)
 };
 #ifdef CID_LONG_PROF
@@ -650,8 +652,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
         // the NEXT read's bases are asked for now: they arrive while this read's table is filled
         if (item + step < item1) fuse_load_pieces<BLOCK>(p.items + item + step, pc);
         LONG_PROF_MARK(1);   // staging (own part)
-        if (__syncthreads_or(lower ? 1 : 0)) {   // (workgroup-uniform) the byte-string path takes this read
-            if (threadIdx.x == 0) { p.redo[read] = 1; atomicOr(&p.flags[0], 1); }
+        if (__syncthreads_or(lower ? 1 : 0)) {   // (workgroup-uniform) a byte-string path takes this read: k_long_bytes, or the sorting path
+            if (threadIdx.x == 0) {
+                p.redo[read] = 1;
+                if (p.lower_list) p.lower_list[atomicAdd(p.n_lower, 1u)] = item | (p.big << 31);
+                else atomicOr(&p.flags[0], 1);
+            }
             __syncthreads();
             continue;
         }
@@ -756,6 +762,154 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
 #ifdef CID_LONG_PROF
     if (threadIdx.x == 0 && p.prof) for (int i = 0; i < 8; ++i) p.prof[(size_t)blockIdx.x * 8 + i] = prof_acc[i];
 #endif
+}
+
+// k_long_bytes: the reads k_long_fused found a lower-case base in (soft-masked sequence).  The reference keeps a base's case
+// (kmer.rs:221-243 never upper-cases: SURVEY App. B Q2), so such a read's k-mers are byte strings: the canonical choice compares the
+// bytes of the window and of its reverse complement (upper case sorts before lower case), "acgt" and "ACGT" are different k-mers, and
+// the search hashes the bytes as they are.  Until round 5 one such base sent the whole batch through round 1's global rocPRIM sort (2.5 x
+// the time, and a 10 MB code object loaded on first use: 40 ms of a 35 ms CLI classification); now the read — alone — is redone here:
+// the bases as three planes in LDS (2-bit fields, bad-base bits, case bits), a k-mer's identity = (canonical code, its case bits in
+// canonical order), the same table, the winners' bits into the read's bitmap words and at each winner's window a (byte offset << 1 | reverse
+// complement) entry in the code array, which k_readid_slices' BYTES instantiation searches slice by slice like any other read.
+struct LongBytesParams {
+    const FuseItem *items_small, *items_big;
+    const uint32_t *lower, *n_lower;
+    const uint8_t *bases;
+    uint32_t k, stride;
+    uint64_t *codes;
+    uint32_t *bitmap;
+    uint8_t *bytes_read;
+    uint8_t *redo;
+    int *flags;
+};
+constexpr uint32_t kBytesBlock = 1024;
+__global__ __launch_bounds__(kBytesBlock) void k_long_bytes(LongBytesParams p) {
+    extern __shared__ __align__(16) uint32_t table[];   // kLongSlotsBig, then the three planes of kFusePosBig positions, then the bitmap
+    __shared__ uint32_t s_first[kFuseSeqs], s_wbase[kFuseSeqs + 1], s_piece0[kFuseSeqs + 1], s_len[kFuseSeqs];
+    __shared__ int s_over;
+    constexpr uint32_t pack_words = kFusePosBig / 16 + 4, bit_words = kFusePosBig / 32 + 4, bm_words = kLongFill / 32;
+    uint32_t *s_pack = table + kLongSlotsBig, *s_bad = s_pack + pack_words, *s_low = s_bad + bit_words, *s_bm = s_low + bit_words;
+    const uint32_t k = p.k, stride = p.stride;
+    const uint32_t n_lower = *p.n_lower;
+    const uint64_t kmask = code_mask(k);
+    const uint32_t lowmask = k >= 32 ? ~0u : ((1u << k) - 1u);
+    for (uint32_t e = blockIdx.x; e < n_lower; e += gridDim.x) {
+        const uint32_t le = p.lower[e];
+        const FuseItem *rec = ((le >> 31) ? p.items_big : p.items_small) + (le & 0x7FFFFFFFu);
+        const uint32_t read = rec->read, nw = rec->nw, ns = rec->n_seq, n_pieces = rec->n_pieces;
+        const uint64_t w0 = rec->w0;
+        uint32_t slots = 1024;
+        while (slots < kLongSlotsBig && slots < 2u * nw) slots <<= 1;
+        const uint32_t mask = slots - 1;
+        if (threadIdx.x < kFuseSeqs) {
+            const uint32_t t = threadIdx.x;
+            s_first[t] = rec->first[t]; s_len[t] = rec->len[t];
+            s_wbase[t] = t < ns ? rec->wbase[t] : nw;
+            s_piece0[t] = t < ns ? rec->piece0[t] : n_pieces;
+            if (t == 0) { s_wbase[kFuseSeqs] = nw; s_piece0[kFuseSeqs] = n_pieces; s_over = 0; }
+        }
+        for (uint32_t s = threadIdx.x; s < slots; s += kBytesBlock) table[s] = kLongEmpty;
+        for (uint32_t s = threadIdx.x; s < bit_words; s += kBytesBlock) { s_bad[s] = 0xFFFFFFFFu; s_low[s] = 0u; }
+        for (uint32_t s = threadIdx.x; s < pack_words; s += kBytesBlock) s_pack[s] = 0u;
+        for (uint32_t s = threadIdx.x; s < bm_words; s += kBytesBlock) s_bm[s] = 0u;
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < n_pieces; x += kBytesBlock) {
+            uint32_t q = 0;
+            while (q + 1 < ns && x >= s_piece0[q + 1]) ++q;
+            const uint32_t pos = x * 16u, lo = s_first[q], hi = s_first[q] + s_len[q];
+            if (pos >= hi) continue;   // (padding behind the mate)
+            const uint4 v = *reinterpret_cast<const uint4 *>(rec->addr[q] + (uint64_t)(x - s_piece0[q]) * 16u);
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+            uint32_t code = 0, bad = 0, low = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < 16; ++t) {
+                const uint32_t b = (words[t >> 2] >> (8u * (t & 3u))) & 0xFFu;
+                const uint32_t c2 = (b >> 1) & 3u;
+                code |= (c2 ^ (c2 >> 1)) << (2 * t);
+                const bool good = pos + t >= lo && pos + t < hi && good_base_dev(b);
+                bad |= (good ? 0u : 1u) << t;
+                low |= (good ? (b >> 5) & 1u : 0u) << t;
+            }
+            s_pack[x] = code;
+            reinterpret_cast<uint16_t *>(s_bad)[x] = (uint16_t)bad;
+            reinterpret_cast<uint16_t *>(s_low)[x] = (uint16_t)low;
+        }
+        __syncthreads();
+        // the k-mer of window w: canonical code (base 0 most significant), its case bits in canonical order (bit j: base j), the strand
+        auto ident = [&](uint32_t w, uint64_t &code, uint32_t &cases, bool &fwd, uint32_t &pos_out, uint32_t &q_out) -> bool {
+            uint32_t q = 0;
+            while (q + 1 < ns && w >= s_wbase[q + 1]) ++q;
+            const uint32_t pos = s_first[q] + (w - s_wbase[q]) * stride;
+            pos_out = pos; q_out = q;
+            if (bits_at_dev(s_bad, pos, k) != 0) return false;
+            const uint64_t lsb = bits_at_dev(s_pack, 2u * pos, 2u * k);
+            const uint32_t low = (uint32_t)bits_at_dev(s_low, pos, k);
+            const uint64_t f_msb = rev_fields(lsb, k), rc_msb = ~lsb & kmask;
+            if (low == 0u || low == lowmask) fwd = f_msb < rc_msb;   // one case: byte order is code order (equal: the reverse-complement branch)
+            else {                                                    // mixed: the bytes decide, upper case before lower case
+                fwd = false;
+                for (uint32_t t = 0; t < k; ++t) {
+                    const uint32_t fb = (uint32_t)(lsb >> (2u * t)) & 3u, fc = (low >> t) & 1u;
+                    const uint32_t rb = 3u - ((uint32_t)(lsb >> (2u * (k - 1u - t))) & 3u), rcs = (low >> (k - 1u - t)) & 1u;
+                    const uint32_t fkey = (fc << 2) | fb, rkey = (rcs << 2) | rb;
+                    if (fkey != rkey) { fwd = fkey < rkey; break; }
+                }
+            }
+            code = fwd ? f_msb : rc_msb;
+            cases = fwd ? low : (__brev(low) >> (32u - k));
+            return true;
+        };
+        for (uint32_t w = threadIdx.x; w < nw; w += kBytesBlock) {
+            uint64_t code; uint32_t cases, pos, q; bool fwd;
+            if (!ident(w, code, cases, fwd, pos, q)) continue;
+            const uint32_t h = long_mix32(code ^ ((uint64_t)cases * 0x9E3779B97F4A7C15ull));
+            const uint32_t tag = h >> (32u - kLongTagBits);
+            const uint32_t mine = (w << kLongTagBits) | tag;
+            uint32_t at = h & mask;
+            for (uint32_t probes = 0;; ++probes) {
+                const uint32_t cur = atomicCAS(&table[at], kLongEmpty, mine);
+                if (cur == kLongEmpty) break;
+                if ((cur & ((1u << kLongTagBits) - 1u)) == tag) {
+                    uint64_t c2; uint32_t cs2, p2, q2; bool f2;
+                    if (ident(cur >> kLongTagBits, c2, cs2, f2, p2, q2) && c2 == code && cs2 == cases) {   // the slot is this k-mer's
+                        atomicMin(&table[at], mine);
+                        break;
+                    }
+                }
+                at = (at + 1) & mask;
+                if (probes >= slots / 4) { s_over = 1; break; }
+            }
+        }
+        __syncthreads();
+        if (s_over) {   // (workgroup-uniform) redo[read] stays set: the sorting path
+            if (threadIdx.x == 0) atomicOr(&p.flags[1], 1);
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t sl = threadIdx.x; sl < slots; sl += kBytesBlock) {
+            const uint32_t cur = table[sl];
+            if (cur != kLongEmpty) atomicOr(&s_bm[cur >> (kLongTagBits + 5u)], 1u << ((cur >> kLongTagBits) & 31u));
+        }
+        __syncthreads();
+        // the winners' bits into the read's own bitmap words, and at each winner's window its entry for the BYTES search: byte offset of
+        // the k-mer in `bases` << 1 | reverse complement
+        const uint32_t n_words = (nw + 31u) / 32u;   // <= 512
+        if (threadIdx.x < n_words) {
+            uint32_t word = s_bm[threadIdx.x];
+            p.bitmap[(w0 >> 5) + threadIdx.x] = word;
+            while (word) {
+                const uint32_t w = threadIdx.x * 32u + (uint32_t)__builtin_ctz(word);
+                word &= word - 1u;
+                uint64_t code; uint32_t cases, pos, q; bool fwd;
+                ident(w, code, cases, fwd, pos, q);
+                const uint64_t off = (rec->addr[q] - (uint64_t)(uintptr_t)p.bases) + (uint64_t)(pos - s_piece0[q] * 16u);
+                p.codes[w0 + w] = (off << 1) | (fwd ? 0ull : 1ull);
+            }
+        }
+        if (threadIdx.x == 0) { p.bytes_read[read] = 1; p.redo[read] = 0; }
+        __syncthreads();
+    }
 }
 
 // Which reads of a batch take this path (route[r] = 1), which the LDS kernels (0), which neither (3: beyond the maxima a device-pointer
@@ -914,6 +1068,17 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         (rc = d_items.alloc((size_t)n_is + n_ib)) || (rc = d_slices.alloc(n_slices)) || (rc = d_combs.alloc(n_combs)) || (rc = d_segs.alloc(n_segs)) ||
         (rc = d_deals.alloc(n_deals)))
         return rc;
+    // soft-masked reads of the fused classes are redone on the device (k_long_bytes + k_readid_list over byte strings): whole k-mers, rows of
+    // at most 1 KiB, no stripe pass — elsewhere they take the sorting path
+    const bool bytes_on_device = own_search && !msz && (n_fs + n_fb) > 0;
+    const uint32_t n_fused = n_fs + n_fb;
+    DevBuf<uint32_t> d_lower(c);
+    DevBuf<uint8_t> d_bytes_read(c);
+    if (bytes_on_device) {
+        if ((rc = d_lower.alloc((size_t)n_fused + 4)) || (rc = d_bytes_read.alloc(n_reads))) return rc;
+        HIP_TRY(hipMemsetAsync(d_lower.p, 0, 16, st));
+        HIP_TRY(hipMemsetAsync(d_bytes_read.p, 0, n_reads, st));
+    }
     LongLists L{};
     L.fused_small = d_fuse.p; L.fused_big = d_fuse.p + n_fs; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
     L.items_small = d_items.p; L.items_big = d_items.p + n_is;
@@ -959,8 +1124,9 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         }
         LongFuseParams fp{};
         fp.k = k; fp.msz = msz; fp.stride = stride_d; fp.sentinel = sentinel; fp.codes = d_codes.p; fp.bitmap = d_bitmap.p; fp.redo = d_redo.p; fp.flags = d_flags.p;
+        if (bytes_on_device) { fp.lower_list = d_lower.p + 4; fp.n_lower = d_lower.p; }
         if (n_fs) {
-            fp.items = L.fused_small; fp.n_list = n_fs; fp.max_slots = kLongSlotsSmall; fp.pos_cap = kFusePosSmall;
+            fp.items = L.fused_small; fp.n_list = n_fs; fp.big = 0; fp.max_slots = kLongSlotsSmall; fp.pos_cap = kFusePosSmall;
             unsigned g = (n_cu * 4u + 7u) & ~7u;
             hipLaunchKernelGGL((k_long_fused<kLongBlockSmall, kLongSmallWin / kLongBlockSmall>), dim3(g), dim3(kLongBlockSmall),
                                (kLongSlotsSmall + kFusePosSmall / 16 + 4 + kFusePosSmall / 32 + 4 + kLongSmallWin / 32) * 4, st, fp);
@@ -972,7 +1138,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         fp.prof = n_fb ? d_prof.p : nullptr;
 #endif
         if (n_fb) {
-            fp.items = L.fused_big; fp.n_list = n_fb; fp.max_slots = kLongSlotsBig; fp.pos_cap = kFusePosBig;
+            fp.items = L.fused_big; fp.n_list = n_fb; fp.big = 1; fp.max_slots = kLongSlotsBig; fp.pos_cap = kFusePosBig;
             const int shmem = (int)((kLongSlotsBig + kFusePosBig / 16 + 4 + kFusePosBig / 32 + 4 + kLongFill / 32) * 4);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_fused<kLongBlockBig, kLongFill / kLongBlockBig>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
@@ -987,6 +1153,16 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
             fprintf(stderr, "k_long_fused<big> %u reads, mean cycles per workgroup: clears %llu, staging %llu, barrier %llu, inserts %llu, wait %llu, winners %llu, loop top %llu\n", n_fb,
                     sum[0] / g, sum[1] / g, sum[2] / g, sum[3] / g, sum[4] / g, sum[5] / g, sum[7] / g);
 #endif
+        }
+        if (bytes_on_device) {
+            LongBytesParams bp{};
+            bp.items_small = L.fused_small; bp.items_big = L.fused_big; bp.lower = d_lower.p + 4; bp.n_lower = d_lower.p; bp.bases = d_bases;
+            bp.k = k; bp.stride = stride_d; bp.codes = d_codes.p; bp.bitmap = d_bitmap.p; bp.bytes_read = d_bytes_read.p;
+            bp.redo = d_redo.p; bp.flags = d_flags.p;
+            const int shmem = (int)((kLongSlotsBig + kFusePosBig / 16 + 4 + 2 * (kFusePosBig / 32 + 4) + kLongFill / 32) * 4);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_bytes), hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+            unsigned g = n_fused < n_cu ? n_fused : n_cu;
+            hipLaunchKernelGGL(k_long_bytes, dim3(g), dim3(kBytesBlock), shmem, st, bp);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -1012,7 +1188,9 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         uint64_t grid = ((uint64_t)n_slices + 3) / 4;
         const uint64_t cap = (uint64_t)ctx_n_cu(c) * 32;
         if (grid > cap) grid = cap;
+        if (bytes_on_device) { p.bytes_read = d_bytes_read.p; p.bases = d_bases; }
         HIP_TRY(launch_readid_slices(p, (int)grid, st));
+        if (bytes_on_device) HIP_TRY(launch_readid_slices(p, (int)grid, st, true));   // the soft-masked reads' slices (none, as a rule: every wave leaves at once)
         HIP_TRY(launch_readid_combine(d_combs.p, n_combs, d_partial.p, C, d_report, st));
         hipLaunchKernelGGL(k_long_short_rows, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, d_status, (uint32_t)n_reads, C, d_report, d_n_kmers);
         HIP_TRY(hipGetLastError());
