@@ -394,7 +394,7 @@ def scale_check(a, n_ranks, counters):
     """{"key", "ranks", "expected", "got", "ok"}: ok None = no digest is committed for this workload and rank count"""
     rec = {"key": workload_key(a), "ranks": n_ranks, "got": counters["sha256"], "expected": None, "ok": None}
     try:
-        with open(os.path.join(ROOT, "tests", "golden", "scale_digests.json")) as f:
+        with open(os.environ.get("BENCH_SCALE_DIGESTS") or os.path.join(ROOT, "tests", "golden", "scale_digests.json")) as f:   # (tests point it at a copy)
             rec["expected"] = json.load(f).get(rec["key"], {}).get(str(n_ranks))
     except (OSError, ValueError):
         pass

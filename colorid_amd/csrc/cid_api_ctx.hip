@@ -103,8 +103,9 @@ hipError_t ctx_side_streams(cid_ctx *c, hipStream_t out[4]) {
 hipEvent_t ctx_event(const cid_ctx *c, int i) { return i == 0 ? c->ev_copied[0] : c->ev_done[0]; }
 
 int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
-    // a started cid_bgzf_inflate batch owns these four slots (and the pinned arena) until its _finish
-    if (c->inflate.open && (s == S_KMERS || s == S_MISC || s == S_BASES || s == S_FREQ))
+    // a started cid_bgzf_inflate batch owns these five slots (and the pinned arena) until its _finish (S_ROWIDS: the wave kernel's match
+    // tokens and retry list)
+    if (c->inflate.open && (s == S_KMERS || s == S_MISC || s == S_BASES || s == S_FREQ || s == S_ROWIDS))
         return fail(CID_ERR_STATE, "a cid_bgzf_inflate_start on this ctx is waiting for its _finish: this call would overwrite its buffers");
     if (bytes == 0) bytes = 16;
     if (c->slot_bytes[s] < bytes) {
@@ -279,7 +280,8 @@ int cid_ctx_tune(cid_ctx *c, const char *name, long value) {
 int cid_warmup(cid_ctx *c, unsigned what) {
     if (!c) return fail(CID_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
-    if (what & CID_WARM_READID) HIP_TRY(cid::warm_readid());
+    if (what & CID_WARM_READID) { HIP_TRY(cid::warm_readid()); HIP_TRY(cid::warm_readlong()); }
+    if (what & CID_WARM_COLD) HIP_TRY(cid::warm_cold());
     if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_search());
     if (what & (CID_WARM_READID | CID_WARM_SEARCH)) HIP_TRY(cid::warm_reports());   // sparse report rows / modes: a small code object
     if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_kmerset());                         // the k-mer set's sorts: 18 MB, 0.2 s to load

@@ -439,7 +439,12 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
         if ((rc = cid::ctx_alloc(c, n_members * 4, &p))) { free_staged(fq, sg); return rc; }
         sg.d_status = (uint32_t *)p;
         if ((rc = cid::ctx_alloc(c, n_bytes + 16, &sg.d_in)) || (rc = cid::ctx_alloc(c, n_members * sizeof(cid::BgzfMember), &sg.d_mem))) { free_staged(fq, sg); return rc; }
-        if (cid::ctx_alloc(c, cid::bgzf_inflate_scratch_bytes((uint32_t)n_members), &sg.d_scratch) != CID_OK) sg.d_scratch = nullptr;   // (refused: one lane per member)
+        if (cid::ctx_alloc(c, cid::bgzf_inflate_scratch_bytes((uint32_t)n_members), &sg.d_scratch) != CID_OK) {   // refused: one lane per member (3 x slower)
+            sg.d_scratch = nullptr;
+            static bool said = false;
+            if (!said) { said = true; fprintf(stderr, "cid_fastq_push_bgzf: no room for the wave-parallel inflate's %zu MB of match tokens (%zu members): "
+                                              "inflating one member per lane; push smaller stretches\n", cid::bgzf_inflate_scratch_bytes((uint32_t)n_members) >> 20, n_members); }
+        }
         // the blocks may have just come back from work queued on the ctx stream: the inflate stream starts behind it
         // (the members travel on the text stream: the inflate stream may still be busy with the push before, and the copy need not wait for it)
         hipEvent_t behind = cid::ctx_event(c, 0);

@@ -128,6 +128,8 @@ const char *bgzf_status_text(uint32_t st);
 
 // load a translation unit's code object ahead of its first kernel launch (cid_warmup)
 hipError_t warm_readid();
+hipError_t warm_readlong();
+hipError_t warm_cold();
 hipError_t warm_search();
 hipError_t warm_kmerset();
 hipError_t warm_reports();

@@ -156,8 +156,8 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
         const uint32_t bits = lbits[l], shift = top - consumed - bits, bins = 1u << bits;
         const uint32_t level_top = l == 0 ? top : 64u;    // the first level leaves the sentinels behind
         const size_t table_n = (size_t)part_max_tiles((uint32_t)n, S) * bins;
-        HIP_TRY(hipMemsetAsync(table.p, 0, table_n * 4, st));
         hipLaunchKernelGGL(k_part_tiles, dim3(1), dim3(kPartBlock), 0, st, seg, S, tile_base.p);
+        hipLaunchKernelGGL(k_part_zero_tail, dim3(256), dim3(256), 0, st, table.p, tile_base.p, S, bins, (uint64_t)table_n);
         hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(kPartBlock), 0, st, src, seg, tile_base.p, S, shift, bits, level_top, table.p, info.p);
         HIP_TRY(scan_launch(U32In{table.p}, U32Out{table.p}, table_n, scan_state.p, st));   // in place: a thread reads its elements before it writes them
         hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, tile_base.p, S, shift, bits, level_top, table.p);
@@ -258,8 +258,8 @@ int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_
     for (unsigned l = 0; l < levels; ++l) {
         const uint32_t bits = lbits[l], shift = 32 - consumed - bits, bins = 1u << bits;
         const size_t table_n = (size_t)part_max_tiles((uint32_t)n, S) * bins;
-        HIP_TRY(hipMemsetAsync(table.p, 0, table_n * 4, st));
         hipLaunchKernelGGL(k_part_tiles, dim3(1), dim3(kPartBlock), 0, st, seg, S, tile_base.p);
+        hipLaunchKernelGGL(k_part_zero_tail, dim3(256), dim3(256), 0, st, table.p, tile_base.p, S, bins, (uint64_t)table_n);
         hipLaunchKernelGGL(k_part_hist_key, dim3(grid), dim3(kPartBlock), 0, st, ksrc, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u, table.p, info.p);
         HIP_TRY(scan_launch(U32In{table.p}, U32Out{table.p}, table_n, scan_state.p, st));   // in place: a thread reads its elements before it writes them
         hipLaunchKernelGGL(k_part_scatter_pair, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, kdst, dst, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u,
@@ -876,13 +876,18 @@ int cid_search_count_set_report(cid_ctx *c, const cid_index *ix, const cid_kmers
     // ONE copy, ONE wait: the three counter arrays, the modes as they stand and the number of multiplicities the mode table did not hold
     // come back together; only when there are such k-mers (deep coverage) a second step counts them in.  (Round 4: two waits, four copies.)
     cid::ModeWork w;
-    if ((rc = cid::unique_freq_modes_begin(c, uc.p, ks->counts, ks->n, C, out.p + 3 * C, &w))) { (void)cid::unique_freq_modes_finish(c, &w, 0, out.p + 3 * C); return rc; }
+    struct ModeGuard {   // whatever way this function is left, the mode table's arrays go back to the ctx's block cache
+        cid_ctx *c; cid::ModeWork *w; uint64_t *modes; bool done = false;
+        ~ModeGuard() { if (!done) (void)cid::unique_freq_modes_finish(c, w, 0, modes); }
+    } guard{c, &w, out.p + 3 * C};
+    if ((rc = cid::unique_freq_modes_begin(c, uc.p, ks->counts, ks->n, C, out.p + 3 * C, &w))) return rc;
     hipStream_t st = cid::ctx_stream(c);
     std::vector<uint64_t> h((size_t)4 * C + 1);
     HIP_TRY(hipMemcpyAsync(out.p + 4 * C, w.ovf_count, 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(h.data(), out.p, ((size_t)4 * C + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const unsigned long long n_ovf = h[(size_t)4 * C];
+    guard.done = true;
     if ((rc = cid::unique_freq_modes_finish(c, &w, n_ovf, out.p + 3 * C))) return rc;
     if (n_ovf) {
         HIP_TRY(hipMemcpyAsync(h.data() + 3 * (size_t)C, out.p + 3 * C, (size_t)C * 8, hipMemcpyDeviceToHost, st));

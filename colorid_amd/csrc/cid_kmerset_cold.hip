@@ -284,9 +284,15 @@ __global__ void k_keep_gt(const uint32_t *counts, uint64_t t, uint32_t *keep, ui
 }
 
 // d_bases resident; host seq_off / read_seq0.  Writes report / n_kmers / status to DEVICE arrays.
+// start-up: this unit's code object — rocPRIM's few thousand kernels, 10 MB, ~40 ms to load — ahead of the first call that needs it
+// (cid_warmup(CID_WARM_COLD): read_id's sorting path for long reads with k > 32 or soft-masked reads of several hash buckets)
 __global__ void k_merge_status(const uint8_t *mine, uint8_t *status, uint64_t n, int only_routed) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n && (!only_routed || mine[r] != 2)) status[r] = mine[r];
+}
+hipError_t warm_cold() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_merge_status));
 }
 
 int readid_long_sorted(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const uint64_t *seq_off, const uint64_t *read_seq0,

@@ -961,6 +961,12 @@ __global__ void k_long_redo_status(const uint8_t *redo, uint8_t *status, uint64_
     if (r < n_reads && redo[r]) status[r] = 2;
 }
 
+// start-up: this unit's code object (the long-read kernels) loaded ahead of the first long read (cid_warmup)
+hipError_t warm_readlong() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k_long_route));
+}
+
 int long_route_launch(cid_ctx *c, const uint64_t *d_seq_off, const uint64_t *d_read_seq0, size_t n_reads, uint32_t k, uint32_t stride_d, uint64_t long_from,
                       uint64_t cap_bytes, uint64_t cap_win, uint8_t *d_route, uint32_t *d_stats) {
     hipStream_t st = ctx_stream(c);

@@ -161,8 +161,12 @@ int unique_freq_modes(cid_ctx *c, const uint32_t *d_uc, const uint32_t *d_freq, 
     int rc = unique_freq_modes_begin(c, d_uc, d_freq, n, C, d_modes, &w);
     if (rc) { (void)unique_freq_modes_finish(c, &w, 0, d_modes); return rc; }
     unsigned long long n_ovf = 0;
-    HIP_TRY(hipMemcpyAsync(&n_ovf, w.ovf_count, 8, hipMemcpyDeviceToHost, ctx_stream(c)));
-    HIP_TRY(hipStreamSynchronize(ctx_stream(c)));
+    hipError_t e = hipMemcpyAsync(&n_ovf, w.ovf_count, 8, hipMemcpyDeviceToHost, ctx_stream(c));
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx_stream(c));
+    if (e != hipSuccess) {   // (w's arrays go back to the block cache on this way out too)
+        (void)unique_freq_modes_finish(c, &w, 0, d_modes);
+        return fail(CID_ERR_HIP, "unique_freq_modes: %s", hipGetErrorString(e));
+    }
     return unique_freq_modes_finish(c, &w, n_ovf, d_modes);
 }
 

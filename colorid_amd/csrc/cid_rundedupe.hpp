@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kPartBlock) void k_run_dedupe_sort(const uint32_t *
                 const uint32_t bkt = bucket_of(key[r], val[r]);
                 const uint32_t lo = s_pre[bkt], hi = s_pre[bkt + 1], c = hi - lo;
                 // where the walk starts: 24 hashed bits scaled to the stretch's length
-                uint32_t slot = HASHED ? lo + ((((uint32_t)((val[r] * 0x9E3779B97F4A7C15ull) >> 40) & 0xFFFFFFu) * c) >> 24) : lo;
+                uint32_t slot = HASHED ? lo + (uint32_t)(((uint64_t)((uint32_t)((val[r] * 0x9E3779B97F4A7C15ull) >> 40) & 0xFFFFFFu) * c) >> 24) : lo;   // (64-bit: c passes 256)
                 bool found = false;
                 const uint32_t limit = c < kDedupeProbes ? c : kDedupeProbes;
                 if (val[r] != EMPTY)   // (a value that looks like an empty slot — no k <= 31 code does — sends the run to the radix kernel)

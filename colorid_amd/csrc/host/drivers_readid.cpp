@@ -564,11 +564,11 @@ FrontEnd classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &f
 
 // the rows written so far belong to a run that is being started over: an empty output again, and the abandoned run's share of the
 // `timing:` lines forgotten.  An output that cannot be emptied (a FIFO, a character device: what was written is gone) ends the run.
-void empty_output(FILE *out) {
+void empty_output(FILE *out, const std::string &prefix) {
     struct stat sb;
     if (fflush(out) != 0 || fstat(fileno(out), &sb) != 0) die("could not empty the outfile for the restart");
     if (!S_ISREG(sb.st_mode)) die("the device front end gave up mid-run and %s_reads.txt is not a regular file: rows already written cannot be taken back; "
-                                  "run again with COLORID_DEVICE_FASTQ=0", "<prefix>");
+                                  "run again with COLORID_DEVICE_FASTQ=0", prefix.c_str());
     if (ftruncate(fileno(out), 0) != 0) die("could not empty the outfile for the restart");
     rewind(out);
     reset_read_id_timing();
@@ -590,7 +590,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     FrontEnd fe = on_device ? classify_bgzf_on_device(ctx, fq, 1, b, d, start_sample, qual_offset, *classifier) : kFrontEndNotMine;
     if (fe == kFrontEndRestart) {
         classifier->finish();
-        empty_output(out);
+        empty_output(out, prefix);
         classifier = make_classifier();
     }
     if (fe != kFrontEndDone)
@@ -623,7 +623,7 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     FrontEnd fe = on_device ? classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, *classifier) : kFrontEndNotMine;
     if (fe == kFrontEndRestart) {
         classifier->finish();
-        empty_output(out);
+        empty_output(out, prefix);
         classifier = make_classifier();
     }
     if (fe != kFrontEndDone)
@@ -649,23 +649,24 @@ void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &f
     if (!f) die("file not found: %s", fq[0].c_str());
     ReadBatch rb;
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, " %llu reads classified\r");
-    std::string sub, id, l;
+    std::string sub, id;
     uint64_t count = 0;
     char *lineptr = nullptr;
     size_t cap = 0;
     ssize_t got;
-    while ((got = getline(&lineptr, &cap, f)) > 0) {
-        l.assign(lineptr, (size_t)got);
+    setvbuf(f, nullptr, _IOFBF, 8u << 20);
+    while ((got = getline(&lineptr, &cap, f)) > 0) {   // (the line is used where getline left it: a copy per line was a third of the loop on long reads)
+        const size_t n = (size_t)got;
         if (count == 0) {
-            id = l.substr(0, l.size() - 1);
-        } else if (l.find('>') != std::string::npos) {
+            id.assign(lineptr, n - 1);
+        } else if (memchr(lineptr, '>', n) != nullptr) {
             if (!sub.empty()) {
                 rb.push(id, &sub, 1);
-                id = l.substr(0, l.size() - 1);
+                id.assign(lineptr, n - 1);
                 sub.clear();
             }
         } else {
-            sub += l;
+            sub.append(lineptr, n);
         }
         ++count;
         if (rb.size() > 0 && (rb.size() % batch == 0 || rb.heavy())) classifier.submit(rb);

@@ -445,7 +445,7 @@ int cmd_read_id(int argc, char **argv) {
     read_ahead(fq, device_front_end);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_READID | (device_front_end ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
+    std::thread warm = warm_async(gpus, CID_WARM_READID | CID_WARM_COLD | (device_front_end ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
@@ -482,7 +482,7 @@ int cmd_batch_id(int argc, char **argv) {
     if (!samples.empty()) read_ahead(samples[0].second, on_device[0]);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_READID | (any_on_device ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
+    std::thread warm = warm_async(gpus, CID_WARM_READID | CID_WARM_COLD | (any_on_device ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);

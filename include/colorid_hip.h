@@ -480,6 +480,8 @@ void cid_fastq_destroy(cid_fastq *);
 #define CID_WARM_SEARCH 2u
 #define CID_WARM_INFLATE 4u
 #define CID_WARM_FASTQ 8u /* the FASTQ front end (cid_fastq_*): its record / packing kernels and scans */
+#define CID_WARM_COLD 16u /* the rocPRIM-built cold paths (10 MB of device code, ~40 ms): read_id's sorting path — long reads with k > 32, soft-masked
+                           * reads of more than 16 384 windows — byte-string k-mer sets, reordering */
 int cid_warmup(cid_ctx *, unsigned what);
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */

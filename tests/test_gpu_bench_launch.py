@@ -20,8 +20,8 @@ TOY = ["--reads", "20000", "--bloom", "1000003", "--genome-len", "30000", "--ste
 TOY_STRIPED = TOY + ["--placement", "striped", "--stripe-log2-bloom", "20", "--stripe-colours", "128", "--density", "0.1"]
 
 
-def run_bench(args, backend=None, timeout=600):
-    env = dict(os.environ)
+def run_bench(args, backend=None, timeout=600, extra_env=None):
+    env = dict(os.environ, **(extra_env or {}))
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
@@ -79,18 +79,14 @@ def test_scale_check_fails_loudly_on_other_counters(tmp_path):
     none = one_json_line(run_bench(["--emulate-world", "2", "--scale-check", "--reads", "20001"] + TOY[2:]))
     assert none["scale_check"]["ok"] is None and none["scale_check"]["expected"] is None     # no digest committed for this workload: reported, not failed
     import json as _json
-    golden = os.path.join(ROOT, "tests", "golden", "scale_digests.json")
-    keep = open(golden).read()
-    try:
-        g = _json.loads(keep)
-        g[good["scale_check"]["key"]]["2"] = "0" * 64
-        open(golden, "w").write(_json.dumps(g))
-        p = run_bench(["--emulate-world", "2", "--scale-check"] + TOY)
-        assert p.returncode == 1
-        bad = _json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
-        assert bad["scale_check"]["ok"] is False
-    finally:
-        open(golden, "w").write(keep)
+    g = _json.load(open(os.path.join(ROOT, "tests", "golden", "scale_digests.json")))
+    g[good["scale_check"]["key"]]["2"] = "0" * 64
+    other = tmp_path / "scale_digests.json"          # (a copy: the committed file is never written to)
+    other.write_text(_json.dumps(g))
+    p = run_bench(["--emulate-world", "2", "--scale-check"] + TOY, extra_env={"BENCH_SCALE_DIGESTS": str(other)})
+    assert p.returncode == 1
+    bad = _json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert bad["scale_check"]["ok"] is False
 
 
 def test_nccl_without_enough_devices_is_a_one_line_refusal():
