@@ -181,7 +181,9 @@ struct PinnedBuf {   // page-locked bytes from the library (cid_pinned_alloc; pl
     void reserve(size_t want);   // (contents are not kept)
 };
 struct BgzfStretch {
-    ByteBuf bytes;                                 // whole members, back to back
+    // whole members, back to back.  (Pageable on purpose — round 6 tried page-locked memory, so that the reads land where the H2D copy takes
+    // them from: locking 70 MB per buffer stalled the runtime's other calls, the loop of 16 M reads went from 320-364 to 350-426 ms.)
+    ByteBuf bytes;
     std::vector<uint32_t> off, len, text_len;      // member i = bytes[off[i], +len[i]), its text has text_len[i] bytes
     uint64_t text_bytes = 0;
     bool last = false;                             // the file ends with this stretch

@@ -2,6 +2,8 @@
 // This is host staging for the GPU path: the reference counts k-mers on the CPU too (String keys + FNV);
 // here keys live packed in one arena and are hashed 8 bytes at a time.
 #include <unistd.h>
+#include <fcntl.h>
+#include <cerrno>
 #include <dlfcn.h>
 #include <zlib.h>
 
@@ -854,28 +856,66 @@ static void inflate_members_host(TaskPool *pool, int n_threads, const BgzfStretc
     for (int t = 0; t < nt; ++t) if (bad[t]) die("corrupt gzip member (inflate / CRC-32 failed)");
 }
 
+// Two stages (round 6; round 5's one thread read a stretch, walked its members and inflated the host's share before it went back for the
+// next read: the device waited 87-168 ms of a 16 M-read file's 310-375 ms for it):
+//   reader   the file's next bytes by several preads side by side (the page cache copies at a few GB/s per thread; the members' sizes are
+//            in their headers, so the walk from member to member needs the bytes and nothing else), the stretch cut at whole members
+//   inflater the host's share of the stretch (its LAST members' text) on the reader's pool
+// A stretch is handed out when both are through; the stages work on different stretches at the same time.
 struct BgzfMemberReader::Impl {
     double host_share = 0.0;
     int host_threads = 0;
-    std::unique_ptr<TaskPool> pool;
-    FILE *raw = nullptr;
+    std::unique_ptr<TaskPool> pool, read_pool;
+    int fd = -1;
+    uint64_t fpos = 0;                 // the next byte of the file not read yet
     size_t text_target;
-    std::thread worker;
+    std::thread worker, inflater;
     std::mutex mu;
-    std::condition_variable cv_full, cv_free;
-    std::deque<BgzfStretch> full, spare;
-    bool eof = false, stop = false, handed_last = false;
+    std::condition_variable cv_full, cv_free, cv_walked;
+    std::deque<BgzfStretch> full, spare, walked;
+    bool eof = false, stop = false, handed_last = false, walked_last = false;
     std::vector<unsigned char> tail;   // bytes read from the file behind the last whole member of the stretch before
     static constexpr size_t kDepth = 2;
+    static constexpr int kReadThreads = 4;
+
+    // up to `chunk` bytes of the file behind fpos to dst; returns what the file had
+    size_t read_some(unsigned char *dst, size_t chunk) {
+        const size_t piece = (size_t)4 << 20;
+        const size_t n_parts = chunk >= 2 * piece ? std::min<size_t>((size_t)kReadThreads, chunk / piece) : 1;
+        std::vector<size_t> got(n_parts, 0);
+        auto part = [&](size_t i) {
+            const size_t a = chunk * i / n_parts, b = chunk * (i + 1) / n_parts;
+            size_t done = 0;
+            while (a + done < b) {
+                const ssize_t n = pread(fd, dst + a + done, b - a - done, (off_t)(fpos + a + done));
+                if (n < 0) { if (errno == EINTR) continue; die("read error on a block-gzip file: %s", strerror(errno)); }
+                if (n == 0) break;
+                done += (size_t)n;
+            }
+            got[i] = done;
+        };
+        if (n_parts > 1) {
+            if (!read_pool) read_pool.reset(new TaskPool(kReadThreads - 1));
+            read_pool->parallel_for(n_parts, part);
+        } else part(0);
+        size_t total = 0;
+        for (size_t i = 0; i < n_parts; ++i) {   // (a short part is the end of the file: nothing behind it was read)
+            const size_t want = chunk * (i + 1) / n_parts - chunk * i / n_parts;
+            total += got[i];
+            if (got[i] < want) break;
+        }
+        fpos += total;
+        return total;
+    }
 
     void run() {
         bool file_end = false;
-        size_t guess = 0;   // compressed bytes of the stretch before: the next one is read with one fread of about that size
+        size_t guess = 0;   // compressed bytes of the stretch before: the next one is read with one round of reads of about that size
         for (;;) {
             BgzfStretch s;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_free.wait(lk, [&] { return stop || full.size() < kDepth; });
+                cv_free.wait(lk, [&] { return stop || full.size() + walked.size() < kDepth + 1; });
                 if (stop) return;
                 if (!spare.empty()) { s = std::move(spare.front()); spare.pop_front(); }
             }
@@ -888,12 +928,12 @@ struct BgzfMemberReader::Impl {
             auto need = [&](size_t bytes) {   // make s.bytes[pos, pos + bytes) available if the file has them
                 while (s.bytes.n - pos < bytes && !file_end) {
                     size_t chunk = (size_t)8 << 20;
-                    if (guess > s.bytes.n + chunk) chunk = guess - s.bytes.n;   // the bulk of a stretch in one read
+                    if (guess > s.bytes.n + chunk) chunk = guess - s.bytes.n;   // the bulk of a stretch in one round of reads
                     if (s.bytes.n - pos + chunk < bytes) chunk = bytes;
                     s.bytes.reserve(s.bytes.n + chunk);
-                    const size_t n = fread(s.bytes.p + s.bytes.n, 1, chunk, raw);
+                    const size_t n = read_some(s.bytes.p + s.bytes.n, chunk);
                     s.bytes.n += n;
-                    if (n == 0) file_end = true;
+                    if (n < chunk) file_end = true;
                 }
                 return s.bytes.n - pos >= bytes;
             };
@@ -922,6 +962,27 @@ struct BgzfMemberReader::Impl {
             tail.assign(s.bytes.p + pos, s.bytes.p + s.bytes.n);
             s.bytes.n = pos;
             guess = pos;
+            const bool last = s.last;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                walked.push_back(std::move(s));
+                if (last) walked_last = true;
+            }
+            cv_walked.notify_one();
+            if (last) return;
+        }
+    }
+
+    void run_inflater() {
+        for (;;) {
+            BgzfStretch s;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_walked.wait(lk, [&] { return stop || !walked.empty(); });
+                if (stop) return;
+                s = std::move(walked.front());
+                walked.pop_front();
+            }
             // the host's share of the stretch: the LAST members' text (the device's members come first in the text)
             s.device_members = s.off.size();
             s.host_text_bytes = 0;
@@ -952,9 +1013,11 @@ BgzfMemberReader::BgzfMemberReader(const std::string &path, size_t text_target, 
     p_->text_target = text_target ? text_target : 1;
     p_->host_share = host_share < 0.0 ? 0.0 : host_share > 1.0 ? 1.0 : host_share;
     p_->host_threads = host_threads;
-    p_->raw = fopen(path.c_str(), "rb");
-    if (!p_->raw) die("file not found: %s", path.c_str());
+    p_->fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (p_->fd < 0) die("file not found: %s", path.c_str());
+    (void)posix_fadvise(p_->fd, 0, 0, POSIX_FADV_SEQUENTIAL);
     p_->worker = std::thread([this] { p_->run(); });
+    p_->inflater = std::thread([this] { p_->run_inflater(); });
 }
 BgzfMemberReader::~BgzfMemberReader() {
     {
@@ -962,8 +1025,10 @@ BgzfMemberReader::~BgzfMemberReader() {
         p_->stop = true;
     }
     p_->cv_free.notify_all();
+    p_->cv_walked.notify_all();
     if (p_->worker.joinable()) p_->worker.join();
-    if (p_->raw) fclose(p_->raw);
+    if (p_->inflater.joinable()) p_->inflater.join();
+    if (p_->fd >= 0) ::close(p_->fd);
     delete p_;
 }
 bool BgzfMemberReader::next(BgzfStretch &s) {
