@@ -87,7 +87,7 @@ hipError_t ctx_side_streams(cid_ctx *c, hipStream_t out[4]) {
         // long-lived waves are placed as soon as a classifier block retires instead of waiting their turn (CID_INFLATE_PRIORITY=0: equal)
         int prio_low = 0, prio_high = 0;
         if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_high = 0;
-        const bool want_prio = !(getenv("CID_INFLATE_PRIORITY") && atoi(getenv("CID_INFLATE_PRIORITY")) == 0);
+        const bool want_prio = c->tune.inflate_priority;
         hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int i = 0; i < 4 && e == hipSuccess; ++i)
             e = i < 2 ? hipStreamCreateWithPriority(&s[i], hipStreamNonBlocking, want_prio ? prio_high : 0) : hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking);
@@ -120,9 +120,8 @@ int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
     *out = c->slot[s];
     return CID_OK;
 }
-static const bool kUsePin = getenv("CID_PIN_STAGING") ? atoi(getenv("CID_PIN_STAGING")) != 0 : true;
 uint8_t *pin_reserve(cid_ctx *c, size_t bytes, size_t cap) {
-    if (!kUsePin || bytes > cap) return nullptr;
+    if (!c->tune.pin_staging || bytes > cap) return nullptr;
     if (c->inflate.open) return nullptr;   // the arena holds a started inflate batch's text and status: callers copy without it
     if (bytes <= c->pin_bytes) return c->pin;
     if (c->pin) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_bytes = 0; }
@@ -150,6 +149,36 @@ int cid_device_count(int *n) {
     return CID_OK;
 }
 
+// The library's one reader of environment variables (cid_switches.def lists them): every switch lands in the new context's cid_tunables.
+static void read_switches(cid_tunables &t) {
+#define CID_SWITCH_B(name, env) if (const char *e = getenv(env)) t.name = atoi(e) != 0;
+#define CID_SWITCH_I(name, env) if (const char *e = getenv(env)) t.name = atoi(e);
+#define CID_SWITCH_L(name, env) if (const char *e = getenv(env)) t.name = atol(e);
+#define CID_SWITCH_U(name, env) if (const char *e = getenv(env)) t.name = strtoull(e, nullptr, 10);
+#define CID_SWITCH_S(name, env)
+#define CID_SWITCH(name, env, kind, dflt, doc) CID_SWITCH_##kind(name, env)
+#include "cid_switches.def"
+#undef CID_SWITCH
+#undef CID_SWITCH_B
+#undef CID_SWITCH_I
+#undef CID_SWITCH_L
+#undef CID_SWITCH_U
+#undef CID_SWITCH_S
+    if (t.search_unroll != 1) t.search_unroll = 2;
+    if (t.readid_blocks_per_cu < 1 || t.readid_blocks_per_cu > 4096) t.readid_blocks_per_cu = 64;
+    if (t.order_bits < 0 || t.order_bits > 32) t.order_bits = 0;
+#ifndef CID_TUNE_BUILD
+    t.search_persist = t.search_mixed = false;   // (their kernels are only in libcolorid_hip_tune.so)
+#endif
+    if (const char *e = getenv("COLORID_REDUCE")) t.reduce_mode = !strcmp(e, "rccl") ? 1 : !strcmp(e, "host") ? 0 : -1;
+    if (const char *e = getenv("COLORID_STRIPE_REDUCE")) t.stripe_reduce_peer = !strcmp(e, "peer");
+    if (const char *sy = getenv("COLORID_SYNC")) {   // how host threads wait for the device (before the device's first use): spin | yield | block
+        const unsigned f = !strcmp(sy, "spin") ? hipDeviceScheduleSpin : !strcmp(sy, "yield") ? hipDeviceScheduleYield : !strcmp(sy, "block")
+            ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        (void)hipSetDeviceFlags(f);   // (refused once the device is active: the first context decides)
+    }
+}
+
 int cid_ctx_create(int device_id, cid_ctx **out) {
     if (!out) return fail(CID_ERR_INVALID, "null out");
     *out = nullptr;
@@ -158,22 +187,10 @@ int cid_ctx_create(int device_id, cid_ctx **out) {
     if (n <= 0) return fail(CID_ERR_HIP, "no HIP device (this library has no CPU path)");
     if (device_id < 0 || device_id >= n) return fail(CID_ERR_INVALID, "device %d of %d", device_id, n);
     HIP_TRY(hipSetDevice(device_id));
-    if (const char *sy = getenv("COLORID_SYNC")) {   // how host threads wait for the device (before the device's first use): spin | yield | block
-        const unsigned f = !strcmp(sy, "spin") ? hipDeviceScheduleSpin : !strcmp(sy, "yield") ? hipDeviceScheduleYield : !strcmp(sy, "block")
-            ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
-        (void)hipSetDeviceFlags(f);   // (refused once the device is active: the first context decides)
-    }
     cid_ctx *c = new (std::nothrow) cid_ctx();
     if (!c) return fail(CID_ERR_NOMEM, "ctx");
     c->device = device_id;
-    if (const char *e = getenv("CID_SEARCH_UNROLL")) c->tune.search_unroll = atoi(e) == 1 ? 1 : 2;
-    if (const char *e = getenv("CID_READID_PACKED_TABLE")) c->tune.readid_packed_table = atoi(e) != 0;
-    if (const char *e = getenv("CID_READID_LONG_LDS")) c->tune.readid_long_lds = atoi(e) != 0;
-    if (const char *e = getenv("CID_FASTQ_REFUSE_AT_STEP")) c->tune.fastq_refuse_at_step = atol(e);
-#ifdef CID_TUNE_BUILD
-    if (const char *e = getenv("CID_SEARCH_PERSIST")) c->tune.search_persist = atoi(e) != 0;
-    if (const char *e = getenv("CID_SEARCH_MIXED")) c->tune.search_mixed = atoi(e) != 0;
-#endif
+    read_switches(c->tune);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
     bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
@@ -271,6 +288,22 @@ int cid_ctx_tune(cid_ctx *c, const char *name, long value) {
                     "`make TUNE=1` build (libcolorid_hip_tune.so)", name);
 #endif
     }
+    // every other switch of cid_switches.def, by its name
+#define CID_SWITCH_B(nm) if (!strcmp(name, #nm)) { c->tune.nm = value != 0; return CID_OK; }
+#define CID_SWITCH_I(nm) if (!strcmp(name, #nm)) { c->tune.nm = (int)value; return CID_OK; }
+#define CID_SWITCH_L(nm) if (!strcmp(name, #nm)) { c->tune.nm = value; return CID_OK; }
+#define CID_SWITCH_U(nm) if (!strcmp(name, #nm)) { if (value < 0) return fail(CID_ERR_INVALID, "'%s' is not negative", name); c->tune.nm = (unsigned long long)value; return CID_OK; }
+#define CID_SWITCH_S(nm)
+#define CID_SWITCH(nm, env, kind, dflt, doc) CID_SWITCH_##kind(nm)
+#include "cid_switches.def"
+#undef CID_SWITCH
+#undef CID_SWITCH_B
+#undef CID_SWITCH_I
+#undef CID_SWITCH_L
+#undef CID_SWITCH_U
+#undef CID_SWITCH_S
+    if (!strcmp(name, "reduce_mode")) { c->tune.reduce_mode = value < 0 ? -1 : value ? 1 : 0; return CID_OK; }
+    if (!strcmp(name, "stripe_reduce_peer")) { c->tune.stripe_reduce_peer = value != 0; return CID_OK; }
     return fail(CID_ERR_INVALID, "unknown tunable '%s'", name);
 }
 

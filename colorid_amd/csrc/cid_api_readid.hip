@@ -73,7 +73,7 @@ static size_t readid_need(const cid_index *ix, uint32_t stride_d, uint32_t start
 
 constexpr size_t kLdsBytes = 160u * 1024u;
 // device scratch for dense read_id report rows per launch: cid_readid_count slices larger batches, the sparse form refuses them
-static size_t kDenseReportBytes = getenv("CID_DENSE_REPORT_BYTES") ? strtoull(getenv("CID_DENSE_REPORT_BYTES"), nullptr, 10) : (2ull << 30);
+// (cid_ctx_tune "dense_report_bytes" / CID_DENSE_REPORT_BYTES: 2 GiB)
 // k_readid keeps a read's set in one wave's LDS.  With fewer than six waves per CU its gathers are no longer hidden and the long-read
 // path (cid_readlong.hip) is faster: 150 Mbases resident, configs[2]'s index, ms per call k_readid / long path (tools/exp_readlen_route.py,
 // profiles/r06_readlen_route.jsonl): 300 bases 6.5 / 9.5, 600 bases 6.5 / 8.0, 800 bases (five waves) 8.7 / 7.7, 1000 bases (four waves)
@@ -525,7 +525,7 @@ int cid_readid_count(cid_ctx *c, const cid_index *ix, const uint8_t *bases, cons
     // A dense report row has n_colors+1 counters (4 GB per million reads at 1024 colours): the batch is worked through in
     // slices whose rows fit kDenseReportBytes of device scratch; a read's row does not depend on its neighbours.
     const size_t C1 = (size_t)ix->n_colors + 1;
-    size_t per = kDenseReportBytes / (C1 * 4);
+    size_t per = (size_t)c->tune.dense_report_bytes / (C1 * 4);
     if (per == 0) per = 1;
     std::vector<uint64_t> so, r0v;
     for (size_t r0 = 0; r0 < n_reads; r0 += per) {

@@ -14,7 +14,7 @@ using namespace cid::slots;
 namespace {
 
 // bytes per chunk of the pipelined host-pointer calls (H2D of chunk i+1 beside the kernel of chunk i)
-const size_t kUploadChunkBytes = getenv("CID_UPLOAD_CHUNK_BYTES") ? strtoull(getenv("CID_UPLOAD_CHUNK_BYTES"), nullptr, 10) : (256ull << 20);
+// (cid_ctx_tune "upload_chunk_bytes" / CID_UPLOAD_CHUNK_BYTES: 256 MiB of k-mers per upload chunk)
 
 int fill_search_params(const cid_ctx *c, const cid_index *ix, cid::SearchParams &p) {
     memset(&p, 0, sizeof(p));
@@ -182,7 +182,7 @@ int cid::search_count_host_input(cid_ctx *c, const cid_index *ix, const uint8_t 
     uint64_t *hits = &hits_dummy, *n_unique = want_unique ? &hits_dummy : nullptr, *sum_unique_freq = n_unique;
     HIP_TRY(hipSetDevice(c->device));
     const size_t C = ix->n_colors, k = ix->k;
-    size_t chunk = kUploadChunkBytes / (k + 8);
+    size_t chunk = (size_t)c->tune.upload_chunk_bytes / (k + 8);
     chunk = (chunk + 63) & ~(size_t)63;          // chunks start on a tile boundary: 64*k bytes keep the 16-byte alignment of the k-mer array
     if (chunk >= n_kmers || c->stream != c->own_stream) chunk = n_kmers ? n_kmers : 1;   // a borrowed stream: keep everything on it
     void *d_k, *d_f = nullptr, *d_out, *d_uc = nullptr;

@@ -337,7 +337,7 @@ int cid_fastq_create(cid_ctx *c, int n_files, uint32_t quality, cid_fastq **out)
     cid_fastq *fq = new (std::nothrow) cid_fastq();
     if (!fq) return fail(CID_ERR_NOMEM, "fastq");
     fq->ctx = c; fq->n_files = n_files; fq->quality = quality;
-    fq->timing = getenv("CID_FASTQ_TIMING") && atoi(getenv("CID_FASTQ_TIMING")) > 0;
+    fq->timing = c->tune.fastq_timing;
     hipStream_t side[4];
     if (cid::ctx_side_streams(c, side) != hipSuccess) {
         delete fq;

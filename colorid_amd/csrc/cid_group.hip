@@ -95,9 +95,9 @@ int cid_group_create(const int *device_ids, int n_devices, cid_group **out) {
         g->dev.push_back(device_ids[i]);
     }
     // RCCL when every rank has its own GPU (one rank too, if asked for: COLORID_REDUCE=rccl exercises the plumbing on one GPU)
-    const char *mode = getenv("COLORID_REDUCE");
-    const bool want = mode ? strcmp(mode, "rccl") == 0 : n_devices > 1;
-    if (want && mode && strcmp(mode, "rccl") == 0 && !distinct) {
+    const int mode = g->ctx[0]->tune.reduce_mode;   // COLORID_REDUCE, read when the ranks' contexts were made: -1 auto, 0 host, 1 rccl
+    const bool want = mode >= 0 ? mode == 1 : n_devices > 1;
+    if (want && mode == 1 && !distinct) {
         cid_group_destroy(g);
         return fail(CID_ERR_INVALID, "COLORID_REDUCE=rccl needs distinct devices");
     }

@@ -131,7 +131,7 @@ int and_by_allgather(cid_group *g, uint32_t *const *d_bufs, size_t count) {
 int reduce_u32(cid_group *g, uint32_t *const *d_bufs, size_t count, bool sum, bool everywhere) {
     const int n = (int)g->ctx.size();
     if (count == 0) return CID_OK;
-    static const bool force_peer = getenv("COLORID_STRIPE_REDUCE") && !strcmp(getenv("COLORID_STRIPE_REDUCE"), "peer");
+    const bool force_peer = g->ctx[0]->tune.stripe_reduce_peer;   // COLORID_STRIPE_REDUCE=peer
     if (g->use_rccl && !force_peer)   // (also with one rank: COLORID_REDUCE=rccl)
         return sum ? allreduce_sum(g, reinterpret_cast<void *const *>(d_bufs), count, 4) : and_by_allgather(g, d_bufs, count);
     if (n == 1) return CID_OK;

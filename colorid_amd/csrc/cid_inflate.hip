@@ -958,7 +958,7 @@ hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_
     // One member per WAVE first (k_bgzf_inflate_wave: 64 lanes on the chunks of a block); what it leaves — stored blocks, corrupt members, the
     // rare block whose chunks do not fall into step — goes to the one-lane kernel through the retry list.  CID_INFLATE_WAVE=0, or a caller
     // without scratch: the one-lane kernel for everything.
-    static const bool wave_env = getenv("CID_INFLATE_WAVE") ? atoi(getenv("CID_INFLATE_WAVE")) != 0 : true;
+    const bool wave_env = c->tune.inflate_wave;
     uint32_t *d_retry = nullptr;
     if (wave_env && d_scratch) {
         uint2 *d_tok = reinterpret_cast<uint2 *>(d_scratch);
@@ -978,7 +978,7 @@ hipError_t bgzf_inflate_launch(cid_ctx *c, hipStream_t stream, const uint8_t *d_
     // doubles what a full chip decodes per unit time, but each runs at 0.6 of the speed it has alone: a launch that leaves the chip mostly
     // idle anyway (<= 1 280 members = five waves per CU) takes one per wave (256 members: 4.5 against 7.9 ms, 1 024: 5.5 against 8.4,
     // the 4 794 of a million reads: 14.3 against 9.3 — tools/exp_inflate_lanes.sh)
-    static const int lanes_env = getenv("CID_INFLATE_LANES") ? atoi(getenv("CID_INFLATE_LANES")) : 0;
+    const int lanes_env = c->tune.inflate_lanes;
     const int lanes = lanes_env ? lanes_env : n_members <= 1280u ? 1 : kInflateLanes;
     const unsigned lpw = lanes == 1 ? 1u : lanes == 4 ? 4u : lanes == 8 ? 8u : 2u;
     unsigned grid = (unsigned)((n_members + lpw - 1) / lpw);

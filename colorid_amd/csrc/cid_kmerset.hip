@@ -14,6 +14,7 @@
 
 #include "../../include/colorid_hip.h"
 #include "cid_internal.hpp"
+#include "cid_objects.hpp"
 #include "cid_partition.hpp"
 #include "cid_rundedupe.hpp"
 #include "cid_scan.hpp"
@@ -112,18 +113,17 @@ struct KeepOut {
         if (keep) { codes_out[excl] = codes[i]; counts_out[excl] = counts[i]; }
     }
 };
-static const bool kMsdSort = getenv("CID_KMERSET_MSD_SORT") ? atoi(getenv("CID_KMERSET_MSD_SORT")) != 0 : true;
 // crowded runs (average comparisons per key in the bucket kernels beyond kCrowdedAt) go through k_run_dedupe_sort; CID_KMERSET_DEDUPE=0: straight
 // to the radix kernel, at round 4's threshold of 32
-static const bool kDedupeSort = getenv("CID_KMERSET_DEDUPE") ? atoi(getenv("CID_KMERSET_DEDUPE")) != 0 : true;
-static const uint32_t kCrowdedAt = getenv("CID_KMERSET_CROWDED_AT") ? (uint32_t)atoi(getenv("CID_KMERSET_CROWDED_AT")) : (kDedupeSort ? 8u : cid::kBucketWork);
 int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, unsigned top, uint64_t **sorted, size_t *n_real) {
     using namespace cid;
+    const cid_tunables &tn = c->tune;   // (the switches of this context: cid_switches.def)
+    const bool kMsdSort = tn.kmerset_msd_sort, kDedupeSort = tn.kmerset_dedupe;
+    const uint32_t kCrowdedAt = tn.kmerset_crowded_at >= 0 ? (uint32_t)tn.kmerset_crowded_at : (kDedupeSort ? 8u : cid::kBucketWork);
     // (CID_KMERSET_MSD_MIN: the tests send small inputs through the cold LSD sorts too.  Until round 4 batches below a million keys went
     // there by default — a dozen launches cost more than one rocPRIM sort — but the first rocPRIM call of a process loads a code object of
     // some thousand kernels, 0.2 s, which no small query earns back.)
-    const char *min_env = getenv("CID_KMERSET_MSD_MIN");
-    const size_t min_n = min_env ? strtoull(min_env, nullptr, 10) : 2;
+    const size_t min_n = (size_t)tn.kmerset_msd_min;
     if (!kMsdSort || top >= 64 || top < 12 || n < min_n || n < 2 || n >= (1ull << 32)) return CID_ERR_UNSUPPORTED;
     // the prefix the partition passes consume: enough bits for runs of 1300 .. 2600 keys (a workgroup sorts up to 4096 in 32 KiB of LDS)
     unsigned prefix = 1;
@@ -226,8 +226,10 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
 int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_a, uint32_t *keys_b, uint64_t *codes_b, size_t n, unsigned code_bits,
                   uint64_t **sorted, size_t *n_real) {
     using namespace cid;
-    const char *min_env = getenv("CID_KMERSET_MSD_MIN");
-    const size_t min_n = min_env ? strtoull(min_env, nullptr, 10) : 2;
+    const cid_tunables &tn = c->tune;   // (the switches of this context: cid_switches.def)
+    const bool kMsdSort = tn.kmerset_msd_sort, kDedupeSort = tn.kmerset_dedupe;
+    const uint32_t kCrowdedAt = tn.kmerset_crowded_at >= 0 ? (uint32_t)tn.kmerset_crowded_at : (kDedupeSort ? 8u : cid::kBucketWork);
+    const size_t min_n = (size_t)tn.kmerset_msd_min;
     if (!kMsdSort || n < min_n || n < 2 || n >= (1ull << 32)) return CID_ERR_UNSUPPORTED;
     unsigned prefix = 1;
     while (prefix < 24 && ((uint64_t)n >> prefix) > 1900) ++prefix;   // runs of ~950 .. 1900 pairs: k_run_bucket_sort_pair<8> takes up to 2048
@@ -395,8 +397,7 @@ int compact(cid_kmerset *ks) {
     if (n_runs == 0) return CID_OK;
     // the batch joins the set: two sorted lists merged in one pass, equal k-mers' multiplicities added (cid_merge.hpp; rocPRIM's merge +
     // reduce_by_key until round 5 — kmerset_merge_batch in cid_kmerset_cold.hip, kept as CID_KMERSET_COLD_MERGE=1 for A/B runs)
-    const bool cold_merge = getenv("CID_KMERSET_COLD_MERGE") && atoi(getenv("CID_KMERSET_COLD_MERGE")) != 0;
-    if (cold_merge) return cid::kmerset_merge_batch(ks, uniq.p, agg.p, n_runs);
+    if (ks->ctx->tune.kmerset_cold_merge) return cid::kmerset_merge_batch(ks, uniq.p, agg.p, n_runs);
     const size_t total = ks->n + n_runs;
     const uint32_t tiles = cid::merge_tiles(ks->n, n_runs);
     DevBuf<uint64_t> ok(ks->ctx), split(ks->ctx), mstate(ks->ctx);
@@ -498,7 +499,7 @@ int cid_kmerset_create(cid_ctx *c, uint32_t k_size, cid_kmerset **out) {
     HIP_TRY(hipSetDevice(cid::ctx_device(c)));
     if (hipMalloc(reinterpret_cast<void **>(&ks->d_flags), 16) != hipSuccess) { delete ks; return fail(CID_ERR_NOMEM, "flags"); }
     HIP_TRY(hipMemset(ks->d_flags, 0, 16));
-    if (const char *e = getenv("CID_KMERSET_COMPACT_WINDOWS")) ks->compact_at = strtoull(e, nullptr, 10);  // tests
+    if (c->tune.kmerset_compact_at) ks->compact_at = (size_t)c->tune.kmerset_compact_at;  // tests (CID_KMERSET_COMPACT_WINDOWS)
     *out = ks;
     return CID_OK;
 }
@@ -575,7 +576,7 @@ int cid_kmerset_add_seqs(cid_kmerset *ks, const uint8_t *bases, const uint64_t *
         hipStream_t cs = piped ? cid::ctx_copy_stream(c) : st;
         hipEvent_t ev_scan = cid::ctx_event(c, 0), ev_done = cid::ctx_event(c, 1);
         if (piped) { HIP_TRY(hipEventRecord(ev_scan, st)); HIP_TRY(hipStreamWaitEvent(cs, ev_scan, 0)); }   // (d_bases may still be read by an earlier kernel of the ctx stream)
-        static const uint64_t slice_bytes = (uint64_t)(getenv("CID_KMERSET_SLICE_MB") ? atoi(getenv("CID_KMERSET_SLICE_MB")) : 32) << 20;   // (experiments)
+        const uint64_t slice_bytes = (uint64_t)(c->tune.kmerset_slice_mb > 0 ? c->tune.kmerset_slice_mb : 32) << 20;   // (experiments: CID_KMERSET_SLICE_MB)
         // (A ring of pinned slots filled by 2-8 helper threads, the DMA engine taking a slot as soon as it is full, was tried in round 5: 4.6-4.9 ms
         // for the 150 MB of a million reads against 3.85 ms for these copies straight out of the caller's pageable memory — the host's memcpy
         // is the slower pipe; profiles/HISTORY.md.)
@@ -673,12 +674,12 @@ int cid_kmerset_set_target_index(cid_kmerset *ks, const cid_index *ix) {
     if (ks->finalized || ks->n_raw || ks->n || ks->g_n) return fail(CID_ERR_STATE, "cid_kmerset_set_target_index comes before the first sequences");
     if (cid::index_k(ix) != ks->k) return fail(CID_ERR_INVALID, "k-mer set k=%u, index k=%u", ks->k, cid::index_k(ix));
     if (ks->general) return CID_OK;   // byte-string sets keep their order (cid_kmerset_order_for_index groups them afterwards)
-    if (getenv("CID_KMERSET_TARGET") && atoi(getenv("CID_KMERSET_TARGET")) == 0) return CID_OK;   // A/B: the code-ordered set
+    if (!ks->ctx->tune.kmerset_target) return CID_OK;   // A/B: the code-ordered set (CID_KMERSET_TARGET=0)
     const cid::ModMagic mm = cid::index_mod(ix);
     if (mm.m >= 0xFFFFFFFFull) return CID_OK;     // the key needs bloom_size < 2^32 - 1 to stay below kNoKey: such a set keeps code order
     // a small index: the keys take only bloom_size values, the partition's runs collapse to a few crowded ones (one LSD sort each, cold path),
     // and an index of a megabyte sits in L2 whatever the order of the queries — such a set keeps code order too
-    if (mm.m < (1ull << 20) && !getenv("CID_KMERSET_TARGET_SMALL")) return CID_OK;
+    if (mm.m < (1ull << 20) && !ks->ctx->tune.kmerset_target_small) return CID_OK;
     ks->targeted = true;
     ks->key_for.mm = mm;
     ks->key_for.scale = 0xFFFFFFFF00000000ull / mm.m;

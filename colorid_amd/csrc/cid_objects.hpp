@@ -11,21 +11,25 @@ enum Slot { S_KMERS = 0, S_FREQ, S_OUT, S_UC, S_ROWIDS, S_WORDS, S_MISC, S_BASES
 }
 }  // namespace cid
 
-// Per-context tunables (cid_ctx_tune): measurement and test switches, read once from the environment when the ctx is made.
+// Per-context tunables (cid_ctx_tune): measurement and test switches, read ONCE from the environment when the ctx is made
+// (cid_api_ctx.hip: read_switches — the only place of the library that calls getenv).  The list, with what each does: cid_switches.def.
 // Defaults are the shipped configuration; none of them changes a result.
 struct cid_tunables {
-    int search_unroll = 2;            // k_search_count on 64- / 128-byte rows: sub-passes whose row loads are issued together (2: -1.5 %)
-    bool readid_packed_table = true;  // k_readid: 8-byte k-mer-set slots where they buy a sixth wave per SIMD (paired reads, k <= 31)
-    int readid_blocks_per_cu = 64;    // k_readid: a batch is cut into about this many workgroups per CU (each takes a stretch of reads)
-    int order_bits = 0;               // cid_kmerset_order_for_index: 0 = by the first row's 128-byte line, b = by its b leading bits
-    long fastq_refuse_at_step = -1;   // tests: cid_fastq_classify_begin refuses its n-th step (as it does a stretch it cannot take); -1 = never
-    long readid_long_from = -1;       // reads of at least this many bases take the long-read path (-1: the shipped rule, readid_route)
-    bool readid_long_deal = true;     // long reads of four buckets and more: their windows dealt to the buckets once (false: every bucket re-reads the read)
-    bool readid_long_lds = true;      // long reads: per-read sets by LDS hash tables (cid_readlong.hip); false = round 1's global radix sort
-    bool readid_long_fuse = true;     // long reads of one hash table: codes + table in one kernel (k_long_fused); false = k_extract_codes + k_long_first_flags
-    // the two measured-and-rejected schedulings of k_search_count; only a `make TUNE=1` build contains their kernels
-    bool search_persist = false;      // persistent grid, one work queue per XCD
-    bool search_mixed = false;        // 32-byte rows: each k-mer's last row through the scalar cache
+#define CID_SWITCH_B(name, dflt) bool name = dflt != 0;
+#define CID_SWITCH_I(name, dflt) int name = dflt;
+#define CID_SWITCH_L(name, dflt) long name = dflt;
+#define CID_SWITCH_U(name, dflt) unsigned long long name = dflt##ull;
+#define CID_SWITCH_S(name, dflt)
+#define CID_SWITCH(name, env, kind, dflt, doc) CID_SWITCH_##kind(name, dflt)
+#include "cid_switches.def"
+#undef CID_SWITCH
+#undef CID_SWITCH_B
+#undef CID_SWITCH_I
+#undef CID_SWITCH_L
+#undef CID_SWITCH_U
+#undef CID_SWITCH_S
+    int reduce_mode = -1;             // COLORID_REDUCE: -1 auto, 0 host, 1 rccl
+    bool stripe_reduce_peer = false;  // COLORID_STRIPE_REDUCE=peer
 };
 
 struct cid_ctx {

@@ -50,7 +50,7 @@ struct BufReader {  // big sequential reads; the file is parsed once, front to b
         memcpy(dst, buf.data() + pos, take);
         pos += take;
         size_t got = take;
-        static const int n_threads = [] { const char *e = getenv("COLORID_IO_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+        static const int n_threads = [] { const char *e = cli_env("COLORID_IO_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
         if (n - got >= (32u << 20) && n_threads > 1) {
             const off_t at = ftello(f);   // the FILE's logical position == the next byte this reader has not seen
             if (at >= 0) {
@@ -118,7 +118,7 @@ std::map<std::string, MappedIndex> g_mapped;
 }  // namespace
 
 void bigsi_read_ahead(const std::string &path) {
-    if (const char *e = getenv("COLORID_INDEX_MMAP")) if (atoi(e) == 0) return;
+    if (const char *e = cli_env("COLORID_INDEX_MMAP")) if (atoi(e) == 0) return;
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return;   // (the loader reports it)
     struct stat st;

@@ -4,8 +4,10 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <thread>
 #include <mutex>
 #include <functional>
@@ -60,6 +62,25 @@ int cpu_budget();
 // A few persistent worker threads.  The pipeline used to start threads per batch (inflating a batch's members, packing a chunk's
 // records, polling a batch's slices): a thread's start and end map and unmap its stack, and in a process whose other threads fault
 // pages all the time those calls queue on the address-space lock — two poll threads per batch were twice as SLOW as one.
+// The command line's environment switches (cli_switches.def lists them; README.md's table is generated from it): cli_env("NAME") returns
+// the variable's value as it was when the first switch was asked for — one snapshot of the listed names, whoever asks — or nullptr.
+inline const char *cli_env(const char *name) {
+    struct Snapshot {
+        std::vector<std::pair<std::string, std::string>> set;   // the listed variables that are set
+        std::vector<std::string> known;
+        Snapshot() {
+#define CLI_SWITCH(id, env, kind, dflt, doc) known.push_back(env); if (const char *e = getenv(env)) set.emplace_back(env, e);
+#include "cli_switches.def"
+#undef CLI_SWITCH
+        }
+    };
+    static const Snapshot snap;
+    for (const auto &kv : snap.set) if (kv.first == name) return kv.second.c_str();
+    for (const auto &k : snap.known) if (k == name) return nullptr;
+    fprintf(stderr, "cli_env: '%s' is not in cli_switches.def\n", name);
+    abort();
+}
+
 class TaskPool {
   public:
     explicit TaskPool(int n_threads) {

@@ -7,7 +7,7 @@
 
 namespace colorid {
 
-bool g_timing = getenv("COLORID_TIMING") != nullptr;
+bool g_timing = cli_env("COLORID_TIMING") != nullptr;
 
 // ---------------------------------------------------------------------------------------------- several GPUs
 cid_group *g_group = nullptr;
@@ -88,7 +88,7 @@ static void generate_report_gene(const std::string &query, const Bigsi &b, const
 //  the k-mer map is built and kept on the device (2-bit codes for k <= 32, byte strings beyond);
 // COLORID_HOST_KMERS=1 forces the host map.
 
-bool gpu_counting_enabled(uint64_t k) { return k <= 128 && !getenv("COLORID_HOST_KMERS"); }
+bool gpu_counting_enabled(uint64_t k) { return k <= 128 && !cli_env("COLORID_HOST_KMERS"); }
 static bool gpu_counting(const Bigsi &b) { return gpu_counting_enabled(b.k_size); }
 
 
@@ -259,7 +259,7 @@ struct GpuSet {
     }
     void destroy() { if (many) cid_group_kmerset_destroy(many); if (one) cid_kmerset_destroy(one); many = nullptr; one = nullptr; }
 };
-static bool count_over_group(uint64_t k) { return g_group && !g_striped && k <= 32 && !getenv("COLORID_ONE_GPU_KMERS"); }
+static bool count_over_group(uint64_t k) { return g_group && !g_striped && k <= 32 && !cli_env("COLORID_ONE_GPU_KMERS"); }
 
 static GpuSet count_fasta_set(cid_ctx *ctx, uint64_t k, const std::vector<std::string> &seqs, const cid_index *target) {
     GpuSet gs;

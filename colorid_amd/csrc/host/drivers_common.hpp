@@ -97,7 +97,7 @@ struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
 // pieces reach `sink` in input order.  The same reads in the same order as the line loops of read_id_mt_pe.rs:862-895 / :927-975
 // and kmer.rs:481-503 / :619-647: a record is pushed at its fourth line; for pairs the walk ends with the shorter file.
 // (default: a fifth of cpu_budget(), at most 4 — 3 on a 16-CPU share of a GPU box)
-const int g_parse_threads = [] { const char *e = getenv("COLORID_PARSE_THREADS"); const int v = e ? atoi(e) : std::min(4, cpu_budget() / 5); return v < 1 ? 1 : v; }();
+const int g_parse_threads = [] { const char *e = cli_env("COLORID_PARSE_THREADS"); const int v = e ? atoi(e) : std::min(4, cpu_budget() / 5); return v < 1 ? 1 : v; }();
 
 struct Line { const char *p; size_t n; };
 inline void record_lines(const RecChunk &c, size_t r, Line out[4]) {

@@ -167,7 +167,7 @@ void count_batch(cid_ctx *ctx, const Bigsi &b, Counted &c, size_t d, size_t star
 // batch are independent, so COLORID_POLL_THREADS (default 8) threads format contiguous slices of it and the slices are written in order
 // (default 2: the poll of a million reads is 50 ms on one thread, 30 ms on two — enough to stay ahead of the GPU stage)
 static int g_poll_threads = [] {
-    const char *e = getenv("COLORID_POLL_THREADS");
+    const char *e = cli_env("COLORID_POLL_THREADS");
     const int v = e ? atoi(e) : std::min(2, std::max(1, cpu_budget() / 8));
     return v < 1 ? 1 : v;
 }();
@@ -411,7 +411,7 @@ static void print_read_id_timing(const Clock::time_point &t0) {
 bool read_id_mt_pe::device_fastq_wanted(const std::vector<std::string> &fq, size_t n_files) {
     // default: on, for single-end input (16 M reads: 0.66-0.70 s against 1.05-1.11 s through the host front end on a 16-CPU share) and
     // for pairs (4 M pairs: 0.33-0.34 s against 0.36-0.38 s) — profiles/r03_frontend_16m.txt; COLORID_DEVICE_FASTQ=0 keeps the host's
-    const char *e = getenv("COLORID_DEVICE_FASTQ");
+    const char *e = cli_env("COLORID_DEVICE_FASTQ");
     if ((e && atoi(e) == 0) || g_group) return false;
     (void)n_files;
     for (size_t i = 0; i < n_files; ++i)
@@ -421,7 +421,7 @@ bool read_id_mt_pe::device_fastq_wanted(const std::vector<std::string> &fq, size
 // a stretch: ~256 MiB of text (800 000 reads of 150 bp: a DEFLATE stream decodes serially, so a launch takes ~14 ms however few members
 // it holds), fewer when the dense report rows of its reads would pass 8 GiB
 size_t read_id_mt_pe::device_fastq_stretch_bytes(size_t n_colors) {
-    size_t target = (size_t)(getenv("COLORID_DEVICE_FASTQ_MB") ? atoi(getenv("COLORID_DEVICE_FASTQ_MB")) : 256) << 20;
+    size_t target = (size_t)(cli_env("COLORID_DEVICE_FASTQ_MB") ? atoi(cli_env("COLORID_DEVICE_FASTQ_MB")) : 256) << 20;
     const size_t by_rows = ((size_t)8 << 30) / ((n_colors + 1) * 4) * 300;
     if (target > by_rows) target = by_rows < ((size_t)1 << 20) ? ((size_t)1 << 20) : by_rows;
     return target;
@@ -430,7 +430,7 @@ size_t read_id_mt_pe::device_fastq_stretch_bytes(size_t n_colors) {
 // host front end would spend on inflating and packing are idle: the reader's threads inflate this share of every stretch (the rest
 // goes up compressed).  Measured on a 16-CPU share (tools/exp_frontend.sh): see DESIGN.md.
 double read_id_mt_pe::device_fastq_host_share() {
-    if (const char *e = getenv("COLORID_DEVICE_FASTQ_HOST_SHARE")) { const double v = atof(e); return v < 0.0 ? 0.0 : v > 1.0 ? 1.0 : v; }
+    if (const char *e = cli_env("COLORID_DEVICE_FASTQ_HOST_SHARE")) { const double v = atof(e); return v < 0.0 ? 0.0 : v > 1.0 ? 1.0 : v; }
     // a host thread inflates ~0.7 GB/s of text, the device ~10 GB/s beside the classification it also runs: with the eight threads a
     // 16-CPU share leaves, an even split keeps both sides busy (16 M reads, tools/exp_frontend_16m.sh: 0.71-0.73 s at share 0.5, 0.84-0.90 s
     // with the host inflating everything, 0.89-0.96 s with the device inflating everything; host front end 1.02-1.21 s)
@@ -442,7 +442,7 @@ double read_id_mt_pe::device_fastq_host_share() {
 int read_id_mt_pe::device_fastq_host_threads(size_t n_files) {
     // the process's CPU share (cgroup quota) minus the threads that are busy anyway — four polling, the readers, the GPU stage, the
     // writer: a process whose runnable threads exceed its quota is throttled as a whole, GPU stage included
-    const char *e = getenv("COLORID_GZ_THREADS");
+    const char *e = cli_env("COLORID_GZ_THREADS");
     const int v = e ? atoi(e) : std::max(1, (cpu_budget() - 8) / (int)(n_files ? n_files : 1));
     return v < 1 ? 1 : v > 12 ? 12 : v;
 }
@@ -465,7 +465,7 @@ FrontEnd classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &f
         rd[i] = BgzfMemberReader::open(fq[i], target, read_id_mt_pe::device_fastq_host_share(), read_id_mt_pe::device_fastq_host_threads(n_files));
     // stretches pushed ahead of the one being classified: their inflate launches (alternating streams in the library) overlap, which
     // matters because a launch cannot be shorter than the decoding of one member (~14 ms) however few members it holds
-    const size_t ahead = [] { const char *e = getenv("COLORID_DEVICE_FASTQ_AHEAD"); const long v = e ? atol(e) : 1; return (size_t)(v < 1 ? 1 : v > 6 ? 6 : v); }();
+    const size_t ahead = [] { const char *e = cli_env("COLORID_DEVICE_FASTQ_AHEAD"); const long v = e ? atol(e) : 1; return (size_t)(v < 1 ? 1 : v > 6 ? 6 : v); }();
     std::vector<BgzfStretch> st[2];   // per file ahead + 1 stretches in turn: the one pushed last stays untouched while its text is still on the bus
     st[0].resize(ahead + 1); st[1].resize(ahead + 1);
     size_t turn[2] = {0, 0};
@@ -583,7 +583,7 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 1);
-    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));   // no packing threads beside them: a stretch's poll on 4 threads takes 18 ms, the GPU side 13
+    if (on_device && !cli_env("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));   // no packing threads beside them: a stretch's poll on 4 threads takes 18 ms, the GPU side 13
     auto make_classifier = [&] { return std::unique_ptr<BatchClassifier>(new BatchClassifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r")); };
     std::unique_ptr<BatchClassifier> classifier = make_classifier();
     if (g_timing) fprintf(stderr, "timing: %.0f ms of set-up before the first read\n", ms_since(t0));
@@ -617,7 +617,7 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 2);
-    if (on_device && !getenv("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));
+    if (on_device && !cli_env("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));
     auto make_classifier = [&] { return std::unique_ptr<BatchClassifier>(new BatchClassifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r")); };
     std::unique_ptr<BatchClassifier> classifier = make_classifier();
     FrontEnd fe = on_device ? classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, *classifier) : kFrontEndNotMine;

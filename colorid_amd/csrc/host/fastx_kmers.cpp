@@ -125,7 +125,7 @@ struct LibDeflate {
     uint32_t (*crc32)(uint32_t, const void *, size_t) = nullptr;
     bool ok = false;
     LibDeflate() {
-        const char *e = getenv("COLORID_LIBDEFLATE");
+        const char *e = cli_env("COLORID_LIBDEFLATE");
         if (e && atoi(e) == 0) return;
         void *lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!lib) return;
@@ -268,7 +268,7 @@ struct LineReader::Impl {
         std::vector<char> blk;
         size_t got = 0;
         bool have_blk = false, first = true;
-        const bool use_fast = !(getenv("COLORID_FAST_INFLATE") && atoi(getenv("COLORID_FAST_INFLATE")) == 0);   // 0: zlib's inflate
+        const bool use_fast = !(cli_env("COLORID_FAST_INFLATE") && atoi(cli_env("COLORID_FAST_INFLATE")) == 0);   // 0: zlib's inflate
         FastInflate fz;
         // COLORID_PAR_GZIP=0: one thread decodes a gzip stream (FastInflate) as before
         // threads: COLORID_GZ_THREADS, else as many as the process has CPUs (at most 16), shared between the gzip streams open at once (the
@@ -276,8 +276,8 @@ struct LineReader::Impl {
         // 4 M reads with forty quality letters, 0.64-0.67 s on 8 threads, 0.50-0.57 s on 12, 0.46-0.48 s on 16 (serial 1.8-1.9 s, zlib
         // 2.8-2.95 s); 4 M pairs 0.67-0.68 s on 8 + 8, 1.18-1.30 s on 4 + 4
         struct Alive { ~Alive() { --g_gzip_streams; } } alive;   // (counted in at open_stream)
-        int par_threads = getenv("COLORID_GZ_THREADS") ? gz_threads : std::min(16, std::max(gz_threads, cpu_budget()));
-        bool par_on = use_fast && par_threads >= 3 && !(getenv("COLORID_PAR_GZIP") && atoi(getenv("COLORID_PAR_GZIP")) == 0);
+        int par_threads = cli_env("COLORID_GZ_THREADS") ? gz_threads : std::min(16, std::max(gz_threads, cpu_budget()));
+        bool par_on = use_fast && par_threads >= 3 && !(cli_env("COLORID_PAR_GZIP") && atoi(cli_env("COLORID_PAR_GZIP")) == 0);
         int par_small = 0;
         std::unique_ptr<TaskPool> par_pool;
         std::vector<char> hist(32768);
@@ -367,12 +367,12 @@ struct LineReader::Impl {
                 // the member's DEFLATE stream on gz_threads threads (par_gunzip.hpp: chunks that find a block boundary of their own and decode
                 // from it with the text before them unknown, put right in order afterwards).  The text's CRC-32 stays with the CRC thread.
                 if (!par_pool) {   // (the first member's body: both readers of a pair exist by now)
-                    if (!getenv("COLORID_GZ_THREADS")) par_threads = std::max(3, par_threads / std::max(1, g_gzip_streams.load()));
+                    if (!cli_env("COLORID_GZ_THREADS")) par_threads = std::max(3, par_threads / std::max(1, g_gzip_streams.load()));
                     par_pool.reset(new TaskPool(par_threads - 1));
                 }
                 // (COLORID_GZ_CHUNK_KB / COLORID_GZ_CHUNKS_PER_THREAD: the experiment's knobs)
-                const size_t chunk_kb = getenv("COLORID_GZ_CHUNK_KB") ? (size_t)atol(getenv("COLORID_GZ_CHUNK_KB")) : 1024;
-                const size_t per_thread = getenv("COLORID_GZ_CHUNKS_PER_THREAD") ? (size_t)atol(getenv("COLORID_GZ_CHUNKS_PER_THREAD")) : 2;
+                const size_t chunk_kb = cli_env("COLORID_GZ_CHUNK_KB") ? (size_t)atol(cli_env("COLORID_GZ_CHUNK_KB")) : 1024;
+                const size_t per_thread = cli_env("COLORID_GZ_CHUNKS_PER_THREAD") ? (size_t)atol(cli_env("COLORID_GZ_CHUNKS_PER_THREAD")) : 2;
                 ParallelInflate pi(chunk_kb << 10, (size_t)par_threads * (per_thread ? per_thread : 1));
                 bool stopped = false;
                 auto reader = [&](uint8_t *dst, size_t cap) -> size_t { return fread(dst, 1, cap, raw); };
@@ -400,7 +400,7 @@ struct LineReader::Impl {
                 const bool ok = pi.run(in.buf.data() + in.pos, in.avail(), reader, sink, pfor, no_crc, no_comb);
                 if (stopped) { inflateEnd(&zs); return; }
                 if (!ok) die("corrupt gzip member (inflate failed: %s)", pi.error());
-                if (getenv("COLORID_TIMING"))
+                if (cli_env("COLORID_TIMING"))
                     fprintf(stderr, "timing: gzip member of %llu bytes of text decoded on %d threads: %llu chunks in %llu rounds, %llu started inside the stream and were taken, "
                             "%llu stretches decoded again serially\n", (unsigned long long)pi.total(), par_threads, (unsigned long long)pi.stats.chunks,
                             (unsigned long long)pi.stats.rounds, (unsigned long long)pi.stats.accepted, (unsigned long long)pi.stats.serial);
@@ -510,7 +510,7 @@ struct LineReader::Impl {
             gpu_ctx = gpu_ctx2 = nullptr;
         }
         if (gpu_ctx) (void)cid_warmup(gpu_ctx, CID_WARM_INFLATE);
-        const size_t kBatchOut = gpu_ctx ? ((size_t)(getenv("COLORID_GPU_INFLATE_MB") ? atoi(getenv("COLORID_GPU_INFLATE_MB")) : 64) << 20) : (16u << 20);
+        const size_t kBatchOut = gpu_ctx ? ((size_t)(cli_env("COLORID_GPU_INFLATE_MB") ? atoi(cli_env("COLORID_GPU_INFLATE_MB")) : 64) << 20) : (16u << 20);
         std::deque<Pending> pending;
         size_t turn = 0;
         std::vector<unsigned char> in;        // compressed bytes of the batch (plus the unread tail of the last fread)
@@ -632,7 +632,7 @@ struct LineReader::Impl {
     }
 };
 
-static int g_inflate_device = [] { const char *e = getenv("COLORID_GPU_INFLATE"); return e && atoi(e) > 0 ? 0 : -1; }();
+static int g_inflate_device = [] { const char *e = cli_env("COLORID_GPU_INFLATE"); return e && atoi(e) > 0 ? 0 : -1; }();
 void LineReader::inflate_on_gpu(int device) { g_inflate_device = device; }
 
 static std::mutex g_prefetch_mu;
@@ -640,7 +640,7 @@ static std::vector<std::pair<std::string, LineReader::Impl *>> g_prefetched;
 
 static LineReader::Impl *open_stream(const std::string &path, bool ahead) {
     LineReader::Impl *p = new LineReader::Impl;
-    const char *gt = getenv("COLORID_GZ_THREADS");
+    const char *gt = cli_env("COLORID_GZ_THREADS");
     if (gt) p->gz_threads = atoi(gt);
     if (p->gz_threads < 1) p->gz_threads = 1;
     if (LineReader::Impl::is_bgzf(path)) {   // (one thread too: whole members through libdeflate beat a zlib stream)
@@ -779,7 +779,7 @@ __attribute__((target("avx2"))) static uint64_t scan_records_avx2(const char *ba
 #endif
 static uint64_t scan_records(const char *base, const char *p, const char *end, uint64_t lines, std::vector<uint32_t> &rec_end) {
 #if defined(__x86_64__)
-    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("COLORID_NO_AVX2");
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !cli_env("COLORID_NO_AVX2");
     if (avx2) return scan_records_avx2(base, p, end, lines, rec_end);
 #endif
     while (p < end) {

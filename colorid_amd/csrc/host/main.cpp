@@ -29,7 +29,7 @@ namespace {
 const char *g_exit_reason = "nothing in the process writes at exit";
 bool tool_may_write_at_exit() {
     for (const char *v : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR", "HSA_TOOLS_LIB", "LLVM_PROFILE_FILE", "GCOV_PREFIX"})
-        if (const char *e = getenv(v)) if (*e) { g_exit_reason = v; return true; }
+        if (const char *e = getenv(v)) if (*e) { g_exit_reason = v; return true; }   // (not a switch: other tools' variables that announce something writing at exit)
     if (FILE *f = fopen("/etc/ld.so.preload", "r")) {
         int ch;
         bool any = false;
@@ -40,8 +40,8 @@ bool tool_may_write_at_exit() {
     return false;
 }
 bool decide_orderly_exit() {
-    if (const char *e = getenv("COLORID_FAST_EXIT")) { g_exit_reason = "COLORID_FAST_EXIT"; return atoi(e) == 0; }
-    if (getenv("COLORID_FULL_TEARDOWN")) { g_exit_reason = "COLORID_FULL_TEARDOWN"; return true; }
+    if (const char *e = cli_env("COLORID_FAST_EXIT")) { g_exit_reason = "COLORID_FAST_EXIT"; return atoi(e) == 0; }
+    if (cli_env("COLORID_FULL_TEARDOWN")) { g_exit_reason = "COLORID_FULL_TEARDOWN"; return true; }
     return tool_may_write_at_exit();
 }
 bool g_orderly_exit = decide_orderly_exit();
@@ -130,7 +130,7 @@ std::vector<int> device_list(const Args &a) {
 }
 
 // COLORID_TIMING=1: wall-clock milliseconds of the CLI's phases on stderr
-const bool g_timing = getenv("COLORID_TIMING") != nullptr;
+const bool g_timing = cli_env("COLORID_TIMING") != nullptr;
 const auto g_t_start = std::chrono::steady_clock::now();
 void phase_done(const char *what) {
     if (!g_timing) return;
@@ -171,7 +171,7 @@ Gpus make_gpus(const Args &a) {
         if (pl == "striped") g.striped = true;
         else if (pl != "replicated") die("--placement expects replicated or striped, got '%s'", pl.c_str());
     }
-    const bool one_rank_group = ids.size() == 1 && (getenv("COLORID_REDUCE") || g.striped);   // the group path with a single rank
+    const bool one_rank_group = ids.size() == 1 && (cli_env("COLORID_REDUCE") || g.striped);   // the group path with a single rank
     if (ids.size() <= 1 && !one_rank_group) {
         if (g.striped) die("--placement striped needs --gpus N or --devices a,b,...");
         const int dev = ids.empty() ? num_or<int>(a, "device", 0) : ids[0];
@@ -254,7 +254,7 @@ Bigsi load_index(cid_ctx *ctx, const Args &a, bool meta_only = false, Gpus *gpus
     fprintf(stderr, "Loading index\n");
     // The file format carries no hash id and the reference's hash crate (xxh3 ^0.1.1) cannot be run here: an index written by
     // this program matches its own --hash; for one written by the Rust binary, `colorid hashcheck` decides which --hash applies.
-    if (!meta_only && !a.has("hash") && !getenv("COLORID_QUIET"))
+    if (!meta_only && !a.has("hash") && !cli_env("COLORID_QUIET"))
         fprintf(stderr, "note: --hash defaults to xxh3_v08 (published XXH3); parity with an index built by the Rust colorid is unverified — "
                         "run `colorid hashcheck -b <index> -r <ref_file>` once to find the variant it was built with\n");
     const bool striped = gpus && gpus->striped;
@@ -320,15 +320,15 @@ int cmd_search(int argc, char **argv) {
         fprintf(stderr, "Error: An index with minimizers (.mxi) is used, but not available for this function\n");
         return 0;
     }
-    if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
+    if (cli_env("COLORID_GPU_INFLATE") && atoi(cli_env("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
     // gzip decoding of the first query starts now and runs beside GPU start-up and the index load; a block-gzip query on one GPU goes
     // up compressed instead (cid_fastq_count_kmers: its members are read ahead, the k-mer map is counted from text that never leaves HBM)
     unsigned warm_what = CID_WARM_SEARCH;
     if (!a.flags.count("perfect_search") && ends_with(files1[0], "gz")) {
         std::vector<std::string> fq{files1[0]};
         if (!files2.empty()) fq.push_back(files2[0]);
-        const bool one_gpu = !a.has("gpus") && !a.has("devices") && !a.has("placement") && !getenv("COLORID_REDUCE");
-        const bool host_kmers = getenv("COLORID_HOST_KMERS") != nullptr;
+        const bool one_gpu = !a.has("gpus") && !a.has("devices") && !a.has("placement") && !cli_env("COLORID_REDUCE");
+        const bool host_kmers = cli_env("COLORID_HOST_KMERS") != nullptr;
         if (one_gpu && !host_kmers && read_id_mt_pe::device_fastq_wanted(fq, fq.size())) {
             warm_what |= CID_WARM_INFLATE | CID_WARM_FASTQ;
             for (const std::string &f : fq)
@@ -395,7 +395,7 @@ ClassifyFlags classify_flags(const Args &a) {
     return f;
 }
 
-bool one_gpu_run(const Args &a) { return !a.has("gpus") && !a.has("devices") && !a.has("placement") && !getenv("COLORID_REDUCE"); }
+bool one_gpu_run(const Args &a) { return !a.has("gpus") && !a.has("devices") && !a.has("placement") && !cli_env("COLORID_REDUCE"); }
 
 // block-gzip input on one GPU goes up compressed and is inflated there (cid_fastq_*)
 bool wants_device_front_end(const Args &a, const std::vector<std::string> &fq) {
@@ -440,7 +440,7 @@ int cmd_read_id(int argc, char **argv) {
     const std::vector<std::string> fq = a.values.at("query");
     const ClassifyFlags flags = classify_flags(a);
     const std::string prefix = a.one("prefix");
-    if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
+    if (cli_env("COLORID_GPU_INFLATE") && atoi(cli_env("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
     const bool device_front_end = wants_device_front_end(a, fq);
     read_ahead(fq, device_front_end);
     Gpus gpus = make_gpus(a);
@@ -475,7 +475,7 @@ int cmd_batch_id(int argc, char **argv) {
     const std::string tag = a.one("tag");
     const auto sheet = tab_to_map(a.one("query"));
     std::vector<std::pair<std::string, std::vector<std::string>>> samples(sheet.begin(), sheet.end());
-    if (getenv("COLORID_GPU_INFLATE") && atoi(getenv("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
+    if (cli_env("COLORID_GPU_INFLATE") && atoi(cli_env("COLORID_GPU_INFLATE")) > 0) LineReader::inflate_on_gpu(num_or<int>(a, "device", 0));
     std::vector<char> on_device(samples.size(), 0);
     bool any_on_device = false;
     for (size_t i = 0; i < samples.size(); ++i) any_on_device |= (on_device[i] = wants_device_front_end(a, samples[i].second));

@@ -33,6 +33,12 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
+/* CORE and EXTENDED (round 6).  The declarations marked CID_CORE are the stable core of this ABI: SURVEY.md §8b's calls — context, index,
+ * the three search calls on k-mers and on k-mer sets, per-read counts — plus what the one-GPU command line runs on (INTEGRATION.md §2-§5:
+ * the k-mer set, the FASTQ front end, .bxi records).  Everything else is EXTENDED: device-pointer forms for callers that keep their data in
+ * HBM, colour stripes, groups of GPUs, measurement helpers.  The core changes only with cid_abi_version(); extended entry points may gain
+ * arguments between rounds.  include/colorid_hip.rs carries the same split as two modules. */
+#define CID_CORE
 #define CID_OK 0
 #define CID_ERR_INVALID (-1)     /* bad argument */
 #define CID_ERR_HIP (-2)         /* HIP runtime error / no device */
@@ -57,67 +63,67 @@ extern "C" {
 typedef struct cid_ctx cid_ctx;     /* one HIP device + stream + scratch */
 typedef struct cid_index cid_index; /* device-resident dense bit matrix: bloom_size rows x n_colors bits */
 
-const char *cid_last_error(void);
-int cid_abi_version(void);   /* 4 (round 5: + cid_readid_count_resident; 3: per-context cid_ctx_tune) */
+CID_CORE const char *cid_last_error(void);
+CID_CORE int cid_abi_version(void);   /* 4 (round 5: + cid_readid_count_resident; 3: per-context cid_ctx_tune) */
 int cid_device_count(int *n_devices);
 
 /* ---- context ---- */
-int cid_ctx_create(int device_id, cid_ctx **out);
+CID_CORE int cid_ctx_create(int device_id, cid_ctx **out);
 /* Page-locked host memory for buffers a host hands to the library over and over (batches of reads, a reader's text): copies from it
  * run at the bus rate; pageable memory is pinned and unpinned by the runtime around every copy.  Needs no ctx. */
-int cid_pinned_alloc(size_t bytes, void **out);
-void cid_pinned_free(void *p);
+CID_CORE int cid_pinned_alloc(size_t bytes, void **out);
+CID_CORE void cid_pinned_free(void *p);
 /* Borrow an existing hipStream_t (e.g. the caller's framework stream); NULL restores the ctx's own stream. */
 int cid_ctx_set_stream(cid_ctx *, void *hip_stream);
 int cid_ctx_synchronize(cid_ctx *);
-void cid_ctx_destroy(cid_ctx *);
+CID_CORE void cid_ctx_destroy(cid_ctx *);
 
 /* ---- index: replaces BigsyMapNew.map (src/bigsi.rs:19-27) as handed to the search functions
  *      (src/main.rs:600-625, :810-865).  Rows follow BitVec<u32> (bit-vec_serde/src/lib.rs:218-224,
  *      :465-474): bit c of a row = colour c = words[c/32] >> (c%32) & 1. ---- */
-int cid_index_create(cid_ctx *, uint64_t bloom_size, uint32_t num_hash, uint32_t k_size, uint32_t n_colors,
+CID_CORE int cid_index_create(cid_ctx *, uint64_t bloom_size, uint32_t num_hash, uint32_t k_size, uint32_t n_colors,
                      int hash_variant, cid_index **out);
 /* Minimizer index (BigsyMapMiniNew, src/bigsi.rs:40-49, the `.mxi` file): the Bloom key of a k-mer is
  * find_minimizer(kmer, m_size) (src/kmer.rs:971-986) instead of the k-mer.  Call once after create.  Affects
  * cid_index_insert_kmers* (src/build.rs:455-459) and cid_readid_count* (src/kmer.rs:363-394); the search entry points
  * refuse such an index, as the reference does (src/main.rs:569-573). */
-int cid_index_set_minimizer(cid_index *, uint32_t m_size);
+CID_CORE int cid_index_set_minimizer(cid_index *, uint32_t m_size);
 /* Re-interpret the same rows under another hash variant (the file carries no hash id; rows are rows).  Changes which rows
  * every later insert / search on this index computes; call it only while no call on the index is in flight. */
-int cid_index_set_hash_variant(cid_index *, int hash_variant);
+CID_CORE int cid_index_set_hash_variant(cid_index *, int hash_variant);
 /* Sparse rows as the .bxi `map` stores them (src/bigsi.rs:59-63): n_rows x W32 little-endian
  * u32 words, W32 = ceil(n_colors/32).  Rows never put stay all-zero == key absent from the map. */
-int cid_index_put_rows(cid_index *, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows);
+CID_CORE int cid_index_put_rows(cid_index *, const uint64_t *row_ids, const uint32_t *words_le, size_t n_rows);
 /* The same rows as they sit in a .bxi/.mxi file: n_records consecutive bincode records
  * { u64 row ; u64 n_words ; n_words x u32 ; u64 n_bits }, 24 + 4*W32 bytes each.  The records are parsed
  * and checked on the device (n_words == W32, n_bits == n_colors, row < bloom_size, no bit beyond n_colors), so a loader
  * only has to read the file: CID_ERR_INVALID for a malformed record (the reference: "can't deserialize" panic, bigsi.rs:61). */
-int cid_index_put_records(cid_index *, const uint8_t *records, size_t n_records);
+CID_CORE int cid_index_put_records(cid_index *, const uint8_t *records, size_t n_records);
 /* Native device layout: row r at matrix + r*row_stride_words (u64 words, little-endian pairs of the u32 words,
  * zero padded).  Exposed so a caller can generate/fill an index in HBM directly (bits >= n_colors MUST be 0). */
 int cid_index_device_matrix(cid_index *, void **dev_ptr, uint64_t *row_stride_words);
-int cid_index_finalize(cid_index *);
+CID_CORE int cid_index_finalize(cid_index *);
 /* Read rows back (host): words_le receives n_rows x W32 u32 words. */
 int cid_index_get_rows(const cid_index *, const uint64_t *row_ids, uint32_t *words_le, size_t n_rows);
 /* save_bigsi (src/bigsi.rs:51-57): the non-zero rows of [row_begin, row_begin + n_rows) in ascending order as the file's row
  * records (see cid_index_put_records), formatted on the device.  `records` must hold n_rows * (24 + 4*W32) bytes;
  * *n_records = how many were written (all-zero rows are not keys of the map, src/build.rs:123-127).  n_rows < 2^32. */
-int cid_index_get_records(const cid_index *, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records);
+CID_CORE int cid_index_get_records(const cid_index *, uint64_t row_begin, uint64_t n_rows, uint8_t *records, uint64_t *n_records);
 /* Bloom insert on device: simple_bloom.rs:19-26 for colour `colour` of every k-mer (used to build/plant
  * indices without leaving HBM; src/build.rs:116-128 transposed on the fly).  Before finalize only. */
 int cid_index_insert_kmers_dev(cid_index *, const uint8_t *d_kmers, const uint32_t *d_colour_of_kmer,
                                size_t n_kmers);
 /* Host-buffer form: every k-mer goes into one colour — one accession's BloomFilter::insert loop
  * (src/build.rs:62-66, :93-97). */
-int cid_index_insert_kmers(cid_index *, const uint8_t *kmers, uint32_t colour, size_t n_kmers);
-void cid_index_destroy(cid_index *);
+CID_CORE int cid_index_insert_kmers(cid_index *, const uint8_t *kmers, uint32_t colour, size_t n_kmers);
+CID_CORE void cid_index_destroy(cid_index *);
 
 /* ---- a5: proportional search, the hot loop of batch_search_pe::batch_search
  *      (src/batch_search_pe.rs:45-84 and :125-164).  For each distinct k-mer: n hashes -> n rows -> AND;
  *      hits[c] += 1 for every set colour c; if exactly one colour is set: n_unique[c] += 1,
  *      sum_unique_freq[c] += freq[kmer] (1 if freq == NULL), unique_colour[kmer] = c (else CID_NOT_UNIQUE).
  *      n_unique / sum_unique_freq / unique_colour may be NULL. ---- */
-int cid_search_count(cid_ctx *, const cid_index *, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
+CID_CORE int cid_search_count(cid_ctx *, const cid_index *, const uint8_t *kmers, const uint32_t *freq, size_t n_kmers,
                      uint64_t *hits, uint64_t *n_unique, uint64_t *sum_unique_freq, uint32_t *unique_colour);
 int cid_search_count_dev(cid_ctx *, const cid_index *, const uint8_t *d_kmers, const uint32_t *d_freq,
                          size_t n_kmers, uint64_t *d_hits, uint64_t *d_n_unique, uint64_t *d_sum_unique_freq,
@@ -196,8 +202,8 @@ int cid_readid_stripe_count(cid_ctx *, const cid_index *, const uint8_t *d_bases
  *      (one stable radix pass per 16 bases) and run-length counted; the finished set is n x k_size ASCII bytes.  Such a set
  *      serves every call below (the cid_group_*_set calls included) except cid_kmerset_device_arrays / _order_for_index. ---- */
 typedef struct cid_kmerset cid_kmerset;
-int cid_kmerset_create(cid_ctx *, uint32_t k_size, cid_kmerset **out);
-int cid_kmerset_add_seqs(cid_kmerset *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode);
+CID_CORE int cid_kmerset_create(cid_ctx *, uint32_t k_size, cid_kmerset **out);
+CID_CORE int cid_kmerset_add_seqs(cid_kmerset *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs, int mode);
 /* the same for reads already in HBM (k_size <= 32): d_seq_off[n_seqs + 1] are offsets into d_bases, no sequence longer than max_len
  * (<= one segment of windows: reads, not genomes — CID_ERR_UNSUPPORTED otherwise) */
 int cid_kmerset_add_seqs_dev(cid_kmerset *, const uint8_t *d_bases, const uint64_t *d_seq_off, size_t n_seqs, uint64_t max_len, int mode);
@@ -208,11 +214,11 @@ int cid_kmerset_add_seqs_dev(cid_kmerset *, const uint8_t *d_bases, const uint64
  * matrix (a fifth fewer line fetches at n = 4, 32-byte rows) and the ordering costs no pass of its own — only 4 more bytes per window
  * through the sort.  Contents, multiplicities and every result are unchanged (the reference iterates a hash map: order is
  * unspecified there).  No-op for byte-string sets (k_size > 32) and for bloom_size >= 2^32 - 1. */
-int cid_kmerset_set_target_index(cid_kmerset *, const cid_index *);
-int cid_kmerset_finalize(cid_kmerset *, uint64_t *n_distinct);
-int cid_kmerset_size(const cid_kmerset *, uint64_t *n_distinct);
-int cid_kmerset_count_histogram(const cid_kmerset *, uint32_t *multiplicity, uint64_t *n_kmers, size_t cap, size_t *n_bins);
-int cid_kmerset_clean(cid_kmerset *, uint64_t t);
+CID_CORE int cid_kmerset_set_target_index(cid_kmerset *, const cid_index *);
+CID_CORE int cid_kmerset_finalize(cid_kmerset *, uint64_t *n_distinct);
+CID_CORE int cid_kmerset_size(const cid_kmerset *, uint64_t *n_distinct);
+CID_CORE int cid_kmerset_count_histogram(const cid_kmerset *, uint32_t *multiplicity, uint64_t *n_kmers, size_t cap, size_t *n_bins);
+CID_CORE int cid_kmerset_clean(cid_kmerset *, uint64_t t);
 /* Optional: reorder the set by the 128-byte index line of each k-mer's first row (seed 0), so that consecutive
  * k-mers share that line (order is unspecified in the reference: it iterates a hash map). */
 int cid_kmerset_order_for_index(cid_kmerset *, const cid_index *);
@@ -224,23 +230,23 @@ int cid_order_codes_for_index_dev(cid_ctx *, const cid_index *, const uint64_t *
                                   uint64_t *d_codes_out, uint32_t *d_counts_out);
 /* Host copies in set order: n_distinct x k_size ASCII bytes and/or multiplicities (either may be NULL).
  * cid_kmerset_order_for_index works on 2-bit-code sets and on byte-string sets (k_size > 32: the rows are permuted) alike. */
-int cid_kmerset_download(const cid_kmerset *, uint8_t *kmers_ascii, uint32_t *counts);
+CID_CORE int cid_kmerset_download(const cid_kmerset *, uint8_t *kmers_ascii, uint32_t *counts);
 int cid_kmerset_device_arrays(const cid_kmerset *, void **d_codes, void **d_counts, uint64_t *n_distinct);
 /* the same for a byte-string set (k_size 33..128): n_distinct x k_size ASCII bytes, in set order */
 int cid_kmerset_device_ascii(const cid_kmerset *, void **d_kmers_ascii, void **d_counts, uint64_t *n_distinct);
-void cid_kmerset_destroy(cid_kmerset *);
+CID_CORE void cid_kmerset_destroy(cid_kmerset *);
 /* Bloom insert of a whole finalized set into one colour: one accession of `build` without the k-mers leaving HBM
  * (src/build.rs:54-99 with the map on the GPU). */
-int cid_index_insert_kmerset(cid_index *, const cid_kmerset *, uint32_t colour);
+CID_CORE int cid_index_insert_kmerset(cid_index *, const cid_kmerset *, uint32_t colour);
 /* a5 / a4 over a finalized set (results in set order; unique_colour has n_distinct entries). */
-int cid_search_count_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
+CID_CORE int cid_search_count_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
                          uint64_t *sum_unique_freq, uint32_t *unique_colour);
-int cid_search_perfect_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint32_t *and_words_le, int *any_row_missing);
+CID_CORE int cid_search_perfect_set(cid_ctx *, const cid_index *, const cid_kmerset *, uint32_t *and_words_le, int *any_row_missing);
 /* The same search with everything reports::generate_report prints (src/reports.rs:8-48) and nothing per k-mer: per colour the
  * hits, the number of k-mers that hit only that colour, the sum of their multiplicities (-> mean) and their MODE
  * (src/reports.rs:65-77; ties -> the smallest value, the reference's tie follows HashMap order) — 4 x n_colors u64 instead of
  * 8 bytes per k-mer crossing PCIe.  cid_unique_freq_modes_dev is the mode step alone on device arrays (d_freq NULL = all 1). */
-int cid_search_count_set_report(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
+CID_CORE int cid_search_count_set_report(cid_ctx *, const cid_index *, const cid_kmerset *, uint64_t *hits, uint64_t *n_unique,
                                 uint64_t *sum_unique_freq, uint64_t *mode_unique_freq);
 int cid_unique_freq_modes_dev(cid_ctx *, const uint32_t *d_unique_colour, const uint32_t *d_freq, size_t n_kmers, uint32_t n_colors,
                               uint64_t *d_modes);
@@ -249,7 +255,7 @@ int cid_unique_freq_modes_dev(cid_ctx *, const uint32_t *d_unique_colour, const 
  *      (src/perfect_search.rs:25-52, :83-110): AND of all n*K rows.  and_words_le: W32 u32 words;
  *      *any_row_missing = 1 iff some row is absent (the reference's "No perfect hits!"), in which case
  *      and_words_le is all zero. ---- */
-int cid_search_perfect(cid_ctx *, const cid_index *, const uint8_t *kmers, size_t n_kmers,
+CID_CORE int cid_search_perfect(cid_ctx *, const cid_index *, const uint8_t *kmers, size_t n_kmers,
                        uint32_t *and_words_le, int *any_row_missing);
 
 /* ---- a6/a7/a9/a10: per-read classification counts, the body of read_id_mt_pe::parallel_vec before
@@ -261,7 +267,7 @@ int cid_search_perfect(cid_ctx *, const cid_index *, const uint8_t *kmers, size_
  *      report: n_reads x (n_colors+1) counts, column n_colors = the reference's no_hits_num entry;
  *      n_kmers[r] = |k-mer set|; status[r] = 1 for too_short, else 0.
  *      k-mer iteration order is first occurrence (mate 1 then mate 2) — SURVEY.md App. B Q7. ---- */
-int cid_readid_count(cid_ctx *, const cid_index *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+CID_CORE int cid_readid_count(cid_ctx *, const cid_index *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
                      const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                      uint32_t *report, uint32_t *n_kmers, uint8_t *status);
 
@@ -269,10 +275,10 @@ int cid_readid_count(cid_ctx *, const cid_index *, const uint8_t *bases, const u
  * ascending colour order, so only those cross PCIe (a row has n_colors+1 counters, a read hits a handful).  The result
  * stays in the ctx until the next call; fetch it with cid_readid_sparse_fetch into row_start[n_reads+1] and
  * colours/counts[*n_entries] (column n_colors, the no_hits_num entry, appears like any colour). */
-int cid_readid_count_sparse(cid_ctx *, const cid_index *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
+CID_CORE int cid_readid_count_sparse(cid_ctx *, const cid_index *, const uint8_t *bases, const uint64_t *seq_off, size_t n_seqs,
                             const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d, uint32_t start_sample,
                             uint32_t *n_kmers, uint8_t *status, uint64_t *n_entries);
-int cid_readid_sparse_fetch(cid_ctx *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
+CID_CORE int cid_readid_sparse_fetch(cid_ctx *, uint64_t *row_start, uint32_t *colours, uint32_t *counts);
 
 /* Device-pointer form: bases AND offsets in HBM (what cid_fastq_* hands over).  The caller states the longest read(-pair) of the
  * batch in bytes and in k-mer windows (sum over its mates of (len-k)/d+1 for len >= k).  A read that exceeds either is not
@@ -413,7 +419,7 @@ int cid_ctx_tune(cid_ctx *, const char *name, long value);
  *      (header, DEFLATE data, CRC-32, ISIZE) at member_off / member_len; member i's text (text_len[i] = its ISIZE) is written to
  *      text + text_off[i].  Every member is checked as zlib checks it — block structure, Huffman codes, ISIZE and CRC-32; the
  *      first bad one is reported (CID_ERR_INVALID, *bad_member = its index).  Host buffers in and out; one call is one batch. ---- */
-int cid_bgzf_inflate(cid_ctx *, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+CID_CORE int cid_bgzf_inflate(cid_ctx *, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
                      const uint32_t *text_off, const uint32_t *text_len, size_t n_members, uint8_t *text, size_t text_bytes,
                      size_t *bad_member);
 /* The same call in two halves, for a reader that keeps two batches in flight on two contexts: _start queues the upload, the kernel
@@ -464,25 +470,25 @@ typedef struct cid_fastq cid_fastq;
 #define CID_FASTQ_LAST 1   /* push flags: the file ends with this push */
 #define CID_FASTQ_KEEP 2   /* push_text: the buffer (page-locked, cid_pinned_alloc) stays untouched until the next push on this file or the
                             * classify call that takes this one — the copy then runs beside the caller instead of being waited for */
-int cid_fastq_create(cid_ctx *, int n_files, uint32_t quality, cid_fastq **out);
-int cid_fastq_push_bgzf(cid_fastq *, int file, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
+CID_CORE int cid_fastq_create(cid_ctx *, int n_files, uint32_t quality, cid_fastq **out);
+CID_CORE int cid_fastq_push_bgzf(cid_fastq *, int file, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
                         const uint32_t *text_len, size_t n_members, int flags);
-int cid_fastq_push_text(cid_fastq *, int file, const uint8_t *text, size_t n_bytes, int flags);
-int cid_fastq_classify(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
+CID_CORE int cid_fastq_push_text(cid_fastq *, int file, const uint8_t *text, size_t n_bytes, int flags);
+CID_CORE int cid_fastq_classify(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes, uint64_t *n_reads,
                        uint64_t *n_entries, uint64_t *id_bytes);
-int cid_fastq_classify_begin(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes);
-int cid_fastq_classify_end(cid_fastq *, uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes);
-int cid_fastq_count_kmers(cid_fastq *, cid_kmerset *set, int max_pushes, uint64_t *n_reads);
-int cid_fastq_fetch(cid_fastq *, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,
+CID_CORE int cid_fastq_classify_begin(cid_fastq *, const cid_index *, uint32_t stride_d, uint32_t start_sample, int max_pushes);
+CID_CORE int cid_fastq_classify_end(cid_fastq *, uint64_t *n_reads, uint64_t *n_entries, uint64_t *id_bytes);
+CID_CORE int cid_fastq_count_kmers(cid_fastq *, cid_kmerset *set, int max_pushes, uint64_t *n_reads);
+CID_CORE int cid_fastq_fetch(cid_fastq *, uint32_t *n_kmers, uint8_t *status, uint64_t *row_start, uint32_t *colours, uint32_t *counts, uint64_t *id_off,
                     char *ids);
-void cid_fastq_destroy(cid_fastq *);
+CID_CORE void cid_fastq_destroy(cid_fastq *);
 #define CID_WARM_READID 1u
 #define CID_WARM_SEARCH 2u
 #define CID_WARM_INFLATE 4u
 #define CID_WARM_FASTQ 8u /* the FASTQ front end (cid_fastq_*): its record / packing kernels and scans */
 #define CID_WARM_COLD 16u /* the rocPRIM-built cold paths (10 MB of device code, ~40 ms): read_id's sorting path — long reads with k > 32, soft-masked
                            * reads of more than 16 384 windows — byte-string k-mer sets, reordering */
-int cid_warmup(cid_ctx *, unsigned what);
+CID_CORE int cid_warmup(cid_ctx *, unsigned what);
 int cid_timer_start(cid_ctx *);
 int cid_timer_stop_ms(cid_ctx *, float *elapsed_ms); /* synchronises on the stop event */
 

@@ -412,11 +412,11 @@ def test_config_d_one_gpus_share_of_the_query(orc, hip_ctx):
     t1 = lap("make_reads_ms", t0)
 
     def count(order, compact_windows):
-        os.environ["CID_KMERSET_COMPACT_WINDOWS"] = str(compact_windows)
+        hip_ctx.tune("kmerset_compact_at", compact_windows)   # (read when the set is made)
         try:
             ks = colorid_amd.KmerSet(hip_ctx, k)
         finally:
-            del os.environ["CID_KMERSET_COMPACT_WINDOWS"]
+            hip_ctx.tune("kmerset_compact_at", 0)
         for c in order:
             check(lib.cid_kmerset_add_seqs(ks.h, vp(host[c].ctypes.data), vp(seq_off.ctypes.data), per, 1))
         nd = ks.finalize()
@@ -505,11 +505,11 @@ def test_config_d_one_gpus_share_of_the_query(orc, hip_ctx):
     t6 = lap("search_whole_set_ms", t5)
     # the same share counted FOR this index (cid_kmerset_set_target_index: what `colorid search` does) — 8 merges on the (first-row key,
     # code) pair: the same k-mers and multiplicities in another order, the same counters from the search, (key, code) order
-    os.environ["CID_KMERSET_COMPACT_WINDOWS"] = str(160_000_000)
+    hip_ctx.tune("kmerset_compact_at", 160_000_000)
     try:
         kt = colorid_amd.KmerSet(hip_ctx, k)
     finally:
-        del os.environ["CID_KMERSET_COMPACT_WINDOWS"]
+        hip_ctx.tune("kmerset_compact_at", 0)
     kt.set_target_index(hx)
     for c in range(CH):
         check(lib.cid_kmerset_add_seqs(kt.h, vp(host[c].ctypes.data), vp(seq_off.ctypes.data), per, 1))

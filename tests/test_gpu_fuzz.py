@@ -163,21 +163,21 @@ def test_kmerset_random_inputs(orc, hip_ctx, seed):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FUZZ_SEED0", 0)), int(os.environ.get("FUZZ_SEED0", 0)) + int(os.environ.get("FUZZ_N", 24)) // 2))
-def test_kmerset_for_an_index_random_inputs(orc, hip_ctx, seed, monkeypatch):
+def test_kmerset_for_an_index_random_inputs(orc, hip_ctx, seed, monkeypatch, tune):
     """A k-mer set built FOR an index (cid_kmerset_set_target_index) on random sequence sets and index sizes — one row, a handful of rows
     (every window in a few runs: the per-run fallbacks), powers of two, primes — through the partition kernels (CID_KMERSET_MSD_MIN=1) or
     the two LSD sorts, in one batch or merged from several: same contents as the oracle's map, (first-row key, code) order, the same
     report as the code-ordered set."""
     import colorid_amd
     from util import random_index, to_hip_index
-    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")   # (by default a set for an index below 2^20 rows keeps code order)
+    tune("CID_KMERSET_TARGET_SMALL", 1)   # (by default a set for an index below 2^20 rows keeps code order)
     rng = np.random.default_rng(7000 + seed)
     k = int(rng.integers(1, 33))
     m = int(rng.choice([1, 2, 7, 64, 4001, 65_536, 1_000_003, (1 << 20) + 3, 50_000_017]))
     if seed % 2:
-        monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
+        tune("CID_KMERSET_MSD_MIN", 1)
     if seed % 3 == 0:
-        monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", str(int(rng.choice([500, 3000, 20000]))))
+        tune("CID_KMERSET_COMPACT_WINDOWS", int(rng.choice([500, 3000, 20000])))
     alphabets = [b"ACGT", b"ACGTN", b"ACGTacgt", b"AC", b"ACGTRY"]
     seqs = []
     for _ in range(int(rng.integers(1, 10))):

@@ -30,9 +30,10 @@ def _group_index(g, oix, variant=0):
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0]])
 @pytest.mark.parametrize("n_colors,k", [(256, 31), (46, 27), (1024, 21), (9000, 31), (200, 40)])
-def test_group_search_equals_single_rank_and_oracle(orc, hip_ctx, devices, n_colors, k, monkeypatch):
+def test_group_search_equals_single_rank_and_oracle(orc, hip_ctx, devices, n_colors, k, monkeypatch, tune):
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")   # (a set for an index below 2^20 rows keeps code order by default)
+    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")   # (a set for an index below 2^20 rows keeps code order by default; the group's contexts are made below)
+    tune("CID_KMERSET_TARGET_SMALL", 1)                   # ... and the session's context
     rng = np.random.default_rng(n_colors + len(devices))
     m = 40_009 if n_colors < 2000 else 4001
     oix = random_index(orc, rng, m, 4, k, n_colors, density=0.15 if n_colors < 2000 else 0.01, zero_row_frac=0.05)

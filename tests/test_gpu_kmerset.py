@@ -190,15 +190,15 @@ def test_byte_string_sets_k_above_32(orc, hip_ctx, k):
 
 
 @pytest.mark.parametrize("cold_sort,cold_merge", [(False, False), (True, False), (False, True)])
-def test_incremental_merge_path(orc, hip_ctx, monkeypatch, cold_sort, cold_merge):
+def test_incremental_merge_path(orc, hip_ctx, monkeypatch, cold_sort, cold_merge, tune):
     """later batches are merged into the set (cid_merge.hpp: merge path, twins joined, one pass); cold_sort: the batches themselves through
     rocPRIM's LSD sorts; cold_merge: rocPRIM's merge + reduce_by_key (both in cid_kmerset_cold.hip)"""
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "20000")   # a merge every few batches
+    tune("CID_KMERSET_COMPACT_WINDOWS", 20000)   # a merge every few batches
     if cold_sort:
-        monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1000000000")
+        tune("CID_KMERSET_MSD_MIN", 1000000000)
     if cold_merge:
-        monkeypatch.setenv("CID_KMERSET_COLD_MERGE", "1")
+        tune("CID_KMERSET_COLD_MERGE", 1)
     rng = np.random.default_rng(3)
     genome = rand_seq(rng, 30000)
     batches = [[genome[s:s + 400] for s in rng.integers(0, len(genome) - 400, 200)] for _ in range(6)]
@@ -238,11 +238,11 @@ def test_histogram_with_multiplicities_beyond_the_lds_bins(orc, hip_ctx):
 
 
 @pytest.mark.parametrize("targeted", [False, True])
-def test_merge_of_large_lists_with_every_kind_of_overlap(orc, hip_ctx, monkeypatch, targeted):
+def test_merge_of_large_lists_with_every_kind_of_overlap(orc, hip_ctx, monkeypatch, targeted, tune):
     """cid_merge.hpp beyond one tile: a set of ~400 k k-mers joined by batches that repeat it wholly, partly and not at all (twins at tile and
     thread borders occur by the thousand), in code order and built for an index; against one set counted in one go"""
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")
+    tune("CID_KMERSET_TARGET_SMALL", 1)
     rng = np.random.default_rng(23)
     g1, g2, g3 = rand_seq(rng, 200_000), rand_seq(rng, 150_000), rand_seq(rng, 120_000)
     batches = [[g1, g2], [g2], [g3, g1[:50_000]], [g1, g2, g3], [rand_seq(rng, 10)], [g3[60_000:]]]
@@ -254,7 +254,7 @@ def test_merge_of_large_lists_with_every_kind_of_overlap(orc, hip_ctx, monkeypat
         one.set_target_index(hx)
     one.add_seqs([s for b in batches for s in b], 0)
     n_one = one.finalize()
-    monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "1000")   # every batch is merged into the set as it comes
+    tune("CID_KMERSET_COMPACT_WINDOWS", 1000)   # every batch is merged into the set as it comes
     many = colorid_amd.KmerSet(hip_ctx, k)
     if targeted:
         many.set_target_index(hx)
@@ -414,13 +414,13 @@ def test_many_add_calls_on_a_used_context(orc, hip_ctx):
 
 @pytest.mark.parametrize("k", [6, 11, 21, 27, 31])
 @pytest.mark.parametrize("flavour", ["random", "deep", "repeats", "one_kmer", "ns", "mixed", "shared_prefix", "deep_errors"])
-def test_msd_sort_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour):
+def test_msd_sort_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour, tune):
     """The k-mer set's own sort (cid_partition.hpp: MSD radix partition passes, then every run finished in LDS) on inputs small enough
     for the oracle — CID_KMERSET_MSD_MIN=1 sends them through the kernels large sets take: evenly spread codes (the LDS bucket sort),
     every k-mer many times (deep coverage: k_run_dedupe_sort for crowded runs, the radix kernel for what is not copies), low-complexity sequence (runs beyond a workgroup's LDS:
     the per-run fallback), a single k-mer, N runs (sentinels dropped by the first pass), and all of it at once."""
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
+    tune("CID_KMERSET_MSD_MIN", 1)
     rng = np.random.default_rng(k * 31 + len(flavour))
     if flavour == "random":
         seqs = [rand_seq(rng, 60_000), rand_seq(rng, 45_000)]
@@ -466,4 +466,3 @@ def test_msd_sort_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour):
         assert order == sorted(order)                         # ascending code == ascending ASCII (A < C < G < T)
         assert int(cnt.sum()) == int(want.counts().sum())
         ks.close()
-    monkeypatch.setenv("CID_KMERSET_MSD_SORT", "0")            # (read once per process: no effect here; the default path is the one tested)

@@ -26,9 +26,9 @@ def assert_target_order(orc, km, m):
 
 
 @pytest.fixture(autouse=True)
-def _small_indices_are_targeted_too(monkeypatch):
+def _small_indices_are_targeted_too(tune):
     """the library leaves a set for an index below 2^20 rows in code order (nothing to gain, crowded runs); the tests' indices are small"""
-    monkeypatch.setenv("CID_KMERSET_TARGET_SMALL", "1")
+    tune("CID_KMERSET_TARGET_SMALL", 1)
 
 
 def empty_index(hip_ctx, m, n_hash, k, n_colors=8):
@@ -41,14 +41,14 @@ def empty_index(hip_ctx, m, n_hash, k, n_colors=8):
 @pytest.mark.parametrize("m", [50_021, 65_536, 4_000_037])
 @pytest.mark.parametrize("k", [6, 21, 31, 32])
 @pytest.mark.parametrize("flavour", ["random", "deep", "repeats", "one_kmer", "ns", "mixed", "shared_prefix", "deep_errors"])
-def test_targeted_msd_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour, m):
+def test_targeted_msd_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavour, m, tune):
     """the pair kernels of cid_partition.hpp on inputs small enough for the oracle (CID_KMERSET_MSD_MIN=1): evenly spread keys (the LDS
     bucket sort), deep coverage (crowded buckets: k_run_dedupe_sort, the radix kernel for what is not copies), one row holding most windows (runs beyond a workgroup's LDS: the
     per-run LSD sorts), windows without a k-mer (dropped by the first level)"""
     import colorid_amd
     if k == 32 and m != 50_021:
         pytest.skip("one index size is enough for the 64-bit codes")
-    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
+    tune("CID_KMERSET_MSD_MIN", 1)
     rng = np.random.default_rng(k * 31 + len(flavour))
     if flavour == "random":
         seqs = [rand_seq(rng, 60_000), rand_seq(rng, 45_000)]
@@ -98,10 +98,10 @@ def test_targeted_msd_path_equals_the_oracle(orc, hip_ctx, monkeypatch, k, flavo
     hx.close()
 
 
-def test_small_sets_take_the_two_lsd_sorts(orc, hip_ctx, monkeypatch):
+def test_small_sets_take_the_two_lsd_sorts(orc, hip_ctx, monkeypatch, tune):
     """below CID_KMERSET_MSD_MIN windows (the cold path, cid_kmerset_cold.hip): sort by code, then stably by key"""
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1000000000")
+    tune("CID_KMERSET_MSD_MIN", 1000000000)
     rng = np.random.default_rng(5)
     g = rand_seq(rng, 5000)
     seqs = [g[s:s + 150] for s in rng.integers(0, len(g) - 150, 300)] + [rand_seq(rng, 700, b"ACGTN"), b"ACG"]
@@ -120,10 +120,10 @@ def test_small_sets_take_the_two_lsd_sorts(orc, hip_ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("msd", [False, True])
-def test_incremental_merge_keeps_the_target_order(orc, hip_ctx, monkeypatch, msd):
+def test_incremental_merge_keeps_the_target_order(orc, hip_ctx, monkeypatch, msd, tune):
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_COMPACT_WINDOWS", "20000")   # a merge every few batches
-    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1" if msd else "1000000000")
+    tune("CID_KMERSET_COMPACT_WINDOWS", 20000)   # a merge every few batches
+    tune("CID_KMERSET_MSD_MIN", 1 if msd else 1000000000)
     rng = np.random.default_rng(3)
     genome = rand_seq(rng, 30000)
     batches = [[genome[s:s + 400] for s in rng.integers(0, len(genome) - 400, 200)] for _ in range(6)]
@@ -148,11 +148,11 @@ def test_incremental_merge_keeps_the_target_order(orc, hip_ctx, monkeypatch, msd
 
 
 @pytest.mark.parametrize("n_colors,n_hash,k", [(4, 4, 27), (256, 4, 31), (1024, 3, 21), (65, 2, 32)])
-def test_search_over_a_targeted_set(orc, hip_ctx, monkeypatch, n_colors, n_hash, k):
+def test_search_over_a_targeted_set(orc, hip_ctx, monkeypatch, n_colors, n_hash, k, tune):
     """every output of the proportional and the perfect search over a targeted set == the oracle on the same k-mers in the set's
     order == (the order-free ones) the code-ordered set's"""
     import colorid_amd
-    monkeypatch.setenv("CID_KMERSET_MSD_MIN", "1")
+    tune("CID_KMERSET_MSD_MIN", 1)
     rng = np.random.default_rng(n_colors + k)
     genome = rand_seq(rng, 20000)
     reads = [genome[s:s + 150] for s in rng.integers(0, len(genome) - 150, 1500)]

@@ -53,3 +53,19 @@ def test_pointer_spellings():
     a = dict(x.split(": ") for x in fns["cid_readid_count_resident"][0])
     assert a["d_bases"] == "*const u8" and a["seq_off"] == "*const u64" and a["d_status"] == "*mut u8" and a["stride_d"] == "u32"
     assert fns["cid_kmerset_destroy"][1] == ""
+
+
+def test_core_and_extended_modules_follow_the_headers_marks():
+    """include/colorid_hip.h marks the stable core with CID_CORE (SURVEY.md §8b's calls + what the one-GPU command line runs on); the
+    generated Rust file carries the same split as `mod core` / `mod extended`, re-exported flat"""
+    hdr = open(os.path.join(ROOT, "include", "colorid_hip.h")).read()
+    core_h = set(re.findall(r"^CID_CORE [\w \*]*?(cid_\w+)\(", hdr, re.M))
+    src = open(os.path.join(ROOT, "include", "colorid_hip.rs")).read()
+    core_rs = set(re.findall(r"pub fn (cid_\w+)\(", src[src.index("pub mod core {"):src.index("pub mod extended {")]))
+    ext_rs = set(re.findall(r"pub fn (cid_\w+)\(", src[src.index("pub mod extended {"):]))
+    assert core_h == core_rs and not (core_rs & ext_rs)
+    for name in ("cid_ctx_create", "cid_index_create", "cid_index_put_rows", "cid_index_finalize", "cid_search_count", "cid_search_perfect", "cid_readid_count",
+                 "cid_index_destroy", "cid_ctx_destroy", "cid_last_error"):            # SURVEY.md §8b's ten
+        assert name in core_rs
+    assert 40 <= len(core_rs) <= 50 and len(core_rs) + len(ext_rs) == len(_rust_fns()[0])
+    assert "pub use self::core::*;" in src and "pub use self::extended::*;" in src
