@@ -1,6 +1,7 @@
 // C ABI of libcolorid_hip.so (see include/colorid_hip.h), part 1: errors, contexts and their scratch memory, per-context tunables,
 // warm-up and timers.  Host-side plumbing only — there is no CPU compute path in this library.
 #include <mutex>
+#include <chrono>
 
 #include "cid_api_common.hpp"
 
@@ -36,7 +37,11 @@ int ctx_alloc(cid_ctx *c, size_t bytes, void **out) {
     }
     const size_t want = bytes + bytes / 8;   // batches vary a little in size: leave room for the next one
     void *p = nullptr;
+    const auto t_alloc = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
+    if (c->tune.alloc_trace)
+        fprintf(stderr, "cid alloc: block %zu B in %.2f ms (%zu blocks held)\n", want,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count(), c->blocks.size());
     size_t got = want;
     if (e != hipSuccess) {   // give the idle blocks back and ask for exactly what is needed
         (void)hipGetLastError();
@@ -113,7 +118,10 @@ int slot_reserve(cid_ctx *c, int s, size_t bytes, void **out) {
         c->slot[s] = nullptr;
         c->slot_bytes[s] = 0;
         const size_t want = bytes + bytes / 4;
+        const auto t_alloc = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&c->slot[s], want);
+        if (c->tune.alloc_trace)
+            fprintf(stderr, "cid alloc: slot %d %zu B in %.2f ms\n", s, want, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count());
         if (e != hipSuccess) return fail(CID_ERR_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
         c->slot_bytes[s] = want;
     }
@@ -310,6 +318,44 @@ int cid_ctx_tune(cid_ctx *c, const char *name, long value) {
 // The runtime loads a translation unit's device code on the first launch of one of its kernels — ~60 ms for the read_id kernels,
 // paid inside the first cid_readid_count* call.  This call pays it ahead of time and may run on another host thread than the one
 // using the ctx (it touches no stream, no ctx state): the CLI runs it beside the index load.
+// What the first call of a process pays beyond its code objects does not grow with the call: the runtime's staging buffers for copies out
+// of pageable memory, its first events and its copy queues — 9-10 ms inside the first cid_kmerset_add_seqs of a process, whatever the query's
+// size (profiles/r06_first_use.txt: a query of 2 000 reads first, and the million-read query after it runs at the steady state's speed).  So the
+// warm-up runs a query of a few reads itself, on a context of its own (its own stream and scratch: nothing of `c` is touched, the caller may
+// be loading an index into it on another thread) against an index of 1 024 rows, and throws both away.
+static void warm_dry_run(int device, unsigned what) {
+    cid_ctx *t = nullptr;
+    if (cid_ctx_create(device, &t) != CID_OK) return;
+    cid_index *ix = nullptr;
+    const uint32_t k = 21;
+    std::vector<uint8_t> bases(16 * 150 + 2400);
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (uint8_t &b : bases) { x = x * 6364136223846793005ull + 1442695040888963407ull; b = (uint8_t)"ACGT"[x >> 62]; }
+    std::vector<uint64_t> so(18), r0(18);
+    for (size_t i = 0; i <= 16; ++i) so[i] = i * 150;
+    so[17] = bases.size();                     // ... and one read of 2 400 bases: the long-read kernels
+    for (size_t i = 0; i < 18; ++i) r0[i] = i;
+    if (cid_index_create(t, 1024, 2, k, 4, 0, &ix) == CID_OK && cid_index_finalize(ix) == CID_OK) {
+        if (what & CID_WARM_SEARCH) {
+            cid_kmerset *ks = nullptr;
+            if (cid_kmerset_create(t, k, &ks) == CID_OK) {
+                uint64_t nd = 0, hits[4], nu[4], su[4], mode[4];
+                if (cid_kmerset_add_seqs(ks, bases.data(), so.data(), 17, 0) == CID_OK && cid_kmerset_finalize(ks, &nd) == CID_OK)
+                    (void)cid_search_count_set_report(t, ix, ks, hits, nu, su, mode);
+                cid_kmerset_destroy(ks);
+            }
+        }
+        if (what & CID_WARM_READID) {
+            uint32_t nk[17];
+            uint8_t st[17];
+            uint64_t ne = 0;
+            (void)cid_readid_count_sparse(t, ix, bases.data(), so.data(), 17, r0.data(), 17, 1, 3, nk, st, &ne);
+        }
+    }
+    if (ix) cid_index_destroy(ix);
+    cid_ctx_destroy(t);
+}
+
 int cid_warmup(cid_ctx *c, unsigned what) {
     if (!c) return fail(CID_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
@@ -320,7 +366,33 @@ int cid_warmup(cid_ctx *c, unsigned what) {
     if (what & CID_WARM_SEARCH) HIP_TRY(cid::warm_kmerset());                         // the k-mer set's sorts: 18 MB, 0.2 s to load
     if (what & CID_WARM_INFLATE) HIP_TRY(cid::warm_inflate());
     if (what & CID_WARM_FASTQ) { hipStream_t s[4]; HIP_TRY(cid::ctx_side_streams(c, s)); }
-    if (what & CID_WARM_FASTQ) HIP_TRY(cid::warm_fastq());                            // 3.9 MB: its scans and selects are rocPRIM's
+    if (what & CID_WARM_FASTQ) HIP_TRY(cid::warm_fastq());
+    if (what & (CID_WARM_SEARCH | CID_WARM_READID)) {
+        warm_dry_run(c->device, what);
+        // ... and this context's own queues: the runtime makes a stream's hardware queue with the first command it is given (7-9 ms for the
+        // copy stream, inside the first cid_kmerset_add_seqs).  A fill kernel and a 64-byte copy on each; HIP's streams may be used from any thread, and nothing
+        // of the ctx's state is touched.
+        {   // ... and the bus: the first large copy after the device has been idle runs at a third of the link's rate (150 MB in 10-11 ms instead of
+            // 3.9: the link and the copy engines wake up; profiles/r06_first_use.txt) — 32 MB from page-locked memory, here, instead of the query's first slice
+            void *hp = nullptr, *dp = nullptr;
+            const size_t nb = 32u << 20;
+            if (hipHostMalloc(&hp, nb, hipHostMallocDefault) == hipSuccess && hipMalloc(&dp, nb) == hipSuccess) {
+                memset(hp, 0, nb);
+                for (int rep = 0; rep < 3; ++rep) (void)hipMemcpy(dp, hp, nb, hipMemcpyHostToDevice);
+            }
+            if (dp) (void)hipFree(dp);
+            if (hp) (void)hipHostFree(hp);
+        }
+        void *d = nullptr;
+        uint8_t h[64] = {0};
+        if (hipMalloc(&d, 256) == hipSuccess) {
+            for (hipStream_t st : {c->copy_stream, c->own_stream})
+                if (st && hipMemsetAsync(d, 0, 256, st) == hipSuccess && hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, st) == hipSuccess)   // (a dispatch and a copy)
+                    (void)hipStreamSynchronize(st);
+            (void)hipFree(d);
+        }
+        (void)hipGetLastError();
+    }                            // 3.9 MB: its scans and selects are rocPRIM's
     return CID_OK;
 }
 
