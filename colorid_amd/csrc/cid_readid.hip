@@ -837,20 +837,21 @@ __global__ __launch_bounds__(kBlock, 5) void k_readid_slices(ReadIdSliceParams p
     }
 }
 
-// one wave per read that was cut into several slices: the slices' rows in order, up to and including the first that stopped
+// one workgroup per read that was cut into several slices: the slices' rows in order, up to and including the first that stopped.  A thread
+// per colour: its loads do not depend on one another.  (One WAVE per read, five colours a lane: 250 us for the 150 reads of 244 slices that
+// 150 Mbases of megabase reads are.)
 __global__ __launch_bounds__(kBlock) void k_readid_combine(const ReadCombine *comb, uint32_t n_comb, const uint32_t *partial, uint32_t C, uint32_t *report) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    __shared__ uint32_t s_last;
+    const uint32_t i = blockIdx.x;
     if (i >= n_comb) return;
     const ReadCombine rc = comb[i];
-    uint32_t last = rc.n_slices;   // slices that count
-    for (uint32_t j0 = 0; j0 < rc.n_slices && last == rc.n_slices; j0 += kWave) {
-        const uint32_t j = j0 + lane;
-        const bool st = j < rc.n_slices && partial[(uint64_t)(rc.first_slice + j) * (C + 2) + C + 1] != 0;
-        const uint64_t bm = __ballot(st);
-        if (bm) last = j0 + (uint32_t)__builtin_ctzll(bm) + 1;
-    }
-    for (uint32_t c = lane; c <= C; c += kWave) {
+    if (threadIdx.x == 0) s_last = rc.n_slices;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < rc.n_slices; j += blockDim.x)   // the first slice that stopped
+        if (partial[(uint64_t)(rc.first_slice + j) * (C + 2) + C + 1] != 0) atomicMin(&s_last, j + 1);
+    __syncthreads();
+    const uint32_t last = s_last;   // slices that count
+    for (uint32_t c = threadIdx.x; c <= C; c += blockDim.x) {
         uint32_t acc = 0;
         for (uint32_t j = 0; j < last; ++j) acc += partial[(uint64_t)(rc.first_slice + j) * (C + 2) + c];
         report[(uint64_t)rc.read * (C + 1) + c] = acc;
@@ -1059,7 +1060,7 @@ hipError_t launch_readid_slices(const ReadIdSliceParams &p, int grid, hipStream_
 hipError_t launch_readid_combine(const ReadCombine *d_comb, uint32_t n_comb, const uint32_t *d_partial, uint32_t n_colors, uint32_t *d_report,
                                  hipStream_t stream) {
     if (n_comb == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_readid_combine, dim3((n_comb + 3) / 4), dim3(kBlock), 0, stream, d_comb, n_comb, d_partial, n_colors, d_report);
+    hipLaunchKernelGGL(k_readid_combine, dim3(n_comb), dim3(kBlock), 0, stream, d_comb, n_comb, d_partial, n_colors, d_report);
     return hipGetLastError();
 }
 

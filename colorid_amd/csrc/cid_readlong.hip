@@ -134,21 +134,17 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
         for (uint32_t w = a + threadIdx.x; w < b; w += kDealBlock) {
             const uint64_t code = codes[w0 + w];
             if (code >= sentinel) continue;
-            s_idx[atomicAdd(&s_cur[(uint32_t)(((long_mix(code) >> 32) * P) >> 32)], 1u)] = w;
+            const uint32_t bk = (uint32_t)(((long_mix(code) >> 32) * P) >> 32);
+            s_idx[atomicAdd(&s_cur[bk], 1u)] = w | (bk << 24);   // (w < 2^22 - 1, bk < 256: the write-out below needs no search for its bucket)
         }
         __syncthreads();
         const uint32_t total = s_start[256];
         bool over = false;
         for (uint32_t p = threadIdx.x; p < total; p += kDealBlock) {
-            uint32_t lo = 0, hi = 256;   // the bucket of place p: s_start[lo] <= p < s_start[lo + 1]
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_start[mid] <= p) lo = mid; else hi = mid;
-            }
+            const uint32_t v = s_idx[p], lo = v >> 24, w = v & 0xFFFFFFu;   // the bucket of place p: s_start[lo] <= p < s_start[lo + 1]
             const uint32_t at = p - s_start[lo];
             if (at < d.cap) {
                 const uint64_t o = d.pair_base + ((uint64_t)lo * d.n_chunks + j) * d.cap + at;
-                const uint32_t w = s_idx[p];
                 pair_code[o] = codes[w0 + w];
                 pair_idx[o] = w;
             } else over = true;
@@ -164,9 +160,10 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
 __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongItem *items, uint32_t n_items, uint64_t sentinel,
                                    uint32_t slots, uint32_t bm_words, uint32_t *bitmap, int *flags, const LongDeal *deals, const uint64_t *pair_code,
                                    const uint32_t *pair_idx, const uint32_t *deal_counts, uint8_t *redo) {
-    extern __shared__ uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
+    extern __shared__ __align__(16) uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
     __shared__ int s_over;
-    __shared__ uint32_t s_pref[kLongMaxChunks + 1];   // a dealt bucket: pairs in the segments before chunk j
+    __shared__ uint32_t s_pref[kLongMaxChunks + 1];   // a dealt bucket: pairs in its segment of chunk j
+    __shared__ uint32_t s_wsum[kLongBlockBig / 64];
     uint32_t *bm = table + slots;
     const uint32_t max_slots = slots, bm_bits = bm_words * 32u;
     const uint32_t chunk = (n_items + 7u) / 8u;
@@ -208,27 +205,36 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                 // chunk after chunk, a segment kept a quarter of the workgroup busy and every chunk paid a memory round trip for its count
                 // (1 Mb reads: 61 chunks, 187 us per bucket against 23 us for a whole 10 kb read)
                 const LongDeal d = deals[im.deal - 1];
-                if (sub == 0 || level) {   // (the prefix is the same in every pass; the table's clearing barrier above separates the passes)
-                    for (uint32_t j = threadIdx.x; j < d.n_chunks; j += blockDim.x) s_pref[j + 1] = deal_counts[d.count_base + im.bucket * d.n_chunks + j];
-                    if (threadIdx.x == 0) s_pref[0] = 0;
-                    __syncthreads();
-                    if (threadIdx.x == 0)
-                        for (uint32_t j = 0; j < d.n_chunks; ++j) s_pref[j + 1] += s_pref[j];
+                if (sub == 0 || level) {   // (the counts are the same in every pass; the table's clearing barrier above separates the passes)
+                    for (uint32_t j = threadIdx.x; j < d.n_chunks; j += blockDim.x) s_pref[j] = deal_counts[d.count_base + im.bucket * d.n_chunks + j];
                     __syncthreads();
                 }
-                const uint32_t total = s_pref[d.n_chunks];
+                // The bucket's segments lie side by side, `cap` places each: the places are walked as they lie — place x = (chunk x / cap, pair
+                // x % cap), taken when the chunk holds that many — four of them in flight per thread.  (Round 5 walked the PAIRS as one index
+                // space: a binary search over the chunks' prefix per pair, eight dependent LDS reads before its two loads could be asked for:
+                // 96 us per bucket of a 1 Mb read.)
+                const uint32_t cap = d.cap, span = d.n_chunks * cap;
+                const uint64_t inv = ((1ull << 40) + cap - 1) / cap;   // x / cap = (x * inv) >> 40 for x < 2^24
                 const uint64_t o0 = d.pair_base + (uint64_t)im.bucket * d.n_chunks * d.cap;
-                for (uint32_t t = threadIdx.x; t < total; t += blockDim.x) {
-                    uint32_t lo = 0, hi = d.n_chunks;   // the chunk whose segment holds pair t: s_pref[lo] <= t < s_pref[lo + 1]
-                    while (hi - lo > 1) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (s_pref[mid] <= t) lo = mid; else hi = mid;
+                for (uint32_t x0 = threadIdx.x; x0 < span; x0 += 4u * blockDim.x) {
+                    uint64_t code4[4];
+                    uint32_t idx4[4];
+                    bool have[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t x = x0 + u * blockDim.x;
+                        const uint32_t j = (uint32_t)(((uint64_t)x * inv) >> 40);
+                        have[u] = x < span && x - j * cap < s_pref[j];
+                        code4[u] = have[u] ? pair_code[o0 + x] : 0ull;
+                        idx4[u] = have[u] ? pair_idx[o0 + x] : 0u;
                     }
-                    const uint64_t o = o0 + (uint64_t)lo * d.cap + (t - s_pref[lo]);
-                    const uint64_t code = pair_code[o];
-                    const uint64_t h = long_mix(code);
-                    if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
-                    insert(code, pair_idx[o], h);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        if (!have[u]) continue;
+                        const uint64_t h = long_mix(code4[u]);
+                        if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
+                        insert(code4[u], idx4[u], h);
+                    }
                 }
             } else
             for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
@@ -254,21 +260,57 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
             // windows start at a multiple of 32, so its words are its own).  One global atomicOr per BIT took 4.4 of this kernel's
             // 5.4 ms on 150 Mbases of 10 kb reads: the atomics of a read all fall into its dozen of 128-byte lines.
             const bool own_words = im.n_buckets == 1 && level == 0;   // else other passes add to the same words
-            for (uint32_t c0 = 0; c0 < nw; c0 += bm_bits) {
-                for (uint32_t i = threadIdx.x; i < bm_words; i += blockDim.x) bm[i] = 0;
+            // A read of several stretches (a megabase: eight of them at 131 072 windows a stretch, the table swept once for each): the table's
+            // entries are first pushed together into its lower half — they are at most half its slots — and the upper half joins the bitmap's
+            // stretch: 655 360 windows a stretch, and a sweep reads the entries there are, not the slots (1 Mb reads: 3.45 -> ms).
+            uint32_t *bmx = bm;
+            uint32_t bmx_words = bm_words, n_entries = slots;
+            if (nw > bm_bits && slots == max_slots && slots == 32u * blockDim.x) {   // (workgroup-uniform)
+                uint32_t mine[32], cnt = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(table)[threadIdx.x * 8u + q];
+                    mine[4 * q] = v.x; mine[4 * q + 1] = v.y; mine[4 * q + 2] = v.z; mine[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 32; ++q) cnt += mine[q] != kLongEmpty ? 1u : 0u;
+                uint32_t inc = cnt;
+                const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += up;
+                }
+                if (lane == 63) s_wsum[wave] = inc;
+                __syncthreads();   // (every thread holds its slots: the table may be written)
+                uint32_t base = 0, total = 0;
+                for (uint32_t t = 0; t < blockDim.x / 64u; ++t) { if ((int)t < wave) base += s_wsum[t]; total += s_wsum[t]; }
+                if (total <= slots / 2u) {   // (workgroup-uniform)
+                    uint32_t at = base + inc - cnt;
+#pragma unroll
+                    for (uint32_t q = 0; q < 32; ++q) if (mine[q] != kLongEmpty) table[at++] = mine[q];
+                    bmx = table + slots / 2u;
+                    bmx_words = slots / 2u + bm_words;
+                    n_entries = total;
+                }
                 __syncthreads();
-                for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) {
+            }
+            const uint32_t bmx_bits = bmx_words * 32u;
+            for (uint32_t c0 = 0; c0 < nw; c0 += bmx_bits) {
+                for (uint32_t i = threadIdx.x; i < bmx_words; i += blockDim.x) bmx[i] = 0;
+                __syncthreads();
+                for (uint32_t s = threadIdx.x; s < n_entries; s += blockDim.x) {
                     const uint32_t cur = table[s];
                     if (cur != kLongEmpty) {
                         const uint32_t w = (cur >> kLongTagBits) - c0;
-                        if (w < bm_bits) atomicOr(&bm[w >> 5], 1u << (w & 31u));
+                        if (w < bmx_bits) atomicOr(&bmx[w >> 5], 1u << (w & 31u));
                     }
                 }
                 __syncthreads();
-                const uint32_t words = (nw - c0 + 31u) / 32u < bm_words ? (nw - c0 + 31u) / 32u : bm_words;
+                const uint32_t words = (nw - c0 + 31u) / 32u < bmx_words ? (nw - c0 + 31u) / 32u : bmx_words;
                 uint32_t *out = bitmap + ((w0 + c0) >> 5);
                 for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
-                    const uint32_t v = bm[i];
+                    const uint32_t v = bmx[i];
                     if (own_words) out[i] = v;
                     else if (v) atomicOr(&out[i], v);
                 }
@@ -317,7 +359,7 @@ __global__ void k_long_short_rows(const uint8_t *status, uint32_t n_reads, uint3
 //   k_long_plan   one thread per read: its class, its windows; ONE pass of seven decoupled look-back scans (cid_scan.hpp's, a word per
 //                 tile and field) gives every read its place in every list; the last tile leaves the totals
 //   (the host reads the totals — 64 bytes, the one wait before the kernels — and sizes the lists)
-//   k_long_emit   one thread per read: its entries of the lists
+//   k_long_emit   one wave per read: its entries of the lists
 enum LongClass : uint8_t {
     kClsOther = 0,      // not routed here (status 2)
     kClsShort = 1,      // the first mate has no window (status 1: too_short)
@@ -464,8 +506,11 @@ struct LongLists {
     LongDeal *deals;
     uint32_t *chunk_deal, *chunk_no;
 };
+// One WAVE per read: the lists of a megabase read are hundreds of entries each (490 segments, 244 slices, 61 items and chunks), written by
+// one thread they took 160 us per 150 such reads.
 __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
     if (r >= p.n_reads) return;
     const uint32_t cls = p.cls[r];
     if (cls < kClsFusedSmall || cls > kClsItemsBig) return;
@@ -473,7 +518,7 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
     const uint32_t win = p.win[r];
     const uint64_t w0 = p.wstart[r];
     auto pre = [&](uint32_t f) { return p.pre[(size_t)f * n + r]; };
-    if (cls == kClsFusedSmall || cls == kClsFusedBig) {
+    if ((cls == kClsFusedSmall || cls == kClsFusedBig) && lane == 0) {
         FuseItem it{};
         it.read = (uint32_t)r; it.nw = win; it.w0 = w0;
         uint32_t ns = 0, wb = 0, piece = 0;
@@ -497,24 +542,24 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
         else L.fused_big[(uint32_t)(pre(1) >> 32)] = it;
     }
     const LongDealShape d = long_deal_shape(win, cls, p.deal);
-    if (cls == kClsItemsSmall) L.items_small[(uint32_t)pre(2)] = LongItem{(uint32_t)r, 0u, 1u, 0u};
+    if (cls == kClsItemsSmall && lane == 0) L.items_small[(uint32_t)pre(2)] = LongItem{(uint32_t)r, 0u, 1u, 0u};
     if (cls == kClsItemsBig) {
         uint32_t deal = 0;
         if (d.deal) {
             const uint32_t di = (uint32_t)(pre(4) >> 32), c0 = (uint32_t)pre(5);
-            L.deals[di] = LongDeal{pre(6), (uint32_t)(pre(5) >> 32), d.nc, d.cap, (uint32_t)r};
+            if (lane == 0) L.deals[di] = LongDeal{pre(6), (uint32_t)(pre(5) >> 32), d.nc, d.cap, (uint32_t)r};
             deal = di + 1;
-            for (uint32_t j = 0; j < d.nc; ++j) { L.chunk_deal[c0 + j] = di; L.chunk_no[c0 + j] = j; }
+            for (uint32_t j = lane; j < d.nc; j += 64u) { L.chunk_deal[c0 + j] = di; L.chunk_no[c0 + j] = j; }
         }
         const uint32_t i0 = (uint32_t)(pre(2) >> 32);
-        for (uint32_t b = 0; b < d.P; ++b) L.items_big[i0 + b] = LongItem{(uint32_t)r, b, d.P, deal};
+        for (uint32_t b = lane; b < d.P; b += 64u) L.items_big[i0 + b] = LongItem{(uint32_t)r, b, d.P, deal};
     }
     if (p.own_search) {
         const uint32_t n_sl = p.cut ? (win + kSliceWindows - 1) / kSliceWindows : 1u;
         const uint32_t s0 = (uint32_t)pre(3);
-        if (n_sl > 1) L.combs[(uint32_t)(pre(3) >> 32)] = ReadCombine{(uint32_t)r, s0, n_sl, 0u};
+        if (n_sl > 1 && lane == 0) L.combs[(uint32_t)(pre(3) >> 32)] = ReadCombine{(uint32_t)r, s0, n_sl, 0u};
         const uint64_t W1 = w0 + win;
-        for (uint32_t j = 0; j < n_sl; ++j) {
+        for (uint32_t j = lane; j < n_sl; j += 64u) {
             const uint64_t a = w0 + (uint64_t)j * kSliceWindows;
             const uint64_t b = n_sl == 1 ? W1 : (a + kSliceWindows < W1 ? a + kSliceWindows : W1);
             L.slices[s0 + j] = ReadSlice{(uint32_t)r, (uint32_t)a, (uint32_t)b, j | (n_sl > 1 ? 0x80000000u : 0u)};
@@ -528,13 +573,15 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
             const uint64_t a = p.seq_off[s], len = p.seq_off[s + 1] - a;
             if (len < p.k) continue;
             const uint64_t nw = (len - p.k) / p.stride + 1;
-            for (uint64_t x = 0; x < nw; x += p.seg_win) {
+            const uint64_t n_sg = (nw + p.seg_win - 1) / p.seg_win;
+            for (uint64_t g = lane; g < n_sg; g += 64u) {
+                const uint64_t x = g * p.seg_win;
                 const uint32_t m = (uint32_t)(nw - x < p.seg_win ? nw - x : p.seg_win);
-                L.segs[sg] = Segment{a + x * p.stride, W, m, p.stride};
-                L.seg_read[sg] = (uint32_t)r;
-                ++sg;
-                W += m;
+                L.segs[sg + g] = Segment{a + x * p.stride, W + x, m, p.stride};
+                L.seg_read[sg + g] = (uint32_t)r;
             }
+            sg += (uint32_t)n_sg;
+            W += nw;
         }
     }
 }
@@ -1089,7 +1136,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     L.fused_small = d_fuse.p; L.fused_big = d_fuse.p + n_fs; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
     L.items_small = d_items.p; L.items_big = d_items.p + n_is;
     L.slices = d_slices.p; L.combs = d_combs.p; L.segs = d_segs.p; L.deals = d_deals.p;
-    hipLaunchKernelGGL(k_long_emit, dim3(grid_for_n(n_reads)), dim3(256), 0, st, pp, L);
+    hipLaunchKernelGGL(k_long_emit, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, pp, L);
     HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, n_words * 4, st));
     HIP_TRY(hipGetLastError());
     int h_flags[4] = {0, 0, 0, 0};
