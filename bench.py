@@ -904,7 +904,7 @@ def side_readid(a, dev, ctx, stream, with_oracle, reads=1_000_000, L=150):
             if oix is None:
                 oix = cpu_baseline_readid_index(ptr, m, n, k, C, rs)
             r.update(cpu_baseline_readid(oix, bases, seq_off, read0, report, nk, reads, mates, max_bytes, d, B))
-        rec[name] = r
+        rec[name] = traffic_fields(r, ms, reads, C, m, n, k, kernel="k_readid_pe" if mates == 2 else "k_readid_se")   # (units per launch: reads)
         del report, nk, st, seq_off, read0
     hx.close()
     return rec
@@ -961,6 +961,7 @@ def side_readid_long(a, dev, ctx, stream, with_oracle, total_bases=150_000_000):
             r.update(cpu_baseline_readid_long(oix, bases, seq_off, read0, report, nk, d, B))
         rec[name] = r
         if name == "reads_10kb":
+            traffic_fields(r, ms, reads, C, m, n, k, kernel="k_readid_slices")   # the search kernel's fetched bytes over the WHOLE call's time
             # Soft-masked reads (a lower-case stretch: its case is kept, SURVEY App. B Q2 — the byte-string path): ONE such read in the batch, and
             # 1 % of the reads.  Until round 5 one lower-case base sent the whole batch through round 1's global sort (2.5 x the time).
             soft = {}

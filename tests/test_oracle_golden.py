@@ -108,6 +108,20 @@ def test_sizing_kat_phage_b056(orc):  # 42 records, 33 726 bp, 32
     assert len(km) == 32634
 
 
+def test_sizing_kat_egd_e(orc):
+    """the 2 912 954 distinct canonical 31-mers of refs/LmonoEGDe.fasta (configs[0]'s query genome, 2.94 Mbp) — the
+    second sizing KAT the survey asked the C oracle to re-derive.  The genome is not a fixture of this repository (3 MB): the test runs in
+    the container that holds /root/reference and is skipped on the GPU box."""
+    path = "/root/reference/refs/LmonoEGDe.fasta"
+    if not os.path.exists(path):
+        pytest.skip("the reference tree is not mounted here")
+    seqs = orc.read_fasta(path)
+    km = orc.Kmers(31)
+    for s in seqs:
+        km.kmerize_vector(s, 1)
+    assert len(km) == 2_912_954
+
+
 def _write_ref_tsv(tmp_path):
     p = tmp_path / "ref_file.txt"
     # same shape as test_data/ref_file.txt (accession \t path), deliberately unsorted

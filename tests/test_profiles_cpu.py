@@ -66,7 +66,7 @@ def test_every_pmc_file_is_named_after_its_contents_and_derivable():
         # re-derive the traffic from the committed counter rows the file cites
         for s in j["sources"]:
             assert os.path.exists(os.path.join(ROOT, s)), s
-        mean = store.counters_mean(os.path.join(ROOT, j["sources"][0]), "k_search_count")
+        mean = store.counters_mean(os.path.join(ROOT, j["sources"][0]), j.get("match", "k_search_count"))
         rd, wr, _ = store.traffic_of(mean)
         assert abs(rd + wr - j["traffic_bytes"]) < 1e-6 * j["traffic_bytes"]
         assert j["traffic_bytes"] >= 0.99 * j["algorithmic_bytes"]
@@ -74,3 +74,14 @@ def test_every_pmc_file_is_named_after_its_contents_and_derivable():
 
 def test_no_fixed_name_summary_is_left():
     assert not os.path.exists(os.path.join(ROOT, "profiles", "pmc_search_count.json"))
+
+
+def test_readid_records_resolve_their_traffic():
+    """round 6: the read_id side records (150-bp reads single-end and paired, 10 kb reads) quote the fetched bytes of committed PMC
+    passes like the search records do (the chain was open for k_readid / k_readid_slices)"""
+    C, m, n, k = 256, 30_000_000, 2, 21
+    for kernel, units, lo, hi in (("k_readid_se", 1_000_000, 2.5e10, 4.5e10), ("k_readid_pe", 1_000_000, 5.0e10, 9.0e10),
+                                  ("k_readid_slices", 15_000, 3.0e10, 5.0e10)):
+        tr, src = bench.profiled_traffic(units, C, m, n, k, kernel)
+        assert tr is not None, src
+        assert lo < tr < hi, (kernel, tr)

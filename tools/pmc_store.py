@@ -42,12 +42,14 @@ def traffic_of(mean):
     return rd, wr, 2 * 1024 * mean.get("FETCH_SIZE", 0)
 
 
-def write(kernel, C, m, n, k, K, alg_bytes_per_kmer, mean, avg_ns, tag, sources, kernel_name=None):
+def write(kernel, C, m, n, k, K, alg_bytes_per_kmer, mean, avg_ns, tag, sources, kernel_name=None, match=None):
     rd, wr, rd_fetch = traffic_of(mean)
     out = {"kernel": kernel, "kernel_name": kernel_name, "tag": tag, "kmers_per_launch": K, "n_colors": C, "bloom_size": m, "num_hash": n,
            "k_size": k, "traffic_bytes": rd + wr, "read_bytes_rdreq": rd, "read_bytes_fetch_size_x2": rd_fetch, "write_bytes": wr,
            "algorithmic_bytes": alg_bytes_per_kmer * K, "alg_bytes_per_kmer": alg_bytes_per_kmer, "rocprof_avg_kernel_ns": avg_ns,
            "sources": sources, "counters_mean_per_launch": mean}
+    if match:
+        out["match"] = match   # the substring of the kernel's name that selects its rows in sources[0] (default: k_search_count)
     path = os.path.join(ROOT, pmc_path(kernel, C, m, n, k))
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:

@@ -26,9 +26,28 @@ with open(f"{dst}/{tag}_pmc.csv", "w") as out:
 ks = next(r for r in rows if "k_readid_slices" in r["Name"])
 t10, mix = bench["reads_10kb"], bench["mix_2k_10k_100k"]
 n = bench["config"]["num_hash"]
-# the bench makes 7 calls per shape, 10 kb first: the first 7 dispatches of k_readid_slices are the 10 kb ones
-lines10 = sum(acc["TCC_EA0_RDREQ_128B_sum"][:7]) / 7 if acc["TCC_EA0_RDREQ_128B_sum"] else 0
-wr10 = sum(acc["WRITE_SIZE"][:7]) / 7 * 1024 if acc["WRITE_SIZE"] else 0
+# the bench makes 7 calls per shape, 10 kb first: the first 7 dispatches of the plain k_readid_slices are the 10 kb ones (the BYTES
+# instantiation — the soft-masked reads' — follows every one of them and finds nothing to do on these reads)
+acc10 = collections.defaultdict(list)
+with open(f"{dst}/{tag}_pmc_10kb.csv", "w") as out10:
+    first = True
+    for fn in ("pmc_rdreq", "pmc_write"):
+        p = f"{src}/{fn}.csv"
+        if not os.path.exists(p):
+            continue
+        rows_p = list(csv.DictReader(open(p)))
+        plain = [r for r in rows_p if "k_readid_slices" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"].split("(")[0]]
+        ids = sorted({int(r["Dispatch_Id"]) for r in plain})[:7]
+        keep = [r for r in plain if int(r["Dispatch_Id"]) in ids]
+        w10 = csv.DictWriter(out10, fieldnames=rows_p[0].keys())
+        if first:
+            w10.writeheader(); first = False
+        w10.writerows(keep)
+        for r in keep:
+            acc10[r["Counter_Name"]].append(float(r["Counter_Value"]))
+mean10 = {c: sum(v) / len(v) for c, v in acc10.items()}
+lines10 = mean10.get("TCC_EA0_RDREQ_128B_sum", 0)
+wr10 = mean10.get("WRITE_SIZE", 0) * 1024
 trace = {r["Name"][:60]: (int(r["Calls"]), float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6) for r in rows}
 ms10 = float(ks["MaxNs"]) / 1e6   # the 10 kb shape holds more long-path k-mers than the mix: its dispatches are the slow ones
 md = f"""# {tag}: the long-read read_id path on MI355X — rocprofv3 evidence
@@ -59,4 +78,10 @@ Kernels (`{tag}_kernel_stats.csv`; both shapes in one run, 7 calls each; min / m
 `tools/gather_probe`).  The path's own passes (window codes, first-occurrence tables, scan) take the rest of the call.
 """
 open(f"{dst}/{tag}_summary.md", "w").write(md)
+import importlib.util
+spec = importlib.util.spec_from_file_location("pmc_store", os.path.join(ROOT, "tools", "pmc_store.py")); store = importlib.util.module_from_spec(spec); spec.loader.exec_module(store)
+c = bench["config"]
+pj = store.write("k_readid_slices", c["n_colors"], c["bloom_size"], c["num_hash"], c["k_size"], t10["reads"], int(t10["alg_bytes"] / t10["reads"]), mean10,
+                 ms10 * 1e6, tag, [f"profiles/{tag}_pmc_10kb.csv", f"profiles/{tag}_kernel_stats.csv"], ks["Name"][:100], match="k_readid_slices")
+print(os.path.relpath(pj, ROOT))
 print(md)

@@ -48,4 +48,11 @@ wave-instructions per read on window extraction, the per-read hash-table set and
 line-rate limit rather than at it.
 """
 open(os.path.join(dst, f"{tag}_readid_summary.md"), "w").write(md)
+# the per-workload traffic summary bench.py's `readid` record looks up (units per launch = reads)
+import importlib.util
+spec = importlib.util.spec_from_file_location("pmc_store", os.path.join(ROOT, "tools", "pmc_store.py")); store = importlib.util.module_from_spec(spec); spec.loader.exec_module(store)
+c = b["config"]
+pj = store.write("k_readid_pe" if b.get("paired") else "k_readid_se", c["C"], c["m"], c["n"], c["k"], b["reads"], int(alg / b["reads"]), mean, avg_ns, tag,
+                 [f"profiles/{tag}_readid_pmc.csv", f"profiles/{tag}_readid_kernel_stats.csv"], ks["Name"][:120], match="k_readid<")
+print(os.path.relpath(pj, ROOT))
 print(md)
