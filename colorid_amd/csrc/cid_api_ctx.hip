@@ -367,7 +367,7 @@ int cid_warmup(cid_ctx *c, unsigned what) {
     if (what & CID_WARM_INFLATE) HIP_TRY(cid::warm_inflate());
     if (what & CID_WARM_FASTQ) { hipStream_t s[4]; HIP_TRY(cid::ctx_side_streams(c, s)); }
     if (what & CID_WARM_FASTQ) HIP_TRY(cid::warm_fastq());
-    if (what & (CID_WARM_SEARCH | CID_WARM_READID)) {
+    if ((what & CID_WARM_PIPES) && (what & (CID_WARM_SEARCH | CID_WARM_READID)) && c->tune.warm_dry_run) {
         warm_dry_run(c->device, what);
         // ... and this context's own queues: the runtime makes a stream's hardware queue with the first command it is given (7-9 ms for the
         // copy stream, inside the first cid_kmerset_add_seqs).  A fill kernel and a 64-byte copy on each; HIP's streams may be used from any thread, and nothing

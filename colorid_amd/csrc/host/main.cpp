@@ -195,7 +195,10 @@ Gpus make_gpus(const Args &a) {
 }
 
 // The device code of the kernels a command will launch is loaded on a helper thread while the index loads (cid_warmup): the
-// runtime would otherwise load it inside the first search / read_id call (~60 ms for the read_id kernels).
+// runtime would otherwise load it inside the first search / read_id call (~60 ms for the read_id kernels).  The helper thread is on the
+// critical path when the index is small (a 1.7 GB index loads in 42 ms, the read_id units in 64-94): nothing goes in that does not pay for
+// itself — not CID_WARM_COLD (40 ms for a path few inputs take), not CID_WARM_PIPES (the index upload has woken the bus and the queues);
+// round 6 measured both: profiles/r06_warm_ab.txt.
 std::thread warm_async(const Gpus &g, unsigned what) {
     std::vector<cid_ctx *> ctxs;
     if (g.group) {
@@ -203,6 +206,7 @@ std::thread warm_async(const Gpus &g, unsigned what) {
         cid_group_size(g.group, &n);
         for (int r = 0; r < n; ++r) { cid_ctx *c = nullptr; if (cid_group_ctx(g.group, r, &c) == CID_OK) ctxs.push_back(c); }
     } else ctxs.push_back(g.ctx);
+    if (const char *e = cli_env("COLORID_WARM")) what = (unsigned)strtoul(e, nullptr, 0);   // (A/B runs: another mask, 0 = nothing ahead of its first use)
     return std::thread([ctxs, what] { for (cid_ctx *c : ctxs) (void)cid_warmup(c, what); });   // (a failure here shows up in the first real call)
 }
 
@@ -445,7 +449,7 @@ int cmd_read_id(int argc, char **argv) {
     read_ahead(fq, device_front_end);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_READID | CID_WARM_COLD | (device_front_end ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
+    std::thread warm = warm_async(gpus, CID_WARM_READID | (device_front_end ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);
@@ -482,7 +486,7 @@ int cmd_batch_id(int argc, char **argv) {
     if (!samples.empty()) read_ahead(samples[0].second, on_device[0]);
     Gpus gpus = make_gpus(a);
     phase_done("GPU context");
-    std::thread warm = warm_async(gpus, CID_WARM_READID | CID_WARM_COLD | (any_on_device ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
+    std::thread warm = warm_async(gpus, CID_WARM_READID | (any_on_device ? CID_WARM_INFLATE | CID_WARM_FASTQ : 0u));
     cid_ctx *ctx = gpus.ctx;
     Bigsi b = load_index(ctx, a, false, &gpus);
     replicate(gpus, b);

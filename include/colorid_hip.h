@@ -486,6 +486,10 @@ CID_CORE void cid_fastq_destroy(cid_fastq *);
 #define CID_WARM_SEARCH 2u
 #define CID_WARM_INFLATE 4u
 #define CID_WARM_FASTQ 8u /* the FASTQ front end (cid_fastq_*): its record / packing kernels and scans */
+#define CID_WARM_PIPES 32u /* with CID_WARM_SEARCH and/or CID_WARM_READID: a query of a few reads on a context of its own, a command on each of
+                            * this context's queues and 3 x 32 MB over the bus — what the first call after an idle start pays beyond its code
+                            * objects (9-10 ms of a 16 ms search, profiles/r06_first_use.txt).  For callers whose context sits idle before its
+                            * first query; a command line that has just uploaded an index gains nothing (its bus and queues are awake) */
 #define CID_WARM_COLD 16u /* the rocPRIM-built cold paths (10 MB of device code, ~40 ms): read_id's sorting path — long reads with k > 32, soft-masked
                            * reads of more than 16 384 windows — byte-string k-mer sets, reordering */
 CID_CORE int cid_warmup(cid_ctx *, unsigned what);

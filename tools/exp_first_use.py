@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What the FIRST `search` of a process costs beyond the steady state: a fresh process per case, the e2e step of
 bench.py (reads in host memory -> cid_kmerset for the index -> search + report, 1 M reads of 150 bp, 256 colours) four times, with the
-library's scratch allocations traced (CID_ALLOC_TRACE=1).  Cases: cold = nothing warmed; warmed = cid_warmup(CID_WARM_SEARCH) first (code
+library's scratch allocations traced (CID_ALLOC_TRACE=1).  Cases: cold = nothing warmed; warmed = cid_warmup(CID_WARM_SEARCH | CID_WARM_PIPES) first (code
 objects + a dry run of a few reads on a context of its own + this context's queues); small_first = warmed + a query of 2 000 reads before;
 host_touched = warmed + the reads' host buffer copied to the device once by the CALLER before the library sees it; pinned_input = warmed +
 the reads in page-locked memory from cid_pinned_alloc (where the command line keeps its batches).
@@ -29,7 +29,7 @@ rng = np.random.default_rng(1)
 reads = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(R, L))].copy()
 so = (np.arange(R + 1, dtype=np.uint64) * L)
 if case != "cold":
-    t = time.perf_counter(); check(ctx.lib.cid_warmup(ctx.h, 2)); print("warmup_ms", round((time.perf_counter() - t) * 1e3, 1), flush=True)
+    t = time.perf_counter(); check(ctx.lib.cid_warmup(ctx.h, 2 | 32)); print("warmup_ms", round((time.perf_counter() - t) * 1e3, 1), flush=True)
 if case == "small_first":   # a query of 2 000 reads first: whatever does not grow with the query is paid there
     t = time.perf_counter()
     ks = colorid_amd.KmerSet(ctx, k); ks.set_target_index(hx)
