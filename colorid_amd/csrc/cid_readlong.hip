@@ -37,14 +37,18 @@ namespace cid {
 
 constexpr uint32_t kLongIdxBits = 22, kLongTagBits = 10, kLongEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kLongMaxWin = (1u << kLongIdxBits) - 2;       // windows of one read the 4-byte slots can number
-constexpr uint32_t kLongSlotsBig = 32768, kLongBlockBig = 1024, kLongBmBig = 4096;   // 128 + 16 KiB of LDS, one workgroup of 16 waves per CU
+constexpr uint32_t kLongSlotsBig = 32768, kLongBlockBig = 1024, kLongBmBig = 6144;   // 128 + 24 KiB of LDS, one workgroup of 16 waves per CU
+constexpr uint32_t kDealQueue = kLongBmBig / (kLongBlockBig / 64);                    // a wave's queue of a dealt bucket's pass (the bitmap stretch is idle there)
 constexpr uint32_t kLongSlotsSmall = 8192, kLongBlockSmall = 256, kLongBmSmall = 128; // 32.5 KiB: reads of up to kLongSmallWin windows, four workgroups per CU
 constexpr uint32_t kLongSmallWin = 4096;
 constexpr uint32_t kLongFill = kLongSlotsBig / 2;                 // distinct k-mers a pass over a big table is planned for
 constexpr uint32_t kLongMaxLevel = 7;
 constexpr uint32_t kSliceWindows = 4096;                          // windows per slice of the search
 
-struct LongItem { uint32_t read, bucket, n_buckets, deal; };   // deal: 1 + index of the read's LongDeal, 0 = the pass reads the code array itself
+// One pass of k_long_first_flags: bucket `bucket` of `n_buckets` of read `read`.  deal: 1 + index of the read's LongDeal, 0 = the pass reads the
+// code array itself.  Everything the pass needs to start lies in the item (the read's windows, the dealt bucket's segments): looked up
+// one after the other — item, window range, deal, counts — a bucket's pass began with four trips to memory and nothing else to do.
+struct LongItem { uint32_t read, bucket, n_buckets, deal, nw, n_chunks, cap, count_base; uint64_t w0, pair_base; };
 // A read of several buckets, dealt: its windows are cut into chunks of kDealChunk, every chunk's (code, window) pairs of bucket b lie in
 // segment (b, chunk) of `cap` places — pairs[pair_base + (b * n_chunks + chunk) * cap ..], their number in counts[count_base + b * n_chunks + chunk].
 struct LongDeal { uint64_t pair_base; uint32_t count_base, n_chunks, cap, read; };
@@ -77,7 +81,10 @@ __device__ __forceinline__ uint32_t long_mix32(uint64_t code) {
 constexpr uint32_t kDealBlock = 1024, kDealStageFrom = 24;   // buckets from which a chunk's pairs are grouped in LDS before they are written
 __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongDeal *deals,
                                                            const uint32_t *chunk_deal, const uint32_t *chunk_no, uint32_t n_chunks_all, uint64_t sentinel,
-                                                           uint64_t *pair_code, uint32_t *pair_idx, uint32_t *counts, int *flags, uint8_t *redo) {
+                                                           uint64_t *pair_code, uint32_t *pair_idx, uint32_t *counts, int *flags, uint8_t *redo,
+                                                           uint32_t *bitmap) {
+    // The chunk's words of the read's bitmap are written here, a bit for every window that holds a k-mer: the buckets' passes
+    // (k_long_first_flags) take the bits of the later occurrences OUT instead of putting the first occurrences' in.
     // A chunk's windows are first grouped by bucket in LDS (their numbers only: 64 KiB), then every bucket's pairs leave as one stretch:
     // written straight from the window loop a wave's 64 pairs went to forty different segments, 8 and 4 bytes at a time — 2.5 ms per 150 M
     // windows of 1 Mb reads, the price of 64-byte memory transactions for 12 bytes.
@@ -93,9 +100,13 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
         if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
         __syncthreads();
         if (P < kDealStageFrom) {   // (uniform) few buckets: a wave's pairs fall into few segments as they are — 100 kb reads 9.4 ms so, 9.9 staged
-            for (uint32_t w = a + threadIdx.x; w < b; w += kDealBlock) {
-                const uint64_t code = codes[w0 + w];
-                if (code >= sentinel) continue;
+            for (uint32_t wb = a; wb < b; wb += kDealBlock) {   // (a is a multiple of 64 and so is every wave's first window)
+                const uint32_t w = wb + threadIdx.x;
+                const uint64_t code = w < b ? codes[w0 + w] : sentinel;
+                const bool valid = code < sentinel;
+                const uint64_t vm = __ballot(valid);
+                if ((threadIdx.x & 31u) == 0 && w < b) bitmap[(w0 + w) >> 5] = (uint32_t)(vm >> (threadIdx.x & 32u));
+                if (!valid) continue;
                 const uint32_t bk = (uint32_t)(((long_mix(code) >> 32) * P) >> 32);
                 const uint32_t at = atomicAdd(&s_cnt[bk], 1u);
                 if (at < d.cap) {
@@ -109,10 +120,13 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
             __syncthreads();
             continue;
         }
-        for (uint32_t w = a + threadIdx.x; w < b; w += kDealBlock) {
-            const uint64_t code = codes[w0 + w];
-            if (code >= sentinel) continue;
-            atomicAdd(&s_cnt[(uint32_t)(((long_mix(code) >> 32) * P) >> 32)], 1u);
+        for (uint32_t wb = a; wb < b; wb += kDealBlock) {
+            const uint32_t w = wb + threadIdx.x;
+            const uint64_t code = w < b ? codes[w0 + w] : sentinel;
+            const bool valid = code < sentinel;
+            const uint64_t vm = __ballot(valid);
+            if ((threadIdx.x & 31u) == 0 && w < b) bitmap[(w0 + w) >> 5] = (uint32_t)(vm >> (threadIdx.x & 32u));
+            if (valid) atomicAdd(&s_cnt[(uint32_t)(((long_mix(code) >> 32) * P) >> 32)], 1u);
         }
         __syncthreads();
         if (threadIdx.x < 64) {   // exclusive prefix over the (<= 256) bucket counts: four per lane
@@ -155,24 +169,49 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
     }
 }
 
+#ifdef CID_LONG_PROF
+__device__ unsigned long long g_ff_prof[8];   // k_long_first_flags: cycles per phase, summed over the workgroups (thread 0's clock)
+#define FF_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_ff_prof[i], t_ - ff_t); ff_t = t_; } } while (0)
+#else
+#define FF_MARK(i) do { } while (0)
+#endif
 // One workgroup per work item at a time; XCD x walks the x-th eighth of the items so that the passes over one read's codes meet in
 // one L2 (workgroups are dealt to the XCDs in turn).  gridDim.x is a multiple of 8.
 __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongItem *items, uint32_t n_items, uint64_t sentinel,
                                    uint32_t slots, uint32_t bm_words, uint32_t *bitmap, int *flags, const LongDeal *deals, const uint64_t *pair_code,
                                    const uint32_t *pair_idx, const uint32_t *deal_counts, uint8_t *redo) {
+    (void)wstart; (void)wend; (void)deals;   // (the items carry what these held)
     extern __shared__ __align__(16) uint32_t table[];   // slots, then bm_words: the stretch of the read's bitmap being put together
     __shared__ int s_over;
-    __shared__ uint32_t s_pref[kLongMaxChunks + 1];   // a dealt bucket: pairs in its segment of chunk j
+    __shared__ uint32_t s_pref2[2][kLongMaxChunks + 1];   // a dealt bucket: pairs in its segment of chunk j (this item's, the next one's)
     __shared__ uint32_t s_wsum[kLongBlockBig / 64];
     uint32_t *bm = table + slots;
     const uint32_t max_slots = slots, bm_bits = bm_words * 32u;
     const uint32_t chunk = (n_items + 7u) / 8u;
-    for (uint32_t it = blockIdx.x >> 3; it < chunk; it += gridDim.x >> 3) {
-        const uint32_t item = (blockIdx.x & 7u) * chunk + it;
-        if (item >= n_items) break;
-        const LongItem im = items[item];
-        const uint64_t w0 = wstart[im.read];
-        const uint32_t nw = (uint32_t)(wend[im.read] - w0);   // (wstart[read + 1] lies beyond the padding)
+#ifdef CID_LONG_PROF
+    unsigned long long ff_t = __builtin_readcyclecounter();
+#endif
+    // The items of this workgroup, three in hand: the one being worked on, the next (whose counts are asked for now and stored at this
+    // item's end) and the one after (asked for now).  A bucket's pass is forty-odd microseconds of which the trips to memory for its own
+    // description were a third, with one workgroup to a CU and nothing to run meanwhile.
+    const uint32_t it_step = gridDim.x >> 3, it_base = (blockIdx.x & 7u) * chunk;
+    auto item_at = [&](uint32_t it, LongItem &o) -> bool {   // (workgroup-uniform)
+        if (it >= chunk || it_base + it >= n_items) return false;
+        o = items[it_base + it];
+        return true;
+    };
+    uint32_t it = blockIdx.x >> 3, pb = 0;
+    LongItem im{}, nxt{}, nn{};
+    bool have_im = item_at(it, im), have_nxt = item_at(it + it_step, nxt);
+    if (have_im && im.deal) for (uint32_t j = threadIdx.x; j < im.n_chunks; j += blockDim.x) s_pref2[0][j] = deal_counts[im.count_base + im.bucket * im.n_chunks + j];
+    bool have_nn = false;
+    for (; have_im; im = nxt, nxt = nn, have_im = have_nxt, have_nxt = have_nn, it += it_step, pb ^= 1u) {
+        have_nn = item_at(it + 2u * it_step, nn);
+        uint32_t cnt_next = 0;   // (n_chunks <= 256 <= blockDim.x)
+        if (have_nxt && nxt.deal && threadIdx.x < nxt.n_chunks) cnt_next = deal_counts[nxt.count_base + nxt.bucket * nxt.n_chunks + threadIdx.x];
+        uint32_t *s_pref = s_pref2[pb];
+        const uint64_t w0 = im.w0;
+        const uint32_t nw = im.nw;
         const uint64_t *rc = codes + w0;
         // a short read takes a corner of the table: clearing and sweeping it is what a pass costs beyond its inserts
         slots = 1024;
@@ -183,6 +222,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
             for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) table[s] = kLongEmpty;
             if (threadIdx.x == 0) s_over = 0;
             __syncthreads();
+            FF_MARK(0);
             auto insert = [&](uint64_t code, uint32_t w, uint64_t h) {
                 const uint32_t tag = (uint32_t)(h >> 15) & ((1u << kLongTagBits) - 1u);
                 const uint32_t mine = (w << kLongTagBits) | tag;
@@ -201,41 +241,146 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                     if (probes >= slots / 4) { s_over = 1; break; }   // a crowded table: the pass is redone on sub-buckets
                 }
             };
-            if (im.deal) {   // the bucket's own pairs: its segments (one per chunk of the read, a few hundred pairs each) walked as ONE index space —
-                // chunk after chunk, a segment kept a quarter of the workgroup busy and every chunk paid a memory round trip for its count
-                // (1 Mb reads: 61 chunks, 187 us per bucket against 23 us for a whole 10 kb read)
-                const LongDeal d = deals[im.deal - 1];
-                if (sub == 0 || level) {   // (the counts are the same in every pass; the table's clearing barrier above separates the passes)
-                    for (uint32_t j = threadIdx.x; j < d.n_chunks; j += blockDim.x) s_pref[j] = deal_counts[d.count_base + im.bucket * d.n_chunks + j];
-                    __syncthreads();
-                }
-                // The bucket's segments lie side by side, `cap` places each: the places are walked as they lie — place x = (chunk x / cap, pair
-                // x % cap), taken when the chunk holds that many — four of them in flight per thread.  (Round 5 walked the PAIRS as one index
-                // space: a binary search over the chunks' prefix per pair, eight dependent LDS reads before its two loads could be asked for:
-                // 96 us per bucket of a 1 Mb read.)
-                const uint32_t cap = d.cap, span = d.n_chunks * cap;
-                const uint64_t inv = ((1ull << 40) + cap - 1) / cap;   // x / cap = (x * inv) >> 40 for x < 2^24
-                const uint64_t o0 = d.pair_base + (uint64_t)im.bucket * d.n_chunks * d.cap;
-                for (uint32_t x0 = threadIdx.x; x0 < span; x0 += 4u * blockDim.x) {
-                    uint64_t code4[4];
-                    uint32_t idx4[4];
-                    bool have[4];
+            if (im.deal) {   // the bucket's own pairs: segment j (one per chunk of the read, `cap` places) holds s_pref[j] of them
+                FF_MARK(1);
+                // This pass is bound by the INSTRUCTIONS it issues (SQ counters, 100 kb reads: 3 070 vector and 2 800 scalar instructions per
+                // wave and bucket, the vector unit busy for more than half of the kernel's cycles at four waves to a SIMD; without its inserts
+                // the kernel took 0.54 of its 1.45 ms), so the common k-mer's way through it is made short:
+                //  * a WAVE takes a segment (a part of one when the read has fewer segments than the workgroup has waves), its lanes the pairs
+                //    that are there — no place without a pair is visited, no division finds a place's segment;
+                //  * the next 256 pairs are asked for before the current 256 are inserted, every load unconditional (loads under a condition
+                //    are loads the compiler waits for one by one — and for the next ones with them);
+                //  * the table is buckets of four slots filled from the front.  ONE 16-byte read shows a k-mer its bucket; no equal tag there
+                //    and a free slot: one compare-and-swap claims it, a lane's four k-mers in step and without a branch (a claim that is not
+                //    wanted compares with a word no slot ever holds).  Everything else — an equal tag, a full bucket, a claim lost to another
+                //    lane: one k-mer in twenty — is put aside in the wave's queue and inserted the general way, 64 lanes at a time: written
+                //    where it happens, the rare case costs every k-mer of the wave its instructions;
+                //  * a slot holds the PLACE of its k-mer's pair (16 bits: a bucket's places are fewer than 45 056) and 16 bits of tag: with the
+                //    window (22 bits) and 10 bits of tag one occupied slot in a thousand sent its wave to memory to compare the codes.  Which of
+                //    two equal k-mers came first is asked of their windows in memory when they meet — repeats only — and the later one's
+                //    bit leaves the bitmap k_long_deal wrote: found exactly once, whichever lane finds it.
+                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+                const uint32_t nc = im.n_chunks, cap = im.cap;
+                const uint32_t parts = nc < n_waves ? n_waves / nc : 1u, units = nc * parts;
+                const uint64_t *pc = pair_code + im.pair_base + (uint64_t)im.bucket * nc * cap;
+                const uint32_t *pi = pair_idx + im.pair_base + (uint64_t)im.bucket * nc * cap;
+                const uint32_t bmask = (slots >> 2) - 1u, tmask = 0xFFFFu;
+                const uint64_t lt_mask = (1ull << lane) - 1ull;
+                uint32_t *queue = bm + wave * kDealQueue;
+                uint32_t q_n = 0;
+                auto general = [&](uint32_t x) {   // place x's k-mer into the table, whatever it meets
+                    const uint64_t code = pc[x];
+                    const uint32_t w = pi[x];
+                    const uint32_t h = long_mix32(code), m = (x << 16) | ((h >> 13) & tmask);
+                    uint32_t bk = h & bmask;
+                    for (uint32_t steps = 0;; ++steps) {
+                        const uint4 v = reinterpret_cast<const uint4 *>(table)[bk];
+                        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+                        uint32_t used = 0;
+                        bool done = false;
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q) {
+                            if (done || e[q] == kLongEmpty) continue;
+                            ++used;
+                            if ((e[q] ^ m) & tmask) continue;
+                            uint32_t cur = e[q];
+                            if (pc[cur >> 16] != code) continue;
+                            uint32_t later;   // the slot is this k-mer's: the earlier window of the two keeps it
+                            for (;;) {
+                                const uint32_t wo = pi[cur >> 16];
+                                if (wo < w) { later = w; break; }
+                                const uint32_t got = atomicCAS(&table[4u * bk + q], cur, m);
+                                if (got == cur) { later = wo; break; }
+                                cur = got;   // (another pair of this k-mer took the slot meanwhile)
+                            }
+                            const uint64_t lw = w0 + later;
+                            atomicAnd(&bitmap[lw >> 5], ~(1u << (lw & 31u)));
+                            done = true;
+                        }
+                        if (done) break;
+                        if (used < 4) { if (atomicCAS(&table[4u * bk + used], kLongEmpty, m) == kLongEmpty) break; }   // (else: the bucket once more)
+                        else bk = (bk + 1u) & bmask;
+                        if (steps >= 256u) { s_over = 1; break; }   // a crowded table: the pass is redone on sub-buckets
+                    }
+                };
+                auto drain = [&]() {
+                    wave_lds_fence();
+                    for (uint32_t b = 0; b < q_n; b += 64u) if (b + lane < q_n) general(queue[b + lane]);
+                    wave_lds_fence();
+                    q_n = 0;
+                };
+                // the wave's stretches of 256 pairs, one after the other: (seg0 + i .. seg0 + end) in the bucket's places
+                uint32_t unit = wave, seg0 = 0, i = 0, end = 0;
+                auto open_unit = [&]() -> bool {
+                    for (; unit < units; unit += n_waves) {
+                        const uint32_t j = parts > 1u ? unit % nc : unit, part = parts > 1u ? unit / nc : 0u;
+                        const uint32_t c = s_pref[j], per = ((c + parts - 1u) / parts + 63u) & ~63u;
+                        i = part * per;
+                        end = c < i + per ? c : i + per;
+                        seg0 = j * cap;
+                        if (i < end) return true;
+                    }
+                    return false;
+                };
+                uint64_t code_n[4];
+                uint32_t w_n[4], x_n[4];
+                bool have_n[4];
+                auto fetch = [&]() {
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t x = x0 + u * blockDim.x;
-                        const uint32_t j = (uint32_t)(((uint64_t)x * inv) >> 40);
-                        have[u] = x < span && x - j * cap < s_pref[j];
-                        code4[u] = have[u] ? pair_code[o0 + x] : 0ull;
-                        idx4[u] = have[u] ? pair_idx[o0 + x] : 0u;
+                        const uint32_t at = i + lane + 64u * u;
+                        have_n[u] = at < end;
+                        x_n[u] = seg0 + (have_n[u] ? at : i);
+                        code_n[u] = pc[x_n[u]];
+                        w_n[u] = pi[x_n[u]];
                     }
+                };
+                bool more = open_unit();
+                if (more) fetch();
+                while (more) {
+                    uint32_t bk4[4], mine4[4], x4[4], act = 0;
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u) {
-                        if (!have[u]) continue;
-                        const uint64_t h = long_mix(code4[u]);
-                        if (level && ((uint32_t)(h >> 25) & ((1u << level) - 1u)) != sub) continue;
-                        insert(code4[u], idx4[u], h);
+                        const uint32_t h = long_mix32(code_n[u]);
+                        x4[u] = x_n[u];
+                        bk4[u] = h & bmask;
+                        mine4[u] = (x_n[u] << 16) | ((h >> 13) & tmask);
+                        if (have_n[u] && (!level || ((h >> 25) & ((1u << level) - 1u)) == sub)) act |= 1u << u;
                     }
+                    i += 256u;
+                    if (i >= end) { unit += n_waves; more = open_unit(); }
+                    if (more) fetch();
+                    FF_MARK(2);
+                    if (q_n > kDealQueue - 256u) drain();   // (wave-uniform)
+                    uint4 v4[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) v4[u] = reinterpret_cast<const uint4 *>(table)[bk4[u]];
+                    uint32_t at4[4], cmp4[4], cas4[4], want = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint4 v = v4[u];
+                        const uint32_t m = mine4[u];
+                        const bool n0 = v.x != kLongEmpty, n1 = v.y != kLongEmpty, n2 = v.z != kLongEmpty, n3 = v.w != kLongEmpty;
+                        const uint32_t used = (uint32_t)n0 + (uint32_t)n1 + (uint32_t)n2 + (uint32_t)n3;
+                        const bool tag = (n0 && !((v.x ^ m) & tmask)) || (n1 && !((v.y ^ m) & tmask)) || (n2 && !((v.z ^ m) & tmask)) || (n3 && !((v.w ^ m) & tmask));
+                        const bool claim = ((act >> u) & 1u) && !tag && used < 4u;
+                        at4[u] = 4u * bk4[u] + (claim ? used : 0u);
+                        cmp4[u] = claim ? kLongEmpty : kLongEmpty - 1u;
+                        if (claim) want |= 1u << u;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) cas4[u] = atomicCAS(&table[at4[u]], cmp4[u], mine4[u]);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const bool aside = ((act >> u) & 1u) && !(((want >> u) & 1u) && cas4[u] == kLongEmpty);
+                        const uint64_t am = __ballot(aside);
+                        if (aside) queue[q_n + (uint32_t)__popcll(am & lt_mask)] = x4[u];
+                        q_n += (uint32_t)__popcll(am);
+                    }
+                    FF_MARK(3);
                 }
+                if (q_n) drain();
+                FF_MARK(5);
             } else
             for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
                 const uint64_t code = rc[w];
@@ -246,6 +391,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                 insert(code, w, h);
             }
             __syncthreads();
+            FF_MARK(4);
             if (s_over) {   // (workgroup-uniform)
                 if (level == kLongMaxLevel) {
                     if (threadIdx.x == 0) { redo[im.read] = 1; atomicOr(&flags[1], 1); }   // the host redoes this read on the sorting path
@@ -256,6 +402,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                 __syncthreads();
                 continue;
             }
+            if (im.deal) continue;   // (workgroup-uniform) nothing to add: the later occurrences' bits went as they were met
             // The winners' bits: put together in LDS, a stretch of bm_bits windows at a time, and written out as whole words (a read's
             // windows start at a multiple of 32, so its words are its own).  One global atomicOr per BIT took 4.4 of this kernel's
             // 5.4 ms on 150 Mbases of 10 kb reads: the atomics of a read all fall into its dozen of 128-byte lines.
@@ -317,6 +464,7 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
                 __syncthreads();
             }
         }
+        if (have_nxt && nxt.deal && threadIdx.x < nxt.n_chunks) s_pref2[pb ^ 1u][threadIdx.x] = cnt_next;   // (read after the next table's clearing barrier)
     }
 }
 
@@ -542,17 +690,20 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
         else L.fused_big[(uint32_t)(pre(1) >> 32)] = it;
     }
     const LongDealShape d = long_deal_shape(win, cls, p.deal);
-    if (cls == kClsItemsSmall && lane == 0) L.items_small[(uint32_t)pre(2)] = LongItem{(uint32_t)r, 0u, 1u, 0u};
+    if (cls == kClsItemsSmall && lane == 0) L.items_small[(uint32_t)pre(2)] = LongItem{(uint32_t)r, 0u, 1u, 0u, win, 0u, 0u, 0u, w0, 0ull};
     if (cls == kClsItemsBig) {
-        uint32_t deal = 0;
+        uint32_t deal = 0, count_base = 0;
+        uint64_t pair_base = 0;
         if (d.deal) {
             const uint32_t di = (uint32_t)(pre(4) >> 32), c0 = (uint32_t)pre(5);
-            if (lane == 0) L.deals[di] = LongDeal{pre(6), (uint32_t)(pre(5) >> 32), d.nc, d.cap, (uint32_t)r};
+            pair_base = pre(6);
+            count_base = (uint32_t)(pre(5) >> 32);
+            if (lane == 0) L.deals[di] = LongDeal{pair_base, count_base, d.nc, d.cap, (uint32_t)r};
             deal = di + 1;
             for (uint32_t j = lane; j < d.nc; j += 64u) { L.chunk_deal[c0 + j] = di; L.chunk_no[c0 + j] = j; }
         }
         const uint32_t i0 = (uint32_t)(pre(2) >> 32);
-        for (uint32_t b = lane; b < d.P; b += 64u) L.items_big[i0 + b] = LongItem{(uint32_t)r, b, d.P, deal};
+        for (uint32_t b = lane; b < d.P; b += 64u) L.items_big[i0 + b] = LongItem{(uint32_t)r, b, d.P, deal, win, d.nc, d.cap, count_base, w0, pair_base};
     }
     if (p.own_search) {
         const uint32_t n_sl = p.cut ? (win + kSliceWindows - 1) / kSliceWindows : 1u;
@@ -1157,7 +1308,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
                 if (g > n_cu * 8u) g = n_cu * 8u;
                 hipLaunchKernelGGL(k_long_deal, dim3(g), dim3(kDealBlock), 0, st, d_codes.p, d_wstart.p, d_wend.p, (const LongDeal *)d_deals.p,
                                    (const uint32_t *)L.chunk_deal, (const uint32_t *)L.chunk_no, n_chunks, sentinel, d_pair_code.p, d_pair_idx.p, d_deal_counts.p,
-                                   d_flags.p, d_redo.p);
+                                   d_flags.p, d_redo.p, d_bitmap.p);
             }
             if (n_is) {
                 unsigned g = n_cu * 4u;   // four 32-KiB workgroups per CU
@@ -1173,6 +1324,15 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
                 hipLaunchKernelGGL(k_long_first_flags, dim3(g), dim3(kLongBlockBig), (kLongSlotsBig + kLongBmBig) * 4, st, d_codes.p, d_wstart.p, d_wend.p,
                                    (const LongItem *)L.items_big, n_ib, sentinel, kLongSlotsBig, kLongBmBig, d_bitmap.p, d_flags.p, (const LongDeal *)d_deals.p,
                                    d_pair_code.p, d_pair_idx.p, d_deal_counts.p, d_redo.p);
+#ifdef CID_LONG_PROF
+                unsigned long long hp[8];
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_ff_prof), sizeof(hp)));
+                fprintf(stderr, "k_long_first_flags<big> %u items, cycles per item: clear %llu, setup %llu, fetch %llu, inserts %llu, drain %llu, barrier %llu\n", n_ib, hp[0] / n_ib,
+                        hp[1] / n_ib, hp[2] / n_ib, hp[3] / n_ib, hp[5] / n_ib, hp[4] / n_ib);
+                unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ff_prof), z, sizeof(z)));
+#endif
             }
         }
         LongFuseParams fp{};

@@ -90,7 +90,8 @@ def test_megabase_read_and_many_buckets(orc, hip_ctx, deal):
     oix = random_index(orc, rng, m, n_hash, k, n_colors, density=0.2, zero_row_frac=0.0)
     hx = to_hip_index(hip_ctx, oix)
     g = rnd(rng, 1_200_000)
-    reads = [[g], [g[:300_000] + g[:300_000]], [g[:5_000]]]
+    reads = [[g], [g[:300_000] + g[:300_000]], [g[:5_000]],
+             [g[:100_000] + b"N" * 70 + g[50_000:150_000] + b"N" + g[:60_000], g[140_000:100_000:-1]]]   # N runs and third occurrences among dealt windows
     try:
         rep, nk, st = compare(oix, hx, reads, 1, 3)
     finally:
