@@ -513,12 +513,18 @@ enum LongClass : uint8_t {
     kClsShort = 1,      // the first mate has no window (status 1: too_short)
     kClsFusedSmall = 2, // one hash table; codes and table in ONE kernel (k_long_fused), 256 threads / 8 192 slots
     kClsFusedBig = 3,   //   ... 1 024 threads / 32 768 slots
-    kClsItemsSmall = 4, // k_extract_codes + k_long_first_flags: reads whose bases do not fit the fused kernel's LDS (strides), many mates
-    kClsItemsBig = 5,   //   ... and every read of several buckets
-    kClsSorted = 6      // more windows than a 4-byte slot numbers: the sorting path (redo[r] is set from the start)
+    kClsFusedMulti = 4, //   ... the same table filled up to three times, a third of the read's k-mers each time (reads of up to 49 152 windows)
+    kClsItemsSmall = 5, // k_extract_codes + k_long_first_flags: reads whose bases do not fit the fused kernel's LDS (strides), many mates
+    kClsItemsBig = 6,   //   ... and every read of several buckets
+    kClsSorted = 7      // more windows than a 4-byte slot numbers: the sorting path (redo[r] is set from the start)
 };
 constexpr uint32_t kFuseSeqs = 4;                 // sequences (mates) of a read the fused kernel keeps a table of
 constexpr uint32_t kFusePosSmall = 6144, kFusePosBig = 20480;   // positions (bases, each mate padded to its 16-byte pieces) of a read in its LDS
+// Reads of 16 385 .. 49 152 windows (what a long-read sequencer's run mostly consists of) used to leave the fused kernel for k_extract_codes +
+// k_long_first_flags, two and three buckets each re-reading the read's codes: 9.2 ms per 150 Mbases at 30 kb against 7.0 at 10 kb.  Their
+// bases fit the LDS beside the table all the same (3 bits a base), so the fused kernel takes them in PASSES: the table is filled with the
+// k-mers of one hash bucket, its winners' bits join the read's bitmap in LDS, and again for the next bucket.
+constexpr uint32_t kFusePassesMax = 3, kFuseWinMulti = kFusePassesMax * kLongFill, kFusePosMulti = 51200, kFusePiecesMulti = 4;
 constexpr uint32_t kPlanFields = 7, kPlanPer = 4, kPlanTile = kScanBlock * kPlanPer;
 struct LongPlanParams {
     const uint64_t *seq_off, *read_seq0;
@@ -526,7 +532,7 @@ struct LongPlanParams {
     const uint8_t *bases;     // (only its address: the 16-byte pieces of the fused kernel are pieces of the address space)
     uint64_t n_reads;
     uint32_t k, stride, seg_win;
-    uint32_t fuse, cut, own_search, deal;
+    uint32_t fuse, cut, own_search, deal, multi;
     // out
     uint64_t *wstart, *wend;   // [n_reads + 1], [n_reads]
     uint32_t *win;             // [n_reads]
@@ -536,6 +542,7 @@ struct LongPlanParams {
     uint64_t *totals;          // [kPlanFields + 1]
     int *flags;
 };
+constexpr uint32_t kPlanMultiShift = 46;   // (places: fewer than 2^34 of them; reads of the third list: fewer than 2^18)
 struct LongRow { uint32_t win, segs, cls; };
 __device__ __forceinline__ LongRow long_row(const LongPlanParams &p, uint64_t r) {
     LongRow o{0u, 0u, kClsOther};
@@ -559,8 +566,9 @@ __device__ __forceinline__ LongRow long_row(const LongPlanParams &p, uint64_t r)
     const bool can_fuse = p.fuse && nk <= kFuseSeqs;
     if (can_fuse && win <= kLongSmallWin && pos <= kFusePosSmall) o.cls = kClsFusedSmall;
     else if (can_fuse && win <= kLongFill && pos <= kFusePosBig) o.cls = kClsFusedBig;
+    else if (can_fuse && p.multi && win <= kFuseWinMulti && pos <= kFusePosMulti) o.cls = kClsFusedMulti;
     else o.cls = win <= kLongSmallWin ? kClsItemsSmall : kClsItemsBig;
-    if (o.cls == kClsFusedSmall || o.cls == kClsFusedBig) o.segs = 0;
+    if (o.cls >= kClsFusedSmall && o.cls <= kClsFusedMulti) o.segs = 0;
     return o;
 }
 // what read r adds to each of the seven lists
@@ -586,7 +594,7 @@ __device__ __forceinline__ void long_fields(const LongPlanParams &p, const LongR
     v[3] = (uint64_t)n_sl | (n_sl > 1 ? 1ull << 32 : 0ull);                                              // slices | reads of several slices
     v[4] = (uint64_t)row.segs | (d.deal ? 1ull << 32 : 0ull);                                            // k_extract_codes' segments | deals
     v[5] = (uint64_t)d.nc | ((uint64_t)d.P * d.nc) << 32;                                                // chunks of dealt reads | their segment counters
-    v[6] = (uint64_t)d.P * d.nc * d.cap;                                                                 // places of dealt pairs
+    v[6] = (uint64_t)d.P * d.nc * d.cap | (row.cls == kClsFusedMulti ? 1ull << kPlanMultiShift : 0ull);   // places of dealt pairs | the fused kernel's third list
 }
 __global__ __launch_bounds__(kScanBlock) void k_long_plan(LongPlanParams p) {
     const uint64_t n = p.n_reads + 1;   // (element n_reads: empty — it receives the totals' positions, wstart[n_reads] among them)
@@ -645,7 +653,7 @@ struct FuseItem {
     uint32_t first[kFuseSeqs], len[kFuseSeqs], wbase[kFuseSeqs], piece0[kFuseSeqs];
 };
 struct LongLists {
-    FuseItem *fused_small, *fused_big;
+    FuseItem *fused_small, *fused_big, *fused_multi;
     LongItem *items_small, *items_big;
     ReadSlice *slices;
     ReadCombine *combs;
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
     const uint32_t win = p.win[r];
     const uint64_t w0 = p.wstart[r];
     auto pre = [&](uint32_t f) { return p.pre[(size_t)f * n + r]; };
-    if ((cls == kClsFusedSmall || cls == kClsFusedBig) && lane == 0) {
+    if (cls >= kClsFusedSmall && cls <= kClsFusedMulti && lane == 0) {
         FuseItem it{};
         it.read = (uint32_t)r; it.nw = win; it.w0 = w0;
         uint32_t ns = 0, wb = 0, piece = 0;
@@ -687,7 +695,8 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
         }
         it.n_seq = ns; it.n_pieces = piece;
         if (cls == kClsFusedSmall) L.fused_small[(uint32_t)pre(1)] = it;
-        else L.fused_big[(uint32_t)(pre(1) >> 32)] = it;
+        else if (cls == kClsFusedBig) L.fused_big[(uint32_t)(pre(1) >> 32)] = it;
+        else L.fused_multi[(uint32_t)(pre(6) >> kPlanMultiShift)] = it;
     }
     const LongDealShape d = long_deal_shape(win, cls, p.deal);
     if (cls == kClsItemsSmall && lane == 0) L.items_small[(uint32_t)pre(2)] = LongItem{(uint32_t)r, 0u, 1u, 0u, win, 0u, 0u, 0u, w0, 0ull};
@@ -696,7 +705,7 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
         uint64_t pair_base = 0;
         if (d.deal) {
             const uint32_t di = (uint32_t)(pre(4) >> 32), c0 = (uint32_t)pre(5);
-            pair_base = pre(6);
+            pair_base = pre(6) & ((1ull << kPlanMultiShift) - 1ull);
             count_base = (uint32_t)(pre(5) >> 32);
             if (lane == 0) L.deals[di] = LongDeal{pair_base, count_base, d.nc, d.cap, (uint32_t)r};
             deal = di + 1;
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
 // A read with a lower-case base (its case would have to be kept: SURVEY App. B Q2) or a table that crowds anyway marks redo[read].
 struct LongFuseParams {
     const FuseItem *items;
-    uint32_t n_list, k, msz, stride, max_slots, pos_cap;
+    uint32_t n_list, k, msz, stride, max_slots, pos_cap, bm_words;   // bm_words: the read's bitmap in LDS (its windows / 32)
     uint64_t sentinel;       // of the keys (k-mers, or minimizers)
     uint64_t *codes;
     uint32_t *bitmap;
@@ -764,12 +773,12 @@ struct LongFuseParams {
 #else
 #define LONG_PROF_MARK(i) do { } while (0)
 #endif
-// this thread's (at most two) 16-byte pieces of a read's bases; a piece of padding behind a mate is never loaded
-template <uint32_t BLOCK>
-__device__ __forceinline__ void fuse_load_pieces(const FuseItem *it, uint4 (&pc)[2]) {
+// this thread's (at most PIECES) 16-byte pieces of a read's bases; a piece of padding behind a mate is never loaded
+template <uint32_t BLOCK, uint32_t PIECES>
+__device__ __forceinline__ void fuse_load_pieces(const FuseItem *it, uint4 (&pc)[PIECES]) {
     const uint32_t ns = it->n_seq, n_pieces = it->n_pieces;
 #pragma unroll
-    for (uint32_t j = 0; j < 2; ++j) {
+    for (uint32_t j = 0; j < PIECES; ++j) {
         const uint32_t x = threadIdx.x + j * BLOCK;
         pc[j] = uint4{0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};   // 'N'
         if (x >= n_pieces) continue;
@@ -779,26 +788,29 @@ __device__ __forceinline__ void fuse_load_pieces(const FuseItem *it, uint4 (&pc)
         if (x * 16u < it->first[q] + it->len[q]) pc[j] = *reinterpret_cast<const uint4 *>(it->addr[q] + (uint64_t)(x - it->piece0[q]) * 16u);
     }
 }
-template <uint32_t BLOCK, uint32_t ITERS>
+// MULTI: reads of up to kFuseWinMulti windows, their k-mers dealt to ceil(windows / kLongFill) hash buckets and the table filled once per
+// bucket — every pass walks all the read's windows (the rolling codes are the cheap part) and inserts its own bucket's.
+template <uint32_t BLOCK, uint32_t ITERS, bool MULTI = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
+    constexpr uint32_t PIECES = MULTI ? kFusePiecesMulti : 2u;
     extern __shared__ __align__(16) uint32_t table[];   // max_slots, then the 2-bit fields (pos_cap / 16 + 4 words), the bad-base bits (pos_cap / 32 + 4 words), the bitmap
     __shared__ uint32_t s_first[kFuseSeqs], s_wbase[kFuseSeqs + 1], s_piece0[kFuseSeqs + 1];
     __shared__ uint32_t s_len[kFuseSeqs];
     __shared__ int s_over;
     uint32_t *s_pack = table + p.max_slots;
     uint32_t *s_bad = s_pack + p.pos_cap / 16 + 4;
-    uint32_t *s_bm = s_bad + p.pos_cap / 32 + 4;   // BLOCK * ITERS / 32 words: the read's first-occurrence bits
+    uint32_t *s_bm = s_bad + p.pos_cap / 32 + 4;   // p.bm_words: the read's first-occurrence bits
     const uint32_t pack_words = p.pos_cap / 16 + 4, bad_words = p.pos_cap / 32 + 4;
     const uint32_t k = p.k, stride = p.stride;
     const uint32_t chunk = (p.n_list + 7u) / 8u;   // (XCD x walks the x-th eighth of the list)
     const uint32_t item0 = (blockIdx.x & 7u) * chunk, item1 = item0 + chunk < p.n_list ? item0 + chunk : p.n_list;
     const uint32_t step = gridDim.x >> 3;
     uint32_t item = item0 + (blockIdx.x >> 3);
-    uint4 pc[2];
+    uint4 pc[PIECES];
 #ifdef CID_LONG_PROF
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
 #endif
-    if (item < item1) fuse_load_pieces<BLOCK>(p.items + item, pc);
+    if (item < item1) fuse_load_pieces<BLOCK, PIECES>(p.items + item, pc);
     for (; item < item1; item += step) {
         LONG_PROF_MARK(7);
         const FuseItem *rec = p.items + item;
@@ -818,12 +830,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
             reinterpret_cast<uint4 *>(table)[s] = uint4{kLongEmpty, kLongEmpty, kLongEmpty, kLongEmpty};
         for (uint32_t s = threadIdx.x; s < bad_words; s += BLOCK) s_bad[s] = 0xFFFFFFFFu;
         for (uint32_t s = threadIdx.x; s < pack_words; s += BLOCK) s_pack[s] = 0u;
-        for (uint32_t s = threadIdx.x; s < BLOCK * ITERS / 32u; s += BLOCK) s_bm[s] = 0u;
+        for (uint32_t s = threadIdx.x; s < p.bm_words; s += BLOCK) s_bm[s] = 0u;
         __syncthreads();
         LONG_PROF_MARK(0);   // record + clears
         bool lower = false;
 #pragma unroll
-        for (uint32_t j = 0; j < 2; ++j) {
+        for (uint32_t j = 0; j < PIECES; ++j) {
             const uint32_t x = threadIdx.x + j * BLOCK;
             if (x >= n_pieces) continue;
             uint32_t q = 0;
@@ -848,7 +860,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
             lower = lower || low != 0;
         }
         // the NEXT read's bases are asked for now: they arrive while this read's table is filled
-        if (item + step < item1) fuse_load_pieces<BLOCK>(p.items + item + step, pc);
+        if (item + step < item1) fuse_load_pieces<BLOCK, PIECES>(p.items + item + step, pc);
         LONG_PROF_MARK(1);   // staging (own part)
         if (__syncthreads_or(lower ? 1 : 0)) {   // (workgroup-uniform) a byte-string path takes this read: k_long_bytes, or the sorting path
             if (threadIdx.x == 0) {
@@ -874,8 +886,16 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
         // A thread takes w_per CONSECUTIVE windows: the forward and the reverse-complement code of a window follow from the window before by
         // one base each (the strided assignment paid two unaligned 64-bit extractions and a field reversal per window: ~150 instructions a
         // window, 24 us per 10 kb read with sixteen waves on a CU — the kernel was instruction-bound).
-        const uint32_t w_per = (nw + BLOCK - 1) / BLOCK;   // <= ITERS
+        const uint32_t w_per = (nw + BLOCK - 1) / BLOCK;   // <= ITERS (MULTI: <= kFusePassesMax * ITERS)
         const uint32_t wa = threadIdx.x * w_per;
+        const uint32_t n_pass = MULTI ? (nw + kLongFill - 1) / kLongFill : 1u;
+        bool crowded = false;
+        for (uint32_t pass = 0; pass < n_pass; ++pass) {
+        if (MULTI && pass) {   // (the winners of the pass before are in s_bm; the barrier behind its sweep lies before this)
+            for (uint32_t s = threadIdx.x; s < slots / 4u; s += BLOCK)
+                reinterpret_cast<uint4 *>(table)[s] = uint4{kLongEmpty, kLongEmpty, kLongEmpty, kLongEmpty};
+            __syncthreads();
+        }
         const uint64_t kmask = code_mask(k);
         uint32_t q = 0, next_base = 0, pos = 0, good_run = 0;
         uint64_t fwd = 0, rcv = 0;
@@ -915,9 +935,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
                 code = fwd < rcv ? fwd : rcv;   // (equal: the same string)
                 if (p.msz) code = minimizer_code(code, k, p.msz);
             }
-            p.codes[w0 + w] = code;
+            if (!MULTI || pass == 0) p.codes[w0 + w] = code;
             if (!valid) continue;
             const uint32_t h = long_mix32(code);
+            if (MULTI && (((h >> 15) & 127u) * n_pass) >> 7 != pass) continue;   // (bits between the slot's and the tag's)
             const uint32_t tag = h >> (32u - kLongTagBits);
             const uint32_t mine = (w << kLongTagBits) | tag;
             uint32_t at = h & mask;
@@ -941,7 +962,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
         if (s_over) {   // (workgroup-uniform; never seen at a load of a half)
             if (threadIdx.x == 0) { p.redo[read] = 1; atomicOr(&p.flags[1], 1); }
             __syncthreads();
-            continue;
+            crowded = true;
+            break;
         }
         // the winners — the smallest window of every k-mer, which is what its slot holds — as bits of the read's own bitmap words
         for (uint32_t sl = threadIdx.x; sl < slots / 4u; sl += BLOCK) {
@@ -952,6 +974,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
                 if (cur[t] != kLongEmpty) atomicOr(&s_bm[cur[t] >> (kLongTagBits + 5u)], 1u << ((cur[t] >> kLongTagBits) & 31u));
         }
         __syncthreads();
+        }   // (passes)
+        if (crowded) continue;
         uint32_t *out = p.bitmap + (w0 >> 5);
         for (uint32_t i = threadIdx.x; i < (nw + 31u) / 32u; i += BLOCK) out[i] = s_bm[i];
         __syncthreads();
@@ -1241,6 +1265,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     LongPlanParams pp{};
     pp.seq_off = d_seq_off; pp.read_seq0 = d_read_seq0; pp.route = d_route; pp.bases = d_bases; pp.n_reads = n_reads;
     pp.k = k; pp.stride = stride_d; pp.seg_win = kSegWindows / stride_d ? kSegWindows / stride_d : 1;
+    pp.multi = c->tune.readid_long_multi ? 1u : 0u;
     pp.fuse = c->tune.readid_long_fuse ? 1u : 0u; pp.cut = cut ? 1u : 0u; pp.own_search = own_search ? 1u : 0u; pp.deal = c->tune.readid_long_deal ? 1u : 0u;
     pp.wstart = d_wstart.p; pp.wend = d_wend.p; pp.win = d_win.p; pp.cls = d_cls.p; pp.redo = d_redo.p; pp.status = d_status;
     pp.pre = d_pre.p; pp.state = d_state.p; pp.totals = d_totals.p; pp.flags = d_flags.p;
@@ -1252,7 +1277,8 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     HIP_TRY(hipMemcpyAsync(t, d_totals.p, sizeof(t), hipMemcpyDeviceToHost, st));
     if (d_route_stats) HIP_TRY(hipMemcpyAsync(route_stats, d_route_stats, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));   // the one wait before the kernels: the lists' sizes
-    const uint64_t W = t[0], n_pairs = t[6];
+    const uint64_t W = t[0], n_pairs = t[6] & ((1ull << kPlanMultiShift) - 1ull);
+    const uint32_t n_fm = (uint32_t)(t[6] >> kPlanMultiShift);
     if (W >= (1ull << 32) - 64) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
     const uint32_t n_fs = (uint32_t)t[1], n_fb = (uint32_t)(t[1] >> 32), n_is = (uint32_t)t[2], n_ib = (uint32_t)(t[2] >> 32);
     const uint32_t n_slices = (uint32_t)t[3], n_combs = (uint32_t)(t[3] >> 32), n_segs = (uint32_t)t[4], n_deals = (uint32_t)(t[4] >> 32);
@@ -1268,7 +1294,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     DevBuf<LongDeal> d_deals(c);
     if ((rc = d_codes.alloc(W + 1)) || (rc = d_scan.alloc(scan_state_words(n_words))) || (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
         (rc = d_partial.alloc(n_combs ? (size_t)n_slices * (C1 + 1) : 1)) || (rc = d_pair_code.alloc(n_pairs)) || (rc = d_pair_idx.alloc(n_pairs)) ||
-        (rc = d_deal_counts.alloc(n_deal_counts)) || (rc = d_lists32.alloc((size_t)n_segs + 2 * (size_t)n_chunks)) || (rc = d_fuse.alloc((size_t)n_fs + n_fb)) ||
+        (rc = d_deal_counts.alloc(n_deal_counts)) || (rc = d_lists32.alloc((size_t)n_segs + 2 * (size_t)n_chunks)) || (rc = d_fuse.alloc((size_t)n_fs + n_fb + n_fm)) ||
         (rc = d_items.alloc((size_t)n_is + n_ib)) || (rc = d_slices.alloc(n_slices)) || (rc = d_combs.alloc(n_combs)) || (rc = d_segs.alloc(n_segs)) ||
         (rc = d_deals.alloc(n_deals)))
         return rc;
@@ -1284,7 +1310,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         HIP_TRY(hipMemsetAsync(d_bytes_read.p, 0, n_reads, st));
     }
     LongLists L{};
-    L.fused_small = d_fuse.p; L.fused_big = d_fuse.p + n_fs; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
+    L.fused_small = d_fuse.p; L.fused_big = d_fuse.p + n_fs; L.fused_multi = L.fused_big + n_fb; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
     L.items_small = d_items.p; L.items_big = d_items.p + n_is;
     L.slices = d_slices.p; L.combs = d_combs.p; L.segs = d_segs.p; L.deals = d_deals.p;
     hipLaunchKernelGGL(k_long_emit, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, pp, L);
@@ -1339,7 +1365,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         fp.k = k; fp.msz = msz; fp.stride = stride_d; fp.sentinel = sentinel; fp.codes = d_codes.p; fp.bitmap = d_bitmap.p; fp.redo = d_redo.p; fp.flags = d_flags.p;
         if (bytes_on_device) { fp.lower_list = d_lower.p + 4; fp.n_lower = d_lower.p; }
         if (n_fs) {
-            fp.items = L.fused_small; fp.n_list = n_fs; fp.big = 0; fp.max_slots = kLongSlotsSmall; fp.pos_cap = kFusePosSmall;
+            fp.items = L.fused_small; fp.n_list = n_fs; fp.big = 0; fp.max_slots = kLongSlotsSmall; fp.pos_cap = kFusePosSmall; fp.bm_words = kLongSmallWin / 32;
             unsigned g = (n_cu * 4u + 7u) & ~7u;
             hipLaunchKernelGGL((k_long_fused<kLongBlockSmall, kLongSmallWin / kLongBlockSmall>), dim3(g), dim3(kLongBlockSmall),
                                (kLongSlotsSmall + kFusePosSmall / 16 + 4 + kFusePosSmall / 32 + 4 + kLongSmallWin / 32) * 4, st, fp);
@@ -1351,7 +1377,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         fp.prof = n_fb ? d_prof.p : nullptr;
 #endif
         if (n_fb) {
-            fp.items = L.fused_big; fp.n_list = n_fb; fp.big = 1; fp.max_slots = kLongSlotsBig; fp.pos_cap = kFusePosBig;
+            fp.items = L.fused_big; fp.n_list = n_fb; fp.big = 1; fp.max_slots = kLongSlotsBig; fp.pos_cap = kFusePosBig; fp.bm_words = kLongFill / 32;
             const int shmem = (int)((kLongSlotsBig + kFusePosBig / 16 + 4 + kFusePosBig / 32 + 4 + kLongFill / 32) * 4);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_fused<kLongBlockBig, kLongFill / kLongBlockBig>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
@@ -1366,6 +1392,15 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
             fprintf(stderr, "k_long_fused<big> %u reads, mean cycles per workgroup: clears %llu, staging %llu, barrier %llu, inserts %llu, wait %llu, winners %llu, loop top %llu\n", n_fb,
                     sum[0] / g, sum[1] / g, sum[2] / g, sum[3] / g, sum[4] / g, sum[5] / g, sum[7] / g);
 #endif
+        }
+        if (n_fm) {   // (a lower-case base in one of these reads: the sorting path at the end of the call)
+            fp.items = L.fused_multi; fp.n_list = n_fm; fp.big = 1; fp.max_slots = kLongSlotsBig; fp.pos_cap = kFusePosMulti; fp.bm_words = kFuseWinMulti / 32;
+            fp.lower_list = nullptr; fp.n_lower = nullptr; fp.prof = nullptr;
+            const int shmem = (int)((kLongSlotsBig + kFusePosMulti / 16 + 4 + kFusePosMulti / 32 + 4 + kFuseWinMulti / 32) * 4);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_fused<kLongBlockBig, kLongFill / kLongBlockBig, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+            unsigned g = (n_cu + 7u) & ~7u;
+            hipLaunchKernelGGL((k_long_fused<kLongBlockBig, kLongFill / kLongBlockBig, true>), dim3(g), dim3(kLongBlockBig), shmem, st, fp);
         }
         if (bytes_on_device) {
             LongBytesParams bp{};

@@ -238,7 +238,7 @@ def test_soft_masked_reads_go_alone(orc, hip_ctx, fuse):
 def test_fused_and_two_kernel_paths_agree_on_every_class(orc, hip_ctx):
     """the classes of the device-made plan: one table in the fused kernel (256 and 1 024 threads), the same reads through
     k_extract_codes + k_long_first_flags (readid_long_fuse = 0), reads of more mates than the fused kernel keeps a table of, strides that
-    stretch a read's bases beyond its LDS, minimizer indices"""
+    stretch a read's bases beyond its LDS, minimizer indices; reads of two and three tables in the fused kernel's passes (readid_long_multi)"""
     import colorid_amd
     rng = np.random.default_rng(77)
     n_colors, n_hash, k, m = 200, 2, 25, 150_001
@@ -248,13 +248,19 @@ def test_fused_and_two_kernel_paths_agree_on_every_class(orc, hip_ctx):
     many = [g[i * 1_000:i * 1_000 + 900] for i in range(7)]                 # seven mates: the items route
     reads = [[g[:3_000]], [g[:4_120]], [g[:4_121]], [g[:16_000]], [g[:16_408]], [g[:16_409]], [g[:40_000]], many, [g[:2_000], b"", g[:1_000], b"ACGT", g[5_000:9_000]],
              [g[:6_100]], [g[:20_400]], [g[:20_500]], [g[50_000:50_000 + 1_100]] * 4, [g[:3_000]] * 5]
-    for fuse in (1, 0):
+    # the fused kernel's passes (two and three tables' worth of windows, the last window a pass still takes, pairs, strides that keep the
+    # bases within its LDS) beside the buckets of k_long_first_flags
+    reads += [[g[:32_792]], [g[:32_793]], [g[:49_176]], [g[:49_177]], [g[:24_000], g[60_000:84_000]], [g[:10_000] * 4], [g[44_999::-1]],
+              [g[:30_000] + b"acgt" + g[30_000:35_000]], [b"N" * 20_000 + g[:25_000]]]
+    for fuse, multi in ((1, 1), (1, 0), (0, 1)):
         hip_ctx.tune("readid_long_fuse", fuse)
+        hip_ctx.tune("readid_long_multi", multi)
         try:
             for d, S in ((1, 3), (4, 0), (13, 2)):
-                compare(oix, hx, reads, d, S, ("classes", fuse, d, S))
+                compare(oix, hx, reads, d, S, ("classes", fuse, multi, d, S))
         finally:
             hip_ctx.tune("readid_long_fuse", 1)
+            hip_ctx.tune("readid_long_multi", 1)
     hx.close()
 
 
