@@ -216,6 +216,7 @@ struct cid_fastq {
         uint32_t *d_status = nullptr;
         size_t n_members = 0;
         void *d_in = nullptr, *d_mem = nullptr, *d_scratch = nullptr;
+        void *h_mem = nullptr;    // the members' table on the host: its copy may still be on the way when push_bgzf returns (CID_FASTQ_KEEP)
         hipEvent_t done = nullptr;
         bool last = false;
     };
@@ -229,6 +230,7 @@ struct cid_fastq {
         bool surplus = false;
         std::deque<Staged> staged;
         hipEvent_t copy_pending = nullptr;   // the H2D of a CID_FASTQ_KEEP text push still to be waited for (owned by its Staged entry)
+        hipEvent_t members_pending = nullptr;   // the H2D of a CID_FASTQ_KEEP push of members: waited for (and destroyed) by the next such push
         size_t members_seen = 0;
     } f[2];
     // the last classify's results (device), fetched by cid_fastq_fetch
@@ -304,6 +306,7 @@ void free_staged(cid_fastq *fq, cid_fastq::Staged &sg) {   // (after its event h
     cid_ctx *c = fq->ctx;
     cid::ctx_free(c, sg.text); cid::ctx_free(c, sg.d_status); cid::ctx_free(c, sg.d_in); cid::ctx_free(c, sg.d_mem);
     if (sg.d_scratch) cid::ctx_free(c, sg.d_scratch);
+    free(sg.h_mem);
     if (sg.done) (void)hipEventDestroy(sg.done);
     sg = cid_fastq::Staged();
 }
@@ -363,6 +366,7 @@ void cid_fastq_destroy(cid_fastq *fq) {
     drop_results(fq);
     drop_inflight(fq);
     for (int i = 0; i < 2; ++i) {
+        if (fq->f[i].members_pending) (void)hipEventDestroy(fq->f[i].members_pending);   // (the streams have drained)
         cid::ctx_free(c, fq->f[i].text);
         for (cid_fastq::Staged &sg : fq->f[i].staged) free_staged(fq, sg);
     }
@@ -414,23 +418,31 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
     if (!fq || file < 0 || file >= fq->n_files) return fail(CID_ERR_INVALID, "bad argument");
     if (n_members && (!members || !member_off || !member_len || !text_len)) return fail(CID_ERR_INVALID, "null argument");
     cid_fastq::File &F = fq->f[file];
+    if (F.members_pending) {   // the CID_FASTQ_KEEP push of members before this one: its buffer is the caller's again from here on
+        const hipError_t e = hipEventSynchronize(F.members_pending);
+        (void)hipEventDestroy(F.members_pending);
+        F.members_pending = nullptr;
+        if (e != hipSuccess) return fail(CID_ERR_HIP, "cid_fastq_push_bgzf: %s", hipGetErrorString(e));
+    }
     if (F.push_closed) return fail(CID_ERR_STATE, "file %d was closed (last) by an earlier push", file);
     if (F.surplus) { F.push_closed = last != 0; if (last) F.last = true; return CID_OK; }   // no mates left for it: nothing travels
     if (F.staged.size() >= 64) return fail(CID_ERR_STATE, "file %d: 64 pushes are waiting for classify calls", file);
     if (n_bytes >= (1ull << 32) || n_members >= (1ull << 31)) return fail(CID_ERR_UNSUPPORTED, "a push of BGZF members is limited to 4 GiB");
     cid_ctx *c = fq->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<cid::BgzfMember> mem(n_members);
+    cid::BgzfMember *mem = static_cast<cid::BgzfMember *>(malloc((n_members ? n_members : 1) * sizeof(cid::BgzfMember)));
+    if (!mem) return fail(CID_ERR_NOMEM, "cid_fastq_push_bgzf: the members' table");
     uint64_t text_total = 0;
     for (size_t i = 0; i < n_members; ++i) {
-        if ((uint64_t)member_off[i] + member_len[i] > n_bytes) return fail(CID_ERR_INVALID, "member %zu lies outside the push", i);
-        if (text_len[i] > 65536u) return fail(CID_ERR_INVALID, "member %zu: more than 64 KiB of text", i);
+        if ((uint64_t)member_off[i] + member_len[i] > n_bytes) { free(mem); return fail(CID_ERR_INVALID, "member %zu lies outside the push", i); }
+        if (text_len[i] > 65536u) { free(mem); return fail(CID_ERR_INVALID, "member %zu: more than 64 KiB of text", i); }
         mem[i] = cid::BgzfMember{member_off[i], member_len[i], (uint32_t)text_total, text_len[i]};
         text_total += text_len[i];
     }
-    if (text_total >= (1ull << 32)) return fail(CID_ERR_UNSUPPORTED, "a push of BGZF members is limited to 4 GiB of text");
+    if (text_total >= (1ull << 32)) { free(mem); return fail(CID_ERR_UNSUPPORTED, "a push of BGZF members is limited to 4 GiB of text"); }
     cid_fastq::Staged sg;
     sg.bytes = (size_t)text_total; sg.n_members = n_members; sg.last = last != 0;
+    sg.h_mem = mem;   // (freed with the entry, after its inflate has been waited for)
     if (n_members) {
         void *p = nullptr;
         int rc;
@@ -452,7 +464,7 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
         if (e == hipSuccess) e = hipStreamWaitEvent(fq->text_stream, behind, 0);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sg.done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMemcpyAsync(sg.d_in, members, n_bytes, hipMemcpyHostToDevice, fq->text_stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(sg.d_mem, mem.data(), n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, fq->text_stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(sg.d_mem, mem, n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, fq->text_stream);
         hipEvent_t copied = cid::ctx_event(c, 1);
         hipStream_t inflate_stream = fq->inflate_streams[fq->n_inflates++ & 1];
         if (e == hipSuccess) e = hipEventRecord(copied, fq->text_stream);
@@ -460,7 +472,10 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
         if (e == hipSuccess) e = cid::bgzf_inflate_launch(c, inflate_stream, (const uint8_t *)sg.d_in, (const cid::BgzfMember *)sg.d_mem, (uint32_t)n_members, sg.text,
                                                           sg.d_status, sg.d_scratch);
         if (e == hipSuccess) e = hipEventRecord(sg.done, inflate_stream);
-        if (e == hipSuccess) e = hipEventSynchronize(copied);   // the caller's buffers (and `mem`) are free again; the kernel runs on
+        if (e == hipSuccess && (flags & CID_FASTQ_KEEP)) {   // (page-locked members: the copy runs on beside the caller)
+            e = hipEventCreateWithFlags(&F.members_pending, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(F.members_pending, fq->text_stream);
+        } else if (e == hipSuccess) e = hipEventSynchronize(copied);   // the caller's buffers are free again; the kernel runs on
         if (e != hipSuccess) {
             (void)hipStreamSynchronize(inflate_stream);
             free_staged(fq, sg);

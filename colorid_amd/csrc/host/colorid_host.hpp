@@ -201,10 +201,33 @@ struct PinnedBuf {   // page-locked bytes from the library (cid_pinned_alloc; pl
     void release();
     void reserve(size_t want);   // (contents are not kept)
 };
+struct StretchBuf {   // a stretch's compressed bytes: page-locked when the library hands such memory out, grown with its contents kept
+    unsigned char *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    StretchBuf() = default;
+    StretchBuf(const StretchBuf &) = delete;
+    StretchBuf &operator=(const StretchBuf &) = delete;
+    StretchBuf(StretchBuf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), pinned(o.pinned) { o.p = nullptr; o.n = o.cap = 0; }
+    StretchBuf &operator=(StretchBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; pinned = o.pinned; o.p = nullptr; o.n = o.cap = 0; }
+        return *this;
+    }
+    ~StretchBuf() { release(); }
+    void release();
+    void reserve(size_t want);   // (the first n bytes are kept)
+    unsigned char *data() { return p; }
+    const unsigned char *data() const { return p; }
+    size_t size() const { return n; }
+};
 struct BgzfStretch {
-    // whole members, back to back.  (Pageable on purpose — round 6 tried page-locked memory, so that the reads land where the H2D copy takes
-    // them from: locking 70 MB per buffer stalled the runtime's other calls, the loop of 16 M reads went from 320-364 to 350-426 ms.)
-    ByteBuf bytes;
+    // Whole members, back to back.  COLORID_DEVICE_FASTQ_PINNED=1 puts them in page-locked memory, sized once per stretch (from the file's
+    // size, then from the stretch before), and their copy to the device then runs beside the loop (CID_FASTQ_KEEP): the push of 16 M
+    // reads falls from 150-190 ms to 14-36 — and the loop stays where it was, 296-310 ms against 307-315, because the GPU is what it
+    // waits for by then (k_bgzf_inflate_wave 10 ms and k_readid 9.6 ms per 256 MiB stretch, side by side 13.3: rocprofv3 of the command
+    // line, profiles/r06_frontend_gpu_bound.txt), while two files of pairs start 25-35 ms later behind their larger first buffers
+    // (4 M pairs 139-142 ms against 97-104).  Off by default.
+    StretchBuf bytes;
     std::vector<uint32_t> off, len, text_len;      // member i = bytes[off[i], +len[i]), its text has text_len[i] bytes
     uint64_t text_bytes = 0;
     bool last = false;                             // the file ends with this stretch

@@ -167,7 +167,8 @@ static bool count_bgzf_on_device(cid_ctx *ctx, cid_kmerset *ks, const std::vecto
         const bool host_part = sx.host_text_bytes > 0;
         // (only the device's members travel: they come first in the stretch; the rest was inflated here)
         const size_t dev_bytes = sx.device_members ? (size_t)sx.off[sx.device_members - 1] + sx.len[sx.device_members - 1] : 0;
-        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members, 0));
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
+                                    sx.bytes.pinned ? CID_FASTQ_KEEP : 0));   // (waited for in the next push of this file; two buffers in turn)
         // ALWAYS the second push, also when it is empty: a classify step takes two pushes per file = exactly one stretch, and the wait
         // for the copy of the stretch before (CID_FASTQ_KEEP) happens here, before the reader gets that stretch's buffer back
         CID_TRY(cid_fastq_push_text(fr, (int)i, host_part ? sx.host_text.p : nullptr, host_part ? sx.host_text_bytes : 0,

@@ -426,16 +426,15 @@ size_t read_id_mt_pe::device_fastq_stretch_bytes(size_t n_colors) {
     if (target > by_rows) target = by_rows < ((size_t)1 << 20) ? ((size_t)1 << 20) : by_rows;
     return target;
 }
-// DEFLATE decodes serially inside a member, so the device inflates a member per lane at ~10 GB/s of text in all, while the cores the
-// host front end would spend on inflating and packing are idle: the reader's threads inflate this share of every stretch (the rest
-// goes up compressed).  Measured on a 16-CPU share (tools/exp_frontend.sh): see DESIGN.md.
+// DEFLATE decodes serially inside a member, so the device inflates a member per lane (rounds 2-4) or per wave (round 5 on), while the
+// cores the host front end would spend on inflating and packing are idle: the reader's threads inflate this share of every stretch (the
+// rest goes up compressed): 0.0375 per spare thread, 0.3 on a 16-CPU share (round 3, tools/exp_frontend_poll.sh: 16 M reads 0.44-0.51 s
+// at 0.5, 0.41-0.44 s at 0.3).  Round 6 measured it again (tools/exp_frontend_share.sh, profiles/r06_frontend_share.txt): with everything
+// inflated on the device and the freed threads in the poll (ten instead of six) 16 M reads take the same 313-335 ms as at 0.3 (297-352),
+// 4 M pairs 101-102 ms instead of 117-122, one million reads 39-41 instead of 33-35 — the loop waits for the GPU either way (the inflate
+// and the classifier of a 256 MiB stretch, 13.3 ms side by side: profiles/r06_frontend_gpu_bound.txt).  The default stays.
 double read_id_mt_pe::device_fastq_host_share() {
     if (const char *e = cli_env("COLORID_DEVICE_FASTQ_HOST_SHARE")) { const double v = atof(e); return v < 0.0 ? 0.0 : v > 1.0 ? 1.0 : v; }
-    // a host thread inflates ~0.7 GB/s of text, the device ~10 GB/s beside the classification it also runs: with the eight threads a
-    // 16-CPU share leaves, an even split keeps both sides busy (16 M reads, tools/exp_frontend_16m.sh: 0.71-0.73 s at share 0.5, 0.84-0.90 s
-    // with the host inflating everything, 0.89-0.96 s with the device inflating everything; host front end 1.02-1.21 s)
-    // (round 3, after the step was cut in two halves and the GPU side of a stretch fell to 13 ms: the host's half had become what the
-    // loop waited for — 16 M reads 0.44-0.51 s at 0.5, 0.41-0.44 s at 0.3, tools/exp_frontend_poll.sh)
     const double v = (double)device_fastq_host_threads(1) * 0.0375;
     return v > 1.0 ? 1.0 : v;
 }
@@ -484,7 +483,10 @@ FrontEnd classify_bgzf_on_device(cid_ctx *ctx, const std::vector<std::string> &f
         const bool host_part = sx.host_text_bytes > 0;
         // (only the device's members travel: they come first in the stretch; the rest was inflated here)
         const size_t dev_bytes = sx.device_members ? (size_t)sx.off[sx.device_members - 1] + sx.len[sx.device_members - 1] : 0;
-        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members, 0));
+        // (page-locked bytes: the copy runs on beside this thread; the library waits for it in the NEXT push of this file, which comes
+        // before the reader gets this stretch's buffer back — st[i] holds ahead + 1 >= 2 of them in turn)
+        CID_TRY(cid_fastq_push_bgzf(fr, (int)i, sx.bytes.data(), dev_bytes, sx.off.data(), sx.len.data(), sx.text_len.data(), sx.device_members,
+                                    sx.bytes.pinned ? CID_FASTQ_KEEP : 0));
         // ALWAYS the second push, also when it is empty: a classify step takes two pushes per file = exactly one stretch, and the wait
         // for the copy of the stretch before (CID_FASTQ_KEEP) happens here, before the reader gets that stretch's buffer back
         CID_TRY(cid_fastq_push_text(fr, (int)i, host_part ? sx.host_text.p : nullptr, host_part ? sx.host_text_bytes : 0,
@@ -583,7 +585,8 @@ void read_id_mt_pe::per_read_stream_se(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 1);
-    if (on_device && !cli_env("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));   // no packing threads beside them: a stretch's poll on 4 threads takes 18 ms, the GPU side 13
+    if (on_device && !cli_env("COLORID_POLL_THREADS"))
+        g_poll_threads = std::max(g_poll_threads, read_id_mt_pe::device_fastq_host_share() > 0.0 ? std::min(6, cpu_budget() * 3 / 8) : std::min(12, cpu_budget() * 5 / 8));   // no packing threads beside them: a stretch's poll on 4 threads takes 18 ms, the GPU side 13
     auto make_classifier = [&] { return std::unique_ptr<BatchClassifier>(new BatchClassifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r")); };
     std::unique_ptr<BatchClassifier> classifier = make_classifier();
     if (g_timing) fprintf(stderr, "timing: %.0f ms of set-up before the first read\n", ms_since(t0));
@@ -617,7 +620,8 @@ void read_id_mt_pe::per_read_stream_pe(cid_ctx *ctx, const std::vector<std::stri
     if (!out) die("could not create outfile!");
     ReadBatch rb;
     const bool on_device = device_fastq_wanted(fq, 2);
-    if (on_device && !cli_env("COLORID_POLL_THREADS")) g_poll_threads = std::max(g_poll_threads, std::min(6, cpu_budget() * 3 / 8));
+    if (on_device && !cli_env("COLORID_POLL_THREADS"))
+        g_poll_threads = std::max(g_poll_threads, read_id_mt_pe::device_fastq_host_share() > 0.0 ? std::min(6, cpu_budget() * 3 / 8) : std::min(12, cpu_budget() * 5 / 8));
     auto make_classifier = [&] { return std::unique_ptr<BatchClassifier>(new BatchClassifier(ctx, b, d, fp_correct, start_sample, fp, out, "%llu read pairs classified\r")); };
     std::unique_ptr<BatchClassifier> classifier = make_classifier();
     FrontEnd fe = on_device ? classify_bgzf_on_device(ctx, fq, 2, b, d, start_sample, qual_offset, *classifier) : kFrontEndNotMine;

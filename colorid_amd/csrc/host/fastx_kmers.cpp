@@ -3,6 +3,7 @@
 // here keys live packed in one arena and are hashed 8 bytes at a time.
 #include <unistd.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <cerrno>
 #include <dlfcn.h>
 #include <zlib.h>
@@ -823,6 +824,40 @@ void PinnedBuf::reserve(size_t want) {
     cap = c;
 }
 
+void StretchBuf::release() {
+    if (!p) return;
+    if (pinned) { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_pool.emplace_back(p, cap); }
+    else free(p);
+    p = nullptr; n = cap = 0;
+}
+void StretchBuf::reserve(size_t want) {
+    if (want <= cap) return;
+    static const bool lock_pages = [] { const char *e = cli_env("COLORID_DEVICE_FASTQ_PINNED"); return e && atoi(e) != 0; }();   // (off: see BgzfStretch)
+    size_t c = cap + cap / 2;
+    if (c < want) c = want;
+    unsigned char *q = nullptr;
+    size_t qcap = c;
+    bool qpinned = false;
+    if (lock_pages) {
+        {
+            std::lock_guard<std::mutex> lk(g_pin_mu);
+            for (size_t i = 0; i < g_pin_pool.size(); ++i)
+                if (g_pin_pool[i].second >= c) {
+                    q = g_pin_pool[i].first; qcap = g_pin_pool[i].second; qpinned = true;
+                    g_pin_pool.erase(g_pin_pool.begin() + (long)i);
+                    break;
+                }
+        }
+        void *v = nullptr;
+        if (!q && cid_pinned_alloc(c, &v) == CID_OK) { q = static_cast<unsigned char *>(v); qpinned = true; }
+    }
+    if (!q) { q = static_cast<unsigned char *>(malloc(c)); if (!q) die("out of memory (%zu bytes)", c); }
+    if (n) memcpy(q, p, n);
+    const size_t keep = n;
+    release();
+    p = q; n = keep; cap = qcap; pinned = qpinned;
+}
+
 // members [m0, m1) of `s` inflated into out (their texts back to back) by the pool's threads and this one; every member's CRC-32 and
 // ISIZE are checked (libdeflate when the host has it, else zlib)
 static void inflate_members_host(TaskPool *pool, int n_threads, const BgzfStretch &s, size_t m0, size_t m1, unsigned char *out) {
@@ -868,6 +903,7 @@ struct BgzfMemberReader::Impl {
     std::unique_ptr<TaskPool> pool, read_pool;
     int fd = -1;
     uint64_t fpos = 0;                 // the next byte of the file not read yet
+    uint64_t file_size = ~0ull;        // (a pipe: unknown)
     size_t text_target;
     std::thread worker, inflater;
     std::mutex mu;
@@ -920,7 +956,13 @@ struct BgzfMemberReader::Impl {
                 if (!spare.empty()) { s = std::move(spare.front()); spare.pop_front(); }
             }
             s.off.clear(); s.len.clear(); s.text_len.clear(); s.text_bytes = 0; s.last = false;
-            s.bytes.reserve(tail.size() + (guess ? guess + guess / 8 : (size_t)8 << 20));
+            {   // ONE allocation per buffer: the stretch before tells the size, the first one takes the file's (compressed FASTQ is a
+                // quarter to a half of its text), and the file's end bounds both
+                const size_t left = file_size > fpos ? (size_t)(file_size - fpos) : 0;
+                size_t room = guess ? guess + guess / 8 : text_target / 2 + ((size_t)1 << 20);
+                if (file_size != ~0ull && room > left + 4096) room = left + 4096;
+                s.bytes.reserve(tail.size() + room);
+            }
             if (!tail.empty()) memcpy(s.bytes.p, tail.data(), tail.size());
             s.bytes.n = tail.size();
             tail.clear();
@@ -1016,6 +1058,10 @@ BgzfMemberReader::BgzfMemberReader(const std::string &path, size_t text_target, 
     p_->fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
     if (p_->fd < 0) die("file not found: %s", path.c_str());
     (void)posix_fadvise(p_->fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    {
+        struct stat sb;
+        if (fstat(p_->fd, &sb) == 0 && S_ISREG(sb.st_mode)) p_->file_size = (uint64_t)sb.st_size;
+    }
     p_->worker = std::thread([this] { p_->run(); });
     p_->inflater = std::thread([this] { p_->run_inflater(); });
 }

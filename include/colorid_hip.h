@@ -469,7 +469,9 @@ int cid_bgzf_inflate_finish(cid_ctx *, uint8_t *text, size_t text_bytes, size_t 
 typedef struct cid_fastq cid_fastq;
 #define CID_FASTQ_LAST 1   /* push flags: the file ends with this push */
 #define CID_FASTQ_KEEP 2   /* push_text: the buffer (page-locked, cid_pinned_alloc) stays untouched until the next push on this file or the
-                            * classify call that takes this one — the copy then runs beside the caller instead of being waited for */
+                            * classify call that takes this one — the copy then runs beside the caller instead of being waited for.
+                            * push_bgzf: the same for `members` (the three arrays are read before the call returns), until the next
+                            * push_bgzf on this file or the destruction of the reader */
 CID_CORE int cid_fastq_create(cid_ctx *, int n_files, uint32_t quality, cid_fastq **out);
 CID_CORE int cid_fastq_push_bgzf(cid_fastq *, int file, const uint8_t *members, size_t n_bytes, const uint32_t *member_off, const uint32_t *member_len,
                         const uint32_t *text_len, size_t n_members, int flags);

@@ -418,7 +418,10 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
     outs = {}
     for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {"COLORID_DEVICE_FASTQ": "1"}), ("dev_small", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_MB": "1"}),
                      ("dev_ahead", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_AHEAD": "3"}), ("dev_default", {}),
-                     ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}), ("dev_host_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "1"})):
+                     ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}), ("dev_host_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "1"}),
+                     # the stretches' bytes page-locked, their copies running beside the loop (CID_FASTQ_KEEP on cid_fastq_push_bgzf), buffers in turn
+                     ("dev_pinned", {"COLORID_DEVICE_FASTQ_PINNED": "1", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}),
+                     ("dev_pinned_ahead", {"COLORID_DEVICE_FASTQ_PINNED": "1", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_AHEAD": "3"})):
         for extra in ([], ["-Q", "0", "-d", "3", "-B", "0"]):
             name = str(tmp_path / f"{tag}{len(extra)}")
             p = subprocess.run([BIN, "read_id", "-b", pre + ".bxi", "-q", *q, "-n", name, *extra], capture_output=True, text=True,
@@ -428,7 +431,7 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
     for extra in (0, 6):
         host = outs[("host", extra)]
         assert host[0].count("\n") == (11500 if paired else 12000)
-        for tag in ("dev", "dev_small", "dev_ahead", "dev_default", "dev_gpu_inflate", "dev_host_inflate"):
+        for tag in ("dev", "dev_small", "dev_ahead", "dev_default", "dev_gpu_inflate", "dev_host_inflate", "dev_pinned", "dev_pinned_ahead"):
             assert outs[(tag, extra)][0] == host[0] and outs[(tag, extra)][1] == host[1], (tag, extra)
             assert "device front end" in outs[(tag, extra)][2], tag      # (the timing line of the path that ran)
     assert "accept" in outs[("dev", 0)][0]
@@ -566,7 +569,7 @@ def test_cli_search_counts_block_gzip_queries_on_the_device(orc, tmp_path, paire
     q = [f1, f2] if paired else [f1]
     outs = {}
     for tag, env in (("host", {"COLORID_DEVICE_FASTQ": "0"}), ("dev", {}), ("dev_small", {"COLORID_DEVICE_FASTQ_MB": "1"}),
-                     ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ_HOST_SHARE": "0"})):
+                     ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}), ("dev_pinned", {"COLORID_DEVICE_FASTQ_PINNED": "1", "COLORID_DEVICE_FASTQ_MB": "1"})):
         for extra in (["-f", "1", "-p", "0.01"], ["-g", "-f", "0", "-p", "0.3"], ["-Q", "0", "-f", "2", "-p", "0.01"]):
             p = subprocess.run([BIN, "search", "-b", pre + ".bxi", "-q", q[0], *(["-r", q[1]] if paired else []), *extra], capture_output=True, text=True,
                                env=dict(os.environ, COLORID_TIMING="1", **env))
