@@ -466,7 +466,7 @@ int cid_fastq_push_bgzf(cid_fastq *fq, int file, const uint8_t *members, size_t 
         if (e == hipSuccess) e = hipMemcpyAsync(sg.d_in, members, n_bytes, hipMemcpyHostToDevice, fq->text_stream);
         if (e == hipSuccess) e = hipMemcpyAsync(sg.d_mem, mem, n_members * sizeof(cid::BgzfMember), hipMemcpyHostToDevice, fq->text_stream);
         hipEvent_t copied = cid::ctx_event(c, 1);
-        hipStream_t inflate_stream = fq->inflate_streams[fq->n_inflates++ & 1];
+        hipStream_t inflate_stream = c->tune.fastq_inflate_beside ? fq->inflate_streams[fq->n_inflates++ & 1] : c->stream;
         if (e == hipSuccess) e = hipEventRecord(copied, fq->text_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(inflate_stream, copied, 0);
         if (e == hipSuccess) e = cid::bgzf_inflate_launch(c, inflate_stream, (const uint8_t *)sg.d_in, (const cid::BgzfMember *)sg.d_mem, (uint32_t)n_members, sg.text,
