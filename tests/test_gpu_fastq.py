@@ -421,7 +421,8 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
                      ("dev_gpu_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}), ("dev_host_inflate", {"COLORID_DEVICE_FASTQ": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "1"}),
                      # the stretches' bytes page-locked, their copies running beside the loop (CID_FASTQ_KEEP on cid_fastq_push_bgzf), buffers in turn
                      ("dev_pinned", {"COLORID_DEVICE_FASTQ_PINNED": "1", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"}),
-                     ("dev_pinned_ahead", {"COLORID_DEVICE_FASTQ_PINNED": "1", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_AHEAD": "3"})):
+                     ("dev_pinned_ahead", {"COLORID_DEVICE_FASTQ_PINNED": "1", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_AHEAD": "3"}),
+                     ("dev_behind", {"CID_FASTQ_INFLATE_BESIDE": "0", "COLORID_DEVICE_FASTQ_MB": "1", "COLORID_DEVICE_FASTQ_HOST_SHARE": "0"})):   # the inflate on the classifier's stream
         for extra in ([], ["-Q", "0", "-d", "3", "-B", "0"]):
             name = str(tmp_path / f"{tag}{len(extra)}")
             p = subprocess.run([BIN, "read_id", "-b", pre + ".bxi", "-q", *q, "-n", name, *extra], capture_output=True, text=True,
@@ -431,7 +432,7 @@ def test_cli_read_id_device_front_end_equals_host_front_end(orc, tmp_path, paire
     for extra in (0, 6):
         host = outs[("host", extra)]
         assert host[0].count("\n") == (11500 if paired else 12000)
-        for tag in ("dev", "dev_small", "dev_ahead", "dev_default", "dev_gpu_inflate", "dev_host_inflate", "dev_pinned", "dev_pinned_ahead"):
+        for tag in ("dev", "dev_small", "dev_ahead", "dev_default", "dev_gpu_inflate", "dev_host_inflate", "dev_pinned", "dev_pinned_ahead", "dev_behind"):
             assert outs[(tag, extra)][0] == host[0] and outs[(tag, extra)][1] == host[1], (tag, extra)
             assert "device front end" in outs[(tag, extra)][2], tag      # (the timing line of the path that ran)
     assert "accept" in outs[("dev", 0)][0]
