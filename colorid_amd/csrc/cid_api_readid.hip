@@ -200,21 +200,29 @@ struct ReadRoute {
 };
 static int readid_route(const cid_ctx *c, const cid_index *ix, const uint64_t *seq_off, size_t n_seqs, const uint64_t *read_seq0, size_t n_reads, uint32_t stride_d,
                         uint32_t start_sample, ReadRoute &rr) {
+    // (this loop runs on the caller's thread before anything is launched: a million reads of 150 bases took 2.1 ms in it — beside 5.2 ms of
+    // kernel — while every read paid a 64-bit division by a stride that is 1 unless -d says otherwise)
     uint64_t max_bytes = 0, max_win = 0;
-    for (size_t r = 0; r < n_reads; ++r) {   // (both bounds before seq_off is read through them)
-        if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
-        if (read_seq0[r + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs at read %zu", r);
-        const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
-        uint64_t win = 0;
-        for (uint64_t s = s0; s < s1; ++s) {
-            if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
-            const uint64_t len = seq_off[s + 1] - seq_off[s];
-            if (len >= ix->k) win += (len - ix->k) / stride_d + 1;
+    const uint64_t k = ix->k;
+    auto walk = [&](auto windows_of) -> int {
+        for (size_t r = 0; r < n_reads; ++r) {   // (both bounds before seq_off is read through them)
+            if (read_seq0[r + 1] < read_seq0[r]) return fail(CID_ERR_INVALID, "read_seq0 not monotonic at read %zu", r);
+            if (read_seq0[r + 1] > n_seqs) return fail(CID_ERR_INVALID, "read_seq0 points past n_seqs at read %zu", r);
+            const uint64_t s0 = read_seq0[r], s1 = read_seq0[r + 1];
+            uint64_t win = 0;
+            for (uint64_t s = s0; s < s1; ++s) {
+                if (seq_off[s + 1] < seq_off[s]) return fail(CID_ERR_INVALID, "seq_off not monotonic at seq %llu", (unsigned long long)s);
+                const uint64_t len = seq_off[s + 1] - seq_off[s];
+                if (len >= k) win += windows_of(len - k);
+            }
+            const uint64_t bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
+            if (bytes > max_bytes) max_bytes = bytes;
+            if (win > max_win) max_win = win;
         }
-        const uint64_t bytes = s1 > s0 ? seq_off[s1] - seq_off[s0] : 0;
-        if (bytes > max_bytes) max_bytes = bytes;
-        if (win > max_win) max_win = win;
-    }
+        return CID_OK;
+    };
+    const int rc_walk = stride_d == 1 ? walk([](uint64_t x) { return x + 1; }) : walk([stride_d](uint64_t x) { return x / stride_d + 1; });
+    if (rc_walk) return rc_walk;
     rr.max_bytes = max_bytes; rr.max_win = max_win;
     rr.any_long = max_bytes >= long_from(c, ix, stride_d, start_sample);
     return CID_OK;

@@ -664,12 +664,16 @@ struct LongLists {
 };
 // One WAVE per read: the lists of a megabase read are hundreds of entries each (490 segments, 244 slices, 61 items and chunks), written by
 // one thread they took 160 us per 150 such reads.
+// LANES = 64: a wave per read, for the reads of k_long_first_flags (their lists are long).  LANES = 1: a thread per read, for the reads of the fused
+// kernel — one record and a dozen slices at most: 187 500 reads of 800 bases kept a wave each busy with one lane, 0.2 ms of the call's 7.9.
+template <uint32_t LANES>
 __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L) {
-    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = LANES == 64u ? (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = LANES == 64u ? threadIdx.x & 63u : 0u;
     if (r >= p.n_reads) return;
     const uint32_t cls = p.cls[r];
     if (cls < kClsFusedSmall || cls > kClsItemsBig) return;
+    if ((cls <= kClsFusedMulti) != (LANES == 1u)) return;   // (the other launch's read)
     const uint64_t n = p.n_reads + 1;
     const uint32_t win = p.win[r];
     const uint64_t w0 = p.wstart[r];
@@ -709,17 +713,17 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
             count_base = (uint32_t)(pre(5) >> 32);
             if (lane == 0) L.deals[di] = LongDeal{pair_base, count_base, d.nc, d.cap, (uint32_t)r};
             deal = di + 1;
-            for (uint32_t j = lane; j < d.nc; j += 64u) { L.chunk_deal[c0 + j] = di; L.chunk_no[c0 + j] = j; }
+            for (uint32_t j = lane; j < d.nc; j += LANES) { L.chunk_deal[c0 + j] = di; L.chunk_no[c0 + j] = j; }
         }
         const uint32_t i0 = (uint32_t)(pre(2) >> 32);
-        for (uint32_t b = lane; b < d.P; b += 64u) L.items_big[i0 + b] = LongItem{(uint32_t)r, b, d.P, deal, win, d.nc, d.cap, count_base, w0, pair_base};
+        for (uint32_t b = lane; b < d.P; b += LANES) L.items_big[i0 + b] = LongItem{(uint32_t)r, b, d.P, deal, win, d.nc, d.cap, count_base, w0, pair_base};
     }
     if (p.own_search) {
         const uint32_t n_sl = p.cut ? (win + kSliceWindows - 1) / kSliceWindows : 1u;
         const uint32_t s0 = (uint32_t)pre(3);
         if (n_sl > 1 && lane == 0) L.combs[(uint32_t)(pre(3) >> 32)] = ReadCombine{(uint32_t)r, s0, n_sl, 0u};
         const uint64_t W1 = w0 + win;
-        for (uint32_t j = lane; j < n_sl; j += 64u) {
+        for (uint32_t j = lane; j < n_sl; j += LANES) {
             const uint64_t a = w0 + (uint64_t)j * kSliceWindows;
             const uint64_t b = n_sl == 1 ? W1 : (a + kSliceWindows < W1 ? a + kSliceWindows : W1);
             L.slices[s0 + j] = ReadSlice{(uint32_t)r, (uint32_t)a, (uint32_t)b, j | (n_sl > 1 ? 0x80000000u : 0u)};
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
             if (len < p.k) continue;
             const uint64_t nw = (len - p.k) / p.stride + 1;
             const uint64_t n_sg = (nw + p.seg_win - 1) / p.seg_win;
-            for (uint64_t g = lane; g < n_sg; g += 64u) {
+            for (uint64_t g = lane; g < n_sg; g += LANES) {
                 const uint64_t x = g * p.seg_win;
                 const uint32_t m = (uint32_t)(nw - x < p.seg_win ? nw - x : p.seg_win);
                 L.segs[sg + g] = Segment{a + x * p.stride, W + x, m, p.stride};
@@ -1313,7 +1317,8 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     L.fused_small = d_fuse.p; L.fused_big = d_fuse.p + n_fs; L.fused_multi = L.fused_big + n_fb; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
     L.items_small = d_items.p; L.items_big = d_items.p + n_is;
     L.slices = d_slices.p; L.combs = d_combs.p; L.segs = d_segs.p; L.deals = d_deals.p;
-    hipLaunchKernelGGL(k_long_emit, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, pp, L);
+    if (n_fs + n_fb + n_fm) hipLaunchKernelGGL(k_long_emit<1u>, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, pp, L);
+    if (n_is + n_ib) hipLaunchKernelGGL(k_long_emit<64u>, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, pp, L);
     HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, n_words * 4, st));
     HIP_TRY(hipGetLastError());
     int h_flags[4] = {0, 0, 0, 0};
