@@ -511,14 +511,18 @@ __global__ void k_long_short_rows(const uint8_t *status, uint32_t n_reads, uint3
 enum LongClass : uint8_t {
     kClsOther = 0,      // not routed here (status 2)
     kClsShort = 1,      // the first mate has no window (status 1: too_short)
-    kClsFusedSmall = 2, // one hash table; codes and table in ONE kernel (k_long_fused), 256 threads / 8 192 slots
-    kClsFusedBig = 3,   //   ... 1 024 threads / 32 768 slots
-    kClsFusedMulti = 4, //   ... the same table filled up to three times, a third of the read's k-mers each time (reads of up to 49 152 windows)
-    kClsItemsSmall = 5, // k_extract_codes + k_long_first_flags: reads whose bases do not fit the fused kernel's LDS (strides), many mates
-    kClsItemsBig = 6,   //   ... and every read of several buckets
-    kClsSorted = 7      // more windows than a 4-byte slot numbers: the sorting path (redo[r] is set from the start)
+    kClsFusedTiny = 2,  // one hash table; codes and table in ONE kernel (k_long_fused): a wave / 2 048 slots (reads of up to 1 024 windows)
+    kClsFusedSmall = 3, //   ... 256 threads / 8 192 slots
+    kClsFusedBig = 4,   //   ... 1 024 threads / 32 768 slots
+    kClsFusedMulti = 5, //   ... the same table filled up to three times, a third of the read's k-mers each time (reads of up to 49 152 windows)
+    kClsItemsSmall = 6, // k_extract_codes + k_long_first_flags: reads whose bases do not fit the fused kernel's LDS (strides), many mates
+    kClsItemsBig = 7,   //   ... and every read of several buckets
+    kClsSorted = 8      // more windows than a 4-byte slot numbers: the sorting path (redo[r] is set from the start)
 };
 constexpr uint32_t kFuseSeqs = 4;                 // sequences (mates) of a read the fused kernel keeps a table of
+// Reads of up to 1 024 windows (the shortest this path takes, 700 bases up) by a WAVE each: a workgroup of 256 threads spent such a read's
+// few microseconds mostly at its barriers, four reads in flight per CU; a wave needs none, and sixteen of them fit (8.8 KiB of LDS each).
+constexpr uint32_t kLongSlotsTiny = 2048, kLongBlockTiny = 64, kLongTinyWin = 1024, kFusePosTiny = 1536, kPlanTinyShift = 40;
 constexpr uint32_t kFusePosSmall = 6144, kFusePosBig = 20480;   // positions (bases, each mate padded to its 16-byte pieces) of a read in its LDS
 // Reads of 16 385 .. 49 152 windows (what a long-read sequencer's run mostly consists of) used to leave the fused kernel for k_extract_codes +
 // k_long_first_flags, two and three buckets each re-reading the read's codes: 9.2 ms per 150 Mbases at 30 kb against 7.0 at 10 kb.  Their
@@ -532,7 +536,7 @@ struct LongPlanParams {
     const uint8_t *bases;     // (only its address: the 16-byte pieces of the fused kernel are pieces of the address space)
     uint64_t n_reads;
     uint32_t k, stride, seg_win;
-    uint32_t fuse, cut, own_search, deal, multi;
+    uint32_t fuse, cut, own_search, deal, multi, tiny;
     // out
     uint64_t *wstart, *wend;   // [n_reads + 1], [n_reads]
     uint32_t *win;             // [n_reads]
@@ -564,11 +568,12 @@ __device__ __forceinline__ LongRow long_row(const LongPlanParams &p, uint64_t r)
     o.win = (uint32_t)win;
     o.segs = (uint32_t)segs;
     const bool can_fuse = p.fuse && nk <= kFuseSeqs;
-    if (can_fuse && win <= kLongSmallWin && pos <= kFusePosSmall) o.cls = kClsFusedSmall;
+    if (can_fuse && p.tiny && win <= kLongTinyWin && pos <= kFusePosTiny) o.cls = kClsFusedTiny;
+    else if (can_fuse && win <= kLongSmallWin && pos <= kFusePosSmall) o.cls = kClsFusedSmall;
     else if (can_fuse && win <= kLongFill && pos <= kFusePosBig) o.cls = kClsFusedBig;
     else if (can_fuse && p.multi && win <= kFuseWinMulti && pos <= kFusePosMulti) o.cls = kClsFusedMulti;
     else o.cls = win <= kLongSmallWin ? kClsItemsSmall : kClsItemsBig;
-    if (o.cls >= kClsFusedSmall && o.cls <= kClsFusedMulti) o.segs = 0;
+    if (o.cls >= kClsFusedTiny && o.cls <= kClsFusedMulti) o.segs = 0;
     return o;
 }
 // what read r adds to each of the seven lists
@@ -585,10 +590,10 @@ __device__ __forceinline__ LongDealShape long_deal_shape(uint32_t win, uint32_t 
     return d;
 }
 __device__ __forceinline__ void long_fields(const LongPlanParams &p, const LongRow &row, uint64_t v[kPlanFields]) {
-    const bool windows = row.cls >= kClsFusedSmall && row.cls <= kClsItemsBig;
+    const bool windows = row.cls >= kClsFusedTiny && row.cls <= kClsItemsBig;
     const LongDealShape d = long_deal_shape(row.win, row.cls, p.deal);
     const uint32_t n_sl = !windows || !p.own_search ? 0u : (p.cut ? (row.win + kSliceWindows - 1) / kSliceWindows : 1u);
-    v[0] = windows ? ((uint64_t)row.win + 31u) & ~(uint64_t)31 : 0ull;                                  // windows (a read's start at a multiple of 32)
+    v[0] = (windows ? ((uint64_t)row.win + 31u) & ~(uint64_t)31 : 0ull) | (row.cls == kClsFusedTiny ? 1ull << kPlanTinyShift : 0ull);   // windows (a read's start at a multiple of 32; fewer than 2^33 in all) | the fused kernel's list of the shortest reads
     v[1] = (row.cls == kClsFusedSmall ? 1ull : 0ull) | (row.cls == kClsFusedBig ? 1ull << 32 : 0ull);    // the fused kernel's two lists
     v[2] = (row.cls == kClsItemsSmall ? 1ull : 0ull) | ((uint64_t)d.P << 32);                            // k_long_first_flags' items
     v[3] = (uint64_t)n_sl | (n_sl > 1 ? 1ull << 32 : 0ull);                                              // slices | reads of several slices
@@ -622,8 +627,9 @@ __global__ __launch_bounds__(kScanBlock) void k_long_plan(LongPlanParams p) {
         for (uint32_t j = 0; j < kPlanPer; ++j) {
             if (i0 + j < n) p.pre[(size_t)f * n + i0 + j] = run;
             if (f == 0 && i0 + j < n) {
-                p.wstart[i0 + j] = run;
-                if (i0 + j < p.n_reads) p.wend[i0 + j] = run + row[j].win;
+                const uint64_t w_at = run & ((1ull << kPlanTinyShift) - 1ull);
+                p.wstart[i0 + j] = w_at;
+                if (i0 + j < p.n_reads) p.wend[i0 + j] = w_at + row[j].win;
             }
             run += v[j][f];
         }
@@ -653,7 +659,7 @@ struct FuseItem {
     uint32_t first[kFuseSeqs], len[kFuseSeqs], wbase[kFuseSeqs], piece0[kFuseSeqs];
 };
 struct LongLists {
-    FuseItem *fused_small, *fused_big, *fused_multi;
+    FuseItem *fused_tiny, *fused_small, *fused_big, *fused_multi;   // (one array, in this order)
     LongItem *items_small, *items_big;
     ReadSlice *slices;
     ReadCombine *combs;
@@ -672,13 +678,13 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
     const uint32_t lane = LANES == 64u ? threadIdx.x & 63u : 0u;
     if (r >= p.n_reads) return;
     const uint32_t cls = p.cls[r];
-    if (cls < kClsFusedSmall || cls > kClsItemsBig) return;
+    if (cls < kClsFusedTiny || cls > kClsItemsBig) return;
     if ((cls <= kClsFusedMulti) != (LANES == 1u)) return;   // (the other launch's read)
     const uint64_t n = p.n_reads + 1;
     const uint32_t win = p.win[r];
     const uint64_t w0 = p.wstart[r];
     auto pre = [&](uint32_t f) { return p.pre[(size_t)f * n + r]; };
-    if (cls >= kClsFusedSmall && cls <= kClsFusedMulti && lane == 0) {
+    if (cls >= kClsFusedTiny && cls <= kClsFusedMulti && lane == 0) {
         FuseItem it{};
         it.read = (uint32_t)r; it.nw = win; it.w0 = w0;
         uint32_t ns = 0, wb = 0, piece = 0;
@@ -698,7 +704,8 @@ __global__ __launch_bounds__(256) void k_long_emit(LongPlanParams p, LongLists L
             ++ns;
         }
         it.n_seq = ns; it.n_pieces = piece;
-        if (cls == kClsFusedSmall) L.fused_small[(uint32_t)pre(1)] = it;
+        if (cls == kClsFusedTiny) L.fused_tiny[(uint32_t)(pre(0) >> kPlanTinyShift)] = it;
+        else if (cls == kClsFusedSmall) L.fused_small[(uint32_t)pre(1)] = it;
         else if (cls == kClsFusedBig) L.fused_big[(uint32_t)(pre(1) >> 32)] = it;
         else L.fused_multi[(uint32_t)(pre(6) >> kPlanMultiShift)] = it;
     }
@@ -768,8 +775,8 @@ struct LongFuseParams {
     uint32_t *bitmap;
     uint8_t *redo;
     int *flags;
-    uint32_t *lower_list, *n_lower;   // non-NULL: a read with a lower-case base is listed here (item | big << 31) for k_long_bytes
-    uint32_t big;
+    uint32_t *lower_list, *n_lower;   // non-NULL: a read with a lower-case base is listed here (item_base + item | big << 31) for k_long_bytes
+    uint32_t big, item_base;
     unsigned long long *prof;   // CID_LONG_PROF builds: [gridDim.x][8] cycles per phase (thread 0's clock)
 };
 #ifdef CID_LONG_PROF
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_long_fused(LongFuseParams p) {
         if (__syncthreads_or(lower ? 1 : 0)) {   // (workgroup-uniform) a byte-string path takes this read: k_long_bytes, or the sorting path
             if (threadIdx.x == 0) {
                 p.redo[read] = 1;
-                if (p.lower_list) p.lower_list[atomicAdd(p.n_lower, 1u)] = item | (p.big << 31);
+                if (p.lower_list) p.lower_list[atomicAdd(p.n_lower, 1u)] = (p.item_base + item) | (p.big << 31);
                 else atomicOr(&p.flags[0], 1);
             }
             __syncthreads();
@@ -1270,6 +1277,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     pp.seq_off = d_seq_off; pp.read_seq0 = d_read_seq0; pp.route = d_route; pp.bases = d_bases; pp.n_reads = n_reads;
     pp.k = k; pp.stride = stride_d; pp.seg_win = kSegWindows / stride_d ? kSegWindows / stride_d : 1;
     pp.multi = c->tune.readid_long_multi ? 1u : 0u;
+    pp.tiny = c->tune.readid_long_tiny ? 1u : 0u;
     pp.fuse = c->tune.readid_long_fuse ? 1u : 0u; pp.cut = cut ? 1u : 0u; pp.own_search = own_search ? 1u : 0u; pp.deal = c->tune.readid_long_deal ? 1u : 0u;
     pp.wstart = d_wstart.p; pp.wend = d_wend.p; pp.win = d_win.p; pp.cls = d_cls.p; pp.redo = d_redo.p; pp.status = d_status;
     pp.pre = d_pre.p; pp.state = d_state.p; pp.totals = d_totals.p; pp.flags = d_flags.p;
@@ -1281,7 +1289,8 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     HIP_TRY(hipMemcpyAsync(t, d_totals.p, sizeof(t), hipMemcpyDeviceToHost, st));
     if (d_route_stats) HIP_TRY(hipMemcpyAsync(route_stats, d_route_stats, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));   // the one wait before the kernels: the lists' sizes
-    const uint64_t W = t[0], n_pairs = t[6] & ((1ull << kPlanMultiShift) - 1ull);
+    const uint64_t W = t[0] & ((1ull << kPlanTinyShift) - 1ull), n_pairs = t[6] & ((1ull << kPlanMultiShift) - 1ull);
+    const uint32_t n_ft = (uint32_t)(t[0] >> kPlanTinyShift);
     const uint32_t n_fm = (uint32_t)(t[6] >> kPlanMultiShift);
     if (W >= (1ull << 32) - 64) return fail(CID_ERR_UNSUPPORTED, "more than 2^32 k-mer windows in one read_id batch");
     const uint32_t n_fs = (uint32_t)t[1], n_fb = (uint32_t)(t[1] >> 32), n_is = (uint32_t)t[2], n_ib = (uint32_t)(t[2] >> 32);
@@ -1298,14 +1307,14 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
     DevBuf<LongDeal> d_deals(c);
     if ((rc = d_codes.alloc(W + 1)) || (rc = d_scan.alloc(scan_state_words(n_words))) || (rc = d_bitmap.alloc(n_words)) || (rc = d_prefix.alloc(n_words)) ||
         (rc = d_partial.alloc(n_combs ? (size_t)n_slices * (C1 + 1) : 1)) || (rc = d_pair_code.alloc(n_pairs)) || (rc = d_pair_idx.alloc(n_pairs)) ||
-        (rc = d_deal_counts.alloc(n_deal_counts)) || (rc = d_lists32.alloc((size_t)n_segs + 2 * (size_t)n_chunks)) || (rc = d_fuse.alloc((size_t)n_fs + n_fb + n_fm)) ||
+        (rc = d_deal_counts.alloc(n_deal_counts)) || (rc = d_lists32.alloc((size_t)n_segs + 2 * (size_t)n_chunks)) || (rc = d_fuse.alloc((size_t)n_ft + n_fs + n_fb + n_fm)) ||
         (rc = d_items.alloc((size_t)n_is + n_ib)) || (rc = d_slices.alloc(n_slices)) || (rc = d_combs.alloc(n_combs)) || (rc = d_segs.alloc(n_segs)) ||
         (rc = d_deals.alloc(n_deals)))
         return rc;
     // soft-masked reads of the fused classes are redone on the device (k_long_bytes + k_readid_list over byte strings): whole k-mers, rows of
     // at most 1 KiB, no stripe pass — elsewhere they take the sorting path
-    const bool bytes_on_device = own_search && !msz && (n_fs + n_fb) > 0;
-    const uint32_t n_fused = n_fs + n_fb;
+    const bool bytes_on_device = own_search && !msz && (n_ft + n_fs + n_fb) > 0;
+    const uint32_t n_fused = n_ft + n_fs + n_fb;
     DevBuf<uint32_t> d_lower(c);
     DevBuf<uint8_t> d_bytes_read(c);
     if (bytes_on_device) {
@@ -1314,10 +1323,10 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         HIP_TRY(hipMemsetAsync(d_bytes_read.p, 0, n_reads, st));
     }
     LongLists L{};
-    L.fused_small = d_fuse.p; L.fused_big = d_fuse.p + n_fs; L.fused_multi = L.fused_big + n_fb; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
+    L.fused_tiny = d_fuse.p; L.fused_small = d_fuse.p + n_ft; L.fused_big = L.fused_small + n_fs; L.fused_multi = L.fused_big + n_fb; L.seg_read = d_lists32.p; L.chunk_deal = L.seg_read + n_segs; L.chunk_no = L.chunk_deal + n_chunks;
     L.items_small = d_items.p; L.items_big = d_items.p + n_is;
     L.slices = d_slices.p; L.combs = d_combs.p; L.segs = d_segs.p; L.deals = d_deals.p;
-    if (n_fs + n_fb + n_fm) hipLaunchKernelGGL(k_long_emit<1u>, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, pp, L);
+    if (n_ft + n_fs + n_fb + n_fm) hipLaunchKernelGGL(k_long_emit<1u>, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, st, pp, L);
     if (n_is + n_ib) hipLaunchKernelGGL(k_long_emit<64u>, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, st, pp, L);
     HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, n_words * 4, st));
     HIP_TRY(hipGetLastError());
@@ -1369,7 +1378,14 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         LongFuseParams fp{};
         fp.k = k; fp.msz = msz; fp.stride = stride_d; fp.sentinel = sentinel; fp.codes = d_codes.p; fp.bitmap = d_bitmap.p; fp.redo = d_redo.p; fp.flags = d_flags.p;
         if (bytes_on_device) { fp.lower_list = d_lower.p + 4; fp.n_lower = d_lower.p; }
+        if (n_ft) {
+            fp.items = L.fused_tiny; fp.n_list = n_ft; fp.big = 0; fp.item_base = 0; fp.max_slots = kLongSlotsTiny; fp.pos_cap = kFusePosTiny; fp.bm_words = kLongTinyWin / 32;
+            unsigned g = (n_cu * 16u + 7u) & ~7u;   // sixteen waves to a CU
+            hipLaunchKernelGGL((k_long_fused<kLongBlockTiny, kLongTinyWin / kLongBlockTiny>), dim3(g), dim3(kLongBlockTiny),
+                               (kLongSlotsTiny + kFusePosTiny / 16 + 4 + kFusePosTiny / 32 + 4 + kLongTinyWin / 32) * 4, st, fp);
+        }
         if (n_fs) {
+            fp.item_base = n_ft;
             fp.items = L.fused_small; fp.n_list = n_fs; fp.big = 0; fp.max_slots = kLongSlotsSmall; fp.pos_cap = kFusePosSmall; fp.bm_words = kLongSmallWin / 32;
             unsigned g = (n_cu * 4u + 7u) & ~7u;
             hipLaunchKernelGGL((k_long_fused<kLongBlockSmall, kLongSmallWin / kLongBlockSmall>), dim3(g), dim3(kLongBlockSmall),
@@ -1382,6 +1398,7 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         fp.prof = n_fb ? d_prof.p : nullptr;
 #endif
         if (n_fb) {
+            fp.item_base = 0;
             fp.items = L.fused_big; fp.n_list = n_fb; fp.big = 1; fp.max_slots = kLongSlotsBig; fp.pos_cap = kFusePosBig; fp.bm_words = kLongFill / 32;
             const int shmem = (int)((kLongSlotsBig + kFusePosBig / 16 + 4 + kFusePosBig / 32 + 4 + kLongFill / 32) * 4);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_long_fused<kLongBlockBig, kLongFill / kLongBlockBig>),
@@ -1409,7 +1426,8 @@ int readid_long(cid_ctx *c, const cid_index *ix, const uint8_t *d_bases, const u
         }
         if (bytes_on_device) {
             LongBytesParams bp{};
-            bp.items_small = L.fused_small; bp.items_big = L.fused_big; bp.lower = d_lower.p + 4; bp.n_lower = d_lower.p; bp.bases = d_bases;
+            // (the shortest reads' list lies before the small ones': item_base)
+            bp.items_small = L.fused_tiny; bp.items_big = L.fused_big; bp.lower = d_lower.p + 4; bp.n_lower = d_lower.p; bp.bases = d_bases;
             bp.k = k; bp.stride = stride_d; bp.codes = d_codes.p; bp.bitmap = d_bitmap.p; bp.bytes_read = d_bytes_read.p;
             bp.redo = d_redo.p; bp.flags = d_flags.p;
             const int shmem = (int)((kLongSlotsBig + kFusePosBig / 16 + 4 + 2 * (kFusePosBig / 32 + 4) + kLongFill / 32) * 4);

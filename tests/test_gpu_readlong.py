@@ -252,15 +252,22 @@ def test_fused_and_two_kernel_paths_agree_on_every_class(orc, hip_ctx):
     # bases within its LDS) beside the buckets of k_long_first_flags
     reads += [[g[:32_792]], [g[:32_793]], [g[:49_176]], [g[:49_177]], [g[:24_000], g[60_000:84_000]], [g[:10_000] * 4], [g[44_999::-1]],
               [g[:30_000] + b"acgt" + g[30_000:35_000]], [b"N" * 20_000 + g[:25_000]]]
-    for fuse, multi in ((1, 1), (1, 0), (0, 1)):
+    # ... and the shortest reads of the path, a wave each (up to 1 024 windows: k = 25, so 1 048 bases), alone and as pairs
+    reads += [[g[:700]], [g[:1_047]], [g[:1_048]], [g[:1_049]], [g[:500], g[300:800]], [g[:300], b"", g[:300], g[100:400]], [g[:512] * 2], [b"N" * 600 + g[:400]],
+              [g[:200] + b"acgtacgt" + g[200:700]]]
+    for fuse, multi, tiny in ((1, 1, 1), (1, 0, 0), (0, 1, 1)):
         hip_ctx.tune("readid_long_fuse", fuse)
         hip_ctx.tune("readid_long_multi", multi)
+        hip_ctx.tune("readid_long_tiny", tiny)
+        hip_ctx.tune("readid_long_from", 0)   # (every read on this path, however short)
         try:
             for d, S in ((1, 3), (4, 0), (13, 2)):
-                compare(oix, hx, reads, d, S, ("classes", fuse, multi, d, S))
+                compare(oix, hx, reads, d, S, ("classes", fuse, multi, tiny, d, S))
         finally:
             hip_ctx.tune("readid_long_fuse", 1)
             hip_ctx.tune("readid_long_multi", 1)
+            hip_ctx.tune("readid_long_tiny", 1)
+            hip_ctx.tune("readid_long_from", -1)
     hx.close()
 
 
