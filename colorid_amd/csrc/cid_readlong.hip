@@ -72,24 +72,20 @@ __device__ __forceinline__ uint32_t long_mix32(uint64_t code) {
     return x;
 }
 
-// The pre-pass of long reads (more than kDealFromBuckets buckets): every bucket's workgroup used to re-read and re-hash ALL the read's
+// The pre-pass of long reads (kDealFromBuckets buckets and more): every bucket's workgroup used to re-read and re-hash ALL the read's
 // windows to find its own — 100 kb reads 11.1 ms, 1 Mb reads 26.9 ms per 150 Mbases against 8.0 at 10 kb.  Here a workgroup takes one
 // chunk of a read and deals its (code, window) pairs to the buckets' segments once (LDS counters hand out the places); a bucket's pass
 // then reads its own pairs only.  A segment has room for the mean + 25 % + 96 (the mixed codes spread evenly: four standard deviations
 // are 12 % at 16 384 / 7 per segment, less at more buckets' smaller means only in absolute terms — hence the + 96); one that
 // overflows anyway marks its read (redo[read], flags[1]): that read alone is redone on the sorting path.
-constexpr uint32_t kDealBlock = 1024, kDealStageFrom = 24;   // buckets from which a chunk's pairs are grouped in LDS before they are written
+// The chunk's words of the read's bitmap are written here as well, a bit for every window that holds a k-mer: the buckets' passes
+// (k_long_first_flags) take the bits of the later occurrences OUT instead of putting the first occurrences' in.
+constexpr uint32_t kDealBlock = 1024;
 __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes, const uint64_t *wstart, const uint64_t *wend, const LongDeal *deals,
                                                            const uint32_t *chunk_deal, const uint32_t *chunk_no, uint32_t n_chunks_all, uint64_t sentinel,
                                                            uint64_t *pair_code, uint32_t *pair_idx, uint32_t *counts, int *flags, uint8_t *redo,
                                                            uint32_t *bitmap) {
-    // The chunk's words of the read's bitmap are written here, a bit for every window that holds a k-mer: the buckets' passes
-    // (k_long_first_flags) take the bits of the later occurrences OUT instead of putting the first occurrences' in.
-    // A chunk's windows are first grouped by bucket in LDS (their numbers only: 64 KiB), then every bucket's pairs leave as one stretch:
-    // written straight from the window loop a wave's 64 pairs went to forty different segments, 8 and 4 bytes at a time — 2.5 ms per 150 M
-    // windows of 1 Mb reads, the price of 64-byte memory transactions for 12 bytes.
-    __shared__ uint32_t s_cnt[256], s_start[257], s_cur[256];
-    __shared__ uint32_t s_idx[kDealChunk];
+    __shared__ uint32_t s_cnt[256];
     for (uint32_t ci = blockIdx.x; ci < n_chunks_all; ci += gridDim.x) {
         const LongDeal d = deals[chunk_deal[ci]];
         const uint32_t j = chunk_no[ci];
@@ -99,70 +95,40 @@ __global__ __launch_bounds__(kDealBlock) void k_long_deal(const uint64_t *codes,
         const uint32_t a = j * kDealChunk, b = a + kDealChunk < nw ? a + kDealChunk : nw;
         if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        if (P < kDealStageFrom) {   // (uniform) few buckets: a wave's pairs fall into few segments as they are — 100 kb reads 9.4 ms so, 9.9 staged
-            for (uint32_t wb = a; wb < b; wb += kDealBlock) {   // (a is a multiple of 64 and so is every wave's first window)
-                const uint32_t w = wb + threadIdx.x;
-                const uint64_t code = w < b ? codes[w0 + w] : sentinel;
-                const bool valid = code < sentinel;
-                const uint64_t vm = __ballot(valid);
-                if ((threadIdx.x & 31u) == 0 && w < b) bitmap[(w0 + w) >> 5] = (uint32_t)(vm >> (threadIdx.x & 32u));
-                if (!valid) continue;
-                const uint32_t bk = (uint32_t)(((long_mix(code) >> 32) * P) >> 32);
-                const uint32_t at = atomicAdd(&s_cnt[bk], 1u);
-                if (at < d.cap) {
-                    const uint64_t o = d.pair_base + ((uint64_t)bk * d.n_chunks + j) * d.cap + at;
-                    pair_code[o] = code;
-                    pair_idx[o] = w;
-                } else { redo[d.read] = 1; atomicOr(&flags[1], 1); }
-            }
-            __syncthreads();
-            if (threadIdx.x < P) counts[d.count_base + threadIdx.x * d.n_chunks + j] = s_cnt[threadIdx.x] < d.cap ? s_cnt[threadIdx.x] : d.cap;
-            __syncthreads();
-            continue;
+        // A thread's sixteen windows are ASKED FOR together (every load unconditional, from an address that exists), then counted together,
+        // then written: one window per trip — load, hash, count, write — was sixteen trips to memory in a row per chunk (and forty-eight
+        // in the form that grouped a chunk's pairs by bucket in LDS before writing them, which reads of 24 buckets and more took until
+        // round 6: 1.62 ms per 150 Mbases of 1 Mb reads; grouped with its loads batched 1.45; this, 1.16 — a wave's 64 pairs fall into
+        // forty segments, but the writes are on their way together).
+        constexpr uint32_t kPer = kDealChunk / kDealBlock, kNoBucket = 0xFFFFu;
+        uint64_t c[kPer];
+        uint32_t bk[kPer], at[kPer];   // the window's bucket (kNoBucket: no k-mer there) and its place in the bucket's segment
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint32_t w = a + i * kDealBlock + threadIdx.x;
+            c[i] = codes[w0 + (w < b ? w : a)];
         }
-        for (uint32_t wb = a; wb < b; wb += kDealBlock) {
-            const uint32_t w = wb + threadIdx.x;
-            const uint64_t code = w < b ? codes[w0 + w] : sentinel;
-            const bool valid = code < sentinel;
-            const uint64_t vm = __ballot(valid);
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            const uint32_t w = a + i * kDealBlock + threadIdx.x;
+            const bool valid = w < b && c[i] < sentinel;
+            const uint64_t vm = __ballot(valid);   // (a is a multiple of 64 and so is every wave's first window)
             if ((threadIdx.x & 31u) == 0 && w < b) bitmap[(w0 + w) >> 5] = (uint32_t)(vm >> (threadIdx.x & 32u));
-            if (valid) atomicAdd(&s_cnt[(uint32_t)(((long_mix(code) >> 32) * P) >> 32)], 1u);
+            bk[i] = valid ? (uint32_t)(((long_mix(c[i]) >> 32) * P) >> 32) : kNoBucket;
         }
-        __syncthreads();
-        if (threadIdx.x < 64) {   // exclusive prefix over the (<= 256) bucket counts: four per lane
-            uint32_t c4[4], sum = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) { c4[q] = s_cnt[threadIdx.x * 4 + q]; sum += c4[q]; }
-            uint32_t inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o, 64);
-                if ((int)threadIdx.x >= o) inc += up;
-            }
-            uint32_t base = inc - sum;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) { s_start[threadIdx.x * 4 + q] = base; s_cur[threadIdx.x * 4 + q] = base; base += c4[q]; }
-            if (threadIdx.x == 63) s_start[256] = base;
-        }
-        __syncthreads();
-        for (uint32_t w = a + threadIdx.x; w < b; w += kDealBlock) {
-            const uint64_t code = codes[w0 + w];
-            if (code >= sentinel) continue;
-            const uint32_t bk = (uint32_t)(((long_mix(code) >> 32) * P) >> 32);
-            s_idx[atomicAdd(&s_cur[bk], 1u)] = w | (bk << 24);   // (w < 2^22 - 1, bk < 256: the write-out below needs no search for its bucket)
-        }
-        __syncthreads();
-        const uint32_t total = s_start[256];
+        for (uint32_t i = 0; i < kPer; ++i) at[i] = bk[i] != kNoBucket ? atomicAdd(&s_cnt[bk[i]], 1u) : 0u;
         bool over = false;
-        for (uint32_t p = threadIdx.x; p < total; p += kDealBlock) {
-            const uint32_t v = s_idx[p], lo = v >> 24, w = v & 0xFFFFFFu;   // the bucket of place p: s_start[lo] <= p < s_start[lo + 1]
-            const uint32_t at = p - s_start[lo];
-            if (at < d.cap) {
-                const uint64_t o = d.pair_base + ((uint64_t)lo * d.n_chunks + j) * d.cap + at;
-                pair_code[o] = codes[w0 + w];
-                pair_idx[o] = w;
+#pragma unroll
+        for (uint32_t i = 0; i < kPer; ++i) {
+            if (bk[i] == kNoBucket) continue;
+            if (at[i] < d.cap) {
+                const uint64_t o = d.pair_base + ((uint64_t)bk[i] * d.n_chunks + j) * d.cap + at[i];
+                pair_code[o] = c[i];
+                pair_idx[o] = a + i * kDealBlock + threadIdx.x;
             } else over = true;
         }
+        __syncthreads();
         if (over) { redo[d.read] = 1; atomicOr(&flags[1], 1); }
         if (threadIdx.x < P) counts[d.count_base + threadIdx.x * d.n_chunks + j] = s_cnt[threadIdx.x] < d.cap ? s_cnt[threadIdx.x] : d.cap;
         __syncthreads();

@@ -272,7 +272,7 @@ def test_fused_and_two_kernel_paths_agree_on_every_class(orc, hip_ctx):
 
 
 def _random_long_read(rng, genome, k):
-    """a read of 1 kb ... 420 kb (two buckets undealt, three and more dealt, 24 and more with the pairs grouped in LDS first) made of stretches
+    """a read of 1 kb ... 420 kb (one to three tables in the fused kernel, more: dealt to hash buckets) made of stretches
     of the genome: some repeated, some with N runs, some reverse-complemented"""
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     L = int(rng.choice([1_000, 1_500, 3_000, 4_100, 9_000, 16_500, 33_000, 50_000, 70_000, 120_000, 420_000]))
