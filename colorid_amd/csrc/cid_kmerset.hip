@@ -139,7 +139,9 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
     constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (sentinels) [1] big runs [2] largest run [3] crowded runs (hard) [4] the radix kernel's runs (hard2) [5] runs sampled [6] of them crowded
     DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c), hard2(c);
     DevBuf<uint64_t> scan_state(c);
+    DevBuf<PartTile> desc(c);
     int rc;
+    if ((rc = desc.alloc((size_t)max_tiles + 1))) return rc;
     if ((rc = seg_a.alloc((size_t)n_runs + 1)) || (rc = seg_b.alloc((size_t)n_runs + 1)) || (rc = tile_base.alloc((size_t)S_last + 1)) ||
         (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)) || (rc = hard2.alloc((size_t)n_runs + 1)))
         return rc;
@@ -157,10 +159,11 @@ int msd_sort(cid_ctx *c, hipStream_t st, uint64_t *a, uint64_t *b, size_t n, uns
         const uint32_t level_top = l == 0 ? top : 64u;    // the first level leaves the sentinels behind
         const size_t table_n = (size_t)part_max_tiles((uint32_t)n, S) * bins;
         hipLaunchKernelGGL(k_part_tiles, dim3(1), dim3(kPartBlock), 0, st, seg, S, tile_base.p);
+        hipLaunchKernelGGL(k_part_tile_desc, dim3((part_max_tiles((uint32_t)n, S) + 255) / 256), dim3(256), 0, st, seg, tile_base.p, S, bins, desc.p);
         hipLaunchKernelGGL(k_part_zero_tail, dim3(256), dim3(256), 0, st, table.p, tile_base.p, S, bins, (uint64_t)table_n);
-        hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(kPartBlock), 0, st, src, seg, tile_base.p, S, shift, bits, level_top, table.p, info.p);
+        hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(kPartBlock), 0, st, (const PartTile *)desc.p, src, seg, tile_base.p, S, shift, bits, level_top, table.p, info.p);
         HIP_TRY(scan_launch(U32In{table.p}, U32Out{table.p}, table_n, scan_state.p, st));   // in place: a thread reads its elements before it writes them
-        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(kPartBlock), 0, st, src, dst, seg, tile_base.p, S, shift, bits, level_top, table.p);
+        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(kPartBlock), 0, st, (const PartTile *)desc.p, src, dst, seg, tile_base.p, S, shift, bits, level_top, table.p);
         hipLaunchKernelGGL(k_part_offsets, dim3((S * bins + 256) / 256), dim3(256), 0, st, table.p, tile_base.p, S, bits, (uint32_t)n, info.p, seg_next);
         HIP_TRY(hipGetLastError());
         std::swap(src, dst);
@@ -243,7 +246,9 @@ int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_
     constexpr uint32_t kInfo = 8, kBigCap = 1024;          // info: [0] dropped (no k-mer) [1] big runs [2] largest run [3] crowded runs (hard) [4] the radix kernel's runs (hard2) [5] runs sampled [6] of them crowded
     DevBuf<uint32_t> seg_a(c), seg_b(c), tile_base(c), table(c), info(c), hard(c), hard2(c);
     DevBuf<uint64_t> scan_state(c);
+    DevBuf<PartTile> desc(c);
     int rc;
+    if ((rc = desc.alloc((size_t)max_tiles + 1))) return rc;
     if ((rc = seg_a.alloc((size_t)n_runs + 1)) || (rc = seg_b.alloc((size_t)n_runs + 1)) || (rc = tile_base.alloc((size_t)S_last + 1)) ||
         (rc = table.alloc((size_t)max_tiles * kPartBins)) || (rc = info.alloc(kInfo + kBigCap)) || (rc = hard.alloc((size_t)n_runs + 1)) || (rc = hard2.alloc((size_t)n_runs + 1)))
         return rc;
@@ -261,10 +266,11 @@ int msd_sort_pair(cid_ctx *c, hipStream_t st, uint32_t *keys_a, uint64_t *codes_
         const uint32_t bits = lbits[l], shift = 32 - consumed - bits, bins = 1u << bits;
         const size_t table_n = (size_t)part_max_tiles((uint32_t)n, S) * bins;
         hipLaunchKernelGGL(k_part_tiles, dim3(1), dim3(kPartBlock), 0, st, seg, S, tile_base.p);
+        hipLaunchKernelGGL(k_part_tile_desc, dim3((part_max_tiles((uint32_t)n, S) + 255) / 256), dim3(256), 0, st, seg, tile_base.p, S, bins, desc.p);
         hipLaunchKernelGGL(k_part_zero_tail, dim3(256), dim3(256), 0, st, table.p, tile_base.p, S, bins, (uint64_t)table_n);
-        hipLaunchKernelGGL(k_part_hist_key, dim3(grid), dim3(kPartBlock), 0, st, ksrc, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u, table.p, info.p);
+        hipLaunchKernelGGL(k_part_hist_key, dim3(grid), dim3(kPartBlock), 0, st, (const PartTile *)desc.p, ksrc, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u, table.p, info.p);
         HIP_TRY(scan_launch(U32In{table.p}, U32Out{table.p}, table_n, scan_state.p, st));   // in place: a thread reads its elements before it writes them
-        hipLaunchKernelGGL(k_part_scatter_pair, dim3(grid), dim3(kPartBlock), 0, st, ksrc, src, kdst, dst, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u,
+        hipLaunchKernelGGL(k_part_scatter_pair, dim3(grid), dim3(kPartBlock), 0, st, (const PartTile *)desc.p, ksrc, src, kdst, dst, seg, tile_base.p, S, shift, bits, l == 0 ? 1u : 0u,
                            table.p);
         hipLaunchKernelGGL(k_part_offsets, dim3((S * bins + 256) / 256), dim3(256), 0, st, table.p, tile_base.p, S, bits, (uint32_t)n, info.p, seg_next);
         HIP_TRY(hipGetLastError());

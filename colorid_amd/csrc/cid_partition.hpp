@@ -65,6 +65,14 @@ __device__ __forceinline__ PartTile part_tile(const uint32_t *seg_off, const uin
     return t;
 }
 
+// Every tile's description, once per level: found tile by tile inside the histogram and scatter kernels it was a chain of dependent loads
+// at the start of every tile — the binary search over tile_base (eight steps at the second level's 256 segments), then the segment's
+// bounds — which an in-order wave cannot overlap with anything.
+__global__ void k_part_tile_desc(const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S, uint32_t bins, PartTile *desc) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile < tile_base[S]) desc[tile] = part_tile(seg_off, tile_base, S, tile, bins);
+}
+
 // Which tiles a workgroup of a scatter kernel takes.  The runs a tile writes continue, byte for byte, the runs of the tile before it
 // (same digit), so neighbouring tiles fill the same 128-byte lines.  Workgroups are dealt to the eight XCDs in turn (blockIdx & 7) and
 // every XCD has an L2 of its own: with tile = blockIdx (+ k * gridDim) those two halves of a line are always written through two
@@ -83,15 +91,20 @@ struct XcdWalk {
 
 // `top` < 64: keys with a bit at or above `top` (the k-mer set's "no k-mer here" sentinel) are left out of the partition — counted
 // into *n_dropped by the first level, skipped by the scatter — so that every digit below `top` orders real keys only.
-__global__ __launch_bounds__(kPartBlock) void k_part_hist(const uint64_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
+__global__ __launch_bounds__(kPartBlock) void k_part_hist(const PartTile *desc, const uint64_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
                                                            uint32_t shift, uint32_t bits, uint32_t top, uint32_t *table, uint32_t *n_dropped) {
     __shared__ uint32_t s_cnt[kPartBins], s_drop;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
     const XcdWalk walk(n_tiles);   // (the table's entries of neighbouring tiles share lines, like the scatter's runs)
+    PartTile t_next = desc[walk.tile(walk.first()) < n_tiles ? walk.tile(walk.first()) : 0u];   // (the next tile's description is asked for a tile ahead)
     for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
         const uint32_t tile = walk.tile(it);
         if (tile >= n_tiles) break;
-        const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        const PartTile t = t_next;
+        {
+            const uint32_t nt = walk.tile(it + walk.stride());
+            t_next = desc[it + walk.stride() < walk.chunk && nt < n_tiles ? nt : tile];
+        }
         constexpr uint32_t PER = kPartTile / kPartBlock;
         uint64_t k[PER];
 #pragma unroll
@@ -116,17 +129,22 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(const uint64_t *keys, 
     }
 }
 
-__global__ __launch_bounds__(kPartBlock) void k_part_scatter(const uint64_t *keys, uint64_t *out, const uint32_t *seg_off, const uint32_t *tile_base,
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter(const PartTile *desc, const uint64_t *keys, uint64_t *out, const uint32_t *seg_off, const uint32_t *tile_base,
                                                               uint32_t S, uint32_t shift, uint32_t bits, uint32_t top, const uint32_t *table) {
     __shared__ uint64_t s_stage[kPartTile];
     __shared__ uint32_t s_cnt[kPartBins], s_pre[kPartBins], s_cur[kPartBins], s_goff[kPartBins], s_wave[kPartBlock / 64];
     constexpr uint32_t PER = kPartTile / kPartBlock;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
     const XcdWalk walk(n_tiles);
+    PartTile t_next = desc[walk.tile(walk.first()) < n_tiles ? walk.tile(walk.first()) : 0u];   // (the next tile's description is asked for a tile ahead)
     for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
         const uint32_t tile = walk.tile(it);
         if (tile >= n_tiles) break;
-        const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        const PartTile t = t_next;
+        {
+            const uint32_t nt = walk.tile(it + walk.stride());
+            t_next = desc[it + walk.stride() < walk.chunk && nt < n_tiles ? nt : tile];
+        }
         s_cnt[threadIdx.x] = 0;
         s_goff[threadIdx.x] = threadIdx.x < bins ? table[t.table_at + threadIdx.x * t.table_stride] : 0u;
         __syncthreads();
@@ -405,16 +423,21 @@ __global__ void k_run_sizes(const uint32_t *run_off, uint32_t n_runs, uint32_t c
 // lines.  A key of all ones marks "no k-mer here" (row0_key never produces it) and is left out by the first level.
 // (kNoKey: cid_kernels.hpp)
 
-__global__ __launch_bounds__(kPartBlock) void k_part_hist_key(const uint32_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
+__global__ __launch_bounds__(kPartBlock) void k_part_hist_key(const PartTile *desc, const uint32_t *keys, const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S,
                                                                uint32_t shift, uint32_t bits, uint32_t first_level, uint32_t *table, uint32_t *n_dropped) {
     __shared__ uint32_t s_cnt[kPartBins], s_drop;
     constexpr uint32_t PER = kPartTile / kPartBlock;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
     const XcdWalk walk(n_tiles);
+    PartTile t_next = desc[walk.tile(walk.first()) < n_tiles ? walk.tile(walk.first()) : 0u];   // (the next tile's description is asked for a tile ahead)
     for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
         const uint32_t tile = walk.tile(it);
         if (tile >= n_tiles) break;
-        const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        const PartTile t = t_next;
+        {
+            const uint32_t nt = walk.tile(it + walk.stride());
+            t_next = desc[it + walk.stride() < walk.chunk && nt < n_tiles ? nt : tile];
+        }
         uint32_t k[PER];
 #pragma unroll
         for (uint32_t j = 0; j < PER; ++j) {   // the tile's loads in flight together
@@ -440,7 +463,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist_key(const uint32_t *ke
 }
 
 // Keys and values are staged side by side in LDS (48 KiB: three workgroups per CU) and leave as one run per digit each.
-__global__ __launch_bounds__(kPartBlock) void k_part_scatter_pair(const uint32_t *keys, const uint64_t *vals, uint32_t *keys_out, uint64_t *vals_out,
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter_pair(const PartTile *desc, const uint32_t *keys, const uint64_t *vals, uint32_t *keys_out, uint64_t *vals_out,
                                                                    const uint32_t *seg_off, const uint32_t *tile_base, uint32_t S, uint32_t shift,
                                                                    uint32_t bits, uint32_t first_level, const uint32_t *table) {
     __shared__ uint64_t s_val[kPartTile];
@@ -449,10 +472,15 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter_pair(const uint32_t
     constexpr uint32_t PER = kPartTile / kPartBlock;
     const uint32_t n_tiles = tile_base[S], bins = 1u << bits;
     const XcdWalk walk(n_tiles);
+    PartTile t_next = desc[walk.tile(walk.first()) < n_tiles ? walk.tile(walk.first()) : 0u];   // (the next tile's description is asked for a tile ahead)
     for (uint32_t it = walk.first(); it < walk.chunk; it += walk.stride()) {
         const uint32_t tile = walk.tile(it);
         if (tile >= n_tiles) break;
-        const PartTile t = part_tile(seg_off, tile_base, S, tile, bins);
+        const PartTile t = t_next;
+        {
+            const uint32_t nt = walk.tile(it + walk.stride());
+            t_next = desc[it + walk.stride() < walk.chunk && nt < n_tiles ? nt : tile];
+        }
         s_cnt[threadIdx.x] = 0;
         s_goff[threadIdx.x] = threadIdx.x < bins ? table[t.table_at + threadIdx.x * t.table_stride] : 0u;
         __syncthreads();

@@ -82,6 +82,8 @@ static void run_msd(const uint64_t *in, uint64_t *out, uint64_t *tmp_keys, size_
     const uint32_t top = end_bit - 1;   // the sentinel's bit: real codes live below it (the product clamps the sentinel into the last bin)
     const uint32_t max_tiles = part_max_tiles((uint32_t)n, S2);
     uint32_t *seg0, *seg1, *seg2, *tile_base, *table, *d_info, *hard;
+    PartTile *desc;
+    CHECK(hipMalloc(&desc, ((size_t)max_tiles + 1) * sizeof(PartTile)));
     CHECK(hipMalloc(&seg0, 2 * 4)); CHECK(hipMalloc(&seg1, (S2 + 1) * 4)); CHECK(hipMalloc(&seg2, (S3 + 1) * 4));
     CHECK(hipMalloc(&tile_base, (S2 + 1) * 4)); CHECK(hipMalloc(&table, (size_t)max_tiles * kPartBins * 4)); CHECK(hipMalloc(&d_info, 1024 * 4)); CHECK(hipMalloc(&hard, (S3 + 1) * 4));
     CHECK(hipMemset(d_info, 0, 64));
@@ -98,9 +100,10 @@ static void run_msd(const uint64_t *in, uint64_t *out, uint64_t *tmp_keys, size_
     auto pass = [&](const uint64_t *src, uint64_t *dst, const uint32_t *seg, uint32_t S, uint32_t shift, uint32_t *seg_next) {
         CHECK(hipMemsetAsync(table, 0, (size_t)max_tiles * kPartBins * 4, hipStreamDefault));
         hipLaunchKernelGGL(k_part_tiles, dim3(1), dim3(kPartBlock), 0, 0, seg, S, tile_base);
-        hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(kPartBlock), 0, 0, src, seg, tile_base, S, shift, 8u, 64u, table, d_info + 8);
+        hipLaunchKernelGGL(k_part_tile_desc, dim3((max_tiles + 255) / 256), dim3(256), 0, 0, seg, tile_base, S, kPartBins, desc);
+        hipLaunchKernelGGL(k_part_hist, dim3(grid), dim3(kPartBlock), 0, 0, (const PartTile *)desc, src, seg, tile_base, S, shift, 8u, 64u, table, d_info + 8);
         CHECK(rocprim::exclusive_scan(scan_tmp, scan_tb, table, table, 0u, (size_t)max_tiles * kPartBins, rocprim::plus<uint32_t>(), hipStreamDefault));
-        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(kPartBlock), 0, 0, src, dst, seg, tile_base, S, shift, 8u, 64u, table);
+        hipLaunchKernelGGL(k_part_scatter, dim3(grid), dim3(kPartBlock), 0, 0, (const PartTile *)desc, src, dst, seg, tile_base, S, shift, 8u, 64u, table);
         hipLaunchKernelGGL(k_part_offsets, dim3((S * kPartBins + 256) / 256), dim3(256), 0, 0, table, tile_base, S, 8u, (uint32_t)n, d_info + 8, seg_next);
         CHECK(hipGetLastError());
     };
