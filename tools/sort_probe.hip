@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "../colorid_amd/csrc/cid_kernels.hpp"   // (kNoKey)
 #include "../colorid_amd/csrc/cid_partition.hpp"
 
 #define CHECK(e)                                                                     \
