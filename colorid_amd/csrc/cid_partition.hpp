@@ -321,6 +321,8 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort(const uint64_t *
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t bshift = bits > kBucketBits ? bits - kBucketBits : 0u;
     const uint32_t bmask = bits >= kBucketBits ? kBuckets - 1u : ((1u << bits) - 1u);
+    // (the same look-ahead as k_run_bucket_sort_pair's made THIS kernel slower — 3.07-3.11 -> 3.25-3.29 ms per set in code order: with
+    // sixteen keys per thread in its larger instantiation the next run's keys cost it its occupancy)
     for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
         const uint32_t start = run_off[run], N = run_off[run + 1] - start;
         if (N < min_size) continue;    // (uniform over the block) nothing there, or a smaller instantiation's run
@@ -567,8 +569,40 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint3
     const uint32_t total_bits = ord.kbits + ord.vbits;
     const uint32_t bbits = total_bits < kBucketBits ? total_bits : kBucketBits;
     const uint32_t kmask = ord.kmask();
+    // The NEXT run's pairs are asked for before this run's are worked on, and the offsets of the run after that: a run is two trips to
+    // memory (its offsets, then its pairs) and seven barriers of LDS work, and a wave issues in order — it cannot be ahead of a load it has
+    // not asked for yet.  Every load unconditional, from an address that exists (pair 0 stands in for what a run does not have).
+    // 1.04 -> 0.81 ms per 120 M pairs.  (The same in k_part_scatter_pair — 48 registers of the next tile's pairs — made it slower:
+    // 0.91 -> 0.94 ms; its tiles are not waiting for their loads.)
+    uint32_t start_n = 0, N_n = 0, start_nn = 0, N_nn = 0;
+    uint64_t val_n[MAXR];
+    uint32_t key_n[MAXR];
+    auto offsets = [&](uint32_t run, uint32_t &st, uint32_t &n) {
+        const uint32_t r = run < n_runs ? run : 0u;
+        st = run_off[r];
+        n = run < n_runs ? run_off[r + 1] - st : 0u;
+    };
+    auto pairs = [&](uint32_t st, uint32_t n) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const uint32_t p = (uint32_t)r * kPartBlock + threadIdx.x;
+            const uint32_t at = p < n ? st + p : 0u;
+            key_n[r] = keys[at];
+            val_n[r] = vals[at];
+        }
+    };
+    offsets(blockIdx.x, start_n, N_n);
+    offsets(blockIdx.x + gridDim.x, start_nn, N_nn);
+    pairs(start_n, N_n);
     for (uint32_t run = blockIdx.x; run < n_runs; run += gridDim.x) {
-        const uint32_t start = run_off[run], N = run_off[run + 1] - start;
+        const uint32_t start = start_n, N = N_n;
+        uint64_t val[MAXR];
+        uint32_t key[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) { key[r] = key_n[r] & kmask; val[r] = val_n[r]; }
+        start_n = start_nn; N_n = N_nn;
+        pairs(start_n, N_n);
+        offsets(run + 2u * gridDim.x, start_nn, N_nn);
         if (N < min_size) continue;
         if (N > kPartBlock * MAXR) {
             if (threadIdx.x == 0 && MAXR == 16) hard_list[atomicAdd(n_hard, 1u)] = run;
@@ -577,14 +611,6 @@ __global__ __launch_bounds__(kPartBlock) void k_run_bucket_sort_pair(const uint3
 #pragma unroll
         for (uint32_t j = 0; j < BPT; ++j) s_cur[threadIdx.x * BPT + j] = 0;
         __syncthreads();
-        uint64_t val[MAXR];
-        uint32_t key[MAXR];
-#pragma unroll
-        for (int r = 0; r < MAXR; ++r) {   // the run's loads in flight together, before the first LDS atomic
-            const uint32_t p = (uint32_t)r * kPartBlock + threadIdx.x;
-            key[r] = p < N ? keys[start + p] & kmask : 0u;
-            val[r] = p < N ? vals[start + p] : 0ull;
-        }
 #pragma unroll
         for (int r = 0; r < MAXR; ++r)
             if ((uint32_t)r * kPartBlock + threadIdx.x < N) atomicAdd(&s_cur[ord.bucket(key[r], val[r], bbits)], 1u);
