@@ -6,13 +6,18 @@
 //   k_long_route         (callers with mixed batches) which reads are this path's: at least `long_from` bases
 //   k_long_plan / _emit  the plan of the batch, on the device (round 6): classes, window numbering, every work list below — from
 //                        seq_off / read_seq0 in HBM; the host reads back 64 bytes of totals to size the lists
-//   k_long_fused         reads of ONE table (<= 16 384 windows: every 10 kb read): bases -> 2-bit fields in LDS -> rolling canonical codes ->
-//                        LDS hash table of 4-byte slots (window index << 10 | 10-bit tag), atomicMin keeps the smallest window per
-//                        code -> the winners' bits as whole words of the first-occurrence bitmap; the codes leave for k_readid_slices
+//   k_long_fused         reads whose bases fit the LDS beside the table: bases -> 2-bit fields in LDS -> rolling canonical codes -> LDS hash
+//                        table of 4-byte slots (window index << 10 | 10-bit tag), atomicMin keeps the smallest window per code -> the
+//                        winners' bits as whole words of the first-occurrence bitmap; the codes leave for k_readid_slices.  Four
+//                        shapes: a wave per read (<= 1 024 windows: 2 048 slots), 256 threads (<= 4 096: 8 192 slots), 1 024 threads
+//                        (<= 16 384 windows, every 10 kb read: 32 768 slots), and that table filled once per hash bucket for reads of
+//                        up to 49 152 windows (two or three passes over the read's bases in LDS)
 //   k_extract_codes      (longer reads, strides that stretch a read beyond the fused kernel's LDS) windows -> canonical 2-bit codes
-//   k_long_deal          reads of three buckets and more: their (code, window) pairs dealt to the buckets' segments once
+//   k_long_deal          reads of three buckets and more: their (code, window) pairs dealt to the buckets' segments once, and a bit
+//                        of the bitmap for every window that holds a k-mer
 //   k_long_first_flags   work item = (read, bucket b of P): the read's windows whose mixed code falls in bucket b through ONE table;
-//                        P = windows / 16 384; a pass that overflows anyway is redone on sub-buckets (a further hash bit per level)
+//                        P = windows / 16 384; a pass that overflows anyway is redone on sub-buckets (a further hash bit per level).
+//                        A dealt bucket's pass takes the LATER occurrences' bits out of the bitmap; the others put the first ones' in
 //   scan (cid_scan.hpp)  exclusive prefix of the bitmap words' popcounts: rank(w) of any window without a second pass
 //   k_readid_slices      the in-order search, one wave per slice of a read, straight from the bitmap and the code array: the flagged
 //                        windows in window order ARE the read's k-mers in first-occurrence order (cid_readid.hip); k_readid_combine
