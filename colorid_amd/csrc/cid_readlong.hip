@@ -190,7 +190,8 @@ __global__ void k_long_first_flags(const uint64_t *codes, const uint64_t *wstart
         const uint32_t mask = slots - 1;
         uint32_t level = 0;
         for (uint32_t sub = 0; sub < (1u << level); ++sub) {
-            for (uint32_t s = threadIdx.x; s < slots; s += blockDim.x) table[s] = kLongEmpty;
+            for (uint32_t s = threadIdx.x; s < slots / 4u; s += blockDim.x)   // (16 bytes a store: slots is a power of two >= 1 024)
+                reinterpret_cast<uint4 *>(table)[s] = uint4{kLongEmpty, kLongEmpty, kLongEmpty, kLongEmpty};
             if (threadIdx.x == 0) s_over = 0;
             __syncthreads();
             FF_MARK(0);
