@@ -61,6 +61,8 @@ for B in tools/bin/colorid_asan "setarch x86_64 -R tools/bin/colorid_tsan"; do
   export COLORID_DEVICE_FASTQ_MB=1
   $B read_id -b $W/ix.bxi -q $W/b_1.fastq.gz -n $W/ridb1 -c 777 > $W/rb1.out 2> $W/rb1.err; echo "read_id SE block gzip rc=$?"; cmp $W/rid1_reads.txt $W/ridb1_reads.txt && echo "same rows as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rb1.err | head -5
   COLORID_DEVICE_FASTQ_AHEAD=3 $B read_id -b $W/ix.bxi -q $W/b_1.fastq.gz $W/b_2.fastq.gz -n $W/ridb -c 5000 > $W/rb.out 2> $W/rb.err; echo "read_id PE block gzip rc=$?"; cmp $W/rid_reads.txt $W/ridb_reads.txt && echo "same rows as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rb.err | head -5
+  # round 6: the stretches in page-locked memory, their copies beside the loop (CID_FASTQ_KEEP on cid_fastq_push_bgzf), the inflate behind the classifier
+  COLORID_DEVICE_FASTQ_PINNED=1 COLORID_DEVICE_FASTQ_HOST_SHARE=0 CID_FASTQ_INFLATE_BESIDE=0 $B read_id -b $W/ix.bxi -q $W/b_1.fastq.gz $W/b_2.fastq.gz -n $W/ridp -c 5000 > $W/rp.out 2> $W/rp.err; echo "read_id PE block gzip, page-locked rc=$?"; cmp $W/rid_reads.txt $W/ridp_reads.txt && echo "same rows as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/rp.err | head -5
   $B search -b $W/ix.bxi -q $W/b_1.fastq.gz -r $W/b_2.fastq.gz -f 0 -p 0.01 > $W/sb.out 2> $W/sb.err; echo "search block gzip rc=$?"; cut -f2- $W/sb.out | sort > $W/sb.sorted; $B search -b $W/ix.bxi -q $W/r_1.fastq.gz -r $W/r_2.fastq.gz -f 0 -p 0.01 2> /dev/null | cut -f2- | sort | cmp - $W/sb.sorted && echo "same report as from the gzip stream"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/sb.err | head -5
   printf "reads\t$W/b_1.fastq.gz\t$W/b_2.fastq.gz\ngenome0\t$W/g0.fasta\n" > $W/refs_fq.tsv
   $B build -s 2000000 -n 3 -k 27 -b $W/ixfq -r $W/refs_fq.tsv > $W/bfq.out 2> $W/bfq.err; echo "build from block gzip rc=$?"; grep -i "sanitizer\|ERROR\|WARNING: Thread" $W/bfq.err | head -5
