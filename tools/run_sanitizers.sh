@@ -1,6 +1,7 @@
 # Host-side sanitizer runs of the CLI on a GPU box (GPU ASan is not available on this pool): build tools/bin/colorid_asan and
 # tools/bin/colorid_tsan with g++ -fsanitize=address,undefined / -fsanitize=thread from colorid_amd/csrc/host/*.cpp first
-# (`make -C tools sanitizers`, in the build container).
+# (`make -C tools sanitizers`, in the build container) and take their two lines out of .gpurunignore for the call (60 MB that the other
+# calls need not carry).
 set -x
 cd $GRAFT_REPO_ROOT
 W=/tmp/san; mkdir -p $W
