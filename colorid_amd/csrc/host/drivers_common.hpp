@@ -85,9 +85,10 @@ struct ReadBatch {  // Vec<(String, Vec<String>)> packed for cid_readid_count
     void end() { read_seq0.push_back(seq_off.size() - 1); }
     const char *id(size_t r) const { return id_chars.data() + id_off[r]; }
     size_t size() const { return id_off.size(); }
-    // long reads: a batch also closes once it holds this many bases (the library numbers a batch's k-mer windows in 32 bits;
-    // batch boundaries never change a read's result)
-    bool heavy() const { return bases.size() >= (256u << 20); }
+    // long reads: a batch also closes once it holds this many bases (batch boundaries never change a read's result).  48 MiB: 150 Mbases of
+    // 10 kb reads are 15 000 reads — fewer than `-c` — and went up as ONE batch behind the whole file's reading (256 MiB until round 6:
+    // 125-140 ms per 150 Mbases of FASTA); in pieces the upload and the GPU's 2 ms per piece run beside the reading of the next
+    bool heavy() const { return bases.size() >= (48u << 20); }
     void clear() { id_chars.clear(); id_off.clear(); bases.clear(); seq_off.assign(1, 0); read_seq0.assign(1, 0); }
 };
 

@@ -1,6 +1,8 @@
 // The reference's read_id drivers with the hot loop replaced by C-ABI calls:
 //   read_id_mt_pe::per_read_stream_se/_pe, stream_fasta (src/read_id_mt_pe.rs) -> cid_readid_count* / cid_fastq_*
 // plus the CPU-side tail (kmer_poll_plus, the counts file of src/reports.rs).  File formats follow the reference.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include "drivers_common.hpp"
 #include <unistd.h>
@@ -649,39 +651,69 @@ void read_id_mt_pe::stream_fasta(cid_ctx *ctx, const std::vector<std::string> &f
     const std::vector<double> fp = false_prob_map(b);
     FILE *out = fopen((prefix + "_reads.txt").c_str(), "w");
     if (!out) die("could not create outfile!");
-    FILE *f = fopen(fq[0].c_str(), "rb");
-    if (!f) die("file not found: %s", fq[0].c_str());
     ReadBatch rb;
     BatchClassifier classifier(ctx, b, d, fp_correct, start_sample, fp, out, " %llu reads classified\r");
-    std::string sub, id;
+    // The reference's loop (read_id_mt_pe.rs:450-569), line by line: the first line is the first id (its last character dropped); a
+    // later line that holds a '>' anywhere closes the record before it IF that record has any sequence yet (else the line is dropped and
+    // the id stays); every other line joins the record's sequence WITH its line end; the end of the file closes the last record
+    // whatever it holds.  A record's lines go straight into the batch's bases (round 6: through getline's buffer, a string of the
+    // record's own and then the batch, a 10 kb read was copied three times and scanned once: 125-140 ms per 150 Mbases, the GPU's 7).
+    std::string id;
     uint64_t count = 0;
-    char *lineptr = nullptr;
-    size_t cap = 0;
-    ssize_t got;
-    setvbuf(f, nullptr, _IOFBF, 8u << 20);
-    while ((got = getline(&lineptr, &cap, f)) > 0) {   // (the line is used where getline left it: a copy per line was a third of the loop on long reads)
-        const size_t n = (size_t)got;
+    size_t rec_start = 0;   // where the open record's sequence begins in rb.bases
+    auto close_record = [&] {
+        rb.begin(id);
+        rb.seq_off.push_back(rb.bases.size());
+        rb.end();
+        rec_start = rb.bases.size();
+    };
+    auto take_line = [&](const char *line, size_t n) {   // n > 0, the line end included when the file has one
         if (count == 0) {
-            id.assign(lineptr, n - 1);
-        } else if (memchr(lineptr, '>', n) != nullptr) {
-            if (!sub.empty()) {
-                rb.push(id, &sub, 1);
-                id.assign(lineptr, n - 1);
-                sub.clear();
+            id.assign(line, n - 1);
+        } else if (memchr(line, '>', n) != nullptr) {
+            if (rb.bases.size() > rec_start) {
+                close_record();
+                id.assign(line, n - 1);
+                if (rb.size() % batch == 0 || rb.heavy()) { classifier.submit(rb); rec_start = rb.bases.size(); }
             }
         } else {
-            sub.append(lineptr, n);
+            rb.bases.insert(rb.bases.end(), reinterpret_cast<const uint8_t *>(line), reinterpret_cast<const uint8_t *>(line) + n);
         }
         ++count;
-        if (rb.size() > 0 && (rb.size() % batch == 0 || rb.heavy())) classifier.submit(rb);
+    };
+    const int fd = ::open(fq[0].c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) die("file not found: %s", fq[0].c_str());
+    struct stat sb;
+    void *map = MAP_FAILED;
+    if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) map = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map != MAP_FAILED) {   // the file's pages as they lie in the page cache
+        (void)madvise(map, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        const char *p = static_cast<const char *>(map), *end = p + sb.st_size;
+        while (p < end) {
+            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            const char *next = nl ? nl + 1 : end;
+            take_line(p, (size_t)(next - p));
+            p = next;
+        }
+        munmap(map, (size_t)sb.st_size);
+        ::close(fd);
+    } else {                   // a pipe, an empty file: line by line
+        FILE *f = fdopen(fd, "rb");
+        if (!f) die("file not found: %s", fq[0].c_str());
+        char *lineptr = nullptr;
+        size_t cap = 0;
+        ssize_t got;
+        setvbuf(f, nullptr, _IOFBF, 8u << 20);
+        while ((got = getline(&lineptr, &cap, f)) > 0) take_line(lineptr, (size_t)got);
+        free(lineptr);
+        fclose(f);
     }
-    free(lineptr);
-    fclose(f);
-    rb.push(id, &sub, 1);
+    close_record();
     classifier.submit(rb);
     const uint64_t read_count = classifier.finish();
     fclose(out);
     fprintf(stderr, "Classified %llu reads in %ld seconds\n", (unsigned long long)read_count, secs_since(t0));
+    print_read_id_timing(t0);
 }
 
 }  // namespace colorid
