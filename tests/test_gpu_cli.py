@@ -276,6 +276,51 @@ def test_read_id_fasta(orc, env):
     assert open(prefix + "_reads.txt").read().splitlines() == want
 
 
+def _stream_fasta_records(text: bytes):
+    """the reference's line loop (read_id_mt_pe.rs:450-569) restated: the first line is the first id (its last byte dropped); a later line
+    holding a '>' ANYWHERE closes the record before it if that record has any sequence yet (else the line is dropped, the id stays); every
+    other line joins the sequence WITH its line end; the end of the file closes the last record whatever it holds"""
+    lines = text.splitlines(keepends=True)
+    recs, cur_id, sub = [], b"", b""
+    for i, line in enumerate(lines):
+        if i == 0:
+            cur_id = line[:-1]
+        elif b">" in line:
+            if sub:
+                recs.append((cur_id, sub))
+                cur_id, sub = line[:-1], b""
+        else:
+            sub += line
+    recs.append((cur_id, sub))
+    return recs
+
+
+@pytest.mark.parametrize("batch", ["3", "50000"])
+def test_read_id_fasta_line_loop_edges(orc, env, batch):
+    """files the loop treats in its own way: headers in a row, a '>' inside a sequence line, a last line without its line end, CRLF, a
+    first line that is no header, a header at the very end; batches of three reads (records closed at a batch's edge)"""
+    d, bxi, oix, genomes = env
+    g = genomes[0]
+    cases = {
+        "plain": b">a\n" + g[:300] + b"\n>b\n" + g[300:500] + b"\n" + g[500:640] + b"\n>c x\n" + g[1000:1200] + b"\n",
+        "headers_in_a_row": b">a\n>b\n>c\n" + g[:200] + b"\n>d\n>e\n" + g[200:420] + b"\n",
+        "gt_inside": b">a\n" + g[:100] + b"\n" + g[100:150] + b">" + g[150:200] + b"\n" + g[200:330] + b"\n>z\n" + g[400:600] + b"\n",
+        "no_last_newline": b">a\n" + g[:250] + b"\n>b\n" + g[300:533],
+        "crlf": b">a\r\n" + g[:120] + b"\r\n" + g[120:260] + b"\r\n>b\r\n" + g[300:480] + b"\r\n",
+        "no_header_first": g[:90] + b"\n" + g[90:300] + b"\n>b\n" + g[300:500] + b"\n",
+        "header_last": b">a\n" + g[:200] + b"\n>b\n",
+        "seven": b"".join(b">r%d\n" % i + g[i * 100:i * 100 + 150 + i] + b"\n" for i in range(7)),
+    }
+    for name, text in cases.items():
+        q = d / f"edge_{name}.fasta"
+        q.write_bytes(text)
+        prefix = str(d / f"rid_edge_{name}_{batch}")
+        run("read_id", "-b", bxi, "-q", str(q), "-n", prefix, "-B", "0", "-c", batch)
+        recs = _stream_fasta_records(text)
+        want = expected_readid(orc, oix, [i.decode() for i, _ in recs], [[s] for _, s in recs], 1, 0)
+        assert open(prefix + "_reads.txt", newline="").read().split("\n")[:-1] == want, name   # (an id keeps its '\r': rows end with '\n' only)
+
+
 def test_batch_id_sample_sheet(orc, env, tmp_path):
     """batch_id (main.rs:869-888, read_id_batch.rs:7-181): a sheet `name \\t reads1 [\\t reads2]`, the index loaded once, every sample
     through read_id's streamers under the prefix NAME_TAG: single-stream gzip single-end, block-gzip pairs (the device FASTQ front
